@@ -1,0 +1,21 @@
+"""dsgcn_amd — MI355X-native DS-GCN hot path behind the PYSKL registry/config API.
+
+Drop-in names (reference: pyskl/models/builder.py, pyskl/models/gcns/*, recognizers/*, heads/*,
+losses/*): ``build_model``, ``RecognizerGCN``, ``DGSTGCN``, ``STGCN``, ``GCNHead``,
+``CrossEntropyLoss``, ``Graph``, ``Config``.
+"""
+from .registry import Registry, build_from_cfg
+from .config import Config, ConfigDict
+from .graph import Graph
+from .builder import (MODELS, BACKBONES, HEADS, LOSSES, NECKS, RECOGNIZERS, build_backbone, build_head, build_loss,
+                      build_model, build_recognizer)
+from .evaluation import top_k_accuracy, mean_class_accuracy, confusion_matrix
+from .losses import CrossEntropyLoss
+from .heads import GCNHead, SimpleHead
+from .gcn_units import dgphgcn1, unit_gcn, Deferred
+from .tcn_units import dgmstcn, unit_tcn
+from .backbones import DGSTGCN, STGCN, DGBlock, STGCNBlock
+from .recognizers import RecognizerGCN, BaseRecognizer
+from . import kernels
+
+__version__ = '0.1.0'

@@ -1,0 +1,255 @@
+"""Backbones behind the reference's registry names and ctor kwargs.
+
+``DGSTGCN`` (reference: pyskl/models/gcns/dgstgcn.py:73-169) with ``DGBlock`` (dgstgcn.py:12-70) and
+``STGCN`` (pyskl/models/gcns/stgcn.py:71-153) with ``STGCNBlock`` (stgcn.py:16-68).  state_dict keys,
+block plan (channels/strides/residuals) and the ``gcn_*``/``tcn_*`` kwarg routing are the reference's; the
+blocks run fused: gcn -> (deferred BN) -> tcn -> (deferred BN) -> one ``fuse_out`` that applies the last
+BN, adds the residual, applies ReLU, writes the block output once and emits its time-mean for the next
+block's dynamic adjacency.
+"""
+import copy as cp
+
+import torch
+import torch.nn as nn
+
+from . import kernels
+from .builder import BACKBONES
+from .gcn_units import dgphgcn1, unit_gcn
+from .graph import Graph
+from .tcn_units import dgmstcn, unit_tcn
+
+EPS = 1e-4
+
+
+def _split_kwargs(kwargs, common=('act', 'norm', 'g1x1')):
+    kwargs = dict(kwargs)
+    for arg in common:
+        if arg in kwargs:
+            value = kwargs.pop(arg)
+            kwargs['tcn_' + arg] = value
+            kwargs['gcn_' + arg] = value
+    gcn_kwargs = {k[4:]: v for k, v in kwargs.items() if k[:4] == 'gcn_'}
+    tcn_kwargs = {k[4:]: v for k, v in kwargs.items() if k[:4] == 'tcn_'}
+    rest = {k: v for k, v in kwargs.items() if k[:4] not in ('gcn_', 'tcn_')}
+    assert len(rest) == 0, f'Invalid arguments: {rest}'
+    return gcn_kwargs, tcn_kwargs
+
+
+class _FusedBlock(nn.Module):
+    """ReLU(tcn(gcn(x)) + residual(x)) with every BN deferred into its consumer."""
+
+    residual_kind = 'none'   # 'none' | 'identity' | 'conv'
+
+    def _set_residual(self, in_channels, out_channels, stride, residual):
+        if not residual:
+            self.residual_kind = 'none'
+            self.residual = lambda x: 0
+        elif in_channels == out_channels and stride == 1:
+            self.residual_kind = 'identity'
+            self.residual = lambda x: x
+        else:
+            self.residual_kind = 'conv'
+            self.residual = unit_tcn(in_channels, out_channels, kernel_size=1, stride=stride)
+
+    def forward_fused(self, x, xbar=None, want_xbar=False):
+        g = self._gcn_deferred(x, xbar)
+        t = self.tcn.forward_deferred(g)
+        if getattr(self.tcn, 'drop', None) is not None and self.tcn.drop.p > 0 and self.training:
+            t = type(t)(self.tcn.drop(t.materialize()), None, None, None, False)
+        x2 = a2 = None
+        if self.residual_kind == 'identity':
+            x2 = x
+        elif self.residual_kind == 'conv':
+            r = self.residual.forward_deferred(x)
+            x2, a2 = r.x1, r.a1
+        return kernels.ops().fuse_out(t.x1, t.a1, x2, a2, True, want_xbar)
+
+    def forward(self, x, A=None):
+        return self.forward_fused(x)[0]
+
+    def init_weights(self):
+        pass
+
+
+class DGBlock(_FusedBlock):
+
+    def __init__(self, in_channels, out_channels, A, edge_type, node_type, stride=1, residual=True, **kwargs):
+        super().__init__()
+        gcn_kwargs, tcn_kwargs = _split_kwargs(kwargs)
+        tcn_type = tcn_kwargs.pop('type', 'unit_tcn')
+        assert tcn_type in ['unit_tcn', 'mstcn', 'dgmstcn', 'dgmsmlp']
+        if tcn_type == 'unit_tcn':
+            self.tcn = unit_tcn(out_channels, out_channels, 9, stride=stride, **tcn_kwargs)
+        elif tcn_type == 'dgmstcn':
+            self.tcn = dgmstcn(out_channels, out_channels, stride=stride, **tcn_kwargs)
+        else:
+            raise NotImplementedError(f'tcn_type={tcn_type} is outside the DS-GCN hot path (SURVEY §8f)')
+        gcn_type = gcn_kwargs.pop('type', 'dghgcn')
+        assert gcn_type in ['dghgcn', 'dgphgcn', 'dgphgcn1', 'dggcn']
+        if gcn_type != 'dgphgcn1':
+            raise NotImplementedError(f'gcn_type={gcn_type} is outside the DS-GCN hot path (SURVEY §8f)')
+        self.gcn = dgphgcn1(in_channels, out_channels, A, edge_type, node_type, **gcn_kwargs)
+        self.relu = nn.ReLU()
+        self._set_residual(in_channels, out_channels, stride, residual)
+
+    def _gcn_deferred(self, x, xbar):
+        return self.gcn.forward_deferred(x, xbar)
+
+
+class STGCNBlock(_FusedBlock):
+
+    def __init__(self, in_channels, out_channels, A, stride=1, residual=True, **kwargs):
+        super().__init__()
+        gcn_kwargs, tcn_kwargs = _split_kwargs(kwargs, common=())
+        tcn_type = tcn_kwargs.pop('type', 'unit_tcn')
+        assert tcn_type in ['unit_tcn', 'mstcn', 'unit_tcnedge', 'unitmlp', 'msmlp']
+        gcn_type = gcn_kwargs.pop('type', 'unit_gcn')
+        assert gcn_type in ['unit_gcn', 'unit_gcnedge']
+        if gcn_type != 'unit_gcn' or tcn_type != 'unit_tcn':
+            raise NotImplementedError(f'{gcn_type}/{tcn_type}: only unit_gcn + unit_tcn (vanilla ST-GCN) is covered')
+        self.gcn = unit_gcn(in_channels, out_channels, A, **gcn_kwargs)
+        self.tcn = unit_tcn(out_channels, out_channels, 9, stride=stride, **tcn_kwargs)
+        self.relu = nn.ReLU()
+        self._set_residual(in_channels, out_channels, stride, residual)
+
+    def _gcn_deferred(self, x, xbar):
+        return self.gcn.forward_deferred(x)
+
+
+def _stage_kwargs(kwargs, num_stages):
+    lw = [cp.deepcopy(kwargs) for _ in range(num_stages)]
+    for k, v in kwargs.items():
+        if isinstance(v, tuple) and len(v) == num_stages:
+            for i in range(num_stages):
+                lw[i][k] = v[i]
+    return lw
+
+
+class _SkeletonBackbone(nn.Module):
+    """Shared forward: (N,M,T,V,C) -> data_bn -> (N*M,C,T,V) -> blocks -> (N,M,C',T',V)."""
+
+    def _make_data_bn(self, data_bn_type, in_channels, num_person, V):
+        self.data_bn_type = data_bn_type
+        if data_bn_type == 'MVC':
+            self.data_bn = nn.BatchNorm1d(num_person * in_channels * V)
+        elif data_bn_type == 'VC':
+            self.data_bn = nn.BatchNorm1d(in_channels * V)
+        else:
+            self.data_bn = nn.Identity()
+
+    def _normalize_input(self, x):
+        # 2.4 MB/step of host-side PyTorch plumbing (reference: dgstgcn.py:158-164)
+        N, M, T, V, C = x.size()
+        x = x.permute(0, 1, 3, 4, 2).contiguous()
+        if self.data_bn_type == 'MVC':
+            x = self.data_bn(x.view(N, M * V * C, T))
+        else:
+            x = self.data_bn(x.view(N * M, V * C, T))
+        return x.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
+
+    def _run_blocks(self, x, blocks, needs_xbar):
+        xbar = None
+        last = len(blocks) - 1
+        for i, blk in enumerate(blocks):
+            x, xbar = blk.forward_fused(x, xbar, needs_xbar and i < last)
+        return x
+
+    def init_weights(self):
+        if isinstance(getattr(self, 'pretrained', None), str):
+            from .checkpoint import load_checkpoint
+            load_checkpoint(self, self.pretrained, strict=False)
+
+
+@BACKBONES.register_module()
+class DGSTGCN(_SkeletonBackbone):
+
+    def __init__(self, graph_cfg, in_channels=3, base_channels=64, ch_ratio=2, num_stages=10, inflate_stages=[5, 8],
+                 down_stages=[5, 8], data_bn_type='VC', num_person=2, pretrained=None, **kwargs):
+        super().__init__()
+        self.graph = Graph(**graph_cfg)
+        A = torch.tensor(self.graph.A, dtype=torch.float32, requires_grad=False)
+        node_type = torch.tensor(self.graph.node_type, requires_grad=False)
+        edge_type = torch.tensor(self.graph.edge_type, dtype=torch.float32, requires_grad=False)
+        self.kwargs = kwargs
+        self._make_data_bn(data_bn_type, in_channels, num_person, A.size(1))
+
+        lw_kwargs = _stage_kwargs(kwargs, num_stages)
+        lw_kwargs[0].pop('tcn_dropout', None)
+        lw_kwargs[0].pop('g1x1', None)
+        lw_kwargs[0].pop('gcn_g1x1', None)
+        if 'gcn_stage' in kwargs:
+            for i in range(num_stages):
+                lw_kwargs[i]['gcn_stage'] = i in kwargs['gcn_stage']
+
+        self.in_channels = in_channels
+        self.base_channels = base_channels
+        self.ch_ratio = ch_ratio
+        self.inflate_stages = inflate_stages
+        self.down_stages = down_stages
+        modules = []
+        if self.in_channels != self.base_channels:
+            modules = [DGBlock(in_channels, base_channels, A.clone(), edge_type, node_type, 1, residual=False,
+                               **lw_kwargs[0])]
+        inflate_times = 0
+        for i in range(2, num_stages + 1):
+            stride = 1 + (i in down_stages)
+            in_channels = base_channels
+            if i in inflate_stages:
+                inflate_times += 1
+            out_channels = int(self.base_channels * self.ch_ratio**inflate_times + EPS)
+            base_channels = out_channels
+            modules.append(DGBlock(in_channels, out_channels, A.clone(), edge_type, node_type, stride,
+                                   **lw_kwargs[i - 1]))
+        if self.in_channels == self.base_channels:
+            num_stages -= 1
+        self.num_stages = num_stages
+        self.gcn = nn.ModuleList(modules)
+        self.pretrained = pretrained
+
+    def forward(self, x):
+        N, M = x.shape[:2]
+        x = self._normalize_input(x)
+        x = self._run_blocks(x, self.gcn[:self.num_stages], True)
+        return x.reshape((N, M) + x.shape[1:])
+
+
+@BACKBONES.register_module()
+class STGCN(_SkeletonBackbone):
+
+    def __init__(self, graph_cfg, in_channels=3, base_channels=64, data_bn_type='VC', ch_ratio=2, num_person=2,
+                 num_stages=10, inflate_stages=[5, 8], down_stages=[5, 8], pretrained=None, **kwargs):
+        super().__init__()
+        self.graph = Graph(**graph_cfg)
+        A = torch.tensor(self.graph.A, dtype=torch.float32, requires_grad=False)
+        self.kwargs = kwargs
+        self._make_data_bn(data_bn_type, in_channels, num_person, A.size(1))
+        lw_kwargs = _stage_kwargs(kwargs, num_stages)
+        lw_kwargs[0].pop('tcn_dropout', None)
+        self.in_channels = in_channels
+        self.base_channels = base_channels
+        self.ch_ratio = ch_ratio
+        self.inflate_stages = inflate_stages
+        self.down_stages = down_stages
+        modules = []
+        if self.in_channels != self.base_channels:
+            modules = [STGCNBlock(in_channels, base_channels, A.clone(), 1, residual=False, **lw_kwargs[0])]
+        inflate_times = 0
+        for i in range(2, num_stages + 1):
+            stride = 1 + (i in down_stages)
+            in_channels = base_channels
+            if i in inflate_stages:
+                inflate_times += 1
+            out_channels = int(self.base_channels * self.ch_ratio**inflate_times + EPS)
+            base_channels = out_channels
+            modules.append(STGCNBlock(in_channels, out_channels, A.clone(), stride, **lw_kwargs[i - 1]))
+        if self.in_channels == self.base_channels:
+            num_stages -= 1
+        self.num_stages = num_stages
+        self.gcn = nn.ModuleList(modules)
+        self.pretrained = pretrained
+
+    def forward(self, x):
+        N, M = x.shape[:2]
+        x = self._normalize_input(x.float())
+        x = self._run_blocks(x, self.gcn[:self.num_stages], False)
+        return x.reshape((N, M) + x.shape[1:])

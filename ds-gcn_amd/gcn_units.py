@@ -1,0 +1,223 @@
+"""Spatial graph-conv units behind the reference's class names and ctor kwargs.
+
+``dgphgcn1`` (reference: pyskl/models/gcns/utils/gcn.py:2074-2372) is the DS-GCN dynamic-semantic
+unit.  The modules own the same parameters/buffers under the same state_dict keys (built in the
+same order, so a given torch seed yields the reference's initial weights), but ``forward`` is a
+short chain of fused HIP ops (``dsgcn_amd.kernels``) instead of ~330 ATen calls:
+
+    xbar --K-B dynadj--> Ahat        x --K-C pwconv--> Zp (+batch stats)
+    (Zp, BN affine, ReLU) x Ahat --K-A aggregate--> Y --K-C pwconv--> Zo (+stats)
+
+Train-mode BatchNorm never runs as its own pass: the producing conv emits the batch statistics,
+the consumer applies ``scale*z+shift`` (+ReLU, +residual) while loading (a ``Deferred`` value).
+"""
+from math import ceil
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import kernels
+
+
+class Deferred(NamedTuple):
+    """relu?( x1*a1.scale + a1.shift [+ x2*a2.scale + a2.shift | + x2] ) — not materialised."""
+    x1: torch.Tensor
+    a1: Optional[Tuple[torch.Tensor, torch.Tensor]]
+    x2: Optional[torch.Tensor]
+    a2: Optional[Tuple[torch.Tensor, torch.Tensor]]
+    relu: bool
+
+    def materialize(self):
+        return kernels.ops().fuse_out(self.x1, self.a1, self.x2, self.a2, self.relu, False)[0]
+
+
+def as_deferred(x):
+    return x if isinstance(x, Deferred) else Deferred(x, None, None, None, False)
+
+
+def bn_affine(bn, mean, var, count):
+    """(scale, shift) of a BatchNorm layer from the producer's batch statistics (train) or from the
+    running statistics (eval); train mode also updates the running buffers the way
+    ``F.batch_norm`` does (momentum, unbiased variance, num_batches_tracked)."""
+    ops = kernels.ops()
+    if bn.training or not bn.track_running_stats:
+        scale, shift = ops.bn_affine(mean, var, bn.weight, bn.bias, bn.eps)
+        if bn.training and bn.track_running_stats:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - m).add_(mean.detach(), alpha=m)
+                bn.running_var.mul_(1 - m).add_(var.detach(), alpha=m * count / max(count - 1, 1))
+        return scale, shift
+    return ops.bn_affine(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps)
+
+
+def _need_stats(bn):
+    return bn.training or not bn.track_running_stats
+
+
+def _norm_layer(norm, num_features):
+    cfg = dict(norm) if isinstance(norm, dict) else dict(type=norm)
+    typ = cfg.pop('type')
+    if typ not in ('BN', 'BN2d'):
+        raise NotImplementedError(f'norm type {typ} is not on the DS-GCN hot path')
+    cfg.setdefault('eps', 1e-5)
+    return nn.BatchNorm2d(num_features, **cfg)
+
+
+def _check_act(act):
+    typ = act['type'] if isinstance(act, dict) else act
+    if typ != 'ReLU':
+        raise NotImplementedError(f'activation {typ} is not fused by the HIP kernels (ReLU only)')
+
+
+class dgphgcn1(nn.Module):
+    """Dynamic-semantic graph conv.  Implemented configuration = the one every shipped DS-STGCN
+    config selects (configs/dsstgcn/DSSTGCN_model.py:10-27): decompose + node/edge attention +
+    subset-wise alpha/beta, ctr='T', ada='T', tanh / softmax.  Other flag combinations of the
+    reference class are research variants outside BASELINE's configs and raise."""
+
+    def __init__(self, in_channels, out_channels, A, edge_type, node_type, ratio=0.25, decompose=False, ctr='T',
+                 ada='T', node_attention=False, edge_attention=False, ada_attention=False, target_specific=False,
+                 add_type=False, sub_att=True, stage=True, num_types=5, edge_num=15, subset_wise=True,
+                 ada_act='softmax', ctr_act='tanh', norm='BN', act='ReLU'):
+        super().__init__()
+        assert ada_act in ['tanh', 'relu', 'sigmoid', 'softmax']
+        assert ctr_act in ['tanh', 'relu', 'sigmoid', 'softmax']
+        assert ctr in [None, 'NA', 'T']
+        assert ada in [None, 'NA', 'T']
+        supported = (decompose and node_attention and edge_attention and subset_wise and sub_att and stage
+                     and not ada_attention and not target_specific and not add_type and ctr == 'T' and ada == 'T'
+                     and ada_act == 'softmax' and ctr_act == 'tanh')
+        if not supported:
+            raise NotImplementedError(
+                'dgphgcn1: only the shipped DS-STGCN configuration (decompose, node_attention, edge_attention, '
+                "subset_wise, sub_att, ctr='T', ada='T', tanh/softmax) has a HIP path")
+        _check_act(act)
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.num_subsets = K = A.size(0)
+        self.num_types = num_types
+        self.edge_num = edge_num
+        if ratio is None:
+            ratio = 1 / K
+        self.ratio = ratio
+        self.mid_channels = mid = int(ratio * out_channels)
+        self.semantic_num = S = ceil(K / 3)
+        self.norm_num = K - S
+        if K != 3:
+            raise NotImplementedError('the HIP dynadj kernel implements K=3 subsets (2 plain + 1 semantic)')
+        self.register_buffer('node_type_idx', torch.as_tensor(node_type).to(torch.int32).contiguous(),
+                             persistent=False)
+        self.register_buffer('edge_type_idx', torch.as_tensor(edge_type).to(torch.int32).contiguous(),
+                             persistent=False)
+        # parameter creation order follows the reference ctor (same RNG consumption, same key order)
+        self.A = nn.Parameter(A.clone())
+        self.pre = nn.Sequential(nn.Conv2d(in_channels, mid * K, 1), _norm_layer(norm, mid * K), nn.ReLU())
+        self.post = nn.Conv2d(mid * K, out_channels, 1)
+        self.alpha = nn.Parameter(torch.zeros(K))
+        self.beta = nn.Parameter(torch.zeros(K))
+        self.conv1_se = nn.Conv2d(in_channels, S * mid * num_types, kernel_size=1)
+        self.conv2_se = nn.Conv2d(in_channels, S * mid * num_types, kernel_size=1)   # never used (quirk Q1)
+        self.conv1 = nn.Conv2d(in_channels, self.norm_num * mid, 1)
+        self.conv2 = nn.Conv2d(in_channels, self.norm_num * mid, 1)
+        self.edge_linears = nn.Conv2d(S * mid, edge_num * S * mid, 1)
+        if in_channels != out_channels:
+            self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), _norm_layer(norm, out_channels))
+        else:
+            self.down = None
+        self.bn = _norm_layer(norm, out_channels)
+
+    def adjacency(self, xbar):
+        """Ahat (n, K*mid, V, V) from the time-averaged input xbar (n, Ci, V)."""
+        c1, c2, cs, el = self.conv1, self.conv2, self.conv1_se, self.edge_linears
+        return kernels.ops().dynadj(
+            xbar, self.A, self.alpha, self.beta,
+            c1.weight.flatten(1), c1.bias, c2.weight.flatten(1), c2.bias, cs.weight.flatten(1), cs.bias,
+            el.weight.flatten(1), el.bias, self.node_type_idx, self.edge_type_idx)
+
+    def forward_deferred(self, x, xbar=None):
+        ops = kernels.ops()
+        n, c, t, v = x.shape
+        count = n * t * v
+        if xbar is None:
+            xbar = ops.tmean(x)
+        ahat = self.adjacency(xbar)
+        pre_bn = self.pre[1]
+        zp, _, m, var = ops.pwconv(x, None, None, None, False, self.pre[0].weight, self.pre[0].bias, 1, False,
+                                   _need_stats(pre_bn))
+        y = ops.aggregate(zp, bn_affine(pre_bn, m, var, count), True, ahat)
+        zo, _, m, var = ops.pwconv(y, None, None, None, False, self.post.weight, self.post.bias, 1, False,
+                                   _need_stats(self.bn))
+        ao = bn_affine(self.bn, m, var, count)
+        if self.down is None:
+            return Deferred(zo, ao, x, None, True)
+        zd, _, m, var = ops.pwconv(x, None, None, None, False, self.down[0].weight, self.down[0].bias, 1, False,
+                                   _need_stats(self.down[1]))
+        return Deferred(zo, ao, zd, bn_affine(self.down[1], m, var, count), True)
+
+    def forward(self, x, A=None):
+        return self.forward_deferred(x).materialize()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out')
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+
+class unit_gcn(nn.Module):
+    """ST-GCN spatial unit (reference: gcn.py:22-97): conv Ci->K*Co, aggregate with the shared learnable
+    A (K,V,V) summed over subsets, BN, ReLU.  ``conv_pos='pre'`` and adaptive in {None,'init'} (the vanilla
+    ST-GCN config) are on the HIP path."""
+
+    def __init__(self, in_channels, out_channels, A, adaptive='init', conv_pos='pre', with_res=False, norm='BN',
+                 act='ReLU'):
+        super().__init__()
+        assert adaptive in [None, 'init', 'offset', 'importance']
+        assert conv_pos in ['pre', 'post']
+        if adaptive not in (None, 'init') or conv_pos != 'pre':
+            raise NotImplementedError("unit_gcn: HIP path covers adaptive in {None,'init'} with conv_pos='pre'")
+        _check_act(act)
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.num_subsets = A.size(0)
+        self.adaptive = adaptive
+        self.conv_pos = conv_pos
+        self.with_res = with_res
+        self.bn = _norm_layer(norm, out_channels)
+        if adaptive == 'init':
+            self.A = nn.Parameter(A.clone())
+        else:
+            self.register_buffer('A', A)
+        self.conv = nn.Conv2d(in_channels, out_channels * A.size(0), 1)
+        self.down = None
+        if with_res and in_channels != out_channels:
+            self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), _norm_layer(norm, out_channels))
+
+    def forward_deferred(self, x):
+        ops = kernels.ops()
+        n, c, t, v = x.shape
+        count = n * t * v
+        h = ops.pwconv(x, None, None, None, False, self.conv.weight, self.conv.bias, 1, False, False)[0]
+        y, m, var = ops.aggregate_shared(h, self.A, self.num_subsets, _need_stats(self.bn))
+        ay = bn_affine(self.bn, m, var, count)
+        if not self.with_res:
+            return Deferred(y, ay, None, None, True)
+        if self.down is None:
+            return Deferred(y, ay, x, None, True)
+        zd, _, m, var = ops.pwconv(x, None, None, None, False, self.down[0].weight, self.down[0].bias, 1, False,
+                                   _need_stats(self.down[1]))
+        return Deferred(y, ay, zd, bn_affine(self.down[1], m, var, count), True)
+
+    def forward(self, x, A=None):
+        if A is not None:
+            raise NotImplementedError('passing A at call time (reference quirk Q9) is not supported')
+        return self.forward_deferred(x).materialize()
+
+    def init_weights(self):
+        pass

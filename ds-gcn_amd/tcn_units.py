@@ -1,0 +1,164 @@
+"""Temporal units behind the reference's class names and ctor kwargs.
+
+``dgmstcn`` (reference: pyskl/models/gcns/utils/tcn.py:344-431): the six branch 1x1 convs share
+their input, so they run as ONE C->C channel mix (weights concatenated) whose epilogue also emits
+the global-joint column (mean over V — by linearity of the 1x1 conv, tcn.py:409) and the batch
+statistics; one K-D kernel then does BN+ReLU, the four dilated 3-tap convs, the max-pool, the
+strided pass-through and the local + global*add_coeff combine (tcn.py:416-420).
+``unit_tcn`` (tcn.py:10-37): k=1 (block residual) is a strided channel mix; k>1 the dense temporal conv.
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels
+from .gcn_units import Deferred, as_deferred, bn_affine, _need_stats, _norm_layer
+
+
+class unit_tcn(nn.Module):
+
+    def __init__(self, in_channels, out_channels, kernel_size=9, stride=1, dilation=1, norm='BN', dropout=0):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.dilation = dilation
+        pad = (kernel_size + (kernel_size - 1) * (dilation - 1) - 1) // 2
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=(kernel_size, 1), padding=(pad, 0),
+                              stride=(stride, 1), dilation=(dilation, 1))
+        self.bn = _norm_layer(norm, out_channels) if norm is not None else nn.Identity()
+        self.drop = nn.Dropout(dropout, inplace=True)
+        self.stride = stride
+
+    def forward_deferred(self, x):
+        """x: tensor or Deferred -> Deferred(z, bn affine) (dropout must be 0 on this path)."""
+        ops = kernels.ops()
+        d = as_deferred(x)
+        has_bn = isinstance(self.bn, nn.BatchNorm2d)
+        stats = has_bn and _need_stats(self.bn)
+        if self.kernel_size == 1:
+            z, _, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, self.conv.weight, self.conv.bias, self.stride,
+                                      False, stats)
+        else:
+            if d.x2 is not None:
+                d = Deferred(d.materialize(), None, None, None, False)
+            z, m, var = ops.tconv(d.x1, d.a1, d.relu, self.conv.weight, self.conv.bias, self.stride, self.dilation,
+                                  stats)
+        if not has_bn:
+            return Deferred(z, None, None, None, False)
+        count = z.shape[0] * z.shape[2] * z.shape[3]
+        return Deferred(z, bn_affine(self.bn, m, var, count), None, None, False)
+
+    def forward(self, x):
+        out = self.forward_deferred(x).materialize()
+        return self.drop(out) if self.drop.p > 0 else out
+
+    def init_weights(self):
+        nn.init.kaiming_normal_(self.conv.weight, mode='fan_out')
+        nn.init.constant_(self.conv.bias, 0)
+        if isinstance(self.bn, nn.BatchNorm2d):
+            nn.init.constant_(self.bn.weight, 1)
+            nn.init.constant_(self.bn.bias, 0)
+
+
+class dgmstcn(nn.Module):
+
+    def __init__(self, in_channels, out_channels, mid_channels=None, num_joints=25, dropout=0.,
+                 ms_cfg=[(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1'], stride=1):
+        super().__init__()
+        self.ms_cfg = [tuple(c) if isinstance(c, (list, tuple)) else c for c in ms_cfg]
+        num_branches = len(ms_cfg)
+        self.num_branches = num_branches
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.stride = stride
+        self.act = nn.ReLU()
+        self.num_joints = num_joints
+        self.add_coeff = nn.Parameter(torch.zeros(self.num_joints))
+        if mid_channels is None:
+            mid_channels = out_channels // num_branches
+            rem_mid_channels = out_channels - mid_channels * (num_branches - 1)
+        else:
+            assert isinstance(mid_channels, float) and mid_channels > 0
+            mid_channels = int(out_channels * mid_channels)
+            rem_mid_channels = mid_channels
+        self.mid_channels = mid_channels
+        self.rem_mid_channels = rem_mid_channels
+
+        branches = []
+        self.widths = []
+        for i, cfg in enumerate(self.ms_cfg):
+            bc = rem_mid_channels if i == 0 else mid_channels
+            self.widths.append(bc)
+            if cfg == '1x1':
+                branches.append(nn.Conv2d(in_channels, bc, kernel_size=1, stride=(stride, 1)))
+                continue
+            assert isinstance(cfg, tuple)
+            if cfg[0] == 'max':
+                branches.append(nn.Sequential(
+                    nn.Conv2d(in_channels, bc, kernel_size=1), nn.BatchNorm2d(bc), self.act,
+                    nn.MaxPool2d(kernel_size=(cfg[1], 1), stride=(stride, 1), padding=(1, 0))))
+                continue
+            assert isinstance(cfg[0], int) and isinstance(cfg[1], int)
+            branches.append(nn.Sequential(
+                nn.Conv2d(in_channels, bc, kernel_size=1), nn.BatchNorm2d(bc), self.act,
+                unit_tcn(bc, bc, kernel_size=cfg[0], stride=stride, dilation=cfg[1], norm=None)))
+        self.branches = nn.ModuleList(branches)
+        tin_channels = mid_channels * (num_branches - 1) + rem_mid_channels
+        self.transform = nn.Sequential(nn.BatchNorm2d(tin_channels), self.act,
+                                       nn.Conv2d(tin_channels, out_channels, kernel_size=1))
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.drop = nn.Dropout(dropout, inplace=True)
+        # HIP K-D layout: BN+ReLU branches first, pass-through ('1x1') branches last
+        seen_plain = False
+        for cfg in self.ms_cfg:
+            if cfg == '1x1':
+                seen_plain = True
+            elif seen_plain:
+                raise NotImplementedError("dgmstcn: '1x1' branches must come last in ms_cfg on the HIP path")
+        self.n_act = sum(w for w, c in zip(self.widths, self.ms_cfg) if c != '1x1')
+
+    def _first_convs(self):
+        return [b if isinstance(b, nn.Conv2d) else b[0] for b in self.branches]
+
+    def forward_deferred(self, g):
+        """g: tensor or Deferred (the gcn output) -> Deferred(zt, affine of self.bn)."""
+        ops = kernels.ops()
+        d = as_deferred(g)
+        n, _, T, V = d.x1.shape
+        convs = self._first_convs()
+        wb = torch.cat([c.weight.flatten(1) for c in convs], 0)
+        bb = torch.cat([c.bias for c in convs], 0)
+        bns = [b[1] for b in self.branches if not isinstance(b, nn.Conv2d)]
+        stats = any(_need_stats(bn) for bn in bns)
+        z, zaug, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, True, stats)
+        count = n * T * (V + 1)
+        scales, shifts, c0 = [], [], 0
+        for bn in bns:
+            bc = bn.num_features
+            s, h = bn_affine(bn, None if m is None else m[c0:c0 + bc], None if var is None else var[c0:c0 + bc],
+                             count)
+            scales.append(s)
+            shifts.append(h)
+            c0 += bc
+        rest = self.out_channels - c0
+        if rest:
+            scales.append(z.new_ones(rest))
+            shifts.append(z.new_zeros(rest))
+        tconvs = [b[3].conv for b in self.branches if not isinstance(b, nn.Conv2d) and isinstance(b[3], unit_tcn)]
+        bn1 = self.transform[0]
+        f, m1, v1 = ops.temporal_ms(z, zaug, torch.cat(scales), torch.cat(shifts), self.n_act, self.ms_cfg,
+                                    self.widths, [c.weight for c in tconvs], [c.bias for c in tconvs],
+                                    self.add_coeff, self.stride, _need_stats(bn1))
+        cnt1 = f.shape[0] * f.shape[2] * f.shape[3]
+        a1 = bn_affine(bn1, m1, v1, cnt1)
+        conv_t = self.transform[2]
+        zt, _, m2, v2 = ops.pwconv(f, a1, None, None, True, conv_t.weight, conv_t.bias, 1, False,
+                                   _need_stats(self.bn))
+        return Deferred(zt, bn_affine(self.bn, m2, v2, cnt1), None, None, False)
+
+    def forward(self, x):
+        out = self.forward_deferred(x).materialize()
+        return self.drop(out) if self.drop.p > 0 else out
+
+    def init_weights(self):
+        pass

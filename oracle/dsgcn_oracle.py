@@ -1,0 +1,404 @@
+"""CPU oracle for the DS-GCN hot path — TEST INFRASTRUCTURE, not product code.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  The product package (``ds-gcn_amd/``) never does, and fails loudly
+when its HIP library is missing.
+
+What it is: a plain-PyTorch (CPU, fp32 or fp64) restatement of the reference's arithmetic
+for the hot path, written from the math in SURVEY.md Appendix A and functional over a
+``state_dict`` with the reference's key names.  Each function cites the
+reference lines it restates (paths relative to the reference root).
+
+Parity pin: ``tests/test_oracle_vs_reference.py`` checks every function here against the
+imported reference in the build container (skipped where /root/reference is absent), and
+``tests/golden/*.npz`` (written by ``tests/golden/gen_golden.py`` from the imported
+reference) pin it on the GPU box.  The reference itself ships no tests/golden vectors
+(SURVEY.md §4), so these fixtures are the pin.
+"""
+from math import ceil
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+EPS_BN = 1e-5
+
+
+# ----------------------------------------------------------------------------------------
+# graph constants  (pyskl/utils/graph.py:58-187)
+# ----------------------------------------------------------------------------------------
+
+NTU_PAIRS_1BASED = [(1, 2), (2, 21), (3, 21), (4, 3), (5, 21), (6, 5), (7, 6), (8, 7), (9, 21), (10, 9),
+                    (11, 10), (12, 11), (13, 1), (14, 13), (15, 14), (16, 15), (17, 1), (18, 17), (19, 18),
+                    (20, 19), (22, 8), (23, 8), (24, 12), (25, 12)]
+COCO_PAIRS = [(15, 13), (13, 11), (16, 14), (14, 12), (11, 5), (12, 6), (9, 7), (7, 5), (10, 8), (8, 6),
+              (5, 0), (6, 0), (1, 0), (3, 1), (2, 0), (4, 2)]
+NTU_PARTS = [0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 0, 1, 1, 2, 2]
+COCO_PARTS = [0, 0, 0, 0, 0, 1, 2, 1, 2, 1, 2, 3, 4, 3, 4, 3, 4]
+
+
+def graph_constants(layout):
+    """node_type (V,), edge_type (V,V) as the reference builds them (graph.py:107-144).
+
+    edge class = rank of the signed product (p_u+1)(-1)^(p_u+1) * (p_w+1)(-1)^(p_w+1) among the
+    distinct products (np.unique order = ascending).
+    """
+    if layout == 'nturgb+d':
+        parts, V = NTU_PARTS, 25
+        inward = [(i - 1, j - 1) for i, j in NTU_PAIRS_1BASED]
+        center = 20
+    elif layout == 'coco':
+        parts, V = COCO_PARTS, 17
+        inward = list(COCO_PAIRS)
+        center = 0
+    else:
+        raise ValueError(layout)
+    code = np.array([(p + 1) * (-1) ** (p + 1) for p in parts]).reshape(V, 1)
+    prod = code @ code.T
+    uniq = np.unique(prod)
+    edge_type = np.zeros((V, V))
+    for r, u in enumerate(uniq):
+        edge_type[prod == u] = r
+    return dict(V=V, inward=inward, center=center, node_type=np.array(parts), edge_type=edge_type)
+
+
+def _norm_digraph(A):
+    # graph.py:27-38: column-normalise (divide column j by its sum when > 0)
+    d = A.sum(0)
+    out = np.zeros_like(A)
+    nz = d > 0
+    out[:, nz] = A[:, nz] / d[nz]
+    return out
+
+
+def _edge2mat(link, V):
+    A = np.zeros((V, V))
+    for i, j in link:
+        A[j, i] = 1
+    return A
+
+
+def graph_A(layout, mode, max_hop=1):
+    """Static adjacency for modes 'spatial' (graph.py:174-179) and 'stgcn_spatial' (151-172)."""
+    g = graph_constants(layout)
+    V, inward, center = g['V'], g['inward'], g['center']
+    outward = [(j, i) for i, j in inward]
+    if mode == 'spatial':
+        return np.stack([np.eye(V), _norm_digraph(_edge2mat(inward, V)), _norm_digraph(_edge2mat(outward, V))])
+    if mode == 'stgcn_spatial':
+        adj1 = np.eye(V)
+        for i, j in inward:
+            adj1[i, j] = 1
+            adj1[j, i] = 1
+        hop = np.full((V, V), np.inf)
+        mats = [np.linalg.matrix_power(adj1, d) for d in range(max_hop + 1)]
+        for d in range(max_hop, -1, -1):
+            hop[mats[d] > 0] = d
+        adj = (hop <= max_hop).astype(float)
+        nadj = _norm_digraph(adj)
+        out = []
+        for h in range(max_hop + 1):
+            close = np.zeros((V, V))
+            far = np.zeros((V, V))
+            for i in range(V):
+                for j in range(V):
+                    if hop[j, i] == h:
+                        if hop[j, center] >= hop[i, center]:
+                            close[j, i] = nadj[j, i]
+                        else:
+                            far[j, i] = nadj[j, i]
+            out.append(close)
+            if h > 0:
+                out.append(far)
+        return np.stack(out)
+    raise ValueError(mode)
+
+
+# ----------------------------------------------------------------------------------------
+# small helpers
+# ----------------------------------------------------------------------------------------
+
+def _conv1x1(x, w, b, stride=1):
+    return F.conv2d(x, w, b, stride=(stride, 1))
+
+
+def _bn(x, sd, prefix, training, eps=EPS_BN):
+    """Functional BatchNorm over dim 1.  Train mode: batch stats (running buffers untouched
+    here — the oracle checks outputs, running-stat updates are checked separately)."""
+    w, b = sd[prefix + 'weight'], sd[prefix + 'bias']
+    if training:
+        return F.batch_norm(x, None, None, w, b, True, 0.0, eps)
+    return F.batch_norm(x, sd[prefix + 'running_mean'].to(x.dtype), sd[prefix + 'running_var'].to(x.dtype),
+                        w, b, False, 0.0, eps)
+
+
+def _sub(sd, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+# ----------------------------------------------------------------------------------------
+# dgphgcn1  (pyskl/models/gcns/utils/gcn.py:2074-2372, config of configs/dsstgcn/DSSTGCN_model.py)
+# ----------------------------------------------------------------------------------------
+
+def dgphgcn1_adjacency(x, sd, node_type, edge_type, K=3, P=5, E=15, ret_parts=False):
+    """Dynamic adjacency Â (n,K,mid,V,V) — SURVEY App. A.1 steps 2-8 (gcn.py:2240-2337).
+
+    sd keys: A, alpha, beta, conv1.*, conv2.*, conv1_se.*, edge_linears.*  (conv2_se unused, Q1).
+    """
+    n, Ci, T, V = x.shape
+    S = ceil(K / 3)
+    assert S == 1 and K == 3, 'oracle restates the shipped DS-STGCN configuration (K=3)'
+    A = sd['A']
+    mid = sd['conv1.weight'].shape[0] // (K - S)
+    nt = torch.as_tensor(np.asarray(node_type), dtype=torch.long)
+    et = torch.as_tensor(np.asarray(edge_type), dtype=torch.long)
+    xbar = x.mean(dim=2)                                             # (n,Ci,V)  gcn.py:2246
+    w1 = sd['conv1.weight'].reshape(-1, Ci)
+    w2 = sd['conv2.weight'].reshape(-1, Ci)
+    a = torch.einsum('oc,ncv->nov', w1, xbar) + sd['conv1.bias'][None, :, None]
+    b = torch.einsum('oc,ncv->nov', w2, xbar) + sd['conv2.bias'][None, :, None]
+    a = a.reshape(n, 2, mid, V)                                      # gcn.py:2248
+    b = b.reshape(n, 2, mid, V)                                      # gcn.py:2249
+    wse = sd['conv1_se.weight'].reshape(mid, P, Ci)                  # channel index c*P+p (gcn.py:2256)
+    bse = sd['conv1_se.bias'].reshape(mid, P)
+    wsel = wse[:, nt, :]                                             # (mid,V,Ci)
+    s = torch.einsum('cvi,niv->ncv', wsel, xbar) + bse[:, nt][None]  # (n,mid,V)  gcn.py:2253-2259
+    x1 = torch.stack([a[:, 0], a[:, 1], s], 1)                       # (n,3,mid,V) gcn.py:2271
+    x2 = torch.stack([b[:, 0], b[:, 1], s], 1)                       # Q1: conv1_se on both sides (2272)
+    D0 = a[:, 0, :, :, None] - b[:, 0, :, None, :]                   # (n,mid,V,V) gcn.py:2292
+    diff1 = a[:, 1, :, :, None] - b[:, 1, :, None, :]
+    we = sd['edge_linears.weight'].reshape(E, mid, mid)              # out index e*mid+c (gcn.py:2280)
+    be = sd['edge_linears.bias'].reshape(E, mid)
+    wsel_e = we[et]                                                  # (V,V,mid,mid)
+    D1 = torch.einsum('uwcd,nduw->ncuw', wsel_e, diff1) + be[et].permute(2, 0, 1)[None]  # 2279-2288
+    D2 = s[:, :, :, None] - s[:, :, None, :]                         # gcn.py:2293
+    D = torch.stack([D0, D1, D2], 1)                                 # (n,3,mid,V,V)
+    th = torch.tanh(D)                                               # gcn.py:2298
+    G = torch.einsum('nkcu,nkcw->nkuw', x1, x2)                      # gcn.py:2314
+    Sm = torch.softmax(G, dim=-2)                                    # softmax over FIRST vertex idx (2174,2326)
+    alpha, beta = sd['alpha'], sd['beta']
+    Ahat = (A[None, :, None] + alpha[None, :, None, None, None] * th
+            + beta[None, :, None, None, None] * Sm[:, :, None])      # gcn.py:2304-2337
+    if ret_parts:
+        return Ahat, dict(xbar=xbar, x1=x1, x2=x2, D=D, Sm=Sm)
+    return Ahat
+
+
+def dgphgcn1_forward(x, sd, node_type, edge_type, training=True, ret_parts=False):
+    """Full spatial unit (gcn.py:2217-2365): res, pre, Â, aggregate, post, BN, +res, ReLU."""
+    n, Ci, T, V = x.shape
+    K = sd['A'].shape[0]
+    Co = sd['post.weight'].shape[0]
+    if 'down.0.weight' in sd:
+        res = _bn(_conv1x1(x, sd['down.0.weight'], sd['down.0.bias']), sd, 'down.1.', training)  # 2209-2214,2221
+    else:
+        res = x
+    Pre = F.relu(_bn(_conv1x1(x, sd['pre.0.weight'], sd['pre.0.bias']), sd, 'pre.1.', training))  # 2236
+    mid = Pre.shape[1] // K
+    Pre5 = Pre.reshape(n, K, mid, T, V)
+    out = dgphgcn1_adjacency(x, sd, node_type, edge_type, K=K, ret_parts=ret_parts)
+    Ahat = out[0] if ret_parts else out
+    Y = torch.einsum('nkctu,nkcuw->nkctw', Pre5, Ahat)               # gcn.py:2350-2352
+    z = _conv1x1(Y.reshape(n, K * mid, T, V), sd['post.weight'], sd['post.bias'])  # 2363-2364
+    y = F.relu(_bn(z, sd, 'bn.', training) + res)                    # 2365
+    if ret_parts:
+        parts = dict(out[1])
+        parts.update(P=Pre5, Ahat=Ahat, Y=Y)
+        return y, parts
+    return y
+
+
+# ----------------------------------------------------------------------------------------
+# unit_tcn / dgmstcn  (pyskl/models/gcns/utils/tcn.py:10-37, 344-431)
+# ----------------------------------------------------------------------------------------
+
+def unit_tcn_forward(x, sd, kernel_size, stride=1, dilation=1, training=True, norm=True):
+    """Dropout_0(BN(Conv((k,1), pad, stride, dil))) — tcn.py:10-37 (dropout p=0 only)."""
+    pad = (kernel_size + (kernel_size - 1) * (dilation - 1) - 1) // 2
+    y = F.conv2d(x, sd['conv.weight'], sd['conv.bias'], stride=(stride, 1), padding=(pad, 0),
+                 dilation=(dilation, 1))
+    if norm:
+        y = _bn(y, sd, 'bn.', training)
+    return y
+
+
+def dgmstcn_forward(x, sd, stride=1, ms_cfg=((3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1'), training=True,
+                    ret_parts=False):
+    """Multi-scale temporal unit with the global joint (tcn.py:407-428)."""
+    n, C, T, V = x.shape
+    xp = torch.cat([x, x.mean(-1, keepdim=True)], -1)                # tcn.py:409
+    outs = []
+    for j, cfg in enumerate(ms_cfg):
+        p = f'branches.{j}.'
+        if cfg == '1x1':
+            outs.append(_conv1x1(xp, sd[p + 'weight'], sd[p + 'bias'], stride))       # tcn.py:383
+            continue
+        h = F.relu(_bn(_conv1x1(xp, sd[p + '0.weight'], sd[p + '0.bias']), sd, p + '1.', training))
+        if cfg[0] == 'max':
+            outs.append(F.max_pool2d(h, (cfg[1], 1), (stride, 1), (1, 0)))            # tcn.py:387-390
+        else:
+            outs.append(unit_tcn_forward(h, _sub(sd, p + '3.'), cfg[0], stride, cfg[1], training, norm=False))
+    o = torch.cat(outs, 1)                                           # tcn.py:415
+    coeff = sd['add_coeff'][:V]
+    f = o[..., :V] + o[..., V, None] * coeff                        # tcn.py:416-420
+    h = F.relu(_bn(f, sd, 'transform.0.', training))
+    zt = _conv1x1(h, sd['transform.2.weight'], sd['transform.2.bias'])               # tcn.py:401-402,422
+    y = _bn(zt, sd, 'bn.', training)                                 # tcn.py:427 (dropout p=0)
+    if ret_parts:
+        return y, dict(o=o, f=f, zt=zt)
+    return y
+
+
+# ----------------------------------------------------------------------------------------
+# DGBlock / DGSTGCN / head / loss
+# ----------------------------------------------------------------------------------------
+
+def dgblock_forward(x, sd, node_type, edge_type, stride, residual, training=True):
+    """ReLU(tcn(gcn(x)) + residual(x)) — dgstgcn.py:12-65."""
+    g = dgphgcn1_forward(x, _sub(sd, 'gcn.'), node_type, edge_type, training)
+    t = dgmstcn_forward(g, _sub(sd, 'tcn.'), stride, training=training)
+    if not residual:
+        res = 0
+    elif 'residual.conv.weight' in sd:
+        res = unit_tcn_forward(x, _sub(sd, 'residual.'), 1, stride, 1, training)      # dgstgcn.py:59
+    else:
+        res = x
+    return F.relu(t + res)
+
+
+def dgstgcn_plan(in_channels=3, base_channels=64, ch_ratio=2, num_stages=10, inflate_stages=(5, 8),
+                 down_stages=(5, 8)):
+    """(Ci, Co, stride, residual) per block — dgstgcn.py:121-142."""
+    plan = []
+    bc = base_channels
+    if in_channels != bc:
+        plan.append((in_channels, bc, 1, False))
+    inflate = 0
+    for i in range(2, num_stages + 1):
+        stride = 1 + (i in down_stages)
+        ci = bc
+        if i in inflate_stages:
+            inflate += 1
+        co = int(base_channels * ch_ratio ** inflate + 1e-4)
+        bc = co
+        plan.append((ci, co, stride, True))
+    return plan
+
+
+def dgstgcn_forward(x, sd, node_type, edge_type, plan, training=True):
+    """Backbone: (N,M,T,V,C) -> (N,M,C_out,T_out,V) — dgstgcn.py:156-170 (data_bn_type='VC')."""
+    N, M, T, V, C = x.shape
+    h = x.permute(0, 1, 3, 4, 2).contiguous().view(N * M, V * C, T)
+    h = _bn(h, sd, 'data_bn.', training)
+    h = h.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
+    for i, (ci, co, stride, residual) in enumerate(plan):
+        h = dgblock_forward(h, _sub(sd, f'gcn.{i}.'), node_type, edge_type, stride, residual, training)
+    return h.reshape((N, M) + h.shape[1:])
+
+
+def gcn_head_forward(feat, sd):
+    """GCNHead: mean over (T,V), mean over M, Linear — heads/simple_head.py:83-97 (dropout 0)."""
+    N, M, C, T, V = feat.shape
+    p = feat.reshape(N * M, C, T * V).mean(-1).reshape(N, M, C).mean(1)
+    return F.linear(p, sd['fc_cls.weight'], sd['fc_cls.bias'])
+
+
+def top_k_accuracy(scores, labels, topk=(1,)):
+    """core/evaluation.py:107-126."""
+    res = []
+    labels = np.array(labels)[:, np.newaxis]
+    for k in topk:
+        pred = np.argsort(scores, axis=1)[:, -k:][:, ::-1]
+        res.append(np.logical_or.reduce(pred == labels, axis=1).sum() / labels.shape[0])
+    return res
+
+
+def recognizer_forward_train(keypoint, label, sd, node_type, edge_type, plan, training=True):
+    """RecognizerGCN.forward_train (recognizers/recognizergcn.py:20-51) + BaseHead.loss
+    (heads/base.py:50-84) + CrossEntropyLoss hard-label branch (losses/cross_entropy_loss.py:75-82).
+    keypoint (N,1,M,T,V,C); label (N,1).  Returns (logits, loss)."""
+    assert keypoint.shape[1] == 1
+    feat = dgstgcn_forward(keypoint[:, 0], _sub(sd, 'backbone.'), node_type, edge_type, plan, training)
+    logits = gcn_head_forward(feat, _sub(sd, 'cls_head.'))
+    loss = F.cross_entropy(logits, label.squeeze(-1))
+    return logits, loss
+
+
+# ----------------------------------------------------------------------------------------
+# ST-GCN units (gcn.py:22-97, tcn.py:10-37, stgcn.py:16-68)   SURVEY App. A.3
+# ----------------------------------------------------------------------------------------
+
+def unit_gcn_forward(x, sd, training=True):
+    n, Ci, T, V = x.shape
+    A = sd['A']
+    K = A.shape[0]
+    h = _conv1x1(x, sd['conv.weight'], sd['conv.bias']).view(n, K, -1, T, V)          # gcn.py:86-87
+    y = torch.einsum('nkctv,kvw->nctw', h, A)                                         # gcn.py:88
+    return F.relu(_bn(y, sd, 'bn.', training))                                        # gcn.py:94
+
+
+def stgcn_block_forward(x, sd, stride, residual, training=True):
+    g = unit_gcn_forward(x, _sub(sd, 'gcn.'), training)
+    t = unit_tcn_forward(g, _sub(sd, 'tcn.'), 9, stride, 1, training)                 # stgcn.py:45-46 (p=0)
+    if not residual:
+        res = 0
+    elif 'residual.conv.weight' in sd:
+        res = unit_tcn_forward(x, _sub(sd, 'residual.'), 1, stride, 1, training)
+    else:
+        res = x
+    return F.relu(t + res)
+
+
+def stgcn_forward(x, sd, plan, training=True):
+    N, M, T, V, C = x.shape
+    h = x.permute(0, 1, 3, 4, 2).contiguous().view(N * M, V * C, T)
+    h = _bn(h, sd, 'data_bn.', training)
+    h = h.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
+    for i, (ci, co, stride, residual) in enumerate(plan):
+        h = stgcn_block_forward(h, _sub(sd, f'gcn.{i}.'), stride, residual, training)
+    return h.reshape((N, M) + h.shape[1:])
+
+
+# ----------------------------------------------------------------------------------------
+# CTR-GCN units (gcn.py:634-666, 882-929; msg3d_utils.py:64-149; ctrgcn.py)   SURVEY App. A.4
+# ----------------------------------------------------------------------------------------
+
+def ctrgc_forward(x, sd, A_i, alpha):
+    x1 = _conv1x1(x, sd['conv1.weight'], sd['conv1.bias']).mean(-2)                   # (n,R,V) gcn.py:652
+    x2 = _conv1x1(x, sd['conv2.weight'], sd['conv2.bias']).mean(-2)
+    x3 = _conv1x1(x, sd['conv3.weight'], sd['conv3.bias'])
+    d = torch.tanh(x1[:, :, :, None] - x2[:, :, None, :])                             # gcn.py:655
+    ah = _conv1x1(d, sd['conv4.weight'], sd['conv4.bias']) * alpha + A_i[None, None]  # gcn.py:657
+    return torch.einsum('ncuv,nctu->nctv', ah, x3)                                    # gcn.py:658
+
+
+def unit_ctrgcn_forward(x, sd, training=True):
+    A = sd['A']
+    y = None
+    for i in range(A.shape[0]):
+        z = ctrgc_forward(x, _sub(sd, f'convs.{i}.'), A[i], sd['alpha'])
+        y = z if y is None else z + y                                                 # gcn.py:915-917
+    y = _bn(y, sd, 'bn.', training)
+    if 'down.0.weight' in sd:
+        y = y + _bn(_conv1x1(x, sd['down.0.weight'], sd['down.0.bias']), sd, 'down.1.', training)
+    else:
+        y = y + x
+    return F.relu(y)
+
+
+def mstcn_msg3d_forward(x, sd, stride=1, kernel_size=5, dilations=(1, 2), training=True):
+    """MSTCN of msg3d_utils.py:64-149 with residual=False (ctrgcn.py:41-48)."""
+    outs = []
+    nb = len(dilations) + 2
+    for j, d in enumerate(dilations):
+        p = f'branches.{j}.'
+        h = F.relu(_bn(_conv1x1(x, sd[p + '0.weight'], sd[p + '0.bias']), sd, p + '1.', training))
+        outs.append(unit_tcn_forward(h, _sub(sd, p + '3.'), kernel_size, stride, d, training))
+    p = f'branches.{nb - 2}.'
+    h = F.relu(_bn(_conv1x1(x, sd[p + '0.weight'], sd[p + '0.bias']), sd, p + '1.', training))
+    h = F.max_pool2d(h, (3, 1), (stride, 1), (1, 0))
+    outs.append(_bn(h, sd, p + '4.', training))
+    p = f'branches.{nb - 1}.'
+    outs.append(_bn(_conv1x1(x, sd[p + '0.weight'], sd[p + '0.bias'], stride), sd, p + '1.', training))
+    return F.relu(torch.cat(outs, 1))

@@ -1,0 +1,148 @@
+"""Plain-PyTorch statement of every fused op the HIP library implements (test infrastructure).
+
+Same call signatures as ``dsgcn_amd.kernels`` so that (a) each HIP op is checked against the
+matching function here on identical inputs (``-m gpu`` tests, fp32 and fp64 references) and
+(b) the host-side composition of ops (deferred BatchNorm wiring, state_dict mapping) can be
+checked against the oracle on CPU by injecting this namespace with ``kernels.use_ops``.
+Autograd of these functions is PyTorch's own.
+"""
+import torch
+import torch.nn.functional as F
+
+NAME = 'torch_ops(test reference)'
+
+
+def _bc(p):
+    return p[None, :, None, None]
+
+
+def virt(x1, a1, x2, a2, relu):
+    """Virtual input of a fused op: relu?( x1*s1+h1 [+ x2*s2+h2 | + x2] )."""
+    v = x1 if a1 is None else x1 * _bc(a1[0]) + _bc(a1[1])
+    if x2 is not None:
+        v = v + (x2 if a2 is None else x2 * _bc(a2[0]) + _bc(a2[1]))
+    return F.relu(v) if relu else v
+
+
+def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, stats=True):
+    """1x1 channel mix over the virtual input (rows subsampled by ``stride``).
+
+    Returns (z, zaug, mean, var): z (n,Co,T',V); zaug (n,Co,T') = mean_v z when ``aug``
+    (the dgmstcn global joint, tcn.py:409, by linearity of the 1x1 conv); mean/var are the
+    biased batch statistics of z over (n,T',V) — including the zaug column when ``aug``."""
+    v = virt(x1, a1, x2, a2, relu)
+    if stride != 1:
+        v = v[:, :, ::stride]
+    w2 = weight.reshape(weight.shape[0], -1)
+    z = torch.einsum('oc,nctv->notv', w2, v)
+    if bias is not None:
+        z = z + _bc(bias)
+    zaug = z.mean(-1) if aug else None
+    mean = var = None
+    if stats:
+        full = torch.cat([z, zaug[..., None]], -1) if aug else z
+        mean = full.mean((0, 2, 3))
+        var = full.var((0, 2, 3), unbiased=False)
+    return z, zaug, mean, var
+
+
+def bn_affine(mean, var, weight, bias, eps):
+    scale = weight * torch.rsqrt(var + eps)
+    return scale, bias - mean * scale
+
+
+def aggregate(zp, ap, relu, ahat):
+    """y[n,c,t,w] = sum_u P[n,c,t,u] * ahat[n,c,u,w],  P = virt(zp, ap)."""
+    p = virt(zp, ap, None, None, relu)
+    return torch.einsum('nctu,ncuw->nctw', p, ahat)
+
+
+def aggregate_shared(zp, A, K):
+    """ST-GCN form (gcn.py:86-88): zp (n,K*Co,T,V), A (K,V,V) -> y (n,Co,T,V) summed over k."""
+    n, KC, T, V = zp.shape
+    return torch.einsum('nkctv,kvw->nctw', zp.view(n, K, KC // K, T, V), A)
+
+
+def tmean(x):
+    return x.mean(2)
+
+
+def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type):
+    """Dynamic adjacency.  xbar (n,Ci,V) -> ahat (n,K*mid,V,V), K=3.
+
+    w1,w2: (2*mid,Ci); wse: (mid*P,Ci) channel index c*P+p; we: (E*mid,mid) out index e*mid+c.
+    node_type (V,) long, edge_type (V,V) long."""
+    n, Ci, V = xbar.shape
+    K = A.shape[0]
+    mid = w1.shape[0] // 2
+    P = wse.shape[0] // mid
+    E = we.shape[0] // mid
+    a = (torch.einsum('oc,ncv->nov', w1, xbar) + b1[None, :, None]).reshape(n, 2, mid, V)
+    b = (torch.einsum('oc,ncv->nov', w2, xbar) + b2[None, :, None]).reshape(n, 2, mid, V)
+    wsel = wse.reshape(mid, P, Ci)[:, node_type, :]
+    s = torch.einsum('cvi,niv->ncv', wsel, xbar) + bse.reshape(mid, P)[:, node_type][None]
+    x1 = torch.stack([a[:, 0], a[:, 1], s], 1)
+    x2 = torch.stack([b[:, 0], b[:, 1], s], 1)
+    d0 = a[:, 0, :, :, None] - b[:, 0, :, None, :]
+    diff1 = a[:, 1, :, :, None] - b[:, 1, :, None, :]
+    wsel_e = we.reshape(E, mid, mid)[edge_type]
+    d1 = torch.einsum('uwcd,nduw->ncuw', wsel_e, diff1) + be.reshape(E, mid)[edge_type].permute(2, 0, 1)[None]
+    d2 = s[:, :, :, None] - s[:, :, None, :]
+    th = torch.tanh(torch.stack([d0, d1, d2], 1))
+    sm = torch.softmax(torch.einsum('nkcu,nkcw->nkuw', x1, x2), dim=-2)
+    ahat = (A[None, :, None] + alpha[None, :, None, None, None] * th + beta[None, :, None, None, None] * sm[:, :, None])
+    return ahat.reshape(n, K * mid, V, V)
+
+
+def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, add_coeff, stride, stats=True):
+    """Multi-scale temporal stage of dgmstcn after the fused branch 1x1 conv.
+
+    z (n,C,T,V), zaug (n,C,T): raw branch-conv outputs (real joints / global joint).
+    scale/shift (C): deferred BN affine; channels < n_act also get ReLU, the rest pass through.
+    branch_cfg: list of (k,dil) | ('max',k) | '1x1'; widths: channels per branch;
+    conv_w[i] (bc,bc,k,1), conv_b[i] (bc) for the conv branches in order.
+    Returns f (n,C,T/stride,V) = local + global*add_coeff, and its batch mean/var."""
+    n, C, T, V = z.shape
+    full = torch.cat([z, zaug[..., None]], -1)
+    h = full * _bc(scale) + _bc(shift)
+    h = torch.cat([F.relu(h[:, :n_act]), h[:, n_act:]], 1)
+    outs = []
+    c0 = 0
+    ci = 0
+    for cfg, bc in zip(branch_cfg, widths):
+        hb = h[:, c0:c0 + bc]
+        if cfg == '1x1':
+            outs.append(hb[:, :, ::stride])
+        elif cfg[0] == 'max':
+            outs.append(F.max_pool2d(hb, (cfg[1], 1), (stride, 1), (1, 0)))
+        else:
+            k, d = cfg
+            pad = (k + (k - 1) * (d - 1) - 1) // 2
+            outs.append(F.conv2d(hb, conv_w[ci], conv_b[ci], stride=(stride, 1), padding=(pad, 0), dilation=(d, 1)))
+            ci += 1
+        c0 += bc
+    o = torch.cat(outs, 1)
+    f = o[..., :V] + o[..., V, None] * add_coeff[:V]
+    mean = var = None
+    if stats:
+        mean = f.mean((0, 2, 3))
+        var = f.var((0, 2, 3), unbiased=False)
+    return f, mean, var
+
+
+def tconv(x1, a1, relu, weight, bias, stride, dilation, stats=True):
+    """Dense temporal conv (k,1) over the virtual input (unit_tcn, tcn.py:21-27)."""
+    v = virt(x1, a1, None, None, relu)
+    k = weight.shape[2]
+    pad = (k + (k - 1) * (dilation - 1) - 1) // 2
+    z = F.conv2d(v, weight, bias, stride=(stride, 1), padding=(pad, 0), dilation=(dilation, 1))
+    mean = var = None
+    if stats:
+        mean = z.mean((0, 2, 3))
+        var = z.var((0, 2, 3), unbiased=False)
+    return z, mean, var
+
+
+def fuse_out(x1, a1, x2, a2, relu, want_tmean=False):
+    out = virt(x1, a1, x2, a2, relu)
+    return out, (out.mean(2) if want_tmean else None)
