@@ -1,0 +1,44 @@
+// Shared device helpers for the DS-GCN HIP kernels (gfx950 / CDNA4 only: wave64, MFMA f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DSGCN_WAVE 64
+
+// Error codes returned by every C-ABI entry point: 0 = ok, >0 = hipError_t of the launch,
+// <0 = argument rejected before any launch (see include/dsgcn.h).
+#define DSGCN_EINVAL (-1)
+#define DSGCN_EUNSUPPORTED (-2)
+
+#define DSGCN_LAUNCH_CHECK()                      \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// relu?(x*s+h)
+__device__ __forceinline__ float affine_act(float x, float s, float h, int relu) {
+  float v = fmaf(x, s, h);
+  return relu ? fmaxf(v, 0.f) : v;
+}

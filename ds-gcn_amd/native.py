@@ -1,0 +1,79 @@
+"""Loader/builder for ``libdsgcn.so`` — the C-ABI HIP library (declared in ``include/dsgcn.h``).
+
+The library is built in-tree (``ds-gcn_amd/lib/libdsgcn.so``) with ``hipcc --offload-arch=gfx950`` and
+loaded with ``ctypes``: no torch types cross the boundary, only raw device pointers, sizes and the
+HIP stream handle.  ``lib()`` raises if the library is missing — there is no fallback.
+"""
+import ctypes
+import glob
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_DIR = os.path.join(_HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libdsgcn.so')
+INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
+
+_lib = None
+
+c_f = ctypes.c_void_p      # const float* / float*  (device)
+c_i = ctypes.c_void_p      # const int*             (device)
+c_int = ctypes.c_int
+c_st = ctypes.c_void_p     # hipStream_t
+
+# name -> argtypes; every entry point returns int (0 ok, >0 hipError_t, <0 argument error)
+SIGNATURES = {
+    'dsgcn_version': [],
+    'dsgcn_aggregate_fwd': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
+    'dsgcn_aggregate_bwd': [c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
+    'dsgcn_dynadj_fwd': [c_f] * 12 + [c_i, c_i, c_f] + [c_int] * 6 + [c_st],
+    'dsgcn_dynadj_bwd': [c_f] * 11 + [c_i] * 4 + [c_f] * 10 + [c_int] * 6 + [c_st],
+}
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into one shared library (cross-compiles without a GPU)."""
+    srcs = sources()
+    deps = srcs + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(INCLUDE, '*.h'))
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in deps):
+            return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I', INCLUDE, '-I', CSRC,
+           '-o', LIB_PATH] + srcs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'dsgcn: {LIB_PATH} is missing — build it with `python -c "import __graft_entry__ as g; g.build()"`. '
+                'The HIP library is the only implementation of the hot path (no CPU/eager fallback).')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lib = handle
+    return _lib
+
+
+class DsgcnError(RuntimeError):
+    pass
+
+
+def check(code, what):
+    if code != 0:
+        kind = 'argument rejected' if code < 0 else 'hipError_t'
+        raise DsgcnError(f'{what} failed: {kind} {code}')

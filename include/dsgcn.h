@@ -1,0 +1,71 @@
+/* libdsgcn — C ABI of the MI355X-native DS-GCN hot path.
+ *
+ * The reference (davelailai/DS-GCN, a PYSKL fork) has no FFI: its hot path is Python calling ATen
+ * (SURVEY.md §2.2).  The drop-in boundary is therefore the PYSKL registry/config API (mirrored in
+ * Python by ds-gcn_amd/), and THIS header is the native boundary underneath it: each entry point
+ * replaces the group of ATen calls cited next to it.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - return int: 0 = ok; >0 = hipError_t of a failed launch; DSGCN_EINVAL (-1) = bad argument;
+ *     DSGCN_EUNSUPPORTED (-2) = shape outside the compiled variants.  Never throws.
+ *   - pointers are DEVICE pointers to contiguous fp32 (or int32 where noted) buffers owned by the
+ *     caller; nothing is allocated or freed; no host/device synchronisation happens inside.
+ *   - `stream` is a hipStream_t (NULL = default stream); launches are asynchronous on it; calls on
+ *     distinct streams are thread-safe.
+ *   - layouts: activations (n, C, T, V) with V fastest ("NCHW"), adjacency (n, C, V, V).
+ */
+#ifndef DSGCN_H_
+#define DSGCN_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSGCN_EINVAL (-1)
+#define DSGCN_EUNSUPPORTED (-2)
+
+/* ABI version (major*100+minor). */
+int dsgcn_version(void);
+
+/* K-A gather-aggregate.  Replaces torch.einsum('nkctv,nkcvw->nkctw', pre_x, A)
+ * (reference pyskl/models/gcns/utils/gcn.py:2350-2352) fused with the BN+ReLU of `pre`
+ * (gcn.py:2165-2167,2236):   y[b,t,w] = sum_u relu?(zp[b,t,u]*scale[c]+shift[c]) * ahat[b,u,w],
+ * b = (sample, channel c) over n*KC units.  scale/shift may be NULL (identity).  V in {25,17,18}. */
+int dsgcn_aggregate_fwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
+                        float* y, int n, int KC, int T, int V, void* stream);
+
+/* Backward of the above: dzp (n,KC,T,V), dahat (n,KC,V,V) and partial (n*KC,2) =
+ * per-unit [sum dP*mask*zp, sum dP*mask] (the d scale / d shift reductions before the sum over n). */
+int dsgcn_aggregate_bwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
+                        const float* dy, float* dzp, float* dahat, float* partial, int n, int KC, int T, int V,
+                        void* stream);
+
+/* K-B dynamic-semantic adjacency.  Replaces gcn.py:2240-2337 (mean-pooled projections conv1/conv2/
+ * conv1_se with the node-typed select, the edge-typed linear with its 625-iteration index loop,
+ * tanh, Gram + Softmax(-2), alpha/beta scale-add).  K = 3 subsets.
+ *   xbar (n,Ci,V) time-mean of the unit input;  A (3,V,V); alpha,beta (3)
+ *   w1,w2 (2*mid,Ci) b1,b2 (2*mid);  wse (mid*P,Ci) row c*P+p, bse (mid*P);  we (E*mid,mid) row e*mid+c, be (E*mid)
+ *   node_type (V) int32 in [0,P);  edge_type (V*V) int32 in [0,E)
+ *   ahat out (n,3*mid,V,V).   V <= 32, mid <= 32. */
+int dsgcn_dynadj_fwd(const float* xbar, const float* A, const float* alpha, const float* beta, const float* w1,
+                     const float* b1, const float* w2, const float* b2, const float* wse, const float* bse,
+                     const float* we, const float* be, const int* node_type, const int* edge_type, float* ahat,
+                     int n, int Ci, int mid, int V, int P, int E, void* stream);
+
+/* Backward of K-B.  pair_order (V*V) = joint pairs sorted by edge class, class_start (E+1) = offsets.
+ * dd_ws: workspace (n,3*mid,V,V).  Outputs: dproj (n,5*mid,V) rows [a|b|s]; dxbar (n,Ci,V);
+ * pA (n,3,V,V) (sum over n = dA); pab (n,6) (sum over n = [dalpha|dbeta]);
+ * dwe (E*mid,mid), dbe (E*mid), dwproj (9*mid,Ci) rows [w1|w2|wse], dbproj (9*mid): ACCUMULATED with
+ * float atomics — the caller zeroes them. */
+int dsgcn_dynadj_bwd(const float* xbar, const float* alpha, const float* beta, const float* w1, const float* b1,
+                     const float* w2, const float* b2, const float* wse, const float* bse, const float* we,
+                     const float* be, const int* node_type, const int* edge_type, const int* pair_order,
+                     const int* class_start, const float* dahat, float* dd_ws, float* dproj, float* dxbar, float* pA,
+                     float* pab, float* dwe, float* dbe, float* dwproj, float* dbproj, int n, int Ci, int mid, int V,
+                     int P, int E, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSGCN_H_ */

@@ -57,10 +57,15 @@ def aggregate(zp, ap, relu, ahat):
     return torch.einsum('nctu,ncuw->nctw', p, ahat)
 
 
-def aggregate_shared(zp, A, K):
-    """ST-GCN form (gcn.py:86-88): zp (n,K*Co,T,V), A (K,V,V) -> y (n,Co,T,V) summed over k."""
+def aggregate_shared(zp, A, K, stats=True):
+    """ST-GCN form (gcn.py:86-88): zp (n,K*Co,T,V), A (K,V,V) -> y (n,Co,T,V) summed over k (+ batch stats)."""
     n, KC, T, V = zp.shape
-    return torch.einsum('nkctv,kvw->nctw', zp.view(n, K, KC // K, T, V), A)
+    y = torch.einsum('nkctv,kvw->nctw', zp.view(n, K, KC // K, T, V), A)
+    mean = var = None
+    if stats:
+        mean = y.mean((0, 2, 3))
+        var = y.var((0, 2, 3), unbiased=False)
+    return y, mean, var
 
 
 def tmean(x):
@@ -73,6 +78,7 @@ def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, ed
     w1,w2: (2*mid,Ci); wse: (mid*P,Ci) channel index c*P+p; we: (E*mid,mid) out index e*mid+c.
     node_type (V,) long, edge_type (V,V) long."""
     n, Ci, V = xbar.shape
+    node_type, edge_type = node_type.long(), edge_type.long()
     K = A.shape[0]
     mid = w1.shape[0] // 2
     P = wse.shape[0] // mid
