@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py — clips/sec forward+backward, DS-STGCN NTU-60 (3x64x25x2 clips), on N MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 it is launched through
+``torch.distributed.run`` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+A "step" = one pass of the hot path over one batch of synthetic clips resident in HBM: forward (train-mode
+BatchNorm, CE loss) + backward + gradient all-reduce (N>1) + the SGD-nesterov update.  Weak scaling: 64
+clips per GPU.  The line also carries
+  roofline     — the gather-aggregate kernel (K-A) timed live with HIP events on the launch stream over the
+                 model's own 10-layer shape mix, against the 8 TB/s HBM peak (algorithmic bytes only);
+  cpu_baseline — the CPU oracle (op-for-op PyTorch restatement of the reference path) timed on this box's
+                 host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
+CLIPS_PER_GPU = 64
+T, V, M, C, CLASSES = 64, 25, 2, 3, 60
+
+
+def ds_cfg(num_classes=CLASSES, layout='nturgb+d'):
+    return dict(
+        type='RecognizerGCN',
+        backbone=dict(
+            type='DGSTGCN', gcn_type='dgphgcn1', gcn_ratio=0.125, gcn_node_attention=True, gcn_edge_attention=True,
+            gcn_decompose=True, gcn_subset_wise=True, gcn_ctr='T', gcn_ada='T', tcn_type='dgmstcn',
+            graph_cfg=dict(layout=layout, mode='random', num_filter=3, init_off=.04, init_std=.02),
+            tcn_ms_cfg=[(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1']),
+        cls_head=dict(type='GCNHead', num_classes=num_classes, in_channels=256))
+
+
+def build_model(seed=0):
+    import dsgcn_amd
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    model = dsgcn_amd.build_model(ds_cfg())
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():   # zero-init alpha/beta/add_coeff would switch the dynamic paths off
+        for k, p in model.named_parameters():
+            if k.endswith(('alpha', 'beta', 'add_coeff')):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    return model
+
+
+def ka_layer_shapes(n):
+    """(n, K*mid, T_at_gcn) of the 10 DS-STGCN layers."""
+    return [(n, 24, 64)] * 4 + [(n, 48, 64)] + [(n, 48, 32)] * 2 + [(n, 96, 32)] + [(n, 96, 16)] * 2
+
+
+def ka_alg_bytes(n, KC, t, v, bwd):
+    units = n * KC
+    return 4 * units * ((3 * t * v + 2 * v * v) if bwd else (2 * t * v + v * v))
+
+
+def measure_ka_roofline(device, n, reps=20):
+    """HIP-event timing of K-A fwd and bwd over the model's layer mix (distinct buffers per layer so the
+    working set, 0.64 GB fwd / 1.05 GB bwd, exceeds the 256 MiB Infinity Cache)."""
+    from dsgcn_amd import native
+    lib = native.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    bufs = []
+    for (nn, KC, t) in ka_layer_shapes(n):
+        zp = torch.randn(nn, KC, t, V, device=device)
+        ah = torch.randn(nn, KC, V, V, device=device) * 0.2
+        sc = torch.rand(KC, device=device) + 0.5
+        sh = torch.randn(KC, device=device) * 0.1
+        bufs.append(dict(zp=zp, ah=ah, sc=sc, sh=sh, y=torch.empty_like(zp), dy=torch.randn_like(zp),
+                         dzp=torch.empty_like(zp), dah=torch.empty_like(ah),
+                         part=torch.empty(nn * KC, 2, device=device), dims=(nn, KC, t)))
+
+    def fwd(b):
+        nn, KC, t = b['dims']
+        rc = lib.dsgcn_aggregate_fwd(b['zp'].data_ptr(), b['sc'].data_ptr(), b['sh'].data_ptr(), 1, b['ah'].data_ptr(),
+                                     b['y'].data_ptr(), nn, KC, t, V, st)
+        assert rc == 0, rc
+
+    def bwd(b):
+        nn, KC, t = b['dims']
+        rc = lib.dsgcn_aggregate_bwd(b['zp'].data_ptr(), b['sc'].data_ptr(), b['sh'].data_ptr(), 1, b['ah'].data_ptr(),
+                                     b['dy'].data_ptr(), b['dzp'].data_ptr(), b['dah'].data_ptr(),
+                                     b['part'].data_ptr(), nn, KC, t, V, st)
+        assert rc == 0, rc
+
+    out = {}
+    for name, fn, is_bwd in (('k_aggregate_fwd', fwd, False), ('k_aggregate_bwd', bwd, True)):
+        for b in bufs:
+            fn(b)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            for b in bufs:
+                fn(b)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        nbytes = sum(ka_alg_bytes(*b['dims'], V, is_bwd) for b in bufs)
+        launches = len(bufs)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[name] = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                         frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                         avg_launch_us=round(ms * 1e3 / launches, 2), alg_bytes_per_launch=nbytes // launches,
+                         launches_per_step=launches)
+    return out
+
+
+def cpu_baseline(budget_s=12.0, batch=16):
+    """Oracle (CPU PyTorch restatement) fwd+bwd on this box's host cores: bounded sample.
+    Intra-op threads are chosen by a short probe (8/16/32): with hundreds of tiny ATen ops per step more
+    threads are SLOWER (measured on the 2x64-core EPYC host: 16 threads 21 clips/s, 128 threads 0.9)."""
+    from oracle import dsgcn_oracle as O
+    model = build_model()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    leaves = {k: v.requires_grad_() for k, v in sd.items() if v.dtype.is_floating_point and 'running' not in k}
+    sd.update(leaves)
+    gc = O.graph_constants('nturgb+d')
+    plan = O.dgstgcn_plan()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(batch, 1, M, T, V, C, generator=g)
+    y = torch.randint(0, CLASSES, (batch, 1), generator=g)
+
+    def step():
+        for v in leaves.values():
+            v.grad = None
+        _, loss = O.recognizer_forward_train(x, y, sd, gc['node_type'], gc['edge_type'], plan)
+        loss.backward()
+
+    avail = os.cpu_count() or 1
+    best_thr, best_t = 1, float('inf')
+    for thr in [c for c in (8, 16, 32) if c <= avail] or [avail]:
+        torch.set_num_threads(thr)
+        step()   # warm-up (allocator, mkldnn primitive cache)
+        t0 = time.perf_counter()
+        step()
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best_thr, best_t = thr, dt
+    torch.set_num_threads(best_thr)
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        step()
+        iters += 1
+        el = time.perf_counter() - t0
+        if (el >= budget_s and iters >= 2) or iters >= 50 or el > 4 * budget_s:
+            break
+    el = time.perf_counter() - t0
+    return dict(value=round(batch * iters / el, 2), unit='clips/s', cores=best_thr, kind='port',
+                sample=f'{iters} fwd+bwd iterations of a {batch}-clip batch (3x{T}x{V}x{M}), oracle/dsgcn_oracle.py, '
+                       f'torch {torch.__version__} CPU, {best_thr} intra-op threads (best of 8/16/32; host has '
+                       f'{avail} hw threads), {el:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--clips-per-gpu', type=int, default=CLIPS_PER_GPU)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (the hot path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    import dsgcn_amd
+    from dsgcn_amd import native
+    native.lib()   # fail loudly if the HIP library is missing
+
+    model = build_model().to(device).train()
+    flat = dsgcn_amd.FlatParams(model)
+    dp = dsgcn_amd.FlatDataParallel(flat)
+    opt = dsgcn_amd.FlatSGD(flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
+
+    B = args.clips_per_gpu
+    g = torch.Generator().manual_seed(1234 + rank)
+    keypoint = torch.randn(B, 1, M, T, V, C, generator=g).to(device)
+    label = torch.randint(0, CLASSES, (B, 1), generator=g).to(device)
+    batch = dict(keypoint=keypoint, label=label)
+
+    def step():
+        opt.zero_grad()
+        out = model.train_step(batch, None, sync_log_vars=False)
+        out['loss'].backward()
+        dp.allreduce_grads()
+        opt.step()
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    loss_val = float(out['loss'].item())
+    assert flat.check_views(), 'a parameter gradient left the flat buffer'
+    assert np.isfinite(loss_val), loss_val
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        result = {
+            'metric': 'clips/sec fwd+bwd, DS-STGCN NTU-60 3x64x25x2', 'value': round(value, 1), 'unit': 'clips/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'DS-STGCN configs/dsstgcn/ntu60_xsub_3dkp/j.py (DSSTGCN_model.py kwargs), '
+                                   f'{B} clips/GPU of 3x{T}x{V}x{M}, 60 classes, train-mode BN, CE loss, '
+                                   'fwd+bwd+grad all-reduce+SGD-nesterov per step',
+                       'clips_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
+            'final_loss': round(loss_val, 5),
+        }
+    if rank == 0 and not args.no_roofline:
+        rf = measure_ka_roofline(device, B * M)
+        result['roofline'] = rf['k_aggregate_bwd'] | {'kernel': 'k_aggregate_bwd'}
+        result['roofline_other'] = {'k_aggregate_fwd': rf['k_aggregate_fwd']}
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline(args.cpu_budget)
+        result['cpu_baseline'] = cb
+        result['gpu_over_cpu'] = round(result['value'] / cb['value'], 1)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -17,5 +17,7 @@ from .tcn_units import dgmstcn, unit_tcn
 from .backbones import DGSTGCN, STGCN, DGBlock, STGCNBlock
 from .recognizers import RecognizerGCN, BaseRecognizer
 from . import kernels
+from .data_parallel import FlatParams, FlatDataParallel, shard_batch
+from .train import FlatSGD, cosine_lr
 
 __version__ = '0.1.0'
