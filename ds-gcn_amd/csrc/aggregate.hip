@@ -1,20 +1,22 @@
 // K-A: gather-aggregate over joints (reference: pyskl/models/gcns/utils/gcn.py:2341-2354,
-//      einsum('nkctv,nkcvw->nkctw'); ST-GCN form gcn.py:88; CTR-GCN form gcn.py:658).
+//      einsum('nkctv,nkcvw->nkctw'); CTR-GCN form gcn.py:658).
 //
 //   Y[b,t,w] = sum_u P[b,t,u] * Ahat[b,u,w],   P = relu?(Zp*scale[c]+shift[c])   b = (n, c) "unit"
 //
-// One wave64 owns one unit (a T x V plane of P/Y plus its V x V adjacency):
+// One wave64 owns one unit (a T x V plane of P/Y plus its V x V adjacency; 64 frames per pass):
 //   * the plane is streamed HBM -> LDS with 16 B/lane coalesced loads, the deferred BatchNorm affine
-//     and ReLU applied in flight (P never exists in HBM);
-//   * lane = frame t; its P row is read from LDS with stride V (V=25/17 is odd -> conflict-free);
-//   * Ahat[b] is wave-uniform, so it is fetched through the SCALAR cache (s_load) and fed to the
-//     FMAs as SGPR operands: V*V v_fma per lane, no LDS/VGPR traffic for the adjacency at all;
-//   * the Y row goes back through LDS and leaves as coalesced 16 B/lane stores.
+//     and ReLU applied in flight (P never exists in HBM); Ahat[b] (V*V floats) is staged next to it;
+//   * the (frames x V) . (V x V) product runs on the f32 matrix core: v_mfma_f32_32x32x2_f32 with
+//     i = frame, j = joint w, k = joint u (V=25 -> 13 k-steps, padded lanes fed zeros).  Operands are
+//     single ds_read_b32 per lane: P rows at stride V (odd -> conflict-free), Ahat rows contiguous;
+//   * the Y tile leaves the accumulators through LDS as coalesced 16 B/lane stores.
 // Algorithmic HBM bytes per unit: 4*(2*T*V + V*V); nothing is read twice.
+// (A first version kept lane = frame and fed Ahat through the scalar cache as SGPR FMA operands;
+//  it measured 24 % of the HBM roofline — k_aggregate_fwd_valu below is kept for that A/B only.)
 //
-// Backward (one wave per unit as well):
-//   dP[t,u]   = sum_w dY[t,w] * Ahat[u,w]          (same SGPR-broadcast FMA form)
-//   dAhat[u,w]= sum_t P[t,u] * dY[t,w]             (V x V x T: f32 MFMA 32x32x2, k = frames)
+// Backward (one wave per unit as well), three MFMA products out of the same LDS tiles:
+//   dAhat[u,w] = sum_t P[t,u] * dY[t,w]            (i=u, j=w, k=frames)
+//   dP[t,u]    = sum_w dY[t,w] * Ahat[u,w]         (i=frame, j=u, k=w)
 //   dZp = dP * 1[P>0] * scale ; per-unit partial sums of dP*1[P>0] and dP*1[P>0]*Zp feed the
 //   deferred-BN backward (d shift, d scale).
 #include "common.h"
@@ -35,7 +37,7 @@ __device__ __forceinline__ void load_plane_to_lds(const float* __restrict__ src,
 }
 
 template <int V, int UNR>
-__global__ __launch_bounds__(64) void k_aggregate_fwd(const float* __restrict__ zp, const float* __restrict__ scale,
+__global__ __launch_bounds__(64) void k_aggregate_fwd_valu(const float* __restrict__ zp, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int relu,
                                                       const float* __restrict__ ahat, long ahat_unit_stride,
                                                       int ahat_mod, float* __restrict__ y, int KC, int T, int vec) {
@@ -95,30 +97,245 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd(const float* __restrict__ 
   }
 }
 
-template <int V, int UNR>
+// MFMA C/D row of accumulator register r for this lane (32x32 tile): (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <int V>
+__global__ __launch_bounds__(64) void k_aggregate_fwd(const float* __restrict__ zp, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int relu,
+                                                      const float* __restrict__ ahat, float* __restrict__ y, int KC,
+                                                      int T, int vec) {
+  constexpr int KS = (V + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldsP = lds;
+  float* ldsA = lds + 64 * V;
+  const int lane = threadIdx.x;
+  const int unit = blockIdx.x;
+  const int t0 = blockIdx.y * 64;
+  const int c = unit % KC;
+  const float s = scale ? scale[c] : 1.f;
+  const float h = shift ? shift[c] : 0.f;
+  const float* __restrict__ A = ahat + (size_t)unit * V * V;
+  const float* __restrict__ src = zp + ((size_t)unit * T + t0) * V;
+  float* __restrict__ dst = y + ((size_t)unit * T + t0) * V;
+  const int rows = min(64, T - t0);
+  const int cnt = rows * V;
+  for (int i = lane; i < V * V; i += 64) ldsA[i] = A[i];
+  if (vec) {
+    const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* l4 = reinterpret_cast<f32x4*>(ldsP);
+    const int c4 = cnt >> 2;
+    for (int i = lane; i < c4; i += 64) {
+      f32x4 v = s4[i];
+      v.x = affine_act(v.x, s, h, relu);
+      v.y = affine_act(v.y, s, h, relu);
+      v.z = affine_act(v.z, s, h, relu);
+      v.w = affine_act(v.w, s, h, relu);
+      l4[i] = v;
+    }
+  } else {
+    for (int i = lane; i < cnt; i += 64) ldsP[i] = affine_act(src[i], s, h, relu);
+  }
+  __syncthreads();
+  const int mi = lane & 31, mk = lane >> 5;
+  const int mic = mi < V ? mi : V - 1;
+  float b[KS];
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int u = 2 * q + mk;
+    const float v = ldsA[(u < V ? u : V - 1) * V + mic];
+    b[q] = (u < V && mi < V) ? v : 0.f;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int tile = 0; tile < 2; ++tile) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[tile][i] = 0.f;
+    if (tile * 32 < rows) {
+      const int t = tile * 32 + mi;
+      const int tc = t < rows ? t : rows - 1;
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        const int u = 2 * q + mk;
+        const float v = ldsP[tc * V + (u < V ? u : V - 1)];
+        const float a = (u < V && t < rows) ? v : 0.f;
+        acc[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[q], acc[tile], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  if (mi < V) {
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = tile * 32 + mfma_row(r, mk);
+        if (t < rows) ldsP[t * V + mi] = acc[tile][r];
+      }
+    }
+  }
+  __syncthreads();
+  if (vec) {
+    f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dst);
+    const f32x4* l4 = reinterpret_cast<const f32x4*>(ldsP);
+    const int c4 = cnt >> 2;
+    for (int i = lane; i < c4; i += 64) d4[i] = l4[i];
+  } else {
+    for (int i = lane; i < cnt; i += 64) dst[i] = ldsP[i];
+  }
+}
+
+// Persistent form of k_aggregate_fwd: each wave walks work items (unit, 64-frame chunk) with a grid
+// stride and keeps the NEXT item's P plane and adjacency in flight (global -> VGPR) while the matrix core
+// works on the current one, so HBM requests, MFMA and stores of neighbouring items overlap inside one wave.
+template <int V>
+__global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restrict__ zp,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu,
+                                                           const float* __restrict__ ahat, float* __restrict__ y,
+                                                           int KC, int T, int chunks, long items) {
+  constexpr int KS = (V + 1) / 2;
+  constexpr int NP4 = (64 * V / 4 + 63) / 64;     // float4 loads per lane for a full 64-frame plane
+  constexpr int NA = (V * V + 63) / 64;           // dword loads per lane for the adjacency
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldsP = lds;
+  float* ldsA = lds + 64 * V;
+  const int lane = threadIdx.x;
+  const int mi = lane & 31, mk = lane >> 5;
+  const int mic = mi < V ? mi : V - 1;
+  f32x4 pre[NP4];
+  float prea[NA];
+
+  auto issue = [&](long item) {
+    const long unit = item / chunks;
+    const int t0 = (int)(item - unit * chunks) * 64;
+    const int rows = min(64, T - t0);
+    const int c4 = (rows * V) >> 2;
+    const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(zp + ((size_t)unit * T + t0) * V);
+    const float* __restrict__ A = ahat + (size_t)unit * V * V;
+#pragma unroll
+    for (int q = 0; q < NP4; ++q) {
+      const int i = lane + q * 64;
+      if (i < c4) pre[q] = s4[i];
+    }
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int i = lane + q * 64;
+      if (i < V * V) prea[q] = A[i];
+    }
+  };
+
+  long item = blockIdx.x;
+  if (item < items) issue(item);
+  while (item < items) {
+    const long unit = item / chunks;
+    const int t0 = (int)(item - unit * chunks) * 64;
+    const int rows = min(64, T - t0);
+    const int c4 = (rows * V) >> 2;
+    const int c = (int)(unit % KC);
+    const float s = scale ? scale[c] : 1.f;
+    const float h = shift ? shift[c] : 0.f;
+    // staged registers -> LDS (deferred BN affine + ReLU applied here)
+    {
+      f32x4* l4 = reinterpret_cast<f32x4*>(ldsP);
+#pragma unroll
+      for (int q = 0; q < NP4; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4) {
+          f32x4 v = pre[q];
+          v.x = affine_act(v.x, s, h, relu);
+          v.y = affine_act(v.y, s, h, relu);
+          v.z = affine_act(v.z, s, h, relu);
+          v.w = affine_act(v.w, s, h, relu);
+          l4[i] = v;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        const int i = lane + q * 64;
+        if (i < V * V) ldsA[i] = prea[q];
+      }
+    }
+    const long next = item + gridDim.x;
+    if (next < items) issue(next);
+    wave_lds_sync();
+    float b[KS];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int u = 2 * q + mk;
+      const float v = ldsA[(u < V ? u : V - 1) * V + mic];
+      b[q] = (u < V && mi < V) ? v : 0.f;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[tile][i] = 0.f;
+      if (tile * 32 < rows) {
+        const int t = tile * 32 + mi;
+        const int tc = t < rows ? t : rows - 1;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const int u = 2 * q + mk;
+          const float v = ldsP[tc * V + (u < V ? u : V - 1)];
+          const float a = (u < V && t < rows) ? v : 0.f;
+          acc[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[q], acc[tile], 0, 0, 0);
+        }
+      }
+    }
+    wave_lds_sync();
+    if (mi < V) {
+#pragma unroll
+      for (int tile = 0; tile < 2; ++tile) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = tile * 32 + mfma_row(r, mk);
+          if (t < rows) ldsP[t * V + mi] = acc[tile][r];
+        }
+      }
+    }
+    wave_lds_sync();
+    {
+      f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(y + ((size_t)unit * T + t0) * V);
+      const f32x4* l4 = reinterpret_cast<const f32x4*>(ldsP);
+#pragma unroll
+      for (int q = 0; q < NP4; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4) d4[i] = l4[i];
+      }
+    }
+    wave_lds_sync();
+    item = next;
+  }
+}
+
+template <int V>
 __global__ __launch_bounds__(64) void k_aggregate_bwd(const float* __restrict__ zp, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int relu,
-                                                      const float* __restrict__ ahat, long ahat_unit_stride,
-                                                      int ahat_mod, const float* __restrict__ dy,
+                                                      const float* __restrict__ ahat, const float* __restrict__ dy,
                                                       float* __restrict__ dzp, float* __restrict__ dahat,
                                                       float* __restrict__ partial, int KC, int T, int vec) {
+  constexpr int KS = (V + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldsZ = lds;
   float* ldsG = lds + 64 * V;
+  float* ldsA = lds + 128 * V;
   const int lane = threadIdx.x;
   const int unit = blockIdx.x;
   const int c = unit % KC;
   const float s = scale ? scale[c] : 1.f;
   const float h = shift ? shift[c] : 0.f;
-  const long aidx = ahat_mod > 0 ? (long)(unit % ahat_mod) : (long)unit;
-  const float* __restrict__ A = ahat + aidx * ahat_unit_stride;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  float sum_h = 0.f, sum_s = 0.f;
-  const int mi = lane & 31;           // MFMA row/col index inside the 32x32 tile (= joint)
-  const int mk = lane >> 5;           // which of the 2 k-slices (= frame parity)
+  const float* __restrict__ A = ahat + (size_t)unit * V * V;
+  const int mi = lane & 31;           // MFMA row (A operand) / column (B operand, C/D) index inside the tile
+  const int mk = lane >> 5;           // which of the 2 k-slices
   const int mic = mi < V ? mi : V - 1;
+  for (int i = lane; i < V * V; i += 64) ldsA[i] = A[i];
+  f32x16 accA;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+  float sum_h = 0.f, sum_s = 0.f;
+  float bt[KS];                       // B operand of dP = dY . Ahat^T : B[k=w][j=u] = Ahat[u][w]
+  bool have_bt = false;
   for (int t0 = 0; t0 < T; t0 += 64) {
     const int rows = min(64, T - t0);
     const int cnt = rows * V;
@@ -126,6 +343,15 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd(const float* __restrict__ 
     load_plane_to_lds<V>(zp + off, ldsZ, cnt, lane, vec);
     load_plane_to_lds<V>(dy + off, ldsG, cnt, lane, vec);
     __syncthreads();
+    if (!have_bt) {
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        const int w = 2 * q + mk;
+        const float v = ldsA[mic * V + (w < V ? w : V - 1)];
+        bt[q] = (w < V && mi < V) ? v : 0.f;
+      }
+      have_bt = true;
+    }
     // dAhat += P^T dY   (A operand: P[t][u] at lane (u, k); B operand: dY[t][w] at lane (w, k))
     for (int j = 0; j < rows; j += 2) {
       const int t = j + mk;
@@ -135,29 +361,39 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd(const float* __restrict__ 
       float b = ldsG[idx];
       a = ok ? a : 0.f;
       b = ok ? b : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accA, 0, 0, 0);
     }
-    __syncthreads();
-    // dP row per lane, then through the ReLU mask and the BN scale, in place over ldsZ
-    if (lane < rows) {
-      float g[V];
+    // dP tiles (i = frame, j = u, k = w), then ReLU mask / BN scale in place over ldsZ
 #pragma unroll
-      for (int w = 0; w < V; ++w) g[w] = ldsG[lane * V + w];
-      // keep the scalar loads of Ahat inside this chunk iteration (no hoisting into 625 live SGPRs)
-      int opaque0 = 0;
-      asm volatile("" : "+s"(opaque0));
-      const float* __restrict__ Aq = A + opaque0;
-#pragma unroll UNR
-      for (int u = 0; u < V; ++u) {
-        float dp = 0.f;
+    for (int tile = 0; tile < 2; ++tile) {
+      if (tile * 32 < rows) {
+        f32x16 acc;
 #pragma unroll
-        for (int w = 0; w < V; ++w) dp = fmaf(g[w], Aq[u * V + w], dp);
-        const float z = ldsZ[lane * V + u];
-        const float pre = fmaf(z, s, h);
-        const float dpre = (!relu || pre > 0.f) ? dp : 0.f;
-        sum_h += dpre;
-        sum_s = fmaf(dpre, z, sum_s);
-        ldsZ[lane * V + u] = dpre * s;
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const int t = tile * 32 + mi;
+        const int tc = t < rows ? t : rows - 1;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const int w = 2 * q + mk;
+          const float v = ldsG[tc * V + (w < V ? w : V - 1)];
+          const float a = (w < V && t < rows) ? v : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt[q], acc, 0, 0, 0);
+        }
+        if (tile == 0) __syncthreads();   // every lane's P reads of the dAhat product are done before ldsZ is rewritten
+        if (mi < V) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int tt = tile * 32 + mfma_row(r, mk);
+            if (tt < rows) {
+              const float z = ldsZ[tt * V + mi];
+              const float pre = fmaf(z, s, h);
+              const float dpre = (!relu || pre > 0.f) ? acc[r] : 0.f;
+              sum_h += dpre;
+              sum_s = fmaf(dpre, z, sum_s);
+              ldsZ[tt * V + mi] = dpre * s;
+            }
+          }
+        }
       }
     }
     __syncthreads();
@@ -177,37 +413,212 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd(const float* __restrict__ 
     partial[(size_t)unit * 2 + 0] = sum_s;
     partial[(size_t)unit * 2 + 1] = sum_h;
   }
-  // D[i=u][j=w]: j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* __restrict__ dA = dahat + (size_t)unit * V * V;
   if (mi < V) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int u = (r & 3) + 8 * (r >> 2) + 4 * mk;
-      if (u < V) dA[u * V + mi] = acc[r];
+      const int u = mfma_row(r, mk);
+      if (u < V) dA[u * V + mi] = accA[r];
     }
   }
 }
 
+// Persistent/pipelined backward for T <= 64 (one 64-frame pass per unit): same products as k_aggregate_bwd,
+// with the next unit's Zp / dY planes and adjacency in flight while the current unit is on the matrix core.
 template <int V>
-int launch_fwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
-               long a_stride, int a_mod, float* y, long units, int KC, int T, hipStream_t st) {
+__global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restrict__ zp,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu,
+                                                           const float* __restrict__ ahat,
+                                                           const float* __restrict__ dy, float* __restrict__ dzp,
+                                                           float* __restrict__ dahat, float* __restrict__ partial,
+                                                           int KC, int T, long units, int ablate) {
+  constexpr int KS = (V + 1) / 2;
+  constexpr int NP4 = (64 * V / 4 + 63) / 64;
+  constexpr int NA = (V * V + 63) / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldsZ = lds;
+  float* ldsG = lds + 64 * V;
+  float* ldsA = lds + 128 * V;
+  const int lane = threadIdx.x;
+  const int mi = lane & 31, mk = lane >> 5;
+  const int mic = mi < V ? mi : V - 1;
+  const int rows = T;                 // T <= 64
+  const int c4 = (rows * V) >> 2;
+  f32x4 prez[NP4], preg[NP4];
+  float prea[NA];
+
+  auto issue = [&](long unit) {
+    const f32x4* __restrict__ z4 = reinterpret_cast<const f32x4*>(zp + (size_t)unit * T * V);
+    const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(dy + (size_t)unit * T * V);
+    const float* __restrict__ A = ahat + (size_t)unit * V * V;
+#pragma unroll
+    for (int q = 0; q < NP4; ++q) {
+      const int i = lane + q * 64;
+      if (i < c4) { prez[q] = z4[i]; preg[q] = g4[i]; }
+    }
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int i = lane + q * 64;
+      if (i < V * V) prea[q] = A[i];
+    }
+  };
+
+  long unit = blockIdx.x;
+  if (unit < units) issue(unit);
+  while (unit < units) {
+    const int c = (int)(unit % KC);
+    const float s = scale ? scale[c] : 1.f;
+    const float h = shift ? shift[c] : 0.f;
+    {
+      f32x4* lz = reinterpret_cast<f32x4*>(ldsZ);
+      f32x4* lg = reinterpret_cast<f32x4*>(ldsG);
+#pragma unroll
+      for (int q = 0; q < NP4; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4) { lz[i] = prez[q]; lg[i] = preg[q]; }
+      }
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        const int i = lane + q * 64;
+        if (i < V * V) ldsA[i] = prea[q];
+      }
+    }
+    const long next = unit + gridDim.x;
+    if (next < units) issue(next);
+    wave_lds_sync();
+    float bt[KS];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int w = 2 * q + mk;
+      const float v = ldsA[mic * V + (w < V ? w : V - 1)];
+      bt[q] = (w < V && mi < V) ? v : 0.f;
+    }
+    f32x16 accA;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+    if (!(ablate & 1))
+    for (int j = 0; j < rows; j += 2) {
+      const int t = j + mk;
+      const bool ok = (mi < V) && (t < rows);
+      const int idx = (t < rows ? t : rows - 1) * V + mic;
+      float a = affine_act(ldsZ[idx], s, h, relu);
+      float b = ldsG[idx];
+      a = ok ? a : 0.f;
+      b = ok ? b : 0.f;
+      accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accA, 0, 0, 0);
+    }
+    {
+      float* __restrict__ dA = dahat + (size_t)unit * V * V;
+      if (mi < V && !(ablate & 4)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int u = mfma_row(r, mk);
+          if (u < V) dA[u * V + mi] = accA[r];
+        }
+      }
+    }
+    float sum_h = 0.f, sum_s = 0.f;
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+      if (tile * 32 < rows && !(ablate & 2)) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const int t = tile * 32 + mi;
+        const int tc = t < rows ? t : rows - 1;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const int w = 2 * q + mk;
+          const float v = ldsG[tc * V + (w < V ? w : V - 1)];
+          const float a = (w < V && t < rows) ? v : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt[q], acc, 0, 0, 0);
+        }
+        wave_lds_sync();
+        if (mi < V) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int tt = tile * 32 + mfma_row(r, mk);
+            if (tt < rows) {
+              const float z = ldsZ[tt * V + mi];
+              const float pre = fmaf(z, s, h);
+              const float dpre = (!relu || pre > 0.f) ? acc[r] : 0.f;
+              sum_h += dpre;
+              sum_s = fmaf(dpre, z, sum_s);
+              ldsZ[tt * V + mi] = dpre * s;
+            }
+          }
+        }
+      }
+    }
+    wave_lds_sync();
+    {
+      f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dzp + (size_t)unit * T * V);
+      const f32x4* l4 = reinterpret_cast<const f32x4*>(ldsZ);
+#pragma unroll
+      for (int q = 0; q < NP4; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4 && !(ablate & 8)) d4[i] = l4[i];
+      }
+    }
+    sum_s = wave_sum(sum_s);
+    sum_h = wave_sum(sum_h);
+    if (lane == 0) {
+      partial[(size_t)unit * 2 + 0] = sum_s;
+      partial[(size_t)unit * 2 + 1] = sum_h;
+    }
+    wave_lds_sync();
+    unit = next;
+  }
+}
+
+int g_pipe_waves = 0;       // tuning knobs (dsgcn_set_tuning)
+int g_pipe_waves_bwd = 0;
+int g_ablate = 0;
+int g_bwd_variant = 0;      // 1 = one-shot kernel (A/B)
+
+template <int V>
+int launch_fwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat, float* y,
+               long units, int KC, int T, int variant, hipStream_t st) {
   const int vec = ((T * V) % 4 == 0) ? 1 : 0;
   dim3 grid((unsigned)units, (unsigned)((T + 63) / 64));
-  const size_t lds = (size_t)64 * V * sizeof(float);
-  hipLaunchKernelGGL((k_aggregate_fwd<V, 5>), grid, dim3(64), lds, st, zp, scale, shift, relu, ahat, a_stride, a_mod,
-                     y, KC, T, vec);
+  if (variant == 1) {
+    const size_t lds = (size_t)64 * V * sizeof(float);
+    hipLaunchKernelGGL((k_aggregate_fwd_valu<V, 5>), grid, dim3(64), lds, st, zp, scale, shift, relu, ahat,
+                       (long)V * V, 0, y, KC, T, vec);
+  } else if (variant == 2 || !vec) {
+    const size_t lds = (size_t)(64 * V + V * V) * sizeof(float);
+    hipLaunchKernelGGL((k_aggregate_fwd<V>), grid, dim3(64), lds, st, zp, scale, shift, relu, ahat, y, KC, T, vec);
+  } else {
+    const size_t lds = (size_t)(64 * V + V * V) * sizeof(float);
+    const int chunks = (T + 63) / 64;
+    const long items = units * chunks;
+    int waves = g_pipe_waves > 0 ? g_pipe_waves : 3072;
+    // equal items per wave where possible
+    const long per = (items + waves - 1) / waves;
+    const long g = (items + per - 1) / per;
+    hipLaunchKernelGGL((k_aggregate_fwd_pipe<V>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu, ahat,
+                       y, KC, T, chunks, items);
+  }
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
 
 template <int V>
-int launch_bwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
-               long a_stride, int a_mod, const float* dy, float* dzp, float* dahat, float* partial, long units,
-               int KC, int T, hipStream_t st) {
+int launch_bwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat, const float* dy,
+               float* dzp, float* dahat, float* partial, long units, int KC, int T, hipStream_t st) {
   const int vec = ((T * V) % 4 == 0) ? 1 : 0;
-  const size_t lds = (size_t)2 * 64 * V * sizeof(float);
-  hipLaunchKernelGGL((k_aggregate_bwd<V, 5>), dim3((unsigned)units), dim3(64), lds, st, zp, scale, shift, relu, ahat,
-                     a_stride, a_mod, dy, dzp, dahat, partial, KC, T, vec);
+  const size_t lds = (size_t)(2 * 64 * V + V * V) * sizeof(float);
+  if (vec && T <= 64 && g_bwd_variant == 0) {
+    int waves = g_pipe_waves_bwd > 0 ? g_pipe_waves_bwd : 2048;
+    const long per = (units + waves - 1) / waves;
+    const long g = (units + per - 1) / per;
+    hipLaunchKernelGGL((k_aggregate_bwd_pipe<V>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu, ahat,
+                       dy, dzp, dahat, partial, KC, T, units, g_ablate);
+  } else {
+    hipLaunchKernelGGL((k_aggregate_bwd<V>), dim3((unsigned)units), dim3(64), lds, st, zp, scale, shift, relu, ahat,
+                       dy, dzp, dahat, partial, KC, T, vec);
+  }
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -216,18 +627,43 @@ int launch_bwd(const float* zp, const float* scale, const float* shift, int relu
 
 extern "C" {
 
-// See include/dsgcn.h for the contract.
-int dsgcn_aggregate_fwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
-                        float* y, int n, int KC, int T, int V, void* stream) {
+static int aggregate_fwd_dispatch(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
+                                  float* y, int n, int KC, int T, int V, int variant, void* stream) {
   if (!zp || !ahat || !y || n <= 0 || KC <= 0 || T <= 0) return DSGCN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long units = (long)n * KC;
   switch (V) {
-    case 25: return launch_fwd<25>(zp, scale, shift, relu, ahat, 25 * 25, 0, y, units, KC, T, st);
-    case 17: return launch_fwd<17>(zp, scale, shift, relu, ahat, 17 * 17, 0, y, units, KC, T, st);
-    case 18: return launch_fwd<18>(zp, scale, shift, relu, ahat, 18 * 18, 0, y, units, KC, T, st);
+    case 25: return launch_fwd<25>(zp, scale, shift, relu, ahat, y, units, KC, T, variant, st);
+    case 17: return launch_fwd<17>(zp, scale, shift, relu, ahat, y, units, KC, T, variant, st);
+    case 18: return launch_fwd<18>(zp, scale, shift, relu, ahat, y, units, KC, T, variant, st);
     default: return DSGCN_EUNSUPPORTED;
   }
+}
+
+// See include/dsgcn.h for the contract.
+int dsgcn_aggregate_fwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
+                        float* y, int n, int KC, int T, int V, void* stream) {
+  return aggregate_fwd_dispatch(zp, scale, shift, relu, ahat, y, n, KC, T, V, 0, stream);
+}
+
+// A/B only (tools/ka_variants.py): variant 1 = scalar-cache/VALU formulation, 2 = one-shot MFMA (no pipelining).
+int dsgcn_aggregate_fwd_variant(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
+                                float* y, int n, int KC, int T, int V, int variant, void* stream) {
+  return aggregate_fwd_dispatch(zp, scale, shift, relu, ahat, y, n, KC, T, V, variant, stream);
+}
+
+int dsgcn_set_tuning(int key, int value) {
+  if (key == 0) { g_pipe_waves = value; return 0; }
+  if (key == 1) { g_pipe_waves_bwd = value; return 0; }
+  if (key == 2) { g_bwd_variant = value; return 0; }
+  if (key == 3) { g_ablate = value; return 0; }
+  return DSGCN_EINVAL;
+}
+
+// A/B only: the scalar-cache/VALU formulation of the same product.
+int dsgcn_aggregate_fwd_valu(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
+                             float* y, int n, int KC, int T, int V, void* stream) {
+  return aggregate_fwd_dispatch(zp, scale, shift, relu, ahat, y, n, KC, T, V, 1, stream);
 }
 
 int dsgcn_aggregate_bwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
@@ -237,9 +673,9 @@ int dsgcn_aggregate_bwd(const float* zp, const float* scale, const float* shift,
   hipStream_t st = (hipStream_t)stream;
   const long units = (long)n * KC;
   switch (V) {
-    case 25: return launch_bwd<25>(zp, scale, shift, relu, ahat, 625, 0, dy, dzp, dahat, partial, units, KC, T, st);
-    case 17: return launch_bwd<17>(zp, scale, shift, relu, ahat, 289, 0, dy, dzp, dahat, partial, units, KC, T, st);
-    case 18: return launch_bwd<18>(zp, scale, shift, relu, ahat, 324, 0, dy, dzp, dahat, partial, units, KC, T, st);
+    case 25: return launch_bwd<25>(zp, scale, shift, relu, ahat, dy, dzp, dahat, partial, units, KC, T, st);
+    case 17: return launch_bwd<17>(zp, scale, shift, relu, ahat, dy, dzp, dahat, partial, units, KC, T, st);
+    case 18: return launch_bwd<18>(zp, scale, shift, relu, ahat, dy, dzp, dahat, partial, units, KC, T, st);
     default: return DSGCN_EUNSUPPORTED;
   }
 }

@@ -42,3 +42,11 @@ __device__ __forceinline__ float affine_act(float x, float s, float h, int relu)
   float v = fmaf(x, s, h);
   return relu ? fmaxf(v, 0.f) : v;
 }
+
+// Single-wave workgroups: LDS traffic of one wave is executed in issue order, so cross-lane exchange through
+// LDS needs no s_barrier — only "all my DS ops are done" and a compiler fence.  Unlike __syncthreads() this does
+// NOT emit s_waitcnt vmcnt(0), so global prefetch loads stay in flight across it.
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}

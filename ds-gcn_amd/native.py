@@ -26,6 +26,9 @@ c_st = ctypes.c_void_p     # hipStream_t
 SIGNATURES = {
     'dsgcn_version': [],
     'dsgcn_aggregate_fwd': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
+    'dsgcn_aggregate_fwd_valu': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
+    'dsgcn_aggregate_fwd_variant': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_st],
+    'dsgcn_set_tuning': [c_int, c_int],
     'dsgcn_aggregate_bwd': [c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
     'dsgcn_dynadj_fwd': [c_f] * 12 + [c_i, c_i, c_f] + [c_int] * 6 + [c_st],
     'dsgcn_dynadj_bwd': [c_f] * 11 + [c_i] * 4 + [c_f] * 10 + [c_int] * 6 + [c_st],

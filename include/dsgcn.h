@@ -35,6 +35,17 @@ int dsgcn_version(void);
 int dsgcn_aggregate_fwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
                         float* y, int n, int KC, int T, int V, void* stream);
 
+/* A/B measurement only: the first (scalar-cache + VALU) formulation of the same product. */
+int dsgcn_aggregate_fwd_valu(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
+                             float* y, int n, int KC, int T, int V, void* stream);
+
+/* A/B measurement only: variant 0 = product path, 1 = scalar-cache/VALU, 2 = one-shot MFMA. */
+int dsgcn_aggregate_fwd_variant(const float* zp, const float* scale, const float* shift, int relu,
+                                const float* ahat, float* y, int n, int KC, int T, int V, int variant, void* stream);
+
+/* Tuning knobs (key 0: persistent waves of K-A forward; 0 = default). */
+int dsgcn_set_tuning(int key, int value);
+
 /* Backward of the above: dzp (n,KC,T,V), dahat (n,KC,V,V) and partial (n*KC,2) =
  * per-unit [sum dP*mask*zp, sum dP*mask] (the d scale / d shift reductions before the sum over n). */
 int dsgcn_aggregate_bwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
