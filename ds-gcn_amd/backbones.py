@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import kernels
 from .builder import BACKBONES
-from .gcn_units import dgphgcn1, unit_gcn
+from .gcn_units import dgphgcn1, unit_gcn, flush_running_stats
 from .graph import Graph
 from .tcn_units import dgmstcn, unit_tcn
 
@@ -152,6 +152,7 @@ class _SkeletonBackbone(nn.Module):
         last = len(blocks) - 1
         for i, blk in enumerate(blocks):
             x, xbar = blk.forward_fused(x, xbar, needs_xbar and i < last)
+        flush_running_stats()
         return x
 
     def init_weights(self):

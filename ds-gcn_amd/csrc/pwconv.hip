@@ -1,0 +1,1460 @@
+// K-C: 1x1 channel mix ("pointwise conv") on the f32 matrix core, with the surrounding train-mode BatchNorm /
+// ReLU / residual work folded into its load prologue and store epilogue.
+// Replaces, per call, the reference's Conv2d(1x1) + BatchNorm2d + ReLU (+ residual add) ATen chains:
+//   pyskl/models/gcns/utils/gcn.py:2165-2169,2209-2215,2236,2363-2365 (pre / post / down / bn of dgphgcn1)
+//   pyskl/models/gcns/utils/tcn.py:379-404,409,422,427 (dgmstcn branch 1x1 convs, global joint, transform, bn)
+//   pyskl/models/gcns/utils/tcn.py:21-28 with kernel_size=1 (block residual, dgstgcn.py:59)
+//
+//   v[n,ci,t,v]  = relu?( x1*s1[ci]+h1[ci] (+ x2*s2[ci]+h2[ci] | + x2) )        "virtual input": deferred BN of the
+//   z[n,co,t',v] = sum_ci W[co,ci] * v[n,ci,t'*stride,v] + b[co]                 producer applied while loading
+//   zaug[n,co,t'] = mean_v z  (= W . mean_v v + b: the dgmstcn "global joint" column, by linearity)
+//   partial[blk,co,0:2] = sum / sum of squares of this block's outputs (incl. zaug)  -> batch statistics
+//
+// Work decomposition: one 256-thread workgroup = (sample n, TR output frames, up to 128 output channels).
+// Per 32-channel input chunk the TR*V (+TR) positions of v are staged in LDS once (prologue applied once per element),
+// W chunk next to it (row stride 33: conflict-free column reads); each wave owns N-tiles {w, w+4} x all M-tiles and
+// issues v_mfma_f32_32x32x2_f32 with A = W[co, k], B = v[k, pos] (both one ds_read_b32 per lane).  Outputs leave the
+// accumulators as 128-B coalesced segments; per-channel sums are reduced in registers -> LDS -> one partial row per
+// block (deterministic two-stage BN statistics, finalised in fp64 by k_bn_finalize).
+// Bound: HBM for Ci,Co <= 64 (16 FLOP/B), f32 MFMA above (32-64 FLOP/B vs ridge ~20).
+#include "common.h"
+
+namespace {
+
+constexpr int KCH = 16;            // input channels per LDS chunk
+constexpr int WSTR = KCH + 1;      // W tile row stride (odd)
+constexpr int NTW = 2;             // N-tiles per wave (NPpad <= 256)
+constexpr int PW_NT = 256;
+constexpr int XCH = KCH / 4;       // channels staged per wave per chunk
+
+struct PwArgs {
+  const float* x1; const float* s1; const float* h1;
+  const float* x2; const float* s2; const float* h2;
+  int relu;
+  const float* w; const float* bias;
+  float* z; float* zaug; float* partial;
+  int n, Ci, Co, T, V, Tout, stride, aug, TR, NPpad, vec, stats, ablate;
+};
+
+__device__ __forceinline__ int mfma_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ float virt1(float a, float b, bool has2, float s1, float h1, float s2, float h2,
+                                       int relu) {
+  float v = fmaf(a, s1, h1);
+  if (has2) v += fmaf(b, s2, h2);
+  return relu ? fmaxf(v, 0.f) : v;
+}
+
+// Pipeline per 16-channel chunk:  regs(chunk c) -> LDS (prologue applied) | barrier | issue global loads of
+// chunk c+1 into registers | MFMA over LDS (loads in flight) | barrier.
+template <int MT>
+__global__ __launch_bounds__(PW_NT) void k_pwconv_fwd(PwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Xs = lds;                               // [KCH][NPpad]
+  float* Ws = lds + KCH * a.NPpad;               // [32*MT][WSTR]
+  float* Ss = lds;                               // epilogue scratch [4 waves][32][2] (aliases Xs after the loop)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int n = blockIdx.y;
+  const int r0 = blockIdx.x * a.TR;
+  const int coBase = blockIdx.z * 32 * MT;
+  const int V = a.V, TR = a.TR, NPpad = a.NPpad, Ci = a.Ci;
+  const int rows_valid = min(TR, a.Tout - r0);
+  const int TRV = TR * V;
+  const int NP = TR * (V + (a.aug ? 1 : 0));
+  const int Nt = NPpad >> 5;
+  const bool has2 = a.x2 != nullptr;
+  const bool wvec = (Ci & 3) == 0;
+
+  f32x16 acc[MT][NTW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
+
+  // ---- prefetch registers ----
+  f32x4 xr[XCH], yr[XCH];           // vec path: one float4 per (channel, lane), lane < TRV/4;
+                                    // scalar path: element q = position lane + 64*q of the channel
+  f32x4 wr[2];
+  const int TRV4 = TRV >> 2;
+  const int valid4 = (rows_valid * V) >> 2;
+  const int wrow = tid >> 1, wk = (tid & 1) * 8;       // W staging: 2 threads per row, 8 k each
+
+  auto issue = [&](int c0) {
+    if (a.vec) {
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const int ci = c0 + wave + 4 * i;
+        if (ci < Ci && lane < valid4) {
+          const size_t g = ((size_t)(n * Ci + ci) * a.T + r0) * V + 4 * lane;
+          xr[i] = *reinterpret_cast<const f32x4*>(a.x1 + g);
+          if (has2) yr[i] = *reinterpret_cast<const f32x4*>(a.x2 + g);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const int ci = c0 + wave + 4 * i;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p = lane + 64 * q;
+          const int rl = (int)(((float)p + 0.5f) / (float)V);
+          if (ci < Ci && p < TRV && rl < rows_valid) {
+            const size_t g = ((size_t)(n * Ci + ci) * a.T + (size_t)(r0 + rl) * a.stride) * V + (p - rl * V);
+            xr[i][q] = a.x1[g];
+            if (has2) yr[i][q] = a.x2[g];
+          }
+        }
+      }
+    }
+    if (wrow < 32 * MT) {
+      const int co = coBase + wrow;
+      if (wvec) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int k = c0 + wk + 4 * q;
+          wr[q] = (co < a.Co && k < Ci) ? *reinterpret_cast<const f32x4*>(a.w + (size_t)co * Ci + k)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k = c0 + wk + 4 * q + e;
+            wr[q][e] = (co < a.Co && k < Ci) ? a.w[(size_t)co * Ci + k] : 0.f;
+          }
+      }
+    }
+  };
+
+  auto commit = [&](int c0) {       // registers -> LDS with the prologue applied; pads written as zeros
+    if (a.vec) {
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const int cl = wave + 4 * i, ci = c0 + cl;
+        if (lane < (NPpad >> 2)) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (ci < Ci && lane < valid4) {
+            const float s1 = a.s1 ? a.s1[ci] : 1.f, h1 = a.s1 ? a.h1[ci] : 0.f;
+            const float s2 = a.s2 ? a.s2[ci] : 1.f, h2 = a.s2 ? a.h2[ci] : 0.f;
+            const f32x4 x = xr[i];
+            const f32x4 y = has2 ? yr[i] : v;
+            v.x = virt1(x.x, y.x, has2, s1, h1, s2, h2, a.relu);
+            v.y = virt1(x.y, y.y, has2, s1, h1, s2, h2, a.relu);
+            v.z = virt1(x.z, y.z, has2, s1, h1, s2, h2, a.relu);
+            v.w = virt1(x.w, y.w, has2, s1, h1, s2, h2, a.relu);
+          }
+          *reinterpret_cast<f32x4*>(Xs + cl * NPpad + 4 * lane) = v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const int cl = wave + 4 * i, ci = c0 + cl;
+        const float s1 = (a.s1 && ci < Ci) ? a.s1[ci] : 1.f, h1 = (a.s1 && ci < Ci) ? a.h1[ci] : 0.f;
+        const float s2 = (a.s2 && ci < Ci) ? a.s2[ci] : 1.f, h2 = (a.s2 && ci < Ci) ? a.h2[ci] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p = lane + 64 * q;
+          if (p < NPpad) {
+            const int rl = (int)(((float)p + 0.5f) / (float)V);
+            float v = 0.f;
+            if (ci < Ci && p < TRV && rl < rows_valid)
+              v = virt1(xr[i][q], has2 ? yr[i][q] : 0.f, has2, s1, h1, s2, h2, a.relu);
+            Xs[cl * NPpad + p] = v;
+          }
+        }
+      }
+    }
+    if (wrow < 32 * MT) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ws[wrow * WSTR + wk + 4 * q + e] = wr[q][e];
+    }
+  };
+
+  if (!(a.ablate & 2)) issue(0);
+  for (int c0 = 0; c0 < Ci; c0 += KCH) {
+    const int kc = min(KCH, Ci - c0);
+    const int kmax = (a.ablate & 1) ? 0 : ((kc + 1) & ~1);
+    if (!(a.ablate & 16)) commit(c0);
+    __syncthreads();
+    if (a.aug) {
+      const float invV = 1.f / (float)V;
+      for (int idx = tid; idx < KCH * TR; idx += PW_NT) {
+        const int cl = idx / TR, rl = idx - cl * TR;
+        float sm = 0.f;
+        if (rl < rows_valid) {
+          const float* row = Xs + cl * NPpad + rl * V;
+          for (int vv = 0; vv < V; ++vv) sm += row[vv];
+          sm *= invV;
+        }
+        Xs[cl * NPpad + TRV + rl] = sm;
+      }
+      __syncthreads();
+    }
+    if (c0 + KCH < Ci && !(a.ablate & 2)) issue(c0 + KCH);
+#pragma unroll 4
+    for (int kk = 0; kk < kmax; kk += 2) {
+      float av[MT], bv[NTW];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) av[m] = Ws[(32 * m + l31) * WSTR + kk + half];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int nt = wave + 4 * j;
+        bv[j] = (nt < Nt) ? Xs[(kk + half) * NPpad + 32 * nt + l31] : 0.f;
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          if (wave + 4 * j < Nt) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[j], acc[m][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, stores, statistics (one M-tile at a time to keep registers low) ----
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int nt = wave + 4 * j;
+      if (nt < Nt) {
+        const int pos = 32 * nt + l31;
+        bool ok = false, is_aug = false;
+        int rl = 0;
+        if (pos < TRV) { rl = (int)(((float)pos + 0.5f) / (float)V); ok = rl < rows_valid; }
+        else if (pos < NP) { rl = pos - TRV; ok = rl < rows_valid; is_aug = true; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = coBase + 32 * m + mfma_row32(r, half);
+          if (co < a.Co && ok) {
+            const float val = acc[m][j][r] + (a.bias ? a.bias[co] : 0.f);
+            if (a.ablate & 4) {}
+            else if (is_aug) a.zaug[(size_t)(n * a.Co + co) * a.Tout + r0 + rl] = val;
+            else a.z[((size_t)(n * a.Co + co) * a.Tout + r0) * V + pos] = val;
+            ssum[r] += val;
+            ssq[r] = fmaf(val, val, ssq[r]);
+          }
+        }
+      }
+    }
+    if (a.stats && !(a.ablate & 8)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv = ssum[r], qv = ssq[r];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+          sv += __shfl_xor(sv, off, 64);
+          qv += __shfl_xor(qv, off, 64);
+        }
+        if (l31 == 0) {
+          const int col = mfma_row32(r, half);
+          Ss[(wave * 32 + col) * 2 + 0] = sv;
+          Ss[(wave * 32 + col) * 2 + 1] = qv;
+        }
+      }
+      __syncthreads();
+      if (tid < 32) {
+        const int co = coBase + 32 * m + tid;
+        if (co < a.Co) {
+          float sv = 0.f, qv = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { sv += Ss[(w * 32 + tid) * 2]; qv += Ss[(w * 32 + tid) * 2 + 1]; }
+          a.partial[(blk * a.Co + co) * 2 + 0] = sv;
+          a.partial[(blk * a.Co + co) * 2 + 1] = qv;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Wave-independent formulation (product path).  Each wave owns NW consecutive 32-position tiles of one sample and ALL
+// output channels of its block (MT 32-channel tiles): the B operand (virtual input) comes straight from HBM in MFMA
+// fragment shape — lane (pos, k-half) loads x[ci = k+half][pos]: two 128-B coalesced segments per instruction — with
+// UNR k-steps in flight per wave, the deferred BN/ReLU/residual applied in registers; only the weights go through LDS
+// (64-channel K chunks, shared by the 4 waves).  No barrier inside a K chunk, every input element is read once.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int KW = 64;             // K (input-channel) chunk of the LDS weight tile
+constexpr int KWS = KW + 1;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+  // raw buffer, stride 0: reads past num_records return 0 (used instead of per-lane predication)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+constexpr int OOB_OFF = 0x7ffffff0;
+
+// MODE 0: v = x1 ; 1: v = relu?(x1*s1+h1) ; 2: v = relu?(x1*s1+h1 + x2*s2+h2)
+// K is walked in groups of UNR k-steps (2 channels each) with two register sets in ping-pong: the loads of group
+// g+1 are issued before the MFMAs of group g.  No per-step branches (they made hipcc sink every load next to its
+// use: one full HBM round trip per k-step): the chunk is padded to a multiple of 4*UNR channels — padded channels
+// have zero weights in Ws and read either valid memory or past the buffer (raw-buffer OOB -> 0).
+constexpr int F2_UNR = 4;
+
+template <int NW, int MODE>
+__device__ __forceinline__ void f2_load(float (&xb)[F2_UNR][NW], float (&yb)[F2_UNR][NW], __amdgpu_buffer_rsrc_t r1,
+                                        __amdgpu_buffer_rsrc_t r2, const int (&voff)[NW], int cbase, int cstride4) {
+#pragma unroll
+  for (int u = 0; u < F2_UNR; ++u) {
+    const int soff = (cbase + 2 * u) * cstride4;              // wave-uniform: SGPR operand of the buffer load
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      xb[u][j] = buf_load(r1, voff[j], soff);
+      if (MODE == 2) yb[u][j] = buf_load(r2, voff[j], soff);
+    }
+  }
+}
+
+template <int MT, int NW, int MODE>
+__device__ __forceinline__ void f2_compute(const PwArgs& a, f32x16 (&acc)[MT][NW], const float* Ws, const f32x4* Ps4,
+                                           const float (&xb)[F2_UNR][NW], const float (&yb)[F2_UNR][NW], int c0,
+                                           int kbase, int kc, int half, int l31) {
+#pragma unroll
+  for (int u = 0; u < F2_UNR; ++u) {
+    const int kl = kbase + 2 * u + half;
+    const bool cok = kl < kc;
+    float av[MT], bv[NW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) av[m] = Ws[(32 * m + l31) * KWS + kl];
+    f32x4 p = {1.f, 0.f, 1.f, 0.f};
+    if (MODE != 0) p = Ps4[cok ? c0 + kl : 0];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      float v = xb[u][j];
+      if (MODE != 0) {
+        v = fmaf(v, p.x, p.y);
+        if (MODE == 2) v += fmaf(yb[u][j], p.z, p.w);
+        if (a.relu) v = fmaxf(v, 0.f);
+      }
+      bv[j] = cok ? v : 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[j], acc[m][j], 0, 0, 0);
+  }
+}
+
+template <int MT, int NW, int MODE>
+__device__ __forceinline__ void fwd2_chunk(const PwArgs& a, f32x16 (&acc)[MT][NW], const float* Ws, const f32x4* Ps4,
+                                           __amdgpu_buffer_rsrc_t r1, __amdgpu_buffer_rsrc_t r2, const int (&voff)[NW],
+                                           int c0, int kc, int cstride4, int half, int l31) {
+  constexpr int G = 2 * F2_UNR;                               // channels per group
+  const int kpad = (kc + 2 * G - 1) / (2 * G) * (2 * G);     // multiple of two groups, <= KW
+  float xa[F2_UNR][NW], ya[F2_UNR][NW], xb[F2_UNR][NW], yb[F2_UNR][NW];
+  f2_load<NW, MODE>(xa, ya, r1, r2, voff, c0, cstride4);
+  for (int k0 = 0; k0 < kpad; k0 += 2 * G) {
+    f2_load<NW, MODE>(xb, yb, r1, r2, voff, c0 + k0 + G, cstride4);
+    f2_compute<MT, NW, MODE>(a, acc, Ws, Ps4, xa, ya, c0, k0, kc, half, l31);
+    f2_load<NW, MODE>(xa, ya, r1, r2, voff, c0 + k0 + 2 * G, cstride4);
+    f2_compute<MT, NW, MODE>(a, acc, Ws, Ps4, xb, yb, c0, k0 + G, kc, half, l31);
+  }
+}
+
+template <int MT, int NW>
+__global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ws = lds;                               // [32*MT][KWS]
+  f32x4* Ps4 = reinterpret_cast<f32x4*>(lds + ((32 * MT * KWS + 3) & ~3));   // [Ci] : (s1,h1,s2,h2)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int n = blockIdx.y;
+  const int coBase = blockIdx.z * 32 * MT;
+  const int V = a.V, Ci = a.Ci, Co = a.Co;
+  const int L = a.Tout * V;                      // output positions per (sample, channel)
+  const int tile0 = (blockIdx.x * 4 + wave) * NW;
+  const bool has2 = a.x2 != nullptr;
+  const bool aff1 = a.s1 != nullptr, aff2 = a.s2 != nullptr;
+  const bool wvec = (Ci & 3) == 0;
+  const int cstride = a.T * V;
+
+  // per-lane byte offsets of the NW position tiles inside channel (n, half); out-of-range lanes read as 0 (OOB)
+  int voff[NW];
+  bool pok[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int pos = (tile0 + j) * 32 + l31;
+    pok[j] = pos < L;
+    const int pc = pok[j] ? pos : 0;
+    const int row = pc / V;
+    const int goff = (row * a.stride) * V + (pc - row * V);
+    voff[j] = pok[j] ? (int)(((size_t)n * Ci + half) * cstride + goff) * 4 : OOB_OFF;
+  }
+  for (int i = tid; i < Ci; i += PW_NT) {
+    f32x4 p;
+    p.x = aff1 ? a.s1[i] : 1.f;
+    p.y = aff1 ? a.h1[i] : 0.f;
+    p.z = aff2 ? a.s2[i] : 1.f;
+    p.w = aff2 ? a.h2[i] : 0.f;
+    Ps4[i] = p;
+  }
+  const size_t xbytes = (size_t)a.n * Ci * cstride * 4;
+  const __amdgpu_buffer_rsrc_t r1 = make_rsrc(a.x1, xbytes);
+  const __amdgpu_buffer_rsrc_t r2 = make_rsrc(has2 ? a.x2 : a.x1, xbytes);
+
+  f32x16 acc[MT][NW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
+
+  const int mode = has2 ? 2 : ((aff1 || a.relu) ? 1 : 0);
+  for (int c0 = 0; c0 < Ci; c0 += KW) {
+    const int kc = min(KW, Ci - c0);
+    __syncthreads();                             // previous chunk's W fully consumed (and Ps written, first time)
+    {
+      // all 2*MT float4 loads of this thread are issued before the first LDS write (a plain load/store loop gets one
+      // HBM round trip per iteration from hipcc: measured 16 us per chunk)
+      f32x4 wr[2 * MT];
+#pragma unroll
+      for (int q = 0; q < 2 * MT; ++q) {
+        const int f = tid + PW_NT * q;
+        const int rowi = f >> 4, kq = (f & 15) * 4;
+        const int co = coBase + rowi, ci = c0 + kq;
+        if (wvec) {
+          wr[q] = (co < Co && ci < Ci) ? *reinterpret_cast<const f32x4*>(a.w + (size_t)co * Ci + ci)
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wr[q][e] = (co < Co && ci + e < Ci) ? a.w[(size_t)co * Ci + ci + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2 * MT; ++q) {
+        const int f = tid + PW_NT * q;
+        const int rowi = f >> 4, kq = (f & 15) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ws[rowi * KWS + kq + e] = wr[q][e];
+      }
+    }
+    __syncthreads();
+    if (mode == 0) fwd2_chunk<MT, NW, 0>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
+    else if (mode == 1) fwd2_chunk<MT, NW, 1>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
+    else fwd2_chunk<MT, NW, 2>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
+  }
+  __syncthreads();
+  // ---- epilogue: bias, coalesced stores; per-channel sum / sum of squares via an LDS transpose of each tile
+  //      (a shuffle tree costs 160 ds_bpermute per tile and made the LDS pipe the bottleneck: measured) ----
+  float* Tw = lds + wave * (32 * 36);            // per-wave 32x32 tile, row stride 36 (conflict-free b128 row reads)
+  float* Ss = lds + 4 * 32 * 36;                 // [4 waves][32][2]
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float sv = 0.f, qv = 0.f;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int pos = (tile0 + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mfma_row32(r, half);
+        const int co = coBase + 32 * m + row;
+        float val = 0.f;
+        if (co < Co && pok[j]) {
+          val = acc[m][j][r] + (a.bias ? a.bias[co] : 0.f);
+          if (!(a.ablate & 4)) a.z[(size_t)(n * Co + co) * L + pos] = val;
+        }
+        if (a.stats && !(a.ablate & 8)) Tw[row * 36 + l31] = val;
+      }
+      if (a.stats && !(a.ablate & 8)) {
+        wave_lds_sync();
+        const f32x4* rowp = reinterpret_cast<const f32x4*>(Tw + l31 * 36 + half * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = rowp[q];
+          sv += (v.x + v.y) + (v.z + v.w);
+          qv = fmaf(v.x, v.x, qv); qv = fmaf(v.y, v.y, qv); qv = fmaf(v.z, v.z, qv); qv = fmaf(v.w, v.w, qv);
+        }
+        wave_lds_sync();
+      }
+    }
+    if (a.stats) {
+      sv += __shfl_xor(sv, 32, 64);
+      qv += __shfl_xor(qv, 32, 64);
+      if (half == 0) {
+        Ss[(wave * 32 + l31) * 2 + 0] = sv;
+        Ss[(wave * 32 + l31) * 2 + 1] = qv;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        const int co = coBase + 32 * m + tid;
+        if (co < Co) {
+          float s4 = 0.f, q4 = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { s4 += Ss[(w * 32 + tid) * 2]; q4 += Ss[(w * 32 + tid) * 2 + 1]; }
+          a.partial[(blk * Co + co) * 2 + 0] = s4;
+          a.partial[(blk * Co + co) * 2 + 1] = q4;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// zaug[n,c,t] = mean_v z[n,c,t,:] plus per-block partial sums of zaug / zaug^2 (the global-joint column's share of the
+// batch statistics).  One thread per (n,c,t) row group; partial rows appended after the conv's own partial rows.
+__global__ __launch_bounds__(256) void k_rowmean_stats(const float* __restrict__ z, float* __restrict__ zaug,
+                                                       float* __restrict__ partial, int n, int C, int T, int V,
+                                                       int tslices) {
+  // grid = (tslices, n); block covers all C channels (thread = channel, loops if C > 256) for T/tslices frames
+  const int nn = blockIdx.y, sl = blockIdx.x;
+  const int t0 = sl * ((T + tslices - 1) / tslices);
+  const int t1 = min(T, t0 + (T + tslices - 1) / tslices);
+  const float invV = 1.f / (float)V;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sv = 0.f, qv = 0.f;
+    for (int t = t0; t < t1; ++t) {
+      const float* row = z + ((size_t)(nn * C + c) * T + t) * V;
+      float m = 0.f;
+      for (int v = 0; v < V; ++v) m += row[v];
+      m *= invV;
+      zaug[(size_t)(nn * C + c) * T + t] = m;
+      sv += m;
+      qv = fmaf(m, m, qv);
+    }
+    if (partial) {
+      const size_t blk = (size_t)nn * tslices + sl;
+      partial[(blk * C + c) * 2 + 0] = sv;
+      partial[(blk * C + c) * 2 + 1] = qv;
+    }
+  }
+}
+
+// Batch statistics -> BN affine.  partial [nblk][C][2] (fp32 block sums) reduced in fp64: one 256-thread workgroup
+// per 32 channels (8 row-slices x 32 channels, coalesced 256-B rows), then a cross-slice LDS reduction.
+//   mean, var (biased) saved for backward; scale = gamma*rsqrt(var+eps); shift = beta - mean*scale.
+// gamma/beta NULL -> identity affine parameters; channels >= c_affine get the identity affine (1, 0).
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int nblk, int C, double count,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, float* __restrict__ mean_out,
+                                                     float* __restrict__ var_out, float* __restrict__ scale_out,
+                                                     float* __restrict__ shift_out, int c_affine) {
+  __shared__ double red[8][32][2];
+  const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    const float2* p2 = reinterpret_cast<const float2*>(partial);
+    for (int b = slice; b < nblk; b += 8) {
+      const float2 v = p2[(size_t)b * C + c];
+      s += (double)v.x;
+      q += (double)v.y;
+    }
+  }
+  red[slice][cl][0] = s;
+  red[slice][cl][1] = q;
+  __syncthreads();
+  if (slice == 0 && c < C) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { s += red[i][cl][0]; q += red[i][cl][1]; }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_out[c] = (float)mean;
+    var_out[c] = (float)var;
+    if (c < c_affine) {
+      const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+      const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float sc = g * rstd;
+      scale_out[c] = sc;
+      shift_out[c] = bt - (float)mean * sc;
+    } else {
+      scale_out[c] = 1.f;
+      shift_out[c] = 0.f;
+    }
+  }
+}
+
+// Column sums of a row-major (R, C) fp32 matrix -> out (C), accumulated in fp64 (partial-buffer reductions).
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ src, int R, int C, float* __restrict__ out) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0;
+  if (c < C)
+    for (int r = slice; r < R; r += 8) s += (double)src[(size_t)r * C + c];
+  red[slice][cl] = s;
+  __syncthreads();
+  if (slice == 0 && c < C) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += red[i][cl];
+    out[c] = (float)s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward.
+//   dz_eff[co,pos] = g_z + A0[co] + B0[co]*z                     (the BN-statistics terms: d mean / d var of this conv's
+//                    (+ (g_zaug[row] + A0 + B0*zaug[row]) / V     own output, folded into the load prologue)
+//   dgrad:  dv[ci,pos] = sum_co W[co,ci] dz_eff[co,pos];  through the ReLU mask / affine of the virtual input:
+//           d_x1 = dv*m*s1, d_x2 = dv*m*s2, partial sums of dv*m*x1, dv*m, dv*m*x2 (-> d s1, d h1=d h2, d s2)
+//   wgrad:  dW[co,ci] = sum_pos dz_eff[co,pos] v[ci,pos];  db[co] = sum_pos dz_eff[co,pos]
+// ------------------------------------------------------------------------------------------------------------
+
+struct PwBwdArgs {
+  // forward operands
+  const float* x1; const float* s1; const float* h1;
+  const float* x2; const float* s2; const float* h2;
+  int relu;
+  const float* w;
+  // saved output + incoming gradients
+  const float* z; const float* zaug;
+  const float* gz; const float* gzaug;
+  const float* A0; const float* B0;        // per Co, may be NULL (no batch-stat terms)
+  // outputs
+  float* dx1; float* dx2; float* ipart;    // ipart [nblk][Ci][3]
+  float* dwp; float* dbp;                  // [ksplit][Co][Ci], [ksplit][Co]
+  int n, Ci, Co, T, V, Tout, stride, aug, TR, NPpad, vec;
+  int chunks_per_split, total_chunks, nb_per_sample;
+};
+
+__device__ __forceinline__ float dz_eff_at(const PwBwdArgs& a, size_t gi, size_t gaug, int co, float invV) {
+  float d = a.gz ? a.gz[gi] : 0.f;
+  if (a.A0) d += fmaf(a.B0[co], a.z[gi], a.A0[co]);
+  if (a.aug) {
+    float e = a.gzaug ? a.gzaug[gaug] : 0.f;
+    if (a.A0) e += fmaf(a.B0[co], a.zaug[gaug], a.A0[co]);
+    d = fmaf(e, invV, d);
+  }
+  return d;
+}
+
+// dgrad: M = input channels (tiles of 32, MT per block), N = positions, K = output channels (chunks of KCH).
+// Same register-prefetch pipeline as the forward: the "input" tile is dz_eff, the weight tile is W^T.
+template <int MT>
+__global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad(PwBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int NPpad = a.NPpad;
+  constexpr int WS2 = 32 * MT + 1;
+  float* Ds = lds;                               // [KCH][NPpad]   dz_eff chunk
+  float* Ws = lds + KCH * NPpad;                 // [KCH][WS2]     W[co_chunk][ci_tile]
+  float* Ss = lds;                               // epilogue scratch [4][32][3]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int n = blockIdx.y;
+  const int r0 = blockIdx.x * a.TR;
+  const int ciBase = blockIdx.z * 32 * MT;
+  const int V = a.V, TR = a.TR, Co = a.Co, Ci = a.Ci;
+  const int rows_valid = min(TR, a.Tout - r0);
+  const int TRV = TR * V;
+  const int Nt = NPpad >> 5;
+  const float invV = 1.f / (float)V;
+  const bool wvec = (Ci & 3) == 0;
+  const bool has_g = a.gz != nullptr, has_c = a.A0 != nullptr;
+
+  f32x16 acc[MT][NTW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
+
+  f32x4 gr[XCH], zr[XCH];
+  f32x4 wr[2];
+  const int valid4 = (rows_valid * V) >> 2;
+  const int wrow = tid >> 4, wseg = (tid & 15) * 8;     // W^T staging: 16 threads per co row, 8 ci each
+
+  auto issue = [&](int c0) {
+    if (a.vec) {
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const int co = c0 + wave + 4 * i;
+        if (co < Co && lane < valid4) {
+          const size_t g = ((size_t)(n * Co + co) * a.Tout + r0) * V + 4 * lane;
+          if (has_g) gr[i] = *reinterpret_cast<const f32x4*>(a.gz + g);
+          if (has_c) zr[i] = *reinterpret_cast<const f32x4*>(a.z + g);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const int co = c0 + wave + 4 * i;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p = lane + 64 * q;
+          if (co < Co && p < rows_valid * V) {
+            const size_t g = ((size_t)(n * Co + co) * a.Tout + r0) * V + p;
+            if (has_g) gr[i][q] = a.gz[g];
+            if (has_c) zr[i][q] = a.z[g];
+          }
+        }
+      }
+    }
+    {
+      const int co = c0 + wrow;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int cil = wseg + 4 * q;
+        const int ci = ciBase + cil;
+        if (cil < 32 * MT) {
+          if (wvec) {
+            wr[q] = (co < Co && ci < Ci) ? *reinterpret_cast<const f32x4*>(a.w + (size_t)co * Ci + ci)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wr[q][e] = (co < Co && ci + e < Ci) ? a.w[(size_t)co * Ci + ci + e] : 0.f;
+          }
+        }
+      }
+    }
+  };
+
+  auto dz_of = [&](float g, float zv, int co, int p, float A0c, float B0c) -> float {
+    float d = has_g ? g : 0.f;
+    if (has_c) d += fmaf(B0c, zv, A0c);
+    if (a.aug) {
+      const int rl = (int)(((float)p + 0.5f) * invV);
+      const size_t ga = (size_t)(n * Co + co) * a.Tout + r0 + rl;
+      float e = a.gzaug ? a.gzaug[ga] : 0.f;
+      if (has_c) e += fmaf(B0c, a.zaug[ga], A0c);
+      d = fmaf(e, invV, d);
+    }
+    return d;
+  };
+
+  auto commit = [&](int c0) {
+    if (a.vec) {
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const int cl = wave + 4 * i, co = c0 + cl;
+        if (lane < (NPpad >> 2)) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (co < Co && lane < valid4) {
+            const float A0c = has_c ? a.A0[co] : 0.f, B0c = has_c ? a.B0[co] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = dz_of(gr[i][e], zr[i][e], co, 4 * lane + e, A0c, B0c);
+          }
+          *reinterpret_cast<f32x4*>(Ds + cl * NPpad + 4 * lane) = v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const int cl = wave + 4 * i, co = c0 + cl;
+        const float A0c = (has_c && co < Co) ? a.A0[co] : 0.f, B0c = (has_c && co < Co) ? a.B0[co] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p = lane + 64 * q;
+          if (p < NPpad) {
+            float v = 0.f;
+            if (co < Co && p < rows_valid * V) v = dz_of(gr[i][q], zr[i][q], co, p, A0c, B0c);
+            Ds[cl * NPpad + p] = v;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int cil = wseg + 4 * q;
+      if (cil < 32 * MT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ws[wrow * WS2 + cil + e] = wr[q][e];
+      }
+    }
+  };
+
+  issue(0);
+  for (int c0 = 0; c0 < Co; c0 += KCH) {
+    const int kc = min(KCH, Co - c0);
+    const int kmax = (kc + 1) & ~1;
+    commit(c0);
+    __syncthreads();
+    if (c0 + KCH < Co) issue(c0 + KCH);
+#pragma unroll 4
+    for (int kk = 0; kk < kmax; kk += 2) {
+      float av[MT], bv[NTW];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) av[m] = Ws[(kk + half) * WS2 + 32 * m + l31];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int nt = wave + 4 * j;
+        bv[j] = (nt < Nt) ? Ds[(kk + half) * NPpad + 32 * nt + l31] : 0.f;
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          if (wave + 4 * j < Nt) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[j], acc[m][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float p0[16], p1[16], p2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { p0[r] = 0.f; p1[r] = 0.f; p2[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int nt = wave + 4 * j;
+      const int pos = 32 * nt + l31;
+      const int rl = (int)(((float)pos + 0.5f) * invV);
+      if (nt < Nt && pos < TRV && rl < rows_valid) {
+        const int vv = pos - rl * V;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = ciBase + 32 * m + mfma_row32(r, half);
+          if (ci < Ci) {
+            const size_t g = ((size_t)(n * Ci + ci) * a.T + (size_t)(r0 + rl) * a.stride) * V + vv;
+            const float xa = a.x1[g];
+            const float sa = a.s1 ? a.s1[ci] : 1.f;
+            float pre = a.s1 ? fmaf(xa, sa, a.h1[ci]) : xa;
+            float xb = 0.f, sb = 1.f;
+            if (a.x2) {
+              xb = a.x2[g];
+              if (a.s2) { sb = a.s2[ci]; pre += fmaf(xb, sb, a.h2[ci]); } else pre += xb;
+            }
+            const float dv = (!a.relu || pre > 0.f) ? acc[m][j][r] : 0.f;
+            a.dx1[g] = dv * sa;
+            if (a.dx2) a.dx2[g] = dv * sb;
+            p0[r] = fmaf(dv, xa, p0[r]);
+            p1[r] += dv;
+            p2[r] = fmaf(dv, xb, p2[r]);
+          }
+        }
+      }
+    }
+    if (a.ipart) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float u0 = p0[r], u1 = p1[r], u2 = p2[r];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+          u0 += __shfl_xor(u0, off, 64);
+          u1 += __shfl_xor(u1, off, 64);
+          u2 += __shfl_xor(u2, off, 64);
+        }
+        if (l31 == 0) {
+          float* q = Ss + (wave * 32 + mfma_row32(r, half)) * 3;
+          q[0] = u0; q[1] = u1; q[2] = u2;
+        }
+      }
+      __syncthreads();
+      if (tid < 32) {
+        const int ci = ciBase + 32 * m + tid;
+        if (ci < Ci) {
+          float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const float* q = Ss + (w * 32 + tid) * 3;
+            u0 += q[0]; u1 += q[1]; u2 += q[2];
+          }
+          float* o = a.ipart + (blk * Ci + ci) * 3;
+          o[0] = u0; o[1] = u1; o[2] = u2;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Wave-independent dgrad (product path): same structure as k_pwconv_fwd2 with B = dz_eff straight from HBM
+// (gz, z [, gzaug, zaug] via raw buffer loads, coefficients A0/B0 from LDS) and A = W^T from LDS.
+template <int NW, bool AUG>
+__device__ __forceinline__ void d2_load(float (&g)[F2_UNR][NW], float (&zz)[F2_UNR][NW], float (&ga)[F2_UNR][NW],
+                                        float (&za)[F2_UNR][NW], __amdgpu_buffer_rsrc_t rg, __amdgpu_buffer_rsrc_t rz,
+                                        __amdgpu_buffer_rsrc_t rga, __amdgpu_buffer_rsrc_t rza, const int (&voff)[NW],
+                                        const int (&voffa)[NW], int cbase, int cstride4, int astride4, bool has_g,
+                                        bool has_c) {
+#pragma unroll
+  for (int u = 0; u < F2_UNR; ++u) {
+    const int soff = (cbase + 2 * u) * cstride4;
+    const int soffa = (cbase + 2 * u) * astride4;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      g[u][j] = has_g ? buf_load(rg, voff[j], soff) : 0.f;
+      zz[u][j] = has_c ? buf_load(rz, voff[j], soff) : 0.f;
+      if (AUG) {
+        ga[u][j] = buf_load(rga, voffa[j], soffa);
+        za[u][j] = has_c ? buf_load(rza, voffa[j], soffa) : 0.f;
+      }
+    }
+  }
+}
+
+template <int MT, int NW, bool AUG>
+__device__ __forceinline__ void d2_compute(f32x16 (&acc)[MT][NW], const float* Ws, const float2* Cs,
+                                           const float (&g)[F2_UNR][NW], const float (&zz)[F2_UNR][NW],
+                                           const float (&ga)[F2_UNR][NW], const float (&za)[F2_UNR][NW], int kbase,
+                                           int kc, int c0, float invV, int half, int l31) {
+  constexpr int WS2 = 32 * MT + 1;
+#pragma unroll
+  for (int u = 0; u < F2_UNR; ++u) {
+    const int kl = kbase + 2 * u + half;
+    const bool cok = kl < kc;
+    float av[MT], bv[NW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) av[m] = Ws[kl * WS2 + 32 * m + l31];
+    const float2 cf = Cs[cok ? c0 + kl : 0];                  // (A0, B0)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      float d = g[u][j] + fmaf(cf.y, zz[u][j], cf.x);
+      if (AUG) d = fmaf(ga[u][j] + fmaf(cf.y, za[u][j], cf.x), invV, d);
+      bv[j] = cok ? d : 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[j], acc[m][j], 0, 0, 0);
+  }
+}
+
+template <int MT, int NW, bool AUG>
+__global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad2(PwBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WS2 = 32 * MT + 1;
+  float* Ws = lds;                               // [KW][WS2]  W[co chunk][ci tile]
+  float2* Cs = reinterpret_cast<float2*>(lds + ((KW * WS2 + 3) & ~3));     // [Co] (A0, B0)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int n = blockIdx.y;
+  const int ciBase = blockIdx.z * 32 * MT;
+  const int V = a.V, Ci = a.Ci, Co = a.Co;
+  const int L = a.Tout * V;
+  const int tile0 = (blockIdx.x * 4 + wave) * NW;
+  const bool has_g = a.gz != nullptr, has_c = a.A0 != nullptr;
+  const bool wvec = (Ci & 3) == 0;
+  const float invV = 1.f / (float)V;
+
+  int voff[NW], voffa[NW], goff[NW];
+  bool pok[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int pos = (tile0 + j) * 32 + l31;
+    pok[j] = pos < L;
+    const int pc = pok[j] ? pos : 0;
+    const int row = pc / V;
+    goff[j] = (row * a.stride) * V + (pc - row * V);
+    voff[j] = pok[j] ? (int)(((size_t)n * Co + half) * L + pc) * 4 : OOB_OFF;
+    voffa[j] = pok[j] ? (int)(((size_t)n * Co + half) * a.Tout + row) * 4 : OOB_OFF;
+  }
+  for (int i = tid; i < Co; i += PW_NT) Cs[i] = has_c ? float2{a.A0[i], a.B0[i]} : float2{0.f, 0.f};
+  const size_t zbytes = (size_t)a.n * Co * L * 4, abytes = (size_t)a.n * Co * a.Tout * 4;
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(has_g ? a.gz : a.x1, has_g ? zbytes : 0);
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(has_c ? a.z : a.x1, has_c ? zbytes : 0);
+  const __amdgpu_buffer_rsrc_t rga = make_rsrc((AUG && a.gzaug) ? a.gzaug : a.x1, (AUG && a.gzaug) ? abytes : 0);
+  const __amdgpu_buffer_rsrc_t rza = make_rsrc((AUG && has_c) ? a.zaug : a.x1, (AUG && has_c) ? abytes : 0);
+
+  f32x16 acc[MT][NW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
+
+  constexpr int G = 2 * F2_UNR;
+  for (int c0 = 0; c0 < Co; c0 += KW) {
+    const int kc = min(KW, Co - c0);
+    __syncthreads();
+    {
+      f32x4 wr[2 * MT];
+#pragma unroll
+      for (int q = 0; q < 2 * MT; ++q) {
+        const int f = tid + PW_NT * q;
+        const int rowi = f / (8 * MT), cq = (f - rowi * (8 * MT)) * 4;
+        const int co = c0 + rowi, ci = ciBase + cq;
+        if (wvec) {
+          wr[q] = (co < Co && ci < Ci) ? *reinterpret_cast<const f32x4*>(a.w + (size_t)co * Ci + ci)
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wr[q][e] = (co < Co && ci + e < Ci) ? a.w[(size_t)co * Ci + ci + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2 * MT; ++q) {
+        const int f = tid + PW_NT * q;
+        const int rowi = f / (8 * MT), cq = (f - rowi * (8 * MT)) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ws[rowi * WS2 + cq + e] = wr[q][e];
+      }
+    }
+    __syncthreads();
+    const int kpad = (kc + 2 * G - 1) / (2 * G) * (2 * G);
+    float ga_[F2_UNR][NW], za_[F2_UNR][NW], gaa[F2_UNR][NW], zaa[F2_UNR][NW];
+    float gb_[F2_UNR][NW], zb_[F2_UNR][NW], gab[F2_UNR][NW], zab[F2_UNR][NW];
+    d2_load<NW, AUG>(ga_, za_, gaa, zaa, rg, rz, rga, rza, voff, voffa, c0, L * 4, a.Tout * 4, has_g, has_c);
+    for (int k0 = 0; k0 < kpad; k0 += 2 * G) {
+      d2_load<NW, AUG>(gb_, zb_, gab, zab, rg, rz, rga, rza, voff, voffa, c0 + k0 + G, L * 4, a.Tout * 4, has_g, has_c);
+      d2_compute<MT, NW, AUG>(acc, Ws, Cs, ga_, za_, gaa, zaa, k0, kc, c0, invV, half, l31);
+      d2_load<NW, AUG>(ga_, za_, gaa, zaa, rg, rz, rga, rza, voff, voffa, c0 + k0 + 2 * G, L * 4, a.Tout * 4, has_g,
+                       has_c);
+      d2_compute<MT, NW, AUG>(acc, Ws, Cs, gb_, zb_, gab, zab, k0 + G, kc, c0, invV, half, l31);
+    }
+  }
+  __syncthreads();
+  // ---- epilogue: ReLU mask / affine of the virtual input, coalesced stores, 3 per-channel partial sums ----
+  float* Tw = lds + wave * (32 * 36);
+  float* Ss = lds + 4 * 32 * 36;                 // [4 waves][32][3]
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const size_t cstride = (size_t)a.T * V;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      float dvv[16], xav[16], xbv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ciBase + 32 * m + mfma_row32(r, half);
+        float dv = 0.f, xa = 0.f, xb = 0.f;
+        if (ci < Ci && pok[j]) {
+          const size_t g = ((size_t)n * Ci + ci) * cstride + goff[j];
+          xa = a.x1[g];
+          const float sa = a.s1 ? a.s1[ci] : 1.f;
+          float pre = a.s1 ? fmaf(xa, sa, a.h1[ci]) : xa;
+          float sb = 1.f;
+          if (a.x2) {
+            xb = a.x2[g];
+            if (a.s2) { sb = a.s2[ci]; pre += fmaf(xb, sb, a.h2[ci]); } else pre += xb;
+          }
+          dv = (!a.relu || pre > 0.f) ? acc[m][j][r] : 0.f;
+          a.dx1[g] = dv * sa;
+          if (a.dx2) a.dx2[g] = dv * sb;
+        }
+        dvv[r] = dv; xav[r] = xa; xbv[r] = xb;
+      }
+      if (a.ipart) {
+        // three LDS-transposed row sums: dv*x1, dv, dv*x2
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+          if (which == 2 && !a.x2) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float val = which == 0 ? dvv[r] * xav[r] : (which == 1 ? dvv[r] : dvv[r] * xbv[r]);
+            Tw[mfma_row32(r, half) * 36 + l31] = val;
+          }
+          wave_lds_sync();
+          const f32x4* rowp = reinterpret_cast<const f32x4*>(Tw + l31 * 36 + half * 16);
+          float sacc = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = rowp[q];
+            sacc += (v.x + v.y) + (v.z + v.w);
+          }
+          if (which == 0) u0 += sacc; else if (which == 1) u1 += sacc; else u2 += sacc;
+          wave_lds_sync();
+        }
+      }
+    }
+    if (a.ipart) {
+      u0 += __shfl_xor(u0, 32, 64);
+      u1 += __shfl_xor(u1, 32, 64);
+      u2 += __shfl_xor(u2, 32, 64);
+      if (half == 0) {
+        float* q = Ss + (wave * 32 + l31) * 3;
+        q[0] = u0; q[1] = u1; q[2] = u2;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        const int ci = ciBase + 32 * m + tid;
+        if (ci < Ci) {
+          float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const float* q = Ss + (w * 32 + tid) * 3;
+            v0 += q[0]; v1 += q[1]; v2 += q[2];
+          }
+          float* o = a.ipart + (blk * Ci + ci) * 3;
+          o[0] = v0; o[1] = v1; o[2] = v2;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// wgrad: block = (64 co x 64 ci output tile, k-split); K = positions of `chunks_per_split` (sample, TR-row) chunks.
+// Thread (row = tid/4, quarter = tid%4) stages positions 16*j + 4*quarter + {0..3}, j < 7, of tile row `row` for both
+// operands (dz_eff of channel coBase+row and the virtual input of channel ciBase+row): all loads of a chunk are issued
+// before the MFMAs of the previous chunk.  LDS rows have an odd stride so the per-lane column reads
+// (A[i=co][k=pos], B[k=pos][j=ci]) are conflict-free.
+constexpr int WG_J = 7;            // float4 slots per thread per operand: covers 4*4*7 = 112 >= TR*V positions
+constexpr int WG_TR = 4;           // frames per wgrad chunk (multiple of 4 keeps every chunk 16-B aligned)
+template <bool VEC, bool HAS2>
+__global__ __launch_bounds__(PW_NT) void k_pwconv_wgrad(PwBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int V = a.V, TR = a.TR, Co = a.Co, Ci = a.Ci;
+  const int TRV = TR * V;
+  const int KP = (TRV + 1) & ~1;                 // positions per chunk, even
+  const int LS = KP | 1;                         // odd row stride
+  float* Ds = lds;                               // [64][LS] dz_eff
+  float* Xs = lds + 64 * LS;                     // [64][LS] virtual input
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int coBase = blockIdx.x * 64, ciBase = blockIdx.y * 64;
+  const int split = blockIdx.z;
+  const int mt = wave >> 1, ntile = wave & 1;
+  const float invV = 1.f / (float)V;
+  const int row = tid >> 2, quarter = tid & 3;
+  const int co = coBase + row, ci = ciBase + row;
+  const bool has_g = a.gz != nullptr, has_c = a.A0 != nullptr;
+  constexpr bool has2 = HAS2;
+  const float A0c = (has_c && co < Co) ? a.A0[co] : 0.f, B0c = (has_c && co < Co) ? a.B0[co] : 0.f;
+  const float s1 = (a.s1 && ci < Ci) ? a.s1[ci] : 1.f, h1 = (a.s1 && ci < Ci) ? a.h1[ci] : 0.f;
+  const float s2 = (a.s2 && ci < Ci) ? a.s2[ci] : 1.f, h2 = (a.s2 && ci < Ci) ? a.h2[ci] : 0.f;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float dbacc = 0.f;
+  f32x4 gr[WG_J], zr[WG_J], xr[WG_J], yr[HAS2 ? WG_J : 1];
+  const int ch0 = split * a.chunks_per_split;
+  const int ch1 = min(a.total_chunks, ch0 + a.chunks_per_split);
+
+  auto issue = [&](int ch) {
+    const int n = ch / a.nb_per_sample;
+    const int r0 = (ch - n * a.nb_per_sample) * TR;
+    const int nvalid = min(TR, a.Tout - r0) * V;
+    const size_t gzb = ((size_t)(n * Co + co) * a.Tout + r0) * V;
+    const size_t gxb = ((size_t)(n * Ci + ci) * a.T + (size_t)r0 * a.stride) * V;
+#pragma unroll
+    for (int j = 0; j < WG_J; ++j) {
+      const int p = 16 * j + 4 * quarter;
+      if (VEC) {
+        if (p < nvalid) {
+          if (co < Co) {
+            if (has_g) gr[j] = *reinterpret_cast<const f32x4*>(a.gz + gzb + p);
+            if (has_c) zr[j] = *reinterpret_cast<const f32x4*>(a.z + gzb + p);
+          }
+          if (ci < Ci) {
+            xr[j] = *reinterpret_cast<const f32x4*>(a.x1 + gxb + p);
+            if (HAS2) yr[HAS2 ? j : 0] = *reinterpret_cast<const f32x4*>(a.x2 + gxb + p);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pe = p + e;
+          if (pe < nvalid) {
+            if (co < Co) {
+              if (has_g) gr[j][e] = a.gz[gzb + pe];
+              if (has_c) zr[j][e] = a.z[gzb + pe];
+            }
+            if (ci < Ci) {
+              const int rl = (int)(((float)pe + 0.5f) * invV);
+              const size_t g = gxb + (size_t)rl * a.stride * V + (pe - rl * V);
+              xr[j][e] = a.x1[g];
+              if (HAS2) yr[HAS2 ? j : 0][e] = a.x2[g];
+            }
+          }
+        }
+      }
+    }
+  };
+
+  auto commit = [&](int ch) {
+    const int n = ch / a.nb_per_sample;
+    const int r0 = (ch - n * a.nb_per_sample) * TR;
+    const int nvalid = min(TR, a.Tout - r0) * V;
+    float dsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < WG_J; ++j) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pe = 16 * j + 4 * quarter + e;
+        if (pe < KP) {
+          float d = 0.f, x = 0.f;
+          if (pe < nvalid) {
+            if (co < Co) {
+              d = has_g ? gr[j][e] : 0.f;
+              if (has_c) d += fmaf(B0c, zr[j][e], A0c);
+              if (a.aug) {
+                const int rl = (int)(((float)pe + 0.5f) * invV);
+                const size_t ga = (size_t)(n * Co + co) * a.Tout + r0 + rl;
+                float ea = a.gzaug ? a.gzaug[ga] : 0.f;
+                if (has_c) ea += fmaf(B0c, a.zaug[ga], A0c);
+                d = fmaf(ea, invV, d);
+              }
+            }
+            if (ci < Ci) x = virt1(xr[j][e], HAS2 ? yr[HAS2 ? j : 0][e] : 0.f, has2, s1, h1, s2, h2, a.relu);
+          }
+          Ds[row * LS + pe] = d;
+          Xs[row * LS + pe] = x;
+          dsum += d;
+        }
+      }
+    }
+    dsum += __shfl_xor(dsum, 1, 64);
+    dsum += __shfl_xor(dsum, 2, 64);
+    dbacc += dsum;
+  };
+
+  if (ch0 < ch1) issue(ch0);
+  for (int ch = ch0; ch < ch1; ++ch) {
+    commit(ch);
+    __syncthreads();
+    if (ch + 1 < ch1) issue(ch + 1);
+    for (int kk = 0; kk < KP; kk += 2) {
+      const float av = Ds[(32 * mt + l31) * LS + kk + half];
+      const float bv = Xs[(32 * ntile + l31) * LS + kk + half];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[i=co][j=ci]
+  const int cio = ciBase + 32 * ntile + l31;
+  if (cio < Ci) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int coo = coBase + 32 * mt + mfma_row32(r, half);
+      if (coo < Co) a.dwp[((size_t)split * Co + coo) * Ci + cio] = acc[r];
+    }
+  }
+  if (blockIdx.y == 0 && quarter == 0 && co < Co) a.dbp[(size_t)split * Co + co] = dbacc;
+}
+
+// BN backward coefficients of a conv whose batch statistics feed a deferred affine (scale, shift):
+//   d gamma = r (g_scale - mean g_shift), d beta = g_shift, A0 = dmean/M - 2 dvar mean/M, B0 = 2 dvar/M
+//   with dmean = -g_shift*gamma*r, dvar = -0.5 r^3 gamma (g_scale - mean g_shift).
+__global__ __launch_bounds__(64) void k_bn_bwd_coef(const float* __restrict__ g_scale,
+                                                    const float* __restrict__ g_shift,
+                                                    const float* __restrict__ mean, const float* __restrict__ var,
+                                                    const float* __restrict__ gamma, float eps, double count, int C,
+                                                    int c_affine, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, float* __restrict__ A0,
+                                                    float* __restrict__ B0) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  if (c >= c_affine) { dgamma[c] = 0.f; dbeta[c] = 0.f; A0[c] = 0.f; B0[c] = 0.f; return; }
+  const double gs = g_scale ? (double)g_scale[c] : 0.0, gh = g_shift ? (double)g_shift[c] : 0.0;
+  const double mu = mean[c], r = 1.0 / sqrt((double)var[c] + (double)eps);
+  const double g = gamma ? (double)gamma[c] : 1.0;
+  const double t = gs - mu * gh;
+  dgamma[c] = (float)(r * t);
+  dbeta[c] = (float)gh;
+  const double dmean = -gh * g * r;
+  const double dvar = -0.5 * r * r * r * g * t;
+  A0[c] = (float)((dmean - 2.0 * dvar * mu) / count);
+  B0[c] = (float)(2.0 * dvar / count);
+}
+
+}  // namespace
+
+int g_pw_ablate = 0;
+int g_pw_maxmt = 4;
+
+extern "C" {
+
+int dsgcn_pwconv_tuning(int key, int value) {
+  if (key == 0) { g_pw_ablate = value; return 0; }
+  if (key == 1) { g_pw_maxmt = value; return 0; }
+  return DSGCN_EINVAL;
+}
+
+int dsgcn_pwconv_plan(int Tout, int V, int aug, int* TR, int* NPpad, int* nblk_per_sample) {
+  int tr = Tout >= 32 ? 8 : 4;
+  if (tr > Tout) tr = Tout;
+  int np = tr * (V + (aug ? 1 : 0));
+  while (np > 256 && tr > 1) { tr >>= 1; np = tr * (V + (aug ? 1 : 0)); }
+  if (np > 256) return DSGCN_EUNSUPPORTED;
+  *TR = tr;
+  *NPpad = (np + 31) & ~31;
+  *nblk_per_sample = (Tout + tr - 1) / tr;
+  return 0;
+}
+
+// Forward.  x2/s1/h1/s2/h2/bias/zaug/partial may be NULL as allowed by the flags.  partial: (n*nblk_per_sample, Co, 2).
+// Rows of the `partial` buffer the forward writes for a given shape (conv blocks [+ global-joint rows when aug]).
+int dsgcn_pwconv_partial_rows(int n, int Co, int T, int V, int stride, int aug) {
+  const int Tout = (T + stride - 1) / stride;
+  const int L = Tout * V;
+  const int mtiles = (Co + 31) / 32;
+  const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
+  const int NW = MT <= 2 ? 2 : 1;
+  const int nbx = (L + 4 * NW * 32 - 1) / (4 * NW * 32);
+  int rows = n * nbx;
+  if (aug) rows += n * (Tout >= 8 ? 8 : 1);
+  return rows;
+}
+
+// Forward.  x2/s1/h1/s2/h2/bias/zaug/partial may be NULL as allowed by the flags.
+// partial: (dsgcn_pwconv_partial_rows(...), Co, 2).
+int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                     const float* h2, int relu, const float* w, const float* bias, float* z, float* zaug,
+                     float* partial, int n, int Ci, int Co, int T, int V, int stride, int aug, int stats,
+                     void* stream) {
+  if (!x1 || !w || !z || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0 || stride <= 0) return DSGCN_EINVAL;
+  if ((aug && !zaug) || (stats && !partial) || (s1 && !h1) || (s2 && !h2)) return DSGCN_EINVAL;
+  const int Tout = (T + stride - 1) / stride;
+  PwArgs a = {};
+  a.x1 = x1; a.s1 = s1; a.h1 = h1; a.x2 = x2; a.s2 = s2; a.h2 = h2; a.relu = relu;
+  a.w = w; a.bias = bias; a.z = z; a.zaug = zaug; a.partial = partial;
+  a.n = n; a.Ci = Ci; a.Co = Co; a.T = T; a.V = V; a.Tout = Tout; a.stride = stride; a.aug = aug;
+  a.stats = stats; a.ablate = g_pw_ablate;
+  hipStream_t st = (hipStream_t)stream;
+  const int L = Tout * V;
+  const int mtiles = (Co + 31) / 32;
+  const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
+  const int NW = MT <= 2 ? 2 : 1;
+  const int nbx = (L + 4 * NW * 32 - 1) / (4 * NW * 32);
+  dim3 grid((unsigned)nbx, (unsigned)n, (unsigned)((mtiles + MT - 1) / MT));
+  size_t ldsf = (size_t)32 * MT * KWS + 4 + (size_t)4 * Ci;
+  if (ldsf < (size_t)4 * 32 * 36 + 256) ldsf = (size_t)4 * 32 * 36 + 256;
+  const size_t lds = ldsf * sizeof(float);
+  switch (MT) {
+    case 1: hipLaunchKernelGGL((k_pwconv_fwd2<1, 2>), grid, dim3(PW_NT), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((k_pwconv_fwd2<2, 2>), grid, dim3(PW_NT), lds, st, a); break;
+    case 3: hipLaunchKernelGGL((k_pwconv_fwd2<3, 1>), grid, dim3(PW_NT), lds, st, a); break;
+    default: hipLaunchKernelGGL((k_pwconv_fwd2<4, 1>), grid, dim3(PW_NT), lds, st, a); break;
+  }
+  DSGCN_LAUNCH_CHECK();
+  if (aug) {
+    const int tsl = Tout >= 8 ? 8 : 1;
+    hipLaunchKernelGGL(k_rowmean_stats, dim3((unsigned)tsl, (unsigned)n), dim3(256), 0, st, z, zaug,
+                       stats ? partial + (size_t)n * nbx * Co * 2 : (float*)nullptr, n, Co, Tout, V, tsl);
+    DSGCN_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
+                      float eps, float* mean_out, float* var_out, float* scale_out, float* shift_out, int c_affine,
+                      void* stream) {
+  if (!partial || !mean_out || !var_out || !scale_out || !shift_out || nblk <= 0 || C <= 0) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk,
+                     C, count, gamma, beta, eps, mean_out, var_out, scale_out, shift_out, c_affine);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[c] = sum_r src[r, c]  (fp64 accumulation).
+int dsgcn_colsum(const float* src, int R, int C, float* out, void* stream) {
+  if (!src || !out || R <= 0 || C <= 0) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, (hipStream_t)stream, src, R, C, out);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Backward, data path.  gz/gzaug/A0/B0/x2/s*/h*/dx2/ipart may be NULL as in the forward.  dx1 (and dx2) are fully
+// written (zero rows where stride skips frames).  ipart: (n*nblk_per_sample, Ci, 3) = [sum dv*x1, sum dv, sum dv*x2].
+int dsgcn_pwconv_ipart_rows(int n, int Ci, int T, int V, int stride) {
+  const int Tout = (T + stride - 1) / stride;
+  const int L = Tout * V;
+  const int mtiles = (Ci + 31) / 32;
+  const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
+  const int NW = MT <= 2 ? 2 : 1;
+  return n * ((L + 4 * NW * 32 - 1) / (4 * NW * 32));
+}
+
+int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                       const float* h2, int relu, const float* w, const float* z, const float* zaug,
+                       const float* gz, const float* gzaug, const float* A0, const float* B0, float* dx1, float* dx2,
+                       float* ipart, int n, int Ci, int Co, int T, int V, int stride, int aug, void* stream) {
+  if (!x1 || !w || !dx1 || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0 || stride <= 0) return DSGCN_EINVAL;
+  if ((A0 && (!B0 || !z)) || (aug && A0 && !zaug) || (x2 && !dx2)) return DSGCN_EINVAL;
+  const int Tout = (T + stride - 1) / stride;
+  hipStream_t st = (hipStream_t)stream;
+  if (stride > 1) {
+    hipError_t e = hipMemsetAsync(dx1, 0, (size_t)n * Ci * T * V * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (dx2) {
+      e = hipMemsetAsync(dx2, 0, (size_t)n * Ci * T * V * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  PwBwdArgs a = {};
+  a.x1 = x1; a.s1 = s1; a.h1 = h1; a.x2 = x2; a.s2 = s2; a.h2 = h2; a.relu = relu; a.w = w;
+  a.z = z; a.zaug = zaug; a.gz = gz; a.gzaug = gzaug; a.A0 = A0; a.B0 = B0;
+  a.dx1 = dx1; a.dx2 = dx2; a.ipart = ipart;
+  a.n = n; a.Ci = Ci; a.Co = Co; a.T = T; a.V = V; a.Tout = Tout; a.stride = stride; a.aug = aug;
+  const int L = Tout * V;
+  const int mtiles = (Ci + 31) / 32;
+  const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
+  const int NW = MT <= 2 ? 2 : 1;
+  const int nbx = (L + 4 * NW * 32 - 1) / (4 * NW * 32);
+  dim3 grid((unsigned)nbx, (unsigned)n, (unsigned)((mtiles + MT - 1) / MT));
+  size_t ldsf = (size_t)KW * (32 * MT + 1) + 4 + (size_t)2 * Co;
+  if (ldsf < (size_t)4 * 32 * 36 + 4 * 32 * 3) ldsf = (size_t)4 * 32 * 36 + 4 * 32 * 3;
+  const size_t lds = ldsf * sizeof(float);
+#define DSGCN_DGRAD(MTv, NWv)                                                                        \
+  do {                                                                                               \
+    if (aug) hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, true>), grid, dim3(PW_NT), lds, st, a);   \
+    else hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, false>), grid, dim3(PW_NT), lds, st, a);      \
+  } while (0)
+  switch (MT) {
+    case 1: DSGCN_DGRAD(1, 2); break;
+    case 2: DSGCN_DGRAD(2, 2); break;
+    case 3: DSGCN_DGRAD(3, 1); break;
+    default: DSGCN_DGRAD(4, 1); break;
+  }
+#undef DSGCN_DGRAD
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// k-split plan of the weight gradient: returns the number of splits (size of dim 0 of dwp / dbp).
+int dsgcn_pwconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int stride) {
+  const int Tout = (T + stride - 1) / stride;
+  const int TR = Tout >= WG_TR ? WG_TR : Tout;
+  const int chunks = n * ((Tout + TR - 1) / TR);
+  const int tiles = ((Co + 63) / 64) * ((Ci + 63) / 64);
+  int splits = 1024 / tiles;
+  if (splits < 1) splits = 1;
+  if (splits > chunks) splits = chunks;
+  const int per = (chunks + splits - 1) / splits;
+  return (chunks + per - 1) / per;
+}
+
+// Backward, weight path.  dwp: (splits, Co, Ci), dbp: (splits, Co) partial sums (sum over dim 0 = dW, db).
+int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                       const float* h2, int relu, const float* z, const float* zaug, const float* gz,
+                       const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int n, int Ci,
+                       int Co, int T, int V, int stride, int aug, void* stream) {
+  if (!x1 || !dwp || !dbp || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0 || stride <= 0) return DSGCN_EINVAL;
+  if ((A0 && (!B0 || !z)) || (aug && A0 && !zaug)) return DSGCN_EINVAL;
+  const int Tout = (T + stride - 1) / stride;
+  const int TR = Tout >= WG_TR ? WG_TR : Tout;
+  if (TR * V > 16 * WG_J) return DSGCN_EUNSUPPORTED;
+  PwBwdArgs a = {};
+  a.x1 = x1; a.s1 = s1; a.h1 = h1; a.x2 = x2; a.s2 = s2; a.h2 = h2; a.relu = relu;
+  a.z = z; a.zaug = zaug; a.gz = gz; a.gzaug = gzaug; a.A0 = A0; a.B0 = B0; a.dwp = dwp; a.dbp = dbp;
+  a.n = n; a.Ci = Ci; a.Co = Co; a.T = T; a.V = V; a.Tout = Tout; a.stride = stride; a.aug = aug; a.TR = TR;
+  a.nb_per_sample = (Tout + TR - 1) / TR;
+  a.total_chunks = n * a.nb_per_sample;
+  a.vec = (stride == 1 && (T * V) % 4 == 0 && (Tout * V) % 4 == 0 && (TR * V) % 4 == 0 &&
+           ((Tout % TR) * V) % 4 == 0) ? 1 : 0;
+  const int splits = dsgcn_pwconv_wgrad_splits(n, Ci, Co, T, V, stride);
+  a.chunks_per_split = (a.total_chunks + splits - 1) / splits;
+  const int KP = (TR * V + 1) & ~1;
+  const int LS = KP | 1;
+  const size_t lds = (size_t)2 * 64 * LS * sizeof(float);
+  dim3 grid((unsigned)((Co + 63) / 64), (unsigned)((Ci + 63) / 64), (unsigned)splits);
+  hipStream_t st = (hipStream_t)stream;
+  if (a.vec && x2) hipLaunchKernelGGL((k_pwconv_wgrad<true, true>), grid, dim3(PW_NT), lds, st, a);
+  else if (a.vec) hipLaunchKernelGGL((k_pwconv_wgrad<true, false>), grid, dim3(PW_NT), lds, st, a);
+  else if (x2) hipLaunchKernelGGL((k_pwconv_wgrad<false, true>), grid, dim3(PW_NT), lds, st, a);
+  else hipLaunchKernelGGL((k_pwconv_wgrad<false, false>), grid, dim3(PW_NT), lds, st, a);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* mean, const float* var,
+                      const float* gamma, float eps, double count, int C, int c_affine, float* dgamma, float* dbeta,
+                      float* A0, float* B0, void* stream) {
+  if (!mean || !var || !dgamma || !dbeta || !A0 || !B0 || C <= 0) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_bn_bwd_coef, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, g_scale,
+                     g_shift, mean, var, gamma, eps, count, C, c_affine, dgamma, dbeta, A0, B0);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

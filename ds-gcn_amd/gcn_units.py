@@ -36,25 +36,72 @@ def as_deferred(x):
     return x if isinstance(x, Deferred) else Deferred(x, None, None, None, False)
 
 
-def bn_affine(bn, mean, var, count):
-    """(scale, shift) of a BatchNorm layer from the producer's batch statistics (train) or from the
-    running statistics (eval); train mode also updates the running buffers the way
-    ``F.batch_norm`` does (momentum, unbiased variance, num_batches_tracked)."""
-    ops = kernels.ops()
-    if bn.training or not bn.track_running_stats:
-        scale, shift = ops.bn_affine(mean, var, bn.weight, bn.bias, bn.eps)
-        if bn.training and bn.track_running_stats:
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
-                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                bn.running_mean.mul_(1 - m).add_(mean.detach(), alpha=m)
-                bn.running_var.mul_(1 - m).add_(var.detach(), alpha=m * count / max(count - 1, 1))
-        return scale, shift
-    return ops.bn_affine(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps)
+_pending_running = []     # (bn, mean, var, count) recorded during a training forward, applied by flush_running_stats
+
+
+def record_running(bn, mean, var, count):
+    if bn.training and bn.track_running_stats and mean is not None:
+        _pending_running.append((bn, mean.detach(), var.detach(), float(count)))
+
+
+@torch.no_grad()
+def flush_running_stats():
+    """Apply the running-statistics updates of every BatchNorm touched since the last flush, the way
+    ``F.batch_norm(training=True)`` does (momentum, unbiased variance, num_batches_tracked) — batched into a few
+    multi-tensor launches instead of three tiny kernels per layer."""
+    if not _pending_running:
+        return
+    items = list(_pending_running)
+    _pending_running.clear()
+    for bn, _, _, _ in items:
+        bn.num_batches_tracked += 1
+    groups = {}
+    for it in items:
+        bn = it[0]
+        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        groups.setdefault(float(m), []).append(it)
+    for m, its in groups.items():
+        rm = [bn.running_mean for bn, _, _, _ in its]
+        rv = [bn.running_var for bn, _, _, _ in its]
+        means = [mean for _, mean, _, _ in its]
+        unb = torch._foreach_mul([var for _, _, var, _ in its], [c / max(c - 1.0, 1.0) for _, _, _, c in its])
+        torch._foreach_mul_(rm, 1.0 - m)
+        torch._foreach_add_(rm, means, alpha=m)
+        torch._foreach_mul_(rv, 1.0 - m)
+        torch._foreach_add_(rv, unb, alpha=m)
 
 
 def _need_stats(bn):
     return bn.training or not bn.track_running_stats
+
+
+def eval_affine(bn):
+    scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    return scale, bn.bias - bn.running_mean * scale
+
+
+def bn_affine(bn, mean, var, count):
+    """(scale, shift) of a BatchNorm layer from batch statistics an op returned (train) or from the running
+    statistics (eval).  Used for the ops whose BN is not fused into the producing kernel yet."""
+    if _need_stats(bn):
+        scale, shift = kernels.ops().bn_affine(mean, var, bn.weight, bn.bias, bn.eps)
+        record_running(bn, mean, var, count)
+        return scale, shift
+    return eval_affine(bn)
+
+
+def conv_bn(x1, a1, x2, a2, relu, conv, stride, aug, bn):
+    """1x1 conv (module ``conv``) of a virtual input followed by BatchNorm ``bn`` as a deferred affine.
+    -> (z, zaug, (scale, shift))"""
+    ops = kernels.ops()
+    n, _, T, V = x1.shape
+    if _need_stats(bn):
+        z, zaug, sc, sh, mean, var = ops.pwconv(x1, a1, x2, a2, relu, conv.weight, conv.bias, stride, aug,
+                                                bn.weight, bn.bias, bn.eps, bn.num_features, True)
+        record_running(bn, mean, var, n * z.shape[2] * (V + (1 if aug else 0)))
+        return z, zaug, (sc, sh)
+    z, zaug = ops.pwconv(x1, a1, x2, a2, relu, conv.weight, conv.bias, stride, aug)[:2]
+    return z, zaug, eval_affine(bn)
 
 
 def _norm_layer(norm, num_features):
@@ -139,23 +186,16 @@ class dgphgcn1(nn.Module):
 
     def forward_deferred(self, x, xbar=None):
         ops = kernels.ops()
-        n, c, t, v = x.shape
-        count = n * t * v
         if xbar is None:
             xbar = ops.tmean(x)
         ahat = self.adjacency(xbar)
-        pre_bn = self.pre[1]
-        zp, _, m, var = ops.pwconv(x, None, None, None, False, self.pre[0].weight, self.pre[0].bias, 1, False,
-                                   _need_stats(pre_bn))
-        y = ops.aggregate(zp, bn_affine(pre_bn, m, var, count), True, ahat)
-        zo, _, m, var = ops.pwconv(y, None, None, None, False, self.post.weight, self.post.bias, 1, False,
-                                   _need_stats(self.bn))
-        ao = bn_affine(self.bn, m, var, count)
+        zp, _, ap = conv_bn(x, None, None, None, False, self.pre[0], 1, False, self.pre[1])
+        y = ops.aggregate(zp, ap, True, ahat)
+        zo, _, ao = conv_bn(y, None, None, None, False, self.post, 1, False, self.bn)
         if self.down is None:
             return Deferred(zo, ao, x, None, True)
-        zd, _, m, var = ops.pwconv(x, None, None, None, False, self.down[0].weight, self.down[0].bias, 1, False,
-                                   _need_stats(self.down[1]))
-        return Deferred(zo, ao, zd, bn_affine(self.down[1], m, var, count), True)
+        zd, _, ad = conv_bn(x, None, None, None, False, self.down[0], 1, False, self.down[1])
+        return Deferred(zo, ao, zd, ad, True)
 
     def forward(self, x, A=None):
         return self.forward_deferred(x).materialize()
@@ -203,16 +243,15 @@ class unit_gcn(nn.Module):
         ops = kernels.ops()
         n, c, t, v = x.shape
         count = n * t * v
-        h = ops.pwconv(x, None, None, None, False, self.conv.weight, self.conv.bias, 1, False, False)[0]
+        h = ops.pwconv(x, None, None, None, False, self.conv.weight, self.conv.bias, 1, False)[0]
         y, m, var = ops.aggregate_shared(h, self.A, self.num_subsets, _need_stats(self.bn))
         ay = bn_affine(self.bn, m, var, count)
         if not self.with_res:
             return Deferred(y, ay, None, None, True)
         if self.down is None:
             return Deferred(y, ay, x, None, True)
-        zd, _, m, var = ops.pwconv(x, None, None, None, False, self.down[0].weight, self.down[0].bias, 1, False,
-                                   _need_stats(self.down[1]))
-        return Deferred(y, ay, zd, bn_affine(self.down[1], m, var, count), True)
+        zd, _, ad = conv_bn(x, None, None, None, False, self.down[0], 1, False, self.down[1])
+        return Deferred(y, ay, zd, ad, True)
 
     def forward(self, x, A=None):
         if A is not None:

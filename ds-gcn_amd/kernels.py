@@ -52,6 +52,15 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def colsum(t):
+    """Sum over dim 0 of a contiguous fp32 tensor (R, ...) -> (...), fp64 accumulation, one small HIP launch."""
+    R = t.shape[0]
+    out = torch.empty(t.shape[1:], device=t.device, dtype=torch.float32)
+    C = out.numel()
+    native.check(native.lib().dsgcn_colsum(_ptr(t), R, C, _ptr(out), _stream()), 'dsgcn_colsum')
+    return out
+
+
 def _f32c(t):
     if t is None:
         return None
@@ -93,7 +102,7 @@ class _Aggregate(torch.autograd.Function):
         native.check(rc, 'dsgcn_aggregate_bwd')
         dscale = dshift = None
         if scale is not None:
-            red = partial.sum(0)
+            red = colsum(partial)
             dscale, dshift = red[:, 0], red[:, 1]
         return dzp, dscale, dshift, None, dahat
 
@@ -168,8 +177,8 @@ class _DynAdj(torch.autograd.Function):
             _ptr(dproj), _ptr(dxbar), _ptr(pA), _ptr(pab), _ptr(dwe), _ptr(dbe), _ptr(dwp), _ptr(dbp),
             n, Ci, mid, V, P, E, _stream())
         native.check(rc, 'dsgcn_dynadj_bwd')
-        dA = pA.sum(0)
-        dab = pab.sum(0)
+        dA = colsum(pA)
+        dab = colsum(pab)
         dwp = dwp.view(9 * mid, Ci)
         return (dxbar, dA, dab[:3], dab[3:], dwp[:2 * mid], dbp[:2 * mid], dwp[2 * mid:4 * mid], dbp[2 * mid:4 * mid],
                 dwp[4 * mid:], dbp[4 * mid:], dwe.view(E * mid, mid), dbe, None, None)
@@ -177,6 +186,120 @@ class _DynAdj(torch.autograd.Function):
 
 def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type):
     return _DynAdj.apply(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type)
+
+
+# ---------------------------------------------------------------------------------------------
+# K-C  1x1 channel mix + train-mode BN statistics / deferred affine
+# ---------------------------------------------------------------------------------------------
+
+import ctypes as _ct
+
+
+def _pw_plan(Tout, V, aug):
+    tr, npad, nb = _ct.c_int(), _ct.c_int(), _ct.c_int()
+    native.check(native.lib().dsgcn_pwconv_plan(Tout, V, int(aug), _ct.byref(tr), _ct.byref(npad), _ct.byref(nb)),
+                 'dsgcn_pwconv_plan')
+    return tr.value, npad.value, nb.value
+
+
+class _PwConv(torch.autograd.Function):
+    """z = W . virt(x1,a1,x2,a2,relu)[::stride] + b ; optional zaug = mean_v z ; optional BN of z:
+    (scale, shift) = (gamma*rsqrt(var+eps), beta-mean*scale) from the batch statistics of z (+zaug)."""
+
+    @staticmethod
+    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, weight, bias, stride, aug, gamma, beta, eps, n_affine, want_bn):
+        _require_cuda(x1, weight)
+        x1, s1, h1, x2, s2, h2, bias, gamma, beta = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2, bias, gamma, beta)]
+        w2 = _f32c(weight.reshape(weight.shape[0], -1))
+        n, Ci, T, V = x1.shape
+        Co = w2.shape[0]
+        assert w2.shape[1] == Ci, (w2.shape, x1.shape)
+        Tout = (T + stride - 1) // stride
+        dev = x1.device
+        z = torch.empty((n, Co, Tout, V), device=dev, dtype=torch.float32)
+        zaug = torch.empty((n, Co, Tout), device=dev, dtype=torch.float32) if aug else None
+        lib = native.lib()
+        partial = None
+        if want_bn:
+            rows = lib.dsgcn_pwconv_partial_rows(n, Co, T, V, stride, int(aug))
+            partial = torch.empty((rows, Co, 2), device=dev, dtype=torch.float32)
+        rc = lib.dsgcn_pwconv_fwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu), _ptr(w2),
+                                  _ptr(bias), _ptr(z), _ptr(zaug), _ptr(partial), n, Ci, Co, T, V, stride, int(aug),
+                                  int(want_bn), _stream())
+        native.check(rc, 'dsgcn_pwconv_fwd')
+        scale = shift = mean = var = None
+        count = float(n * Tout * (V + (1 if aug else 0)))
+        if want_bn:
+            stats = torch.empty((4, Co), device=dev, dtype=torch.float32)
+            mean, var, scale, shift = stats[0], stats[1], stats[2], stats[3]
+            rc = lib.dsgcn_bn_finalize(_ptr(partial), partial.shape[0], Co, count, _ptr(gamma), _ptr(beta), float(eps),
+                                       _ptr(mean), _ptr(var), _ptr(scale), _ptr(shift), int(n_affine), _stream())
+            native.check(rc, 'dsgcn_bn_finalize')
+            ctx.mark_non_differentiable(mean, var)
+        ctx.save_for_backward(x1, s1, h1, x2, s2, h2, w2, z, zaug, gamma, mean, var)
+        ctx.cfg = (int(relu), stride, int(aug), float(eps), int(n_affine), bool(want_bn), count, tuple(weight.shape),
+                   bias is not None, beta is not None)
+        return z, zaug, scale, shift, mean, var
+
+    @staticmethod
+    def backward(ctx, gz, gzaug, gscale, gshift, _gm, _gv):
+        x1, s1, h1, x2, s2, h2, w2, z, zaug, gamma, mean, var = ctx.saved_tensors
+        relu, stride, aug, eps, n_affine, want_bn, count, wshape, has_bias, has_beta = ctx.cfg
+        n, Ci, T, V = x1.shape
+        Co = w2.shape[0]
+        dev = x1.device
+        lib = native.lib()
+        st = _stream()
+        gz, gzaug, gscale, gshift = _f32c(gz), _f32c(gzaug), _f32c(gscale), _f32c(gshift)
+        A0 = B0 = dgamma = dbeta = None
+        if want_bn and (gscale is not None or gshift is not None):
+            coef = torch.empty((4, Co), device=dev, dtype=torch.float32)
+            dgamma, dbeta, A0, B0 = coef[0], coef[1], coef[2], coef[3]
+            rc = lib.dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, Co,
+                                       n_affine, _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), st)
+            native.check(rc, 'dsgcn_bn_bwd_coef')
+        Tout = z.shape[2]
+        dx1 = torch.empty_like(x1)
+        dx2 = torch.empty_like(x2) if x2 is not None else None
+        ipart = None
+        if s1 is not None or s2 is not None:
+            rows = lib.dsgcn_pwconv_ipart_rows(n, Ci, T, V, stride)
+            ipart = torch.zeros((rows, Ci, 3), device=dev, dtype=torch.float32)
+        rc = lib.dsgcn_pwconv_dgrad(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(w2),
+                                    _ptr(z), _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), _ptr(dx1),
+                                    _ptr(dx2), _ptr(ipart), n, Ci, Co, T, V, stride, aug, st)
+        native.check(rc, 'dsgcn_pwconv_dgrad')
+        splits = lib.dsgcn_pwconv_wgrad_splits(n, Ci, Co, T, V, stride)
+        dwp = torch.empty((splits, Co, Ci), device=dev, dtype=torch.float32)
+        dbp = torch.empty((splits, Co), device=dev, dtype=torch.float32)
+        rc = lib.dsgcn_pwconv_wgrad(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(z),
+                                    _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), _ptr(dwp), _ptr(dbp), n,
+                                    Ci, Co, T, V, stride, aug, st)
+        native.check(rc, 'dsgcn_pwconv_wgrad')
+        dw = colsum(dwp).view(wshape)
+        db = colsum(dbp) if has_bias else None
+        ds1 = dh1 = ds2 = dh2 = None
+        if ipart is not None:
+            red = colsum(ipart)
+            if s1 is not None:
+                ds1, dh1 = red[:, 0], red[:, 1]
+            if s2 is not None:
+                ds2, dh2 = red[:, 2], red[:, 1]
+        if dgamma is not None:
+            dgamma = dgamma[:n_affine] if gamma is not None else None
+            dbeta = dbeta[:n_affine] if has_beta else None
+        return (dx1, ds1, dh1, dx2, ds2, dh2, None, dw, db, None, None, dgamma, dbeta, None, None, None)
+
+
+def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, gamma=None, beta=None, eps=1e-5, n_affine=None,
+           want_bn=False):
+    """-> (z, zaug, scale, shift, mean, var); scale/shift/mean/var are None unless want_bn."""
+    s1, h1 = a1 if a1 is not None else (None, None)
+    s2, h2 = a2 if a2 is not None else (None, None)
+    if n_affine is None:
+        n_affine = weight.shape[0] if gamma is not None else 0
+    return _PwConv.apply(x1, s1, h1, x2, s2, h2, bool(relu), weight, bias, int(stride), bool(aug), gamma, beta,
+                         float(eps), int(n_affine), bool(want_bn))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -193,20 +316,6 @@ def _virt(x1, a1, x2, a2, relu):
     if x2 is not None:
         v = v + (x2 if a2 is None else x2 * _bc(a2[0]) + _bc(a2[1]))
     return F.relu(v) if relu else v
-
-
-def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, stats=True):
-    _require_cuda(x1)
-    v = _virt(x1, a1, x2, a2, relu)
-    if stride != 1:
-        v = v[:, :, ::stride]
-    z = F.conv2d(v, weight.reshape(weight.shape[0], -1, 1, 1), bias)
-    zaug = z.mean(-1) if aug else None
-    mean = var = None
-    if stats:
-        full = torch.cat([z, zaug[..., None]], -1) if aug else z
-        var, mean = torch.var_mean(full, (0, 2, 3), unbiased=False)
-    return z, zaug, mean, var
 
 
 def bn_affine(mean, var, weight, bias, eps):

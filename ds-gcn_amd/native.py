@@ -30,6 +30,20 @@ SIGNATURES = {
     'dsgcn_aggregate_fwd_variant': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_st],
     'dsgcn_set_tuning': [c_int, c_int],
     'dsgcn_aggregate_bwd': [c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
+    'dsgcn_pwconv_plan': [c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                          ctypes.POINTER(ctypes.c_int)],
+    'dsgcn_pwconv_fwd': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 8 + [c_st],
+    'dsgcn_bn_finalize': [c_f, c_int, c_int, ctypes.c_double, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f, c_int,
+                          c_st],
+    'dsgcn_pwconv_partial_rows': [c_int] * 6,
+    'dsgcn_pwconv_ipart_rows': [c_int] * 5,
+    'dsgcn_pwconv_tuning': [c_int, c_int],
+    'dsgcn_diag_mfma_probe': [c_f, c_int, c_int, c_int, c_st],
+    'dsgcn_colsum': [c_f, c_int, c_int, c_f, c_st],
+    'dsgcn_pwconv_dgrad': [c_f] * 6 + [c_int] + [c_f] * 10 + [c_int] * 7 + [c_st],
+    'dsgcn_pwconv_wgrad_splits': [c_int] * 6,
+    'dsgcn_pwconv_wgrad': [c_f] * 6 + [c_int] + [c_f] * 8 + [c_int] * 7 + [c_st],
+    'dsgcn_bn_bwd_coef': [c_f] * 5 + [ctypes.c_float, ctypes.c_double, c_int, c_int] + [c_f] * 4 + [c_st],
     'dsgcn_dynadj_fwd': [c_f] * 12 + [c_i, c_i, c_f] + [c_int] * 6 + [c_st],
     'dsgcn_dynadj_bwd': [c_f] * 11 + [c_i] * 4 + [c_f] * 10 + [c_int] * 6 + [c_st],
 }
@@ -39,13 +53,26 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for path in sources() + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + sorted(glob.glob(os.path.join(INCLUDE, '*.h'))):
+        with open(path, 'rb') as f:
+            h.update(os.path.basename(path).encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into one shared library (cross-compiles without a GPU)."""
+    """Compile every HIP source for gfx950 into one shared library (cross-compiles without a GPU).
+    Up-to-date check = content hash of the sources (file times do not survive the copy to a GPU box)."""
     srcs = sources()
-    deps = srcs + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(INCLUDE, '*.h'))
-    if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in deps):
-            return LIB_PATH
+    stamp = LIB_PATH + '.srchash'
+    digest = _source_hash()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == digest:
+                return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I', INCLUDE, '-I', CSRC,
@@ -53,6 +80,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
+    with open(stamp, 'w') as f:
+        f.write(digest)
     return LIB_PATH
 
 

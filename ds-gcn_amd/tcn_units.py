@@ -11,7 +11,8 @@ import torch
 import torch.nn as nn
 
 from . import kernels
-from .gcn_units import Deferred, as_deferred, bn_affine, _need_stats, _norm_layer
+from .gcn_units import (Deferred, as_deferred, bn_affine, conv_bn, eval_affine, record_running, _need_stats,
+                        _norm_layer)
 
 
 class unit_tcn(nn.Module):
@@ -36,13 +37,14 @@ class unit_tcn(nn.Module):
         has_bn = isinstance(self.bn, nn.BatchNorm2d)
         stats = has_bn and _need_stats(self.bn)
         if self.kernel_size == 1:
-            z, _, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, self.conv.weight, self.conv.bias, self.stride,
-                                      False, stats)
-        else:
-            if d.x2 is not None:
-                d = Deferred(d.materialize(), None, None, None, False)
-            z, m, var = ops.tconv(d.x1, d.a1, d.relu, self.conv.weight, self.conv.bias, self.stride, self.dilation,
-                                  stats)
+            if has_bn:
+                z, _, az = conv_bn(d.x1, d.a1, d.x2, d.a2, d.relu, self.conv, self.stride, False, self.bn)
+                return Deferred(z, az, None, None, False)
+            z = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, self.conv.weight, self.conv.bias, self.stride, False)[0]
+            return Deferred(z, None, None, None, False)
+        if d.x2 is not None:
+            d = Deferred(d.materialize(), None, None, None, False)
+        z, m, var = ops.tconv(d.x1, d.a1, d.relu, self.conv.weight, self.conv.bias, self.stride, self.dilation, stats)
         if not has_bn:
             return Deferred(z, None, None, None, False)
         count = z.shape[0] * z.shape[2] * z.shape[3]
@@ -129,32 +131,32 @@ class dgmstcn(nn.Module):
         wb = torch.cat([c.weight.flatten(1) for c in convs], 0)
         bb = torch.cat([c.bias for c in convs], 0)
         bns = [b[1] for b in self.branches if not isinstance(b, nn.Conv2d)]
-        stats = any(_need_stats(bn) for bn in bns)
-        z, zaug, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, True, stats)
+        train_stats = any(_need_stats(bn) for bn in bns)
         count = n * T * (V + 1)
-        scales, shifts, c0 = [], [], 0
-        for bn in bns:
-            bc = bn.num_features
-            s, h = bn_affine(bn, None if m is None else m[c0:c0 + bc], None if var is None else var[c0:c0 + bc],
-                             count)
-            scales.append(s)
-            shifts.append(h)
-            c0 += bc
-        rest = self.out_channels - c0
-        if rest:
-            scales.append(z.new_ones(rest))
-            shifts.append(z.new_zeros(rest))
+        if train_stats:
+            gamma = torch.cat([bn.weight for bn in bns])
+            beta = torch.cat([bn.bias for bn in bns])
+            z, zaug, scale, shift, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, True, gamma, beta,
+                                                      bns[0].eps, self.n_act, True)
+            c0 = 0
+            for bn in bns:
+                record_running(bn, m[c0:c0 + bn.num_features], var[c0:c0 + bn.num_features], count)
+                c0 += bn.num_features
+        else:
+            z, zaug = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, True)[:2]
+            aff = [eval_affine(bn) for bn in bns]
+            rest = self.out_channels - self.n_act
+            scale = torch.cat([a[0] for a in aff] + ([z.new_ones(rest)] if rest else []))
+            shift = torch.cat([a[1] for a in aff] + ([z.new_zeros(rest)] if rest else []))
         tconvs = [b[3].conv for b in self.branches if not isinstance(b, nn.Conv2d) and isinstance(b[3], unit_tcn)]
         bn1 = self.transform[0]
-        f, m1, v1 = ops.temporal_ms(z, zaug, torch.cat(scales), torch.cat(shifts), self.n_act, self.ms_cfg,
+        f, m1, v1 = ops.temporal_ms(z, zaug, scale, shift, self.n_act, self.ms_cfg,
                                     self.widths, [c.weight for c in tconvs], [c.bias for c in tconvs],
                                     self.add_coeff, self.stride, _need_stats(bn1))
         cnt1 = f.shape[0] * f.shape[2] * f.shape[3]
         a1 = bn_affine(bn1, m1, v1, cnt1)
-        conv_t = self.transform[2]
-        zt, _, m2, v2 = ops.pwconv(f, a1, None, None, True, conv_t.weight, conv_t.bias, 1, False,
-                                   _need_stats(self.bn))
-        return Deferred(zt, bn_affine(self.bn, m2, v2, cnt1), None, None, False)
+        zt, _, a2 = conv_bn(f, a1, None, None, True, self.transform[2], 1, False, self.bn)
+        return Deferred(zt, a2, None, None, False)
 
     def forward(self, x):
         out = self.forward_deferred(x).materialize()

@@ -76,6 +76,44 @@ int dsgcn_dynadj_bwd(const float* xbar, const float* alpha, const float* beta, c
                      float* pab, float* dwe, float* dbe, float* dwproj, float* dbproj, int n, int Ci, int mid, int V,
                      int P, int E, void* stream);
 
+/* ---- K-C: 1x1 channel mix with fused train-mode BatchNorm / ReLU / residual --------------------------------
+ * Replaces Conv2d(1x1)+BatchNorm2d+ReLU(+add) chains of gcn.py:2165-2169,2209-2215,2236,2363-2365 and
+ * tcn.py:379-404,409,422,427 and tcn.py:21-28 (kernel_size 1).
+ *   v = relu?(x1*s1[ci]+h1[ci] (+ x2*s2[ci]+h2[ci] | + x2));  z = W v[:, :, ::stride] + bias;  zaug = mean_v z (aug)
+ *   partial (n*nblk, Co, 2): per-block sum / sum of squares of z (+zaug) -> dsgcn_bn_finalize.
+ * x1,x2 (n,Ci,T,V); w (Co,Ci); z (n,Co,Tout,V); zaug (n,Co,Tout); s,h (Ci) or NULL. */
+int dsgcn_pwconv_plan(int Tout, int V, int aug, int* TR, int* NPpad, int* nblk_per_sample);
+/* rows of the forward's `partial` buffer: (rows, Co, 2) */
+int dsgcn_pwconv_partial_rows(int n, int Co, int T, int V, int stride, int aug);
+/* tuning / ablation knobs used by tools/ (key 0: ablation mask, key 1: max 32-channel tiles per block) */
+int dsgcn_pwconv_tuning(int key, int value);
+int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                     const float* h2, int relu, const float* w, const float* bias, float* z, float* zaug,
+                     float* partial, int n, int Ci, int Co, int T, int V, int stride, int aug, int stats,
+                     void* stream);
+/* partial (nblk,C,2) -> mean,var (biased), scale = gamma*rsqrt(var+eps), shift = beta-mean*scale for c < c_affine,
+ * identity affine above.  count = elements per channel. */
+int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
+                      float eps, float* mean_out, float* var_out, float* scale_out, float* shift_out, int c_affine,
+                      void* stream);
+/* out[c] = sum_r src[r,c] (fp64 accumulation). */
+int dsgcn_colsum(const float* src, int R, int C, float* out, void* stream);
+/* BN-statistics backward coefficients: dz_eff = gz + A0[c] + B0[c]*z; also d gamma / d beta. */
+int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* mean, const float* var,
+                      const float* gamma, float eps, double count, int C, int c_affine, float* dgamma, float* dbeta,
+                      float* A0, float* B0, void* stream);
+/* Data gradient: dx1 (, dx2) fully written; ipart (n*nblk, Ci, 3) = [sum dv*x1, sum dv, sum dv*x2] partials. */
+int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                       const float* h2, int relu, const float* w, const float* z, const float* zaug,
+                       const float* gz, const float* gzaug, const float* A0, const float* B0, float* dx1, float* dx2,
+                       float* ipart, int n, int Ci, int Co, int T, int V, int stride, int aug, void* stream);
+/* Weight gradient: dwp (splits,Co,Ci), dbp (splits,Co) partials; splits from dsgcn_pwconv_wgrad_splits. */
+int dsgcn_pwconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int stride);
+int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                       const float* h2, int relu, const float* z, const float* zaug, const float* gz,
+                       const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int n, int Ci,
+                       int Co, int T, int V, int stride, int aug, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

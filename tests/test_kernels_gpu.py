@@ -86,3 +86,75 @@ def test_dynadj(n, Ci, mid, V, layout):
     for k in order:
         # fp32 chain rule with float atomics on the weight grads: 2e-5 relative L2
         assert rel(grads[k].cpu(), rg[k]) < 2e-5, (k, rel(grads[k].cpu(), rg[k]))
+
+
+def _rand(g, *shape, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize('n,Ci,Co,T,V,stride,aug,mode', [
+    (3, 3, 24, 64, 25, 1, False, 'plain'),        # block-0 pre conv
+    (2, 64, 64, 64, 25, 1, True, 'res_plain'),    # tcn branch conv: relu(bn(zo)+x), global joint
+    (2, 64, 128, 32, 25, 1, True, 'res_affine'),  # gcn with down: relu(bn(zo)+bn(zd))
+    (2, 96, 256, 16, 25, 1, False, 'plain'),      # post conv, 8 M-tiles
+    (2, 256, 256, 16, 25, 1, False, 'affine_relu'),   # transform conv: relu(bn1(f))
+    (2, 64, 128, 64, 25, 2, False, 'plain'),      # strided residual conv
+    (2, 128, 96, 50, 17, 1, True, 'res_plain'),   # coco, T not a multiple of the row tile, unaligned planes
+    (1, 5, 7, 9, 18, 2, True, 'affine_relu'),     # ragged everything
+])
+def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
+    g = torch.Generator().manual_seed(Ci * 7 + Co + T)
+    x1 = _rand(g, n, Ci, T, V)
+    a1 = a2 = x2 = None
+    relu = False
+    if mode in ('res_plain', 'res_affine', 'affine_relu'):
+        a1 = (torch.rand(Ci, generator=g) + 0.5, _rand(g, Ci, scale=0.3))
+        relu = True
+    if mode in ('res_plain', 'res_affine'):
+        x2 = _rand(g, n, Ci, T, V)
+    if mode == 'res_affine':
+        a2 = (torch.rand(Ci, generator=g) + 0.5, _rand(g, Ci, scale=0.3))
+    w = _rand(g, Co, Ci, 1, 1, scale=Ci ** -0.5)
+    b = _rand(g, Co, scale=0.1)
+    n_aff = Co - Co // 6 if aug else Co
+    gamma = torch.rand(n_aff, generator=g) + 0.5
+    beta = _rand(g, n_aff, scale=0.2)
+    Tout = (T + stride - 1) // stride
+    gz = _rand(g, n, Co, Tout, V)
+    gza = _rand(g, n, Co, Tout)
+    gsc = _rand(g, Co)
+    gsh = _rand(g, Co)
+
+    def run(mod, dt, dev):
+        def mk(t):
+            return None if t is None else t.to(dev, dt).requires_grad_()
+        tx1, tx2, tw, tb, tg, tbeta = mk(x1), mk(x2), mk(w), mk(b), mk(gamma), mk(beta)
+        ta1 = None if a1 is None else (mk(a1[0]), mk(a1[1]))
+        ta2 = None if a2 is None else (mk(a2[0]), mk(a2[1]))
+        z, zaug, sc, sh, mean, var = mod.pwconv(tx1, ta1, tx2, ta2, relu, tw, tb, stride, aug, tg, tbeta, 1e-5, n_aff,
+                                                True)
+        loss = (z * gz.to(dev, dt)).sum() + (sc * gsc.to(dev, dt)).sum() + (sh * gsh.to(dev, dt)).sum()
+        if aug:
+            loss = loss + (zaug * gza.to(dev, dt)).sum()
+        loss.backward()
+        outs = dict(z=z, sc=sc, sh=sh, mean=mean, var=var, dx1=tx1.grad, dw=tw.grad, db=tb.grad, dgamma=tg.grad,
+                    dbeta=tbeta.grad)
+        if aug:
+            outs['zaug'] = zaug
+        if tx2 is not None:
+            outs['dx2'] = tx2.grad
+        if ta1 is not None:
+            outs['ds1'], outs['dh1'] = ta1[0].grad, ta1[1].grad
+        if ta2 is not None:
+            outs['ds2'], outs['dh2'] = ta2[0].grad, ta2[1].grad
+        return outs
+
+    got = run(K, torch.float32, DEV)
+    ref = run(R, torch.float64, 'cpu')
+    for k, v in ref.items():
+        # fp32 MFMA dot products over <=256 channels, sums over <= n*T*V positions: 1e-5 relative L2
+        tol = 2e-5 if k not in ('db',) else 2e-4      # db of a conv feeding BN is ~0 analytically (cancellation)
+        err = rel(got[k].detach().cpu(), v.detach())
+        if k == 'db':
+            err = maxabs(got[k].detach().cpu(), v.detach()) / (ref['dw'].abs().max().item() + 1e-30)
+        assert err < tol, (k, err)

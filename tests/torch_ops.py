@@ -24,12 +24,15 @@ def virt(x1, a1, x2, a2, relu):
     return F.relu(v) if relu else v
 
 
-def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, stats=True):
-    """1x1 channel mix over the virtual input (rows subsampled by ``stride``).
+def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, gamma=None, beta=None, eps=1e-5, n_affine=None,
+           want_bn=False):
+    """1x1 channel mix over the virtual input (rows subsampled by ``stride``), optionally followed by the
+    train-mode BN of its output expressed as a deferred affine.
 
-    Returns (z, zaug, mean, var): z (n,Co,T',V); zaug (n,Co,T') = mean_v z when ``aug``
-    (the dgmstcn global joint, tcn.py:409, by linearity of the 1x1 conv); mean/var are the
-    biased batch statistics of z over (n,T',V) — including the zaug column when ``aug``."""
+    Returns (z, zaug, scale, shift, mean, var): z (n,Co,T',V); zaug (n,Co,T') = mean_v z when ``aug`` (the
+    dgmstcn global joint, tcn.py:409, by linearity of the 1x1 conv).  With ``want_bn``: mean/var are the biased
+    batch statistics of z over (n,T',V) (including the zaug column when ``aug``), scale = gamma*rsqrt(var+eps),
+    shift = beta - mean*scale for channels < n_affine and (1, 0) for the rest."""
     v = virt(x1, a1, x2, a2, relu)
     if stride != 1:
         v = v[:, :, ::stride]
@@ -38,12 +41,22 @@ def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, stats=True):
     if bias is not None:
         z = z + _bc(bias)
     zaug = z.mean(-1) if aug else None
-    mean = var = None
-    if stats:
-        full = torch.cat([z, zaug[..., None]], -1) if aug else z
-        mean = full.mean((0, 2, 3))
-        var = full.var((0, 2, 3), unbiased=False)
-    return z, zaug, mean, var
+    if not want_bn:
+        return z, zaug, None, None, None, None
+    Co = z.shape[1]
+    if n_affine is None:
+        n_affine = Co if gamma is not None else 0
+    full = torch.cat([z, zaug[..., None]], -1) if aug else z
+    mean = full.mean((0, 2, 3))
+    var = full.var((0, 2, 3), unbiased=False)
+    g = gamma if gamma is not None else z.new_ones(n_affine)
+    b = beta if beta is not None else z.new_zeros(n_affine)
+    sc = g * torch.rsqrt(var[:n_affine] + eps)
+    sh = b - mean[:n_affine] * sc
+    if n_affine < Co:
+        sc = torch.cat([sc, z.new_ones(Co - n_affine)])
+        sh = torch.cat([sh, z.new_zeros(Co - n_affine)])
+    return z, zaug, sc, sh, mean.detach(), var.detach()
 
 
 def bn_affine(mean, var, weight, bias, eps):
