@@ -1,7 +1,7 @@
 // K-B: dynamic-semantic adjacency build (reference: pyskl/models/gcns/utils/gcn.py:2240-2337).
 //
-//   xbar (n,Ci,V)  ->  Ahat (n, 3*mid, V, V)
-//   a_k = W1 xbar + b1, b_k = W2 xbar + b2 (k=0,1);  s[c,v] = Wse[c*P+tau(v)] xbar[:,v] + bse[c*P+tau(v)]
+//   proj (n,9*mid,V) = [W1;W2;Wse] xbar + bias (the K-C kernel on the time-mean xbar)  ->  Ahat (n, 3*mid, V, V)
+//   a_k = proj rows k*mid+c, b_k = rows 2mid+k*mid+c (k=0,1);  s[c,v] = proj row 4mid + c*P+tau(v)
 //   D0 = a0[u]-b0[w];  D1 = We[eps(u,w)] (a1[u]-b1[w]) + be[eps(u,w)];  D2 = s[u]-s[w]
 //   G_k[u,w] = sum_c x1_k[c,u] x2_k[c,w]  (x1=(a0,a1,s), x2=(b0,b1,s): conv2_se is dead, quirk Q1)
 //   Ahat[k,c,u,w] = A[k,u,w] + alpha_k tanh(D_k[c,u,w]) + beta_k softmax_u(G_k)[u,w]
@@ -11,8 +11,8 @@
 // everything V x V in LDS, indexes the typed weight slice directly with tau(v) / eps(u,w) (625-entry
 // integer tables), and only Ahat ever reaches HBM (coalesced).  Bound: HBM writes of Ahat.
 //
-// Backward = the same recompute + the chain rule in LDS (k_dynadj_bwd), and one small reduction kernel
-// for the projection weight gradients (k_dynadj_wgrad).
+// Backward = the same recompute + the chain rule in LDS (k_dynadj_bwd); the projection weights' gradients come from
+// the K-C backward applied to dproj.
 #include "common.h"
 
 namespace {
@@ -24,56 +24,42 @@ struct DynDims {
   int n, Ci, mid, V, P, E;
 };
 
-// LDS carve (floats): xb[Ci*V] | X[5*mid*V] | G[3*V*V] | col[3*V*2]
-__device__ __forceinline__ int lds_X(const DynDims& d) { return d.Ci * d.V; }
+// LDS carve (floats): X[5*mid*V] | G[3*V*V] | col[3*V*2] | We[E*mid*mid] be[E*mid] | (bwd: SC[3*V*V] dX[5*mid*V])
+__device__ __forceinline__ int lds_X(const DynDims& d) { return 0; }
 __device__ __forceinline__ int lds_G(const DynDims& d) { return lds_X(d) + 5 * d.mid * d.V; }
 __device__ __forceinline__ int lds_col(const DynDims& d) { return lds_G(d) + KSUB * d.V * d.V; }
-__device__ __forceinline__ int lds_end(const DynDims& d) { return lds_col(d) + KSUB * d.V * 2; }
+__device__ __forceinline__ int lds_We(const DynDims& d) { return lds_col(d) + KSUB * d.V * 2; }
+__device__ __forceinline__ int lds_end(const DynDims& d) { return lds_We(d) + d.E * d.mid * d.mid + d.E * d.mid; }
 
 // X slot of x1_k / x2_k :  X[0]=a0 X[1]=a1 X[2]=s X[3]=b0 X[4]=b1
 __device__ __forceinline__ int slot_x1(int k) { return k; }
 __device__ __forceinline__ int slot_x2(int k) { return k < 2 ? 3 + k : 2; }
 
-// Steps shared by forward and backward: xbar -> projections -> Gram -> column softmax (in LDS).
-__device__ void dyn_prepare(const DynDims& d, float* lds, const float* __restrict__ xbar_n,
-                            const float* __restrict__ w1, const float* __restrict__ b1,
-                            const float* __restrict__ w2, const float* __restrict__ b2,
-                            const float* __restrict__ wse, const float* __restrict__ bse,
+// Steps shared by forward and backward: projections -> LDS, edge-typed weights -> LDS, Gram, column softmax.
+// proj_n (9*mid, V): rows [a (2mid) | b (2mid) | s-typed (mid*P, row c*P+p)] = the three mean-pooled 1x1 convs
+// (conv1 / conv2 / conv1_se of gcn.py:2248-2253) evaluated by the K-C kernel on xbar; the node-typed select
+// (gcn.py:2256-2259) is the row pick c*P+tau(v) done here.
+__device__ void dyn_prepare(const DynDims& d, float* lds, const float* __restrict__ proj_n,
+                            const float* __restrict__ we, const float* __restrict__ be,
                             const int* __restrict__ node_type) {
   const int tid = threadIdx.x;
-  const int Ci = d.Ci, mid = d.mid, V = d.V;
-  float* xb = lds;
+  const int mid = d.mid, V = d.V;
   float* X = lds + lds_X(d);
   float* G = lds + lds_G(d);
   float* col = lds + lds_col(d);
-  for (int i = tid; i < Ci * V; i += NT) xb[i] = xbar_n[i];
-  __syncthreads();
-  // projections: q in [0,5mid): [0,2mid) a, [2mid,4mid) b, [4mid,5mid) s (node-typed row)
+  float* Wl = lds + lds_We(d);
   for (int o = tid; o < 5 * mid * V; o += NT) {
     const int q = o / V, v = o - q * V;
-    const float* wr;
-    float acc;
-    int slot, c;
-    if (q < 2 * mid) {
-      wr = w1 + (size_t)q * Ci;
-      acc = b1[q];
-      slot = q / mid;
-      c = q - slot * mid;
-    } else if (q < 4 * mid) {
-      const int r = q - 2 * mid;
-      wr = w2 + (size_t)r * Ci;
-      acc = b2[r];
-      slot = 3 + r / mid;
-      c = r % mid;
-    } else {
-      c = q - 4 * mid;
-      const int row = c * d.P + node_type[v];
-      wr = wse + (size_t)row * Ci;
-      acc = bse[row];
-      slot = 2;
-    }
-    for (int ci = 0; ci < Ci; ++ci) acc = fmaf(wr[ci], xb[ci * V + v], acc);
-    X[(slot * mid + c) * V + v] = acc;
+    int slot, c, row;
+    if (q < 2 * mid) { slot = q / mid; c = q - slot * mid; row = q; }
+    else if (q < 4 * mid) { const int r = q - 2 * mid; slot = 3 + r / mid; c = r % mid; row = q; }
+    else { c = q - 4 * mid; slot = 2; row = 4 * mid + c * d.P + node_type[v]; }
+    X[(slot * mid + c) * V + v] = proj_n[row * V + v];
+  }
+  {
+    const int nw = d.E * mid * mid, nb = d.E * mid;
+    for (int i = tid; i < nw; i += NT) Wl[i] = we[i];
+    for (int i = tid; i < nb; i += NT) Wl[nw + i] = be[i];
   }
   __syncthreads();
   for (int i = tid; i < KSUB * V * V; i += NT) {
@@ -104,70 +90,68 @@ __device__ void dyn_prepare(const DynDims& d, float* lds, const float* __restric
   __syncthreads();
 }
 
-// D_k[c,u,w] before tanh
-__device__ __forceinline__ float dyn_D(const DynDims& d, const float* X, const float* __restrict__ we,
-                                       const float* __restrict__ be, const int* __restrict__ edge_type, int k, int c,
-                                       int u, int w) {
+// D_k[c,u,w] before tanh (Wl = edge-typed weights then biases, in LDS)
+__device__ __forceinline__ float dyn_D(const DynDims& d, const float* X, const float* Wl,
+                                       const int* __restrict__ edge_type, int k, int c, int u, int w) {
   const int mid = d.mid, V = d.V;
   if (k == 0) return X[(0 * mid + c) * V + u] - X[(3 * mid + c) * V + w];
   if (k == 2) return X[(2 * mid + c) * V + u] - X[(2 * mid + c) * V + w];
   const int e = edge_type[u * V + w];
-  const float* wr = we + (size_t)(e * mid + c) * mid;
-  float acc = be[e * mid + c];
+  const float* wr = Wl + (e * mid + c) * mid;
+  float acc = Wl[d.E * mid * mid + e * mid + c];
   const float* a1 = X + 1 * mid * V;
   const float* b1 = X + 4 * mid * V;
   for (int cc = 0; cc < mid; ++cc) acc = fmaf(wr[cc], a1[cc * V + u] - b1[cc * V + w], acc);
   return acc;
 }
 
-__global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d, const float* __restrict__ xbar,
+__global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d, const float* __restrict__ proj,
                                                    const float* __restrict__ A, const float* __restrict__ alpha,
-                                                   const float* __restrict__ beta, const float* __restrict__ w1,
-                                                   const float* __restrict__ b1, const float* __restrict__ w2,
-                                                   const float* __restrict__ b2, const float* __restrict__ wse,
-                                                   const float* __restrict__ bse, const float* __restrict__ we,
+                                                   const float* __restrict__ beta, const float* __restrict__ we,
                                                    const float* __restrict__ be, const int* __restrict__ node_type,
                                                    const int* __restrict__ edge_type, float* __restrict__ ahat) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n = blockIdx.x;
   const int mid = d.mid, V = d.V, VV = V * V;
-  dyn_prepare(d, lds, xbar + (size_t)n * d.Ci * V, w1, b1, w2, b2, wse, bse, node_type);
+  dyn_prepare(d, lds, proj + (size_t)n * 9 * mid * V, we, be, node_type);
   const float* X = lds + lds_X(d);
   const float* Sm = lds + lds_G(d);
+  const float* Wl = lds + lds_We(d);
   float* out = ahat + (size_t)n * KSUB * mid * VV;
   const int total = KSUB * mid * VV;
+  const float al0 = alpha[0], al1 = alpha[1], al2 = alpha[2], be0 = beta[0], be1 = beta[1], be2 = beta[2];
   for (int i = threadIdx.x; i < total; i += NT) {
     const int k = i / (mid * VV);
     int r = i - k * mid * VV;
     const int c = r / VV;
     r -= c * VV;
     const int u = r / V, w = r - u * V;
-    const float dk = dyn_D(d, X, we, be, edge_type, k, c, u, w);
-    out[i] = A[k * VV + r] + alpha[k] * tanhf(dk) + beta[k] * Sm[k * VV + r];
+    const float dk = dyn_D(d, X, Wl, edge_type, k, c, u, w);
+    const float al = k == 0 ? al0 : (k == 1 ? al1 : al2), bt = k == 0 ? be0 : (k == 1 ? be1 : be2);
+    out[i] = A[k * VV + r] + al * tanhf(dk) + bt * Sm[k * VV + r];
   }
 }
 
 // Backward, per sample.  Workspace `dd` (n,3,mid,V,V) receives dD_k (k=1: later d(delta)) so the
 // row/column reductions and the per-edge-class weight gradient can read it back; it aliases nothing.
-// Outputs: dproj (n,5mid,V) rows [a | b | s]; dxbar (n,Ci,V); pA (n,3,V,V) = sum_c dAhat;
+// Outputs: dproj (n,9mid,V) (typed rows: only row c*P+tau(v) of joint v is non-zero); pA (n,3,V,V) = sum_c dAhat;
 // pab (n,6) = [dalpha_k | dbeta_k] partials; dwe (E*mid,mid) / dbe (E*mid) accumulated with float atomics
 // (zeroed by the caller).  pair_order / class_start: joint pairs sorted by edge class (host-built constant).
 __global__ __launch_bounds__(NT) void k_dynadj_bwd(
-    DynDims d, const float* __restrict__ xbar, const float* __restrict__ alpha, const float* __restrict__ beta,
-    const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-    const float* __restrict__ b2, const float* __restrict__ wse, const float* __restrict__ bse,
+    DynDims d, const float* __restrict__ proj, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ we, const float* __restrict__ be, const int* __restrict__ node_type,
     const int* __restrict__ edge_type, const int* __restrict__ pair_order, const int* __restrict__ class_start,
-    const float* __restrict__ dahat, float* dd, float* __restrict__ dproj, float* __restrict__ dxbar,
-    float* __restrict__ pA, float* __restrict__ pab, float* __restrict__ dwe, float* __restrict__ dbe) {
+    const float* __restrict__ dahat, float* dd, float* __restrict__ dproj, float* __restrict__ pA,
+    float* __restrict__ pab, float* __restrict__ dwe, float* __restrict__ dbe) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[6][NT / DSGCN_WAVE];
   const int tid = threadIdx.x;
   const int n = blockIdx.x;
-  const int Ci = d.Ci, mid = d.mid, V = d.V, VV = V * V, E = d.E;
-  dyn_prepare(d, lds, xbar + (size_t)n * Ci * V, w1, b1, w2, b2, wse, bse, node_type);
+  const int mid = d.mid, V = d.V, VV = V * V, E = d.E;
+  dyn_prepare(d, lds, proj + (size_t)n * 9 * mid * V, we, be, node_type);
   const float* X = lds + lds_X(d);
   const float* Sm = lds + lds_G(d);
+  const float* Wl = lds + lds_We(d);
   float* SC = lds + lds_end(d);       // [3][V][V]  sum_c dAhat, then dG
   float* dX = SC + KSUB * VV;         // [5][mid][V] grads of a0,a1,s,b0,b1
   const float* g_n = dahat + (size_t)n * KSUB * mid * VV;
@@ -179,12 +163,20 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     const int k = i / VV, r = i - k * VV, u = r / V, w = r - u * V;
     const float al = alpha[k];
     float sc = 0.f, pa = 0.f;
-    for (int c = 0; c < mid; ++c) {
-      const float g = g_n[(k * mid + c) * VV + r];
-      const float th = tanhf(dyn_D(d, X, we, be, edge_type, k, c, u, w));
-      sc += g;
-      pa = fmaf(th, g, pa);
-      dd_n[(k * mid + c) * VV + r] = al * (1.f - th * th) * g;
+    for (int c0 = 0; c0 < mid; c0 += 8) {
+      float gv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] = (c0 + j < mid) ? g_n[(k * mid + c0 + j) * VV + r] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        if (c < mid) {
+          const float th = tanhf(dyn_D(d, X, Wl, edge_type, k, c, u, w));
+          sc += gv[j];
+          pa = fmaf(th, gv[j], pa);
+          dd_n[(k * mid + c) * VV + r] = al * (1.f - th * th) * gv[j];
+        }
+      }
     }
     SC[i] = sc;
     pal0 += (k == 0) ? pa : 0.f;
@@ -224,12 +216,21 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     for (int o = tid; o < E * mid * mid; o += NT) {
       const int e = o / (mid * mid), rr = o - e * mid * mid, c = rr / mid, cc = rr - c * mid;
       float acc = 0.f, accb = 0.f;
-      for (int p = class_start[e]; p < class_start[e + 1]; ++p) {
-        const int r = pair_order[p];
-        const int u = r / V, w = r - u * V;
-        const float g = dd1[c * VV + r];
-        acc = fmaf(g, a1[cc * V + u] - bb1[cc * V + w], acc);
-        accb += g;
+      const int p0 = class_start[e], p1 = class_start[e + 1];
+      for (int pb = p0; pb < p1; pb += 8) {
+        float gv[8];
+        int rv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          rv[j] = (pb + j < p1) ? pair_order[pb + j] : 0;
+          gv[j] = (pb + j < p1) ? dd1[c * VV + rv[j]] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int u = rv[j] / V, w = rv[j] - u * V;
+          acc = fmaf(gv[j], a1[cc * V + u] - bb1[cc * V + w], acc);
+          accb += gv[j];
+        }
       }
       atomicAdd(dwe + o, acc);
       if (cc == 0) atomicAdd(dbe + e * mid + c, accb);
@@ -242,13 +243,21 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     for (int r = tid; r < VV; r += NT) {
       const int e = edge_type[r];
       float dv[32], out[32];
-      for (int c = 0; c < mid; ++c) dv[c] = dd1[c * VV + r];
-      for (int cc = 0; cc < mid; ++cc) {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) dv[c] = (c < mid) ? dd1[c * VV + r] : 0.f;
+#pragma unroll
+      for (int cc = 0; cc < 32; ++cc) {
         float acc = 0.f;
-        for (int c = 0; c < mid; ++c) acc = fmaf(we[(size_t)(e * mid + c) * mid + cc], dv[c], acc);
+        if (cc < mid) {
+#pragma unroll
+          for (int c = 0; c < 32; ++c)
+            if (c < mid) acc = fmaf(Wl[(e * mid + c) * mid + cc], dv[c], acc);
+        }
         out[cc] = acc;
       }
-      for (int cc = 0; cc < mid; ++cc) dd1[cc * VV + r] = out[cc];
+#pragma unroll
+      for (int cc = 0; cc < 32; ++cc)
+        if (cc < mid) dd1[cc * VV + r] = out[cc];
     }
   }
   __syncthreads();
@@ -257,8 +266,16 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     const int k = o / (mid * V), rr = o - k * mid * V, c = rr / V, j = rr - c * V;
     const float* dk = dd_n + (size_t)(k * mid + c) * VV;
     float rs = 0.f, cs = 0.f;
-    for (int w = 0; w < V; ++w) rs += dk[j * V + w];
-    for (int u = 0; u < V; ++u) cs += dk[u * V + j];
+    {
+      float rv[32], cv[32];
+#pragma unroll
+      for (int w = 0; w < 32; ++w) {
+        rv[w] = (w < V) ? dk[j * V + w] : 0.f;
+        cv[w] = (w < V) ? dk[w * V + j] : 0.f;
+      }
+#pragma unroll
+      for (int w = 0; w < 32; ++w) { rs += rv[w]; cs += cv[w]; }
+    }
     const float* x1 = X + (slot_x1(k) * mid + c) * V;
     const float* x2 = X + (slot_x2(k) * mid + c) * V;
     const float* dG = SC + k * VV;
@@ -273,29 +290,18 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     }
   }
   __syncthreads();
-  // dproj rows [a (2mid) | b (2mid) | s (mid)]
-  float* dp_n = dproj + (size_t)n * 5 * mid * V;
-  for (int o = tid; o < 5 * mid * V; o += NT) {
+  // dproj rows [a (2mid) | b (2mid) | s-typed (mid*P)]
+  float* dp_n = dproj + (size_t)n * 9 * mid * V;
+  for (int o = tid; o < 9 * mid * V; o += NT) {
     const int q = o / V, v = o - q * V;
-    int slot, c;
-    if (q < 2 * mid) { slot = q / mid; c = q - slot * mid; }
-    else if (q < 4 * mid) { const int r = q - 2 * mid; slot = 3 + r / mid; c = r % mid; }
-    else { slot = 2; c = q - 4 * mid; }
-    dp_n[o] = dX[(slot * mid + c) * V + v];
-  }
-  // dxbar[ci,v] = sum_q Wrow(q,v)[ci] * dX(q)[v]     thread = (v, ci), ci fastest (coalesced weight rows)
-  float* dxb_n = dxbar + (size_t)n * Ci * V;
-  for (int o = tid; o < Ci * V; o += NT) {
-    const int v = o / Ci, ci = o - v * Ci;
-    const int tv = node_type[v];
-    float acc = 0.f;
-    for (int q = 0; q < 2 * mid; ++q) {
-      const int slot = q / mid, c = q - slot * mid;
-      acc = fmaf(w1[(size_t)q * Ci + ci], dX[(slot * mid + c) * V + v], acc);
-      acc = fmaf(w2[(size_t)q * Ci + ci], dX[((3 + slot) * mid + c) * V + v], acc);
+    float val;
+    if (q < 2 * mid) { const int slot = q / mid, c = q - slot * mid; val = dX[(slot * mid + c) * V + v]; }
+    else if (q < 4 * mid) { const int r = q - 2 * mid; val = dX[((3 + r / mid) * mid + r % mid) * V + v]; }
+    else {
+      const int rr = q - 4 * mid, c = rr / d.P, p = rr - c * d.P;
+      val = (node_type[v] == p) ? dX[(2 * mid + c) * V + v] : 0.f;
     }
-    for (int c = 0; c < mid; ++c) acc = fmaf(wse[(size_t)(c * d.P + tv) * Ci + ci], dX[(2 * mid + c) * V + v], acc);
-    dxb_n[ci * V + v] = acc;
+    dp_n[o] = val;
   }
   // block-reduce the six scalar partials
   float vals[6] = {pal0, pal1, pal2, pbe0, pbe1, pbe2};
@@ -313,52 +319,8 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
   }
 }
 
-// Projection weight gradients (reduction over samples and joints):
-//   rows r in [0,9mid): [0,2mid) W1, [2mid,4mid) W2, [4mid,9mid) Wse (row c*P+p takes joints with tau(v)=p)
-//   dW[r,ci] = sum_n sum_v dproj[n,q(r),v] * [type ok] * xbar[n,ci,v];  dbias[r] = sum_n sum_v dproj * [type ok]
-// grid = (ceil(R*Ci / NT), n_chunks); float atomics into zeroed dw (9mid,Ci) and db (9mid).
-__global__ __launch_bounds__(NT) void k_dynadj_wgrad(DynDims d, const float* __restrict__ xbar,
-                                                     const float* __restrict__ dproj,
-                                                     const int* __restrict__ node_type, float* __restrict__ dw,
-                                                     float* __restrict__ db, int n_per_chunk) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int Ci = d.Ci, mid = d.mid, V = d.V, P = d.P;
-  const int R = 9 * mid;
-  float* xb = lds;                 // [Ci][V]
-  float* dp = lds + Ci * V;        // [5mid][V]
-  const int o = blockIdx.x * NT + threadIdx.x;
-  const bool live = o < R * Ci;
-  const int r = live ? o / Ci : 0, ci = live ? o - r * Ci : 0;
-  int q, typ = -1;
-  if (r < 4 * mid) q = r;
-  else { const int rr = r - 4 * mid; q = 4 * mid + rr / P; typ = rr % P; }
-  const int n0 = blockIdx.y * n_per_chunk;
-  const int n1 = min(d.n, n0 + n_per_chunk);
-  float acc = 0.f, accb = 0.f;
-  for (int n = n0; n < n1; ++n) {
-    __syncthreads();
-    const float* xs = xbar + (size_t)n * Ci * V;
-    const float* ds = dproj + (size_t)n * 5 * mid * V;
-    for (int i = threadIdx.x; i < Ci * V; i += NT) xb[i] = xs[i];
-    for (int i = threadIdx.x; i < 5 * mid * V; i += NT) dp[i] = ds[i];
-    __syncthreads();
-    if (live) {
-      for (int v = 0; v < V; ++v) {
-        float g = dp[q * V + v];
-        if (typ >= 0 && node_type[v] != typ) g = 0.f;
-        acc = fmaf(g, xb[ci * V + v], acc);
-        accb += g;
-      }
-    }
-  }
-  if (live) {
-    atomicAdd(dw + o, acc);
-    if (ci == 0) atomicAdd(db + r, accb);
-  }
-}
-
-size_t dyn_lds_bytes(int Ci, int mid, int V, bool bwd) {
-  size_t f = (size_t)Ci * V + 5 * (size_t)mid * V + 3 * (size_t)V * V + 3 * (size_t)V * 2;
+size_t dyn_lds_bytes(int mid, int V, int E, bool bwd) {
+  size_t f = 5 * (size_t)mid * V + 3 * (size_t)V * V + 3 * (size_t)V * 2 + (size_t)E * mid * mid + (size_t)E * mid;
   if (bwd) f += 3 * (size_t)V * V + 5 * (size_t)mid * V;
   return f * sizeof(float);
 }
@@ -367,51 +329,40 @@ size_t dyn_lds_bytes(int Ci, int mid, int V, bool bwd) {
 
 extern "C" {
 
-int dsgcn_dynadj_fwd(const float* xbar, const float* A, const float* alpha, const float* beta, const float* w1,
-                     const float* b1, const float* w2, const float* b2, const float* wse, const float* bse,
-                     const float* we, const float* be, const int* node_type, const int* edge_type, float* ahat,
-                     int n, int Ci, int mid, int V, int P, int E, void* stream) {
-  if (!xbar || !A || !ahat || n <= 0 || Ci <= 0 || mid <= 0) return DSGCN_EINVAL;
+int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, const float* beta, const float* we,
+                     const float* be, const int* node_type, const int* edge_type, float* ahat, int n, int mid, int V,
+                     int P, int E, void* stream) {
+  if (!proj || !A || !ahat || !we || !be || n <= 0 || mid <= 0) return DSGCN_EINVAL;
   if (V > 32 || mid > 32) return DSGCN_EUNSUPPORTED;
-  const size_t lds = dyn_lds_bytes(Ci, mid, V, false);
+  const size_t lds = dyn_lds_bytes(mid, V, E, false);
   if (lds > 160 * 1024) return DSGCN_EUNSUPPORTED;
-  DynDims d{n, Ci, mid, V, P, E};
+  DynDims d{n, 0, mid, V, P, E};
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(k_dynadj_fwd, dim3(n), dim3(NT), lds, (hipStream_t)stream, d, xbar, A, alpha, beta, w1, b1, w2, b2,
-                     wse, bse, we, be, node_type, edge_type, ahat);
+  hipLaunchKernelGGL(k_dynadj_fwd, dim3(n), dim3(NT), lds, (hipStream_t)stream, d, proj, A, alpha, beta, we, be,
+                     node_type, edge_type, ahat);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
 
-int dsgcn_dynadj_bwd(const float* xbar, const float* alpha, const float* beta, const float* w1, const float* b1,
-                     const float* w2, const float* b2, const float* wse, const float* bse, const float* we,
-                     const float* be, const int* node_type, const int* edge_type, const int* pair_order,
-                     const int* class_start, const float* dahat, float* dd_ws, float* dproj, float* dxbar, float* pA,
-                     float* pab, float* dwe, float* dbe, float* dwproj, float* dbproj, int n, int Ci, int mid, int V,
-                     int P, int E, void* stream) {
-  if (!xbar || !dahat || !dd_ws || !dproj || !dxbar || !pA || !pab || !dwe || !dbe || !dwproj || !dbproj)
-    return DSGCN_EINVAL;
+int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
+                     const int* node_type, const int* edge_type, const int* pair_order, const int* class_start,
+                     const float* dahat, float* dd_ws, float* dproj, float* pA, float* pab, float* dwe, float* dbe,
+                     int n, int mid, int V, int P, int E, void* stream) {
+  if (!proj || !dahat || !dd_ws || !dproj || !pA || !pab || !dwe || !dbe) return DSGCN_EINVAL;
   if (V > 32 || mid > 32) return DSGCN_EUNSUPPORTED;
-  const size_t lds = dyn_lds_bytes(Ci, mid, V, true);
+  const size_t lds = dyn_lds_bytes(mid, V, E, true);
   if (lds > 160 * 1024) return DSGCN_EUNSUPPORTED;
-  DynDims d{n, Ci, mid, V, P, E};
+  DynDims d{n, 0, mid, V, P, E};
   hipStream_t st = (hipStream_t)stream;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(k_dynadj_bwd, dim3(n), dim3(NT), lds, st, d, xbar, alpha, beta, w1, b1, w2, b2, wse, bse, we, be,
-                     node_type, edge_type, pair_order, class_start, dahat, dd_ws, dproj, dxbar, pA, pab, dwe, dbe);
-  DSGCN_LAUNCH_CHECK();
-  const int R = 9 * mid;
-  const int chunks = n >= 16 ? 16 : n;
-  const int per = (n + chunks - 1) / chunks;
-  const size_t lds2 = ((size_t)Ci * V + 5 * (size_t)mid * V) * sizeof(float);
-  dim3 grid((unsigned)((R * Ci + NT - 1) / NT), (unsigned)((n + per - 1) / per));
-  hipLaunchKernelGGL(k_dynadj_wgrad, grid, dim3(NT), lds2, st, d, xbar, dproj, node_type, dwproj, dbproj, per);
+  hipLaunchKernelGGL(k_dynadj_bwd, dim3(n), dim3(NT), lds, st, d, proj, alpha, beta, we, be, node_type, edge_type,
+                     pair_order, class_start, dahat, dd_ws, dproj, pA, pab, dwe, dbe);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

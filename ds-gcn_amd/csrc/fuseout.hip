@@ -1,0 +1,145 @@
+// Block output: the one place an activation is materialised.
+//   out[n,c,t,v] = relu?( x1*s1[c]+h1[c]  (+ x2*s2[c]+h2[c] | + x2) )      xbar[n,c,v] = mean_t out[n,c,t,v]
+// Replaces BatchNorm2d (tcn.py:427 / gcn.py:2365) + residual add + ReLU (dgstgcn.py:63-65) and the
+// x.mean(dim=-2) of the NEXT block's dynamic adjacency (gcn.py:2246) — one read of each operand, one write.
+// One wave per (n,c) plane: coalesced 16-B loads, the plane passes through LDS only to form the per-joint time mean.
+// HBM-bound: 4*(2 or 3)*T*V bytes per plane.
+//
+// Backward: dv = (dout + dxbar/T) * 1[pre>0];  dx1 = dv*s1, dx2 = dv*s2 (or dv);
+//           per-plane partial sums of dv*x1, dv, dv*x2  (-> d s1, d h1 = d h2, d s2 after the sum over n).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x1, const float* __restrict__ s1,
+                                                     const float* __restrict__ h1, const float* __restrict__ x2,
+                                                     const float* __restrict__ s2, const float* __restrict__ h2,
+                                                     int relu, float* __restrict__ out, float* __restrict__ xbar, int C,
+                                                     int T, int V, int vec) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const int L = T * V;
+  const float a1 = s1 ? s1[c] : 1.f, b1 = s1 ? h1[c] : 0.f;
+  const float a2 = s2 ? s2[c] : 1.f, b2 = s2 ? h2[c] : 0.f;
+  const float* p1 = x1 + (size_t)plane * L;
+  const float* p2 = x2 ? x2 + (size_t)plane * L : nullptr;
+  float* po = out + (size_t)plane * L;
+  if (vec) {
+    const int L4 = L >> 2;
+    const f32x4* q1 = reinterpret_cast<const f32x4*>(p1);
+    const f32x4* q2 = reinterpret_cast<const f32x4*>(p2);
+    f32x4* qo = reinterpret_cast<f32x4*>(po);
+    f32x4* ql = reinterpret_cast<f32x4*>(lds);
+#pragma unroll 4
+    for (int i = lane; i < L4; i += 64) {
+      f32x4 v = q1[i];
+      v.x = fmaf(v.x, a1, b1); v.y = fmaf(v.y, a1, b1); v.z = fmaf(v.z, a1, b1); v.w = fmaf(v.w, a1, b1);
+      if (p2) {
+        const f32x4 r = q2[i];
+        v.x += fmaf(r.x, a2, b2); v.y += fmaf(r.y, a2, b2); v.z += fmaf(r.z, a2, b2); v.w += fmaf(r.w, a2, b2);
+      }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      qo[i] = v;
+      if (xbar) ql[i] = v;
+    }
+  } else {
+    for (int i = lane; i < L; i += 64) {
+      float v = fmaf(p1[i], a1, b1);
+      if (p2) v += fmaf(p2[i], a2, b2);
+      if (relu) v = fmaxf(v, 0.f);
+      po[i] = v;
+      if (xbar) lds[i] = v;
+    }
+  }
+  if (xbar) {
+    wave_lds_sync();
+    if (lane < V) {
+      float s = 0.f;
+      for (int t = 0; t < T; ++t) s += lds[t * V + lane];
+      xbar[(size_t)plane * V + lane] = s / (float)T;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x1, const float* __restrict__ s1,
+                                                     const float* __restrict__ h1, const float* __restrict__ x2,
+                                                     const float* __restrict__ s2, const float* __restrict__ h2,
+                                                     int relu, const float* __restrict__ dout,
+                                                     const float* __restrict__ dxbar, float* __restrict__ dx1,
+                                                     float* __restrict__ dx2, float* __restrict__ part, int C, int T,
+                                                     int V) {
+  __shared__ float dxb[32];
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const int L = T * V;
+  const float a1 = s1 ? s1[c] : 1.f, b1 = s1 ? h1[c] : 0.f;
+  const float a2 = s2 ? s2[c] : 1.f, b2 = s2 ? h2[c] : 0.f;
+  if (lane < V) dxb[lane] = dxbar ? dxbar[(size_t)plane * V + lane] / (float)T : 0.f;
+  wave_lds_sync();
+  const float* __restrict__ p1 = x1 + (size_t)plane * L;
+  const float* __restrict__ p2 = x2 ? x2 + (size_t)plane * L : nullptr;
+  const float* __restrict__ pg = dout ? dout + (size_t)plane * L : nullptr;
+  float* __restrict__ o1 = dx1 + (size_t)plane * L;
+  float* __restrict__ o2 = dx2 ? dx2 + (size_t)plane * L : nullptr;
+  float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+  int v = lane % V;                      // joint index of element `lane`; advances by 64 % V per iteration
+  const int step = 64 % V;
+#pragma unroll 5
+  for (int i = lane; i < L; i += 64) {
+    const float xa = p1[i];
+    const float xb = p2 ? p2[i] : 0.f;
+    float pre = fmaf(xa, a1, b1);
+    if (p2) pre += fmaf(xb, a2, b2);
+    float g = (pg ? pg[i] : 0.f) + dxb[v];
+    if (relu && !(pre > 0.f)) g = 0.f;
+    o1[i] = g * a1;
+    if (o2) o2[i] = g * a2;
+    u0 = fmaf(g, xa, u0);
+    u1 += g;
+    u2 = fmaf(g, xb, u2);
+    v += step;
+    if (v >= V) v -= V;
+  }
+  if (part) {
+    u0 = wave_sum(u0);
+    u1 = wave_sum(u1);
+    u2 = wave_sum(u2);
+    if (lane == 0) {
+      part[(size_t)plane * 3 + 0] = u0;
+      part[(size_t)plane * 3 + 1] = u1;
+      part[(size_t)plane * 3 + 2] = u2;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                       const float* h2, int relu, float* out, float* xbar, int n, int C, int T, int V, void* stream) {
+  if (!x1 || !out || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (s1 && !h1) || (s2 && !h2)) return DSGCN_EINVAL;
+  const int vec = ((T * V) % 4 == 0) ? 1 : 0;
+  const size_t lds = xbar ? (size_t)T * V * sizeof(float) : 0;
+  if (lds > 64 * 1024) return DSGCN_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_fuse_out_fwd, dim3((unsigned)((long)n * C)), dim3(64), lds, (hipStream_t)stream, x1, s1, h1, x2,
+                     s2, h2, relu, out, xbar, C, T, V, vec);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// part: (n*C, 3) per-plane [sum dv*x1, sum dv, sum dv*x2]; dout or dxbar may be NULL (treated as zero).
+int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                       const float* h2, int relu, const float* dout, const float* dxbar, float* dx1, float* dx2,
+                       float* part, int n, int C, int T, int V, void* stream) {
+  if (!x1 || !dx1 || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (x2 && !dx2)) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_fuse_out_bwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, x1, s1, h1, x2,
+                     s2, h2, relu, dout, dxbar, dx1, dx2, part, C, T, V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -539,21 +539,26 @@ __global__ __launch_bounds__(256) void k_rowmean_stats(const float* __restrict__
 // per 32 channels (8 row-slices x 32 channels, coalesced 256-B rows), then a cross-slice LDS reduction.
 //   mean, var (biased) saved for backward; scale = gamma*rsqrt(var+eps); shift = beta - mean*scale.
 // gamma/beta NULL -> identity affine parameters; channels >= c_affine get the identity affine (1, 0).
-__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int nblk, int C, double count,
+__global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ partial, int nblk, int C, double count,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float* __restrict__ mean_out,
                                                      float* __restrict__ var_out, float* __restrict__ scale_out,
                                                      float* __restrict__ shift_out, int c_affine) {
-  __shared__ double red[8][32][2];
+  __shared__ double red[32][32][2];
   const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s = 0.0, q = 0.0;
   if (c < C) {
     const float2* p2 = reinterpret_cast<const float2*>(partial);
-    for (int b = slice; b < nblk; b += 8) {
-      const float2 v = p2[(size_t)b * C + c];
-      s += (double)v.x;
-      q += (double)v.y;
+    for (int b0 = slice; b0 < nblk; b0 += 32 * 4) {
+      float2 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int b = b0 + 32 * j;
+        v[j] = b < nblk ? p2[(size_t)b * C + c] : float2{0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s += (double)v[j].x; q += (double)v[j].y; }
     }
   }
   red[slice][cl][0] = s;
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
   __syncthreads();
   if (slice == 0 && c < C) {
 #pragma unroll
-    for (int i = 1; i < 8; ++i) { s += red[i][cl][0]; q += red[i][cl][1]; }
+    for (int i = 1; i < 32; ++i) { s += red[i][cl][0]; q += red[i][cl][1]; }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -581,18 +586,28 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
 }
 
 // Column sums of a row-major (R, C) fp32 matrix -> out (C), accumulated in fp64 (partial-buffer reductions).
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ src, int R, int C, float* __restrict__ out) {
-  __shared__ double red[8][32];
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, int R, int C, float* __restrict__ out) {
+  __shared__ double red[32][32];
   const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s = 0.0;
-  if (c < C)
-    for (int r = slice; r < R; r += 8) s += (double)src[(size_t)r * C + c];
+  if (c < C) {
+    for (int r0 = slice; r0 < R; r0 += 32 * 4) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = r0 + 32 * j;
+        v[j] = r < R ? src[(size_t)r * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += (double)v[j];
+    }
+  }
   red[slice][cl] = s;
   __syncthreads();
   if (slice == 0 && c < C) {
 #pragma unroll
-    for (int i = 1; i < 8; ++i) s += red[i][cl];
+    for (int i = 1; i < 32; ++i) s += red[i][cl];
     out[c] = (float)s;
   }
 }
@@ -1330,7 +1345,7 @@ int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const
                       float eps, float* mean_out, float* var_out, float* scale_out, float* shift_out, int c_affine,
                       void* stream) {
   if (!partial || !mean_out || !var_out || !scale_out || !shift_out || nblk <= 0 || C <= 0) return DSGCN_EINVAL;
-  hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk,
+  hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, partial, nblk,
                      C, count, gamma, beta, eps, mean_out, var_out, scale_out, shift_out, c_affine);
   DSGCN_LAUNCH_CHECK();
   return 0;
@@ -1339,7 +1354,7 @@ int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const
 // out[c] = sum_r src[r, c]  (fp64 accumulation).
 int dsgcn_colsum(const float* src, int R, int C, float* out, void* stream) {
   if (!src || !out || R <= 0 || C <= 0) return DSGCN_EINVAL;
-  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, (hipStream_t)stream, src, R, C, out);
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, src, R, C, out);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

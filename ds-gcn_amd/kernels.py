@@ -136,56 +136,56 @@ def _edge_class_lists(edge_type):
 
 
 class _DynAdj(torch.autograd.Function):
+    """proj (n, 9*mid, V) rows [a | b | s-typed] -> Ahat (n, 3*mid, V, V)."""
 
     @staticmethod
-    def forward(ctx, xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type):
-        _require_cuda(xbar, A)
-        xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be = [
-            _f32c(t) for t in (xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be)]
-        n, Ci, V = xbar.shape
-        mid = w1.shape[0] // 2
-        P = wse.shape[0] // mid
+    def forward(ctx, proj, A, alpha, beta, we, be, node_type, edge_type):
+        _require_cuda(proj, A)
+        proj, A, alpha, beta, we, be = [_f32c(t) for t in (proj, A, alpha, beta, we, be)]
+        n, R, V = proj.shape
+        mid = we.shape[1]
         E = we.shape[0] // mid
+        P = (R // mid - 4)
         assert A.shape[0] == 3 and node_type.dtype == torch.int32 and edge_type.dtype == torch.int32
-        ahat = torch.empty((n, 3 * mid, V, V), device=xbar.device, dtype=torch.float32)
-        rc = native.lib().dsgcn_dynadj_fwd(
-            _ptr(xbar), _ptr(A), _ptr(alpha), _ptr(beta), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(wse),
-            _ptr(bse), _ptr(we), _ptr(be), _ptr(node_type), _ptr(edge_type), _ptr(ahat), n, Ci, mid, V, P, E,
-            _stream())
+        ahat = torch.empty((n, 3 * mid, V, V), device=proj.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_dynadj_fwd(_ptr(proj), _ptr(A), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be),
+                                           _ptr(node_type), _ptr(edge_type), _ptr(ahat), n, mid, V, P, E, _stream())
         native.check(rc, 'dsgcn_dynadj_fwd')
-        ctx.save_for_backward(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type)
-        ctx.dims = (n, Ci, mid, V, P, E)
+        ctx.save_for_backward(proj, A, alpha, beta, we, be, node_type, edge_type)
+        ctx.dims = (n, mid, V, P, E)
         return ahat
 
     @staticmethod
     def backward(ctx, dahat):
-        xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type = ctx.saved_tensors
-        n, Ci, mid, V, P, E = ctx.dims
+        proj, A, alpha, beta, we, be, node_type, edge_type = ctx.saved_tensors
+        n, mid, V, P, E = ctx.dims
         dahat = _f32c(dahat)
-        dev = xbar.device
+        dev = proj.device
         order, start, _ = _edge_class_lists(edge_type)
         dd = torch.empty_like(dahat)
-        dproj = torch.empty((n, 5 * mid, V), device=dev, dtype=torch.float32)
-        dxbar = torch.empty_like(xbar)
+        dproj = torch.empty_like(proj)
         pA = torch.empty((n, 3, V, V), device=dev, dtype=torch.float32)
         pab = torch.empty((n, 6), device=dev, dtype=torch.float32)
-        zeros = torch.zeros(E * mid * mid + E * mid + 9 * mid * Ci + 9 * mid, device=dev, dtype=torch.float32)
-        dwe, dbe, dwp, dbp = torch.split(zeros, [E * mid * mid, E * mid, 9 * mid * Ci, 9 * mid])
+        zeros = torch.zeros(E * mid * mid + E * mid, device=dev, dtype=torch.float32)
+        dwe, dbe = torch.split(zeros, [E * mid * mid, E * mid])
         rc = native.lib().dsgcn_dynadj_bwd(
-            _ptr(xbar), _ptr(alpha), _ptr(beta), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(wse), _ptr(bse),
-            _ptr(we), _ptr(be), _ptr(node_type), _ptr(edge_type), _ptr(order), _ptr(start), _ptr(dahat), _ptr(dd),
-            _ptr(dproj), _ptr(dxbar), _ptr(pA), _ptr(pab), _ptr(dwe), _ptr(dbe), _ptr(dwp), _ptr(dbp),
-            n, Ci, mid, V, P, E, _stream())
+            _ptr(proj), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be), _ptr(node_type), _ptr(edge_type), _ptr(order),
+            _ptr(start), _ptr(dahat), _ptr(dd), _ptr(dproj), _ptr(pA), _ptr(pab), _ptr(dwe), _ptr(dbe), n, mid, V, P,
+            E, _stream())
         native.check(rc, 'dsgcn_dynadj_bwd')
         dA = colsum(pA)
         dab = colsum(pab)
-        dwp = dwp.view(9 * mid, Ci)
-        return (dxbar, dA, dab[:3], dab[3:], dwp[:2 * mid], dbp[:2 * mid], dwp[2 * mid:4 * mid], dbp[2 * mid:4 * mid],
-                dwp[4 * mid:], dbp[4 * mid:], dwe.view(E * mid, mid), dbe, None, None)
+        return dproj, dA, dab[:3], dab[3:], dwe.view(E * mid, mid), dbe, None, None
 
 
 def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type):
-    return _DynAdj.apply(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type)
+    """Dynamic adjacency.  The three mean-pooled projections (conv1/conv2/conv1_se) are one K-C launch on xbar
+    (a (n,Ci,1,V) "clip"), the rest is K-B."""
+    n, Ci, V = xbar.shape
+    w_all = torch.cat([w1, w2, wse], 0)
+    b_all = torch.cat([b1, b2, bse], 0)
+    proj = pwconv(xbar.unsqueeze(2), None, None, None, False, w_all, b_all, 1, False)[0]
+    return _DynAdj.apply(proj.view(n, w_all.shape[0], V), A, alpha, beta, we, be, node_type, edge_type)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -377,7 +377,46 @@ def aggregate_shared(zp, A, K, stats=True):
     return y, mean, var
 
 
+class _FuseOut(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, want_tmean):
+        _require_cuda(x1)
+        x1, s1, h1, x2, s2, h2 = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2)]
+        n, C, T, V = x1.shape
+        out = torch.empty_like(x1)
+        xbar = torch.empty((n, C, V), device=x1.device, dtype=torch.float32) if want_tmean else None
+        rc = native.lib().dsgcn_fuse_out_fwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu),
+                                             _ptr(out), _ptr(xbar), n, C, T, V, _stream())
+        native.check(rc, 'dsgcn_fuse_out_fwd')
+        ctx.save_for_backward(x1, s1, h1, x2, s2, h2)
+        ctx.relu = int(relu)
+        return out, xbar
+
+    @staticmethod
+    def backward(ctx, dout, dxbar):
+        x1, s1, h1, x2, s2, h2 = ctx.saved_tensors
+        n, C, T, V = x1.shape
+        dout, dxbar = _f32c(dout), _f32c(dxbar)
+        dx1 = torch.empty_like(x1)
+        dx2 = torch.empty_like(x2) if x2 is not None else None
+        need_part = s1 is not None or s2 is not None
+        part = torch.empty((n, C, 3), device=x1.device, dtype=torch.float32) if need_part else None
+        rc = native.lib().dsgcn_fuse_out_bwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
+                                             _ptr(dout), _ptr(dxbar), _ptr(dx1), _ptr(dx2), _ptr(part), n, C, T, V,
+                                             _stream())
+        native.check(rc, 'dsgcn_fuse_out_bwd')
+        ds1 = dh1 = ds2 = dh2 = None
+        if need_part:
+            red = colsum(part)
+            if s1 is not None:
+                ds1, dh1 = red[:, 0], red[:, 1]
+            if s2 is not None:
+                ds2, dh2 = red[:, 2], red[:, 1]
+        return dx1, ds1, dh1, dx2, ds2, dh2, None, None
+
+
 def fuse_out(x1, a1, x2, a2, relu, want_tmean=False):
-    _require_cuda(x1)
-    out = _virt(x1, a1, x2, a2, relu)
-    return out, (out.mean(2) if want_tmean else None)
+    s1, h1 = a1 if a1 is not None else (None, None)
+    s2, h2 = a2 if a2 is not None else (None, None)
+    return _FuseOut.apply(x1, s1, h1, x2, s2, h2, bool(relu), bool(want_tmean))

@@ -52,29 +52,31 @@ int dsgcn_aggregate_bwd(const float* zp, const float* scale, const float* shift,
                         const float* dy, float* dzp, float* dahat, float* partial, int n, int KC, int T, int V,
                         void* stream);
 
-/* K-B dynamic-semantic adjacency.  Replaces gcn.py:2240-2337 (mean-pooled projections conv1/conv2/
- * conv1_se with the node-typed select, the edge-typed linear with its 625-iteration index loop,
- * tanh, Gram + Softmax(-2), alpha/beta scale-add).  K = 3 subsets.
- *   xbar (n,Ci,V) time-mean of the unit input;  A (3,V,V); alpha,beta (3)
- *   w1,w2 (2*mid,Ci) b1,b2 (2*mid);  wse (mid*P,Ci) row c*P+p, bse (mid*P);  we (E*mid,mid) row e*mid+c, be (E*mid)
- *   node_type (V) int32 in [0,P);  edge_type (V*V) int32 in [0,E)
- *   ahat out (n,3*mid,V,V).   V <= 32, mid <= 32. */
-int dsgcn_dynadj_fwd(const float* xbar, const float* A, const float* alpha, const float* beta, const float* w1,
-                     const float* b1, const float* w2, const float* b2, const float* wse, const float* bse,
-                     const float* we, const float* be, const int* node_type, const int* edge_type, float* ahat,
-                     int n, int Ci, int mid, int V, int P, int E, void* stream);
+/* K-B dynamic-semantic adjacency.  Replaces gcn.py:2240-2337 (node-typed select of conv1_se, the edge-typed
+ * linear with its 625-iteration index loop, tanh, Gram + Softmax(-2), alpha/beta scale-add).  K = 3 subsets.
+ *   proj (n,9*mid,V): rows [conv1 (2mid) | conv2 (2mid) | conv1_se (mid*P, row c*P+p)] applied to the time-mean
+ *        of the unit input (computed by dsgcn_pwconv_fwd on xbar viewed as (n,Ci,1,V));
+ *   A (3,V,V); alpha,beta (3);  we (E*mid,mid) row e*mid+c, be (E*mid)
+ *   node_type (V) int32 in [0,P);  edge_type (V*V) int32 in [0,E);  ahat out (n,3*mid,V,V).  V <= 32, mid <= 32. */
+int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, const float* beta, const float* we,
+                     const float* be, const int* node_type, const int* edge_type, float* ahat, int n, int mid, int V,
+                     int P, int E, void* stream);
 
 /* Backward of K-B.  pair_order (V*V) = joint pairs sorted by edge class, class_start (E+1) = offsets.
- * dd_ws: workspace (n,3*mid,V,V).  Outputs: dproj (n,5*mid,V) rows [a|b|s]; dxbar (n,Ci,V);
- * pA (n,3,V,V) (sum over n = dA); pab (n,6) (sum over n = [dalpha|dbeta]);
- * dwe (E*mid,mid), dbe (E*mid), dwproj (9*mid,Ci) rows [w1|w2|wse], dbproj (9*mid): ACCUMULATED with
- * float atomics — the caller zeroes them. */
-int dsgcn_dynadj_bwd(const float* xbar, const float* alpha, const float* beta, const float* w1, const float* b1,
-                     const float* w2, const float* b2, const float* wse, const float* bse, const float* we,
-                     const float* be, const int* node_type, const int* edge_type, const int* pair_order,
-                     const int* class_start, const float* dahat, float* dd_ws, float* dproj, float* dxbar, float* pA,
-                     float* pab, float* dwe, float* dbe, float* dwproj, float* dbproj, int n, int Ci, int mid, int V,
-                     int P, int E, void* stream);
+ * dd_ws: workspace (n,3*mid,V,V).  Outputs: dproj (n,9*mid,V); pA (n,3,V,V) (sum over n = dA); pab (n,6)
+ * (sum over n = [dalpha|dbeta]); dwe (E*mid,mid), dbe (E*mid): ACCUMULATED with float atomics — caller zeroes. */
+int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
+                     const int* node_type, const int* edge_type, const int* pair_order, const int* class_start,
+                     const float* dahat, float* dd_ws, float* dproj, float* pA, float* pab, float* dwe, float* dbe,
+                     int n, int mid, int V, int P, int E, void* stream);
+
+/* Block output (materialise once): out = relu?(x1*s1+h1 (+ x2*s2+h2 | + x2)), xbar = mean_t out (optional).
+ * Replaces BN + residual add + ReLU of dgstgcn.py:63-65 / tcn.py:427 and x.mean(-2) of gcn.py:2246. */
+int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                       const float* h2, int relu, float* out, float* xbar, int n, int C, int T, int V, void* stream);
+int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                       const float* h2, int relu, const float* dout, const float* dxbar, float* dx1, float* dx2,
+                       float* part, int n, int C, int T, int V, void* stream);
 
 /* ---- K-C: 1x1 channel mix with fused train-mode BatchNorm / ReLU / residual --------------------------------
  * Replaces Conv2d(1x1)+BatchNorm2d+ReLU(+add) chains of gcn.py:2165-2169,2209-2215,2236,2363-2365 and

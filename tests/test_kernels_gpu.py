@@ -158,3 +158,44 @@ def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
         if k == 'db':
             err = maxabs(got[k].detach().cpu(), v.detach()) / (ref['dw'].abs().max().item() + 1e-30)
         assert err < tol, (k, err)
+
+
+@pytest.mark.parametrize('n,C,T,V,mode,tmean', [
+    (3, 64, 64, 25, 'res_plain', True), (2, 128, 32, 25, 'res_affine', True), (2, 64, 64, 25, 'affine', True),
+    (2, 256, 16, 25, 'res_plain', False), (2, 12, 25, 17, 'res_affine', True), (1, 5, 7, 18, 'plain', True)])
+def test_fuse_out(n, C, T, V, mode, tmean):
+    g = torch.Generator().manual_seed(C + T)
+    x1 = _rand(g, n, C, T, V)
+    a1 = None if mode == 'plain' else (torch.rand(C, generator=g) + 0.5, _rand(g, C, scale=0.3))
+    x2 = _rand(g, n, C, T, V) if mode.startswith('res') else None
+    a2 = (torch.rand(C, generator=g) + 0.5, _rand(g, C, scale=0.3)) if mode == 'res_affine' else None
+    go = _rand(g, n, C, T, V)
+    gb = _rand(g, n, C, V)
+
+    def run(mod, dt, dev):
+        def mk(t):
+            return None if t is None else t.to(dev, dt).requires_grad_()
+        tx1, tx2 = mk(x1), mk(x2)
+        ta1 = None if a1 is None else (mk(a1[0]), mk(a1[1]))
+        ta2 = None if a2 is None else (mk(a2[0]), mk(a2[1]))
+        out, xbar = mod.fuse_out(tx1, ta1, tx2, ta2, True, tmean)
+        loss = (out * go.to(dev, dt)).sum()
+        if tmean:
+            loss = loss + (xbar * gb.to(dev, dt)).sum()
+        loss.backward()
+        res = dict(out=out, dx1=tx1.grad)
+        if tmean:
+            res['xbar'] = xbar
+        if tx2 is not None:
+            res['dx2'] = tx2.grad
+        if ta1 is not None:
+            res['ds1'], res['dh1'] = ta1[0].grad, ta1[1].grad
+        if ta2 is not None:
+            res['ds2'], res['dh2'] = ta2[0].grad, ta2[1].grad
+        return res
+
+    got = run(K, torch.float32, DEV)
+    ref = run(R, torch.float64, 'cpu')
+    for k, v in ref.items():
+        # elementwise fp32 + sums over <= n*T*V terms: 1e-5 relative L2
+        assert rel(got[k].detach().cpu(), v.detach()) < 1e-5, (k, rel(got[k].detach().cpu(), v.detach()))
