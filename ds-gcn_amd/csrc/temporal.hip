@@ -1,0 +1,187 @@
+// K-D (part): the pre- and post-stages of the multi-scale temporal unit dgmstcn (reference:
+// pyskl/models/gcns/utils/tcn.py:379-428).
+//
+//   branch_act : h[n,c,t,0..V) = act_c(z*scale[c]+shift[c]),  h[n,c,t,V] = act_c(zaug*scale[c]+shift[c])
+//                (act_c = ReLU for the BN'd branches c < n_act, identity for the '1x1' branch) — replaces
+//                cat([x, x.mean(-1)]) (tcn.py:409) + the five BatchNorm2d+ReLU (tcn.py:389,394) in one pass.
+//   combine    : f[n,c,t,v] = o[n,c,t,v] + o[n,c,t,V]*add_coeff[v]  (tcn.py:416-420) + per-plane sum / sum of squares of f
+//                (the statistics of transform.0's BatchNorm, tcn.py:401) — replaces slice + einsum + add + the BN pass.
+// One wave per (n,c) plane, coalesced streaming; both are HBM-bound elementwise passes.
+// The four dilated 3x1 convolutions and the 3x1 max-pool between the two still run as PyTorch-ROCm (MIOpen) calls this
+// round (DESIGN.md §"interim").
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(64) void k_branch_act_fwd(const float* __restrict__ z, const float* __restrict__ zaug,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int n_act, float* __restrict__ h, int C, int T, int V) {
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const float s = scale[c], b = shift[c];
+  const bool relu = c < n_act;
+  const int V1 = V + 1, Lo = T * V1;
+  const float* __restrict__ pz = z + (size_t)plane * T * V;
+  const float* __restrict__ pa = zaug + (size_t)plane * T;
+  float* __restrict__ ph = h + (size_t)plane * Lo;
+#pragma unroll 4
+  for (int o = lane; o < Lo; o += 64) {
+    const int t = o / V1, v = o - t * V1;
+    const float x = v < V ? pz[t * V + v] : pa[t];
+    float y = fmaf(x, s, b);
+    if (relu) y = fmaxf(y, 0.f);
+    ph[o] = y;
+  }
+}
+
+// part (n*C, 2): [sum dpre*x, sum dpre]
+__global__ __launch_bounds__(64) void k_branch_act_bwd(const float* __restrict__ z, const float* __restrict__ zaug,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int n_act, const float* __restrict__ dh, float* __restrict__ dz,
+                                                       float* __restrict__ dzaug, float* __restrict__ part, int C, int T,
+                                                       int V) {
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const float s = scale[c], b = shift[c];
+  const bool relu = c < n_act;
+  const int V1 = V + 1, Lo = T * V1;
+  const float* __restrict__ pz = z + (size_t)plane * T * V;
+  const float* __restrict__ pa = zaug + (size_t)plane * T;
+  const float* __restrict__ pg = dh + (size_t)plane * Lo;
+  float* __restrict__ oz = dz + (size_t)plane * T * V;
+  float* __restrict__ oa = dzaug + (size_t)plane * T;
+  float u0 = 0.f, u1 = 0.f;
+#pragma unroll 4
+  for (int o = lane; o < Lo; o += 64) {
+    const int t = o / V1, v = o - t * V1;
+    const float x = v < V ? pz[t * V + v] : pa[t];
+    float g = pg[o];
+    if (relu && !(fmaf(x, s, b) > 0.f)) g = 0.f;
+    if (v < V) oz[t * V + v] = g * s; else oa[t] = g * s;
+    u0 = fmaf(g, x, u0);
+    u1 += g;
+  }
+  u0 = wave_sum(u0);
+  u1 = wave_sum(u1);
+  if (lane == 0) {
+    part[(size_t)plane * 2 + 0] = u0;
+    part[(size_t)plane * 2 + 1] = u1;
+  }
+}
+
+// partial (n*C... laid out [n][C][2]) : per-plane sum / sum of squares of f
+__global__ __launch_bounds__(64) void k_tms_combine_fwd(const float* __restrict__ o, const float* __restrict__ coeff,
+                                                        float* __restrict__ f, float* __restrict__ partial, int C, int T,
+                                                        int V) {
+  __shared__ float cf[32];
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  if (lane < V) cf[lane] = coeff[lane];
+  wave_lds_sync();
+  const int V1 = V + 1, L = T * V;
+  const float* __restrict__ po = o + (size_t)plane * T * V1;
+  float* __restrict__ pf = f + (size_t)plane * L;
+  float sv = 0.f, qv = 0.f;
+#pragma unroll 4
+  for (int i = lane; i < L; i += 64) {
+    const int t = i / V, v = i - t * V;
+    const float val = fmaf(po[t * V1 + V], cf[v], po[t * V1 + v]);
+    pf[i] = val;
+    sv += val;
+    qv = fmaf(val, val, qv);
+  }
+  if (partial) {
+    sv = wave_sum(sv);
+    qv = wave_sum(qv);
+    if (lane == 0) {
+      partial[(size_t)plane * 2 + 0] = sv;
+      partial[(size_t)plane * 2 + 1] = qv;
+    }
+  }
+}
+
+// gf_eff = gf + A0[c] + B0[c]*f ;  do[..,v<V] = gf_eff ; do[..,V] = sum_v gf_eff*coeff[v] ;
+// pcoef (n*C, V): per-plane sum_t gf_eff[t,v]*o[t,V]
+__global__ __launch_bounds__(64) void k_tms_combine_bwd(const float* __restrict__ o, const float* __restrict__ coeff,
+                                                        const float* __restrict__ gf, const float* __restrict__ A0,
+                                                        const float* __restrict__ B0, float* __restrict__ dout,
+                                                        float* __restrict__ pcoef, int C, int T, int V) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [T][V] gf_eff
+  __shared__ float cf[32];
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  if (lane < V) cf[lane] = coeff[lane];
+  const float a0 = A0 ? A0[c] : 0.f, b0 = B0 ? B0[c] : 0.f;
+  wave_lds_sync();
+  const int V1 = V + 1, L = T * V;
+  const float* __restrict__ po = o + (size_t)plane * T * V1;
+  const float* __restrict__ pg = gf ? gf + (size_t)plane * L : nullptr;
+  float* __restrict__ pd = dout + (size_t)plane * T * V1;
+#pragma unroll 4
+  for (int i = lane; i < L; i += 64) {
+    const int t = i / V, v = i - t * V;
+    const float fv = fmaf(po[t * V1 + V], cf[v], po[t * V1 + v]);
+    const float g = (pg ? pg[i] : 0.f) + fmaf(b0, fv, a0);
+    lds[i] = g;
+    pd[t * V1 + v] = g;
+  }
+  wave_lds_sync();
+  for (int t = lane; t < T; t += 64) {
+    float acc = 0.f;
+    for (int v = 0; v < V; ++v) acc = fmaf(lds[t * V + v], cf[v], acc);
+    pd[t * V1 + V] = acc;
+  }
+  if (lane < V) {
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc = fmaf(lds[t * V + lane], po[t * V1 + V], acc);
+    pcoef[(size_t)plane * V + lane] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsgcn_branch_act_fwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                         float* h, int n, int C, int T, int V, void* stream) {
+  if (!z || !zaug || !scale || !shift || !h || n <= 0 || C <= 0 || T <= 0 || V <= 0) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_branch_act_fwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, z, zaug, scale,
+                     shift, n_act, h, C, T, V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+int dsgcn_branch_act_bwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                         const float* dh, float* dz, float* dzaug, float* part, int n, int C, int T, int V,
+                         void* stream) {
+  if (!z || !zaug || !scale || !shift || !dh || !dz || !dzaug || !part) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_branch_act_bwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, z, zaug, scale,
+                     shift, n_act, dh, dz, dzaug, part, C, T, V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+int dsgcn_tms_combine_fwd(const float* o, const float* coeff, float* f, float* partial, int n, int C, int T, int V,
+                          void* stream) {
+  if (!o || !coeff || !f || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_tms_combine_fwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, o, coeff, f,
+                     partial, C, T, V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+int dsgcn_tms_combine_bwd(const float* o, const float* coeff, const float* gf, const float* A0, const float* B0,
+                          float* dout, float* pcoef, int n, int C, int T, int V, void* stream) {
+  if (!o || !coeff || !dout || !pcoef || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32) return DSGCN_EINVAL;
+  const size_t lds = (size_t)T * V * sizeof(float);
+  if (lds > 64 * 1024) return DSGCN_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_tms_combine_bwd, dim3((unsigned)((long)n * C)), dim3(64), lds, (hipStream_t)stream, o, coeff, gf,
+                     A0, B0, dout, pcoef, C, T, V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -328,12 +328,100 @@ def tmean(x):
     return x.mean(2)
 
 
-def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, add_coeff, stride, stats=True):
+class _BranchAct(torch.autograd.Function):
+    """h (n,C,T,V+1) = act(z*scale+shift) with the global-joint column appended (ReLU on channels < n_act)."""
+
+    @staticmethod
+    def forward(ctx, z, zaug, scale, shift, n_act):
+        _require_cuda(z)
+        z, zaug, scale, shift = [_f32c(t) for t in (z, zaug, scale, shift)]
+        n, C, T, V = z.shape
+        h = torch.empty((n, C, T, V + 1), device=z.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_branch_act_fwd(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), int(n_act), _ptr(h), n, C,
+                                               T, V, _stream())
+        native.check(rc, 'dsgcn_branch_act_fwd')
+        ctx.save_for_backward(z, zaug, scale, shift)
+        ctx.n_act = int(n_act)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        z, zaug, scale, shift = ctx.saved_tensors
+        n, C, T, V = z.shape
+        dh = _f32c(dh)
+        dz = torch.empty_like(z)
+        dzaug = torch.empty_like(zaug)
+        part = torch.empty((n, C, 2), device=z.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_branch_act_bwd(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), ctx.n_act, _ptr(dh),
+                                               _ptr(dz), _ptr(dzaug), _ptr(part), n, C, T, V, _stream())
+        native.check(rc, 'dsgcn_branch_act_bwd')
+        red = colsum(part)
+        return dz, dzaug, red[:, 0], red[:, 1], None
+
+
+class _TmsCombine(torch.autograd.Function):
+    """f = o[..., :V] + o[..., V] * coeff, with the train-mode BN of f as a deferred affine (like _PwConv)."""
+
+    @staticmethod
+    def forward(ctx, o, coeff, gamma, beta, eps, want_bn):
+        _require_cuda(o)
+        o, coeff, gamma, beta = [_f32c(t) for t in (o, coeff, gamma, beta)]
+        n, C, T, V1 = o.shape
+        V = V1 - 1
+        dev = o.device
+        f = torch.empty((n, C, T, V), device=dev, dtype=torch.float32)
+        partial = torch.empty((n, C, 2), device=dev, dtype=torch.float32) if want_bn else None
+        lib = native.lib()
+        rc = lib.dsgcn_tms_combine_fwd(_ptr(o), _ptr(coeff), _ptr(f), _ptr(partial), n, C, T, V, _stream())
+        native.check(rc, 'dsgcn_tms_combine_fwd')
+        scale = shift = mean = var = None
+        count = float(n * T * V)
+        if want_bn:
+            stats = torch.empty((4, C), device=dev, dtype=torch.float32)
+            mean, var, scale, shift = stats[0], stats[1], stats[2], stats[3]
+            rc = lib.dsgcn_bn_finalize(_ptr(partial), n, C, count, _ptr(gamma), _ptr(beta), float(eps), _ptr(mean),
+                                       _ptr(var), _ptr(scale), _ptr(shift), C, _stream())
+            native.check(rc, 'dsgcn_bn_finalize')
+            ctx.mark_non_differentiable(mean, var)
+        ctx.save_for_backward(o, coeff, gamma, mean, var)
+        ctx.cfg = (float(eps), bool(want_bn), count, beta is not None)
+        return f, scale, shift, mean, var
+
+    @staticmethod
+    def backward(ctx, gf, gscale, gshift, _gm, _gv):
+        o, coeff, gamma, mean, var = ctx.saved_tensors
+        eps, want_bn, count, has_beta = ctx.cfg
+        n, C, T, V1 = o.shape
+        V = V1 - 1
+        dev = o.device
+        lib = native.lib()
+        gf, gscale, gshift = _f32c(gf), _f32c(gscale), _f32c(gshift)
+        A0 = B0 = dgamma = dbeta = None
+        if want_bn and (gscale is not None or gshift is not None):
+            coef = torch.empty((4, C), device=dev, dtype=torch.float32)
+            dgamma, dbeta, A0, B0 = coef[0], coef[1], coef[2], coef[3]
+            rc = lib.dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, C, C,
+                                       _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), _stream())
+            native.check(rc, 'dsgcn_bn_bwd_coef')
+        do = torch.empty_like(o)
+        pcoef = torch.empty((n * C, V), device=dev, dtype=torch.float32)
+        rc = lib.dsgcn_tms_combine_bwd(_ptr(o), _ptr(coeff), _ptr(gf), _ptr(A0), _ptr(B0), _ptr(do), _ptr(pcoef), n, C,
+                                       T, V, _stream())
+        native.check(rc, 'dsgcn_tms_combine_bwd')
+        dcoeff = colsum(pcoef)
+        if dgamma is not None:
+            dgamma = dgamma if gamma is not None else None
+            dbeta = dbeta if has_beta else None
+        return do, dcoeff, dgamma, dbeta, None, None
+
+
+def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, add_coeff, stride, gamma=None,
+                beta=None, eps=1e-5, want_bn=False):
+    """-> (f, scale, shift, mean, var).  branch_act and combine (+BN statistics) are HIP kernels; the dilated 3x1
+    convolutions / max-pool in between are still PyTorch-ROCm device ops (MIOpen) this round."""
     _require_cuda(z)
     n, C, T, V = z.shape
-    full = torch.cat([z, zaug[..., None]], -1)
-    h = full * _bc(scale) + _bc(shift)
-    h = torch.cat([F.relu(h[:, :n_act]), h[:, n_act:]], 1)
+    h = _BranchAct.apply(z, zaug, scale, shift, n_act)
     outs, c0, ci = [], 0, 0
     for cfg, bc in zip(branch_cfg, widths):
         hb = h[:, c0:c0 + bc]
@@ -348,11 +436,7 @@ def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b
             ci += 1
         c0 += bc
     o = torch.cat(outs, 1)
-    f = o[..., :V] + o[..., V, None] * add_coeff[:V]
-    mean = var = None
-    if stats:
-        var, mean = torch.var_mean(f, (0, 2, 3), unbiased=False)
-    return f, mean, var
+    return _TmsCombine.apply(o, add_coeff[:V].contiguous(), gamma, beta, float(eps), bool(want_bn))
 
 
 def tconv(x1, a1, relu, weight, bias, stride, dilation, stats=True):

@@ -150,11 +150,16 @@ class dgmstcn(nn.Module):
             shift = torch.cat([a[1] for a in aff] + ([z.new_zeros(rest)] if rest else []))
         tconvs = [b[3].conv for b in self.branches if not isinstance(b, nn.Conv2d) and isinstance(b[3], unit_tcn)]
         bn1 = self.transform[0]
-        f, m1, v1 = ops.temporal_ms(z, zaug, scale, shift, self.n_act, self.ms_cfg,
-                                    self.widths, [c.weight for c in tconvs], [c.bias for c in tconvs],
-                                    self.add_coeff, self.stride, _need_stats(bn1))
-        cnt1 = f.shape[0] * f.shape[2] * f.shape[3]
-        a1 = bn_affine(bn1, m1, v1, cnt1)
+        tw, tb = [c.weight for c in tconvs], [c.bias for c in tconvs]
+        if _need_stats(bn1):
+            f, s1, h1, m1, v1 = ops.temporal_ms(z, zaug, scale, shift, self.n_act, self.ms_cfg, self.widths, tw, tb,
+                                                self.add_coeff, self.stride, bn1.weight, bn1.bias, bn1.eps, True)
+            record_running(bn1, m1, v1, f.shape[0] * f.shape[2] * f.shape[3])
+            a1 = (s1, h1)
+        else:
+            f = ops.temporal_ms(z, zaug, scale, shift, self.n_act, self.ms_cfg, self.widths, tw, tb, self.add_coeff,
+                                self.stride)[0]
+            a1 = eval_affine(bn1)
         zt, _, a2 = conv_bn(f, a1, None, None, True, self.transform[2], 1, False, self.bn)
         return Deferred(zt, a2, None, None, False)
 

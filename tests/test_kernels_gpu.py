@@ -199,3 +199,44 @@ def test_fuse_out(n, C, T, V, mode, tmean):
     for k, v in ref.items():
         # elementwise fp32 + sums over <= n*T*V terms: 1e-5 relative L2
         assert rel(got[k].detach().cpu(), v.detach()) < 1e-5, (k, rel(got[k].detach().cpu(), v.detach()))
+
+
+@pytest.mark.parametrize('n,C,T,V,stride', [(2, 64, 32, 25, 1), (2, 128, 32, 25, 2), (2, 48, 20, 17, 1), (1, 12, 9, 18, 2)])
+def test_temporal_ms(n, C, T, V, stride):
+    g = torch.Generator().manual_seed(C + T + stride)
+    cfg = [(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1']
+    mid = C // 6
+    widths = [C - 5 * mid] + [mid] * 5
+    n_act = C - mid
+    z = _rand(g, n, C, T, V)
+    zaug = _rand(g, n, C, T)
+    scale = torch.cat([torch.rand(n_act, generator=g) + 0.5, torch.ones(mid)])
+    shift = torch.cat([_rand(g, n_act, scale=0.3), torch.zeros(mid)])
+    cw = [_rand(g, w, w, 3, 1, scale=(3 * w) ** -0.5) for w in widths[:4]]
+    cb = [_rand(g, w, scale=0.1) for w in widths[:4]]
+    coeff = _rand(g, 25, scale=0.5)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = _rand(g, C, scale=0.2)
+    Tout = (T + stride - 1) // stride
+    gf = _rand(g, n, C, Tout, V)
+    gsc, gsh = _rand(g, C), _rand(g, C)
+
+    def run(mod, dt, dev):
+        def mk(t):
+            return t.to(dev, dt).requires_grad_()
+        tz, tza, tsc, tsh, tco, tga, tbe = mk(z), mk(zaug), mk(scale), mk(shift), mk(coeff), mk(gamma), mk(beta)
+        tw, tb = [mk(w) for w in cw], [mk(b) for b in cb]
+        f, sc, sh, mean, var = mod.temporal_ms(tz, tza, tsc, tsh, n_act, cfg, widths, tw, tb, tco, stride, tga, tbe,
+                                               1e-5, True)
+        ((f * gf.to(dev, dt)).sum() + (sc * gsc.to(dev, dt)).sum() + (sh * gsh.to(dev, dt)).sum()).backward()
+        res = dict(f=f, sc=sc, sh=sh, mean=mean, var=var, dz=tz.grad, dzaug=tza.grad, dscale=tsc.grad, dshift=tsh.grad,
+                   dcoeff=tco.grad[:V], dgamma=tga.grad, dbeta=tbe.grad)
+        for i in range(4):
+            res[f'dw{i}'] = tw[i].grad
+        return res
+
+    got = run(K, torch.float32, DEV)
+    ref = run(R, torch.float64, 'cpu')
+    for k, v in ref.items():
+        # MIOpen fp32 convolutions between the two HIP stages: 5e-5 relative L2
+        assert rel(got[k].detach().cpu(), v.detach()) < 5e-5, (k, rel(got[k].detach().cpu(), v.detach()))

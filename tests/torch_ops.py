@@ -113,14 +113,16 @@ def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, ed
     return ahat.reshape(n, K * mid, V, V)
 
 
-def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, add_coeff, stride, stats=True):
+def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, add_coeff, stride, gamma=None,
+                beta=None, eps=1e-5, want_bn=False):
     """Multi-scale temporal stage of dgmstcn after the fused branch 1x1 conv.
 
     z (n,C,T,V), zaug (n,C,T): raw branch-conv outputs (real joints / global joint).
     scale/shift (C): deferred BN affine; channels < n_act also get ReLU, the rest pass through.
     branch_cfg: list of (k,dil) | ('max',k) | '1x1'; widths: channels per branch;
     conv_w[i] (bc,bc,k,1), conv_b[i] (bc) for the conv branches in order.
-    Returns f (n,C,T/stride,V) = local + global*add_coeff, and its batch mean/var."""
+    Returns (f, scale, shift, mean, var): f (n,C,T/stride,V) = local + global*add_coeff and, with ``want_bn``, the
+    train-mode BN of f (gamma/beta = transform.0) as a deferred affine."""
     n, C, T, V = z.shape
     full = torch.cat([z, zaug[..., None]], -1)
     h = full * _bc(scale) + _bc(shift)
@@ -142,11 +144,14 @@ def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b
         c0 += bc
     o = torch.cat(outs, 1)
     f = o[..., :V] + o[..., V, None] * add_coeff[:V]
-    mean = var = None
-    if stats:
-        mean = f.mean((0, 2, 3))
-        var = f.var((0, 2, 3), unbiased=False)
-    return f, mean, var
+    if not want_bn:
+        return f, None, None, None, None
+    mean = f.mean((0, 2, 3))
+    var = f.var((0, 2, 3), unbiased=False)
+    g = gamma if gamma is not None else f.new_ones(C)
+    b = beta if beta is not None else f.new_zeros(C)
+    sc = g * torch.rsqrt(var + eps)
+    return f, sc, b - mean * sc, mean.detach(), var.detach()
 
 
 def tconv(x1, a1, relu, weight, bias, stride, dilation, stats=True):
