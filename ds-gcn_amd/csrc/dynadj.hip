@@ -335,11 +335,13 @@ int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, cons
   if (!proj || !A || !ahat || !we || !be || n <= 0 || mid <= 0) return DSGCN_EINVAL;
   if (V > 32 || mid > 32) return DSGCN_EUNSUPPORTED;
   const size_t lds = dyn_lds_bytes(mid, V, E, false);
-  if (lds > 160 * 1024) return DSGCN_EUNSUPPORTED;
+  if (lds > 156 * 1024) return DSGCN_EUNSUPPORTED;
   DynDims d{n, 0, mid, V, P, E};
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t attr_fwd = 64 * 1024;      // raised once per size class (not a stream op: keep it out of graph capture)
+  if (lds > attr_fwd) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (e != hipSuccess) return (int)e;
+    attr_fwd = 156 * 1024;
   }
   hipLaunchKernelGGL(k_dynadj_fwd, dim3(n), dim3(NT), lds, (hipStream_t)stream, d, proj, A, alpha, beta, we, be,
                      node_type, edge_type, ahat);
@@ -354,12 +356,14 @@ int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, c
   if (!proj || !dahat || !dd_ws || !dproj || !pA || !pab || !dwe || !dbe) return DSGCN_EINVAL;
   if (V > 32 || mid > 32) return DSGCN_EUNSUPPORTED;
   const size_t lds = dyn_lds_bytes(mid, V, E, true);
-  if (lds > 160 * 1024) return DSGCN_EUNSUPPORTED;
+  if (lds > 156 * 1024) return DSGCN_EUNSUPPORTED;
   DynDims d{n, 0, mid, V, P, E};
   hipStream_t st = (hipStream_t)stream;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t attr_bwd = 64 * 1024;
+  if (lds > attr_bwd) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (e != hipSuccess) return (int)e;
+    attr_bwd = 156 * 1024;
   }
   hipLaunchKernelGGL(k_dynadj_bwd, dim3(n), dim3(NT), lds, st, d, proj, alpha, beta, we, be, node_type, edge_type,
                      pair_order, class_start, dahat, dd_ws, dproj, pA, pab, dwe, dbe);
