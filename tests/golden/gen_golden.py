@@ -1,0 +1,175 @@
+"""Generate the golden fixtures from the IMPORTED reference (build container only: needs /root/reference).
+
+    python tests/golden/gen_golden.py
+
+Writes small .npz/.json files next to this script.  Each fixture holds inputs (weights, activations) and the
+reference's outputs for them — data only, no reference source.  fp64 runs give the "truth"; the fp32 reference
+outputs are stored as well where the noise floor matters (gradients).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+R = ref_shim.load()
+
+
+def ds_cfg(num_classes=60, layout='nturgb+d', **bk):
+    backbone = dict(
+        type='DGSTGCN', gcn_type='dgphgcn1', gcn_ratio=0.125, gcn_node_attention=True, gcn_edge_attention=True,
+        gcn_decompose=True, gcn_subset_wise=True, gcn_ctr='T', gcn_ada='T', tcn_type='dgmstcn',
+        graph_cfg=dict(layout=layout, mode='random', num_filter=3, init_off=.04, init_std=.02),
+        tcn_ms_cfg=[(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1'])
+    backbone.update(bk)
+    return dict(type='RecognizerGCN', backbone=backbone,
+                cls_head=dict(type='GCNHead', num_classes=num_classes, in_channels=bk.get('_head_in', 256)))
+
+
+def liven(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            if k.endswith(('alpha', 'beta', 'add_coeff')):
+                p.copy_(torch.randn(p.shape, generator=g, dtype=torch.float64).to(p.dtype) * 0.5)
+
+
+def sd_np(module, prefix=''):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def graphs():
+    out = {}
+    for lay in ('nturgb+d', 'coco'):
+        g = R.graph.Graph(layout=lay, mode='spatial')
+        tag = lay.replace('+', 'p')
+        out[f'{tag}_node_type'] = np.array(g.node_type)
+        out[f'{tag}_edge_type'] = g.edge_type
+        out[f'{tag}_spatial'] = g.A
+        out[f'{tag}_stgcn_spatial'] = R.graph.Graph(layout=lay, mode='stgcn_spatial').A
+        out[f'{tag}_hop_dis'] = g.hop_dis
+    np.savez_compressed(os.path.join(HERE, 'graph_constants.npz'), **out)
+
+
+def unit_dgphgcn1():
+    np.random.seed(11)
+    G = R.graph.Graph(layout='nturgb+d', mode='random', num_filter=3, init_off=.04, init_std=.02)
+    A = torch.tensor(G.A, dtype=torch.float32)
+    nt = torch.tensor(G.node_type)
+    et = torch.tensor(G.edge_type, dtype=torch.float32)
+    out = {}
+    for i, (ci, co) in enumerate([(3, 64), (64, 64), (64, 128)]):
+        torch.manual_seed(100 + i)
+        m = R.gutils.dgphgcn1(ci, co, A, et, nt, ratio=0.125, decompose=True, node_attention=True,
+                              edge_attention=True, subset_wise=True, ctr='T', ada='T')
+        liven(m, 7 + i)
+        m64 = m.double()
+        x = torch.randn(2, ci, 8, 25, dtype=torch.float64, requires_grad=True)
+        Rm = torch.randn(2, co, 8, 25, dtype=torch.float64)
+        y = m64(x)
+        (y * Rm).sum().backward()
+        tag = f'u{i}_'
+        for k, v in m64.state_dict().items():
+            out[tag + 'sd_' + k] = v.detach().numpy().astype(np.float32) if v.dtype.is_floating_point else v.numpy()
+        out[tag + 'x'] = x.detach().numpy().astype(np.float32)
+        out[tag + 'R'] = Rm.numpy().astype(np.float32)
+        out[tag + 'y'] = y.detach().numpy().astype(np.float32)
+        out[tag + 'dx'] = x.grad.numpy().astype(np.float32)
+        for k, p in m64.named_parameters():
+            if p.grad is not None and k in ('A', 'alpha', 'beta', 'edge_linears.weight', 'conv1_se.weight', 'pre.1.weight'):
+                out[tag + 'grad_' + k] = p.grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, 'unit_dgphgcn1.npz'), **out)
+
+
+def unit_dgmstcn():
+    out = {}
+    for i, (c, s) in enumerate([(64, 1), (96, 2)]):
+        torch.manual_seed(200 + i)
+        m = R.gutils.dgmstcn(c, c, stride=s)
+        liven(m, 17 + i)
+        m64 = m.double()
+        x = torch.randn(2, c, 8, 25, dtype=torch.float64, requires_grad=True)
+        y = m64(x)
+        Rm = torch.randn(y.shape, dtype=torch.float64)
+        (y * Rm).sum().backward()
+        tag = f't{i}_'
+        for k, v in m64.state_dict().items():
+            out[tag + 'sd_' + k] = v.detach().numpy().astype(np.float32) if v.dtype.is_floating_point else v.numpy()
+        out[tag + 'x'] = x.detach().numpy().astype(np.float32)
+        out[tag + 'R'] = Rm.numpy().astype(np.float32)
+        out[tag + 'y'] = y.detach().numpy().astype(np.float32)
+        out[tag + 'dx'] = x.grad.numpy().astype(np.float32)
+        out[tag + 'grad_add_coeff'] = m64.add_coeff.grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, 'unit_dgmstcn.npz'), **out)
+
+
+def reduced_model():
+    cfg = ds_cfg(num_classes=12, base_channels=16, num_stages=4, inflate_stages=[3], down_stages=[3])
+    cfg['cls_head']['in_channels'] = 32
+    np.random.seed(3)
+    torch.manual_seed(3)
+    m = R.builder.build_model(cfg)
+    liven(m, 33)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 1, 2, 16, 25, 3, generator=g)
+    y = torch.randint(0, 12, (4, 1), generator=g)
+    out = {'sd_' + k: v for k, v in sd_np(m).items()}
+    out['x'] = x.numpy()
+    out['label'] = y.numpy()
+    # fp32 reference run (what the reference itself produces)
+    feat = m.extract_feat(x[:, 0])
+    logits = m.cls_head(feat)
+    loss = m.cls_head.loss(logits, y.squeeze(-1))['loss_cls']
+    loss.backward()
+    out['logits_f32'] = logits.detach().numpy()
+    out['loss_f32'] = np.array(loss.item())
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            out['g32_' + k] = p.grad.numpy()
+    # fp64 truth
+    m64 = R.builder.build_model(cfg).double()
+    m64.load_state_dict({k: v.double() if v.dtype.is_floating_point else v for k, v in m.state_dict().items()})
+    feat = m64.extract_feat(x[:, 0].double())
+    logits64 = m64.cls_head(feat)
+    loss64 = torch.nn.functional.cross_entropy(logits64, y.squeeze(-1))
+    loss64.backward()
+    out['logits_f64'] = logits64.detach().numpy().astype(np.float32)
+    out['loss_f64'] = np.array(loss64.item())
+    for k, p in m64.named_parameters():
+        if p.grad is not None:
+            out['g64_' + k] = p.grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, 'model_reduced.npz'), **out)
+    with open(os.path.join(HERE, 'model_reduced_cfg.json'), 'w') as f:
+        json.dump(cfg, f, indent=1)
+
+
+def manifests():
+    man = {}
+    for name, cfg in (('dsstgcn_ntu60', ds_cfg(60)), ('dsstgcn_ntu120', ds_cfg(120)),
+                      ('dsstgcn_k400_coco', ds_cfg(400, 'coco'))):
+        np.random.seed(0)
+        torch.manual_seed(0)
+        m = R.builder.build_model(cfg)
+        man[name] = dict(keys=[[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()],
+                         params=sum(p.numel() for p in m.parameters()),
+                         sha_first=[float(m.state_dict()[k].double().sum()) for k in
+                                    ('backbone.gcn.0.gcn.A', 'backbone.gcn.0.gcn.pre.0.weight',
+                                     'backbone.gcn.9.tcn.transform.2.weight', 'cls_head.fc_cls.weight')])
+    with open(os.path.join(HERE, 'state_dict_manifest.json'), 'w') as f:
+        json.dump(man, f)
+
+
+if __name__ == '__main__':
+    graphs()
+    unit_dgphgcn1()
+    unit_dgmstcn()
+    reduced_model()
+    manifests()
+    for fn in sorted(os.listdir(HERE)):
+        if fn.endswith(('.npz', '.json')):
+            print(fn, os.path.getsize(os.path.join(HERE, fn)))

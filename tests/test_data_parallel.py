@@ -1,0 +1,114 @@
+"""CPU, 2 processes, gloo: the flat-buffer data-parallel path == one process evaluating the two rank batches as
+independent micro-batches (rank-local BatchNorm) and averaging gradients (SURVEY §8e equivalence check)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import dsgcn_amd as D
+import torch_ops
+
+CFG = dict(type='RecognizerGCN',
+           backbone=dict(type='DGSTGCN', gcn_type='dgphgcn1', gcn_ratio=0.125, gcn_node_attention=True,
+                         gcn_edge_attention=True, gcn_decompose=True, gcn_subset_wise=True, gcn_ctr='T', gcn_ada='T',
+                         tcn_type='dgmstcn', base_channels=16, num_stages=3, inflate_stages=[3], down_stages=[3],
+                         graph_cfg=dict(layout='nturgb+d', mode='random', num_filter=3, init_off=.04, init_std=.02),
+                         tcn_ms_cfg=[(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1']),
+           cls_head=dict(type='GCNHead', num_classes=7, in_channels=32))
+
+
+def make_model(seed):
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    m = D.build_model(CFG)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith(('alpha', 'beta', 'add_coeff')):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    return m.train()
+
+
+def batch_for(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return dict(keypoint=torch.randn(2, 1, 2, 8, 25, 3, generator=g), label=torch.randint(0, 7, (2, 1), generator=g))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = make_model(seed=7 + rank)           # different init per rank: the param broadcast must fix it
+    flat = D.FlatParams(model)
+    dp = D.FlatDataParallel(flat)
+    opt = D.FlatSGD(flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    with D.kernels.use_ops(torch_ops):
+        for _ in range(2):
+            opt.zero_grad()
+            out = model.train_step(batch_for(rank), None)
+            out['loss'].backward()
+            dp.allreduce_grads()
+            opt.step()
+    assert flat.check_views()
+    torch.save(dict(p=flat.flat_p.clone(), g=flat.flat_g.clone(), log=out['log_vars']), os.path.join(out_dir, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_dp_equals_microbatch_average(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = [torch.load(tmp_path / f'r{r}.pt') for r in range(world)]
+    assert torch.equal(r0['p'], r1['p'])                    # replicas stay bit-identical
+    assert torch.equal(r0['g'], r1['g'])
+    assert abs(r0['log']['loss'] - r1['log']['loss']) < 1e-12      # logged scalars are the all-reduced means
+
+    # single-process restatement: rank-0 weights, two independent micro-batches, averaged gradients
+    torch.set_num_threads(1)
+    model = make_model(seed=7)
+    flat = D.FlatParams(model)
+    opt = D.FlatSGD(flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    states = [{k: v.clone() for k, v in model.state_dict().items() if 'running' in k or 'num_batches' in k}
+              for _ in range(world)]
+    with D.kernels.use_ops(torch_ops):
+        for _ in range(2):
+            opt.zero_grad()
+            for r in range(world):                           # BN running stats are rank-local state
+                model.load_state_dict(states[r], strict=False)
+                (model.train_step(batch_for(r), None)['loss'] / world).backward()
+                states[r] = {k: v.clone() for k, v in model.state_dict().items() if k in states[r]}
+            opt.step()
+    assert torch.allclose(flat.flat_p, r0['p'], rtol=0, atol=2e-6), (flat.flat_p - r0['p']).abs().max()
+
+
+def test_flat_sgd_matches_torch_sgd():
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    ref = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    ref.load_state_dict(lin.state_dict())
+    flat = D.FlatParams(lin)
+    opt = D.FlatSGD(flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    topt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    x = torch.randn(6, 5)
+    for _ in range(3):
+        opt.zero_grad()
+        lin(x).square().sum().backward()
+        opt.step()
+        topt.zero_grad()
+        ref(x).square().sum().backward()
+        topt.step()
+    for a, b in zip(lin.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, atol=1e-6)
+    assert D.shard_batch(512, 3, 8) == (192, 256)
+    assert abs(D.cosine_lr(0.1, 50, 100) - 0.05) < 1e-12

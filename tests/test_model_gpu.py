@@ -1,0 +1,124 @@
+"""-m gpu: the product path (HIP kernels through the C ABI) at model level against the committed golden vectors and the
+CPU oracle.  Bar (BASELINE.json north_star): logits and loss within 1e-4 relative, fp32."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dsgcn_amd as D
+from dsgcn_amd import native
+from oracle import dsgcn_oracle as O
+from bench import build_model, ds_cfg
+from test_oracle_golden import GOLD, load, rel, sd_of
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_is_loaded():
+    lib = native.lib()
+    assert lib.dsgcn_version() >= 100
+    with open('/proc/self/maps') as f:
+        assert 'libdsgcn.so' in f.read()           # the in-tree HIP library really is the code that runs
+
+
+def test_reduced_model_vs_golden():
+    z = load('model_reduced.npz')
+    with open(os.path.join(GOLD, 'model_reduced_cfg.json')) as f:
+        cfg = json.load(f)
+    cfg['backbone']['tcn_ms_cfg'] = [tuple(c) if isinstance(c, list) else c for c in cfg['backbone']['tcn_ms_cfg']]
+    m = D.build_model(cfg)
+    m.load_state_dict(sd_of(z, 'sd_', torch.float32))
+    m = m.cuda().train()
+    x, y = torch.from_numpy(z['x']).cuda(), torch.from_numpy(z['label']).cuda()
+    losses = m(keypoint=x, label=y, return_loss=True)
+    feat = m.extract_feat(x[:, 0])
+    logits = m.cls_head(feat)
+    loss = m.cls_head.loss(logits, y.squeeze(-1))['loss_cls']
+    loss.backward()
+    assert rel(logits.detach().cpu(), z['logits_f64']) < 1e-4
+    assert abs(loss.item() - float(z['loss_f64'])) / abs(float(z['loss_f64'])) < 1e-4
+    assert abs(losses['loss_cls'].item() - loss.item()) < 1e-5
+    num = den = 0.0
+    for k, p in m.named_parameters():
+        if 'g64_' + k in z:
+            g64 = z['g64_' + k].astype(np.float64)
+            num += float(((p.grad.double().cpu().numpy() - g64) ** 2).sum())
+            den += float((g64 ** 2).sum())
+    assert (num / den) ** .5 < 2e-4, (num / den) ** .5        # whole-gradient relative L2 vs fp64 truth
+
+
+@pytest.mark.parametrize('layout,V,T,classes', [('nturgb+d', 25, 64, 60), ('coco', 17, 100, 400)])
+def test_full_model_vs_oracle(layout, V, T, classes):
+    """Full-width DS-STGCN (configs 2/3 and the K400 V=17,T=100 variant), 2 clips, against the CPU oracle."""
+    np.random.seed(0)
+    torch.manual_seed(0)
+    m = D.build_model(ds_cfg(classes, layout))
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith(('alpha', 'beta', 'add_coeff')):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 1, 2, T, V, 3, generator=g)
+    y = torch.randint(0, classes, (2, 1), generator=g)
+    gc = O.graph_constants(layout)
+    ref_logits, ref_loss = O.recognizer_forward_train(x, y, sd, gc['node_type'], gc['edge_type'], O.dgstgcn_plan())
+    m = m.cuda().train()
+    out = m.train_step(dict(keypoint=x.cuda(), label=y.cuda()), None)
+    feat = m.extract_feat(x.cuda()[:, 0])
+    logits = m.cls_head(feat)
+    assert rel(logits.detach().cpu(), ref_logits) < 1e-4
+    assert abs(out['log_vars']['loss'] - ref_loss.item()) / abs(ref_loss.item()) < 1e-4
+    out['loss'].backward()
+    dead = [k for k, p in m.named_parameters() if p.grad is None]
+    assert len(dead) == 20 and all('conv2_se' in k for k in dead)          # reference quirk Q1
+
+
+def test_running_stats_and_eval_mode():
+    z = load('model_reduced.npz')
+    with open(os.path.join(GOLD, 'model_reduced_cfg.json')) as f:
+        cfg = json.load(f)
+    cfg['backbone']['tcn_ms_cfg'] = [tuple(c) if isinstance(c, list) else c for c in cfg['backbone']['tcn_ms_cfg']]
+    m = D.build_model(cfg)
+    m.load_state_dict(sd_of(z, 'sd_', torch.float32))
+    ref = D.build_model(cfg)
+    ref.load_state_dict(sd_of(z, 'sd_', torch.float32))
+    x, y = torch.from_numpy(z['x']), torch.from_numpy(z['label'])
+    import torch_ops
+    with D.kernels.use_ops(torch_ops):              # CPU statement of the same wiring (itself checked against the reference)
+        ref.train()
+        ref(keypoint=x, label=y, return_loss=True)
+        ref.eval()
+        with torch.no_grad():
+            want = ref(keypoint=x, return_loss=False)
+    m = m.cuda().train()
+    m(keypoint=x.cuda(), label=y.cuda(), return_loss=True)
+    for (k, a), (_, b) in zip(m.state_dict().items(), ref.state_dict().items()):
+        if 'running' in k or 'num_batches' in k:
+            assert torch.allclose(a.cpu().double(), b.double(), rtol=1e-4, atol=1e-6), k
+    m.eval()
+    with torch.no_grad():
+        got = m(keypoint=x.cuda(), return_loss=False)
+    assert np.abs(got - want).max() < 1e-5
+
+
+def test_full_size_properties():
+    """BASELINE size (64 clips): finite loss, gradient views intact, aggregate linearity at full size."""
+    from dsgcn_amd import kernels as K
+    m = build_model().cuda().train()
+    flat = D.FlatParams(m)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 1, 2, 64, 25, 3, generator=g).cuda()
+    y = torch.randint(0, 60, (64, 1), generator=g).cuda()
+    out = m.train_step(dict(keypoint=x, label=y), None)
+    out['loss'].backward()
+    assert np.isfinite(out['log_vars']['loss']) and flat.check_views()
+    assert torch.isfinite(flat.flat_g).all()
+    zp = torch.randn(128, 24, 64, 25, device='cuda')
+    a1 = torch.randn(128, 24, 25, 25, device='cuda')
+    a2 = torch.randn(128, 24, 25, 25, device='cuda')
+    lhs = K.aggregate(zp, None, False, a1 + a2)
+    rhs = K.aggregate(zp, None, False, a1) + K.aggregate(zp, None, False, a2)
+    assert rel(lhs.cpu(), rhs.cpu()) < 1e-6                   # linear in the adjacency

@@ -1,0 +1,119 @@
+"""CPU: the oracle (oracle/dsgcn_oracle.py) against the committed golden vectors (tests/golden/*.npz, generated from the
+imported reference by tests/golden/gen_golden.py) and, where /root/reference exists, against the reference itself."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dsgcn_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+def sd_of(npz, prefix, dtype=torch.float64):
+    out = {}
+    for k, v in npz.items():
+        if k.startswith(prefix):
+            t = torch.from_numpy(v)
+            out[k[len(prefix):]] = t.to(dtype) if t.dtype.is_floating_point else t
+    return out
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+
+
+def test_graph_constants():
+    g = load('graph_constants.npz')
+    for lay, tag in (('nturgb+d', 'nturgbpd'), ('coco', 'coco')):
+        c = O.graph_constants(lay)
+        assert np.array_equal(c['node_type'], g[f'{tag}_node_type'])
+        assert np.array_equal(c['edge_type'], g[f'{tag}_edge_type'])          # integer tables: bit-exact
+        assert np.array_equal(O.graph_A(lay, 'spatial'), g[f'{tag}_spatial'])
+        assert np.array_equal(O.graph_A(lay, 'stgcn_spatial'), g[f'{tag}_stgcn_spatial'])
+
+
+@pytest.mark.parametrize('i', [0, 1, 2])
+def test_dgphgcn1_unit(i):
+    z = load('unit_dgphgcn1.npz')
+    tag = f'u{i}_'
+    sd = sd_of(z, tag + 'sd_')
+    gc = O.graph_constants('nturgb+d')
+    x = torch.from_numpy(z[tag + 'x']).double().requires_grad_()
+    for k in ('A', 'alpha', 'beta', 'edge_linears.weight', 'conv1_se.weight', 'pre.1.weight'):
+        sd[k].requires_grad_()
+    y = O.dgphgcn1_forward(x, sd, gc['node_type'], gc['edge_type'])
+    (y * torch.from_numpy(z[tag + 'R']).double()).sum().backward()
+    # goldens are fp64 results stored as fp32: 1e-6 relative
+    assert rel(y.detach(), z[tag + 'y']) < 1e-6
+    assert rel(x.grad, z[tag + 'dx']) < 1e-6
+    for k in ('A', 'alpha', 'beta', 'edge_linears.weight', 'conv1_se.weight', 'pre.1.weight'):
+        assert rel(sd[k].grad, z[tag + 'grad_' + k]) < 1e-6, k
+
+
+@pytest.mark.parametrize('i,stride', [(0, 1), (1, 2)])
+def test_dgmstcn_unit(i, stride):
+    z = load('unit_dgmstcn.npz')
+    tag = f't{i}_'
+    sd = sd_of(z, tag + 'sd_')
+    sd['add_coeff'].requires_grad_()
+    x = torch.from_numpy(z[tag + 'x']).double().requires_grad_()
+    y = O.dgmstcn_forward(x, sd, stride)
+    (y * torch.from_numpy(z[tag + 'R']).double()).sum().backward()
+    assert rel(y.detach(), z[tag + 'y']) < 1e-6
+    assert rel(x.grad, z[tag + 'dx']) < 1e-6
+    assert rel(sd['add_coeff'].grad, z[tag + 'grad_add_coeff']) < 1e-6
+
+
+def _reduced():
+    z = load('model_reduced.npz')
+    with open(os.path.join(GOLD, 'model_reduced_cfg.json')) as f:
+        cfg = json.load(f)
+    bk = cfg['backbone']
+    plan = O.dgstgcn_plan(3, bk['base_channels'], 2, bk['num_stages'], tuple(bk['inflate_stages']),
+                          tuple(bk['down_stages']))
+    return z, cfg, plan
+
+
+def test_reduced_model_fp64_and_fp32():
+    z, cfg, plan = _reduced()
+    gc = O.graph_constants('nturgb+d')
+    x = torch.from_numpy(z['x'])
+    y = torch.from_numpy(z['label'])
+    sd64 = sd_of(z, 'sd_')
+    logits, loss = O.recognizer_forward_train(x.double(), y, sd64, gc['node_type'], gc['edge_type'], plan)
+    assert rel(logits, z['logits_f64']) < 1e-6
+    assert abs(loss.item() - float(z['loss_f64'])) < 1e-9 * max(1, abs(float(z['loss_f64']))) + 1e-7
+    sd32 = sd_of(z, 'sd_', torch.float32)
+    logits32, loss32 = O.recognizer_forward_train(x, y, sd32, gc['node_type'], gc['edge_type'], plan)
+    # fp32 oracle vs the reference's own fp32 output: same op sequence, 1e-5 relative
+    assert rel(logits32, z['logits_f32']) < 1e-5
+    assert abs(loss32.item() - float(z['loss_f32'])) < 1e-5
+
+
+def test_oracle_vs_reference_live():
+    import ref_shim
+    if not ref_shim.available():
+        pytest.skip('reference tree not present (GPU box)')
+    R = ref_shim.load()
+    torch.manual_seed(1)
+    np.random.seed(1)
+    G = R.graph.Graph(layout='coco', mode='random', num_filter=3, init_off=.04, init_std=.02)
+    A = torch.tensor(G.A, dtype=torch.float32)
+    m = R.gutils.dgphgcn1(64, 64, A, torch.tensor(G.edge_type, dtype=torch.float32), torch.tensor(G.node_type),
+                          ratio=0.125, decompose=True, node_attention=True, edge_attention=True, subset_wise=True,
+                          ctr='T', ada='T').double()
+    with torch.no_grad():
+        m.alpha.normal_(0, .5)
+        m.beta.normal_(0, .5)
+    x = torch.randn(2, 64, 10, 17, dtype=torch.float64)
+    gc = O.graph_constants('coco')
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    assert (m(x) - O.dgphgcn1_forward(x, sd, gc['node_type'], gc['edge_type'])).abs().max().item() < 1e-12
