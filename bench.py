@@ -65,6 +65,21 @@ def ka_alg_bytes(n, KC, t, v, bwd):
     return 4 * units * ((3 * t * v + 2 * v * v) if bwd else (2 * t * v + v * v))
 
 
+def _pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction +
+    WRITE_SIZE, tools/ka_once.py as the profiled program); None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'ka_traffic.json')))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    for k, v in d.items():
+        if k.startswith(kernel):
+            return v.get('hbm_bytes_per_launch')
+    return None
+
+
 def measure_ka_roofline(device, n, reps=20):
     """HIP-event timing of K-A fwd and bwd over the model's layer mix (distinct buffers per layer so the
     working set, 0.64 GB fwd / 1.05 GB bwd, exceeds the 256 MiB Infinity Cache)."""
@@ -111,7 +126,7 @@ def measure_ka_roofline(device, n, reps=20):
         launches = len(bufs)
         gbs = nbytes / (ms * 1e-3) / 1e9
         out[name] = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                         frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                         frac=round(gbs / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(name),
                          avg_launch_us=round(ms * 1e3 / launches, 2), alg_bytes_per_launch=nbytes // launches,
                          launches_per_step=launches)
     return out

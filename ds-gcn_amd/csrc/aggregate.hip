@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
                                                            const float* __restrict__ ahat, float* __restrict__ y,
-                                                           int KC, int T, int chunks, long items) {
+                                                           int KC, int T, int chunks, long items, int direct) {
   constexpr int KS = (V + 1) / 2;
   constexpr int NP4 = (64 * V / 4 + 63) / 64;     // float4 loads per lane for a full 64-frame plane
   constexpr int NA = (V * V + 63) / 64;           // dword loads per lane for the adjacency
@@ -283,28 +283,45 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
         }
       }
     }
-    wave_lds_sync();
-    if (mi < V) {
+    if (direct) {
+      // accumulator layout -> HBM directly: per instruction two 4*V-byte row segments (rows t and t+4); a unit's rows are
+      // contiguous, so every 128-B line is completed by the same wave within a few instructions
+      float* __restrict__ yo = y + ((size_t)unit * T + t0) * V;
+      if (mi < V) {
 #pragma unroll
-      for (int tile = 0; tile < 2; ++tile) {
+        for (int tile = 0; tile < 2; ++tile) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int t = tile * 32 + mfma_row(r, mk);
-          if (t < rows) ldsP[t * V + mi] = acc[tile][r];
+          for (int r = 0; r < 16; ++r) {
+            const int t = tile * 32 + mfma_row(r, mk);
+            if (t < rows) yo[t * V + mi] = acc[tile][r];
+          }
         }
       }
-    }
-    wave_lds_sync();
-    {
-      f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(y + ((size_t)unit * T + t0) * V);
-      const f32x4* l4 = reinterpret_cast<const f32x4*>(ldsP);
+      wave_lds_sync();
+    } else {
+      wave_lds_sync();
+      if (mi < V) {
 #pragma unroll
-      for (int q = 0; q < NP4; ++q) {
-        const int i = lane + q * 64;
-        if (i < c4) d4[i] = l4[i];
+        for (int tile = 0; tile < 2; ++tile) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int t = tile * 32 + mfma_row(r, mk);
+            if (t < rows) ldsP[t * V + mi] = acc[tile][r];
+          }
+        }
       }
+      wave_lds_sync();
+      {
+        f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(y + ((size_t)unit * T + t0) * V);
+        const f32x4* l4 = reinterpret_cast<const f32x4*>(ldsP);
+#pragma unroll
+        for (int q = 0; q < NP4; ++q) {
+          const int i = lane + q * 64;
+          if (i < c4) d4[i] = l4[i];
+        }
+      }
+      wave_lds_sync();
     }
-    wave_lds_sync();
     item = next;
   }
 }
@@ -497,16 +514,24 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
     f32x16 accA;
 #pragma unroll
     for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+    // dAhat = P^T dY : k runs over frames; operands of 8 k-steps are read from LDS before their MFMAs are issued
+    // (a read->use chain per step left the matrix pipe idle ~2/3 of the time: tools/ka_ablate.py)
     if (!(ablate & 1))
-    for (int j = 0; j < rows; j += 2) {
-      const int t = j + mk;
-      const bool ok = (mi < V) && (t < rows);
-      const int idx = (t < rows ? t : rows - 1) * V + mic;
-      float a = affine_act(ldsZ[idx], s, h, relu);
-      float b = ldsG[idx];
-      a = ok ? a : 0.f;
-      b = ok ? b : 0.f;
-      accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accA, 0, 0, 0);
+    for (int j0 = 0; j0 < rows; j0 += 16) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int t = j0 + 2 * q + mk;
+        const bool ok = (mi < V) && (t < rows);
+        const int idx = (t < rows ? t : rows - 1) * V + mic;
+        const float a = affine_act(ldsZ[idx], s, h, relu);
+        const float b = ldsG[idx];
+        av[q] = ok ? a : 0.f;
+        bv[q] = ok ? b : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (j0 + 2 * q < rows) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accA, 0, 0, 0);
     }
     {
       float* __restrict__ dA = dahat + (size_t)unit * V * V;
@@ -575,6 +600,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
 int g_pipe_waves = 0;       // tuning knobs (dsgcn_set_tuning)
 int g_pipe_waves_bwd = 0;
 int g_ablate = 0;
+int g_fwd_direct = 1;
 int g_bwd_variant = 0;      // 1 = one-shot kernel (A/B)
 
 template <int V>
@@ -598,7 +624,7 @@ int launch_fwd(const float* zp, const float* scale, const float* shift, int relu
     const long per = (items + waves - 1) / waves;
     const long g = (items + per - 1) / per;
     hipLaunchKernelGGL((k_aggregate_fwd_pipe<V>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu, ahat,
-                       y, KC, T, chunks, items);
+                       y, KC, T, chunks, items, g_fwd_direct);
   }
   DSGCN_LAUNCH_CHECK();
   return 0;
@@ -657,6 +683,7 @@ int dsgcn_set_tuning(int key, int value) {
   if (key == 1) { g_pipe_waves_bwd = value; return 0; }
   if (key == 2) { g_bwd_variant = value; return 0; }
   if (key == 3) { g_ablate = value; return 0; }
+  if (key == 4) { g_fwd_direct = value; return 0; }
   return DSGCN_EINVAL;
 }
 

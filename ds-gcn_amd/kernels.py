@@ -415,27 +415,90 @@ class _TmsCombine(torch.autograd.Function):
         return do, dcoeff, dgamma, dbeta, None, None
 
 
+def _int_array(vals):
+    return (_ct.c_int * len(vals))(*vals)
+
+
+def _ptr_array(tensors):
+    return (_ct.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class _TapBranches(torch.autograd.Function):
+    """The temporal branches of dgmstcn on the activated tensor h (n,C,T,V+1) -> o (n,C,T',V+1):
+    dilated (3,1) convs on the matrix core, (3,1) max-pool, strided copy — one HIP launch per direction."""
+
+    @staticmethod
+    def forward(ctx, h, stride, types, c0s, bcs, dils, *wb):
+        _require_cuda(h)
+        h = _f32c(h)
+        n, C, T, V1 = h.shape
+        nbr = len(types)
+        ws = [_f32c(t) for t in wb[:nbr]]
+        bs = [_f32c(t) for t in wb[nbr:]]
+        Tout = (T + stride - 1) // stride
+        o = torch.empty((n, C, Tout, V1), device=h.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_tapconv_fwd(_ptr(h), _ptr(o), n, C, T, V1, stride, 3, nbr, _int_array(types),
+                                            _int_array(c0s), _int_array(bcs), _int_array(dils), _ptr_array(ws),
+                                            _ptr_array(bs), _stream())
+        native.check(rc, 'dsgcn_tapconv_fwd')
+        ctx.save_for_backward(h, *[w for w in ws if w is not None])
+        ctx.cfg = (stride, tuple(types), tuple(c0s), tuple(bcs), tuple(dils))
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        h, *wsaved = ctx.saved_tensors
+        stride, types, c0s, bcs, dils = ctx.cfg
+        n, C, T, V1 = h.shape
+        nbr = len(types)
+        go = _f32c(go)
+        lib = native.lib()
+        it = iter(wsaved)
+        ws = [next(it) if t == 0 else None for t in types]
+        dh = torch.empty_like(h)
+        rc = lib.dsgcn_tapconv_dgrad(_ptr(h), _ptr(go), _ptr(dh), n, C, T, V1, stride, 3, nbr, _int_array(types),
+                                     _int_array(c0s), _int_array(bcs), _int_array(dils), _ptr_array(ws), _stream())
+        native.check(rc, 'dsgcn_tapconv_dgrad')
+        Tout = go.shape[2]
+        splits = max(1, min(256, n * ((Tout + 1) // 2)))
+        dwp = [torch.empty((splits, bc * bc * 3), device=h.device, dtype=torch.float32) if t == 0 else None
+               for t, bc in zip(types, bcs)]
+        dbp = [torch.empty((splits, bc), device=h.device, dtype=torch.float32) if t == 0 else None
+               for t, bc in zip(types, bcs)]
+        rc = lib.dsgcn_tapconv_wgrad(_ptr(h), _ptr(go), n, C, T, V1, stride, 3, nbr, _int_array(types),
+                                     _int_array(c0s), _int_array(bcs), _int_array(dils), _ptr_array(dwp),
+                                     _ptr_array(dbp), splits, _stream())
+        native.check(rc, 'dsgcn_tapconv_wgrad')
+        dws = [colsum(p).view(bc, bc, 3, 1) if p is not None else None for p, bc in zip(dwp, bcs)]
+        dbs = [colsum(p) if p is not None else None for p in dbp]
+        return (dh, None, None, None, None, None, *dws, *dbs)
+
+
 def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, add_coeff, stride, gamma=None,
                 beta=None, eps=1e-5, want_bn=False):
-    """-> (f, scale, shift, mean, var).  branch_act and combine (+BN statistics) are HIP kernels; the dilated 3x1
-    convolutions / max-pool in between are still PyTorch-ROCm device ops (MIOpen) this round."""
+    """-> (f, scale, shift, mean, var): branch_act -> temporal branches (dilated convs / max-pool / copy) -> combine
+    (+ statistics of transform.0's BatchNorm); three HIP stages, no torch.cat, no MIOpen."""
     _require_cuda(z)
     n, C, T, V = z.shape
     h = _BranchAct.apply(z, zaug, scale, shift, n_act)
-    outs, c0, ci = [], 0, 0
+    types, c0s, bcs, dils, ws, bs = [], [], [], [], [], []
+    c0 = ci = 0
     for cfg, bc in zip(branch_cfg, widths):
-        hb = h[:, c0:c0 + bc]
         if cfg == '1x1':
-            outs.append(hb[:, :, ::stride])
+            types.append(2); dils.append(1); ws.append(None); bs.append(None)
         elif cfg[0] == 'max':
-            outs.append(F.max_pool2d(hb, (cfg[1], 1), (stride, 1), (1, 0)))
+            if cfg[1] != 3:
+                raise NotImplementedError('max-pool branch: only kernel 3 has a HIP path')
+            types.append(1); dils.append(1); ws.append(None); bs.append(None)
         else:
             k, d = cfg
-            pad = (k + (k - 1) * (d - 1) - 1) // 2
-            outs.append(F.conv2d(hb, conv_w[ci], conv_b[ci], stride=(stride, 1), padding=(pad, 0), dilation=(d, 1)))
+            if k != 3 or bc > 64:
+                raise NotImplementedError('temporal conv branch: HIP path covers kernel 3 and <= 64 channels per branch')
+            types.append(0); dils.append(int(d)); ws.append(conv_w[ci]); bs.append(conv_b[ci])
             ci += 1
+        c0s.append(c0); bcs.append(int(bc))
         c0 += bc
-    o = torch.cat(outs, 1)
+    o = _TapBranches.apply(h, int(stride), types, c0s, bcs, dils, *ws, *bs)
     return _TmsCombine.apply(o, add_coeff[:V].contiguous(), gamma, beta, float(eps), bool(want_bn))
 
 

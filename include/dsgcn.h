@@ -78,6 +78,33 @@ int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const 
                        const float* h2, int relu, const float* dout, const float* dxbar, float* dx1, float* dx2,
                        float* part, int n, int C, int T, int V, void* stream);
 
+/* K-D: dgmstcn temporal stages (tcn.py:379-428).
+ * branch_act: h (n,C,T,V+1) = act_c(z*scale+shift) with the global-joint column zaug appended (ReLU for c < n_act).
+ * tapconv   : the branches between — type 0 dilated (3,1) conv (weights (bc,bc,3,1), bias (bc)), 1 = (3,1) max-pool,
+ *             2 = strided copy — each writing its channel window [c0,c0+bc) of o (n,C,T',V+1); branch tables are
+ *             host arrays of length nbr <= 8.  wgrad writes K-split partials dwp[i] (splits, bc*bc*3), dbp[i] (splits, bc).
+ * combine   : f = o[..,:V] + o[..,V]*coeff, per-plane sum / sum of squares of f (n*C, 2). */
+int dsgcn_branch_act_fwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                         float* h, int n, int C, int T, int V, void* stream);
+int dsgcn_branch_act_bwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                         const float* dh, float* dz, float* dzaug, float* part, int n, int C, int T, int V,
+                         void* stream);
+int dsgcn_tapconv_fwd(const float* h, float* o, int n, int C, int T, int V1, int stride, int KT, int nbr,
+                      const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
+                      const float* const* b, void* stream);
+int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int C, int T, int V1, int stride, int KT,
+                        int nbr, const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
+                        void* stream);
+int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int C, int T, int V1, int stride, int KT, int nbr,
+                        const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp,
+                        float* const* dbp, int splits, void* stream);
+int dsgcn_tms_combine_fwd(const float* o, const float* coeff, float* f, float* partial, int n, int C, int T, int V,
+                          void* stream);
+int dsgcn_tms_combine_bwd(const float* o, const float* coeff, const float* gf, const float* A0, const float* B0,
+                          float* dout, float* pcoef, int n, int C, int T, int V, void* stream);
+int dsgcn_pwconv_ipart_rows(int n, int Ci, int T, int V, int stride);
+int dsgcn_diag_mfma_probe(float* out, int blocks, int iters, int nacc, void* stream);
+
 /* ---- K-C: 1x1 channel mix with fused train-mode BatchNorm / ReLU / residual --------------------------------
  * Replaces Conv2d(1x1)+BatchNorm2d+ReLU(+add) chains of gcn.py:2165-2169,2209-2215,2236,2363-2365 and
  * tcn.py:379-404,409,422,427 and tcn.py:21-28 (kernel_size 1).

@@ -59,14 +59,13 @@ for KC, T in shapes:
     t = timeit(cp); line += f'| copy {t:6.1f}us {2*zp.numel()*4/t/1e3:6.0f}GB/s '
     for v, nm in ():
         t = timeit(mk(v)); line += f'| {nm} {t:6.1f}us {fb/t/1e3:6.0f}GB/s '
-    for w in (3072,):
-        lib.dsgcn_set_tuning(0, w)
-        t = timeit(mk(0)); line += f'| pipe{w} {t:6.1f}us {fb/t/1e3:6.0f}GB/s '
+    for w in (2048, 3072, 4096):
+        for direct in (0, 1):
+            lib.dsgcn_set_tuning(0, w); lib.dsgcn_set_tuning(4, direct)
+            t = timeit(mk(0)); line += f'| p{w}d{direct} {t:5.1f}us {fb/t/1e3:5.0f} '
+    lib.dsgcn_set_tuning(4, 0)
     lib.dsgcn_set_tuning(0, 0)
-    lib.dsgcn_set_tuning(2, 1)
-    t = timeit(bwd); line += f'| bwd1shot {t:6.1f}us {bb/t/1e3:6.0f}GB/s'
-    lib.dsgcn_set_tuning(2, 0)
-    for w in (1536, 2048, 2560, 3072):
+    for w in (2048,):
         lib.dsgcn_set_tuning(1, w)
         t = timeit(bwd); line += f'| bwd{w} {t:6.1f}us {bb/t/1e3:6.0f}GB/s'
     lib.dsgcn_set_tuning(1, 0)
