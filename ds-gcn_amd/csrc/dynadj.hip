@@ -135,19 +135,19 @@ __global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d, const float* __res
 // Backward, per sample.  Workspace `dd` (n,3,mid,V,V) receives dD_k (k=1: later d(delta)) so the
 // row/column reductions and the per-edge-class weight gradient can read it back; it aliases nothing.
 // Outputs: dproj (n,9mid,V) (typed rows: only row c*P+tau(v) of joint v is non-zero); pA (n,3,V,V) = sum_c dAhat;
-// pab (n,6) = [dalpha_k | dbeta_k] partials; dwe (E*mid,mid) / dbe (E*mid) accumulated with float atomics
-// (zeroed by the caller).  pair_order / class_start: joint pairs sorted by edge class (host-built constant).
+// pab (n,6) = [dalpha_k | dbeta_k] partials.  ddelta (n,mid,V,V): second workspace for d(a1[u]-b1[w]).
+// The edge-typed weight gradient is a separate, wider launch (k_dynadj_dwe) reading dd's k=1 slice.
 __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     DynDims d, const float* __restrict__ proj, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ we, const float* __restrict__ be, const int* __restrict__ node_type,
     const int* __restrict__ edge_type, const int* __restrict__ pair_order, const int* __restrict__ class_start,
-    const float* __restrict__ dahat, float* dd, float* __restrict__ dproj, float* __restrict__ pA,
-    float* __restrict__ pab, float* __restrict__ dwe, float* __restrict__ dbe) {
+    const float* __restrict__ dahat, float* dd, float* ddelta, float* __restrict__ dproj, float* __restrict__ pA,
+    float* __restrict__ pab, int pstride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[6][NT / DSGCN_WAVE];
   const int tid = threadIdx.x;
   const int n = blockIdx.x;
-  const int mid = d.mid, V = d.V, VV = V * V, E = d.E;
+  const int mid = d.mid, V = d.V, VV = V * V;
   dyn_prepare(d, lds, proj + (size_t)n * 9 * mid * V, we, be, node_type);
   const float* X = lds + lds_X(d);
   const float* Sm = lds + lds_G(d);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     pbe0 += (k == 0) ? v : 0.f;
     pbe1 += (k == 1) ? v : 0.f;
     pbe2 += (k == 2) ? v : 0.f;
-    pA[(size_t)n * KSUB * VV + i] = SC[i];
+    pA[(size_t)n * pstride + i] = SC[i];
   }
   __syncthreads();
   // softmax backward per column (k,w): SC <- dG = Sm * (beta*SC - sum_u Sm*beta*SC)
@@ -207,39 +207,10 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
       SC[idx] = Sm[idx] * (bk * SC[idx] - dot);
     }
   }
-  // edge-typed weights: thread = (e,c,cc); reduce over the pairs of class e
-  //   dWe[e,c,cc] = sum_pairs dD1[c,pair] * (a1[cc,u]-b1[cc,w]);  dbe[e,c] = sum_pairs dD1[c,pair]
+  // d(delta)[cc,u,w] = sum_c We[eps,c,cc] dD1[c,u,w]  -> second workspace (dD1 itself is kept for k_dynadj_dwe)
   {
-    const float* a1 = X + 1 * mid * V;
-    const float* bb1 = X + 4 * mid * V;
     const float* dd1 = dd_n + (size_t)1 * mid * VV;
-    for (int o = tid; o < E * mid * mid; o += NT) {
-      const int e = o / (mid * mid), rr = o - e * mid * mid, c = rr / mid, cc = rr - c * mid;
-      float acc = 0.f, accb = 0.f;
-      const int p0 = class_start[e], p1 = class_start[e + 1];
-      for (int pb = p0; pb < p1; pb += 8) {
-        float gv[8];
-        int rv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          rv[j] = (pb + j < p1) ? pair_order[pb + j] : 0;
-          gv[j] = (pb + j < p1) ? dd1[c * VV + rv[j]] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int u = rv[j] / V, w = rv[j] - u * V;
-          acc = fmaf(gv[j], a1[cc * V + u] - bb1[cc * V + w], acc);
-          accb += gv[j];
-        }
-      }
-      atomicAdd(dwe + o, acc);
-      if (cc == 0) atomicAdd(dbe + e * mid + c, accb);
-    }
-  }
-  __syncthreads();
-  // d(delta)[cc,u,w] = sum_c We[eps,c,cc] dD1[c,u,w], in place (thread = pair; each thread owns its column)
-  {
-    float* dd1 = dd_n + (size_t)1 * mid * VV;
+    float* dl = ddelta + (size_t)n * mid * VV;
     for (int r = tid; r < VV; r += NT) {
       const int e = edge_type[r];
       float dv[32], out[32];
@@ -257,14 +228,14 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
       }
 #pragma unroll
       for (int cc = 0; cc < 32; ++cc)
-        if (cc < mid) dd1[cc * VV + r] = out[cc];
+        if (cc < mid) dl[cc * VV + r] = out[cc];
     }
   }
   __syncthreads();
   // row/col sums + Gram backward: thread = (k,c,j)
   for (int o = tid; o < KSUB * mid * V; o += NT) {
     const int k = o / (mid * V), rr = o - k * mid * V, c = rr / V, j = rr - c * V;
-    const float* dk = dd_n + (size_t)(k * mid + c) * VV;
+    const float* dk = (k == 1) ? ddelta + ((size_t)n * mid + c) * VV : dd_n + (size_t)(k * mid + c) * VV;
     float rs = 0.f, cs = 0.f;
     {
       float rv[32], cv[32];
@@ -315,7 +286,64 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
   if (tid < 6) {
     float r = 0.f;
     for (int i = 0; i < NT / DSGCN_WAVE; ++i) r += red[tid][i];
-    pab[(size_t)n * 6 + tid] = r;
+    pab[(size_t)n * pstride + tid] = r;
+  }
+}
+
+// Edge-typed weight gradient: one workgroup per (sample, edge class e).
+//   dWe[e,c,cc] += sum_{(u,w) in class e} dD1[n,c,u,w] * (a1[n,cc,u] - b1[n,cc,w]);   dbe[e,c] += sum dD1[n,c,u,w]
+// The class's pairs (<= 256) are staged in LDS once (dD1 column and delta column per pair), then every (c,cc) output is a
+// short LDS dot product; results are accumulated into dwe/dbe with float atomics (128 adders per address).
+__global__ __launch_bounds__(NT) void k_dynadj_dwe(DynDims d, const float* __restrict__ proj,
+                                                   const float* __restrict__ dd, const int* __restrict__ pair_order,
+                                                   const int* __restrict__ class_start, float* __restrict__ dwe,
+                                                   float* __restrict__ dbe) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n = blockIdx.x, e = blockIdx.y;
+  const int mid = d.mid, V = d.V, VV = V * V;
+  const int p0 = class_start[e], np = class_start[e + 1] - p0;
+  if (np <= 0) return;
+  const int NPs = np | 1;
+  float* Dl = lds;                      // [mid][NPs]  dD1[c][pair]
+  float* El = lds + mid * NPs;          // [mid][NPs]  delta[cc][pair]
+  const float* dd1 = dd + ((size_t)n * KSUB + 1) * mid * VV;
+  const float* a1 = proj + ((size_t)n * 9 * mid + 1 * mid) * V;           // rows mid..2mid-1  (a, k=1)
+  const float* b1 = proj + ((size_t)n * 9 * mid + 3 * mid) * V;           // rows 3mid..4mid-1 (b, k=1)
+  for (int i0 = threadIdx.x; i0 < mid * np; i0 += NT * 4) {
+    float dv[4], ev[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q * NT;
+      dv[q] = 0.f; ev[q] = 0.f;
+      if (i < mid * np) {
+        const int c = i / np, p = i - c * np;
+        const int r = pair_order[p0 + p];
+        const int u = r / V, w = r - u * V;
+        dv[q] = dd1[c * VV + r];
+        ev[q] = a1[c * V + u] - b1[c * V + w];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q * NT;
+      if (i < mid * np) {
+        const int c = i / np, p = i - c * np;
+        Dl[c * NPs + p] = dv[q];
+        El[c * NPs + p] = ev[q];
+      }
+    }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < mid * mid; o += NT) {
+    const int c = o / mid, cc = o - c * mid;
+    float acc = 0.f, accb = 0.f;
+    for (int p = 0; p < np; ++p) {
+      const float g = Dl[c * NPs + p];
+      acc = fmaf(g, El[cc * NPs + p], acc);
+      accb += g;
+    }
+    atomicAdd(dwe + (size_t)e * mid * mid + o, acc);
+    if (cc == 0) atomicAdd(dbe + e * mid + c, accb);
   }
 }
 
@@ -351,9 +379,9 @@ int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, cons
 
 int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
                      const int* node_type, const int* edge_type, const int* pair_order, const int* class_start,
-                     const float* dahat, float* dd_ws, float* dproj, float* pA, float* pab, float* dwe, float* dbe,
-                     int n, int mid, int V, int P, int E, void* stream) {
-  if (!proj || !dahat || !dd_ws || !dproj || !pA || !pab || !dwe || !dbe) return DSGCN_EINVAL;
+                     const float* dahat, float* dd_ws, float* ddelta_ws, float* dproj, float* pA, float* pab,
+                     int pstride, float* dwe, float* dbe, int n, int mid, int V, int P, int E, void* stream) {
+  if (!proj || !dahat || !dd_ws || !ddelta_ws || !dproj || !pA || !pab || !dwe || !dbe) return DSGCN_EINVAL;
   if (V > 32 || mid > 32) return DSGCN_EUNSUPPORTED;
   const size_t lds = dyn_lds_bytes(mid, V, E, true);
   if (lds > 156 * 1024) return DSGCN_EUNSUPPORTED;
@@ -366,7 +394,16 @@ int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, c
     attr_bwd = 156 * 1024;
   }
   hipLaunchKernelGGL(k_dynadj_bwd, dim3(n), dim3(NT), lds, st, d, proj, alpha, beta, we, be, node_type, edge_type,
-                     pair_order, class_start, dahat, dd_ws, dproj, pA, pab, dwe, dbe);
+                     pair_order, class_start, dahat, dd_ws, ddelta_ws, dproj, pA, pab, pstride);
+  DSGCN_LAUNCH_CHECK();
+  const size_t lds2 = (size_t)2 * mid * ((V * V) | 1) * sizeof(float);   // worst case: one class holds every pair
+  static size_t attr_dwe = 64 * 1024;
+  if (lds2 > attr_dwe) {
+    hipError_t e2 = hipFuncSetAttribute((const void*)k_dynadj_dwe, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    if (e2 != hipSuccess) return (int)e2;
+    attr_dwe = 156 * 1024;
+  }
+  hipLaunchKernelGGL(k_dynadj_dwe, dim3(n, E), dim3(NT), lds2, st, d, proj, dd_ws, pair_order, class_start, dwe, dbe);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

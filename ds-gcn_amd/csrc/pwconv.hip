@@ -636,6 +636,7 @@ struct PwBwdArgs {
   float* dwp; float* dbp;                  // [ksplit][Co][Ci], [ksplit][Co]
   int n, Ci, Co, T, V, Tout, stride, aug, TR, NPpad, vec;
   int chunks_per_split, total_chunks, nb_per_sample;
+  int pstride;                             // floats between consecutive k-splits in dwp / dbp
 };
 
 __device__ __forceinline__ float dz_eff_at(const PwBwdArgs& a, size_t gi, size_t gaug, int co, float invV) {
@@ -1231,10 +1232,10 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_wgrad(PwBwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int coo = coBase + 32 * mt + mfma_row32(r, half);
-      if (coo < Co) a.dwp[((size_t)split * Co + coo) * Ci + cio] = acc[r];
+      if (coo < Co) a.dwp[(size_t)split * a.pstride + (size_t)coo * Ci + cio] = acc[r];
     }
   }
-  if (blockIdx.y == 0 && quarter == 0 && co < Co) a.dbp[(size_t)split * Co + co] = dbacc;
+  if (blockIdx.y == 0 && quarter == 0 && co < Co) a.dbp[(size_t)split * a.pstride + co] = dbacc;
 }
 
 // BN backward coefficients of a conv whose batch statistics feed a deferred affine (scale, shift):
@@ -1429,11 +1430,12 @@ int dsgcn_pwconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int stride) {
   return (chunks + per - 1) / per;
 }
 
-// Backward, weight path.  dwp: (splits, Co, Ci), dbp: (splits, Co) partial sums (sum over dim 0 = dW, db).
+// Backward, weight path.  Partial sums per k-split: split s writes dW at dwp + s*pstride (Co*Ci floats) and db at
+// dbp + s*pstride (Co floats); one dsgcn_colsum over (splits, pstride) rows finishes both when they share a buffer.
 int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, const float* z, const float* zaug, const float* gz,
-                       const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int n, int Ci,
-                       int Co, int T, int V, int stride, int aug, void* stream) {
+                       const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int pstride, int n,
+                       int Ci, int Co, int T, int V, int stride, int aug, void* stream) {
   if (!x1 || !dwp || !dbp || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0 || stride <= 0) return DSGCN_EINVAL;
   if ((A0 && (!B0 || !z)) || (aug && A0 && !zaug)) return DSGCN_EINVAL;
   const int Tout = (T + stride - 1) / stride;
@@ -1442,6 +1444,8 @@ int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const 
   PwBwdArgs a = {};
   a.x1 = x1; a.s1 = s1; a.h1 = h1; a.x2 = x2; a.s2 = s2; a.h2 = h2; a.relu = relu;
   a.z = z; a.zaug = zaug; a.gz = gz; a.gzaug = gzaug; a.A0 = A0; a.B0 = B0; a.dwp = dwp; a.dbp = dbp;
+  a.pstride = pstride;
+  if (pstride < Co * Ci) return DSGCN_EINVAL;
   a.n = n; a.Ci = Ci; a.Co = Co; a.T = T; a.V = V; a.Tout = Tout; a.stride = stride; a.aug = aug; a.TR = TR;
   a.nb_per_sample = (Tout + TR - 1) / TR;
   a.total_chunks = n * a.nb_per_sample;

@@ -34,7 +34,7 @@ struct TArgs {
   float* o;            // (n, C, Tout, V1)
   const float* go;     // grad of o
   float* dh;           // grad of h
-  int n, C, T, Tout, V1, stride, nbr, splits;
+  int n, C, T, Tout, V1, stride, nbr, splits, pstride;
   TBranch br[TC_MAXBR];
 };
 
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
   }
   // D[i=co][j=ci] per tap -> dwp[split][(co*bc + ci)*KT + tap]
   const int ci = 32 * nt + l31;
-  float* dwp = br.dwp + (size_t)blockIdx.x * bc * bc * KT;
+  float* dwp = br.dwp + (size_t)blockIdx.x * a.pstride;
   if (ci < bc) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
       }
     }
   }
-  if (quarter == 0 && row < bc) br.dbp[(size_t)blockIdx.x * bc + row] = dbacc;
+  if (quarter == 0 && row < bc) br.dbp[(size_t)blockIdx.x * a.pstride + row] = dbacc;
 }
 
 size_t tc_lds_conv(int bcmax, int KT) {
@@ -388,14 +388,16 @@ int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int C
   return 0;
 }
 
-// dwp[i]: (splits, bc*bc*KT), dbp[i]: (splits, bc) for the conv branches (NULL entries for the others).
+// Conv branch i writes split s of its weight / bias partials at dwp[i] + s*pstride / dbp[i] + s*pstride (all branches
+// may share one (splits, pstride) buffer -> one dsgcn_colsum); NULL entries for the other branch types.
 int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int C, int T, int V1, int stride, int KT, int nbr,
                         const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp,
-                        float* const* dbp, int splits, void* stream) {
+                        float* const* dbp, int splits, int pstride, void* stream) {
   if (!h || !go || n <= 0 || nbr <= 0 || nbr > TC_MAXBR || splits <= 0) return DSGCN_EINVAL;
   if (KT != 3 || V1 > 26) return DSGCN_EUNSUPPORTED;
   TArgs a = {};
   a.h = h; a.go = go; a.n = n; a.C = C; a.T = T; a.V1 = V1; a.stride = stride; a.nbr = nbr; a.splits = splits;
+  a.pstride = pstride;
   a.Tout = (T + stride - 1) / stride;
   for (int i = 0; i < nbr; ++i) {
     a.br[i].type = type[i]; a.br[i].c0 = c0[i]; a.br[i].bc = bc[i]; a.br[i].dil = dil[i];

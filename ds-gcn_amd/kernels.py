@@ -163,18 +163,19 @@ class _DynAdj(torch.autograd.Function):
         dev = proj.device
         order, start, _ = _edge_class_lists(edge_type)
         dd = torch.empty_like(dahat)
+        ddelta = torch.empty((n, mid, V, V), device=dev, dtype=torch.float32)
         dproj = torch.empty_like(proj)
-        pA = torch.empty((n, 3, V, V), device=dev, dtype=torch.float32)
-        pab = torch.empty((n, 6), device=dev, dtype=torch.float32)
+        pboth = torch.empty((n, 3 * V * V + 6), device=dev, dtype=torch.float32)   # per-sample [sum_c dAhat | dalpha dbeta]
+        pA, pab = pboth, pboth
         zeros = torch.zeros(E * mid * mid + E * mid, device=dev, dtype=torch.float32)
         dwe, dbe = torch.split(zeros, [E * mid * mid, E * mid])
         rc = native.lib().dsgcn_dynadj_bwd(
             _ptr(proj), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be), _ptr(node_type), _ptr(edge_type), _ptr(order),
-            _ptr(start), _ptr(dahat), _ptr(dd), _ptr(dproj), _ptr(pA), _ptr(pab), _ptr(dwe), _ptr(dbe), n, mid, V, P,
-            E, _stream())
+            _ptr(start), _ptr(dahat), _ptr(dd), _ptr(ddelta), _ptr(dproj), pboth.data_ptr(),
+            pboth.data_ptr() + 4 * 3 * V * V, 3 * V * V + 6, _ptr(dwe), _ptr(dbe), n, mid, V, P, E, _stream())
         native.check(rc, 'dsgcn_dynadj_bwd')
-        dA = colsum(pA)
-        dab = colsum(pab)
+        red = colsum(pboth)
+        dA, dab = red[:3 * V * V].view(3, V, V), red[3 * V * V:]
         return dproj, dA, dab[:3], dab[3:], dwe.view(E * mid, mid), dbe, None, None
 
 
@@ -270,14 +271,15 @@ class _PwConv(torch.autograd.Function):
                                     _ptr(dx2), _ptr(ipart), n, Ci, Co, T, V, stride, aug, st)
         native.check(rc, 'dsgcn_pwconv_dgrad')
         splits = lib.dsgcn_pwconv_wgrad_splits(n, Ci, Co, T, V, stride)
-        dwp = torch.empty((splits, Co, Ci), device=dev, dtype=torch.float32)
-        dbp = torch.empty((splits, Co), device=dev, dtype=torch.float32)
+        pstride = Co * Ci + Co
+        wpart = torch.empty((splits, pstride), device=dev, dtype=torch.float32)
         rc = lib.dsgcn_pwconv_wgrad(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(z),
-                                    _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), _ptr(dwp), _ptr(dbp), n,
-                                    Ci, Co, T, V, stride, aug, st)
+                                    _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), wpart.data_ptr(),
+                                    wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, stride, aug, st)
         native.check(rc, 'dsgcn_pwconv_wgrad')
-        dw = colsum(dwp).view(wshape)
-        db = colsum(dbp) if has_bias else None
+        wsum = colsum(wpart)
+        dw = wsum[:Co * Ci].view(wshape)
+        db = wsum[Co * Ci:] if has_bias else None
         ds1 = dh1 = ds2 = dh2 = None
         if ipart is not None:
             red = colsum(ipart)
@@ -461,16 +463,24 @@ class _TapBranches(torch.autograd.Function):
         native.check(rc, 'dsgcn_tapconv_dgrad')
         Tout = go.shape[2]
         splits = max(1, min(256, n * ((Tout + 1) // 2)))
-        dwp = [torch.empty((splits, bc * bc * 3), device=h.device, dtype=torch.float32) if t == 0 else None
-               for t, bc in zip(types, bcs)]
-        dbp = [torch.empty((splits, bc), device=h.device, dtype=torch.float32) if t == 0 else None
-               for t, bc in zip(types, bcs)]
+        offs, off = [], 0
+        for t, bc in zip(types, bcs):
+            offs.append(off)
+            if t == 0:
+                off += bc * bc * 3 + bc
+        pstride = max(off, 1)
+        part = torch.empty((splits, pstride), device=h.device, dtype=torch.float32)
+        base = part.data_ptr()
+        dwp = (_ct.c_void_p * nbr)(*[base + 4 * o if t == 0 else None for t, o in zip(types, offs)])
+        dbp = (_ct.c_void_p * nbr)(*[base + 4 * (o + bc * bc * 3) if t == 0 else None
+                                     for t, o, bc in zip(types, offs, bcs)])
         rc = lib.dsgcn_tapconv_wgrad(_ptr(h), _ptr(go), n, C, T, V1, stride, 3, nbr, _int_array(types),
-                                     _int_array(c0s), _int_array(bcs), _int_array(dils), _ptr_array(dwp),
-                                     _ptr_array(dbp), splits, _stream())
+                                     _int_array(c0s), _int_array(bcs), _int_array(dils), dwp, dbp, splits, pstride,
+                                     _stream())
         native.check(rc, 'dsgcn_tapconv_wgrad')
-        dws = [colsum(p).view(bc, bc, 3, 1) if p is not None else None for p, bc in zip(dwp, bcs)]
-        dbs = [colsum(p) if p is not None else None for p in dbp]
+        red = colsum(part)
+        dws = [red[o:o + bc * bc * 3].view(bc, bc, 3, 1) if t == 0 else None for t, o, bc in zip(types, offs, bcs)]
+        dbs = [red[o + bc * bc * 3:o + bc * bc * 3 + bc] if t == 0 else None for t, o, bc in zip(types, offs, bcs)]
         return (dh, None, None, None, None, None, *dws, *dbs)
 
 

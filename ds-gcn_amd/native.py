@@ -42,7 +42,7 @@ SIGNATURES = {
     'dsgcn_colsum': [c_f, c_int, c_int, c_f, c_st],
     'dsgcn_pwconv_dgrad': [c_f] * 6 + [c_int] + [c_f] * 10 + [c_int] * 7 + [c_st],
     'dsgcn_pwconv_wgrad_splits': [c_int] * 6,
-    'dsgcn_pwconv_wgrad': [c_f] * 6 + [c_int] + [c_f] * 8 + [c_int] * 7 + [c_st],
+    'dsgcn_pwconv_wgrad': [c_f] * 6 + [c_int] + [c_f] * 8 + [c_int] * 8 + [c_st],
     'dsgcn_bn_bwd_coef': [c_f] * 5 + [ctypes.c_float, ctypes.c_double, c_int, c_int] + [c_f] * 4 + [c_st],
     'dsgcn_branch_act_fwd': [c_f] * 4 + [c_int] + [c_f] + [c_int] * 4 + [c_st],
     'dsgcn_branch_act_bwd': [c_f] * 4 + [c_int] + [c_f] * 4 + [c_int] * 4 + [c_st],
@@ -50,11 +50,11 @@ SIGNATURES = {
     'dsgcn_tms_combine_bwd': [c_f] * 7 + [c_int] * 4 + [c_st],
     'dsgcn_tapconv_fwd': [c_f, c_f] + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_st],
     'dsgcn_tapconv_dgrad': [c_f, c_f, c_f] + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, c_st],
-    'dsgcn_tapconv_wgrad': [c_f, c_f] + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_st],
+    'dsgcn_tapconv_wgrad': [c_f, c_f] + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_st],
     'dsgcn_fuse_out_fwd': [c_f] * 6 + [c_int] + [c_f] * 2 + [c_int] * 4 + [c_st],
     'dsgcn_fuse_out_bwd': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 4 + [c_st],
     'dsgcn_dynadj_fwd': [c_f] * 6 + [c_i, c_i, c_f] + [c_int] * 5 + [c_st],
-    'dsgcn_dynadj_bwd': [c_f] * 5 + [c_i] * 4 + [c_f] * 7 + [c_int] * 5 + [c_st],
+    'dsgcn_dynadj_bwd': [c_f] * 5 + [c_i] * 4 + [c_f] * 6 + [c_int] + [c_f] * 2 + [c_int] * 5 + [c_st],
 }
 
 

@@ -63,12 +63,13 @@ int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, cons
                      int P, int E, void* stream);
 
 /* Backward of K-B.  pair_order (V*V) = joint pairs sorted by edge class, class_start (E+1) = offsets.
- * dd_ws: workspace (n,3*mid,V,V).  Outputs: dproj (n,9*mid,V); pA (n,3,V,V) (sum over n = dA); pab (n,6)
+ * dd_ws: workspace (n,3*mid,V,V); ddelta_ws: workspace (n,mid,V,V).  Outputs: dproj (n,9*mid,V); pA (n,3,V,V)
+ * (sum over n = dA; sample s at pA + s*pstride); pab (n,6) (at pab + s*pstride)
  * (sum over n = [dalpha|dbeta]); dwe (E*mid,mid), dbe (E*mid): ACCUMULATED with float atomics — caller zeroes. */
 int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
                      const int* node_type, const int* edge_type, const int* pair_order, const int* class_start,
-                     const float* dahat, float* dd_ws, float* dproj, float* pA, float* pab, float* dwe, float* dbe,
-                     int n, int mid, int V, int P, int E, void* stream);
+                     const float* dahat, float* dd_ws, float* ddelta_ws, float* dproj, float* pA, float* pab,
+                     int pstride, float* dwe, float* dbe, int n, int mid, int V, int P, int E, void* stream);
 
 /* Block output (materialise once): out = relu?(x1*s1+h1 (+ x2*s2+h2 | + x2)), xbar = mean_t out (optional).
  * Replaces BN + residual add + ReLU of dgstgcn.py:63-65 / tcn.py:427 and x.mean(-2) of gcn.py:2246. */
@@ -82,7 +83,7 @@ int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const 
  * branch_act: h (n,C,T,V+1) = act_c(z*scale+shift) with the global-joint column zaug appended (ReLU for c < n_act).
  * tapconv   : the branches between — type 0 dilated (3,1) conv (weights (bc,bc,3,1), bias (bc)), 1 = (3,1) max-pool,
  *             2 = strided copy — each writing its channel window [c0,c0+bc) of o (n,C,T',V+1); branch tables are
- *             host arrays of length nbr <= 8.  wgrad writes K-split partials dwp[i] (splits, bc*bc*3), dbp[i] (splits, bc).
+ *             host arrays of length nbr <= 8.  wgrad writes K-split partials at dwp[i]/dbp[i] + split*pstride.
  * combine   : f = o[..,:V] + o[..,V]*coeff, per-plane sum / sum of squares of f (n*C, 2). */
 int dsgcn_branch_act_fwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
                          float* h, int n, int C, int T, int V, void* stream);
@@ -97,7 +98,7 @@ int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int C
                         void* stream);
 int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int C, int T, int V1, int stride, int KT, int nbr,
                         const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp,
-                        float* const* dbp, int splits, void* stream);
+                        float* const* dbp, int splits, int pstride, void* stream);
 int dsgcn_tms_combine_fwd(const float* o, const float* coeff, float* f, float* partial, int n, int C, int T, int V,
                           void* stream);
 int dsgcn_tms_combine_bwd(const float* o, const float* coeff, const float* gf, const float* A0, const float* B0,
@@ -136,12 +137,13 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
                        const float* h2, int relu, const float* w, const float* z, const float* zaug,
                        const float* gz, const float* gzaug, const float* A0, const float* B0, float* dx1, float* dx2,
                        float* ipart, int n, int Ci, int Co, int T, int V, int stride, int aug, void* stream);
-/* Weight gradient: dwp (splits,Co,Ci), dbp (splits,Co) partials; splits from dsgcn_pwconv_wgrad_splits. */
+/* Weight gradient: k-split partials, split s at dwp + s*pstride (Co*Ci floats) and dbp + s*pstride (Co floats);
+ * splits from dsgcn_pwconv_wgrad_splits. */
 int dsgcn_pwconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int stride);
 int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, const float* z, const float* zaug, const float* gz,
-                       const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int n, int Ci,
-                       int Co, int T, int V, int stride, int aug, void* stream);
+                       const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int pstride, int n,
+                       int Ci, int Co, int T, int V, int stride, int aug, void* stream);
 
 #ifdef __cplusplus
 }
