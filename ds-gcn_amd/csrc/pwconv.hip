@@ -506,32 +506,62 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
   }
 }
 
-// zaug[n,c,t] = mean_v z[n,c,t,:] plus per-block partial sums of zaug / zaug^2 (the global-joint column's share of the
-// batch statistics).  One thread per (n,c,t) row group; partial rows appended after the conv's own partial rows.
-__global__ __launch_bounds__(256) void k_rowmean_stats(const float* __restrict__ z, float* __restrict__ zaug,
-                                                       float* __restrict__ partial, int n, int C, int T, int V,
-                                                       int tslices) {
-  // grid = (tslices, n); block covers all C channels (thread = channel, loops if C > 256) for T/tslices frames
-  const int nn = blockIdx.y, sl = blockIdx.x;
-  const int t0 = sl * ((T + tslices - 1) / tslices);
-  const int t1 = min(T, t0 + (T + tslices - 1) / tslices);
+// zaug[n,c,t] = mean_v z[n,c,t,:] plus the global-joint column's share of the batch statistics.
+// One wave per (n,c) plane: coalesced plane read into LDS, lanes = frames for the row means; partial row `n` of the
+// extra block holds per-channel sum / sum of squares of zaug.
+__global__ __launch_bounds__(64) void k_rowmean_stats(const float* __restrict__ z, float* __restrict__ zaug,
+                                                      float* __restrict__ partial, int C, int T, int V) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int L = T * V;
+  const float* __restrict__ pz = z + (size_t)plane * L;
+#pragma unroll 4
+  for (int i = lane; i < L; i += 64) lds[i] = pz[i];
+  wave_lds_sync();
   const float invV = 1.f / (float)V;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float sv = 0.f, qv = 0.f;
-    for (int t = t0; t < t1; ++t) {
-      const float* row = z + ((size_t)(nn * C + c) * T + t) * V;
-      float m = 0.f;
-      for (int v = 0; v < V; ++v) m += row[v];
-      m *= invV;
-      zaug[(size_t)(nn * C + c) * T + t] = m;
-      sv += m;
-      qv = fmaf(m, m, qv);
+  float sv = 0.f, qv = 0.f;
+  for (int t = lane; t < T; t += 64) {
+    float m = 0.f;
+    for (int v = 0; v < V; ++v) m += lds[t * V + v];
+    m *= invV;
+    zaug[(size_t)plane * T + t] = m;
+    sv += m;
+    qv = fmaf(m, m, qv);
+  }
+  if (partial) {
+    sv = wave_sum(sv);
+    qv = wave_sum(qv);
+    if (lane == 0) {
+      partial[(size_t)plane * 2 + 0] = sv;       // rows [n][C][2]
+      partial[(size_t)plane * 2 + 1] = qv;
     }
-    if (partial) {
-      const size_t blk = (size_t)nn * tslices + sl;
-      partial[(blk * C + c) * 2 + 0] = sv;
-      partial[(blk * C + c) * 2 + 1] = qv;
-    }
+  }
+}
+
+// dz_eff (n,Co,T,V) materialised for convs with the global-joint column (the dgmstcn branch conv): folds the BN
+// statistics terms and the zaug gradient once so that dgrad / wgrad run in their plain (single-stream) mode.
+//   dz_eff = gz + A0 + B0*z + (gzaug + A0 + B0*zaug)/V
+__global__ __launch_bounds__(64) void k_dz_eff_aug(const float* __restrict__ gz, const float* __restrict__ z,
+                                                   const float* __restrict__ gzaug, const float* __restrict__ zaug,
+                                                   const float* __restrict__ A0, const float* __restrict__ B0,
+                                                   float* __restrict__ out, int C, int T, int V) {
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const int L = T * V;
+  const float a0 = A0 ? A0[c] : 0.f, b0 = A0 ? B0[c] : 0.f;
+  const float invV = 1.f / (float)V;
+  const float* __restrict__ pg = gz ? gz + (size_t)plane * L : nullptr;
+  const float* __restrict__ pz = z + (size_t)plane * L;
+  const float* __restrict__ pga = gzaug ? gzaug + (size_t)plane * T : nullptr;
+  const float* __restrict__ pza = zaug + (size_t)plane * T;
+  float* __restrict__ po = out + (size_t)plane * L;
+#pragma unroll 4
+  for (int i = lane; i < L; i += 64) {
+    const int t = i / V;
+    const float e = (pga ? pga[t] : 0.f) + fmaf(b0, pza[t], a0);
+    po[i] = (pg ? pg[i] : 0.f) + fmaf(b0, pz[i], a0) + e * invV;
   }
 }
 
@@ -1298,7 +1328,7 @@ int dsgcn_pwconv_partial_rows(int n, int Co, int T, int V, int stride, int aug) 
   const int NW = MT <= 2 ? 2 : 1;
   const int nbx = (L + 4 * NW * 32 - 1) / (4 * NW * 32);
   int rows = n * nbx;
-  if (aug) rows += n * (Tout >= 8 ? 8 : 1);
+  if (aug) rows += n;
   return rows;
 }
 
@@ -1334,9 +1364,10 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
   }
   DSGCN_LAUNCH_CHECK();
   if (aug) {
-    const int tsl = Tout >= 8 ? 8 : 1;
-    hipLaunchKernelGGL(k_rowmean_stats, dim3((unsigned)tsl, (unsigned)n), dim3(256), 0, st, z, zaug,
-                       stats ? partial + (size_t)n * nbx * Co * 2 : (float*)nullptr, n, Co, Tout, V, tsl);
+    const size_t l2 = (size_t)Tout * V * sizeof(float);
+    if (l2 > 64 * 1024) return DSGCN_EUNSUPPORTED;
+    hipLaunchKernelGGL(k_rowmean_stats, dim3((unsigned)((long)n * Co)), dim3(64), l2, st, z, zaug,
+                       stats ? partial + (size_t)n * nbx * Co * 2 : (float*)nullptr, Co, Tout, V);
     DSGCN_LAUNCH_CHECK();
   }
   return 0;
@@ -1462,6 +1493,16 @@ int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const 
   else if (a.vec) hipLaunchKernelGGL((k_pwconv_wgrad<true, false>), grid, dim3(PW_NT), lds, st, a);
   else if (x2) hipLaunchKernelGGL((k_pwconv_wgrad<false, true>), grid, dim3(PW_NT), lds, st, a);
   else hipLaunchKernelGGL((k_pwconv_wgrad<false, false>), grid, dim3(PW_NT), lds, st, a);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// out (n,Co,T,V) = gz + A0 + B0*z + (gzaug + A0 + B0*zaug)/V   (gz, gzaug, A0/B0 may be NULL = zero)
+int dsgcn_dz_eff_aug(const float* gz, const float* z, const float* gzaug, const float* zaug, const float* A0,
+                     const float* B0, float* out, int n, int C, int T, int V, void* stream) {
+  if (!z || !zaug || !out || n <= 0 || C <= 0 || T <= 0 || V <= 0) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_dz_eff_aug, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, gz, z, gzaug, zaug,
+                     A0, B0, out, C, T, V);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

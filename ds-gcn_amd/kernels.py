@@ -260,6 +260,13 @@ class _PwConv(torch.autograd.Function):
                                        n_affine, _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), st)
             native.check(rc, 'dsgcn_bn_bwd_coef')
         Tout = z.shape[2]
+        if aug:
+            # fold the statistics terms and the global-joint gradient once; dgrad / wgrad then run in plain mode
+            dzeff = torch.empty_like(z)
+            rc = lib.dsgcn_dz_eff_aug(_ptr(gz), _ptr(z), _ptr(gzaug), _ptr(zaug), _ptr(A0), _ptr(B0), _ptr(dzeff), n,
+                                      Co, Tout, V, st)
+            native.check(rc, 'dsgcn_dz_eff_aug')
+            gz, gzaug, A0, B0, aug = dzeff, None, None, None, 0
         dx1 = torch.empty_like(x1)
         dx2 = torch.empty_like(x2) if x2 is not None else None
         ipart = None

@@ -39,6 +39,7 @@ SIGNATURES = {
     'dsgcn_pwconv_ipart_rows': [c_int] * 5,
     'dsgcn_pwconv_tuning': [c_int, c_int],
     'dsgcn_diag_mfma_probe': [c_f, c_int, c_int, c_int, c_st],
+    'dsgcn_dz_eff_aug': [c_f] * 7 + [c_int] * 4 + [c_st],
     'dsgcn_colsum': [c_f, c_int, c_int, c_f, c_st],
     'dsgcn_pwconv_dgrad': [c_f] * 6 + [c_int] + [c_f] * 10 + [c_int] * 7 + [c_st],
     'dsgcn_pwconv_wgrad_splits': [c_int] * 6,

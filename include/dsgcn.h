@@ -132,6 +132,9 @@ int dsgcn_colsum(const float* src, int R, int C, float* out, void* stream);
 int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* mean, const float* var,
                       const float* gamma, float eps, double count, int C, int c_affine, float* dgamma, float* dbeta,
                       float* A0, float* B0, void* stream);
+/* dz_eff of a conv with the global-joint column, materialised once: gz + A0 + B0*z + (gzaug + A0 + B0*zaug)/V. */
+int dsgcn_dz_eff_aug(const float* gz, const float* z, const float* gzaug, const float* zaug, const float* A0,
+                     const float* B0, float* out, int n, int C, int T, int V, void* stream);
 /* Data gradient: dx1 (, dx2) fully written; ipart (n*nblk, Ci, 3) = [sum dv*x1, sum dv, sum dv*x2] partials. */
 int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, const float* w, const float* z, const float* zaug,
