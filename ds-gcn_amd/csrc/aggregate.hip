@@ -188,18 +188,18 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd(const float* __restrict__ 
 // Persistent form of k_aggregate_fwd: each wave walks work items (unit, 64-frame chunk) with a grid
 // stride and keeps the NEXT item's P plane and adjacency in flight (global -> VGPR) while the matrix core
 // works on the current one, so HBM requests, MFMA and stores of neighbouring items overlap inside one wave.
-template <int V>
+template <int V, int CH>
 __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restrict__ zp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
                                                            const float* __restrict__ ahat, float* __restrict__ y,
                                                            int KC, int T, int chunks, long items, int direct) {
   constexpr int KS = (V + 1) / 2;
-  constexpr int NP4 = (64 * V / 4 + 63) / 64;     // float4 loads per lane for a full 64-frame plane
+  constexpr int NP4 = (CH * V / 4 + 63) / 64;     // float4 loads per lane for a full CH-frame chunk
   constexpr int NA = (V * V + 63) / 64;           // dword loads per lane for the adjacency
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldsP = lds;
-  float* ldsA = lds + 64 * V;
+  float* ldsA = lds + CH * V;
   const int lane = threadIdx.x;
   const int mi = lane & 31, mk = lane >> 5;
   const int mic = mi < V ? mi : V - 1;
@@ -208,8 +208,8 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
 
   auto issue = [&](long item) {
     const long unit = item / chunks;
-    const int t0 = (int)(item - unit * chunks) * 64;
-    const int rows = min(64, T - t0);
+    const int t0 = (int)(item - unit * chunks) * CH;
+    const int rows = min(CH, T - t0);
     const int c4 = (rows * V) >> 2;
     const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(zp + ((size_t)unit * T + t0) * V);
     const float* __restrict__ A = ahat + (size_t)unit * V * V;
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
   if (item < items) issue(item);
   while (item < items) {
     const long unit = item / chunks;
-    const int t0 = (int)(item - unit * chunks) * 64;
-    const int rows = min(64, T - t0);
+    const int t0 = (int)(item - unit * chunks) * CH;
+    const int rows = min(CH, T - t0);
     const int c4 = (rows * V) >> 2;
     const int c = (int)(unit % KC);
     const float s = scale ? scale[c] : 1.f;
@@ -266,9 +266,10 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
       const float v = ldsA[(u < V ? u : V - 1) * V + mic];
       b[q] = (u < V && mi < V) ? v : 0.f;
     }
-    f32x16 acc[2];
+    constexpr int NTILE = CH / 32;
+    f32x16 acc[NTILE];
 #pragma unroll
-    for (int tile = 0; tile < 2; ++tile) {
+    for (int tile = 0; tile < NTILE; ++tile) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[tile][i] = 0.f;
       if (tile * 32 < rows) {
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
       float* __restrict__ yo = y + ((size_t)unit * T + t0) * V;
       if (mi < V) {
 #pragma unroll
-        for (int tile = 0; tile < 2; ++tile) {
+        for (int tile = 0; tile < NTILE; ++tile) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int t = tile * 32 + mfma_row(r, mk);
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
       wave_lds_sync();
       if (mi < V) {
 #pragma unroll
-        for (int tile = 0; tile < 2; ++tile) {
+        for (int tile = 0; tile < NTILE; ++tile) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int t = tile * 32 + mfma_row(r, mk);
@@ -601,6 +602,7 @@ int g_pipe_waves = 0;       // tuning knobs (dsgcn_set_tuning)
 int g_pipe_waves_bwd = 0;
 int g_ablate = 0;
 int g_fwd_direct = 1;
+int g_fwd_chunk = 32;
 int g_bwd_variant = 0;      // 1 = one-shot kernel (A/B)
 
 template <int V>
@@ -616,15 +618,23 @@ int launch_fwd(const float* zp, const float* scale, const float* shift, int relu
     const size_t lds = (size_t)(64 * V + V * V) * sizeof(float);
     hipLaunchKernelGGL((k_aggregate_fwd<V>), grid, dim3(64), lds, st, zp, scale, shift, relu, ahat, y, KC, T, vec);
   } else {
-    const size_t lds = (size_t)(64 * V + V * V) * sizeof(float);
-    const int chunks = (T + 63) / 64;
+    // 32-frame work items when a unit has more than 32 frames (two items per wave keep the prefetch pipeline busy on
+    // the small early layers); (32*V) % 4 == 0 keeps every chunk 16-B aligned
+    const bool half = (T > 32) && ((32 * V) % 4 == 0) && g_fwd_chunk != 64;
+    const int CHv = half ? 32 : 64;
+    const size_t lds = (size_t)(CHv * V + V * V) * sizeof(float);
+    const int chunks = (T + CHv - 1) / CHv;
     const long items = units * chunks;
-    int waves = g_pipe_waves > 0 ? g_pipe_waves : 3072;
+    int waves = g_pipe_waves > 0 ? g_pipe_waves : (T > 32 ? 3072 : 2048);   // measured: tools/ka_variants.py
     // equal items per wave where possible
     const long per = (items + waves - 1) / waves;
     const long g = (items + per - 1) / per;
-    hipLaunchKernelGGL((k_aggregate_fwd_pipe<V>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu, ahat,
-                       y, KC, T, chunks, items, g_fwd_direct);
+    if (half)
+      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 32>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+                         ahat, y, KC, T, chunks, items, g_fwd_direct);
+    else
+      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 64>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+                         ahat, y, KC, T, chunks, items, g_fwd_direct);
   }
   DSGCN_LAUNCH_CHECK();
   return 0;
@@ -684,6 +694,7 @@ int dsgcn_set_tuning(int key, int value) {
   if (key == 2) { g_bwd_variant = value; return 0; }
   if (key == 3) { g_ablate = value; return 0; }
   if (key == 4) { g_fwd_direct = value; return 0; }
+  if (key == 5) { g_fwd_chunk = value; return 0; }
   return DSGCN_EINVAL;
 }
 

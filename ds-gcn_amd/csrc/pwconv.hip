@@ -302,13 +302,14 @@ constexpr int OOB_OFF = 0x7ffffff0;
 // g+1 are issued before the MFMAs of group g.  No per-step branches (they made hipcc sink every load next to its
 // use: one full HBM round trip per k-step): the chunk is padded to a multiple of 4*UNR channels — padded channels
 // have zero weights in Ws and read either valid memory or past the buffer (raw-buffer OOB -> 0).
-constexpr int F2_UNR = 4;
+constexpr int F2_UNR = 4;          // k-steps per register set for narrow inputs (Ci < 48)
+constexpr int F2_UNRW = 4;         // ... for wide inputs: 16 k-steps x MFMAs ~ 4096 cycles of cover per set
 
-template <int NW, int MODE>
-__device__ __forceinline__ void f2_load(float (&xb)[F2_UNR][NW], float (&yb)[F2_UNR][NW], __amdgpu_buffer_rsrc_t r1,
+template <int NW, int MODE, int UNR>
+__device__ __forceinline__ void f2_load(float (&xb)[UNR][NW], float (&yb)[UNR][NW], __amdgpu_buffer_rsrc_t r1,
                                         __amdgpu_buffer_rsrc_t r2, const int (&voff)[NW], int cbase, int cstride4) {
 #pragma unroll
-  for (int u = 0; u < F2_UNR; ++u) {
+  for (int u = 0; u < UNR; ++u) {
     const int soff = (cbase + 2 * u) * cstride4;              // wave-uniform: SGPR operand of the buffer load
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
@@ -318,12 +319,12 @@ __device__ __forceinline__ void f2_load(float (&xb)[F2_UNR][NW], float (&yb)[F2_
   }
 }
 
-template <int MT, int NW, int MODE>
+template <int MT, int NW, int MODE, int UNR>
 __device__ __forceinline__ void f2_compute(const PwArgs& a, f32x16 (&acc)[MT][NW], const float* Ws, const f32x4* Ps4,
-                                           const float (&xb)[F2_UNR][NW], const float (&yb)[F2_UNR][NW], int c0,
+                                           const float (&xb)[UNR][NW], const float (&yb)[UNR][NW], int c0,
                                            int kbase, int kc, int half, int l31) {
 #pragma unroll
-  for (int u = 0; u < F2_UNR; ++u) {
+  for (int u = 0; u < UNR; ++u) {
     const int kl = kbase + 2 * u + half;
     const bool cok = kl < kc;
     float av[MT], bv[NW];
@@ -349,19 +350,18 @@ __device__ __forceinline__ void f2_compute(const PwArgs& a, f32x16 (&acc)[MT][NW
   }
 }
 
-template <int MT, int NW, int MODE>
+template <int MT, int NW, int MODE, int UNR>
 __device__ __forceinline__ void fwd2_chunk(const PwArgs& a, f32x16 (&acc)[MT][NW], const float* Ws, const f32x4* Ps4,
                                            __amdgpu_buffer_rsrc_t r1, __amdgpu_buffer_rsrc_t r2, const int (&voff)[NW],
                                            int c0, int kc, int cstride4, int half, int l31) {
-  constexpr int G = 2 * F2_UNR;                               // channels per group
-  const int kpad = (kc + 2 * G - 1) / (2 * G) * (2 * G);     // multiple of two groups, <= KW
-  float xa[F2_UNR][NW], ya[F2_UNR][NW], xb[F2_UNR][NW], yb[F2_UNR][NW];
-  f2_load<NW, MODE>(xa, ya, r1, r2, voff, c0, cstride4);
-  for (int k0 = 0; k0 < kpad; k0 += 2 * G) {
-    f2_load<NW, MODE>(xb, yb, r1, r2, voff, c0 + k0 + G, cstride4);
-    f2_compute<MT, NW, MODE>(a, acc, Ws, Ps4, xa, ya, c0, k0, kc, half, l31);
-    f2_load<NW, MODE>(xa, ya, r1, r2, voff, c0 + k0 + 2 * G, cstride4);
-    f2_compute<MT, NW, MODE>(a, acc, Ws, Ps4, xb, yb, c0, k0 + G, kc, half, l31);
+  constexpr int G = 2 * UNR;                                  // channels per register set
+  float xa[UNR][NW], ya[UNR][NW], xb[UNR][NW], yb[UNR][NW];
+  f2_load<NW, MODE, UNR>(xa, ya, r1, r2, voff, c0, cstride4);
+  for (int k0 = 0; k0 < kc; k0 += 2 * G) {
+    f2_load<NW, MODE, UNR>(xb, yb, r1, r2, voff, c0 + k0 + G, cstride4);
+    f2_compute<MT, NW, MODE, UNR>(a, acc, Ws, Ps4, xa, ya, c0, k0, kc, half, l31);
+    f2_load<NW, MODE, UNR>(xa, ya, r1, r2, voff, c0 + k0 + 2 * G, cstride4);
+    if (k0 + G < kc) f2_compute<MT, NW, MODE, UNR>(a, acc, Ws, Ps4, xb, yb, c0, k0 + G, kc, half, l31);
   }
 }
 
@@ -444,9 +444,15 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
       }
     }
     __syncthreads();
-    if (mode == 0) fwd2_chunk<MT, NW, 0>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
-    else if (mode == 1) fwd2_chunk<MT, NW, 1>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
-    else fwd2_chunk<MT, NW, 2>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
+    if (Ci >= 48) {
+      if (mode == 0) fwd2_chunk<MT, NW, 0, F2_UNRW>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
+      else if (mode == 1) fwd2_chunk<MT, NW, 1, F2_UNRW>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
+      else fwd2_chunk<MT, NW, 2, F2_UNRW>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
+    } else {
+      if (mode == 0) fwd2_chunk<MT, NW, 0, F2_UNR>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
+      else if (mode == 1) fwd2_chunk<MT, NW, 1, F2_UNR>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
+      else fwd2_chunk<MT, NW, 2, F2_UNR>(a, acc, Ws, Ps4, r1, r2, voff, c0, kc, cstride * 4, half, l31);
+    }
   }
   __syncthreads();
   // ---- epilogue: bias, coalesced stores; per-channel sum / sum of squares via an LDS transpose of each tile

@@ -60,10 +60,10 @@ for KC, T in shapes:
     for v, nm in ():
         t = timeit(mk(v)); line += f'| {nm} {t:6.1f}us {fb/t/1e3:6.0f}GB/s '
     for w in (2048, 3072, 4096):
-        for direct in (0, 1):
-            lib.dsgcn_set_tuning(0, w); lib.dsgcn_set_tuning(4, direct)
-            t = timeit(mk(0)); line += f'| p{w}d{direct} {t:5.1f}us {fb/t/1e3:5.0f} '
-    lib.dsgcn_set_tuning(4, 0)
+        for ch in (64, 32):
+            lib.dsgcn_set_tuning(0, w); lib.dsgcn_set_tuning(5, ch)
+            t = timeit(mk(0)); line += f'| p{w}c{ch} {t:5.1f}us {fb/t/1e3:5.0f} '
+    lib.dsgcn_set_tuning(5, 32)
     lib.dsgcn_set_tuning(0, 0)
     for w in (2048,):
         lib.dsgcn_set_tuning(1, w)
