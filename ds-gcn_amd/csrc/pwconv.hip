@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(64) void k_bn_bwd_coef(const float* __restrict__ g_
 }  // namespace
 
 int g_pw_ablate = 0;
-int g_pw_maxmt = 4;
+int g_pw_maxmt = 2;      // measured (tools/pw_ablate.py): small per-wave tiles + more resident waves win
 
 extern "C" {
 
@@ -1331,7 +1331,7 @@ int dsgcn_pwconv_partial_rows(int n, int Co, int T, int V, int stride, int aug) 
   const int L = Tout * V;
   const int mtiles = (Co + 31) / 32;
   const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
-  const int NW = MT <= 2 ? 2 : 1;
+  const int NW = 1;
   const int nbx = (L + 4 * NW * 32 - 1) / (4 * NW * 32);
   int rows = n * nbx;
   if (aug) rows += n;
@@ -1356,15 +1356,15 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
   const int L = Tout * V;
   const int mtiles = (Co + 31) / 32;
   const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
-  const int NW = MT <= 2 ? 2 : 1;
+  const int NW = 1;
   const int nbx = (L + 4 * NW * 32 - 1) / (4 * NW * 32);
   dim3 grid((unsigned)nbx, (unsigned)n, (unsigned)((mtiles + MT - 1) / MT));
   size_t ldsf = (size_t)32 * MT * KWS + 4 + (size_t)4 * Ci;
   if (ldsf < (size_t)4 * 32 * 36 + 256) ldsf = (size_t)4 * 32 * 36 + 256;
   const size_t lds = ldsf * sizeof(float);
   switch (MT) {
-    case 1: hipLaunchKernelGGL((k_pwconv_fwd2<1, 2>), grid, dim3(PW_NT), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((k_pwconv_fwd2<2, 2>), grid, dim3(PW_NT), lds, st, a); break;
+    case 1: hipLaunchKernelGGL((k_pwconv_fwd2<1, 1>), grid, dim3(PW_NT), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((k_pwconv_fwd2<2, 1>), grid, dim3(PW_NT), lds, st, a); break;
     case 3: hipLaunchKernelGGL((k_pwconv_fwd2<3, 1>), grid, dim3(PW_NT), lds, st, a); break;
     default: hipLaunchKernelGGL((k_pwconv_fwd2<4, 1>), grid, dim3(PW_NT), lds, st, a); break;
   }
@@ -1404,7 +1404,7 @@ int dsgcn_pwconv_ipart_rows(int n, int Ci, int T, int V, int stride) {
   const int L = Tout * V;
   const int mtiles = (Ci + 31) / 32;
   const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
-  const int NW = MT <= 2 ? 2 : 1;
+  const int NW = 1;
   return n * ((L + 4 * NW * 32 - 1) / (4 * NW * 32));
 }
 
@@ -1432,7 +1432,7 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
   const int L = Tout * V;
   const int mtiles = (Ci + 31) / 32;
   const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
-  const int NW = MT <= 2 ? 2 : 1;
+  const int NW = 1;
   const int nbx = (L + 4 * NW * 32 - 1) / (4 * NW * 32);
   dim3 grid((unsigned)nbx, (unsigned)n, (unsigned)((mtiles + MT - 1) / MT));
   size_t ldsf = (size_t)KW * (32 * MT + 1) + 4 + (size_t)2 * Co;
@@ -1444,8 +1444,8 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
     else hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, false>), grid, dim3(PW_NT), lds, st, a);      \
   } while (0)
   switch (MT) {
-    case 1: DSGCN_DGRAD(1, 2); break;
-    case 2: DSGCN_DGRAD(2, 2); break;
+    case 1: DSGCN_DGRAD(1, 1); break;
+    case 2: DSGCN_DGRAD(2, 1); break;
     case 3: DSGCN_DGRAD(3, 1); break;
     default: DSGCN_DGRAD(4, 1); break;
   }

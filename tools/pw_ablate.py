@@ -22,7 +22,7 @@ for (Ci, Co, T, res) in [(64, 64, 64, 0), (64, 64, 64, 1), (128, 128, 32, 0), (2
         rc = lib.dsgcn_pwconv_fwd(x1.data_ptr(), s1.data_ptr(), h1.data_ptr(), x2.data_ptr() if res else None, None, None, 1,
                                   w.data_ptr(), b.data_ptr(), z.data_ptr(), None, part.data_ptr(), n, Ci, Co, T, V, 1, 0, 1, st)
         assert rc == 0
-    for mt in (4, 2):
+    for mt in (2, 1):
         lib.dsgcn_pwconv_tuning(1, mt)
         line = f'Ci={Ci} Co={Co} T={T} res={res} maxMT={mt}: '
         for ab, nm in ((0, 'full'), (4, '-store'), (8, '-stats'), (12, '-store-stats')):
@@ -30,4 +30,4 @@ for (Ci, Co, T, res) in [(64, 64, 64, 0), (64, 64, 64, 1), (128, 128, 32, 0), (2
             line += f'{nm} {timeit(f):6.1f} | '
         lib.dsgcn_pwconv_tuning(0, 0)
         print(line, flush=True)
-    lib.dsgcn_pwconv_tuning(1, 4)
+    lib.dsgcn_pwconv_tuning(1, 2)
