@@ -1460,7 +1460,7 @@ int dsgcn_pwconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int stride) {
   const int TR = Tout >= WG_TR ? WG_TR : Tout;
   const int chunks = n * ((Tout + TR - 1) / TR);
   const int tiles = ((Co + 63) / 64) * ((Ci + 63) / 64);
-  int splits = 1024 / tiles;
+  int splits = 512 / tiles;
   if (splits < 1) splits = 1;
   if (splits > chunks) splits = chunks;
   const int per = (chunks + splits - 1) / splits;

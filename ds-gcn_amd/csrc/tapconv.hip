@@ -277,9 +277,9 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
   float dbacc = 0.f;
   const int row = tid >> 2, quarter = tid & 3;    // staging: 4 threads per channel row
   constexpr int NPT = 14;                         // positions per thread: 4*14 = 56 >= KP for V1 <= 26
-  for (int ch = ch0; ch < ch1; ++ch) {
+  float dv[NPT], xv[KT][NPT];
+  auto issue = [&](int ch) {                      // all global loads of a chunk, issued before the previous chunk's MFMAs
     const int n = ch / nb, r0 = (ch - n * nb) * TRW;
-    float dv[NPT], xv[KT][NPT];
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
       const int p = quarter + 4 * j;
@@ -293,6 +293,9 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
         xv[k][j] = (live && t >= 0 && t < a.T) ? a.h[((size_t)(n * a.C + br.c0 + row) * a.T + t) * V1 + col] : 0.f;
       }
     }
+  };
+  if (ch0 < ch1) issue(ch0);
+  for (int ch = ch0; ch < ch1; ++ch) {
     __syncthreads();
     float dsum = 0.f;
 #pragma unroll
@@ -309,6 +312,7 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
     dsum += __shfl_xor(dsum, 2, 64);
     dbacc += dsum;
     __syncthreads();
+    if (ch + 1 < ch1) issue(ch + 1);
     for (int kk = 0; kk < KP; kk += 2) {
       const float av = Ds[(32 * mt + l31) * LS + kk + half];
 #pragma unroll
