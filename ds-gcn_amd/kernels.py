@@ -469,13 +469,15 @@ class _TapBranches(torch.autograd.Function):
                                      _int_array(c0s), _int_array(bcs), _int_array(dils), _ptr_array(ws), _stream())
         native.check(rc, 'dsgcn_tapconv_dgrad')
         Tout = go.shape[2]
-        splits = max(1, min(256, n * ((Tout + 1) // 2)))
         offs, off = [], 0
         for t, bc in zip(types, bcs):
             offs.append(off)
             if t == 0:
                 off += bc * bc * 3 + bc
         pstride = max(off, 1)
+        # k-splits: enough blocks to fill the chip, but keep the partial buffer (splits x pstride floats) around 8 MB
+        splits = max(16, min(256, (1 << 21) // pstride))
+        splits = max(1, min(splits, n * ((Tout + 1) // 2)))
         part = torch.empty((splits, pstride), device=h.device, dtype=torch.float32)
         base = part.data_ptr()
         dwp = (_ct.c_void_p * nbr)(*[base + 4 * o if t == 0 else None for t, o in zip(types, offs)])
