@@ -1,7 +1,7 @@
 """dsgcn_amd — MI355X-native DS-GCN hot path behind the PYSKL registry/config API.
 
 Drop-in names (reference: pyskl/models/builder.py, pyskl/models/gcns/*, recognizers/*, heads/*,
-losses/*): ``build_model``, ``RecognizerGCN``, ``DGSTGCN``, ``STGCN``, ``GCNHead``,
+losses/*): ``build_model``, ``RecognizerGCN``, ``DGSTGCN``, ``STGCN``, ``CTRGCN``, ``GCNHead``,
 ``CrossEntropyLoss``, ``Graph``, ``Config``.
 """
 from .registry import Registry, build_from_cfg
@@ -12,9 +12,9 @@ from .builder import (MODELS, BACKBONES, HEADS, LOSSES, NECKS, RECOGNIZERS, buil
 from .evaluation import top_k_accuracy, mean_class_accuracy, confusion_matrix
 from .losses import CrossEntropyLoss
 from .heads import GCNHead, SimpleHead
-from .gcn_units import dgphgcn1, unit_gcn, Deferred
-from .tcn_units import dgmstcn, unit_tcn
-from .backbones import DGSTGCN, STGCN, DGBlock, STGCNBlock
+from .gcn_units import dgphgcn1, unit_gcn, unit_ctrgcn, CTRGC, Deferred
+from .tcn_units import dgmstcn, unit_tcn, MSTCN
+from .backbones import DGSTGCN, STGCN, CTRGCN, DGBlock, STGCNBlock, CTRGCNBlock
 from .recognizers import RecognizerGCN, BaseRecognizer
 from . import kernels
 from .data_parallel import FlatParams, FlatDataParallel, shard_batch

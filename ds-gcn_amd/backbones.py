@@ -14,9 +14,9 @@ import torch.nn as nn
 
 from . import kernels
 from .builder import BACKBONES
-from .gcn_units import dgphgcn1, unit_gcn, flush_running_stats
+from .gcn_units import dgphgcn1, unit_ctrgcn, unit_gcn, flush_running_stats
 from .graph import Graph
-from .tcn_units import dgmstcn, unit_tcn
+from .tcn_units import MSTCN, dgmstcn, unit_tcn
 
 EPS = 1e-4
 
@@ -62,7 +62,9 @@ class _FusedBlock(nn.Module):
         elif self.residual_kind == 'conv':
             r = self.residual.forward_deferred(x)
             x2, a2 = r.x1, r.a1
-        return kernels.ops().fuse_out(t.x1, t.a1, x2, a2, True, want_xbar)
+        assert t.x2 is None
+        # t.relu: the temporal unit ends in its own ReLU (CTR-GCN's MSTCN) -> ReLU on the first term, then add + ReLU
+        return kernels.ops().fuse_out(t.x1, t.a1, x2, a2, 3 if t.relu else 1, want_xbar)
 
     def forward(self, x, A=None):
         return self.forward_fused(x)[0]
@@ -114,6 +116,35 @@ class STGCNBlock(_FusedBlock):
 
     def _gcn_deferred(self, x, xbar):
         return self.gcn.forward_deferred(x)
+
+
+class CTRGCNBlock(_FusedBlock):
+    """reference: pyskl/models/gcns/ctrgcn.py:9-66 — relu(tcn1(gcn1(x)) + residual(x))."""
+
+    def __init__(self, in_channels, out_channels, A, edge_type, node_type, semantic_index=False, stride=1,
+                 residual=True, kernel_size=5, dilations=[1, 2], tcn_dropout=0, **kwargs):
+        super().__init__()
+        gcn_kwargs = {k[4:]: v for k, v in kwargs.items() if k[:4] == 'gcn_'}
+        tcn_kwargs = {k[4:]: v for k, v in kwargs.items() if k[:4] == 'tcn_'}
+        kwargs = {k: v for k, v in kwargs.items() if k[:4] not in ['gcn_', 'tcn_']}
+        assert len(kwargs) == 0, f'Invalid arguments: {kwargs}'
+        tcn_type = tcn_kwargs.pop('type', 'mstcn')
+        assert tcn_type in ['unit_tcn', 'mstcn', 'unit_tcnedge', 'unitmlp', 'msmlp']
+        gcn_type = gcn_kwargs.pop('type', 'unit_ctrhgcn')
+        assert gcn_type in ['unit_ctrgcn', 'unit_ctrhgcn']
+        if gcn_type != 'unit_ctrgcn' or tcn_type != 'mstcn':
+            raise NotImplementedError(f'{gcn_type}/{tcn_type}: the HIP path covers classic CTR-GCN (unit_ctrgcn + mstcn); '
+                                      'the unit_ctrhgcn/msmlp variant is SURVEY §8 f-1')
+        self.gcn1 = unit_ctrgcn(in_channels, out_channels, A, **gcn_kwargs)
+        self.tcn1 = MSTCN(out_channels, out_channels, kernel_size=kernel_size, stride=stride, dilations=dilations,
+                          residual=False, tcn_dropout=tcn_dropout)
+        self.relu = nn.ReLU(inplace=True)
+        self._set_residual(in_channels, out_channels, stride, residual)
+
+    tcn = property(lambda self: self.tcn1)
+
+    def _gcn_deferred(self, x, xbar):
+        return self.gcn1.forward_deferred(x, xbar)
 
 
 def _stage_kwargs(kwargs, num_stages):
@@ -253,4 +284,38 @@ class STGCN(_SkeletonBackbone):
         N, M = x.shape[:2]
         x = self._normalize_input(x.float())
         x = self._run_blocks(x, self.gcn[:self.num_stages], False)
+        return x.reshape((N, M) + x.shape[1:])
+
+
+@BACKBONES.register_module()
+class CTRGCN(_SkeletonBackbone):
+    """reference: pyskl/models/gcns/ctrgcn.py:69-123."""
+
+    def __init__(self, graph_cfg, in_channels=3, base_channels=64, num_stages=10, inflate_stages=[5, 8],
+                 down_stages=[5, 8], semantic_stage=range(1, 11), pretrained=None, num_person=2, **kwargs):
+        super().__init__()
+        self.graph = Graph(**graph_cfg)
+        A = torch.tensor(self.graph.A, dtype=torch.float32, requires_grad=False)
+        self.register_buffer('A', A)
+        node_type = torch.tensor(self.graph.node_type, requires_grad=False)
+        edge_type = torch.tensor(self.graph.edge_type, dtype=torch.float32, requires_grad=False)
+        self.num_person = num_person
+        self.base_channels = base_channels
+        self._make_data_bn('MVC', in_channels, num_person, A.size(1))
+        kwargs0 = {k: v for k, v in kwargs.items() if k != 'tcn_dropout'}
+        modules = [CTRGCNBlock(in_channels, base_channels, A.clone(), edge_type, node_type, 1 in semantic_stage,
+                               residual=False, **kwargs0)]
+        for i in range(2, num_stages + 1):
+            out_channels = base_channels * (1 + (i in inflate_stages))
+            stride = 1 + (i in down_stages)
+            modules.append(CTRGCNBlock(base_channels, out_channels, A.clone(), edge_type, node_type,
+                                       i in semantic_stage, stride=stride, **kwargs))
+            base_channels = out_channels
+        self.net = nn.ModuleList(modules)
+        self.pretrained = pretrained
+
+    def forward(self, x):
+        N, M = x.shape[:2]
+        x = self._normalize_input(x)
+        x = self._run_blocks(x, self.net, True)
         return x.reshape((N, M) + x.shape[1:])

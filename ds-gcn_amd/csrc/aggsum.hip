@@ -1,0 +1,306 @@
+// K-A': subset-summed gather-aggregate — the ST-GCN / CTR-GCN form of K-A.
+//
+//   Y[n,c,t,w] = sum_k sum_u P[n, k*Co+c, t, u] * Ahat_k[u,w]
+//
+//   ST-GCN  unit_gcn   (reference: pyskl/models/gcns/utils/gcn.py:81-85, einsum('nkctv,kvw->nctw')): Ahat_k = A[k], shared
+//   CTR-GCN unit_ctrgcn (gcn.py:658 einsum('ncuv,nctu->nctv') + the sum over subsets gcn.py:917-919): Ahat_k = Ahat[n,k,c]
+// The adjacency address is ahat + n*a_ns + k*a_ks + c*a_cs, so both are the same kernel.  One wave64 owns one (n,c)
+// output plane: the K input planes stream through LDS one after the other and accumulate in the same f32 MFMA tile
+// (v_mfma_f32_32x32x2_f32, i = frame, j = joint w, k = joint u), so the K partial products never exist in HBM
+// (the reference writes and re-reads them: 2*K extra planes).  The epilogue stores straight from the accumulators and
+// emits the per-plane sum / sum of squares for the BatchNorm that follows (gcn.py:86 / gcn.py:921).
+// Algorithmic HBM bytes per (n,c): 4*((K+1)*T*V + K*V*V) forward.
+//
+// Backward (one wave per (n,c) as well): G = gy + A0[c] + B0[c]*y (deferred-BN statistics terms), then per subset
+//   dP_k[t,u]   = sum_w G[t,w] * Ahat_k[u,w]      (i = frame, j = u, k = w)
+//   dAhat_k[u,w] = sum_t P_k[t,u] * G[t,w]        (i = u, j = w, k = frames)
+// dAhat_k is written at dahat + n*d_ns + k*d_ks + c*d_cs (for the shared form the caller sums the per-(n,c) pieces).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int as_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <int V>
+__device__ __forceinline__ void as_load_plane(const float* __restrict__ src, float* lds, int cnt, int lane, bool vec) {
+  constexpr int NP4 = (64 * V / 4 + 63) / 64;
+  if (vec) {
+    const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+    const int c4 = cnt >> 2;
+    f32x4 v[NP4];
+#pragma unroll
+    for (int q = 0; q < NP4; ++q) {
+      const int i = lane + q * 64;
+      if (i < c4) v[q] = s4[i];
+    }
+#pragma unroll
+    for (int q = 0; q < NP4; ++q) {
+      const int i = lane + q * 64;
+      if (i < c4) l4[i] = v[q];
+    }
+  } else {
+    for (int i = lane; i < cnt; i += 64) lds[i] = src[i];
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void as_load_adj(const float* __restrict__ A, float* ldsA, int lane) {
+  constexpr int NA = (V * V + 63) / 64;
+  float v[NA];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int i = lane + q * 64;
+    if (i < V * V) v[q] = A[i];
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int i = lane + q * 64;
+    if (i < V * V) ldsA[i] = v[q];
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(64) void k_aggsum_fwd(const float* __restrict__ p, const float* __restrict__ ahat,
+                                                   long a_ns, long a_ks, long a_cs, float* __restrict__ y,
+                                                   float* __restrict__ partial, int K, int Co, int T, int vec) {
+  constexpr int KS = (V + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldsP = lds;
+  float* ldsA = lds + 64 * V;
+  const int lane = threadIdx.x;
+  const long unit = blockIdx.x;
+  const int n = (int)(unit / Co), c = (int)(unit - (long)n * Co);
+  const int mi = lane & 31, mk = lane >> 5;
+  const int mic = mi < V ? mi : V - 1;
+  float sum = 0.f, sq = 0.f;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int rows = min(64, T - t0);
+    const int cnt = rows * V;
+    f32x16 acc[2];
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[tile][i] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const size_t plane = ((size_t)n * K + k) * Co + c;
+      wave_lds_sync();                                   // the previous subset's operand reads are done
+      as_load_plane<V>(p + (plane * T + t0) * V, ldsP, cnt, lane, vec);
+      as_load_adj<V>(ahat + n * a_ns + k * a_ks + c * a_cs, ldsA, lane);
+      wave_lds_sync();
+      float b[KS];
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        const int u = 2 * q + mk;
+        const float v = ldsA[(u < V ? u : V - 1) * V + mic];
+        b[q] = (u < V && mi < V) ? v : 0.f;
+      }
+#pragma unroll
+      for (int tile = 0; tile < 2; ++tile) {
+        if (tile * 32 < rows) {
+          const int t = tile * 32 + mi;
+          const int tc = t < rows ? t : rows - 1;
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            const int u = 2 * q + mk;
+            const float v = ldsP[tc * V + (u < V ? u : V - 1)];
+            const float a = (u < V && t < rows) ? v : 0.f;
+            acc[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[q], acc[tile], 0, 0, 0);
+          }
+        }
+      }
+    }
+    float* __restrict__ yo = y + ((size_t)unit * T + t0) * V;
+    if (mi < V) {
+#pragma unroll
+      for (int tile = 0; tile < 2; ++tile) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = tile * 32 + as_row(r, mk);
+          if (t < rows) {
+            const float v = acc[tile][r];
+            yo[t * V + mi] = v;
+            sum += v;
+            sq = fmaf(v, v, sq);
+          }
+        }
+      }
+    }
+  }
+  if (partial) {
+    sum = wave_sum(sum);
+    sq = wave_sum(sq);
+    if (lane == 0) {
+      partial[unit * 2 + 0] = sum;
+      partial[unit * 2 + 1] = sq;
+    }
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(64) void k_aggsum_bwd(const float* __restrict__ p, const float* __restrict__ ahat,
+                                                   long a_ns, long a_ks, long a_cs, const float* __restrict__ gy,
+                                                   const float* __restrict__ y, const float* __restrict__ A0,
+                                                   const float* __restrict__ B0, float* __restrict__ dp,
+                                                   float* __restrict__ dahat, long d_ns, long d_ks, long d_cs, int K,
+                                                   int Co, int T, int vec) {
+  constexpr int KS = (V + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldsZ = lds;                 // P_k chunk
+  float* ldsG = lds + 64 * V;        // G chunk
+  float* ldsA = lds + 128 * V;
+  const int lane = threadIdx.x;
+  const long unit = blockIdx.x;
+  const int n = (int)(unit / Co), c = (int)(unit - (long)n * Co);
+  const int mi = lane & 31, mk = lane >> 5;
+  const int mic = mi < V ? mi : V - 1;
+  const float a0 = A0 ? A0[c] : 0.f, b0 = (B0 && y) ? B0[c] : 0.f;
+  const int chunks = (T + 63) / 64;
+  for (int k = 0; k < K; ++k) {
+    const size_t plane = ((size_t)n * K + k) * Co + c;
+    wave_lds_sync();
+    as_load_adj<V>(ahat + n * a_ns + k * a_ks + c * a_cs, ldsA, lane);
+    f32x16 accA;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+    float bt[KS];
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int rows = min(64, T - t0);
+      const int cnt = rows * V;
+      const size_t offy = ((size_t)unit * T + t0) * V;
+      if (t0 > 0) wave_lds_sync();
+      if (k == 0 || chunks > 1) {
+        // G = gy + A0 + B0*y
+        if (vec) {
+          const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(gy + offy);
+          const f32x4* __restrict__ y4 = reinterpret_cast<const f32x4*>(y ? y + offy : gy + offy);
+          f32x4* l4 = reinterpret_cast<f32x4*>(ldsG);
+          const int c4 = cnt >> 2;
+          for (int i = lane; i < c4; i += 64) {
+            f32x4 g = g4[i];
+            const f32x4 yy = y4[i];
+            g.x += fmaf(b0, yy.x, a0); g.y += fmaf(b0, yy.y, a0); g.z += fmaf(b0, yy.z, a0); g.w += fmaf(b0, yy.w, a0);
+            l4[i] = g;
+          }
+        } else {
+          for (int i = lane; i < cnt; i += 64) ldsG[i] = gy[offy + i] + fmaf(b0, y ? y[offy + i] : 0.f, a0);
+        }
+      }
+      as_load_plane<V>(p + (plane * T + t0) * V, ldsZ, cnt, lane, vec);
+      wave_lds_sync();
+      if (t0 == 0) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const int w = 2 * q + mk;
+          const float v = ldsA[mic * V + (w < V ? w : V - 1)];
+          bt[q] = (w < V && mi < V) ? v : 0.f;
+        }
+      }
+      // dAhat_k += P_k^T G  (operands of 8 k-steps read before their MFMAs are issued)
+      for (int j0 = 0; j0 < rows; j0 += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int t = j0 + 2 * q + mk;
+          const bool ok = (mi < V) && (t < rows);
+          const int idx = (t < rows ? t : rows - 1) * V + mic;
+          const float a = ldsZ[idx], b = ldsG[idx];
+          av[q] = ok ? a : 0.f;
+          bv[q] = ok ? b : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (j0 + 2 * q < rows) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accA, 0, 0, 0);
+      }
+      // dP_k = G . Ahat_k^T, stored straight from the accumulators
+      float* __restrict__ dpo = dp + (plane * T + t0) * V;
+#pragma unroll
+      for (int tile = 0; tile < 2; ++tile) {
+        if (tile * 32 < rows) {
+          f32x16 acc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+          const int t = tile * 32 + mi;
+          const int tc = t < rows ? t : rows - 1;
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            const int w = 2 * q + mk;
+            const float v = ldsG[tc * V + (w < V ? w : V - 1)];
+            const float a = (w < V && t < rows) ? v : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt[q], acc, 0, 0, 0);
+          }
+          if (mi < V) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int tt = tile * 32 + as_row(r, mk);
+              if (tt < rows) dpo[tt * V + mi] = acc[r];
+            }
+          }
+        }
+      }
+    }
+    float* __restrict__ dA = dahat + n * d_ns + k * d_ks + c * d_cs;
+    if (mi < V) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int u = as_row(r, mk);
+        if (u < V) dA[u * V + mi] = accA[r];
+      }
+    }
+  }
+}
+
+template <int V>
+int as_launch_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long a_cs, float* y, float* partial, int n,
+                  int K, int Co, int T, hipStream_t st) {
+  const int vec = ((T * V) % 4 == 0) ? 1 : 0;
+  const size_t lds = (size_t)(64 * V + V * V) * sizeof(float);
+  hipLaunchKernelGGL((k_aggsum_fwd<V>), dim3((unsigned)((long)n * Co)), dim3(64), lds, st, p, ahat, a_ns, a_ks, a_cs, y,
+                     partial, K, Co, T, vec);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int V>
+int as_launch_bwd(const float* p, const float* ahat, long a_ns, long a_ks, long a_cs, const float* gy, const float* y,
+                  const float* A0, const float* B0, float* dp, float* dahat, long d_ns, long d_ks, long d_cs, int n,
+                  int K, int Co, int T, hipStream_t st) {
+  const int vec = ((T * V) % 4 == 0) ? 1 : 0;
+  const size_t lds = (size_t)(128 * V + V * V) * sizeof(float);
+  hipLaunchKernelGGL((k_aggsum_bwd<V>), dim3((unsigned)((long)n * Co)), dim3(64), lds, st, p, ahat, a_ns, a_ks, a_cs, gy,
+                     y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, K, Co, T, vec);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// See include/dsgcn.h for the contract.
+int dsgcn_aggsum_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long a_cs, float* y, float* partial,
+                     int n, int K, int Co, int T, int V, void* stream) {
+  if (!p || !ahat || !y || n <= 0 || K <= 0 || Co <= 0 || T <= 0) return DSGCN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  switch (V) {
+    case 25: return as_launch_fwd<25>(p, ahat, a_ns, a_ks, a_cs, y, partial, n, K, Co, T, st);
+    case 17: return as_launch_fwd<17>(p, ahat, a_ns, a_ks, a_cs, y, partial, n, K, Co, T, st);
+    case 18: return as_launch_fwd<18>(p, ahat, a_ns, a_ks, a_cs, y, partial, n, K, Co, T, st);
+    default: return DSGCN_EUNSUPPORTED;
+  }
+}
+
+int dsgcn_aggsum_bwd(const float* p, const float* ahat, long a_ns, long a_ks, long a_cs, const float* gy,
+                     const float* y, const float* A0, const float* B0, float* dp, float* dahat, long d_ns, long d_ks,
+                     long d_cs, int n, int K, int Co, int T, int V, void* stream) {
+  if (!p || !ahat || !gy || !dp || !dahat || n <= 0 || K <= 0 || Co <= 0 || T <= 0) return DSGCN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  switch (V) {
+    case 25: return as_launch_bwd<25>(p, ahat, a_ns, a_ks, a_cs, gy, y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, n, K, Co, T, st);
+    case 17: return as_launch_bwd<17>(p, ahat, a_ns, a_ks, a_cs, gy, y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, n, K, Co, T, st);
+    case 18: return as_launch_bwd<18>(p, ahat, a_ns, a_ks, a_cs, gy, y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, n, K, Co, T, st);
+    default: return DSGCN_EUNSUPPORTED;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+// CTR-GCN channel-wise topology refinement (reference: pyskl/models/gcns/utils/gcn.py:634-666, 882-929), the pieces
+// that are not a 1x1 conv (those run through K-C) or the aggregate (K-A'):
+//
+//   tanhdiff   : d[k,n,r,u,v] = tanh(x1[n,k,r,u] - x2[n,k,r,v])            gcn.py:653-655 (after the mean over T)
+//                proj (n, 2*K*R, V): rows [k*R + r] = conv1_k(xbar), rows [K*R + k*R + r] = conv2_k(xbar)
+//   ctr_affine : Ahat[n, k*Co + c, u, v] = alpha * S_k[n,c,u,v] + A[k,u,v]  gcn.py:657  (S_k = conv4_k(d[k]) from K-C)
+//   plane_stats: per-(n,c) sum / sum of squares of a tensor (the BatchNorms that follow a temporal conv / max-pool in
+//                MSTCN, msg3d_utils.py:101-117) -> dsgcn_bn_finalize
+// All are HBM-bound streaming passes, one wave per V*V (or T*V) plane.
+#include "common.h"
+
+namespace {
+
+constexpr int CTR_MAXK = 4;
+
+struct CtrPtrs {
+  const float* s[CTR_MAXK];
+  float* ds[CTR_MAXK];
+};
+
+// one wave per (k, n, r)
+__global__ __launch_bounds__(64) void k_tanhdiff_fwd(const float* __restrict__ proj, float* __restrict__ d, int n, int K,
+                                                     int R, int V) {
+  __shared__ float xs[64];
+  const int lane = threadIdx.x;
+  const long row = blockIdx.x;                 // (k*n + i)*R + r
+  const int r = (int)(row % R);
+  const long ki = row / R;
+  const int i = (int)(ki % n), k = (int)(ki / n);
+  const float* __restrict__ p1 = proj + ((size_t)i * 2 * K * R + (size_t)k * R + r) * V;
+  const float* __restrict__ p2 = p1 + (size_t)K * R * V;
+  if (lane < V) xs[lane] = p1[lane];
+  else if (lane >= 32 && lane - 32 < V) xs[lane] = p2[lane - 32];
+  wave_lds_sync();
+  float* __restrict__ out = d + (size_t)row * V * V;
+  for (int e = lane; e < V * V; e += 64) {
+    const int u = e / V, v = e - u * V;
+    out[e] = tanhf(xs[u] - xs[32 + v]);
+  }
+}
+
+// dproj rows: x1 gets sum_v dd*(1-d^2), x2 gets -sum_u dd*(1-d^2)
+__global__ __launch_bounds__(64) void k_tanhdiff_bwd(const float* __restrict__ d, const float* __restrict__ dd,
+                                                     float* __restrict__ dproj, int n, int K, int R, int V) {
+  extern __shared__ float ts[];                // [V*V]
+  const int lane = threadIdx.x;
+  const long row = blockIdx.x;
+  const int r = (int)(row % R);
+  const long ki = row / R;
+  const int i = (int)(ki % n), k = (int)(ki / n);
+  const float* __restrict__ pd = d + (size_t)row * V * V;
+  const float* __restrict__ pg = dd + (size_t)row * V * V;
+  for (int e = lane; e < V * V; e += 64) {
+    const float t = pd[e];
+    ts[e] = pg[e] * (1.f - t * t);
+  }
+  wave_lds_sync();
+  float* __restrict__ o1 = dproj + ((size_t)i * 2 * K * R + (size_t)k * R + r) * V;
+  float* __restrict__ o2 = o1 + (size_t)K * R * V;
+  if (lane < V) {
+    float acc = 0.f;
+    for (int v = 0; v < V; ++v) acc += ts[lane * V + v];
+    o1[lane] = acc;
+  } else if (lane >= 32 && lane - 32 < V) {
+    const int v = lane - 32;
+    float acc = 0.f;
+    for (int u = 0; u < V; ++u) acc += ts[u * V + v];
+    o2[v] = -acc;
+  }
+}
+
+// one wave per (n, k, c)
+__global__ __launch_bounds__(64) void k_ctr_affine_fwd(CtrPtrs p, const float* __restrict__ alpha,
+                                                       const float* __restrict__ A, float* __restrict__ ahat, int K,
+                                                       int Co, int VV) {
+  const int lane = threadIdx.x;
+  const long unit = blockIdx.x;                // (n*K + k)*Co + c
+  const int c = (int)(unit % Co);
+  const long nk = unit / Co;
+  const int k = (int)(nk % K);
+  const long i = nk / K;
+  const float al = alpha[0];
+  const float* __restrict__ s = p.s[k] + ((size_t)i * Co + c) * VV;
+  const float* __restrict__ a = A + (size_t)k * VV;
+  float* __restrict__ o = ahat + (size_t)unit * VV;
+  for (int e = lane; e < VV; e += 64) o[e] = fmaf(al, s[e], a[e]);
+}
+
+// one block per (n, k): dS_k = alpha*dAhat ; prow (n, K*VV + K): [sum_c dAhat[k,e] | sum dAhat*S]
+__global__ __launch_bounds__(256) void k_ctr_affine_bwd(CtrPtrs p, const float* __restrict__ alpha,
+                                                        const float* __restrict__ dahat, float* __restrict__ prow,
+                                                        int K, int Co, int VV) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const long nk = blockIdx.x;
+  const int k = (int)(nk % K);
+  const long i = nk / K;
+  const float al = alpha[0];
+  const float* __restrict__ g = dahat + (size_t)nk * Co * VV;
+  const float* __restrict__ s = p.s[k] + (size_t)i * Co * VV;
+  float* __restrict__ ds = p.ds[k] + (size_t)i * Co * VV;
+  float accA[4] = {0.f, 0.f, 0.f, 0.f};
+  float acca = 0.f;
+  for (int c = 0; c < Co; ++c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + 256 * j;
+      if (e < VV) {
+        const float gv = g[(size_t)c * VV + e];
+        const float sv = s[(size_t)c * VV + e];
+        ds[(size_t)c * VV + e] = al * gv;
+        accA[j] += gv;
+        acca = fmaf(gv, sv, acca);
+      }
+    }
+  }
+  float* __restrict__ out = prow + (size_t)i * (K * VV + K);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 256 * j;
+    if (e < VV) out[(size_t)k * VV + e] = accA[j];
+  }
+  acca = wave_sum(acca);
+  if ((tid & 63) == 0) red[tid >> 6] = acca;
+  __syncthreads();
+  if (tid == 0) out[(size_t)K * VV + k] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one wave per plane of L elements: partial[plane] = [sum, sum of squares]
+__global__ __launch_bounds__(64) void k_plane_stats(const float* __restrict__ x, float* __restrict__ partial, int L,
+                                                    int vec) {
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const float* __restrict__ p = x + (size_t)plane * L;
+  float s = 0.f, q = 0.f;
+  if (vec) {
+    const f32x4* __restrict__ p4 = reinterpret_cast<const f32x4*>(p);
+    const int L4 = L >> 2;
+#pragma unroll 4
+    for (int i = lane; i < L4; i += 64) {
+      const f32x4 v = p4[i];
+      s += (v.x + v.y) + (v.z + v.w);
+      q = fmaf(v.x, v.x, q); q = fmaf(v.y, v.y, q); q = fmaf(v.z, v.z, q); q = fmaf(v.w, v.w, q);
+    }
+  } else {
+#pragma unroll 4
+    for (int i = lane; i < L; i += 64) {
+      const float v = p[i];
+      s += v;
+      q = fmaf(v, v, q);
+    }
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (lane == 0) {
+    partial[plane * 2 + 0] = s;
+    partial[plane * 2 + 1] = q;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsgcn_tanhdiff_fwd(const float* proj, float* d, int n, int K, int R, int V, void* stream) {
+  if (!proj || !d || n <= 0 || K <= 0 || R <= 0 || V <= 0 || V > 32) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_tanhdiff_fwd, dim3((unsigned)((long)K * n * R)), dim3(64), 0, (hipStream_t)stream, proj, d, n, K,
+                     R, V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+int dsgcn_tanhdiff_bwd(const float* d, const float* dd, float* dproj, int n, int K, int R, int V, void* stream) {
+  if (!d || !dd || !dproj || n <= 0 || K <= 0 || R <= 0 || V <= 0 || V > 32) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_tanhdiff_bwd, dim3((unsigned)((long)K * n * R)), dim3(64), (size_t)V * V * sizeof(float),
+                     (hipStream_t)stream, d, dd, dproj, n, K, R, V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+int dsgcn_ctr_affine_fwd(const float* const* s, const float* alpha, const float* A, float* ahat, int n, int K, int Co,
+                         int V, void* stream) {
+  if (!s || !alpha || !A || !ahat || n <= 0 || K <= 0 || K > CTR_MAXK || Co <= 0 || V <= 0) return DSGCN_EINVAL;
+  CtrPtrs p = {};
+  for (int k = 0; k < K; ++k) {
+    if (!s[k]) return DSGCN_EINVAL;
+    p.s[k] = s[k];
+  }
+  hipLaunchKernelGGL(k_ctr_affine_fwd, dim3((unsigned)((long)n * K * Co)), dim3(64), 0, (hipStream_t)stream, p, alpha, A,
+                     ahat, K, Co, V * V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, const float* dahat, float* const* ds, float* prow,
+                         int n, int K, int Co, int V, void* stream) {
+  if (!s || !alpha || !dahat || !ds || !prow || n <= 0 || K <= 0 || K > CTR_MAXK || Co <= 0 || V <= 0 || V * V > 1024)
+    return DSGCN_EINVAL;
+  CtrPtrs p = {};
+  for (int k = 0; k < K; ++k) {
+    if (!s[k] || !ds[k]) return DSGCN_EINVAL;
+    p.s[k] = s[k];
+    p.ds[k] = ds[k];
+  }
+  hipLaunchKernelGGL(k_ctr_affine_bwd, dim3((unsigned)((long)n * K)), dim3(256), 0, (hipStream_t)stream, p, alpha, dahat,
+                     prow, K, Co, V * V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+int dsgcn_plane_stats(const float* x, float* partial, long planes, int L, void* stream) {
+  if (!x || !partial || planes <= 0 || L <= 0) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_plane_stats, dim3((unsigned)planes), dim3(64), 0, (hipStream_t)stream, x, partial, L,
+                     (L % 4 == 0) ? 1 : 0);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,12 +1,15 @@
 // Block output: the one place an activation is materialised.
 //   out[n,c,t,v] = relu?( x1*s1[c]+h1[c]  (+ x2*s2[c]+h2[c] | + x2) )      xbar[n,c,v] = mean_t out[n,c,t,v]
+//   relu bit 0 = the outer ReLU, bit 1 = a ReLU on the first term alone (CTR-GCN: MSTCN ends in its own ReLU before the
+//   block adds the residual, msg3d_utils.py:139-141 + ctrgcn.py:60)
 // Replaces BatchNorm2d (tcn.py:427 / gcn.py:2365) + residual add + ReLU (dgstgcn.py:63-65) and the
 // x.mean(dim=-2) of the NEXT block's dynamic adjacency (gcn.py:2246) — one read of each operand, one write.
 // One wave per (n,c) plane: coalesced 16-B loads, the plane passes through LDS only to form the per-joint time mean.
 // HBM-bound: 4*(2 or 3)*T*V bytes per plane.
 //
 // Backward: dv = (dout + dxbar/T) * 1[pre>0];  dx1 = dv*s1, dx2 = dv*s2 (or dv);
-//           per-plane partial sums of dv*x1, dv, dv*x2  (-> d s1, d h1 = d h2, d s2 after the sum over n).
+//           per-plane partial sums of dv1*x1, dv, dv*x2, dv1  (-> d s1, d h2, d s2, d h1 after the sum over n;
+//           dv1 = dv unless the first term has its own ReLU).
 #include "common.h"
 
 namespace {
@@ -36,19 +39,21 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
     for (int i = lane; i < L4; i += 64) {
       f32x4 v = q1[i];
       v.x = fmaf(v.x, a1, b1); v.y = fmaf(v.y, a1, b1); v.z = fmaf(v.z, a1, b1); v.w = fmaf(v.w, a1, b1);
+      if (relu & 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       if (p2) {
         const f32x4 r = q2[i];
         v.x += fmaf(r.x, a2, b2); v.y += fmaf(r.y, a2, b2); v.z += fmaf(r.z, a2, b2); v.w += fmaf(r.w, a2, b2);
       }
-      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (relu & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       qo[i] = v;
       if (xbar) ql[i] = v;
     }
   } else {
     for (int i = lane; i < L; i += 64) {
       float v = fmaf(p1[i], a1, b1);
+      if (relu & 2) v = fmaxf(v, 0.f);
       if (p2) v += fmaf(p2[i], a2, b2);
-      if (relu) v = fmaxf(v, 0.f);
+      if (relu & 1) v = fmaxf(v, 0.f);
       po[i] = v;
       if (xbar) lds[i] = v;
     }
@@ -84,22 +89,25 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
   const float* __restrict__ pg = dout ? dout + (size_t)plane * L : nullptr;
   float* __restrict__ o1 = dx1 + (size_t)plane * L;
   float* __restrict__ o2 = dx2 ? dx2 + (size_t)plane * L : nullptr;
-  float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+  float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
   int v = lane % V;                      // joint index of element `lane`; advances by 64 % V per iteration
   const int step = 64 % V;
 #pragma unroll 5
   for (int i = lane; i < L; i += 64) {
     const float xa = p1[i];
     const float xb = p2 ? p2[i] : 0.f;
-    float pre = fmaf(xa, a1, b1);
+    const float pre1 = fmaf(xa, a1, b1);
+    float pre = (relu & 2) ? fmaxf(pre1, 0.f) : pre1;
     if (p2) pre += fmaf(xb, a2, b2);
     float g = (pg ? pg[i] : 0.f) + dxb[v];
-    if (relu && !(pre > 0.f)) g = 0.f;
-    o1[i] = g * a1;
+    if ((relu & 1) && !(pre > 0.f)) g = 0.f;
+    const float g1 = ((relu & 2) && !(pre1 > 0.f)) ? 0.f : g;     // gradient of the first term
+    o1[i] = g1 * a1;
     if (o2) o2[i] = g * a2;
-    u0 = fmaf(g, xa, u0);
+    u0 = fmaf(g1, xa, u0);
     u1 += g;
     u2 = fmaf(g, xb, u2);
+    u3 += g1;
     v += step;
     if (v >= V) v -= V;
   }
@@ -107,10 +115,12 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
     u0 = wave_sum(u0);
     u1 = wave_sum(u1);
     u2 = wave_sum(u2);
+    u3 = wave_sum(u3);
     if (lane == 0) {
-      part[(size_t)plane * 3 + 0] = u0;
-      part[(size_t)plane * 3 + 1] = u1;
-      part[(size_t)plane * 3 + 2] = u2;
+      part[(size_t)plane * 4 + 0] = u0;
+      part[(size_t)plane * 4 + 1] = u1;
+      part[(size_t)plane * 4 + 2] = u2;
+      part[(size_t)plane * 4 + 3] = u3;
     }
   }
 }
@@ -131,7 +141,7 @@ int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const 
   return 0;
 }
 
-// part: (n*C, 3) per-plane [sum dv*x1, sum dv, sum dv*x2]; dout or dxbar may be NULL (treated as zero).
+// part: (n*C, 4) per-plane [sum dv1*x1, sum dv, sum dv*x2, sum dv1]; dout or dxbar may be NULL (treated as zero).
 int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, const float* dout, const float* dxbar, float* dx1, float* dx2,
                        float* part, int n, int C, int T, int V, void* stream) {

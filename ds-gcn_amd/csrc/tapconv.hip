@@ -1,17 +1,22 @@
-// K-D (core): the temporal branches of dgmstcn between branch_act and combine, all in one launch per direction
-// (reference: pyskl/models/gcns/utils/tcn.py:379-398, 410-415):
-//   conv  branch : o[n,c0+co,t',x] = b[co] + sum_tap sum_ci W[co,ci,tap] * h[n,c0+ci, t'*s + (tap-KT/2)*d, x]   (zero pad)
-//                  = unit_tcn(kernel (KT,1), dilation d, stride s, norm=None)   tcn.py:21-28,393-396
-//   max   branch : o = max over the valid taps of a (3,1) window, stride s, pad 1                                   tcn.py:387-390
-//   copy  branch : o = h[..., ::s, :]   (the '1x1' branch: its conv is fused upstream in K-C)                         tcn.py:383
-// h is the activated tensor (n, C, T, V1) written by k_branch_act (V1 = V+1: the global-joint column rides along),
-// o is (n, C, T', V1): every branch writes its own channel window, so there is no torch.cat.
+// K-D (core): temporal (KT x 1) convolutions, max-pool and strided copy over channel windows of one tensor, one launch
+// per direction.  Serves
+//   * the temporal branches of dgmstcn between branch_act and combine (reference: pyskl/models/gcns/utils/tcn.py:379-398,
+//     410-415): four dilated (3,1) convs, the (3,1) max-pool and the strided '1x1' pass-through;
+//   * the branches of CTR-GCN's MSTCN (pyskl/models/gcns/utils/msg3d_utils.py:84-117): two dilated (5,1) convs, max-pool,
+//     strided pass-through;
+//   * the dense (9,1) temporal conv of ST-GCN's unit_tcn (tcn.py:21-28, stgcn.py:45-46).
+//   conv  window : o[n,co0+co,t',x] = b[co] + sum_tap sum_ci W[co,ci,tap] * h[n,ci0+ci, t'*s + (tap-KT/2)*d, x]   (zero pad)
+//   max   window : o = max over the valid taps of a (3,1) window, stride s, pad 1
+//   copy  window : o = h[..., ::s, :]
+// h is (n, Cin, T, V1), o is (n, Cout, T', V1); every window writes its own channel range, so there is no torch.cat.
 //
-// conv branches run on the f32 matrix core, wave-independent like K-C: lane = output position, B operand = h read
-// straight from HBM/L2 with raw buffer loads at the tap-shifted row (out-of-range rows -> buffer OOB -> 0),
-// A operand = the branch's whole weight tensor staged once in LDS as [co][tap*bcp + ci].
-// Backward: dgrad = the transposed gather (same kernel shape over input positions), wgrad = per-tap GEMM over positions
-// with LDS-staged do / shifted-h tiles, K-split partials reduced by dsgcn_colsum.
+// Convs run on the f32 matrix core, wave-independent like K-C: lane = output position, B operand = h read straight from
+// HBM/L2 with raw buffer loads at the tap-shifted row (out-of-range rows -> buffer OOB -> 0), A operand = a 64x64xKT
+// weight tile staged in LDS as [co][tap*CP + ci]; wider convs loop over 64-channel source chunks (grid.z covers the
+// destination chunks).  Backward: dgrad = the transposed gather (same kernel shape over input positions), wgrad =
+// per-tap GEMM over positions with LDS-staged do / shifted-h tiles, K-split partials reduced by dsgcn_colsum.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -22,19 +27,21 @@ constexpr int TC_OOB = 0x7ffffff0;
 
 struct TBranch {
   int type;            // 0 conv, 1 max, 2 copy
-  int c0, bc, dil;
-  const float* w;      // (bc, bc, KT, 1)
-  const float* b;      // (bc)
-  float* dwp;          // (splits, bc*bc*KT) partials
-  float* dbp;          // (splits, bc)
+  int ci0, co0;        // first channel of the window in h / in o
+  int cin, cout;       // window widths (equal for max / copy)
+  int dil;
+  const float* w;      // (cout, cin, KT, 1)
+  const float* b;      // (cout)
+  float* dwp;          // (splits, cout*cin*KT) partials
+  float* dbp;          // (splits, cout)
 };
 
 struct TArgs {
-  const float* h;      // (n, C, T, V1)
-  float* o;            // (n, C, Tout, V1)
+  const float* h;      // (n, Cin, T, V1)
+  float* o;            // (n, Cout, Tout, V1)
   const float* go;     // grad of o
   float* dh;           // grad of h
-  int n, C, T, Tout, V1, stride, nbr, splits, pstride;
+  int n, Cin, Cout, T, Tout, V1, stride, nbr, splits, pstride, dch;
   TBranch br[TC_MAXBR];
 };
 
@@ -45,25 +52,111 @@ __device__ __forceinline__ float tc_load(__amdgpu_buffer_rsrc_t r, int voff, int
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 __device__ __forceinline__ int tc_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+__device__ __forceinline__ int tc_cp(const TBranch& br) { return (min(64, max(br.cin, 1)) + 7) & ~7; }
 
-// One MFMA pass: acc[m] += A(Ws rows 32m.., column kbase+2u+half) * B(loaded values), 4 k-steps.
-// FWD: A[i=co][k] = Ws[co*S + kcol];  BWD (transposed): A[i=ci][k=co] = Ws[k*S + tap*bcp + i]
+// weight tile (co0l.., ci0l..) of W (cout, cin, KT) -> LDS [co_l][tap*CP + ci_l], zero padded to 64 rows
+template <int KT>
+__device__ __forceinline__ void tc_stage_w(const TBranch& br, float* Ws, int co0l, int nco, int ci0l, int nci, int CP) {
+  const int S = KT * CP + 1;
+  if (nco < 64 || nci < CP) {
+    for (int i = threadIdx.x; i < 64 * S + 64; i += TC_NT) Ws[i] = 0.f;
+    __syncthreads();
+  }
+  const int run = nci * KT;
+  const int total = nco * run;
+  for (int i0 = threadIdx.x; i0 < total; i0 += TC_NT * 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * TC_NT;
+      if (i < total) {
+        const int co = i / run, r = i - co * run;
+        v[q] = br.w[((size_t)(co0l + co) * br.cin + ci0l) * KT + r];
+      } else {
+        v[q] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * TC_NT;
+      if (i < total) {
+        const int co = i / run, r = i - co * run, ci = r / KT, tap = r - ci * KT;
+        Ws[co * S + tap * CP + ci] = v[q];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Accumulate one source chunk: acc[m] += A(Ws) * B(loaded values).
+// FWD: A[i=co][k=ci] = Ws[co*S + tap*CP + ci];  BWD (transposed): A[i=ci][k=co] = Ws[co*S + tap*CP + ci]
 template <int KT, bool FWD>
-__device__ __forceinline__ void tc_conv(const TArgs& a, const TBranch& br, float* Ws, int n, int tile, int lane) {
+__device__ __forceinline__ void tc_accum(f32x16 (&acc)[2], const float* Ws, __amdgpu_buffer_rsrc_t rs, const int (&voff)[KT],
+                                         int cstride4, int sbase, int ns, int mtiles, int CP, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const int S = KT * CP + 1;
+  const int nsp = (ns + 7) & ~7;
+#pragma unroll
+  for (int tap = 0; tap < KT; ++tap) {
+    float xa[4], xb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xa[u] = tc_load(rs, voff[tap], (sbase + 2 * u) * cstride4);
+    for (int k0 = 0; k0 < nsp; k0 += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xb[u] = tc_load(rs, voff[tap], (sbase + k0 + 8 + 2 * u) * cstride4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kl = k0 + 2 * u + half;
+        const float bv = kl < ns ? xa[u] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          if (m < mtiles) {
+            const float av = FWD ? Ws[(32 * m + l31) * S + tap * CP + kl] : Ws[kl * S + tap * CP + 32 * m + l31];
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+          }
+        }
+      }
+      if (k0 + 8 < nsp) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xa[u] = tc_load(rs, voff[tap], (sbase + k0 + 16 + 2 * u) * cstride4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kl = k0 + 8 + 2 * u + half;
+          const float bv = kl < ns ? xb[u] : 0.f;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            if (m < mtiles) {
+              const float av = FWD ? Ws[(32 * m + l31) * S + tap * CP + kl] : Ws[kl * S + tap * CP + 32 * m + l31];
+              acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// One block = (4 position tiles of 32) x (one destination chunk of <= 64 channels); loops over the source chunks.
+template <int KT, bool FWD>
+__device__ __forceinline__ void tc_conv(const TArgs& a, const TBranch& br, float* Ws, int n, int tile, int chunk,
+                                        int lane) {
   const int half = lane >> 5, l31 = lane & 31;
   const int V1 = a.V1;
-  const int bc = br.bc;
-  const int bcp = (bc + 7) & ~7;                 // channels per tap padded to a multiple of 8 (two 4-step groups)
-  const int S = KT * bcp + 1;                    // LDS row stride (odd)
+  const int CP = tc_cp(br);
   const int Lout = a.Tout * V1, Lin = a.T * V1;
   const int L = FWD ? Lout : Lin;
   const int pos = tile * 32 + l31;
   const bool pok = pos < L;
   const int pc = pok ? pos : 0;
   const int row = pc / V1, col = pc - row * V1;
-  // source tensor: forward reads h (T rows), backward reads go (Tout rows)
+  // source tensor: forward reads h (T rows, Cin channels), backward reads go (Tout rows, Cout channels)
   const int Tsrc = FWD ? a.T : a.Tout;
-  const size_t src_bytes = (size_t)a.n * a.C * Tsrc * V1 * 4;
+  const int Csrc = FWD ? a.Cin : a.Cout;
+  const int sch0 = FWD ? br.ci0 : br.co0;          // first source channel of the window
+  const int nsrc = FWD ? br.cin : br.cout;
+  const int ndst_all = FWD ? br.cout : br.cin;
+  const int d0 = chunk * 64, nd = min(64, ndst_all - d0);
+  const size_t src_bytes = (size_t)a.n * Csrc * Tsrc * V1 * 4;
   const __amdgpu_buffer_rsrc_t rs = tc_rsrc(FWD ? a.h : a.go, src_bytes);
   const int cstride4 = Tsrc * V1 * 4;
   int voff[KT];
@@ -79,116 +172,61 @@ __device__ __forceinline__ void tc_conv(const TArgs& a, const TBranch& br, float
       rs_row = num / a.stride;
       ok = ok && num >= 0 && (num - rs_row * a.stride) == 0 && rs_row < a.Tout;
     }
-    voff[tap] = ok ? (int)((((size_t)n * a.C + br.c0 + half) * Tsrc + rs_row) * V1 + col) * 4 : TC_OOB;
+    voff[tap] = ok ? (int)((((size_t)n * Csrc + sch0 + half) * Tsrc + rs_row) * V1 + col) * 4 : TC_OOB;
   }
   f32x16 acc[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
-  const int mtiles = (bc + 31) / 32;
-#pragma unroll
-  for (int tap = 0; tap < KT; ++tap) {
-    float xa[4], xb[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) xa[u] = tc_load(rs, voff[tap], (2 * u) * cstride4);
-    for (int k0 = 0; k0 < bcp; k0 += 16) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) xb[u] = tc_load(rs, voff[tap], (k0 + 8 + 2 * u) * cstride4);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kl = k0 + 2 * u + half;
-        const float bv = kl < bc ? xa[u] : 0.f;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          if (m < mtiles) {
-            const float av = FWD ? Ws[(32 * m + l31) * S + tap * bcp + kl] : Ws[kl * S + tap * bcp + 32 * m + l31];
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
-          }
-        }
-      }
-      if (k0 + 8 < bcp) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xa[u] = tc_load(rs, voff[tap], (k0 + 16 + 2 * u) * cstride4);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int kl = k0 + 8 + 2 * u + half;
-          const float bv = kl < bc ? xb[u] : 0.f;
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            if (m < mtiles) {
-              const float av = FWD ? Ws[(32 * m + l31) * S + tap * bcp + kl] : Ws[kl * S + tap * bcp + 32 * m + l31];
-              acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
+  const int mtiles = (nd + 31) / 32;
+  for (int s0 = 0; s0 < nsrc; s0 += 64) {
+    const int ns = min(64, nsrc - s0);
+    if (s0 > 0) __syncthreads();                   // every wave is done with the previous tile
+    if (FWD) tc_stage_w<KT>(br, Ws, d0, nd, s0, ns, CP);
+    else tc_stage_w<KT>(br, Ws, s0, ns, d0, nd, CP);
+    tc_accum<KT, FWD>(acc, Ws, rs, voff, cstride4, s0, ns, mtiles, CP, lane);
   }
   // D[i=channel][j=position]
   float* dst = FWD ? a.o : a.dh;
   const int Tdst = FWD ? a.Tout : a.T;
+  const int Cdst = FWD ? a.Cout : a.Cin;
+  const int dch0 = (FWD ? br.co0 : br.ci0) + d0;
   if (pok) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ch = 32 * m + tc_row32(r, half);
-        if (ch < bc) {
-          const float bias = (FWD && br.b) ? br.b[ch] : 0.f;
-          dst[((size_t)(n * a.C + br.c0 + ch) * Tdst) * V1 + pos] = acc[m][r] + bias;
+        if (ch < nd) {
+          const float bias = (FWD && br.b) ? br.b[d0 + ch] : 0.f;
+          dst[((size_t)(n * Cdst + dch0 + ch) * Tdst) * V1 + pos] = acc[m][r] + bias;
         }
       }
     }
   }
 }
 
-// weights (bc, bc, KT) -> LDS [co][tap*bcp + ci] (zero padded); all loads of a thread are issued in batches of 8
-template <int KT>
-__device__ __forceinline__ void tc_stage_w(const TBranch& br, float* Ws) {
-  const int bc = br.bc, bcp = (bc + 7) & ~7, S = KT * bcp + 1;
-  const int rows = (bc + 31) / 32 * 32;
-  // zero the padded tile first (cheap: <= 64 x 145 floats), then scatter the real weights
-  for (int i = threadIdx.x; i < (rows > bcp ? rows : bcp) * S; i += TC_NT) Ws[i] = 0.f;
-  __syncthreads();
-  const int total = bc * bc * KT;
-  for (int i0 = threadIdx.x; i0 < total; i0 += TC_NT * 8) {
-    float v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = i0 + q * TC_NT;
-      v[q] = i < total ? br.w[i] : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = i0 + q * TC_NT;
-      if (i < total) {
-        const int co = i / (bc * KT), r = i - co * bc * KT, ci = r / KT, tap = r - ci * KT;
-        Ws[co * S + tap * bcp + ci] = v[q];
-      }
-    }
-  }
-  __syncthreads();
-}
-
 template <int KT>
 __global__ __launch_bounds__(TC_NT) void k_tapconv_fwd(TArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const TBranch& br = a.br[blockIdx.z];
+  const int bi = blockIdx.z / a.dch, chunk = blockIdx.z - bi * a.dch;
+  const TBranch& br = a.br[bi];
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int V1 = a.V1, Lout = a.Tout * V1;
   if (br.type == 0) {
-    tc_stage_w<KT>(br, lds);
-    tc_conv<KT, true>(a, br, lds, n, blockIdx.x * 4 + wave, lane);
+    if (chunk * 64 >= br.cout) return;
+    tc_conv<KT, true>(a, br, lds, n, blockIdx.x * 4 + wave, chunk, lane);
     return;
   }
-  // elementwise branches: thread = output position, loop over the branch's channels
+  if (chunk > 0) return;
+  // elementwise windows: thread = output position, loop over the window's channels
   const int pos = blockIdx.x * 128 + (threadIdx.x & 127);
   if (pos >= Lout) return;
   const int tp = pos / V1, col = pos - tp * V1;
-  for (int c = threadIdx.x >> 7; c < br.bc; c += 2) {
-    const float* hp = a.h + ((size_t)(n * a.C + br.c0 + c) * a.T) * V1 + col;
+  for (int c = threadIdx.x >> 7; c < br.cout; c += 2) {
+    const float* hp = a.h + ((size_t)(n * a.Cin + br.ci0 + c) * a.T) * V1 + col;
     float v;
     if (br.type == 2) {
       v = hp[(size_t)(tp * a.stride) * V1];
@@ -200,28 +238,30 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_fwd(TArgs a) {
         if (t >= 0 && t < a.T) v = fmaxf(v, hp[(size_t)t * V1]);
       }
     }
-    a.o[((size_t)(n * a.C + br.c0 + c) * a.Tout) * V1 + pos] = v;
+    a.o[((size_t)(n * a.Cout + br.co0 + c) * a.Tout) * V1 + pos] = v;
   }
 }
 
 template <int KT>
 __global__ __launch_bounds__(TC_NT) void k_tapconv_dgrad(TArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const TBranch& br = a.br[blockIdx.z];
+  const int bi = blockIdx.z / a.dch, chunk = blockIdx.z - bi * a.dch;
+  const TBranch& br = a.br[bi];
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int V1 = a.V1, Lin = a.T * V1;
   if (br.type == 0) {
-    tc_stage_w<KT>(br, lds);
-    tc_conv<KT, false>(a, br, lds, n, blockIdx.x * 4 + wave, lane);
+    if (chunk * 64 >= br.cin) return;
+    tc_conv<KT, false>(a, br, lds, n, blockIdx.x * 4 + wave, chunk, lane);
     return;
   }
+  if (chunk > 0) return;
   const int pos = blockIdx.x * 128 + (threadIdx.x & 127);
   if (pos >= Lin) return;
   const int t = pos / V1, col = pos - t * V1;
-  for (int c = threadIdx.x >> 7; c < br.bc; c += 2) {
-    const float* hp = a.h + ((size_t)(n * a.C + br.c0 + c) * a.T) * V1 + col;
-    const float* gp = a.go + ((size_t)(n * a.C + br.c0 + c) * a.Tout) * V1 + col;
+  for (int c = threadIdx.x >> 7; c < br.cin; c += 2) {
+    const float* hp = a.h + ((size_t)(n * a.Cin + br.ci0 + c) * a.T) * V1 + col;
+    const float* gp = a.go + ((size_t)(n * a.Cout + br.co0 + c) * a.Tout) * V1 + col;
     float g = 0.f;
     if (br.type == 2) {
       if (t % a.stride == 0 && t / a.stride < a.Tout) g = gp[(size_t)(t / a.stride) * V1];
@@ -246,18 +286,23 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_dgrad(TArgs a) {
         if (arg == t) g += gp[(size_t)tp * V1];
       }
     }
-    a.dh[((size_t)(n * a.C + br.c0 + c) * a.T) * V1 + pos] = g;
+    a.dh[((size_t)(n * a.Cin + br.ci0 + c) * a.T) * V1 + pos] = g;
   }
 }
 
-// wgrad: grid = (splits, nbr_conv).  Block: all (co, ci) of one branch (<= 64 x 64), KT accumulators per wave tile.
-// Chunk = (sample, 2 output frames): Ds[64][KP] = do, Xs[tap][64][KP] = h at the tap-shifted frames.
+// wgrad: grid = (splits, nbr * dch * dch).  Block: a 64 (co) x 64 (ci) tile of one conv window, KT accumulators per wave
+// tile.  Chunk of work = (sample, 2 output frames): Ds[64][KP] = do, Xs[tap][64][KP] = h at the tap-shifted frames.
 template <int KT>
 __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const TBranch& br = a.br[blockIdx.y];
-  if (br.type != 0) return;
-  const int V1 = a.V1, bc = br.bc;
+  const int bi = blockIdx.y / (a.dch * a.dch);
+  const int rem = blockIdx.y - bi * a.dch * a.dch;
+  const int coch = rem / a.dch, cich = rem - coch * a.dch;
+  const TBranch& br = a.br[bi];
+  if (br.type != 0 || coch * 64 >= br.cout || cich * 64 >= br.cin) return;
+  const int V1 = a.V1;
+  const int nco = min(64, br.cout - coch * 64), nci = min(64, br.cin - cich * 64);
+  const int chd = br.co0 + coch * 64, chx = br.ci0 + cich * 64;
   constexpr int TRW = 2;
   const int KP = (TRW * V1 + 1) & ~1, LS = KP | 1;
   float* Ds = lds;                                // [64][LS]
@@ -285,12 +330,13 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
       const int p = quarter + 4 * j;
       const int rl = p / V1, col = p - rl * V1;
       const int tp = r0 + rl;
-      const bool live = p < TRW * V1 && tp < a.Tout && row < bc;
-      dv[j] = live ? a.go[((size_t)(n * a.C + br.c0 + row) * a.Tout + tp) * V1 + col] : 0.f;
+      const bool live = p < TRW * V1 && tp < a.Tout;
+      dv[j] = (live && row < nco) ? a.go[((size_t)(n * a.Cout + chd + row) * a.Tout + tp) * V1 + col] : 0.f;
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         const int t = tp * a.stride + (k - KT / 2) * br.dil;
-        xv[k][j] = (live && t >= 0 && t < a.T) ? a.h[((size_t)(n * a.C + br.c0 + row) * a.T + t) * V1 + col] : 0.f;
+        xv[k][j] = (live && row < nci && t >= 0 && t < a.T)
+                       ? a.h[((size_t)(n * a.Cin + chx + row) * a.T + t) * V1 + col] : 0.f;
       }
     }
   };
@@ -322,96 +368,152 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
       }
     }
   }
-  // D[i=co][j=ci] per tap -> dwp[split][(co*bc + ci)*KT + tap]
+  // D[i=co][j=ci] per tap -> dwp[split][(co*cin + ci)*KT + tap]
   const int ci = 32 * nt + l31;
   float* dwp = br.dwp + (size_t)blockIdx.x * a.pstride;
-  if (ci < bc) {
+  if (ci < nci) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = 32 * mt + tc_row32(r, half);
-      if (co < bc) {
+      if (co < nco) {
 #pragma unroll
-        for (int k = 0; k < KT; ++k) dwp[((size_t)co * bc + ci) * KT + k] = acc[k][r];
+        for (int k = 0; k < KT; ++k)
+          dwp[((size_t)(coch * 64 + co) * br.cin + cich * 64 + ci) * KT + k] = acc[k][r];
       }
     }
   }
-  if (quarter == 0 && row < bc) br.dbp[(size_t)blockIdx.x * a.pstride + row] = dbacc;
+  if (cich == 0 && quarter == 0 && row < nco) br.dbp[(size_t)blockIdx.x * a.pstride + coch * 64 + row] = dbacc;
 }
 
-size_t tc_lds_conv(int bcmax, int KT) {
-  const int bcp = (bcmax + 7) & ~7, S = KT * bcp + 1;
-  const int rows = (bcmax + 31) / 32 * 32;
-  return (size_t)((rows > bcp ? rows : bcp) + 1) * S * sizeof(float);
+size_t tc_lds_conv(int CP, int KT) { return (size_t)(64 * (KT * CP + 1) + 64) * sizeof(float); }
+
+constexpr size_t TC_LDS_MAX = 156 * 1024;
+
+template <typename F>
+int tc_raise_lds(F* kernel, size_t lds, size_t* have) {
+  if (lds > TC_LDS_MAX) return DSGCN_EUNSUPPORTED;
+  if (lds > *have) {       // not a stream op: done once per kernel, outside any graph capture (first eager call)
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TC_LDS_MAX);
+    if (e != hipSuccess) return (int)e;
+    *have = TC_LDS_MAX;
+  }
+  return 0;
+}
+
+// fills a.br / a.dch, returns the widest padded source chunk (CP) over the conv windows, or <0 on error
+int tc_fill(TArgs& a, int nbr, const int* type, const int* ci0, const int* co0, const int* cin, const int* cout,
+            const int* dil) {
+  int cpmax = 8, dch = 1;
+  for (int i = 0; i < nbr; ++i) {
+    TBranch& b = a.br[i];
+    b.type = type[i]; b.ci0 = ci0[i]; b.co0 = co0[i]; b.cin = cin[i]; b.cout = cout[i]; b.dil = dil[i];
+    if (b.cin <= 0 || b.cout <= 0 || b.ci0 < 0 || b.co0 < 0 || b.ci0 + b.cin > a.Cin || b.co0 + b.cout > a.Cout)
+      return DSGCN_EINVAL;
+    if (b.type != 0 && b.cin != b.cout) return DSGCN_EINVAL;
+    if (b.type == 0) {
+      const int cp = (std::min(64, b.cin) + 7) & ~7;
+      if (cp > cpmax) cpmax = cp;
+      const int d = (std::max(b.cin, b.cout) + 63) / 64;
+      if (d > dch) dch = d;
+    }
+  }
+  a.dch = dch;
+  return cpmax;
 }
 
 }  // namespace
 
+#define TC_DISPATCH_KT(KTV, CALL) \
+  switch (KTV) {                  \
+    case 3: { constexpr int KTC = 3; CALL; } break; \
+    case 5: { constexpr int KTC = 5; CALL; } break; \
+    case 9: { constexpr int KTC = 9; CALL; } break; \
+    default: return DSGCN_EUNSUPPORTED;             \
+  }
+
 extern "C" {
 
-// Branch tables are passed as parallel arrays (nbr <= 8): type (0 conv / 1 max3 / 2 copy), c0, bc, dil, weight and
-// bias pointers (conv only).  All conv branches share the kernel size KT (3 for dgmstcn).
-int dsgcn_tapconv_fwd(const float* h, float* o, int n, int C, int T, int V1, int stride, int KT, int nbr,
-                      const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
-                      const float* const* b, void* stream) {
-  if (!h || !o || n <= 0 || C <= 0 || T <= 0 || V1 <= 0 || stride <= 0 || nbr <= 0 || nbr > TC_MAXBR) return DSGCN_EINVAL;
-  if (KT != 3) return DSGCN_EUNSUPPORTED;
+// Window tables are passed as parallel arrays (nbr <= 8): type (0 conv / 1 max3 / 2 copy), first channel in h / in o,
+// widths, dilation, weight and bias pointers (conv only).  All conv windows share the kernel size KT (3, 5 or 9).
+int dsgcn_tapconv_fwd(const float* h, float* o, int n, int Cin, int Cout, int T, int V1, int stride, int KT, int nbr,
+                      const int* type, const int* ci0, const int* co0, const int* cin, const int* cout, const int* dil,
+                      const float* const* w, const float* const* b, void* stream) {
+  if (!h || !o || n <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V1 <= 0 || stride <= 0 || nbr <= 0 || nbr > TC_MAXBR)
+    return DSGCN_EINVAL;
+  if ((size_t)n * Cin * T * V1 * 4 >= (size_t)TC_OOB) return DSGCN_EUNSUPPORTED;
   TArgs a = {};
-  a.h = h; a.o = o; a.n = n; a.C = C; a.T = T; a.V1 = V1; a.stride = stride; a.nbr = nbr;
+  a.h = h; a.o = o; a.n = n; a.Cin = Cin; a.Cout = Cout; a.T = T; a.V1 = V1; a.stride = stride; a.nbr = nbr;
   a.Tout = (T + stride - 1) / stride;
-  int bcmax = 1;
+  const int cp = tc_fill(a, nbr, type, ci0, co0, cin, cout, dil);
+  if (cp < 0) return cp;
   for (int i = 0; i < nbr; ++i) {
-    a.br[i].type = type[i]; a.br[i].c0 = c0[i]; a.br[i].bc = bc[i]; a.br[i].dil = dil[i];
     a.br[i].w = w ? w[i] : nullptr; a.br[i].b = b ? b[i] : nullptr;
-    if (type[i] == 0) { if (bc[i] > 64) return DSGCN_EUNSUPPORTED; if (bc[i] > bcmax) bcmax = bc[i]; }
+    if (type[i] == 0 && !a.br[i].w) return DSGCN_EINVAL;
   }
-  const size_t lds = tc_lds_conv(bcmax, KT);
-  dim3 grid((unsigned)((a.Tout * V1 + 127) / 128), (unsigned)n, (unsigned)nbr);
-  hipLaunchKernelGGL(k_tapconv_fwd<3>, grid, dim3(TC_NT), lds, (hipStream_t)stream, a);
+  const size_t lds = tc_lds_conv(cp, KT);
+  dim3 grid((unsigned)((a.Tout * V1 + 127) / 128), (unsigned)n, (unsigned)(nbr * a.dch));
+  TC_DISPATCH_KT(KT, {
+    static size_t have = 64 * 1024;
+    const int rc = tc_raise_lds(k_tapconv_fwd<KTC>, lds, &have);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tapconv_fwd<KTC>, grid, dim3(TC_NT), lds, (hipStream_t)stream, a);
+  })
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
 
-int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int C, int T, int V1, int stride, int KT,
-                        int nbr, const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
-                        void* stream) {
-  if (!h || !go || !dh || n <= 0 || nbr <= 0 || nbr > TC_MAXBR) return DSGCN_EINVAL;
-  if (KT != 3) return DSGCN_EUNSUPPORTED;
+int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int Cin, int Cout, int T, int V1, int stride,
+                        int KT, int nbr, const int* type, const int* ci0, const int* co0, const int* cin,
+                        const int* cout, const int* dil, const float* const* w, void* stream) {
+  if (!h || !go || !dh || n <= 0 || Cin <= 0 || Cout <= 0 || nbr <= 0 || nbr > TC_MAXBR) return DSGCN_EINVAL;
   TArgs a = {};
-  a.h = h; a.go = go; a.dh = dh; a.n = n; a.C = C; a.T = T; a.V1 = V1; a.stride = stride; a.nbr = nbr;
+  a.h = h; a.go = go; a.dh = dh; a.n = n; a.Cin = Cin; a.Cout = Cout; a.T = T; a.V1 = V1; a.stride = stride; a.nbr = nbr;
   a.Tout = (T + stride - 1) / stride;
-  int bcmax = 1;
+  if ((size_t)n * Cout * a.Tout * V1 * 4 >= (size_t)TC_OOB) return DSGCN_EUNSUPPORTED;
+  const int cp = tc_fill(a, nbr, type, ci0, co0, cin, cout, dil);
+  if (cp < 0) return cp;
   for (int i = 0; i < nbr; ++i) {
-    a.br[i].type = type[i]; a.br[i].c0 = c0[i]; a.br[i].bc = bc[i]; a.br[i].dil = dil[i];
     a.br[i].w = w ? w[i] : nullptr;
-    if (type[i] == 0) { if (bc[i] > 64) return DSGCN_EUNSUPPORTED; if (bc[i] > bcmax) bcmax = bc[i]; }
+    if (type[i] == 0 && !a.br[i].w) return DSGCN_EINVAL;
   }
-  const size_t lds = tc_lds_conv(bcmax, KT);
-  dim3 grid((unsigned)((T * V1 + 127) / 128), (unsigned)n, (unsigned)nbr);
-  hipLaunchKernelGGL(k_tapconv_dgrad<3>, grid, dim3(TC_NT), lds, (hipStream_t)stream, a);
+  const size_t lds = tc_lds_conv(cp, KT);
+  dim3 grid((unsigned)((T * V1 + 127) / 128), (unsigned)n, (unsigned)(nbr * a.dch));
+  TC_DISPATCH_KT(KT, {
+    static size_t have = 64 * 1024;
+    const int rc = tc_raise_lds(k_tapconv_dgrad<KTC>, lds, &have);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tapconv_dgrad<KTC>, grid, dim3(TC_NT), lds, (hipStream_t)stream, a);
+  })
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
 
-// Conv branch i writes split s of its weight / bias partials at dwp[i] + s*pstride / dbp[i] + s*pstride (all branches
-// may share one (splits, pstride) buffer -> one dsgcn_colsum); NULL entries for the other branch types.
-int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int C, int T, int V1, int stride, int KT, int nbr,
-                        const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp,
-                        float* const* dbp, int splits, int pstride, void* stream) {
-  if (!h || !go || n <= 0 || nbr <= 0 || nbr > TC_MAXBR || splits <= 0) return DSGCN_EINVAL;
-  if (KT != 3 || V1 > 26) return DSGCN_EUNSUPPORTED;
+// Conv window i writes split s of its weight / bias partials at dwp[i] + s*pstride / dbp[i] + s*pstride (all windows
+// may share one (splits, pstride) buffer -> one dsgcn_colsum); NULL entries for the other window types.
+int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int Cin, int Cout, int T, int V1, int stride, int KT,
+                        int nbr, const int* type, const int* ci0, const int* co0, const int* cin, const int* cout,
+                        const int* dil, float* const* dwp, float* const* dbp, int splits, int pstride, void* stream) {
+  if (!h || !go || n <= 0 || Cin <= 0 || Cout <= 0 || nbr <= 0 || nbr > TC_MAXBR || splits <= 0) return DSGCN_EINVAL;
+  if (V1 > 26) return DSGCN_EUNSUPPORTED;
   TArgs a = {};
-  a.h = h; a.go = go; a.n = n; a.C = C; a.T = T; a.V1 = V1; a.stride = stride; a.nbr = nbr; a.splits = splits;
-  a.pstride = pstride;
+  a.h = h; a.go = go; a.n = n; a.Cin = Cin; a.Cout = Cout; a.T = T; a.V1 = V1; a.stride = stride; a.nbr = nbr;
+  a.splits = splits; a.pstride = pstride;
   a.Tout = (T + stride - 1) / stride;
+  const int cp = tc_fill(a, nbr, type, ci0, co0, cin, cout, dil);
+  if (cp < 0) return cp;
   for (int i = 0; i < nbr; ++i) {
-    a.br[i].type = type[i]; a.br[i].c0 = c0[i]; a.br[i].bc = bc[i]; a.br[i].dil = dil[i];
     a.br[i].dwp = dwp ? dwp[i] : nullptr; a.br[i].dbp = dbp ? dbp[i] : nullptr;
-    if (type[i] == 0 && (bc[i] > 64 || !a.br[i].dwp || !a.br[i].dbp)) return DSGCN_EUNSUPPORTED;
+    if (type[i] == 0 && (!a.br[i].dwp || !a.br[i].dbp)) return DSGCN_EINVAL;
   }
   const int KP = (2 * V1 + 1) & ~1, LS = KP | 1;
   const size_t lds = (size_t)(1 + KT) * 64 * LS * sizeof(float);
-  dim3 grid((unsigned)splits, (unsigned)nbr);
-  hipLaunchKernelGGL(k_tapconv_wgrad<3>, grid, dim3(TC_NT), lds, (hipStream_t)stream, a);
+  dim3 grid((unsigned)splits, (unsigned)(nbr * a.dch * a.dch));
+  TC_DISPATCH_KT(KT, {
+    static size_t have = 64 * 1024;
+    const int rc = tc_raise_lds(k_tapconv_wgrad<KTC>, lds, &have);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tapconv_wgrad<KTC>, grid, dim3(TC_NT), lds, (hipStream_t)stream, a);
+  })
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -6,9 +6,9 @@
 //                cat([x, x.mean(-1)]) (tcn.py:409) + the five BatchNorm2d+ReLU (tcn.py:389,394) in one pass.
 //   combine    : f[n,c,t,v] = o[n,c,t,v] + o[n,c,t,V]*add_coeff[v]  (tcn.py:416-420) + per-plane sum / sum of squares of f
 //                (the statistics of transform.0's BatchNorm, tcn.py:401) — replaces slice + einsum + add + the BN pass.
-// One wave per (n,c) plane, coalesced streaming; both are HBM-bound elementwise passes.
-// The four dilated 3x1 convolutions and the 3x1 max-pool between the two still run as PyTorch-ROCm (MIOpen) calls this
-// round (DESIGN.md §"interim").
+// One wave per (n,c) plane, coalesced streaming; both are HBM-bound elementwise passes.  The temporal convolutions and
+// the max-pool between the two are csrc/tapconv.hip.  With zaug == NULL branch_act has no global-joint column (h is
+// (n,C,T,V)): the form CTR-GCN's MSTCN uses (msg3d_utils.py:84-117).
 #include "common.h"
 
 namespace {
@@ -21,9 +21,9 @@ __global__ __launch_bounds__(64) void k_branch_act_fwd(const float* __restrict__
   const int c = (int)(plane % C);
   const float s = scale[c], b = shift[c];
   const bool relu = c < n_act;
-  const int V1 = V + 1, Lo = T * V1;
+  const int V1 = zaug ? V + 1 : V, Lo = T * V1;
   const float* __restrict__ pz = z + (size_t)plane * T * V;
-  const float* __restrict__ pa = zaug + (size_t)plane * T;
+  const float* __restrict__ pa = zaug ? zaug + (size_t)plane * T : nullptr;
   float* __restrict__ ph = h + (size_t)plane * Lo;
 #pragma unroll 4
   for (int o = lane; o < Lo; o += 64) {
@@ -46,12 +46,12 @@ __global__ __launch_bounds__(64) void k_branch_act_bwd(const float* __restrict__
   const int c = (int)(plane % C);
   const float s = scale[c], b = shift[c];
   const bool relu = c < n_act;
-  const int V1 = V + 1, Lo = T * V1;
+  const int V1 = zaug ? V + 1 : V, Lo = T * V1;
   const float* __restrict__ pz = z + (size_t)plane * T * V;
-  const float* __restrict__ pa = zaug + (size_t)plane * T;
+  const float* __restrict__ pa = zaug ? zaug + (size_t)plane * T : nullptr;
   const float* __restrict__ pg = dh + (size_t)plane * Lo;
   float* __restrict__ oz = dz + (size_t)plane * T * V;
-  float* __restrict__ oa = dzaug + (size_t)plane * T;
+  float* __restrict__ oa = zaug ? dzaug + (size_t)plane * T : nullptr;
   float u0 = 0.f, u1 = 0.f;
 #pragma unroll 4
   for (int o = lane; o < Lo; o += 64) {
@@ -147,7 +147,7 @@ extern "C" {
 
 int dsgcn_branch_act_fwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
                          float* h, int n, int C, int T, int V, void* stream) {
-  if (!z || !zaug || !scale || !shift || !h || n <= 0 || C <= 0 || T <= 0 || V <= 0) return DSGCN_EINVAL;
+  if (!z || !scale || !shift || !h || n <= 0 || C <= 0 || T <= 0 || V <= 0) return DSGCN_EINVAL;
   hipLaunchKernelGGL(k_branch_act_fwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, z, zaug, scale,
                      shift, n_act, h, C, T, V);
   DSGCN_LAUNCH_CHECK();
@@ -157,7 +157,7 @@ int dsgcn_branch_act_fwd(const float* z, const float* zaug, const float* scale, 
 int dsgcn_branch_act_bwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
                          const float* dh, float* dz, float* dzaug, float* part, int n, int C, int T, int V,
                          void* stream) {
-  if (!z || !zaug || !scale || !shift || !dh || !dz || !dzaug || !part) return DSGCN_EINVAL;
+  if (!z || !scale || !shift || !dh || !dz || (zaug && !dzaug) || !part) return DSGCN_EINVAL;
   hipLaunchKernelGGL(k_branch_act_bwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, z, zaug, scale,
                      shift, n_act, dh, dz, dzaug, part, C, T, V);
   DSGCN_LAUNCH_CHECK();

@@ -80,14 +80,14 @@ def eval_affine(bn):
     return scale, bn.bias - bn.running_mean * scale
 
 
-def bn_affine(bn, mean, var, count):
-    """(scale, shift) of a BatchNorm layer from batch statistics an op returned (train) or from the running
-    statistics (eval).  Used for the ops whose BN is not fused into the producing kernel yet."""
+def op_bn(bn, op, count):
+    """Run ``op(gamma, beta, eps, want_bn) -> (out, scale, shift, mean, var)`` with BatchNorm ``bn`` fused as a deferred
+    affine: batch statistics in training (running stats recorded), running statistics in eval.  -> (out, (scale, shift))"""
     if _need_stats(bn):
-        scale, shift = kernels.ops().bn_affine(mean, var, bn.weight, bn.bias, bn.eps)
-        record_running(bn, mean, var, count)
-        return scale, shift
-    return eval_affine(bn)
+        out, sc, sh, mean, var = op(bn.weight, bn.bias, bn.eps, True)
+        record_running(bn, mean, var, count(out))
+        return out, (sc, sh)
+    return op(None, None, bn.eps, False)[0], eval_affine(bn)
 
 
 def conv_bn(x1, a1, x2, a2, relu, conv, stride, aug, bn):
@@ -241,11 +241,9 @@ class unit_gcn(nn.Module):
 
     def forward_deferred(self, x):
         ops = kernels.ops()
-        n, c, t, v = x.shape
-        count = n * t * v
         h = ops.pwconv(x, None, None, None, False, self.conv.weight, self.conv.bias, 1, False)[0]
-        y, m, var = ops.aggregate_shared(h, self.A, self.num_subsets, _need_stats(self.bn))
-        ay = bn_affine(self.bn, m, var, count)
+        y, ay = op_bn(self.bn, lambda g, b, eps, want: ops.aggregate_sum(h, self.A, self.num_subsets, g, b, eps, want),
+                      lambda y: y.shape[0] * y.shape[2] * y.shape[3])
         if not self.with_res:
             return Deferred(y, ay, None, None, True)
         if self.down is None:
@@ -260,3 +258,85 @@ class unit_gcn(nn.Module):
 
     def init_weights(self):
         pass
+
+
+def _kaiming_conv_init(module):
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out')
+            nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+class CTRGC(nn.Module):
+    """Channel-wise topology refinement conv of one subset (reference: gcn.py:634-666).  Owns the parameters; the
+    arithmetic of the K subsets runs batched in ``unit_ctrgcn.forward_deferred``."""
+
+    def __init__(self, in_channels, out_channels, rel_reduction=8):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.rel_channels = 8 if in_channels <= 16 else in_channels // rel_reduction
+        self.conv1 = nn.Conv2d(in_channels, self.rel_channels, kernel_size=1)
+        self.conv2 = nn.Conv2d(in_channels, self.rel_channels, kernel_size=1)
+        self.conv3 = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+        self.conv4 = nn.Conv2d(self.rel_channels, out_channels, kernel_size=1)
+        self.tanh = nn.Tanh()
+        self.init_weights()
+
+    def init_weights(self):
+        _kaiming_conv_init(self)
+
+
+class unit_ctrgcn(nn.Module):
+    """CTR-GCN spatial unit (reference: gcn.py:882-929): per subset k a refined topology
+    ``Ahat_k = alpha*conv4_k(tanh(conv1_k(x).mean(T)[u] - conv2_k(x).mean(T)[v])) + A[k]`` per sample and output
+    channel, ``y = sum_k aggregate(conv3_k(x), Ahat_k)``, BN, + down(x), ReLU.  HIP chain: the six mean-pooled
+    projections are one K-C launch on the time mean (the mean commutes with the 1x1 conv), conv3 of the three subsets
+    is one K-C launch, the sum over subsets happens inside the aggregate's accumulators (K-A')."""
+
+    def __init__(self, in_channels, out_channels, A):
+        super().__init__()
+        self.inter_c = out_channels // 4
+        self.out_c = out_channels
+        self.in_c = in_channels
+        self.num_subset = A.shape[0]
+        self.convs = nn.ModuleList([CTRGC(in_channels, out_channels) for _ in range(self.num_subset)])
+        if in_channels != out_channels:
+            self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels))
+        else:
+            self.down = None
+        self.A = nn.Parameter(A.clone())
+        self.alpha = nn.Parameter(torch.zeros(1))
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.soft = nn.Softmax(-2)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward_deferred(self, x, xbar=None):
+        ops = kernels.ops()
+        if xbar is None:
+            xbar = ops.tmean(x)
+        cs = self.convs
+        ahat = ops.ctr_topology(
+            xbar, torch.cat([c.conv1.weight.flatten(1) for c in cs], 0), torch.cat([c.conv1.bias for c in cs], 0),
+            torch.cat([c.conv2.weight.flatten(1) for c in cs], 0), torch.cat([c.conv2.bias for c in cs], 0),
+            [c.conv4.weight.flatten(1) for c in cs], [c.conv4.bias for c in cs], self.alpha, self.A)
+        w3 = torch.cat([c.conv3.weight.flatten(1) for c in cs], 0)
+        b3 = torch.cat([c.conv3.bias for c in cs], 0)
+        x3 = ops.pwconv(x, None, None, None, False, w3, b3, 1, False)[0]
+        y, ay = op_bn(self.bn, lambda g, b, eps, want: ops.aggregate_sum(x3, ahat, self.num_subset, g, b, eps, want),
+                      lambda y: y.shape[0] * y.shape[2] * y.shape[3])
+        if self.down is None:
+            return Deferred(y, ay, x, None, True)
+        zd, _, ad = conv_bn(x, None, None, None, False, self.down[0], 1, False, self.down[1])
+        return Deferred(y, ay, zd, ad, True)
+
+    def forward(self, x):
+        return self.forward_deferred(x).materialize()
+
+    def init_weights(self):
+        _kaiming_conv_init(self)
+        nn.init.constant_(self.bn.weight, 1e-6)
+        nn.init.constant_(self.bn.bias, 0)

@@ -32,7 +32,6 @@ def use_ops(namespace):
 NAME = 'hip'
 
 import torch
-import torch.nn.functional as F
 
 from . import native
 
@@ -312,40 +311,26 @@ def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, gamma=None, 
 
 
 # ---------------------------------------------------------------------------------------------
-# INTERIM: ops below still run as PyTorch-ROCm device ops (MIOpen/ATen on the GPU) until their HIP
-# kernels (K-C pwconv, K-D temporal_ms, fuse_out) land; they are CUDA-only like everything else here.
+# K-D  temporal units
 # ---------------------------------------------------------------------------------------------
 
-def _bc(p):
-    return p[None, :, None, None]
-
-
-def _virt(x1, a1, x2, a2, relu):
-    v = x1 if a1 is None else x1 * _bc(a1[0]) + _bc(a1[1])
-    if x2 is not None:
-        v = v + (x2 if a2 is None else x2 * _bc(a2[0]) + _bc(a2[1]))
-    return F.relu(v) if relu else v
-
-
-def bn_affine(mean, var, weight, bias, eps):
-    scale = weight * torch.rsqrt(var + eps)
-    return scale, bias - mean * scale
-
-
 def tmean(x):
+    """Mean over frames of the network input (n,C,T,V) -> (n,C,V): the x.mean(-2) of the first block's adjacency
+    (gcn.py:2246 / gcn.py:651); later blocks get it from the previous block's fuse_out."""
     _require_cuda(x)
-    return x.mean(2)
+    return fuse_out(x, None, None, None, 0, True)[1]
 
 
 class _BranchAct(torch.autograd.Function):
-    """h (n,C,T,V+1) = act(z*scale+shift) with the global-joint column appended (ReLU on channels < n_act)."""
+    """h (n,C,T,V+1) = act(z*scale+shift) with the global-joint column appended (ReLU on channels < n_act);
+    zaug=None: no extra column, h (n,C,T,V)."""
 
     @staticmethod
     def forward(ctx, z, zaug, scale, shift, n_act):
         _require_cuda(z)
         z, zaug, scale, shift = [_f32c(t) for t in (z, zaug, scale, shift)]
         n, C, T, V = z.shape
-        h = torch.empty((n, C, T, V + 1), device=z.device, dtype=torch.float32)
+        h = torch.empty((n, C, T, V + (1 if zaug is not None else 0)), device=z.device, dtype=torch.float32)
         rc = native.lib().dsgcn_branch_act_fwd(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), int(n_act), _ptr(h), n, C,
                                                T, V, _stream())
         native.check(rc, 'dsgcn_branch_act_fwd')
@@ -359,7 +344,7 @@ class _BranchAct(torch.autograd.Function):
         n, C, T, V = z.shape
         dh = _f32c(dh)
         dz = torch.empty_like(z)
-        dzaug = torch.empty_like(zaug)
+        dzaug = torch.empty_like(zaug) if zaug is not None else None
         part = torch.empty((n, C, 2), device=z.device, dtype=torch.float32)
         rc = native.lib().dsgcn_branch_act_bwd(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), ctx.n_act, _ptr(dh),
                                                _ptr(dz), _ptr(dzaug), _ptr(part), n, C, T, V, _stream())
@@ -433,47 +418,50 @@ def _ptr_array(tensors):
 
 
 class _TapBranches(torch.autograd.Function):
-    """The temporal branches of dgmstcn on the activated tensor h (n,C,T,V+1) -> o (n,C,T',V+1):
-    dilated (3,1) convs on the matrix core, (3,1) max-pool, strided copy — one HIP launch per direction."""
+    """Temporal windows over h (n,Cin,T,V1) -> o (n,Cout,T',V1): (KT,1) convs on the matrix core, (3,1) max-pool,
+    strided copy — one HIP launch per direction.  Window i reads channels [ci0,ci0+cin) and writes [co0,co0+cout)."""
 
     @staticmethod
-    def forward(ctx, h, stride, types, c0s, bcs, dils, *wb):
+    def forward(ctx, h, stride, KT, Cout, types, ci0s, co0s, cins, couts, dils, *wb):
         _require_cuda(h)
         h = _f32c(h)
-        n, C, T, V1 = h.shape
+        n, Cin, T, V1 = h.shape
         nbr = len(types)
         ws = [_f32c(t) for t in wb[:nbr]]
         bs = [_f32c(t) for t in wb[nbr:]]
         Tout = (T + stride - 1) // stride
-        o = torch.empty((n, C, Tout, V1), device=h.device, dtype=torch.float32)
-        rc = native.lib().dsgcn_tapconv_fwd(_ptr(h), _ptr(o), n, C, T, V1, stride, 3, nbr, _int_array(types),
-                                            _int_array(c0s), _int_array(bcs), _int_array(dils), _ptr_array(ws),
-                                            _ptr_array(bs), _stream())
+        o = torch.empty((n, Cout, Tout, V1), device=h.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_tapconv_fwd(_ptr(h), _ptr(o), n, Cin, Cout, T, V1, stride, KT, nbr, _int_array(types),
+                                            _int_array(ci0s), _int_array(co0s), _int_array(cins), _int_array(couts),
+                                            _int_array(dils), _ptr_array(ws), _ptr_array(bs), _stream())
         native.check(rc, 'dsgcn_tapconv_fwd')
         ctx.save_for_backward(h, *[w for w in ws if w is not None])
-        ctx.cfg = (stride, tuple(types), tuple(c0s), tuple(bcs), tuple(dils))
+        ctx.cfg = (stride, KT, Cout, tuple(types), tuple(ci0s), tuple(co0s), tuple(cins), tuple(couts), tuple(dils),
+                   tuple(b is not None for b in bs))
         return o
 
     @staticmethod
     def backward(ctx, go):
         h, *wsaved = ctx.saved_tensors
-        stride, types, c0s, bcs, dils = ctx.cfg
-        n, C, T, V1 = h.shape
+        stride, KT, Cout, types, ci0s, co0s, cins, couts, dils, has_b = ctx.cfg
+        n, Cin, T, V1 = h.shape
         nbr = len(types)
         go = _f32c(go)
         lib = native.lib()
         it = iter(wsaved)
         ws = [next(it) if t == 0 else None for t in types]
+        tabs = (_int_array(types), _int_array(ci0s), _int_array(co0s), _int_array(cins), _int_array(couts),
+                _int_array(dils))
         dh = torch.empty_like(h)
-        rc = lib.dsgcn_tapconv_dgrad(_ptr(h), _ptr(go), _ptr(dh), n, C, T, V1, stride, 3, nbr, _int_array(types),
-                                     _int_array(c0s), _int_array(bcs), _int_array(dils), _ptr_array(ws), _stream())
+        rc = lib.dsgcn_tapconv_dgrad(_ptr(h), _ptr(go), _ptr(dh), n, Cin, Cout, T, V1, stride, KT, nbr, *tabs,
+                                     _ptr_array(ws), _stream())
         native.check(rc, 'dsgcn_tapconv_dgrad')
         Tout = go.shape[2]
         offs, off = [], 0
-        for t, bc in zip(types, bcs):
+        for t, ci, co in zip(types, cins, couts):
             offs.append(off)
             if t == 0:
-                off += bc * bc * 3 + bc
+                off += co * ci * KT + co
         pstride = max(off, 1)
         # k-splits: enough blocks to fill the chip, but keep the partial buffer (splits x pstride floats) around 8 MB
         splits = max(16, min(256, (1 << 21) // pstride))
@@ -481,27 +469,24 @@ class _TapBranches(torch.autograd.Function):
         part = torch.empty((splits, pstride), device=h.device, dtype=torch.float32)
         base = part.data_ptr()
         dwp = (_ct.c_void_p * nbr)(*[base + 4 * o if t == 0 else None for t, o in zip(types, offs)])
-        dbp = (_ct.c_void_p * nbr)(*[base + 4 * (o + bc * bc * 3) if t == 0 else None
-                                     for t, o, bc in zip(types, offs, bcs)])
-        rc = lib.dsgcn_tapconv_wgrad(_ptr(h), _ptr(go), n, C, T, V1, stride, 3, nbr, _int_array(types),
-                                     _int_array(c0s), _int_array(bcs), _int_array(dils), dwp, dbp, splits, pstride,
-                                     _stream())
+        dbp = (_ct.c_void_p * nbr)(*[base + 4 * (o + co * ci * KT) if t == 0 else None
+                                     for t, o, ci, co in zip(types, offs, cins, couts)])
+        rc = lib.dsgcn_tapconv_wgrad(_ptr(h), _ptr(go), n, Cin, Cout, T, V1, stride, KT, nbr, *tabs, dwp, dbp, splits,
+                                     pstride, _stream())
         native.check(rc, 'dsgcn_tapconv_wgrad')
         red = colsum(part)
-        dws = [red[o:o + bc * bc * 3].view(bc, bc, 3, 1) if t == 0 else None for t, o, bc in zip(types, offs, bcs)]
-        dbs = [red[o + bc * bc * 3:o + bc * bc * 3 + bc] if t == 0 else None for t, o, bc in zip(types, offs, bcs)]
-        return (dh, None, None, None, None, None, *dws, *dbs)
+        dws = [red[o:o + co * ci * KT].view(co, ci, KT, 1) if t == 0 else None
+               for t, o, ci, co in zip(types, offs, cins, couts)]
+        dbs = [red[o + co * ci * KT:o + co * ci * KT + co] if (t == 0 and hb) else None
+               for t, o, ci, co, hb in zip(types, offs, cins, couts, has_b)]
+        return (dh, None, None, None, None, None, None, None, None, None, *dws, *dbs)
 
 
-def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, add_coeff, stride, gamma=None,
-                beta=None, eps=1e-5, want_bn=False):
-    """-> (f, scale, shift, mean, var): branch_act -> temporal branches (dilated convs / max-pool / copy) -> combine
-    (+ statistics of transform.0's BatchNorm); three HIP stages, no torch.cat, no MIOpen."""
-    _require_cuda(z)
-    n, C, T, V = z.shape
-    h = _BranchAct.apply(z, zaug, scale, shift, n_act)
+def _branch_tables(branch_cfg, widths, conv_w, conv_b):
+    """ms_cfg-style branch list -> window tables of _TapBranches (input and output windows coincide)."""
     types, c0s, bcs, dils, ws, bs = [], [], [], [], [], []
     c0 = ci = 0
+    KT = None
     for cfg, bc in zip(branch_cfg, widths):
         if cfg == '1x1':
             types.append(2); dils.append(1); ws.append(None); bs.append(None)
@@ -511,36 +496,254 @@ def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b
             types.append(1); dils.append(1); ws.append(None); bs.append(None)
         else:
             k, d = cfg
-            if k != 3 or bc > 64:
-                raise NotImplementedError('temporal conv branch: HIP path covers kernel 3 and <= 64 channels per branch')
+            if k not in (3, 5, 9) or (KT is not None and k != KT):
+                raise NotImplementedError('temporal conv branches: HIP path covers one kernel size of 3, 5 or 9 per unit')
+            KT = k
             types.append(0); dils.append(int(d)); ws.append(conv_w[ci]); bs.append(conv_b[ci])
             ci += 1
         c0s.append(c0); bcs.append(int(bc))
         c0 += bc
-    o = _TapBranches.apply(h, int(stride), types, c0s, bcs, dils, *ws, *bs)
+    return KT or 3, types, c0s, bcs, dils, ws, bs
+
+
+def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, add_coeff, stride, gamma=None,
+                beta=None, eps=1e-5, want_bn=False):
+    """-> (f, scale, shift, mean, var): branch_act -> temporal branches (dilated convs / max-pool / copy) -> combine
+    (+ statistics of transform.0's BatchNorm); three HIP stages, no torch.cat, no MIOpen."""
+    _require_cuda(z)
+    n, C, T, V = z.shape
+    h = _BranchAct.apply(z, zaug, scale, shift, n_act)
+    KT, types, c0s, bcs, dils, ws, bs = _branch_tables(branch_cfg, widths, conv_w, conv_b)
+    o = _TapBranches.apply(h, int(stride), KT, C, types, c0s, c0s, bcs, bcs, dils, *ws, *bs)
     return _TmsCombine.apply(o, add_coeff[:V].contiguous(), gamma, beta, float(eps), bool(want_bn))
 
 
-def tconv(x1, a1, relu, weight, bias, stride, dilation, stats=True):
-    _require_cuda(x1)
-    v = _virt(x1, a1, None, None, relu)
-    k = weight.shape[2]
-    pad = (k + (k - 1) * (dilation - 1) - 1) // 2
-    z = F.conv2d(v, weight, bias, stride=(stride, 1), padding=(pad, 0), dilation=(dilation, 1))
-    mean = var = None
-    if stats:
-        var, mean = torch.var_mean(z, (0, 2, 3), unbiased=False)
-    return z, mean, var
+class _PlaneStats(torch.autograd.Function):
+    """Train-mode BatchNorm of an already materialised tensor as a deferred affine: (scale, shift, mean, var) from the
+    per-plane sums of o.  Backward adds the statistics terms A0[c] + B0[c]*o to the gradient of o."""
+
+    @staticmethod
+    def forward(ctx, o, gamma, beta, eps):
+        _require_cuda(o)
+        o, gamma, beta = _f32c(o), _f32c(gamma), _f32c(beta)
+        n, C, T, V = o.shape
+        dev = o.device
+        lib = native.lib()
+        partial = torch.empty((n, C, 2), device=dev, dtype=torch.float32)
+        native.check(lib.dsgcn_plane_stats(_ptr(o), _ptr(partial), n * C, T * V, _stream()), 'dsgcn_plane_stats')
+        stats = torch.empty((4, C), device=dev, dtype=torch.float32)
+        mean, var, scale, shift = stats[0], stats[1], stats[2], stats[3]
+        count = float(n * T * V)
+        rc = lib.dsgcn_bn_finalize(_ptr(partial), n, C, count, _ptr(gamma), _ptr(beta), float(eps), _ptr(mean),
+                                   _ptr(var), _ptr(scale), _ptr(shift), C, _stream())
+        native.check(rc, 'dsgcn_bn_finalize')
+        ctx.mark_non_differentiable(mean, var)
+        ctx.save_for_backward(o, gamma, mean, var)
+        ctx.cfg = (float(eps), count, beta is not None)
+        return scale, shift, mean, var
+
+    @staticmethod
+    def backward(ctx, gscale, gshift, _gm, _gv):
+        o, gamma, mean, var = ctx.saved_tensors
+        eps, count, has_beta = ctx.cfg
+        n, C, T, V = o.shape
+        lib = native.lib()
+        gscale, gshift = _f32c(gscale), _f32c(gshift)
+        if gscale is None and gshift is None:
+            return None, None, None, None
+        coef = torch.empty((4, C), device=o.device, dtype=torch.float32)
+        dgamma, dbeta, A0, B0 = coef[0], coef[1], coef[2], coef[3]
+        rc = lib.dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, C, C,
+                                   _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), _stream())
+        native.check(rc, 'dsgcn_bn_bwd_coef')
+        do = torch.empty_like(o)
+        rc = lib.dsgcn_fuse_out_fwd(_ptr(o), _ptr(B0), _ptr(A0), None, None, None, 0, _ptr(do), None, n, C, T, V,
+                                    _stream())
+        native.check(rc, 'dsgcn_fuse_out_fwd')
+        return do, (dgamma if gamma is not None else None), (dbeta if has_beta else None), None
 
 
-def aggregate_shared(zp, A, K, stats=True):
-    _require_cuda(zp)
-    n, KC, T, V = zp.shape
-    y = torch.einsum('nkctv,kvw->nctw', zp.view(n, K, KC // K, T, V), A)
-    mean = var = None
-    if stats:
-        var, mean = torch.var_mean(y, (0, 2, 3), unbiased=False)
-    return y, mean, var
+def _plane_bn(o, gamma, beta, eps, want_bn):
+    if not want_bn:
+        return o, None, None, None, None
+    return (o, *_PlaneStats.apply(o, gamma, beta, float(eps)))
+
+
+def temporal_branches_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, stride, gamma=None, beta=None,
+                         eps=1e-5, want_bn=False):
+    """MSTCN's temporal stage (msg3d_utils.py:84-117) after the fused branch 1x1 conv: BN+ReLU on channels < n_act,
+    (k,1) dilated convs / (3,1) max-pool / strided copy per branch -> o (n,C,T',V) raw, plus the train-mode BN of o
+    (the per-branch BatchNorms that close every branch, concatenated) as a deferred affine.
+    -> (o, scale, shift, mean, var)"""
+    _require_cuda(z)
+    n, C, T, V = z.shape
+    h = _BranchAct.apply(z, None, scale, shift, n_act)
+    KT, types, c0s, bcs, dils, ws, bs = _branch_tables(branch_cfg, widths, conv_w, conv_b)
+    o = _TapBranches.apply(h, int(stride), KT, C, types, c0s, c0s, bcs, bcs, dils, *ws, *bs)
+    return _plane_bn(o, gamma, beta, eps, want_bn)
+
+
+def tconv(h, weight, bias, stride, dilation, gamma=None, beta=None, eps=1e-5, want_bn=False):
+    """Dense (k,1) temporal conv of a materialised tensor (unit_tcn, tcn.py:21-27) + the train-mode BN of its output
+    as a deferred affine.  -> (z, scale, shift, mean, var)"""
+    _require_cuda(h)
+    Co, Ci, KT, _ = weight.shape
+    if KT not in (3, 5, 9):
+        raise NotImplementedError('dense temporal conv: HIP path covers kernel sizes 3, 5 and 9')
+    z = _TapBranches.apply(h, int(stride), KT, Co, [0], [0], [0], [Ci], [Co], [int(dilation)], weight, bias)
+    return _plane_bn(z, gamma, beta, eps, want_bn)
+
+
+# ---------------------------------------------------------------------------------------------
+# K-A'  subset-summed aggregate (ST-GCN shared A / CTR-GCN per-channel topology)
+# ---------------------------------------------------------------------------------------------
+
+class _AggSum(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, p, adj, K, gamma, beta, eps, want_bn):
+        _require_cuda(p, adj)
+        p, adj, gamma, beta = _f32c(p), _f32c(adj), _f32c(gamma), _f32c(beta)
+        n, KC, T, V = p.shape
+        Co = KC // K
+        shared = adj.dim() == 3
+        assert adj.shape == ((K, V, V) if shared else (n, KC, V, V)), (adj.shape, p.shape)
+        astr = (0, V * V, 0) if shared else (KC * V * V, Co * V * V, V * V)
+        dev = p.device
+        lib = native.lib()
+        y = torch.empty((n, Co, T, V), device=dev, dtype=torch.float32)
+        partial = torch.empty((n, Co, 2), device=dev, dtype=torch.float32) if want_bn else None
+        rc = lib.dsgcn_aggsum_fwd(_ptr(p), _ptr(adj), *astr, _ptr(y), _ptr(partial), n, K, Co, T, V, _stream())
+        native.check(rc, 'dsgcn_aggsum_fwd')
+        scale = shift = mean = var = None
+        count = float(n * T * V)
+        if want_bn:
+            stats = torch.empty((4, Co), device=dev, dtype=torch.float32)
+            mean, var, scale, shift = stats[0], stats[1], stats[2], stats[3]
+            rc = lib.dsgcn_bn_finalize(_ptr(partial), n, Co, count, _ptr(gamma), _ptr(beta), float(eps), _ptr(mean),
+                                       _ptr(var), _ptr(scale), _ptr(shift), Co, _stream())
+            native.check(rc, 'dsgcn_bn_finalize')
+            ctx.mark_non_differentiable(mean, var)
+        ctx.save_for_backward(p, adj, y, gamma, mean, var)
+        ctx.cfg = (K, float(eps), bool(want_bn), count, beta is not None, shared, astr)
+        return y, scale, shift, mean, var
+
+    @staticmethod
+    def backward(ctx, gy, gscale, gshift, _gm, _gv):
+        p, adj, y, gamma, mean, var = ctx.saved_tensors
+        K, eps, want_bn, count, has_beta, shared, astr = ctx.cfg
+        n, KC, T, V = p.shape
+        Co = KC // K
+        dev = p.device
+        lib = native.lib()
+        gy, gscale, gshift = _f32c(gy), _f32c(gscale), _f32c(gshift)
+        A0 = B0 = dgamma = dbeta = None
+        if want_bn and (gscale is not None or gshift is not None):
+            coef = torch.empty((4, Co), device=dev, dtype=torch.float32)
+            dgamma, dbeta, A0, B0 = coef[0], coef[1], coef[2], coef[3]
+            rc = lib.dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, Co,
+                                       Co, _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), _stream())
+            native.check(rc, 'dsgcn_bn_bwd_coef')
+        if gy is None:
+            gy = torch.zeros_like(y)
+        dp = torch.empty_like(p)
+        if shared:
+            dpiece = torch.empty((n * Co, K, V, V), device=dev, dtype=torch.float32)   # per-(n,c) pieces of dA
+            dstr = (Co * K * V * V, V * V, K * V * V)
+        else:
+            dpiece = torch.empty_like(adj)
+            dstr = astr
+        rc = lib.dsgcn_aggsum_bwd(_ptr(p), _ptr(adj), *astr, _ptr(gy), _ptr(y), _ptr(A0), _ptr(B0), _ptr(dp),
+                                  _ptr(dpiece), *dstr, n, K, Co, T, V, _stream())
+        native.check(rc, 'dsgcn_aggsum_bwd')
+        dadj = colsum(dpiece) if shared else dpiece
+        if dgamma is not None:
+            dgamma = dgamma if gamma is not None else None
+            dbeta = dbeta if has_beta else None
+        return dp, dadj, None, dgamma, dbeta, None, None
+
+
+def aggregate_sum(p, adj, K, gamma=None, beta=None, eps=1e-5, want_bn=False):
+    """y[n,c,t,w] = sum_k sum_u p[n,k*Co+c,t,u] * adj_k[u,w]; adj (K,V,V) shared (ST-GCN unit_gcn) or (n,K*Co,V,V)
+    per sample and channel (CTR-GCN), plus the train-mode BN of y as a deferred affine.
+    -> (y, scale, shift, mean, var)"""
+    return _AggSum.apply(p, adj, int(K), gamma, beta, float(eps), bool(want_bn))
+
+
+# ---------------------------------------------------------------------------------------------
+# CTR-GCN channel-wise topology (gcn.py:634-666)
+# ---------------------------------------------------------------------------------------------
+
+class _TanhDiff(torch.autograd.Function):
+    """proj (n, 2*K*R, V) -> d (K, n, R, V, V) = tanh(x1[..., u] - x2[..., v])."""
+
+    @staticmethod
+    def forward(ctx, proj, K, R):
+        _require_cuda(proj)
+        proj = _f32c(proj)
+        n, _, V = proj.shape
+        d = torch.empty((K, n, R, V, V), device=proj.device, dtype=torch.float32)
+        native.check(native.lib().dsgcn_tanhdiff_fwd(_ptr(proj), _ptr(d), n, K, R, V, _stream()), 'dsgcn_tanhdiff_fwd')
+        ctx.save_for_backward(d)
+        ctx.dims = (n, K, R, V)
+        return d
+
+    @staticmethod
+    def backward(ctx, dd):
+        d, = ctx.saved_tensors
+        n, K, R, V = ctx.dims
+        dd = _f32c(dd)
+        dproj = torch.empty((n, 2 * K * R, V), device=d.device, dtype=torch.float32)
+        native.check(native.lib().dsgcn_tanhdiff_bwd(_ptr(d), _ptr(dd), _ptr(dproj), n, K, R, V, _stream()),
+                     'dsgcn_tanhdiff_bwd')
+        return dproj, None, None
+
+
+class _CtrAffine(torch.autograd.Function):
+    """Ahat (n, K*Co, V, V) = alpha * S_k + A[k]  for the K per-subset conv4 outputs S_k (n, Co, V, V)."""
+
+    @staticmethod
+    def forward(ctx, alpha, A, *S):
+        _require_cuda(A, *S)
+        alpha, A = _f32c(alpha), _f32c(A)
+        S = [_f32c(t) for t in S]
+        K = len(S)
+        n, Co, V, _ = S[0].shape
+        ahat = torch.empty((n, K * Co, V, V), device=A.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_ctr_affine_fwd(_ptr_array(S), _ptr(alpha), _ptr(A), _ptr(ahat), n, K, Co, V, _stream())
+        native.check(rc, 'dsgcn_ctr_affine_fwd')
+        ctx.save_for_backward(alpha, *S)
+        return ahat
+
+    @staticmethod
+    def backward(ctx, dahat):
+        alpha, *S = ctx.saved_tensors
+        K = len(S)
+        n, Co, V, _ = S[0].shape
+        dahat = _f32c(dahat)
+        dS = [torch.empty_like(t) for t in S]
+        prow = torch.empty((n, K * V * V + K), device=dahat.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_ctr_affine_bwd(_ptr_array(S), _ptr(alpha), _ptr(dahat), _ptr_array(dS), _ptr(prow), n,
+                                               K, Co, V, _stream())
+        native.check(rc, 'dsgcn_ctr_affine_bwd')
+        red = colsum(prow)
+        dA = red[:K * V * V].view(K, V, V)
+        dalpha = colsum(red[K * V * V:].reshape(K, 1))
+        return (dalpha.view_as(alpha), dA, *dS)
+
+
+def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A):
+    """CTR-GCN refined topology.  xbar (n,Ci,V) = mean_T x; w1,w2 (K*R,Ci) / b1,b2 (K*R): conv1/conv2 of the K
+    subsets stacked (their mean over T commutes with the 1x1 conv); w4[k] (Co,R), b4[k] (Co); alpha (1); A (K,V,V).
+    -> Ahat (n, K*Co, V, V) = alpha * conv4_k(tanh(x1_k[u] - x2_k[v])) + A[k]."""
+    n, Ci, V = xbar.shape
+    K = A.shape[0]
+    R = w1.shape[0] // K
+    proj = pwconv(xbar.unsqueeze(2), None, None, None, False, torch.cat([w1, w2], 0), torch.cat([b1, b2], 0), 1,
+                  False)[0]
+    d = _TanhDiff.apply(proj.view(n, 2 * K * R, V), K, R)
+    S = [pwconv(d[k], None, None, None, False, w4[k], b4[k], 1, False)[0] for k in range(K)]
+    return _CtrAffine.apply(alpha, A, *S)
 
 
 class _FuseOut(torch.autograd.Function):
@@ -567,7 +770,7 @@ class _FuseOut(torch.autograd.Function):
         dx1 = torch.empty_like(x1)
         dx2 = torch.empty_like(x2) if x2 is not None else None
         need_part = s1 is not None or s2 is not None
-        part = torch.empty((n, C, 3), device=x1.device, dtype=torch.float32) if need_part else None
+        part = torch.empty((n, C, 4), device=x1.device, dtype=torch.float32) if need_part else None
         rc = native.lib().dsgcn_fuse_out_bwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
                                              _ptr(dout), _ptr(dxbar), _ptr(dx1), _ptr(dx2), _ptr(part), n, C, T, V,
                                              _stream())
@@ -576,13 +779,14 @@ class _FuseOut(torch.autograd.Function):
         if need_part:
             red = colsum(part)
             if s1 is not None:
-                ds1, dh1 = red[:, 0], red[:, 1]
+                ds1, dh1 = red[:, 0], red[:, 3]
             if s2 is not None:
                 ds2, dh2 = red[:, 2], red[:, 1]
         return dx1, ds1, dh1, dx2, ds2, dh2, None, None
 
 
 def fuse_out(x1, a1, x2, a2, relu, want_tmean=False):
+    """relu: bool, or int flags — bit 0 the outer ReLU, bit 1 a ReLU on the first term before the add."""
     s1, h1 = a1 if a1 is not None else (None, None)
     s2, h2 = a2 if a2 is not None else (None, None)
-    return _FuseOut.apply(x1, s1, h1, x2, s2, h2, bool(relu), bool(want_tmean))
+    return _FuseOut.apply(x1, s1, h1, x2, s2, h2, int(relu), bool(want_tmean))

@@ -49,9 +49,16 @@ SIGNATURES = {
     'dsgcn_branch_act_bwd': [c_f] * 4 + [c_int] + [c_f] * 4 + [c_int] * 4 + [c_st],
     'dsgcn_tms_combine_fwd': [c_f] * 4 + [c_int] * 4 + [c_st],
     'dsgcn_tms_combine_bwd': [c_f] * 7 + [c_int] * 4 + [c_st],
-    'dsgcn_tapconv_fwd': [c_f, c_f] + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_st],
-    'dsgcn_tapconv_dgrad': [c_f, c_f, c_f] + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, c_st],
-    'dsgcn_tapconv_wgrad': [c_f, c_f] + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_st],
+    'dsgcn_tapconv_fwd': [c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, ctypes.c_void_p, c_st],
+    'dsgcn_tapconv_dgrad': [c_f, c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, c_st],
+    'dsgcn_tapconv_wgrad': [c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_st],
+    'dsgcn_aggsum_fwd': [c_f, c_f] + [ctypes.c_long] * 3 + [c_f, c_f] + [c_int] * 5 + [c_st],
+    'dsgcn_aggsum_bwd': [c_f, c_f] + [ctypes.c_long] * 3 + [c_f] * 6 + [ctypes.c_long] * 3 + [c_int] * 5 + [c_st],
+    'dsgcn_tanhdiff_fwd': [c_f, c_f] + [c_int] * 4 + [c_st],
+    'dsgcn_tanhdiff_bwd': [c_f, c_f, c_f] + [c_int] * 4 + [c_st],
+    'dsgcn_ctr_affine_fwd': [ctypes.c_void_p, c_f, c_f, c_f] + [c_int] * 4 + [c_st],
+    'dsgcn_ctr_affine_bwd': [ctypes.c_void_p, c_f, c_f, ctypes.c_void_p, c_f] + [c_int] * 4 + [c_st],
+    'dsgcn_plane_stats': [c_f, c_f, ctypes.c_long, c_int, c_st],
     'dsgcn_fuse_out_fwd': [c_f] * 6 + [c_int] + [c_f] * 2 + [c_int] * 4 + [c_st],
     'dsgcn_fuse_out_bwd': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 4 + [c_st],
     'dsgcn_dynadj_fwd': [c_f] * 6 + [c_i, c_i, c_f] + [c_int] * 5 + [c_st],

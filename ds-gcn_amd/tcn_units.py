@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels
-from .gcn_units import (Deferred, as_deferred, bn_affine, conv_bn, eval_affine, record_running, _need_stats,
+from .gcn_units import (Deferred, as_deferred, conv_bn, eval_affine, op_bn, record_running, _need_stats,
                         _norm_layer)
 
 
@@ -35,20 +35,20 @@ class unit_tcn(nn.Module):
         ops = kernels.ops()
         d = as_deferred(x)
         has_bn = isinstance(self.bn, nn.BatchNorm2d)
-        stats = has_bn and _need_stats(self.bn)
         if self.kernel_size == 1:
             if has_bn:
                 z, _, az = conv_bn(d.x1, d.a1, d.x2, d.a2, d.relu, self.conv, self.stride, False, self.bn)
                 return Deferred(z, az, None, None, False)
             z = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, self.conv.weight, self.conv.bias, self.stride, False)[0]
             return Deferred(z, None, None, None, False)
-        if d.x2 is not None:
-            d = Deferred(d.materialize(), None, None, None, False)
-        z, m, var = ops.tconv(d.x1, d.a1, d.relu, self.conv.weight, self.conv.bias, self.stride, self.dilation, stats)
+        # the dense temporal conv reads a materialised tensor (zero padding applies to the activated values)
+        h = d.x1 if (d.a1 is None and d.x2 is None and not d.relu) else d.materialize()
+        w, b = self.conv.weight, self.conv.bias
         if not has_bn:
-            return Deferred(z, None, None, None, False)
-        count = z.shape[0] * z.shape[2] * z.shape[3]
-        return Deferred(z, bn_affine(self.bn, m, var, count), None, None, False)
+            return Deferred(ops.tconv(h, w, b, self.stride, self.dilation)[0], None, None, None, False)
+        z, az = op_bn(self.bn, lambda g, be, eps, want: ops.tconv(h, w, b, self.stride, self.dilation, g, be, eps, want),
+                      lambda z: z.shape[0] * z.shape[2] * z.shape[3])
+        return Deferred(z, az, None, None, False)
 
     def forward(self, x):
         out = self.forward_deferred(x).materialize()
@@ -169,3 +169,114 @@ class dgmstcn(nn.Module):
 
     def init_weights(self):
         pass
+
+
+class MSTCN(nn.Module):
+    """CTR-GCN's multi-scale temporal unit (reference: pyskl/models/gcns/utils/msg3d_utils.py:64-149): per dilation
+    [1x1 -> BN -> ReLU -> (k,1) dilated conv -> BN], [1x1 -> BN -> ReLU -> max-pool(3,1) -> BN], [1x1 stride -> BN];
+    cat; (+ residual); ReLU.  HIP chain: the branch 1x1 convs are ONE K-C launch (+ statistics), then branch_act ->
+    tapconv (convs / max-pool / strided copy) -> plane statistics; the closing BatchNorms ride to the consumer as a
+    deferred affine."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilations=[1, 2, 3, 4], residual=True,
+                 act_cfg=dict(type='ReLU'), tcn_dropout=0):
+        super().__init__()
+        typ = act_cfg['type'] if isinstance(act_cfg, dict) else act_cfg
+        if typ != 'ReLU':
+            raise NotImplementedError(f'activation {typ} is not fused by the HIP kernels (ReLU only)')
+        self.num_branches = len(dilations) + 2
+        bc = out_channels // self.num_branches
+        rem = out_channels - bc * (self.num_branches - 1)
+        if type(kernel_size) == list:
+            assert len(kernel_size) == len(dilations)
+        else:
+            kernel_size = [kernel_size] * len(dilations)
+        self.stride = stride
+        self.out_channels = out_channels
+        self.branch_cfg = [(int(k), int(d)) for k, d in zip(kernel_size, dilations)] + [('max', 3), '1x1']
+        self.widths = [bc] * (self.num_branches - 1) + [rem]
+        self.branches = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(in_channels, bc, kernel_size=1, padding=0), nn.BatchNorm2d(bc), nn.ReLU(),
+                          unit_tcn(bc, bc, kernel_size=ks, stride=stride, dilation=dilation))
+            for ks, dilation in zip(kernel_size, dilations)])
+        self.branches.append(nn.Sequential(
+            nn.Conv2d(in_channels, bc, kernel_size=1, padding=0), nn.BatchNorm2d(bc), nn.ReLU(),
+            nn.MaxPool2d(kernel_size=(3, 1), stride=(stride, 1), padding=(1, 0)), nn.BatchNorm2d(bc)))
+        self.branches.append(nn.Sequential(
+            nn.Conv2d(in_channels, rem, kernel_size=1, padding=0, stride=(stride, 1)), nn.BatchNorm2d(rem)))
+        if not residual:
+            self.residual = None
+            self.residual_kind = 'none'
+        elif in_channels == out_channels and stride == 1:
+            self.residual = None
+            self.residual_kind = 'identity'
+        else:
+            self.residual = unit_tcn(in_channels, out_channels, kernel_size=1, stride=stride)
+            self.residual_kind = 'conv'
+        self.act = nn.ReLU()
+        self.drop = nn.Dropout(tcn_dropout)
+
+    def _branches_deferred(self, g):
+        """cat of the branch outputs before the closing BatchNorms: -> (o raw, (scale, shift))."""
+        ops = kernels.ops()
+        d = as_deferred(g)
+        n, _, T, V = d.x1.shape
+        convs = [b[0] for b in self.branches]
+        wb = torch.cat([c.weight.flatten(1) for c in convs], 0)
+        bb = torch.cat([c.bias for c in convs], 0)
+        bns = [b[1] for b in self.branches[:-1]]
+        n_act = sum(bn.num_features for bn in bns)
+        if any(_need_stats(bn) for bn in bns):
+            gamma = torch.cat([bn.weight for bn in bns])
+            beta = torch.cat([bn.bias for bn in bns])
+            z, _, scale, shift, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, False, gamma, beta,
+                                                   bns[0].eps, n_act, True)
+            c0 = 0
+            for bn in bns:
+                record_running(bn, m[c0:c0 + bn.num_features], var[c0:c0 + bn.num_features], n * T * V)
+                c0 += bn.num_features
+        else:
+            z = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, False)[0]
+            aff = [eval_affine(bn) for bn in bns]
+            rest = self.out_channels - n_act
+            scale = torch.cat([a[0] for a in aff] + [z.new_ones(rest)])
+            shift = torch.cat([a[1] for a in aff] + [z.new_zeros(rest)])
+        tcns = [b[3] for b in self.branches[:-2]]
+        tw, tb = [t.conv.weight for t in tcns], [t.conv.bias for t in tcns]
+        post = [t.bn for t in tcns] + [self.branches[-2][4], self.branches[-1][1]]
+        if any(_need_stats(bn) for bn in post):
+            gamma = torch.cat([bn.weight for bn in post])
+            beta = torch.cat([bn.bias for bn in post])
+            o, s2, h2, m2, v2 = ops.temporal_branches_bn(z, scale, shift, n_act, self.branch_cfg, self.widths, tw, tb,
+                                                         self.stride, gamma, beta, post[0].eps, True)
+            c0 = 0
+            cnt = o.shape[0] * o.shape[2] * o.shape[3]
+            for bn in post:
+                record_running(bn, m2[c0:c0 + bn.num_features], v2[c0:c0 + bn.num_features], cnt)
+                c0 += bn.num_features
+            return o, (s2, h2)
+        o = ops.temporal_branches_bn(z, scale, shift, n_act, self.branch_cfg, self.widths, tw, tb, self.stride)[0]
+        aff = [eval_affine(bn) for bn in post]
+        return o, (torch.cat([a[0] for a in aff]), torch.cat([a[1] for a in aff]))
+
+    def forward_deferred(self, g):
+        """residual=False form (the one CTRGCNBlock builds): -> Deferred(o, closing-BN affine, relu=True)."""
+        if self.residual_kind != 'none':
+            raise NotImplementedError('MSTCN.forward_deferred covers residual=False; use forward()')
+        o, a = self._branches_deferred(g)
+        return Deferred(o, a, None, None, True)
+
+    def forward(self, x):
+        o, a = self._branches_deferred(x)
+        x2 = a2 = None
+        if self.residual_kind == 'identity':
+            x2 = x
+        elif self.residual_kind == 'conv':
+            r = self.residual.forward_deferred(x)
+            x2, a2 = r.x1, r.a1
+        out = kernels.ops().fuse_out(o, a, x2, a2, True, False)[0]
+        return self.drop(out) if self.drop.p > 0 else out
+
+    def init_weights(self):
+        from .gcn_units import _kaiming_conv_init
+        _kaiming_conv_init(self)

@@ -72,7 +72,9 @@ int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, c
                      int pstride, float* dwe, float* dbe, int n, int mid, int V, int P, int E, void* stream);
 
 /* Block output (materialise once): out = relu?(x1*s1+h1 (+ x2*s2+h2 | + x2)), xbar = mean_t out (optional).
- * Replaces BN + residual add + ReLU of dgstgcn.py:63-65 / tcn.py:427 and x.mean(-2) of gcn.py:2246. */
+ * Replaces BN + residual add + ReLU of dgstgcn.py:63-65 / tcn.py:427 and x.mean(-2) of gcn.py:2246.
+ * relu: bit 0 = the outer ReLU, bit 1 = a ReLU on the first term before the add (CTR-GCN: msg3d_utils.py:139-141
+ * followed by ctrgcn.py:60).  bwd part (n*C,4) = per-plane [sum dv1*x1, sum dv, sum dv*x2, sum dv1]. */
 int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, float* out, float* xbar, int n, int C, int T, int V, void* stream);
 int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
@@ -81,24 +83,28 @@ int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const 
 
 /* K-D: dgmstcn temporal stages (tcn.py:379-428).
  * branch_act: h (n,C,T,V+1) = act_c(z*scale+shift) with the global-joint column zaug appended (ReLU for c < n_act).
- * tapconv   : the branches between — type 0 dilated (3,1) conv (weights (bc,bc,3,1), bias (bc)), 1 = (3,1) max-pool,
- *             2 = strided copy — each writing its channel window [c0,c0+bc) of o (n,C,T',V+1); branch tables are
- *             host arrays of length nbr <= 8.  wgrad writes K-split partials at dwp[i]/dbp[i] + split*pstride.
+ * tapconv   : temporal windows over h (n,Cin,T,V1) -> o (n,Cout,T',V1), T' = ceil(T/stride).  Window i: type 0 =
+ *             (KT,1) conv with dilation dil[i] (weights (cout,cin,KT,1), bias (cout) or NULL), 1 = (3,1) max-pool,
+ *             2 = strided copy; it reads channels [ci0,ci0+cin) of h and writes [co0,co0+cout) of o.  KT in {3,5,9},
+ *             shared by the conv windows; window tables are host arrays of length nbr <= 8.  dgmstcn (tcn.py:383-396),
+ *             MSTCN (msg3d_utils.py:84-117) and the dense unit_tcn conv of ST-GCN (tcn.py:21-28; one window, any
+ *             width) all go through it.  wgrad writes K-split partials at dwp[i]/dbp[i] + split*pstride, laid out
+ *             (cout,cin,KT) / (cout).  branch_act with zaug == NULL has no global-joint column (h is (n,C,T,V)).
  * combine   : f = o[..,:V] + o[..,V]*coeff, per-plane sum / sum of squares of f (n*C, 2). */
 int dsgcn_branch_act_fwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
                          float* h, int n, int C, int T, int V, void* stream);
 int dsgcn_branch_act_bwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
                          const float* dh, float* dz, float* dzaug, float* part, int n, int C, int T, int V,
                          void* stream);
-int dsgcn_tapconv_fwd(const float* h, float* o, int n, int C, int T, int V1, int stride, int KT, int nbr,
-                      const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
-                      const float* const* b, void* stream);
-int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int C, int T, int V1, int stride, int KT,
-                        int nbr, const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
-                        void* stream);
-int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int C, int T, int V1, int stride, int KT, int nbr,
-                        const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp,
-                        float* const* dbp, int splits, int pstride, void* stream);
+int dsgcn_tapconv_fwd(const float* h, float* o, int n, int Cin, int Cout, int T, int V1, int stride, int KT, int nbr,
+                      const int* type, const int* ci0, const int* co0, const int* cin, const int* cout, const int* dil,
+                      const float* const* w, const float* const* b, void* stream);
+int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int Cin, int Cout, int T, int V1, int stride,
+                        int KT, int nbr, const int* type, const int* ci0, const int* co0, const int* cin,
+                        const int* cout, const int* dil, const float* const* w, void* stream);
+int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int Cin, int Cout, int T, int V1, int stride, int KT,
+                        int nbr, const int* type, const int* ci0, const int* co0, const int* cin, const int* cout,
+                        const int* dil, float* const* dwp, float* const* dbp, int splits, int pstride, void* stream);
 int dsgcn_tms_combine_fwd(const float* o, const float* coeff, float* f, float* partial, int n, int C, int T, int V,
                           void* stream);
 int dsgcn_tms_combine_bwd(const float* o, const float* coeff, const float* gf, const float* A0, const float* B0,
@@ -147,6 +153,33 @@ int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const 
                        const float* h2, int relu, const float* z, const float* zaug, const float* gz,
                        const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int pstride, int n,
                        int Ci, int Co, int T, int V, int stride, int aug, void* stream);
+
+/* ---- K-A': subset-summed aggregate (ST-GCN unit_gcn gcn.py:81-86, CTR-GCN unit_ctrgcn gcn.py:658,917-921) ----
+ * y[n,c,t,w] = sum_k sum_u p[n,k*Co+c,t,u] * adj_k[u,w], adj_k at ahat + n*a_ns + k*a_ks + c*a_cs (element strides):
+ * shared A (K,V,V): (0, V*V, 0); per sample and channel (n,K*Co,V,V): (K*Co*V*V, Co*V*V, V*V).
+ * partial (n*Co, 2) or NULL: per-plane sum / sum of squares of y -> dsgcn_bn_finalize.
+ * bwd: G = gy + A0[c] + B0[c]*y (y, A0, B0 may be NULL); dp (n,K*Co,T,V) fully written; dAhat_k of plane (n,c) is
+ * written at dahat + n*d_ns + k*d_ks + c*d_cs (shared A: write per-plane pieces, reduce with dsgcn_colsum). */
+int dsgcn_aggsum_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long a_cs, float* y, float* partial,
+                     int n, int K, int Co, int T, int V, void* stream);
+int dsgcn_aggsum_bwd(const float* p, const float* ahat, long a_ns, long a_ks, long a_cs, const float* gy,
+                     const float* y, const float* A0, const float* B0, float* dp, float* dahat, long d_ns, long d_ks,
+                     long d_cs, int n, int K, int Co, int T, int V, void* stream);
+
+/* ---- CTR-GCN channel-wise topology (gcn.py:634-666), the parts that are not 1x1 convs ----
+ * tanhdiff  : proj (n, 2*K*R, V) rows [k*R+r] = conv1_k(xbar), [K*R+k*R+r] = conv2_k(xbar)
+ *             -> d (K, n, R, V, V) = tanh(x1[u] - x2[v])  (gcn.py:653-655); bwd: dproj from dd.
+ * ctr_affine: ahat (n, K*Co, V, V) = alpha[0] * s[k] (n,Co,V,V) + A (K,V,V)  (gcn.py:657); s / ds are host arrays
+ *             of K <= 4 device pointers.  bwd: ds[k] = alpha*dahat; prow (n, K*V*V + K) per-sample
+ *             [sum_c dahat | sum dahat*s] (sum over n = [dA | per-subset dalpha]).
+ * plane_stats: partial (planes, 2) = per-plane [sum, sum of squares] of x (planes, L). */
+int dsgcn_tanhdiff_fwd(const float* proj, float* d, int n, int K, int R, int V, void* stream);
+int dsgcn_tanhdiff_bwd(const float* d, const float* dd, float* dproj, int n, int K, int R, int V, void* stream);
+int dsgcn_ctr_affine_fwd(const float* const* s, const float* alpha, const float* A, float* ahat, int n, int K, int Co,
+                         int V, void* stream);
+int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, const float* dahat, float* const* ds, float* prow,
+                         int n, int K, int Co, int V, void* stream);
+int dsgcn_plane_stats(const float* x, float* partial, long planes, int L, void* stream);
 
 #ifdef __cplusplus
 }

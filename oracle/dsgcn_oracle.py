@@ -402,3 +402,47 @@ def mstcn_msg3d_forward(x, sd, stride=1, kernel_size=5, dilations=(1, 2), traini
     p = f'branches.{nb - 1}.'
     outs.append(_bn(_conv1x1(x, sd[p + '0.weight'], sd[p + '0.bias'], stride), sd, p + '1.', training))
     return F.relu(torch.cat(outs, 1))
+
+
+def ctrgcn_plan(in_channels=3, base_channels=64, num_stages=10, inflate_stages=(5, 8), down_stages=(5, 8)):
+    """(Ci, Co, stride, residual) per block — ctrgcn.py:98-108."""
+    plan = [(in_channels, base_channels, 1, False)]
+    bc = base_channels
+    for i in range(2, num_stages + 1):
+        co = bc * (1 + (i in inflate_stages))
+        plan.append((bc, co, 1 + (i in down_stages), True))
+        bc = co
+    return plan
+
+
+def ctrgcn_block_forward(x, sd, stride, residual, training=True):
+    """CTRGCNBlock.forward (ctrgcn.py:59-61): relu(tcn1(gcn1(x)) + residual(x)), MSTCN kernel 5, dilations (1,2)."""
+    g = unit_ctrgcn_forward(x, _sub(sd, 'gcn1.'), training)
+    t = mstcn_msg3d_forward(g, _sub(sd, 'tcn1.'), stride, 5, (1, 2), training)
+    if not residual:
+        res = 0
+    elif 'residual.conv.weight' in sd:
+        res = unit_tcn_forward(x, _sub(sd, 'residual.'), 1, stride, 1, training)
+    else:
+        res = x
+    return F.relu(t + res)
+
+
+def ctrgcn_forward(x, sd, plan, training=True):
+    """CTRGCN.forward (ctrgcn.py:113-123): data_bn over M*V*C channels."""
+    N, M, T, V, C = x.shape
+    h = x.permute(0, 1, 3, 4, 2).contiguous().view(N, M * V * C, T)
+    h = _bn(h, sd, 'data_bn.', training)
+    h = h.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
+    for i, (ci, co, stride, residual) in enumerate(plan):
+        h = ctrgcn_block_forward(h, _sub(sd, f'net.{i}.'), stride, residual, training)
+    return h.reshape((N, M) + h.shape[1:])
+
+
+def recognizer_forward_train_backbone(backbone, keypoint, label, sd, plan, training=True):
+    """forward_train with the ST-GCN ('stgcn') or CTR-GCN ('ctrgcn') backbone.  Returns (logits, loss)."""
+    assert keypoint.shape[1] == 1
+    fwd = {'stgcn': stgcn_forward, 'ctrgcn': ctrgcn_forward}[backbone]
+    feat = fwd(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training)
+    logits = gcn_head_forward(feat, _sub(sd, 'cls_head.'))
+    return logits, F.cross_entropy(logits, label.squeeze(-1))

@@ -108,11 +108,37 @@ def unit_dgmstcn():
     np.savez_compressed(os.path.join(HERE, 'unit_dgmstcn.npz'), **out)
 
 
-def reduced_model():
-    cfg = ds_cfg(num_classes=12, base_channels=16, num_stages=4, inflate_stages=[3], down_stages=[3])
-    cfg['cls_head']['in_channels'] = 32
-    np.random.seed(3)
-    torch.manual_seed(3)
+def other_cfg(kind, num_classes=60, **bk):
+    if kind == 'ctrgcn':
+        backbone = dict(type='CTRGCN', gcn_type='unit_ctrgcn', graph_cfg=dict(layout='nturgb+d', mode='spatial'))
+    else:
+        backbone = dict(type='STGCN', graph_cfg=dict(layout='nturgb+d', mode='stgcn_spatial'))
+    backbone.update(bk)
+    return dict(type='RecognizerGCN', backbone=backbone,
+                cls_head=dict(type='GCNHead', num_classes=num_classes, in_channels=256))
+
+
+def extract_feat_f64(m64, x):
+    """The reference's STGCN.forward casts its input to fp32 (stgcn.py:141); for the fp64 truth run its own data_bn and
+    blocks on the fp64 input directly (same modules, same order)."""
+    bb = m64.backbone
+    if type(bb).__name__ != 'STGCN':
+        return m64.extract_feat(x)
+    N, M, T, V, C = x.size()
+    h = x.permute(0, 1, 3, 4, 2).contiguous()
+    h = bb.data_bn(h.view(N * M, V * C, T))
+    h = h.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
+    for i in range(bb.num_stages):
+        h = bb.gcn[i](h)
+    return h.reshape((N, M) + h.shape[1:])
+
+
+def reduced_model(cfg=None, name='model_reduced', seed=3):
+    if cfg is None:
+        cfg = ds_cfg(num_classes=12, base_channels=16, num_stages=4, inflate_stages=[3], down_stages=[3])
+        cfg['cls_head']['in_channels'] = 32
+    np.random.seed(seed)
+    torch.manual_seed(seed)
     m = R.builder.build_model(cfg)
     liven(m, 33)
     g = torch.Generator().manual_seed(5)
@@ -134,7 +160,7 @@ def reduced_model():
     # fp64 truth
     m64 = R.builder.build_model(cfg).double()
     m64.load_state_dict({k: v.double() if v.dtype.is_floating_point else v for k, v in m.state_dict().items()})
-    feat = m64.extract_feat(x[:, 0].double())
+    feat = extract_feat_f64(m64, x[:, 0].double())
     logits64 = m64.cls_head(feat)
     loss64 = torch.nn.functional.cross_entropy(logits64, y.squeeze(-1))
     loss64.backward()
@@ -143,23 +169,35 @@ def reduced_model():
     for k, p in m64.named_parameters():
         if p.grad is not None:
             out['g64_' + k] = p.grad.numpy().astype(np.float32)
-    np.savez_compressed(os.path.join(HERE, 'model_reduced.npz'), **out)
-    with open(os.path.join(HERE, 'model_reduced_cfg.json'), 'w') as f:
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    with open(os.path.join(HERE, name + '_cfg.json'), 'w') as f:
         json.dump(cfg, f, indent=1)
+
+
+def reduced_other_models():
+    for kind in ('ctrgcn', 'stgcn'):
+        cfg = other_cfg(kind, 12, base_channels=16, num_stages=4, inflate_stages=[3], down_stages=[3])
+        cfg['cls_head']['in_channels'] = 32
+        reduced_model(cfg, 'model_reduced_' + kind, seed=4)
 
 
 def manifests():
     man = {}
-    for name, cfg in (('dsstgcn_ntu60', ds_cfg(60)), ('dsstgcn_ntu120', ds_cfg(120)),
-                      ('dsstgcn_k400_coco', ds_cfg(400, 'coco'))):
+    ds_keys = ('backbone.gcn.0.gcn.A', 'backbone.gcn.0.gcn.pre.0.weight', 'backbone.gcn.9.tcn.transform.2.weight',
+               'cls_head.fc_cls.weight')
+    ctr_keys = ('backbone.net.0.gcn1.convs.0.conv1.weight', 'backbone.net.4.gcn1.convs.2.conv4.weight',
+                'backbone.net.9.tcn1.branches.1.3.conv.weight', 'cls_head.fc_cls.weight')
+    st_keys = ('backbone.gcn.0.gcn.conv.weight', 'backbone.gcn.4.residual.conv.weight',
+               'backbone.gcn.9.tcn.conv.weight', 'cls_head.fc_cls.weight')
+    for name, cfg, keys in (('dsstgcn_ntu60', ds_cfg(60), ds_keys), ('dsstgcn_ntu120', ds_cfg(120), ds_keys),
+                            ('dsstgcn_k400_coco', ds_cfg(400, 'coco'), ds_keys),
+                            ('ctrgcn_ntu60', other_cfg('ctrgcn'), ctr_keys), ('stgcn_ntu60', other_cfg('stgcn'), st_keys)):
         np.random.seed(0)
         torch.manual_seed(0)
         m = R.builder.build_model(cfg)
         man[name] = dict(keys=[[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()],
-                         params=sum(p.numel() for p in m.parameters()),
-                         sha_first=[float(m.state_dict()[k].double().sum()) for k in
-                                    ('backbone.gcn.0.gcn.A', 'backbone.gcn.0.gcn.pre.0.weight',
-                                     'backbone.gcn.9.tcn.transform.2.weight', 'cls_head.fc_cls.weight')])
+                         params=sum(p.numel() for p in m.parameters()), sha_keys=list(keys),
+                         sha_first=[float(m.state_dict()[k].double().sum()) for k in keys])
     with open(os.path.join(HERE, 'state_dict_manifest.json'), 'w') as f:
         json.dump(man, f)
 
@@ -169,6 +207,7 @@ if __name__ == '__main__':
     unit_dgphgcn1()
     unit_dgmstcn()
     reduced_model()
+    reduced_other_models()
     manifests()
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith(('.npz', '.json')):

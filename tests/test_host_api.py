@@ -63,37 +63,48 @@ def test_graph_matches_golden():
         D.DGSTGCN(graph_cfg=dict(layout='openpose', mode='spatial'), gcn_type='dgphgcn1', tcn_type='dgmstcn')
 
 
-@pytest.mark.parametrize('name,classes,layout', [('dsstgcn_ntu60', 60, 'nturgb+d'), ('dsstgcn_ntu120', 120, 'nturgb+d'),
-                                                 ('dsstgcn_k400_coco', 400, 'coco')])
-def test_state_dict_contract(name, classes, layout):
+def other_cfg(kind, num_classes=60, **bk):
+    if kind == 'ctrgcn':
+        backbone = dict(type='CTRGCN', gcn_type='unit_ctrgcn', graph_cfg=dict(layout='nturgb+d', mode='spatial'))
+    else:
+        backbone = dict(type='STGCN', graph_cfg=dict(layout='nturgb+d', mode='stgcn_spatial'))
+    backbone.update(bk)
+    return dict(type='RecognizerGCN', backbone=backbone,
+                cls_head=dict(type='GCNHead', num_classes=num_classes, in_channels=256))
+
+
+@pytest.mark.parametrize('name,cfg', [('dsstgcn_ntu60', ds_cfg(60, 'nturgb+d')), ('dsstgcn_ntu120', ds_cfg(120, 'nturgb+d')),
+                                      ('dsstgcn_k400_coco', ds_cfg(400, 'coco')), ('ctrgcn_ntu60', other_cfg('ctrgcn')),
+                                      ('stgcn_ntu60', other_cfg('stgcn'))])
+def test_state_dict_contract(name, cfg):
     """Same keys, order, shapes, dtypes — and the same initial values under the same seeds — as the reference."""
     with open(os.path.join(GOLD, 'state_dict_manifest.json')) as f:
         man = json.load(f)[name]
     np.random.seed(0)
     torch.manual_seed(0)
-    m = D.build_model(ds_cfg(classes, layout))
+    m = D.build_model(cfg)
     sd = m.state_dict()
     assert [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()] == man['keys']
     assert sum(p.numel() for p in m.parameters()) == man['params']
-    keys = ('backbone.gcn.0.gcn.A', 'backbone.gcn.0.gcn.pre.0.weight', 'backbone.gcn.9.tcn.transform.2.weight',
-            'cls_head.fc_cls.weight')
-    for k, ref in zip(keys, man['sha_first']):
+    for k, ref in zip(man['sha_keys'], man['sha_first']):
         assert abs(float(sd[k].double().sum()) - ref) < 1e-9 * max(1.0, abs(ref)), k
 
 
-def _reduced_model():
-    z = load('model_reduced.npz')
-    with open(os.path.join(GOLD, 'model_reduced_cfg.json')) as f:
+def _reduced_model(name='model_reduced'):
+    z = load(name + '.npz')
+    with open(os.path.join(GOLD, name + '_cfg.json')) as f:
         cfg = json.load(f)
-    cfg['backbone']['tcn_ms_cfg'] = [tuple(c) if isinstance(c, list) else c for c in cfg['backbone']['tcn_ms_cfg']]
+    if 'tcn_ms_cfg' in cfg['backbone']:
+        cfg['backbone']['tcn_ms_cfg'] = [tuple(c) if isinstance(c, list) else c for c in cfg['backbone']['tcn_ms_cfg']]
     m = D.build_model(cfg)
     m.load_state_dict(sd_of(z, 'sd_', torch.float32))
     return z, m
 
 
-def test_fused_wiring_against_golden_cpu():
+@pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn'])
+def test_fused_wiring_against_golden_cpu(name):
     """forward_train through the deferred-BN op chain (torch op namespace) == the reference's logits / loss / grads."""
-    z, m = _reduced_model()
+    z, m = _reduced_model(name)
     m.train()
     x, y = torch.from_numpy(z['x']), torch.from_numpy(z['label'])
     with D.kernels.use_ops(torch_ops):

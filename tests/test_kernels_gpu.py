@@ -5,6 +5,7 @@ import torch
 
 import dsgcn_amd
 from dsgcn_amd import kernels as K
+K_ = K
 import torch_ops as R
 
 pytestmark = pytest.mark.gpu
@@ -160,10 +161,12 @@ def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
         assert err < tol, (k, err)
 
 
-@pytest.mark.parametrize('n,C,T,V,mode,tmean', [
-    (3, 64, 64, 25, 'res_plain', True), (2, 128, 32, 25, 'res_affine', True), (2, 64, 64, 25, 'affine', True),
-    (2, 256, 16, 25, 'res_plain', False), (2, 12, 25, 17, 'res_affine', True), (1, 5, 7, 18, 'plain', True)])
-def test_fuse_out(n, C, T, V, mode, tmean):
+@pytest.mark.parametrize('n,C,T,V,mode,tmean,flags', [
+    (3, 64, 64, 25, 'res_plain', True, 1), (2, 128, 32, 25, 'res_affine', True, 1), (2, 64, 64, 25, 'affine', True, 1),
+    (2, 256, 16, 25, 'res_plain', False, 1), (2, 12, 25, 17, 'res_affine', True, 1), (1, 5, 7, 18, 'plain', True, 1),
+    (2, 64, 32, 25, 'res_plain', True, 3), (2, 32, 16, 25, 'res_affine', False, 3), (2, 16, 8, 17, 'affine', False, 2),
+    (2, 16, 8, 25, 'res_affine', False, 0)])
+def test_fuse_out(n, C, T, V, mode, tmean, flags):
     g = torch.Generator().manual_seed(C + T)
     x1 = _rand(g, n, C, T, V)
     a1 = None if mode == 'plain' else (torch.rand(C, generator=g) + 0.5, _rand(g, C, scale=0.3))
@@ -178,7 +181,7 @@ def test_fuse_out(n, C, T, V, mode, tmean):
         tx1, tx2 = mk(x1), mk(x2)
         ta1 = None if a1 is None else (mk(a1[0]), mk(a1[1]))
         ta2 = None if a2 is None else (mk(a2[0]), mk(a2[1]))
-        out, xbar = mod.fuse_out(tx1, ta1, tx2, ta2, True, tmean)
+        out, xbar = mod.fuse_out(tx1, ta1, tx2, ta2, flags, tmean)
         loss = (out * go.to(dev, dt)).sum()
         if tmean:
             loss = loss + (xbar * gb.to(dev, dt)).sum()
@@ -240,3 +243,148 @@ def test_temporal_ms(n, C, T, V, stride):
     for k, v in ref.items():
         # MIOpen fp32 convolutions between the two HIP stages: 5e-5 relative L2
         assert rel(got[k].detach().cpu(), v.detach()) < 5e-5, (k, rel(got[k].detach().cpu(), v.detach()))
+
+
+@pytest.mark.parametrize('n,K,Co,T,V,shared,bn', [
+    (2, 3, 16, 64, 25, True, True), (2, 3, 64, 16, 25, True, True), (3, 3, 8, 100, 17, True, False),
+    (2, 3, 16, 64, 25, False, True), (2, 3, 32, 32, 25, False, True), (2, 3, 8, 130, 17, False, True),
+    (1, 2, 5, 7, 18, False, False)])
+def test_aggregate_sum(n, K, Co, T, V, shared, bn):
+    g = torch.Generator().manual_seed(Co + T + V)
+    p = _rand(g, n, K * Co, T, V)
+    adj = _rand(g, K, V, V, scale=0.3) if shared else _rand(g, n, K * Co, V, V, scale=0.3)
+    gamma = torch.rand(Co, generator=g) + 0.5
+    beta = _rand(g, Co, scale=0.2)
+    gy, gsc, gsh = _rand(g, n, Co, T, V), _rand(g, Co), _rand(g, Co)
+
+    def run(mod, dt, dev):
+        def mk(t):
+            return t.to(dev, dt).requires_grad_()
+        tp, ta, tg, tb = mk(p), mk(adj), mk(gamma), mk(beta)
+        y, sc, sh, mean, var = mod.aggregate_sum(tp, ta, K, tg if bn else None, tb if bn else None, 1e-5, bn)
+        loss = (y * gy.to(dev, dt)).sum()
+        if bn:
+            loss = loss + (sc * gsc.to(dev, dt)).sum() + (sh * gsh.to(dev, dt)).sum()
+        loss.backward()
+        res = dict(y=y, dp=tp.grad, dadj=ta.grad)
+        if bn:
+            res.update(sc=sc, sh=sh, mean=mean, var=var, dgamma=tg.grad, dbeta=tb.grad)
+        return res
+
+    got = run(K_, torch.float32, DEV)
+    ref = run(R, torch.float64, 'cpu')
+    for k, v in ref.items():
+        # fp32 accumulation over K*V (fwd) / T (dadj, x n*Co for the shared form) terms: 1e-5 relative L2
+        assert rel(got[k].detach().cpu(), v.detach()) < 1e-5, (k, rel(got[k].detach().cpu(), v.detach()))
+
+
+@pytest.mark.parametrize('n,Ci,Co,V', [(2, 3, 64, 25), (2, 64, 64, 25), (3, 128, 256, 25), (2, 256, 256, 17)])
+def test_ctr_topology(n, Ci, Co, V):
+    g = torch.Generator().manual_seed(Ci + Co)
+    K = 3
+    Rr = 8 if Ci <= 16 else Ci // 8
+    t = dict(xbar=_rand(g, n, Ci, V), w1=_rand(g, K * Rr, Ci, scale=Ci ** -0.5), b1=_rand(g, K * Rr, scale=0.1),
+             w2=_rand(g, K * Rr, Ci, scale=Ci ** -0.5), b2=_rand(g, K * Rr, scale=0.1), alpha=_rand(g, 1, scale=0.7),
+             A=_rand(g, K, V, V, scale=0.2))
+    w4 = [_rand(g, Co, Rr, scale=Rr ** -0.5) for _ in range(K)]
+    b4 = [_rand(g, Co, scale=0.1) for _ in range(K)]
+    gah = _rand(g, n, K * Co, V, V)
+
+    def run(mod, dt, dev):
+        tt = {k: v.to(dev, dt).requires_grad_() for k, v in t.items()}
+        tw4 = [w.to(dev, dt).requires_grad_() for w in w4]
+        tb4 = [b.to(dev, dt).requires_grad_() for b in b4]
+        ah = mod.ctr_topology(tt['xbar'], tt['w1'], tt['b1'], tt['w2'], tt['b2'], tw4, tb4, tt['alpha'], tt['A'])
+        ah.backward(gah.to(dev, dt))
+        res = {'ahat': ah}
+        res.update({'d' + k: v.grad for k, v in tt.items()})
+        for k in range(K):
+            res[f'dw4_{k}'], res[f'db4_{k}'] = tw4[k].grad, tb4[k].grad
+        return res
+
+    got = run(K_, torch.float32, DEV)
+    ref = run(R, torch.float64, 'cpu')
+    for k, v in ref.items():
+        # tanhf + fp32 MFMA accumulation over <= 32 (fwd) / n*V*V*Co (grads) terms: 2e-5 relative L2
+        assert rel(got[k].detach().cpu(), v.detach()) < 2e-5, (k, rel(got[k].detach().cpu(), v.detach()))
+
+
+@pytest.mark.parametrize('n,C,T,V,stride,ks', [(2, 64, 32, 25, 1, 5), (2, 128, 32, 25, 2, 5), (2, 256, 16, 25, 1, 5),
+                                               (2, 32, 21, 17, 2, 5), (1, 16, 9, 18, 1, 3)])
+def test_temporal_branches_bn(n, C, T, V, stride, ks):
+    """MSTCN's stage: BN+ReLU, two dilated (k,1) convs, max-pool, strided copy, closing BatchNorm statistics."""
+    g = torch.Generator().manual_seed(C + T + stride)
+    cfg = [(ks, 1), (ks, 2), ('max', 3), '1x1']
+    bc = C // 4
+    widths = [bc, bc, bc, C - 3 * bc]
+    n_act = 3 * bc
+    z = _rand(g, n, C, T, V)
+    scale = torch.cat([torch.rand(n_act, generator=g) + 0.5, torch.ones(C - n_act)])
+    shift = torch.cat([_rand(g, n_act, scale=0.3), torch.zeros(C - n_act)])
+    cw = [_rand(g, bc, bc, ks, 1, scale=(ks * bc) ** -0.5) for _ in range(2)]
+    cb = [_rand(g, bc, scale=0.1) for _ in range(2)]
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = _rand(g, C, scale=0.2)
+    Tout = (T + stride - 1) // stride
+    go, gsc, gsh = _rand(g, n, C, Tout, V), _rand(g, C), _rand(g, C)
+
+    def run(mod, dt, dev):
+        def mk(t):
+            return t.to(dev, dt).requires_grad_()
+        tz, tsc, tsh, tga, tbe = mk(z), mk(scale), mk(shift), mk(gamma), mk(beta)
+        tw, tb = [mk(w) for w in cw], [mk(b) for b in cb]
+        o, sc, sh, mean, var = mod.temporal_branches_bn(tz, tsc, tsh, n_act, cfg, widths, tw, tb, stride, tga, tbe,
+                                                        1e-5, True)
+        ((o * go.to(dev, dt)).sum() + (sc * gsc.to(dev, dt)).sum() + (sh * gsh.to(dev, dt)).sum()).backward()
+        res = dict(o=o, sc=sc, sh=sh, mean=mean, var=var, dz=tz.grad, dscale=tsc.grad, dshift=tsh.grad,
+                   dgamma=tga.grad, dbeta=tbe.grad)
+        for i in range(2):
+            res[f'dw{i}'], res[f'db{i}'] = tw[i].grad, tb[i].grad
+        return res
+
+    got = run(K_, torch.float32, DEV)
+    ref = run(R, torch.float64, 'cpu')
+    for k, v in ref.items():
+        # fp32 MFMA accumulation over <= 5*64 (fwd) / n*T*V (wgrad, statistics) terms: 2e-5 relative L2
+        assert rel(got[k].detach().cpu(), v.detach()) < 2e-5, (k, rel(got[k].detach().cpu(), v.detach()))
+
+
+@pytest.mark.parametrize('n,Ci,Co,T,V,stride,ks,dil,bn', [
+    (2, 64, 64, 32, 25, 1, 9, 1, True), (2, 64, 64, 32, 25, 2, 9, 1, True), (2, 128, 128, 16, 25, 1, 9, 1, True),
+    (1, 256, 256, 8, 25, 1, 9, 1, True), (2, 40, 72, 21, 17, 2, 9, 1, False), (2, 16, 16, 12, 18, 1, 3, 2, True),
+    (2, 70, 130, 10, 25, 1, 5, 2, True)])
+def test_tconv_dense(n, Ci, Co, T, V, stride, ks, dil, bn):
+    """unit_tcn's dense (k,1) temporal conv (ST-GCN: k=9) + the statistics of the BatchNorm that follows."""
+    g = torch.Generator().manual_seed(Ci + Co + T)
+    h = _rand(g, n, Ci, T, V)
+    w = _rand(g, Co, Ci, ks, 1, scale=(ks * Ci) ** -0.5)
+    b = _rand(g, Co, scale=0.1)
+    gamma = torch.rand(Co, generator=g) + 0.5
+    beta = _rand(g, Co, scale=0.2)
+    Tout = (T + stride - 1) // stride
+    gz, gsc, gsh = _rand(g, n, Co, Tout, V), _rand(g, Co), _rand(g, Co)
+
+    def run(mod, dt, dev):
+        def mk(t):
+            return t.to(dev, dt).requires_grad_()
+        th, tw, tb, tga, tbe = mk(h), mk(w), mk(b), mk(gamma), mk(beta)
+        zz, sc, sh, mean, var = mod.tconv(th, tw, tb, stride, dil, tga if bn else None, tbe if bn else None, 1e-5, bn)
+        loss = (zz * gz.to(dev, dt)).sum()
+        if bn:
+            loss = loss + (sc * gsc.to(dev, dt)).sum() + (sh * gsh.to(dev, dt)).sum()
+        loss.backward()
+        res = dict(z=zz, dh=th.grad, dw=tw.grad, db=tb.grad)
+        if bn:
+            res.update(sc=sc, sh=sh, mean=mean, var=var, dgamma=tga.grad, dbeta=tbe.grad)
+        return res
+
+    got = run(K_, torch.float32, DEV)
+    ref = run(R, torch.float64, 'cpu')
+    for k, v in ref.items():
+        # fp32 MFMA accumulation over <= 9*256 (fwd) / n*T*V (wgrad) terms: 2e-5 relative L2
+        assert rel(got[k].detach().cpu(), v.detach()) < 2e-5, (k, rel(got[k].detach().cpu(), v.detach()))
+
+
+def test_tmean():
+    x = torch.randn(4, 3, 20, 25)
+    assert rel(K_.tmean(x.cuda()).cpu(), x.mean(2)) < 1e-6

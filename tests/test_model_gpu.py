@@ -23,11 +23,14 @@ def test_native_library_is_loaded():
         assert 'libdsgcn.so' in f.read()           # the in-tree HIP library really is the code that runs
 
 
-def test_reduced_model_vs_golden():
-    z = load('model_reduced.npz')
-    with open(os.path.join(GOLD, 'model_reduced_cfg.json')) as f:
+@pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn'])
+def test_reduced_model_vs_golden(name):
+    """DS-STGCN, classic CTR-GCN and ST-GCN (reduced widths) against the reference's committed outputs."""
+    z = load(name + '.npz')
+    with open(os.path.join(GOLD, name + '_cfg.json')) as f:
         cfg = json.load(f)
-    cfg['backbone']['tcn_ms_cfg'] = [tuple(c) if isinstance(c, list) else c for c in cfg['backbone']['tcn_ms_cfg']]
+    if 'tcn_ms_cfg' in cfg['backbone']:
+        cfg['backbone']['tcn_ms_cfg'] = [tuple(c) if isinstance(c, list) else c for c in cfg['backbone']['tcn_ms_cfg']]
     m = D.build_model(cfg)
     m.load_state_dict(sd_of(z, 'sd_', torch.float32))
     m = m.cuda().train()
@@ -74,6 +77,32 @@ def test_full_model_vs_oracle(layout, V, T, classes):
     out['loss'].backward()
     dead = [k for k, p in m.named_parameters() if p.grad is None]
     assert len(dead) == 20 and all('conv2_se' in k for k in dead)          # reference quirk Q1
+
+
+@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn'])
+def test_full_other_backbones_vs_oracle(kind):
+    """Full-width classic CTR-GCN (BASELINE config 4) and vanilla ST-GCN (config 1), 2 clips, against the CPU oracle."""
+    from test_host_api import other_cfg
+    np.random.seed(0)
+    torch.manual_seed(0)
+    m = D.build_model(other_cfg(kind))
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith('alpha'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 1, 2, 64, 25, 3, generator=g)
+    y = torch.randint(0, 60, (2, 1), generator=g)
+    plan = O.ctrgcn_plan() if kind == 'ctrgcn' else O.dgstgcn_plan()
+    ref_logits, ref_loss = O.recognizer_forward_train_backbone(kind, x, y, sd, plan)
+    m = m.cuda().train()
+    out = m.train_step(dict(keypoint=x.cuda(), label=y.cuda()), None)
+    logits = m.cls_head(m.extract_feat(x.cuda()[:, 0]))
+    assert rel(logits.detach().cpu(), ref_logits) < 1e-4
+    assert abs(out['log_vars']['loss'] - ref_loss.item()) / abs(ref_loss.item()) < 1e-4
+    out['loss'].backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
 
 
 def test_running_stats_and_eval_mode():

@@ -98,6 +98,26 @@ def test_reduced_model_fp64_and_fp32():
     assert abs(loss32.item() - float(z['loss_f32'])) < 1e-5
 
 
+@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn'])
+def test_reduced_other_backbones(kind):
+    """ST-GCN (unit_gcn + unit_tcn k=9) and classic CTR-GCN (unit_ctrgcn + MSTCN) end to end against the reference."""
+    z = load(f'model_reduced_{kind}.npz')
+    with open(os.path.join(GOLD, f'model_reduced_{kind}_cfg.json')) as f:
+        bk = json.load(f)['backbone']
+    if kind == 'ctrgcn':
+        plan = O.ctrgcn_plan(3, bk['base_channels'], bk['num_stages'], tuple(bk['inflate_stages']), tuple(bk['down_stages']))
+    else:
+        plan = O.dgstgcn_plan(3, bk['base_channels'], 2, bk['num_stages'], tuple(bk['inflate_stages']),
+                              tuple(bk['down_stages']))
+    x, y = torch.from_numpy(z['x']), torch.from_numpy(z['label'])
+    logits, loss = O.recognizer_forward_train_backbone(kind, x.double(), y, sd_of(z, 'sd_'), plan)
+    assert rel(logits, z['logits_f64']) < 1e-6
+    assert abs(loss.item() - float(z['loss_f64'])) < 1e-7
+    logits32, loss32 = O.recognizer_forward_train_backbone(kind, x, y, sd_of(z, 'sd_', torch.float32), plan)
+    assert rel(logits32, z['logits_f32']) < 1e-5
+    assert abs(loss32.item() - float(z['loss_f32'])) < 1e-5
+
+
 def test_oracle_vs_reference_live():
     import ref_shim
     if not ref_shim.available():

@@ -59,9 +59,16 @@ def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, gamma=None, 
     return z, zaug, sc, sh, mean.detach(), var.detach()
 
 
-def bn_affine(mean, var, weight, bias, eps):
-    scale = weight * torch.rsqrt(var + eps)
-    return scale, bias - mean * scale
+def _bn_of(t, gamma, beta, eps, want_bn):
+    """(t, scale, shift, mean, var): the train-mode BN of t as a deferred affine (or Nones)."""
+    if not want_bn:
+        return t, None, None, None, None
+    mean = t.mean((0, 2, 3))
+    var = t.var((0, 2, 3), unbiased=False)
+    g = gamma if gamma is not None else t.new_ones(t.shape[1])
+    b = beta if beta is not None else t.new_zeros(t.shape[1])
+    sc = g * torch.rsqrt(var + eps)
+    return t, sc, b - mean * sc, mean.detach(), var.detach()
 
 
 def aggregate(zp, ap, relu, ahat):
@@ -70,15 +77,31 @@ def aggregate(zp, ap, relu, ahat):
     return torch.einsum('nctu,ncuw->nctw', p, ahat)
 
 
-def aggregate_shared(zp, A, K, stats=True):
-    """ST-GCN form (gcn.py:86-88): zp (n,K*Co,T,V), A (K,V,V) -> y (n,Co,T,V) summed over k (+ batch stats)."""
-    n, KC, T, V = zp.shape
-    y = torch.einsum('nkctv,kvw->nctw', zp.view(n, K, KC // K, T, V), A)
-    mean = var = None
-    if stats:
-        mean = y.mean((0, 2, 3))
-        var = y.var((0, 2, 3), unbiased=False)
-    return y, mean, var
+def aggregate_sum(p, adj, K, gamma=None, beta=None, eps=1e-5, want_bn=False):
+    """y[n,c,t,w] = sum_k sum_u p[n,k*Co+c,t,u] * adj_k[u,w]; adj (K,V,V) shared (ST-GCN, gcn.py:81-85) or
+    (n,K*Co,V,V) per sample and channel (CTR-GCN, gcn.py:658 + the sum over subsets gcn.py:917-919); + BN of y."""
+    n, KC, T, V = p.shape
+    p5 = p.view(n, K, KC // K, T, V)
+    if adj.dim() == 3:
+        y = torch.einsum('nkctv,kvw->nctw', p5, adj)
+    else:
+        y = torch.einsum('nkctu,nkcuw->nctw', p5, adj.view(n, K, KC // K, V, V))
+    return _bn_of(y, gamma, beta, eps, want_bn)
+
+
+def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A):
+    """CTR-GCN refined topology (gcn.py:651-657): -> Ahat (n, K*Co, V, V)."""
+    n, Ci, V = xbar.shape
+    K = A.shape[0]
+    R = w1.shape[0] // K
+    x1 = (torch.einsum('oc,ncv->nov', w1, xbar) + b1[None, :, None]).view(n, K, R, V)
+    x2 = (torch.einsum('oc,ncv->nov', w2, xbar) + b2[None, :, None]).view(n, K, R, V)
+    d = torch.tanh(x1[..., :, None] - x2[..., None, :])                  # n,K,R,V,V
+    out = []
+    for k in range(K):
+        s = torch.einsum('or,nruv->nouv', w4[k], d[:, k]) + b4[k][None, :, None, None]
+        out.append(s * alpha + A[k][None, None])
+    return torch.cat(out, 1)
 
 
 def tmean(x):
@@ -154,19 +177,50 @@ def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b
     return f, sc, b - mean * sc, mean.detach(), var.detach()
 
 
-def tconv(x1, a1, relu, weight, bias, stride, dilation, stats=True):
-    """Dense temporal conv (k,1) over the virtual input (unit_tcn, tcn.py:21-27)."""
-    v = virt(x1, a1, None, None, relu)
+def _branches(h, branch_cfg, widths, conv_w, conv_b, stride):
+    outs = []
+    c0 = ci = 0
+    for cfg, bc in zip(branch_cfg, widths):
+        hb = h[:, c0:c0 + bc]
+        if cfg == '1x1':
+            outs.append(hb[:, :, ::stride])
+        elif cfg[0] == 'max':
+            outs.append(F.max_pool2d(hb, (cfg[1], 1), (stride, 1), (1, 0)))
+        else:
+            k, d = cfg
+            pad = (k + (k - 1) * (d - 1) - 1) // 2
+            outs.append(F.conv2d(hb, conv_w[ci], conv_b[ci], stride=(stride, 1), padding=(pad, 0), dilation=(d, 1)))
+            ci += 1
+        c0 += bc
+    return torch.cat(outs, 1)
+
+
+def temporal_branches_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, stride, gamma=None, beta=None,
+                         eps=1e-5, want_bn=False):
+    """MSTCN's temporal stage (msg3d_utils.py:84-117) after the fused branch 1x1 conv: BN+ReLU on channels < n_act,
+    per-branch (k,1) dilated conv / max-pool / strided copy -> o (n,C,T',V), + the train-mode BN of o."""
+    h = z * _bc(scale) + _bc(shift)
+    h = torch.cat([F.relu(h[:, :n_act]), h[:, n_act:]], 1)
+    return _bn_of(_branches(h, branch_cfg, widths, conv_w, conv_b, stride), gamma, beta, eps, want_bn)
+
+
+def tconv(h, weight, bias, stride, dilation, gamma=None, beta=None, eps=1e-5, want_bn=False):
+    """Dense temporal conv (k,1) of a materialised tensor (unit_tcn, tcn.py:21-27) + the train-mode BN of its output."""
     k = weight.shape[2]
     pad = (k + (k - 1) * (dilation - 1) - 1) // 2
-    z = F.conv2d(v, weight, bias, stride=(stride, 1), padding=(pad, 0), dilation=(dilation, 1))
-    mean = var = None
-    if stats:
-        mean = z.mean((0, 2, 3))
-        var = z.var((0, 2, 3), unbiased=False)
-    return z, mean, var
+    z = F.conv2d(h, weight, bias, stride=(stride, 1), padding=(pad, 0), dilation=(dilation, 1))
+    return _bn_of(z, gamma, beta, eps, want_bn)
 
 
 def fuse_out(x1, a1, x2, a2, relu, want_tmean=False):
-    out = virt(x1, a1, x2, a2, relu)
+    """relu: bool or int flags (bit 0 outer ReLU, bit 1 ReLU on the first term before the add)."""
+    relu = int(relu)
+    if relu & 2:
+        out = virt(x1, a1, None, None, True)
+        if x2 is not None:
+            out = out + (x2 if a2 is None else x2 * _bc(a2[0]) + _bc(a2[1]))
+        if relu & 1:
+            out = F.relu(out)
+    else:
+        out = virt(x1, a1, x2, a2, bool(relu & 1))
     return out, (out.mean(2) if want_tmean else None)
