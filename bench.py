@@ -94,7 +94,7 @@ def measure_ka_roofline(device, n, reps=20):
         sh = torch.randn(KC, device=device) * 0.1
         bufs.append(dict(zp=zp, ah=ah, sc=sc, sh=sh, y=torch.empty_like(zp), dy=torch.randn_like(zp),
                          dzp=torch.empty_like(zp), dah=torch.empty_like(ah),
-                         part=torch.empty(nn * KC, 2, device=device), dims=(nn, KC, t)))
+                         part=torch.empty(4 * nn * KC, 2, device=device), dims=(nn, KC, t)))
 
     def fwd(b):
         nn, KC, t = b['dims']

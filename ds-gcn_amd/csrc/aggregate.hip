@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd(const float* __restrict__ 
 
 // Persistent/pipelined backward for T <= 64 (one 64-frame pass per unit): same products as k_aggregate_bwd,
 // with the next unit's Zp / dY planes and adjacency in flight while the current unit is on the matrix core.
-template <int V>
+template <int V, bool DA_LDS>
 __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restrict__ zp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
@@ -456,8 +456,8 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
   constexpr int NA = (V * V + 63) / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldsZ = lds;
-  float* ldsG = lds + 64 * V;
-  float* ldsA = lds + 128 * V;
+  float* ldsG = lds + T * V;          // LDS sized by T (T*V % 4 == 0): short layers keep more waves resident
+  float* ldsA = lds + 2 * T * V;
   const int lane = threadIdx.x;
   const int mi = lane & 31, mk = lane >> 5;
   const int mic = mi < V ? mi : V - 1;
@@ -534,13 +534,23 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
       for (int q = 0; q < 8; ++q)
         if (j0 + 2 * q < rows) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accA, 0, 0, 0);
     }
-    {
+    if (!DA_LDS) {
       float* __restrict__ dA = dahat + (size_t)unit * V * V;
       if (mi < V && !(ablate & 4)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int u = mfma_row(r, mk);
           if (u < V) dA[u * V + mi] = accA[r];
+        }
+      }
+    } else {
+      // ldsA is free once bt has been read: bounce dAhat through it so the 2.5 KB leave as contiguous 256-B stores
+      // instead of 16 x two 100-B row segments
+      if (mi < V) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int u = mfma_row(r, mk);
+          if (u < V) ldsA[u * V + mi] = accA[r];
         }
       }
     }
@@ -578,6 +588,14 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
       }
     }
     wave_lds_sync();
+    if (DA_LDS) {
+      float* __restrict__ dA = dahat + (size_t)unit * V * V;
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        const int i = lane + q * 64;
+        if (i < V * V) dA[i] = ldsA[i];
+      }
+    }
     {
       f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dzp + (size_t)unit * T * V);
       const f32x4* l4 = reinterpret_cast<const f32x4*>(ldsZ);
@@ -598,12 +616,184 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
   }
 }
 
+// Two waves per unit for 32 < T <= 64: each wave owns 32 frames (its half of Zp / dY / dZp and half of the adjacency
+// load), so the serial load -> MFMA -> store chain per wave is half as long and twice as many waves are resident
+// (tools/ka_ablate.py: at n=128 the one-wave form spends half its time in the per-wave MFMA chains, not on HBM).
+// dAhat = P^T dY is summed over the two halves through LDS; two raw s_barriers per unit (no vmcnt drain: the next
+// unit's prefetch stays in flight).  partial has 2 rows per unit: [wave][unit][2].
+template <int V, int HR, int NW>
+__global__ __launch_bounds__(64 * NW) void k_aggregate_bwd_pair(const float* __restrict__ zp,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu,
+                                                            const float* __restrict__ ahat,
+                                                            const float* __restrict__ dy, float* __restrict__ dzp,
+                                                            float* __restrict__ dahat, float* __restrict__ partial,
+                                                            int KC, int T, long units) {
+  constexpr int KS = (V + 1) / 2;
+  constexpr int NP4 = (HR * V / 4 + 63) / 64;
+  constexpr int AH = (V * V + NW - 1) / NW;               // adjacency dwords each wave loads
+  constexpr int NAH = (AH + 63) / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* ldsZ = lds + wave * HR * V;
+  float* ldsG = lds + NW * HR * V + wave * HR * V;
+  float* ldsA = lds + 2 * NW * HR * V;
+  float* ldsD = ldsA + V * V;                              // [NW-1][V*V] partial dAhat of waves 1..NW-1
+  const int mi = lane & 31, mk = lane >> 5;
+  const int mic = mi < V ? mi : V - 1;
+  const int rows = min(HR, T - wave * HR);
+  const int c4 = (rows * V) >> 2;
+  const int a0 = wave * AH, a1 = min(V * V, a0 + AH);
+  f32x4 prez[NP4], preg[NP4];
+  float prea[NAH];
+
+  auto issue = [&](long unit) {
+    const size_t off = ((size_t)unit * T + wave * HR) * V;
+    const f32x4* __restrict__ z4 = reinterpret_cast<const f32x4*>(zp + off);
+    const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(dy + off);
+    const float* __restrict__ A = ahat + (size_t)unit * V * V;
+#pragma unroll
+    for (int q = 0; q < NP4; ++q) {
+      const int i = lane + q * 64;
+      if (i < c4) { prez[q] = z4[i]; preg[q] = g4[i]; }
+    }
+#pragma unroll
+    for (int q = 0; q < NAH; ++q) {
+      const int i = a0 + lane + q * 64;
+      if (i < a1) prea[q] = A[i];
+    }
+  };
+
+  long unit = blockIdx.x;
+  if (unit < units) issue(unit);
+  while (unit < units) {
+    const int c = (int)(unit % KC);
+    const float s = scale ? scale[c] : 1.f;
+    const float h = shift ? shift[c] : 0.f;
+    {
+      f32x4* lz = reinterpret_cast<f32x4*>(ldsZ);
+      f32x4* lg = reinterpret_cast<f32x4*>(ldsG);
+#pragma unroll
+      for (int q = 0; q < NP4; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4) { lz[i] = prez[q]; lg[i] = preg[q]; }
+      }
+#pragma unroll
+      for (int q = 0; q < NAH; ++q) {
+        const int i = a0 + lane + q * 64;
+        if (i < a1) ldsA[i] = prea[q];
+      }
+    }
+    const long next = unit + gridDim.x;
+    if (next < units) issue(next);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float bt[KS];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int w = 2 * q + mk;
+      const float v = ldsA[mic * V + (w < V ? w : V - 1)];
+      bt[q] = (w < V && mi < V) ? v : 0.f;
+    }
+    f32x16 accA;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+    for (int j0 = 0; j0 < rows; j0 += 16) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int t = j0 + 2 * q + mk;
+        const bool ok = (mi < V) && (t < rows);
+        const int idx = (t < rows ? t : rows - 1) * V + mic;
+        const float a = affine_act(ldsZ[idx], s, h, relu);
+        const float b = ldsG[idx];
+        av[q] = ok ? a : 0.f;
+        bv[q] = ok ? b : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (j0 + 2 * q < rows) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accA, 0, 0, 0);
+    }
+    if (wave > 0 && mi < V) {
+      float* dd = ldsD + (wave - 1) * V * V;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int u = mfma_row(r, mk);
+        if (u < V) dd[u * V + mi] = accA[r];
+      }
+    }
+    float sum_h = 0.f, sum_s = 0.f;
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const int tc = mi < rows ? mi : rows - 1;
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        const int w = 2 * q + mk;
+        const float v = ldsG[tc * V + (w < V ? w : V - 1)];
+        const float a = (w < V && mi < rows) ? v : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt[q], acc, 0, 0, 0);
+      }
+      wave_lds_sync();
+      if (mi < V) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tt = mfma_row(r, mk);
+          if (tt < rows) {
+            const float z = ldsZ[tt * V + mi];
+            const float pre = fmaf(z, s, h);
+            const float dpre = (!relu || pre > 0.f) ? acc[r] : 0.f;
+            sum_h += dpre;
+            sum_s = fmaf(dpre, z, sum_s);
+            ldsZ[tt * V + mi] = dpre * s;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave == 0 && mi < V) {
+      float* __restrict__ dA = dahat + (size_t)unit * V * V;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int u = mfma_row(r, mk);
+        if (u < V) {
+          float v = accA[r];
+          for (int w = 0; w < NW - 1; ++w) v += ldsD[w * V * V + u * V + mi];
+          dA[u * V + mi] = v;
+        }
+      }
+    }
+    {
+      f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dzp + ((size_t)unit * T + wave * HR) * V);
+      const f32x4* l4 = reinterpret_cast<const f32x4*>(ldsZ);
+#pragma unroll
+      for (int q = 0; q < NP4; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4) d4[i] = l4[i];
+      }
+    }
+    sum_s = wave_sum(sum_s);
+    sum_h = wave_sum(sum_h);
+    if (lane == 0) {
+      partial[((size_t)wave * units + unit) * 2 + 0] = sum_s;
+      partial[((size_t)wave * units + unit) * 2 + 1] = sum_h;
+    }
+    wave_lds_sync();
+    unit = next;
+  }
+}
+
 int g_pipe_waves = 0;       // tuning knobs (dsgcn_set_tuning)
 int g_pipe_waves_bwd = 0;
 int g_ablate = 0;
 int g_fwd_direct = 1;
 int g_fwd_chunk = 32;
 int g_bwd_variant = 0;      // 1 = one-shot kernel (A/B)
+int g_bwd_da_lds = 0;       // dAhat leaves through LDS (A/B)
+int g_bwd_pair = 1;         // two waves per unit when 32 < T <= 64
+int g_pair_wgs = 0;
 
 template <int V>
 int launch_fwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat, float* y,
@@ -641,16 +831,38 @@ int launch_fwd(const float* zp, const float* scale, const float* shift, int relu
 }
 
 template <int V>
+int bwd_pair_hr(int T) {      // frames per wave of the multi-wave backward, 0 = not used
+  if (!g_bwd_pair || g_bwd_variant != 0 || T > 64 || (T * V) % 4 != 0) return 0;
+  const int hr = 32;            // 16-frame pieces (4 waves per unit) measured slower: tools/ka_variants.py
+  if (T <= hr || (hr * V) % 4 != 0) return 0;
+  return hr;
+}
+
+template <int V>
 int launch_bwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat, const float* dy,
                float* dzp, float* dahat, float* partial, long units, int KC, int T, hipStream_t st) {
   const int vec = ((T * V) % 4 == 0) ? 1 : 0;
   const size_t lds = (size_t)(2 * 64 * V + V * V) * sizeof(float);
-  if (vec && T <= 64 && g_bwd_variant == 0) {
+  const int hr = bwd_pair_hr<V>(T);
+  if (hr) {
+    const int nw = (T + hr - 1) / hr;
+    const size_t lds2 = (size_t)(2 * nw * hr * V + nw * V * V) * sizeof(float);
+    const int wgs = g_pair_wgs > 0 ? g_pair_wgs : 1536;
+    const long per = (units + wgs - 1) / wgs;
+    const long g = (units + per - 1) / per;
+    hipLaunchKernelGGL((k_aggregate_bwd_pair<V, 32, 2>), dim3((unsigned)g), dim3(64 * nw), lds2, st, zp, scale, shift,
+                       relu, ahat, dy, dzp, dahat, partial, KC, T, units);
+  } else if (vec && T <= 64 && g_bwd_variant == 0) {
+    const size_t lds = (size_t)(2 * T * V + V * V) * sizeof(float);
     int waves = g_pipe_waves_bwd > 0 ? g_pipe_waves_bwd : 2048;
     const long per = (units + waves - 1) / waves;
     const long g = (units + per - 1) / per;
-    hipLaunchKernelGGL((k_aggregate_bwd_pipe<V>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu, ahat,
-                       dy, dzp, dahat, partial, KC, T, units, g_ablate);
+    if (g_bwd_da_lds)
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, true>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+                         ahat, dy, dzp, dahat, partial, KC, T, units, g_ablate);
+    else
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+                         ahat, dy, dzp, dahat, partial, KC, T, units, g_ablate);
   } else {
     hipLaunchKernelGGL((k_aggregate_bwd<V>), dim3((unsigned)units), dim3(64), lds, st, zp, scale, shift, relu, ahat,
                        dy, dzp, dahat, partial, KC, T, vec);
@@ -695,6 +907,9 @@ int dsgcn_set_tuning(int key, int value) {
   if (key == 3) { g_ablate = value; return 0; }
   if (key == 4) { g_fwd_direct = value; return 0; }
   if (key == 5) { g_fwd_chunk = value; return 0; }
+  if (key == 6) { g_bwd_da_lds = value; return 0; }
+  if (key == 7) { g_bwd_pair = value; return 0; }
+  if (key == 8) { g_pair_wgs = value; return 0; }
   return DSGCN_EINVAL;
 }
 
@@ -702,6 +917,18 @@ int dsgcn_set_tuning(int key, int value) {
 int dsgcn_aggregate_fwd_valu(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
                              float* y, int n, int KC, int T, int V, void* stream) {
   return aggregate_fwd_dispatch(zp, scale, shift, relu, ahat, y, n, KC, T, V, 1, stream);
+}
+
+// rows of the backward's `partial` buffer: (rows, KC, 2); the sum over rows gives [d scale | d shift]
+int dsgcn_aggregate_bwd_partial_rows(int n, int T, int V) {
+  int hr = 0;
+  switch (V) {
+    case 25: hr = bwd_pair_hr<25>(T); break;
+    case 17: hr = bwd_pair_hr<17>(T); break;
+    case 18: hr = bwd_pair_hr<18>(T); break;
+    default: break;
+  }
+  return hr ? n * ((T + hr - 1) / hr) : n;
 }
 
 int dsgcn_aggregate_bwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,

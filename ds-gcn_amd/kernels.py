@@ -95,7 +95,8 @@ class _Aggregate(torch.autograd.Function):
         dy = _f32c(dy)
         dzp = torch.empty_like(zp)
         dahat = torch.empty_like(ahat)
-        partial = torch.empty((n, KC, 2), device=zp.device, dtype=torch.float32)
+        rows = native.lib().dsgcn_aggregate_bwd_partial_rows(n, T, V)
+        partial = torch.empty((rows, KC, 2), device=zp.device, dtype=torch.float32)
         rc = native.lib().dsgcn_aggregate_bwd(_ptr(zp), _ptr(scale), _ptr(shift), ctx.relu, _ptr(ahat), _ptr(dy),
                                               _ptr(dzp), _ptr(dahat), _ptr(partial), n, KC, T, V, _stream())
         native.check(rc, 'dsgcn_aggregate_bwd')

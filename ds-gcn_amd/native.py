@@ -29,6 +29,7 @@ SIGNATURES = {
     'dsgcn_aggregate_fwd_valu': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
     'dsgcn_aggregate_fwd_variant': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_st],
     'dsgcn_set_tuning': [c_int, c_int],
+    'dsgcn_aggregate_bwd_partial_rows': [c_int, c_int, c_int],
     'dsgcn_aggregate_bwd': [c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
     'dsgcn_pwconv_plan': [c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                           ctypes.POINTER(ctypes.c_int)],

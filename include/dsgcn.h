@@ -48,6 +48,8 @@ int dsgcn_set_tuning(int key, int value);
 
 /* Backward of the above: dzp (n,KC,T,V), dahat (n,KC,V,V) and partial (n*KC,2) =
  * per-unit [sum dP*mask*zp, sum dP*mask] (the d scale / d shift reductions before the sum over n). */
+/* rows of dsgcn_aggregate_bwd's `partial` buffer (rows, KC, 2): n, or 2n when a unit is split over two waves */
+int dsgcn_aggregate_bwd_partial_rows(int n, int T, int V);
 int dsgcn_aggregate_bwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
                         const float* dy, float* dzp, float* dahat, float* partial, int n, int KC, int T, int V,
                         void* stream);

@@ -16,7 +16,7 @@ for KC, T in [(24, 64), (96, 16)]:
     sets = []
     for _ in range(6):
         zp = torch.randn(n, KC, T, V, device=dev); ah = torch.randn(n, KC, V, V, device=dev) * .2
-        sets.append((zp, ah, torch.empty_like(zp), torch.randn_like(zp), torch.empty_like(zp), torch.empty_like(ah), torch.empty(n * KC, 2, device=dev)))
+        sets.append((zp, ah, torch.empty_like(zp), torch.randn_like(zp), torch.empty_like(zp), torch.empty_like(ah), torch.empty(4 * n * KC, 2, device=dev)))
     sc = torch.rand(KC, device=dev) + .5; sh = torch.randn(KC, device=dev) * .1
     idx = [0]
     def bwd():

@@ -10,7 +10,7 @@ for rep in range(3):
         zp = torch.randn(n, KC, T, V, device=dev); ah = torch.randn(n, KC, V, V, device=dev) * .2
         sc = torch.rand(KC, device=dev) + .5; sh = torch.randn(KC, device=dev) * .1
         y = torch.empty_like(zp); dy = torch.randn_like(zp); dzp = torch.empty_like(zp); dah = torch.empty_like(ah)
-        part = torch.empty(n * KC, 2, device=dev)
+        part = torch.empty(4 * n * KC, 2, device=dev)
         assert lib.dsgcn_aggregate_fwd(zp.data_ptr(), sc.data_ptr(), sh.data_ptr(), 1, ah.data_ptr(), y.data_ptr(), n, KC, T, V, st) == 0
         assert lib.dsgcn_aggregate_bwd(zp.data_ptr(), sc.data_ptr(), sh.data_ptr(), 1, ah.data_ptr(), dy.data_ptr(), dzp.data_ptr(), dah.data_ptr(), part.data_ptr(), n, KC, T, V, st) == 0
     torch.cuda.synchronize()

@@ -32,7 +32,7 @@ for KC, T in shapes:
     for _ in range(6):
         zp = torch.randn(n, KC, T, V, device=dev); ah = torch.randn(n, KC, V, V, device=dev) * .2
         sets.append((zp, ah, torch.empty_like(zp), torch.randn_like(zp), torch.empty_like(zp), torch.empty_like(ah),
-                     torch.empty(n * KC, 2, device=dev)))
+                     torch.empty(4 * n * KC, 2, device=dev)))
     sc = torch.rand(KC, device=dev) + .5; sh = torch.randn(KC, device=dev) * .1
     fb = bench.ka_alg_bytes(n, KC, T, V, False); bb = bench.ka_alg_bytes(n, KC, T, V, True)
     idx = [0]
@@ -59,14 +59,16 @@ for KC, T in shapes:
     t = timeit(cp); line += f'| copy {t:6.1f}us {2*zp.numel()*4/t/1e3:6.0f}GB/s '
     for v, nm in ():
         t = timeit(mk(v)); line += f'| {nm} {t:6.1f}us {fb/t/1e3:6.0f}GB/s '
-    for w in (2048, 3072, 4096):
-        for ch in (64, 32):
+    for w in (3072,):
+        for ch in (32,):
             lib.dsgcn_set_tuning(0, w); lib.dsgcn_set_tuning(5, ch)
             t = timeit(mk(0)); line += f'| p{w}c{ch} {t:5.1f}us {fb/t/1e3:5.0f} '
     lib.dsgcn_set_tuning(5, 32)
     lib.dsgcn_set_tuning(0, 0)
-    for w in (2048,):
-        lib.dsgcn_set_tuning(1, w)
-        t = timeit(bwd); line += f'| bwd{w} {t:6.1f}us {bb/t/1e3:6.0f}GB/s'
-    lib.dsgcn_set_tuning(1, 0)
+    for hr in (0, 1):
+      lib.dsgcn_set_tuning(7, hr)
+      for w in (1536,):
+        lib.dsgcn_set_tuning(8, w)
+        t = timeit(bwd); line += f'| h{hr}w{w} {t:5.1f}us {bb/t/1e3:5.0f}'
+    lib.dsgcn_set_tuning(8, 0); lib.dsgcn_set_tuning(7, 1)
     print(line, flush=True)
