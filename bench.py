@@ -209,7 +209,7 @@ def main():
     native.lib()   # fail loudly if the HIP library is missing
 
     model = build_model().to(device).train()
-    flat = dsgcn_amd.FlatParams(model)
+    flat = dsgcn_amd.FlatParams(model, gather=True)
     dp = dsgcn_amd.FlatDataParallel(flat)
     opt = dsgcn_amd.FlatSGD(flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
 
@@ -225,6 +225,7 @@ def main():
         opt.zero_grad()
         out = model.train_step(batch, None, sync_log_vars=False)
         out['loss'].backward()
+        flat.collect_grads()
         state['loss'] = out['loss'].detach()
 
     def eager_step():

@@ -14,8 +14,13 @@ import torch.distributed as dist
 class FlatParams:
     """Re-homes a module's parameters and grads into contiguous flat buffers (views keep the module API)."""
 
-    def __init__(self, module):
+    def __init__(self, module, gather=False):
+        """gather=False: every ``p.grad`` is a view of the flat gradient buffer and autograd accumulates into it in
+        place (one small add kernel per parameter tensor per step).  gather=True: ``zero_grad`` drops the grads,
+        autograd hands each parameter its gradient tensor as is, and ``collect_grads`` packs them into the flat buffer
+        with a few multi-tensor copies (~360 fewer launches per DS-STGCN step)."""
         self.module = module
+        self.gather = gather
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError('module has no trainable parameters')
@@ -34,9 +39,28 @@ class FlatParams:
                 self.slices.append((off, n))
                 off += n
         self.numel = total
+        self.views = [self.flat_g[off:off + n].view(p.shape) for p, (off, n) in zip(self.params, self.slices)]
 
     def zero_grad(self):
+        if self.gather:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat_g.zero_()
+
+    @torch.no_grad()
+    def collect_grads(self):
+        """gather mode: pack the gradients autograd produced into the flat buffer and re-point every ``p.grad`` at its
+        view (parameters that received none — the dead conv2_se tensors — read as zero).  No-op otherwise."""
+        if not self.gather:
+            return
         self.flat_g.zero_()
+        dst = [v for v, p in zip(self.views, self.params) if p.grad is not None]
+        src = [p.grad for p in self.params if p.grad is not None]
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def check_views(self):
         """True while every p.grad still aliases the flat buffer (autograd accumulates in place)."""

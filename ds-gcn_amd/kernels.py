@@ -51,13 +51,26 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def colsum(t):
-    """Sum over dim 0 of a contiguous fp32 tensor (R, ...) -> (...), fp64 accumulation, one small HIP launch."""
-    R = t.shape[0]
-    out = torch.empty(t.shape[1:], device=t.device, dtype=torch.float32)
-    C = out.numel()
+def _colsum_raw(t, R, C):
+    out = torch.empty(C, device=t.device, dtype=torch.float32)
     native.check(native.lib().dsgcn_colsum(_ptr(t), R, C, _ptr(out), _stream()), 'dsgcn_colsum')
     return out
+
+
+def colsum(t):
+    """Sum over dim 0 of a contiguous fp32 tensor (R, ...) -> (...), fp64 accumulation.  The kernel gives 32 columns
+    to a block, so a tall, narrow input (e.g. 32768 x 25) would run on one CU: it is folded first — rows grouped g at
+    a time into a (R/g, g*C) view, summed, and the g partial rows summed by a second tiny launch."""
+    R = t.shape[0]
+    shape = t.shape[1:]
+    C = t.numel() // max(R, 1)
+    g = 1
+    while R % (2 * g) == 0 and g * C < 8192 and R // (2 * g) >= 16:
+        g *= 2
+    if g > 1:
+        t = _colsum_raw(t, R // g, g * C)
+        R = g
+    return _colsum_raw(t, R, C).view(shape)
 
 
 def _f32c(t):

@@ -92,18 +92,22 @@ def test_two_rank_dp_equals_microbatch_average(tmp_path):
     assert torch.allclose(flat.flat_p, r0['p'], rtol=0, atol=2e-6), (flat.flat_p - r0['p']).abs().max()
 
 
-def test_flat_sgd_matches_torch_sgd():
+@pytest.mark.parametrize('gather', [False, True])
+def test_flat_sgd_matches_torch_sgd(gather):
     torch.manual_seed(0)
-    lin = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
-    ref = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3), torch.nn.Linear(2, 2))   # last: no grad
+    ref = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3), torch.nn.Linear(2, 2))
     ref.load_state_dict(lin.state_dict())
-    flat = D.FlatParams(lin)
+    lin, ref = lin[:2], ref[:2]
+    flat = D.FlatParams(lin, gather=gather)
     opt = D.FlatSGD(flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
     topt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
     x = torch.randn(6, 5)
     for _ in range(3):
         opt.zero_grad()
         lin(x).square().sum().backward()
+        flat.collect_grads()
+        assert flat.check_views()
         opt.step()
         topt.zero_grad()
         ref(x).square().sum().backward()

@@ -388,3 +388,10 @@ def test_tconv_dense(n, Ci, Co, T, V, stride, ks, dil, bn):
 def test_tmean():
     x = torch.randn(4, 3, 20, 25)
     assert rel(K_.tmean(x.cuda()).cpu(), x.mean(2)) < 1e-6
+
+
+@pytest.mark.parametrize('R,C', [(32768, 25), (1664, 192), (128, 48), (7, 3), (4096, 70000 // 64)])
+def test_colsum(R, C):
+    """Column sums incl. the folded two-stage path for tall, narrow inputs (fp64 accumulation: 1e-6 relative)."""
+    t = torch.randn(R, C)
+    assert rel(K_.colsum(t.cuda()).cpu(), t.double().sum(0)) < 1e-6
