@@ -13,11 +13,12 @@ from .evaluation import top_k_accuracy, mean_class_accuracy, confusion_matrix
 from .losses import CrossEntropyLoss
 from .heads import GCNHead, SimpleHead
 from .gcn_units import dgphgcn1, unit_gcn, unit_ctrgcn, CTRGC, Deferred
-from .tcn_units import dgmstcn, unit_tcn, MSTCN
+from .tcn_units import dgmstcn, mstcn, unit_tcn, MSTCN
 from .backbones import DGSTGCN, STGCN, CTRGCN, DGBlock, STGCNBlock, CTRGCNBlock
 from .recognizers import RecognizerGCN, BaseRecognizer
 from . import kernels
 from .data_parallel import FlatParams, FlatDataParallel, shard_batch
 from .train import FlatSGD, cosine_lr
+from .checkpoint import load_checkpoint, save_checkpoint
 
 __version__ = '0.1.0'

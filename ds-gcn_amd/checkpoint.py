@@ -1,0 +1,43 @@
+"""Checkpoint files in the reference's format (mmcv ``save_checkpoint`` as driven by
+pyskl/core/local_runner/epoch_based_sparse_runner.py:145-190): a ``torch.save``d dict
+``{'meta': {...}, 'state_dict': OrderedDict, 'optimizer': {...}}``; DDP-wrapped models carry a ``module.`` key prefix
+(mmcv strips it on load).  Upstream PYSKL / DS-GCN ``.pth`` files load into the classes of this package unchanged
+because the state_dict keys are the reference's (tests/test_host_api.py::test_state_dict_contract)."""
+import time
+from collections import OrderedDict
+
+import torch
+
+
+def _strip_prefix(state_dict, prefix='module.'):
+    if state_dict and all(k.startswith(prefix) for k in state_dict):
+        return OrderedDict((k[len(prefix):], v) for k, v in state_dict.items())
+    return state_dict
+
+
+def load_checkpoint(model, filename, map_location='cpu', strict=False, revise_keys=((r'^module\.', ''),)):
+    """mmcv.runner.load_checkpoint semantics: accepts a bare state_dict or a dict with 'state_dict'; returns the
+    checkpoint dict.  With ``strict=False`` missing / unexpected keys are reported in the returned dict."""
+    import re
+    ckpt = torch.load(filename, map_location=map_location, weights_only=False)
+    if not isinstance(ckpt, dict):
+        raise RuntimeError(f'No state_dict found in checkpoint file {filename}')
+    sd = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
+    for pat, rep in revise_keys:
+        sd = OrderedDict((re.sub(pat, rep, k), v) for k, v in sd.items())
+    res = model.load_state_dict(sd, strict=strict)
+    if isinstance(ckpt, dict) and 'state_dict' in ckpt:
+        ckpt['missing_keys'], ckpt['unexpected_keys'] = list(res.missing_keys), list(res.unexpected_keys)
+    return ckpt
+
+
+def save_checkpoint(model, filename, optimizer=None, meta=None):
+    """Writes {'meta', 'state_dict', 'optimizer'} with CPU tensors, like mmcv.runner.save_checkpoint."""
+    meta = dict(meta or {})
+    meta.setdefault('time', time.asctime())
+    sd = OrderedDict((k, v.detach().cpu()) for k, v in _strip_prefix(model.state_dict()).items())
+    ckpt = {'meta': meta, 'state_dict': sd}
+    if optimizer is not None:
+        ckpt['optimizer'] = optimizer.state_dict()
+    torch.save(ckpt, filename)
+    return filename

@@ -188,8 +188,15 @@ class dgphgcn1(nn.Module):
         ops = kernels.ops()
         if xbar is None:
             xbar = ops.tmean(x)
-        ahat = self.adjacency(xbar)
-        zp, _, ap = conv_bn(x, None, None, None, False, self.pre[0], 1, False, self.pre[1])
+        fork = getattr(ops, 'side_branch', None)
+        if fork is None:
+            ahat = self.adjacency(xbar)
+            zp, _, ap = conv_bn(x, None, None, None, False, self.pre[0], 1, False, self.pre[1])
+        else:
+            with fork(x) as br:                    # K-B beside the `pre` channel mix (independent until K-A)
+                ahat = self.adjacency(xbar)
+            zp, _, ap = conv_bn(x, None, None, None, False, self.pre[0], 1, False, self.pre[1])
+            br.join(ahat)
         y = ops.aggregate(zp, ap, True, ahat)
         zo, _, ao = conv_bn(y, None, None, None, False, self.post, 1, False, self.bn)
         if self.down is None:

@@ -51,6 +51,46 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_side_streams = {}
+import os as _os
+OVERLAP = _os.environ.get('DSGCN_OVERLAP', '1') != '0'     # run K-B (dynamic adjacency: one block per sample, half the CUs) beside the `pre` channel mix
+
+
+class side_branch:
+    """``with side_branch(t): ...`` runs the body on a second HIP stream that first waits for the current one, and
+    joins it back on exit — the forked work overlaps whatever the main stream launches until ``join()``.  Autograd
+    replays each node's backward on the stream of its forward, so the backward overlaps the same way.  Capturable in
+    a hipGraph (fork/join become graph edges)."""
+
+    def __init__(self, like):
+        self.enabled = OVERLAP and like.is_cuda
+        if self.enabled:
+            dev = like.device
+            if dev not in _side_streams:
+                _side_streams[dev] = torch.cuda.Stream(device=dev)
+            self.side = _side_streams[dev]
+            self.main = torch.cuda.current_stream(dev)
+
+    def __enter__(self):
+        if self.enabled:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        """Make the main stream wait for the side work; ``tensors`` were produced on the side stream."""
+        if self.enabled:
+            self.main.wait_stream(self.side)
+            for t in tensors:
+                t.record_stream(self.main)
+
+
 def _colsum_raw(t, R, C):
     out = torch.empty(C, device=t.device, dtype=torch.float32)
     native.check(native.lib().dsgcn_colsum(_ptr(t), R, C, _ptr(out), _stream()), 'dsgcn_colsum')

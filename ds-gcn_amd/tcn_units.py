@@ -171,6 +171,50 @@ class dgmstcn(nn.Module):
         pass
 
 
+class mstcn(dgmstcn):
+    """ST-GCN++'s multi-scale temporal unit (reference: tcn.py:104-177) = ``dgmstcn`` without the global joint: same
+    branches, ``cat`` -> BN -> ReLU -> 1x1 -> BN.  Same constructor (minus ``num_joints``) and state_dict keys."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None, dropout=0.,
+                 ms_cfg=[(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1'], stride=1):
+        super().__init__(in_channels, out_channels, mid_channels=mid_channels, dropout=dropout, ms_cfg=ms_cfg,
+                         stride=stride)
+        del self.add_coeff            # not a parameter of the reference's mstcn
+        del self.num_joints
+
+    def forward_deferred(self, g):
+        ops = kernels.ops()
+        d = as_deferred(g)
+        n, _, T, V = d.x1.shape
+        convs = self._first_convs()
+        wb = torch.cat([c.weight.flatten(1) for c in convs], 0)
+        bb = torch.cat([c.bias for c in convs], 0)
+        bns = [b[1] for b in self.branches if not isinstance(b, nn.Conv2d)]
+        if any(_need_stats(bn) for bn in bns):
+            gamma = torch.cat([bn.weight for bn in bns])
+            beta = torch.cat([bn.bias for bn in bns])
+            z, _, scale, shift, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, False, gamma, beta,
+                                                   bns[0].eps, self.n_act, True)
+            c0 = 0
+            for bn in bns:
+                record_running(bn, m[c0:c0 + bn.num_features], var[c0:c0 + bn.num_features], n * T * V)
+                c0 += bn.num_features
+        else:
+            z = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, False)[0]
+            aff = [eval_affine(bn) for bn in bns]
+            rest = self.out_channels - self.n_act
+            scale = torch.cat([a[0] for a in aff] + ([z.new_ones(rest)] if rest else []))
+            shift = torch.cat([a[1] for a in aff] + ([z.new_zeros(rest)] if rest else []))
+        tconvs = [b[3].conv for b in self.branches if not isinstance(b, nn.Conv2d) and isinstance(b[3], unit_tcn)]
+        tw, tb = [c.weight for c in tconvs], [c.bias for c in tconvs]
+        bn1 = self.transform[0]
+        f, a1 = op_bn(bn1, lambda g_, b_, eps, want: ops.temporal_branches_bn(
+            z, scale, shift, self.n_act, self.ms_cfg, self.widths, tw, tb, self.stride, g_, b_, eps, want),
+            lambda f: f.shape[0] * f.shape[2] * f.shape[3])
+        zt, _, a2 = conv_bn(f, a1, None, None, True, self.transform[2], 1, False, self.bn)
+        return Deferred(zt, a2, None, None, False)
+
+
 class MSTCN(nn.Module):
     """CTR-GCN's multi-scale temporal unit (reference: pyskl/models/gcns/utils/msg3d_utils.py:64-149): per dilation
     [1x1 -> BN -> ReLU -> (k,1) dilated conv -> BN], [1x1 -> BN -> ReLU -> max-pool(3,1) -> BN], [1x1 stride -> BN];

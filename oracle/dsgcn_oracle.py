@@ -250,6 +250,25 @@ def dgmstcn_forward(x, sd, stride=1, ms_cfg=((3, 1), (3, 2), (3, 3), (3, 4), ('m
     return y
 
 
+def mstcn_forward(x, sd, stride=1, ms_cfg=((3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1'), training=True):
+    """Multi-scale temporal unit of ST-GCN++ (tcn.py:104-177): dgmstcn without the global joint."""
+    outs = []
+    for j, cfg in enumerate(ms_cfg):
+        p = f'branches.{j}.'
+        if cfg == '1x1':
+            outs.append(_conv1x1(x, sd[p + 'weight'], sd[p + 'bias'], stride))        # tcn.py:137
+            continue
+        h = F.relu(_bn(_conv1x1(x, sd[p + '0.weight'], sd[p + '0.bias']), sd, p + '1.', training))
+        if cfg[0] == 'max':
+            outs.append(F.max_pool2d(h, (cfg[1], 1), (stride, 1), (1, 0)))            # tcn.py:141-145
+        else:
+            outs.append(unit_tcn_forward(h, _sub(sd, p + '3.'), cfg[0], stride, cfg[1], training, norm=False))
+    f = torch.cat(outs, 1)                                                            # tcn.py:167
+    h = F.relu(_bn(f, sd, 'transform.0.', training))
+    zt = _conv1x1(h, sd['transform.2.weight'], sd['transform.2.bias'])               # tcn.py:156-157,168
+    return _bn(zt, sd, 'bn.', training)                                               # tcn.py:173 (dropout p=0)
+
+
 # ----------------------------------------------------------------------------------------
 # DGBlock / DGSTGCN / head / loss
 # ----------------------------------------------------------------------------------------
@@ -329,18 +348,27 @@ def recognizer_forward_train(keypoint, label, sd, node_type, edge_type, plan, tr
 # ST-GCN units (gcn.py:22-97, tcn.py:10-37, stgcn.py:16-68)   SURVEY App. A.3
 # ----------------------------------------------------------------------------------------
 
-def unit_gcn_forward(x, sd, training=True):
+def unit_gcn_forward(x, sd, training=True, with_res=False):
     n, Ci, T, V = x.shape
     A = sd['A']
     K = A.shape[0]
     h = _conv1x1(x, sd['conv.weight'], sd['conv.bias']).view(n, K, -1, T, V)          # gcn.py:86-87
     y = torch.einsum('nkctv,kvw->nctw', h, A)                                         # gcn.py:88
-    return F.relu(_bn(y, sd, 'bn.', training))                                        # gcn.py:94
+    y = _bn(y, sd, 'bn.', training)
+    if with_res:                                                                      # gcn.py:57-66,70,94
+        if 'down.0.weight' in sd:
+            y = y + _bn(_conv1x1(x, sd['down.0.weight'], sd['down.0.bias']), sd, 'down.1.', training)
+        else:
+            y = y + x
+    return F.relu(y)                                                                  # gcn.py:94
 
 
-def stgcn_block_forward(x, sd, stride, residual, training=True):
-    g = unit_gcn_forward(x, _sub(sd, 'gcn.'), training)
-    t = unit_tcn_forward(g, _sub(sd, 'tcn.'), 9, stride, 1, training)                 # stgcn.py:45-46 (p=0)
+def stgcn_block_forward(x, sd, stride, residual, training=True, with_res=False, tcn_type='unit_tcn'):
+    g = unit_gcn_forward(x, _sub(sd, 'gcn.'), training, with_res)
+    if tcn_type == 'mstcn':
+        t = mstcn_forward(g, _sub(sd, 'tcn.'), stride, training=training)             # stgcn.py:47-48 (ST-GCN++)
+    else:
+        t = unit_tcn_forward(g, _sub(sd, 'tcn.'), 9, stride, 1, training)             # stgcn.py:45-46 (p=0)
     if not residual:
         res = 0
     elif 'residual.conv.weight' in sd:
@@ -350,13 +378,13 @@ def stgcn_block_forward(x, sd, stride, residual, training=True):
     return F.relu(t + res)
 
 
-def stgcn_forward(x, sd, plan, training=True):
+def stgcn_forward(x, sd, plan, training=True, with_res=False, tcn_type='unit_tcn'):
     N, M, T, V, C = x.shape
     h = x.permute(0, 1, 3, 4, 2).contiguous().view(N * M, V * C, T)
     h = _bn(h, sd, 'data_bn.', training)
     h = h.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
     for i, (ci, co, stride, residual) in enumerate(plan):
-        h = stgcn_block_forward(h, _sub(sd, f'gcn.{i}.'), stride, residual, training)
+        h = stgcn_block_forward(h, _sub(sd, f'gcn.{i}.'), stride, residual, training, with_res, tcn_type)
     return h.reshape((N, M) + h.shape[1:])
 
 
@@ -440,9 +468,12 @@ def ctrgcn_forward(x, sd, plan, training=True):
 
 
 def recognizer_forward_train_backbone(backbone, keypoint, label, sd, plan, training=True):
-    """forward_train with the ST-GCN ('stgcn') or CTR-GCN ('ctrgcn') backbone.  Returns (logits, loss)."""
+    """forward_train with the ST-GCN ('stgcn'), ST-GCN++ ('stgcnpp') or CTR-GCN ('ctrgcn') backbone -> (logits, loss)."""
     assert keypoint.shape[1] == 1
-    fwd = {'stgcn': stgcn_forward, 'ctrgcn': ctrgcn_forward}[backbone]
-    feat = fwd(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training)
+    if backbone == 'stgcnpp':        # ST-GCN++ (configs/stgcn++): gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn'
+        feat = stgcn_forward(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training, True, 'mstcn')
+    else:
+        fwd = {'stgcn': stgcn_forward, 'ctrgcn': ctrgcn_forward}[backbone]
+        feat = fwd(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training)
     logits = gcn_head_forward(feat, _sub(sd, 'cls_head.'))
     return logits, F.cross_entropy(logits, label.squeeze(-1))

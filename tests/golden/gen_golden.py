@@ -111,6 +111,9 @@ def unit_dgmstcn():
 def other_cfg(kind, num_classes=60, **bk):
     if kind == 'ctrgcn':
         backbone = dict(type='CTRGCN', gcn_type='unit_ctrgcn', graph_cfg=dict(layout='nturgb+d', mode='spatial'))
+    elif kind == 'stgcnpp':
+        backbone = dict(type='STGCN', gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn',
+                        graph_cfg=dict(layout='nturgb+d', mode='spatial'))
     else:
         backbone = dict(type='STGCN', graph_cfg=dict(layout='nturgb+d', mode='stgcn_spatial'))
     backbone.update(bk)
@@ -175,7 +178,7 @@ def reduced_model(cfg=None, name='model_reduced', seed=3):
 
 
 def reduced_other_models():
-    for kind in ('ctrgcn', 'stgcn'):
+    for kind in ('ctrgcn', 'stgcn', 'stgcnpp'):
         cfg = other_cfg(kind, 12, base_channels=16, num_stages=4, inflate_stages=[3], down_stages=[3])
         cfg['cls_head']['in_channels'] = 32
         reduced_model(cfg, 'model_reduced_' + kind, seed=4)
@@ -191,7 +194,11 @@ def manifests():
                'backbone.gcn.9.tcn.conv.weight', 'cls_head.fc_cls.weight')
     for name, cfg, keys in (('dsstgcn_ntu60', ds_cfg(60), ds_keys), ('dsstgcn_ntu120', ds_cfg(120), ds_keys),
                             ('dsstgcn_k400_coco', ds_cfg(400, 'coco'), ds_keys),
-                            ('ctrgcn_ntu60', other_cfg('ctrgcn'), ctr_keys), ('stgcn_ntu60', other_cfg('stgcn'), st_keys)):
+                            ('ctrgcn_ntu60', other_cfg('ctrgcn'), ctr_keys), ('stgcn_ntu60', other_cfg('stgcn'), st_keys),
+                            ('stgcnpp_ntu60', other_cfg('stgcnpp'), ('backbone.gcn.0.gcn.conv.weight',
+                                                                      'backbone.gcn.4.gcn.down.0.weight',
+                                                                      'backbone.gcn.9.tcn.transform.2.weight',
+                                                                      'cls_head.fc_cls.weight'))):
         np.random.seed(0)
         torch.manual_seed(0)
         m = R.builder.build_model(cfg)

@@ -66,6 +66,9 @@ def test_graph_matches_golden():
 def other_cfg(kind, num_classes=60, **bk):
     if kind == 'ctrgcn':
         backbone = dict(type='CTRGCN', gcn_type='unit_ctrgcn', graph_cfg=dict(layout='nturgb+d', mode='spatial'))
+    elif kind == 'stgcnpp':
+        backbone = dict(type='STGCN', gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn',
+                        graph_cfg=dict(layout='nturgb+d', mode='spatial'))
     else:
         backbone = dict(type='STGCN', graph_cfg=dict(layout='nturgb+d', mode='stgcn_spatial'))
     backbone.update(bk)
@@ -75,7 +78,7 @@ def other_cfg(kind, num_classes=60, **bk):
 
 @pytest.mark.parametrize('name,cfg', [('dsstgcn_ntu60', ds_cfg(60, 'nturgb+d')), ('dsstgcn_ntu120', ds_cfg(120, 'nturgb+d')),
                                       ('dsstgcn_k400_coco', ds_cfg(400, 'coco')), ('ctrgcn_ntu60', other_cfg('ctrgcn')),
-                                      ('stgcn_ntu60', other_cfg('stgcn'))])
+                                      ('stgcn_ntu60', other_cfg('stgcn')), ('stgcnpp_ntu60', other_cfg('stgcnpp'))])
 def test_state_dict_contract(name, cfg):
     """Same keys, order, shapes, dtypes — and the same initial values under the same seeds — as the reference."""
     with open(os.path.join(GOLD, 'state_dict_manifest.json')) as f:
@@ -101,7 +104,7 @@ def _reduced_model(name='model_reduced'):
     return z, m
 
 
-@pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn'])
+@pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn', 'model_reduced_stgcnpp'])
 def test_fused_wiring_against_golden_cpu(name):
     """forward_train through the deferred-BN op chain (torch op namespace) == the reference's logits / loss / grads."""
     z, m = _reduced_model(name)
@@ -156,3 +159,21 @@ def test_train_step_api_and_eval_numpy():
 def test_top_k_accuracy():
     s = np.array([[.1, .7, .2], [.5, .3, .2], [.2, .3, .5]])
     assert D.top_k_accuracy(s, [1, 1, 2], (1, 2)) == [2 / 3, 1.0]
+
+
+def test_checkpoint_roundtrip_mmcv_format(tmp_path):
+    """{'meta','state_dict','optimizer'} files, with or without the DDP 'module.' prefix, load back bit-exactly."""
+    z, m = _reduced_model()
+    path = str(tmp_path / 'epoch_1.pth')
+    D.save_checkpoint(m, path, meta=dict(epoch=1, iter=10))
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {'meta', 'state_dict'} and ck['meta']['epoch'] == 1
+    torch.save({'meta': {}, 'state_dict': {'module.' + k: v for k, v in ck['state_dict'].items()}}, path)   # as DDP saves it
+    _, m2 = _reduced_model()
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.zero_()
+    out = D.load_checkpoint(m2, path, strict=True)
+    assert out['missing_keys'] == [] and out['unexpected_keys'] == []
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k

@@ -23,7 +23,7 @@ def test_native_library_is_loaded():
         assert 'libdsgcn.so' in f.read()           # the in-tree HIP library really is the code that runs
 
 
-@pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn'])
+@pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn', 'model_reduced_stgcnpp'])
 def test_reduced_model_vs_golden(name):
     """DS-STGCN, classic CTR-GCN and ST-GCN (reduced widths) against the reference's committed outputs."""
     z = load(name + '.npz')
@@ -79,7 +79,7 @@ def test_full_model_vs_oracle(layout, V, T, classes):
     assert len(dead) == 20 and all('conv2_se' in k for k in dead)          # reference quirk Q1
 
 
-@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn'])
+@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn', 'stgcnpp'])
 def test_full_other_backbones_vs_oracle(kind):
     """Full-width classic CTR-GCN (BASELINE config 4) and vanilla ST-GCN (config 1), 2 clips, against the CPU oracle."""
     from test_host_api import other_cfg

@@ -98,9 +98,10 @@ def test_reduced_model_fp64_and_fp32():
     assert abs(loss32.item() - float(z['loss_f32'])) < 1e-5
 
 
-@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn'])
+@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn', 'stgcnpp'])
 def test_reduced_other_backbones(kind):
-    """ST-GCN (unit_gcn + unit_tcn k=9) and classic CTR-GCN (unit_ctrgcn + MSTCN) end to end against the reference."""
+    """ST-GCN (unit_gcn + unit_tcn k=9), ST-GCN++ (with_res + mstcn) and classic CTR-GCN (unit_ctrgcn + MSTCN) end to end
+    against the reference."""
     z = load(f'model_reduced_{kind}.npz')
     with open(os.path.join(GOLD, f'model_reduced_{kind}_cfg.json')) as f:
         bk = json.load(f)['backbone']
