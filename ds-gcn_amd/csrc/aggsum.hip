@@ -250,15 +250,368 @@ __global__ __launch_bounds__(64) void k_aggsum_bwd(const float* __restrict__ p, 
   }
 }
 
+// ---- pipelined forms (T*V % 4 == 0) -----------------------------------------------------------------------------
+// Forward: persistent single-wave workgroups walk (unit, 32-frame chunk) items; inside an item the K subset planes
+// stream through LDS one after the other into the same accumulator tile, and the NEXT plane / adjacency (of this
+// item or of the wave's next item) is already in flight while the matrix core works on the current one.
+// partial has one row per chunk: [chunk][unit][2].
+template <int V>
+__global__ __launch_bounds__(64) void k_aggsum_fwd_pipe(const float* __restrict__ p, const float* __restrict__ ahat,
+                                                        long a_ns, long a_ks, long a_cs, float* __restrict__ y,
+                                                        float* __restrict__ partial, int K, int Co, int T, int chunks,
+                                                        long items, long units) {
+  constexpr int KS = (V + 1) / 2;
+  constexpr int CH = 32;
+  constexpr int NP4 = (CH * V / 4 + 63) / 64;
+  constexpr int NA = (V * V + 63) / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldsP = lds;
+  float* ldsA = lds + CH * V;
+  const int lane = threadIdx.x;
+  const int mi = lane & 31, mk = lane >> 5;
+  const int mic = mi < V ? mi : V - 1;
+  f32x4 pre[NP4];
+  float prea[NA];
+
+  auto issue = [&](long item, int k) {
+    const long unit = item / chunks;
+    const int t0 = (int)(item - unit * chunks) * CH;
+    const int c4 = (min(CH, T - t0) * V) >> 2;
+    const long n = unit / Co;
+    const int c = (int)(unit - n * Co);
+    const size_t plane = ((size_t)n * K + k) * Co + c;
+    const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(p + (plane * T + t0) * V);
+    const float* __restrict__ A = ahat + n * a_ns + k * a_ks + c * a_cs;
+#pragma unroll
+    for (int q = 0; q < NP4; ++q) {
+      const int i = lane + q * 64;
+      if (i < c4) pre[q] = s4[i];
+    }
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int i = lane + q * 64;
+      if (i < V * V) prea[q] = A[i];
+    }
+  };
+
+  long item = blockIdx.x;
+  int k = 0;
+  if (item < items) issue(item, 0);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  while (item < items) {
+    const long unit = item / chunks;
+    const int ch = (int)(item - unit * chunks);
+    const int t0 = ch * CH;
+    const int rows = min(CH, T - t0);
+    const int c4 = (rows * V) >> 2;
+    {
+      f32x4* l4 = reinterpret_cast<f32x4*>(ldsP);
+#pragma unroll
+      for (int q = 0; q < NP4; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4) l4[i] = pre[q];
+      }
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        const int i = lane + q * 64;
+        if (i < V * V) ldsA[i] = prea[q];
+      }
+    }
+    int nk = k + 1;
+    long nitem = item;
+    if (nk == K) { nk = 0; nitem = item + gridDim.x; }
+    if (nitem < items) issue(nitem, nk);
+    wave_lds_sync();
+    {
+      float b[KS];
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        const int u = 2 * q + mk;
+        const float v = ldsA[(u < V ? u : V - 1) * V + mic];
+        b[q] = (u < V && mi < V) ? v : 0.f;
+      }
+      const int tc = mi < rows ? mi : rows - 1;
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        const int u = 2 * q + mk;
+        const float v = ldsP[tc * V + (u < V ? u : V - 1)];
+        const float a = (u < V && mi < rows) ? v : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[q], acc, 0, 0, 0);
+      }
+    }
+    if (k == K - 1) {
+      float* __restrict__ yo = y + ((size_t)unit * T + t0) * V;
+      float sum = 0.f, sq = 0.f;
+      if (mi < V) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = as_row(r, mk);
+          if (t < rows) {
+            const float v = acc[r];
+            yo[t * V + mi] = v;
+            sum += v;
+            sq = fmaf(v, v, sq);
+          }
+        }
+      }
+      if (partial) {
+        sum = wave_sum(sum);
+        sq = wave_sum(sq);
+        if (lane == 0) {
+          partial[((size_t)ch * units + unit) * 2 + 0] = sum;
+          partial[((size_t)ch * units + unit) * 2 + 1] = sq;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    }
+    wave_lds_sync();
+    item = nitem;
+    k = nk;
+  }
+}
+
+// Backward: NW waves per unit (32 frames each, NW = ceil(T/32) <= 2).  G is staged once per unit, then the K subsets
+// stream through: per subset each wave forms its part of dAhat_k = P_k^T G and its rows of dP_k = G Ahat_k^T.
+// PER_UNIT: dAhat_k is summed over the waves through LDS and written per (n,c) (CTR-GCN).  Otherwise (shared A,
+// K == 3) every wave keeps three running dA_k accumulators over all the units it walks and writes them once at
+// the end: pieces[(wg*NW + wave)][k][V*V] -> dsgcn_colsum.
+template <int V, int NW, bool PER_UNIT>
+__global__ __launch_bounds__(64 * NW) void k_aggsum_bwd_pipe(const float* __restrict__ p, const float* __restrict__ ahat,
+                                                             long a_ns, long a_ks, long a_cs,
+                                                             const float* __restrict__ gy, const float* __restrict__ y,
+                                                             const float* __restrict__ A0, const float* __restrict__ B0,
+                                                             float* __restrict__ dp, float* __restrict__ dahat,
+                                                             long d_ns, long d_ks, long d_cs, int K, int Co, int T,
+                                                             long units) {
+  constexpr int KS = (V + 1) / 2;
+  constexpr int HR = 32;
+  constexpr int NP4 = (HR * V / 4 + 63) / 64;
+  constexpr int AH = (V * V + NW - 1) / NW;
+  constexpr int NAH = (AH + 63) / 64;
+  constexpr int KACC = PER_UNIT ? 1 : 3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* ldsZ = lds + wave * HR * V;
+  float* ldsG = lds + NW * HR * V + wave * HR * V;
+  float* ldsA = lds + 2 * NW * HR * V;
+  float* ldsD = ldsA + V * V;
+  const int mi = lane & 31, mk = lane >> 5;
+  const int mic = mi < V ? mi : V - 1;
+  const int rows = min(HR, T - wave * HR);
+  const int c4 = (rows * V) >> 2;
+  const int a0 = wave * AH, a1 = min(V * V, a0 + AH);
+  const bool has_y = (y != nullptr) && (B0 != nullptr);
+  f32x4 prez[NP4], preg[NP4], prey[NP4];
+  float prea[NAH];
+  f32x16 accS[KACC];
+#pragma unroll
+  for (int j = 0; j < KACC; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accS[j][i] = 0.f;
+
+  auto issueG = [&](long unit) {
+    const size_t off = ((size_t)unit * T + wave * HR) * V;
+    const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(gy + off);
+    const f32x4* __restrict__ y4 = reinterpret_cast<const f32x4*>((has_y ? y : gy) + off);
+#pragma unroll
+    for (int q = 0; q < NP4; ++q) {
+      const int i = lane + q * 64;
+      if (i < c4) { preg[q] = g4[i]; if (has_y) prey[q] = y4[i]; }
+    }
+  };
+  auto issueK = [&](long unit, int k) {
+    const long n = unit / Co;
+    const int c = (int)(unit - n * Co);
+    const size_t plane = ((size_t)n * K + k) * Co + c;
+    const f32x4* __restrict__ z4 = reinterpret_cast<const f32x4*>(p + (plane * T + wave * HR) * V);
+    const float* __restrict__ A = ahat + n * a_ns + k * a_ks + c * a_cs;
+#pragma unroll
+    for (int q = 0; q < NP4; ++q) {
+      const int i = lane + q * 64;
+      if (i < c4) prez[q] = z4[i];
+    }
+#pragma unroll
+    for (int q = 0; q < NAH; ++q) {
+      const int i = a0 + lane + q * 64;
+      if (i < a1) prea[q] = A[i];
+    }
+  };
+
+  long unit = blockIdx.x;
+  if (unit < units) { issueG(unit); issueK(unit, 0); }
+  while (unit < units) {
+    const long n = unit / Co;
+    const int c = (int)(unit - n * Co);
+    const float ca = A0 ? A0[c] : 0.f, cb = has_y ? B0[c] : 0.f;
+    {
+      f32x4* lg = reinterpret_cast<f32x4*>(ldsG);
+#pragma unroll
+      for (int q = 0; q < NP4; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4) {
+          f32x4 g = preg[q];
+          if (has_y) {
+            const f32x4 yy = prey[q];
+            g.x += fmaf(cb, yy.x, ca); g.y += fmaf(cb, yy.y, ca); g.z += fmaf(cb, yy.z, ca); g.w += fmaf(cb, yy.w, ca);
+          } else {
+            g.x += ca; g.y += ca; g.z += ca; g.w += ca;
+          }
+          lg[i] = g;
+        }
+      }
+    }
+    const long next = unit + gridDim.x;
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+      {
+        f32x4* lz = reinterpret_cast<f32x4*>(ldsZ);
+#pragma unroll
+        for (int q = 0; q < NP4; ++q) {
+          const int i = lane + q * 64;
+          if (i < c4) lz[i] = prez[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NAH; ++q) {
+          const int i = a0 + lane + q * 64;
+          if (i < a1) ldsA[i] = prea[q];
+        }
+      }
+      if (k + 1 < K) {
+        issueK(unit, k + 1);
+      } else if (next < units) {
+        issueG(next);
+        issueK(next, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (NW > 1) __builtin_amdgcn_s_barrier(); else __builtin_amdgcn_wave_barrier();
+      float bt[KS];
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        const int w = 2 * q + mk;
+        const float v = ldsA[mic * V + (w < V ? w : V - 1)];
+        bt[q] = (w < V && mi < V) ? v : 0.f;
+      }
+      f32x16 accA;
+      if (PER_UNIT) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+      } else {
+        accA = k == 0 ? accS[0] : (k == 1 ? accS[KACC > 1 ? 1 : 0] : accS[KACC > 2 ? 2 : 0]);
+      }
+      for (int j0 = 0; j0 < rows; j0 += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int t = j0 + 2 * q + mk;
+          const bool ok = (mi < V) && (t < rows);
+          const int idx = (t < rows ? t : rows - 1) * V + mic;
+          const float a = ldsZ[idx], b = ldsG[idx];
+          av[q] = ok ? a : 0.f;
+          bv[q] = ok ? b : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (j0 + 2 * q < rows) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accA, 0, 0, 0);
+      }
+      if (!PER_UNIT) {
+        if (k == 0) accS[0] = accA;
+        else if (k == 1) accS[KACC > 1 ? 1 : 0] = accA;
+        else accS[KACC > 2 ? 2 : 0] = accA;
+      } else if (NW > 1 && wave > 0 && mi < V) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int u = as_row(r, mk);
+          if (u < V) ldsD[u * V + mi] = accA[r];
+        }
+      }
+      {
+        const size_t plane = ((size_t)n * K + k) * Co + c;
+        float* __restrict__ dpo = dp + (plane * T + wave * HR) * V;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const int tc = mi < rows ? mi : rows - 1;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const int w = 2 * q + mk;
+          const float v = ldsG[tc * V + (w < V ? w : V - 1)];
+          const float a = (w < V && mi < rows) ? v : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt[q], acc, 0, 0, 0);
+        }
+        if (mi < V) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int tt = as_row(r, mk);
+            if (tt < rows) dpo[tt * V + mi] = acc[r];
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (NW > 1) __builtin_amdgcn_s_barrier(); else __builtin_amdgcn_wave_barrier();
+      if (PER_UNIT && wave == 0 && mi < V) {
+        float* __restrict__ dA = dahat + n * d_ns + k * d_ks + c * d_cs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int u = as_row(r, mk);
+          if (u < V) dA[u * V + mi] = accA[r] + (NW > 1 ? ldsD[u * V + mi] : 0.f);
+        }
+      }
+    }
+    unit = next;
+  }
+  if (!PER_UNIT && mi < V) {
+    float* __restrict__ out = dahat + ((size_t)blockIdx.x * NW + wave) * 3 * V * V;
+#pragma unroll
+    for (int j = 0; j < KACC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int u = as_row(r, mk);
+        if (u < V) out[(size_t)j * V * V + u * V + mi] = accS[j][r];
+      }
+  }
+}
+
+int g_as_pipe = 1;         // 0: one-shot kernels only (A/B)
+int g_as_waves_fwd = 0;
+int g_as_wgs_bwd = 0;
+
+template <int V>
+bool as_pipe_ok(int T) { return g_as_pipe && (T * V) % 4 == 0 && (32 * V) % 4 == 0; }
+
+inline long as_grid(long items, int want) {
+  const long per = (items + want - 1) / want;
+  return (items + per - 1) / per;
+}
+
 template <int V>
 int as_launch_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long a_cs, float* y, float* partial, int n,
                   int K, int Co, int T, hipStream_t st) {
   const int vec = ((T * V) % 4 == 0) ? 1 : 0;
-  const size_t lds = (size_t)(64 * V + V * V) * sizeof(float);
-  hipLaunchKernelGGL((k_aggsum_fwd<V>), dim3((unsigned)((long)n * Co)), dim3(64), lds, st, p, ahat, a_ns, a_ks, a_cs, y,
-                     partial, K, Co, T, vec);
+  if (as_pipe_ok<V>(T)) {
+    const int chunks = (T + 31) / 32;
+    const long units = (long)n * Co, items = units * chunks;
+    const long g = as_grid(items, g_as_waves_fwd > 0 ? g_as_waves_fwd : 3072);
+    const size_t lds = (size_t)(32 * V + V * V) * sizeof(float);
+    hipLaunchKernelGGL((k_aggsum_fwd_pipe<V>), dim3((unsigned)g), dim3(64), lds, st, p, ahat, a_ns, a_ks, a_cs, y,
+                       partial, K, Co, T, chunks, items, units);
+  } else {
+    const size_t lds = (size_t)(64 * V + V * V) * sizeof(float);
+    hipLaunchKernelGGL((k_aggsum_fwd<V>), dim3((unsigned)((long)n * Co)), dim3(64), lds, st, p, ahat, a_ns, a_ks, a_cs,
+                       y, partial, K, Co, T, vec);
+  }
   DSGCN_LAUNCH_CHECK();
   return 0;
+}
+
+// pieces rows of the shared-A pipelined backward (0: the one-shot kernel writes per-(n,c) pieces instead)
+template <int V>
+long as_bwd_piece_rows(int n, int K, int Co, int T) {
+  if (!as_pipe_ok<V>(T) || T > 64 || K != 3) return 0;
+  const int nw = T > 32 ? 2 : 1;
+  return as_grid((long)n * Co, g_as_wgs_bwd > 0 ? g_as_wgs_bwd : (nw == 2 ? 1536 : 2048)) * nw;
 }
 
 template <int V>
@@ -266,9 +619,23 @@ int as_launch_bwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
                   const float* A0, const float* B0, float* dp, float* dahat, long d_ns, long d_ks, long d_cs, int n,
                   int K, int Co, int T, hipStream_t st) {
   const int vec = ((T * V) % 4 == 0) ? 1 : 0;
-  const size_t lds = (size_t)(128 * V + V * V) * sizeof(float);
-  hipLaunchKernelGGL((k_aggsum_bwd<V>), dim3((unsigned)((long)n * Co)), dim3(64), lds, st, p, ahat, a_ns, a_ks, a_cs, gy,
-                     y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, K, Co, T, vec);
+  const bool shared = (a_ns == 0 && a_cs == 0);
+  const long units = (long)n * Co;
+  if (as_pipe_ok<V>(T) && T <= 64 && (!shared || K == 3)) {
+    const int nw = T > 32 ? 2 : 1;
+    const long g = as_grid(units, g_as_wgs_bwd > 0 ? g_as_wgs_bwd : (nw == 2 ? 1536 : 2048));
+    const size_t lds = (size_t)(2 * nw * 32 * V + 2 * V * V) * sizeof(float);
+#define AS_BWD(NWV, PU)                                                                                             \
+  hipLaunchKernelGGL((k_aggsum_bwd_pipe<V, NWV, PU>), dim3((unsigned)g), dim3(64 * NWV), lds, st, p, ahat, a_ns, a_ks, \
+                     a_cs, gy, y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, K, Co, T, units)
+    if (nw == 2) { if (shared) AS_BWD(2, false); else AS_BWD(2, true); }
+    else { if (shared) AS_BWD(1, false); else AS_BWD(1, true); }
+#undef AS_BWD
+  } else {
+    const size_t lds = (size_t)(128 * V + V * V) * sizeof(float);
+    hipLaunchKernelGGL((k_aggsum_bwd<V>), dim3((unsigned)units), dim3(64), lds, st, p, ahat, a_ns, a_ks, a_cs, gy, y,
+                       A0, B0, dp, dahat, d_ns, d_ks, d_cs, K, Co, T, vec);
+  }
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -301,6 +668,36 @@ int dsgcn_aggsum_bwd(const float* p, const float* ahat, long a_ns, long a_ks, lo
     case 18: return as_launch_bwd<18>(p, ahat, a_ns, a_ks, a_cs, gy, y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, n, K, Co, T, st);
     default: return DSGCN_EUNSUPPORTED;
   }
+}
+
+// rows of the forward's `partial` buffer (rows, Co, 2)
+int dsgcn_aggsum_partial_rows(int n, int T, int V) {
+  bool pipe = false;
+  switch (V) {
+    case 25: pipe = as_pipe_ok<25>(T); break;
+    case 17: pipe = as_pipe_ok<17>(T); break;
+    case 18: pipe = as_pipe_ok<18>(T); break;
+    default: break;
+  }
+  return pipe ? n * ((T + 31) / 32) : n;
+}
+
+// Shared adjacency (a_ns == a_cs == 0): rows R > 0 means the backward writes dahat as (R, K, V, V) per-wave pieces
+// (strides ignored); 0 means per-(n,c) pieces through the d_* strides.
+int dsgcn_aggsum_bwd_piece_rows(int n, int K, int Co, int T, int V) {
+  switch (V) {
+    case 25: return (int)as_bwd_piece_rows<25>(n, K, Co, T);
+    case 17: return (int)as_bwd_piece_rows<17>(n, K, Co, T);
+    case 18: return (int)as_bwd_piece_rows<18>(n, K, Co, T);
+    default: return 0;
+  }
+}
+
+int dsgcn_aggsum_tuning(int key, int value) {
+  if (key == 0) { g_as_pipe = value; return 0; }
+  if (key == 1) { g_as_waves_fwd = value; return 0; }
+  if (key == 2) { g_as_wgs_bwd = value; return 0; }
+  return DSGCN_EINVAL;
 }
 
 }  // extern "C"

@@ -666,7 +666,8 @@ class _AggSum(torch.autograd.Function):
         dev = p.device
         lib = native.lib()
         y = torch.empty((n, Co, T, V), device=dev, dtype=torch.float32)
-        partial = torch.empty((n, Co, 2), device=dev, dtype=torch.float32) if want_bn else None
+        prow = lib.dsgcn_aggsum_partial_rows(n, T, V)
+        partial = torch.empty((prow, Co, 2), device=dev, dtype=torch.float32) if want_bn else None
         rc = lib.dsgcn_aggsum_fwd(_ptr(p), _ptr(adj), *astr, _ptr(y), _ptr(partial), n, K, Co, T, V, _stream())
         native.check(rc, 'dsgcn_aggsum_fwd')
         scale = shift = mean = var = None
@@ -674,7 +675,7 @@ class _AggSum(torch.autograd.Function):
         if want_bn:
             stats = torch.empty((4, Co), device=dev, dtype=torch.float32)
             mean, var, scale, shift = stats[0], stats[1], stats[2], stats[3]
-            rc = lib.dsgcn_bn_finalize(_ptr(partial), n, Co, count, _ptr(gamma), _ptr(beta), float(eps), _ptr(mean),
+            rc = lib.dsgcn_bn_finalize(_ptr(partial), prow, Co, count, _ptr(gamma), _ptr(beta), float(eps), _ptr(mean),
                                        _ptr(var), _ptr(scale), _ptr(shift), Co, _stream())
             native.check(rc, 'dsgcn_bn_finalize')
             ctx.mark_non_differentiable(mean, var)
@@ -702,7 +703,8 @@ class _AggSum(torch.autograd.Function):
             gy = torch.zeros_like(y)
         dp = torch.empty_like(p)
         if shared:
-            dpiece = torch.empty((n * Co, K, V, V), device=dev, dtype=torch.float32)   # per-(n,c) pieces of dA
+            rows = lib.dsgcn_aggsum_bwd_piece_rows(n, K, Co, T, V)       # per-wave pieces, or per-(n,c) ones if 0
+            dpiece = torch.empty((rows or n * Co, K, V, V), device=dev, dtype=torch.float32)
             dstr = (Co * K * V * V, V * V, K * V * V)
         else:
             dpiece = torch.empty_like(adj)

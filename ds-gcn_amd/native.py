@@ -53,6 +53,9 @@ SIGNATURES = {
     'dsgcn_tapconv_fwd': [c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, ctypes.c_void_p, c_st],
     'dsgcn_tapconv_dgrad': [c_f, c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, c_st],
     'dsgcn_tapconv_wgrad': [c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_st],
+    'dsgcn_aggsum_partial_rows': [c_int, c_int, c_int],
+    'dsgcn_aggsum_bwd_piece_rows': [c_int] * 5,
+    'dsgcn_aggsum_tuning': [c_int, c_int],
     'dsgcn_aggsum_fwd': [c_f, c_f] + [ctypes.c_long] * 3 + [c_f, c_f] + [c_int] * 5 + [c_st],
     'dsgcn_aggsum_bwd': [c_f, c_f] + [ctypes.c_long] * 3 + [c_f] * 6 + [ctypes.c_long] * 3 + [c_int] * 5 + [c_st],
     'dsgcn_tanhdiff_fwd': [c_f, c_f] + [c_int] * 4 + [c_st],

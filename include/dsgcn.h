@@ -162,6 +162,13 @@ int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const 
  * partial (n*Co, 2) or NULL: per-plane sum / sum of squares of y -> dsgcn_bn_finalize.
  * bwd: G = gy + A0[c] + B0[c]*y (y, A0, B0 may be NULL); dp (n,K*Co,T,V) fully written; dAhat_k of plane (n,c) is
  * written at dahat + n*d_ns + k*d_ks + c*d_cs (shared A: write per-plane pieces, reduce with dsgcn_colsum). */
+/* rows of the forward's `partial` buffer (rows, Co, 2) */
+int dsgcn_aggsum_partial_rows(int n, int T, int V);
+/* shared adjacency only: R > 0 -> the backward writes dahat as (R, K, V, V) per-wave pieces (d_* strides ignored),
+ * 0 -> per-(n,c) pieces through the d_* strides; either way dA = column sum over the pieces */
+int dsgcn_aggsum_bwd_piece_rows(int n, int K, int Co, int T, int V);
+/* tuning / A-B knobs used by tools/ (0: pipelined kernels on/off, 1: forward waves, 2: backward workgroups) */
+int dsgcn_aggsum_tuning(int key, int value);
 int dsgcn_aggsum_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long a_cs, float* y, float* partial,
                      int n, int K, int Co, int T, int V, void* stream);
 int dsgcn_aggsum_bwd(const float* p, const float* ahat, long a_ns, long a_ks, long a_cs, const float* gy,
