@@ -41,7 +41,7 @@ struct TArgs {
   float* o;            // (n, Cout, Tout, V1)
   const float* go;     // grad of o
   float* dh;           // grad of h
-  int n, Cin, Cout, T, Tout, V1, stride, nbr, splits, pstride, dch;
+  int n, Cin, Cout, T, Tout, V1, stride, nbr, splits, pstride, dch, narrow;
   TBranch br[TC_MAXBR];
 };
 
@@ -90,12 +90,35 @@ __device__ __forceinline__ void tc_stage_w(const TBranch& br, float* Ws, int co0
 
 // Accumulate one source chunk: acc[m] += A(Ws) * B(loaded values).
 // FWD: A[i=co][k=ci] = Ws[co*S + tap*CP + ci];  BWD (transposed): A[i=ci][k=co] = Ws[co*S + tap*CP + ci]
-template <int KT, bool FWD>
+template <int KT, bool FWD, int NG>
 __device__ __forceinline__ void tc_accum(f32x16 (&acc)[2], const float* Ws, __amdgpu_buffer_rsrc_t rs, const int (&voff)[KT],
                                          int cstride4, int sbase, int ns, int mtiles, int CP, int lane) {
   const int half = lane >> 5, l31 = lane & 31;
   const int S = KT * CP + 1;
   const int nsp = (ns + 7) & ~7;
+  if (NG > 0) {
+    // every conv window <= 8*NG channels wide: all loads of the tile (KT*4*NG dwords per lane) are issued before the
+    // first MFMA — the load -> MFMA chain per tap below exposes one memory round trip per tap, which dominates such
+    // short tiles (tools/tc_bench.py: 127 -> 50 us on the 64-channel layers)
+    float x[KT][NG * 4];
+#pragma unroll
+    for (int tap = 0; tap < KT; ++tap)
+#pragma unroll
+      for (int u = 0; u < NG * 4; ++u) x[tap][u] = tc_load(rs, voff[tap], (sbase + 2 * u) * cstride4);
+#pragma unroll
+    for (int tap = 0; tap < KT; ++tap)
+#pragma unroll
+      for (int u = 0; u < NG * 4; ++u) {
+        const int kl = 2 * u + half;
+        const float bv = kl < ns ? x[tap][u] : 0.f;
+#pragma unroll
+        for (int m = 0; m < (NG > 4 ? 2 : 1); ++m) {
+          const float av = FWD ? Ws[(32 * m + l31) * S + tap * CP + kl] : Ws[kl * S + tap * CP + 32 * m + l31];
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int tap = 0; tap < KT; ++tap) {
     float xa[4], xb[4];
@@ -137,7 +160,7 @@ __device__ __forceinline__ void tc_accum(f32x16 (&acc)[2], const float* Ws, __am
 }
 
 // One block = (4 position tiles of 32) x (one destination chunk of <= 64 channels); loops over the source chunks.
-template <int KT, bool FWD>
+template <int KT, bool FWD, int NG>
 __device__ __forceinline__ void tc_conv(const TArgs& a, const TBranch& br, float* Ws, int n, int tile, int chunk,
                                         int lane) {
   const int half = lane >> 5, l31 = lane & 31;
@@ -185,7 +208,7 @@ __device__ __forceinline__ void tc_conv(const TArgs& a, const TBranch& br, float
     if (s0 > 0) __syncthreads();                   // every wave is done with the previous tile
     if (FWD) tc_stage_w<KT>(br, Ws, d0, nd, s0, ns, CP);
     else tc_stage_w<KT>(br, Ws, s0, ns, d0, nd, CP);
-    tc_accum<KT, FWD>(acc, Ws, rs, voff, cstride4, s0, ns, mtiles, CP, lane);
+    tc_accum<KT, FWD, NG>(acc, Ws, rs, voff, cstride4, s0, ns, mtiles, CP, lane);
   }
   // D[i=channel][j=position]
   float* dst = FWD ? a.o : a.dh;
@@ -207,7 +230,7 @@ __device__ __forceinline__ void tc_conv(const TArgs& a, const TBranch& br, float
   }
 }
 
-template <int KT>
+template <int KT, int NG>
 __global__ __launch_bounds__(TC_NT) void k_tapconv_fwd(TArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int bi = blockIdx.z / a.dch, chunk = blockIdx.z - bi * a.dch;
@@ -217,7 +240,7 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_fwd(TArgs a) {
   const int V1 = a.V1, Lout = a.Tout * V1;
   if (br.type == 0) {
     if (chunk * 64 >= br.cout) return;
-    tc_conv<KT, true>(a, br, lds, n, blockIdx.x * 4 + wave, chunk, lane);
+    tc_conv<KT, true, NG>(a, br, lds, n, blockIdx.x * 4 + wave, chunk, lane);
     return;
   }
   if (chunk > 0) return;
@@ -242,7 +265,7 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_fwd(TArgs a) {
   }
 }
 
-template <int KT>
+template <int KT, int NG>
 __global__ __launch_bounds__(TC_NT) void k_tapconv_dgrad(TArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int bi = blockIdx.z / a.dch, chunk = blockIdx.z - bi * a.dch;
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_dgrad(TArgs a) {
   const int V1 = a.V1, Lin = a.T * V1;
   if (br.type == 0) {
     if (chunk * 64 >= br.cin) return;
-    tc_conv<KT, false>(a, br, lds, n, blockIdx.x * 4 + wave, chunk, lane);
+    tc_conv<KT, false, NG>(a, br, lds, n, blockIdx.x * 4 + wave, chunk, lane);
     return;
   }
   if (chunk > 0) return;
@@ -385,6 +408,100 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
   if (cich == 0 && quarter == 0 && row < nco) br.dbp[(size_t)blockIdx.x * a.pstride + coch * 64 + row] = dbacc;
 }
 
+// wgrad for narrow windows (every conv window <= 32 channels wide: the 64-/128-channel dgmstcn layers, MSTCN up to
+// 128 channels): the (co x ci) tile is ONE 32x32 MFMA tile, so the four waves of a block would have nothing to split
+// but zeros.  Here every wave is its own K-split instead: it walks its own (sample, output frame) chunks with a
+// wave-private LDS image (Ds[32][LS] = do, Xs[tap][32][LS] = shifted h), register prefetch of the next chunk, no
+// block barrier, and writes its own partial row (row = blockIdx.x*4 + wave).
+template <int KT>
+__global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad_narrow(TArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const TBranch& br = a.br[blockIdx.y];
+  if (br.type != 0) return;
+  const int V1 = a.V1;
+  const int nco = br.cout, nci = br.cin;
+  const int KP = (V1 + 1) & ~1, LS = KP | 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Ds = lds + (size_t)wave * (1 + KT) * 32 * LS;      // [32][LS]
+  float* Xs = Ds + 32 * LS;                                 // [KT][32][LS]
+  const int half = lane >> 5, l31 = lane & 31;
+  // staging: lane = (row parity, position): one instruction moves two whole channel rows (two 104-B segments)
+  const int total = a.n * a.Tout;
+  const int nsplit = a.splits;                              // rows of the partial buffer = waves in the grid
+  const int per = (total + nsplit - 1) / nsplit;
+  const int me = blockIdx.x * 4 + wave;
+  const int ch0 = me * per, ch1 = min(total, ch0 + per);
+  f32x16 acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+  constexpr int NRP = 16;                                   // row pairs
+  float dbl[NRP];
+#pragma unroll
+  for (int j = 0; j < NRP; ++j) dbl[j] = 0.f;
+  float dv[NRP], xv[KT][NRP];
+  const bool plive = l31 < V1;
+  auto issue = [&](int ch) {
+    const int n = ch / a.Tout, tp = ch - n * a.Tout;
+#pragma unroll
+    for (int j = 0; j < NRP; ++j) {
+      const int row = 2 * j + half;
+      dv[j] = (plive && row < nco) ? a.go[((size_t)(n * a.Cout + br.co0 + row) * a.Tout + tp) * V1 + l31] : 0.f;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const int t = tp * a.stride + (k - KT / 2) * br.dil;
+        xv[k][j] = (plive && row < nci && t >= 0 && t < a.T)
+                       ? a.h[((size_t)(n * a.Cin + br.ci0 + row) * a.T + t) * V1 + l31] : 0.f;
+      }
+    }
+  };
+  if (ch0 < ch1) issue(ch0);
+  for (int ch = ch0; ch < ch1; ++ch) {
+    wave_lds_sync();                                        // the previous chunk's operand reads are done
+    if (l31 < KP) {
+#pragma unroll
+      for (int j = 0; j < NRP; ++j) {
+        const int row = 2 * j + half;
+        Ds[row * LS + l31] = dv[j];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) Xs[(k * 32 + row) * LS + l31] = xv[k][j];
+        dbl[j] += dv[j];
+      }
+    }
+    if (ch + 1 < ch1) issue(ch + 1);
+    wave_lds_sync();
+    for (int kk = 0; kk < KP; kk += 2) {
+      const float av = Ds[l31 * LS + kk + half];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const float bv = Xs[(k * 32 + l31) * LS + kk + half];
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
+      }
+    }
+  }
+  // D[i=co][j=ci] per tap -> dwp[row me][(co*cin + ci)*KT + tap]
+  float* dwp = br.dwp + (size_t)me * a.pstride;
+  if (l31 < nci) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = tc_row32(r, half);
+      if (co < nco) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) dwp[((size_t)co * br.cin + l31) * KT + k] = acc[k][r];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NRP; ++j) {
+    float v = dbl[j];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);      // over the 32 positions of this half
+    const int row = 2 * j + half;
+    if (l31 == 0 && row < nco) br.dbp[(size_t)me * a.pstride + row] = v;
+  }
+}
+
 size_t tc_lds_conv(int CP, int KT) { return (size_t)(64 * (KT * CP + 1) + 64) * sizeof(float); }
 
 constexpr size_t TC_LDS_MAX = 156 * 1024;
@@ -403,7 +520,7 @@ int tc_raise_lds(F* kernel, size_t lds, size_t* have) {
 // fills a.br / a.dch, returns the widest padded source chunk (CP) over the conv windows, or <0 on error
 int tc_fill(TArgs& a, int nbr, const int* type, const int* ci0, const int* co0, const int* cin, const int* cout,
             const int* dil) {
-  int cpmax = 8, dch = 1;
+  int cpmax = 8, dch = 1, wmax = 0;
   for (int i = 0; i < nbr; ++i) {
     TBranch& b = a.br[i];
     b.type = type[i]; b.ci0 = ci0[i]; b.co0 = co0[i]; b.cin = cin[i]; b.cout = cout[i]; b.dil = dil[i];
@@ -415,9 +532,11 @@ int tc_fill(TArgs& a, int nbr, const int* type, const int* ci0, const int* co0, 
       if (cp > cpmax) cpmax = cp;
       const int d = (std::max(b.cin, b.cout) + 63) / 64;
       if (d > dch) dch = d;
+      wmax = std::max(wmax, std::max(b.cin, b.cout));
     }
   }
   a.dch = dch;
+  a.narrow = wmax;                                 // widest conv window (channels)
   return cpmax;
 }
 
@@ -429,6 +548,23 @@ int tc_fill(TArgs& a, int nbr, const int* type, const int* ci0, const int* co0, 
     case 5: { constexpr int KTC = 5; CALL; } break; \
     case 9: { constexpr int KTC = 9; CALL; } break; \
     default: return DSGCN_EUNSUPPORTED;             \
+  }
+
+// preload depth by widest window: 8*NG channels; KT*4*NG registers must stay modest (<= 80)
+#define TC_LAUNCH_NG(KERNEL)                                                                                         \
+  {                                                                                                                   \
+    const int w_ = a.narrow;                                                                                          \
+    constexpr int cap_ = 80 / (KTC * 4);                                                                              \
+    if (w_ > 0 && w_ <= 16 && cap_ >= 2)                                                                              \
+      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 2 ? 2 : 0)>), grid, dim3(TC_NT), lds, (hipStream_t)stream, a);          \
+    else if (w_ > 0 && w_ <= 24 && cap_ >= 3)                                                                         \
+      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 3 ? 3 : 0)>), grid, dim3(TC_NT), lds, (hipStream_t)stream, a);          \
+    else if (w_ > 0 && w_ <= 32 && cap_ >= 4)                                                                         \
+      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 4 ? 4 : 0)>), grid, dim3(TC_NT), lds, (hipStream_t)stream, a);          \
+    else if (w_ > 0 && w_ <= 48 && cap_ >= 6)                                                                         \
+      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 6 ? 6 : 0)>), grid, dim3(TC_NT), lds, (hipStream_t)stream, a);          \
+    else                                                                                                              \
+      hipLaunchKernelGGL((KERNEL<KTC, 0>), grid, dim3(TC_NT), lds, (hipStream_t)stream, a);                            \
   }
 
 extern "C" {
@@ -454,9 +590,9 @@ int dsgcn_tapconv_fwd(const float* h, float* o, int n, int Cin, int Cout, int T,
   dim3 grid((unsigned)((a.Tout * V1 + 127) / 128), (unsigned)n, (unsigned)(nbr * a.dch));
   TC_DISPATCH_KT(KT, {
     static size_t have = 64 * 1024;
-    const int rc = tc_raise_lds(k_tapconv_fwd<KTC>, lds, &have);
+    const int rc = tc_raise_lds(k_tapconv_fwd<KTC, 0>, lds, &have);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tapconv_fwd<KTC>, grid, dim3(TC_NT), lds, (hipStream_t)stream, a);
+    TC_LAUNCH_NG(k_tapconv_fwd)
   })
   DSGCN_LAUNCH_CHECK();
   return 0;
@@ -480,9 +616,9 @@ int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int C
   dim3 grid((unsigned)((T * V1 + 127) / 128), (unsigned)n, (unsigned)(nbr * a.dch));
   TC_DISPATCH_KT(KT, {
     static size_t have = 64 * 1024;
-    const int rc = tc_raise_lds(k_tapconv_dgrad<KTC>, lds, &have);
+    const int rc = tc_raise_lds(k_tapconv_dgrad<KTC, 0>, lds, &have);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tapconv_dgrad<KTC>, grid, dim3(TC_NT), lds, (hipStream_t)stream, a);
+    TC_LAUNCH_NG(k_tapconv_dgrad)
   })
   DSGCN_LAUNCH_CHECK();
   return 0;
@@ -504,6 +640,32 @@ int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int Cin, int Cou
   for (int i = 0; i < nbr; ++i) {
     a.br[i].dwp = dwp ? dwp[i] : nullptr; a.br[i].dbp = dbp ? dbp[i] : nullptr;
     if (type[i] == 0 && (!a.br[i].dwp || !a.br[i].dbp)) return DSGCN_EINVAL;
+  }
+  int wmax = 0;
+  for (int i = 0; i < nbr; ++i)
+    if (type[i] == 0) wmax = std::max(wmax, std::max(cin[i], cout[i]));
+  if (wmax <= 32 && splits % 4 == 0 && KT <= 5) {
+    // narrow windows: one K-split per wave
+    const int KPn = (V1 + 1) & ~1, LSn = KPn | 1;
+    const size_t ldsn = (size_t)4 * (1 + KT) * 32 * LSn * sizeof(float);
+    dim3 gridn((unsigned)(splits / 4), (unsigned)nbr);
+    switch (KT) {
+      case 3: {
+        static size_t have = 64 * 1024;
+        const int rc = tc_raise_lds(k_tapconv_wgrad_narrow<3>, ldsn, &have);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_tapconv_wgrad_narrow<3>, gridn, dim3(TC_NT), ldsn, (hipStream_t)stream, a);
+      } break;
+      case 5: {
+        static size_t have = 64 * 1024;
+        const int rc = tc_raise_lds(k_tapconv_wgrad_narrow<5>, ldsn, &have);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_tapconv_wgrad_narrow<5>, gridn, dim3(TC_NT), ldsn, (hipStream_t)stream, a);
+      } break;
+      default: return DSGCN_EUNSUPPORTED;
+    }
+    DSGCN_LAUNCH_CHECK();
+    return 0;
   }
   const int KP = (2 * V1 + 1) & ~1, LS = KP | 1;
   const size_t lds = (size_t)(1 + KT) * 64 * LS * sizeof(float);

@@ -518,8 +518,13 @@ class _TapBranches(torch.autograd.Function):
                 off += co * ci * KT + co
         pstride = max(off, 1)
         # k-splits: enough blocks to fill the chip, but keep the partial buffer (splits x pstride floats) around 8 MB
-        splits = max(16, min(256, (1 << 21) // pstride))
-        splits = max(1, min(splits, n * ((Tout + 1) // 2)))
+        wmax = max([max(ci, co) for t, ci, co in zip(types, cins, couts) if t == 0] or [0])
+        if wmax <= 32:      # narrow windows: every wave is its own split (csrc/tapconv.hip k_tapconv_wgrad_narrow)
+            splits = max(64, min(1024, (1 << 21) // pstride)) // 4 * 4
+            splits = max(4, min(splits, (n * Tout) // 4 * 4))
+        else:
+            splits = max(16, min(256, (1 << 21) // pstride))
+            splits = max(1, min(splits, n * ((Tout + 1) // 2)))
         part = torch.empty((splits, pstride), device=h.device, dtype=torch.float32)
         base = part.data_ptr()
         dwp = (_ct.c_void_p * nbr)(*[base + 4 * o if t == 0 else None for t, o in zip(types, offs)])
