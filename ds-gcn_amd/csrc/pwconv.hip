@@ -33,7 +33,7 @@ struct PwArgs {
   int relu;
   const float* w; const float* bias;
   float* z; float* zaug; float* partial;
-  int n, Ci, Co, T, V, Tout, stride, aug, TR, NPpad, vec, stats, ablate;
+  int n, Ci, Co, T, V, Tout, stride, aug, TR, NPpad, vec, stats, ablate, roll;
 };
 
 __device__ __forceinline__ int mfma_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -365,7 +365,77 @@ __device__ __forceinline__ void fwd2_chunk(const PwArgs& a, f32x16 (&acc)[MT][NW
   }
 }
 
-template <int MT, int NW>
+// Whole-chunk rolling prefetch (Ci a multiple of 64, one position tile per wave): the 32 B-operand registers of a
+// 64-channel chunk are all in flight at once; each is refilled with the same k-step of the NEXT chunk right after its
+// MFMAs have consumed it, and the next chunk's weight rows are fetched into registers during the MFMA phase, so a
+// chunk boundary costs two raw s_barriers and an LDS write, not a memory round trip (the 4-k-step ping-pong above
+// covers only ~512 cycles per set and re-exposes the latency at every chunk: MFMA pipe 40 % busy at 256 channels).
+// The barriers are raw s_barrier + lgkmcnt(0): __syncthreads() would drain vmcnt(0) and with it the prefetch.
+template <int MT, int MODE>
+__device__ __forceinline__ void fwd2_roll(const PwArgs& a, f32x16 (&acc)[MT][1], float* Ws, const f32x4* Ps4,
+                                          __amdgpu_buffer_rsrc_t r1, __amdgpu_buffer_rsrc_t r2, int voff, int coBase,
+                                          int cstride4, int tid, int half, int l31) {
+  const int Ci = a.Ci, Co = a.Co;
+  const int nch = Ci / KW;
+  float xr[32], yr[MODE == 2 ? 32 : 1];
+  f32x4 wr[2 * MT];
+  auto loadW = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q < 2 * MT; ++q) {
+      const int f = tid + PW_NT * q;
+      const int rowi = f >> 4, kq = (f & 15) * 4;
+      const int co = coBase + rowi;
+      wr[q] = co < Co ? *reinterpret_cast<const f32x4*>(a.w + (size_t)co * Ci + c0 + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    xr[u] = buf_load(r1, voff, (2 * u) * cstride4);
+    if (MODE == 2) yr[u] = buf_load(r2, voff, (2 * u) * cstride4);
+  }
+  loadW(0);
+  for (int c = 0; c < nch; ++c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // the previous chunk's weight tile is consumed (first: Ps4 written)
+#pragma unroll
+    for (int q = 0; q < 2 * MT; ++q) {
+      const int f = tid + PW_NT * q;
+      const int rowi = f >> 4, kq = (f & 15) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Ws[rowi * KWS + kq + e] = wr[q][e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool more = c + 1 < nch;
+    const int cn = (c + 1) * KW;
+    if (more) loadW(cn);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int kl = 2 * u + half;
+      float av[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) av[m] = Ws[(32 * m + l31) * KWS + kl];
+      float v = xr[u];
+      if (MODE != 0) {
+        const f32x4 p = Ps4[c * KW + kl];
+        v = fmaf(v, p.x, p.y);
+        if (MODE == 2) v += fmaf(yr[u], p.z, p.w);
+        if (a.relu) v = fmaxf(v, 0.f);
+      }
+      if (more) {
+        xr[u] = buf_load(r1, voff, (cn + 2 * u) * cstride4);
+        if (MODE == 2) yr[u] = buf_load(r2, voff, (cn + 2 * u) * cstride4);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], v, acc[m][0], 0, 0, 0);
+    }
+  }
+}
+
+int g_pw_roll = 1;         // bit 0: rolling prefetch in the forward (on), bit 1: in the data gradient (off: 64 more VGPRs halve
+                           // the occupancy, measured -4 % on the step: tools/roll_ab.py)
+
+template <int MT, int NW, bool ROLL>
 __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ws = lds;                               // [32*MT][KWS]
@@ -415,6 +485,11 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
       for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
 
   const int mode = has2 ? 2 : ((aff1 || a.relu) ? 1 : 0);
+  if (NW == 1 && ROLL) {
+    if (mode == 0) fwd2_roll<MT, 0>(a, reinterpret_cast<f32x16 (&)[MT][1]>(acc), Ws, Ps4, r1, r2, voff[0], coBase, cstride * 4, tid, half, l31);
+    else if (mode == 1) fwd2_roll<MT, 1>(a, reinterpret_cast<f32x16 (&)[MT][1]>(acc), Ws, Ps4, r1, r2, voff[0], coBase, cstride * 4, tid, half, l31);
+    else fwd2_roll<MT, 2>(a, reinterpret_cast<f32x16 (&)[MT][1]>(acc), Ws, Ps4, r1, r2, voff[0], coBase, cstride * 4, tid, half, l31);
+  } else
   for (int c0 = 0; c0 < Ci; c0 += KW) {
     const int kc = min(KW, Ci - c0);
     __syncthreads();                             // previous chunk's W fully consumed (and Ps written, first time)
@@ -671,7 +746,7 @@ struct PwBwdArgs {
   float* dx1; float* dx2; float* ipart;    // ipart [nblk][Ci][3]
   float* dwp; float* dbp;                  // [ksplit][Co][Ci], [ksplit][Co]
   int n, Ci, Co, T, V, Tout, stride, aug, TR, NPpad, vec;
-  int chunks_per_split, total_chunks, nb_per_sample;
+  int chunks_per_split, total_chunks, nb_per_sample, roll;
   int pstride;                             // floats between consecutive k-splits in dwp / dbp
 };
 
@@ -969,7 +1044,65 @@ __device__ __forceinline__ void d2_compute(f32x16 (&acc)[MT][NW], const float* W
   }
 }
 
-template <int MT, int NW, bool AUG>
+// Rolling whole-chunk prefetch for the data gradient (Co a multiple of 64, no global-joint column): see fwd2_roll.
+template <int MT>
+__device__ __forceinline__ void dgrad2_roll(const PwBwdArgs& a, f32x16 (&acc)[MT][1], float* Ws, const float2* Cs,
+                                            __amdgpu_buffer_rsrc_t rg, __amdgpu_buffer_rsrc_t rz, int voff, int ciBase,
+                                            int cstride4, bool has_g, bool has_c, int tid, int half, int l31) {
+  constexpr int WS2 = 32 * MT + 1;
+  const int Ci = a.Ci, Co = a.Co;
+  const int nch = Co / KW;
+  float gr[32], zr[32];
+  f32x4 wr[2 * MT];
+  auto loadW = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q < 2 * MT; ++q) {
+      const int f = tid + PW_NT * q;
+      const int rowi = f / (8 * MT), cq = (f - rowi * (8 * MT)) * 4;
+      const int ci = ciBase + cq;
+      wr[q] = ci < Ci ? *reinterpret_cast<const f32x4*>(a.w + (size_t)(c0 + rowi) * Ci + ci) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    gr[u] = has_g ? buf_load(rg, voff, (2 * u) * cstride4) : 0.f;
+    zr[u] = has_c ? buf_load(rz, voff, (2 * u) * cstride4) : 0.f;
+  }
+  loadW(0);
+  for (int c = 0; c < nch; ++c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < 2 * MT; ++q) {
+      const int f = tid + PW_NT * q;
+      const int rowi = f / (8 * MT), cq = (f - rowi * (8 * MT)) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Ws[rowi * WS2 + cq + e] = wr[q][e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool more = c + 1 < nch;
+    const int cn = (c + 1) * KW;
+    if (more) loadW(cn);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int kl = 2 * u + half;
+      float av[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) av[m] = Ws[kl * WS2 + 32 * m + l31];
+      const float2 cf = Cs[c * KW + kl];                      // (A0, B0)
+      const float d = gr[u] + fmaf(cf.y, zr[u], cf.x);
+      if (more) {
+        gr[u] = has_g ? buf_load(rg, voff, (cn + 2 * u) * cstride4) : 0.f;
+        zr[u] = has_c ? buf_load(rz, voff, (cn + 2 * u) * cstride4) : 0.f;
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], d, acc[m][0], 0, 0, 0);
+    }
+  }
+}
+
+template <int MT, int NW, bool AUG, bool ROLL>
 __global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad2(PwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WS2 = 32 * MT + 1;
@@ -1014,6 +1147,10 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad2(PwBwdArgs a) {
       for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
 
   constexpr int G = 2 * F2_UNR;
+  if (NW == 1 && !AUG && ROLL) {
+    dgrad2_roll<MT>(a, reinterpret_cast<f32x16 (&)[MT][1]>(acc), Ws, Cs, rg, rz, voff[0], ciBase, L * 4, has_g, has_c, tid,
+                    half, l31);
+  } else
   for (int c0 = 0; c0 < Co; c0 += KW) {
     const int kc = min(KW, Co - c0);
     __syncthreads();
@@ -1309,6 +1446,7 @@ extern "C" {
 int dsgcn_pwconv_tuning(int key, int value) {
   if (key == 0) { g_pw_ablate = value; return 0; }
   if (key == 1) { g_pw_maxmt = value; return 0; }
+  if (key == 2) { g_pw_roll = value; return 0; }
   return DSGCN_EINVAL;
 }
 
@@ -1352,6 +1490,7 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
   a.w = w; a.bias = bias; a.z = z; a.zaug = zaug; a.partial = partial;
   a.n = n; a.Ci = Ci; a.Co = Co; a.T = T; a.V = V; a.Tout = Tout; a.stride = stride; a.aug = aug;
   a.stats = stats; a.ablate = g_pw_ablate;
+  a.roll = ((g_pw_roll & 1) && Ci % KW == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int L = Tout * V;
   const int mtiles = (Co + 31) / 32;
@@ -1362,12 +1501,16 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
   size_t ldsf = (size_t)32 * MT * KWS + 4 + (size_t)4 * Ci;
   if (ldsf < (size_t)4 * 32 * 36 + 256) ldsf = (size_t)4 * 32 * 36 + 256;
   const size_t lds = ldsf * sizeof(float);
+#define PW_FWD2(MTV)                                                                                  \
+  if (a.roll) hipLaunchKernelGGL((k_pwconv_fwd2<MTV, 1, true>), grid, dim3(PW_NT), lds, st, a);       \
+  else hipLaunchKernelGGL((k_pwconv_fwd2<MTV, 1, false>), grid, dim3(PW_NT), lds, st, a)
   switch (MT) {
-    case 1: hipLaunchKernelGGL((k_pwconv_fwd2<1, 1>), grid, dim3(PW_NT), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((k_pwconv_fwd2<2, 1>), grid, dim3(PW_NT), lds, st, a); break;
-    case 3: hipLaunchKernelGGL((k_pwconv_fwd2<3, 1>), grid, dim3(PW_NT), lds, st, a); break;
-    default: hipLaunchKernelGGL((k_pwconv_fwd2<4, 1>), grid, dim3(PW_NT), lds, st, a); break;
+    case 1: PW_FWD2(1); break;
+    case 2: PW_FWD2(2); break;
+    case 3: PW_FWD2(3); break;
+    default: PW_FWD2(4); break;
   }
+#undef PW_FWD2
   DSGCN_LAUNCH_CHECK();
   if (aug) {
     const size_t l2 = (size_t)Tout * V * sizeof(float);
@@ -1429,6 +1572,7 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
   a.z = z; a.zaug = zaug; a.gz = gz; a.gzaug = gzaug; a.A0 = A0; a.B0 = B0;
   a.dx1 = dx1; a.dx2 = dx2; a.ipart = ipart;
   a.n = n; a.Ci = Ci; a.Co = Co; a.T = T; a.V = V; a.Tout = Tout; a.stride = stride; a.aug = aug;
+  a.roll = ((g_pw_roll & 2) && Co % KW == 0 && (Ci & 3) == 0) ? 1 : 0;
   const int L = Tout * V;
   const int mtiles = (Ci + 31) / 32;
   const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
@@ -1440,8 +1584,9 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
   const size_t lds = ldsf * sizeof(float);
 #define DSGCN_DGRAD(MTv, NWv)                                                                        \
   do {                                                                                               \
-    if (aug) hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, true>), grid, dim3(PW_NT), lds, st, a);   \
-    else hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, false>), grid, dim3(PW_NT), lds, st, a);      \
+    if (aug) hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, true, false>), grid, dim3(PW_NT), lds, st, a);   \
+    else if (a.roll) hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, false, true>), grid, dim3(PW_NT), lds, st, a);   \
+    else hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, false, false>), grid, dim3(PW_NT), lds, st, a);      \
   } while (0)
   switch (MT) {
     case 1: DSGCN_DGRAD(1, 1); break;

@@ -19,6 +19,9 @@ shapes = [  # name, Ci, Co, T, stride, aug, res
     ('pre5', 128, 48, 32, 1, 0, 0), ('post5', 48, 128, 32, 1, 0, 0), ('branch5', 128, 128, 32, 1, 1, 1),
     ('pre8', 256, 96, 16, 1, 0, 0), ('post8', 96, 256, 16, 1, 0, 0), ('branch8', 256, 256, 16, 1, 1, 1),
     ('resid4', 64, 128, 64, 2, 0, 0)]
+roll = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+native.lib().dsgcn_pwconv_tuning(2, roll)
+print('roll', roll)
 print(f'{"name":9s} {"fwd us":>8s} {"GB/s":>7s} {"TF/s":>6s} | {"f+b us":>8s} {"TF/s":>6s}')
 for name, Ci, Co, T, stride, aug, res in shapes:
     x1 = torch.randn(n, Ci, T, V, device=dev, requires_grad=True)
