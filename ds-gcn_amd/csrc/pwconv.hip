@@ -432,8 +432,9 @@ __device__ __forceinline__ void fwd2_roll(const PwArgs& a, f32x16 (&acc)[MT][1],
   }
 }
 
-int g_pw_roll = 1;         // bit 0: rolling prefetch in the forward (on), bit 1: in the data gradient (off: 64 more VGPRs halve
-                           // the occupancy, measured -4 % on the step: tools/roll_ab.py)
+int g_pw_roll = 5;         // bit 0: rolling prefetch in the forward (on), bit 1: in the data gradient (off: 64 more VGPRs halve
+                           // the occupancy, measured -4 % on the step: tools/roll_ab.py), bit 2: dgrad epilogue operands
+                           // fetched before the K loop (on: +0.5 %)
 
 template <int MT, int NW, bool ROLL>
 __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
@@ -1102,7 +1103,7 @@ __device__ __forceinline__ void dgrad2_roll(const PwBwdArgs& a, f32x16 (&acc)[MT
   }
 }
 
-template <int MT, int NW, bool AUG, bool ROLL>
+template <int MT, int NW, bool AUG, bool ROLL, bool PREX>
 __global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad2(PwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WS2 = 32 * MT + 1;
@@ -1146,6 +1147,22 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad2(PwBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
 
+  // PREX: the epilogue's operands (the forward input at this tile, for the ReLU mask / affine / partial sums) are
+  // fetched before the K loop instead of after it, where their latency is fully exposed
+  float xpre[PREX ? MT : 1][PREX ? 16 : 1], ypre[PREX ? MT : 1][PREX ? 16 : 1];
+  if (PREX) {
+    const size_t cst = (size_t)a.T * V;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ciBase + 32 * m + mfma_row32(r, half);
+        const bool ok = ci < Ci && pok[0];
+        const size_t g = ((size_t)n * Ci + (ok ? ci : 0)) * cst + (ok ? goff[0] : 0);
+        xpre[m][r] = ok ? a.x1[g] : 0.f;
+        ypre[m][r] = (ok && a.x2) ? a.x2[g] : 0.f;
+      }
+  }
   constexpr int G = 2 * F2_UNR;
   if (NW == 1 && !AUG && ROLL) {
     dgrad2_roll<MT>(a, reinterpret_cast<f32x16 (&)[MT][1]>(acc), Ws, Cs, rg, rz, voff[0], ciBase, L * 4, has_g, has_c, tid,
@@ -1208,12 +1225,12 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad2(PwBwdArgs a) {
         float dv = 0.f, xa = 0.f, xb = 0.f;
         if (ci < Ci && pok[j]) {
           const size_t g = ((size_t)n * Ci + ci) * cstride + goff[j];
-          xa = a.x1[g];
+          xa = PREX ? xpre[m][r] : a.x1[g];
           const float sa = a.s1 ? a.s1[ci] : 1.f;
           float pre = a.s1 ? fmaf(xa, sa, a.h1[ci]) : xa;
           float sb = 1.f;
           if (a.x2) {
-            xb = a.x2[g];
+            xb = PREX ? ypre[m][r] : a.x2[g];
             if (a.s2) { sb = a.s2[ci]; pre += fmaf(xb, sb, a.h2[ci]); } else pre += xb;
           }
           dv = (!a.relu || pre > 0.f) ? acc[m][j][r] : 0.f;
@@ -1584,9 +1601,10 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
   const size_t lds = ldsf * sizeof(float);
 #define DSGCN_DGRAD(MTv, NWv)                                                                        \
   do {                                                                                               \
-    if (aug) hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, true, false>), grid, dim3(PW_NT), lds, st, a);   \
-    else if (a.roll) hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, false, true>), grid, dim3(PW_NT), lds, st, a);   \
-    else hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, false, false>), grid, dim3(PW_NT), lds, st, a);      \
+    if (aug) hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, true, false, false>), grid, dim3(PW_NT), lds, st, a);   \
+    else if (a.roll) hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, false, true, false>), grid, dim3(PW_NT), lds, st, a);   \
+    else if (g_pw_roll & 4) hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, false, false, (NWv == 1)>), grid, dim3(PW_NT), lds, st, a);      \
+    else hipLaunchKernelGGL((k_pwconv_dgrad2<MTv, NWv, false, false, false>), grid, dim3(PW_NT), lds, st, a);      \
   } while (0)
   switch (MT) {
     case 1: DSGCN_DGRAD(1, 1); break;
