@@ -33,7 +33,7 @@ struct PwArgs {
   int relu;
   const float* w; const float* bias;
   float* z; float* zaug; float* partial;
-  int n, Ci, Co, T, V, Tout, stride, aug, TR, NPpad, vec, stats, ablate, roll;
+  int n, Ci, Co, T, V, Tout, stride, aug, TR, NPpad, vec, stats, ablate, roll, nbx, cc;
 };
 
 __device__ __forceinline__ int mfma_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -365,6 +365,24 @@ __device__ __forceinline__ void fwd2_chunk(const PwArgs& a, f32x16 (&acc)[MT][NW
   }
 }
 
+// XCD-aware block decode for the wave-independent kernels: the CC blocks that read the same input tile (one per 64-channel
+// output chunk) get consecutive slots on the SAME XCD (blockIdx % 8 labels the XCD group, MI355X_MICROARCH.md), so the
+// tile's lines are still in that XCD's L2 when the second..CC-th reader arrives; with the plain (x,y,z) order the readers
+// are a whole tensor pass apart and every one of them goes to HBM / Infinity Cache.
+struct PwBlk { int bx, n, cz; bool live; };
+__device__ __forceinline__ PwBlk pw_decode(int nbx, int ntiles, int cc) {
+  const int id = blockIdx.x;
+  const int xcd = id & 7, slot = id >> 3;
+  const int cz = slot % cc;
+  const int tile = (slot / cc) * 8 + xcd;
+  PwBlk b;
+  b.live = tile < ntiles;
+  b.cz = cz;
+  b.n = tile / nbx;
+  b.bx = tile - b.n * nbx;
+  return b;
+}
+
 // Whole-chunk rolling prefetch (Ci a multiple of 64, one position tile per wave): the 32 B-operand registers of a
 // 64-channel chunk are all in flight at once; each is refilled with the same k-step of the NEXT chunk right after its
 // MFMAs have consumed it, and the next chunk's weight rows are fetched into registers during the MFMA phase, so a
@@ -443,11 +461,13 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
   f32x4* Ps4 = reinterpret_cast<f32x4*>(lds + ((32 * MT * KWS + 3) & ~3));   // [Ci] : (s1,h1,s2,h2)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int n = blockIdx.y;
-  const int coBase = blockIdx.z * 32 * MT;
+  const PwBlk bk = pw_decode(a.nbx, a.nbx * a.n, a.cc);
+  if (!bk.live) return;
+  const int n = bk.n;
+  const int coBase = bk.cz * 32 * MT;
   const int V = a.V, Ci = a.Ci, Co = a.Co;
   const int L = a.Tout * V;                      // output positions per (sample, channel)
-  const int tile0 = (blockIdx.x * 4 + wave) * NW;
+  const int tile0 = (bk.bx * 4 + wave) * NW;
   const bool has2 = a.x2 != nullptr;
   const bool aff1 = a.s1 != nullptr, aff2 = a.s2 != nullptr;
   const bool wvec = (Ci & 3) == 0;
@@ -535,7 +555,7 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
   //      (a shuffle tree costs 160 ds_bpermute per tile and made the LDS pipe the bottleneck: measured) ----
   float* Tw = lds + wave * (32 * 36);            // per-wave 32x32 tile, row stride 36 (conflict-free b128 row reads)
   float* Ss = lds + 4 * 32 * 36;                 // [4 waves][32][2]
-  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const size_t blk = (size_t)bk.n * a.nbx + bk.bx;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     float sv = 0.f, qv = 0.f;
@@ -747,7 +767,7 @@ struct PwBwdArgs {
   float* dx1; float* dx2; float* ipart;    // ipart [nblk][Ci][3]
   float* dwp; float* dbp;                  // [ksplit][Co][Ci], [ksplit][Co]
   int n, Ci, Co, T, V, Tout, stride, aug, TR, NPpad, vec;
-  int chunks_per_split, total_chunks, nb_per_sample, roll;
+  int chunks_per_split, total_chunks, nb_per_sample, roll, nbx, cc;
   int pstride;                             // floats between consecutive k-splits in dwp / dbp
 };
 
@@ -1111,11 +1131,13 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad2(PwBwdArgs a) {
   float2* Cs = reinterpret_cast<float2*>(lds + ((KW * WS2 + 3) & ~3));     // [Co] (A0, B0)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int n = blockIdx.y;
-  const int ciBase = blockIdx.z * 32 * MT;
+  const PwBlk bk = pw_decode(a.nbx, a.nbx * a.n, a.cc);
+  if (!bk.live) return;
+  const int n = bk.n;
+  const int ciBase = bk.cz * 32 * MT;
   const int V = a.V, Ci = a.Ci, Co = a.Co;
   const int L = a.Tout * V;
-  const int tile0 = (blockIdx.x * 4 + wave) * NW;
+  const int tile0 = (bk.bx * 4 + wave) * NW;
   const bool has_g = a.gz != nullptr, has_c = a.A0 != nullptr;
   const bool wvec = (Ci & 3) == 0;
   const float invV = 1.f / (float)V;
@@ -1211,7 +1233,7 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad2(PwBwdArgs a) {
   // ---- epilogue: ReLU mask / affine of the virtual input, coalesced stores, 3 per-channel partial sums ----
   float* Tw = lds + wave * (32 * 36);
   float* Ss = lds + 4 * 32 * 36;                 // [4 waves][32][3]
-  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const size_t blk = (size_t)bk.n * a.nbx + bk.bx;
   const size_t cstride = (size_t)a.T * V;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -1514,7 +1536,9 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
   const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
   const int NW = 1;
   const int nbx = (L + 4 * NW * 32 - 1) / (4 * NW * 32);
-  dim3 grid((unsigned)nbx, (unsigned)n, (unsigned)((mtiles + MT - 1) / MT));
+  a.nbx = nbx;
+  a.cc = (mtiles + MT - 1) / MT;
+  dim3 grid((unsigned)(((long)nbx * n + 7) / 8 * 8 * a.cc));
   size_t ldsf = (size_t)32 * MT * KWS + 4 + (size_t)4 * Ci;
   if (ldsf < (size_t)4 * 32 * 36 + 256) ldsf = (size_t)4 * 32 * 36 + 256;
   const size_t lds = ldsf * sizeof(float);
@@ -1595,7 +1619,9 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
   const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
   const int NW = 1;
   const int nbx = (L + 4 * NW * 32 - 1) / (4 * NW * 32);
-  dim3 grid((unsigned)nbx, (unsigned)n, (unsigned)((mtiles + MT - 1) / MT));
+  a.nbx = nbx;
+  a.cc = (mtiles + MT - 1) / MT;
+  dim3 grid((unsigned)(((long)nbx * n + 7) / 8 * 8 * a.cc));
   size_t ldsf = (size_t)KW * (32 * MT + 1) + 4 + (size_t)2 * Co;
   if (ldsf < (size_t)4 * 32 * 36 + 4 * 32 * 3) ldsf = (size_t)4 * 32 * 36 + 4 * 32 * 3;
   const size_t lds = ldsf * sizeof(float);
