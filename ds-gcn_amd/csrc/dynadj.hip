@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int KSUB = 3;     // subsets: 2 plain + 1 semantic
-constexpr int NT = 256;     // threads per workgroup
+constexpr int NT = 1024;    // threads per workgroup: the LDS image allows one workgroup per CU, so it has to bring all 16 waves
 
 struct DynDims {
   int n, Ci, mid, V, P, E;
