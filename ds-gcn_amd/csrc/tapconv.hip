@@ -59,16 +59,17 @@ template <int KT>
 __device__ __forceinline__ void tc_stage_w(const TBranch& br, float* Ws, int co0l, int nco, int ci0l, int nci, int CP) {
   const int S = KT * CP + 1;
   if (nco < 64 || nci < CP) {
-    for (int i = threadIdx.x; i < 64 * S + 64; i += TC_NT) Ws[i] = 0.f;
+    for (int i = threadIdx.x; i < 64 * S + 64; i += blockDim.x) Ws[i] = 0.f;
     __syncthreads();
   }
   const int run = nci * KT;
   const int total = nco * run;
-  for (int i0 = threadIdx.x; i0 < total; i0 += TC_NT * 8) {
+  const int ntb = blockDim.x;
+  for (int i0 = threadIdx.x; i0 < total; i0 += ntb * 8) {
     float v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int i = i0 + q * TC_NT;
+      const int i = i0 + q * ntb;
       if (i < total) {
         const int co = i / run, r = i - co * run;
         v[q] = br.w[((size_t)(co0l + co) * br.cin + ci0l) * KT + r];
@@ -78,7 +79,7 @@ __device__ __forceinline__ void tc_stage_w(const TBranch& br, float* Ws, int co0
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int i = i0 + q * TC_NT;
+      const int i = i0 + q * ntb;
       if (i < total) {
         const int co = i / run, r = i - co * run, ci = r / KT, tap = r - ci * KT;
         Ws[co * S + tap * CP + ci] = v[q];
@@ -231,7 +232,7 @@ __device__ __forceinline__ void tc_conv(const TArgs& a, const TBranch& br, float
 }
 
 template <int KT, int NG>
-__global__ __launch_bounds__(TC_NT) void k_tapconv_fwd(TArgs a) {
+__global__ __launch_bounds__(512) void k_tapconv_fwd(TArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int bi = blockIdx.z / a.dch, chunk = blockIdx.z - bi * a.dch;
   const TBranch& br = a.br[bi];
@@ -240,15 +241,16 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_fwd(TArgs a) {
   const int V1 = a.V1, Lout = a.Tout * V1;
   if (br.type == 0) {
     if (chunk * 64 >= br.cout) return;
-    tc_conv<KT, true, NG>(a, br, lds, n, blockIdx.x * 4 + wave, chunk, lane);
+    tc_conv<KT, true, NG>(a, br, lds, n, blockIdx.x * (blockDim.x >> 6) + wave, chunk, lane);
     return;
   }
   if (chunk > 0) return;
   // elementwise windows: thread = output position, loop over the window's channels
-  const int pos = blockIdx.x * 128 + (threadIdx.x & 127);
+  const int pb = blockDim.x >> 1;                  // positions per block (32 per wave)
+  const int pos = blockIdx.x * pb + (threadIdx.x % pb);
   if (pos >= Lout) return;
   const int tp = pos / V1, col = pos - tp * V1;
-  for (int c = threadIdx.x >> 7; c < br.cout; c += 2) {
+  for (int c = threadIdx.x / pb; c < br.cout; c += 2) {
     const float* hp = a.h + ((size_t)(n * a.Cin + br.ci0 + c) * a.T) * V1 + col;
     float v;
     if (br.type == 2) {
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_fwd(TArgs a) {
 }
 
 template <int KT, int NG>
-__global__ __launch_bounds__(TC_NT) void k_tapconv_dgrad(TArgs a) {
+__global__ __launch_bounds__(512) void k_tapconv_dgrad(TArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int bi = blockIdx.z / a.dch, chunk = blockIdx.z - bi * a.dch;
   const TBranch& br = a.br[bi];
@@ -275,14 +277,15 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_dgrad(TArgs a) {
   const int V1 = a.V1, Lin = a.T * V1;
   if (br.type == 0) {
     if (chunk * 64 >= br.cin) return;
-    tc_conv<KT, false, NG>(a, br, lds, n, blockIdx.x * 4 + wave, chunk, lane);
+    tc_conv<KT, false, NG>(a, br, lds, n, blockIdx.x * (blockDim.x >> 6) + wave, chunk, lane);
     return;
   }
   if (chunk > 0) return;
-  const int pos = blockIdx.x * 128 + (threadIdx.x & 127);
+  const int pb = blockDim.x >> 1;
+  const int pos = blockIdx.x * pb + (threadIdx.x % pb);
   if (pos >= Lin) return;
   const int t = pos / V1, col = pos - t * V1;
-  for (int c = threadIdx.x >> 7; c < br.cin; c += 2) {
+  for (int c = threadIdx.x / pb; c < br.cin; c += 2) {
     const float* hp = a.h + ((size_t)(n * a.Cin + br.ci0 + c) * a.T) * V1 + col;
     const float* gp = a.go + ((size_t)(n * a.Cout + br.co0 + c) * a.Tout) * V1 + col;
     float g = 0.f;
@@ -556,15 +559,15 @@ int tc_fill(TArgs& a, int nbr, const int* type, const int* ci0, const int* co0, 
     const int w_ = a.narrow;                                                                                          \
     constexpr int cap_ = 80 / (KTC * 4);                                                                              \
     if (w_ > 0 && w_ <= 16 && cap_ >= 2)                                                                              \
-      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 2 ? 2 : 0)>), grid, dim3(TC_NT), lds, (hipStream_t)stream, a);          \
+      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 2 ? 2 : 0)>), grid, dim3(ntb), lds, (hipStream_t)stream, a);          \
     else if (w_ > 0 && w_ <= 24 && cap_ >= 3)                                                                         \
-      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 3 ? 3 : 0)>), grid, dim3(TC_NT), lds, (hipStream_t)stream, a);          \
+      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 3 ? 3 : 0)>), grid, dim3(ntb), lds, (hipStream_t)stream, a);          \
     else if (w_ > 0 && w_ <= 32 && cap_ >= 4)                                                                         \
-      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 4 ? 4 : 0)>), grid, dim3(TC_NT), lds, (hipStream_t)stream, a);          \
+      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 4 ? 4 : 0)>), grid, dim3(ntb), lds, (hipStream_t)stream, a);          \
     else if (w_ > 0 && w_ <= 48 && cap_ >= 6)                                                                         \
-      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 6 ? 6 : 0)>), grid, dim3(TC_NT), lds, (hipStream_t)stream, a);          \
+      hipLaunchKernelGGL((KERNEL<KTC, (cap_ >= 6 ? 6 : 0)>), grid, dim3(ntb), lds, (hipStream_t)stream, a);          \
     else                                                                                                              \
-      hipLaunchKernelGGL((KERNEL<KTC, 0>), grid, dim3(TC_NT), lds, (hipStream_t)stream, a);                            \
+      hipLaunchKernelGGL((KERNEL<KTC, 0>), grid, dim3(ntb), lds, (hipStream_t)stream, a);                            \
   }
 
 extern "C" {
@@ -587,7 +590,9 @@ int dsgcn_tapconv_fwd(const float* h, float* o, int n, int Cin, int Cout, int T,
     if (type[i] == 0 && !a.br[i].w) return DSGCN_EINVAL;
   }
   const size_t lds = tc_lds_conv(cp, KT);
-  dim3 grid((unsigned)((a.Tout * V1 + 127) / 128), (unsigned)n, (unsigned)(nbr * a.dch));
+  const int ntb = lds > 80 * 1024 ? 512 : TC_NT;   // one workgroup per CU by LDS -> give it 8 waves
+  const int pbk = ntb / 2;
+  dim3 grid((unsigned)((a.Tout * V1 + pbk - 1) / pbk), (unsigned)n, (unsigned)(nbr * a.dch));
   TC_DISPATCH_KT(KT, {
     static size_t have = 64 * 1024;
     const int rc = tc_raise_lds(k_tapconv_fwd<KTC, 0>, lds, &have);
@@ -613,7 +618,9 @@ int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int C
     if (type[i] == 0 && !a.br[i].w) return DSGCN_EINVAL;
   }
   const size_t lds = tc_lds_conv(cp, KT);
-  dim3 grid((unsigned)((T * V1 + 127) / 128), (unsigned)n, (unsigned)(nbr * a.dch));
+  const int ntb = lds > 80 * 1024 ? 512 : TC_NT;
+  const int pbk = ntb / 2;
+  dim3 grid((unsigned)((T * V1 + pbk - 1) / pbk), (unsigned)n, (unsigned)(nbr * a.dch));
   TC_DISPATCH_KT(KT, {
     static size_t have = 64 * 1024;
     const int rc = tc_raise_lds(k_tapconv_dgrad<KTC, 0>, lds, &have);
