@@ -53,8 +53,7 @@ def flush_running_stats():
         return
     items = list(_pending_running)
     _pending_running.clear()
-    for bn, _, _, _ in items:
-        bn.num_batches_tracked += 1
+    torch._foreach_add_([bn.num_batches_tracked for bn, _, _, _ in items], 1)
     groups = {}
     for it in items:
         bn = it[0]

@@ -325,7 +325,7 @@ class _PwConv(torch.autograd.Function):
         ipart = None
         if s1 is not None or s2 is not None:
             rows = lib.dsgcn_pwconv_ipart_rows(n, Ci, T, V, stride)
-            ipart = torch.zeros((rows, Ci, 3), device=dev, dtype=torch.float32)
+            ipart = torch.empty((rows, Ci, 3), device=dev, dtype=torch.float32)     # every row is written by dgrad
         rc = lib.dsgcn_pwconv_dgrad(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(w2),
                                     _ptr(z), _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), _ptr(dx1),
                                     _ptr(dx2), _ptr(ipart), n, Ci, Co, T, V, stride, aug, st)
