@@ -718,7 +718,8 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
 }
 
 // Column sums of a row-major (R, C) fp32 matrix -> out (C), accumulated in fp64 (partial-buffer reductions).
-__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, int R, int C, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, int R, int C, float* __restrict__ out,
+                                                 int inner) {
   __shared__ double red[32][32];
   const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -740,7 +741,9 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, 
   if (slice == 0 && c < C) {
 #pragma unroll
     for (int i = 1; i < 32; ++i) s += red[i][cl];
-    out[c] = (float)s;
+    // inner > 1: columns are (C/inner, inner) pairs and leave transposed, out (inner, C/inner), so that each of the
+    // `inner` reductions is a contiguous vector for its consumer
+    out[inner > 1 ? (c % inner) * (C / inner) + c / inner : c] = (float)s;
   }
 }
 
@@ -1576,7 +1579,16 @@ int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const
 // out[c] = sum_r src[r, c]  (fp64 accumulation).
 int dsgcn_colsum(const float* src, int R, int C, float* out, void* stream) {
   if (!src || !out || R <= 0 || C <= 0) return DSGCN_EINVAL;
-  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, src, R, C, out);
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, src, R, C, out, 1);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Same, with the result transposed: src (R, C/inner, inner) -> out (inner, C/inner).
+int dsgcn_colsum_t(const float* src, int R, int C, int inner, float* out, void* stream) {
+  if (!src || !out || R <= 0 || C <= 0 || inner <= 0 || C % inner) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, src, R, C, out,
+                     inner);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -91,16 +91,21 @@ class side_branch:
                 t.record_stream(self.main)
 
 
-def _colsum_raw(t, R, C):
+def _colsum_raw(t, R, C, inner=1):
     out = torch.empty(C, device=t.device, dtype=torch.float32)
-    native.check(native.lib().dsgcn_colsum(_ptr(t), R, C, _ptr(out), _stream()), 'dsgcn_colsum')
+    if inner > 1:
+        native.check(native.lib().dsgcn_colsum_t(_ptr(t), R, C, inner, _ptr(out), _stream()), 'dsgcn_colsum_t')
+    else:
+        native.check(native.lib().dsgcn_colsum(_ptr(t), R, C, _ptr(out), _stream()), 'dsgcn_colsum')
     return out
 
 
-def colsum(t):
+def colsum(t, split_last=False):
     """Sum over dim 0 of a contiguous fp32 tensor (R, ...) -> (...), fp64 accumulation.  The kernel gives 32 columns
     to a block, so a tall, narrow input (e.g. 32768 x 25) would run on one CU: it is folded first — rows grouped g at
-    a time into a (R/g, g*C) view, summed, and the g partial rows summed by a second tiny launch."""
+    a time into a (R/g, g*C) view, summed, and the g partial rows summed by a second tiny launch.
+    split_last: input (R, C, k) -> output (k, C), each of the k sums a contiguous vector (no strided slices
+    downstream, which would cost their consumers a copy each)."""
     R = t.shape[0]
     shape = t.shape[1:]
     C = t.numel() // max(R, 1)
@@ -110,6 +115,9 @@ def colsum(t):
     if g > 1:
         t = _colsum_raw(t, R // g, g * C)
         R = g
+    if split_last:
+        k = shape[-1]
+        return _colsum_raw(t, R, C, k).view(k, C // k)
     return _colsum_raw(t, R, C).view(shape)
 
 
@@ -155,8 +163,8 @@ class _Aggregate(torch.autograd.Function):
         native.check(rc, 'dsgcn_aggregate_bwd')
         dscale = dshift = None
         if scale is not None:
-            red = colsum(partial)
-            dscale, dshift = red[:, 0], red[:, 1]
+            red = colsum(partial, split_last=True)
+            dscale, dshift = red[0], red[1]
         return dzp, dscale, dshift, None, dahat
 
 
@@ -290,6 +298,7 @@ class _PwConv(torch.autograd.Function):
                                        _ptr(mean), _ptr(var), _ptr(scale), _ptr(shift), int(n_affine), _stream())
             native.check(rc, 'dsgcn_bn_finalize')
             ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)      # no zero tensors for the unused / non-differentiable outputs (mean, var)
         ctx.save_for_backward(x1, s1, h1, x2, s2, h2, w2, z, zaug, gamma, mean, var)
         ctx.cfg = (int(relu), stride, int(aug), float(eps), int(n_affine), bool(want_bn), count, tuple(weight.shape),
                    bias is not None, beta is not None)
@@ -342,11 +351,11 @@ class _PwConv(torch.autograd.Function):
         db = wsum[Co * Ci:] if has_bias else None
         ds1 = dh1 = ds2 = dh2 = None
         if ipart is not None:
-            red = colsum(ipart)
+            red = colsum(ipart, split_last=True)
             if s1 is not None:
-                ds1, dh1 = red[:, 0], red[:, 1]
+                ds1, dh1 = red[0], red[1]
             if s2 is not None:
-                ds2, dh2 = red[:, 2], red[:, 1]
+                ds2, dh2 = red[2], red[1]
         if dgamma is not None:
             dgamma = dgamma[:n_affine] if gamma is not None else None
             dbeta = dbeta[:n_affine] if has_beta else None
@@ -403,8 +412,8 @@ class _BranchAct(torch.autograd.Function):
         rc = native.lib().dsgcn_branch_act_bwd(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), ctx.n_act, _ptr(dh),
                                                _ptr(dz), _ptr(dzaug), _ptr(part), n, C, T, V, _stream())
         native.check(rc, 'dsgcn_branch_act_bwd')
-        red = colsum(part)
-        return dz, dzaug, red[:, 0], red[:, 1], None
+        red = colsum(part, split_last=True)
+        return dz, dzaug, red[0], red[1], None
 
 
 class _TmsCombine(torch.autograd.Function):
@@ -431,6 +440,7 @@ class _TmsCombine(torch.autograd.Function):
                                        _ptr(var), _ptr(scale), _ptr(shift), C, _stream())
             native.check(rc, 'dsgcn_bn_finalize')
             ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(o, coeff, gamma, mean, var)
         ctx.cfg = (float(eps), bool(want_bn), count, beta is not None)
         return f, scale, shift, mean, var
@@ -574,7 +584,8 @@ def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b
     h = _BranchAct.apply(z, zaug, scale, shift, n_act)
     KT, types, c0s, bcs, dils, ws, bs = _branch_tables(branch_cfg, widths, conv_w, conv_b)
     o = _TapBranches.apply(h, int(stride), KT, C, types, c0s, c0s, bcs, bcs, dils, *ws, *bs)
-    return _TmsCombine.apply(o, add_coeff[:V].contiguous(), gamma, beta, float(eps), bool(want_bn))
+    coeff = add_coeff if add_coeff.shape[0] == V else add_coeff[:V].contiguous()
+    return _TmsCombine.apply(o, coeff, gamma, beta, float(eps), bool(want_bn))
 
 
 class _PlaneStats(torch.autograd.Function):
@@ -597,6 +608,7 @@ class _PlaneStats(torch.autograd.Function):
                                    _ptr(var), _ptr(scale), _ptr(shift), C, _stream())
         native.check(rc, 'dsgcn_bn_finalize')
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(o, gamma, mean, var)
         ctx.cfg = (float(eps), count, beta is not None)
         return scale, shift, mean, var
@@ -684,6 +696,7 @@ class _AggSum(torch.autograd.Function):
                                        _ptr(var), _ptr(scale), _ptr(shift), Co, _stream())
             native.check(rc, 'dsgcn_bn_finalize')
             ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(p, adj, y, gamma, mean, var)
         ctx.cfg = (K, float(eps), bool(want_bn), count, beta is not None, shared, astr)
         return y, scale, shift, mean, var
@@ -838,11 +851,11 @@ class _FuseOut(torch.autograd.Function):
         native.check(rc, 'dsgcn_fuse_out_bwd')
         ds1 = dh1 = ds2 = dh2 = None
         if need_part:
-            red = colsum(part)
+            red = colsum(part, split_last=True)
             if s1 is not None:
-                ds1, dh1 = red[:, 0], red[:, 3]
+                ds1, dh1 = red[0], red[3]
             if s2 is not None:
-                ds2, dh2 = red[:, 2], red[:, 1]
+                ds2, dh2 = red[2], red[1]
         return dx1, ds1, dh1, dx2, ds2, dh2, None, None
 
 
