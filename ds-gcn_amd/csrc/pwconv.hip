@@ -450,9 +450,9 @@ __device__ __forceinline__ void fwd2_roll(const PwArgs& a, f32x16 (&acc)[MT][1],
   }
 }
 
-int g_pw_roll = 5;         // bit 0: rolling prefetch in the forward (on), bit 1: in the data gradient (off: 64 more VGPRs halve
+int g_pw_roll = 13;        // bit 0: rolling prefetch in the forward (on), bit 1: in the data gradient (off: 64 more VGPRs halve
                            // the occupancy, measured -4 % on the step: tools/roll_ab.py), bit 2: dgrad epilogue operands
-                           // fetched before the K loop (on: +0.5 %)
+                           // fetched before the K loop (on: +0.5 %), bit 3: XCD-aware block order in wgrad (on: +0.5 %)
 
 template <int MT, int NW, bool ROLL>
 __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
@@ -1332,8 +1332,19 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_wgrad(PwBwdArgs a) {
   float* Xs = lds + 64 * LS;                     // [64][LS] virtual input
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int coBase = blockIdx.x * 64, ciBase = blockIdx.y * 64;
-  const int split = blockIdx.z;
+  // XCD-aware decode of a 1-D grid when a layer has several (co, ci) tiles: the tiles of one K-split read the same dz /
+  // input chunks, so they get consecutive slots on one XCD (blockIdx % 8 labels the XCD group) and share its L2.
+  int bxx = blockIdx.x, byy = blockIdx.y, bzz = blockIdx.z;
+  if (a.cc > 0) {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int tiles = a.cc * a.nbx;                    // nbx = co tiles, cc = ci tiles
+    const int tile = slot % tiles;
+    bzz = (slot / tiles) * 8 + xcd;
+    bxx = tile % a.nbx;
+    byy = tile / a.nbx;
+  }
+  const int coBase = bxx * 64, ciBase = byy * 64;
+  const int split = bzz;
   const int mt = wave >> 1, ntile = wave & 1;
   const float invV = 1.f / (float)V;
   const int row = tid >> 2, quarter = tid & 3;
@@ -1450,7 +1461,7 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_wgrad(PwBwdArgs a) {
       if (coo < Co) a.dwp[(size_t)split * a.pstride + (size_t)coo * Ci + cio] = acc[r];
     }
   }
-  if (blockIdx.y == 0 && quarter == 0 && co < Co) a.dbp[(size_t)split * a.pstride + co] = dbacc;
+  if (byy == 0 && quarter == 0 && co < Co) a.dbp[(size_t)split * a.pstride + co] = dbacc;
 }
 
 // BN backward coefficients of a conv whose batch statistics feed a deferred affine (scale, shift):
@@ -1695,6 +1706,11 @@ int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const 
   const int LS = KP | 1;
   const size_t lds = (size_t)2 * 64 * LS * sizeof(float);
   dim3 grid((unsigned)((Co + 63) / 64), (unsigned)((Ci + 63) / 64), (unsigned)splits);
+  a.nbx = a.cc = 0;
+  if (grid.x * grid.y > 1 && splits % 8 == 0 && (g_pw_roll & 8)) {
+    a.nbx = (int)grid.x; a.cc = (int)grid.y;
+    grid = dim3(grid.x * grid.y * (unsigned)splits);
+  }
   hipStream_t st = (hipStream_t)stream;
   if (a.vec && x2) hipLaunchKernelGGL((k_pwconv_wgrad<true, true>), grid, dim3(PW_NT), lds, st, a);
   else if (a.vec) hipLaunchKernelGGL((k_pwconv_wgrad<true, false>), grid, dim3(PW_NT), lds, st, a);
