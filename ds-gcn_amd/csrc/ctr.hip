@@ -132,29 +132,30 @@ __global__ __launch_bounds__(64) void k_plane_stats(const float* __restrict__ x,
   const int lane = threadIdx.x;
   const long plane = blockIdx.x;
   const float* __restrict__ p = x + (size_t)plane * L;
-  float s = 0.f, q = 0.f;
+  double s = 0.0, q = 0.0;
   if (vec) {
     const f32x4* __restrict__ p4 = reinterpret_cast<const f32x4*>(p);
     const int L4 = L >> 2;
 #pragma unroll 4
     for (int i = lane; i < L4; i += 64) {
       const f32x4 v = p4[i];
-      s += (v.x + v.y) + (v.z + v.w);
-      q = fmaf(v.x, v.x, q); q = fmaf(v.y, v.y, q); q = fmaf(v.z, v.z, q); q = fmaf(v.w, v.w, q);
+      s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+      q = fma((double)v.x, (double)v.x, q); q = fma((double)v.y, (double)v.y, q);
+      q = fma((double)v.z, (double)v.z, q); q = fma((double)v.w, (double)v.w, q);
     }
   } else {
 #pragma unroll 4
     for (int i = lane; i < L; i += 64) {
-      const float v = p[i];
+      const double v = (double)p[i];
       s += v;
-      q = fmaf(v, v, q);
+      q = fma(v, v, q);
     }
   }
-  s = wave_sum(s);
-  q = wave_sum(q);
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
   if (lane == 0) {
-    partial[plane * 2 + 0] = s;
-    partial[plane * 2 + 1] = q;
+    partial[plane * 2 + 0] = (float)s;
+    partial[plane * 2 + 1] = (float)q;
   }
 }
 

@@ -554,11 +554,11 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
   // ---- epilogue: bias, coalesced stores; per-channel sum / sum of squares via an LDS transpose of each tile
   //      (a shuffle tree costs 160 ds_bpermute per tile and made the LDS pipe the bottleneck: measured) ----
   float* Tw = lds + wave * (32 * 36);            // per-wave 32x32 tile, row stride 36 (conflict-free b128 row reads)
-  float* Ss = lds + 4 * 32 * 36;                 // [4 waves][32][2]
+  double* Ss = reinterpret_cast<double*>(lds + 4 * 32 * 36);   // [4 waves][32][2]; fp64: var = E[z^2]-mean^2 downstream
   const size_t blk = (size_t)bk.n * a.nbx + bk.bx;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    float sv = 0.f, qv = 0.f;
+    double sv = 0.0, qv = 0.0;                   // fp64 (full rate on CDNA): the variance formula amplifies sum errors
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int pos = (tile0 + j) * 32 + l31;
@@ -579,15 +579,16 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 v = rowp[q];
-          sv += (v.x + v.y) + (v.z + v.w);
-          qv = fmaf(v.x, v.x, qv); qv = fmaf(v.y, v.y, qv); qv = fmaf(v.z, v.z, qv); qv = fmaf(v.w, v.w, qv);
+          sv += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+          qv = fma((double)v.x, (double)v.x, qv); qv = fma((double)v.y, (double)v.y, qv);
+          qv = fma((double)v.z, (double)v.z, qv); qv = fma((double)v.w, (double)v.w, qv);
         }
         wave_lds_sync();
       }
     }
     if (a.stats) {
       sv += __shfl_xor(sv, 32, 64);
-      qv += __shfl_xor(qv, 32, 64);
+      qv += __shfl_xor(qv, 32, 64);              // (double overload: two dword shuffles)
       if (half == 0) {
         Ss[(wave * 32 + l31) * 2 + 0] = sv;
         Ss[(wave * 32 + l31) * 2 + 1] = qv;
@@ -596,11 +597,11 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
       if (tid < 32) {
         const int co = coBase + 32 * m + tid;
         if (co < Co) {
-          float s4 = 0.f, q4 = 0.f;
+          double s4 = 0.0, q4 = 0.0;
 #pragma unroll
           for (int w = 0; w < 4; ++w) { s4 += Ss[(w * 32 + tid) * 2]; q4 += Ss[(w * 32 + tid) * 2 + 1]; }
-          a.partial[(blk * Co + co) * 2 + 0] = s4;
-          a.partial[(blk * Co + co) * 2 + 1] = q4;
+          a.partial[(blk * Co + co) * 2 + 0] = (float)s4;
+          a.partial[(blk * Co + co) * 2 + 1] = (float)q4;
         }
       }
       __syncthreads();
@@ -622,21 +623,21 @@ __global__ __launch_bounds__(64) void k_rowmean_stats(const float* __restrict__ 
   for (int i = lane; i < L; i += 64) lds[i] = pz[i];
   wave_lds_sync();
   const float invV = 1.f / (float)V;
-  float sv = 0.f, qv = 0.f;
+  double sv = 0.0, qv = 0.0;
   for (int t = lane; t < T; t += 64) {
     float m = 0.f;
     for (int v = 0; v < V; ++v) m += lds[t * V + v];
     m *= invV;
     zaug[(size_t)plane * T + t] = m;
-    sv += m;
-    qv = fmaf(m, m, qv);
+    sv += (double)m;
+    qv = fma((double)m, (double)m, qv);
   }
   if (partial) {
-    sv = wave_sum(sv);
-    qv = wave_sum(qv);
+    sv = wave_sum_d(sv);
+    qv = wave_sum_d(qv);
     if (lane == 0) {
-      partial[(size_t)plane * 2 + 0] = sv;       // rows [n][C][2]
-      partial[(size_t)plane * 2 + 1] = qv;
+      partial[(size_t)plane * 2 + 0] = (float)sv;       // rows [n][C][2]
+      partial[(size_t)plane * 2 + 1] = (float)qv;
     }
   }
 }
@@ -1554,7 +1555,7 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
   a.cc = (mtiles + MT - 1) / MT;
   dim3 grid((unsigned)(((long)nbx * n + 7) / 8 * 8 * a.cc));
   size_t ldsf = (size_t)32 * MT * KWS + 4 + (size_t)4 * Ci;
-  if (ldsf < (size_t)4 * 32 * 36 + 256) ldsf = (size_t)4 * 32 * 36 + 256;
+  if (ldsf < (size_t)4 * 32 * 36 + 512) ldsf = (size_t)4 * 32 * 36 + 512;
   const size_t lds = ldsf * sizeof(float);
 #define PW_FWD2(MTV)                                                                                  \
   if (a.roll) hipLaunchKernelGGL((k_pwconv_fwd2<MTV, 1, true>), grid, dim3(PW_NT), lds, st, a);       \

@@ -83,21 +83,21 @@ __global__ __launch_bounds__(64) void k_tms_combine_fwd(const float* __restrict_
   const int V1 = V + 1, L = T * V;
   const float* __restrict__ po = o + (size_t)plane * T * V1;
   float* __restrict__ pf = f + (size_t)plane * L;
-  float sv = 0.f, qv = 0.f;
+  double sv = 0.0, qv = 0.0;               // fp64: the variance formula downstream (E[f^2]-mean^2) amplifies sum errors
 #pragma unroll 4
   for (int i = lane; i < L; i += 64) {
     const int t = i / V, v = i - t * V;
     const float val = fmaf(po[t * V1 + V], cf[v], po[t * V1 + v]);
     pf[i] = val;
-    sv += val;
-    qv = fmaf(val, val, qv);
+    sv += (double)val;
+    qv = fma((double)val, (double)val, qv);
   }
   if (partial) {
-    sv = wave_sum(sv);
-    qv = wave_sum(qv);
+    sv = wave_sum_d(sv);
+    qv = wave_sum_d(qv);
     if (lane == 0) {
-      partial[(size_t)plane * 2 + 0] = sv;
-      partial[(size_t)plane * 2 + 1] = qv;
+      partial[(size_t)plane * 2 + 0] = (float)sv;
+      partial[(size_t)plane * 2 + 1] = (float)qv;
     }
   }
 }

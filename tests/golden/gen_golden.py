@@ -184,6 +184,56 @@ def reduced_other_models():
         reduced_model(cfg, 'model_reduced_' + kind, seed=4)
 
 
+from closed_form import closed_form_fill, counter_input  # noqa: E402
+
+
+def full_size():
+    """G4: full-width models with closed-form weights and inputs — only logits, loss and per-tensor gradient norms are
+    stored (the weights / inputs are regenerated by the same formulas in tests/test_model_gpu.py)."""
+    out = {}
+    cases = [('dsstgcn_ntu60', ds_cfg(60), 64, 25), ('dsstgcn_k400_coco', ds_cfg(400, 'coco'), 100, 17),
+             ('ctrgcn_ntu60', other_cfg('ctrgcn'), 64, 25), ('stgcnpp_ntu60', other_cfg('stgcnpp'), 64, 25)]
+    for name, cfg, T, V in cases:
+        np.random.seed(0)
+        torch.manual_seed(0)
+        m = R.builder.build_model(cfg)
+        closed_form_fill(m)
+        classes = cfg['cls_head']['num_classes']
+        x, y = counter_input(2, T, V, classes)
+        m.train()
+        logits = m.cls_head(m.extract_feat(x[:, 0]))
+        loss = torch.nn.functional.cross_entropy(logits, y.squeeze(-1))
+        loss.backward()
+        out[name + '_logits'] = logits.detach().numpy()
+        out[name + '_loss'] = np.array(loss.item())
+        names = [k for k, p in m.named_parameters() if p.grad is not None]
+        out[name + '_gnorm'] = np.array([float(p.grad.double().norm()) for k, p in m.named_parameters() if p.grad is not None])
+        with open(os.path.join(HERE, f'full_{name}_gradnames.json'), 'w') as f:
+            json.dump(names, f)
+        # fp64 truth of the same case (the fp32 gradients of a 10-block train-mode-BN network are only ~1e-3..1e-1
+        # accurate per tensor: the tests judge against fp64, relative to the reference's own fp32 error)
+        m64 = R.builder.build_model(cfg).double()
+        m64.load_state_dict({k: v.double() if v.dtype.is_floating_point else v for k, v in m.state_dict().items()})
+        m64.train()
+        logits64 = m64.cls_head(extract_feat_f64(m64, x[:, 0].double()))
+        loss64 = torch.nn.functional.cross_entropy(logits64, y.squeeze(-1))
+        loss64.backward()
+        g64 = dict(m64.named_parameters())
+        out[name + '_logits64'] = logits64.detach().numpy().astype(np.float32)
+        out[name + '_loss64'] = np.array(loss64.item())
+        out[name + '_gnorm64'] = np.array([float(g64[k].grad.norm()) for k in names])
+        # per-tensor relative error of the reference's fp32 gradient against fp64 (full tensors compared here)
+        g32 = dict(m.named_parameters())
+        out[name + '_gerr32'] = np.array([float((g32[k].grad.double() - g64[k].grad).norm() / (g64[k].grad.norm() + 1e-30))
+                                          for k in names])
+        tot = (sum(float((g32[k].grad.double() - g64[k].grad).pow(2).sum()) for k in names) /
+               sum(float(g64[k].grad.pow(2).sum()) for k in names)) ** .5
+        out[name + '_gerr32_total'] = np.array(tot)
+        print(name, 'ref fp32 grad error vs fp64 (whole gradient):', tot)
+        print(name, float(loss), logits.abs().mean().item())
+    np.savez_compressed(os.path.join(HERE, 'full_size.npz'), **out)
+
+
 def manifests():
     man = {}
     ds_keys = ('backbone.gcn.0.gcn.A', 'backbone.gcn.0.gcn.pre.0.weight', 'backbone.gcn.9.tcn.transform.2.weight',
@@ -215,6 +265,7 @@ if __name__ == '__main__':
     unit_dgmstcn()
     reduced_model()
     reduced_other_models()
+    full_size()
     manifests()
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith(('.npz', '.json')):

@@ -105,6 +105,46 @@ def test_full_other_backbones_vs_oracle(kind):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
 
 
+@pytest.mark.parametrize('name,T,V,classes', [('dsstgcn_ntu60', 64, 25, 60), ('dsstgcn_k400_coco', 100, 17, 400),
+                                              ('ctrgcn_ntu60', 64, 25, 60), ('stgcnpp_ntu60', 64, 25, 60)])
+def test_full_size_vs_reference_fixture(name, T, V, classes):
+    """Full-width models (BASELINE configs 2, 5, 4 and ST-GCN++) with closed-form weights and inputs against the outputs
+    the REFERENCE produced for them (tests/golden/full_size.npz, its fp32 and fp64 runs)."""
+    import sys
+    sys.path.insert(0, GOLD)
+    from closed_form import closed_form_fill, counter_input
+    from test_host_api import other_cfg
+    cfg = {'dsstgcn_ntu60': ds_cfg(60, 'nturgb+d'), 'dsstgcn_k400_coco': ds_cfg(400, 'coco'),
+           'ctrgcn_ntu60': other_cfg('ctrgcn'), 'stgcnpp_ntu60': other_cfg('stgcnpp')}[name]
+    np.random.seed(0)
+    torch.manual_seed(0)
+    m = D.build_model(cfg)
+    closed_form_fill(m)
+    z = load('full_size.npz')
+    with open(os.path.join(GOLD, f'full_{name}_gradnames.json')) as f:
+        names = json.load(f)
+    x, y = counter_input(2, T, V, classes)
+    m = m.cuda().train()
+    logits = m.cls_head(m.extract_feat(x.cuda()[:, 0]))
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda().squeeze(-1))
+    loss.backward()
+    # judged against the reference's fp64 evaluation of the same case; the reference's own fp32 run is the yardstick:
+    # logits / loss within max(2x its error, 1e-4) (north_star bar 1e-4)
+    l64 = z[name + '_logits64']
+    ref_err = rel(z[name + '_logits'], l64)
+    assert rel(logits.detach().cpu(), l64) < max(2 * ref_err, 1e-4), (rel(logits.detach().cpu(), l64), ref_err)
+    assert abs(loss.item() - float(z[name + '_loss64'])) / abs(float(z[name + '_loss64'])) < 1e-4
+    # gradients: with 4 person-samples of batch statistics and these weights the fp32 gradient itself is ill-conditioned
+    # (the reference's fp32 gradient is 3.5 %..25 % off its fp64 one, stored as *_gerr32_total); per-tensor norms must
+    # be no further from fp64 than twice the reference's fp32 norms are
+    params = dict(m.named_parameters())
+    got = np.array([float(params[k].grad.double().norm()) for k in names])
+    g64 = z[name + '_gnorm64']
+    ours = np.linalg.norm(got - g64) / np.linalg.norm(g64)
+    theirs = np.linalg.norm(z[name + '_gnorm'] - g64) / np.linalg.norm(g64)
+    assert ours < max(2 * theirs, 2e-3), (ours, theirs)
+
+
 def test_running_stats_and_eval_mode():
     z = load('model_reduced.npz')
     with open(os.path.join(GOLD, 'model_reduced_cfg.json')) as f:

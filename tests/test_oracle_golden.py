@@ -119,6 +119,29 @@ def test_reduced_other_backbones(kind):
     assert abs(loss32.item() - float(z['loss_f32'])) < 1e-5
 
 
+def test_full_size_closed_form_ds():
+    """Full-width DS-STGCN (BASELINE config 2 shapes, 2 clips) with closed-form weights: oracle vs the reference's
+    stored logits / loss.  Both sides are fp32 evaluations of a 10-block network with different reduction orders
+    (measured 1.8e-5 apart): the bar is the north_star's 1e-4."""
+    import sys
+    sys.path.insert(0, GOLD)
+    from closed_form import closed_form_fill, counter_input
+    import dsgcn_amd as D
+    from bench import ds_cfg
+    np.random.seed(0)
+    torch.manual_seed(0)
+    m = D.build_model(ds_cfg(60, 'nturgb+d'))
+    closed_form_fill(m)
+    z = load('full_size.npz')
+    x, y = counter_input(2, 64, 25, 60)
+    gc = O.graph_constants('nturgb+d')
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        logits, loss = O.recognizer_forward_train(x, y, sd, gc['node_type'], gc['edge_type'], O.dgstgcn_plan())
+    assert rel(logits, z['dsstgcn_ntu60_logits']) < 1e-4
+    assert abs(loss.item() - float(z['dsstgcn_ntu60_loss'])) < 1e-4
+
+
 def test_oracle_vs_reference_live():
     import ref_shim
     if not ref_shim.available():
