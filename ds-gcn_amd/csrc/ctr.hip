@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int CTR_MAXK = 4;
+#define DSGCN_CTR_SLICES 4      // channel slices per (n, k) in ctr_affine_bwd: prow has n*4 rows
 
 struct CtrPtrs {
   const float* s[CTR_MAXK];
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(64) void k_ctr_affine_fwd(CtrPtrs p, const float* _
   for (int e = lane; e < VV; e += 64) o[e] = fmaf(al, s[e], a[e]);
 }
 
-// one block per (n, k): dS_k = alpha*dAhat ; prow (n, K*VV + K): [sum_c dAhat[k,e] | sum dAhat*S]
+// one block per (n, k, channel slice): dS_k = alpha*dAhat ; prow (n*CS, K*VV + K): [sum_c dAhat[k,e] | sum dAhat*S] over
+// the slice's channels (row = n*CS + slice; the caller's column sum adds the slices and the samples)
 __global__ __launch_bounds__(256) void k_ctr_affine_bwd(CtrPtrs p, const float* __restrict__ alpha,
                                                         const float* __restrict__ dahat, float* __restrict__ prow,
                                                         int K, int Co, int VV) {
@@ -101,7 +103,10 @@ __global__ __launch_bounds__(256) void k_ctr_affine_bwd(CtrPtrs p, const float* 
   float* __restrict__ ds = p.ds[k] + (size_t)i * Co * VV;
   float accA[4] = {0.f, 0.f, 0.f, 0.f};
   float acca = 0.f;
-  for (int c = 0; c < Co; ++c) {
+  const int CS = gridDim.y, sl = blockIdx.y;
+  const int cper = (Co + CS - 1) / CS;
+  const int cbeg = sl * cper, cend = min(Co, cbeg + cper);
+  for (int c = cbeg; c < cend; ++c) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int e = tid + 256 * j;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void k_ctr_affine_bwd(CtrPtrs p, const float* 
       }
     }
   }
-  float* __restrict__ out = prow + (size_t)i * (K * VV + K);
+  float* __restrict__ out = prow + ((size_t)i * CS + sl) * (K * VV + K);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int e = tid + 256 * j;
@@ -203,8 +208,8 @@ int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, const float*
     p.s[k] = s[k];
     p.ds[k] = ds[k];
   }
-  hipLaunchKernelGGL(k_ctr_affine_bwd, dim3((unsigned)((long)n * K)), dim3(256), 0, (hipStream_t)stream, p, alpha, dahat,
-                     prow, K, Co, V * V);
+  hipLaunchKernelGGL(k_ctr_affine_bwd, dim3((unsigned)((long)n * K), (unsigned)DSGCN_CTR_SLICES), dim3(256), 0,
+                     (hipStream_t)stream, p, alpha, dahat, prow, K, Co, V * V);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -796,7 +796,7 @@ class _CtrAffine(torch.autograd.Function):
         n, Co, V, _ = S[0].shape
         dahat = _f32c(dahat)
         dS = [torch.empty_like(t) for t in S]
-        prow = torch.empty((n, K * V * V + K), device=dahat.device, dtype=torch.float32)
+        prow = torch.empty((4 * n, K * V * V + K), device=dahat.device, dtype=torch.float32)   # 4 channel slices
         rc = native.lib().dsgcn_ctr_affine_bwd(_ptr_array(S), _ptr(alpha), _ptr(dahat), _ptr_array(dS), _ptr(prow), n,
                                                K, Co, V, _stream())
         native.check(rc, 'dsgcn_ctr_affine_bwd')

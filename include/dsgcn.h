@@ -181,8 +181,8 @@ int dsgcn_aggsum_bwd(const float* p, const float* ahat, long a_ns, long a_ks, lo
  * tanhdiff  : proj (n, 2*K*R, V) rows [k*R+r] = conv1_k(xbar), [K*R+k*R+r] = conv2_k(xbar)
  *             -> d (K, n, R, V, V) = tanh(x1[u] - x2[v])  (gcn.py:653-655); bwd: dproj from dd.
  * ctr_affine: ahat (n, K*Co, V, V) = alpha[0] * s[k] (n,Co,V,V) + A (K,V,V)  (gcn.py:657); s / ds are host arrays
- *             of K <= 4 device pointers.  bwd: ds[k] = alpha*dahat; prow (n, K*V*V + K) per-sample
- *             [sum_c dahat | sum dahat*s] (sum over n = [dA | per-subset dalpha]).
+ *             of K <= 4 device pointers.  bwd: ds[k] = alpha*dahat; prow (4*n, K*V*V + K): per (sample, channel
+ *             slice) [sum_c dahat | sum dahat*s] (sum over the rows = [dA | per-subset dalpha]).
  * plane_stats: partial (planes, 2) = per-plane [sum, sum of squares] of x (planes, L). */
 int dsgcn_tanhdiff_fwd(const float* proj, float* d, int n, int K, int R, int V, void* stream);
 int dsgcn_tanhdiff_bwd(const float* d, const float* dd, float* dproj, int n, int K, int R, int V, void* stream);

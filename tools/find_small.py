@@ -20,7 +20,7 @@ with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=F
 torch.cuda.synchronize()
 cnt = collections.Counter()
 for ev in prof.events():
-    if ev.name in ('aten::zero_', 'aten::clone', 'aten::cat', 'aten::fill_'):
+    if ev.name in ('aten::zero_', 'aten::clone', 'aten::cat', 'aten::fill_', 'aten::copy_', 'aten::add', 'aten::add_', 'aten::mul', 'aten::sum'):
         chain = []
         p = ev.cpu_parent
         while p is not None and len(chain) < 3:
