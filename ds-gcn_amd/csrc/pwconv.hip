@@ -10,12 +10,10 @@
 //   zaug[n,co,t'] = mean_v z  (= W . mean_v v + b: the dgmstcn "global joint" column, by linearity)
 //   partial[blk,co,0:2] = sum / sum of squares of this block's outputs (incl. zaug)  -> batch statistics
 //
-// Work decomposition: one 256-thread workgroup = (sample n, TR output frames, up to 128 output channels).
-// Per 32-channel input chunk the TR*V (+TR) positions of v are staged in LDS once (prologue applied once per element),
-// W chunk next to it (row stride 33: conflict-free column reads); each wave owns N-tiles {w, w+4} x all M-tiles and
-// issues v_mfma_f32_32x32x2_f32 with A = W[co, k], B = v[k, pos] (both one ds_read_b32 per lane).  Outputs leave the
-// accumulators as 128-B coalesced segments; per-channel sums are reduced in registers -> LDS -> one partial row per
-// block (deterministic two-stage BN statistics, finalised in fp64 by k_bn_finalize).
+// Work decomposition (k_pwconv_fwd2 / _dgrad2, below): wave-independent — each wave owns one 32-position tile of one
+// sample and <= 64 output channels; the B operand comes straight from HBM in MFMA fragment shape (raw buffer loads), only
+// the weights pass through LDS; per-channel sums leave through an LDS transpose, one partial row per block
+// (deterministic two-stage BN statistics, finalised in fp64 by k_bn_finalize).  wgrad stages both operands in LDS.
 // Bound: HBM for Ci,Co <= 64 (16 FLOP/B), f32 MFMA above (32-64 FLOP/B vs ridge ~20).
 #include "common.h"
 
@@ -43,239 +41,6 @@ __device__ __forceinline__ float virt1(float a, float b, bool has2, float s1, fl
   float v = fmaf(a, s1, h1);
   if (has2) v += fmaf(b, s2, h2);
   return relu ? fmaxf(v, 0.f) : v;
-}
-
-// Pipeline per 16-channel chunk:  regs(chunk c) -> LDS (prologue applied) | barrier | issue global loads of
-// chunk c+1 into registers | MFMA over LDS (loads in flight) | barrier.
-template <int MT>
-__global__ __launch_bounds__(PW_NT) void k_pwconv_fwd(PwArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Xs = lds;                               // [KCH][NPpad]
-  float* Ws = lds + KCH * a.NPpad;               // [32*MT][WSTR]
-  float* Ss = lds;                               // epilogue scratch [4 waves][32][2] (aliases Xs after the loop)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int n = blockIdx.y;
-  const int r0 = blockIdx.x * a.TR;
-  const int coBase = blockIdx.z * 32 * MT;
-  const int V = a.V, TR = a.TR, NPpad = a.NPpad, Ci = a.Ci;
-  const int rows_valid = min(TR, a.Tout - r0);
-  const int TRV = TR * V;
-  const int NP = TR * (V + (a.aug ? 1 : 0));
-  const int Nt = NPpad >> 5;
-  const bool has2 = a.x2 != nullptr;
-  const bool wvec = (Ci & 3) == 0;
-
-  f32x16 acc[MT][NTW];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
-
-  // ---- prefetch registers ----
-  f32x4 xr[XCH], yr[XCH];           // vec path: one float4 per (channel, lane), lane < TRV/4;
-                                    // scalar path: element q = position lane + 64*q of the channel
-  f32x4 wr[2];
-  const int TRV4 = TRV >> 2;
-  const int valid4 = (rows_valid * V) >> 2;
-  const int wrow = tid >> 1, wk = (tid & 1) * 8;       // W staging: 2 threads per row, 8 k each
-
-  auto issue = [&](int c0) {
-    if (a.vec) {
-#pragma unroll
-      for (int i = 0; i < XCH; ++i) {
-        const int ci = c0 + wave + 4 * i;
-        if (ci < Ci && lane < valid4) {
-          const size_t g = ((size_t)(n * Ci + ci) * a.T + r0) * V + 4 * lane;
-          xr[i] = *reinterpret_cast<const f32x4*>(a.x1 + g);
-          if (has2) yr[i] = *reinterpret_cast<const f32x4*>(a.x2 + g);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < XCH; ++i) {
-        const int ci = c0 + wave + 4 * i;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int p = lane + 64 * q;
-          const int rl = (int)(((float)p + 0.5f) / (float)V);
-          if (ci < Ci && p < TRV && rl < rows_valid) {
-            const size_t g = ((size_t)(n * Ci + ci) * a.T + (size_t)(r0 + rl) * a.stride) * V + (p - rl * V);
-            xr[i][q] = a.x1[g];
-            if (has2) yr[i][q] = a.x2[g];
-          }
-        }
-      }
-    }
-    if (wrow < 32 * MT) {
-      const int co = coBase + wrow;
-      if (wvec) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int k = c0 + wk + 4 * q;
-          wr[q] = (co < a.Co && k < Ci) ? *reinterpret_cast<const f32x4*>(a.w + (size_t)co * Ci + k)
-                                        : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int k = c0 + wk + 4 * q + e;
-            wr[q][e] = (co < a.Co && k < Ci) ? a.w[(size_t)co * Ci + k] : 0.f;
-          }
-      }
-    }
-  };
-
-  auto commit = [&](int c0) {       // registers -> LDS with the prologue applied; pads written as zeros
-    if (a.vec) {
-#pragma unroll
-      for (int i = 0; i < XCH; ++i) {
-        const int cl = wave + 4 * i, ci = c0 + cl;
-        if (lane < (NPpad >> 2)) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (ci < Ci && lane < valid4) {
-            const float s1 = a.s1 ? a.s1[ci] : 1.f, h1 = a.s1 ? a.h1[ci] : 0.f;
-            const float s2 = a.s2 ? a.s2[ci] : 1.f, h2 = a.s2 ? a.h2[ci] : 0.f;
-            const f32x4 x = xr[i];
-            const f32x4 y = has2 ? yr[i] : v;
-            v.x = virt1(x.x, y.x, has2, s1, h1, s2, h2, a.relu);
-            v.y = virt1(x.y, y.y, has2, s1, h1, s2, h2, a.relu);
-            v.z = virt1(x.z, y.z, has2, s1, h1, s2, h2, a.relu);
-            v.w = virt1(x.w, y.w, has2, s1, h1, s2, h2, a.relu);
-          }
-          *reinterpret_cast<f32x4*>(Xs + cl * NPpad + 4 * lane) = v;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < XCH; ++i) {
-        const int cl = wave + 4 * i, ci = c0 + cl;
-        const float s1 = (a.s1 && ci < Ci) ? a.s1[ci] : 1.f, h1 = (a.s1 && ci < Ci) ? a.h1[ci] : 0.f;
-        const float s2 = (a.s2 && ci < Ci) ? a.s2[ci] : 1.f, h2 = (a.s2 && ci < Ci) ? a.h2[ci] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int p = lane + 64 * q;
-          if (p < NPpad) {
-            const int rl = (int)(((float)p + 0.5f) / (float)V);
-            float v = 0.f;
-            if (ci < Ci && p < TRV && rl < rows_valid)
-              v = virt1(xr[i][q], has2 ? yr[i][q] : 0.f, has2, s1, h1, s2, h2, a.relu);
-            Xs[cl * NPpad + p] = v;
-          }
-        }
-      }
-    }
-    if (wrow < 32 * MT) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Ws[wrow * WSTR + wk + 4 * q + e] = wr[q][e];
-    }
-  };
-
-  if (!(a.ablate & 2)) issue(0);
-  for (int c0 = 0; c0 < Ci; c0 += KCH) {
-    const int kc = min(KCH, Ci - c0);
-    const int kmax = (a.ablate & 1) ? 0 : ((kc + 1) & ~1);
-    if (!(a.ablate & 16)) commit(c0);
-    __syncthreads();
-    if (a.aug) {
-      const float invV = 1.f / (float)V;
-      for (int idx = tid; idx < KCH * TR; idx += PW_NT) {
-        const int cl = idx / TR, rl = idx - cl * TR;
-        float sm = 0.f;
-        if (rl < rows_valid) {
-          const float* row = Xs + cl * NPpad + rl * V;
-          for (int vv = 0; vv < V; ++vv) sm += row[vv];
-          sm *= invV;
-        }
-        Xs[cl * NPpad + TRV + rl] = sm;
-      }
-      __syncthreads();
-    }
-    if (c0 + KCH < Ci && !(a.ablate & 2)) issue(c0 + KCH);
-#pragma unroll 4
-    for (int kk = 0; kk < kmax; kk += 2) {
-      float av[MT], bv[NTW];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) av[m] = Ws[(32 * m + l31) * WSTR + kk + half];
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const int nt = wave + 4 * j;
-        bv[j] = (nt < Nt) ? Xs[(kk + half) * NPpad + 32 * nt + l31] : 0.f;
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-          if (wave + 4 * j < Nt) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[j], acc[m][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue: bias, stores, statistics (one M-tile at a time to keep registers low) ----
-  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    float ssum[16], ssq[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const int nt = wave + 4 * j;
-      if (nt < Nt) {
-        const int pos = 32 * nt + l31;
-        bool ok = false, is_aug = false;
-        int rl = 0;
-        if (pos < TRV) { rl = (int)(((float)pos + 0.5f) / (float)V); ok = rl < rows_valid; }
-        else if (pos < NP) { rl = pos - TRV; ok = rl < rows_valid; is_aug = true; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = coBase + 32 * m + mfma_row32(r, half);
-          if (co < a.Co && ok) {
-            const float val = acc[m][j][r] + (a.bias ? a.bias[co] : 0.f);
-            if (a.ablate & 4) {}
-            else if (is_aug) a.zaug[(size_t)(n * a.Co + co) * a.Tout + r0 + rl] = val;
-            else a.z[((size_t)(n * a.Co + co) * a.Tout + r0) * V + pos] = val;
-            ssum[r] += val;
-            ssq[r] = fmaf(val, val, ssq[r]);
-          }
-        }
-      }
-    }
-    if (a.stats && !(a.ablate & 8)) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float sv = ssum[r], qv = ssq[r];
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-          sv += __shfl_xor(sv, off, 64);
-          qv += __shfl_xor(qv, off, 64);
-        }
-        if (l31 == 0) {
-          const int col = mfma_row32(r, half);
-          Ss[(wave * 32 + col) * 2 + 0] = sv;
-          Ss[(wave * 32 + col) * 2 + 1] = qv;
-        }
-      }
-      __syncthreads();
-      if (tid < 32) {
-        const int co = coBase + 32 * m + tid;
-        if (co < a.Co) {
-          float sv = 0.f, qv = 0.f;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) { sv += Ss[(w * 32 + tid) * 2]; qv += Ss[(w * 32 + tid) * 2 + 1]; }
-          a.partial[(blk * a.Co + co) * 2 + 0] = sv;
-          a.partial[(blk * a.Co + co) * 2 + 1] = qv;
-        }
-      }
-      __syncthreads();
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -784,237 +549,6 @@ __device__ __forceinline__ float dz_eff_at(const PwBwdArgs& a, size_t gi, size_t
     d = fmaf(e, invV, d);
   }
   return d;
-}
-
-// dgrad: M = input channels (tiles of 32, MT per block), N = positions, K = output channels (chunks of KCH).
-// Same register-prefetch pipeline as the forward: the "input" tile is dz_eff, the weight tile is W^T.
-template <int MT>
-__global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad(PwBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int NPpad = a.NPpad;
-  constexpr int WS2 = 32 * MT + 1;
-  float* Ds = lds;                               // [KCH][NPpad]   dz_eff chunk
-  float* Ws = lds + KCH * NPpad;                 // [KCH][WS2]     W[co_chunk][ci_tile]
-  float* Ss = lds;                               // epilogue scratch [4][32][3]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int n = blockIdx.y;
-  const int r0 = blockIdx.x * a.TR;
-  const int ciBase = blockIdx.z * 32 * MT;
-  const int V = a.V, TR = a.TR, Co = a.Co, Ci = a.Ci;
-  const int rows_valid = min(TR, a.Tout - r0);
-  const int TRV = TR * V;
-  const int Nt = NPpad >> 5;
-  const float invV = 1.f / (float)V;
-  const bool wvec = (Ci & 3) == 0;
-  const bool has_g = a.gz != nullptr, has_c = a.A0 != nullptr;
-
-  f32x16 acc[MT][NTW];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
-
-  f32x4 gr[XCH], zr[XCH];
-  f32x4 wr[2];
-  const int valid4 = (rows_valid * V) >> 2;
-  const int wrow = tid >> 4, wseg = (tid & 15) * 8;     // W^T staging: 16 threads per co row, 8 ci each
-
-  auto issue = [&](int c0) {
-    if (a.vec) {
-#pragma unroll
-      for (int i = 0; i < XCH; ++i) {
-        const int co = c0 + wave + 4 * i;
-        if (co < Co && lane < valid4) {
-          const size_t g = ((size_t)(n * Co + co) * a.Tout + r0) * V + 4 * lane;
-          if (has_g) gr[i] = *reinterpret_cast<const f32x4*>(a.gz + g);
-          if (has_c) zr[i] = *reinterpret_cast<const f32x4*>(a.z + g);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < XCH; ++i) {
-        const int co = c0 + wave + 4 * i;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int p = lane + 64 * q;
-          if (co < Co && p < rows_valid * V) {
-            const size_t g = ((size_t)(n * Co + co) * a.Tout + r0) * V + p;
-            if (has_g) gr[i][q] = a.gz[g];
-            if (has_c) zr[i][q] = a.z[g];
-          }
-        }
-      }
-    }
-    {
-      const int co = c0 + wrow;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int cil = wseg + 4 * q;
-        const int ci = ciBase + cil;
-        if (cil < 32 * MT) {
-          if (wvec) {
-            wr[q] = (co < Co && ci < Ci) ? *reinterpret_cast<const f32x4*>(a.w + (size_t)co * Ci + ci)
-                                         : f32x4{0.f, 0.f, 0.f, 0.f};
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) wr[q][e] = (co < Co && ci + e < Ci) ? a.w[(size_t)co * Ci + ci + e] : 0.f;
-          }
-        }
-      }
-    }
-  };
-
-  auto dz_of = [&](float g, float zv, int co, int p, float A0c, float B0c) -> float {
-    float d = has_g ? g : 0.f;
-    if (has_c) d += fmaf(B0c, zv, A0c);
-    if (a.aug) {
-      const int rl = (int)(((float)p + 0.5f) * invV);
-      const size_t ga = (size_t)(n * Co + co) * a.Tout + r0 + rl;
-      float e = a.gzaug ? a.gzaug[ga] : 0.f;
-      if (has_c) e += fmaf(B0c, a.zaug[ga], A0c);
-      d = fmaf(e, invV, d);
-    }
-    return d;
-  };
-
-  auto commit = [&](int c0) {
-    if (a.vec) {
-#pragma unroll
-      for (int i = 0; i < XCH; ++i) {
-        const int cl = wave + 4 * i, co = c0 + cl;
-        if (lane < (NPpad >> 2)) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (co < Co && lane < valid4) {
-            const float A0c = has_c ? a.A0[co] : 0.f, B0c = has_c ? a.B0[co] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = dz_of(gr[i][e], zr[i][e], co, 4 * lane + e, A0c, B0c);
-          }
-          *reinterpret_cast<f32x4*>(Ds + cl * NPpad + 4 * lane) = v;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < XCH; ++i) {
-        const int cl = wave + 4 * i, co = c0 + cl;
-        const float A0c = (has_c && co < Co) ? a.A0[co] : 0.f, B0c = (has_c && co < Co) ? a.B0[co] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int p = lane + 64 * q;
-          if (p < NPpad) {
-            float v = 0.f;
-            if (co < Co && p < rows_valid * V) v = dz_of(gr[i][q], zr[i][q], co, p, A0c, B0c);
-            Ds[cl * NPpad + p] = v;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int cil = wseg + 4 * q;
-      if (cil < 32 * MT) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Ws[wrow * WS2 + cil + e] = wr[q][e];
-      }
-    }
-  };
-
-  issue(0);
-  for (int c0 = 0; c0 < Co; c0 += KCH) {
-    const int kc = min(KCH, Co - c0);
-    const int kmax = (kc + 1) & ~1;
-    commit(c0);
-    __syncthreads();
-    if (c0 + KCH < Co) issue(c0 + KCH);
-#pragma unroll 4
-    for (int kk = 0; kk < kmax; kk += 2) {
-      float av[MT], bv[NTW];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) av[m] = Ws[(kk + half) * WS2 + 32 * m + l31];
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const int nt = wave + 4 * j;
-        bv[j] = (nt < Nt) ? Ds[(kk + half) * NPpad + 32 * nt + l31] : 0.f;
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-          if (wave + 4 * j < Nt) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[j], acc[m][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    float p0[16], p1[16], p2[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { p0[r] = 0.f; p1[r] = 0.f; p2[r] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const int nt = wave + 4 * j;
-      const int pos = 32 * nt + l31;
-      const int rl = (int)(((float)pos + 0.5f) * invV);
-      if (nt < Nt && pos < TRV && rl < rows_valid) {
-        const int vv = pos - rl * V;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ci = ciBase + 32 * m + mfma_row32(r, half);
-          if (ci < Ci) {
-            const size_t g = ((size_t)(n * Ci + ci) * a.T + (size_t)(r0 + rl) * a.stride) * V + vv;
-            const float xa = a.x1[g];
-            const float sa = a.s1 ? a.s1[ci] : 1.f;
-            float pre = a.s1 ? fmaf(xa, sa, a.h1[ci]) : xa;
-            float xb = 0.f, sb = 1.f;
-            if (a.x2) {
-              xb = a.x2[g];
-              if (a.s2) { sb = a.s2[ci]; pre += fmaf(xb, sb, a.h2[ci]); } else pre += xb;
-            }
-            const float dv = (!a.relu || pre > 0.f) ? acc[m][j][r] : 0.f;
-            a.dx1[g] = dv * sa;
-            if (a.dx2) a.dx2[g] = dv * sb;
-            p0[r] = fmaf(dv, xa, p0[r]);
-            p1[r] += dv;
-            p2[r] = fmaf(dv, xb, p2[r]);
-          }
-        }
-      }
-    }
-    if (a.ipart) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float u0 = p0[r], u1 = p1[r], u2 = p2[r];
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-          u0 += __shfl_xor(u0, off, 64);
-          u1 += __shfl_xor(u1, off, 64);
-          u2 += __shfl_xor(u2, off, 64);
-        }
-        if (l31 == 0) {
-          float* q = Ss + (wave * 32 + mfma_row32(r, half)) * 3;
-          q[0] = u0; q[1] = u1; q[2] = u2;
-        }
-      }
-      __syncthreads();
-      if (tid < 32) {
-        const int ci = ciBase + 32 * m + tid;
-        if (ci < Ci) {
-          float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            const float* q = Ss + (w * 32 + tid) * 3;
-            u0 += q[0]; u1 += q[1]; u2 += q[2];
-          }
-          float* o = a.ipart + (blk * Ci + ci) * 3;
-          o[0] = u0; o[1] = u1; o[2] = u2;
-        }
-      }
-      __syncthreads();
-    }
-  }
 }
 
 // Wave-independent dgrad (product path): same structure as k_pwconv_fwd2 with B = dz_eff straight from HBM
