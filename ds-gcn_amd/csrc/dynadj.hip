@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int KSUB = 3;     // subsets: 2 plain + 1 semantic
+constexpr int NT_DWE = 256; // the per-(sample, edge class) weight-gradient kernel has many small workgroups
 constexpr int NT = 1024;    // threads per workgroup: the LDS image allows one workgroup per CU, so it has to bring all 16 waves
 
 struct DynDims {
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
 //   dWe[e,c,cc] += sum_{(u,w) in class e} dD1[n,c,u,w] * (a1[n,cc,u] - b1[n,cc,w]);   dbe[e,c] += sum dD1[n,c,u,w]
 // The class's pairs (<= 256) are staged in LDS once (dD1 column and delta column per pair), then every (c,cc) output is a
 // short LDS dot product; results are accumulated into dwe/dbe with float atomics (128 adders per address).
-__global__ __launch_bounds__(NT) void k_dynadj_dwe(DynDims d, const float* __restrict__ proj,
+__global__ __launch_bounds__(NT_DWE) void k_dynadj_dwe(DynDims d, const float* __restrict__ proj,
                                                    const float* __restrict__ dd, const int* __restrict__ pair_order,
                                                    const int* __restrict__ class_start, float* __restrict__ dwe,
                                                    float* __restrict__ dbe) {
@@ -309,11 +310,11 @@ __global__ __launch_bounds__(NT) void k_dynadj_dwe(DynDims d, const float* __res
   const float* dd1 = dd + ((size_t)n * KSUB + 1) * mid * VV;
   const float* a1 = proj + ((size_t)n * 9 * mid + 1 * mid) * V;           // rows mid..2mid-1  (a, k=1)
   const float* b1 = proj + ((size_t)n * 9 * mid + 3 * mid) * V;           // rows 3mid..4mid-1 (b, k=1)
-  for (int i0 = threadIdx.x; i0 < mid * np; i0 += NT * 4) {
+  for (int i0 = threadIdx.x; i0 < mid * np; i0 += NT_DWE * 4) {
     float dv[4], ev[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int i = i0 + q * NT;
+      const int i = i0 + q * NT_DWE;
       dv[q] = 0.f; ev[q] = 0.f;
       if (i < mid * np) {
         const int c = i / np, p = i - c * np;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(NT) void k_dynadj_dwe(DynDims d, const float* __res
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int i = i0 + q * NT;
+      const int i = i0 + q * NT_DWE;
       if (i < mid * np) {
         const int c = i / np, p = i - c * np;
         Dl[c * NPs + p] = dv[q];
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(NT) void k_dynadj_dwe(DynDims d, const float* __res
     }
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < mid * mid; o += NT) {
+  for (int o = threadIdx.x; o < mid * mid; o += NT_DWE) {
     const int c = o / mid, cc = o - c * mid;
     float acc = 0.f, accb = 0.f;
     for (int p = 0; p < np; ++p) {
@@ -403,7 +404,7 @@ int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, c
     if (e2 != hipSuccess) return (int)e2;
     attr_dwe = 156 * 1024;
   }
-  hipLaunchKernelGGL(k_dynadj_dwe, dim3(n, E), dim3(NT), lds2, st, d, proj, dd_ws, pair_order, class_start, dwe, dbe);
+  hipLaunchKernelGGL(k_dynadj_dwe, dim3(n, E), dim3(NT_DWE), lds2, st, d, proj, dd_ws, pair_order, class_start, dwe, dbe);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
