@@ -40,6 +40,7 @@ class FlatParams:
                 off += n
         self.numel = total
         self.views = [self.flat_g[off:off + n].view(p.shape) for p, (off, n) in zip(self.params, self.slices)]
+        self.flat_views = [self.flat_g[off:off + n] for (off, n) in self.slices]
 
     def zero_grad(self):
         if self.gather:
@@ -55,10 +56,11 @@ class FlatParams:
         if not self.gather:
             return
         self.flat_g.zero_()
-        dst = [v for v, p in zip(self.views, self.params) if p.grad is not None]
-        src = [p.grad for p in self.params if p.grad is not None]
-        if dst:
-            torch._foreach_copy_(dst, src)
+        live = [(p.grad, off, n) for p, (off, n) in zip(self.params, self.slices) if p.grad is not None]
+        if live and self.flat_g.is_cuda:
+            self._pack_cuda(live)
+        elif live:
+            torch._foreach_copy_([self.flat_g[off:off + n] for _, off, n in live], [g.reshape(-1) for g, _, _ in live])
         for p, v in zip(self.params, self.views):
             p.grad = v
 
@@ -67,6 +69,31 @@ class FlatParams:
         base = self.flat_g.data_ptr()
         return all(p.grad is not None and p.grad.data_ptr() == base + off * self.flat_g.element_size()
                    for p, (off, _) in zip(self.params, self.slices))
+
+
+    def _pack_cuda(self, live):
+        """One HIP launch (dsgcn_pack) instead of one blit per tensor.  The (pointer, offset, length) table goes to the
+        device through a pinned staging buffer that stays alive, so the copy is capturable in a hipGraph (replays
+        see the same gradient addresses: they live in the graph's private pool)."""
+        import numpy as np
+        from . import native
+        k = len(live)
+        if getattr(self, '_pack_host', None) is None or self._pack_host.shape[1] < k:
+            self._pack_host = torch.empty((3, max(k, len(self.params))), dtype=torch.int64).pin_memory()
+            self._pack_dev = torch.empty_like(self._pack_host, device=self.flat_g.device)
+            self._pack_len = torch.empty(self._pack_host.shape[1], dtype=torch.int32, device=self.flat_g.device)
+        grads = [g if g.is_contiguous() else g.contiguous() for g, _, _ in live]
+        self._pack_keep = grads                                   # alive until the kernel has run
+        tab = self._pack_host.numpy()
+        tab[0, :k] = [g.data_ptr() for g in grads]
+        tab[1, :k] = [off for _, off, _ in live]
+        tab[2, :k] = [n for _, _, n in live]
+        self._pack_dev.copy_(self._pack_host, non_blocking=True)
+        self._pack_len.copy_(self._pack_dev[2])
+        st = torch.cuda.current_stream().cuda_stream
+        rc = native.lib().dsgcn_pack(self._pack_dev[0].data_ptr(), self._pack_dev[1].data_ptr(),
+                                     self._pack_len.data_ptr(), k, self.flat_g.data_ptr(), st)
+        native.check(rc, 'dsgcn_pack')
 
 
 class FlatDataParallel:

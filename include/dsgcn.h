@@ -192,6 +192,11 @@ int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, const float*
                          int n, int K, int Co, int V, void* stream);
 int dsgcn_plane_stats(const float* x, float* partial, long planes, int L, void* stream);
 
+/* Pack `count` gradient tensors into the flat data-parallel buffer in one launch: src_table / dst_offsets / numels
+ * are DEVICE arrays (pointers to the tensors, element offsets into dst, element counts). */
+int dsgcn_pack(const float* const* src_table, const long* dst_offsets, const int* numels, int count, float* dst,
+               void* stream);
+
 #ifdef __cplusplus
 }
 #endif
