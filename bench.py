@@ -200,8 +200,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X (the hot path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    force_dist = os.environ.get('DSGCN_BENCH_FORCE_DIST') == '1'      # 1-rank RCCL group: exercises the N>1 code path
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     import dsgcn_amd
@@ -228,9 +230,14 @@ def main():
         flat.collect_grads()
         state['loss'] = out['loss'].detach()
 
+    def exchange():
+        dp.allreduce_grads()
+        if force_dist and world == 1:
+            dist.all_reduce(flat.flat_g)      # 1-rank RCCL all-reduce: same call sequence as N > 1
+
     def eager_step():
         fwd_bwd()
-        dp.allreduce_grads()
+        exchange()
         opt.step()
 
     # untimed warm-up, eager (also populates caches: edge-class lists, momentum buffer, allocator pools)
@@ -253,10 +260,12 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g_a = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_a):
+            # thread_local: the RCCL watchdog thread polls its events while we capture (N > 1); in the default
+            # 'global' mode that would invalidate the capture
+            with torch.cuda.graph(g_a, capture_error_mode='thread_local'):
                 fwd_bwd()
             g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_b):
+            with torch.cuda.graph(g_b, capture_error_mode='thread_local'):
                 opt.step()
             torch.cuda.synchronize()
         except Exception as exc:      # capture is an optimisation; the eager path computes the same thing
@@ -267,7 +276,7 @@ def main():
     def step():
         if use_graph:
             g_a.replay()
-            dp.allreduce_grads()
+            exchange()
             g_b.replay()
         else:
             eager_step()
@@ -320,7 +329,7 @@ def main():
         result['gpu_over_cpu'] = round(result['value'] / cb['value'], 1)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 
