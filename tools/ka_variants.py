@@ -9,7 +9,7 @@ lib = native.lib()
 dev = torch.device('cuda')
 st = torch.cuda.current_stream().cuda_stream
 V = 25
-n = 128
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 shapes = [(24, 64), (48, 64), (48, 32), (96, 32), (96, 16)]
 
 
