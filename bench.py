@@ -173,10 +173,19 @@ def cpu_baseline(budget_s=12.0, batch=16):
         if (el >= budget_s and iters >= 2) or iters >= 50 or el > 4 * budget_s:
             break
     el = time.perf_counter() - t0
+    cpu_model = 'unknown CPU'
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    cpu_model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return dict(value=round(batch * iters / el, 2), unit='clips/s', cores=best_thr, kind='port',
                 sample=f'{iters} fwd+bwd iterations of a {batch}-clip batch (3x{T}x{V}x{M}), oracle/dsgcn_oracle.py, '
                        f'torch {torch.__version__} CPU, {best_thr} intra-op threads (best of 8/16/32; host has '
-                       f'{avail} hw threads), {el:.1f} s')
+                       f'{avail} hw threads: {cpu_model}), {el:.1f} s')
 
 
 def main():
