@@ -318,8 +318,10 @@ __global__ __launch_bounds__(512) void k_tapconv_dgrad(TArgs a) {
 
 // wgrad: grid = (splits, nbr * dch * dch).  Block: a 64 (co) x 64 (ci) tile of one conv window, KT accumulators per wave
 // tile.  Chunk of work = (sample, 2 output frames): Ds[64][KP] = do, Xs[tap][64][KP] = h at the tap-shifted frames.
-template <int KT>
-__global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
+// W8: 512 threads — the (co, ci) tile is still 2x2 wave tiles, the two wave groups split the TAPS (each keeps (KT+1)/2
+// accumulators); used where the LDS image allows only one workgroup per CU.
+template <int KT, bool W8>
+__global__ __launch_bounds__(W8 ? 512 : TC_NT) void k_tapconv_wgrad(TArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int bi = blockIdx.y / (a.dch * a.dch);
   const int rem = blockIdx.y - bi * a.dch * a.dch;
@@ -335,25 +337,28 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
   float* Xs = lds + 64 * LS;                      // [KT][64][LS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int mt = wave >> 1, nt = wave & 1;
+  constexpr int KTG = W8 ? (KT + 1) / 2 : KT;        // taps per wave group
+  const int tap0 = W8 ? (wave >> 2) * KTG : 0;
+  const int mt = (wave >> 1) & 1, nt = wave & 1;
   const int nb = (a.Tout + TRW - 1) / TRW;
   const int total = a.n * nb;
   const int per = (total + a.splits - 1) / a.splits;
   const int ch0 = blockIdx.x * per, ch1 = min(total, ch0 + per);
-  f32x16 acc[KT];
+  f32x16 acc[KTG];
 #pragma unroll
-  for (int k = 0; k < KT; ++k)
+  for (int k = 0; k < KTG; ++k)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
   float dbacc = 0.f;
-  const int row = tid >> 2, quarter = tid & 3;    // staging: 4 threads per channel row
-  constexpr int NPT = 14;                         // positions per thread: 4*14 = 56 >= KP for V1 <= 26
+  constexpr int TPR = W8 ? 8 : 4;                 // staging threads per channel row
+  const int row = tid / TPR, quarter = tid % TPR;
+  constexpr int NPT = 56 / TPR;                   // positions per thread: TPR*NPT = 56 >= KP for V1 <= 26
   float dv[NPT], xv[KT][NPT];
   auto issue = [&](int ch) {                      // all global loads of a chunk, issued before the previous chunk's MFMAs
     const int n = ch / nb, r0 = (ch - n * nb) * TRW;
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
-      const int p = quarter + 4 * j;
+      const int p = quarter + TPR * j;
       const int rl = p / V1, col = p - rl * V1;
       const int tp = r0 + rl;
       const bool live = p < TRW * V1 && tp < a.Tout;
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
     float dsum = 0.f;
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
-      const int p = quarter + 4 * j;
+      const int p = quarter + TPR * j;
       if (p < KP) {
         Ds[row * LS + p] = dv[j];
 #pragma unroll
@@ -382,15 +387,18 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
     }
     dsum += __shfl_xor(dsum, 1, 64);
     dsum += __shfl_xor(dsum, 2, 64);
+    if (W8) dsum += __shfl_xor(dsum, 4, 64);
     dbacc += dsum;
     __syncthreads();
     if (ch + 1 < ch1) issue(ch + 1);
     for (int kk = 0; kk < KP; kk += 2) {
       const float av = Ds[(32 * mt + l31) * LS + kk + half];
 #pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        const float bv = Xs[(k * 64 + 32 * nt + l31) * LS + kk + half];
-        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
+      for (int k = 0; k < KTG; ++k) {
+        if (tap0 + k < KT) {
+          const float bv = Xs[((tap0 + k) * 64 + 32 * nt + l31) * LS + kk + half];
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
+        }
       }
     }
   }
@@ -403,8 +411,8 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad(TArgs a) {
       const int co = 32 * mt + tc_row32(r, half);
       if (co < nco) {
 #pragma unroll
-        for (int k = 0; k < KT; ++k)
-          dwp[((size_t)(coch * 64 + co) * br.cin + cich * 64 + ci) * KT + k] = acc[k][r];
+        for (int k = 0; k < KTG; ++k)
+          if (tap0 + k < KT) dwp[((size_t)(coch * 64 + co) * br.cin + cich * 64 + ci) * KT + tap0 + k] = acc[k][r];
       }
     }
   }
@@ -676,12 +684,20 @@ int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int Cin, int Cou
   }
   const int KP = (2 * V1 + 1) & ~1, LS = KP | 1;
   const size_t lds = (size_t)(1 + KT) * 64 * LS * sizeof(float);
+  const bool w8 = lds > 80 * 1024;                          // one workgroup per CU by LDS -> 8 waves
   dim3 grid((unsigned)splits, (unsigned)(nbr * a.dch * a.dch));
   TC_DISPATCH_KT(KT, {
     static size_t have = 64 * 1024;
-    const int rc = tc_raise_lds(k_tapconv_wgrad<KTC>, lds, &have);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_tapconv_wgrad<KTC>, grid, dim3(TC_NT), lds, (hipStream_t)stream, a);
+    static size_t have8 = 64 * 1024;
+    if (w8) {
+      const int rc = tc_raise_lds(k_tapconv_wgrad<KTC, true>, lds, &have8);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_tapconv_wgrad<KTC, true>), grid, dim3(512), lds, (hipStream_t)stream, a);
+    } else {
+      const int rc = tc_raise_lds(k_tapconv_wgrad<KTC, false>, lds, &have);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_tapconv_wgrad<KTC, false>), grid, dim3(TC_NT), lds, (hipStream_t)stream, a);
+    }
   })
   DSGCN_LAUNCH_CHECK();
   return 0;

@@ -533,7 +533,9 @@ class _TapBranches(torch.autograd.Function):
             splits = max(64, min(1024, (1 << 21) // pstride)) // 4 * 4
             splits = max(4, min(splits, (n * Tout) // 4 * 4))
         else:
-            splits = max(16, min(256, (1 << 21) // pstride))
+            # wide windows: ~512 workgroups over (64x64 tiles) x (K-splits), partial buffer capped at 64 MB
+            tiles = sum(((ci + 63) // 64) * ((co + 63) // 64) for t, ci, co in zip(types, cins, couts) if t == 0)
+            splits = max(16, min(256, 512 // max(tiles, 1), (1 << 24) // pstride))
             splits = max(1, min(splits, n * ((Tout + 1) // 2)))
         part = torch.empty((splits, pstride), device=h.device, dtype=torch.float32)
         base = part.data_ptr()
