@@ -145,6 +145,45 @@ def test_full_size_vs_reference_fixture(name, T, V, classes):
     assert ours < max(2 * theirs, 2e-3), (ours, theirs)
 
 
+@pytest.mark.parametrize('kind,T,N', [('ds', 18, 3), ('ds', 7, 1), ('ds', 33, 2), ('ctrgcn', 18, 3), ('stgcnpp', 9, 2),
+                                      ('stgcn', 21, 1)])
+def test_ragged_shapes_vs_oracle(kind, T, N):
+    """Frame counts that are not multiples of 4 / of the stride (the non-vectorised and remainder paths of every kernel),
+    single-clip batches: reduced-width models against the CPU oracle, logits and loss 1e-4."""
+    from test_host_api import other_cfg
+    if kind == 'ds':
+        cfg = ds_cfg(12, 'nturgb+d')
+        cfg['backbone'].update(base_channels=16, num_stages=4, inflate_stages=[3], down_stages=[3])
+    else:
+        cfg = other_cfg(kind, 12, base_channels=16, num_stages=4, inflate_stages=[3], down_stages=[3])
+    cfg['cls_head']['in_channels'] = 32
+    np.random.seed(1)
+    torch.manual_seed(1)
+    m = D.build_model(cfg)
+    g = torch.Generator().manual_seed(T * 10 + N)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith(('alpha', 'beta', 'add_coeff')):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(N, 1, 2, T, 25, 3, generator=g)
+    y = torch.randint(0, 12, (N, 1), generator=g)
+    if kind == 'ds':
+        gc = O.graph_constants('nturgb+d')
+        plan = O.dgstgcn_plan(3, 16, 2, 4, (3,), (3,))
+        ref_logits, ref_loss = O.recognizer_forward_train(x, y, sd, gc['node_type'], gc['edge_type'], plan)
+    else:
+        plan = O.ctrgcn_plan(3, 16, 4, (3,), (3,)) if kind == 'ctrgcn' else O.dgstgcn_plan(3, 16, 2, 4, (3,), (3,))
+        ref_logits, ref_loss = O.recognizer_forward_train_backbone(kind, x, y, sd, plan)
+    m = m.cuda().train()
+    logits = m.cls_head(m.extract_feat(x.cuda()[:, 0]))
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda().squeeze(-1))
+    loss.backward()
+    assert rel(logits.detach().cpu(), ref_logits) < 1e-4
+    assert abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()) < 1e-4
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
 def test_gradient_packing_modes_agree():
     """FlatParams(gather=True) (autograd hands over gradient tensors, one dsgcn_pack launch packs them) must give the
     same flat gradient buffer as the in-place accumulating mode."""
@@ -213,6 +252,12 @@ def test_full_size_properties():
     zp = torch.randn(128, 24, 64, 25, device='cuda')
     a1 = torch.randn(128, 24, 25, 25, device='cuda')
     a2 = torch.randn(128, 24, 25, 25, device='cuda')
+    # permuting the clips permutes the logits (train-mode BN statistics are permutation-invariant): BASELINE size
+    perm = torch.randperm(64, generator=g).cuda()
+    with torch.no_grad():
+        l0 = m.cls_head(m.extract_feat(x[:, 0]))
+        l1 = m.cls_head(m.extract_feat(x[perm][:, 0]))
+    assert rel(l1.cpu(), l0[perm].cpu()) < 1e-5
     lhs = K.aggregate(zp, None, False, a1 + a2)
     rhs = K.aggregate(zp, None, False, a1) + K.aggregate(zp, None, False, a2)
     assert rel(lhs.cpu(), rhs.cpu()) < 1e-6                   # linear in the adjacency
