@@ -192,7 +192,9 @@ int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, const float*
                          int n, int K, int Co, int V, void* stream);
 int dsgcn_plane_stats(const float* x, float* partial, long planes, int L, void* stream);
 
-/* Pack `count` gradient tensors into the flat data-parallel buffer in one launch: src_table / dst_offsets / numels
+/* Replaces the per-parameter gradient copies of torch DDP's bucketing (the reference wraps the model in
+ * MMDistributedDataParallel, pyskl/apis/train.py:94-102).  Pack `count` gradient tensors into the flat data-parallel
+ * buffer in one launch: src_table / dst_offsets / numels
  * are DEVICE arrays (pointers to the tensors, element offsets into dst, element counts). */
 int dsgcn_pack(const float* const* src_table, const long* dst_offsets, const int* numels, int count, float* dst,
                void* stream);
