@@ -121,7 +121,9 @@ __global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d, const float* __res
   float* out = ahat + (size_t)n * KSUB * mid * VV;
   const int total = KSUB * mid * VV;
   const float al0 = alpha[0], al1 = alpha[1], al2 = alpha[2], be0 = beta[0], be1 = beta[1], be2 = beta[2];
-  for (int i = threadIdx.x; i < total; i += NT) {
+  // gridDim.y workgroups share one sample (each repeats the small prepare step): at n = 128 one workgroup per sample
+  // would leave half of the 256 CUs idle
+  for (int i = threadIdx.x + NT * blockIdx.y; i < total; i += NT * gridDim.y) {
     const int k = i / (mid * VV);
     int r = i - k * mid * VV;
     const int c = r / VV;
@@ -372,7 +374,7 @@ int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, cons
     if (e != hipSuccess) return (int)e;
     attr_fwd = 156 * 1024;
   }
-  hipLaunchKernelGGL(k_dynadj_fwd, dim3(n), dim3(NT), lds, (hipStream_t)stream, d, proj, A, alpha, beta, we, be,
+  hipLaunchKernelGGL(k_dynadj_fwd, dim3(n, n <= 128 ? 2 : 1), dim3(NT), lds, (hipStream_t)stream, d, proj, A, alpha, beta, we, be,
                      node_type, edge_type, ahat);
   DSGCN_LAUNCH_CHECK();
   return 0;
