@@ -42,6 +42,21 @@ def ds_cfg(num_classes=CLASSES, layout='nturgb+d'):
         cls_head=dict(type='GCNHead', num_classes=num_classes, in_channels=256))
 
 
+def other_cfg(kind, num_classes=60, **bk):
+    """Model dicts of the other backbones that run on the same kernels: 'stgcn' (vanilla ST-GCN, BASELINE config 1),
+    'stgcnpp' (configs/stgcn++), 'ctrgcn' (classic CTR-GCN, BASELINE config 4)."""
+    if kind == 'ctrgcn':
+        backbone = dict(type='CTRGCN', gcn_type='unit_ctrgcn', graph_cfg=dict(layout='nturgb+d', mode='spatial'))
+    elif kind == 'stgcnpp':
+        backbone = dict(type='STGCN', gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn',
+                        graph_cfg=dict(layout='nturgb+d', mode='spatial'))
+    else:
+        backbone = dict(type='STGCN', graph_cfg=dict(layout='nturgb+d', mode='stgcn_spatial'))
+    backbone.update(bk)
+    return dict(type='RecognizerGCN', backbone=backbone,
+                cls_head=dict(type='GCNHead', num_classes=num_classes, in_channels=256))
+
+
 def build_model(seed=0):
     import dsgcn_amd
     np.random.seed(seed)

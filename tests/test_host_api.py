@@ -11,7 +11,7 @@ import dsgcn_amd as D
 import torch_ops
 from test_oracle_golden import GOLD, load, rel, sd_of
 
-from bench import ds_cfg
+from bench import ds_cfg, other_cfg
 
 
 def test_registry_and_build_errors():
@@ -61,19 +61,6 @@ def test_graph_matches_golden():
     assert np.array_equal(a, np.random.randn(3, 25, 25) * .02 + .04)      # consumes the numpy global RNG like the reference
     with pytest.raises(AttributeError):
         D.DGSTGCN(graph_cfg=dict(layout='openpose', mode='spatial'), gcn_type='dgphgcn1', tcn_type='dgmstcn')
-
-
-def other_cfg(kind, num_classes=60, **bk):
-    if kind == 'ctrgcn':
-        backbone = dict(type='CTRGCN', gcn_type='unit_ctrgcn', graph_cfg=dict(layout='nturgb+d', mode='spatial'))
-    elif kind == 'stgcnpp':
-        backbone = dict(type='STGCN', gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn',
-                        graph_cfg=dict(layout='nturgb+d', mode='spatial'))
-    else:
-        backbone = dict(type='STGCN', graph_cfg=dict(layout='nturgb+d', mode='stgcn_spatial'))
-    backbone.update(bk)
-    return dict(type='RecognizerGCN', backbone=backbone,
-                cls_head=dict(type='GCNHead', num_classes=num_classes, in_channels=256))
 
 
 @pytest.mark.parametrize('name,cfg', [('dsstgcn_ntu60', ds_cfg(60, 'nturgb+d')), ('dsstgcn_ntu120', ds_cfg(120, 'nturgb+d')),

@@ -10,7 +10,7 @@ import torch
 import dsgcn_amd as D
 from dsgcn_amd import native
 from oracle import dsgcn_oracle as O
-from bench import build_model, ds_cfg
+from bench import build_model, ds_cfg, other_cfg
 from test_oracle_golden import GOLD, load, rel, sd_of
 
 pytestmark = pytest.mark.gpu
@@ -82,7 +82,6 @@ def test_full_model_vs_oracle(layout, V, T, classes):
 @pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn', 'stgcnpp'])
 def test_full_other_backbones_vs_oracle(kind):
     """Full-width classic CTR-GCN (BASELINE config 4) and vanilla ST-GCN (config 1), 2 clips, against the CPU oracle."""
-    from test_host_api import other_cfg
     np.random.seed(0)
     torch.manual_seed(0)
     m = D.build_model(other_cfg(kind))
@@ -113,7 +112,6 @@ def test_full_size_vs_reference_fixture(name, T, V, classes):
     import sys
     sys.path.insert(0, GOLD)
     from closed_form import closed_form_fill, counter_input
-    from test_host_api import other_cfg
     cfg = {'dsstgcn_ntu60': ds_cfg(60, 'nturgb+d'), 'dsstgcn_k400_coco': ds_cfg(400, 'coco'),
            'ctrgcn_ntu60': other_cfg('ctrgcn'), 'stgcnpp_ntu60': other_cfg('stgcnpp')}[name]
     np.random.seed(0)
@@ -150,7 +148,6 @@ def test_full_size_vs_reference_fixture(name, T, V, classes):
 def test_ragged_shapes_vs_oracle(kind, T, N):
     """Frame counts that are not multiples of 4 / of the stride (the non-vectorised and remainder paths of every kernel),
     single-clip batches: reduced-width models against the CPU oracle, logits and loss 1e-4."""
-    from test_host_api import other_cfg
     if kind == 'ds':
         cfg = ds_cfg(12, 'nturgb+d')
         cfg['backbone'].update(base_channels=16, num_stages=4, inflate_stages=[3], down_stages=[3])

@@ -6,7 +6,7 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np, torch
 import dsgcn_amd as D
 import bench
-from test_host_api import other_cfg
+from bench import other_cfg
 kind = sys.argv[1] if len(sys.argv) > 1 else 'ds'
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 np.random.seed(0); torch.manual_seed(0)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np
 import torch
 import dsgcn_amd as D
-from test_host_api import other_cfg
+from bench import other_cfg
 
 kind = sys.argv[1] if len(sys.argv) > 1 else 'ctrgcn'
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
