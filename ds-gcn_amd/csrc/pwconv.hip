@@ -442,17 +442,20 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
                                                      float eps, float* __restrict__ mean_out,
                                                      float* __restrict__ var_out, float* __restrict__ scale_out,
                                                      float* __restrict__ shift_out, int c_affine) {
-  __shared__ double red[32][32][2];
-  const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  // 8 channels x 128 row slices per block: the kernel is a latency chain over the partial rows (up to ~1800 of them),
+  // so the rows are spread over many threads and C/8 blocks rather than walked by 32 slices in C/32 blocks
+  constexpr int CB = 8, NS = 128;
+  __shared__ double red[NS][CB][2];
+  const int cl = threadIdx.x & (CB - 1), slice = threadIdx.x / CB;
+  const int c = blockIdx.x * CB + cl;
   double s = 0.0, q = 0.0;
   if (c < C) {
     const float2* p2 = reinterpret_cast<const float2*>(partial);
-    for (int b0 = slice; b0 < nblk; b0 += 32 * 4) {
+    for (int b0 = slice; b0 < nblk; b0 += NS * 4) {
       float2 v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int b = b0 + 32 * j;
+        const int b = b0 + NS * j;
         v[j] = b < nblk ? p2[(size_t)b * C + c] : float2{0.f, 0.f};
       }
 #pragma unroll
@@ -462,9 +465,17 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
   red[slice][cl][0] = s;
   red[slice][cl][1] = q;
   __syncthreads();
+  // tree over the slices (fixed order: deterministic)
+  for (int h = NS / 2; h >= 1; h >>= 1) {
+    if (slice < h) {
+      red[slice][cl][0] += red[slice + h][cl][0];
+      red[slice][cl][1] += red[slice + h][cl][1];
+    }
+    __syncthreads();
+  }
   if (slice == 0 && c < C) {
-#pragma unroll
-    for (int i = 1; i < 32; ++i) { s += red[i][cl][0]; q += red[i][cl][1]; }
+    s = red[0][cl][0];
+    q = red[0][cl][1];
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -1116,7 +1127,7 @@ int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const
                       float eps, float* mean_out, float* var_out, float* scale_out, float* shift_out, int c_affine,
                       void* stream) {
   if (!partial || !mean_out || !var_out || !scale_out || !shift_out || nblk <= 0 || C <= 0) return DSGCN_EINVAL;
-  hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, partial, nblk,
+  hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)((C + 7) / 8)), dim3(1024), 0, (hipStream_t)stream, partial, nblk,
                      C, count, gamma, beta, eps, mean_out, var_out, scale_out, shift_out, c_affine);
   DSGCN_LAUNCH_CHECK();
   return 0;
