@@ -495,22 +495,24 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
 }
 
 // Column sums of a row-major (R, C) fp32 matrix -> out (C), accumulated in fp64 (partial-buffer reductions).
-__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, int R, int C, float* __restrict__ out,
-                                                 int inner) {
+struct ColJob { const float* src; float* out; int R, C, inner, nblk; };
+
+__device__ __forceinline__ void colsum_body(const ColJob& j, int bid) {
   __shared__ double red[32][32];
   const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  const int c = bid * 32 + cl;
+  const int R = j.R, C = j.C;
   double s = 0.0;
   if (c < C) {
     for (int r0 = slice; r0 < R; r0 += 32 * 4) {
       float v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = r0 + 32 * j;
-        v[j] = r < R ? src[(size_t)r * C + c] : 0.f;
+      for (int q = 0; q < 4; ++q) {
+        const int r = r0 + 32 * q;
+        v[q] = r < R ? j.src[(size_t)r * C + c] : 0.f;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s += (double)v[j];
+      for (int q = 0; q < 4; ++q) s += (double)v[q];
     }
   }
   red[slice][cl] = s;
@@ -520,8 +522,14 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ src, 
     for (int i = 1; i < 32; ++i) s += red[i][cl];
     // inner > 1: columns are (C/inner, inner) pairs and leave transposed, out (inner, C/inner), so that each of the
     // `inner` reductions is a contiguous vector for its consumer
-    out[inner > 1 ? (c % inner) * (C / inner) + c / inner : c] = (float)s;
+    j.out[j.inner > 1 ? (c % j.inner) * (C / j.inner) + c / j.inner : c] = (float)s;
   }
+}
+
+// up to two independent reductions in one launch (the weight-gradient and the input-affine partials of one conv)
+__global__ __launch_bounds__(1024) void k_colsum(ColJob a, ColJob b) {
+  if ((int)blockIdx.x < a.nblk) colsum_body(a, blockIdx.x);
+  else colsum_body(b, blockIdx.x - a.nblk);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1136,7 +1144,8 @@ int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const
 // out[c] = sum_r src[r, c]  (fp64 accumulation).
 int dsgcn_colsum(const float* src, int R, int C, float* out, void* stream) {
   if (!src || !out || R <= 0 || C <= 0) return DSGCN_EINVAL;
-  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, src, R, C, out, 1);
+  ColJob a{src, out, R, C, 1, (C + 31) / 32}, b{nullptr, nullptr, 0, 0, 1, 0};
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)a.nblk), dim3(1024), 0, (hipStream_t)stream, a, b);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -1144,8 +1153,20 @@ int dsgcn_colsum(const float* src, int R, int C, float* out, void* stream) {
 // Same, with the result transposed: src (R, C/inner, inner) -> out (inner, C/inner).
 int dsgcn_colsum_t(const float* src, int R, int C, int inner, float* out, void* stream) {
   if (!src || !out || R <= 0 || C <= 0 || inner <= 0 || C % inner) return DSGCN_EINVAL;
-  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, src, R, C, out,
-                     inner);
+  ColJob a{src, out, R, C, inner, (C + 31) / 32}, b{nullptr, nullptr, 0, 0, 1, 0};
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)a.nblk), dim3(1024), 0, (hipStream_t)stream, a, b);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Two reductions (as dsgcn_colsum_t each; inner = 1 for the plain form) in one launch.
+int dsgcn_colsum2(const float* src_a, int Ra, int Ca, int inner_a, float* out_a, const float* src_b, int Rb, int Cb,
+                  int inner_b, float* out_b, void* stream) {
+  if (!src_a || !out_a || !src_b || !out_b || Ra <= 0 || Ca <= 0 || Rb <= 0 || Cb <= 0 || inner_a <= 0 ||
+      inner_b <= 0 || Ca % inner_a || Cb % inner_b)
+    return DSGCN_EINVAL;
+  ColJob a{src_a, out_a, Ra, Ca, inner_a, (Ca + 31) / 32}, b{src_b, out_b, Rb, Cb, inner_b, (Cb + 31) / 32};
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)(a.nblk + b.nblk)), dim3(1024), 0, (hipStream_t)stream, a, b);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

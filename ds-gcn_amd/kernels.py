@@ -121,6 +121,39 @@ def colsum(t, split_last=False):
     return _colsum_raw(t, R, C).view(shape)
 
 
+def _fold(R, C):
+    g = 1
+    while R % (2 * g) == 0 and g * C < 8192 and R // (2 * g) >= 16:
+        g *= 2
+    return g
+
+
+def colsum_pair(ta, tb, split_last_b=False):
+    """colsum(ta), colsum(tb, split_last=split_last_b) with both reductions sharing their launches (two instead of up
+    to four: the folded first stages together, then the second stages)."""
+    dev = ta.device
+    Ra, Rb = ta.shape[0], tb.shape[0]
+    Ca, Cb = ta.numel() // Ra, tb.numel() // Rb
+    kb = tb.shape[-1] if split_last_b else 1
+    ga, gb = _fold(Ra, Ca), _fold(Rb, Cb)
+    lib = native.lib()
+    outa = torch.empty(Ca, device=dev, dtype=torch.float32)
+    outb = torch.empty(Cb, device=dev, dtype=torch.float32)
+    if ga > 1 and gb > 1:
+        ma = torch.empty(ga * Ca, device=dev, dtype=torch.float32)
+        mb = torch.empty(gb * Cb, device=dev, dtype=torch.float32)
+        native.check(lib.dsgcn_colsum2(_ptr(ta), Ra // ga, ga * Ca, 1, _ptr(ma), _ptr(tb), Rb // gb, gb * Cb, 1, _ptr(mb),
+                                       _stream()), 'dsgcn_colsum2')
+        native.check(lib.dsgcn_colsum2(_ptr(ma), ga, Ca, 1, _ptr(outa), _ptr(mb), gb, Cb, kb, _ptr(outb), _stream()),
+                     'dsgcn_colsum2')
+    elif ga == 1 and gb == 1:
+        native.check(lib.dsgcn_colsum2(_ptr(ta), Ra, Ca, 1, _ptr(outa), _ptr(tb), Rb, Cb, kb, _ptr(outb), _stream()),
+                     'dsgcn_colsum2')
+    else:
+        return colsum(ta), colsum(tb, split_last=split_last_b)
+    return outa.view(ta.shape[1:]), (outb.view(kb, Cb // kb) if split_last_b else outb.view(tb.shape[1:]))
+
+
 def _f32c(t):
     if t is None:
         return None
@@ -346,12 +379,14 @@ class _PwConv(torch.autograd.Function):
                                     _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), wpart.data_ptr(),
                                     wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, stride, aug, st)
         native.check(rc, 'dsgcn_pwconv_wgrad')
-        wsum = colsum(wpart)
+        if ipart is not None:
+            wsum, red = colsum_pair(wpart, ipart, split_last_b=True)
+        else:
+            wsum = colsum(wpart)
         dw = wsum[:Co * Ci].view(wshape)
         db = wsum[Co * Ci:] if has_bias else None
         ds1 = dh1 = ds2 = dh2 = None
         if ipart is not None:
-            red = colsum(ipart, split_last=True)
             if s1 is not None:
                 ds1, dh1 = red[0], red[1]
             if s2 is not None:

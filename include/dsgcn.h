@@ -138,6 +138,9 @@ int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const
 int dsgcn_colsum(const float* src, int R, int C, float* out, void* stream);
 /* same, result transposed: src (R, C/inner, inner) -> out (inner, C/inner): every one of the `inner` sums contiguous */
 int dsgcn_colsum_t(const float* src, int R, int C, int inner, float* out, void* stream);
+/* two such reductions in one launch (inner = 1: plain) */
+int dsgcn_colsum2(const float* src_a, int Ra, int Ca, int inner_a, float* out_a, const float* src_b, int Rb, int Cb,
+                  int inner_b, float* out_b, void* stream);
 /* BN-statistics backward coefficients: dz_eff = gz + A0[c] + B0[c]*z; also d gamma / d beta. */
 int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* mean, const float* var,
                       const float* gamma, float eps, double count, int C, int c_affine, float* dgamma, float* dbeta,
