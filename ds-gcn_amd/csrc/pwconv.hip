@@ -728,8 +728,10 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad2(PwBwdArgs a) {
 
   // PREX: the epilogue's operands (the forward input at this tile, for the ReLU mask / affine / partial sums) are
   // fetched before the K loop instead of after it, where their latency is fully exposed
+  // a plain input (no affine, no ReLU, no second operand — `pre`, `down`, the projections) is not needed at all here
+  const bool need_x = a.relu || a.s1 != nullptr || a.x2 != nullptr;
   float xpre[PREX ? MT : 1][PREX ? 16 : 1], ypre[PREX ? MT : 1][PREX ? 16 : 1];
-  if (PREX) {
+  if (PREX && need_x) {
     const size_t cst = (size_t)a.T * V;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_dgrad2(PwBwdArgs a) {
         float dv = 0.f, xa = 0.f, xb = 0.f;
         if (ci < Ci && pok[j]) {
           const size_t g = ((size_t)n * Ci + ci) * cstride + goff[j];
-          xa = PREX ? xpre[m][r] : a.x1[g];
+          xa = !need_x ? 0.f : (PREX ? xpre[m][r] : a.x1[g]);
           const float sa = a.s1 ? a.s1[ci] : 1.f;
           float pre = a.s1 ? fmaf(xa, sa, a.h1[ci]) : xa;
           float sb = 1.f;
