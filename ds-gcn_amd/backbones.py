@@ -52,7 +52,11 @@ class _FusedBlock(nn.Module):
             self.residual = unit_tcn(in_channels, out_channels, kernel_size=1, stride=stride)
 
     def forward_fused(self, x, xbar=None, want_xbar=False):
-        g = self._gcn_deferred(x, xbar)
+        # the block input has up to three consumers (gcn main path, gcn residual operand, block residual): give each its
+        # own alias so that their gradients are summed in one launch instead of autograd's pairwise adds
+        xa, xb, xc = kernels.ops().tee3(x)
+        g = self._gcn_deferred(xa, xbar, xb)
+        x = xc
         t = self.tcn.forward_deferred(g)
         if getattr(self.tcn, 'drop', None) is not None and self.tcn.drop.p > 0 and self.training:
             t = type(t)(self.tcn.drop(t.materialize()), None, None, None, False)
@@ -94,8 +98,8 @@ class DGBlock(_FusedBlock):
         self.relu = nn.ReLU()
         self._set_residual(in_channels, out_channels, stride, residual)
 
-    def _gcn_deferred(self, x, xbar):
-        return self.gcn.forward_deferred(x, xbar)
+    def _gcn_deferred(self, x, xbar, x_res):
+        return self.gcn.forward_deferred(x, xbar, x_res)
 
 
 class STGCNBlock(_FusedBlock):
@@ -118,8 +122,8 @@ class STGCNBlock(_FusedBlock):
         self.relu = nn.ReLU()
         self._set_residual(in_channels, out_channels, stride, residual)
 
-    def _gcn_deferred(self, x, xbar):
-        return self.gcn.forward_deferred(x)
+    def _gcn_deferred(self, x, xbar, x_res):
+        return self.gcn.forward_deferred(x, x_res)
 
 
 class CTRGCNBlock(_FusedBlock):
@@ -147,8 +151,8 @@ class CTRGCNBlock(_FusedBlock):
 
     tcn = property(lambda self: self.tcn1)
 
-    def _gcn_deferred(self, x, xbar):
-        return self.gcn1.forward_deferred(x, xbar)
+    def _gcn_deferred(self, x, xbar, x_res):
+        return self.gcn1.forward_deferred(x, xbar, x_res)
 
 
 def _stage_kwargs(kwargs, num_stages):

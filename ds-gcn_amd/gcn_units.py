@@ -183,8 +183,11 @@ class dgphgcn1(nn.Module):
             c1.weight.flatten(1), c1.bias, c2.weight.flatten(1), c2.bias, cs.weight.flatten(1), cs.bias,
             el.weight.flatten(1), el.bias, self.node_type_idx, self.edge_type_idx)
 
-    def forward_deferred(self, x, xbar=None):
+    def forward_deferred(self, x, xbar=None, x_res=None):
+        """x_res: an alias of x for the residual operand (lets the caller route the gradients of the two uses of x
+        separately, see kernels.tee3)."""
         ops = kernels.ops()
+        x_res = x if x_res is None else x_res
         if xbar is None:
             xbar = ops.tmean(x)
         fork = getattr(ops, 'side_branch', None)
@@ -199,8 +202,8 @@ class dgphgcn1(nn.Module):
         y = ops.aggregate(zp, ap, True, ahat)
         zo, _, ao = conv_bn(y, None, None, None, False, self.post, 1, False, self.bn)
         if self.down is None:
-            return Deferred(zo, ao, x, None, True)
-        zd, _, ad = conv_bn(x, None, None, None, False, self.down[0], 1, False, self.down[1])
+            return Deferred(zo, ao, x_res, None, True)
+        zd, _, ad = conv_bn(x_res, None, None, None, False, self.down[0], 1, False, self.down[1])
         return Deferred(zo, ao, zd, ad, True)
 
     def forward(self, x, A=None):
@@ -245,16 +248,17 @@ class unit_gcn(nn.Module):
         if with_res and in_channels != out_channels:
             self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), _norm_layer(norm, out_channels))
 
-    def forward_deferred(self, x):
+    def forward_deferred(self, x, x_res=None):
         ops = kernels.ops()
+        x_res = x if x_res is None else x_res
         h = ops.pwconv(x, None, None, None, False, self.conv.weight, self.conv.bias, 1, False)[0]
         y, ay = op_bn(self.bn, lambda g, b, eps, want: ops.aggregate_sum(h, self.A, self.num_subsets, g, b, eps, want),
                       lambda y: y.shape[0] * y.shape[2] * y.shape[3])
         if not self.with_res:
             return Deferred(y, ay, None, None, True)
         if self.down is None:
-            return Deferred(y, ay, x, None, True)
-        zd, _, ad = conv_bn(x, None, None, None, False, self.down[0], 1, False, self.down[1])
+            return Deferred(y, ay, x_res, None, True)
+        zd, _, ad = conv_bn(x_res, None, None, None, False, self.down[0], 1, False, self.down[1])
         return Deferred(y, ay, zd, ad, True)
 
     def forward(self, x, A=None):
@@ -320,8 +324,9 @@ class unit_ctrgcn(nn.Module):
         self.soft = nn.Softmax(-2)
         self.relu = nn.ReLU(inplace=True)
 
-    def forward_deferred(self, x, xbar=None):
+    def forward_deferred(self, x, xbar=None, x_res=None):
         ops = kernels.ops()
+        x_res = x if x_res is None else x_res
         if xbar is None:
             xbar = ops.tmean(x)
         cs = self.convs
@@ -335,8 +340,8 @@ class unit_ctrgcn(nn.Module):
         y, ay = op_bn(self.bn, lambda g, b, eps, want: ops.aggregate_sum(x3, ahat, self.num_subset, g, b, eps, want),
                       lambda y: y.shape[0] * y.shape[2] * y.shape[3])
         if self.down is None:
-            return Deferred(y, ay, x, None, True)
-        zd, _, ad = conv_bn(x, None, None, None, False, self.down[0], 1, False, self.down[1])
+            return Deferred(y, ay, x_res, None, True)
+        zd, _, ad = conv_bn(x_res, None, None, None, False, self.down[0], 1, False, self.down[1])
         return Deferred(y, ay, zd, ad, True)
 
     def forward(self, x):

@@ -195,6 +195,11 @@ int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, const float*
                          int n, int K, int Co, int V, void* stream);
 int dsgcn_plane_stats(const float* x, float* partial, long planes, int L, void* stream);
 
+/* out = a + b (+ c), n elements (c may be NULL; 16-B aligned buffers): the gradients of one block input from its
+ * consumers (pre conv, residual operand of the temporal unit, block residual: dgstgcn.py:63-65) summed in one pass —
+ * replaces autograd's pairwise accumulation. */
+int dsgcn_add3(const float* a, const float* b, const float* c, float* out, long n, void* stream);
+
 /* Replaces the per-parameter gradient copies of torch DDP's bucketing (the reference wraps the model in
  * MMDistributedDataParallel, pyskl/apis/train.py:94-102).  Pack `count` gradient tensors into the flat data-parallel
  * buffer in one launch: src_table / dst_offsets / numels
