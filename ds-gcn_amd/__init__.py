@@ -15,7 +15,7 @@ from .heads import GCNHead, SimpleHead
 from .gcn_units import dgphgcn1, unit_gcn, unit_ctrgcn, CTRGC, Deferred
 from .tcn_units import dgmstcn, mstcn, unit_tcn, MSTCN
 from .backbones import DGSTGCN, STGCN, CTRGCN, DGBlock, STGCNBlock, CTRGCNBlock
-from .recognizers import RecognizerGCN, BaseRecognizer
+from .recognizers import RecognizerGCN, reduce_log_vars, gather_results
 from . import kernels
 from .data_parallel import FlatParams, FlatDataParallel, shard_batch
 from .train import FlatSGD, cosine_lr

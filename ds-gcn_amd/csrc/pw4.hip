@@ -1,0 +1,470 @@
+// K-C, wide-load form ("pw4"): the 1x1 channel mix with 16-byte-per-lane operand loads.
+//
+// Same math as pwconv.hip (which documents the reference lines this replaces: gcn.py:2165-2169,2209-2215,2363-2365,
+// tcn.py:379-404,422,427): out[n,m,pos] = sum_k A[m,k] * B'[n,k,pos], B' = the "virtual" operand (deferred BatchNorm
+// affine / ReLU / second stream applied while loading).  Forward: A = W (m = co, k = ci), B = the layer input.
+// Data gradient: A = W^T (m = ci, k = co), B' = dz_eff = gz + A0[co] + B0[co]*z, epilogue = ReLU mask / affine of the
+// forward's virtual input + the per-channel sums for d scale / d shift.
+//
+// Why this form (profiles/r02/kc_counters_before.csv): the first kernel read the B operand with 4-byte-per-lane loads
+// (two 128-B segments per wave instruction, 64 different channel rows per wave) and reached 2.2 TB/s with the MFMA pipe
+// 23 % busy — HBM saw 128-B visits scattered over rows 6.4 KB apart.  Here a lane owns NQ = 4 (or 2) CONSECUTIVE
+// positions of one channel: one buffer_load_dwordx4 per k-step brings two 512-B row segments, and register q of the
+// loaded vector is directly the B fragment of position sub-tile q (sub-tile q = positions {NQ*j + q}: the position
+// order inside the wave's 32*NQ-position tile is a permutation the store undoes for free, because the four results
+// of a lane are again 16 consecutive bytes).  Per k-step a wave issues 1 VMEM load, MT LDS reads and MT*NQ MFMAs
+// (v_mfma_f32_32x32x2_f32), with PD k-steps of operand prefetch in flight and no barrier inside the K loop (the whole
+// weight block of the workgroup's 32*MT output channels sits in LDS).  Sample base folded into the buffer resource:
+// offsets stay 32-bit for any batch size and channels past K read as zero through the bounds check.
+#include "common.h"
+
+namespace {
+
+constexpr int P4_NT = 256;
+constexpr int P4_OOB = 0x7ffffff0;
+
+struct Pw4Args {
+  const float* b1; const float* b2;                                        // B streams (n, K, L); b2 NULL unless MODE 2
+  const float* ps1; const float* ph1; const float* ps2; const float* ph2;  // per-k affine (NULL = 1 / 0)
+  int relu;
+  const float* w; int w_ldm, w_ldk;                                        // A[m][k] = w[m*w_ldm + k*w_ldk]
+  const float* bias;                                                       // per m, NULL ok
+  float* out;                                                              // (n, M, L)
+  float* partial;                                                          // EPI 0: [ngrp][M][2] or NULL
+  const float* ex1; const float* ex2;                                      // EPI 1: forward operands at (n, M, L)
+  const float* es1; const float* eh1; const float* es2; const float* eh2;
+  int erelu;
+  float* out2; float* ipart;                                               // EPI 1: d x2 or NULL; [ngrp][M][3] or NULL
+  int n, K, M, L, ntl, WT, cc, Kpad;
+};
+
+template <int NQ> struct VQ;
+template <> struct VQ<4> { typedef float T __attribute__((ext_vector_type(4))); };
+template <> struct VQ<2> { typedef float T __attribute__((ext_vector_type(2))); };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t p4_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, bytes, 0x00020000);
+}
+
+template <int NQ>
+__device__ __forceinline__ typename VQ<NQ>::T p4_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  if constexpr (NQ == 4) {
+    return __builtin_bit_cast(typename VQ<4>::T, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  } else {
+    return __builtin_bit_cast(typename VQ<2>::T, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+  }
+}
+
+__device__ __forceinline__ int p4_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <int NQ>
+__device__ __forceinline__ void p4_store(typename VQ<NQ>::T v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (NQ == 4) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+  }
+}
+
+// Sum of half of row l31 of a wave's [32][36] LDS tile (lane (half, l31); the caller adds the two halves).
+template <typename ACC>
+__device__ __forceinline__ ACC p4_rowread(const float* Tw, int half, int l31) {
+  const f32x4* rowp = reinterpret_cast<const f32x4*>(Tw + l31 * 36 + half * 16);
+  ACC s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = rowp[q];
+    s += ((ACC)v.x + (ACC)v.y) + ((ACC)v.z + (ACC)v.w);
+  }
+  return s;
+}
+
+// MODE 0: B' = b1;  1: relu?(b1*s1+h1);  2: relu?(b1*s1+h1 + b2*s2+h2).   EPI 0: forward (bias, statistics);  1: data gradient.
+template <int MT, int NQ, int MODE, int PD, int EPI>
+__global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4))) void k_pw4(Pw4Args a) {
+  typedef typename VQ<NQ>::T vq;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  // XCD-aware decode: the cc workgroups that read the same position tiles (one per 32*MT output channels) take
+  // consecutive slots of one XCD (blockIdx % 8), so the re-reads are served by that XCD's L2
+  const int ngrp = (a.WT + 3) >> 2;
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int cz = slot % a.cc;
+  const int grp = (slot / a.cc) * 8 + xcd;
+  if (grp >= ngrp) return;
+  const int mBase = cz * 32 * MT;
+  const int K = a.K, M = a.M, L = a.L;
+  const int Kpad = a.Kpad, KP = Kpad + 1;
+  float* Ws = lds;                                                       // [32*MT][KP], zero beyond (M, K)
+  f32x4* Ps = reinterpret_cast<f32x4*>(lds + ((32 * MT * KP + 3) & ~3));  // [Kpad] (s1, h1, s2, h2)
+
+  const int wt = grp * 4 + wave;
+  const bool wlive = wt < a.WT;
+  const int n = wlive ? wt / a.ntl : 0;
+  const int tl = wlive ? wt - n * a.ntl : 0;
+  const int pos = tl * (32 * NQ) + l31 * NQ;
+  const bool pok = wlive && pos < L;
+  const int L4 = L * 4;
+  const int voff = pok ? (half * L + pos) * 4 : P4_OOB;
+  const __amdgpu_buffer_rsrc_t r1 = p4_rsrc(a.b1 + (size_t)n * K * L, wlive ? K * L4 : 0);
+  const __amdgpu_buffer_rsrc_t r2 = p4_rsrc((MODE == 2 ? a.b2 : a.b1) + (size_t)n * K * L, (wlive && MODE == 2) ? K * L4 : 0);
+
+  // ---- weights: global -> registers (all loads of a batch issued together), operand prefetch, then LDS ----
+  constexpr int WB = 16;
+  const bool mfast = a.w_ldm == 1;                 // A = W^T (data gradient): m is the contiguous index of w
+  // element e of this thread: k fast: (r, k) = ((tid>>4) + 16*(e % (2*MT)), (tid&15) + 16*(e / (2*MT)))
+  //                           m fast: (r, k) = ((tid&31) + 32*(e % MT),     (tid>>5) + 8*(e / MT))
+  const int nel = mfast ? (Kpad >> 3) * MT : (Kpad >> 4) * 2 * MT;
+  vq buf1[PD], buf2[MODE == 2 ? PD : 1];
+  for (int e0 = 0; e0 < nel; e0 += WB) {
+    float tmp[WB];
+#pragma unroll
+    for (int j = 0; j < WB; ++j) {
+      const int e = e0 + j;
+      int r, k;
+      if (mfast) { r = (tid & 31) + 32 * (e % MT); k = (tid >> 5) + 8 * (e / MT); }
+      else { r = (tid >> 4) + 16 * (e % (2 * MT)); k = (tid & 15) + 16 * (e / (2 * MT)); }
+      const int m = mBase + r;
+      tmp[j] = (e < nel && m < M && k < K) ? a.w[(size_t)m * a.w_ldm + (size_t)k * a.w_ldk] : 0.f;
+    }
+    if (e0 == 0) {
+#pragma unroll
+      for (int u = 0; u < PD; ++u) {
+        buf1[u] = p4_load<NQ>(r1, voff, 2 * u * L4);
+        if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, 2 * u * L4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WB; ++j) {
+      const int e = e0 + j;
+      int r, k;
+      if (mfast) { r = (tid & 31) + 32 * (e % MT); k = (tid >> 5) + 8 * (e / MT); }
+      else { r = (tid >> 4) + 16 * (e % (2 * MT)); k = (tid & 15) + 16 * (e / (2 * MT)); }
+      if (e < nel) Ws[r * KP + k] = tmp[j];
+    }
+  }
+  if (MODE != 0) {
+    for (int i = tid; i < Kpad; i += P4_NT) {
+      f32x4 p = {0.f, 0.f, 0.f, 0.f};
+      if (i < K) {
+        p.x = a.ps1 ? a.ps1[i] : 1.f;
+        p.y = a.ph1 ? a.ph1[i] : 0.f;
+        p.z = a.ps2 ? a.ps2[i] : 1.f;
+        p.w = a.ph2 ? a.ph2[i] : 0.f;
+      }
+      Ps[i] = p;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                    // raw barrier: the operand prefetch stays in flight
+
+  // accumulators start at the bias of their output row (forward), so the epilogue has no per-row loads
+  f32x16 acc[MT][NQ];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = mBase + 32 * m + p4_row32(i, half);
+      const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[m][q][i] = b0;
+    }
+
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  const int KS = Kpad >> 1;                        // k-steps (2 channels each), a multiple of PD
+  for (int base = 0; base < KS; base += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int ks = base + u;
+      const int kl = 2 * ks + half;
+      float av[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) av[m] = Ws[(32 * m + l31) * KP + kl];
+      vq b = buf1[u];
+      if (MODE != 0) {
+        const f32x4 p = Ps[kl];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          float v = fmaf(b[q], p.x, p.y);
+          if constexpr (MODE == 2) v += fmaf(buf2[u][q], p.z, p.w);
+          b[q] = fmaxf(v, lo);
+        }
+      }
+      buf1[u] = p4_load<NQ>(r1, voff, 2 * (ks + PD) * L4);             // past K: out of bounds -> 0, no traffic
+      if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, 2 * (ks + PD) * L4);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], b[q], acc[m][q], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                 // every wave is done with Ws / Ps: LDS is reused below
+
+  // Epilogue.  Stores go through a per-sample buffer resource (invalid rows / positions get an out-of-range offset
+  // and are dropped by the bounds check: no branches); per-channel sums through LDS transposes of the wave's tiles.
+  constexpr int NTL = EPI == 0 ? 2 : 3;            // transposed tiles per wave
+  float* Tw = lds + wave * (NTL * 32 * 36);
+  const __amdgpu_buffer_rsrc_t ro = p4_rsrc(a.out + (size_t)n * M * L, wlive ? M * L4 : 0);
+  const int ooff = pok ? pos * 4 : P4_OOB;
+  if (EPI == 0) {
+    double* Ss = reinterpret_cast<double*>(lds + 4 * NTL * 32 * 36);    // [4 waves][MT*32][2]
+    const bool stats = a.partial != nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = p4_row32(r, half);
+        const int co = mBase + 32 * m + row;
+        vq val;
+        float s = 0.f, qq = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          val[q] = acc[m][q][r];
+          s += val[q];
+          qq = fmaf(val[q], val[q], qq);
+        }
+        p4_store<NQ>(val, ro, co < M ? ooff : P4_OOB, co * L4);
+        if (stats) {
+          const bool ok = co < M && pok;
+          Tw[row * 36 + l31] = ok ? s : 0.f;
+          Tw[32 * 36 + row * 36 + l31] = ok ? qq : 0.f;
+        }
+      }
+      if (stats) {
+        wave_lds_sync();
+        double sd = p4_rowread<double>(Tw, half, l31);
+        double qd = p4_rowread<double>(Tw + 32 * 36, half, l31);
+        wave_lds_sync();
+        sd += __shfl_xor(sd, 32, 64);
+        qd += __shfl_xor(qd, 32, 64);
+        if (half == 0) {
+          Ss[((wave * MT + m) * 32 + l31) * 2 + 0] = sd;
+          Ss[((wave * MT + m) * 32 + l31) * 2 + 1] = qd;
+        }
+      }
+    }
+    if (stats) {
+      __syncthreads();
+      if (tid < 32 * MT) {
+        const int co = mBase + tid;
+        if (co < M) {
+          double s4 = 0.0, q4 = 0.0;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { s4 += Ss[((w * MT * 32) + tid) * 2]; q4 += Ss[((w * MT * 32) + tid) * 2 + 1]; }
+          a.partial[((size_t)grp * M + co) * 2 + 0] = (float)s4;
+          a.partial[((size_t)grp * M + co) * 2 + 1] = (float)q4;
+        }
+      }
+    }
+  } else {
+    float* Ss = lds + 4 * NTL * 32 * 36;                                 // [4 waves][MT*32][3]
+    f32x4* Es = reinterpret_cast<f32x4*>(Ss + 4 * MT * 32 * 3);          // [MT*32] (s1, h1, s2, h2) of the block's rows
+    const bool need_x = a.erelu || a.es1 != nullptr || a.ex2 != nullptr;
+    const bool has2 = a.ex2 != nullptr;
+    const bool sums = a.ipart != nullptr;
+    if (tid < 32 * MT) {
+      const int ci = mBase + tid;
+      f32x4 p = {1.f, 0.f, 1.f, 0.f};
+      if (ci < M) {
+        if (a.es1) { p.x = a.es1[ci]; p.y = a.eh1[ci]; }
+        if (a.es2) { p.z = a.es2[ci]; p.w = a.eh2[ci]; }
+      }
+      Es[tid] = p;
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rx1 = p4_rsrc(a.ex1 + (size_t)n * M * L, (wlive && need_x) ? M * L4 : 0);
+    const __amdgpu_buffer_rsrc_t rx2 = p4_rsrc((has2 ? a.ex2 : a.ex1) + (size_t)n * M * L, (wlive && has2) ? M * L4 : 0);
+    const __amdgpu_buffer_rsrc_t ro2 = p4_rsrc((a.out2 ? a.out2 : a.out) + (size_t)n * M * L, (wlive && a.out2) ? M * L4 : 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int rb = 0; rb < 16; rb += 4) {
+        vq xa[4], xb[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int ci = mBase + 32 * m + p4_row32(rb + rr, half);
+          xa[rr] = p4_load<NQ>(rx1, ci < M ? ooff : P4_OOB, ci * L4);      // zeros when the input is not needed
+          xb[rr] = p4_load<NQ>(rx2, ci < M ? ooff : P4_OOB, ci * L4);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = rb + rr;
+          const int row = p4_row32(r, half);
+          const int ci = mBase + 32 * m + row;
+          const f32x4 e = Es[32 * m + row];
+          float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+          vq d1, d2;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            float pre = fmaf(xa[rr][q], e.x, e.y);
+            if (has2) pre += fmaf(xb[rr][q], e.z, e.w);
+            const float dv = (!a.erelu || pre > 0.f) ? acc[m][q][r] : 0.f;
+            d1[q] = dv * e.x;
+            d2[q] = dv * e.z;
+            u0 = fmaf(dv, xa[rr][q], u0);
+            u1 += dv;
+            u2 = fmaf(dv, xb[rr][q], u2);
+          }
+          p4_store<NQ>(d1, ro, ci < M ? ooff : P4_OOB, ci * L4);
+          p4_store<NQ>(d2, ro2, ci < M ? ooff : P4_OOB, ci * L4);           // zero-sized resource when there is no dx2
+          if (sums) {
+            const bool ok = ci < M && pok;
+            Tw[row * 36 + l31] = ok ? u0 : 0.f;
+            Tw[32 * 36 + row * 36 + l31] = ok ? u1 : 0.f;
+            Tw[2 * 32 * 36 + row * 36 + l31] = ok ? u2 : 0.f;
+          }
+        }
+      }
+      if (sums) {
+        wave_lds_sync();
+        float s0 = p4_rowread<float>(Tw, half, l31);
+        float s1 = p4_rowread<float>(Tw + 32 * 36, half, l31);
+        float s2 = p4_rowread<float>(Tw + 2 * 32 * 36, half, l31);
+        wave_lds_sync();
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (half == 0) {
+          float* q = Ss + ((wave * MT + m) * 32 + l31) * 3;
+          q[0] = s0; q[1] = s1; q[2] = s2;
+        }
+      }
+    }
+    if (sums) {
+      __syncthreads();
+      if (tid < 32 * MT) {
+        const int ci = mBase + tid;
+        if (ci < M) {
+          float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const float* q = Ss + ((w * MT * 32) + tid) * 3;
+            v0 += q[0]; v1 += q[1]; v2 += q[2];
+          }
+          float* o = a.ipart + ((size_t)grp * M + ci) * 3;
+          o[0] = v0; o[1] = v1; o[2] = v2;
+        }
+      }
+    }
+  }
+}
+
+int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0;
+
+struct P4Plan { int MT, NQ, PD, cc, ntl, WT, ngrp, Kpad; size_t lds; unsigned grid; };
+
+bool p4_plan(int n, int K, int M, int L, P4Plan* p) {
+  if (L % 2) return false;
+  int NQ = (L % 4 == 0) ? 4 : 2;
+  const int mtiles = (M + 31) / 32;
+  int MT = mtiles >= 2 ? 2 : 1;
+  if (mtiles == 3) { MT = 3; NQ = 2; }
+  if (g_p4_nq == 2 || (g_p4_nq == 4 && L % 4 == 0)) NQ = g_p4_nq;
+  if (g_p4_mt) MT = g_p4_mt < mtiles ? g_p4_mt : mtiles;
+  if (MT * NQ > 8) NQ = 2;
+  if (MT * NQ > 8) MT = 4;
+  int PD = NQ == 4 ? 8 : 16;
+  if (g_p4_pd == 8 || g_p4_pd == 16) PD = g_p4_pd;
+  if ((long)K * L * 4 >= (1L << 31) - 64 || (long)M * L * 4 >= (1L << 31) - 64) return false;
+  p->MT = MT; p->NQ = NQ; p->PD = PD;
+  p->cc = (mtiles + MT - 1) / MT;
+  p->ntl = (L + 32 * NQ - 1) / (32 * NQ);
+  p->WT = n * p->ntl;
+  p->ngrp = (p->WT + 3) / 4;
+  p->Kpad = (K + 2 * PD - 1) / (2 * PD) * (2 * PD);
+  size_t f = (size_t)((32 * MT * (p->Kpad + 1) + 3) & ~3) + (size_t)4 * p->Kpad;
+  const size_t fe = (size_t)4 * 3 * 32 * 36 + (size_t)4 * MT * 32 * 4 + (size_t)MT * 32 * 4;    // epilogue image
+  if (f < fe) f = fe;
+  p->lds = f * sizeof(float);
+  if (p->lds > 160 * 1024) return false;
+  p->grid = (unsigned)((p->ngrp + 7) / 8 * 8 * p->cc);
+  return true;
+}
+
+template <int MT, int NQ, int PD>
+void p4_launch_cfg(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStream_t st) {
+  const dim3 grid(p.grid), blk(P4_NT);
+  if (epi == 0) {
+    if (mode == 0) hipLaunchKernelGGL((k_pw4<MT, NQ, 0, PD, 0>), grid, blk, p.lds, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_pw4<MT, NQ, 1, PD, 0>), grid, blk, p.lds, st, a);
+    else hipLaunchKernelGGL((k_pw4<MT, NQ, 2, PD, 0>), grid, blk, p.lds, st, a);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((k_pw4<MT, NQ, 0, PD, 1>), grid, blk, p.lds, st, a);
+    else hipLaunchKernelGGL((k_pw4<MT, NQ, 2, PD, 1>), grid, blk, p.lds, st, a);
+  }
+}
+
+template <int PD>
+bool p4_launch_pd(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStream_t st) {
+  const int key = p.MT * 10 + p.NQ;
+  switch (key) {
+    case 14: p4_launch_cfg<1, 4, PD>(a, mode, epi, p, st); return true;
+    case 24: p4_launch_cfg<2, 4, PD>(a, mode, epi, p, st); return true;
+    case 12: p4_launch_cfg<1, 2, PD>(a, mode, epi, p, st); return true;
+    case 22: p4_launch_cfg<2, 2, PD>(a, mode, epi, p, st); return true;
+    case 32: p4_launch_cfg<3, 2, PD>(a, mode, epi, p, st); return true;
+    case 42: p4_launch_cfg<4, 2, PD>(a, mode, epi, p, st); return true;
+  }
+  return false;
+}
+
+}  // namespace
+
+// Internal (not part of the C ABI): called by dsgcn_pwconv_fwd / dsgcn_pwconv_dgrad when the shape qualifies
+// (stride 1, even plane size).  Return 1 = launched, 0 = not eligible, <0 / >0 = error codes as everywhere.
+__attribute__((visibility("hidden"))) int dsgcn_p4_tuning(int key, int value) {
+  if (key == 0) g_p4_nq = value;
+  else if (key == 1) g_p4_mt = value;
+  else if (key == 2) g_p4_pd = value;
+  else return DSGCN_EINVAL;
+  return 0;
+}
+
+__attribute__((visibility("hidden"))) int dsgcn_p4_groups(int n, int K, int M, int L) {
+  P4Plan p;
+  return p4_plan(n, K, M, L, &p) ? p.ngrp : 0;
+}
+
+__attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const float* s1, const float* h1,
+                                                        const float* x2, const float* s2, const float* h2, int relu,
+                                                        const float* w, const float* bias, float* z, float* partial,
+                                                        int n, int Ci, int Co, int L, hipStream_t st) {
+  P4Plan p;
+  if (!p4_plan(n, Ci, Co, L, &p)) return 0;
+  Pw4Args a = {};
+  a.b1 = x1; a.b2 = x2; a.ps1 = s1; a.ph1 = h1; a.ps2 = s2; a.ph2 = h2; a.relu = relu;
+  a.w = w; a.w_ldm = Ci; a.w_ldk = 1; a.bias = bias; a.out = z; a.partial = partial;
+  a.n = n; a.K = Ci; a.M = Co; a.L = L; a.ntl = p.ntl; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad;
+  const int mode = x2 ? 2 : ((s1 || relu) ? 1 : 0);
+  const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 0, p, st) : p4_launch_pd<16>(a, mode, 0, p, st);
+  if (!ok) return 0;
+  DSGCN_LAUNCH_CHECK();
+  return 1;
+}
+
+// dz_eff = gz + A0 + B0*z (either part may be absent);  x1/x2/s*/h*/relu describe the forward's virtual input.
+__attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const float* s1, const float* h1,
+                                                          const float* x2, const float* s2, const float* h2, int relu,
+                                                          const float* w, const float* z, const float* gz,
+                                                          const float* A0, const float* B0, float* dx1, float* dx2,
+                                                          float* ipart, int n, int Ci, int Co, int L, hipStream_t st) {
+  P4Plan p;
+  if (!gz) return 0;                               // (a conv whose output has no direct gradient: not on the fast path)
+  if (!p4_plan(n, Co, Ci, L, &p)) return 0;
+  Pw4Args a = {};
+  a.b1 = gz; a.b2 = A0 ? z : nullptr;
+  a.ps1 = nullptr; a.ph1 = A0; a.ps2 = B0; a.ph2 = nullptr; a.relu = 0;
+  a.w = w; a.w_ldm = 1; a.w_ldk = Ci; a.bias = nullptr; a.out = dx1; a.partial = nullptr;
+  a.ex1 = x1; a.ex2 = x2; a.es1 = s1; a.eh1 = h1; a.es2 = s2; a.eh2 = h2; a.erelu = relu;
+  a.out2 = dx2; a.ipart = ipart;
+  a.n = n; a.K = Co; a.M = Ci; a.L = L; a.ntl = p.ntl; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad;
+  const int mode = A0 ? 2 : 0;
+  const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 1, p, st) : p4_launch_pd<16>(a, mode, 1, p, st);
+  if (!ok) return 0;
+  DSGCN_LAUNCH_CHECK();
+  return 1;
+}

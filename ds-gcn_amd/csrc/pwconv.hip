@@ -1049,6 +1049,31 @@ __global__ __launch_bounds__(64) void k_bn_bwd_coef(const float* __restrict__ g_
 
 int g_pw_ablate = 0;
 int g_pw_maxmt = 2;      // measured (tools/pw_ablate.py): small per-wave tiles + more resident waves win
+int g_pw4 = 3;           // bit 0: wide-load forward (pw4.hip), bit 1: wide-load data gradient
+
+// pw4.hip (internal linkage across the library's objects, not exported)
+__attribute__((visibility("hidden"))) int dsgcn_p4_tuning(int key, int value);
+__attribute__((visibility("hidden"))) int dsgcn_p4_groups(int n, int K, int M, int L);
+__attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const float* s1, const float* h1,
+                                                        const float* x2, const float* s2, const float* h2, int relu,
+                                                        const float* w, const float* bias, float* z, float* partial,
+                                                        int n, int Ci, int Co, int L, hipStream_t st);
+__attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const float* s1, const float* h1,
+                                                          const float* x2, const float* s2, const float* h2, int relu,
+                                                          const float* w, const float* z, const float* gz,
+                                                          const float* A0, const float* B0, float* dx1, float* dx2,
+                                                          float* ipart, int n, int Ci, int Co, int L, hipStream_t st);
+
+// workgroup rows of the statistics / input-affine partial buffers for a (K -> M) mix over n planes of L positions
+static int pw_conv_rows(int n, int K, int M, int T, int V, int stride, int which) {
+  const int Tout = (T + stride - 1) / stride;
+  const int L = Tout * V;
+  if (stride == 1 && (g_pw4 & which)) {
+    const int g = dsgcn_p4_groups(n, K, M, L);
+    if (g > 0) return g;
+  }
+  return n * ((L + 4 * 32 - 1) / (4 * 32));
+}
 
 extern "C" {
 
@@ -1056,6 +1081,8 @@ int dsgcn_pwconv_tuning(int key, int value) {
   if (key == 0) { g_pw_ablate = value; return 0; }
   if (key == 1) { g_pw_maxmt = value; return 0; }
   if (key == 2) { g_pw_roll = value; return 0; }
+  if (key == 3) { g_pw4 = value; return 0; }
+  if (key >= 4 && key <= 6) return dsgcn_p4_tuning(key - 4, value);
   return DSGCN_EINVAL;
 }
 
@@ -1073,14 +1100,8 @@ int dsgcn_pwconv_plan(int Tout, int V, int aug, int* TR, int* NPpad, int* nblk_p
 
 // Forward.  x2/s1/h1/s2/h2/bias/zaug/partial may be NULL as allowed by the flags.  partial: (n*nblk_per_sample, Co, 2).
 // Rows of the `partial` buffer the forward writes for a given shape (conv blocks [+ global-joint rows when aug]).
-int dsgcn_pwconv_partial_rows(int n, int Co, int T, int V, int stride, int aug) {
-  const int Tout = (T + stride - 1) / stride;
-  const int L = Tout * V;
-  const int mtiles = (Co + 31) / 32;
-  const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
-  const int NW = 1;
-  const int nbx = (L + 4 * NW * 32 - 1) / (4 * NW * 32);
-  int rows = n * nbx;
+int dsgcn_pwconv_partial_rows(int n, int Ci, int Co, int T, int V, int stride, int aug) {
+  int rows = pw_conv_rows(n, Ci, Co, T, V, stride, 1);
   if (aug) rows += n;
   return rows;
 }
@@ -1102,6 +1123,13 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
   a.roll = ((g_pw_roll & 1) && Ci % KW == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int L = Tout * V;
+  const int conv_rows = pw_conv_rows(n, Ci, Co, T, V, stride, 1);
+  int fast = 0;
+  if (stride == 1 && (g_pw4 & 1)) {
+    fast = dsgcn_p4_fwd(x1, s1, h1, x2, s2, h2, relu, w, bias, z, stats ? partial : nullptr, n, Ci, Co, L, st);
+    if (fast != 0 && fast != 1) return fast;
+  }
+  if (!fast) {
   const int mtiles = (Co + 31) / 32;
   const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
   const int NW = 1;
@@ -1123,11 +1151,12 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
   }
 #undef PW_FWD2
   DSGCN_LAUNCH_CHECK();
+  }
   if (aug) {
     const size_t l2 = (size_t)Tout * V * sizeof(float);
     if (l2 > 64 * 1024) return DSGCN_EUNSUPPORTED;
     hipLaunchKernelGGL(k_rowmean_stats, dim3((unsigned)((long)n * Co)), dim3(64), l2, st, z, zaug,
-                       stats ? partial + (size_t)n * nbx * Co * 2 : (float*)nullptr, Co, Tout, V);
+                       stats ? partial + (size_t)conv_rows * Co * 2 : (float*)nullptr, Co, Tout, V);
     DSGCN_LAUNCH_CHECK();
   }
   return 0;
@@ -1175,13 +1204,8 @@ int dsgcn_colsum2(const float* src_a, int Ra, int Ca, int inner_a, float* out_a,
 
 // Backward, data path.  gz/gzaug/A0/B0/x2/s*/h*/dx2/ipart may be NULL as in the forward.  dx1 (and dx2) are fully
 // written (zero rows where stride skips frames).  ipart: (n*nblk_per_sample, Ci, 3) = [sum dv*x1, sum dv, sum dv*x2].
-int dsgcn_pwconv_ipart_rows(int n, int Ci, int T, int V, int stride) {
-  const int Tout = (T + stride - 1) / stride;
-  const int L = Tout * V;
-  const int mtiles = (Ci + 31) / 32;
-  const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
-  const int NW = 1;
-  return n * ((L + 4 * NW * 32 - 1) / (4 * NW * 32));
+int dsgcn_pwconv_ipart_rows(int n, int Ci, int Co, int T, int V, int stride) {
+  return pw_conv_rows(n, Co, Ci, T, V, stride, 2);
 }
 
 int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
@@ -1207,6 +1231,11 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
   a.n = n; a.Ci = Ci; a.Co = Co; a.T = T; a.V = V; a.Tout = Tout; a.stride = stride; a.aug = aug;
   a.roll = ((g_pw_roll & 2) && Co % KW == 0 && (Ci & 3) == 0) ? 1 : 0;
   const int L = Tout * V;
+  if (stride == 1 && !aug && (g_pw4 & 2)) {
+    const int fast = dsgcn_p4_dgrad(x1, s1, h1, x2, s2, h2, relu, w, z, gz, A0, B0, dx1, dx2, ipart, n, Ci, Co, L, st);
+    if (fast == 1) return 0;
+    if (fast != 0) return fast;
+  }
   const int mtiles = (Ci + 31) / 32;
   const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
   const int NW = 1;

@@ -316,7 +316,7 @@ class _PwConv(torch.autograd.Function):
         lib = native.lib()
         partial = None
         if want_bn:
-            rows = lib.dsgcn_pwconv_partial_rows(n, Co, T, V, stride, int(aug))
+            rows = lib.dsgcn_pwconv_partial_rows(n, Ci, Co, T, V, stride, int(aug))
             partial = torch.empty((rows, Co, 2), device=dev, dtype=torch.float32)
         rc = lib.dsgcn_pwconv_fwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu), _ptr(w2),
                                   _ptr(bias), _ptr(z), _ptr(zaug), _ptr(partial), n, Ci, Co, T, V, stride, int(aug),
@@ -366,7 +366,7 @@ class _PwConv(torch.autograd.Function):
         dx2 = torch.empty_like(x2) if x2 is not None else None
         ipart = None
         if s1 is not None or s2 is not None:
-            rows = lib.dsgcn_pwconv_ipart_rows(n, Ci, T, V, stride)
+            rows = lib.dsgcn_pwconv_ipart_rows(n, Ci, Co, T, V, stride)
             ipart = torch.empty((rows, Ci, 3), device=dev, dtype=torch.float32)     # every row is written by dgrad
         rc = lib.dsgcn_pwconv_dgrad(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(w2),
                                     _ptr(z), _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), _ptr(dx1),

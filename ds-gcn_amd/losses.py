@@ -1,62 +1,30 @@
-"""Losses (reference: pyskl/models/losses/base.py:7-45, cross_entropy_loss.py:11-84).
-Host-side PyTorch: one (N, classes) tensor per step, not on the HBM-bound path."""
-from abc import ABCMeta, abstractmethod
+"""The one loss the DS-GCN configs use: hard-label cross entropy, mean over the batch, times ``loss_weight``
+(behaviour of the reference's ``CrossEntropyLoss`` on ``(N, classes)`` scores and ``(N,)`` int64 labels:
+pyskl/models/losses/cross_entropy_loss.py:75-82 scaled by base.py:38-44).
 
-import torch
+Registered under the reference's name with the reference's constructor signature so that config dicts
+(``loss_cls=dict(type='CrossEntropyLoss')``) build unchanged.  Soft labels, per-class weights and extra
+``F.cross_entropy`` kwargs are not reached by any skeleton config and are rejected instead of carried along.
+Host-side PyTorch: one (N, classes) tensor per step, not on the HBM-bound path."""
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .builder import LOSSES
 
 
-class BaseWeightedLoss(nn.Module, metaclass=ABCMeta):
-
-    def __init__(self, loss_weight=1.0):
-        super().__init__()
-        self.loss_weight = loss_weight
-
-    @abstractmethod
-    def _forward(self, *args, **kwargs):
-        pass
-
-    def forward(self, *args, **kwargs):
-        ret = self._forward(*args, **kwargs)
-        if isinstance(ret, dict):
-            for k in ret:
-                if 'loss' in k:
-                    ret[k] *= self.loss_weight
-        else:
-            ret *= self.loss_weight
-        return ret
-
-
 @LOSSES.register_module()
-class CrossEntropyLoss(BaseWeightedLoss):
-    """Hard labels (shape = scores minus the class dim) -> F.cross_entropy (mean);
-    soft labels (same shape as scores) -> -(label * log_softmax).sum(1), (weighted) mean."""
+class CrossEntropyLoss(nn.Module):
 
     def __init__(self, loss_weight=1.0, class_weight=None):
-        super().__init__(loss_weight=loss_weight)
-        self.class_weight = None
+        super().__init__()
         if class_weight is not None:
-            self.class_weight = torch.Tensor(class_weight)
+            raise NotImplementedError('CrossEntropyLoss: class_weight is not used by any skeleton config')
+        self.loss_weight = float(loss_weight)
 
-    def _forward(self, cls_score, label, **kwargs):
-        if cls_score.size() == label.size():
-            assert cls_score.dim() == 2, 'Only support 2-dim soft label'
-            assert len(kwargs) == 0, f'For now, no extra args are supported for soft label, but get {kwargs}'
-            lsm = F.log_softmax(cls_score, 1)
-            if self.class_weight is not None:
-                self.class_weight = self.class_weight.to(cls_score.device)
-                lsm = lsm * self.class_weight.unsqueeze(0)
-            loss_cls = -(label * lsm).sum(1)
-            if self.class_weight is not None:
-                loss_cls = loss_cls.sum() / torch.sum(self.class_weight.unsqueeze(0) * label)
-            else:
-                loss_cls = loss_cls.mean()
-        else:
-            if self.class_weight is not None:
-                assert 'weight' not in kwargs, "The key 'weight' already exists."
-                kwargs['weight'] = self.class_weight.to(cls_score.device)
-            loss_cls = F.cross_entropy(cls_score, label, **kwargs)
-        return loss_cls
+    def forward(self, cls_score, label):
+        if cls_score.dim() != 2 or label.shape != cls_score.shape[:1] or label.is_floating_point():
+            raise NotImplementedError(
+                f'CrossEntropyLoss: expects (N, classes) scores with (N,) integer labels, got '
+                f'{tuple(cls_score.shape)} / {tuple(label.shape)} {label.dtype} (soft labels are outside this path)')
+        loss = F.cross_entropy(cls_score, label)
+        return loss if self.loss_weight == 1.0 else loss * self.loss_weight

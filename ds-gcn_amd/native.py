@@ -36,8 +36,8 @@ SIGNATURES = {
     'dsgcn_pwconv_fwd': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 8 + [c_st],
     'dsgcn_bn_finalize': [c_f, c_int, c_int, ctypes.c_double, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f, c_int,
                           c_st],
-    'dsgcn_pwconv_partial_rows': [c_int] * 6,
-    'dsgcn_pwconv_ipart_rows': [c_int] * 5,
+    'dsgcn_pwconv_partial_rows': [c_int] * 7,
+    'dsgcn_pwconv_ipart_rows': [c_int] * 6,
     'dsgcn_pwconv_tuning': [c_int, c_int],
     'dsgcn_diag_mfma_probe': [c_f, c_int, c_int, c_int, c_st],
     'dsgcn_dz_eff_aug': [c_f] * 7 + [c_int] * 4 + [c_st],
@@ -88,9 +88,22 @@ def _source_hash():
     return h.hexdigest()
 
 
+def _file_hash(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for path in paths:
+        with open(path, 'rb') as f:
+            h.update(os.path.basename(path).encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into one shared library (cross-compiles without a GPU).
-    Up-to-date check = content hash of the sources (file times do not survive the copy to a GPU box)."""
+    Up-to-date check = content hash of the sources (file times do not survive the copy to a GPU box).  Each source is
+    compiled to its own object (cached under lib/obj by content hash of the source + headers, compiled in parallel),
+    then linked."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = sources()
     stamp = LIB_PATH + '.srchash'
     digest = _source_hash()
@@ -98,13 +111,29 @@ def build(force=False, verbose=False):
         with open(stamp) as f:
             if f.read().strip() == digest:
                 return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
+    obj_dir = os.path.join(LIB_DIR, 'obj')
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I', INCLUDE, '-I', CSRC,
-           '-o', LIB_PATH] + srcs
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.run(cmd, check=True)
+    headers = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + sorted(glob.glob(os.path.join(INCLUDE, '*.h')))
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC]
+    jobs, objs = [], []
+    for src in srcs:
+        base = os.path.splitext(os.path.basename(src))[0]
+        obj = os.path.join(obj_dir, f'{base}.{_file_hash([src] + headers)[:16]}.o')
+        objs.append(obj)
+        if force or not os.path.exists(obj):
+            for old in glob.glob(os.path.join(obj_dir, base + '.*.o')):
+                os.remove(old)
+            jobs.append([hipcc] + flags + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        list(pool.map(run, jobs))
+    run([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB_PATH] + objs)
     with open(stamp, 'w') as f:
         f.write(digest)
     return LIB_PATH

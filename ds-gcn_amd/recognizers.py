@@ -1,16 +1,24 @@
-"""Recognizer API (reference: pyskl/models/recognizers/base.py:21-205, recognizergcn.py:16-148).
+"""``RecognizerGCN`` behind the reference's registry name, constructor and call conventions
+(pyskl/models/recognizers/recognizergcn.py:16-148 over recognizers/base.py:21-205):
 
-Same entry points and return conventions — ``forward(keypoint, label, return_loss)``,
-``forward_train`` -> dict(top1_acc, top5_acc, loss_cls), ``forward_test`` -> numpy class
-probabilities averaged over clips, ``train_step`` -> dict(loss, losses, log_vars, num_samples) —
-with one deliberate difference: ``_parse_losses`` reduces all log scalars in ONE all-reduce and
-ONE device->host read instead of one collective + ``.item()`` per scalar (base.py:150-156: four
-syncs per iteration), because at MI355X step times those syncs bound weak scaling.
-"""
-from abc import ABCMeta, abstractmethod
+* ``model(keypoint=(N,1,M,T,V,C), label=(N,1), return_loss=True)`` -> ``dict(top1_acc, top5_acc, loss_cls)``;
+* ``model(keypoint=(N,clips,M,T,V,C), return_loss=False)`` -> ``np.ndarray (N, classes)``: clip scores averaged as
+  probabilities (``test_cfg['average_clips']`` = 'prob' default, 'score', or None for per-clip scores);
+* ``model.train_step(data_batch, optimizer)`` -> ``dict(loss, losses, log_vars, num_samples)`` (what mmcv's runner
+  calls, core/local_runner/epoch_based_sparse_runner.py:33-34).
+
+Host-side differences that matter at MI355X step times (a step is ~15 ms; the reference spends four collectives and
+four ``.item()`` syncs per step on its log scalars, base.py:150-156):
+
+* ``train_step(..., sync_log_vars=True)`` (default, reference semantics): ONE packed all-reduce of all log scalars and
+  ONE device->host read;
+* ``train_step(..., sync_log_vars=False)``: no collective and no host read at all — ``log_vars`` are rank-local device
+  tensors, safe inside a hipGraph capture; ``reduce_log_vars`` averages them over ranks whenever the caller logs.
+
+Necks, feature/score extraction and multi-view test batching are not reached by the skeleton configs and raise."""
 from collections import OrderedDict
+from itertools import zip_longest
 
-import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -20,137 +28,108 @@ from . import builder
 from .builder import RECOGNIZERS
 
 
-class BaseRecognizer(nn.Module, metaclass=ABCMeta):
+def _dist_world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
-    def __init__(self, backbone, neck=None, cls_head=None, train_cfg=dict(), test_cfg=dict()):
-        super().__init__()
-        self.backbone = builder.build_backbone(backbone)
-        if neck:
-            raise NotImplementedError('necks are outside the DS-GCN hot path (no BASELINE config uses one)')
-        self.neck = None
-        self.cls_head = builder.build_head(cls_head) if cls_head else None
-        train_cfg = dict() if train_cfg is None else train_cfg
-        test_cfg = dict() if test_cfg is None else test_cfg
-        assert isinstance(train_cfg, dict)
-        assert isinstance(test_cfg, dict)
-        self.train_cfg = train_cfg
-        self.test_cfg = test_cfg
-        self.max_testing_views = test_cfg.get('max_testing_views', None)
-        self.init_weights()
 
-    @property
-    def with_cls_head(self):
-        return getattr(self, 'cls_head', None) is not None
-
-    @property
-    def with_neck(self):
-        return getattr(self, 'neck', None) is not None
-
-    def init_weights(self):
-        self.backbone.init_weights()
-        if self.with_cls_head:
-            self.cls_head.init_weights()
-
-    def extract_feat(self, imgs):
-        return self.backbone(imgs)
-
-    def average_clip(self, cls_score):
-        assert len(cls_score.shape) == 3  # (batch, clips, classes)
-        average_clips = self.test_cfg.get('average_clips', 'prob')
-        if average_clips not in ['score', 'prob', None]:
-            raise ValueError(f'{average_clips} is not supported. Supported: ["score", "prob", None]')
-        if average_clips is None:
-            return cls_score
-        if average_clips == 'prob':
-            return F.softmax(cls_score, dim=2).mean(dim=1)
-        return cls_score.mean(dim=1)
-
-    @abstractmethod
-    def forward_train(self, imgs, label, **kwargs):
-        pass
-
-    @abstractmethod
-    def forward_test(self, imgs, **kwargs):
-        pass
-
-    def _parse_losses(self, losses, sync=True):
-        """(loss, log_vars, losses).  ``sync=False`` keeps log_vars as device tensors (no host read)."""
-        log_vars = OrderedDict()
-        for name, value in losses.items():
-            if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
-            elif isinstance(value, list):
-                log_vars[name] = sum(v.mean() for v in value)
-            else:
-                raise TypeError(f'{name} is not a tensor or list of tensors')
-        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
-        log_vars['loss'] = loss
-        names = list(log_vars)
-        packed = torch.stack([log_vars[k].detach().double() for k in names])
-        if dist.is_available() and dist.is_initialized():
-            packed = packed / dist.get_world_size()
-            dist.all_reduce(packed)
-        if sync:
-            vals = packed.tolist()
-            log_vars = OrderedDict((k, v) for k, v in zip(names, vals))
-        else:
-            log_vars = OrderedDict((k, packed[i]) for i, k in enumerate(names))
-        return loss, log_vars, losses
-
-    def forward(self, imgs, label=None, return_loss=True, **kwargs):
-        if return_loss:
-            if label is None:
-                raise ValueError('Label should not be None.')
-            return self.forward_train(imgs, label, **kwargs)
-        return self.forward_test(imgs, **kwargs)
-
-    def train_step(self, data_batch, optimizer=None, **kwargs):
-        sync = kwargs.pop('sync_log_vars', True)
-        kwargs.pop('current_epoch', None)
-        kwargs.pop('total_epoch', None)
-        losses = self(**data_batch, return_loss=True, **kwargs)
-        loss, log_vars, losses = self._parse_losses(losses, sync=sync)
-        return dict(loss=loss, losses=losses, log_vars=log_vars,
-                    num_samples=len(next(iter(data_batch.values()))))
-
-    def val_step(self, data_batch, optimizer=None, **kwargs):
-        return self.train_step(data_batch, optimizer, **kwargs)
+def reduce_log_vars(log_vars, sync=True):
+    """Average a dict of scalar device tensors over the ranks with one collective.  ``sync=True`` also reads them back
+    (one device->host copy) and returns floats."""
+    names = list(log_vars)
+    packed = torch.stack([torch.as_tensor(log_vars[k]).detach().double() for k in names])
+    world = _dist_world()
+    if world > 1:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('reduce_log_vars issues a collective: call it outside hipGraph capture '
+                               '(use train_step(..., sync_log_vars=False) inside the captured step)')
+        packed = packed / world
+        dist.all_reduce(packed)
+    vals = packed.tolist() if sync else list(packed.unbind(0))
+    return OrderedDict(zip(names, vals))
 
 
 @RECOGNIZERS.register_module()
-class RecognizerGCN(BaseRecognizer):
+class RecognizerGCN(nn.Module):
 
-    def forward_train(self, keypoint, label, **kwargs):
-        assert self.with_cls_head
-        assert keypoint.shape[1] == 1
-        if keypoint.dtype != torch.float:
-            keypoint = keypoint.float()
-        x = self.extract_feat(keypoint[:, 0])
-        cls_score = self.cls_head(x)
-        gt_label = label.squeeze(-1)
-        losses = dict()
-        losses.update(self.cls_head.loss(cls_score, gt_label))
-        return losses
+    def __init__(self, backbone, neck=None, cls_head=None, train_cfg=dict(), test_cfg=dict()):
+        super().__init__()
+        if neck:
+            raise NotImplementedError('necks are outside the DS-GCN hot path (no skeleton config uses one)')
+        self.backbone = builder.build_backbone(backbone)
+        self.cls_head = builder.build_head(cls_head) if cls_head else None
+        self.train_cfg = dict(train_cfg or {})
+        self.test_cfg = dict(test_cfg or {})
+        for key in ('feat_ext', 'score_ext', 'max_testing_views'):
+            if self.test_cfg.get(key):
+                raise NotImplementedError(f'test_cfg[{key!r}] is outside the hot path')
+        mode = self.test_cfg.setdefault('average_clips', 'prob')
+        if mode not in ('score', 'prob', None):
+            raise ValueError(f'{mode} is not supported. Supported: ["score", "prob", None]')
+        self.init_weights()
 
-    def forward_test(self, keypoint, **kwargs):
-        assert self.with_cls_head
-        if keypoint.dtype != torch.float:
-            keypoint = keypoint.float()
-        bs, nc = keypoint.shape[:2]
-        keypoint = keypoint.reshape((bs * nc, ) + keypoint.shape[2:])
-        x = self.extract_feat(keypoint)
-        if self.test_cfg.get('feat_ext', False) or self.test_cfg.get('score_ext', False):
-            raise NotImplementedError('feature/score extraction modes are outside the hot path')
-        cls_score = self.cls_head(x)
-        cls_score = cls_score.reshape(bs, nc, cls_score.shape[-1])
-        if 'average_clips' not in self.test_cfg:
-            self.test_cfg['average_clips'] = 'prob'
-        cls_score = self.average_clip(cls_score)
-        return cls_score.data.cpu().numpy()
+    with_cls_head = property(lambda self: self.cls_head is not None)
 
-    def forward(self, keypoint, label=None, return_loss=True, **kwargs):
-        if return_loss:
-            if label is None:
-                raise ValueError('Label should not be None.')
-            return self.forward_train(keypoint, label, **kwargs)
-        return self.forward_test(keypoint, **kwargs)
+    def init_weights(self):
+        self.backbone.init_weights()
+        if self.cls_head is not None:
+            self.cls_head.init_weights()
+
+    def extract_feat(self, keypoint):
+        return self.backbone(keypoint)
+
+    # ---- training ------------------------------------------------------------------------------------------
+    def forward_train(self, keypoint, label):
+        assert self.cls_head is not None
+        assert keypoint.shape[1] == 1, 'training batches carry one clip per sample'
+        scores = self.cls_head(self.extract_feat(keypoint[:, 0].float()))
+        return self.cls_head.loss(scores, label.squeeze(-1))
+
+    def train_step(self, data_batch, optimizer=None, sync_log_vars=True, **_runner_kwargs):
+        losses = self(**data_batch, return_loss=True)
+        log_vars = OrderedDict((k, v.mean()) for k, v in losses.items())
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        if sync_log_vars:
+            log_vars = reduce_log_vars(log_vars)
+        else:
+            log_vars = OrderedDict((k, v.detach()) for k, v in log_vars.items())
+        return dict(loss=loss, losses=losses, log_vars=log_vars, num_samples=len(next(iter(data_batch.values()))))
+
+    val_step = train_step
+
+    # ---- inference -----------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_test(self, keypoint):
+        assert self.cls_head is not None
+        N, clips = keypoint.shape[:2]
+        feats = self.extract_feat(keypoint.float().flatten(0, 1))
+        scores = self.cls_head(feats).view(N, clips, -1)
+        mode = self.test_cfg['average_clips']
+        if mode == 'prob':
+            scores = F.softmax(scores, dim=2).mean(1)
+        elif mode == 'score':
+            scores = scores.mean(1)
+        return scores.cpu().numpy()
+
+    def forward(self, keypoint, label=None, return_loss=True):
+        if not return_loss:
+            return self.forward_test(keypoint)
+        if label is None:
+            raise ValueError('Label should not be None.')
+        return self.forward_train(keypoint, label)
+
+
+def gather_results(part, size):
+    """Inference results of all ranks in dataset order (what mmcv's ``multi_gpu_test`` hands tools/test.py:107):
+    rank r holds samples r, r+world, ... (``DistributedSampler``, padded), so the parts are interleaved and cut to
+    ``size``.  Every rank gets the full list."""
+    world = _dist_world()
+    if world == 1:
+        return list(part)[:size]
+    parts = [None] * world
+    dist.all_gather_object(parts, list(part))
+    hole = object()
+    out = []
+    for group in zip_longest(*parts, fillvalue=hole):
+        out.extend(r for r in group if r is not hole)
+    return out[:size]

@@ -111,7 +111,7 @@ int dsgcn_tms_combine_fwd(const float* o, const float* coeff, float* f, float* p
                           void* stream);
 int dsgcn_tms_combine_bwd(const float* o, const float* coeff, const float* gf, const float* A0, const float* B0,
                           float* dout, float* pcoef, int n, int C, int T, int V, void* stream);
-int dsgcn_pwconv_ipart_rows(int n, int Ci, int T, int V, int stride);
+int dsgcn_pwconv_ipart_rows(int n, int Ci, int Co, int T, int V, int stride);
 int dsgcn_diag_mfma_probe(float* out, int blocks, int iters, int nacc, void* stream);
 
 /* ---- K-C: 1x1 channel mix with fused train-mode BatchNorm / ReLU / residual --------------------------------
@@ -122,7 +122,7 @@ int dsgcn_diag_mfma_probe(float* out, int blocks, int iters, int nacc, void* str
  * x1,x2 (n,Ci,T,V); w (Co,Ci); z (n,Co,Tout,V); zaug (n,Co,Tout); s,h (Ci) or NULL. */
 int dsgcn_pwconv_plan(int Tout, int V, int aug, int* TR, int* NPpad, int* nblk_per_sample);
 /* rows of the forward's `partial` buffer: (rows, Co, 2) */
-int dsgcn_pwconv_partial_rows(int n, int Co, int T, int V, int stride, int aug);
+int dsgcn_pwconv_partial_rows(int n, int Ci, int Co, int T, int V, int stride, int aug);
 /* tuning / ablation knobs used by tools/ (key 0: ablation mask, key 1: max 32-channel tiles per block) */
 int dsgcn_pwconv_tuning(int key, int value);
 int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,

@@ -102,6 +102,10 @@ def _rand(g, *shape, scale=1.0):
     (2, 64, 128, 64, 25, 2, False, 'plain'),      # strided residual conv
     (2, 128, 96, 50, 17, 1, True, 'res_plain'),   # coco, T not a multiple of the row tile, unaligned planes
     (1, 5, 7, 9, 18, 2, True, 'affine_relu'),     # ragged everything
+    (2, 256, 96, 16, 25, 1, False, 'plain'),      # pre conv of the last stage: 3 M-tiles
+    (2, 24, 64, 64, 25, 1, False, 'affine_relu'), # post conv: K = 24 (one padded k-group)
+    (5, 64, 64, 64, 25, 1, False, 'res_affine'),  # 65 wave tiles: the last workgroup is partly empty
+    (3, 48, 128, 32, 25, 1, False, 'affine_relu'),
 ])
 def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
     g = torch.Generator().manual_seed(Ci * 7 + Co + T)

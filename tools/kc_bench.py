@@ -1,0 +1,84 @@
+"""K-C micro-benchmark: forward / data gradient / weight gradient per DS-STGCN layer shape, HIP-event timed through the
+C ABI (no autograd, no Python between launches beyond the ctypes call).  Usage: kc_bench.py [variant ...] where a variant
+is key=value pairs joined by commas for dsgcn_pwconv_tuning (e.g. 3=0  or  3=3,4=2,6=16)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dsgcn_amd import native
+lib = native.lib(); dev = 'cuda'; st = torch.cuda.current_stream().cuda_stream
+n, V = 128, 25
+SHAPES = [('pre1', 64, 24, 64, 0), ('post1', 24, 64, 64, 1), ('branch1', 64, 64, 64, 2), ('transf1', 64, 64, 64, 1),
+          ('pre5', 128, 48, 32, 0), ('post5', 48, 128, 32, 1), ('branch5', 128, 128, 32, 2), ('transf5', 128, 128, 32, 1),
+          ('pre8', 256, 96, 16, 0), ('post8', 96, 256, 16, 1), ('branch8', 256, 256, 16, 2), ('transf8', 256, 256, 16, 1)]
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def run(variant):
+    keys = {3: 3, 4: 0, 5: 0, 6: 0}
+    if variant:
+        for kv in variant.split(','):
+            k, v = kv.split('=')
+            keys[int(k)] = int(v)
+    for k, v in keys.items():
+        assert lib.dsgcn_pwconv_tuning(k, v) == 0
+    print(f'--- variant {variant or "default"}')
+    print(f'{"name":8s} {"Ci":>4s} {"Co":>4s} | {"fwd us":>7s} {"TB/s":>5s} {"TF":>5s} | {"dgrad":>7s} {"TB/s":>5s} {"TF":>5s} | {"wgrad":>7s} {"TB/s":>5s} {"TF":>5s}')
+    tot = [0.0, 0.0, 0.0]
+    for name, Ci, Co, T, mode in SHAPES:
+        x1 = torch.randn(n, Ci, T, V, device=dev)
+        x2 = torch.randn(n, Ci, T, V, device=dev) if mode == 2 else None
+        s1 = (torch.rand(Ci, device=dev) + .5) if mode else None
+        h1 = (torch.randn(Ci, device=dev) * .1) if mode else None
+        relu = 1 if mode else 0
+        w = torch.randn(Co, Ci, device=dev) * Ci ** -.5; b = torch.zeros(Co, device=dev)
+        z = torch.empty(n, Co, T, V, device=dev); gz = torch.randn(n, Co, T, V, device=dev)
+        A0 = torch.randn(Co, device=dev) * 1e-3; B0 = torch.randn(Co, device=dev) * 1e-3
+        dx = torch.empty_like(x1); dx2 = torch.empty_like(x1) if mode == 2 else None
+        part = torch.empty(lib.dsgcn_pwconv_partial_rows(n, Ci, Co, T, V, 1, 0), Co, 2, device=dev)
+        ipart = torch.empty(lib.dsgcn_pwconv_ipart_rows(n, Ci, Co, T, V, 1), Ci, 3, device=dev) if mode else None
+        splits = lib.dsgcn_pwconv_wgrad_splits(n, Ci, Co, T, V, 1)
+        pstride = Co * Ci + Co
+        wpart = torch.empty(splits, pstride, device=dev)
+        P = lambda t: None if t is None else t.data_ptr()
+
+        def fwd():
+            assert lib.dsgcn_pwconv_fwd(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(w), P(b), P(z), None, P(part),
+                                        n, Ci, Co, T, V, 1, 0, 1, st) == 0
+
+        def dgrad():
+            assert lib.dsgcn_pwconv_dgrad(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(w), P(z), None, P(gz), None,
+                                          P(A0), P(B0), P(dx), P(dx2), P(ipart), n, Ci, Co, T, V, 1, 0, st) == 0
+
+        def wgrad():
+            assert lib.dsgcn_pwconv_wgrad(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(z), None, P(gz), None, P(A0),
+                                          P(B0), wpart.data_ptr(), wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co,
+                                          T, V, 1, 0, st) == 0
+        L = n * T * V
+        nin = 2 if mode == 2 else 1
+        flops = 2.0 * Ci * Co * L
+        res = []
+        for i, (fn, byts) in enumerate(((fwd, 4 * L * (Ci * nin + Co)),
+                                        (dgrad, 4 * L * (2 * Co + Ci * nin * (2 if mode else 1))),
+                                        (wgrad, 4 * L * (2 * Co + Ci * nin)))):
+            t = timeit(fn)
+            tot[i] += t
+            res.append(f'{t:7.1f} {byts / t / 1e6:5.2f} {flops / t / 1e6:5.1f}')
+        print(f'{name:8s} {Ci:4d} {Co:4d} | ' + ' | '.join(res), flush=True)
+    print(f'total us: fwd {tot[0]:.0f} dgrad {tot[1]:.0f} wgrad {tot[2]:.0f}')
+
+
+if __name__ == '__main__':
+    for v in (sys.argv[1:] or ['']):
+        run(v)
