@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(64) void k_bn_bwd_coef(const float* __restrict__ g_
 
 int g_pw_ablate = 0;
 int g_pw_maxmt = 2;      // measured (tools/pw_ablate.py): small per-wave tiles + more resident waves win
-int g_pw4 = 3;           // bit 0: wide-load forward (pw4.hip), bit 1: wide-load data gradient
+int g_pw4 = 7;           // bit 0: wide-load forward (pw4.hip), bit 1: wide-load data gradient, bit 2: blocked wgrad (wgrad.hip)
 
 // pw4.hip (internal linkage across the library's objects, not exported)
 __attribute__((visibility("hidden"))) int dsgcn_p4_tuning(int key, int value);
@@ -1063,6 +1063,14 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const 
                                                           const float* w, const float* z, const float* gz,
                                                           const float* A0, const float* B0, float* dx1, float* dx2,
                                                           float* ipart, int n, int Ci, int Co, int L, hipStream_t st);
+
+// wgrad.hip
+__attribute__((visibility("hidden"))) int dsgcn_wg2_splits(int n, int Ci, int Co, int L);
+__attribute__((visibility("hidden"))) int dsgcn_wg2(const float* x1, const float* s1, const float* h1, const float* x2,
+                                                     const float* s2, const float* h2, int relu, const float* z,
+                                                     const float* gz, const float* A0, const float* B0, float* dwp,
+                                                     float* dbp, int pstride, int n, int Ci, int Co, int L,
+                                                     hipStream_t st);
 
 // workgroup rows of the statistics / input-affine partial buffers for a (K -> M) mix over n planes of L positions
 static int pw_conv_rows(int n, int K, int M, int T, int V, int stride, int which) {
@@ -1267,6 +1275,10 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
 // k-split plan of the weight gradient: returns the number of splits (size of dim 0 of dwp / dbp).
 int dsgcn_pwconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int stride) {
   const int Tout = (T + stride - 1) / stride;
+  if (stride == 1 && (g_pw4 & 4)) {
+    const int s = dsgcn_wg2_splits(n, Ci, Co, T * V);
+    if (s > 0) return s;
+  }
   const int TR = Tout >= WG_TR ? WG_TR : Tout;
   const int chunks = n * ((Tout + TR - 1) / TR);
   const int tiles = ((Co + 63) / 64) * ((Ci + 63) / 64);
@@ -1285,6 +1297,13 @@ int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const 
                        int Ci, int Co, int T, int V, int stride, int aug, void* stream) {
   if (!x1 || !dwp || !dbp || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0 || stride <= 0) return DSGCN_EINVAL;
   if ((A0 && (!B0 || !z)) || (aug && A0 && !zaug)) return DSGCN_EINVAL;
+  if (stride == 1 && !aug && (g_pw4 & 4)) {
+    if (pstride < Co * Ci) return DSGCN_EINVAL;
+    const int fast = dsgcn_wg2(x1, s1, h1, x2, s2, h2, relu, z, gz, A0, B0, dwp, dbp, pstride, n, Ci, Co, T * V,
+                               (hipStream_t)stream);
+    if (fast == 1) return 0;
+    if (fast != 0) return fast;
+  }
   const int Tout = (T + stride - 1) / stride;
   const int TR = Tout >= WG_TR ? WG_TR : Tout;
   if (TR * V > 16 * WG_J) return DSGCN_EUNSUPPORTED;

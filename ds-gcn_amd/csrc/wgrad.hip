@@ -1,0 +1,284 @@
+// K-C weight gradient, register-blocked form:  dW[co,ci] = sum_{n,pos} dz_eff[n,co,pos] * v[n,ci,pos],  db[co] = sum dz_eff
+// (backward of the 1x1 convs cited in pwconv.hip: gcn.py:2165-2169,2209-2215,2363-2365, tcn.py:379-404,422,427), with
+//   dz_eff = gz + A0[co] + B0[co]*z          (BatchNorm-statistics terms of the conv's own output, folded while loading)
+//   v      = relu?(x1*s1+h1 (+ x2*s2+h2))    (the forward's virtual input, rebuilt while loading).
+// The reduction runs over positions, so both MFMA operands need "lane = channel" fragments: the tiles are staged through
+// LDS — coalesced 16-B global loads (8..32 lanes per 128..512-B row segment), the prologue arithmetic in registers, rows
+// stored with stride KC+2 (= 2*odd: conflict-free ds_read_b64, each read feeds two k-steps) — and every wave owns a
+// (TM/2)x(TN/2) block of the workgroup's TMxTN output tile (up to 2x2 MFMA tiles: one LDS read per MFMA instead of the
+// two of the first version, and a 128x128 tile reads each operand row once for 128 output columns instead of 64).
+// K (positions) is split over workgroups; each split writes its partial dW / db (deterministic: summed by dsgcn_colsum).
+#include "common.h"
+
+namespace {
+
+constexpr int WG_NT = 256;
+constexpr int WG_OOB = 0x7ffffff0;
+
+struct Wg2Args {
+  const float* x1; const float* s1; const float* h1;
+  const float* x2; const float* s2; const float* h2;
+  int relu;
+  const float* z; const float* gz; const float* A0; const float* B0;
+  float* dwp; float* dbp; int pstride;
+  int n, Ci, Co, L, cpn, total_chunks, cps, tm_tiles, tn_tiles;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 wg_load(__amdgpu_buffer_rsrc_t r, int voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ int wg_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int TM, int TN, int KC, bool HAS2, bool HASC>
+__global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
+  constexpr int LS = KC + 2;
+  constexpr int Q = KC / 4;                       // float4 slots per row
+  constexpr int JD = TM * Q / WG_NT, JX = TN * Q / WG_NT;
+  constexpr int MI = TM / 64, NI = TN / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ds = lds;                                // [TM][LS] dz_eff
+  float* Xs = lds + TM * LS;                      // [TN][LS] virtual input
+  f32x2* Cs = reinterpret_cast<f32x2*>(lds + (TM + TN) * LS);          // [TM] (A0, B0)
+  f32x4* Ps = reinterpret_cast<f32x4*>(lds + (TM + TN) * LS + 2 * TM);  // [TN] (s1, h1, s2, h2)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  // XCD-aware decode: the tiles of one K-split read the same chunks -> consecutive slots of one XCD (blockIdx % 8)
+  const int tiles = a.tm_tiles * a.tn_tiles;
+  int split, tile;
+  if (tiles > 1) {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    tile = slot % tiles;
+    split = (slot / tiles) * 8 + xcd;
+  } else {
+    tile = 0;
+    split = blockIdx.x;
+  }
+  const int ch0 = split * a.cps;
+  const int ch1 = min(a.total_chunks, ch0 + a.cps);
+  if (ch0 >= ch1) return;
+  const int coBase = (tile % a.tm_tiles) * TM, ciBase = (tile / a.tm_tiles) * TN;
+  const int Co = a.Co, Ci = a.Ci, L = a.L;
+  const int L4 = L * 4;
+
+  for (int i = tid; i < TM; i += WG_NT) {
+    const int co = coBase + i;
+    Cs[i] = (HASC && co < Co) ? f32x2{a.A0[co], a.B0[co]} : f32x2{0.f, 0.f};
+  }
+  for (int i = tid; i < TN; i += WG_NT) {
+    const int ci = ciBase + i;
+    f32x4 p = {1.f, 0.f, 1.f, 0.f};
+    if (ci < Ci) {
+      if (a.s1) { p.x = a.s1[ci]; p.y = a.h1[ci]; }
+      if (a.s2) { p.z = a.s2[ci]; p.w = a.h2[ci]; }
+    }
+    Ps[i] = p;
+  }
+
+  // this thread's staging slots: slot f = tid + 256*j -> (row f / Q, positions 4*(f % Q) ..+3); rows are fixed per thread
+  const int col = (tid % Q) * 4;
+  const int rowD0 = tid / Q, rowX0 = tid / Q;     // + (256/Q)*j
+  constexpr int RSTEP = WG_NT / Q;
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+
+  f32x4 gr[JD], zr[HASC ? JD : 1], xr[JX], yr[HAS2 ? JX : 1];
+  auto issue = [&](int ch) {
+    const int n = ch / a.cpn;
+    const int c0 = (ch - n * a.cpn) * KC;
+    const bool pv = c0 + col < L;
+    const __amdgpu_buffer_rsrc_t rg = wg_rsrc((a.gz ? a.gz : a.x1) + (size_t)(a.gz ? n : 0) * Co * L, a.gz ? Co * L4 : 0);
+    const __amdgpu_buffer_rsrc_t rz = wg_rsrc((HASC ? a.z : a.x1) + (size_t)(HASC ? n : 0) * Co * L, HASC ? Co * L4 : 0);
+    const __amdgpu_buffer_rsrc_t rx = wg_rsrc(a.x1 + (size_t)n * Ci * L, Ci * L4);
+    const __amdgpu_buffer_rsrc_t ry = wg_rsrc((HAS2 ? a.x2 : a.x1) + (size_t)n * Ci * L, Ci * L4);
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      const int co = coBase + rowD0 + RSTEP * j;
+      const int voff = (pv && co < Co) ? (co * L + c0 + col) * 4 : WG_OOB;
+      gr[j] = wg_load(rg, voff);
+      if constexpr (HASC) zr[j] = wg_load(rz, voff);
+    }
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const int ci = ciBase + rowX0 + RSTEP * j;
+      const int voff = (pv && ci < Ci) ? (ci * L + c0 + col) * 4 : WG_OOB;
+      xr[j] = wg_load(rx, voff);
+      if constexpr (HAS2) yr[j] = wg_load(ry, voff);
+    }
+  };
+
+  float dsum[JD];
+#pragma unroll
+  for (int j = 0; j < JD; ++j) dsum[j] = 0.f;
+
+  auto commit = [&](int ch) {
+    const int n = ch / a.cpn;
+    const int c0 = (ch - n * a.cpn) * KC;
+    const bool pv = c0 + col < L;
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      const int row = rowD0 + RSTEP * j;
+      const bool ok = pv && coBase + row < Co;
+      f32x4 d = gr[j];
+      if constexpr (HASC) {
+        const f32x2 c = Cs[row];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] += fmaf(c.y, zr[j][e], c.x);
+      }
+      if (!ok) d = f32x4{0.f, 0.f, 0.f, 0.f};
+      dsum[j] += (d.x + d.y) + (d.z + d.w);
+      f32x2* dst = reinterpret_cast<f32x2*>(Ds + row * LS + col);
+      dst[0] = f32x2{d.x, d.y};
+      dst[1] = f32x2{d.z, d.w};
+    }
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const int row = rowX0 + RSTEP * j;
+      const bool ok = pv && ciBase + row < Ci;
+      const f32x4 p = Ps[row];
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = fmaf(xr[j][e], p.x, p.y);
+        if constexpr (HAS2) t += fmaf(yr[j][e], p.z, p.w);
+        v[e] = ok ? fmaxf(t, lo) : 0.f;
+      }
+      f32x2* dst = reinterpret_cast<f32x2*>(Xs + row * LS + col);
+      dst[0] = f32x2{v.x, v.y};
+      dst[1] = f32x2{v.z, v.w};
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+  const int m0 = (wave >> 1) * (TM / 2), n0 = (wave & 1) * (TN / 2);
+  const float* Ap = Ds + (m0 + l31) * LS + 2 * half;
+  const float* Bp = Xs + (n0 + l31) * LS + 2 * half;
+
+  __syncthreads();                                // Cs / Ps visible
+  issue(ch0);
+  for (int ch = ch0; ch < ch1; ++ch) {
+    commit(ch);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ch + 1 < ch1) issue(ch + 1);
+#pragma unroll
+    for (int w = 0; w < Q; ++w) {
+      f32x2 av[MI], bv[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x2*>(Ap + 32 * mi * LS + 4 * w);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bv[ni] = *reinterpret_cast<const f32x2*>(Bp + 32 * ni * LS + 4 * w);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].x, bv[ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].y, bv[ni].y, acc[mi][ni], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // raw barrier: the next chunk's loads stay in flight
+  }
+
+  // D[i = co][j = ci] -> partial dW of this split
+  float* dw = a.dwp + (size_t)split * a.pstride;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int ci = ciBase + n0 + 32 * ni + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = coBase + m0 + 32 * mi + wg_row32(r, half);
+        if (co < Co && ci < Ci) dw[(size_t)co * Ci + ci] = acc[mi][ni][r];
+      }
+    }
+  // db: the Q threads that stage one row hold its pieces
+  if (tile / a.tm_tiles == 0) {
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      float s = dsum[j];
+#pragma unroll
+      for (int off = 1; off < Q; off <<= 1) s += __shfl_xor(s, off, 64);
+      const int co = coBase + rowD0 + RSTEP * j;
+      if ((tid % Q) == 0 && co < Co) a.dbp[(size_t)split * a.pstride + co] = s;
+    }
+  }
+}
+
+struct Wg2Plan { int TM, TN, KC, cpn, chunks, tm_tiles, tn_tiles, splits, cps; size_t lds; };
+
+bool wg2_plan(int n, int Ci, int Co, int L, Wg2Plan* p) {
+  if (L % 4) return false;
+  if ((long)Ci * L * 4 >= (1L << 31) - 64 || (long)Co * L * 4 >= (1L << 31) - 64) return false;
+  p->TM = Co > 64 ? 128 : 64;
+  p->TN = Ci > 64 ? 128 : 64;
+  p->KC = (p->TM == 128 && p->TN == 128) ? 32 : ((p->TM == 64 && p->TN == 64) ? 128 : 64);
+  p->cpn = (L + p->KC - 1) / p->KC;
+  p->chunks = n * p->cpn;
+  p->tm_tiles = (Co + p->TM - 1) / p->TM;
+  p->tn_tiles = (Ci + p->TN - 1) / p->TN;
+  const int tiles = p->tm_tiles * p->tn_tiles;
+  int target = (tiles >= 4 ? 256 : 512) / tiles;
+  if (target < 1) target = 1;
+  if (tiles > 1) target = (target + 7) / 8 * 8;       // the XCD decode deals splits in groups of 8
+  if (target > p->chunks) target = p->chunks;
+  p->cps = (p->chunks + target - 1) / target;
+  p->splits = (p->chunks + p->cps - 1) / p->cps;
+  p->lds = ((size_t)(p->TM + p->TN) * (p->KC + 2) + 2 * p->TM + 4 * p->TN) * sizeof(float);
+  return true;
+}
+
+template <int TM, int TN, int KC>
+void wg2_launch(const Wg2Args& a, bool has2, bool hasc, dim3 grid, size_t lds, hipStream_t st) {
+  if (has2) {
+    if (hasc) hipLaunchKernelGGL((k_wg2<TM, TN, KC, true, true>), grid, dim3(WG_NT), lds, st, a);
+    else hipLaunchKernelGGL((k_wg2<TM, TN, KC, true, false>), grid, dim3(WG_NT), lds, st, a);
+  } else {
+    if (hasc) hipLaunchKernelGGL((k_wg2<TM, TN, KC, false, true>), grid, dim3(WG_NT), lds, st, a);
+    else hipLaunchKernelGGL((k_wg2<TM, TN, KC, false, false>), grid, dim3(WG_NT), lds, st, a);
+  }
+}
+
+}  // namespace
+
+// Internal (not exported): K-split count of the fast weight gradient for this shape, 0 = not eligible.
+__attribute__((visibility("hidden"))) int dsgcn_wg2_splits(int n, int Ci, int Co, int L) {
+  Wg2Plan p;
+  return wg2_plan(n, Ci, Co, L, &p) ? p.splits : 0;
+}
+
+// Returns 1 = launched, 0 = not eligible (caller falls back), other = error.
+__attribute__((visibility("hidden"))) int dsgcn_wg2(const float* x1, const float* s1, const float* h1, const float* x2,
+                                                     const float* s2, const float* h2, int relu, const float* z,
+                                                     const float* gz, const float* A0, const float* B0, float* dwp,
+                                                     float* dbp, int pstride, int n, int Ci, int Co, int L,
+                                                     hipStream_t st) {
+  Wg2Plan p;
+  if (!wg2_plan(n, Ci, Co, L, &p)) return 0;
+  Wg2Args a = {};
+  a.x1 = x1; a.s1 = s1; a.h1 = h1; a.x2 = x2; a.s2 = s2; a.h2 = h2; a.relu = relu;
+  a.z = z; a.gz = gz; a.A0 = A0; a.B0 = B0; a.dwp = dwp; a.dbp = dbp; a.pstride = pstride;
+  a.n = n; a.Ci = Ci; a.Co = Co; a.L = L; a.cpn = p.cpn; a.total_chunks = p.chunks; a.cps = p.cps;
+  a.tm_tiles = p.tm_tiles; a.tn_tiles = p.tn_tiles;
+  const int tiles = p.tm_tiles * p.tn_tiles;
+  const dim3 grid(tiles > 1 ? (unsigned)((p.splits + 7) / 8 * 8 * tiles) : (unsigned)p.splits);
+  const bool has2 = x2 != nullptr, hasc = A0 != nullptr;
+  if (p.TM == 128 && p.TN == 128) wg2_launch<128, 128, 32>(a, has2, hasc, grid, p.lds, st);
+  else if (p.TM == 128) wg2_launch<128, 64, 64>(a, has2, hasc, grid, p.lds, st);
+  else if (p.TN == 128) wg2_launch<64, 128, 64>(a, has2, hasc, grid, p.lds, st);
+  else wg2_launch<64, 64, 128>(a, has2, hasc, grid, p.lds, st);
+  DSGCN_LAUNCH_CHECK();
+  return 1;
+}
