@@ -275,6 +275,7 @@ def main():
     use_graph = not args.no_graph
     g_a = g_b = None
     if use_graph:
+        capture_error = None
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -285,15 +286,30 @@ def main():
             torch.cuda.synchronize()
             g_a = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread polls its events while we capture (N > 1); in the default
-            # 'global' mode that would invalidate the capture
+            # 'global' mode that would invalidate the capture.  Neither graph contains a collective: the log scalars
+            # stay rank-local in the captured step (train_step(sync_log_vars=False)) and the gradient all-reduce runs
+            # between the two replays.
             with torch.cuda.graph(g_a, capture_error_mode='thread_local'):
                 fwd_bwd()
             g_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_b, capture_error_mode='thread_local'):
                 opt.step()
             torch.cuda.synchronize()
-        except Exception as exc:      # capture is an optimisation; the eager path computes the same thing
-            print(f'[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly', file=sys.stderr)
+        except Exception as exc:
+            capture_error = f'{type(exc).__name__}: {exc}'
+        # The graph-vs-eager decision is collective: ranks that replay and ranks that launch eagerly would issue the
+        # same collectives, but a silently slower rank makes the aggregate number meaningless — so a failed capture is
+        # an error at N > 1 (run with --no-graph to measure the eager path), and only a warning on one GPU.
+        ok = torch.tensor([0 if capture_error else 1], device=device, dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            msg = f'[bench] rank {rank}: hipGraph capture failed on at least one rank ({capture_error or "another rank"})'
+            if world > 1:
+                print(msg + '; aborting (pass --no-graph for an eager run)', file=sys.stderr)
+                dist.destroy_process_group()
+                raise SystemExit(3)
+            print(msg + '; running eagerly', file=sys.stderr)
             use_graph = False
             g_a = g_b = None
 

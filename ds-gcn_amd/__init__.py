@@ -19,6 +19,6 @@ from .recognizers import RecognizerGCN, reduce_log_vars, gather_results
 from . import kernels
 from .data_parallel import FlatParams, FlatDataParallel, shard_batch
 from .train import FlatSGD, cosine_lr
-from .checkpoint import load_checkpoint, save_checkpoint
+from .checkpoint import load_checkpoint, save_checkpoint, resume, find_resume
 
 __version__ = '0.1.0'

@@ -31,8 +31,11 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False, revise_ke
     return ckpt
 
 
-def save_checkpoint(model, filename, optimizer=None, meta=None):
-    """Writes {'meta', 'state_dict', 'optimizer'} with CPU tensors, like mmcv.runner.save_checkpoint."""
+def save_checkpoint(model, filename, optimizer=None, meta=None, create_symlink=False):
+    """Writes {'meta', 'state_dict', 'optimizer'} with CPU tensors, like mmcv.runner.save_checkpoint.  ``meta`` carries
+    the runner's ``epoch`` / ``iter`` (epoch_based_sparse_runner.py:175).  ``create_symlink`` also points
+    ``latest.pth`` in the same directory at the file (epoch_based_sparse_runner.py:185-188) — what auto-resume finds."""
+    import os
     meta = dict(meta or {})
     meta.setdefault('time', time.asctime())
     sd = OrderedDict((k, v.detach().cpu()) for k, v in _strip_prefix(model.state_dict()).items())
@@ -40,4 +43,28 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
     if optimizer is not None:
         ckpt['optimizer'] = optimizer.state_dict()
     torch.save(ckpt, filename)
+    if create_symlink:
+        dst = os.path.join(os.path.dirname(os.path.abspath(filename)), 'latest.pth')
+        if os.path.lexists(dst):
+            os.remove(dst)
+        os.symlink(os.path.basename(filename), dst)
     return filename
+
+
+def resume(model, optimizer, filename, map_location='cpu'):
+    """mmcv ``BaseRunner.resume``: model weights, optimizer state and the (epoch, iter) counters of a checkpoint.
+    -> meta dict (``meta['epoch']`` completed epochs, ``meta['iter']`` completed iterations)."""
+    ckpt = load_checkpoint(model, filename, map_location=map_location, strict=True)
+    if optimizer is not None and 'optimizer' in ckpt:
+        optimizer.load_state_dict(ckpt['optimizer'])
+    return dict(ckpt.get('meta', {}))
+
+
+def find_resume(work_dir, resume_from=None, auto_resume=True):
+    """The checkpoint a run in ``work_dir`` continues from (reference tools/train.py:82-86): an explicit ``resume_from``
+    wins; otherwise ``work_dir/latest.pth`` when ``auto_resume`` and it exists; else None."""
+    import os
+    if resume_from is not None:
+        return resume_from
+    path = os.path.join(work_dir, 'latest.pth')
+    return path if auto_resume and os.path.exists(path) else None

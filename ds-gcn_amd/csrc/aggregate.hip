@@ -36,6 +36,7 @@ __device__ __forceinline__ void load_plane_to_lds(const float* __restrict__ src,
   }
 }
 
+#ifdef DSGCN_LAB   // the first (scalar-cache + VALU) formulation, kept for A/B measurements only
 template <int V, int UNR>
 __global__ __launch_bounds__(64) void k_aggregate_fwd_valu(const float* __restrict__ zp, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int relu,
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_valu(const float* __restri
     for (int i = lane; i < cnt; i += 64) dst[i] = lds[i];
   }
 }
+#endif
 
 // MFMA C/D row of accumulator register r for this lane (32x32 tile): (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
                                                            const float* __restrict__ ahat,
                                                            const float* __restrict__ dy, float* __restrict__ dzp,
                                                            float* __restrict__ dahat, float* __restrict__ partial,
-                                                           int KC, int T, long units, int ablate) {
+                                                           int KC, int T, long units) {
   constexpr int KS = (V + 1) / 2;
   constexpr int NP4 = (64 * V / 4 + 63) / 64;
   constexpr int NA = (V * V + 63) / 64;
@@ -516,8 +518,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
 #pragma unroll
     for (int i = 0; i < 16; ++i) accA[i] = 0.f;
     // dAhat = P^T dY : k runs over frames; operands of 8 k-steps are read from LDS before their MFMAs are issued
-    // (a read->use chain per step left the matrix pipe idle ~2/3 of the time: tools/ka_ablate.py)
-    if (!(ablate & 1))
+    // (a read->use chain per step left the matrix pipe idle ~2/3 of the time: round-1 ablation)
     for (int j0 = 0; j0 < rows; j0 += 16) {
       float av[8], bv[8];
 #pragma unroll
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
     }
     if (!DA_LDS) {
       float* __restrict__ dA = dahat + (size_t)unit * V * V;
-      if (mi < V && !(ablate & 4)) {
+      if (mi < V) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int u = mfma_row(r, mk);
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
     float sum_h = 0.f, sum_s = 0.f;
 #pragma unroll
     for (int tile = 0; tile < 2; ++tile) {
-      if (tile * 32 < rows && !(ablate & 2)) {
+      if (tile * 32 < rows) {
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
 #pragma unroll
       for (int q = 0; q < NP4; ++q) {
         const int i = lane + q * 64;
-        if (i < c4 && !(ablate & 8)) d4[i] = l4[i];
+        if (i < c4) d4[i] = l4[i];
       }
     }
     sum_s = wave_sum(sum_s);
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
 
 // Two waves per unit for 32 < T <= 64: each wave owns 32 frames (its half of Zp / dY / dZp and half of the adjacency
 // load), so the serial load -> MFMA -> store chain per wave is half as long and twice as many waves are resident
-// (tools/ka_ablate.py: at n=128 the one-wave form spends half its time in the per-wave MFMA chains, not on HBM).
+// (round-1 ablation: at n=128 the one-wave form spends half its time in the per-wave MFMA chains, not on HBM).
 // dAhat = P^T dY is summed over the two halves through LDS; two raw s_barriers per unit (no vmcnt drain: the next
 // unit's prefetch stays in flight).  partial has 2 rows per unit: [wave][unit][2].
 template <int V, int HR, int NW>
@@ -787,7 +788,6 @@ __global__ __launch_bounds__(64 * NW) void k_aggregate_bwd_pair(const float* __r
 
 int g_pipe_waves = 0;       // tuning knobs (dsgcn_set_tuning)
 int g_pipe_waves_bwd = 0;
-int g_ablate = 0;
 int g_fwd_direct = 1;
 int g_fwd_chunk = 32;
 int g_bwd_variant = 0;      // 1 = one-shot kernel (A/B)
@@ -800,11 +800,14 @@ int launch_fwd(const float* zp, const float* scale, const float* shift, int relu
                long units, int KC, int T, int variant, hipStream_t st) {
   const int vec = ((T * V) % 4 == 0) ? 1 : 0;
   dim3 grid((unsigned)units, (unsigned)((T + 63) / 64));
+#ifdef DSGCN_LAB
   if (variant == 1) {
     const size_t lds = (size_t)64 * V * sizeof(float);
     hipLaunchKernelGGL((k_aggregate_fwd_valu<V, 5>), grid, dim3(64), lds, st, zp, scale, shift, relu, ahat,
                        (long)V * V, 0, y, KC, T, vec);
-  } else if (variant == 2 || !vec) {
+  } else
+#endif
+  if (variant == 2 || !vec) {
     const size_t lds = (size_t)(64 * V + V * V) * sizeof(float);
     hipLaunchKernelGGL((k_aggregate_fwd<V>), grid, dim3(64), lds, st, zp, scale, shift, relu, ahat, y, KC, T, vec);
   } else {
@@ -859,10 +862,10 @@ int launch_bwd(const float* zp, const float* scale, const float* shift, int relu
     const long g = (units + per - 1) / per;
     if (g_bwd_da_lds)
       hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, true>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
-                         ahat, dy, dzp, dahat, partial, KC, T, units, g_ablate);
+                         ahat, dy, dzp, dahat, partial, KC, T, units);
     else
       hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
-                         ahat, dy, dzp, dahat, partial, KC, T, units, g_ablate);
+                         ahat, dy, dzp, dahat, partial, KC, T, units);
   } else {
     hipLaunchKernelGGL((k_aggregate_bwd<V>), dim3((unsigned)units), dim3(64), lds, st, zp, scale, shift, relu, ahat,
                        dy, dzp, dahat, partial, KC, T, vec);
@@ -894,6 +897,7 @@ int dsgcn_aggregate_fwd(const float* zp, const float* scale, const float* shift,
   return aggregate_fwd_dispatch(zp, scale, shift, relu, ahat, y, n, KC, T, V, 0, stream);
 }
 
+#ifdef DSGCN_LAB
 // A/B only (tools/ka_variants.py): variant 1 = scalar-cache/VALU formulation, 2 = one-shot MFMA (no pipelining).
 int dsgcn_aggregate_fwd_variant(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
                                 float* y, int n, int KC, int T, int V, int variant, void* stream) {
@@ -904,7 +908,6 @@ int dsgcn_set_tuning(int key, int value) {
   if (key == 0) { g_pipe_waves = value; return 0; }
   if (key == 1) { g_pipe_waves_bwd = value; return 0; }
   if (key == 2) { g_bwd_variant = value; return 0; }
-  if (key == 3) { g_ablate = value; return 0; }
   if (key == 4) { g_fwd_direct = value; return 0; }
   if (key == 5) { g_fwd_chunk = value; return 0; }
   if (key == 6) { g_bwd_da_lds = value; return 0; }
@@ -918,6 +921,8 @@ int dsgcn_aggregate_fwd_valu(const float* zp, const float* scale, const float* s
                              float* y, int n, int KC, int T, int V, void* stream) {
   return aggregate_fwd_dispatch(zp, scale, shift, relu, ahat, y, n, KC, T, V, 1, stream);
 }
+
+#endif  // DSGCN_LAB
 
 // rows of the backward's `partial` buffer: (rows, KC, 2); the sum over rows gives [d scale | d shift]
 int dsgcn_aggregate_bwd_partial_rows(int n, int T, int V) {

@@ -693,11 +693,13 @@ int dsgcn_aggsum_bwd_piece_rows(int n, int K, int Co, int T, int V) {
   }
 }
 
+#ifdef DSGCN_LAB
 int dsgcn_aggsum_tuning(int key, int value) {
   if (key == 0) { g_as_pipe = value; return 0; }
   if (key == 1) { g_as_waves_fwd = value; return 0; }
   if (key == 2) { g_as_wgs_bwd = value; return 0; }
   return DSGCN_EINVAL;
 }
+#endif
 
 }  // extern "C"

@@ -1,5 +1,6 @@
 // Diagnostics (tools/ only): raw f32 MFMA issue-rate probe used to calibrate the roofline of K-C.
 #include "common.h"
+#ifdef DSGCN_LAB
 namespace {
 template <int NACC>
 __global__ __launch_bounds__(256) void k_mfma_probe(float* out, int iters, float a0, float b0) {
@@ -29,3 +30,4 @@ extern "C" int dsgcn_diag_mfma_probe(float* out, int blocks, int iters, int nacc
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
+#endif

@@ -31,7 +31,7 @@ struct PwArgs {
   int relu;
   const float* w; const float* bias;
   float* z; float* zaug; float* partial;
-  int n, Ci, Co, T, V, Tout, stride, aug, TR, NPpad, vec, stats, ablate, roll, nbx, cc;
+  int n, Ci, Co, T, V, Tout, stride, aug, TR, NPpad, vec, stats, roll, nbx, cc;
 };
 
 __device__ __forceinline__ int mfma_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -216,7 +216,7 @@ __device__ __forceinline__ void fwd2_roll(const PwArgs& a, f32x16 (&acc)[MT][1],
 }
 
 int g_pw_roll = 13;        // bit 0: rolling prefetch in the forward (on), bit 1: in the data gradient (off: 64 more VGPRs halve
-                           // the occupancy, measured -4 % on the step: tools/roll_ab.py), bit 2: dgrad epilogue operands
+                           // the occupancy, measured -4 % on the step: round-1 A/B), bit 2: dgrad epilogue operands
                            // fetched before the K loop (on: +0.5 %), bit 3: XCD-aware block order in wgrad (on: +0.5 %)
 
 template <int MT, int NW, bool ROLL>
@@ -334,11 +334,11 @@ __global__ __launch_bounds__(PW_NT) void k_pwconv_fwd2(PwArgs a) {
         float val = 0.f;
         if (co < Co && pok[j]) {
           val = acc[m][j][r] + (a.bias ? a.bias[co] : 0.f);
-          if (!(a.ablate & 4)) a.z[(size_t)(n * Co + co) * L + pos] = val;
+          a.z[(size_t)(n * Co + co) * L + pos] = val;
         }
-        if (a.stats && !(a.ablate & 8)) Tw[row * 36 + l31] = val;
+        if (a.stats) Tw[row * 36 + l31] = val;
       }
-      if (a.stats && !(a.ablate & 8)) {
+      if (a.stats) {
         wave_lds_sync();
         const f32x4* rowp = reinterpret_cast<const f32x4*>(Tw + l31 * 36 + half * 16);
 #pragma unroll
@@ -1047,8 +1047,7 @@ __global__ __launch_bounds__(64) void k_bn_bwd_coef(const float* __restrict__ g_
 
 }  // namespace
 
-int g_pw_ablate = 0;
-int g_pw_maxmt = 2;      // measured (tools/pw_ablate.py): small per-wave tiles + more resident waves win
+int g_pw_maxmt = 2;      // measured (round-1 ablation): small per-wave tiles + more resident waves win
 int g_pw4 = 7;           // bit 0: wide-load forward (pw4.hip), bit 1: wide-load data gradient, bit 2: blocked wgrad (wgrad.hip)
 
 // pw4.hip (internal linkage across the library's objects, not exported)
@@ -1085,14 +1084,15 @@ static int pw_conv_rows(int n, int K, int M, int T, int V, int stride, int which
 
 extern "C" {
 
+#ifdef DSGCN_LAB
 int dsgcn_pwconv_tuning(int key, int value) {
-  if (key == 0) { g_pw_ablate = value; return 0; }
   if (key == 1) { g_pw_maxmt = value; return 0; }
   if (key == 2) { g_pw_roll = value; return 0; }
   if (key == 3) { g_pw4 = value; return 0; }
   if (key >= 4 && key <= 6) return dsgcn_p4_tuning(key - 4, value);
   return DSGCN_EINVAL;
 }
+#endif
 
 int dsgcn_pwconv_plan(int Tout, int V, int aug, int* TR, int* NPpad, int* nblk_per_sample) {
   int tr = Tout >= 32 ? 8 : 4;
@@ -1127,7 +1127,7 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
   a.x1 = x1; a.s1 = s1; a.h1 = h1; a.x2 = x2; a.s2 = s2; a.h2 = h2; a.relu = relu;
   a.w = w; a.bias = bias; a.z = z; a.zaug = zaug; a.partial = partial;
   a.n = n; a.Ci = Ci; a.Co = Co; a.T = T; a.V = V; a.Tout = Tout; a.stride = stride; a.aug = aug;
-  a.stats = stats; a.ablate = g_pw_ablate;
+  a.stats = stats;
   a.roll = ((g_pw_roll & 1) && Ci % KW == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int L = Tout * V;

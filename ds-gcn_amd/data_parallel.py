@@ -55,6 +55,12 @@ class FlatParams:
         view (parameters that received none — the dead conv2_se tensors — read as zero).  No-op otherwise."""
         if not self.gather:
             return
+        base, esz = self.flat_g.data_ptr(), self.flat_g.element_size()
+        first = next(((p, off) for p, (off, _) in zip(self.params, self.slices) if p.grad is not None), None)
+        if first is not None and first[0].grad.data_ptr() == base + first[1] * esz:
+            raise RuntimeError('FlatParams(gather=True): a gradient still aliases the flat buffer — call zero_grad() '
+                               'before every backward (a second backward would accumulate into the views and this '
+                               'call would wipe it)')
         self.flat_g.zero_()
         live = [(p.grad, off, n) for p, (off, n) in zip(self.params, self.slices) if p.grad is not None]
         if live and self.flat_g.is_cuda:
@@ -71,28 +77,61 @@ class FlatParams:
                    for p, (off, _) in zip(self.params, self.slices))
 
 
+    _PACK_SLOTS = 4
+
+    def _pack_tables(self, k):
+        """A (pinned host, device) table pair for one dsgcn_pack call.  The H2D copy of the table is asynchronous: the
+        DMA reads the pinned memory when it EXECUTES, so a table must not be rewritten before its copy has run (the
+        host may be a whole step ahead of the GPU: nothing in the step syncs).  Eager calls rotate over a few slots and
+        wait on the slot's copy event before reusing it; a call under hipGraph capture gets tables of its own that are
+        never rewritten (every replay re-reads them; the gradient addresses they hold live in the graph's pool)."""
+        cap = max(k, len(self.params))
+        dev = self.flat_g.device
+
+        def new_slot():
+            host = torch.empty((3, cap), dtype=torch.int64).pin_memory()
+            return dict(host=host, dev=torch.empty_like(host, device=dev),
+                        len=torch.empty(cap, dtype=torch.int32, device=dev), event=None)
+
+        if torch.cuda.is_current_stream_capturing():
+            # the slot reserved by an earlier eager call (pinned allocation is not a capturable operation in the
+            # default capture mode); further captures allocate (works under capture_error_mode='thread_local')
+            slot = self.__dict__.pop('_pack_reserved', None) or new_slot()
+            self.__dict__.setdefault('_pack_graph_slots', []).append(slot)      # alive as long as the graph may replay
+            return slot
+        if self.__dict__.get('_pack_reserved') is None:
+            self._pack_reserved = new_slot()
+        slots = self.__dict__.setdefault('_pack_slots', [])
+        self._pack_next = (getattr(self, '_pack_next', -1) + 1) % self._PACK_SLOTS
+        if len(slots) <= self._pack_next:
+            slots.append(new_slot())
+        slot = slots[self._pack_next]
+        if slot['host'].shape[1] < cap:
+            slots[self._pack_next] = slot = new_slot()
+        if slot['event'] is not None:
+            slot['event'].synchronize()
+        return slot
+
     def _pack_cuda(self, live):
-        """One HIP launch (dsgcn_pack) instead of one blit per tensor.  The (pointer, offset, length) table goes to the
-        device through a pinned staging buffer that stays alive, so the copy is capturable in a hipGraph (replays
-        see the same gradient addresses: they live in the graph's private pool)."""
-        import numpy as np
+        """One HIP launch (dsgcn_pack) instead of one blit per tensor: a (pointer, offset, length) table goes to the
+        device through pinned staging memory (see _pack_tables for its lifetime rules)."""
         from . import native
         k = len(live)
-        if getattr(self, '_pack_host', None) is None or self._pack_host.shape[1] < k:
-            self._pack_host = torch.empty((3, max(k, len(self.params))), dtype=torch.int64).pin_memory()
-            self._pack_dev = torch.empty_like(self._pack_host, device=self.flat_g.device)
-            self._pack_len = torch.empty(self._pack_host.shape[1], dtype=torch.int32, device=self.flat_g.device)
         grads = [g if g.is_contiguous() else g.contiguous() for g, _, _ in live]
-        self._pack_keep = grads                                   # alive until the kernel has run
-        tab = self._pack_host.numpy()
+        slot = self._pack_tables(k)
+        slot['keep'] = grads                                      # alive until the slot is reused (>= one full step)
+        tab = slot['host'].numpy()
         tab[0, :k] = [g.data_ptr() for g in grads]
         tab[1, :k] = [off for _, off, _ in live]
         tab[2, :k] = [n for _, _, n in live]
-        self._pack_dev.copy_(self._pack_host, non_blocking=True)
-        self._pack_len.copy_(self._pack_dev[2])
+        slot['dev'].copy_(slot['host'], non_blocking=True)
+        if not torch.cuda.is_current_stream_capturing():
+            slot['event'] = torch.cuda.Event()
+            slot['event'].record()
+        slot['len'].copy_(slot['dev'][2])
         st = torch.cuda.current_stream().cuda_stream
-        rc = native.lib().dsgcn_pack(self._pack_dev[0].data_ptr(), self._pack_dev[1].data_ptr(),
-                                     self._pack_len.data_ptr(), k, self.flat_g.data_ptr(), st)
+        rc = native.lib().dsgcn_pack(slot['dev'][0].data_ptr(), slot['dev'][1].data_ptr(), slot['len'].data_ptr(), k,
+                                     self.flat_g.data_ptr(), st)
         native.check(rc, 'dsgcn_pack')
 
 

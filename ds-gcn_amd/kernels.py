@@ -210,30 +210,24 @@ def aggregate(zp, ap, relu, ahat):
 # K-B  dynamic adjacency
 # ---------------------------------------------------------------------------------------------
 
-_pair_cache = {}
-
-
-def _edge_class_lists(edge_type):
-    """Joint pairs sorted by edge class + class offsets (device int32), cached per edge_type tensor."""
-    key = (edge_type.data_ptr(), edge_type.device)
-    hit = _pair_cache.get(key)
-    if hit is None:
-        et = edge_type.flatten().to(torch.int64)
-        order = torch.argsort(et, stable=True).to(torch.int32)
-        E = int(et.max().item()) + 1
-        counts = torch.bincount(et, minlength=E)
-        start = torch.zeros(E + 1, dtype=torch.int32, device=edge_type.device)
-        start[1:] = torch.cumsum(counts, 0).to(torch.int32)
-        hit = (order.contiguous(), start.contiguous(), E)
-        _pair_cache[key] = hit
-    return hit
+def edge_class_lists(edge_type, num_classes=None):
+    """Joint pairs sorted by edge class + class offsets (int32, on edge_type's device): the index tables of the
+    edge-typed weight gradient.  Built once per module (dgphgcn1 keeps them as buffers next to edge_type); nothing is
+    cached here."""
+    et = edge_type.flatten().to(torch.int64)
+    order = torch.argsort(et, stable=True).to(torch.int32)
+    E = int(num_classes) if num_classes is not None else int(et.max().item()) + 1
+    counts = torch.bincount(et, minlength=E)
+    start = torch.zeros(E + 1, dtype=torch.int32, device=edge_type.device)
+    start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return order.contiguous(), start.contiguous()
 
 
 class _DynAdj(torch.autograd.Function):
     """proj (n, 9*mid, V) rows [a | b | s-typed] -> Ahat (n, 3*mid, V, V)."""
 
     @staticmethod
-    def forward(ctx, proj, A, alpha, beta, we, be, node_type, edge_type):
+    def forward(ctx, proj, A, alpha, beta, we, be, node_type, edge_type, order, start):
         _require_cuda(proj, A)
         proj, A, alpha, beta, we, be = [_f32c(t) for t in (proj, A, alpha, beta, we, be)]
         n, R, V = proj.shape
@@ -245,17 +239,16 @@ class _DynAdj(torch.autograd.Function):
         rc = native.lib().dsgcn_dynadj_fwd(_ptr(proj), _ptr(A), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be),
                                            _ptr(node_type), _ptr(edge_type), _ptr(ahat), n, mid, V, P, E, _stream())
         native.check(rc, 'dsgcn_dynadj_fwd')
-        ctx.save_for_backward(proj, A, alpha, beta, we, be, node_type, edge_type)
+        ctx.save_for_backward(proj, A, alpha, beta, we, be, node_type, edge_type, order, start)
         ctx.dims = (n, mid, V, P, E)
         return ahat
 
     @staticmethod
     def backward(ctx, dahat):
-        proj, A, alpha, beta, we, be, node_type, edge_type = ctx.saved_tensors
+        proj, A, alpha, beta, we, be, node_type, edge_type, order, start = ctx.saved_tensors
         n, mid, V, P, E = ctx.dims
         dahat = _f32c(dahat)
         dev = proj.device
-        order, start, _ = _edge_class_lists(edge_type)
         dd = torch.empty_like(dahat)
         ddelta = torch.empty((n, mid, V, V), device=dev, dtype=torch.float32)
         dproj = torch.empty_like(proj)
@@ -270,17 +263,20 @@ class _DynAdj(torch.autograd.Function):
         native.check(rc, 'dsgcn_dynadj_bwd')
         red = colsum(pboth)
         dA, dab = red[:3 * V * V].view(3, V, V), red[3 * V * V:]
-        return dproj, dA, dab[:3], dab[3:], dwe.view(E * mid, mid), dbe, None, None
+        return dproj, dA, dab[:3], dab[3:], dwe.view(E * mid, mid), dbe, None, None, None, None
 
 
-def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type):
+def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type, edge_lists=None):
     """Dynamic adjacency.  The three mean-pooled projections (conv1/conv2/conv1_se) are one K-C launch on xbar
-    (a (n,Ci,1,V) "clip"), the rest is K-B."""
+    (a (n,Ci,1,V) "clip"), the rest is K-B.  edge_lists: (pair order, class offsets) from edge_class_lists — pass the
+    module's buffers; built on the fly when omitted."""
     n, Ci, V = xbar.shape
+    if edge_lists is None:
+        edge_lists = edge_class_lists(edge_type, we.shape[0] // we.shape[1])
     w_all = torch.cat([w1, w2, wse], 0)
     b_all = torch.cat([b1, b2, bse], 0)
     proj = pwconv(xbar.unsqueeze(2), None, None, None, False, w_all, b_all, 1, False)[0]
-    return _DynAdj.apply(proj.view(n, w_all.shape[0], V), A, alpha, beta, we, be, node_type, edge_type)
+    return _DynAdj.apply(proj.view(n, w_all.shape[0], V), A, alpha, beta, we, be, node_type, edge_type, *edge_lists)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -13,9 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_DIR = os.path.join(_HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libdsgcn.so')
+LAB_LIB_PATH = os.path.join(LIB_DIR, 'libdsgcn_lab.so')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 
 _lib = None
+_lab = None
 
 c_f = ctypes.c_void_p      # const float* / float*  (device)
 c_i = ctypes.c_void_p      # const int*             (device)
@@ -26,9 +28,6 @@ c_st = ctypes.c_void_p     # hipStream_t
 SIGNATURES = {
     'dsgcn_version': [],
     'dsgcn_aggregate_fwd': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
-    'dsgcn_aggregate_fwd_valu': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
-    'dsgcn_aggregate_fwd_variant': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_st],
-    'dsgcn_set_tuning': [c_int, c_int],
     'dsgcn_aggregate_bwd_partial_rows': [c_int, c_int, c_int],
     'dsgcn_aggregate_bwd': [c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
     'dsgcn_pwconv_plan': [c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
@@ -38,8 +37,6 @@ SIGNATURES = {
                           c_st],
     'dsgcn_pwconv_partial_rows': [c_int] * 7,
     'dsgcn_pwconv_ipart_rows': [c_int] * 6,
-    'dsgcn_pwconv_tuning': [c_int, c_int],
-    'dsgcn_diag_mfma_probe': [c_f, c_int, c_int, c_int, c_st],
     'dsgcn_dz_eff_aug': [c_f] * 7 + [c_int] * 4 + [c_st],
     'dsgcn_colsum': [c_f, c_int, c_int, c_f, c_st],
     'dsgcn_colsum_t': [c_f, c_int, c_int, c_int, c_f, c_st],
@@ -57,7 +54,6 @@ SIGNATURES = {
     'dsgcn_tapconv_wgrad': [c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_st],
     'dsgcn_aggsum_partial_rows': [c_int, c_int, c_int],
     'dsgcn_aggsum_bwd_piece_rows': [c_int] * 5,
-    'dsgcn_aggsum_tuning': [c_int, c_int],
     'dsgcn_aggsum_fwd': [c_f, c_f] + [ctypes.c_long] * 3 + [c_f, c_f] + [c_int] * 5 + [c_st],
     'dsgcn_aggsum_bwd': [c_f, c_f] + [ctypes.c_long] * 3 + [c_f] * 6 + [ctypes.c_long] * 3 + [c_int] * 5 + [c_st],
     'dsgcn_tanhdiff_fwd': [c_f, c_f] + [c_int] * 4 + [c_st],
@@ -71,6 +67,17 @@ SIGNATURES = {
     'dsgcn_fuse_out_bwd': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 4 + [c_st],
     'dsgcn_dynadj_fwd': [c_f] * 6 + [c_i, c_i, c_f] + [c_int] * 5 + [c_st],
     'dsgcn_dynadj_bwd': [c_f] * 5 + [c_i] * 4 + [c_f] * 6 + [c_int] + [c_f] * 2 + [c_int] * 5 + [c_st],
+}
+
+
+# measurement-only entry points: exported by libdsgcn_lab.so only (include/dsgcn_lab.h)
+LAB_SIGNATURES = {
+    'dsgcn_aggregate_fwd_valu': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
+    'dsgcn_aggregate_fwd_variant': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_st],
+    'dsgcn_set_tuning': [c_int, c_int],
+    'dsgcn_pwconv_tuning': [c_int, c_int],
+    'dsgcn_diag_mfma_probe': [c_f, c_int, c_int, c_int, c_st],
+    'dsgcn_aggsum_tuning': [c_int, c_int],
 }
 
 
@@ -98,24 +105,29 @@ def _file_hash(paths):
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, lab=False):
     """Compile every HIP source for gfx950 into one shared library (cross-compiles without a GPU).
+    lab=True builds ``libdsgcn_lab.so`` instead: the same sources with -DDSGCN_LAB, which adds the measurement-only
+    entry points of include/dsgcn_lab.h (used by tools/, never by the package).
     Up-to-date check = content hash of the sources (file times do not survive the copy to a GPU box).  Each source is
     compiled to its own object (cached under lib/obj by content hash of the source + headers, compiled in parallel),
     then linked."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = sources()
-    stamp = LIB_PATH + '.srchash'
+    lib_path = LAB_LIB_PATH if lab else LIB_PATH
+    stamp = lib_path + '.srchash'
     digest = _source_hash()
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp):
+    if not force and os.path.exists(lib_path) and os.path.exists(stamp):
         with open(stamp) as f:
             if f.read().strip() == digest:
-                return LIB_PATH
-    obj_dir = os.path.join(LIB_DIR, 'obj')
+                return lib_path
+    obj_dir = os.path.join(LIB_DIR, 'obj_lab' if lab else 'obj')
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     headers = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + sorted(glob.glob(os.path.join(INCLUDE, '*.h')))
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC]
+    if lab:
+        flags.append('-DDSGCN_LAB')
     jobs, objs = [], []
     for src in srcs:
         base = os.path.splitext(os.path.basename(src))[0]
@@ -133,10 +145,10 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         list(pool.map(run, jobs))
-    run([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB_PATH] + objs)
+    run([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', lib_path] + objs)
     with open(stamp, 'w') as f:
         f.write(digest)
-    return LIB_PATH
+    return lib_path
 
 
 def lib():
@@ -153,6 +165,19 @@ def lib():
             fn.restype = ctypes.c_int
         _lib = handle
     return _lib
+
+
+def lab_lib():
+    """``libdsgcn_lab.so`` (product + measurement-only entry points), built on first use.  tools/ only."""
+    global _lab
+    if _lab is None:
+        handle = ctypes.CDLL(build(lab=True))
+        for name, argtypes in {**SIGNATURES, **LAB_SIGNATURES}.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lab = handle
+    return _lab
 
 
 class DsgcnError(RuntimeError):

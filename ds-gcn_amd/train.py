@@ -36,11 +36,41 @@ class FlatSGD:
         self.flat.zero_grad()
 
     def state_dict(self):
-        return dict(lr=self.lr, momentum_buffer=None if self.buf is None else self.buf.clone())
+        """torch.optim.SGD's layout — ``{'state': {i: {'momentum_buffer': tensor}}, 'param_groups': [{...}]}`` with one
+        entry per parameter tensor in ``module.parameters()`` order — so the ``optimizer`` entry of a checkpoint is
+        interchangeable with the reference's (mmcv saves ``optimizer.state_dict()`` of a torch SGD).  CPU tensors."""
+        state = {}
+        if self.buf is not None:
+            for i, (p, (off, n)) in enumerate(zip(self.flat.params, self.flat.slices)):
+                state[i] = {'momentum_buffer': self.buf[off:off + n].view(p.shape).detach().cpu().clone()}
+        group = dict(lr=self.lr, momentum=self.momentum, dampening=0, weight_decay=self.weight_decay,
+                     nesterov=self.nesterov, maximize=False, foreach=None, differentiable=False, fused=None,
+                     initial_lr=self.base_lr, params=list(range(len(self.flat.params))))
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        self.lr = sd['lr']
-        self.buf = sd['momentum_buffer']
+        """Accepts the torch SGD layout (this class's own checkpoints and the reference's)."""
+        groups = sd['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.flat.params):
+            raise ValueError('FlatSGD.load_state_dict: expected one param group over '
+                             f'{len(self.flat.params)} tensors, got {[len(g["params"]) for g in groups]}')
+        g = groups[0]
+        self.lr = g['lr']
+        self.base_lr = g.get('initial_lr', self.base_lr)
+        self.momentum = g.get('momentum', self.momentum)
+        self.weight_decay = g.get('weight_decay', self.weight_decay)
+        self.nesterov = g.get('nesterov', self.nesterov)
+        state = sd.get('state', {})
+        if not state:
+            self.buf = None
+            return
+        buf = torch.zeros_like(self.flat.flat_p)
+        for i, pid in enumerate(g['params']):
+            mb = state.get(pid, state.get(str(pid), {})).get('momentum_buffer')
+            if mb is not None:
+                off, n = self.flat.slices[i]
+                buf[off:off + n].copy_(mb.reshape(-1))
+        self.buf = buf
 
 
 def cosine_lr(base_lr, it, total_iters, min_lr=0.0):

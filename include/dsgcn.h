@@ -35,17 +35,6 @@ int dsgcn_version(void);
 int dsgcn_aggregate_fwd(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
                         float* y, int n, int KC, int T, int V, void* stream);
 
-/* A/B measurement only: the first (scalar-cache + VALU) formulation of the same product. */
-int dsgcn_aggregate_fwd_valu(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
-                             float* y, int n, int KC, int T, int V, void* stream);
-
-/* A/B measurement only: variant 0 = product path, 1 = scalar-cache/VALU, 2 = one-shot MFMA. */
-int dsgcn_aggregate_fwd_variant(const float* zp, const float* scale, const float* shift, int relu,
-                                const float* ahat, float* y, int n, int KC, int T, int V, int variant, void* stream);
-
-/* Tuning knobs (key 0: persistent waves of K-A forward; 0 = default). */
-int dsgcn_set_tuning(int key, int value);
-
 /* Backward of the above: dzp (n,KC,T,V), dahat (n,KC,V,V) and partial (n*KC,2) =
  * per-unit [sum dP*mask*zp, sum dP*mask] (the d scale / d shift reductions before the sum over n). */
 /* rows of dsgcn_aggregate_bwd's `partial` buffer (rows, KC, 2): n, or 2n when a unit is split over two waves */
@@ -112,7 +101,6 @@ int dsgcn_tms_combine_fwd(const float* o, const float* coeff, float* f, float* p
 int dsgcn_tms_combine_bwd(const float* o, const float* coeff, const float* gf, const float* A0, const float* B0,
                           float* dout, float* pcoef, int n, int C, int T, int V, void* stream);
 int dsgcn_pwconv_ipart_rows(int n, int Ci, int Co, int T, int V, int stride);
-int dsgcn_diag_mfma_probe(float* out, int blocks, int iters, int nacc, void* stream);
 
 /* ---- K-C: 1x1 channel mix with fused train-mode BatchNorm / ReLU / residual --------------------------------
  * Replaces Conv2d(1x1)+BatchNorm2d+ReLU(+add) chains of gcn.py:2165-2169,2209-2215,2236,2363-2365 and
@@ -123,8 +111,6 @@ int dsgcn_diag_mfma_probe(float* out, int blocks, int iters, int nacc, void* str
 int dsgcn_pwconv_plan(int Tout, int V, int aug, int* TR, int* NPpad, int* nblk_per_sample);
 /* rows of the forward's `partial` buffer: (rows, Co, 2) */
 int dsgcn_pwconv_partial_rows(int n, int Ci, int Co, int T, int V, int stride, int aug);
-/* tuning / ablation knobs used by tools/ (key 0: ablation mask, key 1: max 32-channel tiles per block) */
-int dsgcn_pwconv_tuning(int key, int value);
 int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                      const float* h2, int relu, const float* w, const float* bias, float* z, float* zaug,
                      float* partial, int n, int Ci, int Co, int T, int V, int stride, int aug, int stats,
@@ -173,7 +159,6 @@ int dsgcn_aggsum_partial_rows(int n, int T, int V);
  * 0 -> per-(n,c) pieces through the d_* strides; either way dA = column sum over the pieces */
 int dsgcn_aggsum_bwd_piece_rows(int n, int K, int Co, int T, int V);
 /* tuning / A-B knobs used by tools/ (0: pipelined kernels on/off, 1: forward waves, 2: backward workgroups) */
-int dsgcn_aggsum_tuning(int key, int value);
 int dsgcn_aggsum_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long a_cs, float* y, float* partial,
                      int n, int K, int Co, int T, int V, void* stream);
 int dsgcn_aggsum_bwd(const float* p, const float* ahat, long a_ns, long a_ks, long a_cs, const float* gy,

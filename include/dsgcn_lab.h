@@ -1,0 +1,33 @@
+/* libdsgcn_lab — measurement-only entry points (tools/): A/B variants of superseded kernels, launch-geometry knobs and
+ * a raw MFMA issue-rate probe.  NOT part of the product ABI: ``libdsgcn.so`` does not export these; they exist only in
+ * ``libdsgcn_lab.so``, the same sources compiled with -DDSGCN_LAB (``dsgcn_amd.native.build(lab=True)``). */
+#ifndef DSGCN_LAB_H_
+#define DSGCN_LAB_H_
+#include "dsgcn.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A/B measurement only: the first (scalar-cache + VALU) formulation of the same product. */
+int dsgcn_aggregate_fwd_valu(const float* zp, const float* scale, const float* shift, int relu, const float* ahat,
+                             float* y, int n, int KC, int T, int V, void* stream);
+
+/* A/B measurement only: variant 0 = product path, 1 = scalar-cache/VALU, 2 = one-shot MFMA. */
+int dsgcn_aggregate_fwd_variant(const float* zp, const float* scale, const float* shift, int relu,
+                                const float* ahat, float* y, int n, int KC, int T, int V, int variant, void* stream);
+
+/* Tuning knobs (key 0: persistent waves of K-A forward; 0 = default). */
+int dsgcn_set_tuning(int key, int value);
+
+int dsgcn_diag_mfma_probe(float* out, int blocks, int iters, int nacc, void* stream);
+
+/* tuning / ablation knobs used by tools/ (key 0: ablation mask, key 1: max 32-channel tiles per block) */
+int dsgcn_pwconv_tuning(int key, int value);
+
+/* launch-geometry knobs of K-A' (key 0: pipelined kernels on/off, 1: forward waves, 2: backward workgroups) */
+int dsgcn_aggsum_tuning(int key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

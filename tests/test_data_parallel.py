@@ -38,23 +38,34 @@ def batch_for(rank):
     return dict(keypoint=torch.randn(2, 1, 2, 8, 25, 3, generator=g), label=torch.randint(0, 7, (2, 1), generator=g))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, gather):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(1)
     model = make_model(seed=7 + rank)           # different init per rank: the param broadcast must fix it
-    flat = D.FlatParams(model)
+    flat = D.FlatParams(model, gather=gather)
     dp = D.FlatDataParallel(flat)
     opt = D.FlatSGD(flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
     with D.kernels.use_ops(torch_ops):
         for _ in range(2):
             opt.zero_grad()
-            out = model.train_step(batch_for(rank), None)
-            out['loss'].backward()
+            if gather:      # the bench's step: no collective inside train_step, gradients packed after backward
+                out = model.train_step(batch_for(rank), None, sync_log_vars=False)
+                assert all(torch.is_tensor(v) for v in out['log_vars'].values())
+                out['loss'].backward()
+                flat.collect_grads()
+                log = D.reduce_log_vars(out['log_vars'])
+            else:
+                out = model.train_step(batch_for(rank), None)
+                out['loss'].backward()
+                log = out['log_vars']
             dp.allreduce_grads()
             opt.step()
     assert flat.check_views()
-    torch.save(dict(p=flat.flat_p.clone(), g=flat.flat_g.clone(), log=out['log_vars']), os.path.join(out_dir, f'r{rank}.pt'))
+    # inference results come back in dataset order on every rank (rank r holds samples r, r+world, ...)
+    part = [f'sample{i}' for i in range(rank, 5 + (5 % world and world - 5 % world), world)]
+    assert D.gather_results(part, 5) == [f'sample{i}' for i in range(5)]
+    torch.save(dict(p=flat.flat_p.clone(), g=flat.flat_g.clone(), log=log), os.path.join(out_dir, f'r{rank}.pt'))
     dist.destroy_process_group()
 
 
@@ -66,9 +77,10 @@ def _free_port():
     return port
 
 
-def test_two_rank_dp_equals_microbatch_average(tmp_path):
+@pytest.mark.parametrize('gather', [False, True])
+def test_two_rank_dp_equals_microbatch_average(tmp_path, gather):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), gather), nprocs=world, join=True)
     r0, r1 = [torch.load(tmp_path / f'r{r}.pt') for r in range(world)]
     assert torch.equal(r0['p'], r1['p'])                    # replicas stay bit-identical
     assert torch.equal(r0['g'], r1['g'])

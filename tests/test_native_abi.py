@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 from dsgcn_amd import native
 
@@ -23,6 +24,13 @@ def test_library_builds_and_exports_header_symbols():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/dsgcn.h but not exported'
     assert native.lib().dsgcn_version() >= 100
+    # the product library exports exactly the header: no measurement-only entry points (those live in
+    # libdsgcn_lab.so, include/dsgcn_lab.h) and no internal cross-file helpers
+    out = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r' T (dsgcn_\w+)', out)))
+    assert exported == names, (set(exported) ^ set(names))
+    for n in native.LAB_SIGNATURES:
+        assert not hasattr(lib, n), f'{n} is a lab entry point and must not be in the product ABI'
 
 
 def test_python_binding_covers_header():

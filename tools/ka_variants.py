@@ -5,7 +5,7 @@ import torch
 import bench
 from dsgcn_amd import native
 
-lib = native.lib()
+lib = native.lab_lib()
 dev = torch.device('cuda')
 st = torch.cuda.current_stream().cuda_stream
 V = 25

@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dsgcn_amd import native
-lib = native.lib(); st = torch.cuda.current_stream().cuda_stream
+lib = native.lab_lib(); st = torch.cuda.current_stream().cuda_stream
 out = torch.empty(4096 * 256, device='cuda')
 for blocks in (256, 512, 1024):
     for nacc in (1, 2, 4):
