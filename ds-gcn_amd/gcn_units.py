@@ -212,7 +212,9 @@ class dgphgcn1(nn.Module):
         return Deferred(zo, ao, zd, ad, True)
 
     def forward(self, x, A=None):
-        return self.forward_deferred(x).materialize()
+        out = self.forward_deferred(x).materialize()
+        flush_running_stats()          # standalone use: running statistics move with the call, as in F.batch_norm
+        return out
 
     def init_weights(self):
         for m in self.modules():
@@ -269,7 +271,9 @@ class unit_gcn(nn.Module):
     def forward(self, x, A=None):
         if A is not None:
             raise NotImplementedError('passing A at call time (reference quirk Q9) is not supported')
-        return self.forward_deferred(x).materialize()
+        out = self.forward_deferred(x).materialize()
+        flush_running_stats()
+        return out
 
     def init_weights(self):
         pass
@@ -350,7 +354,9 @@ class unit_ctrgcn(nn.Module):
         return Deferred(y, ay, zd, ad, True)
 
     def forward(self, x):
-        return self.forward_deferred(x).materialize()
+        out = self.forward_deferred(x).materialize()
+        flush_running_stats()
+        return out
 
     def init_weights(self):
         _kaiming_conv_init(self)

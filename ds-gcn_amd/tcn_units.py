@@ -11,8 +11,8 @@ import torch
 import torch.nn as nn
 
 from . import kernels
-from .gcn_units import (Deferred, as_deferred, conv_bn, eval_affine, op_bn, record_running, _need_stats,
-                        _norm_layer)
+from .gcn_units import (Deferred, as_deferred, conv_bn, eval_affine, flush_running_stats, op_bn, record_running,
+                        _need_stats, _norm_layer)
 
 
 class unit_tcn(nn.Module):
@@ -52,6 +52,7 @@ class unit_tcn(nn.Module):
 
     def forward(self, x):
         out = self.forward_deferred(x).materialize()
+        flush_running_stats()
         return self.drop(out) if self.drop.p > 0 else out
 
     def init_weights(self):
@@ -165,6 +166,7 @@ class dgmstcn(nn.Module):
 
     def forward(self, x):
         out = self.forward_deferred(x).materialize()
+        flush_running_stats()
         return self.drop(out) if self.drop.p > 0 else out
 
     def init_weights(self):
@@ -319,6 +321,7 @@ class MSTCN(nn.Module):
             r = self.residual.forward_deferred(x)
             x2, a2 = r.x1, r.a1
         out = kernels.ops().fuse_out(o, a, x2, a2, True, False)[0]
+        flush_running_stats()
         return self.drop(out) if self.drop.p > 0 else out
 
     def init_weights(self):

@@ -9,7 +9,7 @@ for the hot path, written from the math in SURVEY.md Appendix A and functional o
 ``state_dict`` with the reference's key names.  Each function cites the
 reference lines it restates (paths relative to the reference root).
 
-Parity pin: ``tests/test_oracle_vs_reference.py`` checks every function here against the
+Parity pin: ``tests/test_oracle_golden.py`` (``*_live`` tests) checks every unit here against the
 imported reference in the build container (skipped where /root/reference is absent), and
 ``tests/golden/*.npz`` (written by ``tests/golden/gen_golden.py`` from the imported
 reference) pin it on the GPU box.  The reference itself ships no tests/golden vectors

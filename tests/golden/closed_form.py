@@ -37,3 +37,89 @@ def counter_input(N, T, V, classes):
     x = (torch.sin(0.0137 * i) + 0.3 * torch.cos(0.00071 * i * i % 6.283185307179586)).reshape(N, 1, 2, T, V, 3).float()
     y = (torch.arange(N) * 7 % classes).reshape(N, 1)
     return x, y
+
+
+def liven32(module, seed):
+    """alpha / beta / add_coeff ~ N(0, 0.5^2) from a seeded generator (zero-init would switch the dynamic-adjacency
+    and global-joint paths off): the bench's and the round-2 fixtures' way of making a default-initialised model live."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            if k.endswith(('alpha', 'beta', 'add_coeff')):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+
+
+def fill_running(module):
+    """RNG-free BatchNorm running statistics (eval-mode fixtures): mean 0.05*sin, var 1 + 0.25*sin, phase by key."""
+    import zlib
+    with torch.no_grad():
+        for k, v in module.state_dict().items():
+            if not k.endswith(('running_mean', 'running_var')):
+                continue
+            i = torch.arange(v.numel(), dtype=torch.float64)
+            phase = (zlib.crc32(k.encode()) % 1000) / 1000.0 * 6.283185307179586
+            wave = torch.sin(0.37 * i + phase).reshape(v.shape)
+            v.copy_((1.0 + 0.25 * wave if k.endswith('running_var') else 0.05 * wave).to(v.dtype))
+
+
+def counter_clips(N, clips, T, V):
+    """(N, clips, 2, T, V, 3) test-time input (several views per sample), closed form."""
+    i = torch.arange(N * clips * 2 * T * V * 3, dtype=torch.float64)
+    x = torch.sin(0.0211 * i) + 0.3 * torch.cos(0.00053 * i * i % 6.283185307179586)
+    return x.reshape(N, clips, 2, T, V, 3).float()
+
+
+def pick_tensors(named_numels, count=12, max_numel=70000):
+    """A fixed, name-ordered selection of `count` gradient tensors (each <= max_numel elements) spread over the
+    parameter list — the tensors whose full fp64 gradients the full-size fixtures store."""
+    names = [k for k, n in named_numels if n <= max_numel]
+    if len(names) <= count:
+        return names
+    idx = sorted({round(j * (len(names) - 1) / (count - 1)) for j in range(count)})
+    return [names[i] for i in idx]
+
+
+UNIT_CASES = {       # tag -> (class name, ctor args after the graph, input shape): the same call builds the reference's
+    'gcn': ('unit_gcn', dict(in_channels=64, out_channels=128, adaptive='init'), (2, 64, 8, 25)),           # unit and ours
+    'gcn_res': ('unit_gcn', dict(in_channels=64, out_channels=128, adaptive='init', with_res=True), (2, 64, 8, 25)),
+    'tcn9': ('unit_tcn', dict(in_channels=64, out_channels=64, kernel_size=9, stride=1), (2, 64, 8, 25)),
+    'tcn1s2': ('unit_tcn', dict(in_channels=64, out_channels=128, kernel_size=1, stride=2), (2, 64, 8, 25)),
+    'ctrgcn': ('unit_ctrgcn', dict(in_channels=64, out_channels=128), (2, 64, 8, 25)),
+    'MSTCN': ('MSTCN', dict(in_channels=64, out_channels=64, kernel_size=5, stride=1, dilations=[1, 2], residual=False),
+              (2, 64, 8, 25)),
+    'MSTCNs2': ('MSTCN', dict(in_channels=64, out_channels=128, kernel_size=5, stride=2, dilations=[1, 2], residual=True),
+                (2, 64, 8, 25)),
+}
+
+
+def make_unit(ns, tag, A):
+    """Build unit `tag` from namespace `ns` (the reference's gcns.utils or this package) with seeded default init,
+    live alpha/beta and BatchNorm affines away from (1, 0); -> (module fp32, input fp32, cotangent R fp32)."""
+    idx = list(UNIT_CASES).index(tag)
+    cls, kw, shape = UNIT_CASES[tag]
+    kw = dict(kw)
+    if cls in ('unit_gcn', 'unit_ctrgcn'):
+        kw['A'] = A.clone()
+    torch.manual_seed(300 + idx)
+    m = getattr(ns, cls)(**kw)
+    liven32(m, 40 + idx)
+    g = torch.Generator().manual_seed(50 + idx)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
+                mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.2)
+    x = torch.randn(*shape, generator=g)
+    stride = kw.get('stride', 1)
+    yshape = (shape[0], kw['out_channels'], (shape[2] + stride - 1) // stride, shape[3])
+    Rm = torch.randn(*yshape, generator=g)
+    return m.train(), x, Rm
+
+
+def sd_digest(module):
+    import hashlib
+    h = hashlib.sha256()
+    for k, v in module.state_dict().items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().numpy().tobytes())
+    return h.hexdigest()

@@ -2,7 +2,7 @@
 
 Build-container only: the GPU box has no /root/reference.  Used by
 ``tests/golden/gen_golden.py`` (fixture generation) and by the optional
-``tests/test_oracle_vs_reference.py`` (skipped when the reference is absent).
+the ``*_live`` tests of ``tests/test_oracle_golden.py`` (skipped when the reference is absent).
 
 Nothing from the reference is copied: the real modules are imported in place
 (``sys.dont_write_bytecode`` so no __pycache__ lands in the read-only tree).

@@ -1,5 +1,6 @@
 """-m gpu: every HIP op through the C ABI vs the plain-PyTorch statement of the same op
 (tests/torch_ops.py) evaluated in fp64 on the same inputs.  Tolerances are written per test."""
+import numpy as np
 import pytest
 import torch
 
@@ -13,7 +14,8 @@ DEV = 'cuda'
 
 
 def rel(a, b):
-    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
 def maxabs(a, b):
@@ -399,3 +401,70 @@ def test_colsum(R, C):
     """Column sums incl. the folded two-stage path for tall, narrow inputs (fp64 accumulation: 1e-6 relative)."""
     t = torch.randn(R, C)
     assert rel(K_.colsum(t.cuda()).cpu(), t.double().sum(0)) < 1e-6
+
+
+
+@pytest.mark.parametrize('tag,layout,ci,co', [('v25', 'nturgb+d', 64, 64), ('v17', 'coco', 64, 128)])
+def test_dgphgcn1_kernels_vs_reference_intermediates(tag, layout, ci, co):
+    """K-B and K-A against the intermediates the REFERENCE computed inside dgphgcn1.forward (captured from its own
+    einsum / conv calls, tests/golden/unit_intermediates.npz): the time mean, the dynamic adjacency Ahat, the aggregate
+    Y = P x Ahat, and the unit output."""
+    import dsgcn_amd as D
+    from test_oracle_golden import load, sd_of
+    z = load('unit_intermediates.npz')
+    A = torch.from_numpy(z[f'{tag}_sd_A'])
+    m = D.dgphgcn1(ci, co, A, torch.from_numpy(z[f'{tag}_edge_type']).float(), torch.from_numpy(z[f'{tag}_node_type']),
+                   ratio=0.125, decompose=True, node_attention=True, edge_attention=True, subset_wise=True, ctr='T',
+                   ada='T')
+    m.load_state_dict(sd_of({k[len(tag) + 1:]: v for k, v in z.items() if k.startswith(tag + '_')}, 'sd_', torch.float32))
+    m = m.cuda().train()
+    x = torch.from_numpy(z[f'{tag}_x']).cuda()
+    xbar = K.tmean(x)
+    assert rel(xbar.cpu(), z[f'{tag}_xbar']) < 1e-6
+    with torch.no_grad():
+        ahat = m.adjacency(xbar)                                  # (n, K*mid, V, V)
+    want = torch.from_numpy(z[f'{tag}_Ahat'])
+    assert rel(ahat.cpu().reshape(want.shape), want) < 3e-6       # tanh / exp in fp32
+    P = torch.from_numpy(z[f'{tag}_P']).cuda()                    # (n, K, mid, T, V): after pre's BN + ReLU
+    n, Kk, mid, T, V = P.shape
+    y = K.aggregate(P.reshape(n, Kk * mid, T, V), None, False, want.cuda().reshape(n, Kk * mid, V, V))
+    assert rel(y.cpu().reshape(z[f'{tag}_Y'].shape), z[f'{tag}_Y']) < 2e-6
+    with torch.no_grad():
+        out = m(x)
+    assert rel(out.cpu(), z[f'{tag}_out']) < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'MSTCNs2'])
+def test_units_vs_reference_fixture(tag):
+    """unit_gcn, unit_tcn (k=9 dense; k=1 stride 2), unit_ctrgcn / CTRGC and MSTCN at real widths on the HIP path
+    against the REFERENCE's output, input gradient, parameter gradients and running statistics (fp64 run;
+    tests/golden/unit_others.npz).  The seeded weights are rebuilt here and their digest compared with the fixture's."""
+    import sys
+    import dsgcn_amd as D
+    from test_oracle_golden import GOLD, load
+    from oracle import dsgcn_oracle as O
+    sys.path.insert(0, GOLD)
+    from closed_form import make_unit, sd_digest
+    z = load('unit_others.npz')
+    A = torch.tensor(O.graph_A('nturgb+d', 'spatial'), dtype=torch.float32)
+    m, x, Rm = make_unit(D, tag, A)
+    assert sd_digest(m) == str(z[f'{tag}_digest'])
+    m = m.cuda().train()
+    x = x.cuda().requires_grad_()
+    y = m(x)
+    (y * Rm.cuda()).sum().backward()
+    assert rel(y.detach().cpu(), z[f'{tag}_y']) < 1e-5
+    assert rel(x.grad.cpu(), z[f'{tag}_dx']) < 5e-5
+    gmax = max(float(np.abs(z[k]).max()) for k in z if k.startswith(f'{tag}_grad_'))
+    for k, p in m.named_parameters():
+        if f'{tag}_grad_{k}' in z:
+            want = z[f'{tag}_grad_{k}']
+            if np.abs(want).max() < 1e-9:      # analytically zero (a conv bias feeding BatchNorm): fp32 cancellation noise
+                assert p.grad is None or float(p.grad.abs().max()) < 2e-4 * gmax, k
+            else:
+                assert rel(p.grad.cpu(), want) < 1e-4, (k, rel(p.grad.cpu(), want))
+        elif f'{tag}_gnorm_{k}' in z:
+            assert abs(float(p.grad.double().norm()) - float(z[f'{tag}_gnorm_{k}'])) < 1e-4 * float(z[f'{tag}_gnorm_{k}']), k
+    for k, v in m.state_dict().items():
+        if 'running' in k:
+            assert rel(v.cpu(), z[f'{tag}_{k}']) < 1e-5, k

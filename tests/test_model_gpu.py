@@ -52,9 +52,10 @@ def test_reduced_model_vs_golden(name):
     assert (num / den) ** .5 < 2e-4, (num / den) ** .5        # whole-gradient relative L2 vs fp64 truth
 
 
-@pytest.mark.parametrize('layout,V,T,classes', [('nturgb+d', 25, 64, 60), ('coco', 17, 100, 400)])
+@pytest.mark.parametrize('layout,V,T,classes', [('nturgb+d', 25, 64, 60), ('nturgb+d', 25, 64, 120), ('coco', 17, 100, 400)])
 def test_full_model_vs_oracle(layout, V, T, classes):
-    """Full-width DS-STGCN (configs 2/3 and the K400 V=17,T=100 variant), 2 clips, against the CPU oracle."""
+    """Full-width DS-STGCN — BASELINE config 2 (NTU-60), config 3 (NTU-120, 120 classes) and config 5 (K400, V=17,
+    T=100, 400 classes) — 2 clips, against the CPU oracle."""
     np.random.seed(0)
     torch.manual_seed(0)
     m = D.build_model(ds_cfg(classes, layout))
@@ -206,32 +207,101 @@ def test_gradient_packing_modes_agree():
     assert rel(flats[1].cpu(), flats[0].cpu()) < 1e-6
 
 
-def test_running_stats_and_eval_mode():
-    z = load('model_reduced.npz')
-    with open(os.path.join(GOLD, 'model_reduced_cfg.json')) as f:
-        cfg = json.load(f)
-    cfg['backbone']['tcn_ms_cfg'] = [tuple(c) if isinstance(c, list) else c for c in cfg['backbone']['tcn_ms_cfg']]
+R2_CONFIGS = {
+    'dsstgcn_ntu60': (lambda: ds_cfg(60), 64, 25), 'dsstgcn_ntu120': (lambda: ds_cfg(120), 64, 25),
+    'dsstgcn_k400_coco': (lambda: ds_cfg(400, 'coco'), 100, 17), 'ctrgcn_ntu60': (lambda: other_cfg('ctrgcn'), 64, 25),
+    'stgcn_ntu60': (lambda: other_cfg('stgcn'), 64, 25), 'stgcnpp_ntu60': (lambda: other_cfg('stgcnpp'), 64, 25)}
+
+
+def _r2_model(name):
+    import sys
+    sys.path.insert(0, GOLD)
+    from closed_form import liven32
+    mk, T, V = R2_CONFIGS[name]
+    cfg = mk()
+    np.random.seed(0)
+    torch.manual_seed(0)
     m = D.build_model(cfg)
-    m.load_state_dict(sd_of(z, 'sd_', torch.float32))
-    ref = D.build_model(cfg)
-    ref.load_state_dict(sd_of(z, 'sd_', torch.float32))
-    x, y = torch.from_numpy(z['x']), torch.from_numpy(z['label'])
-    import torch_ops
-    with D.kernels.use_ops(torch_ops):              # CPU statement of the same wiring (itself checked against the reference)
-        ref.train()
-        ref(keypoint=x, label=y, return_loss=True)
-        ref.eval()
-        with torch.no_grad():
-            want = ref(keypoint=x, return_loss=False)
+    liven32(m, 1)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0                                       # vanilla ST-GCN's Dropout(0.5): off on both sides
+    return m, cfg, T, V
+
+
+@pytest.mark.parametrize('name', list(R2_CONFIGS))
+def test_full_width_gradients_vs_reference_fixture(name):
+    """Full-width models of every BASELINE config (1: ST-GCN, 2: DS-STGCN NTU-60, 3: NTU-120, 4: CTR-GCN, 5: K400/coco)
+    and ST-GCN++, DEFAULT init + live alpha/beta/add_coeff, closed-form input, train mode: logits, loss, the FULL
+    gradients of a fixed selection of tensors and the BatchNorm running statistics against what the REFERENCE produced
+    (tests/golden/full_grads_*.npz; fp64 run = truth, its fp32 run = yardstick)."""
+    from closed_form import counter_input
+    m, cfg, T, V = _r2_model(name)
+    classes = cfg['cls_head']['num_classes']
+    z = load(f'full_grads_{name}.npz')
+    x, y = counter_input(2, T, V, classes)
     m = m.cuda().train()
-    m(keypoint=x.cuda(), label=y.cuda(), return_loss=True)
-    for (k, a), (_, b) in zip(m.state_dict().items(), ref.state_dict().items()):
-        if 'running' in k or 'num_batches' in k:
-            assert torch.allclose(a.cpu().double(), b.double(), rtol=1e-4, atol=1e-6), k
-    m.eval()
+    logits = m.cls_head(m.extract_feat(x.cuda()[:, 0]))
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda().squeeze(-1))
+    loss.backward()
+    ref_err = rel(z['logits32'], z['logits64'])
+    assert rel(logits.detach().cpu(), z['logits64']) < max(2 * ref_err, 1e-4)          # north_star bar
+    assert abs(loss.item() - float(z['loss64'])) / abs(float(z['loss64'])) < 1e-4
+    names = json.loads(str(z['names']))
+    params = dict(m.named_parameters())
+    num = den = 0.0
+    for i, k in enumerate(names):
+        g64 = z[f'g64_{i}'].astype(np.float64)
+        num += float(((params[k].grad.double().cpu().numpy() - g64) ** 2).sum())
+        den += float((g64 ** 2).sum())
+    ours, theirs, noise = (num / den) ** .5, float(z['gerr32_set']), float(z['gnoise32_set'])
+    # Whole-selection relative L2 against the fp64 truth.  Yardstick: these 2-clip cases are ill-conditioned (train-mode
+    # BN over 4 person-samples, ReLU / max-pool decisions): the reference's own fp32 gradient is 0.04-0.7 % off fp64
+    # (gerr32_set) and moves by the same amount when its input is perturbed at the 2e-7 level (gnoise32_set: the
+    # amplification is ~1e3-3e4, so that is the floor for ANY fp32 evaluation order).  The deferred-BN form
+    # (z*scale + shift instead of (z-mean)*rstd*gamma + beta) perturbs activations ~2x more than the reference's
+    # arithmetic (logits 3e-7 vs 1.3e-7 from fp64), hence the factor: within 4x the reference's noise floor.
+    assert ours < max(4 * max(theirs, noise), 1e-4), (ours, theirs, noise)
+    sd = m.state_dict()
+    for i, k in enumerate(json.loads(str(z['running_names']))):
+        assert rel(sd[k].cpu(), z[f'running_{i}']) < 1e-4, k                             # F.batch_norm's running update
+
+
+@pytest.mark.parametrize('name', list(R2_CONFIGS))
+def test_eval_mode_vs_reference_fixture(name):
+    """Inference path (f-2): eval-mode BatchNorm from running statistics, 2 samples x 10 clips, scores averaged as
+    probabilities (recognizergcn.py:53-107), against the REFERENCE's forward_test output and per-clip class scores."""
+    from closed_form import counter_clips, fill_running
+    m, cfg, T, V = _r2_model(name)
+    fill_running(m)
+    z = load(f'eval_{name}.npz')
+    x = counter_clips(2, 10, T, V).cuda()
+    m = m.cuda().eval()
+    probs = m(keypoint=x, return_loss=False)
+    assert isinstance(probs, np.ndarray) and probs.shape == z['probs64'].shape
+    assert rel(probs, z['probs64']) < 1e-5
     with torch.no_grad():
-        got = m(keypoint=x.cuda(), return_loss=False)
-    assert np.abs(got - want).max() < 1e-5
+        scores = m.cls_head(m.extract_feat(x.flatten(0, 1))).reshape(2, 10, -1)
+    assert rel(scores.cpu(), z['scores64_clips']) < 1e-4
+
+
+def test_config5_batch_properties():
+    """BASELINE config 5 at its per-GPU size (32 clips of 2 x 100 x 17 x 3, 400 classes): finite loss and gradients,
+    clip-permutation equivariance of the logits (train-mode statistics are permutation invariant), T > 64 K-A path."""
+    m, cfg, T, V = _r2_model('dsstgcn_k400_coco')
+    m = m.cuda().train()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(32, 1, 2, T, V, 3, generator=g).cuda()
+    y = torch.randint(0, 400, (32, 1), generator=g).cuda()
+    out = m.train_step(dict(keypoint=x, label=y), None)
+    out['loss'].backward()
+    assert np.isfinite(out['log_vars']['loss'])
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    perm = torch.randperm(32, generator=g).cuda()
+    with torch.no_grad():
+        l0 = m.cls_head(m.extract_feat(x[:, 0]))
+        l1 = m.cls_head(m.extract_feat(x[perm][:, 0]))
+    assert rel(l1.cpu(), l0[perm].cpu()) < 1e-5
 
 
 def test_full_size_properties():

@@ -161,3 +161,127 @@ def test_oracle_vs_reference_live():
     gc = O.graph_constants('coco')
     sd = {k: v.detach() for k, v in m.state_dict().items()}
     assert (m(x) - O.dgphgcn1_forward(x, sd, gc['node_type'], gc['edge_type'])).abs().max().item() < 1e-12
+
+
+# ---- round-2 fixtures (tests/golden/gen_golden_r2.py) ------------------------------------------------------------
+
+@pytest.mark.parametrize('tag,layout', [('v25', 'nturgb+d'), ('v17', 'coco')])
+def test_dgphgcn1_intermediates(tag, layout):
+    """Every intermediate of the reference's dgphgcn1 forward (captured from its own einsum / conv calls): xbar, x1,
+    x2, tanh(D), softmax(G), Ahat, P, Y, output — the oracle reproduces each one, not only the unit's output."""
+    z = load('unit_intermediates.npz')
+    sd = sd_of({k[len(tag) + 1:]: v for k, v in z.items() if k.startswith(tag + '_')}, 'sd_')
+    x = torch.from_numpy(z[tag + '_x']).double()
+    gc = O.graph_constants(layout)
+    assert np.array_equal(np.asarray(gc['node_type']), z[tag + '_node_type'])
+    assert np.array_equal(np.asarray(gc['edge_type']), z[tag + '_edge_type'])
+    y, p = O.dgphgcn1_forward(x, sd, gc['node_type'], gc['edge_type'], ret_parts=True)
+    got = dict(xbar=p['xbar'], x1=p['x1'], x2=p['x2'], tanhD=torch.tanh(p['D']), softG=p['Sm'], Ahat=p['Ahat'], P=p['P'],
+               Y=p['Y'], out=y)
+    for k, v in got.items():
+        assert rel(v, z[f'{tag}_{k}']) < 2e-6, (k, rel(v, z[f'{tag}_{k}']))      # fixtures are stored as fp32
+
+
+def _unit_oracle(tag, x, sd):
+    if tag in ('gcn', 'gcn_res'):
+        return O.unit_gcn_forward(x, sd, with_res=(tag == 'gcn_res'))
+    if tag == 'tcn9':
+        return O.unit_tcn_forward(x, sd, 9, 1)
+    if tag == 'tcn1s2':
+        return O.unit_tcn_forward(x, sd, 1, 2)
+    if tag == 'ctrgcn':
+        return O.unit_ctrgcn_forward(x, sd)
+    if tag == 'MSTCN':
+        return O.mstcn_msg3d_forward(x, sd, 1, 5, (1, 2))
+    raise KeyError(tag)
+
+
+@pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN'])
+def test_other_units_vs_reference_fixture(tag):
+    """unit_gcn, unit_tcn (k=9; k=1 stride 2), unit_ctrgcn, MSTCN at real widths: oracle output and input gradient
+    against the reference's (weights rebuilt from the shared seeded recipe; their digest is part of the fixture)."""
+    import sys
+    sys.path.insert(0, GOLD)
+    from closed_form import make_unit, sd_digest
+    import dsgcn_amd as D
+    z = load('unit_others.npz')
+    A = torch.tensor(O.graph_A('nturgb+d', 'spatial'), dtype=torch.float32)
+    m, x, Rm = make_unit(D, tag, A)
+    assert sd_digest(m) == str(z[f'{tag}_digest']), 'seeded unit weights differ from the reference build'
+    sd = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in m.state_dict().items()}
+    x = x.double().requires_grad_()
+    y = _unit_oracle(tag, x, sd)
+    (y * Rm.double()).sum().backward()
+    assert rel(y.detach(), z[f'{tag}_y']) < 2e-6
+    assert rel(x.grad, z[f'{tag}_dx']) < 2e-6
+
+
+@pytest.mark.parametrize('name,kind,T,V,classes,layout', [
+    ('dsstgcn_ntu60', 'ds', 64, 25, 60, 'nturgb+d'), ('stgcnpp_ntu60', 'stgcnpp', 64, 25, 60, 'nturgb+d')])
+def test_eval_fixture_oracle(name, kind, T, V, classes, layout):
+    """Eval-mode (running statistics) test-time scores of the reference, 2 samples x 10 clips averaged as
+    probabilities (recognizergcn.py:53-107): the oracle's inference path against the stored fp64 scores."""
+    import sys
+    sys.path.insert(0, GOLD)
+    from closed_form import counter_clips, fill_running, liven32
+    import dsgcn_amd as D
+    from bench import ds_cfg, other_cfg
+    np.random.seed(0)
+    torch.manual_seed(0)
+    m = D.build_model(ds_cfg(classes, layout) if kind == 'ds' else other_cfg(kind))
+    liven32(m, 1)
+    fill_running(m)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = counter_clips(2, 10, T, V)[:, :2]          # 2 of the 10 clips keep the CPU suite fast (-m gpu checks all 10)
+    z = load(f'eval_{name}.npz')
+    gc = O.graph_constants(layout)
+    flat = x.flatten(0, 1)
+    label = torch.zeros(flat.shape[0], 1, dtype=torch.long)
+    with torch.no_grad():
+        if kind == 'ds':
+            logits, _ = O.recognizer_forward_train(flat[:, None], label, sd, gc['node_type'], gc['edge_type'],
+                                                   O.dgstgcn_plan(), training=False)
+        else:
+            logits, _ = O.recognizer_forward_train_backbone(kind, flat[:, None], label, sd, O.dgstgcn_plan(),
+                                                            training=False)
+    assert rel(logits.reshape(2, 2, -1), z['scores64_clips'][:, :2]) < 1e-4          # class scores of each clip
+    assert rel(torch.softmax(logits.reshape(2, 2, -1), 2), z['probs64_clips'][:, :2]) < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN'])
+def test_oracle_units_vs_reference_live(tag):
+    """Build container only: every unit restated in the oracle against the IMPORTED reference module, fp64."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import ref_shim
+    if not ref_shim.available():
+        pytest.skip('reference tree not present (GPU box)')
+    from closed_form import make_unit
+    R = ref_shim.load()
+    A = torch.tensor(R.graph.Graph(layout='nturgb+d', mode='spatial').A, dtype=torch.float32)
+    m, x, _ = make_unit(R.gutils, tag, A)
+    m = m.double().train()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    want = m(x.double())
+    got = _unit_oracle(tag, x.double(), sd)
+    assert (want - got).abs().max().item() < 1e-11
+
+
+@pytest.mark.parametrize('cls,stride', [('dgmstcn', 1), ('dgmstcn', 2), ('mstcn', 1), ('mstcn', 2)])
+def test_oracle_temporal_units_vs_reference_live(cls, stride):
+    import sys
+    sys.path.insert(0, GOLD)
+    import ref_shim
+    if not ref_shim.available():
+        pytest.skip('reference tree not present (GPU box)')
+    R = ref_shim.load()
+    torch.manual_seed(5)
+    m = getattr(R.gutils, cls)(64, 64, stride=stride).double().train()
+    with torch.no_grad():
+        if hasattr(m, 'add_coeff'):
+            m.add_coeff.normal_(0, .5)
+    x = torch.randn(2, 64, 10, 25, dtype=torch.float64)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    want = m(x)
+    got = (O.dgmstcn_forward if cls == 'dgmstcn' else O.mstcn_forward)(x, sd, stride)
+    assert (want - got).abs().max().item() < 1e-11
