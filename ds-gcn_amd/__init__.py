@@ -17,6 +17,8 @@ from .tcn_units import dgmstcn, mstcn, unit_tcn, MSTCN
 from .backbones import DGSTGCN, STGCN, CTRGCN, DGBlock, STGCNBlock, CTRGCNBlock
 from .recognizers import RecognizerGCN, reduce_log_vars, gather_results
 from . import kernels
+from . import pipeline
+from .pipeline import PIPELINES, DATASETS, Compose, PoseDataset, SkeletonStore, SkeletonBatcher, build_dataset
 from .data_parallel import FlatParams, FlatDataParallel, shard_batch
 from .train import FlatSGD, cosine_lr
 from .checkpoint import load_checkpoint, save_checkpoint, resume, find_resume

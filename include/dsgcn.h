@@ -192,6 +192,22 @@ int dsgcn_add3(const float* a, const float* b, const float* c, float* out, long 
 int dsgcn_pack(const float* const* src_table, const long* dst_offsets, const int* numels, int count, float* dst,
                void* stream);
 
+/* Skeleton input pipeline, per-element half (csrc/skeleton.hip).  Replaces the numpy transforms of the reference's
+ * loader workers — PreNormalize3D (pose_related.py:250-336), RandomRot (144-178), JointToBone / ToMotion / GenSkeFeat
+ * (340-442), PoseDecode (19-54), FormatGCNInput (468-518) — for a whole batch in one launch; the per-clip decisions
+ * (kept frames, person swap, body centre, linear map, UniformSample's frame indices: sampling.py:10-192) come from the host.
+ *   raw: packed clips, clip n = (M[n], T[n], V, C) fp32 at raw + offset[n] (offset in floats, int64);
+ *   flags[n]: bit 0 = persons swapped, bit 1 = subtract center[n] from non-zero joints and zero the others (else plain
+ *   subtraction);  center (N,3);  matrix (N,9) row-major, applied after centring;  f0 / f1 (N, clips*clip_len): original
+ *   frame of each output frame and of its successor in the kept sequence (-1 = none: motion features are 0);
+ *   parent (V): bone parent of each joint;  fmask: 2 bits per feature (0 j, 1 b, 2 jm, 3 bm), nfeat features;
+ *   scored: third channel is a confidence (2-D layouts: bone / motion entries average it);  loop: pad missing persons
+ *   with person 0 instead of zeros.   out (N, clips, Mout, clip_len, V, C*nfeat). */
+int dsgcn_skeleton_prep(const float* raw, const long* offset, const int* M, const int* T, const int* flags,
+                        const int* f0, const int* f1, const float* center, const float* matrix, const int* parent,
+                        float* out, int N, int clips, int Mout, int clip_len, int V, int C, int nfeat, int fmask,
+                        int scored, int loop, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,32 @@
+"""Input-pipeline golden fixture from the IMPORTED reference transforms (build container only).
+
+    python tests/golden/gen_golden_pipeline.py
+
+For every pipeline config of pipeline_cases.pipelines() the reference's Compose (pyskl/datasets/pipelines) is run over the
+seven synthetic clips with numpy's global RNG seeded once per config; the resulting network inputs and labels are
+stored in pipeline.npz.  Data only."""
+import copy
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim_data  # noqa: E402
+from pipeline_cases import annotations, pipelines  # noqa: E402
+
+R = ref_shim_data.load()
+out = {}
+for pi, (name, cfg) in enumerate(pipelines().items()):
+    pipe = R.Compose(copy.deepcopy(cfg))
+    np.random.seed(1000 + pi)
+    for si, ann in enumerate(annotations()):
+        sample = copy.deepcopy(ann)
+        sample.update(start_index=0, modality='Pose')
+        res = pipe(sample)
+        out[f'{name}_{si}'] = res['keypoint'].numpy()
+        assert res['label'] == ann['label']
+np.savez_compressed(os.path.join(HERE, 'pipeline.npz'), **out)
+print('pipeline.npz', os.path.getsize(os.path.join(HERE, 'pipeline.npz')), len(out), 'arrays;',
+      {k: v.shape for k, v in list(out.items())[:3]})

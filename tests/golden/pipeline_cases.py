@@ -1,0 +1,56 @@
+"""Synthetic raw clips and pipeline configs of the input-pipeline fixtures (tests/golden/pipeline.npz): shared by the
+generator (reference side) and the tests, so only the reference's OUTPUTS are stored."""
+import numpy as np
+
+CLIP_LEN = 16
+
+
+def raw_clips():
+    """Seven (M, T, 25, 3) float32 clips covering PreNormalize3D's and UniformSample's branches."""
+    rng = np.random.RandomState(2024)
+
+    def body(M, T):
+        base = rng.randn(1, 1, 25, 3).astype(np.float32) * 0.4 + np.array([0.2, 0.1, 3.0], dtype=np.float32)
+        walk = np.cumsum(rng.randn(M, T, 1, 3).astype(np.float32) * 0.02, axis=1)
+        return (base + walk + rng.randn(M, T, 25, 3).astype(np.float32) * 0.05).astype(np.float32)
+    clips = []
+    a = body(2, 80)                                  # two full persons, T >= 2 * clip_len (block sampling)
+    clips.append(a)
+    b = body(2, 43)
+    b[1] = 0                                         # second person absent (the common NTU case)
+    b[0, :5] = 0                                     # leading empty frames are dropped
+    clips.append(b)
+    c = body(2, 30)
+    c[0, 10:] = 0                                    # person 1 has more valid frames: the persons swap
+    clips.append(c)
+    clips.append(body(1, 11))                        # shorter than the clip: looped indices
+    d = body(2, 50)
+    d[0, 7, 3] = 0                                   # isolated zero joints stay zero after centring (mask)
+    d[1, 20:25] = 0
+    clips.append(d)
+    clips.append(body(1, 25))                        # clip_len <= T < 2 * clip_len
+    clips.append(np.zeros((2, 20, 25, 3), dtype=np.float32))     # all-zero clip passes through
+    return clips
+
+
+def annotations():
+    return [dict(frame_dir=f'clip{i}', label=(7 * i) % 60, keypoint=k, total_frames=k.shape[1]) for i, k in enumerate(raw_clips())]
+
+
+def pipelines():
+    def pipe(norm=None, rot=0.2, feats=('j',), clips=1, test_mode=False, fmt=None):
+        p = [dict(type='PreNormalize3D', **(norm if norm is not None else dict(align_spine=False)))]
+        if rot:
+            p.append(dict(type='RandomRot', theta=rot))
+        p += [dict(type='GenSkeFeat', feats=list(feats)),
+              dict(type='UniformSample', clip_len=CLIP_LEN, num_clips=clips, test_mode=test_mode),
+              dict(type='PoseDecode'), dict(type='FormatGCNInput', **(fmt or {})),
+              dict(type='Collect', keys=['keypoint', 'label'], meta_keys=[]), dict(type='ToTensor', keys=['keypoint'])]
+        return p
+    return {
+        'train_j': pipe(), 'train_b': pipe(feats=('b',)), 'train_jm': pipe(feats=('jm',)), 'train_bm': pipe(feats=('bm',)),
+        'train_all': pipe(feats=('j', 'b', 'jm', 'bm')),
+        'val_j': pipe(rot=0), 'test10_j': pipe(rot=0, clips=10), 'test10_seeded': pipe(rot=0, clips=10, test_mode=True),
+        'spine_j': pipe(norm=dict()), 'loop_j': pipe(fmt=dict(num_person=2, mode='loop')),
+        'three_persons': pipe(fmt=dict(num_person=3)),
+    }

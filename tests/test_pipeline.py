@@ -1,0 +1,118 @@
+"""Input pipeline against outputs of the REFERENCE's transforms (tests/golden/pipeline.npz, written by
+tests/golden/gen_golden_pipeline.py from the imported pyskl/datasets/pipelines): the host (numpy, per sample) form on CPU,
+the batched HIP form (-m gpu) on the same configs with the same RNG seeds."""
+import copy
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import dsgcn_amd as D
+from dsgcn_amd import pipeline as P
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+sys.path.insert(0, GOLD)
+from pipeline_cases import CLIP_LEN, annotations, pipelines, raw_clips  # noqa: E402
+
+Z = dict(np.load(os.path.join(GOLD, 'pipeline.npz')))
+NAMES = list(pipelines())
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_host_pipeline_vs_reference(name):
+    """numpy transforms, one sample at a time, numpy's global RNG seeded like the generator: frame choice, rotation
+    angles, person order and every value agree with the reference (float data to 1e-6: the reference rotates in fp64
+    and rounds once, evaluation order inside einsum may differ in the last bit)."""
+    pipe = P.Compose(copy.deepcopy(pipelines()[name]))
+    np.random.seed(1000 + NAMES.index(name))
+    for si, ann in enumerate(annotations()):
+        sample = copy.deepcopy(ann)
+        sample.update(start_index=0, modality='Pose')
+        res = pipe(sample)
+        want = Z[f'{name}_{si}']
+        got = res['keypoint']
+        assert torch.is_tensor(got) and got.dtype == torch.float32 and tuple(got.shape) == want.shape
+        assert res['label'] == ann['label']
+        assert np.abs(got.numpy() - want).max() < 1e-6, (name, si)
+
+
+def test_frame_indices_branches_and_rng_stream():
+    """UniformSample draws: every branch (T < clip, clip <= T < 2 clip, T >= 2 clip), several clips, seeded test mode —
+    indices in range, sorted within a clip where the reference's are, and the test-mode stream is reproducible."""
+    np.random.seed(3)
+    for T in (5, 16, 20, 31, 32, 100):
+        inds = P.uniform_frame_indices(T, 16, 3)
+        assert inds.shape == (48,) and inds.min() >= 0 and inds.max() < T
+        if T >= 16:
+            assert all((np.diff(inds[c * 16:(c + 1) * 16]) >= 0).all() for c in range(3))
+    a = P.uniform_frame_indices(57, 16, 10, test_mode=True)
+    np.random.seed(99)
+    b = P.uniform_frame_indices(57, 16, 10, test_mode=True)
+    assert np.array_equal(a, b)
+
+
+def test_pose_dataset_pickle_and_split(tmp_path):
+    """PoseDataset reads the reference's annotation pickle ({'split': ..., 'annotations': [...]}) and applies the split."""
+    anns = annotations()
+    path = tmp_path / 'toy.pkl'
+    with open(path, 'wb') as f:
+        pickle.dump(dict(split=dict(train=[a['frame_dir'] for a in anns[:5]], val=[a['frame_dir'] for a in anns[5:]]),
+                         annotations=anns), f)
+    ds = D.build_dataset(dict(type='PoseDataset', ann_file=str(path), pipeline=pipelines()['val_j'], split='train'))
+    assert len(ds) == 5 and len(D.PoseDataset(str(path), pipelines()['val_j'], split='val')) == 2
+    np.random.seed(1000 + NAMES.index('val_j'))
+    item = ds[0]
+    assert np.abs(item['keypoint'].numpy() - Z['val_j_0']).max() < 1e-6 and item['label'] == anns[0]['label']
+    with pytest.raises(NotImplementedError):
+        D.PoseDataset(str(path), pipelines()['val_j'], split='val', memcached=True)
+
+
+def test_batcher_rejects_what_it_cannot_batch():
+    with pytest.raises(NotImplementedError):
+        P.SkeletonBatcher([dict(type='PreNormalize3D'), dict(type='RandomScale', scale=0.1), dict(type='GenSkeFeat'),
+                           dict(type='UniformSample', clip_len=8)])
+    with pytest.raises(NotImplementedError):
+        P.SkeletonBatcher([dict(type='GenSkeFeat'), dict(type='PreNormalize3D'), dict(type='UniformSample', clip_len=8)])
+    with pytest.raises(RuntimeError):
+        P.SkeletonStore(annotations(), device='cpu')            # the clips live in HBM: no CPU form
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', NAMES)
+def test_batched_hip_pipeline_vs_reference(name):
+    """One dsgcn_skeleton_prep launch for the whole batch == the reference's per-sample transforms (same seed, same RNG
+    draws on the host): fp32 on the device vs the reference's fp64-then-round: 2e-6 absolute on O(1) coordinates."""
+    store = P.SkeletonStore(annotations())
+    batcher = P.SkeletonBatcher(pipelines()[name])
+    np.random.seed(1000 + NAMES.index(name))
+    kp, label = batcher(store, list(range(len(store))))
+    kp = kp.cpu().numpy()
+    assert label.shape == (len(store), 1) and label[:, 0].tolist() == [a['label'] for a in annotations()]
+    for si in range(len(store)):
+        want = Z[f'{name}_{si}']
+        assert kp[si].shape == want.shape
+        assert np.abs(kp[si] - want).max() < 2e-6, (name, si, np.abs(kp[si] - want).max())
+
+
+@pytest.mark.gpu
+def test_batched_pipeline_feeds_the_recognizer():
+    """(N, clips, M, T, V, C) straight from the HIP pipeline into RecognizerGCN.train_step / forward_test."""
+    from bench import ds_cfg
+    store = P.SkeletonStore(annotations())
+    np.random.seed(0)
+    torch.manual_seed(0)
+    cfg = ds_cfg(60)
+    cfg['backbone'].update(base_channels=16, num_stages=4, inflate_stages=[3], down_stages=[3])
+    cfg['cls_head']['in_channels'] = 32
+    m = D.build_model(cfg).cuda().train()
+    kp, label = P.SkeletonBatcher(pipelines()['train_j'])(store, [0, 1, 2, 4])
+    out = m.train_step(dict(keypoint=kp, label=label), None)
+    out['loss'].backward()
+    assert np.isfinite(out['log_vars']['loss'])
+    m.eval()
+    kp10, _ = P.SkeletonBatcher(pipelines()['test10_j'])(store, [0, 5])
+    probs = m(keypoint=kp10, return_loss=False)
+    assert probs.shape == (2, 60) and np.allclose(probs.sum(1), 1, atol=1e-5)
