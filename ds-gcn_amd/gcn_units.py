@@ -227,17 +227,17 @@ class dgphgcn1(nn.Module):
 
 
 class unit_gcn(nn.Module):
-    """ST-GCN spatial unit (reference: gcn.py:22-97): conv Ci->K*Co, aggregate with the shared learnable
-    A (K,V,V) summed over subsets, BN, ReLU.  ``conv_pos='pre'`` and adaptive in {None,'init'} (the vanilla
-    ST-GCN config) are on the HIP path."""
+    """ST-GCN spatial unit (reference: gcn.py:22-97).  ``conv_pos='pre'``: conv Ci->K*Co, aggregate with the K learnable /
+    fixed adjacencies summed over subsets (K-A'), BN, (+res), ReLU.  ``conv_pos='post'``: aggregate the input with each
+    adjacency first (K launches of K-A' on one subset each), then one conv over the K*Ci stacked channels.
+    ``adaptive``: None / 'init' use ``A`` (buffer / parameter); 'offset' uses ``A + PA``, 'importance' ``A * PA`` with the
+    extra parameter ``PA`` (gcn.py:54-60,83)."""
 
     def __init__(self, in_channels, out_channels, A, adaptive='init', conv_pos='pre', with_res=False, norm='BN',
                  act='ReLU'):
         super().__init__()
         assert adaptive in [None, 'init', 'offset', 'importance']
         assert conv_pos in ['pre', 'post']
-        if adaptive not in (None, 'init') or conv_pos != 'pre':
-            raise NotImplementedError("unit_gcn: HIP path covers adaptive in {None,'init'} with conv_pos='pre'")
         _check_act(act)
         self.in_channels = in_channels
         self.out_channels = out_channels
@@ -250,17 +250,39 @@ class unit_gcn(nn.Module):
             self.A = nn.Parameter(A.clone())
         else:
             self.register_buffer('A', A)
-        self.conv = nn.Conv2d(in_channels, out_channels * A.size(0), 1)
+        if adaptive in ('offset', 'importance'):
+            self.PA = nn.Parameter(A.clone())
+            if adaptive == 'offset':
+                nn.init.uniform_(self.PA, -1e-6, 1e-6)
+            else:
+                nn.init.constant_(self.PA, 1)
+        if conv_pos == 'pre':
+            self.conv = nn.Conv2d(in_channels, out_channels * A.size(0), 1)
+        else:
+            self.conv = nn.Conv2d(A.size(0) * in_channels, out_channels, 1)
         self.down = None
         if with_res and in_channels != out_channels:
             self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), _norm_layer(norm, out_channels))
 
+    def effective_A(self):
+        if self.adaptive == 'offset':
+            return self.A + self.PA
+        if self.adaptive == 'importance':
+            return self.A * self.PA
+        return self.A
+
     def forward_deferred(self, x, x_res=None):
         ops = kernels.ops()
         x_res = x if x_res is None else x_res
-        h = ops.pwconv(x, None, None, None, False, self.conv.weight, self.conv.bias, 1, False)[0]
-        y, ay = op_bn(self.bn, lambda g, b, eps, want: ops.aggregate_sum(h, self.A, self.num_subsets, g, b, eps, want),
-                      lambda y: y.shape[0] * y.shape[2] * y.shape[3])
+        A = self.effective_A()                                   # (K, V, V): a KB-sized elementwise op on parameters
+        K = self.num_subsets
+        if self.conv_pos == 'pre':
+            h = ops.pwconv(x, None, None, None, False, self.conv.weight, self.conv.bias, 1, False)[0]
+            y, ay = op_bn(self.bn, lambda g, b, eps, want: ops.aggregate_sum(h, A, K, g, b, eps, want),
+                          lambda y: y.shape[0] * y.shape[2] * y.shape[3])
+        else:
+            parts = [ops.aggregate_sum(x, A[k:k + 1], 1)[0] for k in range(K)]        # x . A_k, one subset per launch
+            y, _, ay = conv_bn(torch.cat(parts, 1), None, None, None, False, self.conv, 1, False, self.bn)
         if not self.with_res:
             return Deferred(y, ay, None, None, True)
         if self.down is None:

@@ -348,12 +348,22 @@ def recognizer_forward_train(keypoint, label, sd, node_type, edge_type, plan, tr
 # ST-GCN units (gcn.py:22-97, tcn.py:10-37, stgcn.py:16-68)   SURVEY App. A.3
 # ----------------------------------------------------------------------------------------
 
-def unit_gcn_forward(x, sd, training=True, with_res=False):
+def unit_gcn_forward(x, sd, training=True, with_res=False, adaptive='init', conv_pos='pre'):
+    """ST-GCN spatial unit (gcn.py:73-97).  adaptive 'offset' / 'importance' combine A with the PA parameter
+    (gcn.py:80-84); conv_pos 'post' aggregates the input per subset first and mixes the K*Ci stacked channels (89-92)."""
     n, Ci, T, V = x.shape
     A = sd['A']
+    if adaptive == 'offset':
+        A = A + sd['PA']                                                              # gcn.py:83
+    elif adaptive == 'importance':
+        A = A * sd['PA']
     K = A.shape[0]
-    h = _conv1x1(x, sd['conv.weight'], sd['conv.bias']).view(n, K, -1, T, V)          # gcn.py:86-87
-    y = torch.einsum('nkctv,kvw->nctw', h, A)                                         # gcn.py:88
+    if conv_pos == 'pre':
+        h = _conv1x1(x, sd['conv.weight'], sd['conv.bias']).view(n, K, -1, T, V)      # gcn.py:86-87
+        y = torch.einsum('nkctv,kvw->nctw', h, A)                                     # gcn.py:88
+    else:
+        h = torch.einsum('nctv,kvw->nkctw', x, A).reshape(n, K * Ci, T, V)            # gcn.py:90-91
+        y = _conv1x1(h, sd['conv.weight'], sd['conv.bias'])                           # gcn.py:92
     y = _bn(y, sd, 'bn.', training)
     if with_res:                                                                      # gcn.py:57-66,70,94
         if 'down.0.weight' in sd:

@@ -89,6 +89,9 @@ UNIT_CASES = {       # tag -> (class name, ctor args after the graph, input shap
               (2, 64, 8, 25)),
     'MSTCNs2': ('MSTCN', dict(in_channels=64, out_channels=128, kernel_size=5, stride=2, dilations=[1, 2], residual=True),
                 (2, 64, 8, 25)),
+    'gcn_offset_post': ('unit_gcn', dict(in_channels=64, out_channels=128, adaptive='offset', conv_pos='post'), (2, 64, 8, 25)),
+    'gcn_importance': ('unit_gcn', dict(in_channels=64, out_channels=64, adaptive='importance', with_res=True), (2, 64, 8, 25)),
+    'gcn_fixed_post': ('unit_gcn', dict(in_channels=3, out_channels=64, adaptive=None, conv_pos='post'), (2, 3, 8, 25)),
 }
 
 
@@ -105,6 +108,8 @@ def make_unit(ns, tag, A):
     liven32(m, 40 + idx)
     g = torch.Generator().manual_seed(50 + idx)
     with torch.no_grad():
+        if hasattr(m, 'PA'):                                   # offset / importance: move PA off its init value
+            m.PA.add_(torch.randn(m.PA.shape, generator=g) * 0.05)
         for mod in m.modules():
             if isinstance(mod, torch.nn.BatchNorm2d):
                 mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)

@@ -434,7 +434,8 @@ def test_dgphgcn1_kernels_vs_reference_intermediates(tag, layout, ci, co):
     assert rel(out.cpu(), z[f'{tag}_out']) < 1e-5
 
 
-@pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'MSTCNs2'])
+@pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'MSTCNs2', 'gcn_offset_post',
+                                 'gcn_importance', 'gcn_fixed_post'])
 def test_units_vs_reference_fixture(tag):
     """unit_gcn, unit_tcn (k=9 dense; k=1 stride 2), unit_ctrgcn / CTRGC and MSTCN at real widths on the HIP path
     against the REFERENCE's output, input gradient, parameter gradients and running statistics (fp64 run;

@@ -185,6 +185,12 @@ def test_dgphgcn1_intermediates(tag, layout):
 def _unit_oracle(tag, x, sd):
     if tag in ('gcn', 'gcn_res'):
         return O.unit_gcn_forward(x, sd, with_res=(tag == 'gcn_res'))
+    if tag == 'gcn_offset_post':
+        return O.unit_gcn_forward(x, sd, adaptive='offset', conv_pos='post')
+    if tag == 'gcn_importance':
+        return O.unit_gcn_forward(x, sd, with_res=True, adaptive='importance')
+    if tag == 'gcn_fixed_post':
+        return O.unit_gcn_forward(x, sd, adaptive=None, conv_pos='post')
     if tag == 'tcn9':
         return O.unit_tcn_forward(x, sd, 9, 1)
     if tag == 'tcn1s2':
@@ -196,7 +202,8 @@ def _unit_oracle(tag, x, sd):
     raise KeyError(tag)
 
 
-@pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN'])
+@pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'gcn_offset_post', 'gcn_importance',
+                                 'gcn_fixed_post'])
 def test_other_units_vs_reference_fixture(tag):
     """unit_gcn, unit_tcn (k=9; k=1 stride 2), unit_ctrgcn, MSTCN at real widths: oracle output and input gradient
     against the reference's (weights rebuilt from the shared seeded recipe; their digest is part of the fixture)."""
@@ -248,7 +255,8 @@ def test_eval_fixture_oracle(name, kind, T, V, classes, layout):
     assert rel(torch.softmax(logits.reshape(2, 2, -1), 2), z['probs64_clips'][:, :2]) < 1e-5
 
 
-@pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN'])
+@pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'gcn_offset_post', 'gcn_importance',
+                                 'gcn_fixed_post'])
 def test_oracle_units_vs_reference_live(tag):
     """Build container only: every unit restated in the oracle against the IMPORTED reference module, fp64."""
     import sys
