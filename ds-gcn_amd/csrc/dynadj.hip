@@ -1,85 +1,111 @@
-// K-B: dynamic-semantic adjacency build (reference: pyskl/models/gcns/utils/gcn.py:2240-2337).
+// K-B: dynamic-semantic adjacency build (reference: pyskl/models/gcns/utils/gcn.py:2240-2337), one workgroup per sample.
 //
-//   proj (n,9*mid,V) = [W1;W2;Wse] xbar + bias (the K-C kernel on the time-mean xbar)  ->  Ahat (n, 3*mid, V, V)
-//   a_k = proj rows k*mid+c, b_k = rows 2mid+k*mid+c (k=0,1);  s[c,v] = proj row 4mid + c*P+tau(v)
-//   D0 = a0[u]-b0[w];  D1 = We[eps(u,w)] (a1[u]-b1[w]) + be[eps(u,w)];  D2 = s[u]-s[w]
+//   proj (n, 4m + m*P, V) = [conv1 (2m) | conv2 (2m) | conv1_se (m*P, row c*P+p)] applied to xbar = time mean of the input
+//   a_k = rows k*m+c, b_k = rows 2m+k*m+c (k = 0,1);  s[c,v] = row 4m + c*P + tau(v)                 (node-typed select)
+//   D0 = a0[u]-b0[w];  D1 = We[eps(u,w)] (a1[u]-b1[w]) + be[eps(u,w)];  D2 = s[u]-s[w]                (edge-typed linear)
 //   G_k[u,w] = sum_c x1_k[c,u] x2_k[c,w]  (x1=(a0,a1,s), x2=(b0,b1,s): conv2_se is dead, quirk Q1)
 //   Ahat[k,c,u,w] = A[k,u,w] + alpha_k tanh(D_k[c,u,w]) + beta_k softmax_u(G_k)[u,w]
 //
-// The reference spends ~40 launches plus a 625-iteration host loop per layer on this and computes all
-// 15 edge-typed / 5 node-typed variants before selecting one.  Here one workgroup per sample keeps
-// everything V x V in LDS, indexes the typed weight slice directly with tau(v) / eps(u,w) (625-entry
-// integer tables), and only Ahat ever reaches HBM (coalesced).  Bound: HBM writes of Ahat.
-//
-// Backward = the same recompute + the chain rule in LDS (k_dynadj_bwd); the projection weights' gradients come from
-// the K-C backward applied to dproj.
+// The reference spends ~40 launches plus a 625-iteration host loop per layer on this and computes all 15 edge-typed /
+// 5 node-typed variants before selecting one.  Round 1 kept the three mean-pooled projections as a K-C launch (three
+// more for its backward) and evaluated the edge-typed linear per joint pair, a m x m product read from LDS with a
+// different weight slice per lane (bank conflicts: 44-260 us per layer, 2 ms of a 18 ms step with the tiny projection
+// launches).  The projections stay on the matrix core (a K-C launch on xbar: 1 M MAC per sample at 256 channels is VALU-
+// bound inside a one-workgroup-per-sample kernel — measured 100-250 us — so they are not folded in); the rest is one launch
+// each way with the per-pair product removed:
+//   * the edge-typed linear is factored: P_e = We[e] a1 + be[e], Q_e = We[e] b1 for all E classes (E*m*V outputs each,
+//     conflict-free inner loops), D1[c,u,w] = P_eps(u,w)[c,u] - Q_eps(u,w)[c,w]: two LDS gathers per element;
+//   * the backward mirrors it: dP_e / dQ_e are masked row / column sums of dD1, then
+//       d a1 = sum_e We[e]^T dP_e,  d b1 = sum_e We[e]^T dQ_e,  dWe[e] = dP_e a1^T + dQ_e b1^T,  dbe[e] = sum_u dP_e
+//     with per-sample partials for the parameters (deterministic: summed by dsgcn_colsum, no float atomics);
+//   * dproj (the gradient of the projections) leaves for the K-C backward.
+// Bound: HBM writes of Ahat forward, reads of dAhat backward; the arithmetic above is ~3 M MAC per sample at mid = 32.
 #include "common.h"
 
 namespace {
 
 constexpr int KSUB = 3;     // subsets: 2 plain + 1 semantic
-constexpr int NT_DWE = 256; // the per-(sample, edge class) weight-gradient kernel has many small workgroups
-constexpr int NT = 1024;    // threads per workgroup: the LDS image allows one workgroup per CU, so it has to bring all 16 waves
+constexpr int NT = 1024;    // the LDS image allows one workgroup per CU, so it brings all 16 waves
 
-struct DynDims {
-  int n, Ci, mid, V, P, E;
-};
+struct DynDims { int n, Ci, mid, V, P, E; };
 
-// LDS carve (floats): X[5*mid*V] | G[3*V*V] | col[3*V*2] | We[E*mid*mid] be[E*mid] | (bwd: SC[3*V*V] dX[5*mid*V])
+// LDS carve (floats):  X [5][mid][V] | G [3][V][V] | col [3][V][2] | PQ [2][E][mid][V] | (bwd: SC [3][V][V] dX [5][mid][V])
 __device__ __forceinline__ int lds_X(const DynDims& d) { return 0; }
 __device__ __forceinline__ int lds_G(const DynDims& d) { return lds_X(d) + 5 * d.mid * d.V; }
 __device__ __forceinline__ int lds_col(const DynDims& d) { return lds_G(d) + KSUB * d.V * d.V; }
-__device__ __forceinline__ int lds_We(const DynDims& d) { return lds_col(d) + KSUB * d.V * 2; }
-__device__ __forceinline__ int lds_end(const DynDims& d) { return lds_We(d) + d.E * d.mid * d.mid + d.E * d.mid; }
+__device__ __forceinline__ int lds_PQ(const DynDims& d) { return lds_col(d) + KSUB * d.V * 2; }
+__device__ __forceinline__ int lds_end(const DynDims& d) { return lds_PQ(d) + 2 * d.E * d.mid * d.V; }
 
 // X slot of x1_k / x2_k :  X[0]=a0 X[1]=a1 X[2]=s X[3]=b0 X[4]=b1
 __device__ __forceinline__ int slot_x1(int k) { return k; }
 __device__ __forceinline__ int slot_x2(int k) { return k < 2 ? 3 + k : 2; }
 
-// Steps shared by forward and backward: projections -> LDS, edge-typed weights -> LDS, Gram, column softmax.
-// proj_n (9*mid, V): rows [a (2mid) | b (2mid) | s-typed (mid*P, row c*P+p)] = the three mean-pooled 1x1 convs
-// (conv1 / conv2 / conv1_se of gcn.py:2248-2253) evaluated by the K-C kernel on xbar; the node-typed select
-// (gcn.py:2256-2259) is the row pick c*P+tau(v) done here.
-__device__ void dyn_prepare(const DynDims& d, float* lds, const float* __restrict__ proj_n,
-                            const float* __restrict__ we, const float* __restrict__ be,
-                            const int* __restrict__ node_type) {
+// W_all row feeding X slot `slot`, channel c, joint v
+__device__ __forceinline__ int proj_row(const DynDims& d, int slot, int c, int tau_v) {
+  const int m = d.mid;
+  if (slot < 2) return slot * m + c;                 // a0, a1
+  if (slot == 2) return 4 * m + c * d.P + tau_v;     // s (typed)
+  return 2 * m + (slot - 3) * m + c;                 // b0, b1
+}
+
+// Steps shared by forward and backward: projections -> LDS (node-typed row pick), Gram + column softmax, factored
+// edge-typed linear.
+__device__ void dyn_prepare(const DynDims& d, float* lds, const float* __restrict__ proj_n, const float* __restrict__ we,
+                            const float* __restrict__ be, const int* __restrict__ node_type) {
   const int tid = threadIdx.x;
-  const int mid = d.mid, V = d.V;
+  const int m = d.mid, V = d.V;
   float* X = lds + lds_X(d);
   float* G = lds + lds_G(d);
   float* col = lds + lds_col(d);
-  float* Wl = lds + lds_We(d);
-  for (int o = tid; o < 5 * mid * V; o += NT) {
+  float* PQ = lds + lds_PQ(d);
+  for (int o = tid; o < 5 * m * V; o += NT) {
     const int q = o / V, v = o - q * V;
-    int slot, c, row;
-    if (q < 2 * mid) { slot = q / mid; c = q - slot * mid; row = q; }
-    else if (q < 4 * mid) { const int r = q - 2 * mid; slot = 3 + r / mid; c = r % mid; row = q; }
-    else { c = q - 4 * mid; slot = 2; row = 4 * mid + c * d.P + node_type[v]; }
-    X[(slot * mid + c) * V + v] = proj_n[row * V + v];
-  }
-  {
-    const int nw = d.E * mid * mid, nb = d.E * mid;
-    for (int i = tid; i < nw; i += NT) Wl[i] = we[i];
-    for (int i = tid; i < nb; i += NT) Wl[nw + i] = be[i];
+    const int slot = q / m, c = q - slot * m;
+    X[o] = proj_n[proj_row(d, slot, c, node_type[v]) * V + v];
   }
   __syncthreads();
   for (int i = tid; i < KSUB * V * V; i += NT) {
     const int k = i / (V * V), r = i - k * V * V, u = r / V, w = r - u * V;
-    const float* x1 = X + slot_x1(k) * mid * V;
-    const float* x2 = X + slot_x2(k) * mid * V;
+    const float* x1 = X + slot_x1(k) * m * V;
+    const float* x2 = X + slot_x2(k) * m * V;
     float g = 0.f;
-    for (int c = 0; c < mid; ++c) g = fmaf(x1[c * V + u], x2[c * V + w], g);
+    for (int c = 0; c < m; ++c) g = fmaf(x1[c * V + u], x2[c * V + w], g);
     G[i] = g;
+  }
+  // P_e[c,v] = be[e,c] + sum_cc We[e,c,cc] a1[cc,v];  Q_e[c,v] = sum_cc We[e,c,cc] b1[cc,v]
+  {
+    const float* a1 = X + 1 * m * V;
+    const float* b1 = X + 4 * m * V;
+    const int half = d.E * m * V;
+    for (int o = tid; o < 2 * half; o += NT) {
+      const int pq = o >= half, r = o - pq * half;
+      const int ec = r / V, v = r - ec * V;           // ec = e*m + c
+      const float* __restrict__ wr = we + (size_t)ec * m;
+      const float* src = pq ? b1 : a1;
+      float acc = pq ? 0.f : be[ec];
+      int cc = 0;
+      if ((m & 7) == 0) {
+        for (; cc < m; cc += 8) {
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(wr + cc), wb = *reinterpret_cast<const f32x4*>(wr + cc + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = fmaf(wa[e], src[(cc + e) * V + v], acc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = fmaf(wb[e], src[(cc + 4 + e) * V + v], acc);
+        }
+      }
+      for (; cc < m; ++cc) acc = fmaf(wr[cc], src[cc * V + v], acc);
+      PQ[o] = acc;
+    }
   }
   __syncthreads();
   for (int j = tid; j < KSUB * V; j += NT) {
     const int k = j / V, w = j - k * V;
     const float* g = G + k * V * V + w;
-    float m = -INFINITY;
-    for (int u = 0; u < V; ++u) m = fmaxf(m, g[u * V]);
+    float mx = -INFINITY;
+    for (int u = 0; u < V; ++u) mx = fmaxf(mx, g[u * V]);
     float ssum = 0.f;
-    for (int u = 0; u < V; ++u) ssum += expf(g[u * V] - m);
-    col[j * 2 + 0] = m;
+    for (int u = 0; u < V; ++u) ssum += expf(g[u * V] - mx);
+    col[j * 2 + 0] = mx;
     col[j * 2 + 1] = 1.f / ssum;
   }
   __syncthreads();
@@ -91,19 +117,12 @@ __device__ void dyn_prepare(const DynDims& d, float* lds, const float* __restric
   __syncthreads();
 }
 
-// D_k[c,u,w] before tanh (Wl = edge-typed weights then biases, in LDS)
-__device__ __forceinline__ float dyn_D(const DynDims& d, const float* X, const float* Wl,
-                                       const int* __restrict__ edge_type, int k, int c, int u, int w) {
-  const int mid = d.mid, V = d.V;
-  if (k == 0) return X[(0 * mid + c) * V + u] - X[(3 * mid + c) * V + w];
-  if (k == 2) return X[(2 * mid + c) * V + u] - X[(2 * mid + c) * V + w];
-  const int e = edge_type[u * V + w];
-  const float* wr = Wl + (e * mid + c) * mid;
-  float acc = Wl[d.E * mid * mid + e * mid + c];
-  const float* a1 = X + 1 * mid * V;
-  const float* b1 = X + 4 * mid * V;
-  for (int cc = 0; cc < mid; ++cc) acc = fmaf(wr[cc], a1[cc * V + u] - b1[cc * V + w], acc);
-  return acc;
+// D_k[c,u,w] before tanh
+__device__ __forceinline__ float dyn_D(const DynDims& d, const float* X, const float* PQ, int e, int k, int c, int u, int w) {
+  const int m = d.mid, V = d.V;
+  if (k == 0) return X[(0 * m + c) * V + u] - X[(3 * m + c) * V + w];
+  if (k == 2) return X[(2 * m + c) * V + u] - X[(2 * m + c) * V + w];
+  return PQ[(e * m + c) * V + u] - PQ[((d.E + e) * m + c) * V + w];
 }
 
 __global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d, const float* __restrict__ proj,
@@ -113,71 +132,71 @@ __global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d, const float* __res
                                                    const int* __restrict__ edge_type, float* __restrict__ ahat) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n = blockIdx.x;
-  const int mid = d.mid, V = d.V, VV = V * V;
-  dyn_prepare(d, lds, proj + (size_t)n * 9 * mid * V, we, be, node_type);
+  const int m = d.mid, V = d.V, VV = V * V;
+  dyn_prepare(d, lds, proj + (size_t)n * (4 + d.P) * m * V, we, be, node_type);
   const float* X = lds + lds_X(d);
   const float* Sm = lds + lds_G(d);
-  const float* Wl = lds + lds_We(d);
-  float* out = ahat + (size_t)n * KSUB * mid * VV;
-  const int total = KSUB * mid * VV;
+  const float* PQ = lds + lds_PQ(d);
+  float* out = ahat + (size_t)n * KSUB * m * VV;
+  const int total = KSUB * m * VV;
   const float al0 = alpha[0], al1 = alpha[1], al2 = alpha[2], be0 = beta[0], be1 = beta[1], be2 = beta[2];
   // gridDim.y workgroups share one sample (each repeats the small prepare step): at n = 128 one workgroup per sample
   // would leave half of the 256 CUs idle
   for (int i = threadIdx.x + NT * blockIdx.y; i < total; i += NT * gridDim.y) {
-    const int k = i / (mid * VV);
-    int r = i - k * mid * VV;
+    const int k = i / (m * VV);
+    int r = i - k * m * VV;
     const int c = r / VV;
     r -= c * VV;
     const int u = r / V, w = r - u * V;
-    const float dk = dyn_D(d, X, Wl, edge_type, k, c, u, w);
+    const float dk = dyn_D(d, X, PQ, edge_type[r], k, c, u, w);
     const float al = k == 0 ? al0 : (k == 1 ? al1 : al2), bt = k == 0 ? be0 : (k == 1 ? be1 : be2);
     out[i] = A[k * VV + r] + al * tanhf(dk) + bt * Sm[k * VV + r];
   }
 }
 
-// Backward, per sample.  Workspace `dd` (n,3,mid,V,V) receives dD_k (k=1: later d(delta)) so the
-// row/column reductions and the per-edge-class weight gradient can read it back; it aliases nothing.
-// Outputs: dproj (n,9mid,V) (typed rows: only row c*P+tau(v) of joint v is non-zero); pA (n,3,V,V) = sum_c dAhat;
-// pab (n,6) = [dalpha_k | dbeta_k] partials.  ddelta (n,mid,V,V): second workspace for d(a1[u]-b1[w]).
-// The edge-typed weight gradient is a separate, wider launch (k_dynadj_dwe) reading dd's k=1 slice.
+// Backward, per sample.  Workspace `dd` (n,3,mid,V,V) receives dD_k so the masked row / column sums can read it back (it
+// stays in L2).  Outputs: dproj (n, 4m+mP, V) (typed rows: only row c*P+tau(v) of joint v is non-zero); ppar (n, pstride)
+// per-sample partials [sum_c dAhat (3VV) | dalpha (3) | dbeta (3) |
+// dWe (E*m*m) | dbe (E*m)] — the sum over samples gives the parameter gradients.
 __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     DynDims d, const float* __restrict__ proj, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ we, const float* __restrict__ be, const int* __restrict__ node_type,
-    const int* __restrict__ edge_type, const int* __restrict__ pair_order, const int* __restrict__ class_start,
-    const float* __restrict__ dahat, float* dd, float* ddelta, float* __restrict__ dproj, float* __restrict__ pA,
-    float* __restrict__ pab, int pstride) {
+    const int* __restrict__ edge_type, const float* __restrict__ dahat, float* dd, float* __restrict__ dproj,
+    float* __restrict__ ppar, int pstride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[6][NT / DSGCN_WAVE];
   const int tid = threadIdx.x;
   const int n = blockIdx.x;
-  const int mid = d.mid, V = d.V, VV = V * V;
-  dyn_prepare(d, lds, proj + (size_t)n * 9 * mid * V, we, be, node_type);
+  const int m = d.mid, V = d.V, VV = V * V, E = d.E;
+  dyn_prepare(d, lds, proj + (size_t)n * (4 + d.P) * m * V, we, be, node_type);
   const float* X = lds + lds_X(d);
   const float* Sm = lds + lds_G(d);
-  const float* Wl = lds + lds_We(d);
-  float* SC = lds + lds_end(d);       // [3][V][V]  sum_c dAhat, then dG
-  float* dX = SC + KSUB * VV;         // [5][mid][V] grads of a0,a1,s,b0,b1
-  const float* g_n = dahat + (size_t)n * KSUB * mid * VV;
-  float* dd_n = dd + (size_t)n * KSUB * mid * VV;
+  float* PQ = lds + lds_PQ(d);
+  float* SC = lds + lds_end(d);         // [3][V][V]  sum_c dAhat, then dG
+  float* dX = SC + KSUB * VV;           // [5][mid][V] grads of a0,a1,s,b0,b1
+  const float* g_n = dahat + (size_t)n * KSUB * m * VV;
+  float* dd_n = dd + (size_t)n * KSUB * m * VV;
+  float* par = ppar + (size_t)n * pstride;
 
   // pass 1: thread = (k,u,w), loop channels: SC = sum_c dAhat, dalpha partial, dD -> workspace
   float pal0 = 0.f, pal1 = 0.f, pal2 = 0.f;
   for (int i = tid; i < KSUB * VV; i += NT) {
     const int k = i / VV, r = i - k * VV, u = r / V, w = r - u * V;
     const float al = alpha[k];
+    const int e = edge_type[r];
     float sc = 0.f, pa = 0.f;
-    for (int c0 = 0; c0 < mid; c0 += 8) {
+    for (int c0 = 0; c0 < m; c0 += 8) {
       float gv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gv[j] = (c0 + j < mid) ? g_n[(k * mid + c0 + j) * VV + r] : 0.f;
+      for (int j = 0; j < 8; ++j) gv[j] = (c0 + j < m) ? g_n[(k * m + c0 + j) * VV + r] : 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = c0 + j;
-        if (c < mid) {
-          const float th = tanhf(dyn_D(d, X, Wl, edge_type, k, c, u, w));
+        if (c < m) {
+          const float th = tanhf(dyn_D(d, X, PQ, e, k, c, u, w));
           sc += gv[j];
           pa = fmaf(th, gv[j], pa);
-          dd_n[(k * mid + c) * VV + r] = al * (1.f - th * th) * gv[j];
+          dd_n[(k * m + c) * VV + r] = al * (1.f - th * th) * gv[j];
         }
       }
     }
@@ -186,9 +205,9 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     pal1 += (k == 1) ? pa : 0.f;
     pal2 += (k == 2) ? pa : 0.f;
   }
-  __syncthreads();
+  __syncthreads();                      // (also: every dd_n element this block wrote is visible to the block below)
 
-  // dbeta partial, pA write-out
+  // dbeta partial, sum_c dAhat write-out
   float pbe0 = 0.f, pbe1 = 0.f, pbe2 = 0.f;
   for (int i = tid; i < KSUB * VV; i += NT) {
     const int k = i / VV;
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     pbe0 += (k == 0) ? v : 0.f;
     pbe1 += (k == 1) ? v : 0.f;
     pbe2 += (k == 2) ? v : 0.f;
-    pA[(size_t)n * pstride + i] = SC[i];
+    par[i] = SC[i];
   }
   __syncthreads();
   // softmax backward per column (k,w): SC <- dG = Sm * (beta*SC - sum_u Sm*beta*SC)
@@ -210,72 +229,124 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
       SC[idx] = Sm[idx] * (bk * SC[idx] - dot);
     }
   }
-  // d(delta)[cc,u,w] = sum_c We[eps,c,cc] dD1[c,u,w]  -> second workspace (dD1 itself is kept for k_dynadj_dwe)
+  // dP_e[c,u] = sum_{w: eps(u,w)=e} dD1[c,u,w];  dQ_e[c,w] = -sum_{u: eps(u,w)=e} dD1[c,u,w]   (P/Q are dead: reuse)
   {
-    const float* dd1 = dd_n + (size_t)1 * mid * VV;
-    float* dl = ddelta + (size_t)n * mid * VV;
-    for (int r = tid; r < VV; r += NT) {
-      const int e = edge_type[r];
-      float dv[32], out[32];
+    const float* dd1 = dd_n + (size_t)1 * m * VV;
+    float* dP = PQ;
+    float* dQ = PQ + E * m * V;
+    for (int o = tid; o < 2 * m * V; o += NT) {
+      const int col = o >= m * V, r = o - col * m * V;
+      const int c = r / V, j = r - c * V;
+      float* dst = (col ? dQ : dP) + c * V + j;
 #pragma unroll
-      for (int c = 0; c < 32; ++c) dv[c] = (c < mid) ? dd1[c * VV + r] : 0.f;
+      for (int h = 0; h < 2; ++h) {                    // two 16-element halves of the line: bounded register use
+        float line[16];
+        int cls[16];
 #pragma unroll
-      for (int cc = 0; cc < 32; ++cc) {
-        float acc = 0.f;
-        if (cc < mid) {
-#pragma unroll
-          for (int c = 0; c < 32; ++c)
-            if (c < mid) acc = fmaf(Wl[(e * mid + c) * mid + cc], dv[c], acc);
+        for (int q = 0; q < 16; ++q) {
+          const int qq = 16 * h + q;
+          const int idx = col ? qq * V + j : j * V + qq;          // row j (over w) or column j (over u)
+          line[q] = qq < V ? dd1[c * VV + idx] : 0.f;
+          cls[q] = qq < V ? edge_type[idx] : -1;
         }
-        out[cc] = acc;
-      }
+        for (int e = 0; e < E; ++e) {
+          float s = 0.f;
 #pragma unroll
-      for (int cc = 0; cc < 32; ++cc)
-        if (cc < mid) dl[cc * VV + r] = out[cc];
+          for (int q = 0; q < 16; ++q) s += cls[q] == e ? line[q] : 0.f;
+          s = col ? -s : s;
+          dst[e * m * V] = h == 0 ? s : dst[e * m * V] + s;
+        }
+      }
     }
   }
   __syncthreads();
-  // row/col sums + Gram backward: thread = (k,c,j)
-  for (int o = tid; o < KSUB * mid * V; o += NT) {
-    const int k = o / (mid * V), rr = o - k * mid * V, c = rr / V, j = rr - c * V;
-    const float* dk = (k == 1) ? ddelta + ((size_t)n * mid + c) * VV : dd_n + (size_t)(k * mid + c) * VV;
-    float rs = 0.f, cs = 0.f;
-    {
-      float rv[32], cv[32];
+  // row/col sums (k = 0, 2) + Gram backward + the edge-typed linear's transpose (k = 1): thread = (k,c,j)
+  {
+    const float* dP = PQ;
+    const float* dQ = PQ + E * m * V;
+    for (int o = tid; o < KSUB * m * V; o += NT) {
+      const int k = o / (m * V), rr = o - k * m * V, c = rr / V, j = rr - c * V;
+      float rs = 0.f, cs = 0.f;
+      if (k != 1) {
+        const float* dk = dd_n + (size_t)(k * m + c) * VV;
 #pragma unroll
-      for (int w = 0; w < 32; ++w) {
-        rv[w] = (w < V) ? dk[j * V + w] : 0.f;
-        cv[w] = (w < V) ? dk[w * V + j] : 0.f;
+        for (int w0 = 0; w0 < 32; w0 += 8) {
+          float rv[8], cv[8];
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            rv[b] = (w0 + b < V) ? dk[j * V + w0 + b] : 0.f;
+            cv[b] = (w0 + b < V) ? dk[(w0 + b) * V + j] : 0.f;
+          }
+#pragma unroll
+          for (int b = 0; b < 8; ++b) { rs += rv[b]; cs += cv[b]; }
+        }
+      } else {
+        // d a1[c,j] = sum_{e,c'} We[e,c',c] dP_e[c',j];  d b1[c,j] = sum_{e,c'} We[e,c',c] dQ_e[c',j]   (cs carries -d b1)
+        const int nec = E * m;
+        int ec = 0;
+        for (; ec + 8 <= nec; ec += 8) {
+          float wv[8];
+#pragma unroll
+          for (int b = 0; b < 8; ++b) wv[b] = we[(size_t)(ec + b) * m + c];
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            rs = fmaf(wv[b], dP[(ec + b) * V + j], rs);
+            cs = fmaf(-wv[b], dQ[(ec + b) * V + j], cs);
+          }
+        }
+        for (; ec < nec; ++ec) {
+          const float wv = we[(size_t)ec * m + c];
+          rs = fmaf(wv, dP[ec * V + j], rs);
+          cs = fmaf(-wv, dQ[ec * V + j], cs);
+        }
       }
-#pragma unroll
-      for (int w = 0; w < 32; ++w) { rs += rv[w]; cs += cv[w]; }
+      const float* x1 = X + (slot_x1(k) * m + c) * V;
+      const float* x2 = X + (slot_x2(k) * m + c) * V;
+      const float* dG = SC + k * VV;
+      float g1 = 0.f, g2 = 0.f;
+      for (int w = 0; w < V; ++w) g1 = fmaf(dG[j * V + w], x2[w], g1);   // d x1_k[c,j]
+      for (int u = 0; u < V; ++u) g2 = fmaf(dG[u * V + j], x1[u], g2);   // d x2_k[c,j]
+      if (k < 2) {
+        dX[(slot_x1(k) * m + c) * V + j] = rs + g1;
+        dX[(slot_x2(k) * m + c) * V + j] = g2 - cs;
+      } else {
+        dX[(2 * m + c) * V + j] = rs - cs + g1 + g2;
+      }
     }
-    const float* x1 = X + (slot_x1(k) * mid + c) * V;
-    const float* x2 = X + (slot_x2(k) * mid + c) * V;
-    const float* dG = SC + k * VV;
-    float g1 = 0.f, g2 = 0.f;
-    for (int w = 0; w < V; ++w) g1 = fmaf(dG[j * V + w], x2[w], g1);   // d x1_k[c,j]
-    for (int u = 0; u < V; ++u) g2 = fmaf(dG[u * V + j], x1[u], g2);   // d x2_k[c,j]
-    if (k < 2) {
-      dX[(slot_x1(k) * mid + c) * V + j] = rs + g1;
-      dX[(slot_x2(k) * mid + c) * V + j] = g2 - cs;
-    } else {
-      dX[(2 * mid + c) * V + j] = rs - cs + g1 + g2;
+    // dWe[e,c,cc] = sum_u dP_e[c,u] a1[cc,u] + sum_w dQ_e[c,w] b1[cc,w];  dbe[e,c] = sum_u dP_e[c,u]   (this sample)
+    const float* a1 = X + 1 * m * V;
+    const float* b1 = X + 4 * m * V;
+    float* pwe = par + KSUB * VV + 6;
+    float* pbe = pwe + E * m * m;
+    for (int o = tid; o < E * m * m; o += NT) {
+      const int ec = o / m, cc = o - ec * m;
+      float acc = 0.f;
+      for (int u = 0; u < V; ++u) acc = fmaf(dP[ec * V + u], a1[cc * V + u], acc);
+      for (int w = 0; w < V; ++w) acc = fmaf(dQ[ec * V + w], b1[cc * V + w], acc);
+      pwe[o] = acc;
+    }
+    for (int ec = tid; ec < E * m; ec += NT) {
+      float acc = 0.f;
+      for (int u = 0; u < V; ++u) acc += dP[ec * V + u];
+      pbe[ec] = acc;
     }
   }
   __syncthreads();
-  // dproj rows [a (2mid) | b (2mid) | s-typed (mid*P)]
-  float* dp_n = dproj + (size_t)n * 9 * mid * V;
-  for (int o = tid; o < 9 * mid * V; o += NT) {
-    const int q = o / V, v = o - q * V;
-    float val;
-    if (q < 2 * mid) { const int slot = q / mid, c = q - slot * mid; val = dX[(slot * mid + c) * V + v]; }
-    else if (q < 4 * mid) { const int r = q - 2 * mid; val = dX[((3 + r / mid) * mid + r % mid) * V + v]; }
-    else {
-      const int rr = q - 4 * mid, c = rr / d.P, p = rr - c * d.P;
-      val = (node_type[v] == p) ? dX[(2 * mid + c) * V + v] : 0.f;
+  // dproj rows [a (2m) | b (2m) | s-typed (m*P)]
+  {
+    const int R = 4 * m + m * d.P;
+    float* dp_n = dproj + (size_t)n * R * V;
+    for (int o = tid; o < R * V; o += NT) {
+      const int q = o / V, v = o - q * V;
+      float val;
+      if (q < 2 * m) val = dX[q * V + v];                                          // slots 0,1 = rows 0..2m-1
+      else if (q < 4 * m) val = dX[(3 * m + (q - 2 * m)) * V + v];                 // slots 3,4
+      else {
+        const int rr = q - 4 * m, c = rr / d.P, p = rr - c * d.P;
+        val = (node_type[v] == p) ? dX[(2 * m + c) * V + v] : 0.f;
+      }
+      dp_n[o] = val;
     }
-    dp_n[o] = val;
   }
   // block-reduce the six scalar partials
   float vals[6] = {pal0, pal1, pal2, pbe0, pbe1, pbe2};
@@ -289,69 +360,12 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
   if (tid < 6) {
     float r = 0.f;
     for (int i = 0; i < NT / DSGCN_WAVE; ++i) r += red[tid][i];
-    pab[(size_t)n * pstride + tid] = r;
-  }
-}
-
-// Edge-typed weight gradient: one workgroup per (sample, edge class e).
-//   dWe[e,c,cc] += sum_{(u,w) in class e} dD1[n,c,u,w] * (a1[n,cc,u] - b1[n,cc,w]);   dbe[e,c] += sum dD1[n,c,u,w]
-// The class's pairs (<= 256) are staged in LDS once (dD1 column and delta column per pair), then every (c,cc) output is a
-// short LDS dot product; results are accumulated into dwe/dbe with float atomics (128 adders per address).
-__global__ __launch_bounds__(NT_DWE) void k_dynadj_dwe(DynDims d, const float* __restrict__ proj,
-                                                   const float* __restrict__ dd, const int* __restrict__ pair_order,
-                                                   const int* __restrict__ class_start, float* __restrict__ dwe,
-                                                   float* __restrict__ dbe) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int n = blockIdx.x, e = blockIdx.y;
-  const int mid = d.mid, V = d.V, VV = V * V;
-  const int p0 = class_start[e], np = class_start[e + 1] - p0;
-  if (np <= 0) return;
-  const int NPs = np | 1;
-  float* Dl = lds;                      // [mid][NPs]  dD1[c][pair]
-  float* El = lds + mid * NPs;          // [mid][NPs]  delta[cc][pair]
-  const float* dd1 = dd + ((size_t)n * KSUB + 1) * mid * VV;
-  const float* a1 = proj + ((size_t)n * 9 * mid + 1 * mid) * V;           // rows mid..2mid-1  (a, k=1)
-  const float* b1 = proj + ((size_t)n * 9 * mid + 3 * mid) * V;           // rows 3mid..4mid-1 (b, k=1)
-  for (int i0 = threadIdx.x; i0 < mid * np; i0 += NT_DWE * 4) {
-    float dv[4], ev[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = i0 + q * NT_DWE;
-      dv[q] = 0.f; ev[q] = 0.f;
-      if (i < mid * np) {
-        const int c = i / np, p = i - c * np;
-        const int r = pair_order[p0 + p];
-        const int u = r / V, w = r - u * V;
-        dv[q] = dd1[c * VV + r];
-        ev[q] = a1[c * V + u] - b1[c * V + w];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = i0 + q * NT_DWE;
-      if (i < mid * np) {
-        const int c = i / np, p = i - c * np;
-        Dl[c * NPs + p] = dv[q];
-        El[c * NPs + p] = ev[q];
-      }
-    }
-  }
-  __syncthreads();
-  for (int o = threadIdx.x; o < mid * mid; o += NT_DWE) {
-    const int c = o / mid, cc = o - c * mid;
-    float acc = 0.f, accb = 0.f;
-    for (int p = 0; p < np; ++p) {
-      const float g = Dl[c * NPs + p];
-      acc = fmaf(g, El[cc * NPs + p], acc);
-      accb += g;
-    }
-    atomicAdd(dwe + (size_t)e * mid * mid + o, acc);
-    if (cc == 0) atomicAdd(dbe + e * mid + c, accb);
+    par[KSUB * VV + tid] = r;
   }
 }
 
 size_t dyn_lds_bytes(int mid, int V, int E, bool bwd) {
-  size_t f = 5 * (size_t)mid * V + 3 * (size_t)V * V + 3 * (size_t)V * 2 + (size_t)E * mid * mid + (size_t)E * mid;
+  size_t f = 5 * (size_t)mid * V + 3 * (size_t)V * V + 3 * (size_t)V * 2 + 2 * (size_t)E * mid * V;
   if (bwd) f += 3 * (size_t)V * V + 5 * (size_t)mid * V;
   return f * sizeof(float);
 }
@@ -360,53 +374,49 @@ size_t dyn_lds_bytes(int mid, int V, int E, bool bwd) {
 
 extern "C" {
 
+// floats per sample of the backward's parameter-partial buffer
+int dsgcn_dynadj_partial_stride(int mid, int V, int E) { return KSUB * V * V + 6 + E * mid * mid + E * mid; }
+
 int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, const float* beta, const float* we,
                      const float* be, const int* node_type, const int* edge_type, float* ahat, int n, int mid, int V,
                      int P, int E, void* stream) {
-  if (!proj || !A || !ahat || !we || !be || n <= 0 || mid <= 0) return DSGCN_EINVAL;
+  if (!proj || !A || !alpha || !beta || !ahat || !we || !be || !node_type || !edge_type || n <= 0 || mid <= 0)
+    return DSGCN_EINVAL;
   if (V > 32 || mid > 32) return DSGCN_EUNSUPPORTED;
   const size_t lds = dyn_lds_bytes(mid, V, E, false);
-  if (lds > 156 * 1024) return DSGCN_EUNSUPPORTED;
+  if (lds > 158 * 1024) return DSGCN_EUNSUPPORTED;
   DynDims d{n, 0, mid, V, P, E};
   static size_t attr_fwd = 64 * 1024;      // raised once per size class (not a stream op: keep it out of graph capture)
   if (lds > attr_fwd) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_fwd = 156 * 1024;
+    attr_fwd = 158 * 1024;
   }
-  hipLaunchKernelGGL(k_dynadj_fwd, dim3(n, n <= 128 ? 2 : 1), dim3(NT), lds, (hipStream_t)stream, d, proj, A, alpha, beta, we, be,
-                     node_type, edge_type, ahat);
+  hipLaunchKernelGGL(k_dynadj_fwd, dim3(n, n <= 128 ? 2 : 1), dim3(NT), lds, (hipStream_t)stream, d, proj, A, alpha, beta,
+                     we, be, node_type, edge_type, ahat);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
 
 int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
-                     const int* node_type, const int* edge_type, const int* pair_order, const int* class_start,
-                     const float* dahat, float* dd_ws, float* ddelta_ws, float* dproj, float* pA, float* pab,
-                     int pstride, float* dwe, float* dbe, int n, int mid, int V, int P, int E, void* stream) {
-  if (!proj || !dahat || !dd_ws || !ddelta_ws || !dproj || !pA || !pab || !dwe || !dbe) return DSGCN_EINVAL;
+                     const int* node_type, const int* edge_type, const float* dahat, float* dd_ws, float* dproj,
+                     float* ppar, int pstride, int n, int mid, int V, int P, int E, void* stream) {
+  if (!proj || !alpha || !beta || !we || !be || !node_type || !edge_type || !dahat || !dd_ws || !dproj || !ppar ||
+      n <= 0 || mid <= 0)
+    return DSGCN_EINVAL;
   if (V > 32 || mid > 32) return DSGCN_EUNSUPPORTED;
+  if (pstride < dsgcn_dynadj_partial_stride(mid, V, E)) return DSGCN_EINVAL;
   const size_t lds = dyn_lds_bytes(mid, V, E, true);
-  if (lds > 156 * 1024) return DSGCN_EUNSUPPORTED;
+  if (lds > 158 * 1024) return DSGCN_EUNSUPPORTED;
   DynDims d{n, 0, mid, V, P, E};
-  hipStream_t st = (hipStream_t)stream;
   static size_t attr_bwd = 64 * 1024;
   if (lds > attr_bwd) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_bwd = 156 * 1024;
+    attr_bwd = 158 * 1024;
   }
-  hipLaunchKernelGGL(k_dynadj_bwd, dim3(n), dim3(NT), lds, st, d, proj, alpha, beta, we, be, node_type, edge_type,
-                     pair_order, class_start, dahat, dd_ws, ddelta_ws, dproj, pA, pab, pstride);
-  DSGCN_LAUNCH_CHECK();
-  const size_t lds2 = (size_t)2 * mid * ((V * V) | 1) * sizeof(float);   // worst case: one class holds every pair
-  static size_t attr_dwe = 64 * 1024;
-  if (lds2 > attr_dwe) {
-    hipError_t e2 = hipFuncSetAttribute((const void*)k_dynadj_dwe, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    if (e2 != hipSuccess) return (int)e2;
-    attr_dwe = 156 * 1024;
-  }
-  hipLaunchKernelGGL(k_dynadj_dwe, dim3(n, E), dim3(NT_DWE), lds2, st, d, proj, dd_ws, pair_order, class_start, dwe, dbe);
+  hipLaunchKernelGGL(k_dynadj_bwd, dim3(n), dim3(NT), lds, (hipStream_t)stream, d, proj, alpha, beta, we, be, node_type,
+                     edge_type, dahat, dd_ws, dproj, ppar, pstride);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

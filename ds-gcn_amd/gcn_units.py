@@ -158,10 +158,6 @@ class dgphgcn1(nn.Module):
                              persistent=False)
         self.register_buffer('edge_type_idx', torch.as_tensor(edge_type).to(torch.int32).contiguous(),
                              persistent=False)
-        # pair lists of the edge-typed weight gradient (K-B backward): owned by the module, like the type tables
-        order, start = kernels.edge_class_lists(self.edge_type_idx, edge_num * self.semantic_num)
-        self.register_buffer('edge_order_idx', order, persistent=False)
-        self.register_buffer('edge_start_idx', start, persistent=False)
         # parameter creation order follows the reference ctor (same RNG consumption, same key order)
         self.A = nn.Parameter(A.clone())
         self.pre = nn.Sequential(nn.Conv2d(in_channels, mid * K, 1), _norm_layer(norm, mid * K), nn.ReLU())
@@ -185,8 +181,7 @@ class dgphgcn1(nn.Module):
         return kernels.ops().dynadj(
             xbar, self.A, self.alpha, self.beta,
             c1.weight.flatten(1), c1.bias, c2.weight.flatten(1), c2.bias, cs.weight.flatten(1), cs.bias,
-            el.weight.flatten(1), el.bias, self.node_type_idx, self.edge_type_idx,
-            (self.edge_order_idx, self.edge_start_idx))
+            el.weight.flatten(1), el.bias, self.node_type_idx, self.edge_type_idx)
 
     def forward_deferred(self, x, xbar=None, x_res=None):
         """x_res: an alias of x for the residual operand (lets the caller route the gradients of the two uses of x

@@ -210,24 +210,11 @@ def aggregate(zp, ap, relu, ahat):
 # K-B  dynamic adjacency
 # ---------------------------------------------------------------------------------------------
 
-def edge_class_lists(edge_type, num_classes=None):
-    """Joint pairs sorted by edge class + class offsets (int32, on edge_type's device): the index tables of the
-    edge-typed weight gradient.  Built once per module (dgphgcn1 keeps them as buffers next to edge_type); nothing is
-    cached here."""
-    et = edge_type.flatten().to(torch.int64)
-    order = torch.argsort(et, stable=True).to(torch.int32)
-    E = int(num_classes) if num_classes is not None else int(et.max().item()) + 1
-    counts = torch.bincount(et, minlength=E)
-    start = torch.zeros(E + 1, dtype=torch.int32, device=edge_type.device)
-    start[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    return order.contiguous(), start.contiguous()
-
-
 class _DynAdj(torch.autograd.Function):
-    """proj (n, 9*mid, V) rows [a | b | s-typed] -> Ahat (n, 3*mid, V, V)."""
+    """proj (n, (4+P)*mid, V) rows [a | b | s-typed] -> Ahat (n, 3*mid, V, V)  (K-B, one HIP launch each way)."""
 
     @staticmethod
-    def forward(ctx, proj, A, alpha, beta, we, be, node_type, edge_type, order, start):
+    def forward(ctx, proj, A, alpha, beta, we, be, node_type, edge_type):
         _require_cuda(proj, A)
         proj, A, alpha, beta, we, be = [_f32c(t) for t in (proj, A, alpha, beta, we, be)]
         n, R, V = proj.shape
@@ -239,44 +226,41 @@ class _DynAdj(torch.autograd.Function):
         rc = native.lib().dsgcn_dynadj_fwd(_ptr(proj), _ptr(A), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be),
                                            _ptr(node_type), _ptr(edge_type), _ptr(ahat), n, mid, V, P, E, _stream())
         native.check(rc, 'dsgcn_dynadj_fwd')
-        ctx.save_for_backward(proj, A, alpha, beta, we, be, node_type, edge_type, order, start)
+        ctx.save_for_backward(proj, alpha, beta, we, be, node_type, edge_type)
         ctx.dims = (n, mid, V, P, E)
         return ahat
 
     @staticmethod
     def backward(ctx, dahat):
-        proj, A, alpha, beta, we, be, node_type, edge_type, order, start = ctx.saved_tensors
+        proj, alpha, beta, we, be, node_type, edge_type = ctx.saved_tensors
         n, mid, V, P, E = ctx.dims
         dahat = _f32c(dahat)
         dev = proj.device
+        lib = native.lib()
         dd = torch.empty_like(dahat)
-        ddelta = torch.empty((n, mid, V, V), device=dev, dtype=torch.float32)
         dproj = torch.empty_like(proj)
-        pboth = torch.empty((n, 3 * V * V + 6), device=dev, dtype=torch.float32)   # per-sample [sum_c dAhat | dalpha dbeta]
-        pA, pab = pboth, pboth
-        zeros = torch.zeros(E * mid * mid + E * mid, device=dev, dtype=torch.float32)
-        dwe, dbe = torch.split(zeros, [E * mid * mid, E * mid])
-        rc = native.lib().dsgcn_dynadj_bwd(
-            _ptr(proj), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be), _ptr(node_type), _ptr(edge_type), _ptr(order),
-            _ptr(start), _ptr(dahat), _ptr(dd), _ptr(ddelta), _ptr(dproj), pboth.data_ptr(),
-            pboth.data_ptr() + 4 * 3 * V * V, 3 * V * V + 6, _ptr(dwe), _ptr(dbe), n, mid, V, P, E, _stream())
+        pstride = lib.dsgcn_dynadj_partial_stride(mid, V, E)
+        ppar = torch.empty((n, pstride), device=dev, dtype=torch.float32)      # per-sample parameter-gradient partials
+        rc = lib.dsgcn_dynadj_bwd(_ptr(proj), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be), _ptr(node_type),
+                                  _ptr(edge_type), _ptr(dahat), _ptr(dd), _ptr(dproj), _ptr(ppar), pstride, n, mid, V, P,
+                                  E, _stream())
         native.check(rc, 'dsgcn_dynadj_bwd')
-        red = colsum(pboth)
-        dA, dab = red[:3 * V * V].view(3, V, V), red[3 * V * V:]
-        return dproj, dA, dab[:3], dab[3:], dwe.view(E * mid, mid), dbe, None, None, None, None
+        red = colsum(ppar)                                                      # ordered sum over samples: deterministic
+        o = 3 * V * V
+        dA, dalpha, dbeta = red[:o].view(3, V, V), red[o:o + 3], red[o + 3:o + 6]
+        dwe = red[o + 6:o + 6 + E * mid * mid].view(E * mid, mid)
+        dbe = red[o + 6 + E * mid * mid:o + 6 + E * mid * mid + E * mid]
+        return dproj, dA, dalpha, dbeta, dwe, dbe, None, None
 
 
-def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type, edge_lists=None):
+def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type):
     """Dynamic adjacency.  The three mean-pooled projections (conv1/conv2/conv1_se) are one K-C launch on xbar
-    (a (n,Ci,1,V) "clip"), the rest is K-B.  edge_lists: (pair order, class offsets) from edge_class_lists — pass the
-    module's buffers; built on the fly when omitted."""
+    (a (n,Ci,1,V) "clip"), the rest is K-B."""
     n, Ci, V = xbar.shape
-    if edge_lists is None:
-        edge_lists = edge_class_lists(edge_type, we.shape[0] // we.shape[1])
     w_all = torch.cat([w1, w2, wse], 0)
     b_all = torch.cat([b1, b2, bse], 0)
     proj = pwconv(xbar.unsqueeze(2), None, None, None, False, w_all, b_all, 1, False)[0]
-    return _DynAdj.apply(proj.view(n, w_all.shape[0], V), A, alpha, beta, we, be, node_type, edge_type, *edge_lists)
+    return _DynAdj.apply(proj.view(n, w_all.shape[0], V), A, alpha, beta, we, be, node_type, edge_type)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -43,24 +43,23 @@ int dsgcn_aggregate_bwd(const float* zp, const float* scale, const float* shift,
                         const float* dy, float* dzp, float* dahat, float* partial, int n, int KC, int T, int V,
                         void* stream);
 
-/* K-B dynamic-semantic adjacency.  Replaces gcn.py:2240-2337 (node-typed select of conv1_se, the edge-typed
- * linear with its 625-iteration index loop, tanh, Gram + Softmax(-2), alpha/beta scale-add).  K = 3 subsets.
- *   proj (n,9*mid,V): rows [conv1 (2mid) | conv2 (2mid) | conv1_se (mid*P, row c*P+p)] applied to the time-mean
+/* K-B dynamic-semantic adjacency.  Replaces gcn.py:2240-2337 (node-typed select of conv1_se 2256-2259, the edge-typed
+ * linear with its 625-iteration index loop 2279-2288, tanh 2298, Gram + Softmax(-2) 2314-2326, alpha/beta scale-add
+ * 2304-2337).  K = 3 subsets.
+ *   proj (n,(4+P)*mid,V): rows [conv1 (2mid) | conv2 (2mid) | conv1_se (mid*P, row c*P+p)] applied to the time-mean
  *        of the unit input (computed by dsgcn_pwconv_fwd on xbar viewed as (n,Ci,1,V));
  *   A (3,V,V); alpha,beta (3);  we (E*mid,mid) row e*mid+c, be (E*mid)
- *   node_type (V) int32 in [0,P);  edge_type (V*V) int32 in [0,E);  ahat out (n,3*mid,V,V).  V <= 32, mid <= 32. */
+ *   node_type (V) int32 in [0,P);  edge_type (V*V) int32 in [0,E);  ahat out (n,3*mid,V,V).  V <= 32, mid <= 32.
+ * Backward: dd_ws workspace (n,3*mid,V,V); outputs dproj (n,(4+P)*mid,V) and ppar (n, pstride >=
+ * dsgcn_dynadj_partial_stride): per-sample partials [sum_c dAhat (3*V*V) | dalpha (3) | dbeta (3) | dwe (E*mid*mid) |
+ * dbe (E*mid)] — their sum over samples (dsgcn_colsum: ordered, no float atomics) gives dA, dalpha, dbeta, dwe, dbe. */
+int dsgcn_dynadj_partial_stride(int mid, int V, int E);
 int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, const float* beta, const float* we,
                      const float* be, const int* node_type, const int* edge_type, float* ahat, int n, int mid, int V,
                      int P, int E, void* stream);
-
-/* Backward of K-B.  pair_order (V*V) = joint pairs sorted by edge class, class_start (E+1) = offsets.
- * dd_ws: workspace (n,3*mid,V,V); ddelta_ws: workspace (n,mid,V,V).  Outputs: dproj (n,9*mid,V); pA (n,3,V,V)
- * (sum over n = dA; sample s at pA + s*pstride); pab (n,6) (at pab + s*pstride)
- * (sum over n = [dalpha|dbeta]); dwe (E*mid,mid), dbe (E*mid): ACCUMULATED with float atomics — caller zeroes. */
 int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
-                     const int* node_type, const int* edge_type, const int* pair_order, const int* class_start,
-                     const float* dahat, float* dd_ws, float* ddelta_ws, float* dproj, float* pA, float* pab,
-                     int pstride, float* dwe, float* dbe, int n, int mid, int V, int P, int E, void* stream);
+                     const int* node_type, const int* edge_type, const float* dahat, float* dd_ws, float* dproj,
+                     float* ppar, int pstride, int n, int mid, int V, int P, int E, void* stream);
 
 /* Block output (materialise once): out = relu?(x1*s1+h1 (+ x2*s2+h2 | + x2)), xbar = mean_t out (optional).
  * Replaces BN + residual add + ReLU of dgstgcn.py:63-65 / tcn.py:427 and x.mean(-2) of gcn.py:2246.
