@@ -27,7 +27,7 @@ namespace {
 constexpr int KSUB = 3;     // subsets: 2 plain + 1 semantic
 constexpr int NT = 1024;    // the LDS image allows one workgroup per CU, so it brings all 16 waves
 
-struct DynDims { int n, Ci, mid, V, P, E; };
+struct DynDims { int n, ld, mid, V, P, E; };     // ld: joint stride of the proj / dproj rows (>= V; 32 = padded)
 
 // LDS carve (floats):  X [5][mid][V] | G [3][V][V] | col [3][V][2] | PQ [2][E][mid][V] | (bwd: SC [3][V][V] dX [5][mid][V])
 __device__ __forceinline__ int lds_X(const DynDims& d) { return 0; }
@@ -61,7 +61,7 @@ __device__ void dyn_prepare(const DynDims& d, float* lds, const float* __restric
   for (int o = tid; o < 5 * m * V; o += NT) {
     const int q = o / V, v = o - q * V;
     const int slot = q / m, c = q - slot * m;
-    X[o] = proj_n[proj_row(d, slot, c, node_type[v]) * V + v];
+    X[o] = proj_n[proj_row(d, slot, c, node_type[v]) * d.ld + v];
   }
   __syncthreads();
   for (int i = tid; i < KSUB * V * V; i += NT) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d, const float* __res
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n = blockIdx.x;
   const int m = d.mid, V = d.V, VV = V * V;
-  dyn_prepare(d, lds, proj + (size_t)n * (4 + d.P) * m * V, we, be, node_type);
+  dyn_prepare(d, lds, proj + (size_t)n * (4 + d.P) * m * d.ld, we, be, node_type);
   const float* X = lds + lds_X(d);
   const float* Sm = lds + lds_G(d);
   const float* PQ = lds + lds_PQ(d);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
   const int tid = threadIdx.x;
   const int n = blockIdx.x;
   const int m = d.mid, V = d.V, VV = V * V, E = d.E;
-  dyn_prepare(d, lds, proj + (size_t)n * (4 + d.P) * m * V, we, be, node_type);
+  dyn_prepare(d, lds, proj + (size_t)n * (4 + d.P) * m * d.ld, we, be, node_type);
   const float* X = lds + lds_X(d);
   const float* Sm = lds + lds_G(d);
   float* PQ = lds + lds_PQ(d);
@@ -332,18 +332,20 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     }
   }
   __syncthreads();
-  // dproj rows [a (2m) | b (2m) | s-typed (m*P)]
+  // dproj rows [a (2m) | b (2m) | s-typed (m*P)], joint stride ld (padding columns are written as zeros)
   {
-    const int R = 4 * m + m * d.P;
-    float* dp_n = dproj + (size_t)n * R * V;
-    for (int o = tid; o < R * V; o += NT) {
-      const int q = o / V, v = o - q * V;
-      float val;
-      if (q < 2 * m) val = dX[q * V + v];                                          // slots 0,1 = rows 0..2m-1
-      else if (q < 4 * m) val = dX[(3 * m + (q - 2 * m)) * V + v];                 // slots 3,4
-      else {
-        const int rr = q - 4 * m, c = rr / d.P, p = rr - c * d.P;
-        val = (node_type[v] == p) ? dX[(2 * m + c) * V + v] : 0.f;
+    const int R = 4 * m + m * d.P, ld = d.ld;
+    float* dp_n = dproj + (size_t)n * R * ld;
+    for (int o = tid; o < R * ld; o += NT) {
+      const int q = o / ld, v = o - q * ld;
+      float val = 0.f;
+      if (v < V) {
+        if (q < 2 * m) val = dX[q * V + v];                                          // slots 0,1 = rows 0..2m-1
+        else if (q < 4 * m) val = dX[(3 * m + (q - 2 * m)) * V + v];                 // slots 3,4
+        else {
+          const int rr = q - 4 * m, c = rr / d.P, p = rr - c * d.P;
+          val = (node_type[v] == p) ? dX[(2 * m + c) * V + v] : 0.f;
+        }
       }
       dp_n[o] = val;
     }
@@ -379,13 +381,13 @@ int dsgcn_dynadj_partial_stride(int mid, int V, int E) { return KSUB * V * V + 6
 
 int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, const float* beta, const float* we,
                      const float* be, const int* node_type, const int* edge_type, float* ahat, int n, int mid, int V,
-                     int P, int E, void* stream) {
+                     int ld, int P, int E, void* stream) {
   if (!proj || !A || !alpha || !beta || !ahat || !we || !be || !node_type || !edge_type || n <= 0 || mid <= 0)
     return DSGCN_EINVAL;
-  if (V > 32 || mid > 32) return DSGCN_EUNSUPPORTED;
+  if (V > 32 || mid > 32 || ld < V) return DSGCN_EUNSUPPORTED;
   const size_t lds = dyn_lds_bytes(mid, V, E, false);
   if (lds > 158 * 1024) return DSGCN_EUNSUPPORTED;
-  DynDims d{n, 0, mid, V, P, E};
+  DynDims d{n, ld, mid, V, P, E};
   static size_t attr_fwd = 64 * 1024;      // raised once per size class (not a stream op: keep it out of graph capture)
   if (lds > attr_fwd) {
     hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
@@ -400,15 +402,15 @@ int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, cons
 
 int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
                      const int* node_type, const int* edge_type, const float* dahat, float* dd_ws, float* dproj,
-                     float* ppar, int pstride, int n, int mid, int V, int P, int E, void* stream) {
+                     float* ppar, int pstride, int n, int mid, int V, int ld, int P, int E, void* stream) {
   if (!proj || !alpha || !beta || !we || !be || !node_type || !edge_type || !dahat || !dd_ws || !dproj || !ppar ||
       n <= 0 || mid <= 0)
     return DSGCN_EINVAL;
-  if (V > 32 || mid > 32) return DSGCN_EUNSUPPORTED;
+  if (V > 32 || mid > 32 || ld < V) return DSGCN_EUNSUPPORTED;
   if (pstride < dsgcn_dynadj_partial_stride(mid, V, E)) return DSGCN_EINVAL;
   const size_t lds = dyn_lds_bytes(mid, V, E, true);
   if (lds > 158 * 1024) return DSGCN_EUNSUPPORTED;
-  DynDims d{n, 0, mid, V, P, E};
+  DynDims d{n, ld, mid, V, P, E};
   static size_t attr_bwd = 64 * 1024;
   if (lds > attr_bwd) {
     hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);

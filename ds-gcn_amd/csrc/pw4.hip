@@ -363,6 +363,9 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p) {
   const int mtiles = (M + 31) / 32;
   int MT = mtiles >= 2 ? 2 : 1;
   if (mtiles == 3) { MT = 3; NQ = 2; }
+  // tiny planes (the dynamic-adjacency projections: 32 padded joints per sample): the launch is a latency chain of K/2
+  // k-steps on few waves, so give every wave the smallest tile (1 x 2 MFMAs per k-step) and the grid the most waves
+  if (L <= 64 && (long)n * ((L + 127) / 128) < 1024) { NQ = 2; MT = 1; }
   if (g_p4_nq == 2 || (g_p4_nq == 4 && L % 4 == 0)) NQ = g_p4_nq;
   if (g_p4_mt) MT = g_p4_mt < mtiles ? g_p4_mt : mtiles;
   if (MT * NQ > 8) NQ = 2;

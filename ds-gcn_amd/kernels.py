@@ -70,6 +70,8 @@ class side_branch:
                 _side_streams[dev] = torch.cuda.Stream(device=dev)
             self.side = _side_streams[dev]
             self.main = torch.cuda.current_stream(dev)
+            if self.main == self.side:            # already inside a forked region (e.g. K-B's backward): no nesting
+                self.enabled = False
 
     def __enter__(self):
         if self.enabled:
@@ -211,29 +213,31 @@ def aggregate(zp, ap, relu, ahat):
 # ---------------------------------------------------------------------------------------------
 
 class _DynAdj(torch.autograd.Function):
-    """proj (n, (4+P)*mid, V) rows [a | b | s-typed] -> Ahat (n, 3*mid, V, V)  (K-B, one HIP launch each way)."""
+    """proj (n, (4+P)*mid, ld) rows [a | b | s-typed] (ld >= V: padded joint stride) -> Ahat (n, 3*mid, V, V)
+    (K-B, one HIP launch each way)."""
 
     @staticmethod
     def forward(ctx, proj, A, alpha, beta, we, be, node_type, edge_type):
         _require_cuda(proj, A)
         proj, A, alpha, beta, we, be = [_f32c(t) for t in (proj, A, alpha, beta, we, be)]
-        n, R, V = proj.shape
+        n, R, ld = proj.shape
+        V = A.shape[-1]
         mid = we.shape[1]
         E = we.shape[0] // mid
         P = (R // mid - 4)
         assert A.shape[0] == 3 and node_type.dtype == torch.int32 and edge_type.dtype == torch.int32
         ahat = torch.empty((n, 3 * mid, V, V), device=proj.device, dtype=torch.float32)
         rc = native.lib().dsgcn_dynadj_fwd(_ptr(proj), _ptr(A), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be),
-                                           _ptr(node_type), _ptr(edge_type), _ptr(ahat), n, mid, V, P, E, _stream())
+                                           _ptr(node_type), _ptr(edge_type), _ptr(ahat), n, mid, V, ld, P, E, _stream())
         native.check(rc, 'dsgcn_dynadj_fwd')
         ctx.save_for_backward(proj, alpha, beta, we, be, node_type, edge_type)
-        ctx.dims = (n, mid, V, P, E)
+        ctx.dims = (n, mid, V, ld, P, E)
         return ahat
 
     @staticmethod
     def backward(ctx, dahat):
         proj, alpha, beta, we, be, node_type, edge_type = ctx.saved_tensors
-        n, mid, V, P, E = ctx.dims
+        n, mid, V, ld, P, E = ctx.dims
         dahat = _f32c(dahat)
         dev = proj.device
         lib = native.lib()
@@ -242,8 +246,8 @@ class _DynAdj(torch.autograd.Function):
         pstride = lib.dsgcn_dynadj_partial_stride(mid, V, E)
         ppar = torch.empty((n, pstride), device=dev, dtype=torch.float32)      # per-sample parameter-gradient partials
         rc = lib.dsgcn_dynadj_bwd(_ptr(proj), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be), _ptr(node_type),
-                                  _ptr(edge_type), _ptr(dahat), _ptr(dd), _ptr(dproj), _ptr(ppar), pstride, n, mid, V, P,
-                                  E, _stream())
+                                  _ptr(edge_type), _ptr(dahat), _ptr(dd), _ptr(dproj), _ptr(ppar), pstride, n, mid, V, ld,
+                                  P, E, _stream())
         native.check(rc, 'dsgcn_dynadj_bwd')
         red = colsum(ppar)                                                      # ordered sum over samples: deterministic
         o = 3 * V * V
@@ -254,13 +258,16 @@ class _DynAdj(torch.autograd.Function):
 
 
 def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type):
-    """Dynamic adjacency.  The three mean-pooled projections (conv1/conv2/conv1_se) are one K-C launch on xbar
-    (a (n,Ci,1,V) "clip"), the rest is K-B."""
+    """Dynamic adjacency.  The three mean-pooled projections (conv1/conv2/conv1_se) are one K-C launch on xbar — viewed
+    as a (n, Ci, 1, 32) "clip" with the joint rows zero-padded to 32, so that forward, data gradient and weight gradient
+    all take the 16-byte-per-lane K-C kernels (an unpadded 25-joint row is odd-sized: it fell to the scalar-load kernels,
+    ~35 us per launch for 0.1 GFLOP) — and the rest is K-B reading / writing the padded rows."""
     n, Ci, V = xbar.shape
     w_all = torch.cat([w1, w2, wse], 0)
     b_all = torch.cat([b1, b2, bse], 0)
-    proj = pwconv(xbar.unsqueeze(2), None, None, None, False, w_all, b_all, 1, False)[0]
-    return _DynAdj.apply(proj.view(n, w_all.shape[0], V), A, alpha, beta, we, be, node_type, edge_type)
+    xpad = torch.nn.functional.pad(xbar, (0, 32 - V)) if V < 32 else xbar
+    proj = pwconv(xpad.unsqueeze(2), None, None, None, False, w_all, b_all, 1, False)[0]
+    return _DynAdj.apply(proj.view(n, w_all.shape[0], xpad.shape[-1]), A, alpha, beta, we, be, node_type, edge_type)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -352,6 +359,8 @@ class _PwConv(torch.autograd.Function):
                                     _ptr(z), _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), _ptr(dx1),
                                     _ptr(dx2), _ptr(ipart), n, Ci, Co, T, V, stride, aug, st)
         native.check(rc, 'dsgcn_pwconv_dgrad')
+        # (the weight gradient on a second stream beside the data gradient was measured: 17.65 vs 17.68 ms/step — both
+        # launches are HBM-bound, so it stays on the one stream)
         splits = lib.dsgcn_pwconv_wgrad_splits(n, Ci, Co, T, V, stride)
         pstride = Co * Ci + Co
         wpart = torch.empty((splits, pstride), device=dev, dtype=torch.float32)
@@ -536,6 +545,8 @@ class _TapBranches(torch.autograd.Function):
                                      _ptr_array(ws), _stream())
         native.check(rc, 'dsgcn_tapconv_dgrad')
         Tout = go.shape[2]
+        if 0 not in types:                 # pooling / pass-through windows only: nothing to learn
+            return (dh, None, None, None, None, None, None, None, None, None, *([None] * (2 * nbr)))
         offs, off = [], 0
         for t, ci, co in zip(types, cins, couts):
             offs.append(off)
@@ -669,6 +680,14 @@ def temporal_branches_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, con
     KT, types, c0s, bcs, dils, ws, bs = _branch_tables(branch_cfg, widths, conv_w, conv_b)
     o = _TapBranches.apply(h, int(stride), KT, C, types, c0s, c0s, bcs, bcs, dils, *ws, *bs)
     return _plane_bn(o, gamma, beta, eps, want_bn)
+
+
+def strided_frames(x, stride):
+    """x (n,C,T,V) -> x[:, :, ::stride] as a contiguous tensor (tapconv's pass-through window: one HIP launch; the
+    backward scatters into a zero-filled tensor)."""
+    _require_cuda(x)
+    C = x.shape[1]
+    return _TapBranches.apply(x, int(stride), 3, C, [2], [0], [0], [C], [C], [1], None, None)
 
 
 def tconv(h, weight, bias, stride, dilation, gamma=None, beta=None, eps=1e-5, want_bn=False):

@@ -36,10 +36,17 @@ class unit_tcn(nn.Module):
         d = as_deferred(x)
         has_bn = isinstance(self.bn, nn.BatchNorm2d)
         if self.kernel_size == 1:
+            stride = self.stride
+            if stride > 1 and d.a1 is None and d.x2 is None and not d.relu and hasattr(ops, 'strided_frames'):
+                # a plain input (the block residual): pick the kept frames first (one strided-copy launch, tapconv's
+                # pass-through window) and run the channel mix on the compact tensor — the strided 1x1 conv has only the
+                # scalar-load kernels (planes of every other 25-joint row are not 16-byte runs): 290 -> ~125 us per block
+                d = Deferred(ops.strided_frames(d.x1, stride), None, None, None, False)
+                stride = 1
             if has_bn:
-                z, _, az = conv_bn(d.x1, d.a1, d.x2, d.a2, d.relu, self.conv, self.stride, False, self.bn)
+                z, _, az = conv_bn(d.x1, d.a1, d.x2, d.a2, d.relu, self.conv, stride, False, self.bn)
                 return Deferred(z, az, None, None, False)
-            z = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, self.conv.weight, self.conv.bias, self.stride, False)[0]
+            z = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, self.conv.weight, self.conv.bias, stride, False)[0]
             return Deferred(z, None, None, None, False)
         # the dense temporal conv reads a materialised tensor (zero padding applies to the activated values)
         h = d.x1 if (d.a1 is None and d.x2 is None and not d.relu) else d.materialize()

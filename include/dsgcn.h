@@ -46,20 +46,21 @@ int dsgcn_aggregate_bwd(const float* zp, const float* scale, const float* shift,
 /* K-B dynamic-semantic adjacency.  Replaces gcn.py:2240-2337 (node-typed select of conv1_se 2256-2259, the edge-typed
  * linear with its 625-iteration index loop 2279-2288, tanh 2298, Gram + Softmax(-2) 2314-2326, alpha/beta scale-add
  * 2304-2337).  K = 3 subsets.
- *   proj (n,(4+P)*mid,V): rows [conv1 (2mid) | conv2 (2mid) | conv1_se (mid*P, row c*P+p)] applied to the time-mean
- *        of the unit input (computed by dsgcn_pwconv_fwd on xbar viewed as (n,Ci,1,V));
+ *   proj (n,(4+P)*mid,ld): rows [conv1 (2mid) | conv2 (2mid) | conv1_se (mid*P, row c*P+p)] applied to the time-mean
+ *        of the unit input (computed by dsgcn_pwconv_fwd on xbar viewed as (n,Ci,1,ld)); ld >= V is the joint stride of a
+ *        row (32: rows zero-padded so the K-C kernels take their 16-byte-per-lane path);
  *   A (3,V,V); alpha,beta (3);  we (E*mid,mid) row e*mid+c, be (E*mid)
  *   node_type (V) int32 in [0,P);  edge_type (V*V) int32 in [0,E);  ahat out (n,3*mid,V,V).  V <= 32, mid <= 32.
- * Backward: dd_ws workspace (n,3*mid,V,V); outputs dproj (n,(4+P)*mid,V) and ppar (n, pstride >=
+ * Backward: dd_ws workspace (n,3*mid,V,V); outputs dproj (n,(4+P)*mid,ld) (padding columns zero) and ppar (n, pstride >=
  * dsgcn_dynadj_partial_stride): per-sample partials [sum_c dAhat (3*V*V) | dalpha (3) | dbeta (3) | dwe (E*mid*mid) |
  * dbe (E*mid)] — their sum over samples (dsgcn_colsum: ordered, no float atomics) gives dA, dalpha, dbeta, dwe, dbe. */
 int dsgcn_dynadj_partial_stride(int mid, int V, int E);
 int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, const float* beta, const float* we,
                      const float* be, const int* node_type, const int* edge_type, float* ahat, int n, int mid, int V,
-                     int P, int E, void* stream);
+                     int ld, int P, int E, void* stream);
 int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
                      const int* node_type, const int* edge_type, const float* dahat, float* dd_ws, float* dproj,
-                     float* ppar, int pstride, int n, int mid, int V, int P, int E, void* stream);
+                     float* ppar, int pstride, int n, int mid, int V, int ld, int P, int E, void* stream);
 
 /* Block output (materialise once): out = relu?(x1*s1+h1 (+ x2*s2+h2 | + x2)), xbar = mean_t out (optional).
  * Replaces BN + residual add + ReLU of dgstgcn.py:63-65 / tcn.py:427 and x.mean(-2) of gcn.py:2246.
