@@ -47,6 +47,11 @@ def other_cfg(kind, num_classes=60, **bk):
     'stgcnpp' (configs/stgcn++), 'ctrgcn' (classic CTR-GCN, BASELINE config 4)."""
     if kind == 'ctrgcn':
         backbone = dict(type='CTRGCN', gcn_type='unit_ctrgcn', graph_cfg=dict(layout='nturgb+d', mode='spatial'))
+    elif kind == 'ctrgcn_shipped':        # configs/ctrgcn/CTRGCN_model.py: unit_ctrhgcn + msmlp on the random graph
+        backbone = dict(type='CTRGCN', gcn_type='unit_ctrhgcn', gcn_node_attention=True, gcn_edge_attention=True,
+                        gcn_add_type=False, gcn_ada=True, gcn_num_types=5, gcn_rel_reduction=8, gcn_edge_num=15,
+                        tcn_type='msmlp', tcn_add_tcn=True, tcn_merge_after=True,
+                        graph_cfg=dict(layout='nturgb+d', mode='random', num_filter=3, init_off=.04, init_std=.02))
     elif kind == 'stgcnpp':
         backbone = dict(type='STGCN', gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn',
                         graph_cfg=dict(layout='nturgb+d', mode='spatial'))

@@ -12,8 +12,8 @@ from .builder import (MODELS, BACKBONES, HEADS, LOSSES, NECKS, RECOGNIZERS, buil
 from .evaluation import top_k_accuracy, mean_class_accuracy, confusion_matrix
 from .losses import CrossEntropyLoss
 from .heads import GCNHead, SimpleHead
-from .gcn_units import dgphgcn1, unit_gcn, unit_ctrgcn, CTRGC, Deferred
-from .tcn_units import dgmstcn, mstcn, unit_tcn, MSTCN
+from .gcn_units import dgphgcn1, unit_gcn, unit_ctrgcn, unit_ctrhgcn, CTRGC, CTRHGC, Deferred
+from .tcn_units import dgmstcn, mstcn, msmlp, unitmlp, unit_tcn, MSTCN
 from .backbones import DGSTGCN, STGCN, CTRGCN, DGBlock, STGCNBlock, CTRGCNBlock
 from .recognizers import RecognizerGCN, reduce_log_vars, gather_results
 from . import kernels
@@ -21,6 +21,6 @@ from . import pipeline
 from .pipeline import PIPELINES, DATASETS, Compose, PoseDataset, SkeletonStore, SkeletonBatcher, build_dataset
 from .data_parallel import FlatParams, FlatDataParallel, shard_batch
 from .train import FlatSGD, cosine_lr
-from .checkpoint import load_checkpoint, save_checkpoint, resume, find_resume
+from .checkpoint import load_checkpoint, save_checkpoint, resume, find_resume, fuse_conv_bn
 
 __version__ = '0.1.0'

@@ -14,9 +14,9 @@ import torch.nn as nn
 
 from . import kernels
 from .builder import BACKBONES
-from .gcn_units import dgphgcn1, unit_ctrgcn, unit_gcn, flush_running_stats
+from .gcn_units import dgphgcn1, unit_ctrgcn, unit_ctrhgcn, unit_gcn, flush_running_stats
 from .graph import Graph
-from .tcn_units import MSTCN, dgmstcn, mstcn, unit_tcn
+from .tcn_units import MSTCN, dgmstcn, msmlp, mstcn, unit_tcn
 
 EPS = 1e-4
 
@@ -142,12 +142,18 @@ class CTRGCNBlock(_FusedBlock):
         assert tcn_type in ['unit_tcn', 'mstcn', 'unit_tcnedge', 'unitmlp', 'msmlp']
         gcn_type = gcn_kwargs.pop('type', 'unit_ctrhgcn')
         assert gcn_type in ['unit_ctrgcn', 'unit_ctrhgcn']
-        if gcn_type != 'unit_ctrgcn' or tcn_type != 'mstcn':
-            raise NotImplementedError(f'{gcn_type}/{tcn_type}: the HIP path covers classic CTR-GCN (unit_ctrgcn + mstcn); '
-                                      'the unit_ctrhgcn/msmlp variant is SURVEY §8 f-1')
-        self.gcn1 = unit_ctrgcn(in_channels, out_channels, A, **gcn_kwargs)
-        self.tcn1 = MSTCN(out_channels, out_channels, kernel_size=kernel_size, stride=stride, dilations=dilations,
-                          residual=False, tcn_dropout=tcn_dropout)
+        if tcn_type not in ('mstcn', 'msmlp'):
+            raise NotImplementedError(f'tcn_type={tcn_type}: the HIP path covers mstcn (classic CTR-GCN) and msmlp (the '
+                                      'shipped configs/ctrgcn/CTRGCN_model.py)')
+        if gcn_type == 'unit_ctrgcn':
+            self.gcn1 = unit_ctrgcn(in_channels, out_channels, A, **gcn_kwargs)
+        else:
+            self.gcn1 = unit_ctrhgcn(in_channels, out_channels, A, edge_type, node_type, semantic_index, **gcn_kwargs)
+        if tcn_type == 'mstcn':
+            self.tcn1 = MSTCN(out_channels, out_channels, kernel_size=kernel_size, stride=stride, dilations=dilations,
+                              residual=False, tcn_dropout=tcn_dropout)
+        else:
+            self.tcn1 = msmlp(out_channels, out_channels, stride=stride, **tcn_kwargs)
         self.relu = nn.ReLU(inplace=True)
         self._set_residual(in_channels, out_channels, stride, residual)
 

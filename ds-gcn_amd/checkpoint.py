@@ -68,3 +68,36 @@ def find_resume(work_dir, resume_from=None, auto_resume=True):
         return resume_from
     path = os.path.join(work_dir, 'latest.pth')
     return path if auto_resume and os.path.exists(path) else None
+
+
+@torch.no_grad()
+def fuse_conv_bn(module):
+    """Inference-time folding of every ``Conv2d -> BatchNorm2d`` pair that sits back to back in a container (what the
+    reference's ``tools/test.py --fuse-conv-bn`` does through mmcv.cnn.fuse_conv_bn, tools/test.py:98-99): the conv takes
+    ``w * gamma / sqrt(var + eps)`` and ``(b - mean) * gamma / sqrt(var + eps) + beta``, the BatchNorm becomes the identity
+    (gamma 1, beta 0, mean 0, var 1 - eps... kept as a BatchNorm2d so the module tree and state_dict keys do not change).
+    Eval mode only: with training statistics the fold is meaningless.  Returns ``module``."""
+    import torch.nn as nn
+    last_conv = None
+    for name, child in module.named_children():
+        if isinstance(child, nn.BatchNorm2d):
+            if last_conv is not None and child.track_running_stats and last_conv.out_channels == child.num_features:
+                scale = child.weight / torch.sqrt(child.running_var + child.eps)
+                last_conv.weight.mul_(scale.view(-1, 1, 1, 1))
+                bias = last_conv.bias if last_conv.bias is not None else torch.zeros_like(child.running_mean)
+                new_bias = (bias - child.running_mean) * scale + child.bias
+                if last_conv.bias is None:
+                    last_conv.bias = nn.Parameter(new_bias)
+                else:
+                    last_conv.bias.copy_(new_bias)
+                child.weight.fill_(1.0)
+                child.bias.zero_()
+                child.running_mean.zero_()
+                child.running_var.fill_(1.0 - child.eps)          # so that 1 / sqrt(var + eps) is exactly 1
+            last_conv = None
+        elif isinstance(child, nn.Conv2d):
+            last_conv = child
+        else:
+            last_conv = None
+            fuse_conv_bn(child)
+    return module

@@ -3,7 +3,11 @@
 //
 //   tanhdiff   : d[k,n,r,u,v] = tanh(x1[n,k,r,u] - x2[n,k,r,v])            gcn.py:653-655 (after the mean over T)
 //                proj (n, 2*K*R, V): rows [k*R + r] = conv1_k(xbar), rows [K*R + k*R + r] = conv2_k(xbar)
-//   ctr_affine : Ahat[n, k*Co + c, u, v] = alpha * S_k[n,c,u,v] + A[k,u,v]  gcn.py:657  (S_k = conv4_k(d[k]) from K-C)
+//   ctr_affine : Ahat[n, k*Co + c, u, v] = alpha_k * S_k[n,c,u,v] + A[k,u,v] (+ beta_k * G[n,k,u,v])
+//                gcn.py:657 (classic: one shared alpha, no G; S_k = conv4_k(d[k]) from K-C); gcn.py:755-760 (CTRHGC:
+//                alpha per subset and the "ada" Gram term G_k = x1_k^T x2_k scaled by the subset's beta)
+//   edge_select: out[n,r,u,v] = in[n, eps(u,v)*R + r, u, v]                 gcn.py:737-745 (CTRHGC edge attention: the
+//                edge-typed conv computes all E variants; each joint pair keeps the one of its edge class)
 //   plane_stats: per-(n,c) sum / sum of squares of a tensor (the BatchNorms that follow a temporal conv / max-pool in
 //                MSTCN, msg3d_utils.py:101-117) -> dsgcn_bn_finalize
 // All are HBM-bound streaming passes, one wave per V*V (or T*V) plane.
@@ -71,8 +75,9 @@ __global__ __launch_bounds__(64) void k_tanhdiff_bwd(const float* __restrict__ d
 }
 
 // one wave per (n, k, c)
-__global__ __launch_bounds__(64) void k_ctr_affine_fwd(CtrPtrs p, const float* __restrict__ alpha,
-                                                       const float* __restrict__ A, float* __restrict__ ahat, int K,
+__global__ __launch_bounds__(64) void k_ctr_affine_fwd(CtrPtrs p, const float* __restrict__ alpha, int astride,
+                                                       const float* __restrict__ A, const float* __restrict__ beta,
+                                                       const float* __restrict__ G, float* __restrict__ ahat, int K,
                                                        int Co, int VV) {
   const int lane = threadIdx.x;
   const long unit = blockIdx.x;                // (n*K + k)*Co + c
@@ -80,16 +85,22 @@ __global__ __launch_bounds__(64) void k_ctr_affine_fwd(CtrPtrs p, const float* _
   const long nk = unit / Co;
   const int k = (int)(nk % K);
   const long i = nk / K;
-  const float al = alpha[0];
+  const float al = alpha[k * astride];
   const float* __restrict__ s = p.s[k] + ((size_t)i * Co + c) * VV;
   const float* __restrict__ a = A + (size_t)k * VV;
   float* __restrict__ o = ahat + (size_t)unit * VV;
-  for (int e = lane; e < VV; e += 64) o[e] = fmaf(al, s[e], a[e]);
+  if (G) {
+    const float bt = beta[k];
+    const float* __restrict__ g = G + (size_t)nk * VV;
+    for (int e = lane; e < VV; e += 64) o[e] = fmaf(bt, g[e], fmaf(al, s[e], a[e]));
+  } else {
+    for (int e = lane; e < VV; e += 64) o[e] = fmaf(al, s[e], a[e]);
+  }
 }
 
 // one block per (n, k, channel slice): dS_k = alpha*dAhat ; prow (n*CS, K*VV + K): [sum_c dAhat[k,e] | sum dAhat*S] over
 // the slice's channels (row = n*CS + slice; the caller's column sum adds the slices and the samples)
-__global__ __launch_bounds__(256) void k_ctr_affine_bwd(CtrPtrs p, const float* __restrict__ alpha,
+__global__ __launch_bounds__(256) void k_ctr_affine_bwd(CtrPtrs p, const float* __restrict__ alpha, int astride,
                                                         const float* __restrict__ dahat, float* __restrict__ prow,
                                                         int K, int Co, int VV) {
   __shared__ float red[4];
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(256) void k_ctr_affine_bwd(CtrPtrs p, const float* 
   const long nk = blockIdx.x;
   const int k = (int)(nk % K);
   const long i = nk / K;
-  const float al = alpha[0];
+  const float al = alpha[k * astride];
   const float* __restrict__ g = dahat + (size_t)nk * Co * VV;
   const float* __restrict__ s = p.s[k] + (size_t)i * Co * VV;
   float* __restrict__ ds = p.ds[k] + (size_t)i * Co * VV;
@@ -129,6 +140,31 @@ __global__ __launch_bounds__(256) void k_ctr_affine_bwd(CtrPtrs p, const float* 
   if ((tid & 63) == 0) red[tid >> 6] = acca;
   __syncthreads();
   if (tid == 0) out[(size_t)K * VV + k] = red[0] + red[1] + red[2] + red[3];
+}
+
+// edge-typed select: thread = (n, r, pair); in (n, E*R, VV), out (n, R, VV)
+__global__ __launch_bounds__(256) void k_edge_select_fwd(const float* __restrict__ in, const int* __restrict__ et,
+                                                         float* __restrict__ out, int R, int E, int VV, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int e = (int)(idx % VV);
+  const long nr = idx / VV;
+  const int r = (int)(nr % R);
+  const long i = nr / R;
+  out[idx] = in[((size_t)i * E * R + (size_t)et[e] * R + r) * VV + e];
+}
+
+// backward: din (n, E*R, VV) = dout at the selected class, zero elsewhere (every element is written)
+__global__ __launch_bounds__(256) void k_edge_select_bwd(const float* __restrict__ dout, const int* __restrict__ et,
+                                                         float* __restrict__ din, int R, int E, int VV, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // over (n, E*R, VV)
+  if (idx >= total) return;
+  const int e = (int)(idx % VV);
+  const long nc = idx / VV;
+  const int ch = (int)(nc % (E * R));
+  const long i = nc / (E * R);
+  const int cls = ch / R, r = ch - cls * R;
+  din[idx] = (et[e] == cls) ? dout[((size_t)i * R + r) * VV + e] : 0.f;
 }
 
 // one wave per plane of L elements: partial[plane] = [sum, sum of squares]
@@ -184,23 +220,26 @@ int dsgcn_tanhdiff_bwd(const float* d, const float* dd, float* dproj, int n, int
   return 0;
 }
 
-int dsgcn_ctr_affine_fwd(const float* const* s, const float* alpha, const float* A, float* ahat, int n, int K, int Co,
-                         int V, void* stream) {
-  if (!s || !alpha || !A || !ahat || n <= 0 || K <= 0 || K > CTR_MAXK || Co <= 0 || V <= 0) return DSGCN_EINVAL;
+int dsgcn_ctr_affine_fwd(const float* const* s, const float* alpha, int alpha_stride, const float* A, const float* beta,
+                         const float* G, float* ahat, int n, int K, int Co, int V, void* stream) {
+  if (!s || !alpha || !A || !ahat || n <= 0 || K <= 0 || K > CTR_MAXK || Co <= 0 || V <= 0 || (G && !beta) ||
+      (alpha_stride != 0 && alpha_stride != 1))
+    return DSGCN_EINVAL;
   CtrPtrs p = {};
   for (int k = 0; k < K; ++k) {
     if (!s[k]) return DSGCN_EINVAL;
     p.s[k] = s[k];
   }
-  hipLaunchKernelGGL(k_ctr_affine_fwd, dim3((unsigned)((long)n * K * Co)), dim3(64), 0, (hipStream_t)stream, p, alpha, A,
-                     ahat, K, Co, V * V);
+  hipLaunchKernelGGL(k_ctr_affine_fwd, dim3((unsigned)((long)n * K * Co)), dim3(64), 0, (hipStream_t)stream, p, alpha,
+                     alpha_stride, A, beta, G, ahat, K, Co, V * V);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
 
-int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, const float* dahat, float* const* ds, float* prow,
-                         int n, int K, int Co, int V, void* stream) {
-  if (!s || !alpha || !dahat || !ds || !prow || n <= 0 || K <= 0 || K > CTR_MAXK || Co <= 0 || V <= 0 || V * V > 1024)
+int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, int alpha_stride, const float* dahat,
+                         float* const* ds, float* prow, int n, int K, int Co, int V, void* stream) {
+  if (!s || !alpha || !dahat || !ds || !prow || n <= 0 || K <= 0 || K > CTR_MAXK || Co <= 0 || V <= 0 || V * V > 1024 ||
+      (alpha_stride != 0 && alpha_stride != 1))
     return DSGCN_EINVAL;
   CtrPtrs p = {};
   for (int k = 0; k < K; ++k) {
@@ -209,7 +248,25 @@ int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, const float*
     p.ds[k] = ds[k];
   }
   hipLaunchKernelGGL(k_ctr_affine_bwd, dim3((unsigned)((long)n * K), (unsigned)DSGCN_CTR_SLICES), dim3(256), 0,
-                     (hipStream_t)stream, p, alpha, dahat, prow, K, Co, V * V);
+                     (hipStream_t)stream, p, alpha, alpha_stride, dahat, prow, K, Co, V * V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+int dsgcn_edge_select_fwd(const float* in, const int* edge_type, float* out, int n, int R, int E, int V, void* stream) {
+  if (!in || !edge_type || !out || n <= 0 || R <= 0 || E <= 0 || V <= 0) return DSGCN_EINVAL;
+  const long total = (long)n * R * V * V;
+  hipLaunchKernelGGL(k_edge_select_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     edge_type, out, R, E, V * V, total);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+int dsgcn_edge_select_bwd(const float* dout, const int* edge_type, float* din, int n, int R, int E, int V, void* stream) {
+  if (!dout || !edge_type || !din || n <= 0 || R <= 0 || E <= 0 || V <= 0) return DSGCN_EINVAL;
+  const long total = (long)n * E * R * V * V;
+  hipLaunchKernelGGL(k_edge_select_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout,
+                     edge_type, din, R, E, V * V, total);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -185,3 +185,130 @@ int dsgcn_tms_combine_bwd(const float* o, const float* coeff, const float* gf, c
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Depthwise causal temporal taps of unitmlp (reference: pyskl/models/gcns/utils/tcn.py:525-614: F.pad on the left, then
+// a grouped Conv1d with groups = channels over the frames of every joint, tcn.py:586-592):
+//   y[n,c,t',v] = b[c] + sum_j w[c,j] * h[n,c, t'*s - (KM-1-j)*dil[c], v]        (frames < 0 read as zero)
+// dil[c] = 0 marks channels outside the mlp windows (the max-pool / pass-through branches of msmlp): y = 0 there.
+// One wave per (n,c) plane; the backward also leaves the per-plane sums for dw (KM) and db.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int DW_MAXK = 4;
+
+__global__ __launch_bounds__(64) void k_dwcausal_fwd(const float* __restrict__ h, const float* __restrict__ w,
+                                                     const float* __restrict__ b, const int* __restrict__ dil,
+                                                     float* __restrict__ y, int C, int T, int Tout, int V, int stride,
+                                                     int KM) {
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const int d = dil[c];
+  float* __restrict__ py = y + (size_t)plane * Tout * V;
+  const int L = Tout * V;
+  if (d == 0) {
+    for (int i = lane; i < L; i += 64) py[i] = 0.f;
+    return;
+  }
+  const float* __restrict__ ph = h + (size_t)plane * T * V;
+  float wk[DW_MAXK];
+#pragma unroll
+  for (int j = 0; j < DW_MAXK; ++j) wk[j] = j < KM ? w[c * KM + j] : 0.f;
+  const float bc = b ? b[c] : 0.f;
+  for (int i = lane; i < L; i += 64) {
+    const int tp = i / V, v = i - tp * V;
+    float acc = bc;
+#pragma unroll
+    for (int j = 0; j < DW_MAXK; ++j) {
+      const int t = tp * stride - (KM - 1 - j) * d;
+      if (j < KM && t >= 0 && t < T) acc = fmaf(wk[j], ph[t * V + v], acc);
+    }
+    py[i] = acc;
+  }
+}
+
+// dh[n,c,t,v] = sum_j w[c,j] * dy[n,c,t',v] with t'*s - (KM-1-j)*d = t;  part[plane] = [dw_0..dw_{KM-1}, db]
+__global__ __launch_bounds__(64) void k_dwcausal_bwd(const float* __restrict__ h, const float* __restrict__ w,
+                                                     const int* __restrict__ dil, const float* __restrict__ dy,
+                                                     float* __restrict__ dh, float* __restrict__ part, int C, int T,
+                                                     int Tout, int V, int stride, int KM) {
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const int d = dil[c];
+  float* __restrict__ pdh = dh + (size_t)plane * T * V;
+  float* __restrict__ pp = part + (size_t)plane * (DW_MAXK + 1);
+  if (d == 0) {
+    for (int i = lane; i < T * V; i += 64) pdh[i] = 0.f;
+    if (lane <= DW_MAXK) pp[lane] = 0.f;
+    return;
+  }
+  const float* __restrict__ ph = h + (size_t)plane * T * V;
+  const float* __restrict__ pg = dy + (size_t)plane * Tout * V;
+  float wk[DW_MAXK], sw[DW_MAXK];
+#pragma unroll
+  for (int j = 0; j < DW_MAXK; ++j) { wk[j] = j < KM ? w[c * KM + j] : 0.f; sw[j] = 0.f; }
+  float sb = 0.f;
+  for (int i = lane; i < T * V; i += 64) {
+    const int t = i / V, v = i - t * V;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < DW_MAXK; ++j) {
+      const int num = t + (KM - 1 - j) * d;
+      if (j < KM && num % stride == 0) {
+        const int tp = num / stride;
+        if (tp < Tout) acc = fmaf(wk[j], pg[tp * V + v], acc);
+      }
+    }
+    pdh[i] = acc;
+  }
+  for (int i = lane; i < Tout * V; i += 64) {
+    const int tp = i / V, v = i - tp * V;
+    const float g = pg[i];
+    sb += g;
+#pragma unroll
+    for (int j = 0; j < DW_MAXK; ++j) {
+      const int t = tp * stride - (KM - 1 - j) * d;
+      if (j < KM && t >= 0 && t < T) sw[j] = fmaf(g, ph[t * V + v], sw[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < DW_MAXK; ++j) sw[j] = wave_sum(sw[j]);
+  sb = wave_sum(sb);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < DW_MAXK; ++j) pp[j] = sw[j];
+    pp[DW_MAXK] = sb;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsgcn_dwcausal_fwd(const float* h, const float* w, const float* b, const int* dil, float* y, int n, int C, int T,
+                       int V, int stride, int KM, void* stream) {
+  if (!h || !w || !dil || !y || n <= 0 || C <= 0 || T <= 0 || V <= 0 || stride <= 0 || KM < 1 || KM > DW_MAXK)
+    return DSGCN_EINVAL;
+  const int Tout = (T + stride - 1) / stride;
+  hipLaunchKernelGGL(k_dwcausal_fwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, h, w, b, dil, y, C, T,
+                     Tout, V, stride, KM);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// part (n*C, 5): per-plane [dw_0, dw_1, dw_2, dw_3, db]; the sum over n gives the parameter gradients
+int dsgcn_dwcausal_bwd(const float* h, const float* w, const int* dil, const float* dy, float* dh, float* part, int n,
+                       int C, int T, int V, int stride, int KM, void* stream) {
+  if (!h || !w || !dil || !dy || !dh || !part || n <= 0 || C <= 0 || T <= 0 || V <= 0 || stride <= 0 || KM < 1 ||
+      KM > DW_MAXK)
+    return DSGCN_EINVAL;
+  const int Tout = (T + stride - 1) / stride;
+  hipLaunchKernelGGL(k_dwcausal_bwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, h, w, dil, dy, dh,
+                     part, C, T, Tout, V, stride, KM);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -379,3 +379,102 @@ class unit_ctrgcn(nn.Module):
         _kaiming_conv_init(self)
         nn.init.constant_(self.bn.weight, 1e-6)
         nn.init.constant_(self.bn.bias, 0)
+
+
+class CTRHGC(nn.Module):
+    """One subset of the heterogeneous CTR unit (reference: gcn.py:668-771).  Owns the parameters; the arithmetic of the K
+    subsets runs batched in ``unit_ctrhgcn.forward_deferred``.  Supported flag set = what the shipped CTR-GCN config
+    reaches (configs/ctrgcn/CTRGCN_model.py through unit_ctrhgcn's per-subset overrides): no node attention, optional
+    edge attention (reduced channels), optional ``ada`` Gram term; target_specific / full_channels / add_type raise."""
+
+    def __init__(self, in_channels, out_channels, rel_reduction=8, node_attention=True, edge_attention=False,
+                 target_specific=False, full_channels=False, add_type=False, ada=False, num_types=5, edge_num=15,
+                 semantic_index=False):
+        super().__init__()
+        if (node_attention and semantic_index) or target_specific or full_channels or add_type:
+            raise NotImplementedError('CTRHGC: node attention / target_specific / full_channels / add_type have no HIP path')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.node_attention, self.edge_attention = node_attention, edge_attention
+        self.num_types, self.edge_num, self.ada, self.semantic_index = num_types, edge_num, ada, semantic_index
+        if ada:
+            self.beta = nn.Parameter(torch.zeros(1))
+        self.rel_channels = 8 if in_channels <= 16 else in_channels // rel_reduction
+        self.conv1 = nn.Conv2d(in_channels, self.rel_channels, kernel_size=1)
+        self.conv2 = nn.Conv2d(in_channels, self.rel_channels, kernel_size=1)
+        if edge_attention and semantic_index:
+            self.edge_att_conv = nn.Conv2d(self.rel_channels, edge_num * self.rel_channels, 1)
+        self.conv4 = nn.Conv2d(self.rel_channels, out_channels, kernel_size=1)
+        self.conv3 = nn.Conv2d(in_channels, out_channels, 1)
+        self.tanh = nn.Tanh()
+        _kaiming_conv_init(self)
+
+
+class unit_ctrhgcn(nn.Module):
+    """Heterogeneous CTR-GCN spatial unit (reference: gcn.py:773-880): like ``unit_ctrgcn`` with a learnable scale per
+    subset, an edge-typed attention conv on the first subset (each joint pair keeps the variant of its edge class) and
+    the Gram term ``beta_k * x1_k^T x2_k`` (``ada``).  Quirk kept: the constructor's per-subset overrides leave node
+    attention off everywhere and edge attention on for subset 0 only (gcn.py:801-842)."""
+
+    def __init__(self, in_channels, out_channels, A, edge_type, node_type, semantic_index=False, rel_reduction=8,
+                 node_attention=False, edge_attention=False, target_specific=False, full_channels=False, add_type=False,
+                 ada=False, num_types=5, edge_num=15):
+        super().__init__()
+        self.inter_c, self.out_c, self.in_c = out_channels // 4, out_channels, in_channels
+        self.num_subset = A.shape[0]
+        self.register_buffer('edge_type_idx', torch.as_tensor(edge_type).to(torch.int32).reshape(-1).contiguous(),
+                             persistent=False)
+        self.convs = nn.ModuleList()
+        for i in range(self.num_subset):
+            if i == 0:
+                node_attention = False
+            if i >= 1:
+                edge_attention = False
+            if i == 2:
+                node_attention = False
+            if i <= 2:
+                self.convs.append(CTRHGC(in_channels, out_channels, rel_reduction=rel_reduction,
+                                         node_attention=node_attention, edge_attention=edge_attention,
+                                         target_specific=target_specific, full_channels=full_channels, add_type=add_type,
+                                         ada=ada, num_types=num_types, edge_num=edge_num, semantic_index=semantic_index))
+        if in_channels != out_channels:
+            self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels))
+        else:
+            self.down = None
+        self.A = nn.Parameter(A.clone())
+        self.alpha = nn.Parameter(torch.zeros(self.A.size(0)))
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.soft = nn.Softmax(-2)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward_deferred(self, x, xbar=None, x_res=None):
+        ops = kernels.ops()
+        x_res = x if x_res is None else x_res
+        if xbar is None:
+            xbar = ops.tmean(x)
+        cs = self.convs
+        edge = {k: (c.edge_att_conv.weight.flatten(1), c.edge_att_conv.bias, self.edge_type_idx)
+                for k, c in enumerate(cs) if hasattr(c, 'edge_att_conv')}
+        beta = torch.cat([c.beta for c in cs]) if all(c.ada for c in cs) else None
+        ahat = ops.ctr_topology(
+            xbar, torch.cat([c.conv1.weight.flatten(1) for c in cs], 0), torch.cat([c.conv1.bias for c in cs], 0),
+            torch.cat([c.conv2.weight.flatten(1) for c in cs], 0), torch.cat([c.conv2.bias for c in cs], 0),
+            [c.conv4.weight.flatten(1) for c in cs], [c.conv4.bias for c in cs], self.alpha, self.A, beta, edge)
+        w3 = torch.cat([c.conv3.weight.flatten(1) for c in cs], 0)
+        b3 = torch.cat([c.conv3.bias for c in cs], 0)
+        x3 = ops.pwconv(x, None, None, None, False, w3, b3, 1, False)[0]
+        y, ay = op_bn(self.bn, lambda g, b, eps, want: ops.aggregate_sum(x3, ahat, self.num_subset, g, b, eps, want),
+                      lambda y: y.shape[0] * y.shape[2] * y.shape[3])
+        if self.down is None:
+            return Deferred(y, ay, x_res, None, True)
+        zd, _, ad = conv_bn(x_res, None, None, None, False, self.down[0], 1, False, self.down[1])
+        return Deferred(y, ay, zd, ad, True)
+
+    def forward(self, x):
+        out = self.forward_deferred(x).materialize()
+        flush_running_stats()
+        return out
+
+    def init_weights(self):
+        _kaiming_conv_init(self)
+        nn.init.constant_(self.bn.weight, 1e-6)
+        nn.init.constant_(self.bn.bias, 0)

@@ -682,6 +682,64 @@ def temporal_branches_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, con
     return _plane_bn(o, gamma, beta, eps, want_bn)
 
 
+class _DwCausal(torch.autograd.Function):
+    """Depthwise causal temporal taps (unitmlp's grouped Conv1d) over the mlp windows of h; zero elsewhere."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, dil, stride):
+        _require_cuda(h, w)
+        h, w, b = _f32c(h), _f32c(w), _f32c(b)
+        n, C, T, V = h.shape
+        KM = w.shape[1]
+        Tout = (T + stride - 1) // stride
+        y = torch.empty((n, C, Tout, V), device=h.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_dwcausal_fwd(_ptr(h), _ptr(w), _ptr(b), _ptr(dil), _ptr(y), n, C, T, V, stride, KM,
+                                             _stream())
+        native.check(rc, 'dsgcn_dwcausal_fwd')
+        ctx.save_for_backward(h, w, dil)
+        ctx.cfg = (stride, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w, dil = ctx.saved_tensors
+        stride, has_b = ctx.cfg
+        n, C, T, V = h.shape
+        KM = w.shape[1]
+        dy = _f32c(dy)
+        dh = torch.empty_like(h)
+        part = torch.empty((n, C, 5), device=h.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_dwcausal_bwd(_ptr(h), _ptr(w), _ptr(dil), _ptr(dy), _ptr(dh), _ptr(part), n, C, T, V,
+                                             stride, KM, _stream())
+        native.check(rc, 'dsgcn_dwcausal_bwd')
+        red = colsum(part)                                    # (C, 5)
+        return dh, red[:, :KM].contiguous(), (red[:, 4].contiguous() if has_b else None), None, None
+
+
+def temporal_mlp_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, dw_w, dw_b, dw_dil, pw_w, pw_b,
+                    merge_after, stride, gamma=None, beta=None, eps=1e-5, want_bn=False):
+    """msmlp's temporal stage (tcn.py:182-261 with unitmlp 525-614) after the fused branch 1x1 conv: BN+ReLU on channels
+    < n_act, then per mlp window  conv1(dw(h)) + alpha * tconv(h)  (merge_after) or  conv1(dw(h) + alpha * tconv(h)),
+    beside the (3,1) max-pool and the strided pass-through windows; plus the train-mode BN of the result (transform.0) as a
+    deferred affine.  conv_w / conv_b: the (k,1) dilated convs ALREADY scaled by their window's alpha;
+    dw_w (C, KM), dw_b (C), dw_dil (C) int32: depthwise taps per channel (dil 0 outside the mlp windows); pw_w (C, C),
+    pw_b (C): the windows' conv1 as one block-diagonal channel mix (identity / zero blocks for the other windows according
+    to merge_after).  -> (o, scale, shift, mean, var)"""
+    _require_cuda(z)
+    n, C, T, V = z.shape
+    h = _BranchAct.apply(z, None, scale, shift, n_act)
+    KT, types, c0s, bcs, dils, ws, bs = _branch_tables(branch_cfg, widths, conv_w, conv_b)
+    o = _TapBranches.apply(h, int(stride), KT, C, types, c0s, c0s, bcs, bcs, dils, *ws, *bs)
+    dw = _DwCausal.apply(h, dw_w, dw_b, dw_dil, int(stride))
+    if merge_after:
+        u = pwconv(dw, None, None, None, False, pw_w, pw_b, 1, False)[0]
+        out = fuse_out(u, None, o, None, 0, False)[0]
+    else:
+        u = fuse_out(dw, None, o, None, 0, False)[0]
+        out = pwconv(u, None, None, None, False, pw_w, pw_b, 1, False)[0]
+    return _plane_bn(out, gamma, beta, eps, want_bn)
+
+
 def strided_frames(x, stride):
     """x (n,C,T,V) -> x[:, :, ::stride] as a contiguous tensor (tapconv's pass-through window: one HIP launch; the
     backward scatters into a zero-filled tensor)."""
@@ -810,50 +868,104 @@ class _TanhDiff(torch.autograd.Function):
 
 
 class _CtrAffine(torch.autograd.Function):
-    """Ahat (n, K*Co, V, V) = alpha * S_k + A[k]  for the K per-subset conv4 outputs S_k (n, Co, V, V)."""
+    """Ahat (n, K*Co, V, V) = alpha_k * S_k + A[k] (+ beta_k * G[:, k])  for the K per-subset conv4 outputs S_k
+    (n, Co, V, V).  alpha: 1 element (classic CTR-GCN: shared) or K elements (CTRHGC: per subset); G (n, K, V, V) with
+    beta (K): the optional Gram term of CTRHGC's ``ada`` branch."""
 
     @staticmethod
-    def forward(ctx, alpha, A, *S):
+    def forward(ctx, alpha, A, beta, G, *S):
         _require_cuda(A, *S)
-        alpha, A = _f32c(alpha), _f32c(A)
+        alpha, A, beta, G = _f32c(alpha), _f32c(A), _f32c(beta), _f32c(G)
         S = [_f32c(t) for t in S]
         K = len(S)
         n, Co, V, _ = S[0].shape
+        astride = 1 if alpha.numel() == K and K > 1 else 0
+        assert alpha.numel() in (1, K)
         ahat = torch.empty((n, K * Co, V, V), device=A.device, dtype=torch.float32)
-        rc = native.lib().dsgcn_ctr_affine_fwd(_ptr_array(S), _ptr(alpha), _ptr(A), _ptr(ahat), n, K, Co, V, _stream())
+        rc = native.lib().dsgcn_ctr_affine_fwd(_ptr_array(S), _ptr(alpha), astride, _ptr(A), _ptr(beta), _ptr(G),
+                                               _ptr(ahat), n, K, Co, V, _stream())
         native.check(rc, 'dsgcn_ctr_affine_fwd')
-        ctx.save_for_backward(alpha, *S)
+        ctx.save_for_backward(alpha, beta, G, *S)
+        ctx.astride = astride
         return ahat
 
     @staticmethod
     def backward(ctx, dahat):
-        alpha, *S = ctx.saved_tensors
+        alpha, beta, G, *S = ctx.saved_tensors
         K = len(S)
         n, Co, V, _ = S[0].shape
         dahat = _f32c(dahat)
         dS = [torch.empty_like(t) for t in S]
         prow = torch.empty((4 * n, K * V * V + K), device=dahat.device, dtype=torch.float32)   # 4 channel slices
-        rc = native.lib().dsgcn_ctr_affine_bwd(_ptr_array(S), _ptr(alpha), _ptr(dahat), _ptr_array(dS), _ptr(prow), n,
-                                               K, Co, V, _stream())
+        rc = native.lib().dsgcn_ctr_affine_bwd(_ptr_array(S), _ptr(alpha), ctx.astride, _ptr(dahat), _ptr_array(dS),
+                                               _ptr(prow), n, K, Co, V, _stream())
         native.check(rc, 'dsgcn_ctr_affine_bwd')
         red = colsum(prow)
         dA = red[:K * V * V].view(K, V, V)
-        dalpha = colsum(red[K * V * V:].reshape(K, 1))
-        return (dalpha.view_as(alpha), dA, *dS)
+        ds_k = red[K * V * V:]                                      # sum dAhat * S per subset
+        dalpha = ds_k.view_as(alpha) if ctx.astride else colsum(ds_k.reshape(K, 1)).view_as(alpha)
+        dbeta = dG = None
+        if G is not None:
+            # per-sample sum over channels of dAhat (the 4 channel slices of each sample added): KB-sized host-side algebra
+            sumc = prow.view(n, 4, -1)[:, :, :K * V * V].sum(1).view(n, K, V, V)
+            dG = sumc * beta.view(1, K, 1, 1)
+            dbeta = (sumc * G).sum((0, 2, 3))
+        return (dalpha, dA, dbeta, dG, *dS)
 
 
-def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A):
+class _EdgeSelect(torch.autograd.Function):
+    """x (n, E*R, V, V) -> (n, R, V, V): joint pair (u,v) keeps channel eps(u,v)*R + r (CTRHGC edge attention)."""
+
+    @staticmethod
+    def forward(ctx, x, edge_type, R):
+        _require_cuda(x)
+        x = _f32c(x)
+        n, ER, V, _ = x.shape
+        E = ER // R
+        out = torch.empty((n, R, V, V), device=x.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_edge_select_fwd(_ptr(x), _ptr(edge_type), _ptr(out), n, R, E, V, _stream())
+        native.check(rc, 'dsgcn_edge_select_fwd')
+        ctx.save_for_backward(edge_type)
+        ctx.dims = (n, R, E, V)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        edge_type, = ctx.saved_tensors
+        n, R, E, V = ctx.dims
+        dout = _f32c(dout)
+        din = torch.empty((n, E * R, V, V), device=dout.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_edge_select_bwd(_ptr(dout), _ptr(edge_type), _ptr(din), n, R, E, V, _stream())
+        native.check(rc, 'dsgcn_edge_select_bwd')
+        return din, None, None
+
+
+def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None):
     """CTR-GCN refined topology.  xbar (n,Ci,V) = mean_T x; w1,w2 (K*R,Ci) / b1,b2 (K*R): conv1/conv2 of the K
-    subsets stacked (their mean over T commutes with the 1x1 conv); w4[k] (Co,R), b4[k] (Co); alpha (1); A (K,V,V).
-    -> Ahat (n, K*Co, V, V) = alpha * conv4_k(tanh(x1_k[u] - x2_k[v])) + A[k]."""
+    subsets stacked (their mean over T commutes with the 1x1 conv); w4[k] (Co,R), b4[k] (Co); A (K,V,V).
+    alpha (1): classic unit_ctrgcn;  alpha (K) [+ beta (K)]: unit_ctrhgcn — per-subset scale and the Gram term
+    beta_k * x1_k^T x2_k;  edge = {k: (w_edge (E*R,R), b_edge (E*R), edge_type (V*V) int32)}: subsets whose tanh-difference
+    first passes the edge-typed attention conv + select (gcn.py:737-745).
+    -> Ahat (n, K*Co, V, V) = alpha_k * conv4_k(sel_k(tanh(x1_k[u] - x2_k[v]))) + A[k] (+ beta_k G_k)."""
     n, Ci, V = xbar.shape
     K = A.shape[0]
     R = w1.shape[0] // K
     proj = pwconv(xbar.unsqueeze(2), None, None, None, False, torch.cat([w1, w2], 0), torch.cat([b1, b2], 0), 1,
-                  False)[0]
-    d = _TanhDiff.apply(proj.view(n, 2 * K * R, V), K, R)
-    S = [pwconv(d[k], None, None, None, False, w4[k], b4[k], 1, False)[0] for k in range(K)]
-    return _CtrAffine.apply(alpha, A, *S)
+                  False)[0].view(n, 2 * K * R, V)
+    d = _TanhDiff.apply(proj, K, R)
+    S = []
+    for k in range(K):
+        dk = d[k]
+        if edge and k in edge:
+            we, be, et = edge[k]
+            dk = _EdgeSelect.apply(pwconv(dk, None, None, None, False, we, be, 1, False)[0], et, R)
+        S.append(pwconv(dk, None, None, None, False, w4[k], b4[k], 1, False)[0])
+    G = None
+    if beta is not None:      # Gram of the mean-pooled projections per subset: a plain batched GEMM (rocBLAS via torch.bmm)
+        x1 = proj[:, :K * R].reshape(n * K, R, V)
+        x2 = proj[:, K * R:].reshape(n * K, R, V)
+        G = torch.bmm(x1.transpose(1, 2), x2).view(n, K, V, V)
+    return _CtrAffine.apply(alpha, A, beta, G, *S)
 
 
 class _Tee3(torch.autograd.Function):

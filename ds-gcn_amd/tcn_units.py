@@ -334,3 +334,145 @@ class MSTCN(nn.Module):
     def init_weights(self):
         from .gcn_units import _kaiming_conv_init
         _kaiming_conv_init(self)
+
+
+class unitmlp(nn.Module):
+    """Temporal "mlp" unit of the shipped CTR-GCN config (reference: tcn.py:525-614): a depthwise causal Conv1d over the
+    frames of every joint (kernel (k+1)/2, left zero padding), a 1x1 conv, and — ``add_tcn`` — a dilated (k,1) conv of the
+    input scaled by the learnable ``alpha``, merged after (``merge_after``) or before the 1x1 conv.  Owns the parameters;
+    the arithmetic runs batched over the branches in ``msmlp``.  ``channel_annention`` raises."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=5, stride=1, dilation=1, norm='BN', dropout=0,
+                 adaptive=True, channel_annention=False, reduce=4, add_tcn=False, merge_after=False):
+        super().__init__()
+        if channel_annention:
+            raise NotImplementedError('unitmlp(channel_annention=True) has no HIP path')
+        if in_channels != out_channels:
+            raise NotImplementedError('unitmlp: the depthwise Conv1d needs in_channels == out_channels')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.dilation, self.stride = kernel_size, dilation, stride
+        self.mlp_size = int((kernel_size + 1) / 2)
+        self.channel_annention, self.add_tcn, self.merge_after = channel_annention, add_tcn, merge_after
+        pad = (kernel_size + (kernel_size - 1) * (dilation - 1) - 1) // 2
+        self.inter_channels = 8 if in_channels <= 16 else in_channels // reduce
+        self.group = 1
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=self.mlp_size, stride=stride, dilation=dilation,
+                              groups=out_channels)
+        self.conv1 = nn.Conv2d(out_channels, out_channels, 1)
+        if add_tcn:
+            self.conv2 = nn.Conv2d(in_channels, out_channels, kernel_size=(kernel_size, 1), padding=(pad, 0),
+                                   stride=(stride, 1), dilation=(dilation, 1))
+            if adaptive:
+                self.alpha = nn.Parameter(torch.zeros(1))
+            else:
+                self.register_buffer('alpha', torch.ones(1))
+        self.bn = _norm_layer(norm, out_channels) if norm is not None else nn.Identity()
+        self.drop = nn.Dropout(dropout, inplace=True)
+
+
+class msmlp(dgmstcn):
+    """Multi-scale temporal unit of the shipped CTR-GCN config (reference: tcn.py:182-261) = ``mstcn`` with ``unitmlp``
+    in place of the dilated-conv branches.  HIP chain: branch 1x1 convs as ONE K-C launch (+ statistics), then branch_act,
+    tapconv (alpha-scaled dilated convs / max-pool / strided copy), the depthwise causal taps (dsgcn_dwcausal), the
+    branches' 1x1 convs as one block-diagonal K-C launch, one add; transform's BN rides to its conv as a deferred affine."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None, dropout=0.,
+                 ms_cfg=[(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1'], stride=1, channel_annention=False,
+                 add_tcn=False, merge_after=False):
+        nn.Module.__init__(self)
+        if not add_tcn:
+            raise NotImplementedError('msmlp(add_tcn=False) has no HIP path (the shipped config sets add_tcn=True)')
+        self.ms_cfg = [tuple(c) if isinstance(c, (list, tuple)) else c for c in ms_cfg]
+        num_branches = len(ms_cfg)
+        self.num_branches, self.in_channels, self.out_channels, self.stride = num_branches, in_channels, out_channels, stride
+        self.act = nn.ReLU()
+        self.merge_after = merge_after
+        if mid_channels is None:
+            mid_channels = out_channels // num_branches
+            rem_mid_channels = out_channels - mid_channels * (num_branches - 1)
+        else:
+            assert isinstance(mid_channels, float) and mid_channels > 0
+            mid_channels = int(out_channels * mid_channels)
+            rem_mid_channels = mid_channels
+        self.mid_channels, self.rem_mid_channels = mid_channels, rem_mid_channels
+        branches, self.widths = [], []
+        for i, cfg in enumerate(self.ms_cfg):
+            bc = rem_mid_channels if i == 0 else mid_channels
+            self.widths.append(bc)
+            if cfg == '1x1':
+                branches.append(nn.Conv2d(in_channels, bc, kernel_size=1, stride=(stride, 1)))
+            elif cfg[0] == 'max':
+                branches.append(nn.Sequential(
+                    nn.Conv2d(in_channels, bc, kernel_size=1), nn.BatchNorm2d(bc), self.act,
+                    nn.MaxPool2d(kernel_size=(cfg[1], 1), stride=(stride, 1), padding=(1, 0))))
+            else:
+                branches.append(nn.Sequential(
+                    nn.Conv2d(in_channels, bc, kernel_size=1), nn.BatchNorm2d(bc), self.act,
+                    unitmlp(bc, bc, kernel_size=cfg[0], stride=stride, dilation=cfg[1], norm=None,
+                            channel_annention=channel_annention, add_tcn=add_tcn, merge_after=merge_after)))
+        self.branches = nn.ModuleList(branches)
+        tin_channels = mid_channels * (num_branches - 1) + rem_mid_channels
+        self.transform = nn.Sequential(nn.BatchNorm2d(tin_channels), self.act,
+                                       nn.Conv2d(tin_channels, out_channels, kernel_size=1))
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.drop = nn.Dropout(dropout, inplace=True)
+        seen_plain = False
+        for cfg in self.ms_cfg:
+            if cfg == '1x1':
+                seen_plain = True
+            elif seen_plain:
+                raise NotImplementedError("msmlp: '1x1' branches must come last in ms_cfg on the HIP path")
+        self.n_act = sum(w for w, c in zip(self.widths, self.ms_cfg) if c != '1x1')
+        kms = {b[3].mlp_size for b in self.branches if not isinstance(b, nn.Conv2d) and isinstance(b[3], unitmlp)}
+        if len(kms) != 1:
+            raise NotImplementedError('msmlp: the mlp branches must share one kernel size on the HIP path')
+        self.mlp_size = kms.pop()
+        dil = []
+        for w, cfg, b in zip(self.widths, self.ms_cfg, self.branches):
+            dil += [int(cfg[1]) if (not isinstance(b, nn.Conv2d) and isinstance(b[3], unitmlp)) else 0] * w
+        self.register_buffer('dw_dil', torch.tensor(dil, dtype=torch.int32), persistent=False)
+
+    def forward_deferred(self, g):
+        ops = kernels.ops()
+        d = as_deferred(g)
+        n, _, T, V = d.x1.shape
+        convs = self._first_convs()
+        wb = torch.cat([c.weight.flatten(1) for c in convs], 0)
+        bb = torch.cat([c.bias for c in convs], 0)
+        bns = [b[1] for b in self.branches if not isinstance(b, nn.Conv2d)]
+        if any(_need_stats(bn) for bn in bns):
+            gamma = torch.cat([bn.weight for bn in bns])
+            beta = torch.cat([bn.bias for bn in bns])
+            z, _, scale, shift, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, False, gamma, beta,
+                                                   bns[0].eps, self.n_act, True)
+            c0 = 0
+            for bn in bns:
+                record_running(bn, m[c0:c0 + bn.num_features], var[c0:c0 + bn.num_features], n * T * V)
+                c0 += bn.num_features
+        else:
+            z = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, False)[0]
+            aff = [eval_affine(bn) for bn in bns]
+            rest = self.out_channels - self.n_act
+            scale = torch.cat([a[0] for a in aff] + ([z.new_ones(rest)] if rest else []))
+            shift = torch.cat([a[1] for a in aff] + ([z.new_zeros(rest)] if rest else []))
+        mlps = [b[3] for b in self.branches if not isinstance(b, nn.Conv2d) and isinstance(b[3], unitmlp)]
+        # the dilated convs carry their window's alpha (KB-sized products on parameters; autograd returns d alpha)
+        tw = [u.conv2.weight * u.alpha for u in mlps]
+        tb = [u.conv2.bias * u.alpha for u in mlps]
+        C = self.out_channels
+        nm = sum(u.out_channels for u in mlps)
+        dw_w = torch.cat([u.conv.weight.flatten(1) for u in mlps] + [z.new_zeros(C - nm, self.mlp_size)], 0)
+        dw_b = torch.cat([u.conv.bias for u in mlps] + [z.new_zeros(C - nm)], 0)
+        blocks = [u.conv1.weight.flatten(1) for u in mlps]
+        if self.merge_after:       # conv1(dw) + alpha*tconv: zero blocks leave max-pool / pass-through to the add
+            blocks.append(z.new_zeros(C - nm, C - nm))
+        else:                      # conv1(dw + alpha*tconv): identity blocks pass the other windows through the mix
+            blocks.append(torch.eye(C - nm, device=z.device, dtype=z.dtype))
+        pw_w = torch.block_diag(*blocks)
+        pw_b = torch.cat([u.conv1.bias for u in mlps] + [z.new_zeros(C - nm)], 0)
+        bn1 = self.transform[0]
+        f, a1 = op_bn(bn1, lambda g_, b_, eps, want: ops.temporal_mlp_bn(
+            z, scale, shift, self.n_act, self.ms_cfg, self.widths, tw, tb, dw_w, dw_b, self.dw_dil, pw_w, pw_b,
+            self.merge_after, self.stride, g_, b_, eps, want), lambda f: f.shape[0] * f.shape[2] * f.shape[3])
+        zt, _, a2 = conv_bn(f, a1, None, None, True, self.transform[2], 1, False, self.bn)
+        return Deferred(zt, a2, None, None, False)

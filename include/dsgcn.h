@@ -174,10 +174,17 @@ int dsgcn_aggsum_bwd(const float* p, const float* ahat, long a_ns, long a_ks, lo
  * plane_stats: partial (planes, 2) = per-plane [sum, sum of squares] of x (planes, L). */
 int dsgcn_tanhdiff_fwd(const float* proj, float* d, int n, int K, int R, int V, void* stream);
 int dsgcn_tanhdiff_bwd(const float* d, const float* dd, float* dproj, int n, int K, int R, int V, void* stream);
-int dsgcn_ctr_affine_fwd(const float* const* s, const float* alpha, const float* A, float* ahat, int n, int K, int Co,
-                         int V, void* stream);
-int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, const float* dahat, float* const* ds, float* prow,
-                         int n, int K, int Co, int V, void* stream);
+int dsgcn_ctr_affine_fwd(const float* const* s, const float* alpha, int alpha_stride, const float* A, const float* beta,
+                         const float* G, float* ahat, int n, int K, int Co, int V, void* stream);
+int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, int alpha_stride, const float* dahat,
+                         float* const* ds, float* prow, int n, int K, int Co, int V, void* stream);
+/* CTRHGC (gcn.py:668-771) extras of the same step: alpha_stride 1 = one alpha per subset (unit_ctrhgcn.alpha, gcn.py:862),
+ * 0 = the classic shared scalar; G (n,K,V,V) with beta (K): the "ada" Gram term x1^T x2 added as beta_k * G (gcn.py:755-760),
+ * NULL = none.  edge_select: the edge-typed attention conv (gcn.py:737) yields E*R channels; joint pair (u,v) keeps channel
+ * eps(u,v)*R + r (gcn.py:738-745, the index_select over a 625-iteration host loop).  in (n,E*R,V,V) -> out (n,R,V,V);
+ * backward writes din completely (zeros at the classes not selected). */
+int dsgcn_edge_select_fwd(const float* in, const int* edge_type, float* out, int n, int R, int E, int V, void* stream);
+int dsgcn_edge_select_bwd(const float* dout, const int* edge_type, float* din, int n, int R, int E, int V, void* stream);
 int dsgcn_plane_stats(const float* x, float* partial, long planes, int L, void* stream);
 
 /* out = a + b (+ c), n elements (c may be NULL; 16-B aligned buffers): the gradients of one block input from its
@@ -191,6 +198,15 @@ int dsgcn_add3(const float* a, const float* b, const float* c, float* out, long 
  * are DEVICE arrays (pointers to the tensors, element offsets into dst, element counts). */
 int dsgcn_pack(const float* const* src_table, const long* dst_offsets, const int* numels, int count, float* dst,
                void* stream);
+
+/* Depthwise causal temporal taps of unitmlp (tcn.py:525-614: left zero pad + grouped Conv1d, groups = channels):
+ *   y[n,c,t',v] = b[c] + sum_{j<KM} w[c,j] * h[n,c, t'*stride - (KM-1-j)*dil[c], v]   (frames < 0 read as zero), KM <= 4;
+ * dil (C) int32, 0 = channel outside the mlp windows (y = 0, dh = 0).  h (n,C,T,V); y (n,C,ceil(T/stride),V); w (C,KM).
+ * Backward: dh (n,C,T,V), part (n*C, 5) = per-plane [dw_0..dw_3, db] (dsgcn_colsum over n finishes them). */
+int dsgcn_dwcausal_fwd(const float* h, const float* w, const float* b, const int* dil, float* y, int n, int C, int T,
+                       int V, int stride, int KM, void* stream);
+int dsgcn_dwcausal_bwd(const float* h, const float* w, const int* dil, const float* dy, float* dh, float* part, int n,
+                       int C, int T, int V, int stride, int KM, void* stream);
 
 /* Skeleton input pipeline, per-element half (csrc/skeleton.hip).  Replaces the numpy transforms of the reference's
  * loader workers — PreNormalize3D (pose_related.py:250-336), RandomRot (144-178), JointToBone / ToMotion / GenSkeFeat

@@ -425,6 +425,79 @@ def unit_ctrgcn_forward(x, sd, training=True):
     return F.relu(y)
 
 
+def unitmlp_forward(x, sd, kernel_size, stride, dilation, add_tcn=True, merge_after=True):
+    """unitmlp with norm=None (tcn.py:578-612): depthwise causal Conv1d over the frames of every joint (left zero pad
+    (m-1)*d, m = (k+1)/2 taps, groups = channels), 1x1 conv, + alpha * dilated (k,1) conv of the input."""
+    B, C, T, V = x.shape
+    m = int((kernel_size + 1) / 2)
+    xs = x.permute(0, 3, 1, 2).reshape(B * V, C, T)                                         # tcn.py:584
+    xs = F.pad(xs, ((m + (m - 1) * (dilation - 1) - 1), 0))                                 # tcn.py:585-586
+    y = F.conv1d(xs, sd['conv.weight'], sd['conv.bias'], stride=stride, dilation=dilation, groups=C)   # 588
+    y = y.reshape(B, V, C, 1, -1).mean(-2).permute(0, 2, 3, 1)                              # tcn.py:589 (group 1)
+    if add_tcn:
+        pad = (kernel_size + (kernel_size - 1) * (dilation - 1) - 1) // 2
+        t = F.conv2d(x, sd['conv2.weight'], sd['conv2.bias'], stride=(stride, 1), padding=(pad, 0), dilation=(dilation, 1))
+        if merge_after:
+            return _conv1x1(y, sd['conv1.weight'], sd['conv1.bias']) + sd['alpha'] * t     # tcn.py:594-596
+        return _conv1x1(y + sd['alpha'] * t, sd['conv1.weight'], sd['conv1.bias'])          # tcn.py:599-600
+    return _conv1x1(y, sd['conv1.weight'], sd['conv1.bias'])
+
+
+def msmlp_forward(x, sd, stride=1, ms_cfg=((3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1'), training=True, add_tcn=True,
+                  merge_after=True):
+    """msmlp (tcn.py:182-261): mstcn's scaffold with unitmlp in the dilated branches; cat -> BN -> ReLU -> 1x1 -> BN."""
+    outs = []
+    for i, cfg in enumerate(ms_cfg):
+        p = f'branches.{i}.'
+        if cfg == '1x1':
+            outs.append(_conv1x1(x, sd[p + 'weight'], sd[p + 'bias'], stride))
+            continue
+        h = F.relu(_bn(_conv1x1(x, sd[p + '0.weight'], sd[p + '0.bias']), sd, p + '1.', training))
+        if cfg[0] == 'max':
+            outs.append(F.max_pool2d(h, (cfg[1], 1), (stride, 1), (1, 0)))
+        else:
+            outs.append(unitmlp_forward(h, _sub(sd, p + '3.'), cfg[0], stride, cfg[1], add_tcn, merge_after))
+    feat = torch.cat(outs, 1)
+    feat = F.relu(_bn(feat, sd, 'transform.0.', training))
+    feat = _conv1x1(feat, sd['transform.2.weight'], sd['transform.2.bias'])
+    return _bn(feat, sd, 'bn.', training)
+
+
+def unit_ctrhgcn_forward(x, sd, edge_type, training=True):
+    """Heterogeneous CTR unit with the shipped config's flags (gcn.py:773-880 over CTRHGC 668-771; node attention is
+    off in every subset and edge attention on in subset 0 only, through the constructor's per-subset overrides 801-842).
+    Per subset i: x1 = conv1(x).mean(T), x2 = conv2(x).mean(T), d = tanh(x1[u] - x2[v]); subset 0: the edge-typed conv
+    gives E variants of d and pair (u,v) keeps variant eps(u,v) (737-745); S = conv4(.); topology = S*alpha_i + A_i +
+    beta_i * x1^T x2 (752-760); out_i = einsum('ncuv,nctu->nctv', topology, conv3(x)) (769).  Sum, BN, + down(x), ReLU."""
+    n, Ci, T, V = x.shape
+    et = torch.as_tensor(np.asarray(edge_type), dtype=torch.long).reshape(-1)
+    K = sd['A'].shape[0]
+    y = 0
+    for i in range(K):
+        p = f'convs.{i}.'
+        x1 = _conv1x1(x, sd[p + 'conv1.weight'], sd[p + 'conv1.bias']).mean(-2)          # gcn.py:732 (n,R,V)
+        x2 = _conv1x1(x, sd[p + 'conv2.weight'], sd[p + 'conv2.bias']).mean(-2)
+        x3 = _conv1x1(x, sd[p + 'conv3.weight'], sd[p + 'conv3.bias'])
+        d = torch.tanh(x1.unsqueeze(-1) - x2.unsqueeze(-2))                              # gcn.py:735
+        R = d.shape[1]
+        if p + 'edge_att_conv.weight' in sd:                                             # gcn.py:736-745
+            full = _conv1x1(d, sd[p + 'edge_att_conv.weight'], sd[p + 'edge_att_conv.bias'])   # (n, E*R, V, V)
+            E = full.shape[1] // R
+            full = full.view(n, E, R, V * V)
+            d = torch.gather(full, 1, et.view(1, 1, 1, V * V).expand(n, 1, R, V * V))[:, 0].view(n, R, V, V)
+        S = _conv1x1(d, sd[p + 'conv4.weight'], sd[p + 'conv4.bias'])                    # gcn.py:747 / 751
+        topo = S * sd['alpha'][i] + sd['A'][i][None, None]                               # gcn.py:755
+        if p + 'beta' in sd:
+            topo = topo + torch.einsum('ncv,ncw->nvw', x1, x2)[:, None] * sd[p + 'beta']  # gcn.py:759-760
+        y = y + torch.einsum('ncuv,nctu->nctv', topo, x3)                                # gcn.py:769
+    y = _bn(y, sd, 'bn.', training)
+    if 'down.0.weight' in sd:
+        y = y + _bn(_conv1x1(x, sd['down.0.weight'], sd['down.0.bias']), sd, 'down.1.', training)
+    else:
+        y = y + x
+    return F.relu(y)
+
+
 def mstcn_msg3d_forward(x, sd, stride=1, kernel_size=5, dilations=(1, 2), training=True):
     """MSTCN of msg3d_utils.py:64-149 with residual=False (ctrgcn.py:41-48)."""
     outs = []
@@ -453,10 +526,16 @@ def ctrgcn_plan(in_channels=3, base_channels=64, num_stages=10, inflate_stages=(
     return plan
 
 
-def ctrgcn_block_forward(x, sd, stride, residual, training=True):
-    """CTRGCNBlock.forward (ctrgcn.py:59-61): relu(tcn1(gcn1(x)) + residual(x)), MSTCN kernel 5, dilations (1,2)."""
-    g = unit_ctrgcn_forward(x, _sub(sd, 'gcn1.'), training)
-    t = mstcn_msg3d_forward(g, _sub(sd, 'tcn1.'), stride, 5, (1, 2), training)
+def ctrgcn_block_forward(x, sd, stride, residual, training=True, edge_type=None):
+    """CTRGCNBlock.forward (ctrgcn.py:59-61): relu(tcn1(gcn1(x)) + residual(x)).  Classic: unit_ctrgcn + MSTCN (kernel 5,
+    dilations (1,2)); with edge_type: the shipped configs/ctrgcn/CTRGCN_model.py variant, unit_ctrhgcn + msmlp
+    (add_tcn, merge_after)."""
+    if edge_type is None:
+        g = unit_ctrgcn_forward(x, _sub(sd, 'gcn1.'), training)
+        t = mstcn_msg3d_forward(g, _sub(sd, 'tcn1.'), stride, 5, (1, 2), training)
+    else:
+        g = unit_ctrhgcn_forward(x, _sub(sd, 'gcn1.'), edge_type, training)
+        t = msmlp_forward(g, _sub(sd, 'tcn1.'), stride, training=training, add_tcn=True, merge_after=True)
     if not residual:
         res = 0
     elif 'residual.conv.weight' in sd:
@@ -466,21 +545,25 @@ def ctrgcn_block_forward(x, sd, stride, residual, training=True):
     return F.relu(t + res)
 
 
-def ctrgcn_forward(x, sd, plan, training=True):
+def ctrgcn_forward(x, sd, plan, training=True, edge_type=None):
     """CTRGCN.forward (ctrgcn.py:113-123): data_bn over M*V*C channels."""
     N, M, T, V, C = x.shape
     h = x.permute(0, 1, 3, 4, 2).contiguous().view(N, M * V * C, T)
     h = _bn(h, sd, 'data_bn.', training)
     h = h.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
     for i, (ci, co, stride, residual) in enumerate(plan):
-        h = ctrgcn_block_forward(h, _sub(sd, f'net.{i}.'), stride, residual, training)
+        h = ctrgcn_block_forward(h, _sub(sd, f'net.{i}.'), stride, residual, training, edge_type)
     return h.reshape((N, M) + h.shape[1:])
 
 
 def recognizer_forward_train_backbone(backbone, keypoint, label, sd, plan, training=True):
-    """forward_train with the ST-GCN ('stgcn'), ST-GCN++ ('stgcnpp') or CTR-GCN ('ctrgcn') backbone -> (logits, loss)."""
+    """forward_train with the ST-GCN ('stgcn'), ST-GCN++ ('stgcnpp'), classic CTR-GCN ('ctrgcn') or shipped-config CTR-GCN
+    ('ctrgcn_shipped': unit_ctrhgcn + msmlp, NTU graph) backbone -> (logits, loss)."""
     assert keypoint.shape[1] == 1
-    if backbone == 'stgcnpp':        # ST-GCN++ (configs/stgcn++): gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn'
+    if backbone == 'ctrgcn_shipped':
+        feat = ctrgcn_forward(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training,
+                              graph_constants('nturgb+d')['edge_type'])
+    elif backbone == 'stgcnpp':        # ST-GCN++ (configs/stgcn++): gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn'
         feat = stgcn_forward(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training, True, 'mstcn')
     else:
         fwd = {'stgcn': stgcn_forward, 'ctrgcn': ctrgcn_forward}[backbone]

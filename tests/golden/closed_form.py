@@ -39,14 +39,14 @@ def counter_input(N, T, V, classes):
     return x, y
 
 
-def liven32(module, seed):
-    """alpha / beta / add_coeff ~ N(0, 0.5^2) from a seeded generator (zero-init would switch the dynamic-adjacency
+def liven32(module, seed, scale=0.5):
+    """alpha / beta / add_coeff ~ N(0, scale^2) (default 0.5) from a seeded generator (zero-init would switch the dynamic-adjacency
     and global-joint paths off): the bench's and the round-2 fixtures' way of making a default-initialised model live."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for k, p in module.named_parameters():
             if k.endswith(('alpha', 'beta', 'add_coeff')):
-                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+                p.copy_(torch.randn(p.shape, generator=g) * scale)
 
 
 def fill_running(module):
@@ -62,11 +62,53 @@ def fill_running(module):
             v.copy_((1.0 + 0.25 * wave if k.endswith('running_var') else 0.05 * wave).to(v.dtype))
 
 
+def calibrate_running(model, x, extract):
+    """Running statistics of a plausible trained state (eval-mode fixtures): one train-mode pass over `x` with momentum 1
+    (running = batch statistics), then the closed-form wobble of fill_running scaled to them — closed-form statistics
+    alone leave activations mis-scaled, which the quadratic Gram terms of the CTR variants amplify to overflow."""
+    import zlib
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    saved = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        extract(model, x)
+    for m, mom in zip(bns, saved):
+        m.momentum = mom
+    with torch.no_grad():
+        sd = model.state_dict()
+        for k, v in sd.items():
+            if not k.endswith(('running_mean', 'running_var')):
+                continue
+            i = torch.arange(v.numel(), dtype=torch.float64)
+            phase = (zlib.crc32(k.encode()) % 1000) / 1000.0 * 6.283185307179586
+            wave = torch.sin(0.37 * i + phase).reshape(v.shape).to(v.dtype)
+            if k.endswith('running_var'):
+                v.mul_(1.0 + 0.1 * wave)
+            else:
+                v.add_(0.05 * wave * sd[k[:-len('running_mean')] + 'running_var'].sqrt())
+    return model.eval()
+
+
 def counter_clips(N, clips, T, V):
     """(N, clips, 2, T, V, 3) test-time input (several views per sample), closed form."""
     i = torch.arange(N * clips * 2 * T * V * 3, dtype=torch.float64)
     x = torch.sin(0.0211 * i) + 0.3 * torch.cos(0.00053 * i * i % 6.283185307179586)
     return x.reshape(N, clips, 2, T, V, 3).float()
+
+
+def eval_clips(name, T, V):
+    """(2, 10, 2, T, V, 3) test-time input of the eval fixture `name`."""
+    return counter_clips(2, 10, T, V)
+
+
+# alpha / beta scale of the eval fixtures.  The shipped CTR-GCN variant carries an unbounded quadratic Gram term (beta *
+# x1^T x2, no softmax): in eval mode (no batch renormalisation) a random-init network with beta != 0 overflows fp32
+# within a few blocks on any clip other than the one its running statistics came from (measured on the reference:
+# 7e2 -> 2e5 -> 1e13 -> inf over blocks 5-8).  Its eval fixture therefore keeps the reference's own initial state
+# alpha = beta = 0; the dynamic terms are pinned by the train-mode fixtures (full_grads_*, unit_others).
+EVAL_LIVEN = {'ctrgcn_shipped_ntu60': 0.0}
 
 
 def pick_tensors(named_numels, count=12, max_numel=70000):
@@ -92,17 +134,29 @@ UNIT_CASES = {       # tag -> (class name, ctor args after the graph, input shap
     'gcn_offset_post': ('unit_gcn', dict(in_channels=64, out_channels=128, adaptive='offset', conv_pos='post'), (2, 64, 8, 25)),
     'gcn_importance': ('unit_gcn', dict(in_channels=64, out_channels=64, adaptive='importance', with_res=True), (2, 64, 8, 25)),
     'gcn_fixed_post': ('unit_gcn', dict(in_channels=3, out_channels=64, adaptive=None, conv_pos='post'), (2, 3, 8, 25)),
+    # the heterogeneous CTR unit with the shipped config's flags (configs/ctrgcn/CTRGCN_model.py)
+    'ctrhgcn': ('unit_ctrhgcn', dict(in_channels=64, out_channels=128, semantic_index=True, node_attention=True,
+                                     edge_attention=True, add_type=False, ada=True, num_types=5, rel_reduction=8,
+                                     edge_num=15), (2, 64, 8, 25)),
+    'msmlp': ('msmlp', dict(in_channels=64, out_channels=64, stride=1, add_tcn=True, merge_after=True), (2, 64, 8, 25)),
+    'msmlp_s2': ('msmlp', dict(in_channels=128, out_channels=128, stride=2, add_tcn=True, merge_after=False), (2, 128, 8, 25)),
+    'ctrhgcn_same': ('unit_ctrhgcn', dict(in_channels=64, out_channels=64, semantic_index=True, node_attention=True,
+                                          edge_attention=True, ada=True), (2, 64, 8, 25)),
 }
 
 
-def make_unit(ns, tag, A):
+def make_unit(ns, tag, A, edge_type=None, node_type=None):
     """Build unit `tag` from namespace `ns` (the reference's gcns.utils or this package) with seeded default init,
-    live alpha/beta and BatchNorm affines away from (1, 0); -> (module fp32, input fp32, cotangent R fp32)."""
+    live alpha/beta and BatchNorm affines away from (1, 0); -> (module fp32, input fp32, cotangent R fp32).
+    edge_type (V,V) / node_type (V): the graph's type tables, needed by the heterogeneous units."""
     idx = list(UNIT_CASES).index(tag)
     cls, kw, shape = UNIT_CASES[tag]
     kw = dict(kw)
-    if cls in ('unit_gcn', 'unit_ctrgcn'):
+    if cls in ('unit_gcn', 'unit_ctrgcn', 'unit_ctrhgcn'):
         kw['A'] = A.clone()
+    if cls == 'unit_ctrhgcn':
+        kw['edge_type'] = torch.as_tensor(edge_type, dtype=torch.float32)
+        kw['node_type'] = torch.as_tensor(node_type)
     torch.manual_seed(300 + idx)
     m = getattr(ns, cls)(**kw)
     liven32(m, 40 + idx)

@@ -25,11 +25,22 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ref_shim  # noqa: E402
-from closed_form import (UNIT_CASES, counter_clips, counter_input, fill_running, liven32, make_unit, pick_tensors,  # noqa: E402
+from closed_form import (UNIT_CASES, calibrate_running, counter_clips, counter_input, eval_clips, EVAL_LIVEN, fill_running, liven32, make_unit, pick_tensors,  # noqa: E402
                          sd_digest)
 from gen_golden import ds_cfg, extract_feat_f64, other_cfg  # noqa: E402
 
 R = ref_shim.load()
+
+def shipped_ctr_cfg(num_classes=60, **bk):
+    """configs/ctrgcn/CTRGCN_model.py: unit_ctrhgcn + msmlp on the random graph."""
+    backbone = dict(type='CTRGCN', gcn_type='unit_ctrhgcn', gcn_node_attention=True, gcn_edge_attention=True,
+                    gcn_add_type=False, gcn_ada=True, gcn_num_types=5, gcn_rel_reduction=8, gcn_edge_num=15,
+                    tcn_type='msmlp', tcn_add_tcn=True, tcn_merge_after=True,
+                    graph_cfg=dict(layout='nturgb+d', mode='random', num_filter=3, init_off=.04, init_std=.02))
+    backbone.update(bk)
+    return dict(type='RecognizerGCN', backbone=backbone,
+                cls_head=dict(type='GCNHead', num_classes=num_classes, in_channels=256))
+
 
 CONFIGS = {
     'dsstgcn_ntu60': (lambda: ds_cfg(60), 64, 25),            # BASELINE config 2
@@ -38,14 +49,15 @@ CONFIGS = {
     'ctrgcn_ntu60': (lambda: other_cfg('ctrgcn'), 64, 25),    # BASELINE config 4
     'stgcn_ntu60': (lambda: other_cfg('stgcn'), 64, 25),      # BASELINE config 1
     'stgcnpp_ntu60': (lambda: other_cfg('stgcnpp'), 64, 25),
+    'ctrgcn_shipped_ntu60': (lambda: shipped_ctr_cfg(), 64, 25),       # the CTR-GCN variant the reference ships (f-1)
 }
 
 
-def build(cfg):
+def build(cfg, scale=0.5):
     np.random.seed(0)
     torch.manual_seed(0)
     m = R.builder.build_model(cfg)
-    liven32(m, 1)
+    liven32(m, 1, scale)
     return m
 
 
@@ -117,10 +129,9 @@ def full_grads():
 def eval_fixtures():
     for name, (mk, T, V) in CONFIGS.items():
         cfg = mk()
-        m = build(cfg)
-        fill_running(m)
-        m.eval()
-        x = counter_clips(2, 10, T, V)
+        m = build(cfg, EVAL_LIVEN.get(name, 0.5))
+        x = eval_clips(name, T, V)
+        calibrate_running(m, x[:, 0], lambda mod, inp: mod.extract_feat(inp))
         with torch.no_grad():
             probs = m(keypoint=x, return_loss=False)
         m64 = to64(m, cfg).eval()
@@ -129,9 +140,13 @@ def eval_fixtures():
             sc = m64.cls_head(feat).reshape(x.shape[1], 2, -1).permute(1, 0, 2)
             clip_probs = torch.softmax(sc, 2)
             probs64 = clip_probs.mean(1).numpy()
-        np.savez_compressed(os.path.join(HERE, f'eval_{name}.npz'), probs32=np.asarray(probs, dtype=np.float32),
-                            probs64=probs64.astype(np.float32), probs64_clips=clip_probs.numpy().astype(np.float32),
-                            scores64_clips=sc.numpy().astype(np.float32))
+        out = dict(probs32=np.asarray(probs, dtype=np.float32), probs64=probs64.astype(np.float32),
+                   probs64_clips=clip_probs.numpy().astype(np.float32), scores64_clips=sc.numpy().astype(np.float32))
+        rk = [k for k in m.state_dict() if k.endswith(('running_mean', 'running_var'))]
+        out['running_keys'] = np.array(json.dumps(rk))
+        out['running_values'] = np.concatenate([m.state_dict()[k].numpy().reshape(-1) for k in rk]).astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, f'eval_{name}.npz'), **out)
+        assert np.isfinite(probs64).all(), name
         print(name, 'eval: ref fp32 vs fp64', float(np.abs(probs - probs64).max()), 'max prob', float(probs64.max()))
 
 
@@ -201,9 +216,10 @@ def unit_others():
     """Units rebuilt on both sides from the same seeded recipe (closed_form.make_unit: weights are not stored, their
     digest is): reference output, input gradient and parameter gradients from an fp64 run."""
     out = {}
-    A = torch.tensor(R.graph.Graph(layout='nturgb+d', mode='spatial').A, dtype=torch.float32)
+    Gs = R.graph.Graph(layout='nturgb+d', mode='spatial')
+    A = torch.tensor(Gs.A, dtype=torch.float32)
     for tag in UNIT_CASES:
-        m, x, Rm = make_unit(R.gutils, tag, A)
+        m, x, Rm = make_unit(R.gutils, tag, A, Gs.edge_type, Gs.node_type)
         out[f'{tag}_digest'] = np.array(sd_digest(m))
         m = m.double().train()
         x = x.double().requires_grad_()

@@ -214,3 +214,26 @@ def test_resume_optimizer_state_torch_layout(tmp_path):
     opt2.load_state_dict(topt.state_dict())
     off, n = flat2.slices[0]
     assert torch.allclose(opt2.buf[off:off + n], tsd['state'][0]['momentum_buffer'].reshape(-1), atol=1e-6)
+
+
+def test_fuse_conv_bn_keeps_eval_outputs():
+    """f-2: folding eval-mode BatchNorms into the convs before them (tools/test.py:98-99) leaves the features unchanged
+    and the module tree / state_dict keys intact."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from closed_form import fill_running, liven32
+    z, m = _reduced_model()
+    liven32(m, 1)
+    fill_running(m)
+    m.eval()
+    keys = list(m.state_dict())
+    x = torch.from_numpy(z['x'])[:, 0]
+    with D.kernels.use_ops(torch_ops), torch.no_grad():
+        before = m.extract_feat(x)
+        D.fuse_conv_bn(m)
+        after = m.extract_feat(x)
+    assert list(m.state_dict()) == keys
+    folded = [t for t in m.modules() if isinstance(t, torch.nn.BatchNorm2d) and float(t.running_mean.abs().max()) == 0]
+    assert len(folded) >= 20
+    assert float((before - after).abs().max()) < 1e-5 * float(before.abs().max())
+    assert float((before - after).abs().max()) > 0          # the arithmetic really changed (weights were rescaled)

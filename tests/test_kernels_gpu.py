@@ -437,7 +437,7 @@ def test_dgphgcn1_kernels_vs_reference_intermediates(tag, layout, ci, co):
 
 
 @pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'MSTCNs2', 'gcn_offset_post',
-                                 'gcn_importance', 'gcn_fixed_post'])
+                                 'gcn_importance', 'gcn_fixed_post', 'ctrhgcn', 'ctrhgcn_same', 'msmlp', 'msmlp_s2'])
 def test_units_vs_reference_fixture(tag):
     """unit_gcn, unit_tcn (k=9 dense; k=1 stride 2), unit_ctrgcn / CTRGC and MSTCN at real widths on the HIP path
     against the REFERENCE's output, input gradient, parameter gradients and running statistics (fp64 run;
@@ -450,7 +450,8 @@ def test_units_vs_reference_fixture(tag):
     from closed_form import make_unit, sd_digest
     z = load('unit_others.npz')
     A = torch.tensor(O.graph_A('nturgb+d', 'spatial'), dtype=torch.float32)
-    m, x, Rm = make_unit(D, tag, A)
+    gc = O.graph_constants('nturgb+d')
+    m, x, Rm = make_unit(D, tag, A, np.asarray(gc['edge_type']), np.asarray(gc['node_type']))
     assert sd_digest(m) == str(z[f'{tag}_digest'])
     m = m.cuda().train()
     x = x.cuda().requires_grad_()

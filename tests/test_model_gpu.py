@@ -80,7 +80,7 @@ def test_full_model_vs_oracle(layout, V, T, classes):
     assert len(dead) == 20 and all('conv2_se' in k for k in dead)          # reference quirk Q1
 
 
-@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn', 'stgcnpp'])
+@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn', 'stgcnpp', 'ctrgcn_shipped'])
 def test_full_other_backbones_vs_oracle(kind):
     """Full-width classic CTR-GCN (BASELINE config 4) and vanilla ST-GCN (config 1), 2 clips, against the CPU oracle."""
     np.random.seed(0)
@@ -94,7 +94,7 @@ def test_full_other_backbones_vs_oracle(kind):
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     x = torch.randn(2, 1, 2, 64, 25, 3, generator=g)
     y = torch.randint(0, 60, (2, 1), generator=g)
-    plan = O.ctrgcn_plan() if kind == 'ctrgcn' else O.dgstgcn_plan()
+    plan = O.ctrgcn_plan() if kind.startswith('ctrgcn') else O.dgstgcn_plan()
     ref_logits, ref_loss = O.recognizer_forward_train_backbone(kind, x, y, sd, plan)
     m = m.cuda().train()
     out = m.train_step(dict(keypoint=x.cuda(), label=y.cuda()), None)
@@ -209,10 +209,11 @@ def test_gradient_packing_modes_agree():
 R2_CONFIGS = {
     'dsstgcn_ntu60': (lambda: ds_cfg(60), 64, 25), 'dsstgcn_ntu120': (lambda: ds_cfg(120), 64, 25),
     'dsstgcn_k400_coco': (lambda: ds_cfg(400, 'coco'), 100, 17), 'ctrgcn_ntu60': (lambda: other_cfg('ctrgcn'), 64, 25),
-    'stgcn_ntu60': (lambda: other_cfg('stgcn'), 64, 25), 'stgcnpp_ntu60': (lambda: other_cfg('stgcnpp'), 64, 25)}
+    'stgcn_ntu60': (lambda: other_cfg('stgcn'), 64, 25), 'stgcnpp_ntu60': (lambda: other_cfg('stgcnpp'), 64, 25),
+    'ctrgcn_shipped_ntu60': (lambda: other_cfg('ctrgcn_shipped'), 64, 25)}
 
 
-def _r2_model(name):
+def _r2_model(name, scale=0.5):
     import sys
     sys.path.insert(0, GOLD)
     from closed_form import liven32
@@ -221,7 +222,7 @@ def _r2_model(name):
     np.random.seed(0)
     torch.manual_seed(0)
     m = D.build_model(cfg)
-    liven32(m, 1)
+    liven32(m, 1, scale)
     for mod in m.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0                                       # vanilla ST-GCN's Dropout(0.5): off on both sides
@@ -266,15 +267,28 @@ def test_full_width_gradients_vs_reference_fixture(name):
         assert rel(sd[k].cpu(), z[f'running_{i}']) < 1e-4, k                             # F.batch_norm's running update
 
 
+def _load_running(m, z):
+    """BatchNorm running statistics of the eval fixture (the reference's calibrated state) into model m."""
+    keys = json.loads(str(z['running_keys']))
+    vals = torch.from_numpy(z['running_values'])
+    sd, off = m.state_dict(), 0
+    with torch.no_grad():
+        for k in keys:
+            n = sd[k].numel()
+            sd[k].copy_(vals[off:off + n].view_as(sd[k]))
+            off += n
+    assert off == vals.numel()
+
+
 @pytest.mark.parametrize('name', list(R2_CONFIGS))
 def test_eval_mode_vs_reference_fixture(name):
     """Inference path (f-2): eval-mode BatchNorm from running statistics, 2 samples x 10 clips, scores averaged as
     probabilities (recognizergcn.py:53-107), against the REFERENCE's forward_test output and per-clip class scores."""
-    from closed_form import counter_clips, fill_running
-    m, cfg, T, V = _r2_model(name)
-    fill_running(m)
+    from closed_form import EVAL_LIVEN, eval_clips
+    m, cfg, T, V = _r2_model(name, EVAL_LIVEN.get(name, 0.5))
     z = load(f'eval_{name}.npz')
-    x = counter_clips(2, 10, T, V).cuda()
+    _load_running(m, z)
+    x = eval_clips(name, T, V).cuda()
     m = m.cuda().eval()
     probs = m(keypoint=x, return_loss=False)
     assert isinstance(probs, np.ndarray) and probs.shape == z['probs64'].shape

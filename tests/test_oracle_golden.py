@@ -182,7 +182,18 @@ def test_dgphgcn1_intermediates(tag, layout):
         assert rel(v, z[f'{tag}_{k}']) < 2e-6, (k, rel(v, z[f'{tag}_{k}']))      # fixtures are stored as fp32
 
 
+def _graph_tables():
+    gc = O.graph_constants('nturgb+d')
+    return np.asarray(gc['edge_type']), np.asarray(gc['node_type'])
+
+
 def _unit_oracle(tag, x, sd):
+    if tag.startswith('ctrhgcn'):
+        return O.unit_ctrhgcn_forward(x, sd, _graph_tables()[0])
+    if tag == 'msmlp':
+        return O.msmlp_forward(x, sd, 1, merge_after=True)
+    if tag == 'msmlp_s2':
+        return O.msmlp_forward(x, sd, 2, merge_after=False)
     if tag in ('gcn', 'gcn_res'):
         return O.unit_gcn_forward(x, sd, with_res=(tag == 'gcn_res'))
     if tag == 'gcn_offset_post':
@@ -203,7 +214,7 @@ def _unit_oracle(tag, x, sd):
 
 
 @pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'gcn_offset_post', 'gcn_importance',
-                                 'gcn_fixed_post'])
+                                 'gcn_fixed_post', 'ctrhgcn', 'ctrhgcn_same', 'msmlp', 'msmlp_s2'])
 def test_other_units_vs_reference_fixture(tag):
     """unit_gcn, unit_tcn (k=9; k=1 stride 2), unit_ctrgcn, MSTCN at real widths: oracle output and input gradient
     against the reference's (weights rebuilt from the shared seeded recipe; their digest is part of the fixture)."""
@@ -213,7 +224,7 @@ def test_other_units_vs_reference_fixture(tag):
     import dsgcn_amd as D
     z = load('unit_others.npz')
     A = torch.tensor(O.graph_A('nturgb+d', 'spatial'), dtype=torch.float32)
-    m, x, Rm = make_unit(D, tag, A)
+    m, x, Rm = make_unit(D, tag, A, *_graph_tables())
     assert sd_digest(m) == str(z[f'{tag}_digest']), 'seeded unit weights differ from the reference build'
     sd = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in m.state_dict().items()}
     x = x.double().requires_grad_()
@@ -224,23 +235,29 @@ def test_other_units_vs_reference_fixture(tag):
 
 
 @pytest.mark.parametrize('name,kind,T,V,classes,layout', [
-    ('dsstgcn_ntu60', 'ds', 64, 25, 60, 'nturgb+d'), ('stgcnpp_ntu60', 'stgcnpp', 64, 25, 60, 'nturgb+d')])
+    ('dsstgcn_ntu60', 'ds', 64, 25, 60, 'nturgb+d'), ('stgcnpp_ntu60', 'stgcnpp', 64, 25, 60, 'nturgb+d'),
+    ('ctrgcn_shipped_ntu60', 'ctrgcn_shipped', 64, 25, 60, 'nturgb+d')])
 def test_eval_fixture_oracle(name, kind, T, V, classes, layout):
     """Eval-mode (running statistics) test-time scores of the reference, 2 samples x 10 clips averaged as
     probabilities (recognizergcn.py:53-107): the oracle's inference path against the stored fp64 scores."""
     import sys
     sys.path.insert(0, GOLD)
-    from closed_form import counter_clips, fill_running, liven32
+    from closed_form import EVAL_LIVEN, eval_clips, liven32
     import dsgcn_amd as D
     from bench import ds_cfg, other_cfg
     np.random.seed(0)
     torch.manual_seed(0)
     m = D.build_model(ds_cfg(classes, layout) if kind == 'ds' else other_cfg(kind))
-    liven32(m, 1)
-    fill_running(m)
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    x = counter_clips(2, 10, T, V)[:, :2]          # 2 of the 10 clips keep the CPU suite fast (-m gpu checks all 10)
+    liven32(m, 1, EVAL_LIVEN.get(name, 0.5))
     z = load(f'eval_{name}.npz')
+    keys, vals, off = json.loads(str(z['running_keys'])), torch.from_numpy(z['running_values']), 0
+    with torch.no_grad():
+        for k in keys:                                # the reference's calibrated running statistics
+            t = m.state_dict()[k]
+            t.copy_(vals[off:off + t.numel()].view_as(t))
+            off += t.numel()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = eval_clips(name, T, V)[:, :2]              # 2 of the 10 clips keep the CPU suite fast (-m gpu checks all 10)
     gc = O.graph_constants(layout)
     flat = x.flatten(0, 1)
     label = torch.zeros(flat.shape[0], 1, dtype=torch.long)
@@ -249,14 +266,14 @@ def test_eval_fixture_oracle(name, kind, T, V, classes, layout):
             logits, _ = O.recognizer_forward_train(flat[:, None], label, sd, gc['node_type'], gc['edge_type'],
                                                    O.dgstgcn_plan(), training=False)
         else:
-            logits, _ = O.recognizer_forward_train_backbone(kind, flat[:, None], label, sd, O.dgstgcn_plan(),
-                                                            training=False)
+            plan = O.ctrgcn_plan() if kind.startswith('ctrgcn') else O.dgstgcn_plan()
+            logits, _ = O.recognizer_forward_train_backbone(kind, flat[:, None], label, sd, plan, training=False)
     assert rel(logits.reshape(2, 2, -1), z['scores64_clips'][:, :2]) < 1e-4          # class scores of each clip
     assert rel(torch.softmax(logits.reshape(2, 2, -1), 2), z['probs64_clips'][:, :2]) < 1e-5
 
 
 @pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'gcn_offset_post', 'gcn_importance',
-                                 'gcn_fixed_post'])
+                                 'gcn_fixed_post', 'ctrhgcn', 'ctrhgcn_same', 'msmlp', 'msmlp_s2'])
 def test_oracle_units_vs_reference_live(tag):
     """Build container only: every unit restated in the oracle against the IMPORTED reference module, fp64."""
     import sys
@@ -266,8 +283,9 @@ def test_oracle_units_vs_reference_live(tag):
         pytest.skip('reference tree not present (GPU box)')
     from closed_form import make_unit
     R = ref_shim.load()
-    A = torch.tensor(R.graph.Graph(layout='nturgb+d', mode='spatial').A, dtype=torch.float32)
-    m, x, _ = make_unit(R.gutils, tag, A)
+    Gs = R.graph.Graph(layout='nturgb+d', mode='spatial')
+    A = torch.tensor(Gs.A, dtype=torch.float32)
+    m, x, _ = make_unit(R.gutils, tag, A, Gs.edge_type, Gs.node_type)
     m = m.double().train()
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     want = m(x.double())

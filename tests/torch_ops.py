@@ -89,8 +89,9 @@ def aggregate_sum(p, adj, K, gamma=None, beta=None, eps=1e-5, want_bn=False):
     return _bn_of(y, gamma, beta, eps, want_bn)
 
 
-def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A):
-    """CTR-GCN refined topology (gcn.py:651-657): -> Ahat (n, K*Co, V, V)."""
+def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None):
+    """CTR-GCN refined topology (gcn.py:651-657) and its CTRHGC form (gcn.py:719-760: per-subset alpha, edge-typed
+    attention on chosen subsets, Gram term scaled by beta): -> Ahat (n, K*Co, V, V)."""
     n, Ci, V = xbar.shape
     K = A.shape[0]
     R = w1.shape[0] // K
@@ -99,8 +100,18 @@ def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A):
     d = torch.tanh(x1[..., :, None] - x2[..., None, :])                  # n,K,R,V,V
     out = []
     for k in range(K):
-        s = torch.einsum('or,nruv->nouv', w4[k], d[:, k]) + b4[k][None, :, None, None]
-        out.append(s * alpha + A[k][None, None])
+        dk = d[:, k]
+        if edge and k in edge:
+            we, be, et = edge[k]
+            E = we.shape[0] // R
+            full = (torch.einsum('or,nruv->nouv', we, dk) + be[None, :, None, None]).view(n, E, R, V * V)
+            dk = torch.gather(full, 1, et.long().view(1, 1, 1, V * V).expand(n, 1, R, V * V))[:, 0].view(n, R, V, V)
+        s = torch.einsum('or,nruv->nouv', w4[k], dk) + b4[k][None, :, None, None]
+        al = alpha[k] if alpha.numel() == K and K > 1 else alpha
+        a = s * al + A[k][None, None]
+        if beta is not None:
+            a = a + beta[k] * torch.einsum('nru,nrv->nuv', x1[:, k], x2[:, k])[:, None]
+        out.append(a)
     return torch.cat(out, 1)
 
 
@@ -228,3 +239,27 @@ def fuse_out(x1, a1, x2, a2, relu, want_tmean=False):
     else:
         out = virt(x1, a1, x2, a2, bool(relu & 1))
     return out, (out.mean(2) if want_tmean else None)
+
+
+def temporal_mlp_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, dw_w, dw_b, dw_dil, pw_w, pw_b,
+                    merge_after, stride, gamma=None, beta=None, eps=1e-5, want_bn=False):
+    """msmlp's temporal stage (see dsgcn_amd.kernels.temporal_mlp_bn) in plain torch ops."""
+    n, C, T, V = z.shape
+    h = z * _bc(scale) + _bc(shift)
+    h = torch.cat([F.relu(h[:, :n_act]), h[:, n_act:]], 1)
+    o = _branches(h, branch_cfg, widths, conv_w, conv_b, stride)
+    KM = dw_w.shape[1]
+    Tout = o.shape[2]
+    dw = torch.zeros_like(o)
+    for c in range(C):
+        dl = int(dw_dil[c])
+        if dl == 0:
+            continue
+        xp = F.pad(h[:, c], (0, 0, (KM - 1) * dl, 0))                     # left pad on the frame axis
+        acc = dw_b[c]
+        for j in range(KM):
+            acc = acc + dw_w[c, j] * xp[:, j * dl:j * dl + (Tout - 1) * stride + 1:stride]
+        dw[:, c] = acc
+    mix = lambda t: torch.einsum('oc,nctv->notv', pw_w, t) + _bc(pw_b)    # noqa: E731
+    out = mix(dw) + o if merge_after else mix(dw + o)
+    return _bn_of(out, gamma, beta, eps, want_bn)
