@@ -443,9 +443,10 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd(const float* __restrict__ 
   }
 }
 
-// Persistent/pipelined backward for T <= 64 (one 64-frame pass per unit): same products as k_aggregate_bwd,
-// with the next unit's Zp / dY planes and adjacency in flight while the current unit is on the matrix core.
-template <int V, bool DA_LDS>
+// Persistent/pipelined backward for T <= TM (TM = 64, or 128 for the long clips of the K400 config: T = 100 / 50): same
+// products as k_aggregate_bwd, with the next unit's Zp / dY planes and adjacency in flight while the current unit is on
+// the matrix core.
+template <int V, bool DA_LDS, int TM>
 __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restrict__ zp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
                                                            float* __restrict__ dahat, float* __restrict__ partial,
                                                            int KC, int T, long units) {
   constexpr int KS = (V + 1) / 2;
-  constexpr int NP4 = (64 * V / 4 + 63) / 64;
+  constexpr int NP4 = (TM * V / 4 + 63) / 64;
   constexpr int NA = (V * V + 63) / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldsZ = lds;
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
   const int lane = threadIdx.x;
   const int mi = lane & 31, mk = lane >> 5;
   const int mic = mi < V ? mi : V - 1;
-  const int rows = T;                 // T <= 64
+  const int rows = T;                 // T <= TM
   const int c4 = (rows * V) >> 2;
   f32x4 prez[NP4], preg[NP4];
   float prea[NA];
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
     }
     float sum_h = 0.f, sum_s = 0.f;
 #pragma unroll
-    for (int tile = 0; tile < 2; ++tile) {
+    for (int tile = 0; tile < TM / 32; ++tile) {
       if (tile * 32 < rows) {
         f32x16 acc;
 #pragma unroll
@@ -855,16 +856,19 @@ int launch_bwd(const float* zp, const float* scale, const float* shift, int relu
     const long g = (units + per - 1) / per;
     hipLaunchKernelGGL((k_aggregate_bwd_pair<V, 32, 2>), dim3((unsigned)g), dim3(64 * nw), lds2, st, zp, scale, shift,
                        relu, ahat, dy, dzp, dahat, partial, KC, T, units);
-  } else if (vec && T <= 64 && g_bwd_variant == 0) {
+  } else if (vec && T <= 128 && g_bwd_variant == 0) {
     const size_t lds = (size_t)(2 * T * V + V * V) * sizeof(float);
     int waves = g_pipe_waves_bwd > 0 ? g_pipe_waves_bwd : 2048;
     const long per = (units + waves - 1) / waves;
     const long g = (units + per - 1) / per;
-    if (g_bwd_da_lds)
-      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, true>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+    if (T > 64)        // the long clips of BASELINE config 5 (V = 17, T = 100 / 50): four 32-frame tiles per unit
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 128>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift,
+                         relu, ahat, dy, dzp, dahat, partial, KC, T, units);
+    else if (g_bwd_da_lds)
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, true, 64>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
                          ahat, dy, dzp, dahat, partial, KC, T, units);
     else
-      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 64>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
                          ahat, dy, dzp, dahat, partial, KC, T, units);
   } else {
     hipLaunchKernelGGL((k_aggregate_bwd<V>), dim3((unsigned)units), dim3(64), lds, st, zp, scale, shift, relu, ahat,

@@ -4,7 +4,8 @@
 //   v      = relu?(x1*s1+h1 (+ x2*s2+h2))    (the forward's virtual input, rebuilt while loading).
 // The reduction runs over positions, so both MFMA operands need "lane = channel" fragments: the tiles are staged through
 // LDS — coalesced 16-B global loads (8..32 lanes per 128..512-B row segment), the prologue arithmetic in registers, rows
-// stored with stride KC+2 (= 2*odd: conflict-free ds_read_b64, each read feeds two k-steps) — and every wave owns a
+// (any plane length: a row that is not a multiple of 4 long is loaded with dword-aligned 16-B loads and its tail group is
+// masked per element) stored with stride KC+2 (= 2*odd: conflict-free ds_read_b64, each read feeds two k-steps) — and every wave owns a
 // (TM/2)x(TN/2) block of the workgroup's TMxTN output tile (up to 2x2 MFMA tiles: one LDS read per MFMA instead of the
 // two of the first version, and a 128x128 tile reads each operand row once for 128 output columns instead of 64).
 // K (positions) is split over workgroups; each split writes its partial dW / db (deterministic: summed by dsgcn_colsum).
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
     const int n = ch / a.cpn;
     const int c0 = (ch - n * a.cpn) * KC;
     const bool pv = c0 + col < L;
-#pragma unroll
+    const int nv = L - (c0 + col);                 // valid elements of this thread's float4 (planes need not be x4 long:
+#pragma unroll                                     // the tail group then also holds the next row's first elements)
     for (int j = 0; j < JD; ++j) {
       const int row = rowD0 + RSTEP * j;
       const bool ok = pv && coBase + row < Co;
@@ -130,6 +132,8 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
         for (int e = 0; e < 4; ++e) d[e] += fmaf(c.y, zr[j][e], c.x);
       }
       if (!ok) d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 1; e < 4; ++e) d[e] = e < nv ? d[e] : 0.f;
       dsum[j] += (d.x + d.y) + (d.z + d.w);
       f32x2* dst = reinterpret_cast<f32x2*>(Ds + row * LS + col);
       dst[0] = f32x2{d.x, d.y};
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
       for (int e = 0; e < 4; ++e) {
         float t = fmaf(xr[j][e], p.x, p.y);
         if constexpr (HAS2) t += fmaf(yr[j][e], p.z, p.w);
-        v[e] = ok ? fmaxf(t, lo) : 0.f;
+        v[e] = (ok && e < nv) ? fmaxf(t, lo) : 0.f;
       }
       f32x2* dst = reinterpret_cast<f32x2*>(Xs + row * LS + col);
       dst[0] = f32x2{v.x, v.y};
@@ -220,7 +224,6 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
 struct Wg2Plan { int TM, TN, KC, cpn, chunks, tm_tiles, tn_tiles, splits, cps; size_t lds; };
 
 bool wg2_plan(int n, int Ci, int Co, int L, Wg2Plan* p) {
-  if (L % 4) return false;
   if ((long)Ci * L * 4 >= (1L << 31) - 64 || (long)Co * L * 4 >= (1L << 31) - 64) return false;
   p->TM = Co > 64 ? 128 : 64;
   p->TN = Ci > 64 ? 128 : 64;

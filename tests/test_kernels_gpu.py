@@ -110,6 +110,8 @@ def _rand(g, *shape, scale=1.0):
     (2, 24, 64, 64, 25, 1, False, 'affine_relu'), # post conv: K = 24 (one padded k-group)
     (5, 64, 64, 64, 25, 1, False, 'res_affine'),  # 65 wave tiles: the last workgroup is partly empty
     (3, 48, 128, 32, 25, 1, False, 'affine_relu'),
+    (2, 64, 64, 25, 17, 1, False, 'res_affine'),  # coco last stage: odd plane length (425): dword-aligned 16-B loads in wgrad
+    (2, 128, 256, 25, 17, 1, False, 'plain'),
 ])
 def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
     g = torch.Generator().manual_seed(Ci * 7 + Co + T)
