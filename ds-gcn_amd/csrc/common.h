@@ -50,3 +50,31 @@ __device__ __forceinline__ void wave_lds_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
+
+// t = e / V, v = e % V for 0 <= e < 2^22 with invV = 1.f / V (float reciprocal + one fix-up step: exact)
+__device__ __forceinline__ void divmod_small(int e, int V, float invV, int& t, int& v) {
+  t = (int)((float)e * invV);
+  v = e - t * V;
+  if (v < 0) { v += V; --t; }
+  else if (v >= V) { v -= V; ++t; }
+}
+
+// One wave copies a 16-B aligned run of L4 float4 from global memory into LDS; the loads of a 512-float4 chunk are all
+// issued before the first LDS write (whole (T,V) planes are <= a few KB: the wave keeps the entire plane in flight).
+__device__ __forceinline__ void plane_to_lds(const float* __restrict__ src, float* __restrict__ dst, int L4, int lane) {
+  const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(src);
+  f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dst);
+  for (int base = 0; base < L4; base += 512) {
+    f32x4 r[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = base + q * 64 + lane;
+      if (i < L4) r[q] = s4[i];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = base + q * 64 + lane;
+      if (i < L4) d4[i] = r[q];
+    }
+  }
+}

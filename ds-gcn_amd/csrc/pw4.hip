@@ -35,7 +35,7 @@ struct Pw4Args {
   const float* es1; const float* eh1; const float* es2; const float* eh2;
   int erelu;
   float* out2; float* ipart;                                               // EPI 1: d x2 or NULL; [ngrp][M][3] or NULL
-  int n, K, M, L, ntl, WT, cc, Kpad;
+  int n, K, M, L, span, WT, cc, Kpad;
 };
 
 template <int NQ> struct VQ;
@@ -100,18 +100,25 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   const int K = a.K, M = a.M, L = a.L;
   const int Kpad = a.Kpad, KP = Kpad + 1;
   float* Ws = lds;                                                       // [32*MT][KP], zero beyond (M, K)
-  f32x4* Ps = reinterpret_cast<f32x4*>(lds + ((32 * MT * KP + 3) & ~3));  // [Kpad] (s1, h1, s2, h2)
+  f32x4* Ps = reinterpret_cast<f32x4*>(lds + ((32 * MT * KP + 2 + 3) & ~3));  // [Kpad + 2] (s1, h1, s2, h2)
 
+  // Position tiles run over the planes of all samples back to back (a tile may straddle samples: L % NQ == 0, so a lane's
+  // NQ positions never do): no per-sample tail tile — at L = 400 (256 channels, 16 frames) per-sample tiling left
+  // 22 % of the MFMA work on padding.  The wave's buffer resources start at its first sample n; a lane adds ds sample
+  // strides in its vector offset.
   const int wt = grp * 4 + wave;
   const bool wlive = wt < a.WT;
-  const int n = wlive ? wt / a.ntl : 0;
-  const int tl = wlive ? wt - n * a.ntl : 0;
-  const int pos = tl * (32 * NQ) + l31 * NQ;
-  const bool pok = wlive && pos < L;
+  const int g0 = (wlive ? wt : 0) * (32 * NQ);          // < 2^31 (p4_plan)
+  const int n = g0 / L;
+  int pos = g0 - n * L + l31 * NQ;
+  int ds = 0;
+  while (pos >= L) { pos -= L; ++ds; }
+  const bool pok = wlive && n + ds < a.n;
   const int L4 = L * 4;
-  const int voff = pok ? (half * L + pos) * 4 : P4_OOB;
-  const __amdgpu_buffer_rsrc_t r1 = p4_rsrc(a.b1 + (size_t)n * K * L, wlive ? K * L4 : 0);
-  const __amdgpu_buffer_rsrc_t r2 = p4_rsrc((MODE == 2 ? a.b2 : a.b1) + (size_t)n * K * L, (wlive && MODE == 2) ? K * L4 : 0);
+  const int nrem = a.n - n < a.span ? a.n - n : a.span;     // samples the wave can touch
+  const int voff = pok ? ds * K * L4 + (half * L + pos) * 4 : P4_OOB;
+  const __amdgpu_buffer_rsrc_t r1 = p4_rsrc(a.b1 + (size_t)n * K * L, wlive ? nrem * K * L4 : 0);
+  const __amdgpu_buffer_rsrc_t r2 = p4_rsrc((MODE == 2 ? a.b2 : a.b1) + (size_t)n * K * L, (wlive && MODE == 2) ? nrem * K * L4 : 0);
 
   // ---- weights: global -> registers (all loads of a batch issued together), operand prefetch, then LDS ----
   constexpr int WB = 16;
@@ -176,17 +183,29 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
 
   const float lo = a.relu ? 0.f : -__builtin_inff();
   const int KS = Kpad >> 1;                        // k-steps (2 channels each), a multiple of PD
+  // Software pipeline, pinned with scheduling barriers.  Step ks: start the LDS reads of step ks+1 (A fragment, affine
+  // row; double-buffered by step parity), apply the affine to the operand loaded PD steps ago, run the MT*NQ MFMAs, then
+  // re-issue that operand buffer's load for step ks+PD (after the MFMAs: the buffer registers are dead by then, so the
+  // load lands in place).  Left to itself the compiler sinks all PD loads to the end of the unrolled body and waits for
+  // the first of them at the top of the next one — or, with the load ahead of the MFMAs, rotates the PD buffers through
+  // v_mov chains behind a vmcnt(0) (profiles/r02: matrix pipe 61 % busy at 256 -> 256 channels).
+  float avb[2][MT];
+  f32x4 pb[2] = {{1.f, 0.f, 1.f, 0.f}, {1.f, 0.f, 1.f, 0.f}};
+#pragma unroll
+  for (int m = 0; m < MT; ++m) avb[0][m] = Ws[(32 * m + l31) * KP + half];
+  if (MODE != 0) pb[0] = Ps[half];
   for (int base = 0; base < KS; base += PD) {
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
       const int ks = base + u;
-      const int kl = 2 * ks + half;
-      float av[MT];
+      const int cur = u & 1, nxt = cur ^ 1;                              // PD is even: the parity survives the back edge
+      const int kn = 2 * (ks + 1) + half;                                // last step: reads the LDS pad, never used
 #pragma unroll
-      for (int m = 0; m < MT; ++m) av[m] = Ws[(32 * m + l31) * KP + kl];
+      for (int m = 0; m < MT; ++m) avb[nxt][m] = Ws[(32 * m + l31) * KP + kn];
+      if (MODE != 0) pb[nxt] = Ps[kn];
       vq b = buf1[u];
       if (MODE != 0) {
-        const f32x4 p = Ps[kl];
+        const f32x4 p = pb[cur];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           float v = fmaf(b[q], p.x, p.y);
@@ -194,12 +213,15 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
           b[q] = fmaxf(v, lo);
         }
       }
-      buf1[u] = p4_load<NQ>(r1, voff, 2 * (ks + PD) * L4);             // past K: out of bounds -> 0, no traffic
-      if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, 2 * (ks + PD) * L4);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], b[q], acc[m][q], 0, 0, 0);
+        for (int q = 0; q < NQ; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(avb[cur][m], b[q], acc[m][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      buf1[u] = p4_load<NQ>(r1, voff, 2 * (ks + PD) * L4);             // past K: weights are zero
+      if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, 2 * (ks + PD) * L4);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();                                 // every wave is done with Ws / Ps: LDS is reused below
@@ -208,8 +230,8 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   // and are dropped by the bounds check: no branches); per-channel sums through LDS transposes of the wave's tiles.
   constexpr int NTL = EPI == 0 ? 2 : 3;            // transposed tiles per wave
   float* Tw = lds + wave * (NTL * 32 * 36);
-  const __amdgpu_buffer_rsrc_t ro = p4_rsrc(a.out + (size_t)n * M * L, wlive ? M * L4 : 0);
-  const int ooff = pok ? pos * 4 : P4_OOB;
+  const __amdgpu_buffer_rsrc_t ro = p4_rsrc(a.out + (size_t)n * M * L, wlive ? nrem * M * L4 : 0);
+  const int ooff = pok ? ds * M * L4 + pos * 4 : P4_OOB;
   if (EPI == 0) {
     double* Ss = reinterpret_cast<double*>(lds + 4 * NTL * 32 * 36);    // [4 waves][MT*32][2]
     const bool stats = a.partial != nullptr;
@@ -276,9 +298,9 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
       Es[tid] = p;
     }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rx1 = p4_rsrc(a.ex1 + (size_t)n * M * L, (wlive && need_x) ? M * L4 : 0);
-    const __amdgpu_buffer_rsrc_t rx2 = p4_rsrc((has2 ? a.ex2 : a.ex1) + (size_t)n * M * L, (wlive && has2) ? M * L4 : 0);
-    const __amdgpu_buffer_rsrc_t ro2 = p4_rsrc((a.out2 ? a.out2 : a.out) + (size_t)n * M * L, (wlive && a.out2) ? M * L4 : 0);
+    const __amdgpu_buffer_rsrc_t rx1 = p4_rsrc(a.ex1 + (size_t)n * M * L, (wlive && need_x) ? nrem * M * L4 : 0);
+    const __amdgpu_buffer_rsrc_t rx2 = p4_rsrc((has2 ? a.ex2 : a.ex1) + (size_t)n * M * L, (wlive && has2) ? nrem * M * L4 : 0);
+    const __amdgpu_buffer_rsrc_t ro2 = p4_rsrc((a.out2 ? a.out2 : a.out) + (size_t)n * M * L, (wlive && a.out2) ? nrem * M * L4 : 0);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
 
 int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0;
 
-struct P4Plan { int MT, NQ, PD, cc, ntl, WT, ngrp, Kpad; size_t lds; unsigned grid; };
+struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad; size_t lds; unsigned grid; };
 
 bool p4_plan(int n, int K, int M, int L, P4Plan* p) {
   if (L % 2) return false;
@@ -372,14 +394,17 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p) {
   if (MT * NQ > 8) MT = 4;
   int PD = NQ == 4 ? 8 : 16;
   if (g_p4_pd == 8 || g_p4_pd == 16) PD = g_p4_pd;
-  if ((long)K * L * 4 >= (1L << 31) - 64 || (long)M * L * 4 >= (1L << 31) - 64) return false;
+  // samples a wave's 32*NQ-position tile can touch; its buffer resources span that many planes (32-bit offsets)
+  const int span = (32 * NQ + L - 1) / L + 1;
+  if ((long)K * L * 4 * span >= (1L << 31) - 64 || (long)M * L * 4 * span >= (1L << 31) - 64) return false;
+  if ((long)n * L >= (1L << 31) - 256) return false;
   p->MT = MT; p->NQ = NQ; p->PD = PD;
   p->cc = (mtiles + MT - 1) / MT;
-  p->ntl = (L + 32 * NQ - 1) / (32 * NQ);
-  p->WT = n * p->ntl;
+  p->span = span;
+  p->WT = (int)(((long)n * L + 32 * NQ - 1) / (32 * NQ));
   p->ngrp = (p->WT + 3) / 4;
   p->Kpad = (K + 2 * PD - 1) / (2 * PD) * (2 * PD);
-  size_t f = (size_t)((32 * MT * (p->Kpad + 1) + 3) & ~3) + (size_t)4 * p->Kpad;
+  size_t f = (size_t)((32 * MT * (p->Kpad + 1) + 2 + 3) & ~3) + (size_t)4 * (p->Kpad + 2);   // + the pipeline's read-ahead pad
   const size_t fe = (size_t)4 * 3 * 32 * 36 + (size_t)4 * MT * 32 * 4 + (size_t)MT * 32 * 4;    // epilogue image
   if (f < fe) f = fe;
   p->lds = f * sizeof(float);
@@ -441,7 +466,7 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const fl
   Pw4Args a = {};
   a.b1 = x1; a.b2 = x2; a.ps1 = s1; a.ph1 = h1; a.ps2 = s2; a.ph2 = h2; a.relu = relu;
   a.w = w; a.w_ldm = Ci; a.w_ldk = 1; a.bias = bias; a.out = z; a.partial = partial;
-  a.n = n; a.K = Ci; a.M = Co; a.L = L; a.ntl = p.ntl; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad;
+  a.n = n; a.K = Ci; a.M = Co; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad;
   const int mode = x2 ? 2 : ((s1 || relu) ? 1 : 0);
   const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 0, p, st) : p4_launch_pd<16>(a, mode, 0, p, st);
   if (!ok) return 0;
@@ -464,7 +489,7 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const 
   a.w = w; a.w_ldm = 1; a.w_ldk = Ci; a.bias = nullptr; a.out = dx1; a.partial = nullptr;
   a.ex1 = x1; a.ex2 = x2; a.es1 = s1; a.eh1 = h1; a.es2 = s2; a.eh2 = h2; a.erelu = relu;
   a.out2 = dx2; a.ipart = ipart;
-  a.n = n; a.K = Co; a.M = Ci; a.L = L; a.ntl = p.ntl; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad;
+  a.n = n; a.K = Co; a.M = Ci; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad;
   const int mode = A0 ? 2 : 0;
   const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 1, p, st) : p4_launch_pd<16>(a, mode, 1, p, st);
   if (!ok) return 0;

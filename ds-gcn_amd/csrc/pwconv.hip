@@ -384,8 +384,12 @@ __global__ __launch_bounds__(64) void k_rowmean_stats(const float* __restrict__ 
   const long plane = blockIdx.x;
   const int L = T * V;
   const float* __restrict__ pz = z + (size_t)plane * L;
+  if ((L & 3) == 0) {
+    plane_to_lds(pz, lds, L >> 2, lane);
+  } else {
 #pragma unroll 4
-  for (int i = lane; i < L; i += 64) lds[i] = pz[i];
+    for (int i = lane; i < L; i += 64) lds[i] = pz[i];
+  }
   wave_lds_sync();
   const float invV = 1.f / (float)V;
   double sv = 0.0, qv = 0.0;
@@ -430,6 +434,54 @@ __global__ __launch_bounds__(64) void k_dz_eff_aug(const float* __restrict__ gz,
     const int t = i / V;
     const float e = (pga ? pga[t] : 0.f) + fmaf(b0, pza[t], a0);
     po[i] = (pg ? pg[i] : 0.f) + fmaf(b0, pz[i], a0) + e * invV;
+  }
+}
+
+// 16-byte form of k_dz_eff_aug (T*V % 4 == 0): per-frame term e[t] staged in LDS, planes streamed as float4 with
+// all loads of a 256-float4 chunk issued before the arithmetic
+__global__ __launch_bounds__(64) void k_dz_eff_aug4(const float* __restrict__ gz, const float* __restrict__ z,
+                                                    const float* __restrict__ gzaug, const float* __restrict__ zaug,
+                                                    const float* __restrict__ A0, const float* __restrict__ B0,
+                                                    float* __restrict__ out, int C, int T, int V) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];       // [T] e
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const int L = T * V, L4 = L >> 2;
+  const float a0 = A0 ? A0[c] : 0.f, b0 = A0 ? B0[c] : 0.f;
+  const float invV = 1.f / (float)V;
+  for (int t = lane; t < T; t += 64)
+    lds[t] = ((gzaug ? gzaug[(size_t)plane * T + t] : 0.f) + fmaf(b0, zaug[(size_t)plane * T + t], a0)) * invV;
+  wave_lds_sync();
+  const f32x4* __restrict__ pg = gz ? reinterpret_cast<const f32x4*>(gz + (size_t)plane * L) : nullptr;
+  const f32x4* __restrict__ pz = reinterpret_cast<const f32x4*>(z + (size_t)plane * L);
+  f32x4* __restrict__ po = reinterpret_cast<f32x4*>(out + (size_t)plane * L);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (int base = 0; base < L4; base += 256) {
+    f32x4 g4[4], z4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = base + q * 64 + lane;
+      const bool ok = i < L4;
+      g4[q] = (ok && pg) ? pg[i] : zero4;
+      z4[q] = ok ? pz[i] : zero4;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = base + q * 64 + lane;
+      if (i >= L4) break;
+      const float gg[4] = {g4[q].x, g4[q].y, g4[q].z, g4[q].w};
+      const float zz[4] = {z4[q].x, z4[q].y, z4[q].z, z4[q].w};
+      int t, v;
+      divmod_small(4 * i, V, invV, t, v);
+      float r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        r[k] = gg[k] + fmaf(b0, zz[k], a0) + lds[t];
+        if (++v == V) { v = 0; ++t; }
+      }
+      po[i] = f32x4{r[0], r[1], r[2], r[3]};
+    }
   }
 }
 
@@ -1341,6 +1393,12 @@ int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const 
 int dsgcn_dz_eff_aug(const float* gz, const float* z, const float* gzaug, const float* zaug, const float* A0,
                      const float* B0, float* out, int n, int C, int T, int V, void* stream) {
   if (!z || !zaug || !out || n <= 0 || C <= 0 || T <= 0 || V <= 0) return DSGCN_EINVAL;
+  if ((T * V) % 4 == 0 && T <= 8192) {
+    hipLaunchKernelGGL(k_dz_eff_aug4, dim3((unsigned)((long)n * C)), dim3(64), (size_t)T * 4, (hipStream_t)stream, gz, z,
+                       gzaug, zaug, A0, B0, out, C, T, V);
+    DSGCN_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_dz_eff_aug, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, gz, z, gzaug, zaug,
                      A0, B0, out, C, T, V);
   DSGCN_LAUNCH_CHECK();

@@ -1,10 +1,10 @@
-"""Where do the per-step D2D blits / column sums come from?  torch.profiler over one eager bench step, aten::copy_ /
-aten::contiguous / aten::clone / aten::cat grouped by the calling Python line."""
+"""Which phase of the step issues the D2D blits (rocclr copyBuffer)?  torch.profiler (CPU+CUDA) over one eager step split
+into phases; prints per phase the count of memcpy-like device activities and the CPU ops that launched them."""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench, dsgcn_amd
-from torch.profiler import profile, ProfilerActivity
+from torch.profiler import profile, ProfilerActivity, record_function
 dev = torch.device('cuda')
 model = bench.build_model().to(dev).train()
 flat = dsgcn_amd.FlatParams(model, gather=True)
@@ -12,17 +12,30 @@ opt = dsgcn_amd.FlatSGD(flat)
 g = torch.Generator().manual_seed(0)
 batch = dict(keypoint=torch.randn(64, 1, 2, 64, 25, 3, generator=g).to(dev), label=torch.randint(0, 60, (64, 1), generator=g).to(dev))
 def step():
-    opt.zero_grad(); out = model.train_step(batch, None, sync_log_vars=False); out['loss'].backward(); flat.collect_grads(); opt.step()
+    with record_function('PH_zero'): opt.zero_grad()
+    with record_function('PH_fwd'): out = model.train_step(batch, None, sync_log_vars=False)
+    with record_function('PH_bwd'): out['loss'].backward()
+    with record_function('PH_collect'): flat.collect_grads()
+    with record_function('PH_opt'): opt.step()
 for _ in range(2): step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
-    step()
-torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step(); torch.cuda.synchronize()
+evs = prof.events()
+phases = [(e.name, e.time_range.start, e.time_range.end) for e in evs if e.name.startswith('PH_')]
 cnt = collections.Counter()
-for ev in prof.events():
-    if ev.name in ('aten::copy_', 'aten::contiguous', 'aten::clone', 'aten::cat', 'aten::zeros', 'aten::zero_', 'aten::fill_', 'aten::add', 'aten::mul', 'aten::pad', 'aten::constant_pad_nd'):
-        frames = [f for f in (ev.stack or []) if 'ds-gcn_amd' in f or 'bench.py' in f or 'autograd' in f]
-        key = (ev.name, frames[0].split('/')[-1] if frames else 'no-stack')
-        cnt[key] += 1
-for (name, where), c in cnt.most_common(40):
-    print(f'{c:5d}  {name:24s} {where}')
+for e in evs:
+    if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith('aten::') and e.cpu_parent is not None:
+        pass
+memc = [e for e in evs if ('Memcpy' in e.name or 'copyBuffer' in e.name or 'memcpy' in e.name.lower())]
+print('memcpy-like events:', len(memc), collections.Counter(e.name for e in memc).most_common(5))
+# attribute launches: CPU-side ops that have a memcpy kernel child
+ops = collections.Counter()
+for e in evs:
+    if e.device_type == torch.autograd.DeviceType.CPU and e.kernels:
+        for k in e.kernels:
+            if 'Memcpy' in k.name or 'copyBuffer' in k.name:
+                ph = next((p[0] for p in phases if p[1] <= e.time_range.start <= p[2]), '?')
+                ops[(ph, e.name)] += 1
+for (ph, name), c in ops.most_common(30):
+    print(f'{c:5d} {ph:12s} {name}')

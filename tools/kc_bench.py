@@ -12,6 +12,10 @@ SHAPES = [('pre1', 64, 24, 64, 0), ('post1', 24, 64, 64, 1), ('branch1', 64, 64,
           ('pre8', 256, 96, 16, 0), ('post8', 96, 256, 16, 1), ('branch8', 256, 256, 16, 2), ('transf8', 256, 256, 16, 1)]
 
 
+if os.environ.get('KC_SHAPES'):          # name,Ci,Co,T,mode;...
+    SHAPES = [(a, int(b), int(c), int(d), int(e)) for a, b, c, d, e in (x.split(',') for x in os.environ['KC_SHAPES'].split(';'))]
+
+
 def timeit(fn, reps=20):
     for _ in range(3):
         fn()
