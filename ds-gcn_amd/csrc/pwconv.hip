@@ -1105,6 +1105,7 @@ int g_pw4 = 7;           // bit 0: wide-load forward (pw4.hip), bit 1: wide-load
 // pw4.hip (internal linkage across the library's objects, not exported)
 __attribute__((visibility("hidden"))) int dsgcn_p4_tuning(int key, int value);
 __attribute__((visibility("hidden"))) int dsgcn_p4_groups(int n, int K, int M, int L);
+__attribute__((visibility("hidden"))) int dsgcn_wg2_tuning(int key, int value);
 __attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const float* s1, const float* h1,
                                                         const float* x2, const float* s2, const float* h2, int relu,
                                                         const float* w, const float* bias, float* z, float* partial,
@@ -1142,6 +1143,7 @@ int dsgcn_pwconv_tuning(int key, int value) {
   if (key == 2) { g_pw_roll = value; return 0; }
   if (key == 3) { g_pw4 = value; return 0; }
   if (key >= 4 && key <= 6) return dsgcn_p4_tuning(key - 4, value);
+  if (key >= 7 && key <= 9) return dsgcn_wg2_tuning(key - 7, value);
   return DSGCN_EINVAL;
 }
 #endif

@@ -221,19 +221,21 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
   }
 }
 
+int g_wg2_target4 = 512, g_wg2_kc128 = 32, g_wg2_target1 = 512;    // lab knobs (dsgcn_pwconv_tuning keys 7, 8); the values are the product's
+
 struct Wg2Plan { int TM, TN, KC, cpn, chunks, tm_tiles, tn_tiles, splits, cps; size_t lds; };
 
 bool wg2_plan(int n, int Ci, int Co, int L, Wg2Plan* p) {
   if ((long)Ci * L * 4 >= (1L << 31) - 64 || (long)Co * L * 4 >= (1L << 31) - 64) return false;
   p->TM = Co > 64 ? 128 : 64;
   p->TN = Ci > 64 ? 128 : 64;
-  p->KC = (p->TM == 128 && p->TN == 128) ? 32 : ((p->TM == 64 && p->TN == 64) ? 128 : 64);
+  p->KC = (p->TM == 128 && p->TN == 128) ? g_wg2_kc128 : ((p->TM == 64 && p->TN == 64) ? 128 : 64);
   p->cpn = (L + p->KC - 1) / p->KC;
   p->chunks = n * p->cpn;
   p->tm_tiles = (Co + p->TM - 1) / p->TM;
   p->tn_tiles = (Ci + p->TN - 1) / p->TN;
   const int tiles = p->tm_tiles * p->tn_tiles;
-  int target = (tiles >= 4 ? 256 : 512) / tiles;
+  int target = (tiles >= 4 ? g_wg2_target4 : g_wg2_target1) / tiles;
   if (target < 1) target = 1;
   if (tiles > 1) target = (target + 7) / 8 * 8;       // the XCD decode deals splits in groups of 8
   if (target > p->chunks) target = p->chunks;
@@ -255,6 +257,14 @@ void wg2_launch(const Wg2Args& a, bool has2, bool hasc, dim3 grid, size_t lds, h
 }
 
 }  // namespace
+
+__attribute__((visibility("hidden"))) int dsgcn_wg2_tuning(int key, int value) {
+  if (key == 0) g_wg2_target4 = value;
+  else if (key == 1) g_wg2_kc128 = value;
+  else if (key == 2) g_wg2_target1 = value;
+  else return DSGCN_EINVAL;
+  return 0;
+}
 
 // Internal (not exported): K-split count of the fast weight gradient for this shape, 0 = not eligible.
 __attribute__((visibility("hidden"))) int dsgcn_wg2_splits(int n, int Ci, int Co, int L) {
@@ -278,7 +288,8 @@ __attribute__((visibility("hidden"))) int dsgcn_wg2(const float* x1, const float
   const int tiles = p.tm_tiles * p.tn_tiles;
   const dim3 grid(tiles > 1 ? (unsigned)((p.splits + 7) / 8 * 8 * tiles) : (unsigned)p.splits);
   const bool has2 = x2 != nullptr, hasc = A0 != nullptr;
-  if (p.TM == 128 && p.TN == 128) wg2_launch<128, 128, 32>(a, has2, hasc, grid, p.lds, st);
+  if (p.TM == 128 && p.TN == 128 && p.KC == 64) wg2_launch<128, 128, 64>(a, has2, hasc, grid, p.lds, st);
+  else if (p.TM == 128 && p.TN == 128) wg2_launch<128, 128, 32>(a, has2, hasc, grid, p.lds, st);
   else if (p.TM == 128) wg2_launch<128, 64, 64>(a, has2, hasc, grid, p.lds, st);
   else if (p.TN == 128) wg2_launch<64, 128, 64>(a, has2, hasc, grid, p.lds, st);
   else wg2_launch<64, 64, 128>(a, has2, hasc, grid, p.lds, st);

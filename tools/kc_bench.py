@@ -30,7 +30,7 @@ def timeit(fn, reps=20):
 
 
 def run(variant):
-    keys = {3: 3, 4: 0, 5: 0, 6: 0}
+    keys = {3: 7, 4: 0, 5: 0, 6: 0, 7: 512, 8: 32, 9: 512}
     if variant:
         for kv in variant.split(','):
             k, v = kv.split('=')
