@@ -513,6 +513,398 @@ __global__ __launch_bounds__(TC_NT) void k_tapconv_wgrad_narrow(TArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wide-load form of the forward / data gradient ("tap4") for the multi-scale units' narrow windows: stride 1, KT = 3,
+// windows <= 64 channels, T*V1 % 4 == 0 and dil*V1 even (DS-STGCN: V1 = 26; K400: 18).  Same idea as K-C's pw4 form: a
+// lane owns FOUR consecutive positions of one channel row, register q of the loaded vector is the B fragment of
+// position sub-tile q, and the four results of a lane are again 16 consecutive bytes.  The tap shift is a whole number of
+// rows (+-dil*V1 positions, even): the centre tap is one aligned 16-byte load, a side tap two 8-byte loads, each pair
+// entirely inside or entirely outside the plane (zero padding = the buffer bounds check, no per-element masks).  K runs
+// channel-pair major / tap minor through a pinned software pipeline (3*PDK operand slots in flight, A fragments read
+// from LDS one step ahead).  Position tiles run over all samples back to back.  The max-pool / pass-through windows
+// ride in the same launch as whole-plane passes through LDS (one wave per (n,c) plane) — the first version walked
+// their channels in a per-thread loop of dependent loads and recomputed the pooling argmax from global memory
+// (tools/tc_bench.py, 128 samples: forward 53..93 us, data gradient 71..134 us per layer before).
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x2t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 t4_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x2t t4_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x2t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
+template <bool FWD, int MT>
+__device__ __forceinline__ void t4_conv(const TArgs& a, const TBranch& br, float* Ws, int grp, int lane, int wave) {
+  constexpr int KT = 3, PDK = 2, NS = KT * PDK;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int V1 = a.V1, L = a.T * V1, L4 = L * 4;
+  const int Csrc = FWD ? a.Cin : a.Cout, Cdst = FWD ? a.Cout : a.Cin;
+  const int sch0 = FWD ? br.ci0 : br.co0, nsrc = FWD ? br.cin : br.cout;
+  const int dch0 = FWD ? br.co0 : br.ci0, ndst = FWD ? br.cout : br.cin;
+  const int CP = tc_cp(br), S = KT * CP + 1;
+  tc_stage_w<KT>(br, Ws, 0, br.cout, 0, br.cin, CP);          // [co][tap*CP + ci], zero padded; ends with a barrier
+
+  const int wt = grp * 4 + wave;
+  const long total = (long)a.n * L;
+  const bool wlive = (long)wt * 128 < total;
+  const int g0 = wlive ? wt * 128 : 0;
+  const int n0 = g0 / L;
+  int p = g0 - n0 * L + 4 * l31, ds = 0;
+  while (p >= L) { p -= L; ++ds; }
+  const bool pok = wlive && n0 + ds < a.n;
+  const __amdgpu_buffer_rsrc_t rs = tc_rsrc(FWD ? a.h : a.go, (size_t)a.n * Csrc * L4);
+  const int rowbase = ((n0 + ds) * Csrc + sch0 + half) * L;   // (the launch checks the tensor stays below 2^31 bytes)
+  const int sh = (FWD ? br.dil : -br.dil) * V1;               // shift of tap 2 (tap 0: -sh)
+  const int qa = p - sh, qb = p + sh;
+  const int vC = pok ? (rowbase + p) * 4 : TC_OOB;
+  const int vA0 = (pok && qa >= 0 && qa <= L - 2) ? (rowbase + qa) * 4 : TC_OOB;
+  const int vA1 = (pok && qa + 2 >= 0 && qa + 2 <= L - 2) ? (rowbase + qa + 2) * 4 : TC_OOB;
+  const int vB0 = (pok && qb >= 0 && qb <= L - 2) ? (rowbase + qb) * 4 : TC_OOB;
+  const int vB1 = (pok && qb + 2 >= 0 && qb + 2 <= L - 2) ? (rowbase + qb + 2) * 4 : TC_OOB;
+  auto load = [&](int tap, int ks) -> f32x4 {
+    const int soff = 2 * ks * L4;
+    if (tap == 1) return t4_load4(rs, vC, soff);
+    const f32x2t lo = t4_load2(rs, tap == 0 ? vA0 : vB0, soff), hi = t4_load2(rs, tap == 0 ? vA1 : vB1, soff);
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+  };
+
+  const int KS2 = ((nsrc + 3) >> 2) << 1;                    // k-steps of two channels, even (weights are zero past nsrc)
+  f32x4 buf[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    buf[u] = load(u % KT, u / KT);
+    __builtin_amdgcn_sched_barrier(0);             // issue order = slot order, as in the loop (exact vmcnt waits)
+  }
+  f32x16 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+  // A fragment of step (ks, tap): FWD Ws[(32m + l31)*S + tap*CP + 2ks + half];  BWD Ws[(2ks + half)*S + tap*CP + 32m + l31]
+  auto afrag = [&](int tap, int ks, int m) -> float {
+    const int kl = 2 * ks + half;
+    return FWD ? Ws[(32 * m + l31) * S + tap * CP + kl] : Ws[kl * S + tap * CP + 32 * m + l31];
+  };
+  float avb[2][MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) avb[0][m] = afrag(0, 0, m);
+  for (int base = 0; base < KS2; base += PDK) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int tap = u % KT, ks = base + u / KT;
+      const int cur = u & 1, nxt = cur ^ 1;                   // NS is even: the parity survives the back edge
+      const int tn = (u + 1) % KT, kn = base + (u + 1) / KT;  // next step (past the end: reads pad rows, never used)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) avb[nxt][m] = afrag(tn, kn < 32 ? kn : 31, m);
+      const f32x4 b = buf[u];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(avb[cur][m], b[q], acc[m][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      buf[u] = load(tap, min(ks + PDK, KS2 - 1));           // branch-free (the tail re-reads the last step: L2 hits), so the
+                                                            // compiler's vmcnt bookkeeping stays exact
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float* dst = FWD ? a.o : a.dh;
+  const __amdgpu_buffer_rsrc_t ro = tc_rsrc(dst, (size_t)a.n * Cdst * L4);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = 32 * m + tc_row32(r, half);
+      const float bias = (FWD && br.b && ch < ndst) ? br.b[ch] : 0.f;
+      const f32x4 v = {acc[m][0][r] + bias, acc[m][1][r] + bias, acc[m][2][r] + bias, acc[m][3][r] + bias};
+      const int voff = (pok && ch < ndst) ? (((n0 + ds) * Cdst + dch0 + ch) * L + p) * 4 : TC_OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, voff, 0, 0);
+    }
+  }
+}
+
+// one wave per (n, c) plane of a max-pool / pass-through window, stride 1
+template <bool FWD>
+__device__ __forceinline__ void t4_elem(const TArgs& a, const TBranch& br, float* lw, int n, int c, int lane) {
+  const int V1 = a.V1, L = a.T * V1, L4c = L >> 2;
+  const float* hp = a.h + ((size_t)n * a.Cin + br.ci0 + c) * L;
+  if (FWD) {
+    f32x4* op = reinterpret_cast<f32x4*>(a.o + ((size_t)n * a.Cout + br.co0 + c) * L);
+    if (br.type == 2) {
+      const f32x4* h4 = reinterpret_cast<const f32x4*>(hp);
+      for (int i = lane; i < L4c; i += 64) op[i] = h4[i];
+      return;
+    }
+    plane_to_lds(hp, lw, L4c, lane);
+    wave_lds_sync();
+    for (int i = lane; i < L4c; i += 64) {
+      const int e = 4 * i;
+      float r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v = lw[e + k];
+        if (e + k - V1 >= 0) v = fmaxf(v, lw[e + k - V1]);
+        if (e + k + V1 < L) v = fmaxf(v, lw[e + k + V1]);
+        r[k] = v;
+      }
+      op[i] = f32x4{r[0], r[1], r[2], r[3]};
+    }
+    return;
+  }
+  const float* gp = a.go + ((size_t)n * a.Cout + br.co0 + c) * L;
+  f32x4* dp = reinterpret_cast<f32x4*>(a.dh + ((size_t)n * a.Cin + br.ci0 + c) * L);
+  if (br.type == 2) {
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gp);
+    for (int i = lane; i < L4c; i += 64) dp[i] = g4[i];
+    return;
+  }
+  float* lg = lw + L;
+  plane_to_lds(hp, lw, L4c, lane);
+  plane_to_lds(gp, lg, L4c, lane);
+  wave_lds_sync();
+  // the gradient of window t' goes to its FIRST maximal valid tap (ATen max_pool2d_with_indices order)
+  for (int i = lane; i < L4c; i += 64) {
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = 4 * i + k;                    // position of (t, x)
+      float g = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int ec = e - (kk - 1) * V1;          // centre (t', x) of a window that covers t
+        if (ec < 0 || ec >= L) continue;
+        float best = -INFINITY;
+        int arg = -1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int et = ec + (j - 1) * V1;
+          if (et >= 0 && et < L) {
+            const float v = lw[et];
+            if (v > best || arg < 0) { best = v; arg = et; }
+          }
+        }
+        if (arg == e) g += lg[ec];
+      }
+      r[k] = g;
+    }
+    dp[i] = f32x4{r[0], r[1], r[2], r[3]};
+  }
+}
+
+// grid.x = [conv blocks: (position group, conv window)] ++ [elementwise blocks: 4 planes each]
+template <bool FWD, int MT>
+__global__ __launch_bounds__(TC_NT, MT == 1 ? 3 : 2) void k_tap4(TArgs a, int nconv, int ngrp, int eplanes) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cb = nconv * ngrp;
+  if ((int)blockIdx.x < cb) {
+    const int w = blockIdx.x % nconv, grp = blockIdx.x / nconv;
+    int bi = 0;
+    for (int i = 0, k = 0; i < a.nbr; ++i)
+      if (a.br[i].type == 0) { if (k == w) bi = i; ++k; }
+    t4_conv<FWD, MT>(a, a.br[bi], lds, grp, lane, wave);
+    return;
+  }
+  int pl = ((int)blockIdx.x - cb) * 4 + wave;      // plane index over (n, elementwise channels)
+  if (pl >= a.n * eplanes) return;
+  const int n = pl / eplanes;
+  int c = pl - n * eplanes;
+  for (int i = 0; i < a.nbr; ++i) {
+    if (a.br[i].type == 0) continue;
+    if (c < a.br[i].cin) {
+      t4_elem<FWD>(a, a.br[i], lds + (size_t)wave * 2 * a.T * a.V1, n, c, lane);
+      return;
+    }
+    c -= a.br[i].cin;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wide-load weight gradient ("tapw") for the same shapes as tap4 (stride 1, KT = 3, V1 even, windows <= 64 channels)
+// with T % 4 == 0:   dW[co,ci,tap] = sum_{n,p} do[n,co,p] * h[n,ci,p + (tap-1)*dil*V1],   db[co] = sum do.
+// Work unit = (sample, 4 frames).  The workgroup stages do (4 frames) and h (the 4 frames plus a 4-frame halo on either
+// side: every dilation <= 4 reads its shifted operand from the SAME tile) with 16-byte loads — the first version loaded
+// each tap's shifted copy separately with 4-byte loads in 16-byte row pieces and was bound by the address path (TA), not
+// by memory or the matrix core (92..121 us per layer at 128 samples) — into LDS rows of stride = 2 mod 4 floats
+// (conflict-free ds_read_b64, one read feeds two MFMA k-steps as in K-C's weight gradient).  CH = 32: the (co x ci) tile
+// is one MFMA tile, the four waves split the POSITIONS of a unit and their accumulators are summed through LDS at the
+// end; CH = 64: 2x2 wave tiles.  grid = (K-splits, conv windows); every split writes its partial row (dsgcn_colsum).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TW_R = 4, TW_H = 4;                 // frames per unit, halo frames per side (max dilation)
+
+__host__ __device__ inline int tw_ls(int w) { return ((w + 1) & ~3) + 2; }      // >= w, = 2 mod 4
+
+template <int CH>
+__global__ __launch_bounds__(TC_NT, CH == 32 ? 2 : 1) void k_tapw(TArgs a, int nconv) {
+  constexpr int KT = 3;
+  constexpr int JD = CH == 32 ? 4 : 7, JX = CH == 32 ? 10 : 20;     // float4 staging slots per thread (V1 <= 26)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  int bi = 0;
+  for (int i = 0, k = 0; i < a.nbr; ++i)
+    if (a.br[i].type == 0) { if (k == (int)blockIdx.y) bi = i; ++k; }
+  const TBranch& br = a.br[bi];
+  const int V1 = a.V1, T = a.T, L = T * V1;
+  const int nco = br.cout, nci = br.cin;
+  const int GW = TW_R * V1, XW = (TW_R + 2 * TW_H) * V1;            // tile widths (floats); multiples of 4
+  const int GW4 = GW >> 2, XW4 = XW >> 2, SEG4 = (TW_H * V1) >> 2;  // float4 per row; float4 per 4-frame segment
+  const int LSd = tw_ls(GW), LSx = tw_ls(XW);
+  float* Ds = lds;                                                   // [CH][LSd]
+  float* Xs = lds + CH * LSd;                                        // [CH][LSx]
+  for (int i = tid; i < CH * (LSd + LSx); i += TC_NT) lds[i] = 0.f;  // rows >= nco / nci and the pad columns stay zero
+
+  const int units = a.n * (T / TW_R);
+  const int per = (units + a.splits - 1) / a.splits;
+  const int u0 = blockIdx.x * per, u1 = min(units, u0 + per);
+
+  const __amdgpu_buffer_rsrc_t rg = tc_rsrc(a.go, (size_t)a.n * a.Cout * L * 4);
+  const __amdgpu_buffer_rsrc_t rh = tc_rsrc(a.h, (size_t)a.n * a.Cin * L * 4);
+  // staging slots: f = tid + 256*j -> (row, float4 column); fixed per thread
+  int vD[JD], lD[JD], vX[JX], lX[JX], segX[JX];
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int f = tid + TC_NT * j, row = f / GW4, c4 = f - row * GW4;
+    const bool ok = row < nco;
+    vD[j] = ok ? (row * L + 4 * c4) * 4 : TC_OOB;
+    lD[j] = ok ? row * LSd + 4 * c4 : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < JX; ++j) {
+    const int f = tid + TC_NT * j, row = f / XW4, c4 = f - row * XW4;
+    const bool ok = row < nci;
+    vX[j] = ok ? (row * L + 4 * c4) * 4 : TC_OOB;
+    lX[j] = ok ? row * LSx + 4 * c4 : -1;
+    segX[j] = c4 / SEG4;                                             // 0 = halo before, 1 = the unit, 2 = halo after
+  }
+  f32x4 gr[JD], xr[JX];
+  float dsum[JD];
+#pragma unroll
+  for (int j = 0; j < JD; ++j) dsum[j] = 0.f;
+  auto issue = [&](int u) {
+    const int n = u / (T / TW_R), t0 = (u - n * (T / TW_R)) * TW_R;
+    const int sg = ((n * a.Cout + br.co0) * L + t0 * V1) * 4;
+    const int sx = ((n * a.Cin + br.ci0) * L + (t0 - TW_H) * V1) * 4;    // may be negative: only used with valid slots
+    const bool before = t0 >= TW_H, after = t0 + TW_R < T;
+#pragma unroll
+    for (int j = 0; j < JD; ++j) gr[j] = t4_load4(rg, vD[j], sg);
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const bool ok = segX[j] == 1 || (segX[j] == 0 ? before : after);
+      xr[j] = t4_load4(rh, ok ? vX[j] + sx : TC_OOB, 0);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      if (lD[j] >= 0) {
+        f32x2t* d = reinterpret_cast<f32x2t*>(Ds + lD[j]);
+        d[0] = f32x2t{gr[j].x, gr[j].y};
+        d[1] = f32x2t{gr[j].z, gr[j].w};
+        dsum[j] += (gr[j].x + gr[j].y) + (gr[j].z + gr[j].w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      if (lX[j] >= 0) {
+        f32x2t* d = reinterpret_cast<f32x2t*>(Xs + lX[j]);
+        d[0] = f32x2t{xr[j].x, xr[j].y};
+        d[1] = f32x2t{xr[j].z, xr[j].w};
+      }
+    }
+  };
+
+  constexpr int NA = CH == 32 ? 1 : 1;
+  f32x16 acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+  (void)NA;
+  // CH = 32: wave w takes the position groups [g0, g1) of the unit's GW4 groups of 4; CH = 64: wave = (mt, nt), all groups
+  const int mt = CH == 64 ? (wave >> 1) : 0, nt = CH == 64 ? (wave & 1) : 0;
+  const int g0 = CH == 32 ? (GW4 * wave) / 4 : 0, g1 = CH == 32 ? (GW4 * (wave + 1)) / 4 : GW4;
+  const int sh = br.dil * V1;
+  const float* Ap = Ds + (32 * mt + l31) * LSd + 2 * half;
+  const float* Bp = Xs + (32 * nt + l31) * LSx + TW_H * V1 + 2 * half;
+
+  __syncthreads();                                  // zero fill done
+  if (u0 < u1) issue(u0);
+  for (int u = u0; u < u1; ++u) {
+    commit();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (u + 1 < u1) issue(u + 1);
+    for (int g = g0; g < g1; ++g) {
+      const f32x2t av = *reinterpret_cast<const f32x2t*>(Ap + 4 * g);
+      const f32x2t b0 = *reinterpret_cast<const f32x2t*>(Bp + 4 * g - sh);
+      const f32x2t b1 = *reinterpret_cast<const f32x2t*>(Bp + 4 * g);
+      const f32x2t b2 = *reinterpret_cast<const f32x2t*>(Bp + 4 * g + sh);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b2.x, acc[2], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b2.y, acc[2], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // raw barrier: the next unit's loads stay in flight
+  }
+
+  float* dw = br.dwp + (size_t)blockIdx.x * a.pstride;
+  float* db = br.dbp + (size_t)blockIdx.x * a.pstride;
+  if (CH == 32) {
+    // sum the four position shares: Rs[wave][tap][co][ci] in the tile's LDS (48 KB <= the staging image)
+    float* Rs = lds;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Rs[((wave * KT + k) * 32 + tc_row32(r, half)) * 33 + l31] = acc[k][r];
+    __syncthreads();
+    for (int o = tid; o < KT * nco * nci; o += TC_NT) {
+      const int co = o / (nci * KT), r2 = o - co * nci * KT, ci = r2 / KT, k = r2 - ci * KT;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += Rs[((w * KT + k) * 32 + co) * 33 + ci];
+      dw[o] = v;                                     // (co*cin + ci)*KT + tap
+    }
+    __syncthreads();
+  } else {
+    const int ci = 32 * nt + l31;
+    if (ci < nci) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * mt + tc_row32(r, half);
+        if (co < nco) {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) dw[((size_t)co * nci + ci) * KT + k] = acc[k][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // db: per-thread row pieces -> LDS -> one thread per row
+  float* Bs = lds;                                   // [CH][GW4 + 1]... laid out [row][c4]
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int f = tid + TC_NT * j, row = f / GW4, c4 = f - row * GW4;
+    if (row < nco) Bs[row * (GW4 + 1) + c4] = dsum[j];
+  }
+  __syncthreads();
+  if (tid < nco) {
+    float v = 0.f;
+    for (int c = 0; c < GW4; ++c) v += Bs[tid * (GW4 + 1) + c];
+    db[tid] = v;
+  }
+}
+
 size_t tc_lds_conv(int CP, int KT) { return (size_t)(64 * (KT * CP + 1) + 64) * sizeof(float); }
 
 constexpr size_t TC_LDS_MAX = 156 * 1024;
@@ -549,6 +941,61 @@ int tc_fill(TArgs& a, int nbr, const int* type, const int* ci0, const int* co0, 
   a.dch = dch;
   a.narrow = wmax;                                 // widest conv window (channels)
   return cpmax;
+}
+
+
+// tap4 eligibility and launch (forward / data gradient); returns 1 = launched, 0 = not eligible, else an error code
+template <bool FWD>
+int t4_try(const TArgs& a, int KT, hipStream_t st) {
+  if (KT != 3 || a.stride != 1 || a.narrow <= 0 || a.narrow > 64) return 0;
+  const long L = (long)a.T * a.V1;
+  if (L % 4 || (a.V1 & 1)) return 0;
+  const int cmax = a.Cin > a.Cout ? a.Cin : a.Cout;
+  if ((long)a.n * cmax * L * 4 >= (1L << 31) - 4096 || (long)a.n * L >= (1L << 31) - 256) return 0;
+  int nconv = 0, eplanes = 0, cpmax = 8;
+  for (int i = 0; i < a.nbr; ++i) {
+    const TBranch& b = a.br[i];
+    if (b.type == 0) {
+      ++nconv;
+      cpmax = std::max(cpmax, (std::min(64, b.cin) + 7) & ~7);
+      if ((b.dil * a.V1) & 1) return 0;
+    } else {
+      eplanes += b.cin;
+    }
+  }
+  const size_t lds = std::max(tc_lds_conv(cpmax, 3), (size_t)4 * 2 * L * sizeof(float));
+  if (lds > 64 * 1024) return 0;
+  const int WT = (int)(((long)a.n * L + 127) / 128), ngrp = (WT + 3) / 4;
+  const long blocks = (long)nconv * ngrp + ((long)a.n * eplanes + 3) / 4;
+  if (blocks <= 0 || blocks >= (1L << 31)) return 0;
+  const dim3 grid((unsigned)blocks), blk(TC_NT);
+  if (a.narrow <= 32) hipLaunchKernelGGL((k_tap4<FWD, 1>), grid, blk, lds, st, a, nconv, ngrp, eplanes);
+  else hipLaunchKernelGGL((k_tap4<FWD, 2>), grid, blk, lds, st, a, nconv, ngrp, eplanes);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 1 : (int)e;
+}
+
+
+// tapw eligibility; fills the launch geometry.  Returns 1 = eligible.
+int tw_plan(const TArgs& a, int KT, int* nconv, int* ch, size_t* lds) {
+  if (KT != 3 || a.stride != 1 || a.narrow <= 0 || a.narrow > 64) return 0;
+  if ((a.V1 & 1) || a.V1 > 26 || a.T % TW_R) return 0;
+  const long L = (long)a.T * a.V1;
+  const int cmax = a.Cin > a.Cout ? a.Cin : a.Cout;
+  if ((long)a.n * cmax * L * 4 >= (1L << 31) - 4096) return 0;
+  int nc = 0;
+  for (int i = 0; i < a.nbr; ++i)
+    if (a.br[i].type == 0) {
+      ++nc;
+      if (a.br[i].dil > TW_H || a.br[i].dil < 1) return 0;
+    }
+  if (nc == 0) return 0;
+  *nconv = nc;
+  *ch = a.narrow <= 32 ? 32 : 64;
+  const size_t tile = (size_t)*ch * (tw_ls(TW_R * a.V1) + tw_ls((TW_R + 2 * TW_H) * a.V1)) * sizeof(float);
+  const size_t red = (size_t)4 * 3 * 32 * 33 * sizeof(float);
+  *lds = std::max(tile, *ch == 32 ? red : (size_t)0);
+  return 1;
 }
 
 }  // namespace
@@ -597,6 +1044,11 @@ int dsgcn_tapconv_fwd(const float* h, float* o, int n, int Cin, int Cout, int T,
     a.br[i].w = w ? w[i] : nullptr; a.br[i].b = b ? b[i] : nullptr;
     if (type[i] == 0 && !a.br[i].w) return DSGCN_EINVAL;
   }
+  {
+    const int rc4 = t4_try<true>(a, KT, (hipStream_t)stream);
+    if (rc4 == 1) return 0;
+    if (rc4 != 0) return rc4;
+  }
   const size_t lds = tc_lds_conv(cp, KT);
   const int ntb = lds > 80 * 1024 ? 512 : TC_NT;   // one workgroup per CU by LDS -> give it 8 waves
   const int pbk = ntb / 2;
@@ -625,6 +1077,11 @@ int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int C
     a.br[i].w = w ? w[i] : nullptr;
     if (type[i] == 0 && !a.br[i].w) return DSGCN_EINVAL;
   }
+  {
+    const int rc4 = t4_try<false>(a, KT, (hipStream_t)stream);
+    if (rc4 == 1) return 0;
+    if (rc4 != 0) return rc4;
+  }
   const size_t lds = tc_lds_conv(cp, KT);
   const int ntb = lds > 80 * 1024 ? 512 : TC_NT;
   const int pbk = ntb / 2;
@@ -637,6 +1094,29 @@ int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int C
   })
   DSGCN_LAUNCH_CHECK();
   return 0;
+}
+
+// K-split count the weight gradient prefers for this shape (rows of the partial buffer), 0 = no preference (the caller's
+// own heuristic applies).  The wide-load kernel wants ~512 workgroups over the conv windows, several units each.
+int dsgcn_tapconv_wgrad_splits(int n, int Cin, int Cout, int T, int V1, int stride, int KT, int nbr, const int* type,
+                               const int* cin, const int* cout, const int* dil) {
+  if (n <= 0 || nbr <= 0 || nbr > TC_MAXBR || !type || !cin || !cout || !dil) return 0;
+  TArgs a = {};
+  a.n = n; a.Cin = Cin; a.Cout = Cout; a.T = T; a.V1 = V1; a.stride = stride; a.nbr = nbr;
+  int wmax = 0;
+  for (int i = 0; i < nbr; ++i) {
+    a.br[i].type = type[i]; a.br[i].cin = cin[i]; a.br[i].cout = cout[i]; a.br[i].dil = dil[i];
+    if (type[i] == 0) wmax = std::max(wmax, std::max(cin[i], cout[i]));
+  }
+  a.narrow = wmax;
+  int nconv = 0, ch = 0;
+  size_t lds = 0;
+  if (!tw_plan(a, KT, &nconv, &ch, &lds)) return 0;
+  const int units = n * (T / TW_R);
+  int splits = (ch == 32 ? 512 : 256) / nconv;
+  if (splits < 1) splits = 1;
+  if (splits > units) splits = units;
+  return splits;
 }
 
 // Conv window i writes split s of its weight / bias partials at dwp[i] + s*pstride / dbp[i] + s*pstride (all windows
@@ -655,6 +1135,26 @@ int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int Cin, int Cou
   for (int i = 0; i < nbr; ++i) {
     a.br[i].dwp = dwp ? dwp[i] : nullptr; a.br[i].dbp = dbp ? dbp[i] : nullptr;
     if (type[i] == 0 && (!a.br[i].dwp || !a.br[i].dbp)) return DSGCN_EINVAL;
+  }
+  {
+    int nconv = 0, ch = 0;
+    size_t ldsw = 0;
+    if (tw_plan(a, KT, &nconv, &ch, &ldsw)) {
+      const dim3 gridw((unsigned)splits, (unsigned)nconv);
+      if (ch == 32) {
+        static size_t have = 64 * 1024;
+        const int rc = tc_raise_lds(k_tapw<32>, ldsw, &have);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_tapw<32>, gridw, dim3(TC_NT), ldsw, (hipStream_t)stream, a, nconv);
+      } else {
+        static size_t have = 64 * 1024;
+        const int rc = tc_raise_lds(k_tapw<64>, ldsw, &have);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_tapw<64>, gridw, dim3(TC_NT), ldsw, (hipStream_t)stream, a, nconv);
+      }
+      DSGCN_LAUNCH_CHECK();
+      return 0;
+    }
   }
   int wmax = 0;
   for (int i = 0; i < nbr; ++i)

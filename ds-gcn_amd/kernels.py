@@ -555,7 +555,10 @@ class _TapBranches(torch.autograd.Function):
         pstride = max(off, 1)
         # k-splits: enough blocks to fill the chip, but keep the partial buffer (splits x pstride floats) around 8 MB
         wmax = max([max(ci, co) for t, ci, co in zip(types, cins, couts) if t == 0] or [0])
-        if wmax <= 32:      # narrow windows: every wave is its own split (csrc/tapconv.hip k_tapconv_wgrad_narrow)
+        pref = lib.dsgcn_tapconv_wgrad_splits(n, Cin, Cout, T, V1, stride, KT, nbr, tabs[0], tabs[3], tabs[4], tabs[5])
+        if pref > 0:        # wide-load kernel (csrc/tapconv.hip k_tapw): one partial row per workgroup
+            splits = pref
+        elif wmax <= 32:    # narrow windows: every wave is its own split (csrc/tapconv.hip k_tapconv_wgrad_narrow)
             splits = max(64, min(1024, (1 << 21) // pstride)) // 4 * 4
             splits = max(4, min(splits, (n * Tout) // 4 * 4))
         else:

@@ -51,6 +51,7 @@ SIGNATURES = {
     'dsgcn_tms_combine_bwd': [c_f] * 7 + [c_int] * 4 + [c_st],
     'dsgcn_tapconv_fwd': [c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, ctypes.c_void_p, c_st],
     'dsgcn_tapconv_dgrad': [c_f, c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, c_st],
+    'dsgcn_tapconv_wgrad_splits': [c_int] * 8 + [c_i] * 4,
     'dsgcn_tapconv_wgrad': [c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_st],
     'dsgcn_aggsum_partial_rows': [c_int, c_int, c_int],
     'dsgcn_aggsum_bwd_piece_rows': [c_int] * 5,

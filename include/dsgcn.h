@@ -93,6 +93,9 @@ int dsgcn_tapconv_fwd(const float* h, float* o, int n, int Cin, int Cout, int T,
 int dsgcn_tapconv_dgrad(const float* h, const float* go, float* dh, int n, int Cin, int Cout, int T, int V1, int stride,
                         int KT, int nbr, const int* type, const int* ci0, const int* co0, const int* cin,
                         const int* cout, const int* dil, const float* const* w, void* stream);
+/* rows of the partial buffer (K-splits) dsgcn_tapconv_wgrad prefers for this shape; 0 = the caller chooses */
+int dsgcn_tapconv_wgrad_splits(int n, int Cin, int Cout, int T, int V1, int stride, int KT, int nbr, const int* type,
+                               const int* cin, const int* cout, const int* dil);
 int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int Cin, int Cout, int T, int V1, int stride, int KT,
                         int nbr, const int* type, const int* ci0, const int* co0, const int* cin, const int* cout,
                         const int* dil, float* const* dwp, float* const* dbp, int splits, int pstride, void* stream);

@@ -1,4 +1,5 @@
-"""Per-layer GPU time of the K-D tapconv launches (fwd / dgrad / wgrad), C ABI called directly: python tools/tc_bench.py"""
+"""Per-layer GPU time of the K-D tapconv launches (fwd / dgrad / wgrad), C ABI called directly: python tools/tc_bench.py
+(TC_ONLY=conv|elem: only the conv windows / only the max-pool and pass-through windows)."""
 import os, sys, ctypes as ct
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,6 +26,10 @@ for name, cfg, C, T, V1, stride in [('ds', cfg3, 64, 64, 26, 1), ('ds', cfg3, 12
     ks = cfg[0][0]
     wl = [torch.randn(w, w, ks, 1, device=dev) * .1 for w in widths]; bl = [torch.randn(w, device=dev) for w in widths]
     KT, types, c0s, bcs, dils, ws, bs = K._branch_tables(cfg, widths, wl, bl)
+    only = os.environ.get('TC_ONLY')            # conv | elem: time a subset of the windows
+    if only:
+        keep = [i for i, t in enumerate(types) if (t == 0) == (only == 'conv')]
+        types, c0s, bcs, dils, ws, bs = [[x[i] for i in keep] for x in (types, c0s, bcs, dils, ws, bs)]
     n = 128
     Tout = (T + stride - 1) // stride
     h = torch.randn(n, C, T, V1, device=dev); o = torch.empty(n, C, Tout, V1, device=dev); go = torch.randn_like(o); dh = torch.empty_like(h)
@@ -37,6 +42,8 @@ for name, cfg, C, T, V1, stride in [('ds', cfg3, 64, 64, 26, 1), ('ds', cfg3, 12
         if t == 0: off += bc * bc * KT + bc
     pstride = max(off, 1)
     splits = max(64, min(1024, (1 << 21) // pstride)) // 4 * 4 if max(bcs) <= 32 else max(16, min(256, (1 << 21) // pstride))
+    pref = lib.dsgcn_tapconv_wgrad_splits(n, C, C, T, V1, stride, KT, nbr, tabs[0], tabs[3], tabs[4], tabs[5])
+    splits = pref or splits
     part = torch.empty(splits, pstride, device=dev)
     base = part.data_ptr()
     dwp = (ct.c_void_p * nbr)(*[base + 4 * o_ if t == 0 else None for t, o_ in zip(types, offs)])
