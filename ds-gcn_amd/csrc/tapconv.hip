@@ -535,11 +535,13 @@ __device__ __forceinline__ f32x2t t4_load2(__amdgpu_buffer_rsrc_t r, int voff, i
   return __builtin_bit_cast(f32x2t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 
-template <bool FWD, int MT>
+template <bool FWD, int MT, bool S2>
 __device__ __forceinline__ void t4_conv(const TArgs& a, const TBranch& br, float* Ws, int grp, int lane, int wave) {
   constexpr int KT = 3, PDK = 2, NS = KT * PDK;
   const int half = lane >> 5, l31 = lane & 31;
-  const int V1 = a.V1, L = a.T * V1, L4 = L * 4;
+  const int V1 = a.V1;
+  const int Ls = (FWD ? a.T : a.Tout) * V1, L = (FWD ? a.Tout : a.T) * V1;   // source / destination plane lengths
+  const int L4 = Ls * 4;
   const int Csrc = FWD ? a.Cin : a.Cout, Cdst = FWD ? a.Cout : a.Cin;
   const int sch0 = FWD ? br.ci0 : br.co0, nsrc = FWD ? br.cin : br.cout;
   const int dch0 = FWD ? br.co0 : br.ci0, ndst = FWD ? br.cout : br.cin;
@@ -555,18 +557,46 @@ __device__ __forceinline__ void t4_conv(const TArgs& a, const TBranch& br, float
   while (p >= L) { p -= L; ++ds; }
   const bool pok = wlive && n0 + ds < a.n;
   const __amdgpu_buffer_rsrc_t rs = tc_rsrc(FWD ? a.h : a.go, (size_t)a.n * Csrc * L4);
-  const int rowbase = ((n0 + ds) * Csrc + sch0 + half) * L;   // (the launch checks the tensor stays below 2^31 bytes)
-  const int sh = (FWD ? br.dil : -br.dil) * V1;               // shift of tap 2 (tap 0: -sh)
-  const int qa = p - sh, qb = p + sh;
-  const int vC = pok ? (rowbase + p) * 4 : TC_OOB;
-  const int vA0 = (pok && qa >= 0 && qa <= L - 2) ? (rowbase + qa) * 4 : TC_OOB;
-  const int vA1 = (pok && qa + 2 >= 0 && qa + 2 <= L - 2) ? (rowbase + qa + 2) * 4 : TC_OOB;
-  const int vB0 = (pok && qb >= 0 && qb <= L - 2) ? (rowbase + qb) * 4 : TC_OOB;
-  const int vB1 = (pok && qb + 2 >= 0 && qb + 2 <= L - 2) ? (rowbase + qb + 2) * 4 : TC_OOB;
+  const int rowbase = ((n0 + ds) * Csrc + sch0 + half) * Ls;  // (the launch checks the tensor stays below 2^31 bytes)
+  // operand offsets of the lane's two position pairs, per tap.  Stride 1: a tap shifts by whole rows, the centre tap is
+  // one 16-byte load.  Stride 2 (forward: output row t' reads input rows 2t' + (tap-1)*dil; data gradient: input row t
+  // collects from the output rows (t - (tap-1)*dil)/2 that exist): every pair has its own row, all loads are 8 bytes.
+  int vP[KT][2];
+  if constexpr (!S2) {
+    const int sh = (FWD ? br.dil : -br.dil) * V1;             // shift of tap 2 (tap 0: -sh)
+#pragma unroll
+    for (int tap = 0; tap < KT; ++tap)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = p + (tap - 1) * sh + 2 * j;
+        vP[tap][j] = (pok && q >= 0 && q <= Ls - 2) ? (rowbase + q) * 4 : TC_OOB;
+      }
+  } else {
+    const float invV1 = 1.f / (float)V1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int t, x;
+      divmod_small(p + 2 * j, V1, invV1, t, x);
+#pragma unroll
+      for (int tap = 0; tap < KT; ++tap) {
+        int row;
+        bool ok = pok;
+        if (FWD) {
+          row = 2 * t + (tap - 1) * br.dil;
+          ok = ok && row >= 0 && row < a.T;
+        } else {
+          const int num = t - (tap - 1) * br.dil;
+          row = num >> 1;
+          ok = ok && num >= 0 && !(num & 1) && row < a.Tout;
+        }
+        vP[tap][j] = ok ? (rowbase + row * V1 + x) * 4 : TC_OOB;
+      }
+    }
+  }
   auto load = [&](int tap, int ks) -> f32x4 {
     const int soff = 2 * ks * L4;
-    if (tap == 1) return t4_load4(rs, vC, soff);
-    const f32x2t lo = t4_load2(rs, tap == 0 ? vA0 : vB0, soff), hi = t4_load2(rs, tap == 0 ? vA1 : vB1, soff);
+    if (!S2 && tap == 1) return t4_load4(rs, vP[1][0], soff);
+    const f32x2t lo = t4_load2(rs, vP[tap][0], soff), hi = t4_load2(rs, vP[tap][1], soff);
     return f32x4{lo.x, lo.y, hi.x, hi.y};
   };
 
@@ -613,7 +643,7 @@ __device__ __forceinline__ void t4_conv(const TArgs& a, const TBranch& br, float
     }
   }
   float* dst = FWD ? a.o : a.dh;
-  const __amdgpu_buffer_rsrc_t ro = tc_rsrc(dst, (size_t)a.n * Cdst * L4);
+  const __amdgpu_buffer_rsrc_t ro = tc_rsrc(dst, (size_t)a.n * Cdst * L * 4);
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -628,97 +658,114 @@ __device__ __forceinline__ void t4_conv(const TArgs& a, const TBranch& br, float
   }
 }
 
-// one wave per (n, c) plane of a max-pool / pass-through window, stride 1
-template <bool FWD>
+// one wave per (n, c) plane of a max-pool / pass-through window (stride 1 or 2)
+template <bool FWD, int ST>
 __device__ __forceinline__ void t4_elem(const TArgs& a, const TBranch& br, float* lw, int n, int c, int lane) {
-  const int V1 = a.V1, L = a.T * V1, L4c = L >> 2;
+  constexpr int st = ST;
+  const int V1 = a.V1;
+  const int L = a.T * V1, Lo = a.Tout * V1;
+  const float invV1 = 1.f / (float)V1;
   const float* hp = a.h + ((size_t)n * a.Cin + br.ci0 + c) * L;
   if (FWD) {
-    f32x4* op = reinterpret_cast<f32x4*>(a.o + ((size_t)n * a.Cout + br.co0 + c) * L);
-    if (br.type == 2) {
+    f32x4* op = reinterpret_cast<f32x4*>(a.o + ((size_t)n * a.Cout + br.co0 + c) * Lo);
+    if (br.type == 2 && st == 1) {
       const f32x4* h4 = reinterpret_cast<const f32x4*>(hp);
-      for (int i = lane; i < L4c; i += 64) op[i] = h4[i];
+      for (int i = lane; i < (L >> 2); i += 64) op[i] = h4[i];
       return;
     }
-    plane_to_lds(hp, lw, L4c, lane);
+    plane_to_lds(hp, lw, L >> 2, lane);
     wave_lds_sync();
-    for (int i = lane; i < L4c; i += 64) {
-      const int e = 4 * i;
+    for (int i = lane; i < (Lo >> 2); i += 64) {
+      int tp, x;
+      divmod_small(4 * i, V1, invV1, tp, x);
       float r[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float v = lw[e + k];
-        if (e + k - V1 >= 0) v = fmaxf(v, lw[e + k - V1]);
-        if (e + k + V1 < L) v = fmaxf(v, lw[e + k + V1]);
+        const int e = tp * st * V1 + x;               // centre of the window / the strided source element
+        float v = lw[e];
+        if (br.type == 1) {
+          if (tp * st - 1 >= 0) v = fmaxf(v, lw[e - V1]);
+          if (tp * st + 1 < a.T) v = fmaxf(v, lw[e + V1]);
+        }
         r[k] = v;
+        if (++x == V1) { x = 0; ++tp; }
       }
       op[i] = f32x4{r[0], r[1], r[2], r[3]};
     }
     return;
   }
-  const float* gp = a.go + ((size_t)n * a.Cout + br.co0 + c) * L;
+  const float* gp = a.go + ((size_t)n * a.Cout + br.co0 + c) * Lo;
   f32x4* dp = reinterpret_cast<f32x4*>(a.dh + ((size_t)n * a.Cin + br.ci0 + c) * L);
-  if (br.type == 2) {
+  if (br.type == 2 && st == 1) {
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gp);
-    for (int i = lane; i < L4c; i += 64) dp[i] = g4[i];
+    for (int i = lane; i < (L >> 2); i += 64) dp[i] = g4[i];
     return;
   }
   float* lg = lw + L;
-  plane_to_lds(hp, lw, L4c, lane);
-  plane_to_lds(gp, lg, L4c, lane);
+  if (br.type == 1) plane_to_lds(hp, lw, L >> 2, lane);
+  plane_to_lds(gp, lg, Lo >> 2, lane);
   wave_lds_sync();
-  // the gradient of window t' goes to its FIRST maximal valid tap (ATen max_pool2d_with_indices order)
-  for (int i = lane; i < L4c; i += 64) {
+  for (int i = lane; i < (L >> 2); i += 64) {
+    int t, x;
+    divmod_small(4 * i, V1, invV1, t, x);
     float r[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int e = 4 * i + k;                    // position of (t, x)
       float g = 0.f;
+      if (br.type == 2) {
+        if (t % st == 0 && t / st < a.Tout) g = lg[(t / st) * V1 + x];
+      } else {
+        // max-pool: the gradient of window t' goes to its FIRST maximal valid tap (ATen max_pool2d_with_indices order)
 #pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
-        const int ec = e - (kk - 1) * V1;          // centre (t', x) of a window that covers t
-        if (ec < 0 || ec >= L) continue;
-        float best = -INFINITY;
-        int arg = -1;
+        for (int kk = 0; kk < 3; ++kk) {
+          const int num = t - (kk - 1);
+          if (num < 0 || num % st != 0) continue;
+          const int tp = num / st;
+          if (tp >= a.Tout) continue;
+          float best = -INFINITY;
+          int arg = -1;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int et = ec + (j - 1) * V1;
-          if (et >= 0 && et < L) {
-            const float v = lw[et];
-            if (v > best || arg < 0) { best = v; arg = et; }
+          for (int j = 0; j < 3; ++j) {
+            const int tt = tp * st + j - 1;
+            if (tt >= 0 && tt < a.T) {
+              const float v = lw[tt * V1 + x];
+              if (v > best || arg < 0) { best = v; arg = tt; }
+            }
           }
+          if (arg == t) g += lg[tp * V1 + x];
         }
-        if (arg == e) g += lg[ec];
       }
       r[k] = g;
+      if (++x == V1) { x = 0; ++t; }
     }
     dp[i] = f32x4{r[0], r[1], r[2], r[3]};
   }
 }
 
 // grid.x = [conv blocks: (position group, conv window)] ++ [elementwise blocks: 4 planes each]
-template <bool FWD, int MT>
+template <bool FWD, int MT, bool S2>
 __global__ __launch_bounds__(TC_NT, MT == 1 ? 3 : 2) void k_tap4(TArgs a, int nconv, int ngrp, int eplanes) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int cb = nconv * ngrp;
-  if ((int)blockIdx.x < cb) {
-    const int w = blockIdx.x % nconv, grp = blockIdx.x / nconv;
+  // conv blocks first, elementwise blocks after them (dealing them evenly among the conv blocks measured slower)
+  const int cb = nconv * ngrp, b = blockIdx.x;
+  if (b < cb) {
+    const int w = b % nconv, grp = b / nconv;
     int bi = 0;
     for (int i = 0, k = 0; i < a.nbr; ++i)
       if (a.br[i].type == 0) { if (k == w) bi = i; ++k; }
-    t4_conv<FWD, MT>(a, a.br[bi], lds, grp, lane, wave);
+    t4_conv<FWD, MT, S2>(a, a.br[bi], lds, grp, lane, wave);
     return;
   }
-  int pl = ((int)blockIdx.x - cb) * 4 + wave;      // plane index over (n, elementwise channels)
+  int pl = (b - cb) * 4 + wave;                    // plane index over (n, elementwise channels)
   if (pl >= a.n * eplanes) return;
   const int n = pl / eplanes;
   int c = pl - n * eplanes;
   for (int i = 0; i < a.nbr; ++i) {
     if (a.br[i].type == 0) continue;
     if (c < a.br[i].cin) {
-      t4_elem<FWD>(a, a.br[i], lds + (size_t)wave * 2 * a.T * a.V1, n, c, lane);
+      t4_elem<FWD, S2 ? 2 : 1>(a, a.br[i], lds + (size_t)wave * 2 * a.T * a.V1, n, c, lane);
       return;
     }
     c -= a.br[i].cin;
@@ -905,6 +952,164 @@ __global__ __launch_bounds__(TC_NT, CH == 32 ? 2 : 1) void k_tapw(TArgs a, int n
   }
 }
 
+// Stride-2 form of tapw:  dW[co,ci,tap] = sum do[n,co,t',x] * h[n,ci, 2t' + (tap-1)*dil, x].  The input rows a unit of 4
+// output frames needs are every second row, so the haloed tile does not apply: the three taps get their own decimated
+// tiles Xs[tap][ci][4 frames] (8-byte loads: a frame row is V1/2 pairs), the MFMA loop reads do and h at the SAME tile
+// position.  Same grid, splits and epilogue as k_tapw.
+template <int CH>
+__global__ __launch_bounds__(TC_NT, CH == 32 ? 2 : 1) void k_tapw2(TArgs a, int nconv) {
+  constexpr int KT = 3;
+  constexpr int JD = CH == 32 ? 4 : 7, JX = CH == 32 ? 20 : 40;     // float4 / float2 staging slots per thread (V1 <= 26)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  int bi = 0;
+  for (int i = 0, k = 0; i < a.nbr; ++i)
+    if (a.br[i].type == 0) { if (k == (int)blockIdx.y) bi = i; ++k; }
+  const TBranch& br = a.br[bi];
+  const int V1 = a.V1, T = a.T, To = a.Tout, L = T * V1, Lo = To * V1;
+  const int nco = br.cout, nci = br.cin;
+  const int GW = TW_R * V1, GW4 = GW >> 2, PV = V1 >> 1;
+  const int LSd = tw_ls(GW);
+  float* Ds = lds;                                                   // [CH][LSd]
+  float* Xs = lds + CH * LSd;                                        // [KT][CH][LSd]
+  for (int i = tid; i < (1 + KT) * CH * LSd; i += TC_NT) lds[i] = 0.f;
+
+  const int units = a.n * (To / TW_R);
+  const int per = (units + a.splits - 1) / a.splits;
+  const int u0 = blockIdx.x * per, u1 = min(units, u0 + per);
+  const __amdgpu_buffer_rsrc_t rg = tc_rsrc(a.go, (size_t)a.n * a.Cout * Lo * 4);
+  const __amdgpu_buffer_rsrc_t rh = tc_rsrc(a.h, (size_t)a.n * a.Cin * L * 4);
+  int vD[JD], lD[JD], vX[JX], lX[JX], rX[JX];
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int f = tid + TC_NT * j, row = f / GW4, c4 = f - row * GW4;
+    const bool ok = row < nco;
+    vD[j] = ok ? (row * Lo + 4 * c4) * 4 : TC_OOB;
+    lD[j] = ok ? row * LSd + 4 * c4 : -1;
+  }
+  const int xslots = KT * TW_R * nci * PV;                           // (tap, frame r, channel, pair)
+#pragma unroll
+  for (int j = 0; j < JX; ++j) {
+    const int f = tid + TC_NT * j;
+    const int pp = f % PV, q = f / PV, ch = q % nci, tr = q / nci;   // tr = tap*4 + r
+    const bool ok = f < xslots;
+    const int tap = tr >> 2, r = tr & 3;
+    vX[j] = ok ? (ch * L + 2 * pp) * 4 : TC_OOB;                     // + input row offset per unit
+    lX[j] = ok ? (tap * CH + ch) * LSd + r * V1 + 2 * pp : -1;
+    rX[j] = 2 * r + (tap - 1) * br.dil;                              // input row relative to 2*t0
+  }
+  f32x4 gr[JD];
+  f32x2t xr[JX];
+  float dsum[JD];
+#pragma unroll
+  for (int j = 0; j < JD; ++j) dsum[j] = 0.f;
+  auto issue = [&](int u) {
+    const int n = u / (To / TW_R), t0 = (u - n * (To / TW_R)) * TW_R;
+    const int sg = ((n * a.Cout + br.co0) * Lo + t0 * V1) * 4;
+    const int sx = (n * a.Cin + br.ci0) * L * 4;
+#pragma unroll
+    for (int j = 0; j < JD; ++j) gr[j] = t4_load4(rg, vD[j], sg);
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const int row = 2 * t0 + rX[j];
+      const bool ok = row >= 0 && row < T;
+      xr[j] = t4_load2(rh, ok ? vX[j] + row * V1 * 4 : TC_OOB, sx);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      if (lD[j] >= 0) {
+        f32x2t* d = reinterpret_cast<f32x2t*>(Ds + lD[j]);
+        d[0] = f32x2t{gr[j].x, gr[j].y};
+        d[1] = f32x2t{gr[j].z, gr[j].w};
+        dsum[j] += (gr[j].x + gr[j].y) + (gr[j].z + gr[j].w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < JX; ++j)
+      if (lX[j] >= 0) *reinterpret_cast<f32x2t*>(Xs + lX[j]) = xr[j];
+  };
+  f32x16 acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+  const int mt = CH == 64 ? (wave >> 1) : 0, nt = CH == 64 ? (wave & 1) : 0;
+  const int g0 = CH == 32 ? (GW4 * wave) / 4 : 0, g1 = CH == 32 ? (GW4 * (wave + 1)) / 4 : GW4;
+  const float* Ap = Ds + (32 * mt + l31) * LSd + 2 * half;
+  const float* Bp = Xs + (32 * nt + l31) * LSd + 2 * half;
+
+  __syncthreads();
+  if (u0 < u1) issue(u0);
+  for (int u = u0; u < u1; ++u) {
+    commit();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (u + 1 < u1) issue(u + 1);
+    for (int g = g0; g < g1; ++g) {
+      const f32x2t av = *reinterpret_cast<const f32x2t*>(Ap + 4 * g);
+      const f32x2t b0 = *reinterpret_cast<const f32x2t*>(Bp + 4 * g);
+      const f32x2t b1 = *reinterpret_cast<const f32x2t*>(Bp + CH * LSd + 4 * g);
+      const f32x2t b2 = *reinterpret_cast<const f32x2t*>(Bp + 2 * CH * LSd + 4 * g);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b2.x, acc[2], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b2.y, acc[2], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  float* dw = br.dwp + (size_t)blockIdx.x * a.pstride;
+  float* db = br.dbp + (size_t)blockIdx.x * a.pstride;
+  if (CH == 32) {
+    float* Rs = lds;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Rs[((wave * KT + k) * 32 + tc_row32(r, half)) * 33 + l31] = acc[k][r];
+    __syncthreads();
+    for (int o = tid; o < KT * nco * nci; o += TC_NT) {
+      const int co = o / (nci * KT), r2 = o - co * nci * KT, ci = r2 / KT, k = r2 - ci * KT;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += Rs[((w * KT + k) * 32 + co) * 33 + ci];
+      dw[o] = v;
+    }
+    __syncthreads();
+  } else {
+    const int ci = 32 * nt + l31;
+    if (ci < nci) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * mt + tc_row32(r, half);
+        if (co < nco) {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) dw[((size_t)co * nci + ci) * KT + k] = acc[k][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* Bs = lds;
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int f = tid + TC_NT * j, row = f / GW4, c4 = f - row * GW4;
+    if (row < nco) Bs[row * (GW4 + 1) + c4] = dsum[j];
+  }
+  __syncthreads();
+  if (tid < nco) {
+    float v = 0.f;
+    for (int c = 0; c < GW4; ++c) v += Bs[tid * (GW4 + 1) + c];
+    db[tid] = v;
+  }
+}
+
 size_t tc_lds_conv(int CP, int KT) { return (size_t)(64 * (KT * CP + 1) + 64) * sizeof(float); }
 
 constexpr size_t TC_LDS_MAX = 156 * 1024;
@@ -947,9 +1152,9 @@ int tc_fill(TArgs& a, int nbr, const int* type, const int* ci0, const int* co0, 
 // tap4 eligibility and launch (forward / data gradient); returns 1 = launched, 0 = not eligible, else an error code
 template <bool FWD>
 int t4_try(const TArgs& a, int KT, hipStream_t st) {
-  if (KT != 3 || a.stride != 1 || a.narrow <= 0 || a.narrow > 64) return 0;
-  const long L = (long)a.T * a.V1;
-  if (L % 4 || (a.V1 & 1)) return 0;
+  if (KT != 3 || (a.stride != 1 && a.stride != 2) || a.narrow <= 0 || a.narrow > 64) return 0;
+  const long L = (long)a.T * a.V1, Lo = (long)a.Tout * a.V1;
+  if (L % 4 || Lo % 4 || (a.V1 & 1) || (a.stride == 2 && (a.T & 1))) return 0;
   const int cmax = a.Cin > a.Cout ? a.Cin : a.Cout;
   if ((long)a.n * cmax * L * 4 >= (1L << 31) - 4096 || (long)a.n * L >= (1L << 31) - 256) return 0;
   int nconv = 0, eplanes = 0, cpmax = 8;
@@ -958,28 +1163,33 @@ int t4_try(const TArgs& a, int KT, hipStream_t st) {
     if (b.type == 0) {
       ++nconv;
       cpmax = std::max(cpmax, (std::min(64, b.cin) + 7) & ~7);
-      if ((b.dil * a.V1) & 1) return 0;
     } else {
       eplanes += b.cin;
     }
   }
   const size_t lds = std::max(tc_lds_conv(cpmax, 3), (size_t)4 * 2 * L * sizeof(float));
   if (lds > 64 * 1024) return 0;
-  const int WT = (int)(((long)a.n * L + 127) / 128), ngrp = (WT + 3) / 4;
+  const long Ld = FWD ? Lo : L;                    // destination plane
+  const int WT = (int)(((long)a.n * Ld + 127) / 128), ngrp = (WT + 3) / 4;
   const long blocks = (long)nconv * ngrp + ((long)a.n * eplanes + 3) / 4;
   if (blocks <= 0 || blocks >= (1L << 31)) return 0;
   const dim3 grid((unsigned)blocks), blk(TC_NT);
-  if (a.narrow <= 32) hipLaunchKernelGGL((k_tap4<FWD, 1>), grid, blk, lds, st, a, nconv, ngrp, eplanes);
-  else hipLaunchKernelGGL((k_tap4<FWD, 2>), grid, blk, lds, st, a, nconv, ngrp, eplanes);
+  const bool m1 = a.narrow <= 32;
+  if (a.stride == 1) {
+    if (m1) hipLaunchKernelGGL((k_tap4<FWD, 1, false>), grid, blk, lds, st, a, nconv, ngrp, eplanes);
+    else hipLaunchKernelGGL((k_tap4<FWD, 2, false>), grid, blk, lds, st, a, nconv, ngrp, eplanes);
+  } else {
+    if (m1) hipLaunchKernelGGL((k_tap4<FWD, 1, true>), grid, blk, lds, st, a, nconv, ngrp, eplanes);
+    else hipLaunchKernelGGL((k_tap4<FWD, 2, true>), grid, blk, lds, st, a, nconv, ngrp, eplanes);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 1 : (int)e;
 }
 
-
 // tapw eligibility; fills the launch geometry.  Returns 1 = eligible.
 int tw_plan(const TArgs& a, int KT, int* nconv, int* ch, size_t* lds) {
-  if (KT != 3 || a.stride != 1 || a.narrow <= 0 || a.narrow > 64) return 0;
-  if ((a.V1 & 1) || a.V1 > 26 || a.T % TW_R) return 0;
+  if (KT != 3 || (a.stride != 1 && a.stride != 2) || a.narrow <= 0 || a.narrow > 64) return 0;
+  if ((a.V1 & 1) || a.V1 > 26 || a.Tout % TW_R || (a.stride == 2 && (a.T & 1))) return 0;
   const long L = (long)a.T * a.V1;
   const int cmax = a.Cin > a.Cout ? a.Cin : a.Cout;
   if ((long)a.n * cmax * L * 4 >= (1L << 31) - 4096) return 0;
@@ -987,12 +1197,14 @@ int tw_plan(const TArgs& a, int KT, int* nconv, int* ch, size_t* lds) {
   for (int i = 0; i < a.nbr; ++i)
     if (a.br[i].type == 0) {
       ++nc;
-      if (a.br[i].dil > TW_H || a.br[i].dil < 1) return 0;
+      if (a.br[i].dil < 1 || (a.stride == 1 && a.br[i].dil > TW_H)) return 0;
     }
   if (nc == 0) return 0;
   *nconv = nc;
   *ch = a.narrow <= 32 ? 32 : 64;
-  const size_t tile = (size_t)*ch * (tw_ls(TW_R * a.V1) + tw_ls((TW_R + 2 * TW_H) * a.V1)) * sizeof(float);
+  const size_t gw = tw_ls(TW_R * a.V1);
+  const size_t tile = a.stride == 1 ? (size_t)*ch * (gw + tw_ls((TW_R + 2 * TW_H) * a.V1)) * sizeof(float)
+                                    : (size_t)*ch * 4 * gw * sizeof(float);
   const size_t red = (size_t)4 * 3 * 32 * 33 * sizeof(float);
   *lds = std::max(tile, *ch == 32 ? red : (size_t)0);
   return 1;
@@ -1103,6 +1315,7 @@ int dsgcn_tapconv_wgrad_splits(int n, int Cin, int Cout, int T, int V1, int stri
   if (n <= 0 || nbr <= 0 || nbr > TC_MAXBR || !type || !cin || !cout || !dil) return 0;
   TArgs a = {};
   a.n = n; a.Cin = Cin; a.Cout = Cout; a.T = T; a.V1 = V1; a.stride = stride; a.nbr = nbr;
+  a.Tout = stride > 0 ? (T + stride - 1) / stride : T;
   int wmax = 0;
   for (int i = 0; i < nbr; ++i) {
     a.br[i].type = type[i]; a.br[i].cin = cin[i]; a.br[i].cout = cout[i]; a.br[i].dil = dil[i];
@@ -1112,7 +1325,7 @@ int dsgcn_tapconv_wgrad_splits(int n, int Cin, int Cout, int T, int V1, int stri
   int nconv = 0, ch = 0;
   size_t lds = 0;
   if (!tw_plan(a, KT, &nconv, &ch, &lds)) return 0;
-  const int units = n * (T / TW_R);
+  const int units = n * (a.Tout / TW_R);
   int splits = (ch == 32 ? 512 : 256) / nconv;
   if (splits < 1) splits = 1;
   if (splits > units) splits = units;
@@ -1141,16 +1354,26 @@ int dsgcn_tapconv_wgrad(const float* h, const float* go, int n, int Cin, int Cou
     size_t ldsw = 0;
     if (tw_plan(a, KT, &nconv, &ch, &ldsw)) {
       const dim3 gridw((unsigned)splits, (unsigned)nconv);
-      if (ch == 32) {
+      if (stride == 1 && ch == 32) {
         static size_t have = 64 * 1024;
         const int rc = tc_raise_lds(k_tapw<32>, ldsw, &have);
         if (rc) return rc;
         hipLaunchKernelGGL(k_tapw<32>, gridw, dim3(TC_NT), ldsw, (hipStream_t)stream, a, nconv);
-      } else {
+      } else if (stride == 1) {
         static size_t have = 64 * 1024;
         const int rc = tc_raise_lds(k_tapw<64>, ldsw, &have);
         if (rc) return rc;
         hipLaunchKernelGGL(k_tapw<64>, gridw, dim3(TC_NT), ldsw, (hipStream_t)stream, a, nconv);
+      } else if (ch == 32) {
+        static size_t have = 64 * 1024;
+        const int rc = tc_raise_lds(k_tapw2<32>, ldsw, &have);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_tapw2<32>, gridw, dim3(TC_NT), ldsw, (hipStream_t)stream, a, nconv);
+      } else {
+        static size_t have = 64 * 1024;
+        const int rc = tc_raise_lds(k_tapw2<64>, ldsw, &have);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_tapw2<64>, gridw, dim3(TC_NT), ldsw, (hipStream_t)stream, a, nconv);
       }
       DSGCN_LAUNCH_CHECK();
       return 0;
