@@ -141,8 +141,9 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
     if (e0 == 0) {
 #pragma unroll
       for (int u = 0; u < PD; ++u) {
-        buf1[u] = p4_load<NQ>(r1, voff, 2 * u * L4);
-        if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, 2 * u * L4);
+        const int s0 = 2 * u < K ? 2 * u * L4 : P4_OOB;               // (channels past K: out of range, zeros)
+        buf1[u] = p4_load<NQ>(r1, voff, s0);
+        if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, s0);
       }
     }
 #pragma unroll
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
 
   const float lo = a.relu ? 0.f : -__builtin_inff();
   const int KS = Kpad >> 1;                        // k-steps (2 channels each), a multiple of PD
+  const int KSr = (K + 1) >> 1;                    // k-steps that hold real channels
   // Software pipeline, pinned with scheduling barriers.  Step ks: start the LDS reads of step ks+1 (A fragment, affine
   // row; double-buffered by step parity), apply the affine to the operand loaded PD steps ago, run the MT*NQ MFMAs, then
   // re-issue that operand buffer's load for step ks+PD (after the MFMAs: the buffer registers are dead by then, so the
@@ -219,8 +221,10 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(avb[cur][m], b[q], acc[m][q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      buf1[u] = p4_load<NQ>(r1, voff, 2 * (ks + PD) * L4);             // past K: weights are zero
-      if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, 2 * (ks + PD) * L4);
+      // past K: the scalar offset jumps out of the buffer's range (zeros, no traffic: the bounds check covers it)
+      const int sn = ks + PD < KSr ? 2 * (ks + PD) * L4 : P4_OOB;
+      buf1[u] = p4_load<NQ>(r1, voff, sn);
+      if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, sn);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
