@@ -715,25 +715,16 @@ __device__ __forceinline__ void t4_elem(const TArgs& a, const TBranch& br, float
       if (br.type == 2) {
         if (t % st == 0 && t / st < a.Tout) g = lg[(t / st) * V1 + x];
       } else {
-        // max-pool: the gradient of window t' goes to its FIRST maximal valid tap (ATen max_pool2d_with_indices order)
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          const int num = t - (kk - 1);
-          if (num < 0 || num % st != 0) continue;
-          const int tp = num / st;
-          if (tp >= a.Tout) continue;
-          float best = -INFINITY;
-          int arg = -1;
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const int tt = tp * st + j - 1;
-            if (tt >= 0 && tt < a.T) {
-              const float v = lw[tt * V1 + x];
-              if (v > best || arg < 0) { best = v; arg = tt; }
-            }
-          }
-          if (arg == t) g += lg[tp * V1 + x];
-        }
+        // max-pool: the gradient of window t' goes to its FIRST maximal valid row (ATen max_pool2d_with_indices order:
+        // ties go to the earlier row).  Row t can be the last row of the window centred at t-1, the centre of its own
+        // window, or the first row of the window centred at t+1 (centres are the multiples of the stride); it owns a
+        // window iff it beats every earlier row strictly and every later row weakly.  Rows outside the plane: -inf.
+        const float v = lw[t * V1 + x];
+        auto row = [&](int r) -> float { return (r >= 0 && r < a.T) ? lw[r * V1 + x] : -INFINITY; };
+        const float m2 = row(t - 2), m1 = row(t - 1), p1 = row(t + 1), p2 = row(t + 2);
+        if (t >= 1 && (t - 1) % st == 0 && (t - 1) / st < a.Tout && v > m2 && v > m1) g += lg[((t - 1) / st) * V1 + x];
+        if (t % st == 0 && t / st < a.Tout && v > m1 && v >= p1) g += lg[(t / st) * V1 + x];
+        if ((t + 1) % st == 0 && (t + 1) / st < a.Tout && v >= p1 && v >= p2) g += lg[((t + 1) / st) * V1 + x];
       }
       r[k] = g;
       if (++x == V1) { x = 0; ++t; }

@@ -214,7 +214,11 @@ def test_fuse_out(n, C, T, V, mode, tmean, flags):
         assert rel(got[k].detach().cpu(), v.detach()) < 1e-5, (k, rel(got[k].detach().cpu(), v.detach()))
 
 
-@pytest.mark.parametrize('n,C,T,V,stride', [(2, 64, 32, 25, 1), (2, 128, 32, 25, 2), (2, 48, 20, 17, 1), (1, 12, 9, 18, 2)])
+@pytest.mark.parametrize('n,C,T,V,stride', [(2, 64, 32, 25, 1), (2, 128, 32, 25, 2), (2, 48, 20, 17, 1), (1, 12, 9, 18, 2),
+                                            # wide-load kernels at 2 MFMA row tiles / 64-channel weight-gradient tiles, both strides
+                                            (2, 256, 16, 25, 1), (2, 256, 16, 25, 2),
+                                            # frame counts the weight gradient's 4-frame units do not divide (mixed paths)
+                                            (2, 64, 10, 25, 1), (2, 64, 12, 25, 2), (3, 64, 6, 17, 1)])
 def test_temporal_ms(n, C, T, V, stride):
     g = torch.Generator().manual_seed(C + T + stride)
     cfg = [(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1']

@@ -21,7 +21,8 @@ for a, b in list(zip(packs[:-1], packs[1:]))[-3:]:
             gaps[short(n)] += s - cur_e; ngap[short(n)] += 1
         if e > cur_e:
             busy += e - max(s, cur_e); cur_e = e
-    print(f'step: {len(seg)} kernels, wall {wall/1e6:.3f} ms, busy {busy/1e6:.3f} ms, idle {(wall-busy)/1e6:.3f} ms')
+    tot = sum(e - s for s, e, n in seg)
+    print(f'step: {len(seg)} kernels, wall {wall/1e6:.3f} ms, busy {busy/1e6:.3f} ms, idle {(wall-busy)/1e6:.3f} ms, sum of durations {tot/1e6:.3f} ms')
 a, b = packs[-3], packs[-2]          # a steady-state step: list its large gaps with both neighbours
 seg = rows[a + 1:b + 1]
 cur_e = seg[0][0]; prev = ''
@@ -30,6 +31,11 @@ for s_, e_, n_ in seg:
         print(f'  gap {(s_-cur_e)/1e3:7.1f} us  after {short(prev):28s} before {short(n_)}')
     if e_ > cur_e:
         cur_e = e_; prev = n_
+# kernels running concurrently with K-B (the side-stream branch)
+for s_, e_, n_ in seg:
+    if 'k_dynadj' in n_:
+        ov = [(short(n2), min(e_, e2) - max(s_, s2)) for s2, e2, n2 in seg if n2 is not n_ and min(e_, e2) > max(s_, s2)]
+        print(f'  {short(n_)} {(e_-s_)/1e3:.1f} us overlaps: ' + ', '.join(f'{k} {v/1e3:.1f}' for k, v in ov[:6]))
 top = sorted(gaps.items(), key=lambda kv: -kv[1])[:15]
 for k, v in top:
     print(f'  idle before {k:32s} {v/1e3:8.1f} us over {ngap[k]} gaps ({v/1e3/max(ngap[k],1):.2f} us each)')
