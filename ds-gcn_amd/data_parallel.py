@@ -28,15 +28,32 @@ class FlatParams:
         total = sum(p.numel() for p in self.params)
         self.flat_p = torch.empty(total, device=dev, dtype=dt)
         self.flat_g = torch.zeros(total, device=dev, dtype=dt)
+        # layout order: parameters() order, except that the groups a module declares in flat_groups() (tensors its
+        # forward concatenates) are placed back to back at the position of their first member
+        index = {id(p): i for i, p in enumerate(self.params)}
+        group_of = {}
+        for m in module.modules():
+            for grp in (m.flat_groups() if hasattr(m, 'flat_groups') else []):
+                ids = [index[id(p)] for p in grp if id(p) in index]
+                if len(ids) == len(grp) and len(ids) > 1 and not any(i in group_of for i in ids):
+                    for i in ids:
+                        group_of[i] = ids
+        order, placed = [], set()
+        for i in range(len(self.params)):
+            for j in (group_of.get(i, [i]) if i not in placed else []):
+                if j not in placed:
+                    placed.add(j)
+                    order.append(j)
+        self.slices = [None] * len(self.params)
         off = 0
-        self.slices = []
         with torch.no_grad():
-            for p in self.params:
+            for i in order:
+                p = self.params[i]
                 n = p.numel()
                 self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[off:off + n].view(p.shape)
                 p.grad = self.flat_g[off:off + n].view(p.shape)
-                self.slices.append((off, n))
+                self.slices[i] = (off, n)
                 off += n
         self.numel = total
         self.views = [self.flat_g[off:off + n].view(p.shape) for p, (off, n) in zip(self.params, self.slices)]

@@ -175,6 +175,11 @@ class dgphgcn1(nn.Module):
             self.down = None
         self.bn = _norm_layer(norm, out_channels)
 
+    def flat_groups(self):
+        """(see dgmstcn.flat_groups) the three mean-pooled projections run as one conv over their stacked weights"""
+        return [[self.conv1.weight, self.conv2.weight, self.conv1_se.weight],
+                [self.conv1.bias, self.conv2.bias, self.conv1_se.bias]]
+
     def adjacency(self, xbar):
         """Ahat (n, K*mid, V, V) from the time-averaged input xbar (n, Ci, V)."""
         c1, c2, cs, el = self.conv1, self.conv2, self.conv1_se, self.edge_linears

@@ -156,6 +156,44 @@ def colsum_pair(ta, tb, split_last_b=False):
     return outa.view(ta.shape[1:]), (outb.view(kb, Cb // kb) if split_last_b else outb.view(tb.shape[1:]))
 
 
+class _CatRows(torch.autograd.Function):
+    """torch.cat(tensors, 0) for parameter tensors.  When the tensors already lie back to back in one storage (FlatParams
+    lays the groups its modules declare in ``flat_groups()`` out that way) the result is a view of that storage — no
+    launch; the gradient is handed back as row slices either way (what CatBackward does)."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        ctx.rows = [t.shape[0] for t in ts]
+        t0 = ts[0]
+        adjacent = all(t.is_contiguous() and t.dtype == t0.dtype and t.device == t0.device and
+                       t.shape[1:] == t0.shape[1:] for t in ts)
+        if adjacent:
+            esz = t0.element_size()
+            base = t0.untyped_storage().data_ptr()
+            for a, b in zip(ts[:-1], ts[1:]):
+                if b.untyped_storage().data_ptr() != base or a.data_ptr() + a.numel() * esz != b.data_ptr():
+                    adjacent = False
+                    break
+        if not adjacent:
+            return torch.cat(ts, 0)
+        size = (sum(ctx.rows),) + tuple(t0.shape[1:])
+        stride = []
+        acc = 1
+        for d in reversed(size):
+            stride.append(acc)
+            acc *= d
+        return torch.as_strided(t0.detach(), size, tuple(reversed(stride)))
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.split(ctx.rows, 0))
+
+
+def cat_rows(tensors):
+    tensors = list(tensors)
+    return tensors[0] if len(tensors) == 1 else _CatRows.apply(*tensors)
+
+
 def _f32c(t):
     if t is None:
         return None
@@ -263,8 +301,8 @@ def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, ed
     all take the 16-byte-per-lane K-C kernels (an unpadded 25-joint row is odd-sized: it fell to the scalar-load kernels,
     ~35 us per launch for 0.1 GFLOP) — and the rest is K-B reading / writing the padded rows."""
     n, Ci, V = xbar.shape
-    w_all = torch.cat([w1, w2, wse], 0)
-    b_all = torch.cat([b1, b2, bse], 0)
+    w_all = cat_rows([w1, w2, wse])
+    b_all = cat_rows([b1, b2, bse])
     xpad = torch.nn.functional.pad(xbar, (0, 32 - V)) if V < 32 else xbar
     proj = pwconv(xpad.unsqueeze(2), None, None, None, False, w_all, b_all, 1, False)[0]
     return _DynAdj.apply(proj.view(n, w_all.shape[0], xpad.shape[-1]), A, alpha, beta, we, be, node_type, edge_type)

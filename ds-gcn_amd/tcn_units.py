@@ -130,20 +130,27 @@ class dgmstcn(nn.Module):
     def _first_convs(self):
         return [b if isinstance(b, nn.Conv2d) else b[0] for b in self.branches]
 
+    def flat_groups(self):
+        """Parameter tensors the forward concatenates: FlatParams lays each group out back to back, so the
+        concatenation is a view (kernels.cat_rows)."""
+        convs = self._first_convs()
+        bns = [b[1] for b in self.branches if not isinstance(b, nn.Conv2d)]
+        return [[c.weight for c in convs], [c.bias for c in convs], [bn.weight for bn in bns], [bn.bias for bn in bns]]
+
     def forward_deferred(self, g):
         """g: tensor or Deferred (the gcn output) -> Deferred(zt, affine of self.bn)."""
         ops = kernels.ops()
         d = as_deferred(g)
         n, _, T, V = d.x1.shape
         convs = self._first_convs()
-        wb = torch.cat([c.weight.flatten(1) for c in convs], 0)
-        bb = torch.cat([c.bias for c in convs], 0)
+        wb = kernels.cat_rows([c.weight.flatten(1) for c in convs])
+        bb = kernels.cat_rows([c.bias for c in convs])
         bns = [b[1] for b in self.branches if not isinstance(b, nn.Conv2d)]
         train_stats = any(_need_stats(bn) for bn in bns)
         count = n * T * (V + 1)
         if train_stats:
-            gamma = torch.cat([bn.weight for bn in bns])
-            beta = torch.cat([bn.bias for bn in bns])
+            gamma = kernels.cat_rows([bn.weight for bn in bns])
+            beta = kernels.cat_rows([bn.bias for bn in bns])
             z, zaug, scale, shift, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, True, gamma, beta,
                                                       bns[0].eps, self.n_act, True)
             c0 = 0

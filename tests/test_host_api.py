@@ -237,3 +237,40 @@ def test_fuse_conv_bn_keeps_eval_outputs():
     assert len(folded) >= 20
     assert float((before - after).abs().max()) < 1e-5 * float(before.abs().max())
     assert float((before - after).abs().max()) > 0          # the arithmetic really changed (weights were rescaled)
+
+
+def test_cat_rows_is_a_view_under_flat_params():
+    """Modules declare the parameter tensors their forward concatenates (flat_groups); FlatParams lays them out back to
+    back and kernels.cat_rows then returns a view of the flat buffer (no launch) with the gradients of torch.cat."""
+    import torch.nn as nn
+    from dsgcn_amd import kernels, FlatParams
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Conv2d(5, 3, 1)
+            self.mid = nn.Linear(4, 4)                    # sits between the group members in parameters() order
+            self.b = nn.Conv2d(5, 2, 1)
+
+        def flat_groups(self):
+            return [[self.a.weight, self.b.weight], [self.a.bias, self.b.bias]]
+
+    torch.manual_seed(0)
+    m = M()
+    ref_w = torch.cat([m.a.weight.detach().flatten(1), m.b.weight.detach().flatten(1)], 0).clone()
+    w_plain = kernels.cat_rows([m.a.weight.flatten(1), m.b.weight.flatten(1)])
+    assert w_plain.data_ptr() != m.a.weight.data_ptr() and torch.equal(w_plain, ref_w)      # separate storages: a copy
+    flat = FlatParams(m, gather=True)
+    names = [k for k, _ in m.named_parameters()]
+    assert [n for n, _ in flat.slices] is not None and len(flat.slices) == len(names)
+    w = kernels.cat_rows([m.a.weight.flatten(1), m.b.weight.flatten(1)])
+    b = kernels.cat_rows([m.a.bias, m.b.bias])
+    assert w.data_ptr() == m.a.weight.data_ptr() and b.data_ptr() == m.a.bias.data_ptr()     # views of the flat buffer
+    assert torch.equal(w, ref_w) and w.shape == (5, 5)
+    flat.zero_grad()
+    g = torch.randn(5, 5)
+    ((w * g).sum() + (b * torch.arange(5.)).sum()).backward()
+    assert torch.equal(m.a.weight.grad.flatten(1), g[:3]) and torch.equal(m.b.weight.grad.flatten(1), g[3:])
+    assert torch.equal(m.b.bias.grad, torch.tensor([3., 4.]))
+    flat.collect_grads()
+    assert flat.check_views() and torch.equal(m.b.weight.grad.flatten(1), g[3:])
