@@ -51,6 +51,8 @@ class _FusedBlock(nn.Module):
             self.residual_kind = 'conv'
             self.residual = unit_tcn(in_channels, out_channels, kernel_size=1, stride=stride)
 
+    xbar_ld = True           # layout of the time mean handed to the next block: True = (n, C, V); an int = padded joint row
+
     def forward_fused(self, x, xbar=None, want_xbar=False):
         # the block input has up to three consumers (gcn main path, gcn residual operand, block residual): give each its
         # own alias so that their gradients are summed in one launch instead of autograd's pairwise adds
@@ -68,7 +70,7 @@ class _FusedBlock(nn.Module):
             x2, a2 = r.x1, r.a1
         assert t.x2 is None
         # t.relu: the temporal unit ends in its own ReLU (CTR-GCN's MSTCN) -> ReLU on the first term, then add + ReLU
-        return kernels.ops().fuse_out(t.x1, t.a1, x2, a2, 3 if t.relu else 1, want_xbar)
+        return kernels.ops().fuse_out(t.x1, t.a1, x2, a2, 3 if t.relu else 1, want_xbar and self.xbar_ld)
 
     def forward(self, x, A=None):
         out = self.forward_fused(x)[0]
@@ -80,6 +82,7 @@ class _FusedBlock(nn.Module):
 
 
 class DGBlock(_FusedBlock):
+    xbar_ld = 32             # the next block's dynamic-adjacency projections run on 32-joint padded rows
 
     def __init__(self, in_channels, out_channels, A, edge_type, node_type, stride=1, residual=True, **kwargs):
         super().__init__()

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
                                                      const float* __restrict__ h1, const float* __restrict__ x2,
                                                      const float* __restrict__ s2, const float* __restrict__ h2,
                                                      int relu, float* __restrict__ out, float* __restrict__ xbar, int C,
-                                                     int T, int V, int vec) {
+                                                     int T, int V, int vec, int ld) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   const long plane = blockIdx.x;
@@ -60,10 +60,11 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
   }
   if (xbar) {
     wave_lds_sync();
-    if (lane < V) {
+    if (lane < ld) {                              // ld >= V: the joint row is zero-padded to ld (ld <= 64)
       float s = 0.f;
-      for (int t = 0; t < T; ++t) s += lds[t * V + lane];
-      xbar[(size_t)plane * V + lane] = s / (float)T;
+      if (lane < V)
+        for (int t = 0; t < T; ++t) s += lds[t * V + lane];
+      xbar[(size_t)plane * ld + lane] = s / (float)T;
     }
   }
 }
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
                                                      int relu, const float* __restrict__ dout,
                                                      const float* __restrict__ dxbar, float* __restrict__ dx1,
                                                      float* __restrict__ dx2, float* __restrict__ part, int C, int T,
-                                                     int V) {
+                                                     int V, int ld) {
   __shared__ float dxb[32];
   const int lane = threadIdx.x;
   const long plane = blockIdx.x;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
   const int L = T * V;
   const float a1 = s1 ? s1[c] : 1.f, b1 = s1 ? h1[c] : 0.f;
   const float a2 = s2 ? s2[c] : 1.f, b2 = s2 ? h2[c] : 0.f;
-  if (lane < V) dxb[lane] = dxbar ? dxbar[(size_t)plane * V + lane] / (float)T : 0.f;
+  if (lane < V) dxb[lane] = dxbar ? dxbar[(size_t)plane * ld + lane] / (float)T : 0.f;
   wave_lds_sync();
   const float* __restrict__ p1 = x1 + (size_t)plane * L;
   const float* __restrict__ p2 = x2 ? x2 + (size_t)plane * L : nullptr;
@@ -130,13 +131,15 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
 extern "C" {
 
 int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
-                       const float* h2, int relu, float* out, float* xbar, int n, int C, int T, int V, void* stream) {
+                       const float* h2, int relu, float* out, float* xbar, int n, int C, int T, int V, int xbar_ld,
+                       void* stream) {
   if (!x1 || !out || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (s1 && !h1) || (s2 && !h2)) return DSGCN_EINVAL;
+  if (xbar && (xbar_ld < V || xbar_ld > 64)) return DSGCN_EINVAL;
   const int vec = ((T * V) % 4 == 0) ? 1 : 0;
   const size_t lds = xbar ? (size_t)T * V * sizeof(float) : 0;
   if (lds > 64 * 1024) return DSGCN_EUNSUPPORTED;
   hipLaunchKernelGGL(k_fuse_out_fwd, dim3((unsigned)((long)n * C)), dim3(64), lds, (hipStream_t)stream, x1, s1, h1, x2,
-                     s2, h2, relu, out, xbar, C, T, V, vec);
+                     s2, h2, relu, out, xbar, C, T, V, vec, xbar_ld);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -144,10 +147,11 @@ int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const 
 // part: (n*C, 4) per-plane [sum dv1*x1, sum dv, sum dv*x2, sum dv1]; dout or dxbar may be NULL (treated as zero).
 int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, const float* dout, const float* dxbar, float* dx1, float* dx2,
-                       float* part, int n, int C, int T, int V, void* stream) {
+                       float* part, int n, int C, int T, int V, int xbar_ld, void* stream) {
   if (!x1 || !dx1 || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (x2 && !dx2)) return DSGCN_EINVAL;
+  if (dxbar && xbar_ld < V) return DSGCN_EINVAL;
   hipLaunchKernelGGL(k_fuse_out_bwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, x1, s1, h1, x2,
-                     s2, h2, relu, dout, dxbar, dx1, dx2, part, C, T, V);
+                     s2, h2, relu, dout, dxbar, dx1, dx2, part, C, T, V, xbar_ld);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

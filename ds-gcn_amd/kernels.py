@@ -300,10 +300,12 @@ def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, ed
     as a (n, Ci, 1, 32) "clip" with the joint rows zero-padded to 32, so that forward, data gradient and weight gradient
     all take the 16-byte-per-lane K-C kernels (an unpadded 25-joint row is odd-sized: it fell to the scalar-load kernels,
     ~35 us per launch for 0.1 GFLOP) — and the rest is K-B reading / writing the padded rows."""
-    n, Ci, V = xbar.shape
+    n, Ci, _ = xbar.shape
+    V = A.shape[-1]
     w_all = cat_rows([w1, w2, wse])
     b_all = cat_rows([b1, b2, bse])
-    xpad = torch.nn.functional.pad(xbar, (0, 32 - V)) if V < 32 else xbar
+    # xbar arrives zero-padded to 32 joints from the previous block's fuse_out (want_tmean=32); the first block pads here
+    xpad = torch.nn.functional.pad(xbar, (0, 32 - V)) if xbar.shape[-1] < 32 else xbar
     proj = pwconv(xpad.unsqueeze(2), None, None, None, False, w_all, b_all, 1, False)[0]
     return _DynAdj.apply(proj.view(n, w_all.shape[0], xpad.shape[-1]), A, alpha, beta, we, be, node_type, edge_type)
 
@@ -697,7 +699,7 @@ class _PlaneStats(torch.autograd.Function):
                                    _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), _stream())
         native.check(rc, 'dsgcn_bn_bwd_coef')
         do = torch.empty_like(o)
-        rc = lib.dsgcn_fuse_out_fwd(_ptr(o), _ptr(B0), _ptr(A0), None, None, None, 0, _ptr(do), None, n, C, T, V,
+        rc = lib.dsgcn_fuse_out_fwd(_ptr(o), _ptr(B0), _ptr(A0), None, None, None, 0, _ptr(do), None, n, C, T, V, V,
                                     _stream())
         native.check(rc, 'dsgcn_fuse_out_fwd')
         return do, (dgamma if gamma is not None else None), (dbeta if has_beta else None), None
@@ -1043,17 +1045,18 @@ def tee3(x):
 class _FuseOut(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, want_tmean):
+    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, xbar_ld):
         _require_cuda(x1)
         x1, s1, h1, x2, s2, h2 = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2)]
         n, C, T, V = x1.shape
         out = torch.empty_like(x1)
-        xbar = torch.empty((n, C, V), device=x1.device, dtype=torch.float32) if want_tmean else None
+        xbar = torch.empty((n, C, xbar_ld), device=x1.device, dtype=torch.float32) if xbar_ld else None
         rc = native.lib().dsgcn_fuse_out_fwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu),
-                                             _ptr(out), _ptr(xbar), n, C, T, V, _stream())
+                                             _ptr(out), _ptr(xbar), n, C, T, V, int(xbar_ld), _stream())
         native.check(rc, 'dsgcn_fuse_out_fwd')
         ctx.save_for_backward(x1, s1, h1, x2, s2, h2)
         ctx.relu = int(relu)
+        ctx.xbar_ld = int(xbar_ld)
         return out, xbar
 
     @staticmethod
@@ -1067,7 +1070,7 @@ class _FuseOut(torch.autograd.Function):
         part = torch.empty((n, C, 4), device=x1.device, dtype=torch.float32) if need_part else None
         rc = native.lib().dsgcn_fuse_out_bwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
                                              _ptr(dout), _ptr(dxbar), _ptr(dx1), _ptr(dx2), _ptr(part), n, C, T, V,
-                                             _stream())
+                                             ctx.xbar_ld or V, _stream())
         native.check(rc, 'dsgcn_fuse_out_bwd')
         ds1 = dh1 = ds2 = dh2 = None
         if need_part:
@@ -1080,7 +1083,10 @@ class _FuseOut(torch.autograd.Function):
 
 
 def fuse_out(x1, a1, x2, a2, relu, want_tmean=False):
-    """relu: bool, or int flags — bit 0 the outer ReLU, bit 1 a ReLU on the first term before the add."""
+    """relu: bool, or int flags — bit 0 the outer ReLU, bit 1 a ReLU on the first term before the add.
+    want_tmean: False / True (time mean (n, C, V)) / an int ld >= V (time mean with the joint row zero-padded to ld: the
+    layout `dynadj` consumes directly)."""
     s1, h1 = a1 if a1 is not None else (None, None)
     s2, h2 = a2 if a2 is not None else (None, None)
-    return _FuseOut.apply(x1, s1, h1, x2, s2, h2, int(relu), bool(want_tmean))
+    ld = 0 if not want_tmean else (x1.shape[-1] if want_tmean is True else int(want_tmean))
+    return _FuseOut.apply(x1, s1, h1, x2, s2, h2, int(relu), ld)

@@ -65,12 +65,15 @@ int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, c
 /* Block output (materialise once): out = relu?(x1*s1+h1 (+ x2*s2+h2 | + x2)), xbar = mean_t out (optional).
  * Replaces BN + residual add + ReLU of dgstgcn.py:63-65 / tcn.py:427 and x.mean(-2) of gcn.py:2246.
  * relu: bit 0 = the outer ReLU, bit 1 = a ReLU on the first term before the add (CTR-GCN: msg3d_utils.py:139-141
- * followed by ctrgcn.py:60).  bwd part (n*C,4) = per-plane [sum dv1*x1, sum dv, sum dv*x2, sum dv1]. */
+ * followed by ctrgcn.py:60).  bwd part (n*C,4) = per-plane [sum dv1*x1, sum dv, sum dv*x2, sum dv1].
+ * xbar / dxbar are (n, C, xbar_ld) with xbar_ld >= V: the joint row zero-padded (32: the layout the dynamic-adjacency
+ * projections run on, so no pad / slice launches sit between the blocks). */
 int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
-                       const float* h2, int relu, float* out, float* xbar, int n, int C, int T, int V, void* stream);
+                       const float* h2, int relu, float* out, float* xbar, int n, int C, int T, int V, int xbar_ld,
+                       void* stream);
 int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, const float* dout, const float* dxbar, float* dx1, float* dx2,
-                       float* part, int n, int C, int T, int V, void* stream);
+                       float* part, int n, int C, int T, int V, int xbar_ld, void* stream);
 
 /* K-D: dgmstcn temporal stages (tcn.py:379-428).
  * branch_act: h (n,C,T,V+1) = act_c(z*scale+shift) with the global-joint column zaug appended (ReLU for c < n_act).

@@ -128,7 +128,9 @@ def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, ed
 
     w1,w2: (2*mid,Ci); wse: (mid*P,Ci) channel index c*P+p; we: (E*mid,mid) out index e*mid+c.
     node_type (V,) long, edge_type (V,V) long."""
-    n, Ci, V = xbar.shape
+    V = A.shape[-1]
+    xbar = xbar[..., :V]                                   # (a padded joint row from fuse_out(want_tmean=32))
+    n, Ci, _ = xbar.shape
     node_type, edge_type = node_type.long(), edge_type.long()
     K = A.shape[0]
     mid = w1.shape[0] // 2
@@ -238,7 +240,10 @@ def fuse_out(x1, a1, x2, a2, relu, want_tmean=False):
             out = F.relu(out)
     else:
         out = virt(x1, a1, x2, a2, bool(relu & 1))
-    return out, (out.mean(2) if want_tmean else None)
+    xbar = out.mean(2) if want_tmean else None
+    if xbar is not None and want_tmean is not True and int(want_tmean) > xbar.shape[-1]:
+        xbar = F.pad(xbar, (0, int(want_tmean) - xbar.shape[-1]))         # padded joint row (kernels.fuse_out)
+    return out, xbar
 
 
 def temporal_mlp_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, dw_w, dw_b, dw_dil, pw_w, pw_b,

@@ -52,9 +52,9 @@ for (C, T) in [(64, 64), (128, 32), (256, 16)]:
     add('branch_act_bwd', 2 * pl + pl1, lambda i: lib.dsgcn_branch_act_bwd(P(S[i].z), P(S[i].zaug), P(sc), P(sh), na, P(S[i].dh), P(S[i].dz), P(S[i].dzaug), P(part2), n, C, T, V, st))
     add('tms_combine_fwd', pl + pl1, lambda i: lib.dsgcn_tms_combine_fwd(P(S[i].o), P(coeff), P(S[i].f), P(part2), n, C, T, V, st))
     add('tms_combine_bwd', pl + 2 * pl1, lambda i: lib.dsgcn_tms_combine_bwd(P(S[i].o), P(coeff), P(S[i].g), P(A0), P(B0), P(S[i].do), P(pcoef), n, C, T, V, st))
-    add('fuse_out_fwd', 3 * pl, lambda i: lib.dsgcn_fuse_out_fwd(P(S[i].z), P(sc), P(sh), P(S[i].x2), P(sc), P(sh), 1, P(S[i].out), P(xbar), n, C, T, V, st))
-    add('fuse_out_bwd', 5 * pl, lambda i: lib.dsgcn_fuse_out_bwd(P(S[i].z), P(sc), P(sh), P(S[i].x2), P(sc), P(sh), 1, P(S[i].g), P(dxbar), P(S[i].dz), P(S[i].dz2), P(part4), n, C, T, V, st))
-    add('fuse_out_bwd(id)', 5 * pl, lambda i: lib.dsgcn_fuse_out_bwd(P(S[i].z), P(sc), P(sh), P(S[i].x2), None, None, 1, P(S[i].g), P(dxbar), P(S[i].dz), P(S[i].dz2), P(part4), n, C, T, V, st))
+    add('fuse_out_fwd', 3 * pl, lambda i: lib.dsgcn_fuse_out_fwd(P(S[i].z), P(sc), P(sh), P(S[i].x2), P(sc), P(sh), 1, P(S[i].out), P(xbar), n, C, T, V, V, st))
+    add('fuse_out_bwd', 5 * pl, lambda i: lib.dsgcn_fuse_out_bwd(P(S[i].z), P(sc), P(sh), P(S[i].x2), P(sc), P(sh), 1, P(S[i].g), P(dxbar), P(S[i].dz), P(S[i].dz2), P(part4), n, C, T, V, V, st))
+    add('fuse_out_bwd(id)', 5 * pl, lambda i: lib.dsgcn_fuse_out_bwd(P(S[i].z), P(sc), P(sh), P(S[i].x2), None, None, 1, P(S[i].g), P(dxbar), P(S[i].dz), P(S[i].dz2), P(part4), n, C, T, V, V, st))
     add('dz_eff_aug', 3 * pl, lambda i: lib.dsgcn_dz_eff_aug(P(S[i].g), P(S[i].z), P(S[i].dzaug), P(S[i].zaug), P(A0), P(B0), P(S[i].dz), n, C, T, V, st))
     add('add3', 4 * pl, lambda i: lib.dsgcn_add3(P(S[i].z), P(S[i].x2), P(S[i].g), P(S[i].dz), S[i].z.numel(), st))
     add('copy (torch)', 2 * pl, lambda i: S[i].dz.copy_(S[i].z))
