@@ -556,15 +556,15 @@ __device__ __forceinline__ void colsum_body(const ColJob& j, int bid) {
   const int R = j.R, C = j.C;
   double s = 0.0;
   if (c < C) {
-    for (int r0 = slice; r0 < R; r0 += 32 * 4) {
-      float v[4];
+    for (int r0 = slice; r0 < R; r0 += 32 * 8) {
+      float v[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 8; ++q) {
         const int r = r0 + 32 * q;
         v[q] = r < R ? j.src[(size_t)r * C + c] : 0.f;
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s += (double)v[q];
+      for (int q = 0; q < 8; ++q) s += (double)v[q];
     }
   }
   red[slice][cl] = s;

@@ -111,9 +111,7 @@ def colsum(t, split_last=False):
     R = t.shape[0]
     shape = t.shape[1:]
     C = t.numel() // max(R, 1)
-    g = 1
-    while R % (2 * g) == 0 and g * C < 8192 and R // (2 * g) >= 16:
-        g *= 2
+    g = _fold(R, C)
     if g > 1:
         t = _colsum_raw(t, R // g, g * C)
         R = g
@@ -124,8 +122,13 @@ def colsum(t, split_last=False):
 
 
 def _fold(R, C):
+    """Row groups for the two-stage column sum.  Up to 512 rows one launch does it (a block's 32 row slices read 8 rows
+    per batch, all loads of a batch in flight); taller inputs (per-plane partials: n*C rows) are dealt to g groups so
+    that every first-stage block sees ~128 rows, and a second launch adds the g partial rows."""
+    if R <= 512:
+        return 1
     g = 1
-    while R % (2 * g) == 0 and g * C < 8192 and R // (2 * g) >= 16:
+    while R % (2 * g) == 0 and 2 * g * C < 16384 and R // g > 128:
         g *= 2
     return g
 
