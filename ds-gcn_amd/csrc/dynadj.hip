@@ -27,14 +27,16 @@ namespace {
 constexpr int KSUB = 3;     // subsets: 2 plain + 1 semantic
 constexpr int NT = 1024;    // the LDS image allows one workgroup per CU, so it brings all 16 waves
 
-struct DynDims { int n, ld, mid, V, P, E; };     // ld: joint stride of the proj / dproj rows (>= V; 32 = padded)
+struct DynDims { int n, ld, mid, V, P, E, pc0, pm; };     // ld: joint stride of the proj / dproj rows (>= V; 32 = padded)
+// pc0, pm: the channel window [pc0, pc0+pm) whose factored edge-typed linear (P_e, Q_e) this workgroup holds — the
+// backward keeps all mid channels, the forward splits a sample's channels over gridDim.y workgroups
 
 // LDS carve (floats):  X [5][mid][V] | G [3][V][V] | col [3][V][2] | PQ [2][E][mid][V] | (bwd: SC [3][V][V] dX [5][mid][V])
 __device__ __forceinline__ int lds_X(const DynDims& d) { return 0; }
 __device__ __forceinline__ int lds_G(const DynDims& d) { return lds_X(d) + 5 * d.mid * d.V; }
 __device__ __forceinline__ int lds_col(const DynDims& d) { return lds_G(d) + KSUB * d.V * d.V; }
 __device__ __forceinline__ int lds_PQ(const DynDims& d) { return lds_col(d) + KSUB * d.V * 2; }
-__device__ __forceinline__ int lds_end(const DynDims& d) { return lds_PQ(d) + 2 * d.E * d.mid * d.V; }
+__device__ __forceinline__ int lds_end(const DynDims& d) { return lds_PQ(d) + 2 * d.E * d.pm * d.V; }
 
 // X slot of x1_k / x2_k :  X[0]=a0 X[1]=a1 X[2]=s X[3]=b0 X[4]=b1
 __device__ __forceinline__ int slot_x1(int k) { return k; }
@@ -76,10 +78,11 @@ __device__ void dyn_prepare(const DynDims& d, float* lds, const float* __restric
   {
     const float* a1 = X + 1 * m * V;
     const float* b1 = X + 4 * m * V;
-    const int half = d.E * m * V;
+    const int half = d.E * d.pm * V;
     for (int o = tid; o < 2 * half; o += NT) {
       const int pq = o >= half, r = o - pq * half;
-      const int ec = r / V, v = r - ec * V;           // ec = e*m + c
+      const int el = r / V, v = r - el * V;           // el = e*pm + (c - pc0)
+      const int e_ = el / d.pm, ec = e_ * m + d.pc0 + (el - e_ * d.pm);     // row e*m + c of We / be
       const float* __restrict__ wr = we + (size_t)ec * m;
       const float* src = pq ? b1 : a1;
       float acc = pq ? 0.f : be[ec];
@@ -122,7 +125,8 @@ __device__ __forceinline__ float dyn_D(const DynDims& d, const float* X, const f
   const int m = d.mid, V = d.V;
   if (k == 0) return X[(0 * m + c) * V + u] - X[(3 * m + c) * V + w];
   if (k == 2) return X[(2 * m + c) * V + u] - X[(2 * m + c) * V + w];
-  return PQ[(e * m + c) * V + u] - PQ[((d.E + e) * m + c) * V + w];
+  const int cl = c - d.pc0;
+  return PQ[(e * d.pm + cl) * V + u] - PQ[((d.E + e) * d.pm + cl) * V + w];
 }
 
 __global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d, const float* __restrict__ proj,
@@ -133,24 +137,27 @@ __global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d, const float* __res
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n = blockIdx.x;
   const int m = d.mid, V = d.V, VV = V * V;
+  // gridDim.y workgroups share one sample, each owning a window of its channels: the Gram / softmax part of the prepare
+  // step is repeated, the factored edge-typed linear (its bulk: 2*E*mid*V*mid FMAs) and the outputs are split.  At
+  // n = 128 one workgroup per sample would leave half of the 256 CUs idle.
+  d.pc0 = (m * (int)blockIdx.y) / (int)gridDim.y;
+  d.pm = (m * ((int)blockIdx.y + 1)) / (int)gridDim.y - d.pc0;
   dyn_prepare(d, lds, proj + (size_t)n * (4 + d.P) * m * d.ld, we, be, node_type);
   const float* X = lds + lds_X(d);
   const float* Sm = lds + lds_G(d);
   const float* PQ = lds + lds_PQ(d);
   float* out = ahat + (size_t)n * KSUB * m * VV;
-  const int total = KSUB * m * VV;
+  const int total = KSUB * d.pm * VV;
   const float al0 = alpha[0], al1 = alpha[1], al2 = alpha[2], be0 = beta[0], be1 = beta[1], be2 = beta[2];
-  // gridDim.y workgroups share one sample (each repeats the small prepare step): at n = 128 one workgroup per sample
-  // would leave half of the 256 CUs idle
-  for (int i = threadIdx.x + NT * blockIdx.y; i < total; i += NT * gridDim.y) {
-    const int k = i / (m * VV);
-    int r = i - k * m * VV;
-    const int c = r / VV;
-    r -= c * VV;
+  for (int i = threadIdx.x; i < total; i += NT) {
+    const int k = i / (d.pm * VV);
+    int r = i - k * d.pm * VV;
+    const int c = d.pc0 + r / VV;
+    r -= (c - d.pc0) * VV;
     const int u = r / V, w = r - u * V;
     const float dk = dyn_D(d, X, PQ, edge_type[r], k, c, u, w);
     const float al = k == 0 ? al0 : (k == 1 ? al1 : al2), bt = k == 0 ? be0 : (k == 1 ? be1 : be2);
-    out[i] = A[k * VV + r] + al * tanhf(dk) + bt * Sm[k * VV + r];
+    out[(k * m + c) * VV + r] = A[k * VV + r] + al * tanhf(dk) + bt * Sm[k * VV + r];
   }
 }
 
@@ -366,8 +373,8 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
   }
 }
 
-size_t dyn_lds_bytes(int mid, int V, int E, bool bwd) {
-  size_t f = 5 * (size_t)mid * V + 3 * (size_t)V * V + 3 * (size_t)V * 2 + 2 * (size_t)E * mid * V;
+size_t dyn_lds_bytes(int mid, int V, int E, bool bwd, int pm) {
+  size_t f = 5 * (size_t)mid * V + 3 * (size_t)V * V + 3 * (size_t)V * 2 + 2 * (size_t)E * pm * V;
   if (bwd) f += 3 * (size_t)V * V + 5 * (size_t)mid * V;
   return f * sizeof(float);
 }
@@ -385,16 +392,19 @@ int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, cons
   if (!proj || !A || !alpha || !beta || !ahat || !we || !be || !node_type || !edge_type || n <= 0 || mid <= 0)
     return DSGCN_EINVAL;
   if (V > 32 || mid > 32 || ld < V) return DSGCN_EUNSUPPORTED;
-  const size_t lds = dyn_lds_bytes(mid, V, E, false);
+  // workgroups per sample: enough to fill the chip at small batches, each with a channel window of >= 4
+  int split = n <= 128 ? (mid >= 16 ? 4 : 2) : (n <= 256 && mid >= 16 ? 2 : 1);
+  if (split > mid) split = 1;
+  const size_t lds = dyn_lds_bytes(mid, V, E, false, (mid + split - 1) / split);
   if (lds > 158 * 1024) return DSGCN_EUNSUPPORTED;
-  DynDims d{n, ld, mid, V, P, E};
+  DynDims d{n, ld, mid, V, P, E, 0, mid};
   static size_t attr_fwd = 64 * 1024;      // raised once per size class (not a stream op: keep it out of graph capture)
   if (lds > attr_fwd) {
     hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_fwd = 158 * 1024;
   }
-  hipLaunchKernelGGL(k_dynadj_fwd, dim3(n, n <= 128 ? 2 : 1), dim3(NT), lds, (hipStream_t)stream, d, proj, A, alpha, beta,
+  hipLaunchKernelGGL(k_dynadj_fwd, dim3(n, split), dim3(NT), lds, (hipStream_t)stream, d, proj, A, alpha, beta,
                      we, be, node_type, edge_type, ahat);
   DSGCN_LAUNCH_CHECK();
   return 0;
@@ -408,9 +418,9 @@ int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, c
     return DSGCN_EINVAL;
   if (V > 32 || mid > 32 || ld < V) return DSGCN_EUNSUPPORTED;
   if (pstride < dsgcn_dynadj_partial_stride(mid, V, E)) return DSGCN_EINVAL;
-  const size_t lds = dyn_lds_bytes(mid, V, E, true);
+  const size_t lds = dyn_lds_bytes(mid, V, E, true, mid);
   if (lds > 158 * 1024) return DSGCN_EUNSUPPORTED;
-  DynDims d{n, ld, mid, V, P, E};
+  DynDims d{n, ld, mid, V, P, E, 0, mid};
   static size_t attr_bwd = 64 * 1024;
   if (lds > attr_bwd) {
     hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
