@@ -388,7 +388,11 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p) {
   int NQ = (L % 4 == 0) ? 4 : 2;
   const int mtiles = (M + 31) / 32;
   int MT = mtiles >= 2 ? 2 : 1;
-  if (mtiles == 3) { MT = 3; NQ = 2; }
+  // 33..48 and 65..96 output rows (the K*mid widths of the `pre` conv and of the `post` conv's data gradient): one row
+  // tile per wave and one more workgroup per tile column — a 3-tile wave (NQ = 2) left the launch at 200 workgroups,
+  // a 2-tile wave wastes a half-empty tile on every wave (tools/kc_bench.py 5=1: 256->96 forward 50 -> 39 us,
+  // 96->256 data gradient 70 -> 62 us, 128->48 forward 29 -> 25 us, 48->128 data gradient 45 -> 36 us)
+  if (mtiles == 3 || (mtiles == 2 && M <= 48)) MT = 1;
   // tiny planes (the dynamic-adjacency projections: 32 padded joints per sample): the launch is a latency chain of K/2
   // k-steps on few waves, so give every wave the smallest tile (1 x 2 MFMAs per k-step) and the grid the most waves
   if (L <= 64 && (long)n * ((L + 127) / 128) < 1024) { NQ = 2; MT = 1; }
