@@ -1192,6 +1192,9 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
     if (fast != 0 && fast != 1) return fast;
   }
   if (!fast) {
+  // the first-generation kernels address the whole tensor with 32-bit byte offsets (the wide-load kernels above carry
+  // the sample base in the buffer resource): refuse what they cannot address instead of wrapping silently
+  if ((long)n * Ci * T * V * 4 >= (1L << 31) - 64 || (long)n * Co * T * V * 4 >= (1L << 31) - 64) return DSGCN_EUNSUPPORTED;
   const int mtiles = (Co + 31) / 32;
   const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
   const int NW = 1;
@@ -1298,6 +1301,9 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
     if (fast == 1) return 0;
     if (fast != 0) return fast;
   }
+  // the first-generation kernels address the whole tensor with 32-bit byte offsets (the wide-load kernels above carry
+  // the sample base in the buffer resource): refuse what they cannot address instead of wrapping silently
+  if ((long)n * Ci * T * V * 4 >= (1L << 31) - 64 || (long)n * Co * T * V * 4 >= (1L << 31) - 64) return DSGCN_EUNSUPPORTED;
   const int mtiles = (Ci + 31) / 32;
   const int MT = mtiles >= g_pw_maxmt ? g_pw_maxmt : mtiles;
   const int NW = 1;
@@ -1358,6 +1364,9 @@ int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const 
     if (fast == 1) return 0;
     if (fast != 0) return fast;
   }
+  // the first-generation kernels address the whole tensor with 32-bit byte offsets (the wide-load kernels above carry
+  // the sample base in the buffer resource): refuse what they cannot address instead of wrapping silently
+  if ((long)n * Ci * T * V * 4 >= (1L << 31) - 64 || (long)n * Co * T * V * 4 >= (1L << 31) - 64) return DSGCN_EUNSUPPORTED;
   const int Tout = (T + stride - 1) / stride;
   const int TR = Tout >= WG_TR ? WG_TR : Tout;
   if (TR * V > 16 * WG_J) return DSGCN_EUNSUPPORTED;
