@@ -1,5 +1,5 @@
-"""Which phase of the step issues the D2D blits (rocclr copyBuffer)?  torch.profiler (CPU+CUDA) over one eager step split
-into phases; prints per phase the count of memcpy-like device activities and the CPU ops that launched them."""
+"""Which host-side ATen ops launch the non-library kernels of a step?  torch.profiler (CPU+CUDA) over one eager step
+split into phases; prints per (phase, op) the number of device kernels that are NOT from libdsgcn (k_*)."""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,19 +23,17 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
 evs = prof.events()
 phases = [(e.name, e.time_range.start, e.time_range.end) for e in evs if e.name.startswith('PH_')]
-cnt = collections.Counter()
-for e in evs:
-    if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith('aten::') and e.cpu_parent is not None:
-        pass
-memc = [e for e in evs if ('Memcpy' in e.name or 'copyBuffer' in e.name or 'memcpy' in e.name.lower())]
-print('memcpy-like events:', len(memc), collections.Counter(e.name for e in memc).most_common(5))
-# attribute launches: CPU-side ops that have a memcpy kernel child
 ops = collections.Counter()
 for e in evs:
-    if e.device_type == torch.autograd.DeviceType.CPU and e.kernels:
-        for k in e.kernels:
-            if 'Memcpy' in k.name or 'copyBuffer' in k.name:
-                ph = next((p[0] for p in phases if p[1] <= e.time_range.start <= p[2]), '?')
-                ops[(ph, e.name)] += 1
-for (ph, name), c in ops.most_common(30):
+    if e.device_type == torch.autograd.DeviceType.CPU and e.kernels and e.name.startswith('aten::'):
+        ks = [k for k in e.kernels if 'k_' not in k.name[:40] or 'at::native' in k.name]
+        if not ks:
+            continue
+        # count only leaf ops (the innermost aten op that owns the kernel)
+        if any(c.kernels for c in e.cpu_children if c.name.startswith('aten::')):
+            continue
+        ph = next((p[0] for p in phases if p[1] <= e.time_range.start <= p[2]), '?')
+        shp = ''
+        ops[(ph, e.name)] += len(ks)
+for (ph, name), c in ops.most_common(40):
     print(f'{c:5d} {ph:12s} {name}')
