@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 2 profile set: bench line, rocprof stats of the bench command, K-C SQ counters, K-A and whole-step HBM traffic
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r2j; mkdir -p $O
+# profile set of a round: bench line, rocprof stats of the bench command, K-C SQ counters, K-A and whole-step HBM traffic
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/profile_set; mkdir -p $O
 cd $R
 timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench.err
 cd /tmp; export TMPDIR=/tmp
