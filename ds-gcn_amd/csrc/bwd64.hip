@@ -1,0 +1,272 @@
+// K-C backward in ONE pass for narrow convs (Ci, Co <= 64, one input stream, stride 1): data gradient and weight
+// gradient share the loads of gz, z and the input (reference ops: the backward of the 1x1 Conv2d + BatchNorm + ReLU chains
+// cited in pwconv.hip — gcn.py:2165-2169,2209-2215,2363-2365, tcn.py:379-404,422,427).
+//
+//   dz_eff[co,pos] = gz + A0[co] + B0[co]*z                    v[ci,pos] = relu?(x*s1[ci] + h1[ci])
+//   dW[co,ci] = sum_pos dz_eff * v      db[co] = sum_pos dz_eff
+//   dv[ci,pos] = sum_co W[co,ci] dz_eff[co,pos]     dx = dv * 1[pre>0] * s1     ipart: sum dvm*x, sum dvm
+//
+// At these widths both separate kernels are HBM-bound and each reads gz, z and x: 367 MB for a 64 -> 64 conv at 128
+// samples where one pass needs 262 MB ("fuse dgrad + wgrad into one pass").  The weight gradient contracts
+// over positions, so both of its operands must be staged through LDS as [channel][position] tiles (as in wgrad.hip);
+// the data gradient then takes its B operand (dz_eff, k = co, j = position) from the SAME tile and its A operand (W^T)
+// from a 64x64 weight image in LDS.  Work unit = (sample, 64 positions); K-splits over the grid, every split writes
+// its partial dW / db / ipart row (ordered sums later: dsgcn_colsum).
+#include "common.h"
+
+namespace {
+
+constexpr int BF_NT = 256, BF_KC = 64, BF_LS = BF_KC + 2, BF_Q = BF_KC / 4, BF_J = 64 * BF_Q / BF_NT;   // 4 slots
+constexpr int BF_OOB = 0x7ffffff0;
+
+struct BfArgs {
+  const float* x1; const float* s1; const float* h1; int relu;
+  const float* w;                                   // (Co, Ci)
+  const float* z; const float* gz; const float* A0; const float* B0;
+  float* dx; float* dwp; float* dbp; float* ipart;  // ipart (splits, Ci, 3) or NULL
+  int pstride, n, Ci, Co, L, cpn, total_chunks, cps;
+};
+
+typedef float bf_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bf_load(__amdgpu_buffer_rsrc_t r, int voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ int bf_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <bool HASC, bool AFF>
+__global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ds = lds;                                  // [64][LS] dz_eff (zero rows >= Co)
+  float* Xs = lds + 64 * BF_LS;                     // [64][LS] raw input (zero rows >= Ci)
+  float* Ws = lds + 128 * BF_LS;                    // [64 co][65] W[co][ci], zero padded
+  bf_f2* Cs = reinterpret_cast<bf_f2*>(Ws + 64 * 65);      // [64] (A0, B0)
+  bf_f2* Ps = Cs + 64;                                     // [64] (s1, h1)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int Ci = a.Ci, Co = a.Co, L = a.L, L4 = L * 4;
+  const int split = blockIdx.x;
+  const int ch0 = split * a.cps, ch1 = min(a.total_chunks, ch0 + a.cps);
+
+  for (int i = tid; i < 64 * 65; i += BF_NT) {
+    const int co = i / 65, ci = i - co * 65;
+    Ws[i] = (co < Co && ci < Ci) ? a.w[(size_t)co * Ci + ci] : 0.f;
+  }
+  if (tid < 64) {
+    Cs[tid] = (HASC && tid < Co) ? bf_f2{a.A0[tid], a.B0[tid]} : bf_f2{0.f, 0.f};
+    Ps[tid] = (AFF && a.s1 && tid < Ci) ? bf_f2{a.s1[tid], a.h1[tid]} : bf_f2{1.f, 0.f};
+  }
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+
+  // staging slots: f = tid + 256*j -> row f / 16, positions 4*(f % 16) ..+3 of the 64-position unit
+  const int col = (tid % BF_Q) * 4, row0 = tid / BF_Q;          // rows row0 + 16*j
+  f32x4 gr[BF_J], zr[HASC ? BF_J : 1], xr[BF_J];
+  float dsum[BF_J];
+#pragma unroll
+  for (int j = 0; j < BF_J; ++j) dsum[j] = 0.f;
+  auto issue = [&](int ch) {
+    const int n = ch / a.cpn, c0 = (ch - n * a.cpn) * BF_KC;
+    const bool pv = c0 + col < L;                                // L % 4 == 0: a float4 is entirely in or out
+    const __amdgpu_buffer_rsrc_t rg = bf_rsrc(a.gz + (size_t)n * Co * L, Co * L4);
+    const __amdgpu_buffer_rsrc_t rz = bf_rsrc((HASC ? a.z : a.gz) + (size_t)n * Co * L, HASC ? Co * L4 : 0);
+    const __amdgpu_buffer_rsrc_t rx = bf_rsrc(a.x1 + (size_t)n * Ci * L, Ci * L4);
+#pragma unroll
+    for (int j = 0; j < BF_J; ++j) {
+      const int row = row0 + 16 * j;
+      const int vd = (pv && row < Co) ? (row * L + c0 + col) * 4 : BF_OOB;
+      const int vx = (pv && row < Ci) ? (row * L + c0 + col) * 4 : BF_OOB;
+      gr[j] = bf_load(rg, vd);
+      if constexpr (HASC) zr[j] = bf_load(rz, vd);
+      xr[j] = bf_load(rx, vx);
+    }
+  };
+  auto commit = [&](int ch) {
+    const int n = ch / a.cpn, c0 = (ch - n * a.cpn) * BF_KC;
+    const bool pv = c0 + col < L;
+#pragma unroll
+    for (int j = 0; j < BF_J; ++j) {
+      const int row = row0 + 16 * j;
+      f32x4 d = gr[j];
+      if constexpr (HASC) {
+        const bf_f2 c = Cs[row];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] += fmaf(c.y, zr[j][e], c.x);
+      }
+      if (!(pv && row < Co)) d = f32x4{0.f, 0.f, 0.f, 0.f};
+      dsum[j] += (d.x + d.y) + (d.z + d.w);
+      bf_f2* dd = reinterpret_cast<bf_f2*>(Ds + row * BF_LS + col);
+      dd[0] = bf_f2{d.x, d.y};
+      dd[1] = bf_f2{d.z, d.w};
+      bf_f2* dxs = reinterpret_cast<bf_f2*>(Xs + row * BF_LS + col);
+      dxs[0] = bf_f2{xr[j].x, xr[j].y};
+      dxs[1] = bf_f2{xr[j].z, xr[j].w};
+    }
+  };
+
+  f32x16 accw, accw2, accd, accd2;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { accw[i] = 0.f; accw2[i] = 0.f; }
+  float u0[16], u1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { u0[r] = 0.f; u1[r] = 0.f; }
+  // weight gradient: wave (mt, nt) owns the 32x32 block (co tile mt, ci tile nt) of dW
+  // data gradient:   wave (cit, pt) owns (ci tile cit) x (position tile pt) of the unit's 64 x 64 dv
+  const int mt = wave >> 1, nt = wave & 1, cit = wave >> 1, pt = wave & 1;
+  const float* Ap = Ds + (32 * mt + l31) * BF_LS + 2 * half;
+  const float* Bp = Xs + (32 * nt + l31) * BF_LS + 2 * half;
+  const int KSd = (Co + 1) >> 1;                                 // data-gradient k-steps (two output channels each)
+  const bool wg_on = 32 * mt < Co && 32 * nt < Ci, dg_on = 32 * cit < Ci;      // tiles that hold real channels
+
+  __syncthreads();
+  const bf_f2 pw = Ps[32 * nt + l31];                             // affine of this lane's weight-gradient B row
+  if (ch0 < ch1) issue(ch0);
+  for (int ch = ch0; ch < ch1; ++ch) {
+    commit(ch);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ch + 1 < ch1) issue(ch + 1);
+    // ---- weight gradient ---- (two accumulators: a single one is a chain of dependent MFMAs, and only two or three
+    // waves share a SIMD here)
+    if (wg_on) {
+#pragma unroll 4
+      for (int w = 0; w < BF_Q; ++w) {
+        const bf_f2 av = *reinterpret_cast<const bf_f2*>(Ap + 4 * w);
+        bf_f2 bv = *reinterpret_cast<const bf_f2*>(Bp + 4 * w);
+        if (AFF) {
+          bv.x = fmaxf(fmaf(bv.x, pw.x, pw.y), lo);
+          bv.y = fmaxf(fmaf(bv.y, pw.x, pw.y), lo);
+        }
+        accw = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, accw, 0, 0, 0);
+        accw2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, accw2, 0, 0, 0);
+      }
+    }
+    // ---- data gradient ----
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accd[i] = 0.f; accd2[i] = 0.f; }
+    if (dg_on) {
+      const float* Wa = Ws + half * 65 + 32 * cit + l31;          // A[i = ci][k = co] = W[co][ci]
+      const float* Db = Ds + half * BF_LS + 32 * pt + l31;        // B[k = co][j = position]
+      int ks = 0;
+#pragma unroll 2
+      for (; ks + 1 < KSd; ks += 2) {
+        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(Wa[2 * ks * 65], Db[2 * ks * BF_LS], accd, 0, 0, 0);
+        accd2 = __builtin_amdgcn_mfma_f32_32x32x2f32(Wa[(2 * ks + 2) * 65], Db[(2 * ks + 2) * BF_LS], accd2, 0, 0, 0);
+      }
+      if (ks < KSd) accd = __builtin_amdgcn_mfma_f32_32x32x2f32(Wa[2 * ks * 65], Db[2 * ks * BF_LS], accd, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accd[i] += accd2[i];
+    }
+    {
+      const int n = ch / a.cpn, c0 = (ch - n * a.cpn) * BF_KC;
+      const int pos = c0 + 32 * pt + l31;
+      const bool pok = dg_on && pos < L;
+      float* dxn = a.dx + (size_t)n * Ci * L + pos;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = 32 * cit + bf_row32(r, half);
+        const float x = Xs[ci * BF_LS + 32 * pt + l31];
+        const bf_f2 p = Ps[ci];
+        float dv = accd[r];
+        if (AFF && a.relu && !(fmaf(x, p.x, p.y) > 0.f)) dv = 0.f;
+        if (pok && ci < Ci) dxn[(size_t)ci * L] = dv * p.x;
+        if (AFF && pok) { u0[r] = fmaf(dv, x, u0[r]); u1[r] += dv; }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                 // raw barrier: the next unit's loads stay in flight
+  }
+
+  // ---- partial rows of this split ----
+  float* dw = a.dwp + (size_t)split * a.pstride;
+  {
+    const int ci = 32 * nt + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = 32 * mt + bf_row32(r, half);
+      if (co < Co && ci < Ci) dw[(size_t)co * Ci + ci] = accw[r] + accw2[r];
+    }
+  }
+  if (true) {
+#pragma unroll
+    for (int j = 0; j < BF_J; ++j) {
+      float s = dsum[j];
+#pragma unroll
+      for (int off = 1; off < BF_Q; off <<= 1) s += __shfl_xor(s, off, 64);
+      const int co = row0 + 16 * j;
+      if ((tid % BF_Q) == 0 && co < Co) a.dbp[(size_t)split * a.pstride + co] = s;
+    }
+  }
+  if (AFF && a.ipart) {
+    // u0/u1: sums over this lane's positions; add the 32 lanes of the half-wave, then the two position tiles
+    float* Rd = lds;                                              // [4 waves][32 rows][2]   (tiles are dead)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s0 = u0[r], s1 = u1[r];
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+      if (l31 == 0) {
+        Rd[(wave * 32 + bf_row32(r, half)) * 2 + 0] = s0;
+        Rd[(wave * 32 + bf_row32(r, half)) * 2 + 1] = s1;
+      }
+    }
+    __syncthreads();
+    if (tid < 64 && tid < Ci) {
+      const int t2 = tid >> 5, rr = tid & 31;                     // ci tile, row
+      const float v0 = Rd[((2 * t2) * 32 + rr) * 2 + 0] + Rd[((2 * t2 + 1) * 32 + rr) * 2 + 0];
+      const float v1 = Rd[((2 * t2) * 32 + rr) * 2 + 1] + Rd[((2 * t2 + 1) * 32 + rr) * 2 + 1];
+      float* o = a.ipart + ((size_t)split * Ci + tid) * 3;
+      o[0] = v0; o[1] = v1; o[2] = 0.f;
+    }
+  }
+}
+
+struct BfPlan { int cpn, chunks, splits, cps; };
+
+bool bf_plan(int n, int Ci, int Co, int L, BfPlan* p) {
+  if (Ci <= 0 || Co <= 0 || Ci > 64 || Co > 64 || L % 4) return false;
+  if ((long)64 * L * 4 >= (1L << 31) - 64) return false;
+  p->cpn = (L + BF_KC - 1) / BF_KC;
+  p->chunks = n * p->cpn;
+  int target = 512;                                               // two workgroups per CU
+  if (target > p->chunks) target = p->chunks;
+  p->cps = (p->chunks + target - 1) / target;
+  p->splits = (p->chunks + p->cps - 1) / p->cps;
+  return true;
+}
+
+}  // namespace
+
+// Internal (hidden): partial rows of the fused backward for this shape, 0 = not eligible.
+__attribute__((visibility("hidden"))) int dsgcn_bwd64_splits(int n, int Ci, int Co, int L) {
+  BfPlan p;
+  return bf_plan(n, Ci, Co, L, &p) ? p.splits : 0;
+}
+
+__attribute__((visibility("hidden"))) int dsgcn_bwd64(const float* x1, const float* s1, const float* h1, int relu,
+                                                       const float* w, const float* z, const float* gz, const float* A0,
+                                                       const float* B0, float* dx, float* dwp, float* dbp, int pstride,
+                                                       float* ipart, int n, int Ci, int Co, int L, hipStream_t st) {
+  BfPlan p;
+  if (!bf_plan(n, Ci, Co, L, &p)) return 0;
+  BfArgs a = {};
+  a.x1 = x1; a.s1 = s1; a.h1 = h1; a.relu = relu; a.w = w; a.z = z; a.gz = gz; a.A0 = A0; a.B0 = B0;
+  a.dx = dx; a.dwp = dwp; a.dbp = dbp; a.ipart = ipart; a.pstride = pstride;
+  a.n = n; a.Ci = Ci; a.Co = Co; a.L = L; a.cpn = p.cpn; a.total_chunks = p.chunks; a.cps = p.cps;
+  const size_t lds = (size_t)(128 * BF_LS + 64 * 65 + 4 * 64) * sizeof(float);
+  const dim3 grid((unsigned)p.splits), blk(BF_NT);
+  const bool hasc = A0 != nullptr, aff = s1 != nullptr || relu != 0;
+  if (hasc) {
+    if (aff) hipLaunchKernelGGL((k_bwd64<true, true>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((k_bwd64<true, false>), grid, blk, lds, st, a);
+  } else {
+    if (aff) hipLaunchKernelGGL((k_bwd64<false, true>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((k_bwd64<false, false>), grid, blk, lds, st, a);
+  }
+  DSGCN_LAUNCH_CHECK();
+  return 1;
+}

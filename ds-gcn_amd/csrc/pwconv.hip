@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(64) void k_bn_bwd_coef(const float* __restrict__ g_
 }  // namespace
 
 int g_pw_maxmt = 2;      // measured (round-1 ablation): small per-wave tiles + more resident waves win
-int g_pw4 = 7;           // bit 0: wide-load forward (pw4.hip), bit 1: wide-load data gradient, bit 2: blocked wgrad (wgrad.hip)
+int g_pw4 = 15;           // bit 0: wide-load forward (pw4.hip), bit 1: wide-load data gradient, bit 2: blocked wgrad (wgrad.hip)
 
 // pw4.hip (internal linkage across the library's objects, not exported)
 __attribute__((visibility("hidden"))) int dsgcn_p4_tuning(int key, int value);
@@ -1115,6 +1115,13 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const 
                                                           const float* w, const float* z, const float* gz,
                                                           const float* A0, const float* B0, float* dx1, float* dx2,
                                                           float* ipart, int n, int Ci, int Co, int L, hipStream_t st);
+
+// bwd64.hip
+__attribute__((visibility("hidden"))) int dsgcn_bwd64_splits(int n, int Ci, int Co, int L);
+__attribute__((visibility("hidden"))) int dsgcn_bwd64(const float* x1, const float* s1, const float* h1, int relu,
+                                                       const float* w, const float* z, const float* gz, const float* A0,
+                                                       const float* B0, float* dx, float* dwp, float* dbp, int pstride,
+                                                       float* ipart, int n, int Ci, int Co, int L, hipStream_t st);
 
 // wgrad.hip
 __attribute__((visibility("hidden"))) int dsgcn_wg2_splits(int n, int Ci, int Co, int L);
@@ -1424,6 +1431,31 @@ int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* m
                      g_shift, mean, var, gamma, eps, count, C, c_affine, dgamma, dbeta, A0, B0);
   DSGCN_LAUNCH_CHECK();
   return 0;
+}
+
+}  // extern "C"
+
+
+extern "C" {
+
+// Fused backward (data gradient + weight gradient + input-affine partial sums in one pass over gz, z and the input) for
+// narrow convs: one input stream, stride 1, no global-joint column, Ci and Co <= 64, T*V % 4 == 0.
+// dsgcn_pwconv_bwd_rows: rows of the partial buffers (dwp/dbp as in dsgcn_pwconv_wgrad with this many splits, ipart
+// (rows, Ci, 3)); 0 = shape not covered (use dsgcn_pwconv_dgrad + dsgcn_pwconv_wgrad).
+int dsgcn_pwconv_bwd_rows(int n, int Ci, int Co, int T, int V, int stride) {
+  if (stride != 1 || !(g_pw4 & 8) || n <= 0 || T <= 0 || V <= 0) return 0;
+  return dsgcn_bwd64_splits(n, Ci, Co, T * V);
+}
+
+int dsgcn_pwconv_bwd(const float* x1, const float* s1, const float* h1, int relu, const float* w, const float* z,
+                     const float* gz, const float* A0, const float* B0, float* dx1, float* ipart, float* dwp, float* dbp,
+                     int pstride, int n, int Ci, int Co, int T, int V, void* stream) {
+  if (!x1 || !w || !gz || !dx1 || !dwp || !dbp || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0) return DSGCN_EINVAL;
+  if ((A0 && (!B0 || !z)) || (s1 && !h1) || pstride < Co * Ci) return DSGCN_EINVAL;
+  const int rc = dsgcn_bwd64(x1, s1, h1, relu, w, z, gz, A0, B0, dx1, dwp, dbp, pstride, ipart, n, Ci, Co, T * V,
+                             (hipStream_t)stream);
+  if (rc == 1) return 0;
+  return rc == 0 ? DSGCN_EUNSUPPORTED : rc;
 }
 
 }  // extern "C"

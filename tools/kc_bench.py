@@ -30,7 +30,7 @@ def timeit(fn, reps=20):
 
 
 def run(variant):
-    keys = {3: 7, 4: 0, 5: 0, 6: 0, 7: 512, 8: 32, 9: 512}
+    keys = {3: 15, 4: 0, 5: 0, 6: 0, 7: 512, 8: 32, 9: 512}
     if variant:
         for kv in variant.split(','):
             k, v = kv.split('=')
@@ -69,6 +69,14 @@ def run(variant):
             assert lib.dsgcn_pwconv_wgrad(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(z), None, P(gz), None, P(A0),
                                           P(B0), wpart.data_ptr(), wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co,
                                           T, V, 1, 0, st) == 0
+        rows_f = lib.dsgcn_pwconv_bwd_rows(n, Ci, Co, T, V, 1) if mode != 2 else 0
+        if rows_f:
+            wpf = torch.empty(rows_f, pstride, device=dev)
+            ipf = torch.empty(rows_f, Ci, 3, device=dev) if mode else None
+
+            def fused():
+                assert lib.dsgcn_pwconv_bwd(P(x1), P(s1), P(h1), relu, P(w), P(z), P(gz), P(A0), P(B0), P(dx), P(ipf),
+                                            wpf.data_ptr(), wpf.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, st) == 0
         L = n * T * V
         nin = 2 if mode == 2 else 1
         flops = 2.0 * Ci * Co * L
@@ -79,6 +87,9 @@ def run(variant):
             t = timeit(fn)
             tot[i] += t
             res.append(f'{t:7.1f} {byts / t / 1e6:5.2f} {flops / t / 1e6:5.1f}')
+        if rows_f:
+            t = timeit(fused)
+            res.append(f'fused bwd {t:6.1f} us {4 * L * (2 * Co + 2 * Ci) / t / 1e6:5.2f} TB/s')
         print(f'{name:8s} {Ci:4d} {Co:4d} | ' + ' | '.join(res), flush=True)
     print(f'total us: fwd {tot[0]:.0f} dgrad {tot[1]:.0f} wgrad {tot[2]:.0f}')
 
