@@ -42,7 +42,8 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ds = lds;                                  // [64][LS] dz_eff (zero rows >= Co)
   float* Xs = lds + 64 * BF_LS;                     // [64][LS] raw input (zero rows >= Ci)
-  float* Ws = lds + 128 * BF_LS;                    // [64 co][65] W[co][ci], zero padded
+  float* Os = lds + 128 * BF_LS;                    // [64][LS] dx tile of the unit
+  float* Ws = lds + 192 * BF_LS;                    // [64 co][65] W[co][ci], zero padded
   bf_f2* Cs = reinterpret_cast<bf_f2*>(Ws + 64 * 65);      // [64] (A0, B0)
   bf_f2* Ps = Cs + 64;                                     // [64] (s1, h1)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -115,11 +116,16 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
   for (int r = 0; r < 16; ++r) { u0[r] = 0.f; u1[r] = 0.f; }
   // weight gradient: wave (mt, nt) owns the 32x32 block (co tile mt, ci tile nt) of dW
   // data gradient:   wave (cit, pt) owns (ci tile cit) x (position tile pt) of the unit's 64 x 64 dv
-  const int mt = wave >> 1, nt = wave & 1, cit = wave >> 1, pt = wave & 1;
+  // (Ci <= 32: only one ci tile exists — waves 0,1 take the two co tiles of dW, waves 2,3 the two position tiles of dv,
+  // instead of two waves doing both jobs and two idling)
+  const bool narrow_i = Ci <= 32;
+  const int mt = narrow_i ? (wave & 1) : (wave >> 1), nt = narrow_i ? 0 : (wave & 1);
+  const int cit = narrow_i ? 0 : (wave >> 1), pt = wave & 1;
   const float* Ap = Ds + (32 * mt + l31) * BF_LS + 2 * half;
   const float* Bp = Xs + (32 * nt + l31) * BF_LS + 2 * half;
   const int KSd = (Co + 1) >> 1;                                 // data-gradient k-steps (two output channels each)
-  const bool wg_on = 32 * mt < Co && 32 * nt < Ci, dg_on = 32 * cit < Ci;      // tiles that hold real channels
+  const bool wg_on = 32 * mt < Co && 32 * nt < Ci && !(narrow_i && wave >= 2);      // tiles that hold real channels
+  const bool dg_on = 32 * cit < Ci && !(narrow_i && wave < 2);
 
   __syncthreads();
   const bf_f2 pw = Ps[32 * nt + l31];                             // affine of this lane's weight-gradient B row
@@ -164,20 +170,38 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
       const int n = ch / a.cpn, c0 = (ch - n * a.cpn) * BF_KC;
       const int pos = c0 + 32 * pt + l31;
       const bool pok = dg_on && pos < L;
-      float* dxn = a.dx + (size_t)n * Ci * L + pos;
+      // the dx tile leaves through LDS (Os) so that it is stored as 256-byte row pieces (16 B per lane) after the
+      // barrier below instead of 128-byte pieces of 4-byte stores from the accumulator layout
+      if (dg_on) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ci = 32 * cit + bf_row32(r, half);
-        const float x = Xs[ci * BF_LS + 32 * pt + l31];
-        const bf_f2 p = Ps[ci];
-        float dv = accd[r];
-        if (AFF && a.relu && !(fmaf(x, p.x, p.y) > 0.f)) dv = 0.f;
-        if (pok && ci < Ci) dxn[(size_t)ci * L] = dv * p.x;
-        if (AFF && pok) { u0[r] = fmaf(dv, x, u0[r]); u1[r] += dv; }
+        for (int r = 0; r < 16; ++r) {
+          const int ci = 32 * cit + bf_row32(r, half);
+          const float x = Xs[ci * BF_LS + 32 * pt + l31];
+          const bf_f2 p = Ps[ci];
+          float dv = accd[r];
+          if (AFF && a.relu && !(fmaf(x, p.x, p.y) > 0.f)) dv = 0.f;
+          Os[ci * BF_LS + 32 * pt + l31] = dv * p.x;
+          if (AFF && pok) { u0[r] = fmaf(dv, x, u0[r]); u1[r] += dv; }
+        }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                 // raw barrier: the next unit's loads stay in flight
+    {
+      // (Os is rewritten only after the NEXT unit's first barrier)
+      const int n = ch / a.cpn, c0 = (ch - n * a.cpn) * BF_KC;
+      if (c0 + col < L) {
+#pragma unroll
+        for (int j = 0; j < BF_J; ++j) {
+          const int row = row0 + 16 * j;
+          if (row < Ci) {
+            const bf_f2* o = reinterpret_cast<const bf_f2*>(Os + row * BF_LS + col);
+            const bf_f2 lo2 = o[0], hi2 = o[1];
+            *reinterpret_cast<f32x4*>(a.dx + ((size_t)n * Ci + row) * L + c0 + col) = f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
+          }
+        }
+      }
+    }
   }
 
   // ---- partial rows of this split ----
@@ -187,7 +211,7 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = 32 * mt + bf_row32(r, half);
-      if (co < Co && ci < Ci) dw[(size_t)co * Ci + ci] = accw[r] + accw2[r];
+      if (wg_on && co < Co && ci < Ci) dw[(size_t)co * Ci + ci] = accw[r] + accw2[r];
     }
   }
   if (true) {
@@ -217,8 +241,9 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
     __syncthreads();
     if (tid < 64 && tid < Ci) {
       const int t2 = tid >> 5, rr = tid & 31;                     // ci tile, row
-      const float v0 = Rd[((2 * t2) * 32 + rr) * 2 + 0] + Rd[((2 * t2 + 1) * 32 + rr) * 2 + 0];
-      const float v1 = Rd[((2 * t2) * 32 + rr) * 2 + 1] + Rd[((2 * t2 + 1) * 32 + rr) * 2 + 1];
+      const int wa = narrow_i ? 2 : 2 * t2;                       // the two waves that hold this ci tile's position tiles
+      const float v0 = Rd[(wa * 32 + rr) * 2 + 0] + Rd[((wa + 1) * 32 + rr) * 2 + 0];
+      const float v1 = Rd[(wa * 32 + rr) * 2 + 1] + Rd[((wa + 1) * 32 + rr) * 2 + 1];
       float* o = a.ipart + ((size_t)split * Ci + tid) * 3;
       o[0] = v0; o[1] = v1; o[2] = 0.f;
     }
@@ -257,7 +282,7 @@ __attribute__((visibility("hidden"))) int dsgcn_bwd64(const float* x1, const flo
   a.x1 = x1; a.s1 = s1; a.h1 = h1; a.relu = relu; a.w = w; a.z = z; a.gz = gz; a.A0 = A0; a.B0 = B0;
   a.dx = dx; a.dwp = dwp; a.dbp = dbp; a.ipart = ipart; a.pstride = pstride;
   a.n = n; a.Ci = Ci; a.Co = Co; a.L = L; a.cpn = p.cpn; a.total_chunks = p.chunks; a.cps = p.cps;
-  const size_t lds = (size_t)(128 * BF_LS + 64 * 65 + 4 * 64) * sizeof(float);
+  const size_t lds = (size_t)(192 * BF_LS + 64 * 65 + 4 * 64) * sizeof(float);
   const dim3 grid((unsigned)p.splits), blk(BF_NT);
   const bool hasc = A0 != nullptr, aff = s1 != nullptr || relu != 0;
   if (hasc) {
