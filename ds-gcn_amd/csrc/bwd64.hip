@@ -20,10 +20,11 @@ constexpr int BF_NT = 256, BF_KC = 64, BF_LS = BF_KC + 2, BF_Q = BF_KC / 4, BF_J
 constexpr int BF_OOB = 0x7ffffff0;
 
 struct BfArgs {
-  const float* x1; const float* s1; const float* h1; int relu;
+  const float* x1; const float* s1; const float* h1;
+  const float* x2; const float* s2; const float* h2; int relu;
   const float* w;                                   // (Co, Ci)
   const float* z; const float* gz; const float* A0; const float* B0;
-  float* dx; float* dwp; float* dbp; float* ipart;  // ipart (splits, Ci, 3) or NULL
+  float* dx; float* dx2; float* dwp; float* dbp; float* ipart;  // ipart (splits, Ci, 3) or NULL
   int pstride, n, Ci, Co, L, cpn, total_chunks, cps;
 };
 
@@ -37,15 +38,16 @@ __device__ __forceinline__ f32x4 bf_load(__amdgpu_buffer_rsrc_t r, int voff) {
 }
 __device__ __forceinline__ int bf_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <bool HASC, bool AFF>
+// HASC: batch-statistics terms (A0, B0);  AFF: the input carries an affine and / or a ReLU;  HAS2: second input stream.
+template <bool HASC, bool AFF, bool HAS2>
 __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ds = lds;                                  // [64][LS] dz_eff (zero rows >= Co)
-  float* Xs = lds + 64 * BF_LS;                     // [64][LS] raw input (zero rows >= Ci)
-  float* Os = lds + 128 * BF_LS;                    // [64][LS] dx tile of the unit
+  float* Xs = lds + 64 * BF_LS;                     // [64][LS] the ACTIVATED virtual input v (zero rows >= Ci)
+  float* Os = lds + 128 * BF_LS;                    // [64][LS] dv tile of the unit (before mask / scale)
   float* Ws = lds + 192 * BF_LS;                    // [64 co][65] W[co][ci], zero padded
   bf_f2* Cs = reinterpret_cast<bf_f2*>(Ws + 64 * 65);      // [64] (A0, B0)
-  bf_f2* Ps = Cs + 64;                                     // [64] (s1, h1)
+  f32x4* Ps = reinterpret_cast<f32x4*>(Cs + 64);           // [64] (s1, h1, s2, h2)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -59,22 +61,30 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
   }
   if (tid < 64) {
     Cs[tid] = (HASC && tid < Co) ? bf_f2{a.A0[tid], a.B0[tid]} : bf_f2{0.f, 0.f};
-    Ps[tid] = (AFF && a.s1 && tid < Ci) ? bf_f2{a.s1[tid], a.h1[tid]} : bf_f2{1.f, 0.f};
+    f32x4 p = {1.f, 0.f, 1.f, 0.f};
+    if (AFF && tid < Ci) {
+      if (a.s1) { p.x = a.s1[tid]; p.y = a.h1[tid]; }
+      if (HAS2 && a.s2) { p.z = a.s2[tid]; p.w = a.h2[tid]; }
+    }
+    Ps[tid] = p;
   }
   const float lo = a.relu ? 0.f : -__builtin_inff();
 
-  // staging slots: f = tid + 256*j -> row f / 16, positions 4*(f % 16) ..+3 of the 64-position unit
+  // staging slots: f = tid + 256*j -> row f / 16, positions 4*(f % 16) ..+3 of the 64-position unit.  The same
+  // threads finish the data gradient of "their" elements after the MFMA phases (they still hold the raw inputs).
   const int col = (tid % BF_Q) * 4, row0 = tid / BF_Q;          // rows row0 + 16*j
-  f32x4 gr[BF_J], zr[HASC ? BF_J : 1], xr[BF_J];
-  float dsum[BF_J];
+  f32x4 gr[BF_J], zr[HASC ? BF_J : 1], xr[BF_J], yr[HAS2 ? BF_J : 1];
+  f32x4 xk[AFF ? BF_J : 1], yk[HAS2 ? BF_J : 1];
+  float dsum[BF_J], r0[BF_J], r1[BF_J], r2[BF_J];
 #pragma unroll
-  for (int j = 0; j < BF_J; ++j) dsum[j] = 0.f;
+  for (int j = 0; j < BF_J; ++j) { dsum[j] = 0.f; r0[j] = 0.f; r1[j] = 0.f; r2[j] = 0.f; }
   auto issue = [&](int ch) {
     const int n = ch / a.cpn, c0 = (ch - n * a.cpn) * BF_KC;
     const bool pv = c0 + col < L;                                // L % 4 == 0: a float4 is entirely in or out
     const __amdgpu_buffer_rsrc_t rg = bf_rsrc(a.gz + (size_t)n * Co * L, Co * L4);
     const __amdgpu_buffer_rsrc_t rz = bf_rsrc((HASC ? a.z : a.gz) + (size_t)n * Co * L, HASC ? Co * L4 : 0);
     const __amdgpu_buffer_rsrc_t rx = bf_rsrc(a.x1 + (size_t)n * Ci * L, Ci * L4);
+    const __amdgpu_buffer_rsrc_t ry = bf_rsrc((HAS2 ? a.x2 : a.x1) + (size_t)n * Ci * L, HAS2 ? Ci * L4 : 0);
 #pragma unroll
     for (int j = 0; j < BF_J; ++j) {
       const int row = row0 + 16 * j;
@@ -83,6 +93,7 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
       gr[j] = bf_load(rg, vd);
       if constexpr (HASC) zr[j] = bf_load(rz, vd);
       xr[j] = bf_load(rx, vx);
+      if constexpr (HAS2) yr[j] = bf_load(ry, vx);
     }
   };
   auto commit = [&](int ch) {
@@ -102,18 +113,28 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
       bf_f2* dd = reinterpret_cast<bf_f2*>(Ds + row * BF_LS + col);
       dd[0] = bf_f2{d.x, d.y};
       dd[1] = bf_f2{d.z, d.w};
+      f32x4 v = xr[j];
+      if constexpr (AFF) {
+        const f32x4 p = Ps[row];
+        xk[j] = xr[j];
+        if constexpr (HAS2) yk[j] = yr[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = fmaf(xr[j][e], p.x, p.y);
+          if constexpr (HAS2) t += fmaf(yr[j][e], p.z, p.w);
+          v[e] = fmaxf(t, lo);
+        }
+      }
+      if (!(pv && row < Ci)) v = f32x4{0.f, 0.f, 0.f, 0.f};
       bf_f2* dxs = reinterpret_cast<bf_f2*>(Xs + row * BF_LS + col);
-      dxs[0] = bf_f2{xr[j].x, xr[j].y};
-      dxs[1] = bf_f2{xr[j].z, xr[j].w};
+      dxs[0] = bf_f2{v.x, v.y};
+      dxs[1] = bf_f2{v.z, v.w};
     }
   };
 
   f32x16 accw, accw2, accd, accd2;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { accw[i] = 0.f; accw2[i] = 0.f; }
-  float u0[16], u1[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { u0[r] = 0.f; u1[r] = 0.f; }
   // weight gradient: wave (mt, nt) owns the 32x32 block (co tile mt, ci tile nt) of dW
   // data gradient:   wave (cit, pt) owns (ci tile cit) x (position tile pt) of the unit's 64 x 64 dv
   // (Ci <= 32: only one ci tile exists — waves 0,1 take the two co tiles of dW, waves 2,3 the two position tiles of dv,
@@ -128,32 +149,27 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
   const bool dg_on = 32 * cit < Ci && !(narrow_i && wave < 2);
 
   __syncthreads();
-  const bf_f2 pw = Ps[32 * nt + l31];                             // affine of this lane's weight-gradient B row
   if (ch0 < ch1) issue(ch0);
   for (int ch = ch0; ch < ch1; ++ch) {
     commit(ch);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (ch + 1 < ch1) issue(ch + 1);
-    // ---- weight gradient ---- (two accumulators: a single one is a chain of dependent MFMAs, and only two or three
-    // waves share a SIMD here)
+    // ---- weight gradient ---- (two accumulators: a single one is a chain of dependent MFMAs, and only two waves
+    // share a SIMD here)
     if (wg_on) {
 #pragma unroll 4
       for (int w = 0; w < BF_Q; ++w) {
         const bf_f2 av = *reinterpret_cast<const bf_f2*>(Ap + 4 * w);
-        bf_f2 bv = *reinterpret_cast<const bf_f2*>(Bp + 4 * w);
-        if (AFF) {
-          bv.x = fmaxf(fmaf(bv.x, pw.x, pw.y), lo);
-          bv.y = fmaxf(fmaf(bv.y, pw.x, pw.y), lo);
-        }
+        const bf_f2 bv = *reinterpret_cast<const bf_f2*>(Bp + 4 * w);
         accw = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, accw, 0, 0, 0);
         accw2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, accw2, 0, 0, 0);
       }
     }
-    // ---- data gradient ----
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { accd[i] = 0.f; accd2[i] = 0.f; }
+    // ---- data gradient: dv tile -> Os ----
     if (dg_on) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { accd[i] = 0.f; accd2[i] = 0.f; }
       const float* Wa = Ws + half * 65 + 32 * cit + l31;          // A[i = ci][k = co] = W[co][ci]
       const float* Db = Ds + half * BF_LS + 32 * pt + l31;        // B[k = co][j = position]
       int ks = 0;
@@ -164,31 +180,14 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
       }
       if (ks < KSd) accd = __builtin_amdgcn_mfma_f32_32x32x2f32(Wa[2 * ks * 65], Db[2 * ks * BF_LS], accd, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) accd[i] += accd2[i];
-    }
-    {
-      const int n = ch / a.cpn, c0 = (ch - n * a.cpn) * BF_KC;
-      const int pos = c0 + 32 * pt + l31;
-      const bool pok = dg_on && pos < L;
-      // the dx tile leaves through LDS (Os) so that it is stored as 256-byte row pieces (16 B per lane) after the
-      // barrier below instead of 128-byte pieces of 4-byte stores from the accumulator layout
-      if (dg_on) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ci = 32 * cit + bf_row32(r, half);
-          const float x = Xs[ci * BF_LS + 32 * pt + l31];
-          const bf_f2 p = Ps[ci];
-          float dv = accd[r];
-          if (AFF && a.relu && !(fmaf(x, p.x, p.y) > 0.f)) dv = 0.f;
-          Os[ci * BF_LS + 32 * pt + l31] = dv * p.x;
-          if (AFF && pok) { u0[r] = fmaf(dv, x, u0[r]); u1[r] += dv; }
-        }
-      }
+      for (int r = 0; r < 16; ++r)
+        Os[(32 * cit + bf_row32(r, half)) * BF_LS + 32 * pt + l31] = accd[r] + accd2[r];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                 // raw barrier: the next unit's loads stay in flight
     {
-      // (Os is rewritten only after the NEXT unit's first barrier)
+      // finish the data gradient in the staging layout (16 B per lane, the raw inputs are still in registers):
+      // dx = dv * 1[pre > 0] * s;  (Os is rewritten only after the NEXT unit's first barrier)
       const int n = ch / a.cpn, c0 = (ch - n * a.cpn) * BF_KC;
       if (c0 + col < L) {
 #pragma unroll
@@ -197,7 +196,23 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
           if (row < Ci) {
             const bf_f2* o = reinterpret_cast<const bf_f2*>(Os + row * BF_LS + col);
             const bf_f2 lo2 = o[0], hi2 = o[1];
-            *reinterpret_cast<f32x4*>(a.dx + ((size_t)n * Ci + row) * L + c0 + col) = f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
+            f32x4 dv = {lo2.x, lo2.y, hi2.x, hi2.y};
+            f32x4 p = {1.f, 0.f, 1.f, 0.f};
+            if constexpr (AFF) {
+              p = Ps[row];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float t = fmaf(xk[j][e], p.x, p.y);
+                if constexpr (HAS2) t += fmaf(yk[j][e], p.z, p.w);
+                if (a.relu && !(t > 0.f)) dv[e] = 0.f;
+                r0[j] = fmaf(dv[e], xk[j][e], r0[j]);
+                r1[j] += dv[e];
+                if constexpr (HAS2) r2[j] = fmaf(dv[e], yk[j][e], r2[j]);
+              }
+            }
+            const size_t go = ((size_t)n * Ci + row) * L + c0 + col;
+            *reinterpret_cast<f32x4*>(a.dx + go) = f32x4{dv.x * p.x, dv.y * p.x, dv.z * p.x, dv.w * p.x};
+            if constexpr (HAS2) *reinterpret_cast<f32x4*>(a.dx2 + go) = f32x4{dv.x * p.z, dv.y * p.z, dv.z * p.z, dv.w * p.z};
           }
         }
       }
@@ -214,38 +229,22 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
       if (wg_on && co < Co && ci < Ci) dw[(size_t)co * Ci + ci] = accw[r] + accw2[r];
     }
   }
-  if (true) {
 #pragma unroll
-    for (int j = 0; j < BF_J; ++j) {
-      float s = dsum[j];
+  for (int j = 0; j < BF_J; ++j) {
+    float s = dsum[j], s0 = r0[j], s1 = r1[j], s2 = r2[j];
 #pragma unroll
-      for (int off = 1; off < BF_Q; off <<= 1) s += __shfl_xor(s, off, 64);
-      const int co = row0 + 16 * j;
-      if ((tid % BF_Q) == 0 && co < Co) a.dbp[(size_t)split * a.pstride + co] = s;
+    for (int off = 1; off < BF_Q; off <<= 1) {
+      s += __shfl_xor(s, off, 64);
+      if (AFF) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+      if (HAS2) s2 += __shfl_xor(s2, off, 64);
     }
-  }
-  if (AFF && a.ipart) {
-    // u0/u1: sums over this lane's positions; add the 32 lanes of the half-wave, then the two position tiles
-    float* Rd = lds;                                              // [4 waves][32 rows][2]   (tiles are dead)
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float s0 = u0[r], s1 = u1[r];
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
-      if (l31 == 0) {
-        Rd[(wave * 32 + bf_row32(r, half)) * 2 + 0] = s0;
-        Rd[(wave * 32 + bf_row32(r, half)) * 2 + 1] = s1;
+    const int row = row0 + 16 * j;
+    if ((tid % BF_Q) == 0) {
+      if (row < Co) a.dbp[(size_t)split * a.pstride + row] = s;
+      if (AFF && a.ipart && row < Ci) {
+        float* o = a.ipart + ((size_t)split * Ci + row) * 3;
+        o[0] = s0; o[1] = s1; o[2] = s2;
       }
-    }
-    __syncthreads();
-    if (tid < 64 && tid < Ci) {
-      const int t2 = tid >> 5, rr = tid & 31;                     // ci tile, row
-      const int wa = narrow_i ? 2 : 2 * t2;                       // the two waves that hold this ci tile's position tiles
-      const float v0 = Rd[(wa * 32 + rr) * 2 + 0] + Rd[((wa + 1) * 32 + rr) * 2 + 0];
-      const float v1 = Rd[(wa * 32 + rr) * 2 + 1] + Rd[((wa + 1) * 32 + rr) * 2 + 1];
-      float* o = a.ipart + ((size_t)split * Ci + tid) * 3;
-      o[0] = v0; o[1] = v1; o[2] = 0.f;
     }
   }
 }
@@ -272,26 +271,41 @@ __attribute__((visibility("hidden"))) int dsgcn_bwd64_splits(int n, int Ci, int 
   return bf_plan(n, Ci, Co, L, &p) ? p.splits : 0;
 }
 
-__attribute__((visibility("hidden"))) int dsgcn_bwd64(const float* x1, const float* s1, const float* h1, int relu,
-                                                       const float* w, const float* z, const float* gz, const float* A0,
-                                                       const float* B0, float* dx, float* dwp, float* dbp, int pstride,
+__attribute__((visibility("hidden"))) int dsgcn_bwd64(const float* x1, const float* s1, const float* h1, const float* x2,
+                                                       const float* s2, const float* h2, int relu, const float* w,
+                                                       const float* z, const float* gz, const float* A0, const float* B0,
+                                                       float* dx, float* dx2, float* dwp, float* dbp, int pstride,
                                                        float* ipart, int n, int Ci, int Co, int L, hipStream_t st) {
   BfPlan p;
   if (!bf_plan(n, Ci, Co, L, &p)) return 0;
   BfArgs a = {};
-  a.x1 = x1; a.s1 = s1; a.h1 = h1; a.relu = relu; a.w = w; a.z = z; a.gz = gz; a.A0 = A0; a.B0 = B0;
-  a.dx = dx; a.dwp = dwp; a.dbp = dbp; a.ipart = ipart; a.pstride = pstride;
+  a.x1 = x1; a.s1 = s1; a.h1 = h1; a.x2 = x2; a.s2 = s2; a.h2 = h2; a.relu = relu; a.w = w; a.z = z; a.gz = gz;
+  a.A0 = A0; a.B0 = B0; a.dx = dx; a.dx2 = dx2; a.dwp = dwp; a.dbp = dbp; a.ipart = ipart; a.pstride = pstride;
   a.n = n; a.Ci = Ci; a.Co = Co; a.L = L; a.cpn = p.cpn; a.total_chunks = p.chunks; a.cps = p.cps;
-  const size_t lds = (size_t)(192 * BF_LS + 64 * 65 + 4 * 64) * sizeof(float);
+  const size_t lds = (size_t)(192 * BF_LS + 64 * 65 + 2 * 64 + 4 * 64) * sizeof(float);
   const dim3 grid((unsigned)p.splits), blk(BF_NT);
-  const bool hasc = A0 != nullptr, aff = s1 != nullptr || relu != 0;
-  if (hasc) {
-    if (aff) hipLaunchKernelGGL((k_bwd64<true, true>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((k_bwd64<true, false>), grid, blk, lds, st, a);
-  } else {
-    if (aff) hipLaunchKernelGGL((k_bwd64<false, true>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((k_bwd64<false, false>), grid, blk, lds, st, a);
+  const bool hasc = A0 != nullptr, has2 = x2 != nullptr, aff = s1 != nullptr || s2 != nullptr || relu != 0 || has2;
+  // the LDS image (69 KB) is above the default dynamic limit: raised once per instantiation (not a stream operation:
+  // the first call of a shape class is an eager one, outside any graph capture)
+#define BF_LAUNCH(HC, AF, H2)                                                                                          \
+  {                                                                                                                   \
+    static bool raised = false;                                                                                       \
+    if (!raised) {                                                                                                    \
+      hipError_t e = hipFuncSetAttribute((const void*)k_bwd64<HC, AF, H2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)lds);                                                                   \
+      if (e != hipSuccess) return (int)e;                                                                             \
+      raised = true;                                                                                                  \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((k_bwd64<HC, AF, H2>), grid, blk, lds, st, a);                                                 \
   }
+  if (has2) {
+    if (hasc) BF_LAUNCH(true, true, true) else BF_LAUNCH(false, true, true)
+  } else if (hasc) {
+    if (aff) BF_LAUNCH(true, true, false) else BF_LAUNCH(true, false, false)
+  } else {
+    if (aff) BF_LAUNCH(false, true, false) else BF_LAUNCH(false, false, false)
+  }
+#undef BF_LAUNCH
   DSGCN_LAUNCH_CHECK();
   return 1;
 }

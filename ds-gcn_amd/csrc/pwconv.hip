@@ -1118,9 +1118,10 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const 
 
 // bwd64.hip
 __attribute__((visibility("hidden"))) int dsgcn_bwd64_splits(int n, int Ci, int Co, int L);
-__attribute__((visibility("hidden"))) int dsgcn_bwd64(const float* x1, const float* s1, const float* h1, int relu,
-                                                       const float* w, const float* z, const float* gz, const float* A0,
-                                                       const float* B0, float* dx, float* dwp, float* dbp, int pstride,
+__attribute__((visibility("hidden"))) int dsgcn_bwd64(const float* x1, const float* s1, const float* h1, const float* x2,
+                                                       const float* s2, const float* h2, int relu, const float* w,
+                                                       const float* z, const float* gz, const float* A0, const float* B0,
+                                                       float* dx, float* dx2, float* dwp, float* dbp, int pstride,
                                                        float* ipart, int n, int Ci, int Co, int L, hipStream_t st);
 
 // wgrad.hip
@@ -1439,7 +1440,7 @@ int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* m
 extern "C" {
 
 // Fused backward (data gradient + weight gradient + input-affine partial sums in one pass over gz, z and the input) for
-// narrow convs: one input stream, stride 1, no global-joint column, Ci and Co <= 64, T*V % 4 == 0.
+// narrow convs: stride 1, no global-joint column, Ci and Co <= 64, T*V % 4 == 0 (one or two input streams).
 // dsgcn_pwconv_bwd_rows: rows of the partial buffers (dwp/dbp as in dsgcn_pwconv_wgrad with this many splits, ipart
 // (rows, Ci, 3)); 0 = shape not covered (use dsgcn_pwconv_dgrad + dsgcn_pwconv_wgrad).
 int dsgcn_pwconv_bwd_rows(int n, int Ci, int Co, int T, int V, int stride) {
@@ -1447,13 +1448,14 @@ int dsgcn_pwconv_bwd_rows(int n, int Ci, int Co, int T, int V, int stride) {
   return dsgcn_bwd64_splits(n, Ci, Co, T * V);
 }
 
-int dsgcn_pwconv_bwd(const float* x1, const float* s1, const float* h1, int relu, const float* w, const float* z,
-                     const float* gz, const float* A0, const float* B0, float* dx1, float* ipart, float* dwp, float* dbp,
-                     int pstride, int n, int Ci, int Co, int T, int V, void* stream) {
+int dsgcn_pwconv_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2, const float* h2,
+                     int relu, const float* w, const float* z, const float* gz, const float* A0, const float* B0,
+                     float* dx1, float* dx2, float* ipart, float* dwp, float* dbp, int pstride, int n, int Ci, int Co,
+                     int T, int V, void* stream) {
   if (!x1 || !w || !gz || !dx1 || !dwp || !dbp || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0) return DSGCN_EINVAL;
-  if ((A0 && (!B0 || !z)) || (s1 && !h1) || pstride < Co * Ci) return DSGCN_EINVAL;
-  const int rc = dsgcn_bwd64(x1, s1, h1, relu, w, z, gz, A0, B0, dx1, dwp, dbp, pstride, ipart, n, Ci, Co, T * V,
-                             (hipStream_t)stream);
+  if ((A0 && (!B0 || !z)) || (s1 && !h1) || (s2 && !h2) || (x2 && !dx2) || pstride < Co * Ci) return DSGCN_EINVAL;
+  const int rc = dsgcn_bwd64(x1, s1, h1, x2, s2, h2, relu, w, z, gz, A0, B0, dx1, dx2, dwp, dbp, pstride, ipart, n, Ci, Co,
+                             T * V, (hipStream_t)stream);
   if (rc == 1) return 0;
   return rc == 0 ? DSGCN_EUNSUPPORTED : rc;
 }

@@ -395,16 +395,17 @@ class _PwConv(torch.autograd.Function):
         dx1 = torch.empty_like(x1)
         dx2 = torch.empty_like(x2) if x2 is not None else None
         pstride = Co * Ci + Co
-        rows = lib.dsgcn_pwconv_bwd_rows(n, Ci, Co, T, V, stride) if (x2 is None and not aug and gz is not None) else 0
+        rows = lib.dsgcn_pwconv_bwd_rows(n, Ci, Co, T, V, stride) if (not aug and gz is not None) else 0
         if rows > 0:
             # narrow conv: data gradient, weight gradient and the input-affine sums in one pass (csrc/bwd64.hip)
             wpart = torch.empty((rows, pstride), device=dev, dtype=torch.float32)
-            ipart = torch.empty((rows, Ci, 3), device=dev, dtype=torch.float32) if s1 is not None else None
-            rc = lib.dsgcn_pwconv_bwd(_ptr(x1), _ptr(s1), _ptr(h1), relu, _ptr(w2), _ptr(z), _ptr(gz), _ptr(A0), _ptr(B0),
-                                      _ptr(dx1), _ptr(ipart), wpart.data_ptr(), wpart.data_ptr() + 4 * Co * Ci, pstride,
-                                      n, Ci, Co, T, V, st)
+            ipart = (torch.empty((rows, Ci, 3), device=dev, dtype=torch.float32)
+                     if (s1 is not None or s2 is not None) else None)
+            rc = lib.dsgcn_pwconv_bwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(w2), _ptr(z),
+                                      _ptr(gz), _ptr(A0), _ptr(B0), _ptr(dx1), _ptr(dx2), _ptr(ipart), wpart.data_ptr(),
+                                      wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, st)
             native.check(rc, 'dsgcn_pwconv_bwd')
-            return _PwConv._finish(wpart, ipart, dx1, None, s1, None, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma,
+            return _PwConv._finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma,
                                    has_beta, n_affine)
         ipart = None
         if s1 is not None or s2 is not None:

@@ -44,7 +44,7 @@ SIGNATURES = {
     'dsgcn_pwconv_dgrad': [c_f] * 6 + [c_int] + [c_f] * 10 + [c_int] * 7 + [c_st],
     'dsgcn_pwconv_wgrad_splits': [c_int] * 6,
     'dsgcn_pwconv_bwd_rows': [c_int] * 6,
-    'dsgcn_pwconv_bwd': [c_f, c_f, c_f, c_int] + [c_f] * 9 + [c_int] * 6 + [c_st],
+    'dsgcn_pwconv_bwd': [c_f] * 6 + [c_int] + [c_f] * 10 + [c_int] * 6 + [c_st],
     'dsgcn_pwconv_wgrad': [c_f] * 6 + [c_int] + [c_f] * 8 + [c_int] * 8 + [c_st],
     'dsgcn_bn_bwd_coef': [c_f] * 5 + [ctypes.c_float, ctypes.c_double, c_int, c_int] + [c_f] * 4 + [c_st],
     'dsgcn_branch_act_fwd': [c_f] * 4 + [c_int] + [c_f] + [c_int] * 4 + [c_st],

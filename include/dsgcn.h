@@ -148,15 +148,16 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
 /* Weight gradient: k-split partials, split s at dwp + s*pstride (Co*Ci floats) and dbp + s*pstride (Co floats);
  * splits from dsgcn_pwconv_wgrad_splits. */
 int dsgcn_pwconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int stride);
-/* Both gradients in ONE pass over gz, z and the input, for narrow convs (one input stream, stride 1, no global-joint
- * column, Ci and Co <= 64, T*V % 4 == 0): dx1 = data gradient through the ReLU mask / affine of the virtual input,
- * dwp/dbp = per-split partials (rows = dsgcn_pwconv_bwd_rows, layout as dsgcn_pwconv_wgrad), ipart (rows, Ci, 3) =
- * [sum dv*x1, sum dv, 0] (NULL when the input has no affine).  dsgcn_pwconv_bwd_rows returns 0 for shapes it does not
- * cover (then: dsgcn_pwconv_dgrad + dsgcn_pwconv_wgrad).  Replaces the same reference ops as those two. */
+/* Both gradients in ONE pass over gz, z and the input(s), for narrow convs (stride 1, no global-joint column, Ci and
+ * Co <= 64, T*V % 4 == 0): dx1 / dx2 = data gradient through the ReLU mask / affines of the virtual input, dwp/dbp =
+ * per-split partials (rows = dsgcn_pwconv_bwd_rows, layout as dsgcn_pwconv_wgrad), ipart (rows, Ci, 3) =
+ * [sum dv*x1, sum dv, sum dv*x2] (NULL when the input has no affine).  dsgcn_pwconv_bwd_rows returns 0 for shapes it
+ * does not cover (then: dsgcn_pwconv_dgrad + dsgcn_pwconv_wgrad).  Replaces the same reference ops as those two. */
 int dsgcn_pwconv_bwd_rows(int n, int Ci, int Co, int T, int V, int stride);
-int dsgcn_pwconv_bwd(const float* x1, const float* s1, const float* h1, int relu, const float* w, const float* z,
-                     const float* gz, const float* A0, const float* B0, float* dx1, float* ipart, float* dwp, float* dbp,
-                     int pstride, int n, int Ci, int Co, int T, int V, void* stream);
+int dsgcn_pwconv_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2, const float* h2,
+                     int relu, const float* w, const float* z, const float* gz, const float* A0, const float* B0,
+                     float* dx1, float* dx2, float* ipart, float* dwp, float* dbp, int pstride, int n, int Ci, int Co,
+                     int T, int V, void* stream);
 int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, const float* z, const float* zaug, const float* gz,
                        const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int pstride, int n,

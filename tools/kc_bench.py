@@ -69,14 +69,14 @@ def run(variant):
             assert lib.dsgcn_pwconv_wgrad(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(z), None, P(gz), None, P(A0),
                                           P(B0), wpart.data_ptr(), wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co,
                                           T, V, 1, 0, st) == 0
-        rows_f = lib.dsgcn_pwconv_bwd_rows(n, Ci, Co, T, V, 1) if mode != 2 else 0
+        rows_f = lib.dsgcn_pwconv_bwd_rows(n, Ci, Co, T, V, 1)
         if rows_f:
             wpf = torch.empty(rows_f, pstride, device=dev)
             ipf = torch.empty(rows_f, Ci, 3, device=dev) if mode else None
 
             def fused():
-                assert lib.dsgcn_pwconv_bwd(P(x1), P(s1), P(h1), relu, P(w), P(z), P(gz), P(A0), P(B0), P(dx), P(ipf),
-                                            wpf.data_ptr(), wpf.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, st) == 0
+                assert lib.dsgcn_pwconv_bwd(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(w), P(z), P(gz), P(A0), P(B0), P(dx),
+                                            P(dx2), P(ipf), wpf.data_ptr(), wpf.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, st) == 0
         L = n * T * V
         nin = 2 if mode == 2 else 1
         flops = 2.0 * Ci * Co * L
