@@ -112,6 +112,11 @@ def _rand(g, *shape, scale=1.0):
     (3, 48, 128, 32, 25, 1, False, 'affine_relu'),
     (2, 64, 64, 25, 17, 1, False, 'res_affine'),  # coco last stage: odd plane length (425): dword-aligned 16-B loads in wgrad
     (2, 128, 256, 25, 17, 1, False, 'plain'),
+    # one-pass backward (csrc/bwd64.hip): narrow outputs, one / two input tiles, every input mode
+    (3, 128, 48, 32, 25, 1, False, 'plain'),      # pre conv of the middle stage: two 64-channel input tiles
+    (2, 96, 40, 20, 17, 1, False, 'affine_relu'), # second input tile half empty (narrow wave roles), coco planes
+    (2, 64, 24, 64, 25, 1, False, 'res_affine'),  # two input streams, 24 output rows
+    (3, 64, 64, 64, 25, 1, False, 'affine_relu'),
 ])
 def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
     g = torch.Generator().manual_seed(Ci * 7 + Co + T)
