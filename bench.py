@@ -195,8 +195,19 @@ def measure_kc_roofline(device, n, reps=20):
                                           0, st) == 0
         L = n * t * V
         flops = 2.0 * Ci * Co * L
-        for name, fn, nbytes in (('fwd', fwd, 4 * L * (Ci + Co)), ('dgrad', dgrad, 4 * L * (2 * Co + 2 * Ci)),
-                                 ('wgrad', wgrad, 4 * L * (2 * Co + Ci))):
+        jobs = [('fwd', fwd, 4 * L * (Ci + Co), 1), ('dgrad', dgrad, 4 * L * (2 * Co + 2 * Ci), 1),
+                ('wgrad', wgrad, 4 * L * (2 * Co + Ci), 1)]
+        rows_f = lib.dsgcn_pwconv_bwd_rows(n, Ci, Co, t, V, 1)
+        if rows_f:        # narrow convs: the step runs both gradients as one pass (csrc/bwd64.hip)
+            wpf = torch.empty(rows_f, pstride, device=device)
+            ipf = torch.empty(rows_f, Ci, 3, device=device)
+
+            def bwd():
+                assert lib.dsgcn_pwconv_bwd(P(x1), P(s1), P(h1), None, None, None, 1, P(w), P(z), P(gz), P(A0), P(B0), P(dx),
+                                            None, P(ipf), wpf.data_ptr(), wpf.data_ptr() + 4 * Co * Ci, pstride, n, Ci,
+                                            Co, t, V, st) == 0
+            jobs.append(('bwd', bwd, 4 * L * (2 * Co + 2 * Ci), 2))
+        for name, fn, nbytes, nprod in jobs:
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
@@ -207,7 +218,7 @@ def measure_kc_roofline(device, n, reps=20):
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / reps * 1e3
-            gbs, tf = nbytes / us / 1e3, flops / us / 1e6
+            gbs, tf = nbytes / us / 1e3, nprod * flops / us / 1e6
             hbm_bound = Ci <= 64
             out[f'k_pwconv_{name}_{Ci}x{Co}'] = dict(
                 bound='hbm' if hbm_bound else 'mfma', achieved=round(gbs if hbm_bound else tf, 1),
