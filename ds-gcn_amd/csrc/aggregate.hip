@@ -190,7 +190,8 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd(const float* __restrict__ 
 // Persistent form of k_aggregate_fwd: each wave walks work items (unit, 64-frame chunk) with a grid
 // stride and keeps the NEXT item's P plane and adjacency in flight (global -> VGPR) while the matrix core
 // works on the current one, so HBM requests, MFMA and stores of neighbouring items overlap inside one wave.
-template <int V, int CH>
+// RW: the exact row count of every work item when the shape makes it one (loop bounds and tail guards fold), 0 = runtime
+template <int V, int CH, int RW = 0>
 __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restrict__ zp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
   auto issue = [&](long item) {
     const long unit = item / chunks;
     const int t0 = (int)(item - unit * chunks) * CH;
-    const int rows = min(CH, T - t0);
+    const int rows = RW ? RW : min(CH, T - t0);
     const int c4 = (rows * V) >> 2;
     const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(zp + ((size_t)unit * T + t0) * V);
     const float* __restrict__ A = ahat + (size_t)unit * V * V;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
   while (item < items) {
     const long unit = item / chunks;
     const int t0 = (int)(item - unit * chunks) * CH;
-    const int rows = min(CH, T - t0);
+    const int rows = RW ? RW : min(CH, T - t0);
     const int c4 = (rows * V) >> 2;
     const int c = (int)(unit % KC);
     const float s = scale ? scale[c] : 1.f;
@@ -446,7 +447,8 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd(const float* __restrict__ 
 // Persistent/pipelined backward for T <= TM (TM = 64, or 128 for the long clips of the K400 config: T = 100 / 50): same
 // products as k_aggregate_bwd, with the next unit's Zp / dY planes and adjacency in flight while the current unit is on
 // the matrix core.
-template <int V, bool DA_LDS, int TM>
+// TE: the exact frame count when it is one of the model's (32 / 16: loop bounds and tail guards fold), 0 = runtime T <= TM
+template <int V, bool DA_LDS, int TM, int TE = 0>
 __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restrict__ zp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
@@ -459,19 +461,19 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
   constexpr int NA = (V * V + 63) / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldsZ = lds;
-  float* ldsG = lds + T * V;          // LDS sized by T (T*V % 4 == 0): short layers keep more waves resident
-  float* ldsA = lds + 2 * T * V;
+  float* ldsG = lds + (TE ? TE : T) * V;          // LDS sized by T (T*V % 4 == 0): short layers keep more waves resident
+  float* ldsA = lds + 2 * (TE ? TE : T) * V;
   const int lane = threadIdx.x;
   const int mi = lane & 31, mk = lane >> 5;
   const int mic = mi < V ? mi : V - 1;
-  const int rows = T;                 // T <= TM
+  const int rows = TE ? TE : T;       // T <= TM
   const int c4 = (rows * V) >> 2;
   f32x4 prez[NP4], preg[NP4];
   float prea[NA];
 
   auto issue = [&](long unit) {
-    const f32x4* __restrict__ z4 = reinterpret_cast<const f32x4*>(zp + (size_t)unit * T * V);
-    const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(dy + (size_t)unit * T * V);
+    const f32x4* __restrict__ z4 = reinterpret_cast<const f32x4*>(zp + (size_t)unit * (TE ? TE : T) * V);
+    const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(dy + (size_t)unit * (TE ? TE : T) * V);
     const float* __restrict__ A = ahat + (size_t)unit * V * V;
 #pragma unroll
     for (int q = 0; q < NP4; ++q) {
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
       }
     }
     {
-      f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dzp + (size_t)unit * T * V);
+      f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dzp + (size_t)unit * (TE ? TE : T) * V);
       const f32x4* l4 = reinterpret_cast<const f32x4*>(ldsZ);
 #pragma unroll
       for (int q = 0; q < NP4; ++q) {
@@ -623,7 +625,8 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
 // (round-1 ablation: at n=128 the one-wave form spends half its time in the per-wave MFMA chains, not on HBM).
 // dAhat = P^T dY is summed over the two halves through LDS; two raw s_barriers per unit (no vmcnt drain: the next
 // unit's prefetch stays in flight).  partial has 2 rows per unit: [wave][unit][2].
-template <int V, int HR, int NW>
+// FULL: T == NW*HR exactly (every wave has HR rows: bounds and tail guards fold)
+template <int V, int HR, int NW, bool FULL = false>
 __global__ __launch_bounds__(64 * NW) void k_aggregate_bwd_pair(const float* __restrict__ zp,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu,
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(64 * NW) void k_aggregate_bwd_pair(const float* __r
   float* ldsD = ldsA + V * V;                              // [NW-1][V*V] partial dAhat of waves 1..NW-1
   const int mi = lane & 31, mk = lane >> 5;
   const int mic = mi < V ? mi : V - 1;
-  const int rows = min(HR, T - wave * HR);
+  const int rows = FULL ? HR : min(HR, T - wave * HR);
   const int c4 = (rows * V) >> 2;
   const int a0 = wave * AH, a1 = min(V * V, a0 + AH);
   f32x4 prez[NP4], preg[NP4];
@@ -823,8 +826,17 @@ int launch_fwd(const float* zp, const float* scale, const float* shift, int relu
     // equal items per wave where possible
     const long per = (items + waves - 1) / waves;
     const long g = (items + per - 1) / per;
-    if (half)
+    if (half && T % 32 == 0)
+      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 32, 32>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+                         ahat, y, KC, T, chunks, items, g_fwd_direct);
+    else if (half)
       hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 32>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+                         ahat, y, KC, T, chunks, items, g_fwd_direct);
+    else if (T == 32)
+      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 64, 32>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+                         ahat, y, KC, T, chunks, items, g_fwd_direct);
+    else if (T == 16)
+      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 64, 16>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
                          ahat, y, KC, T, chunks, items, g_fwd_direct);
     else
       hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 64>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
@@ -854,8 +866,12 @@ int launch_bwd(const float* zp, const float* scale, const float* shift, int relu
     const int wgs = g_pair_wgs > 0 ? g_pair_wgs : 1536;
     const long per = (units + wgs - 1) / wgs;
     const long g = (units + per - 1) / per;
-    hipLaunchKernelGGL((k_aggregate_bwd_pair<V, 32, 2>), dim3((unsigned)g), dim3(64 * nw), lds2, st, zp, scale, shift,
-                       relu, ahat, dy, dzp, dahat, partial, KC, T, units);
+    if (T == 64)
+      hipLaunchKernelGGL((k_aggregate_bwd_pair<V, 32, 2, true>), dim3((unsigned)g), dim3(64 * nw), lds2, st, zp, scale,
+                         shift, relu, ahat, dy, dzp, dahat, partial, KC, T, units);
+    else
+      hipLaunchKernelGGL((k_aggregate_bwd_pair<V, 32, 2>), dim3((unsigned)g), dim3(64 * nw), lds2, st, zp, scale, shift,
+                         relu, ahat, dy, dzp, dahat, partial, KC, T, units);
   } else if (vec && T <= 128 && g_bwd_variant == 0) {
     const size_t lds = (size_t)(2 * T * V + V * V) * sizeof(float);
     int waves = g_pipe_waves_bwd > 0 ? g_pipe_waves_bwd : 2048;
@@ -867,6 +883,12 @@ int launch_bwd(const float* zp, const float* scale, const float* shift, int relu
     else if (g_bwd_da_lds)
       hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, true, 64>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
                          ahat, dy, dzp, dahat, partial, KC, T, units);
+    else if (T == 32)
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 64, 32>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift,
+                         relu, ahat, dy, dzp, dahat, partial, KC, T, units);
+    else if (T == 16)
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 64, 16>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift,
+                         relu, ahat, dy, dzp, dahat, partial, KC, T, units);
     else
       hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 64>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
                          ahat, dy, dzp, dahat, partial, KC, T, units);
