@@ -792,7 +792,7 @@ __global__ __launch_bounds__(64 * NW) void k_aggregate_bwd_pair(const float* __r
 
 int g_pipe_waves = 0;       // tuning knobs (dsgcn_set_tuning)
 int g_pipe_waves_bwd = 0;
-int g_fwd_direct = 1;
+int g_fwd_direct = 0;      // accumulator -> LDS -> 16-byte stores (direct accumulator stores measured 1-2 % slower once the kernels were specialised on T)
 int g_fwd_chunk = 32;
 int g_bwd_variant = 0;      // 1 = one-shot kernel (A/B)
 int g_bwd_da_lds = 0;       // dAhat leaves through LDS (A/B)
@@ -822,7 +822,7 @@ int launch_fwd(const float* zp, const float* scale, const float* shift, int relu
     const size_t lds = (size_t)(CHv * V + V * V) * sizeof(float);
     const int chunks = (T + CHv - 1) / CHv;
     const long items = units * chunks;
-    int waves = g_pipe_waves > 0 ? g_pipe_waves : (T > 32 ? 3072 : 2048);   // measured: tools/ka_variants.py
+    int waves = g_pipe_waves > 0 ? g_pipe_waves : 3072;                     // measured: tools/ka_sweep.py
     // equal items per wave where possible
     const long per = (items + waves - 1) / waves;
     const long g = (items + per - 1) / per;
