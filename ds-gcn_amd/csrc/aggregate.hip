@@ -517,9 +517,9 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
       const float v = ldsA[mic * V + (w < V ? w : V - 1)];
       bt[q] = (w < V && mi < V) ? v : 0.f;
     }
-    f32x16 accA;
+    f32x16 accA, accB;            // two chains: consecutive MFMAs on one accumulator wait for each other
 #pragma unroll
-    for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+    for (int i = 0; i < 16; ++i) { accA[i] = 0.f; accB[i] = 0.f; }
     // dAhat = P^T dY : k runs over frames; operands of 8 k-steps are read from LDS before their MFMAs are issued
     // (a read->use chain per step left the matrix pipe idle ~2/3 of the time: round-1 ablation)
     for (int j0 = 0; j0 < rows; j0 += 16) {
@@ -535,9 +535,15 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
         bv[q] = ok ? b : 0.f;
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (j0 + 2 * q < rows) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accA, 0, 0, 0);
+      for (int q = 0; q < 8; ++q) {
+        if (j0 + 2 * q < rows) {
+          if (q & 1) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accB, 0, 0, 0);
+          else accA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accA, 0, 0, 0);
+        }
+      }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accA[i] += accB[i];
     if (!DA_LDS) {
       float* __restrict__ dA = dahat + (size_t)unit * V * V;
       if (mi < V) {
@@ -700,9 +706,9 @@ __global__ __launch_bounds__(64 * NW) void k_aggregate_bwd_pair(const float* __r
       const float v = ldsA[mic * V + (w < V ? w : V - 1)];
       bt[q] = (w < V && mi < V) ? v : 0.f;
     }
-    f32x16 accA;
+    f32x16 accA, accB;            // two chains: consecutive MFMAs on one accumulator wait for each other
 #pragma unroll
-    for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+    for (int i = 0; i < 16; ++i) { accA[i] = 0.f; accB[i] = 0.f; }
     for (int j0 = 0; j0 < rows; j0 += 16) {
       float av[8], bv[8];
 #pragma unroll
@@ -716,9 +722,15 @@ __global__ __launch_bounds__(64 * NW) void k_aggregate_bwd_pair(const float* __r
         bv[q] = ok ? b : 0.f;
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (j0 + 2 * q < rows) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accA, 0, 0, 0);
+      for (int q = 0; q < 8; ++q) {
+        if (j0 + 2 * q < rows) {
+          if (q & 1) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accB, 0, 0, 0);
+          else accA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accA, 0, 0, 0);
+        }
+      }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accA[i] += accB[i];
     if (wave > 0 && mi < V) {
       float* dd = ldsD + (wave - 1) * V * V;
 #pragma unroll
