@@ -52,7 +52,7 @@ __device__ __forceinline__ int proj_row(const DynDims& d, int slot, int c, int t
 
 // Steps shared by forward and backward: projections -> LDS (node-typed row pick), Gram + column softmax, factored
 // edge-typed linear.
-__device__ void dyn_prepare(const DynDims& d, float* lds, const float* __restrict__ proj_n, const float* __restrict__ we,
+__device__ __forceinline__ void dyn_prepare(const DynDims& d, float* lds, const float* __restrict__ proj_n, const float* __restrict__ we,
                             const float* __restrict__ be, const int* __restrict__ node_type) {
   const int tid = threadIdx.x;
   const int m = d.mid, V = d.V;
@@ -129,12 +129,19 @@ __device__ __forceinline__ float dyn_D(const DynDims& d, const float* X, const f
   return PQ[(e * d.pm + cl) * V + u] - PQ[((d.E + e) * d.pm + cl) * V + w];
 }
 
-__global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d, const float* __restrict__ proj,
+// VT / MD: the joint count and the mid width as compile-time constants for the model's shapes (25 / 17 / 18 joints, mid
+// 8 / 16 / 32), 0 = take them from the arguments.  Every phase decodes (k, c, u, w) from a flat index: with run-time V and
+// mid that is two or three integer divisions (~30 instructions each) per element.
+template <int VT, int MD>
+__global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d_, const float* __restrict__ proj,
                                                    const float* __restrict__ A, const float* __restrict__ alpha,
                                                    const float* __restrict__ beta, const float* __restrict__ we,
                                                    const float* __restrict__ be, const int* __restrict__ node_type,
                                                    const int* __restrict__ edge_type, float* __restrict__ ahat) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  DynDims d = d_;
+  if (VT) d.V = VT;
+  if (MD) d.mid = MD;
   const int n = blockIdx.x;
   const int m = d.mid, V = d.V, VV = V * V;
   // gridDim.y workgroups share one sample, each owning a window of its channels: the Gram / softmax part of the prepare
@@ -165,13 +172,17 @@ __global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d, const float* __res
 // stays in L2).  Outputs: dproj (n, 4m+mP, V) (typed rows: only row c*P+tau(v) of joint v is non-zero); ppar (n, pstride)
 // per-sample partials [sum_c dAhat (3VV) | dalpha (3) | dbeta (3) |
 // dWe (E*m*m) | dbe (E*m)] — the sum over samples gives the parameter gradients.
+template <int VT, int MD>
 __global__ __launch_bounds__(NT) void k_dynadj_bwd(
-    DynDims d, const float* __restrict__ proj, const float* __restrict__ alpha, const float* __restrict__ beta,
+    DynDims d_, const float* __restrict__ proj, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ we, const float* __restrict__ be, const int* __restrict__ node_type,
     const int* __restrict__ edge_type, const float* __restrict__ dahat, float* dd, float* __restrict__ dproj,
     float* __restrict__ ppar, int pstride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[6][NT / DSGCN_WAVE];
+  DynDims d = d_;
+  if (VT) d.V = VT;
+  if (MD) d.mid = MD;
   const int tid = threadIdx.x;
   const int n = blockIdx.x;
   const int m = d.mid, V = d.V, VV = V * V, E = d.E;
@@ -381,6 +392,16 @@ size_t dyn_lds_bytes(int mid, int V, int E, bool bwd, int pm) {
 
 }  // namespace
 
+// the model's (V, mid) combinations get their own instantiation, everything else the run-time form
+#define DYN_DISPATCH(L)                                   \
+  if (V == 25 && mid == 8) L(25, 8)                       \
+  else if (V == 25 && mid == 16) L(25, 16)                \
+  else if (V == 25 && mid == 32) L(25, 32)                \
+  else if (V == 17 && mid == 8) L(17, 8)                  \
+  else if (V == 17 && mid == 16) L(17, 16)                \
+  else if (V == 17 && mid == 32) L(17, 32)                \
+  else L(0, 0)
+
 extern "C" {
 
 // floats per sample of the backward's parameter-partial buffer
@@ -398,14 +419,20 @@ int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, cons
   const size_t lds = dyn_lds_bytes(mid, V, E, false, (mid + split - 1) / split);
   if (lds > 158 * 1024) return DSGCN_EUNSUPPORTED;
   DynDims d{n, ld, mid, V, P, E, 0, mid};
-  static size_t attr_fwd = 64 * 1024;      // raised once per size class (not a stream op: keep it out of graph capture)
-  if (lds > attr_fwd) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_fwd = 158 * 1024;
+#define DYN_FWD(VT, MD)                                                                                               \
+  {                                                                                                                   \
+    static size_t attr = 64 * 1024;                                                                                   \
+    if (lds > attr) {                                                                                                 \
+      hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_fwd<VT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         158 * 1024);                                                                 \
+      if (e != hipSuccess) return (int)e;                                                                             \
+      attr = 158 * 1024;                                                                                              \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((k_dynadj_fwd<VT, MD>), dim3(n, split), dim3(NT), lds, (hipStream_t)stream, d, proj, A, alpha,  \
+                       beta, we, be, node_type, edge_type, ahat);                                                     \
   }
-  hipLaunchKernelGGL(k_dynadj_fwd, dim3(n, split), dim3(NT), lds, (hipStream_t)stream, d, proj, A, alpha, beta,
-                     we, be, node_type, edge_type, ahat);
+  DYN_DISPATCH(DYN_FWD)
+#undef DYN_FWD
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -421,14 +448,20 @@ int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, c
   const size_t lds = dyn_lds_bytes(mid, V, E, true, mid);
   if (lds > 158 * 1024) return DSGCN_EUNSUPPORTED;
   DynDims d{n, ld, mid, V, P, E, 0, mid};
-  static size_t attr_bwd = 64 * 1024;
-  if (lds > attr_bwd) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_bwd = 158 * 1024;
+#define DYN_BWD(VT, MD)                                                                                               \
+  {                                                                                                                   \
+    static size_t attr = 64 * 1024;                                                                                   \
+    if (lds > attr) {                                                                                                 \
+      hipError_t e = hipFuncSetAttribute((const void*)k_dynadj_bwd<VT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         158 * 1024);                                                                 \
+      if (e != hipSuccess) return (int)e;                                                                             \
+      attr = 158 * 1024;                                                                                              \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((k_dynadj_bwd<VT, MD>), dim3(n), dim3(NT), lds, (hipStream_t)stream, d, proj, alpha, beta, we, \
+                       be, node_type, edge_type, dahat, dd_ws, dproj, ppar, pstride);                                 \
   }
-  hipLaunchKernelGGL(k_dynadj_bwd, dim3(n), dim3(NT), lds, (hipStream_t)stream, d, proj, alpha, beta, we, be, node_type,
-                     edge_type, dahat, dd_ws, dproj, ppar, pstride);
+  DYN_DISPATCH(DYN_BWD)
+#undef DYN_BWD
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
