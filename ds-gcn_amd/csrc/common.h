@@ -78,3 +78,31 @@ __device__ __forceinline__ void plane_to_lds(const float* __restrict__ src, floa
     }
   }
 }
+
+// ---- three-term bf16 form of the fp32 product (B3) -----------------------------------------------------------------
+// An fp32 value is the exact sum of three bf16 terms (8 significand bits each, round-to-nearest residues: x0 = bf16(x),
+// x1 = bf16(x - x0), x2 = x - x0 - x1; both subtractions are exact in fp32 and the last residue has at most 6 bits).
+// a*b = sum_{i,j} a_i*b_j; the six terms with i + j <= 2 are kept (each exact in fp32, accumulated in the MFMA's fp32
+// accumulator), the dropped ones are below 2^-24 |a||b| — the rounding class of the fp32 MFMA it replaces, at 2.7x its
+// rate: six v_mfma_f32_32x32x16_bf16 (32 cycles each) per 16 channels against eight v_mfma_f32_32x32x2_f32 (64 cycles).
+// Non-finite inputs give NaN where fp32 would keep an infinity (inf - inf in the residue).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned b3_pack(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, bf16x2));   // v_cvt_pk_bf16_f32: lo = a, hi = b
+}
+
+// packed bf16 pairs p[s] = (lo: term s of a, hi: term s of b)
+__device__ __forceinline__ void b3_split(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = b3_pack(a, b);
+  a -= __builtin_bit_cast(float, p0 << 16);
+  b -= __builtin_bit_cast(float, p0 & 0xffff0000u);
+  p1 = b3_pack(a, b);
+  a -= __builtin_bit_cast(float, p1 << 16);
+  b -= __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = b3_pack(a, b);
+}

@@ -1152,6 +1152,8 @@ int dsgcn_pwconv_tuning(int key, int value) {
   if (key == 3) { g_pw4 = value; return 0; }
   if (key >= 4 && key <= 6) return dsgcn_p4_tuning(key - 4, value);
   if (key >= 7 && key <= 9) return dsgcn_wg2_tuning(key - 7, value);
+  if (key >= 10 && key <= 11) return dsgcn_p4_tuning(key - 7, value);
+  if (key == 12) return dsgcn_wg2_tuning(3, value);
   return DSGCN_EINVAL;
 }
 #endif

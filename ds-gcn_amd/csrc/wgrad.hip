@@ -35,17 +35,24 @@ __device__ __forceinline__ int wg_row32(int r, int half) { return (r & 3) + 8 * 
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int TM, int TN, int KC, bool HAS2, bool HASC>
+// B3: the tiles are staged as the three bf16 terms of every value (common.h: exact split, six bf16 MFMAs per 16 positions
+// in place of eight fp32 ones at twice the cycles each); rows of KC bf16 + 16 B of pad per term (conflict-free 16-byte
+// fragment reads: a lane reads 8 consecutive positions of its channel row).
+template <int TM, int TN, int KC, bool HAS2, bool HASC, bool B3 = false>
 __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
   constexpr int LS = KC + 2;
+  constexpr int RB = KC * 2 + 16;                 // B3: bytes per row per term
   constexpr int Q = KC / 4;                       // float4 slots per row
   constexpr int JD = TM * Q / WG_NT, JX = TN * Q / WG_NT;
   constexpr int MI = TM / 64, NI = TN / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ds = lds;                                // [TM][LS] dz_eff
   float* Xs = lds + TM * LS;                      // [TN][LS] virtual input
-  f32x2* Cs = reinterpret_cast<f32x2*>(lds + (TM + TN) * LS);          // [TM] (A0, B0)
-  f32x4* Ps = reinterpret_cast<f32x4*>(lds + (TM + TN) * LS + 2 * TM);  // [TN] (s1, h1, s2, h2)
+  constexpr int TF = B3 ? 3 * (TM + TN) * RB / 4 : (TM + TN) * LS;   // floats of tile storage
+  char* Db = reinterpret_cast<char*>(lds);        // B3: [3][TM][RB] dz_eff terms
+  char* Xb = Db + 3 * TM * RB;                    // B3: [3][TN][RB] virtual-input terms
+  f32x2* Cs = reinterpret_cast<f32x2*>(lds + TF);          // [TM] (A0, B0)
+  f32x4* Ps = reinterpret_cast<f32x4*>(lds + TF + 2 * TM);  // [TN] (s1, h1, s2, h2)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -135,9 +142,19 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
 #pragma unroll
       for (int e = 1; e < 4; ++e) d[e] = e < nv ? d[e] : 0.f;
       dsum[j] += (d.x + d.y) + (d.z + d.w);
-      f32x2* dst = reinterpret_cast<f32x2*>(Ds + row * LS + col);
-      dst[0] = f32x2{d.x, d.y};
-      dst[1] = f32x2{d.z, d.w};
+      if constexpr (B3) {
+        unsigned p0, p1, p2, q0, q1, q2;
+        b3_split(d.x, d.y, p0, p1, p2);
+        b3_split(d.z, d.w, q0, q1, q2);
+        char* dst = Db + row * RB + col * 2;
+        *reinterpret_cast<u32x2v*>(dst) = u32x2v{p0, q0};
+        *reinterpret_cast<u32x2v*>(dst + TM * RB) = u32x2v{p1, q1};
+        *reinterpret_cast<u32x2v*>(dst + 2 * TM * RB) = u32x2v{p2, q2};
+      } else {
+        f32x2* dst = reinterpret_cast<f32x2*>(Ds + row * LS + col);
+        dst[0] = f32x2{d.x, d.y};
+        dst[1] = f32x2{d.z, d.w};
+      }
     }
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
@@ -151,9 +168,19 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
         if constexpr (HAS2) t += fmaf(yr[j][e], p.z, p.w);
         v[e] = (ok && e < nv) ? fmaxf(t, lo) : 0.f;
       }
-      f32x2* dst = reinterpret_cast<f32x2*>(Xs + row * LS + col);
-      dst[0] = f32x2{v.x, v.y};
-      dst[1] = f32x2{v.z, v.w};
+      if constexpr (B3) {
+        unsigned p0, p1, p2, q0, q1, q2;
+        b3_split(v.x, v.y, p0, p1, p2);
+        b3_split(v.z, v.w, q0, q1, q2);
+        char* dst = Xb + row * RB + col * 2;
+        *reinterpret_cast<u32x2v*>(dst) = u32x2v{p0, q0};
+        *reinterpret_cast<u32x2v*>(dst + TN * RB) = u32x2v{p1, q1};
+        *reinterpret_cast<u32x2v*>(dst + 2 * TN * RB) = u32x2v{p2, q2};
+      } else {
+        f32x2* dst = reinterpret_cast<f32x2*>(Xs + row * LS + col);
+        dst[0] = f32x2{v.x, v.y};
+        dst[1] = f32x2{v.z, v.w};
+      }
     }
   };
 
@@ -176,6 +203,36 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (ch + 1 < ch1) issue(ch + 1);
+    if constexpr (B3) {
+      const char* Ab = Db + (m0 + l31) * RB + 16 * half;
+      const char* Bb = Xb + (n0 + l31) * RB + 16 * half;
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) {
+        bf16x8 af[MI][3], bf[NI][3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            af[mi][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Ab + (t * TM + 32 * mi) * RB + 32 * ks));
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            bf[ni][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Bb + (t * TN + 32 * ni) * RB + 32 * ks));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            f32x16 c = acc[mi][ni];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][2], bf[ni][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], bf[ni][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[ni][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], bf[ni][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[ni][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[ni][0], c, 0, 0, 0);
+            acc[mi][ni] = c;
+          }
+      }
+    } else {
 #pragma unroll
     for (int w = 0; w < Q; ++w) {
       f32x2 av[MI], bv[NI];
@@ -190,6 +247,7 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].x, bv[ni].x, acc[mi][ni], 0, 0, 0);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].y, bv[ni].y, acc[mi][ni], 0, 0, 0);
         }
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                 // raw barrier: the next chunk's loads stay in flight
@@ -221,9 +279,9 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
   }
 }
 
-int g_wg2_target4 = 512, g_wg2_kc128 = 32, g_wg2_target1 = 512;    // lab knobs (dsgcn_pwconv_tuning keys 7, 8); the values are the product's
+int g_wg2_target4 = 512, g_wg2_kc128 = 32, g_wg2_target1 = 512, g_wg2_b3 = 1;    // lab knobs (dsgcn_pwconv_tuning keys 7, 8); the values are the product's
 
-struct Wg2Plan { int TM, TN, KC, cpn, chunks, tm_tiles, tn_tiles, splits, cps; size_t lds; };
+struct Wg2Plan { int TM, TN, KC, cpn, chunks, tm_tiles, tn_tiles, splits, cps, b3; size_t lds; };
 
 bool wg2_plan(int n, int Ci, int Co, int L, Wg2Plan* p) {
   if ((long)Ci * L * 4 >= (1L << 31) - 64 || (long)Co * L * 4 >= (1L << 31) - 64) return false;
@@ -242,17 +300,20 @@ bool wg2_plan(int n, int Ci, int Co, int L, Wg2Plan* p) {
   p->cps = (p->chunks + target - 1) / target;
   p->splits = (p->chunks + p->cps - 1) / p->cps;
   p->lds = ((size_t)(p->TM + p->TN) * (p->KC + 2) + 2 * p->TM + 4 * p->TN) * sizeof(float);
+  // both sides wide: the fp32 form is bound by the matrix pipe -> three-term bf16 products
+  p->b3 = (g_wg2_b3 && p->TM == 128 && p->TN == 128 && p->KC == 32) ? 1 : 0;
+  if (p->b3) p->lds = (size_t)3 * (p->TM + p->TN) * (p->KC * 2 + 16) + (2 * p->TM + 4 * p->TN) * sizeof(float);
   return true;
 }
 
-template <int TM, int TN, int KC>
+template <int TM, int TN, int KC, bool B3 = false>
 void wg2_launch(const Wg2Args& a, bool has2, bool hasc, dim3 grid, size_t lds, hipStream_t st) {
   if (has2) {
-    if (hasc) hipLaunchKernelGGL((k_wg2<TM, TN, KC, true, true>), grid, dim3(WG_NT), lds, st, a);
-    else hipLaunchKernelGGL((k_wg2<TM, TN, KC, true, false>), grid, dim3(WG_NT), lds, st, a);
+    if (hasc) hipLaunchKernelGGL((k_wg2<TM, TN, KC, true, true, B3>), grid, dim3(WG_NT), lds, st, a);
+    else hipLaunchKernelGGL((k_wg2<TM, TN, KC, true, false, B3>), grid, dim3(WG_NT), lds, st, a);
   } else {
-    if (hasc) hipLaunchKernelGGL((k_wg2<TM, TN, KC, false, true>), grid, dim3(WG_NT), lds, st, a);
-    else hipLaunchKernelGGL((k_wg2<TM, TN, KC, false, false>), grid, dim3(WG_NT), lds, st, a);
+    if (hasc) hipLaunchKernelGGL((k_wg2<TM, TN, KC, false, true, B3>), grid, dim3(WG_NT), lds, st, a);
+    else hipLaunchKernelGGL((k_wg2<TM, TN, KC, false, false, B3>), grid, dim3(WG_NT), lds, st, a);
   }
 }
 
@@ -262,6 +323,7 @@ __attribute__((visibility("hidden"))) int dsgcn_wg2_tuning(int key, int value) {
   if (key == 0) g_wg2_target4 = value;
   else if (key == 1) g_wg2_kc128 = value;
   else if (key == 2) g_wg2_target1 = value;
+  else if (key == 3) g_wg2_b3 = value;
   else return DSGCN_EINVAL;
   return 0;
 }
@@ -289,6 +351,7 @@ __attribute__((visibility("hidden"))) int dsgcn_wg2(const float* x1, const float
   const dim3 grid(tiles > 1 ? (unsigned)((p.splits + 7) / 8 * 8 * tiles) : (unsigned)p.splits);
   const bool has2 = x2 != nullptr, hasc = A0 != nullptr;
   if (p.TM == 128 && p.TN == 128 && p.KC == 64) wg2_launch<128, 128, 64>(a, has2, hasc, grid, p.lds, st);
+  else if (p.b3) wg2_launch<128, 128, 32, true>(a, has2, hasc, grid, p.lds, st);
   else if (p.TM == 128 && p.TN == 128) wg2_launch<128, 128, 32>(a, has2, hasc, grid, p.lds, st);
   else if (p.TM == 128) wg2_launch<128, 64, 64>(a, has2, hasc, grid, p.lds, st);
   else if (p.TN == 128) wg2_launch<64, 128, 64>(a, has2, hasc, grid, p.lds, st);
