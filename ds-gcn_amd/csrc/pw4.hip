@@ -82,333 +82,20 @@ __device__ __forceinline__ ACC p4_rowread(const float* Tw, int half, int l31) {
 }
 
 // MODE 0: B' = b1;  1: relu?(b1*s1+h1);  2: relu?(b1*s1+h1 + b2*s2+h2).   EPI 0: forward (bias, statistics);  1: data gradient.
-template <int MT, int NQ, int MODE, int PD, int EPI, int B3 = 0>
-__global__ __launch_bounds__(P4_NT, B3 ? 1 : (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4))) void k_pw4(Pw4Args a) {
+struct P4Tile { int wave, half, l31, tid, mBase, n, nrem, ds, pos, grp; bool wlive, pok; };
+
+// Epilogue of a wave's (32*MT rows) x (32*NQ positions, lane-owned runs of NQ) accumulator tile, shared by k_pw4 and
+// k_pwg.  OWNROWS = false: the workgroup's four waves hold the SAME rows at different positions (their per-row sums are
+// added through LDS, one partial row per workgroup); true: the waves hold different rows of one position tile (each wave
+// writes its rows of the workgroup's partial row itself).
+template <int MT, int NQ, int EPI, bool OWNROWS>
+__device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][NQ], float* lds, const P4Tile& t) {
   typedef typename VQ<NQ>::T vq;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  // XCD-aware decode: the cc workgroups that read the same position tiles (one per 32*MT output channels) take
-  // consecutive slots of one XCD (blockIdx % 8), so the re-reads are served by that XCD's L2
-  const int ngrp = (a.WT + 3) >> 2;
-  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-  const int cz = slot % a.cc;
-  const int grp = (slot / a.cc) * 8 + xcd;
-  if (grp >= ngrp) return;
-  const int mBase = cz * 32 * MT;
-  const int K = a.K, M = a.M, L = a.L;
-  const int Kpad = a.Kpad, KP = Kpad + 1;
-  float* Ws = lds;                                                       // [32*MT][KP], zero beyond (M, K)
-  // B3: Ws holds the three bf16 terms of the weight block in fragment order, [3][Kpad/16 + 1][32*MT][2 halves] x 16 B
-  const int KSI = (Kpad >> 4) + 1;
-  f32x4* Ps = reinterpret_cast<f32x4*>(lds + (B3 ? 3 * KSI * 32 * MT * 8 : ((32 * MT * KP + 2 + 3) & ~3)));  // [Kpad + 2] (s1, h1, s2, h2)
-
-  // Position tiles run over the planes of all samples back to back (a tile may straddle samples: L % NQ == 0, so a lane's
-  // NQ positions never do): no per-sample tail tile — at L = 400 (256 channels, 16 frames) per-sample tiling left
-  // 22 % of the MFMA work on padding.  The wave's buffer resources start at its first sample n; a lane adds ds sample
-  // strides in its vector offset.
-  const int wt = grp * 4 + wave;
-  const bool wlive = wt < a.WT;
-  const int g0 = (wlive ? wt : 0) * (32 * NQ);          // < 2^31 (p4_plan)
-  const int n = g0 / L;
-  int pos = g0 - n * L + l31 * NQ;
-  int ds = 0;
-  while (pos >= L) { pos -= L; ++ds; }
-  const bool pok = wlive && n + ds < a.n;
-  const int L4 = L * 4;
-  const int nrem = a.n - n < a.span ? a.n - n : a.span;     // samples the wave can touch
-  const int voff = pok ? ds * K * L4 + ((B3 ? 8 : 1) * half * L + pos) * 4 : P4_OOB;   // B3: a lane's half owns 8 channels of 16
-  const __amdgpu_buffer_rsrc_t r1 = p4_rsrc(a.b1 + (size_t)n * K * L, wlive ? nrem * K * L4 : 0);
-  const __amdgpu_buffer_rsrc_t r2 = p4_rsrc((MODE == 2 ? a.b2 : a.b1) + (size_t)n * K * L, (wlive && MODE == 2) ? nrem * K * L4 : 0);
-
-  f32x16 acc[MT][NQ];
-  const float lo = a.relu ? 0.f : -__builtin_inff();
-  if constexpr (B3) {
-    // ---- B3: K advances 16 channels per step; a lane's half owns channels 16*ks + 8*half + (0..7) of its 4 positions ----
-    static_assert(!B3 || NQ == 4, "B3 runs on position quads");
-    constexpr int PB = 2;                            // 16-channel steps of operand prefetch (8 x 16-byte loads each)
-    constexpr int R = 32 * MT;
-    u32x4v* Wi = reinterpret_cast<u32x4v*>(Ws);
-    const int KS = Kpad >> 4, KSr = K >> 4;          // K % 16 == 0 (p4_plan)
-    vq bb1[PB][8], bb2[MODE == 2 ? PB : 1][8];
-    auto issue = [&](int u, int ks) {
-      const unsigned s0 = ks < KSr ? (unsigned)(16 * ks) * (unsigned)L4 : (unsigned)P4_OOB;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bb1[u][j] = p4_load<4>(r1, voff, (int)(s0 + (unsigned)(j * L4)));
-        if constexpr (MODE == 2) bb2[u][j] = p4_load<4>(r2, voff, (int)(s0 + (unsigned)(j * L4)));
-      }
-    };
-    // weight block: global -> three bf16 terms -> LDS in fragment order.  One group = 8 consecutive k of one row = one
-    // lane's A fragment; thread order follows the LDS order (k fast in memory: (half, row); m fast: (row)) so that the
-    // 16-byte LDS writes of a wave are contiguous or 32-byte strided.
-    const bool mfast = a.w_ldm == 1;
-    const bool vec = a.w_ldk == 1 && (a.w_ldm & 3) == 0 && (reinterpret_cast<size_t>(a.w) & 15) == 0;
-    const int ngr = R * (Kpad >> 3);
-    constexpr int GB = 4;
-    for (int g0 = tid; g0 < ngr; g0 += P4_NT * GB) {
-      float t[GB][8];
-#pragma unroll
-      for (int b = 0; b < GB; ++b) {
-        const int g = g0 + b * P4_NT;
-        int r, kg;
-        if (mfast) { r = g % R; kg = g / R; }
-        else { r = (g >> 1) % R; kg = 2 * ((g >> 1) / R) + (g & 1); }
-        const int m = mBase + r, k0 = 8 * kg;
-        const bool ok = g < ngr && m < M;
-        if (vec) {
-          const f32x4* src = reinterpret_cast<const f32x4*>(a.w + (size_t)m * a.w_ldm + k0);
-          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-          const f32x4 v0 = (ok && k0 < K) ? src[0] : z4;
-          const f32x4 v1 = (ok && k0 + 4 < K) ? src[1] : z4;
-          t[b][0] = v0.x; t[b][1] = v0.y; t[b][2] = v0.z; t[b][3] = v0.w;
-          t[b][4] = v1.x; t[b][5] = v1.y; t[b][6] = v1.z; t[b][7] = v1.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            t[b][j] = (ok && k0 + j < K) ? a.w[(size_t)m * a.w_ldm + (size_t)(k0 + j) * a.w_ldk] : 0.f;
-        }
-      }
-      if (g0 == tid) {
-#pragma unroll
-        for (int u = 0; u < PB; ++u) issue(u, u);
-      }
-#pragma unroll
-      for (int b = 0; b < GB; ++b) {
-        const int g = g0 + b * P4_NT;
-        int r, kg;
-        if (mfast) { r = g % R; kg = g / R; }
-        else { r = (g >> 1) % R; kg = 2 * ((g >> 1) / R) + (g & 1); }
-        u32x4v w0, w1, w2;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          unsigned p0, p1, p2;
-          b3_split(t[b][2 * jj], t[b][2 * jj + 1], p0, p1, p2);
-          w0[jj] = p0; w1[jj] = p1; w2[jj] = p2;
-        }
-        if (g < ngr) {
-          const int at = ((kg >> 1) * R + r) * 2 + (kg & 1);
-          Wi[at] = w0;
-          Wi[KSI * R * 2 + at] = w1;
-          Wi[2 * KSI * R * 2 + at] = w2;
-        }
-      }
-    }
-    if (MODE != 0) {
-      for (int i = tid; i < 16 * KSI; i += P4_NT) {
-        f32x4 p = {0.f, 0.f, 0.f, 0.f};
-        if (i < K) {
-          p.x = a.ps1 ? a.ps1[i] : 1.f;
-          p.y = a.ph1 ? a.ph1[i] : 0.f;
-          p.z = a.ps2 ? a.ps2[i] : 1.f;
-          p.w = a.ph2 ? a.ph2[i] : 0.f;
-        }
-        Ps[i] = p;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                    // raw barrier: the operand prefetch stays in flight
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = mBase + 32 * m + p4_row32(i, half);
-        const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[m][q][i] = b0;
-      }
-    u32x4v af[2][MT][3];
-    f32x4 pq[2][8];
-    auto ldsread = [&](int ks, int slot) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) af[slot][m][t3] = Wi[((t3 * KSI + ks) * R + 32 * m + l31) * 2 + half];
-      if (MODE != 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pq[slot][j] = Ps[16 * ks + 8 * half + j];
-      }
-    };
-    // One wave per SIMD (the weight image fills most of the LDS), so the wave hides its own VALU work — affine, ReLU and
-    // the three-term split of the NEXT position sub-tile — in the shadow of the current sub-tile's MFMAs: each region
-    // below is pinned as (1 MFMA, VPM VALU) groups.  Left alone the scheduler clusters 6-7 MFMAs and runs of 40 VALU
-    // instructions, and a lone in-order wave then pays the two in series.
-    auto split_q = [&](int u, int slot, int q, u32x4v (&bt)[3]) {
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        float v[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int j = 2 * jj + e;
-          float x = bb1[u][j][q];
-          if (MODE != 0) {
-            const f32x4 pr = pq[slot][j];
-            x = fmaf(x, pr.x, pr.y);
-            if constexpr (MODE == 2) x += fmaf(bb2[u][j][q], pr.z, pr.w);
-            x = fmaxf(x, lo);
-          }
-          v[e] = x;
-        }
-        unsigned p0, p1, p2;
-        b3_split(v[0], v[1], p0, p1, p2);
-        bt[0][jj] = p0; bt[1][jj] = p1; bt[2][jj] = p2;
-      }
-    };
-    auto mma_q = [&](int slot, int q, const u32x4v (&bt)[3]) {
-      const bf16x8 b0 = __builtin_bit_cast(bf16x8, bt[0]), b1 = __builtin_bit_cast(bf16x8, bt[1]),
-                   b2 = __builtin_bit_cast(bf16x8, bt[2]);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[slot][m][0]), a1 = __builtin_bit_cast(bf16x8, af[slot][m][1]),
-                     a2 = __builtin_bit_cast(bf16x8, af[slot][m][2]);
-        f32x16 c = acc[m][q];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
-        acc[m][q] = c;
-      }
-    };
-    constexpr int VPM = MODE == 2 ? 6 : (MODE == 1 ? 5 : 4);
-    auto weave = [&]() {
-#pragma unroll
-      for (int i = 0; i < 6 * MT; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    u32x4v btA[3], btB[3];
-    ldsread(0, 0);
-    split_q(0, 0, 0, btA);
-    for (int base = 0; base < KS; base += PB) {
-#pragma unroll
-      for (int u = 0; u < PB; ++u) {
-        const int ks = base + u;
-        const int cur = u & 1, nxt = cur ^ 1;
-        ldsread(ks + 1, nxt);                        // last step: the image's pad step, never used
-        __builtin_amdgcn_sched_barrier(0);
-        split_q(u, cur, 1, btB); mma_q(cur, 0, btA); weave();
-        split_q(u, cur, 2, btA); mma_q(cur, 1, btB); weave();
-        split_q(u, cur, 3, btB); mma_q(cur, 2, btA); weave();
-        issue(u, ks + PB);                           // in place: the buffer's registers are dead by now
-        __builtin_amdgcn_sched_barrier(0);
-        split_q((u + 1) % PB, nxt, 0, btA); mma_q(cur, 3, btB); weave();
-      }
-    }
-  } else {
-    // ---- weights: global -> registers (all loads of a batch issued together), operand prefetch, then LDS ----
-    constexpr int WB = 16;
-    const bool mfast = a.w_ldm == 1;                 // A = W^T (data gradient): m is the contiguous index of w
-    // element e of this thread: k fast: (r, k) = ((tid>>4) + 16*(e % (2*MT)), (tid&15) + 16*(e / (2*MT)))
-    //                           m fast: (r, k) = ((tid&31) + 32*(e % MT),     (tid>>5) + 8*(e / MT))
-    const int nel = mfast ? (Kpad >> 3) * MT : (Kpad >> 4) * 2 * MT;
-    vq buf1[PD], buf2[MODE == 2 ? PD : 1];
-    for (int e0 = 0; e0 < nel; e0 += WB) {
-      float tmp[WB];
-  #pragma unroll
-      for (int j = 0; j < WB; ++j) {
-        const int e = e0 + j;
-        int r, k;
-        if (mfast) { r = (tid & 31) + 32 * (e % MT); k = (tid >> 5) + 8 * (e / MT); }
-        else { r = (tid >> 4) + 16 * (e % (2 * MT)); k = (tid & 15) + 16 * (e / (2 * MT)); }
-        const int m = mBase + r;
-        tmp[j] = (e < nel && m < M && k < K) ? a.w[(size_t)m * a.w_ldm + (size_t)k * a.w_ldk] : 0.f;
-      }
-      if (e0 == 0) {
-  #pragma unroll
-        for (int u = 0; u < PD; ++u) {
-          const int s0 = 2 * u < K ? 2 * u * L4 : P4_OOB;               // (channels past K: out of range, zeros)
-          buf1[u] = p4_load<NQ>(r1, voff, s0);
-          if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, s0);
-        }
-      }
-  #pragma unroll
-      for (int j = 0; j < WB; ++j) {
-        const int e = e0 + j;
-        int r, k;
-        if (mfast) { r = (tid & 31) + 32 * (e % MT); k = (tid >> 5) + 8 * (e / MT); }
-        else { r = (tid >> 4) + 16 * (e % (2 * MT)); k = (tid & 15) + 16 * (e / (2 * MT)); }
-        if (e < nel) Ws[r * KP + k] = tmp[j];
-      }
-    }
-    if (MODE != 0) {
-      for (int i = tid; i < Kpad; i += P4_NT) {
-        f32x4 p = {0.f, 0.f, 0.f, 0.f};
-        if (i < K) {
-          p.x = a.ps1 ? a.ps1[i] : 1.f;
-          p.y = a.ph1 ? a.ph1[i] : 0.f;
-          p.z = a.ps2 ? a.ps2[i] : 1.f;
-          p.w = a.ph2 ? a.ph2[i] : 0.f;
-        }
-        Ps[i] = p;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                    // raw barrier: the operand prefetch stays in flight
-
-    // accumulators start at the bias of their output row (forward), so the epilogue has no per-row loads
-  #pragma unroll
-    for (int m = 0; m < MT; ++m)
-  #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = mBase + 32 * m + p4_row32(i, half);
-        const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
-  #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[m][q][i] = b0;
-      }
-
-    const int KS = Kpad >> 1;                        // k-steps (2 channels each), a multiple of PD
-    const int KSr = (K + 1) >> 1;                    // k-steps that hold real channels
-    // Software pipeline, pinned with scheduling barriers.  Step ks: start the LDS reads of step ks+1 (A fragment, affine
-    // row; double-buffered by step parity), apply the affine to the operand loaded PD steps ago, run the MT*NQ MFMAs, then
-    // re-issue that operand buffer's load for step ks+PD (after the MFMAs: the buffer registers are dead by then, so the
-    // load lands in place).  Left to itself the compiler sinks all PD loads to the end of the unrolled body and waits for
-    // the first of them at the top of the next one — or, with the load ahead of the MFMAs, rotates the PD buffers through
-    // v_mov chains behind a vmcnt(0) (profiles/r02: matrix pipe 61 % busy at 256 -> 256 channels).
-    float avb[2][MT];
-    f32x4 pb[2] = {{1.f, 0.f, 1.f, 0.f}, {1.f, 0.f, 1.f, 0.f}};
-  #pragma unroll
-    for (int m = 0; m < MT; ++m) avb[0][m] = Ws[(32 * m + l31) * KP + half];
-    if (MODE != 0) pb[0] = Ps[half];
-    for (int base = 0; base < KS; base += PD) {
-  #pragma unroll
-      for (int u = 0; u < PD; ++u) {
-        const int ks = base + u;
-        const int cur = u & 1, nxt = cur ^ 1;                              // PD is even: the parity survives the back edge
-        const int kn = 2 * (ks + 1) + half;                                // last step: reads the LDS pad, never used
-  #pragma unroll
-        for (int m = 0; m < MT; ++m) avb[nxt][m] = Ws[(32 * m + l31) * KP + kn];
-        if (MODE != 0) pb[nxt] = Ps[kn];
-        vq b = buf1[u];
-        if (MODE != 0) {
-          const f32x4 p = pb[cur];
-  #pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            float v = fmaf(b[q], p.x, p.y);
-            if constexpr (MODE == 2) v += fmaf(buf2[u][q], p.z, p.w);
-            b[q] = fmaxf(v, lo);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
-        for (int m = 0; m < MT; ++m)
-  #pragma unroll
-          for (int q = 0; q < NQ; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(avb[cur][m], b[q], acc[m][q], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // past K: the scalar offset jumps out of the buffer's range (zeros, no traffic: the bounds check covers it)
-        const int sn = ks + PD < KSr ? 2 * (ks + PD) * L4 : P4_OOB;
-        buf1[u] = p4_load<NQ>(r1, voff, sn);
-        if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, sn);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  __syncthreads();                                 // every wave is done with Ws / Ps: LDS is reused below
-
+  const int wave = t.wave, half = t.half, l31 = t.l31, tid = t.tid, mBase = t.mBase, n = t.n, nrem = t.nrem, ds = t.ds,
+            pos = t.pos, grp = t.grp;
+  const bool wlive = t.wlive, pok = t.pok;
+  const int M = a.M, L = a.L, L4 = L * 4;
+  (void)L;
   // Epilogue.  Stores go through a per-sample buffer resource (invalid rows / positions get an out-of-range offset
   // and are dropped by the bounds check: no branches); per-channel sums through LDS transposes of the wave's tiles.
   constexpr int NTL = EPI == 0 ? 2 : 3;            // transposed tiles per wave
@@ -447,12 +134,20 @@ __global__ __launch_bounds__(P4_NT, B3 ? 1 : (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ?
         sd += __shfl_xor(sd, 32, 64);
         qd += __shfl_xor(qd, 32, 64);
         if (half == 0) {
-          Ss[((wave * MT + m) * 32 + l31) * 2 + 0] = sd;
-          Ss[((wave * MT + m) * 32 + l31) * 2 + 1] = qd;
+          if constexpr (OWNROWS) {
+            const int co = mBase + 32 * m + l31;
+            if (co < M) {
+              a.partial[((size_t)grp * M + co) * 2 + 0] = (float)sd;
+              a.partial[((size_t)grp * M + co) * 2 + 1] = (float)qd;
+            }
+          } else {
+            Ss[((wave * MT + m) * 32 + l31) * 2 + 0] = sd;
+            Ss[((wave * MT + m) * 32 + l31) * 2 + 1] = qd;
+          }
         }
       }
     }
-    if (stats) {
+    if (stats && !OWNROWS) {
       __syncthreads();
       if (tid < 32 * MT) {
         const int co = mBase + tid;
@@ -471,14 +166,16 @@ __global__ __launch_bounds__(P4_NT, B3 ? 1 : (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ?
     const bool need_x = a.erelu || a.es1 != nullptr || a.ex2 != nullptr;
     const bool has2 = a.ex2 != nullptr;
     const bool sums = a.ipart != nullptr;
-    if (tid < 32 * MT) {
-      const int ci = mBase + tid;
+    if constexpr (OWNROWS) Es += wave * 32 * MT;       // every wave its own rows
+    const int et = OWNROWS ? (tid & 63) : tid;
+    if (et < 32 * MT) {
+      const int ci = mBase + et;
       f32x4 p = {1.f, 0.f, 1.f, 0.f};
       if (ci < M) {
         if (a.es1) { p.x = a.es1[ci]; p.y = a.eh1[ci]; }
         if (a.es2) { p.z = a.es2[ci]; p.w = a.eh2[ci]; }
       }
-      Es[tid] = p;
+      Es[et] = p;
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rx1 = p4_rsrc(a.ex1 + (size_t)n * M * L, (wlive && need_x) ? nrem * M * L4 : 0);
@@ -534,12 +231,20 @@ __global__ __launch_bounds__(P4_NT, B3 ? 1 : (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ?
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         if (half == 0) {
-          float* q = Ss + ((wave * MT + m) * 32 + l31) * 3;
-          q[0] = s0; q[1] = s1; q[2] = s2;
+          if constexpr (OWNROWS) {
+            const int ci = mBase + 32 * m + l31;
+            if (ci < M) {
+              float* o = a.ipart + ((size_t)grp * M + ci) * 3;
+              o[0] = s0; o[1] = s1; o[2] = s2;
+            }
+          } else {
+            float* q = Ss + ((wave * MT + m) * 32 + l31) * 3;
+            q[0] = s0; q[1] = s1; q[2] = s2;
+          }
         }
       }
     }
-    if (sums) {
+    if (sums && !OWNROWS) {
       __syncthreads();
       if (tid < 32 * MT) {
         const int ci = mBase + tid;
@@ -558,9 +263,345 @@ __global__ __launch_bounds__(P4_NT, B3 ? 1 : (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ?
   }
 }
 
-int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_b3 = 1, g_p4_b3min = 96;
+template <int MT, int NQ, int MODE, int PD, int EPI>
+__global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4))) void k_pw4(Pw4Args a) {
+  typedef typename VQ<NQ>::T vq;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  // XCD-aware decode: the cc workgroups that read the same position tiles (one per 32*MT output channels) take
+  // consecutive slots of one XCD (blockIdx % 8), so the re-reads are served by that XCD's L2
+  const int ngrp = (a.WT + 3) >> 2;
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int cz = slot % a.cc;
+  const int grp = (slot / a.cc) * 8 + xcd;
+  if (grp >= ngrp) return;
+  const int mBase = cz * 32 * MT;
+  const int K = a.K, M = a.M, L = a.L;
+  const int Kpad = a.Kpad, KP = Kpad + 1;
+  float* Ws = lds;                                                       // [32*MT][KP], zero beyond (M, K)
+  f32x4* Ps = reinterpret_cast<f32x4*>(lds + ((32 * MT * KP + 2 + 3) & ~3));  // [Kpad + 2] (s1, h1, s2, h2)
 
-struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad, b3; size_t lds; unsigned grid; };
+  // Position tiles run over the planes of all samples back to back (a tile may straddle samples: L % NQ == 0, so a lane's
+  // NQ positions never do): no per-sample tail tile — at L = 400 (256 channels, 16 frames) per-sample tiling left
+  // 22 % of the MFMA work on padding.  The wave's buffer resources start at its first sample n; a lane adds ds sample
+  // strides in its vector offset.
+  const int wt = grp * 4 + wave;
+  const bool wlive = wt < a.WT;
+  const int g0 = (wlive ? wt : 0) * (32 * NQ);          // < 2^31 (p4_plan)
+  const int n = g0 / L;
+  int pos = g0 - n * L + l31 * NQ;
+  int ds = 0;
+  while (pos >= L) { pos -= L; ++ds; }
+  const bool pok = wlive && n + ds < a.n;
+  const int L4 = L * 4;
+  const int nrem = a.n - n < a.span ? a.n - n : a.span;     // samples the wave can touch
+  const int voff = pok ? ds * K * L4 + (half * L + pos) * 4 : P4_OOB;
+  const __amdgpu_buffer_rsrc_t r1 = p4_rsrc(a.b1 + (size_t)n * K * L, wlive ? nrem * K * L4 : 0);
+  const __amdgpu_buffer_rsrc_t r2 = p4_rsrc((MODE == 2 ? a.b2 : a.b1) + (size_t)n * K * L, (wlive && MODE == 2) ? nrem * K * L4 : 0);
+
+  f32x16 acc[MT][NQ];
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  // ---- weights: global -> registers (all loads of a batch issued together), operand prefetch, then LDS ----
+  constexpr int WB = 16;
+  const bool mfast = a.w_ldm == 1;                 // A = W^T (data gradient): m is the contiguous index of w
+  // element e of this thread: k fast: (r, k) = ((tid>>4) + 16*(e % (2*MT)), (tid&15) + 16*(e / (2*MT)))
+  //                           m fast: (r, k) = ((tid&31) + 32*(e % MT),     (tid>>5) + 8*(e / MT))
+  const int nel = mfast ? (Kpad >> 3) * MT : (Kpad >> 4) * 2 * MT;
+  vq buf1[PD], buf2[MODE == 2 ? PD : 1];
+  for (int e0 = 0; e0 < nel; e0 += WB) {
+    float tmp[WB];
+#pragma unroll
+    for (int j = 0; j < WB; ++j) {
+      const int e = e0 + j;
+      int r, k;
+      if (mfast) { r = (tid & 31) + 32 * (e % MT); k = (tid >> 5) + 8 * (e / MT); }
+      else { r = (tid >> 4) + 16 * (e % (2 * MT)); k = (tid & 15) + 16 * (e / (2 * MT)); }
+      const int m = mBase + r;
+      tmp[j] = (e < nel && m < M && k < K) ? a.w[(size_t)m * a.w_ldm + (size_t)k * a.w_ldk] : 0.f;
+    }
+    if (e0 == 0) {
+#pragma unroll
+      for (int u = 0; u < PD; ++u) {
+        const int s0 = 2 * u < K ? 2 * u * L4 : P4_OOB;               // (channels past K: out of range, zeros)
+        buf1[u] = p4_load<NQ>(r1, voff, s0);
+        if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, s0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WB; ++j) {
+      const int e = e0 + j;
+      int r, k;
+      if (mfast) { r = (tid & 31) + 32 * (e % MT); k = (tid >> 5) + 8 * (e / MT); }
+      else { r = (tid >> 4) + 16 * (e % (2 * MT)); k = (tid & 15) + 16 * (e / (2 * MT)); }
+      if (e < nel) Ws[r * KP + k] = tmp[j];
+    }
+  }
+  if (MODE != 0) {
+    for (int i = tid; i < Kpad; i += P4_NT) {
+      f32x4 p = {0.f, 0.f, 0.f, 0.f};
+      if (i < K) {
+        p.x = a.ps1 ? a.ps1[i] : 1.f;
+        p.y = a.ph1 ? a.ph1[i] : 0.f;
+        p.z = a.ps2 ? a.ps2[i] : 1.f;
+        p.w = a.ph2 ? a.ph2[i] : 0.f;
+      }
+      Ps[i] = p;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                    // raw barrier: the operand prefetch stays in flight
+
+  // accumulators start at the bias of their output row (forward), so the epilogue has no per-row loads
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = mBase + 32 * m + p4_row32(i, half);
+      const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[m][q][i] = b0;
+    }
+
+  const int KS = Kpad >> 1;                        // k-steps (2 channels each), a multiple of PD
+  const int KSr = (K + 1) >> 1;                    // k-steps that hold real channels
+  // Software pipeline, pinned with scheduling barriers.  Step ks: start the LDS reads of step ks+1 (A fragment, affine
+  // row; double-buffered by step parity), apply the affine to the operand loaded PD steps ago, run the MT*NQ MFMAs, then
+  // re-issue that operand buffer's load for step ks+PD (after the MFMAs: the buffer registers are dead by then, so the
+  // load lands in place).  Left to itself the compiler sinks all PD loads to the end of the unrolled body and waits for
+  // the first of them at the top of the next one — or, with the load ahead of the MFMAs, rotates the PD buffers through
+  // v_mov chains behind a vmcnt(0) (profiles/r02: matrix pipe 61 % busy at 256 -> 256 channels).
+  float avb[2][MT];
+  f32x4 pb[2] = {{1.f, 0.f, 1.f, 0.f}, {1.f, 0.f, 1.f, 0.f}};
+#pragma unroll
+  for (int m = 0; m < MT; ++m) avb[0][m] = Ws[(32 * m + l31) * KP + half];
+  if (MODE != 0) pb[0] = Ps[half];
+  for (int base = 0; base < KS; base += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int ks = base + u;
+      const int cur = u & 1, nxt = cur ^ 1;                              // PD is even: the parity survives the back edge
+      const int kn = 2 * (ks + 1) + half;                                // last step: reads the LDS pad, never used
+#pragma unroll
+      for (int m = 0; m < MT; ++m) avb[nxt][m] = Ws[(32 * m + l31) * KP + kn];
+      if (MODE != 0) pb[nxt] = Ps[kn];
+      vq b = buf1[u];
+      if (MODE != 0) {
+        const f32x4 p = pb[cur];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          float v = fmaf(b[q], p.x, p.y);
+          if constexpr (MODE == 2) v += fmaf(buf2[u][q], p.z, p.w);
+          b[q] = fmaxf(v, lo);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(avb[cur][m], b[q], acc[m][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // past K: the scalar offset jumps out of the buffer's range (zeros, no traffic: the bounds check covers it)
+      const int sn = ks + PD < KSr ? 2 * (ks + PD) * L4 : P4_OOB;
+      buf1[u] = p4_load<NQ>(r1, voff, sn);
+      if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, sn);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();                                 // every wave is done with Ws / Ps: LDS is reused below
+
+  const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, wlive, pok};
+  p4_epilogue<MT, NQ, EPI, false>(a, acc, lds, tile);
+}
+
+
+// ---- K-C, GEMM form with three-term bf16 products ("pwg") ----------------------------------------------------------
+// For convs wide on both sides (the fp32 MFMA form is bound by the matrix pipe: 85 TF of 157 at 256 -> 256) the product
+// runs as six v_mfma_f32_32x32x16_bf16 per 16 channels on the exact three-way bf16 split of both operands (common.h).
+// The split costs ~5 VALU operations per value, so it must not be repeated per output-row block the way k_pw4 re-reads
+// its B operand: here a workgroup owns 128 output rows x 128 positions, its four waves hold 32 rows each of the SAME
+// position tile, and both operand tiles of a 32-channel chunk are split once by the thread that loaded them and shared
+// through LDS — rows of 32 bf16 (+16 B pad: conflict-free 16-byte fragment reads) per term, k contiguous.  The loader
+// thread holds a 4 x 4 register block (4 channels x its lane's 4 positions; for W^T 4 k x 4 rows), so the k-contiguous
+// image is written with 8-byte stores and no transposed reads are needed; position sub-tile q is again {4j + q}: the
+// accumulators have k_pw4's layout and the epilogue is shared (p4_epilogue, OWNROWS).
+constexpr int PG_KC = 32, PG_RB = PG_KC * 2 + 16, PG_T = 128;
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
+  typedef VQ<4>::T vq;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* Ab = reinterpret_cast<char*>(lds);                               // [3][128 rows][RB]
+  char* Bb = Ab + 3 * PG_T * PG_RB;                                      // [3][128 position slots][RB]
+  f32x4* Ps = reinterpret_cast<f32x4*>(Bb + 3 * PG_T * PG_RB);           // [Kpad] (s1, h1, s2, h2)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ngrp = a.WT;
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int cz = slot % a.cc;
+  const int grp = (slot / a.cc) * 8 + xcd;
+  if (grp >= ngrp) return;
+  const int mBase0 = cz * PG_T, mBase = mBase0 + 32 * wave;
+  const int K = a.K, M = a.M, L = a.L, Kpad = a.Kpad;
+  const int g0 = grp * 128;
+  const int n = g0 / L;
+  int pos = g0 - n * L + l31 * 4;
+  int ds = 0;
+  while (pos >= L) { pos -= L; ++ds; }
+  const bool pok = n + ds < a.n;
+  const int L4 = L * 4;
+  const int nrem = a.n - n < a.span ? a.n - n : a.span;
+  const __amdgpu_buffer_rsrc_t r1 = p4_rsrc(a.b1 + (size_t)n * K * L, nrem * K * L4);
+  const __amdgpu_buffer_rsrc_t r2 = p4_rsrc((MODE == 2 ? a.b2 : a.b1) + (size_t)n * K * L, MODE == 2 ? nrem * K * L4 : 0);
+  // loader roles.  B: channels 4*cg .. 4*cg+3 of the chunk (cg = tid / 32) at the lane's own position quad.
+  const int cg = tid >> 5;
+  const int voffB = pok ? ds * K * L4 + pos * 4 : P4_OOB;
+  // A, k contiguous in memory (forward): rows (tid / 8) + 32*i, k = 4*(tid % 8) ..+3;  m contiguous (data gradient: W^T):
+  // k = 4*(tid / 32) + e, rows 4*(tid % 32) ..+3
+  constexpr bool mfast = EPI == 1;                 // data gradient: A = W^T, m contiguous in memory
+  f32x4 aw[4];
+  vq bwA[4], bwB[4], bw2A[MODE == 2 ? 4 : 1], bw2B[MODE == 2 ? 4 : 1];     // two chunks of B in flight (ping-pong sets)
+  auto issueB = [&](int ch0, vq (&bw)[4], vq (&bw2)[MODE == 2 ? 4 : 1]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = ch0 + 4 * cg + e;                 // per half-wave: the channel goes into the vector offset
+      const int vo = c < K ? voffB + c * L4 : P4_OOB;
+      bw[e] = p4_load<4>(r1, vo, 0);
+      if constexpr (MODE == 2) bw2[e] = p4_load<4>(r2, vo, 0);
+    }
+  };
+  // weights through a buffer resource too: rows / channels past the matrix are out-of-range offsets (zeros), no branches
+  const __amdgpu_buffer_rsrc_t rw = p4_rsrc(a.w, M * K * 4);
+  const int offA0 = mfast ? (4 * cg * a.w_ldk + mBase0 + 4 * l31) * 4 : ((mBase0 + (tid >> 3)) * a.w_ldm + 4 * (tid & 7)) * 4;
+  const int stepE = mfast ? a.w_ldk * 4 : 32 * a.w_ldm * 4;             // between this thread's four loads
+  const int stepC = mfast ? a.w_ldk * 4 : 4;                            // per channel of chunk advance
+  const int kA = mfast ? 4 * cg : 4 * (tid & 7), mA = mfast ? mBase0 + 4 * l31 : mBase0 + (tid >> 3);
+  auto issueA = [&](int ch0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = (kA + ch0 + (mfast ? e : 0) < K) & (mA + (mfast ? 0 : 32 * e) < M);
+      aw[e] = p4_load<4>(rw, ok ? offA0 + e * stepE + ch0 * stepC : P4_OOB, 0);
+    }
+  };
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  auto put = [&](char* base, float v0, float v1, float v2, float v3) {     // four consecutive k of one row -> 8 B per term
+    unsigned p0, p1, p2, q0, q1, q2;
+    b3_split(v0, v1, p0, p1, p2);
+    b3_split(v2, v3, q0, q1, q2);
+    *reinterpret_cast<u32x2v*>(base) = u32x2v{p0, q0};
+    *reinterpret_cast<u32x2v*>(base + PG_T * PG_RB) = u32x2v{p1, q1};
+    *reinterpret_cast<u32x2v*>(base + 2 * PG_T * PG_RB) = u32x2v{p2, q2};
+  };
+  auto commit = [&](int ch0, vq (&bw)[4], vq (&bw2)[MODE == 2 ? 4 : 1]) {
+    if (mfast) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) put(Ab + (4 * l31 + rr) * PG_RB + cg * 8, aw[0][rr], aw[1][rr], aw[2][rr], aw[3][rr]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) put(Ab + ((tid >> 3) + 32 * e) * PG_RB + (tid & 7) * 8, aw[e].x, aw[e].y, aw[e].z, aw[e].w);
+    }
+    f32x4 pr[4];
+    if (MODE != 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pr[e] = Ps[ch0 + 4 * cg + e];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = bw[e][q];
+        if (MODE != 0) {
+          x = fmaf(x, pr[e].x, pr[e].y);
+          if constexpr (MODE == 2) x += fmaf(bw2[e][q], pr[e].z, pr[e].w);
+          x = fmaxf(x, lo);
+        }
+        v[e] = x;
+      }
+      put(Bb + (32 * q + l31) * PG_RB + cg * 8, v[0], v[1], v[2], v[3]);
+    }
+  };
+
+  if (MODE != 0) {                                 // (before the operand loads: its own loads end in a vmcnt(0))
+    for (int i = tid; i < Kpad; i += P4_NT) {
+      f32x4 p = {0.f, 0.f, 0.f, 0.f};
+      if (i < K) {
+        p.x = a.ps1 ? a.ps1[i] : 1.f;
+        p.y = a.ph1 ? a.ph1[i] : 0.f;
+        p.z = a.ps2 ? a.ps2[i] : 1.f;
+        p.w = a.ph2 ? a.ph2[i] : 0.f;
+      }
+      Ps[i] = p;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  issueA(0);
+  issueB(0, bwA, bw2A);
+  issueB(PG_KC, bwB, bw2B);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 acc[1][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = mBase + p4_row32(i, half);
+    const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[0][q][i] = b0;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                    // Ps visible (raw barrier: the operand loads stay in flight)
+  const char* Af = Ab + (32 * wave + l31) * PG_RB + 16 * half;
+  const char* Bf = Bb + l31 * PG_RB + 16 * half;
+  auto chunk = [&](int ch0, vq (&bw)[4], vq (&bw2)[MODE == 2 ? 4 : 1]) {
+    commit(ch0, bw, bw2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issueA(ch0 + PG_KC);                           // (past K: zeros)
+    issueB(ch0 + 2 * PG_KC, bw, bw2);              // this set is free again: two chunks ahead
+    __builtin_amdgcn_sched_barrier(0);             // pinned here, in this order: the next commit's vmcnt leaves this set in flight
+#pragma unroll
+    for (int ks = 0; ks < PG_KC / 16; ++ks) {
+      bf16x8 af[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        af[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Af + t * PG_T * PG_RB + 32 * ks));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bf16x8 bf[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          bf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Bf + (t * PG_T + 32 * q) * PG_RB + 32 * ks));
+        f32x16 c = acc[0][q];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], c, 0, 0, 0);
+        acc[0][q] = c;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // raw barrier: the loads in flight stay in flight
+  };
+  // (pairs in the loop, an odd last chunk outside it: with the second call conditional inside the loop the compiler
+  // must allow for a first-call -> first-call path, on which the set just refilled is the next one consumed: vmcnt(0))
+  int ch0 = 0;
+  for (; ch0 + PG_KC < Kpad; ch0 += 2 * PG_KC) {
+    chunk(ch0, bwA, bw2A);
+    chunk(ch0 + PG_KC, bwB, bw2B);
+  }
+  if (ch0 < Kpad) chunk(ch0, bwA, bw2A);
+  __syncthreads();                                 // drains the read-ahead loads before LDS is reused
+  const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, true, pok};
+  p4_epilogue<1, 4, EPI, true>(a, acc, lds, tile);
+}
+
+int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128;
+
+struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad, gemm; size_t lds; unsigned grid; };
 
 bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
   if (L % 2) return false;
@@ -581,9 +622,6 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
   if (MT * NQ > 8) MT = 4;
   int PD = NQ == 4 ? 8 : 16;
   if (g_p4_pd == 8 || g_p4_pd == 16) PD = g_p4_pd;
-  // three-term bf16 products where the conv is bound by the matrix pipe (wide on both sides); 16-channel k-steps
-  const bool b3 = (g_p4_b3 & (1 << epi)) && NQ == 4 && MT <= 2 && K % 16 == 0 && K >= g_p4_b3min && M >= g_p4_b3min;
-  if (b3) PD = 8;
   // samples a wave's 32*NQ-position tile can touch; its buffer resources span that many planes (32-bit offsets)
   const int span = (32 * NQ + L - 1) / L + 1;
   if ((long)K * L * 4 * span >= (1L << 31) - 64 || (long)M * L * 4 * span >= (1L << 31) - 64) return false;
@@ -593,42 +631,26 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
   p->span = span;
   p->WT = (int)(((long)n * L + 32 * NQ - 1) / (32 * NQ));
   p->ngrp = (p->WT + 3) / 4;
-  p->b3 = b3 ? 1 : 0;
-  p->Kpad = b3 ? (K + 31) / 32 * 32 : (K + 2 * PD - 1) / (2 * PD) * (2 * PD);
+  p->Kpad = (K + 2 * PD - 1) / (2 * PD) * (2 * PD);
   size_t f = (size_t)((32 * MT * (p->Kpad + 1) + 2 + 3) & ~3) + (size_t)4 * (p->Kpad + 2);   // + the pipeline's read-ahead pad
-  if (b3) {
-    const size_t ksi = (size_t)(p->Kpad / 16 + 1);
-    f = 3 * ksi * 32 * MT * 8 + 4 * 16 * ksi;      // three bf16 images in fragment order + the affine rows
-  }
   const size_t fe = (size_t)4 * 3 * 32 * 36 + (size_t)4 * MT * 32 * 4 + (size_t)MT * 32 * 4;    // epilogue image
   if (f < fe) f = fe;
   p->lds = f * sizeof(float);
+  p->gemm = 0;
+  if ((g_p4_gemm & (1 << epi)) && L % 4 == 0 && K % 4 == 0 && M % 4 == 0 && K >= g_p4_gmin && M > 64 && L >= g_p4_gminl) {
+    p->gemm = 1; p->MT = 1; p->NQ = 4;
+    p->cc = (M + PG_T - 1) / PG_T;
+    p->span = (128 + L - 1) / L + 1;               // (the tiny-plane rule above may have chosen 64-position tiles)
+    p->WT = (int)(((long)n * L + 127) / 128);
+    p->ngrp = p->WT;                               // one position tile per workgroup
+    p->Kpad = (K + PG_KC - 1) / PG_KC * PG_KC;
+    size_t b = (size_t)2 * 3 * PG_T * PG_RB + (size_t)p->Kpad * 16;
+    const size_t be = ((size_t)4 * 3 * 32 * 36 + 4 * 32 * 4 + 4 * 32 * 4) * sizeof(float);   // epilogue image, per-wave rows
+    p->lds = b < be ? be : b;
+  }
   if (p->lds > 160 * 1024) return false;
   p->grid = (unsigned)((p->ngrp + 7) / 8 * 8 * p->cc);
   return true;
-}
-
-template <int MT, int MODE, int EPI, int PB = 1>
-void p4_launch_b3(const Pw4Args& a, const P4Plan& p, hipStream_t st) {
-  static bool raised = false;                      // > 64 KB of dynamic LDS: raised once per instantiation
-  if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw4<MT, 4, MODE, 8, EPI, PB>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    raised = true;
-  }
-  hipLaunchKernelGGL((k_pw4<MT, 4, MODE, 8, EPI, PB>), dim3(p.grid), dim3(P4_NT), p.lds, st, a);
-}
-
-template <int MT>
-void p4_launch_b3m(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStream_t st) {
-  if (epi == 0) {
-    if (mode == 0) p4_launch_b3<MT, 0, 0>(a, p, st);
-    else if (mode == 1) p4_launch_b3<MT, 1, 0>(a, p, st);
-    else p4_launch_b3<MT, 2, 0>(a, p, st);
-  } else {
-    if (mode == 0) p4_launch_b3<MT, 0, 1>(a, p, st);
-    else p4_launch_b3<MT, 2, 1>(a, p, st);
-  }
 }
 
 template <int MT, int NQ, int PD>
@@ -647,9 +669,25 @@ void p4_launch_cfg(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStre
 template <int PD>
 bool p4_launch_pd(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStream_t st) {
   const int key = p.MT * 10 + p.NQ;
-  if (p.b3) {
-    if (p.MT == 1) p4_launch_b3m<1>(a, mode, epi, p, st);
-    else p4_launch_b3m<2>(a, mode, epi, p, st);
+  if (p.gemm) {
+    static bool raised = false;                    // 64 KB+ of dynamic LDS
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pwg<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pwg<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pwg<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pwg<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pwg<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      raised = true;
+    }
+    const dim3 grid(p.grid), blk(P4_NT);
+    if (epi == 0) {
+      if (mode == 0) hipLaunchKernelGGL((k_pwg<0, 0>), grid, blk, p.lds, st, a);
+      else if (mode == 1) hipLaunchKernelGGL((k_pwg<1, 0>), grid, blk, p.lds, st, a);
+      else hipLaunchKernelGGL((k_pwg<2, 0>), grid, blk, p.lds, st, a);
+    } else {
+      if (mode == 0) hipLaunchKernelGGL((k_pwg<0, 1>), grid, blk, p.lds, st, a);
+      else hipLaunchKernelGGL((k_pwg<2, 1>), grid, blk, p.lds, st, a);
+    }
     return true;
   }
   switch (key) {
@@ -671,15 +709,16 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_tuning(int key, int value) {
   if (key == 0) g_p4_nq = value;
   else if (key == 1) g_p4_mt = value;
   else if (key == 2) g_p4_pd = value;
-  else if (key == 3) g_p4_b3 = value;
-  else if (key == 4) g_p4_b3min = value;
+  else if (key == 3) g_p4_gemm = value;
+  else if (key == 4) g_p4_gmin = value;
+  else if (key == 5) g_p4_gminl = value;
   else return DSGCN_EINVAL;
   return 0;
 }
 
-__attribute__((visibility("hidden"))) int dsgcn_p4_groups(int n, int K, int M, int L) {
+__attribute__((visibility("hidden"))) int dsgcn_p4_groups(int n, int K, int M, int L, int epi) {
   P4Plan p;
-  return p4_plan(n, K, M, L, &p) ? p.ngrp : 0;
+  return p4_plan(n, K, M, L, &p, epi) ? p.ngrp : 0;
 }
 
 __attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const float* s1, const float* h1,

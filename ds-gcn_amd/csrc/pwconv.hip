@@ -1104,7 +1104,7 @@ int g_pw4 = 15;           // bit 0: wide-load forward (pw4.hip), bit 1: wide-loa
 
 // pw4.hip (internal linkage across the library's objects, not exported)
 __attribute__((visibility("hidden"))) int dsgcn_p4_tuning(int key, int value);
-__attribute__((visibility("hidden"))) int dsgcn_p4_groups(int n, int K, int M, int L);
+__attribute__((visibility("hidden"))) int dsgcn_p4_groups(int n, int K, int M, int L, int epi);
 __attribute__((visibility("hidden"))) int dsgcn_wg2_tuning(int key, int value);
 __attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const float* s1, const float* h1,
                                                         const float* x2, const float* s2, const float* h2, int relu,
@@ -1137,7 +1137,7 @@ static int pw_conv_rows(int n, int K, int M, int T, int V, int stride, int which
   const int Tout = (T + stride - 1) / stride;
   const int L = Tout * V;
   if (stride == 1 && (g_pw4 & which)) {
-    const int g = dsgcn_p4_groups(n, K, M, L);
+    const int g = dsgcn_p4_groups(n, K, M, L, which == 2 ? 1 : 0);
     if (g > 0) return g;
   }
   return n * ((L + 4 * 32 - 1) / (4 * 32));
@@ -1152,8 +1152,8 @@ int dsgcn_pwconv_tuning(int key, int value) {
   if (key == 3) { g_pw4 = value; return 0; }
   if (key >= 4 && key <= 6) return dsgcn_p4_tuning(key - 4, value);
   if (key >= 7 && key <= 9) return dsgcn_wg2_tuning(key - 7, value);
-  if (key >= 10 && key <= 11) return dsgcn_p4_tuning(key - 7, value);
-  if (key == 12) return dsgcn_wg2_tuning(3, value);
+  if (key >= 10 && key <= 12) return dsgcn_p4_tuning(key - 7, value);      // GEMM form: bits, min K, min plane
+  if (key == 13) return dsgcn_wg2_tuning(3, value);                        // weight gradient: bf16 terms on / off
   return DSGCN_EINVAL;
 }
 #endif

@@ -117,6 +117,11 @@ def _rand(g, *shape, scale=1.0):
     (2, 96, 40, 20, 17, 1, False, 'affine_relu'), # second input tile half empty (narrow wave roles), coco planes
     (2, 64, 24, 64, 25, 1, False, 'res_affine'),  # two input streams, 24 output rows
     (3, 64, 64, 64, 25, 1, False, 'affine_relu'),
+    # GEMM form with three-term bf16 products (csrc/pw4.hip k_pwg; weight gradient csrc/wgrad.hip B3): wide on both sides
+    (3, 128, 160, 12, 25, 1, False, 'res_affine'),   # 900 positions: tiles straddle samples, last tile partly empty, 2 row blocks
+    (5, 96, 256, 8, 17, 1, False, 'affine_relu'),    # K = 96: odd chunk count (ping-pong tail), 136-position planes
+    (2, 64, 128, 8, 16, 1, False, 'plain'),          # smallest eligible plane (128), K = 64
+    (2, 256, 132, 16, 25, 1, True, 'res_plain'),     # 132 rows: second row block nearly empty; global-joint column beside it
 ])
 def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
     g = torch.Generator().manual_seed(Ci * 7 + Co + T)

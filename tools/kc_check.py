@@ -1,15 +1,15 @@
 """K-C accuracy check: the three-term bf16 form (B3) and the fp32 MFMA form of the 1x1 conv forward / data gradient /
 weight gradient against an fp64 evaluation of the same inputs (relative L2 error of each: z, column sums, dx, dW, db,
-[dx2], [input sums]), through the lab library's tuning keys 10 (forward / data gradient bits) and 12 (weight gradient)."""
+[dx2], [input sums]), through the lab library's tuning keys 10 (GEMM form: forward / data gradient bits) and 13 (weight gradient)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dsgcn_amd import native
 lib = native.lab_lib(); dev = 'cuda'; st = torch.cuda.current_stream().cuda_stream
-n, V = 16, 25
+n, V = int(os.environ.get('KC_N', 16)), int(os.environ.get('KC_V', 25))
 SHAPES = [('pre5', 128, 48, 32, 0), ('post5', 48, 128, 32, 1), ('branch5', 128, 128, 32, 2), ('transf5', 128, 128, 32, 1),
           ('pre8', 256, 96, 16, 0), ('post8', 96, 256, 16, 1), ('branch8', 256, 256, 16, 2), ('transf8', 256, 256, 16, 1),
-          ('odd', 112, 200, 7, 2)]
+          ('odd', 112, 200, 7, 2), ('odd2', 70, 130, 12, 1), ('down5', 64, 128, 32, 0), ('proj', 256, 96, 1, 0)]
 P = lambda t: None if t is None else t.data_ptr()
 
 
@@ -38,7 +38,7 @@ for name, Ci, Co, T, mode in SHAPES:
     zr = torch.einsum('oc,nctv->notv', w.double(), v) + b.double().view(1, -1, 1, 1)
     out = {}
     for b3 in (0, 1):
-        assert lib.dsgcn_pwconv_tuning(10, 3 * b3) == 0 and lib.dsgcn_pwconv_tuning(12, b3) == 0
+        assert lib.dsgcn_pwconv_tuning(12, int(os.environ.get('KC_MINL', 128))) == 0 and lib.dsgcn_pwconv_tuning(10, 3 * b3) == 0 and lib.dsgcn_pwconv_tuning(13, b3) == 0
         z = torch.empty(n, Co, T, V, device=dev)
         part = torch.empty(lib.dsgcn_pwconv_partial_rows(n, Ci, Co, T, V, 1, 0), Co, 2, device=dev)
         assert lib.dsgcn_pwconv_fwd(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(w), P(b), P(z), None, P(part),
