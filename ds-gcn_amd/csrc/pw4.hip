@@ -426,14 +426,18 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
 // thread holds a 4 x 4 register block (4 channels x its lane's 4 positions; for W^T 4 k x 4 rows), so the k-contiguous
 // image is written with 8-byte stores and no transposed reads are needed; position sub-tile q is again {4j + q}: the
 // accumulators have k_pw4's layout and the epilogue is shared (p4_epilogue, OWNROWS).
-constexpr int PG_KC = 32, PG_RB = PG_KC * 2 + 16, PG_T = 128;
+constexpr int PG_KC = 32, PG_RB = PG_KC * 2 + 16, PG_T = 128, PG_TAM = 144;
 
 template <int MODE, int EPI>
 __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
   typedef VQ<4>::T vq;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* Ab = reinterpret_cast<char*>(lds);                               // [3][128 rows][RB]
-  char* Bb = Ab + 3 * PG_T * PG_RB;                                      // [3][128 position slots][RB]
+  // W^T arrives four consecutive ROWS per loader thread: written in row order the 8-byte stores of a wave would sit 320 B
+  // apart (16-way bank conflicts: profiles/r02 counters); row 4a + rr is therefore kept at LDS row 36*rr + a (lanes 80 B
+  // apart on the store side, and the 16-byte fragment reads of a wave's 32 rows — 4 row groups x 8 — stay conflict-free)
+  constexpr int TA = EPI == 1 ? PG_TAM : PG_T;                           // A rows per term
+  char* Bb = Ab + 3 * TA * PG_RB;                                        // [3][128 position slots][RB]
   f32x4* Ps = reinterpret_cast<f32x4*>(Bb + 3 * PG_T * PG_RB);           // [Kpad] (s1, h1, s2, h2)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -486,21 +490,21 @@ __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
     }
   };
   const float lo = a.relu ? 0.f : -__builtin_inff();
-  auto put = [&](char* base, float v0, float v1, float v2, float v3) {     // four consecutive k of one row -> 8 B per term
+  auto put = [&](char* base, int tstride, float v0, float v1, float v2, float v3) {   // four consecutive k of one row -> 8 B per term
     unsigned p0, p1, p2, q0, q1, q2;
     b3_split(v0, v1, p0, p1, p2);
     b3_split(v2, v3, q0, q1, q2);
     *reinterpret_cast<u32x2v*>(base) = u32x2v{p0, q0};
-    *reinterpret_cast<u32x2v*>(base + PG_T * PG_RB) = u32x2v{p1, q1};
-    *reinterpret_cast<u32x2v*>(base + 2 * PG_T * PG_RB) = u32x2v{p2, q2};
+    *reinterpret_cast<u32x2v*>(base + tstride) = u32x2v{p1, q1};
+    *reinterpret_cast<u32x2v*>(base + 2 * tstride) = u32x2v{p2, q2};
   };
   auto commit = [&](int ch0, vq (&bw)[4], vq (&bw2)[MODE == 2 ? 4 : 1]) {
     if (mfast) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) put(Ab + (4 * l31 + rr) * PG_RB + cg * 8, aw[0][rr], aw[1][rr], aw[2][rr], aw[3][rr]);
+      for (int rr = 0; rr < 4; ++rr) put(Ab + (36 * rr + l31) * PG_RB + cg * 8, TA * PG_RB, aw[0][rr], aw[1][rr], aw[2][rr], aw[3][rr]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) put(Ab + ((tid >> 3) + 32 * e) * PG_RB + (tid & 7) * 8, aw[e].x, aw[e].y, aw[e].z, aw[e].w);
+      for (int e = 0; e < 4; ++e) put(Ab + ((tid >> 3) + 32 * e) * PG_RB + (tid & 7) * 8, TA * PG_RB, aw[e].x, aw[e].y, aw[e].z, aw[e].w);
     }
     f32x4 pr[4];
     if (MODE != 0) {
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
         }
         v[e] = x;
       }
-      put(Bb + (32 * q + l31) * PG_RB + cg * 8, v[0], v[1], v[2], v[3]);
+      put(Bb + (32 * q + l31) * PG_RB + cg * 8, PG_T * PG_RB, v[0], v[1], v[2], v[3]);
     }
   };
 
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // Ps visible (raw barrier: the operand loads stay in flight)
-  const char* Af = Ab + (32 * wave + l31) * PG_RB + 16 * half;
+  const char* Af = Ab + (mfast ? 36 * (l31 & 3) + 8 * wave + (l31 >> 2) : 32 * wave + l31) * PG_RB + 16 * half;
   const char* Bf = Bb + l31 * PG_RB + 16 * half;
   auto chunk = [&](int ch0, vq (&bw)[4], vq (&bw2)[MODE == 2 ? 4 : 1]) {
     commit(ch0, bw, bw2);
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
       bf16x8 af[3];
 #pragma unroll
       for (int t = 0; t < 3; ++t)
-        af[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Af + t * PG_T * PG_RB + 32 * ks));
+        af[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Af + t * TA * PG_RB + 32 * ks));
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         bf16x8 bf[3];
@@ -644,7 +648,7 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
     p->WT = (int)(((long)n * L + 127) / 128);
     p->ngrp = p->WT;                               // one position tile per workgroup
     p->Kpad = (K + PG_KC - 1) / PG_KC * PG_KC;
-    size_t b = (size_t)2 * 3 * PG_T * PG_RB + (size_t)p->Kpad * 16;
+    size_t b = (size_t)3 * ((epi ? PG_TAM : PG_T) + PG_T) * PG_RB + (size_t)p->Kpad * 16;
     const size_t be = ((size_t)4 * 3 * 32 * 36 + 4 * 32 * 4 + 4 * 32 * 4) * sizeof(float);   // epilogue image, per-wave rows
     p->lds = b < be ? be : b;
   }
