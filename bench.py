@@ -153,12 +153,17 @@ def measure_ka_roofline(device, n, reps=20):
 
 
 MFMA_F32_PEAK_TF = 157.3        # MI355X_MICROARCH.md: f32-input MFMA = vector f32 rate
+MFMA_BF16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def measure_kc_roofline(device, n, reps=20):
     """K-C (1x1 channel mix) forward / data gradient / weight gradient through the C ABI, HIP-event timed, on the two
     shapes that bracket the model: 64->64 at T=64 (16 FLOP/B: HBM-bound) and 256->256 at T=16 (64 FLOP/B: MFMA-bound).
-    Algorithmic bytes: inputs read once + outputs written once; flops 2*Ci*Co per position."""
+    Algorithmic bytes: inputs read once + outputs written once; flops 2*Ci*Co per position (fp32 products: `achieved` is
+    priced against the fp32 MFMA peak whatever instruction carries them).  The wide shape runs on the exact three-term
+    bf16 split of both operands (csrc/common.h b3_split: six v_mfma_f32_32x32x16_bf16 per 16 channels, fp32 accumulate,
+    fp32-class error: tools/kc_check.py); `mfma_util` there is the matrix pipe's own utilisation — six issued bf16
+    products per algorithmic one against the dense bf16 peak."""
     from dsgcn_amd import native
     lib = native.lib()
     st = torch.cuda.current_stream().cuda_stream
@@ -220,12 +225,16 @@ def measure_kc_roofline(device, n, reps=20):
             us = e0.elapsed_time(e1) / reps * 1e3
             gbs, tf = nbytes / us / 1e3, nprod * flops / us / 1e6
             hbm_bound = Ci <= 64
-            out[f'k_pwconv_{name}_{Ci}x{Co}'] = dict(
+            row = dict(
                 bound='hbm' if hbm_bound else 'mfma', achieved=round(gbs if hbm_bound else tf, 1),
                 peak=HBM_PEAK_GBS if hbm_bound else MFMA_F32_PEAK_TF, unit='GB/s' if hbm_bound else 'TFLOP/s',
                 frac=round((gbs / HBM_PEAK_GBS) if hbm_bound else (tf / MFMA_F32_PEAK_TF), 4), traffic=None,
                 avg_launch_us=round(us, 2), hbm_gbs=round(gbs, 1), mfma_tflops=round(tf, 1),
                 mfma_util=round(tf / MFMA_F32_PEAK_TF, 4))
+            if not hbm_bound:
+                row.update(arith='fp32 products as 6 bf16 MFMA terms of the exact 3-way bf16 split, fp32 accumulate',
+                           issued_bf16_tflops=round(6 * tf, 1), mfma_util=round(6 * tf / MFMA_BF16_PEAK_TF, 4))
+            out[f'k_pwconv_{name}_{Ci}x{Co}'] = row
     return out
 
 
