@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
 #pragma unroll
         for (int q = 0; q < NP4; ++q) {
           const int i = lane + q * 64;
-          if (i < c4) d4[i] = l4[i];
+          if (i < c4) __builtin_nontemporal_store(l4[i], &d4[i]);
         }
       }
       wave_lds_sync();
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
 #pragma unroll
       for (int q = 0; q < NP4; ++q) {
         const int i = lane + q * 64;
-        if (i < c4) d4[i] = l4[i];
+        if (i < c4) __builtin_nontemporal_store(l4[i], &d4[i]);
       }
     }
     sum_s = wave_sum(sum_s);
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(64 * NW) void k_aggregate_bwd_pair(const float* __r
 #pragma unroll
       for (int q = 0; q < NP4; ++q) {
         const int i = lane + q * 64;
-        if (i < c4) d4[i] = l4[i];
+        if (i < c4) __builtin_nontemporal_store(l4[i], &d4[i]);
       }
     }
     sum_s = wave_sum(sum_s);
