@@ -22,6 +22,7 @@ namespace {
 
 constexpr int P4_NT = 256;
 constexpr int P4_OOB = 0x7ffffff0;
+constexpr int P4_NT_STORE = 2;                   // cache-policy bits of the output stores: non-temporal (written once, read by a later launch)
 
 struct Pw4Args {
   const float* b1; const float* b2;                                        // B streams (n, K, L); b2 NULL unless MODE 2
@@ -62,9 +63,9 @@ __device__ __forceinline__ void p4_store(typename VQ<NQ>::T v, __amdgpu_buffer_r
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   if constexpr (NQ == 4) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, P4_NT_STORE);
   } else {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, P4_NT_STORE);
   }
 }
 
