@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int u = mfma_row(r, mk);
-          if (u < V) dA[u * V + mi] = accA[r];
+          if (u < V) __builtin_nontemporal_store(accA[r], &dA[u * V + mi]);
         }
       }
     } else {
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
 #pragma unroll
       for (int q = 0; q < NA; ++q) {
         const int i = lane + q * 64;
-        if (i < V * V) dA[i] = ldsA[i];
+        if (i < V * V) __builtin_nontemporal_store(ldsA[i], &dA[i]);
       }
     }
     {
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(64 * NW) void k_aggregate_bwd_pair(const float* __r
         if (u < V) {
           float v = accA[r];
           for (int w = 0; w < NW - 1; ++w) v += ldsD[w * V * V + u * V + mi];
-          dA[u * V + mi] = v;
+          __builtin_nontemporal_store(v, &dA[u * V + mi]);
         }
       }
     }
