@@ -191,8 +191,12 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd(const float* __restrict__ 
 // stride and keeps the NEXT item's P plane and adjacency in flight (global -> VGPR) while the matrix core
 // works on the current one, so HBM requests, MFMA and stores of neighbouring items overlap inside one wave.
 // RW: the exact row count of every work item when the shape makes it one (loop bounds and tail guards fold), 0 = runtime
+// KA_WPB independent waves share one workgroup (its LDS cut into per-wave slices, no workgroup barrier anywhere): the
+// launch dispatches a quarter of the workgroups.
+constexpr int KA_WPB = 4;
+
 template <int V, int CH, int RW = 0>
-__global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restrict__ zp,
+__global__ __launch_bounds__(64 * KA_WPB) void k_aggregate_fwd_pipe(const float* __restrict__ zp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
                                                            const float* __restrict__ ahat, float* __restrict__ y,
@@ -201,9 +205,10 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
   constexpr int NP4 = (CH * V / 4 + 63) / 64;     // float4 loads per lane for a full CH-frame chunk
   constexpr int NA = (V * V + 63) / 64;           // dword loads per lane for the adjacency
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* ldsP = lds;
-  float* ldsA = lds + CH * V;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* ldsP = lds + wv * (CH * V + V * V);
+  float* ldsA = ldsP + CH * V;
   const int mi = lane & 31, mk = lane >> 5;
   const int mic = mi < V ? mi : V - 1;
   f32x4 pre[NP4];
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
     }
   };
 
-  long item = blockIdx.x;
+  long item = (long)blockIdx.x * KA_WPB + wv;
   if (item < items) issue(item);
   while (item < items) {
     const long unit = item / chunks;
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(64) void k_aggregate_fwd_pipe(const float* __restri
         if (i < V * V) ldsA[i] = prea[q];
       }
     }
-    const long next = item + gridDim.x;
+    const long next = item + (long)gridDim.x * KA_WPB;
     if (next < items) issue(next);
     wave_lds_sync();
     float b[KS];
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd(const float* __restrict__ 
 // the matrix core.
 // TE: the exact frame count when it is one of the model's (32 / 16: loop bounds and tail guards fold), 0 = runtime T <= TM
 template <int V, bool DA_LDS, int TM, int TE = 0>
-__global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restrict__ zp,
+__global__ __launch_bounds__(64 * KA_WPB) void k_aggregate_bwd_pipe(const float* __restrict__ zp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
                                                            const float* __restrict__ ahat,
@@ -460,10 +465,11 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
   constexpr int NP4 = (TM * V / 4 + 63) / 64;
   constexpr int NA = (V * V + 63) / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* ldsZ = lds;
-  float* ldsG = lds + (TE ? TE : T) * V;          // LDS sized by T (T*V % 4 == 0): short layers keep more waves resident
-  float* ldsA = lds + 2 * (TE ? TE : T) * V;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* ldsZ = lds + wv * (2 * (TE ? TE : T) * V + V * V);
+  float* ldsG = ldsZ + (TE ? TE : T) * V;         // LDS sized by T (T*V % 4 == 0): short layers keep more waves resident
+  float* ldsA = ldsZ + 2 * (TE ? TE : T) * V;
   const int mi = lane & 31, mk = lane >> 5;
   const int mic = mi < V ? mi : V - 1;
   const int rows = TE ? TE : T;       // T <= TM
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
     }
   };
 
-  long unit = blockIdx.x;
+  long unit = (long)blockIdx.x * KA_WPB + wv;
   if (unit < units) issue(unit);
   while (unit < units) {
     const int c = (int)(unit % KC);
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(64) void k_aggregate_bwd_pipe(const float* __restri
         if (i < V * V) ldsA[i] = prea[q];
       }
     }
-    const long next = unit + gridDim.x;
+    const long next = unit + (long)gridDim.x * KA_WPB;
     if (next < units) issue(next);
     wave_lds_sync();
     float bt[KS];
@@ -839,19 +845,19 @@ int launch_fwd(const float* zp, const float* scale, const float* shift, int relu
     const long per = (items + waves - 1) / waves;
     const long g = (items + per - 1) / per;
     if (half && T % 32 == 0)
-      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 32, 32>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 32, 32>), dim3((unsigned)((g + KA_WPB - 1) / KA_WPB)), dim3(64 * KA_WPB), lds * KA_WPB, st, zp, scale, shift, relu,
                          ahat, y, KC, T, chunks, items, g_fwd_direct);
     else if (half)
-      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 32>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 32>), dim3((unsigned)((g + KA_WPB - 1) / KA_WPB)), dim3(64 * KA_WPB), lds * KA_WPB, st, zp, scale, shift, relu,
                          ahat, y, KC, T, chunks, items, g_fwd_direct);
     else if (T == 32)
-      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 64, 32>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 64, 32>), dim3((unsigned)((g + KA_WPB - 1) / KA_WPB)), dim3(64 * KA_WPB), lds * KA_WPB, st, zp, scale, shift, relu,
                          ahat, y, KC, T, chunks, items, g_fwd_direct);
     else if (T == 16)
-      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 64, 16>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 64, 16>), dim3((unsigned)((g + KA_WPB - 1) / KA_WPB)), dim3(64 * KA_WPB), lds * KA_WPB, st, zp, scale, shift, relu,
                          ahat, y, KC, T, chunks, items, g_fwd_direct);
     else
-      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 64>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+      hipLaunchKernelGGL((k_aggregate_fwd_pipe<V, 64>), dim3((unsigned)((g + KA_WPB - 1) / KA_WPB)), dim3(64 * KA_WPB), lds * KA_WPB, st, zp, scale, shift, relu,
                          ahat, y, KC, T, chunks, items, g_fwd_direct);
   }
   DSGCN_LAUNCH_CHECK();
@@ -890,19 +896,19 @@ int launch_bwd(const float* zp, const float* scale, const float* shift, int relu
     const long per = (units + waves - 1) / waves;
     const long g = (units + per - 1) / per;
     if (T > 64)        // the long clips of BASELINE config 5 (V = 17, T = 100 / 50): four 32-frame tiles per unit
-      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 128>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift,
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 128>), dim3((unsigned)((g + KA_WPB - 1) / KA_WPB)), dim3(64 * KA_WPB), lds * KA_WPB, st, zp, scale, shift,
                          relu, ahat, dy, dzp, dahat, partial, KC, T, units);
     else if (g_bwd_da_lds)
-      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, true, 64>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, true, 64>), dim3((unsigned)((g + KA_WPB - 1) / KA_WPB)), dim3(64 * KA_WPB), lds * KA_WPB, st, zp, scale, shift, relu,
                          ahat, dy, dzp, dahat, partial, KC, T, units);
     else if (T == 32)
-      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 64, 32>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift,
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 64, 32>), dim3((unsigned)((g + KA_WPB - 1) / KA_WPB)), dim3(64 * KA_WPB), lds * KA_WPB, st, zp, scale, shift,
                          relu, ahat, dy, dzp, dahat, partial, KC, T, units);
     else if (T == 16)
-      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 64, 16>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift,
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 64, 16>), dim3((unsigned)((g + KA_WPB - 1) / KA_WPB)), dim3(64 * KA_WPB), lds * KA_WPB, st, zp, scale, shift,
                          relu, ahat, dy, dzp, dahat, partial, KC, T, units);
     else
-      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 64>), dim3((unsigned)g), dim3(64), lds, st, zp, scale, shift, relu,
+      hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 64>), dim3((unsigned)((g + KA_WPB - 1) / KA_WPB)), dim3(64 * KA_WPB), lds * KA_WPB, st, zp, scale, shift, relu,
                          ahat, dy, dzp, dahat, partial, KC, T, units);
   } else {
     hipLaunchKernelGGL((k_aggregate_bwd<V>), dim3((unsigned)units), dim3(64), lds, st, zp, scale, shift, relu, ahat,
