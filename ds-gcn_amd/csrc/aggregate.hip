@@ -892,7 +892,7 @@ int launch_bwd(const float* zp, const float* scale, const float* shift, int relu
                          relu, ahat, dy, dzp, dahat, partial, KC, T, units);
   } else if (vec && T <= 128 && g_bwd_variant == 0) {
     const size_t lds = (size_t)(2 * T * V + V * V) * sizeof(float);
-    int waves = g_pipe_waves_bwd > 0 ? g_pipe_waves_bwd : 2048;
+    int waves = g_pipe_waves_bwd > 0 ? g_pipe_waves_bwd : (T == 32 ? 3072 : 2048);      // tools/ka_variants.py
     const long per = (units + waves - 1) / waves;
     const long g = (units + per - 1) / per;
     if (T > 64)        // the long clips of BASELINE config 5 (V = 17, T = 100 / 50): four 32-frame tiles per unit

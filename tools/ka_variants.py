@@ -59,16 +59,14 @@ for KC, T in shapes:
     t = timeit(cp); line += f'| copy {t:6.1f}us {2*zp.numel()*4/t/1e3:6.0f}GB/s '
     for v, nm in ():
         t = timeit(mk(v)); line += f'| {nm} {t:6.1f}us {fb/t/1e3:6.0f}GB/s '
-    for w in (3072,):
-        for ch in (32,):
-            lib.dsgcn_set_tuning(0, w); lib.dsgcn_set_tuning(5, ch)
-            t = timeit(mk(0)); line += f'| p{w}c{ch} {t:5.1f}us {fb/t/1e3:5.0f} '
-    lib.dsgcn_set_tuning(5, 32)
+    for w in (3072, 4096, 6144):
+        lib.dsgcn_set_tuning(0, w); lib.dsgcn_set_tuning(5, 32)
+        t = timeit(mk(0)); line += f'| fwd w{w} {t:5.1f}us {fb/t/1e3:5.0f} '
     lib.dsgcn_set_tuning(0, 0)
-    for hr in (0, 1):
-      lib.dsgcn_set_tuning(7, hr)
-      for w in (1536,):
-        lib.dsgcn_set_tuning(8, w)
-        t = timeit(bwd); line += f'| h{hr}w{w} {t:5.1f}us {bb/t/1e3:5.0f}'
-    lib.dsgcn_set_tuning(8, 0); lib.dsgcn_set_tuning(7, 1)
+    for hr, ws in ((0, (2048, 3072, 4096)), (1, (1536, 2048, 3072))):
+        lib.dsgcn_set_tuning(7, hr)
+        for w in ws:
+            lib.dsgcn_set_tuning(8 if hr else 1, w)
+            t = timeit(bwd); line += f'| bwd {"pair" if hr else "pipe"} w{w} {t:5.1f}us {bb/t/1e3:5.0f}'
+    lib.dsgcn_set_tuning(8, 0); lib.dsgcn_set_tuning(1, 0); lib.dsgcn_set_tuning(7, 1)
     print(line, flush=True)
