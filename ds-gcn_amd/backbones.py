@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import kernels
 from .builder import BACKBONES
-from .gcn_units import dgphgcn1, unit_ctrgcn, unit_ctrhgcn, unit_gcn, flush_running_stats
+from .gcn_units import dggcn, dgphgcn1, unit_ctrgcn, unit_ctrhgcn, unit_gcn, flush_running_stats
 from .graph import Graph
 from .tcn_units import MSTCN, dgmstcn, msmlp, mstcn, unit_tcn
 
@@ -97,9 +97,12 @@ class DGBlock(_FusedBlock):
             raise NotImplementedError(f'tcn_type={tcn_type} is outside the DS-GCN hot path (SURVEY §8f)')
         gcn_type = gcn_kwargs.pop('type', 'dghgcn')
         assert gcn_type in ['dghgcn', 'dgphgcn', 'dgphgcn1', 'dggcn']
-        if gcn_type != 'dgphgcn1':
+        if gcn_type == 'dggcn':                      # the original DG-STGCN unit (dgstgcn.py:42-43)
+            self.gcn = dggcn(in_channels, out_channels, A, **gcn_kwargs)
+        elif gcn_type == 'dgphgcn1':
+            self.gcn = dgphgcn1(in_channels, out_channels, A, edge_type, node_type, **gcn_kwargs)
+        else:
             raise NotImplementedError(f'gcn_type={gcn_type} is outside the DS-GCN hot path (SURVEY §8f)')
-        self.gcn = dgphgcn1(in_channels, out_channels, A, edge_type, node_type, **gcn_kwargs)
         self.relu = nn.ReLU()
         self._set_residual(in_channels, out_channels, stride, residual)
 

@@ -226,6 +226,96 @@ class dgphgcn1(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
 
+class dggcn(nn.Module):
+    """The original DG-STGCN spatial unit (reference: pyskl/models/gcns/utils/gcn.py:1445-1584; selected by
+    ``DGSTGCN(gcn_type='dggcn')``, dgstgcn.py:42-43): K subsets, each with its own mean-pooled projections x1_k = conv1_k
+    (xbar), x2_k = conv2_k(xbar), ``Ahat_k = A_k + alpha * tanh(x1_k[u] - x2_k[w]) + beta * softmax_u(sum_c x1_k x2_k)`` — the
+    ``dgphgcn1`` arithmetic without the node-typed select and the edge-typed linear.  Implemented configuration: the
+    class defaults (ctr='T', ada='T', tanh / softmax), subset_wise on or off.
+
+    K-B (dsgcn_dynadj_*) evaluates one plain subset pair (a0-b0, a1-b1) exactly when its edge-typed linear is the
+    identity (one edge class, We = I, be = 0); the third subset goes through a second call whose first slot carries
+    (a2, b2).  Two launches instead of one and a concatenation of the result: this unit is an f-4 row, not a bench path."""
+
+    def __init__(self, in_channels, out_channels, A, ratio=0.25, ctr='T', ada='T', subset_wise=False, ada_act='softmax',
+                 ctr_act='tanh', norm='BN', act='ReLU'):
+        super().__init__()
+        assert ada_act in ['tanh', 'relu', 'sigmoid', 'softmax']
+        assert ctr_act in ['tanh', 'relu', 'sigmoid', 'softmax']
+        assert ctr in [None, 'NA', 'T']
+        assert ada in [None, 'NA', 'T']
+        if not (ctr == 'T' and ada == 'T' and ada_act == 'softmax' and ctr_act == 'tanh'):
+            raise NotImplementedError("dggcn: only ctr='T', ada='T', tanh / softmax (the class defaults) has a HIP path")
+        _check_act(act)
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.num_subsets = K = A.size(0)
+        if K != 3:
+            raise NotImplementedError('the HIP dynadj kernel implements K=3 subsets')
+        self.subset_wise = subset_wise
+        if ratio is None:
+            ratio = 1 / K
+        self.ratio = ratio
+        self.mid_channels = mid = int(ratio * out_channels)
+        # parameter creation order follows the reference ctor (same RNG consumption, same key order)
+        self.A = nn.Parameter(A.clone())
+        self.pre = nn.Sequential(nn.Conv2d(in_channels, mid * K, 1), _norm_layer(norm, mid * K), nn.ReLU())
+        self.post = nn.Conv2d(mid * K, out_channels, 1)
+        self.alpha = nn.Parameter(torch.zeros(K))
+        self.beta = nn.Parameter(torch.zeros(K))
+        self.conv1 = nn.Conv2d(in_channels, mid * K, 1)
+        self.conv2 = nn.Conv2d(in_channels, mid * K, 1)
+        if in_channels != out_channels:
+            self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), _norm_layer(norm, out_channels))
+        else:
+            self.down = None
+        self.bn = _norm_layer(norm, out_channels)
+        V = A.size(-1)
+        # constants that turn K-B's typed slots into plain ones: one node type, one edge class, identity edge linear
+        self.register_buffer('_nt0', torch.zeros(V, dtype=torch.int32), persistent=False)
+        self.register_buffer('_et0', torch.zeros(V, V, dtype=torch.int32), persistent=False)
+        self.register_buffer('_we_eye', torch.eye(mid), persistent=False)
+
+    def adjacency(self, xbar):
+        """Ahat (n, K*mid, V, V) from the time-averaged input xbar (n, Ci, V)."""
+        m, Ci = self.mid_channels, self.in_channels
+        w1, b1 = self.conv1.weight.flatten(1), self.conv1.bias
+        w2, b2 = self.conv2.weight.flatten(1), self.conv2.bias
+        zw, zb = w1.new_zeros(m, Ci), b1.new_zeros(m)
+        we, be = self._we_eye, zb
+        a = self.alpha if self.subset_wise else self.alpha[0].expand(3)
+        b = self.beta if self.subset_wise else self.beta[0].expand(3)
+        dyn = kernels.ops().dynadj
+        # subsets 0 and 1: slots (a0, b0) and (a1, b1) of one call (its third, node-typed slot is fed zeros and dropped)
+        first = dyn(xbar, self.A, a, b, w1[:2 * m], b1[:2 * m], w2[:2 * m], b2[:2 * m], zw, zb, we, be, self._nt0, self._et0)
+        # subset 2: slot (a0, b0) of a second call
+        A2 = torch.cat([self.A[2:3], torch.zeros_like(self.A[:2])])
+        a2 = torch.cat([a[2:3], a.new_zeros(2)])
+        b2s = torch.cat([b[2:3], b.new_zeros(2)])
+        second = dyn(xbar, A2, a2, b2s, torch.cat([w1[2 * m:], zw]), torch.cat([b1[2 * m:], zb]),
+                     torch.cat([w2[2 * m:], zw]), torch.cat([b2[2 * m:], zb]), zw, zb, we, be, self._nt0, self._et0)
+        return torch.cat([first[:, :2 * m], second[:, :m]], 1)
+
+    def forward_deferred(self, x, xbar=None, x_res=None):
+        ops = kernels.ops()
+        x_res = x if x_res is None else x_res
+        if xbar is None:
+            xbar = ops.tmean(x)
+        ahat = self.adjacency(xbar)
+        zp, _, ap = conv_bn(x, None, None, None, False, self.pre[0], 1, False, self.pre[1])
+        y = ops.aggregate(zp, ap, True, ahat)
+        zo, _, ao = conv_bn(y, None, None, None, False, self.post, 1, False, self.bn)
+        if self.down is None:
+            return Deferred(zo, ao, x_res, None, True)
+        zd, _, ad = conv_bn(x_res, None, None, None, False, self.down[0], 1, False, self.down[1])
+        return Deferred(zo, ao, zd, ad, True)
+
+    def forward(self, x, A=None):
+        out = self.forward_deferred(x).materialize()
+        flush_running_stats()
+        return out
+
+
 class unit_gcn(nn.Module):
     """ST-GCN spatial unit (reference: gcn.py:22-97).  ``conv_pos='pre'``: conv Ci->K*Co, aggregate with the K learnable /
     fixed adjacencies summed over subsets (K-A'), BN, (+res), ReLU.  ``conv_pos='post'``: aggregate the input with each

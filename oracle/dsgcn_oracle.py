@@ -209,6 +209,34 @@ def dgphgcn1_forward(x, sd, node_type, edge_type, training=True, ret_parts=False
     return y
 
 
+def dggcn_forward(x, sd, training=True, subset_wise=False):
+    """The original DG-STGCN spatial unit with its class defaults ctr='T', ada='T', tanh / softmax (gcn.py:1445-1584)."""
+    n, Ci, T, V = x.shape
+    A = sd['A']
+    K = A.shape[0]
+    if 'down.0.weight' in sd:
+        res = _bn(_conv1x1(x, sd['down.0.weight'], sd['down.0.bias']), sd, 'down.1.', training)   # gcn.py:1506-1509,1517
+    else:
+        res = x
+    Pre = F.relu(_bn(_conv1x1(x, sd['pre.0.weight'], sd['pre.0.bias']), sd, 'pre.1.', training))  # gcn.py:1522
+    mid = Pre.shape[1] // K
+    Pre5 = Pre.reshape(n, K, mid, T, V)
+    xbar = x.mean(dim=-2, keepdim=True)                                                            # gcn.py:1530-1531
+    x1 = _conv1x1(xbar, sd['conv1.weight'], sd['conv1.bias']).reshape(n, K, mid, V)                # gcn.py:1533
+    x2 = _conv1x1(xbar, sd['conv2.weight'], sd['conv2.bias']).reshape(n, K, mid, V)                # gcn.py:1534
+    th = torch.tanh(x1[..., :, None] - x2[..., None, :])                                           # gcn.py:1538-1539
+    G = torch.einsum('nkcv,nkcw->nkvw', x1, x2)                                                    # gcn.py:1549
+    Sm = torch.softmax(G, dim=-2)                                                                  # nn.Softmax(-2), 1499
+    if subset_wise:
+        a, b = sd['alpha'][None, :, None, None, None], sd['beta'][None, :, None, None, None]       # gcn.py:1541-1542,1552-1553
+    else:
+        a, b = sd['alpha'][0], sd['beta'][0]                                                       # gcn.py:1544,1555
+    Ahat = A[None, :, None] + a * th + b * Sm[:, :, None]                                          # gcn.py:1545,1556
+    Y = torch.einsum('nkctv,nkcvw->nkctw', Pre5, Ahat)                                             # gcn.py:1567-1568
+    z = _conv1x1(Y.reshape(n, K * mid, T, V), sd['post.weight'], sd['post.bias'])                  # gcn.py:1581-1582
+    return F.relu(_bn(z, sd, 'bn.', training) + res)                                               # gcn.py:1583
+
+
 # ----------------------------------------------------------------------------------------
 # unit_tcn / dgmstcn  (pyskl/models/gcns/utils/tcn.py:10-37, 344-431)
 # ----------------------------------------------------------------------------------------
@@ -273,9 +301,13 @@ def mstcn_forward(x, sd, stride=1, ms_cfg=((3, 1), (3, 2), (3, 3), (3, 4), ('max
 # DGBlock / DGSTGCN / head / loss
 # ----------------------------------------------------------------------------------------
 
-def dgblock_forward(x, sd, node_type, edge_type, stride, residual, training=True):
+def dgblock_forward(x, sd, node_type, edge_type, stride, residual, training=True, subset_wise=False):
     """ReLU(tcn(gcn(x)) + residual(x)) — dgstgcn.py:12-65."""
-    g = dgphgcn1_forward(x, _sub(sd, 'gcn.'), node_type, edge_type, training)
+    gsd = _sub(sd, 'gcn.')
+    if 'edge_linears.weight' in gsd:
+        g = dgphgcn1_forward(x, gsd, node_type, edge_type, training)
+    else:                                                            # gcn_type='dggcn' (dgstgcn.py:42-43)
+        g = dggcn_forward(x, gsd, training, subset_wise=subset_wise)
     t = dgmstcn_forward(g, _sub(sd, 'tcn.'), stride, training=training)
     if not residual:
         res = 0

@@ -452,6 +452,34 @@ def test_dgphgcn1_kernels_vs_reference_intermediates(tag, layout, ci, co):
     assert rel(out.cpu(), z[f'{tag}_out']) < 1e-5
 
 
+@pytest.mark.parametrize('i', [0, 1])
+def test_dggcn_unit_vs_reference_fixture(i):
+    """The original DG-STGCN unit `dggcn` (gcn.py:1445-1584) on the HIP path — two K-B launches with the typed slots made
+    plain, K-A, K-C — against the REFERENCE's fp64 output, input gradient and parameter gradients
+    (tests/golden/unit_dggcn.npz); the module takes the reference's state_dict as is."""
+    import dsgcn_amd as D
+    from test_oracle_golden import load, sd_of
+    z = load('unit_dggcn.npz')
+    tag = f'u{i}_'
+    sd = sd_of(z, tag + 'sd_', torch.float32)
+    Co, Ci = sd['post.weight'].shape[0], sd['pre.0.weight'].shape[1]
+    m = D.dggcn(Ci, Co, sd['A'].clone(), ratio=0.25, subset_wise=bool(z[tag + 'subset_wise']))
+    m.load_state_dict(sd)                       # strict: same keys and shapes as the reference module
+    m = m.cuda().train()
+    x = torch.from_numpy(z[tag + 'x']).cuda().requires_grad_()
+    y = m(x)
+    (y * torch.from_numpy(z[tag + 'R']).cuda()).sum().backward()
+    assert rel(y.detach().cpu(), z[tag + 'y']) < 1e-5
+    assert rel(x.grad.cpu(), z[tag + 'dx']) < 5e-5
+    params = dict(m.named_parameters())
+    for k in ('A', 'alpha', 'beta', 'conv1.weight', 'conv2.bias', 'pre.1.weight', 'post.weight'):
+        want = z[tag + 'grad_' + k]
+        if np.abs(want).max() < 1e-12:           # alpha[1:], beta[1:] are unused without subset_wise
+            assert params[k].grad is None or float(params[k].grad.abs().max()) < 1e-6, k
+        else:
+            assert rel(params[k].grad.cpu(), want) < 1e-4, (k, rel(params[k].grad.cpu(), want))
+
+
 @pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'MSTCNs2', 'gcn_offset_post',
                                  'gcn_importance', 'gcn_fixed_post', 'ctrhgcn', 'ctrhgcn_same', 'msmlp', 'msmlp_s2'])
 def test_units_vs_reference_fixture(tag):

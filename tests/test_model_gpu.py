@@ -23,9 +23,11 @@ def test_native_library_is_loaded():
         assert 'libdsgcn.so' in f.read()           # the in-tree HIP library really is the code that runs
 
 
-@pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn', 'model_reduced_stgcnpp'])
+@pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn', 'model_reduced_stgcnpp',
+                                  'model_reduced_dggcn'])
 def test_reduced_model_vs_golden(name):
-    """DS-STGCN, classic CTR-GCN and ST-GCN (reduced widths) against the reference's committed outputs."""
+    """DS-STGCN, classic CTR-GCN, ST-GCN / ST-GCN++ and the original DG-STGCN (gcn_type='dggcn') at reduced widths against
+    the reference's committed outputs."""
     z = load(name + '.npz')
     with open(os.path.join(GOLD, name + '_cfg.json')) as f:
         cfg = json.load(f)

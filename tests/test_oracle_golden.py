@@ -58,6 +58,46 @@ def test_dgphgcn1_unit(i):
         assert rel(sd[k].grad, z[tag + 'grad_' + k]) < 1e-6, k
 
 
+DGGCN_GRADS = ('A', 'alpha', 'beta', 'conv1.weight', 'conv2.bias', 'pre.1.weight', 'post.weight')
+
+
+@pytest.mark.parametrize('i', [0, 1])
+def test_dggcn_unit(i):
+    """The original DG-STGCN unit (gcn.py:1445-1584; f-4): scalar and subset-wise alpha / beta, with and without `down`."""
+    z = load('unit_dggcn.npz')
+    tag = f'u{i}_'
+    sd = sd_of(z, tag + 'sd_')
+    x = torch.from_numpy(z[tag + 'x']).double().requires_grad_()
+    for k in DGGCN_GRADS:
+        sd[k].requires_grad_()
+    y = O.dggcn_forward(x, sd, subset_wise=bool(z[tag + 'subset_wise']))
+    (y * torch.from_numpy(z[tag + 'R']).double()).sum().backward()
+    assert rel(y.detach(), z[tag + 'y']) < 1e-6
+    assert rel(x.grad, z[tag + 'dx']) < 1e-6
+    for k in DGGCN_GRADS:
+        want = z[tag + 'grad_' + k]
+        if np.abs(want).max() < 1e-12:           # alpha[1:], beta[1:] are unused without subset_wise
+            assert sd[k].grad is None or float(sd[k].grad.abs().max()) < 1e-12, k
+        else:
+            assert rel(sd[k].grad, want) < 1e-6, k
+
+
+def test_reduced_dggcn_model():
+    """DGSTGCN(gcn_type='dggcn') end to end (reduced width) against the reference's fp64 and fp32 runs."""
+    z = load('model_reduced_dggcn.npz')
+    with open(os.path.join(GOLD, 'model_reduced_dggcn_cfg.json')) as f:
+        bk = json.load(f)['backbone']
+    plan = O.dgstgcn_plan(3, bk['base_channels'], 2, bk['num_stages'], tuple(bk['inflate_stages']), tuple(bk['down_stages']))
+    gc = O.graph_constants('nturgb+d')
+    x, y = torch.from_numpy(z['x']), torch.from_numpy(z['label'])
+    logits, loss = O.recognizer_forward_train(x.double(), y, sd_of(z, 'sd_'), gc['node_type'], gc['edge_type'], plan)
+    assert rel(logits, z['logits_f64']) < 1e-6
+    assert abs(loss.item() - float(z['loss_f64'])) < 1e-7
+    logits32, loss32 = O.recognizer_forward_train(x, y, sd_of(z, 'sd_', torch.float32), gc['node_type'], gc['edge_type'], plan)
+    assert rel(logits32, z['logits_f32']) < 1e-5
+    assert abs(loss32.item() - float(z['loss_f32'])) < 1e-5
+
+
 @pytest.mark.parametrize('i,stride', [(0, 1), (1, 2)])
 def test_dgmstcn_unit(i, stride):
     z = load('unit_dgmstcn.npz')
@@ -161,6 +201,26 @@ def test_oracle_vs_reference_live():
     gc = O.graph_constants('coco')
     sd = {k: v.detach() for k, v in m.state_dict().items()}
     assert (m(x) - O.dgphgcn1_forward(x, sd, gc['node_type'], gc['edge_type'])).abs().max().item() < 1e-12
+
+
+def test_dggcn_vs_reference_live():
+    """dggcn restatement against the imported reference class, fp64, other widths / joints than the fixture's."""
+    import ref_shim
+    if not ref_shim.available():
+        pytest.skip('reference tree not present (GPU box)')
+    R = ref_shim.load()
+    torch.manual_seed(2)
+    np.random.seed(2)
+    G = R.graph.Graph(layout='coco', mode='random', num_filter=3, init_off=.04, init_std=.02)
+    A = torch.tensor(G.A, dtype=torch.float32)
+    for ci, co, sw in ((48, 48, False), (32, 64, True)):
+        m = R.gutils.dggcn(ci, co, A, ratio=0.25, subset_wise=sw).double()
+        with torch.no_grad():
+            m.alpha.normal_(0, .5)
+            m.beta.normal_(0, .5)
+        x = torch.randn(2, ci, 10, 17, dtype=torch.float64)
+        sd = {k: v.detach() for k, v in m.state_dict().items()}
+        assert (m(x) - O.dggcn_forward(x, sd, subset_wise=sw)).abs().max().item() < 1e-12
 
 
 # ---- round-2 fixtures (tests/golden/gen_golden_r2.py) ------------------------------------------------------------
