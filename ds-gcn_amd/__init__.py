@@ -12,9 +12,9 @@ from .builder import (MODELS, BACKBONES, HEADS, LOSSES, NECKS, RECOGNIZERS, buil
 from .evaluation import top_k_accuracy, mean_class_accuracy, confusion_matrix
 from .losses import CrossEntropyLoss
 from .heads import GCNHead, SimpleHead
-from .gcn_units import dggcn, dgphgcn1, unit_gcn, unit_ctrgcn, unit_ctrhgcn, CTRGC, CTRHGC, Deferred
+from .gcn_units import dggcn, dgphgcn1, unit_aagcn, unit_gcn, unit_ctrgcn, unit_ctrhgcn, CTRGC, CTRHGC, Deferred
 from .tcn_units import dgmstcn, mstcn, msmlp, unitmlp, unit_tcn, MSTCN
-from .backbones import DGSTGCN, STGCN, CTRGCN, DGBlock, STGCNBlock, CTRGCNBlock
+from .backbones import DGSTGCN, STGCN, CTRGCN, AAGCN, DGBlock, STGCNBlock, CTRGCNBlock, AAGCNBlock
 from .recognizers import RecognizerGCN, reduce_log_vars, gather_results
 from . import kernels
 from . import pipeline

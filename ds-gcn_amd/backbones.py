@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import kernels
 from .builder import BACKBONES
-from .gcn_units import dggcn, dgphgcn1, unit_ctrgcn, unit_ctrhgcn, unit_gcn, flush_running_stats
+from .gcn_units import dggcn, dgphgcn1, unit_aagcn, unit_ctrgcn, unit_ctrhgcn, unit_gcn, flush_running_stats
 from .graph import Graph
 from .tcn_units import MSTCN, dgmstcn, msmlp, mstcn, unit_tcn
 
@@ -305,6 +305,87 @@ class STGCN(_SkeletonBackbone):
     def forward(self, x):
         N, M = x.shape[:2]
         x = self._normalize_input(x.float())
+        x = self._run_blocks(x, self.gcn[:self.num_stages], False)
+        return x.reshape((N, M) + x.shape[1:])
+
+
+class AAGCNBlock(_FusedBlock):
+    """reference: pyskl/models/gcns/aagcn.py:12-54 — relu(tcn(gcn(x)) + residual(x))."""
+
+    def __init__(self, in_channels, out_channels, A, edge_type, node_type, stride=1, residual=True, **kwargs):
+        super().__init__()
+        gcn_kwargs, tcn_kwargs = _split_kwargs(kwargs)
+        tcn_type = tcn_kwargs.pop('type', 'unit_tcn')
+        assert tcn_type in ['unit_tcn', 'mstcn', 'unitmlp', 'msmlp']
+        gcn_type = gcn_kwargs.pop('type', 'unit_aagcn')
+        assert gcn_type in ['unit_aagcn', 'unit_aahgcn']
+        if gcn_type != 'unit_aagcn' or tcn_type not in ('unit_tcn', 'mstcn'):
+            raise NotImplementedError(f'{gcn_type}/{tcn_type}: the HIP path covers unit_aagcn with unit_tcn or mstcn')
+        self.gcn = unit_aagcn(in_channels, out_channels, A, **gcn_kwargs)
+        if tcn_type == 'unit_tcn':
+            self.tcn = unit_tcn(out_channels, out_channels, 9, stride=stride, **tcn_kwargs)
+        else:
+            self.tcn = mstcn(out_channels, out_channels, stride=stride, **tcn_kwargs)
+        self.relu = nn.ReLU()
+        self._set_residual(in_channels, out_channels, stride, residual)
+
+    def _gcn_deferred(self, x, xbar, x_res):
+        return self.gcn.forward_deferred(x, xbar, x_res)
+
+    def init_weights(self):
+        self.tcn.init_weights()
+        self.gcn.init_weights()
+
+
+@BACKBONES.register_module()
+class AAGCN(_SkeletonBackbone):
+    """reference: pyskl/models/gcns/aagcn.py:57-142."""
+
+    def __init__(self, graph_cfg, in_channels=3, base_channels=64, data_bn_type='MVC', num_person=2, num_stages=10,
+                 inflate_stages=[5, 8], down_stages=[5, 8], pretrained=None, **kwargs):
+        super().__init__()
+        self.graph = Graph(**graph_cfg)
+        A = torch.tensor(self.graph.A, dtype=torch.float32, requires_grad=False)
+        self.register_buffer('A', A)
+        self.kwargs = kwargs
+        node_type = torch.tensor(self.graph.node_type, requires_grad=False)
+        edge_type = torch.tensor(self.graph.edge_type, dtype=torch.float32, requires_grad=False)
+        assert data_bn_type in ['MVC', 'VC', None]
+        self.in_channels = in_channels
+        self.base_channels = base_channels
+        self.num_person = num_person
+        self.num_stages = num_stages
+        self.inflate_stages = inflate_stages
+        self.down_stages = down_stages
+        self._make_data_bn(data_bn_type, in_channels, num_person, A.size(1))
+        lw_kwargs = _stage_kwargs(kwargs, num_stages)
+        lw_kwargs[0].pop('tcn_dropout', None)
+        modules = []
+        if self.in_channels != self.base_channels:
+            modules = [AAGCNBlock(in_channels, base_channels, A.clone(), edge_type, node_type, 1, residual=False,
+                                  **lw_kwargs[0])]
+        for i in range(2, num_stages + 1):
+            out_channels = base_channels * (1 + (i in inflate_stages))
+            stride = 1 + (i in down_stages)
+            modules.append(AAGCNBlock(base_channels, out_channels, A.clone(), edge_type, node_type, stride=stride,
+                                      **lw_kwargs[i - 1]))
+            base_channels = out_channels
+        if self.in_channels == self.base_channels:
+            self.num_stages -= 1
+        self.gcn = nn.ModuleList(modules)
+        self.pretrained = pretrained
+
+    def init_weights(self):
+        if isinstance(self.data_bn, nn.BatchNorm1d):
+            nn.init.constant_(self.data_bn.weight, 1)
+            nn.init.constant_(self.data_bn.bias, 0)
+        for module in self.gcn:
+            module.init_weights()
+        super().init_weights()
+
+    def forward(self, x):
+        N, M = x.shape[:2]
+        x = self._normalize_input(x)
         x = self._run_blocks(x, self.gcn[:self.num_stages], False)
         return x.reshape((N, M) + x.shape[1:])
 

@@ -316,6 +316,122 @@ class dggcn(nn.Module):
         return out
 
 
+class unit_aagcn(nn.Module):
+    """2s-AGCN / AAGCN spatial unit (reference: pyskl/models/gcns/utils/gcn.py:349-460): per subset a data-dependent
+    topology ``A_i + alpha * tanh(conv_a_i(x)^T conv_b_i(x) / (inter_c * T))`` per sample, ``y = sum_i conv_d_i(x A_i)``,
+    BN, + down(x), ReLU, then the spatial / temporal / channel attention gates (``y * sigmoid(.) + y`` each).
+    HIP chain for the channel mixes — the six embedding convs as ONE K-C launch over stacked weights, the three
+    ``conv_d`` as ONE K-C launch over the concatenated aggregated inputs (their sum is the conv's own K reduction) with
+    the BN statistics in its epilogue, ``down`` + BN + ReLU fused into the output pass — while the V x V Gram / aggregation
+    products (batched GEMMs with K = 25 .. inter_c*T) and the three attention gates stay ATen ops: this unit is an f-4
+    row, not a bench path."""
+
+    def __init__(self, in_channels, out_channels, A, coff_embedding=4, adaptive=True, attention=True):
+        super().__init__()
+        inter_channels = out_channels // coff_embedding
+        self.inter_c = inter_channels
+        self.out_c = out_channels
+        self.in_c = in_channels
+        self.num_subset = A.shape[0]
+        self.adaptive = adaptive
+        self.attention = attention
+        num_joints = A.shape[-1]
+        # parameter creation order follows the reference ctor (same RNG consumption, same key order)
+        self.conv_d = nn.ModuleList([nn.Conv2d(in_channels, out_channels, 1) for _ in range(self.num_subset)])
+        if self.adaptive:
+            self.A = nn.Parameter(A)
+            self.alpha = nn.Parameter(torch.zeros(1))
+            self.conv_a = nn.ModuleList()
+            self.conv_b = nn.ModuleList()
+            for _ in range(self.num_subset):
+                self.conv_a.append(nn.Conv2d(in_channels, inter_channels, 1))
+                self.conv_b.append(nn.Conv2d(in_channels, inter_channels, 1))
+        else:
+            self.register_buffer('A', A)
+        if self.attention:
+            self.conv_ta = nn.Conv1d(out_channels, 1, 9, padding=4)
+            ker_joint = num_joints if num_joints % 2 else num_joints - 1
+            self.conv_sa = nn.Conv1d(out_channels, 1, ker_joint, padding=(ker_joint - 1) // 2)
+            self.fc1c = nn.Linear(out_channels, out_channels // 2)
+            self.fc2c = nn.Linear(out_channels // 2, out_channels)
+        if in_channels != out_channels:
+            self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels))
+        else:
+            self.down = None
+        self.bn = nn.BatchNorm2d(out_channels)
+
+    def init_weights(self):
+        # reference: gcn.py:401-423 (same order of random draws)
+        import math
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out')
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        nn.init.constant_(self.bn.weight, 1e-6)
+        nn.init.constant_(self.bn.bias, 0)
+        for conv in self.conv_d:
+            w = conv.weight
+            nn.init.normal_(w, 0, math.sqrt(2. / (w.size(0) * w.size(1) * w.size(2) * self.num_subset)))
+            nn.init.constant_(conv.bias, 0)
+        if self.attention:
+            nn.init.constant_(self.conv_ta.weight, 0)
+            nn.init.constant_(self.conv_ta.bias, 0)
+            nn.init.xavier_normal_(self.conv_sa.weight)
+            nn.init.constant_(self.conv_sa.bias, 0)
+            nn.init.kaiming_normal_(self.fc1c.weight)
+            nn.init.constant_(self.fc1c.bias, 0)
+            nn.init.constant_(self.fc2c.weight, 0)
+            nn.init.constant_(self.fc2c.bias, 0)
+
+    def forward_deferred(self, x, xbar=None, x_res=None):
+        ops = kernels.ops()
+        x_res = x if x_res is None else x_res
+        N, C, T, V = x.shape
+        S, ic = self.num_subset, self.inter_c
+        if self.adaptive:
+            wab = torch.cat([m.weight.flatten(1) for pair in zip(self.conv_a, self.conv_b) for m in pair], 0)
+            bab = torch.cat([m.bias for pair in zip(self.conv_a, self.conv_b) for m in pair], 0)
+            ab = ops.pwconv(x, None, None, None, False, wab, bab, 1, False)[0].reshape(N, S, 2, ic * T, V)
+            gram = torch.matmul(ab[:, :, 0].transpose(-1, -2), ab[:, :, 1]) / (ic * T)       # (N,S,V,V)  gcn.py:432-434
+            adj = self.A[None] + torch.tanh(gram) * self.alpha                               # gcn.py:435
+        else:
+            adj = self.A[None]
+        z = torch.matmul(x.reshape(N, 1, C * T, V), adj).reshape(N, S * C, T, V)              # gcn.py:436-437 per subset
+        wd = torch.cat([m.weight.flatten(1) for m in self.conv_d], 1)                        # (Co, S*C): sum_i conv_d_i
+        bd = torch.stack([m.bias for m in self.conv_d]).sum(0)
+        zo, ao = op_bn(self.bn, lambda g, b, eps, want: _pw_bn(ops, z, wd, bd, g, b, eps, want),
+                       lambda o: N * T * V)
+        if self.down is None:
+            y = Deferred(zo, ao, x_res, None, True).materialize()
+        else:
+            zd, _, ad = conv_bn(x_res, None, None, None, False, self.down[0], 1, False, self.down[1])
+            y = Deferred(zo, ao, zd, ad, True).materialize()
+        if self.attention:                                                                   # gcn.py:447-459
+            se1 = torch.sigmoid(self.conv_sa(y.mean(-2)))                                    # N 1 V
+            y = y * se1.unsqueeze(-2) + y
+            se1 = torch.sigmoid(self.conv_ta(y.mean(-1)))                                    # N 1 T
+            y = y * se1.unsqueeze(-1) + y
+            se2 = torch.sigmoid(self.fc2c(torch.relu(self.fc1c(y.mean(-1).mean(-1)))))       # N C
+            y = y * se2.unsqueeze(-1).unsqueeze(-1) + y
+        return as_deferred(y)
+
+    def forward(self, x):
+        out = self.forward_deferred(x).materialize()
+        flush_running_stats()
+        return out
+
+
+def _pw_bn(ops, z, w, b, gamma, beta, eps, want):
+    """pwconv with the BN statistics of its output -> (out, scale, shift, mean, var) (the op_bn contract)"""
+    if want:
+        out, _, sc, sh, mean, var = ops.pwconv(z, None, None, None, False, w, b, 1, False, gamma, beta, eps, w.shape[0], True)
+        return out, sc, sh, mean, var
+    return (ops.pwconv(z, None, None, None, False, w, b, 1, False)[0], None, None, None, None)
+
+
 class unit_gcn(nn.Module):
     """ST-GCN spatial unit (reference: gcn.py:22-97).  ``conv_pos='pre'``: conv Ci->K*Co, aggregate with the K learnable /
     fixed adjacencies summed over subsets (K-A'), BN, (+res), ReLU.  ``conv_pos='post'``: aggregate the input with each

@@ -237,6 +237,81 @@ def dggcn_forward(x, sd, training=True, subset_wise=False):
     return F.relu(_bn(z, sd, 'bn.', training) + res)                                               # gcn.py:1583
 
 
+def unit_aagcn_forward(x, sd, training=True, adaptive=True, attention=True):
+    """2s-AGCN / AAGCN spatial unit (gcn.py:349-460; f-4)."""
+    n, C, T, V = x.shape
+    A = sd['A']
+    S = A.shape[0]
+    y = None
+    for i in range(S):
+        if adaptive:
+            a1 = _conv1x1(x, sd[f'conv_a.{i}.weight'], sd[f'conv_a.{i}.bias'])                     # gcn.py:432
+            ic = a1.shape[1]
+            a1 = a1.permute(0, 3, 1, 2).reshape(n, V, ic * T)
+            a2 = _conv1x1(x, sd[f'conv_b.{i}.weight'], sd[f'conv_b.{i}.bias']).reshape(n, ic * T, V)   # gcn.py:433
+            adj = A[i] + torch.tanh(torch.matmul(a1, a2) / (ic * T)) * sd['alpha']                # gcn.py:434-435
+        else:
+            adj = A[i]                                                                            # gcn.py:441
+        z = _conv1x1(torch.matmul(x.reshape(n, C * T, V), adj).reshape(n, C, T, V),
+                     sd[f'conv_d.{i}.weight'], sd[f'conv_d.{i}.bias'])                            # gcn.py:436-437
+        y = z if y is None else z + y
+    if 'down.0.weight' in sd:
+        res = _bn(_conv1x1(x, sd['down.0.weight'], sd['down.0.bias']), sd, 'down.1.', training)   # gcn.py:391-395
+    else:
+        res = x
+    y = F.relu(_bn(y, sd, 'bn.', training) + res)                                                 # gcn.py:445
+    if attention:
+        pj = (sd['conv_sa.weight'].shape[-1] - 1) // 2
+        se1 = torch.sigmoid(F.conv1d(y.mean(-2), sd['conv_sa.weight'], sd['conv_sa.bias'], padding=pj))   # gcn.py:449-450
+        y = y * se1.unsqueeze(-2) + y
+        se1 = torch.sigmoid(F.conv1d(y.mean(-1), sd['conv_ta.weight'], sd['conv_ta.bias'], padding=4))    # gcn.py:453-454
+        y = y * se1.unsqueeze(-1) + y
+        se = y.mean(-1).mean(-1)                                                                  # gcn.py:457
+        se2 = torch.sigmoid(F.linear(F.relu(F.linear(se, sd['fc1c.weight'], sd['fc1c.bias'])),
+                                     sd['fc2c.weight'], sd['fc2c.bias']))                         # gcn.py:458-459
+        y = y * se2.unsqueeze(-1).unsqueeze(-1) + y
+    return y
+
+
+def aagcn_block_forward(x, sd, stride, residual, training=True):
+    """relu(tcn(gcn(x)) + residual(x)) with unit_aagcn + unit_tcn(k=9) — aagcn.py:12-54."""
+    g = unit_aagcn_forward(x, _sub(sd, 'gcn.'), training)
+    t = unit_tcn_forward(g, _sub(sd, 'tcn.'), 9, stride, 1, training)
+    if not residual:
+        res = 0
+    elif 'residual.conv.weight' in sd:
+        res = unit_tcn_forward(x, _sub(sd, 'residual.'), 1, stride, 1, training)
+    else:
+        res = x
+    return F.relu(t + res)
+
+
+def aagcn_plan(in_channels=3, base_channels=64, num_stages=10, inflate_stages=(5, 8), down_stages=(5, 8)):
+    """(Ci, Co, stride, residual) per block — aagcn.py:106-116."""
+    plan = []
+    bc = base_channels
+    if in_channels != bc:
+        plan.append((in_channels, bc, 1, False))
+    for i in range(2, num_stages + 1):
+        co = bc * (1 + (i in inflate_stages))
+        plan.append((bc, co, 1 + (i in down_stages), True))
+        bc = co
+    return plan
+
+
+def aagcn_forward(x, sd, plan, training=True):
+    """AAGCN.forward (aagcn.py:127-141): data_bn over (M V C), blocks."""
+    N, M, T, V, C = x.shape
+    h = x.permute(0, 1, 3, 4, 2).contiguous().view(N, M * V * C, T)
+    h = F.batch_norm(h, sd.get('data_bn.running_mean').clone() if not training else None,
+                     sd.get('data_bn.running_var').clone() if not training else None,
+                     sd['data_bn.weight'], sd['data_bn.bias'], training, 0.1, 1e-5)
+    h = h.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
+    for i, (_, _, stride, residual) in enumerate(plan):
+        h = aagcn_block_forward(h, _sub(sd, f'gcn.{i}.'), stride, residual, training)
+    return h.reshape((N, M) + h.shape[1:])
+
+
 # ----------------------------------------------------------------------------------------
 # unit_tcn / dgmstcn  (pyskl/models/gcns/utils/tcn.py:10-37, 344-431)
 # ----------------------------------------------------------------------------------------
@@ -589,8 +664,8 @@ def ctrgcn_forward(x, sd, plan, training=True, edge_type=None):
 
 
 def recognizer_forward_train_backbone(backbone, keypoint, label, sd, plan, training=True):
-    """forward_train with the ST-GCN ('stgcn'), ST-GCN++ ('stgcnpp'), classic CTR-GCN ('ctrgcn') or shipped-config CTR-GCN
-    ('ctrgcn_shipped': unit_ctrhgcn + msmlp, NTU graph) backbone -> (logits, loss)."""
+    """forward_train with the ST-GCN ('stgcn'), ST-GCN++ ('stgcnpp'), classic CTR-GCN ('ctrgcn'), shipped-config CTR-GCN
+    ('ctrgcn_shipped': unit_ctrhgcn + msmlp, NTU graph) or AAGCN ('aagcn') backbone -> (logits, loss)."""
     assert keypoint.shape[1] == 1
     if backbone == 'ctrgcn_shipped':
         feat = ctrgcn_forward(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training,
@@ -598,7 +673,7 @@ def recognizer_forward_train_backbone(backbone, keypoint, label, sd, plan, train
     elif backbone == 'stgcnpp':        # ST-GCN++ (configs/stgcn++): gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn'
         feat = stgcn_forward(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training, True, 'mstcn')
     else:
-        fwd = {'stgcn': stgcn_forward, 'ctrgcn': ctrgcn_forward}[backbone]
+        fwd = {'stgcn': stgcn_forward, 'ctrgcn': ctrgcn_forward, 'aagcn': aagcn_forward}[backbone]
         feat = fwd(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training)
     logits = gcn_head_forward(feat, _sub(sd, 'cls_head.'))
     return logits, F.cross_entropy(logits, label.squeeze(-1))

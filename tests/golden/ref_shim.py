@@ -142,10 +142,11 @@ def load():
     dgstgcn = importlib.import_module('pyskl.models.gcns.dgstgcn')
     stgcn = importlib.import_module('pyskl.models.gcns.stgcn')
     ctrgcn = importlib.import_module('pyskl.models.gcns.ctrgcn')
+    aagcn = importlib.import_module('pyskl.models.gcns.aagcn')
     ce = importlib.import_module('pyskl.models.losses.cross_entropy_loss')
     head = importlib.import_module('pyskl.models.heads.simple_head')
     rec = importlib.import_module('pyskl.models.recognizers.recognizergcn')
     _loaded = types.SimpleNamespace(
-        graph=graph, builder=builder, gutils=gutils, dgstgcn=dgstgcn, stgcn=stgcn, ctrgcn=ctrgcn,
+        graph=graph, builder=builder, gutils=gutils, dgstgcn=dgstgcn, stgcn=stgcn, ctrgcn=ctrgcn, aagcn=aagcn,
         ce=ce, head=head, rec=rec, evaluation=evaluation, torch=torch)
     return _loaded

@@ -453,6 +453,30 @@ def test_dgphgcn1_kernels_vs_reference_intermediates(tag, layout, ci, co):
 
 
 @pytest.mark.parametrize('i', [0, 1])
+def test_unit_aagcn_vs_reference_fixture(i):
+    """The 2s-AGCN / AAGCN unit (gcn.py:349-460) with the HIP channel mixes (embedding convs and conv_d as one K-C launch
+    each, BN + down + ReLU fused) against the REFERENCE's fp64 output, input gradient and parameter gradients
+    (tests/golden/unit_aagcn.npz); the module takes the reference's state_dict as is."""
+    import dsgcn_amd as D
+    from test_oracle_golden import load, sd_of, AAGCN_GRADS
+    z = load('unit_aagcn.npz')
+    tag = f'u{i}_'
+    sd = sd_of(z, tag + 'sd_', torch.float32)
+    Co, Ci = sd['conv_d.0.weight'].shape[:2]
+    m = D.unit_aagcn(Ci, Co, sd['A'].clone())
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x = torch.from_numpy(z[tag + 'x']).cuda().requires_grad_()
+    y = m(x)
+    (y * torch.from_numpy(z[tag + 'R']).cuda()).sum().backward()
+    assert rel(y.detach().cpu(), z[tag + 'y']) < 1e-5
+    assert rel(x.grad.cpu(), z[tag + 'dx']) < 5e-5
+    params = dict(m.named_parameters())
+    for k in AAGCN_GRADS:
+        assert rel(params[k].grad.cpu(), z[tag + 'grad_' + k]) < 1e-4, (k, rel(params[k].grad.cpu(), z[tag + 'grad_' + k]))
+
+
+@pytest.mark.parametrize('i', [0, 1])
 def test_dggcn_unit_vs_reference_fixture(i):
     """The original DG-STGCN unit `dggcn` (gcn.py:1445-1584) on the HIP path — two K-B launches with the typed slots made
     plain, K-A, K-C — against the REFERENCE's fp64 output, input gradient and parameter gradients

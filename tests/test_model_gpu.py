@@ -24,9 +24,9 @@ def test_native_library_is_loaded():
 
 
 @pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn', 'model_reduced_stgcnpp',
-                                  'model_reduced_dggcn'])
+                                  'model_reduced_dggcn', 'model_reduced_aagcn'])
 def test_reduced_model_vs_golden(name):
-    """DS-STGCN, classic CTR-GCN, ST-GCN / ST-GCN++ and the original DG-STGCN (gcn_type='dggcn') at reduced widths against
+    """DS-STGCN, classic CTR-GCN, ST-GCN / ST-GCN++ the original DG-STGCN (gcn_type='dggcn') and AAGCN at reduced widths against
     the reference's committed outputs."""
     z = load(name + '.npz')
     with open(os.path.join(GOLD, name + '_cfg.json')) as f:

@@ -82,6 +82,48 @@ def test_dggcn_unit(i):
             assert rel(sd[k].grad, want) < 1e-6, k
 
 
+AAGCN_GRADS = ('A', 'alpha', 'conv_d.1.weight', 'conv_a.0.weight', 'conv_b.2.bias', 'conv_ta.weight', 'conv_sa.weight',
+               'fc1c.weight', 'fc2c.bias', 'bn.weight')
+
+
+@pytest.mark.parametrize('i', [0, 1])
+def test_unit_aagcn(i):
+    """2s-AGCN / AAGCN unit (gcn.py:349-460; f-4): adaptive topology + the three attention gates, with and without `down`."""
+    z = load('unit_aagcn.npz')
+    tag = f'u{i}_'
+    sd = sd_of(z, tag + 'sd_')
+    x = torch.from_numpy(z[tag + 'x']).double().requires_grad_()
+    for k in AAGCN_GRADS:
+        sd[k].requires_grad_()
+    y = O.unit_aagcn_forward(x, sd)
+    (y * torch.from_numpy(z[tag + 'R']).double()).sum().backward()
+    assert rel(y.detach(), z[tag + 'y']) < 1e-6
+    assert rel(x.grad, z[tag + 'dx']) < 1e-6
+    for k in AAGCN_GRADS:
+        assert rel(sd[k].grad, z[tag + 'grad_' + k]) < 1e-6, k
+
+
+def test_unit_aagcn_vs_reference_live():
+    import ref_shim
+    if not ref_shim.available():
+        pytest.skip('reference tree not present (GPU box)')
+    R = ref_shim.load()
+    torch.manual_seed(4)
+    A = torch.tensor(R.graph.Graph(layout='coco', mode='spatial').A, dtype=torch.float32)
+    for ci, co in ((48, 48), (32, 64)):
+        m = R.gutils.unit_aagcn(ci, co, A.clone())
+        m.init_weights()
+        with torch.no_grad():
+            m.alpha.normal_(0, .5)
+            m.conv_ta.weight.normal_(0, .1)
+            m.fc2c.weight.normal_(0, .05)
+            m.bn.weight.fill_(1.0)
+        m = m.double()
+        x = torch.randn(2, ci, 10, 17, dtype=torch.float64)
+        sd = {k: v.detach() for k, v in m.state_dict().items()}
+        assert (m(x) - O.unit_aagcn_forward(x, sd)).abs().max().item() < 1e-11
+
+
 def test_reduced_dggcn_model():
     """DGSTGCN(gcn_type='dggcn') end to end (reduced width) against the reference's fp64 and fp32 runs."""
     z = load('model_reduced_dggcn.npz')
@@ -138,15 +180,17 @@ def test_reduced_model_fp64_and_fp32():
     assert abs(loss32.item() - float(z['loss_f32'])) < 1e-5
 
 
-@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn', 'stgcnpp'])
+@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn', 'stgcnpp', 'aagcn'])
 def test_reduced_other_backbones(kind):
-    """ST-GCN (unit_gcn + unit_tcn k=9), ST-GCN++ (with_res + mstcn) and classic CTR-GCN (unit_ctrgcn + MSTCN) end to end
-    against the reference."""
+    """ST-GCN (unit_gcn + unit_tcn k=9), ST-GCN++ (with_res + mstcn), classic CTR-GCN (unit_ctrgcn + MSTCN) and AAGCN
+    (unit_aagcn + unit_tcn k=9, data_bn over M V C) end to end against the reference."""
     z = load(f'model_reduced_{kind}.npz')
     with open(os.path.join(GOLD, f'model_reduced_{kind}_cfg.json')) as f:
         bk = json.load(f)['backbone']
     if kind == 'ctrgcn':
         plan = O.ctrgcn_plan(3, bk['base_channels'], bk['num_stages'], tuple(bk['inflate_stages']), tuple(bk['down_stages']))
+    elif kind == 'aagcn':
+        plan = O.aagcn_plan(3, bk['base_channels'], bk['num_stages'], tuple(bk['inflate_stages']), tuple(bk['down_stages']))
     else:
         plan = O.dgstgcn_plan(3, bk['base_channels'], 2, bk['num_stages'], tuple(bk['inflate_stages']),
                               tuple(bk['down_stages']))
