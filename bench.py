@@ -44,7 +44,7 @@ def ds_cfg(num_classes=CLASSES, layout='nturgb+d'):
 
 def other_cfg(kind, num_classes=60, **bk):
     """Model dicts of the other backbones that run on the same kernels: 'stgcn' (vanilla ST-GCN, BASELINE config 1),
-    'stgcnpp' (configs/stgcn++), 'ctrgcn' (classic CTR-GCN, BASELINE config 4)."""
+    'stgcnpp' (configs/stgcn++), 'ctrgcn' (classic CTR-GCN, BASELINE config 4), 'aagcn', 'dggcn' (the f-4 backbones)."""
     if kind == 'ctrgcn':
         backbone = dict(type='CTRGCN', gcn_type='unit_ctrgcn', graph_cfg=dict(layout='nturgb+d', mode='spatial'))
     elif kind == 'ctrgcn_shipped':        # configs/ctrgcn/CTRGCN_model.py: unit_ctrhgcn + msmlp on the random graph
@@ -52,6 +52,12 @@ def other_cfg(kind, num_classes=60, **bk):
                         gcn_add_type=False, gcn_ada=True, gcn_num_types=5, gcn_rel_reduction=8, gcn_edge_num=15,
                         tcn_type='msmlp', tcn_add_tcn=True, tcn_merge_after=True,
                         graph_cfg=dict(layout='nturgb+d', mode='random', num_filter=3, init_off=.04, init_std=.02))
+    elif kind == 'aagcn':                 # 2s-AGCN / AAGCN with its class defaults (unit_aagcn + unit_tcn k=9)
+        backbone = dict(type='AAGCN', graph_cfg=dict(layout='nturgb+d', mode='spatial'))
+    elif kind == 'dggcn':                 # the original DG-STGCN (PYSKL dgstgcn configs): dggcn + dgmstcn on the random graph
+        backbone = dict(type='DGSTGCN', gcn_type='dggcn', gcn_ratio=0.125, gcn_ctr='T', gcn_ada='T', tcn_type='dgmstcn',
+                        graph_cfg=dict(layout='nturgb+d', mode='random', num_filter=3, init_off=.04, init_std=.02),
+                        tcn_ms_cfg=[(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1'])
     elif kind == 'stgcnpp':
         backbone = dict(type='STGCN', gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn',
                         graph_cfg=dict(layout='nturgb+d', mode='spatial'))

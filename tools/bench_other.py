@@ -1,6 +1,6 @@
 """Step time (fwd + bwd, hipGraph replay) of the other configurations that run on the same kernels:
     python tools/bench_other.py KIND [clips] [steps]
-KIND: stgcn (BASELINE config 1), ctrgcn (config 4, classic), ctrgcn_shipped (configs/ctrgcn/CTRGCN_model.py), stgcnpp,
+KIND: stgcn (BASELINE config 1), ctrgcn (config 4, classic), ctrgcn_shipped (configs/ctrgcn/CTRGCN_model.py), stgcnpp, aagcn, dggcn,
 ds120 (config 3 per-GPU: DS-STGCN NTU-120), ds_k400 (config 5 per-GPU: DS-STGCN coco V=17 T=100, 400 classes, 32 clips)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
