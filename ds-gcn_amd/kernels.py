@@ -154,8 +154,18 @@ def colsum_pair(ta, tb, split_last_b=False):
     elif ga == 1 and gb == 1:
         native.check(lib.dsgcn_colsum2(_ptr(ta), Ra, Ca, 1, _ptr(outa), _ptr(tb), Rb, Cb, kb, _ptr(outb), _stream()),
                      'dsgcn_colsum2')
+    elif ga == 1:
+        # only the second input is tall (the GEMM-form convs write one partial row per 128-position tile): its first
+        # stage rides with the whole first reduction, then its second stage alone — two launches, not three
+        mb = torch.empty(gb * Cb, device=dev, dtype=torch.float32)
+        native.check(lib.dsgcn_colsum2(_ptr(ta), Ra, Ca, 1, _ptr(outa), _ptr(tb), Rb // gb, gb * Cb, 1, _ptr(mb),
+                                       _stream()), 'dsgcn_colsum2')
+        outb = _colsum_raw(mb, gb, Cb, kb)
     else:
-        return colsum(ta), colsum(tb, split_last=split_last_b)
+        ma = torch.empty(ga * Ca, device=dev, dtype=torch.float32)
+        native.check(lib.dsgcn_colsum2(_ptr(ta), Ra // ga, ga * Ca, 1, _ptr(ma), _ptr(tb), Rb, Cb, kb, _ptr(outb),
+                                       _stream()), 'dsgcn_colsum2')
+        outa = _colsum_raw(ma, ga, Ca)
     return outa.view(ta.shape[1:]), (outb.view(kb, Cb // kb) if split_last_b else outb.view(tb.shape[1:]))
 
 

@@ -421,6 +421,18 @@ def test_colsum(R, C):
     assert rel(K_.colsum(t.cuda()).cpu(), t.double().sum(0)) < 1e-6
 
 
+@pytest.mark.parametrize('Ra,Ca,Rb,Cb', [(128, 4160, 100, 64), (512, 4160, 1600, 64), (1600, 300, 64, 4160), (4096, 96, 2048, 64),
+                                         (7, 3, 5, 2)])
+def test_colsum_pair(Ra, Ca, Rb, Cb):
+    """Two column sums sharing their launches: both short, only one tall (its first stage rides with the other's whole
+    reduction), both tall; the second one with its (C, 3) columns split into three contiguous vectors."""
+    ta, tb = torch.randn(Ra, Ca), torch.randn(Rb, Cb, 3)
+    a, b = K_.colsum_pair(ta.cuda(), tb.cuda(), split_last_b=True)
+    assert rel(a.cpu(), ta.double().sum(0)) < 1e-6
+    assert rel(b.cpu(), tb.double().sum(0).t()) < 1e-6
+    a2, b2 = K_.colsum_pair(ta.cuda(), tb.cuda())
+    assert rel(b2.cpu(), tb.double().sum(0)) < 1e-6 and rel(a2.cpu(), ta.double().sum(0)) < 1e-6
+
 
 @pytest.mark.parametrize('tag,layout,ci,co', [('v25', 'nturgb+d', 64, 64), ('v17', 'coco', 64, 128)])
 def test_dgphgcn1_kernels_vs_reference_intermediates(tag, layout, ci, co):
