@@ -895,6 +895,14 @@ int launch_bwd(const float* zp, const float* scale, const float* shift, int relu
     int waves = g_pipe_waves_bwd > 0 ? g_pipe_waves_bwd : (T == 32 ? 3072 : 2048);      // tools/ka_variants.py
     const long per = (units + waves - 1) / waves;
     const long g = (units + per - 1) / per;
+    if (T > 64) {      // four waves' slices of up to 128 frames can pass 64 KB (V = 25, T = 100: 90 KB)
+      static bool raised = false;
+      if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate_bwd_pipe<V, false, 128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+      }
+    }
     if (T > 64)        // the long clips of BASELINE config 5 (V = 17, T = 100 / 50): four 32-frame tiles per unit
       hipLaunchKernelGGL((k_aggregate_bwd_pipe<V, false, 128>), dim3((unsigned)((g + KA_WPB - 1) / KA_WPB)), dim3(64 * KA_WPB), lds * KA_WPB, st, zp, scale, shift,
                          relu, ahat, dy, dzp, dahat, partial, KC, T, units);

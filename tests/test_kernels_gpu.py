@@ -25,7 +25,9 @@ def maxabs(a, b):
 @pytest.mark.parametrize('n,KC,T,V,relu,affine', [
     (3, 24, 64, 25, True, True), (2, 48, 32, 25, True, True), (2, 96, 16, 25, True, True),
     (2, 24, 100, 17, True, True), (2, 10, 25, 17, True, True), (2, 6, 64, 25, False, False),
-    (1, 5, 7, 25, True, True), (2, 4, 130, 18, True, True)])
+    (1, 5, 7, 25, True, True), (2, 4, 130, 18, True, True),
+    (2, 6, 100, 25, True, True),        # 25 joints x 100 frames: the four-wave workgroup's LDS slices pass 64 KB
+    (1, 3, 128, 25, False, True)])
 def test_aggregate(n, KC, T, V, relu, affine):
     g = torch.Generator().manual_seed(n * 1000 + KC + T)
     zp = torch.randn(n, KC, T, V, generator=g)
