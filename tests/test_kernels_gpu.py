@@ -183,6 +183,33 @@ def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
         assert err < tol, (k, err)
 
 
+@pytest.mark.parametrize('Ci,Co,T', [(256, 256, 16), (128, 128, 32), (96, 256, 16)])
+def test_pwconv_bf16_terms_are_fp32_class(Ci, Co, T):
+    """The wide 1x1 convs carry every fp32 product as six bf16 MFMA terms of the exact three-way bf16 split of both
+    operands (csrc/common.h b3_split).  Claim pinned here: the error against an fp64 evaluation is that of an fp32 dot
+    product — measured 3.0e-7 (z), 2.4e-7 (dx), 2.2e-8 (dW) relative L2 at 256 -> 256, against 2.6e-7 / 2.9e-7 / 1.8e-8 for
+    the fp32 MFMA form (tools/kc_check.py) — an order of magnitude tighter than this file's generic 2e-5 bar, and three
+    orders below what a plain bf16 product would give (4e-3)."""
+    n, V = 6, 25
+    g = torch.Generator().manual_seed(Ci + Co)
+    x = _rand(g, n, Ci, T, V)
+    s1, h1 = torch.rand(Ci, generator=g) + 0.5, _rand(g, Ci, scale=0.1)
+    w = _rand(g, Co, Ci, 1, 1, scale=Ci ** -0.5)
+    b = _rand(g, Co, scale=0.1)
+    gz = _rand(g, n, Co, T, V)
+
+    def run(mod, dt, dev):
+        tx, tw, tb = (t.to(dev, dt).requires_grad_() for t in (x, w, b))
+        z = mod.pwconv(tx, (s1.to(dev, dt), h1.to(dev, dt)), None, None, True, tw, tb, 1, False)[0]
+        (z * gz.to(dev, dt)).sum().backward()
+        return z.detach().cpu(), tx.grad.cpu(), tw.grad.cpu()
+
+    got = run(K, torch.float32, DEV)
+    ref = run(R, torch.float64, 'cpu')
+    for name, a, r_, bar in zip(('z', 'dx', 'dW'), got, ref, (6e-7, 6e-7, 3e-7)):      # (dW at n = 6: 1.0-1.2e-7)
+        assert rel(a, r_) < bar, (name, rel(a, r_))
+
+
 @pytest.mark.parametrize('n,C,T,V,mode,tmean,flags', [
     (3, 64, 64, 25, 'res_plain', True, 1), (2, 128, 32, 25, 'res_affine', True, 1), (2, 64, 64, 25, 'affine', True, 1),
     (2, 256, 16, 25, 'res_plain', False, 1), (2, 12, 25, 17, 'res_affine', True, 1), (1, 5, 7, 18, 'plain', True, 1),
