@@ -211,8 +211,8 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
               }
             }
             const size_t go = ((size_t)n * Ci + row) * L + c0 + col;
-            *reinterpret_cast<f32x4*>(a.dx + go) = f32x4{dv.x * p.x, dv.y * p.x, dv.z * p.x, dv.w * p.x};
-            if constexpr (HAS2) *reinterpret_cast<f32x4*>(a.dx2 + go) = f32x4{dv.x * p.z, dv.y * p.z, dv.z * p.z, dv.w * p.z};
+            __builtin_nontemporal_store(f32x4{dv.x * p.x, dv.y * p.x, dv.z * p.x, dv.w * p.x}, reinterpret_cast<f32x4*>(a.dx + go));
+            if constexpr (HAS2) __builtin_nontemporal_store(f32x4{dv.x * p.z, dv.y * p.z, dv.z * p.z, dv.w * p.z}, reinterpret_cast<f32x4*>(a.dx2 + go));
           }
         }
       }
