@@ -412,7 +412,7 @@ int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, cons
                      int ld, int P, int E, void* stream) {
   if (!proj || !A || !alpha || !beta || !ahat || !we || !be || !node_type || !edge_type || n <= 0 || mid <= 0)
     return DSGCN_EINVAL;
-  if (V > 32 || mid > 32 || ld < V) return DSGCN_EUNSUPPORTED;
+  if (V > 32 || mid > 64 || ld < V) return DSGCN_EUNSUPPORTED;      // (the LDS check below is what bounds mid for a given E)
   // workgroups per sample: enough to fill the chip at small batches, each with a channel window of >= 4
   int split = n <= 128 ? (mid >= 16 ? 4 : 2) : (n <= 256 && mid >= 16 ? 2 : 1);
   if (split > mid) split = 1;
@@ -443,7 +443,7 @@ int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, c
   if (!proj || !alpha || !beta || !we || !be || !node_type || !edge_type || !dahat || !dd_ws || !dproj || !ppar ||
       n <= 0 || mid <= 0)
     return DSGCN_EINVAL;
-  if (V > 32 || mid > 32 || ld < V) return DSGCN_EUNSUPPORTED;
+  if (V > 32 || mid > 64 || ld < V) return DSGCN_EUNSUPPORTED;      // (the LDS check below is what bounds mid for a given E)
   if (pstride < dsgcn_dynadj_partial_stride(mid, V, E)) return DSGCN_EINVAL;
   const size_t lds = dyn_lds_bytes(mid, V, E, true, mid);
   if (lds > 158 * 1024) return DSGCN_EUNSUPPORTED;

@@ -493,6 +493,31 @@ def test_dgphgcn1_kernels_vs_reference_intermediates(tag, layout, ci, co):
     assert rel(out.cpu(), z[f'{tag}_out']) < 1e-5
 
 
+def test_dggcn_wide_vs_oracle():
+    """dggcn at its class-default ratio on the last stage (128 -> 256: mid = 64, above the fixtures' 16 / 32) against the
+    oracle's fp64 evaluation of the same state_dict."""
+    import dsgcn_amd as D
+    from oracle import dsgcn_oracle as O
+    torch.manual_seed(7)
+    A = torch.randn(3, 25, 25) * 0.02 + 0.04
+    m = D.dggcn(128, 256, A, ratio=0.25)
+    with torch.no_grad():
+        m.alpha.normal_(0, .5)
+        m.beta.normal_(0, .5)
+    sd = {k: v.detach().double() for k, v in m.state_dict().items()}
+    x = torch.randn(3, 128, 8, 25)
+    g = torch.randn(3, 256, 8, 25)
+    xo = x.double().requires_grad_()
+    yo = O.dggcn_forward(xo, sd)
+    (yo * g.double()).sum().backward()
+    m = m.cuda().train()
+    xg = x.cuda().requires_grad_()
+    y = m(xg)
+    (y * g.cuda()).sum().backward()
+    assert rel(y.detach().cpu(), yo.detach()) < 1e-5
+    assert rel(xg.grad.cpu(), xo.grad) < 5e-5
+
+
 @pytest.mark.parametrize('i', [0, 1])
 def test_unit_aagcn_vs_reference_fixture(i):
     """The 2s-AGCN / AAGCN unit (gcn.py:349-460) with the HIP channel mixes (embedding convs and conv_d as one K-C launch
