@@ -58,6 +58,9 @@ def other_cfg(kind, num_classes=60, **bk):
         backbone = dict(type='DGSTGCN', gcn_type='dggcn', gcn_ratio=0.125, gcn_ctr='T', gcn_ada='T', tcn_type='dgmstcn',
                         graph_cfg=dict(layout='nturgb+d', mode='random', num_filter=3, init_off=.04, init_std=.02),
                         tcn_ms_cfg=[(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1'])
+    elif kind == 'stgcn_shipped':         # configs/stgcn/STGCN_model.py: unit_gcn + unitmlp (k=9) on the random graph
+        backbone = dict(type='STGCN', gcn_adaptive='init', tcn_type='unitmlp', tcn_add_tcn=True, tcn_merge_after=True,
+                        graph_cfg=dict(layout='nturgb+d', mode='random', num_filter=3, init_off=.04, init_std=.02))
     elif kind == 'stgcnpp':
         backbone = dict(type='STGCN', gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn',
                         graph_cfg=dict(layout='nturgb+d', mode='spatial'))
@@ -162,84 +165,88 @@ MFMA_F32_PEAK_TF = 157.3        # MI355X_MICROARCH.md: f32-input MFMA = vector f
 MFMA_BF16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
-def measure_kc_roofline(device, n, reps=20):
+def measure_kc_roofline(device, n, reps=20, nsets=4):
     """K-C (1x1 channel mix) forward / data gradient / weight gradient through the C ABI, HIP-event timed, on the two
-    shapes that bracket the model: 64->64 at T=64 (16 FLOP/B: HBM-bound) and 256->256 at T=16 (64 FLOP/B: MFMA-bound).
-    Algorithmic bytes: inputs read once + outputs written once; flops 2*Ci*Co per position (fp32 products: `achieved` is
-    priced against the fp32 MFMA peak whatever instruction carries them).  The wide shape runs on the exact three-term
-    bf16 split of both operands (csrc/common.h b3_split: six v_mfma_f32_32x32x16_bf16 per 16 channels, fp32 accumulate,
-    fp32-class error: tools/kc_check.py); `mfma_util` there is the matrix pipe's own utilisation — six issued bf16
-    products per algorithmic one against the dense bf16 peak."""
+    shapes that bracket the model: 64->64 at T=64 (fp32 MFMA, 16 FLOP/B) and 256->256 at T=16 (six bf16 MFMA terms per
+    fp32 product, csrc/common.h b3_split).  Every launch works on one of `nsets` disjoint operand sets (0.6-0.8 GB in
+    rotation, beyond the 256 MiB Infinity Cache): HBM-cold operands, as in the step.
+    The roof of a launch is max(algorithmic bytes / 8 TB/s, ISSUED matrix flops / the peak of the instruction that
+    carries them): `frac` = roof time / measured time, `bound` names the larger term.  Algorithmic bytes: inputs read once
+    + outputs written once.  `fp32_equiv_tflops` (2*Ci*Co per position, whatever carries it) is context only."""
     from dsgcn_amd import native
     lib = native.lib()
     st = torch.cuda.current_stream().cuda_stream
     out = {}
+    P = lambda tt: tt.data_ptr()      # noqa: E731
     for Ci, Co, t in ((64, 64, 64), (256, 256, 16)):
-        x1 = torch.randn(n, Ci, t, V, device=device)
         s1 = torch.rand(Ci, device=device) + .5
         h1 = torch.randn(Ci, device=device) * .1
         w = torch.randn(Co, Ci, device=device) * Ci ** -.5
         b = torch.zeros(Co, device=device)
-        z = torch.empty(n, Co, t, V, device=device)
-        gz = torch.randn(n, Co, t, V, device=device)
         A0 = torch.randn(Co, device=device) * 1e-3
         B0 = torch.randn(Co, device=device) * 1e-3
-        dx = torch.empty_like(x1)
         part = torch.empty(lib.dsgcn_pwconv_partial_rows(n, Ci, Co, t, V, 1, 0), Co, 2, device=device)
         ipart = torch.empty(lib.dsgcn_pwconv_ipart_rows(n, Ci, Co, t, V, 1), Ci, 3, device=device)
         splits = lib.dsgcn_pwconv_wgrad_splits(n, Ci, Co, t, V, 1)
         pstride = Co * Ci + Co
         wpart = torch.empty(splits, pstride, device=device)
-        P = lambda tt: tt.data_ptr()      # noqa: E731
+        sets = [dict(x=torch.randn(n, Ci, t, V, device=device), z=torch.randn(n, Co, t, V, device=device),
+                     gz=torch.randn(n, Co, t, V, device=device), dx=torch.empty(n, Ci, t, V, device=device))
+                for _ in range(nsets)]
+        rows_f = lib.dsgcn_pwconv_bwd_rows(n, Ci, Co, t, V, 1)
+        wpf = torch.empty(max(rows_f, 1), pstride, device=device)
+        ipf = torch.empty(max(rows_f, 1), Ci, 3, device=device)
 
-        def fwd():
-            assert lib.dsgcn_pwconv_fwd(P(x1), P(s1), P(h1), None, None, None, 1, P(w), P(b), P(z), None, P(part), n, Ci,
-                                        Co, t, V, 1, 0, 1, st) == 0
+        def fwd(q):
+            assert lib.dsgcn_pwconv_fwd(P(q['x']), P(s1), P(h1), None, None, None, 1, P(w), P(b), P(q['z']), None, P(part),
+                                        n, Ci, Co, t, V, 1, 0, 1, st) == 0
 
-        def dgrad():
-            assert lib.dsgcn_pwconv_dgrad(P(x1), P(s1), P(h1), None, None, None, 1, P(w), P(z), None, P(gz), None, P(A0),
-                                          P(B0), P(dx), None, P(ipart), n, Ci, Co, t, V, 1, 0, st) == 0
+        def dgrad(q):
+            assert lib.dsgcn_pwconv_dgrad(P(q['x']), P(s1), P(h1), None, None, None, 1, P(w), P(q['z']), None, P(q['gz']),
+                                          None, P(A0), P(B0), P(q['dx']), None, P(ipart), n, Ci, Co, t, V, 1, 0, st) == 0
 
-        def wgrad():
-            assert lib.dsgcn_pwconv_wgrad(P(x1), P(s1), P(h1), None, None, None, 1, P(z), None, P(gz), None, P(A0), P(B0),
-                                          wpart.data_ptr(), wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, t, V, 1,
-                                          0, st) == 0
+        def wgrad(q):
+            assert lib.dsgcn_pwconv_wgrad(P(q['x']), P(s1), P(h1), None, None, None, 1, P(q['z']), None, P(q['gz']), None,
+                                          P(A0), P(B0), wpart.data_ptr(), wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci,
+                                          Co, t, V, 1, 0, st) == 0
+
+        def bwd(q):
+            assert lib.dsgcn_pwconv_bwd(P(q['x']), P(s1), P(h1), None, None, None, 1, P(w), P(q['z']), P(q['gz']), P(A0),
+                                        P(B0), P(q['dx']), None, P(ipf), wpf.data_ptr(), wpf.data_ptr() + 4 * Co * Ci,
+                                        pstride, n, Ci, Co, t, V, st) == 0
         L = n * t * V
         flops = 2.0 * Ci * Co * L
         jobs = [('fwd', fwd, 4 * L * (Ci + Co), 1), ('dgrad', dgrad, 4 * L * (2 * Co + 2 * Ci), 1),
                 ('wgrad', wgrad, 4 * L * (2 * Co + Ci), 1)]
-        rows_f = lib.dsgcn_pwconv_bwd_rows(n, Ci, Co, t, V, 1)
         if rows_f:        # narrow convs: the step runs both gradients as one pass (csrc/bwd64.hip)
-            wpf = torch.empty(rows_f, pstride, device=device)
-            ipf = torch.empty(rows_f, Ci, 3, device=device)
-
-            def bwd():
-                assert lib.dsgcn_pwconv_bwd(P(x1), P(s1), P(h1), None, None, None, 1, P(w), P(z), P(gz), P(A0), P(B0), P(dx),
-                                            None, P(ipf), wpf.data_ptr(), wpf.data_ptr() + 4 * Co * Ci, pstride, n, Ci,
-                                            Co, t, V, st) == 0
             jobs.append(('bwd', bwd, 4 * L * (2 * Co + 2 * Ci), 2))
+        wide = Ci > 64          # >= 128 channels: the bf16-term kernels (k_pwg, k_wg2<..., B3>)
         for name, fn, nbytes, nprod in jobs:
-            for _ in range(3):
-                fn()
+            for q in sets:
+                fn(q)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(reps):
-                fn()
+            for r in range(reps):
+                fn(sets[r % nsets])
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / reps * 1e3
             gbs, tf = nbytes / us / 1e3, nprod * flops / us / 1e6
-            hbm_bound = Ci <= 64
+            issued_tf = (6 if wide else 1) * tf
+            t_hbm = nbytes / (HBM_PEAK_GBS * 1e3)                                        # us
+            t_mfma = nprod * flops * (6 if wide else 1) / ((MFMA_BF16_PEAK_TF if wide else MFMA_F32_PEAK_TF) * 1e6)
+            hbm_bound = t_hbm >= t_mfma
             row = dict(
-                bound='hbm' if hbm_bound else 'mfma', achieved=round(gbs if hbm_bound else tf, 1),
-                peak=HBM_PEAK_GBS if hbm_bound else MFMA_F32_PEAK_TF, unit='GB/s' if hbm_bound else 'TFLOP/s',
-                frac=round((gbs / HBM_PEAK_GBS) if hbm_bound else (tf / MFMA_F32_PEAK_TF), 4), traffic=None,
-                avg_launch_us=round(us, 2), hbm_gbs=round(gbs, 1), mfma_tflops=round(tf, 1),
-                mfma_util=round(tf / MFMA_F32_PEAK_TF, 4))
-            if not hbm_bound:
-                row.update(arith='fp32 products as 6 bf16 MFMA terms of the exact 3-way bf16 split, fp32 accumulate',
-                           issued_bf16_tflops=round(6 * tf, 1), mfma_util=round(6 * tf / MFMA_BF16_PEAK_TF, 4))
+                bound='hbm' if hbm_bound else 'mfma', achieved=round(gbs if hbm_bound else issued_tf, 1),
+                peak=HBM_PEAK_GBS if hbm_bound else (MFMA_BF16_PEAK_TF if wide else MFMA_F32_PEAK_TF),
+                unit='GB/s' if hbm_bound else 'TFLOP/s', frac=round(max(t_hbm, t_mfma) / us, 4), traffic=None,
+                avg_launch_us=round(us, 2), roof_us=round(max(t_hbm, t_mfma), 2), hbm_gbs=round(gbs, 1),
+                hbm_frac=round(gbs / HBM_PEAK_GBS, 4), fp32_equiv_tflops=round(tf, 1),
+                mfma_instr='v_mfma_f32_32x32x16_bf16 x6 terms' if wide else 'v_mfma_f32_32x32x2_f32',
+                issued_tflops=round(issued_tf, 1),
+                mfma_util=round(issued_tf / (MFMA_BF16_PEAK_TF if wide else MFMA_F32_PEAK_TF), 4),
+                operands=f'{nsets} rotating sets, HBM-cold')
             out[f'k_pwconv_{name}_{Ci}x{Co}'] = row
     return out
 
@@ -378,95 +385,47 @@ def main():
     native.lib()   # fail loudly if the HIP library is missing
 
     model = build_model().to(device).train()
-    flat = dsgcn_amd.FlatParams(model, gather=True)
-    dp = dsgcn_amd.FlatDataParallel(flat)
-    opt = dsgcn_amd.FlatSGD(flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    # the step under test is the package's own training engine (ds-gcn_amd/engine.py): graph A (zero-grad + forward +
+    # backward + gradient packing) -> RCCL all-reduce of the flat gradient buffer -> graph B (SGD-nesterov update)
+    n_eager_warm = min(max(args.warmup, 1), 3) if not args.no_graph else args.warmup
+    engine = dsgcn_amd.TrainEngine(model, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True,
+                                   use_graph=not args.no_graph, warmup_eager=n_eager_warm, strict_graph=False,
+                                   extra_allreduce=force_dist)
+    flat = engine.flat
 
     B = args.clips_per_gpu
     g = torch.Generator().manual_seed(1234 + rank)
     keypoint = torch.randn(B, 1, M, T, V, C, generator=g).to(device)
     label = torch.randint(0, CLASSES, (B, 1), generator=g).to(device)
-    batch = dict(keypoint=keypoint, label=label)
 
     state = {}
 
-    def fwd_bwd():
-        opt.zero_grad()
-        out = model.train_step(batch, None, sync_log_vars=False)
-        out['loss'].backward()
-        flat.collect_grads()
-        state['loss'] = out['loss'].detach()
+    def step():
+        state['loss'] = engine.step(keypoint, label)['loss']
 
-    def exchange():
-        dp.allreduce_grads()
-        if force_dist and world == 1:
-            dist.all_reduce(flat.flat_g)      # 1-rank RCCL all-reduce: same call sequence as N > 1
-
-    def eager_step():
-        fwd_bwd()
-        exchange()
-        opt.step()
-
-    # untimed warm-up, eager (also populates caches: edge-class lists, momentum buffer, allocator pools)
-    n_eager_warm = min(args.warmup, 3) if not args.no_graph else args.warmup
-    for _ in range(n_eager_warm):
-        eager_step()
+    # untimed warm-up: the first steps run eagerly (caches: edge-class lists, allocator pools, pinned tables), then the
+    # engine captures the launch-bound inner loop (~800 kernels per step) into its two hipGraphs and replays them
+    for _ in range(max(args.warmup, n_eager_warm + 1) if not args.no_graph else args.warmup):
+        step()
     torch.cuda.synchronize()
-
-    # The launch-bound inner loop (~1.5k kernels per step) is captured once into hipGraphs and replayed:
-    # graph A = zero-grad + forward + backward, graph B = SGD update; the RCCL all-reduce stays between them.
-    use_graph = not args.no_graph
-    g_a = g_b = None
-    if use_graph:
-        capture_error = None
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                fwd_bwd()
-                opt.step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g_a = torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread polls its events while we capture (N > 1); in the default
-            # 'global' mode that would invalidate the capture.  Neither graph contains a collective: the log scalars
-            # stay rank-local in the captured step (train_step(sync_log_vars=False)) and the gradient all-reduce runs
-            # between the two replays.
-            with torch.cuda.graph(g_a, capture_error_mode='thread_local'):
-                fwd_bwd()
-            g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_b, capture_error_mode='thread_local'):
-                opt.step()
-            torch.cuda.synchronize()
-        except Exception as exc:
-            capture_error = f'{type(exc).__name__}: {exc}'
+    use_graph = engine.graphed(keypoint, label)
+    if not args.no_graph:
         # The graph-vs-eager decision is collective: ranks that replay and ranks that launch eagerly would issue the
         # same collectives, but a silently slower rank makes the aggregate number meaningless — so a failed capture is
         # an error at N > 1 (run with --no-graph to measure the eager path), and only a warning on one GPU.
-        ok = torch.tensor([0 if capture_error else 1], device=device, dtype=torch.int32)
+        ok = torch.tensor([1 if use_graph else 0], device=device, dtype=torch.int32)
         if world > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
-            msg = f'[bench] rank {rank}: hipGraph capture failed on at least one rank ({capture_error or "another rank"})'
+            msg = (f'[bench] rank {rank}: hipGraph capture failed on at least one rank '
+                   f'({engine.capture_error or "another rank"})')
             if world > 1:
                 print(msg + '; aborting (pass --no-graph for an eager run)', file=sys.stderr)
                 dist.destroy_process_group()
                 raise SystemExit(3)
             print(msg + '; running eagerly', file=sys.stderr)
-            use_graph = False
-            g_a = g_b = None
+            engine.use_graph = use_graph = False
 
-    def step():
-        if use_graph:
-            g_a.replay()
-            exchange()
-            g_b.replay()
-        else:
-            eager_step()
-
-    for _ in range(max(args.warmup - n_eager_warm, 0)):
-        step()
-    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -504,16 +463,22 @@ def main():
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
+    g_b = engine._graphs[(tuple(keypoint.shape), tuple(label.shape))][1] if use_graph else None
     for _ in range(10):
         if use_graph:
             g_b.replay()
         else:
-            opt.step()
+            engine.opt.step()
     e1.record()
     torch.cuda.synchronize()
     if rank == 0:
         result['optimizer_ms'] = round(e0.elapsed_time(e1) / 10, 3)
         result['fwd_bwd_ms'] = round(result['ms_per_step'] - result['optimizer_ms'], 3)
+    if rank == 0:
+        # fingerprint of the parameters after the run (W + K steps + the 10 update replays above): two runs of the same
+        # command must agree bit for bit, with or without the RCCL group (tests/test_model_gpu.py spawns both)
+        import hashlib
+        result['param_sha256'] = hashlib.sha256(flat.flat_p.detach().cpu().numpy().tobytes()).hexdigest()[:16]
     if rank == 0 and not args.no_roofline:
         rf = measure_ka_roofline(device, B * M)
         result['roofline'] = rf['k_aggregate_bwd'] | {'kernel': 'k_aggregate_bwd'}

@@ -22,5 +22,7 @@ from .pipeline import PIPELINES, DATASETS, Compose, PoseDataset, SkeletonStore, 
 from .data_parallel import FlatParams, FlatDataParallel, shard_batch
 from .train import FlatSGD, cosine_lr
 from .checkpoint import load_checkpoint, save_checkpoint, resume, find_resume, fuse_conv_bn
+from .engine import TrainEngine
+from .apis import train_model, EpochRunner, epoch_indices
 
 __version__ = '0.1.0'

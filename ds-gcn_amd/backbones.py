@@ -16,7 +16,7 @@ from . import kernels
 from .builder import BACKBONES
 from .gcn_units import dggcn, dgphgcn1, unit_aagcn, unit_ctrgcn, unit_ctrhgcn, unit_gcn, flush_running_stats
 from .graph import Graph
-from .tcn_units import MSTCN, dgmstcn, msmlp, mstcn, unit_tcn
+from .tcn_units import MSTCN, dgmstcn, msmlp, mstcn, unit_tcn, unitmlp
 
 EPS = 1e-4
 
@@ -119,14 +119,18 @@ class STGCNBlock(_FusedBlock):
         assert tcn_type in ['unit_tcn', 'mstcn', 'unit_tcnedge', 'unitmlp', 'msmlp']
         gcn_type = gcn_kwargs.pop('type', 'unit_gcn')
         assert gcn_type in ['unit_gcn', 'unit_gcnedge']
-        if gcn_type != 'unit_gcn' or tcn_type not in ('unit_tcn', 'mstcn'):
-            raise NotImplementedError(f'{gcn_type}/{tcn_type}: the HIP path covers unit_gcn with unit_tcn (ST-GCN) or '
-                                      'mstcn (ST-GCN++)')
+        if gcn_type != 'unit_gcn' or tcn_type not in ('unit_tcn', 'mstcn', 'unitmlp', 'msmlp'):
+            raise NotImplementedError(f'{gcn_type}/{tcn_type}: the HIP path covers unit_gcn with unit_tcn (ST-GCN), mstcn '
+                                      '(ST-GCN++), unitmlp (the shipped configs/stgcn/STGCN_model.py) or msmlp')
         self.gcn = unit_gcn(in_channels, out_channels, A, **gcn_kwargs)
         if tcn_type == 'unit_tcn':
             self.tcn = unit_tcn(out_channels, out_channels, 9, stride=stride, **tcn_kwargs)
-        else:
+        elif tcn_type == 'mstcn':
             self.tcn = mstcn(out_channels, out_channels, stride=stride, **tcn_kwargs)
+        elif tcn_type == 'unitmlp':
+            self.tcn = unitmlp(out_channels, out_channels, 9, stride=stride, **tcn_kwargs)
+        else:
+            self.tcn = msmlp(out_channels, out_channels, stride=stride, **tcn_kwargs)
         self.relu = nn.ReLU()
         self._set_residual(in_channels, out_channels, stride, residual)
 

@@ -70,34 +70,42 @@ def find_resume(work_dir, resume_from=None, auto_resume=True):
     return path if auto_resume and os.path.exists(path) else None
 
 
+def _fold(conv, bn):
+    import torch.nn as nn
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    conv.weight.mul_(scale.view(-1, *([1] * (conv.weight.dim() - 1))))
+    bias = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+    new_bias = (bias - bn.running_mean) * scale + bn.bias
+    if conv.bias is None:
+        conv.bias = nn.Parameter(new_bias)
+    else:
+        conv.bias.copy_(new_bias)
+    bn.weight.fill_(1.0)
+    bn.bias.zero_()
+    bn.running_mean.zero_()
+    bn.running_var.fill_(1.0 - bn.eps)          # so that 1 / sqrt(var + eps) is exactly 1
+
+
 @torch.no_grad()
 def fuse_conv_bn(module):
-    """Inference-time folding of every ``Conv2d -> BatchNorm2d`` pair that sits back to back in a container (what the
-    reference's ``tools/test.py --fuse-conv-bn`` does through mmcv.cnn.fuse_conv_bn, tools/test.py:98-99): the conv takes
-    ``w * gamma / sqrt(var + eps)`` and ``(b - mean) * gamma / sqrt(var + eps) + beta``, the BatchNorm becomes the identity
-    (gamma 1, beta 0, mean 0, var 1 - eps... kept as a BatchNorm2d so the module tree and state_dict keys do not change).
+    """Inference-time folding of ``Conv2d -> BatchNorm2d`` pairs (what the reference's ``tools/test.py --fuse-conv-bn`` asks
+    of mmcv.cnn.fuse_conv_bn, tools/test.py:98-99): the conv takes ``w * gamma / sqrt(var + eps)`` and ``(b - mean) * gamma /
+    sqrt(var + eps) + beta``, the BatchNorm becomes the identity (kept as a BatchNorm2d so the module tree and state_dict
+    keys do not change).  Only pairs where the BatchNorm really consumes the conv's output are folded: neighbours inside an
+    ``nn.Sequential`` (execution order = registration order), and the pairs a unit declares in ``fusable_pairs()`` —
+    registration order alone is not dataflow (in ``dggcn`` / ``dgphgcn1`` the projection convs are registered right before
+    ``self.bn``, which normalises ``post(...)``; with equal widths a by-order fold would silently change the outputs).
     Eval mode only: with training statistics the fold is meaningless.  Returns ``module``."""
     import torch.nn as nn
-    last_conv = None
-    for name, child in module.named_children():
-        if isinstance(child, nn.BatchNorm2d):
-            if last_conv is not None and child.track_running_stats and last_conv.out_channels == child.num_features:
-                scale = child.weight / torch.sqrt(child.running_var + child.eps)
-                last_conv.weight.mul_(scale.view(-1, 1, 1, 1))
-                bias = last_conv.bias if last_conv.bias is not None else torch.zeros_like(child.running_mean)
-                new_bias = (bias - child.running_mean) * scale + child.bias
-                if last_conv.bias is None:
-                    last_conv.bias = nn.Parameter(new_bias)
-                else:
-                    last_conv.bias.copy_(new_bias)
-                child.weight.fill_(1.0)
-                child.bias.zero_()
-                child.running_mean.zero_()
-                child.running_var.fill_(1.0 - child.eps)          # so that 1 / sqrt(var + eps) is exactly 1
-            last_conv = None
-        elif isinstance(child, nn.Conv2d):
-            last_conv = child
-        else:
-            last_conv = None
-            fuse_conv_bn(child)
+    for m in module.modules():
+        pairs = []
+        if isinstance(m, nn.Sequential):
+            kids = list(m.children())
+            pairs = [(a, b) for a, b in zip(kids[:-1], kids[1:])]
+        elif hasattr(m, 'fusable_pairs'):
+            pairs = list(m.fusable_pairs())
+        for conv, bn in pairs:
+            if (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and bn.track_running_stats
+                    and conv.out_channels == bn.num_features):
+                _fold(conv, bn)
     return module

@@ -1289,6 +1289,9 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
                        float* ipart, int n, int Ci, int Co, int T, int V, int stride, int aug, void* stream) {
   if (!x1 || !w || !dx1 || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0 || stride <= 0) return DSGCN_EINVAL;
   if ((A0 && (!B0 || !z)) || (aug && A0 && !zaug) || (x2 && !dx2)) return DSGCN_EINVAL;
+  // dsgcn_pwconv_ipart_rows sizes `ipart` for the wide-load plan, which needs gz: a NULL gz would drop to the scalar
+  // kernels and their (larger) row count — refuse instead of writing past the caller's buffer
+  if (!gz && ipart) return DSGCN_EINVAL;
   const int Tout = (T + stride - 1) / stride;
   hipStream_t st = (hipStream_t)stream;
   if (stride > 1) {

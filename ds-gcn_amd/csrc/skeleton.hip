@@ -50,12 +50,14 @@ __global__ __launch_bounds__(256) void k_skeleton_prep(SkArgs a) {
   float* __restrict__ o = a.out + idx * Cout;
   const int M = a.M[n], T = a.T[n], fl = a.flags[n];
   int m_src = mo;
-  if (mo >= M) {
-    if (!a.loop) {
-      for (int i = 0; i < Cout; ++i) o[i] = 0.f;
-      return;
-    }
-    m_src = 0;                                    // 'loop' padding repeats the first (formatted) person
+  if (a.loop && M < a.Mout) {
+    // FormatGCNInput(mode='loop') with fewer persons than slots: EVERY slot after the first repeats the first formatted
+    // person — the reference assigns keypoint[1:] = keypoint[0] after padding, overwriting a real second person too
+    // (pose_related.py:492-497)
+    if (mo >= 1) m_src = 0;
+  } else if (mo >= M) {
+    for (int i = 0; i < Cout; ++i) o[i] = 0.f;
+    return;
   }
   const int pm = (fl & 1) ? 1 - m_src : m_src;    // swap: the formatted person 0 is raw person 1
   const bool masked = (fl & 2) != 0;
@@ -79,6 +81,9 @@ __global__ __launch_bounds__(256) void k_skeleton_prep(SkArgs a) {
     sk_joint(a, base, T, pm, fb, v, masked, c, m, j1);
     if (need_b) sk_joint(a, base, T, pm, fb, par, masked, c, m, p1);
   }
+  // fl bit 2: fp16-sourced clip without rotation — the reference builds bones and joint motion by numpy arithmetic on the
+  // fp16 arrays (differences and score sums round to fp16) and stores bones in an fp32 array (bone motion: fp32 arithmetic)
+  const bool h16 = (fl & 4) != 0;
   for (int i = 0; i < a.nfeat; ++i) {
     const int code = (a.fmask >> (2 * i)) & 3;    // 0 j, 1 b, 2 jm, 3 bm
     float cur[3], nxt[3];
@@ -86,13 +91,27 @@ __global__ __launch_bounds__(256) void k_skeleton_prep(SkArgs a) {
     for (int k = 0; k < 3; ++k) {
       cur[k] = (code & 1) ? j0[k] - p0[k] : j0[k];
       nxt[k] = (code & 1) ? j1[k] - p1[k] : j1[k];
+      if ((code & 1) && h16) { cur[k] = (float)(_Float16)cur[k]; nxt[k] = (float)(_Float16)nxt[k]; }
     }
-    if ((code & 1) && a.scored) { cur[2] = 0.5f * (j0[2] + p0[2]); nxt[2] = 0.5f * (j1[2] + p1[2]); }
+    if ((code & 1) && a.scored) {
+      float s0 = j0[2] + p0[2], s1 = j1[2] + p1[2];
+      if (h16) { s0 = (float)(_Float16)s0; s1 = (float)(_Float16)s1; }
+      cur[2] = 0.5f * s0; nxt[2] = 0.5f * s1;
+    }
     float val[3];
     if (code & 2) {
+      const bool r16 = h16 && code == 2;          // joint motion stays in the fp16 array; bone motion is fp32 arithmetic
 #pragma unroll
-      for (int k = 0; k < 3; ++k) val[k] = fb >= 0 ? nxt[k] - cur[k] : 0.f;
-      if (a.scored) val[2] = fb >= 0 ? 0.5f * (cur[2] + nxt[2]) : 0.f;
+      for (int k = 0; k < 3; ++k) {
+        float d = nxt[k] - cur[k];
+        if (r16) d = (float)(_Float16)d;
+        val[k] = fb >= 0 ? d : 0.f;
+      }
+      if (a.scored) {
+        float sm = cur[2] + nxt[2];
+        if (r16) sm = (float)(_Float16)sm;
+        val[2] = fb >= 0 ? 0.5f * sm : 0.f;
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 3; ++k) val[k] = cur[k];

@@ -381,7 +381,7 @@ int dsgcn_tms_combine_bwd(const float* o, const float* coeff, const float* gf, c
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int DW_MAXK = 4;
+constexpr int DW_MAXK = 5;      // unitmlp kernel 9 (ST-GCN temporal unit) -> 5 causal taps; msmlp kernel 3 -> 2
 
 __global__ __launch_bounds__(64) void k_dwcausal_fwd(const float* __restrict__ h, const float* __restrict__ w,
                                                      const float* __restrict__ b, const int* __restrict__ dil,
@@ -484,7 +484,7 @@ int dsgcn_dwcausal_fwd(const float* h, const float* w, const float* b, const int
   return 0;
 }
 
-// part (n*C, 5): per-plane [dw_0, dw_1, dw_2, dw_3, db]; the sum over n gives the parameter gradients
+// part (n*C, 6): per-plane [dw_0 .. dw_4, db]; the sum over n gives the parameter gradients
 int dsgcn_dwcausal_bwd(const float* h, const float* w, const int* dil, const float* dy, float* dh, float* part, int n,
                        int C, int T, int V, int stride, int KM, void* stream) {
   if (!h || !w || !dil || !dy || !dh || !part || n <= 0 || C <= 0 || T <= 0 || V <= 0 || stride <= 0 || KM < 1 ||

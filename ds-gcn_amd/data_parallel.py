@@ -153,7 +153,11 @@ class FlatParams:
 
 
 class FlatDataParallel:
-    """Gradient averaging across ranks for a ``FlatParams`` (no-op at world size 1)."""
+    """Gradient averaging across ranks for a ``FlatParams`` (no-op at world size 1).  At wrap time rank 0's parameters
+    AND buffers (BatchNorm running statistics, ``num_batches_tracked``, ``backbone.A``) are broadcast once — what torch
+    DDP's constructor does with the module state (``_sync_module_states``: parameters and buffers) even under the
+    reference's ``broadcast_buffers=False`` (pyskl/apis/train.py:98-102), which only switches the PER-STEP buffer sync
+    off: BatchNorm statistics then evolve rank-locally, as here."""
 
     def __init__(self, flat, process_group=None, broadcast_params=True):
         self.flat = flat
@@ -161,6 +165,22 @@ class FlatDataParallel:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         if self.world > 1 and broadcast_params:
             dist.broadcast(self.flat.flat_p, src=0, group=process_group)     # C1b: params rank0 -> all
+            self._broadcast_buffers()
+
+    @torch.no_grad()
+    def _broadcast_buffers(self):
+        """All module buffers in two packed collectives (floating / integer) instead of one per tensor."""
+        bufs = [b for b in self.flat.module.buffers() if b.numel() > 0]
+        for pick, dt in ((lambda b: b.dtype.is_floating_point, self.flat.flat_p.dtype), (lambda b: not b.dtype.is_floating_point, torch.int64)):
+            grp = [b for b in bufs if pick(b)]
+            if not grp:
+                continue
+            packed = torch.cat([b.detach().reshape(-1).to(dt) for b in grp])
+            dist.broadcast(packed, src=0, group=self.group)
+            off = 0
+            for b in grp:
+                b.copy_(packed[off:off + b.numel()].view_as(b).to(b.dtype))
+                off += b.numel()
 
     def allreduce_grads(self):
         if self.world > 1:

@@ -180,6 +180,11 @@ class dgphgcn1(nn.Module):
         return [[self.conv1.weight, self.conv2.weight, self.conv1_se.weight],
                 [self.conv1.bias, self.conv2.bias, self.conv1_se.bias]]
 
+    def fusable_pairs(self):
+        """(conv, bn) pairs whose BatchNorm consumes the conv's output directly (checkpoint.fuse_conv_bn); `pre` and
+        `down` are Sequential(conv, bn)."""
+        return [(self.post, self.bn)]
+
     def adjacency(self, xbar):
         """Ahat (n, K*mid, V, V) from the time-averaged input xbar (n, Ci, V)."""
         c1, c2, cs, el = self.conv1, self.conv2, self.conv1_se, self.edge_linears
@@ -275,6 +280,9 @@ class dggcn(nn.Module):
         self.register_buffer('_nt0', torch.zeros(V, dtype=torch.int32), persistent=False)
         self.register_buffer('_et0', torch.zeros(V, V, dtype=torch.int32), persistent=False)
         self.register_buffer('_we_eye', torch.eye(mid), persistent=False)
+
+    def fusable_pairs(self):
+        return [(self.post, self.bn)]
 
     def adjacency(self, xbar):
         """Ahat (n, K*mid, V, V) from the time-averaged input xbar (n, Ci, V)."""
@@ -469,6 +477,10 @@ class unit_gcn(nn.Module):
         self.down = None
         if with_res and in_channels != out_channels:
             self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), _norm_layer(norm, out_channels))
+
+    def fusable_pairs(self):
+        # conv_pos='pre': the aggregate sits between conv and bn (the bias does not commute with it): nothing to fold
+        return [(self.conv, self.bn)] if self.conv_pos == 'post' else []
 
     def effective_A(self):
         if self.adaptive == 'offset':

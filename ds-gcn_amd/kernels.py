@@ -395,6 +395,11 @@ class _PwConv(torch.autograd.Function):
                                        n_affine, _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), st)
             native.check(rc, 'dsgcn_bn_bwd_coef')
         Tout = z.shape[2]
+        if gz is None:
+            # z itself received no gradient (only its statistics did): the kernels size their partial rows for the
+            # wide-load path, which needs the operand — hand them explicit zeros instead of a NULL (the scalar
+            # fallback taken for a NULL wrote more ipart rows than dsgcn_pwconv_ipart_rows reports)
+            gz = torch.zeros_like(z)
         if aug:
             # fold the statistics terms and the global-joint gradient once; dgrad / wgrad then run in plain mode
             dzeff = torch.empty_like(z)
@@ -783,12 +788,12 @@ class _DwCausal(torch.autograd.Function):
         KM = w.shape[1]
         dy = _f32c(dy)
         dh = torch.empty_like(h)
-        part = torch.empty((n, C, 5), device=h.device, dtype=torch.float32)
+        part = torch.empty((n, C, 6), device=h.device, dtype=torch.float32)
         rc = native.lib().dsgcn_dwcausal_bwd(_ptr(h), _ptr(w), _ptr(dil), _ptr(dy), _ptr(dh), _ptr(part), n, C, T, V,
                                              stride, KM, _stream())
         native.check(rc, 'dsgcn_dwcausal_bwd')
-        red = colsum(part)                                    # (C, 5)
-        return dh, red[:, :KM].contiguous(), (red[:, 4].contiguous() if has_b else None), None, None
+        red = colsum(part)                                    # (C, 6): [dw_0 .. dw_4, db]
+        return dh, red[:, :KM].contiguous(), (red[:, 5].contiguous() if has_b else None), None, None
 
 
 def temporal_mlp_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, dw_w, dw_b, dw_dil, pw_w, pw_b,
@@ -813,6 +818,23 @@ def temporal_mlp_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, 
         u = fuse_out(dw, None, o, None, 0, False)[0]
         out = pwconv(u, None, None, None, False, pw_w, pw_b, 1, False)[0]
     return _plane_bn(out, gamma, beta, eps, want_bn)
+
+
+def temporal_unitmlp_bn(h, dw_w, dw_b, dw_dil, tw, tb, tdil, pw_w, pw_b, merge_after, stride, gamma=None, beta=None,
+                        eps=1e-5, want_bn=False):
+    """``unitmlp`` as a whole temporal unit (ST-GCN with tcn_type='unitmlp': stgcn.py:51-52 over tcn.py:525-614) on a
+    materialised input h (n,C,T,V): depthwise causal taps (dsgcn_dwcausal), the dense (k,1) conv already scaled by alpha
+    (tw / tb, None without add_tcn), the 1x1 conv after (merge_after) or before the add, plus the train-mode BN of the
+    result as a deferred affine.  -> (out, scale, shift, mean, var)"""
+    _require_cuda(h)
+    dw = _DwCausal.apply(h, dw_w, dw_b, dw_dil, int(stride))
+    t = tconv(h, tw, tb, stride, tdil)[0] if tw is not None else None
+    if t is not None and merge_after:
+        u = pwconv(dw, None, None, None, False, pw_w, pw_b, 1, False)[0]
+        return _plane_bn(fuse_out(u, None, t, None, 0, False)[0], gamma, beta, eps, want_bn)
+    u = dw if t is None else fuse_out(dw, None, t, None, 0, False)[0]
+    z, _, sc, sh, mean, var = pwconv(u, None, None, None, False, pw_w, pw_b, 1, False, gamma, beta, eps, None, want_bn)
+    return z, sc, sh, mean, var
 
 
 def strided_frames(x, stride):

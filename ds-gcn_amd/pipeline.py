@@ -420,25 +420,69 @@ class PoseDataset(torch.utils.data.Dataset):
 
 class SkeletonStore:
     """Raw clips of a dataset packed into ONE device buffer (ragged: each clip keeps its own M and T).
-    ``annotations``: sequence of dicts with 'keypoint' (M, T, V, C) [+ 'label', 'total_frames']."""
+    ``annotations``: sequence of dicts with 'keypoint' (M, T, V, C) [+ 'label', 'total_frames'] and, for 2-D pose pickles,
+    'keypoint_score' (M, T, V) and 'img_shape' (h, w).  A score rides as channel 2 behind the two coordinates (what
+    ``GenSkeFeat`` builds, pose_related.py:427-432); ``coordC`` is the number of coordinate channels the geometric
+    transforms act on, ``C`` the channels per joint in the buffer."""
 
     def __init__(self, annotations, device='cuda'):
-        kps = [np.ascontiguousarray(a['keypoint'], dtype=np.float32) for a in annotations]
-        self.V, self.C = kps[0].shape[2], kps[0].shape[3]
-        assert all(k.shape[2:] == (self.V, self.C) for k in kps), 'clips must share the joint layout'
-        self.M = np.array([k.shape[0] for k in kps], dtype=np.int32)
-        self.T = np.array([k.shape[1] for k in kps], dtype=np.int32)
-        sizes = np.array([k.size for k in kps], dtype=np.int64)
+        self.src = [np.ascontiguousarray(a['keypoint']) for a in annotations]          # original dtype (see normalize2d)
+        self.scores = [a.get('keypoint_score') for a in annotations]
+        self.img_shapes = [tuple(a['img_shape']) if a.get('img_shape') is not None else None for a in annotations]
+        self.V, self.coordC = self.src[0].shape[2], self.src[0].shape[3]
+        assert all(k.shape[2:] == (self.V, self.coordC) for k in self.src), 'clips must share the joint layout'
+        has_score = [s is not None for s in self.scores]
+        if any(has_score):
+            if not all(has_score) or self.coordC != 2:
+                raise ValueError("'keypoint_score' must accompany every clip, and only 2-D keypoints carry one")
+        self.C = self.coordC + (1 if any(has_score) else 0)
+        self.M = np.array([k.shape[0] for k in self.src], dtype=np.int32)
+        self.T = np.array([k.shape[1] for k in self.src], dtype=np.int32)
+        sizes = np.array([k.size // self.coordC * self.C for k in self.src], dtype=np.int64)
         self.offset = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
         self.labels = np.array([int(a.get('label', -1)) for a in annotations], dtype=np.int64)
-        self.host = kps                       # the decisions read a few frames of the raw clip on the host
-        flat = torch.from_numpy(np.concatenate([k.reshape(-1) for k in kps]))
-        self.data = flat.to(device)
+        self.device = device
+        self.norm2d_shape = None
+        if not torch.device(device).type == 'cuda':
+            raise RuntimeError('SkeletonStore keeps the clips in HBM: it needs a CUDA/ROCm device (no CPU fallback)')
+        self._upload(self.src)
+
+    def _upload(self, kps):
+        host = []
+        for k, sc in zip(kps, self.scores):
+            k32 = k.astype(np.float32)
+            if sc is not None:
+                k32 = np.concatenate([k32, np.asarray(sc, dtype=np.float32)[..., None]], -1)
+            host.append(np.ascontiguousarray(k32))
+        self.host = host                      # the decisions read a few frames of the clip on the host
+        self.data = torch.from_numpy(np.concatenate([k.reshape(-1) for k in host])).to(self.device)
         if not self.data.is_cuda:
             raise RuntimeError('SkeletonStore keeps the clips in HBM: it needs a CUDA/ROCm device (no CPU fallback)')
 
+    def normalize2d(self, default_img_shape):
+        """``PreNormalize2D`` (pose_related.py:130-140) for the whole store, once: the transform is deterministic, so it is
+        applied when the pipeline first asks for it instead of per epoch — on the host, in each clip's OWN dtype and with
+        its own ``img_shape`` (the reference normalises in place: an fp16 pickle is rounded to fp16 here too), then the
+        buffer is re-uploaded."""
+        shape = tuple(default_img_shape)
+        if self.norm2d_shape is not None:
+            if self.norm2d_shape != shape:
+                raise ValueError('SkeletonStore was already normalised with another default img_shape')
+            return
+        if self.coordC != 2:
+            raise ValueError('PreNormalize2D applies to 2-D keypoints')
+        out = []
+        for k, ishape in zip(self.src, self.img_shapes):
+            h, w = ishape if ishape is not None else shape
+            k = k.copy()
+            k[..., 0] = (k[..., 0] - (w / 2)) / (w / 2)
+            k[..., 1] = (k[..., 1] - (h / 2)) / (h / 2)
+            out.append(k)
+        self.norm2d_shape = shape
+        self._upload(out)
+
     def __len__(self):
-        return len(self.host)
+        return len(self.src)
 
 
 class SkeletonBatcher:
@@ -485,12 +529,15 @@ class SkeletonBatcher:
         N = len(indices)
         clip_len, num_clips = self.sample.clip_len, self.sample.num_clips
         F = num_clips * clip_len
-        C = store.C
+        if self.norm2d is not None:
+            store.normalize2d(self.norm2d.img_shape)      # once per store (deterministic): per-clip img_shape, source dtype
+        if self.norm3d is not None and store.coordC != 3:
+            raise ValueError('PreNormalize3D needs 3-D keypoints')
         p = dict(offset=np.zeros(N, np.int64), M=np.zeros(N, np.int32), T=np.zeros(N, np.int32),
                  flags=np.zeros(N, np.int32), center=np.zeros((N, 3), np.float32), matrix=np.zeros((N, 9), np.float32),
                  f0=np.zeros((N, F), np.int32), f1=np.zeros((N, F), np.int32), label=np.zeros(N, np.int64))
         for row, idx in enumerate(indices):
-            kp = store.host[idx]
+            kp = store.host[idx][..., :store.coordC]          # coordinates only: a score channel is not geometry
             M, T = kp.shape[:2]
             frames, swap, masked = np.arange(T), False, False
             center, mat = np.zeros(3), np.eye(3)
@@ -505,13 +552,9 @@ class SkeletonBatcher:
                         kept = kp[:, frames]            # RandomRot's "nothing to rotate" test sees the centred clip
                         allzero = bool(np.all(np.isclose((kept - center) * ((kept != 0).sum(-1) > 0)[..., None], 0)))
                     mat = d['matrix']
-            elif self.norm2d is not None:
-                h, w = self.norm2d.img_shape
-                center = np.array([w / 2, h / 2, 0.0])
-                mat = np.diag([2.0 / w, 2.0 / h, 1.0])
             if self.rot is not None and not allzero:
-                r = self.rot.draw(C)
-                if C == 2:
+                r = self.rot.draw(store.coordC)
+                if store.coordC == 2:
                     r3 = np.eye(3)
                     r3[:2, :2] = r
                     r = r3
@@ -520,7 +563,9 @@ class SkeletonBatcher:
                                          self.sample.seed)
             nxt = np.where(inds + 1 < len(frames), inds + 1, -1)
             p['offset'][row], p['M'][row], p['T'][row] = store.offset[idx], M, T
-            p['flags'][row] = (1 if swap else 0) | (2 if masked else 0)
+            rotated = self.rot is not None and not allzero
+            half = store.src[idx].dtype == np.float16 and not rotated and self.norm3d is None   # fp16 feature arithmetic
+            p['flags'][row] = (1 if swap else 0) | (2 if masked else 0) | (4 if half else 0)
             p['center'][row], p['matrix'][row] = center, mat.reshape(-1)
             p['f0'][row] = frames[inds]
             p['f1'][row] = np.where(nxt >= 0, frames[np.maximum(nxt, 0)], -1)

@@ -30,6 +30,9 @@ class unit_tcn(nn.Module):
         self.drop = nn.Dropout(dropout, inplace=True)
         self.stride = stride
 
+    def fusable_pairs(self):
+        return [(self.conv, self.bn)]
+
     def forward_deferred(self, x):
         """x: tensor or Deferred -> Deferred(z, bn affine) (dropout must be 0 on this path)."""
         ops = kernels.ops()
@@ -129,6 +132,9 @@ class dgmstcn(nn.Module):
 
     def _first_convs(self):
         return [b if isinstance(b, nn.Conv2d) else b[0] for b in self.branches]
+
+    def fusable_pairs(self):
+        return [(self.transform[2], self.bn)]
 
     def flat_groups(self):
         """Parameter tensors the forward concatenates: FlatParams lays each group out back to back, so the
@@ -375,6 +381,42 @@ class unitmlp(nn.Module):
                 self.register_buffer('alpha', torch.ones(1))
         self.bn = _norm_layer(norm, out_channels) if norm is not None else nn.Identity()
         self.drop = nn.Dropout(dropout, inplace=True)
+        self.register_buffer('dw_dil', torch.full((out_channels,), int(dilation), dtype=torch.int32), persistent=False)
+
+    def fusable_pairs(self):
+        # conv1 feeds the BatchNorm directly only when nothing is added after it
+        return [(self.conv1, self.bn)] if not (self.add_tcn and self.merge_after) else []
+
+    def forward_deferred(self, x):
+        """The unit on its own (``STGCN(tcn_type='unitmlp')``, stgcn.py:51-52 — the reference's shipped
+        configs/stgcn/STGCN_model.py): x tensor or Deferred -> Deferred(out, affine of self.bn)."""
+        ops = kernels.ops()
+        d = as_deferred(x)
+        h = d.x1 if (d.a1 is None and d.x2 is None and not d.relu) else d.materialize()
+        tw = tb = None
+        if self.add_tcn:                          # KB-sized products on parameters; autograd returns d alpha
+            tw, tb = self.conv2.weight * self.alpha, self.conv2.bias * self.alpha
+        args = (h, self.conv.weight.flatten(1), self.conv.bias, self.dw_dil, tw, tb, self.dilation,
+                self.conv1.weight.flatten(1), self.conv1.bias, self.merge_after, self.stride)
+        if not isinstance(self.bn, nn.BatchNorm2d):
+            return Deferred(ops.temporal_unitmlp_bn(*args)[0], None, None, None, False)
+        out, a = op_bn(self.bn, lambda g, b, eps, want: ops.temporal_unitmlp_bn(*args, g, b, eps, want),
+                       lambda o: o.shape[0] * o.shape[2] * o.shape[3])
+        return Deferred(out, a, None, None, False)
+
+    def forward(self, x):
+        out = self.forward_deferred(x).materialize()
+        flush_running_stats()
+        return self.drop(out) if self.drop.p > 0 else out
+
+    def init_weights(self):
+        # reference: tcn.py:611-614 (conv_init = kaiming_normal fan_out + zero bias; bn_init(bn, 1))
+        for c in (self.conv, self.conv1):
+            nn.init.kaiming_normal_(c.weight, mode='fan_out')
+            nn.init.constant_(c.bias, 0)
+        if isinstance(self.bn, nn.BatchNorm2d):
+            nn.init.constant_(self.bn.weight, 1)
+            nn.init.constant_(self.bn.bias, 0)
 
 
 class msmlp(dgmstcn):

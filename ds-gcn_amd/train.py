@@ -8,9 +8,14 @@ import torch
 
 class FlatSGD:
     """Nesterov SGD over ``FlatParams`` buffers: a handful of elementwise launches per step regardless of
-    the 604 parameter tensors.  Matches torch.optim.SGD(nesterov=True, dampening=0) update-for-update."""
+    the 604 parameter tensors.  Matches torch.optim.SGD(nesterov=True, dampening=0) update-for-update.
 
-    def __init__(self, flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True):
+    ``capturable=True`` keeps the learning rate in a one-element device tensor (``set_lr`` fills it): a ``step()`` captured
+    in a hipGraph then follows the per-iteration schedule on replay instead of freezing the rate of the capture.  The
+    momentum buffer is allocated once and only ever written in place (``load_state_dict`` included), so a captured
+    ``step()`` keeps updating the live buffer after a resume."""
+
+    def __init__(self, flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True, capturable=False):
         self.flat = flat
         self.lr = lr
         self.base_lr = lr
@@ -18,6 +23,15 @@ class FlatSGD:
         self.weight_decay = weight_decay
         self.nesterov = nesterov
         self.buf = None
+        self.capturable = capturable
+        self.lr_t = torch.full((1,), float(lr), device=flat.flat_p.device, dtype=flat.flat_p.dtype) if capturable else None
+        if capturable and momentum:
+            self.buf = torch.zeros_like(flat.flat_p)       # torch's first step sets buf = g; momentum * 0 + g is the same value
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+        if self.lr_t is not None:
+            self.lr_t.fill_(self.lr)
 
     @torch.no_grad()
     def step(self):
@@ -30,7 +44,10 @@ class FlatSGD:
             else:
                 self.buf.mul_(self.momentum).add_(g)
             g = g.add(self.buf, alpha=self.momentum) if self.nesterov else self.buf
-        p.add_(g, alpha=-self.lr)
+        if self.capturable:
+            p.addcmul_(g, self.lr_t, value=-1.0)
+        else:
+            p.add_(g, alpha=-self.lr)
 
     def zero_grad(self):
         self.flat.zero_grad()
@@ -40,7 +57,7 @@ class FlatSGD:
         entry per parameter tensor in ``module.parameters()`` order — so the ``optimizer`` entry of a checkpoint is
         interchangeable with the reference's (mmcv saves ``optimizer.state_dict()`` of a torch SGD).  CPU tensors."""
         state = {}
-        if self.buf is not None:
+        if self.buf is not None and (not self.capturable or bool(self.buf.any())):     # all-zero = no step taken yet
             for i, (p, (off, n)) in enumerate(zip(self.flat.params, self.flat.slices)):
                 state[i] = {'momentum_buffer': self.buf[off:off + n].view(p.shape).detach().cpu().clone()}
         group = dict(lr=self.lr, momentum=self.momentum, dampening=0, weight_decay=self.weight_decay,
@@ -55,16 +72,21 @@ class FlatSGD:
             raise ValueError('FlatSGD.load_state_dict: expected one param group over '
                              f'{len(self.flat.params)} tensors, got {[len(g["params"]) for g in groups]}')
         g = groups[0]
-        self.lr = g['lr']
+        self.set_lr(g['lr'])
         self.base_lr = g.get('initial_lr', self.base_lr)
         self.momentum = g.get('momentum', self.momentum)
         self.weight_decay = g.get('weight_decay', self.weight_decay)
         self.nesterov = g.get('nesterov', self.nesterov)
         state = sd.get('state', {})
         if not state:
-            self.buf = None
+            if self.capturable and self.buf is not None:
+                self.buf.zero_()
+            else:
+                self.buf = None
             return
-        buf = torch.zeros_like(self.flat.flat_p)
+        # in place when the buffer exists: a hipGraph captured around step() holds its address
+        buf = self.buf if self.buf is not None else torch.zeros_like(self.flat.flat_p)
+        buf.zero_()
         for i, pid in enumerate(g['params']):
             mb = state.get(pid, state.get(str(pid), {})).get('momentum_buffer')
             if mb is not None:

@@ -216,9 +216,9 @@ int dsgcn_pack(const float* const* src_table, const long* dst_offsets, const int
                void* stream);
 
 /* Depthwise causal temporal taps of unitmlp (tcn.py:525-614: left zero pad + grouped Conv1d, groups = channels):
- *   y[n,c,t',v] = b[c] + sum_{j<KM} w[c,j] * h[n,c, t'*stride - (KM-1-j)*dil[c], v]   (frames < 0 read as zero), KM <= 4;
+ *   y[n,c,t',v] = b[c] + sum_{j<KM} w[c,j] * h[n,c, t'*stride - (KM-1-j)*dil[c], v]   (frames < 0 read as zero), KM <= 5;
  * dil (C) int32, 0 = channel outside the mlp windows (y = 0, dh = 0).  h (n,C,T,V); y (n,C,ceil(T/stride),V); w (C,KM).
- * Backward: dh (n,C,T,V), part (n*C, 5) = per-plane [dw_0..dw_3, db] (dsgcn_colsum over n finishes them). */
+ * Backward: dh (n,C,T,V), part (n*C, 6) = per-plane [dw_0..dw_4, db] (dsgcn_colsum over n finishes them). */
 int dsgcn_dwcausal_fwd(const float* h, const float* w, const float* b, const int* dil, float* y, int n, int C, int T,
                        int V, int stride, int KM, void* stream);
 int dsgcn_dwcausal_bwd(const float* h, const float* w, const int* dil, const float* dy, float* dh, float* part, int n,
@@ -233,8 +233,11 @@ int dsgcn_dwcausal_bwd(const float* h, const float* w, const int* dil, const flo
  *   subtraction);  center (N,3);  matrix (N,9) row-major, applied after centring;  f0 / f1 (N, clips*clip_len): original
  *   frame of each output frame and of its successor in the kept sequence (-1 = none: motion features are 0);
  *   parent (V): bone parent of each joint;  fmask: 2 bits per feature (0 j, 1 b, 2 jm, 3 bm), nfeat features;
- *   scored: third channel is a confidence (2-D layouts: bone / motion entries average it);  loop: pad missing persons
- *   with person 0 instead of zeros.   out (N, clips, Mout, clip_len, V, C*nfeat). */
+ *   scored: third channel is a confidence (2-D layouts: bone / motion entries average it);  loop: with fewer persons
+ *   than slots every slot after the first repeats person 0 (FormatGCNInput mode='loop', pose_related.py:492-497);
+ *   flags[n] bit 2: the clip came from an fp16 pickle and is not rotated — its bone / motion differences are rounded to
+ *   fp16 like the reference's in-place numpy arithmetic on the pickle's dtype (GenSkeFeat runs before PoseDecode's cast
+ *   to fp32, pose_related.py:340-412).   out (N, clips, Mout, clip_len, V, C*nfeat). */
 int dsgcn_skeleton_prep(const float* raw, const long* offset, const int* M, const int* T, const int* flags,
                         const int* f0, const int* f1, const float* center, const float* matrix, const int* parent,
                         float* out, int N, int clips, int Mout, int clip_len, int V, int C, int nfeat, int fmask,

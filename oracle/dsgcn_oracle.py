@@ -480,10 +480,13 @@ def unit_gcn_forward(x, sd, training=True, with_res=False, adaptive='init', conv
     return F.relu(y)                                                                  # gcn.py:94
 
 
-def stgcn_block_forward(x, sd, stride, residual, training=True, with_res=False, tcn_type='unit_tcn'):
+def stgcn_block_forward(x, sd, stride, residual, training=True, with_res=False, tcn_type='unit_tcn', merge_after=True):
     g = unit_gcn_forward(x, _sub(sd, 'gcn.'), training, with_res)
     if tcn_type == 'mstcn':
         t = mstcn_forward(g, _sub(sd, 'tcn.'), stride, training=training)             # stgcn.py:47-48 (ST-GCN++)
+    elif tcn_type == 'unitmlp':                                                       # stgcn.py:51-52 (shipped STGCN_model.py)
+        ts = _sub(sd, 'tcn.')
+        t = _bn(unitmlp_forward(g, ts, 9, stride, 1, 'conv2.weight' in ts, merge_after), ts, 'bn.', training)   # tcn.py:609
     else:
         t = unit_tcn_forward(g, _sub(sd, 'tcn.'), 9, stride, 1, training)             # stgcn.py:45-46 (p=0)
     if not residual:
@@ -495,13 +498,13 @@ def stgcn_block_forward(x, sd, stride, residual, training=True, with_res=False, 
     return F.relu(t + res)
 
 
-def stgcn_forward(x, sd, plan, training=True, with_res=False, tcn_type='unit_tcn'):
+def stgcn_forward(x, sd, plan, training=True, with_res=False, tcn_type='unit_tcn', merge_after=True):
     N, M, T, V, C = x.shape
     h = x.permute(0, 1, 3, 4, 2).contiguous().view(N * M, V * C, T)
     h = _bn(h, sd, 'data_bn.', training)
     h = h.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
     for i, (ci, co, stride, residual) in enumerate(plan):
-        h = stgcn_block_forward(h, _sub(sd, f'gcn.{i}.'), stride, residual, training, with_res, tcn_type)
+        h = stgcn_block_forward(h, _sub(sd, f'gcn.{i}.'), stride, residual, training, with_res, tcn_type, merge_after)
     return h.reshape((N, M) + h.shape[1:])
 
 
@@ -664,12 +667,14 @@ def ctrgcn_forward(x, sd, plan, training=True, edge_type=None):
 
 
 def recognizer_forward_train_backbone(backbone, keypoint, label, sd, plan, training=True):
-    """forward_train with the ST-GCN ('stgcn'), ST-GCN++ ('stgcnpp'), classic CTR-GCN ('ctrgcn'), shipped-config CTR-GCN
+    """forward_train with the ST-GCN ('stgcn'), shipped ST-GCN ('stgcn_shipped': unitmlp temporal unit), ST-GCN++ ('stgcnpp'), classic CTR-GCN ('ctrgcn'), shipped-config CTR-GCN
     ('ctrgcn_shipped': unit_ctrhgcn + msmlp, NTU graph) or AAGCN ('aagcn') backbone -> (logits, loss)."""
     assert keypoint.shape[1] == 1
     if backbone == 'ctrgcn_shipped':
         feat = ctrgcn_forward(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training,
                               graph_constants('nturgb+d')['edge_type'])
+    elif backbone == 'stgcn_shipped':  # configs/stgcn/STGCN_model.py: gcn_adaptive='init', tcn_type='unitmlp' (add_tcn, merge_after)
+        feat = stgcn_forward(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training, False, 'unitmlp', True)
     elif backbone == 'stgcnpp':        # ST-GCN++ (configs/stgcn++): gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn'
         feat = stgcn_forward(keypoint[:, 0], _sub(sd, 'backbone.'), plan, training, True, 'mstcn')
     else:

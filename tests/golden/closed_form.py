@@ -142,6 +142,11 @@ UNIT_CASES = {       # tag -> (class name, ctor args after the graph, input shap
     'msmlp_s2': ('msmlp', dict(in_channels=128, out_channels=128, stride=2, add_tcn=True, merge_after=False), (2, 128, 8, 25)),
     'ctrhgcn_same': ('unit_ctrhgcn', dict(in_channels=64, out_channels=64, semantic_index=True, node_attention=True,
                                           edge_attention=True, ada=True), (2, 64, 8, 25)),
+    # unitmlp as the whole temporal unit of the shipped ST-GCN config (configs/stgcn/STGCN_model.py: kernel 9 -> 5 causal taps)
+    'unitmlp9': ('unitmlp', dict(in_channels=64, out_channels=64, kernel_size=9, stride=1, add_tcn=True, merge_after=True),
+                 (2, 64, 12, 25)),
+    'unitmlp9_s2': ('unitmlp', dict(in_channels=128, out_channels=128, kernel_size=9, stride=2, add_tcn=True,
+                                    merge_after=False), (2, 128, 12, 25)),
 }
 
 
@@ -182,3 +187,57 @@ def sd_digest(module):
         h.update(k.encode())
         h.update(v.detach().cpu().numpy().tobytes())
     return h.hexdigest()
+
+
+# The two headline units of DS-STGCN at every width the model uses (round 3): tag -> (class, layout, ctor kwargs, input shape)
+DS_KW = dict(ratio=0.125, decompose=True, node_attention=True, edge_attention=True, subset_wise=True, ctr='T', ada='T')
+DS_UNIT_CASES = {
+    'g3_64': ('dgphgcn1', 'nturgb+d', dict(in_channels=3, out_channels=64), (2, 3, 8, 25)),
+    'g64_64': ('dgphgcn1', 'nturgb+d', dict(in_channels=64, out_channels=64), (2, 64, 8, 25)),
+    'g64_128': ('dgphgcn1', 'nturgb+d', dict(in_channels=64, out_channels=128), (2, 64, 8, 25)),
+    'g128_128': ('dgphgcn1', 'nturgb+d', dict(in_channels=128, out_channels=128), (2, 128, 8, 25)),
+    'g128_256': ('dgphgcn1', 'nturgb+d', dict(in_channels=128, out_channels=256), (3, 128, 4, 25)),
+    'g256_256': ('dgphgcn1', 'nturgb+d', dict(in_channels=256, out_channels=256), (3, 256, 4, 25)),
+    'g64_64_coco': ('dgphgcn1', 'coco', dict(in_channels=64, out_channels=64), (2, 64, 10, 17)),
+    't64': ('dgmstcn', 'nturgb+d', dict(in_channels=64, out_channels=64, stride=1), (2, 64, 8, 25)),
+    't128_s2': ('dgmstcn', 'nturgb+d', dict(in_channels=128, out_channels=128, stride=2), (2, 128, 8, 25)),
+    't256': ('dgmstcn', 'nturgb+d', dict(in_channels=256, out_channels=256, stride=1), (3, 256, 4, 25)),
+    't64_s2_coco': ('dgmstcn', 'coco', dict(in_channels=64, out_channels=64, stride=2, num_joints=17), (2, 64, 10, 17)),
+}
+
+
+def make_ds_unit(ns, graph_cls, tag):
+    """Build the DS-STGCN unit `tag` from namespace `ns` (the reference's gcns.utils or this package) with the graph class
+    of the same side: seeded default init (the random graph draws from numpy's RNG), live alpha / beta / add_coeff,
+    BatchNorm affines away from (1, 0); -> (module fp32, input fp32, cotangent R fp32)."""
+    import numpy as np
+    idx = list(DS_UNIT_CASES).index(tag)
+    cls, layout, kw, shape = DS_UNIT_CASES[tag]
+    kw = dict(kw)
+    np.random.seed(600 + idx)
+    torch.manual_seed(600 + idx)
+    if cls == 'dgphgcn1':
+        G = graph_cls(layout=layout, mode='random', num_filter=3, init_off=.04, init_std=.02)
+        m = getattr(ns, cls)(kw['in_channels'], kw['out_channels'], torch.tensor(G.A, dtype=torch.float32),
+                             torch.tensor(G.edge_type, dtype=torch.float32), torch.tensor(G.node_type), **DS_KW)
+    else:
+        m = getattr(ns, cls)(**kw)
+    liven32(m, 700 + idx)
+    g = torch.Generator().manual_seed(800 + idx)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
+                mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.2)
+    x = torch.randn(*shape, generator=g)
+    stride = kw.get('stride', 1)
+    Rm = torch.randn(shape[0], kw['out_channels'], (shape[2] + stride - 1) // stride, shape[3], generator=g)
+    return m.train(), x, Rm
+
+
+def step_input(step, N, T, V, classes):
+    """Closed-form batch `step` of the training-trajectory fixture: (N,1,2,T,V,3) clips and (N,1) labels."""
+    i = torch.arange(N * 2 * T * V * 3, dtype=torch.float64) + 1000003.0 * step
+    x = (torch.sin(0.0137 * i) + 0.3 * torch.cos(0.00071 * i * i % 6.283185307179586)).reshape(N, 1, 2, T, V, 3).float()
+    y = ((torch.arange(N) * 7 + 3 * step) % classes).reshape(N, 1)
+    return x, y

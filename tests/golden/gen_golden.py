@@ -111,6 +111,9 @@ def unit_dgmstcn():
 def other_cfg(kind, num_classes=60, **bk):
     if kind == 'ctrgcn':
         backbone = dict(type='CTRGCN', gcn_type='unit_ctrgcn', graph_cfg=dict(layout='nturgb+d', mode='spatial'))
+    elif kind == 'stgcn_shipped':      # configs/stgcn/STGCN_model.py
+        backbone = dict(type='STGCN', gcn_adaptive='init', tcn_type='unitmlp', tcn_add_tcn=True, tcn_merge_after=True,
+                        graph_cfg=dict(layout='nturgb+d', mode='random', num_filter=3, init_off=.04, init_std=.02))
     elif kind == 'stgcnpp':
         backbone = dict(type='STGCN', gcn_adaptive='init', gcn_with_res=True, tcn_type='mstcn',
                         graph_cfg=dict(layout='nturgb+d', mode='spatial'))

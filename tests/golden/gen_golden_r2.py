@@ -3,7 +3,7 @@
     python tests/golden/gen_golden_r2.py
 
 Adds to gen_golden.py's set (which it leaves untouched):
-  full_grads_<config>.npz   full-width models, DEFAULT init (seed 0) + live alpha/beta/add_coeff, closed-form input:
+  full_grads_<config>.npz   full-width models, DEFAULT init (seed 0) + live alpha/beta/add_coeff, closed-form input (8 clips):
                             reference logits / loss (fp32 and fp64) and the full fp64 gradients of a fixed selection of
                             ~12 tensors + the reference's own fp32 error on that selection (a well-conditioned case,
                             unlike full_size.npz's sine weights: a tight full-width gradient check);
@@ -50,7 +50,9 @@ CONFIGS = {
     'stgcn_ntu60': (lambda: other_cfg('stgcn'), 64, 25),      # BASELINE config 1
     'stgcnpp_ntu60': (lambda: other_cfg('stgcnpp'), 64, 25),
     'ctrgcn_shipped_ntu60': (lambda: shipped_ctr_cfg(), 64, 25),       # the CTR-GCN variant the reference ships (f-1)
+    'stgcn_shipped_ntu60': (lambda: other_cfg('stgcn_shipped'), 64, 25),    # the ST-GCN variant the reference ships (unitmlp)
 }
+GRAD_CLIPS = 8           # clips per full_grads case (16 person-samples of batch statistics)
 
 
 def build(cfg, scale=0.5):
@@ -76,7 +78,7 @@ def full_grads():
             for mod in m.modules():                     # vanilla ST-GCN's Dropout(0.5) would make the case random
                 if isinstance(mod, torch.nn.Dropout):
                     mod.p = 0.0
-        x, y = counter_input(2, T, V, classes)
+        x, y = counter_input(GRAD_CLIPS, T, V, classes)
         logits = m.cls_head(m.extract_feat(x[:, 0]))
         loss = torch.nn.functional.cross_entropy(logits, y.squeeze(-1))
         loss.backward()

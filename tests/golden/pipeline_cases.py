@@ -53,4 +53,40 @@ def pipelines():
         'val_j': pipe(rot=0), 'test10_j': pipe(rot=0, clips=10), 'test10_seeded': pipe(rot=0, clips=10, test_mode=True),
         'spine_j': pipe(norm=dict()), 'loop_j': pipe(fmt=dict(num_person=2, mode='loop')),
         'three_persons': pipe(fmt=dict(num_person=3)),
+        'loop_three': pipe(fmt=dict(num_person=3, mode='loop')),      # M = 2 < 3 slots: the real second person is overwritten
     }
+
+
+# ---- 2-D pose clips (HRNet / coco layout): keypoint (M, T, 17, 2) + keypoint_score (M, T, 17) + img_shape ----------------
+
+def annotations_2d():
+    """Five coco clips in pixel coordinates: fp16 and fp32 storage (PreNormalize2D works in place, in the pickle's dtype),
+    with and without a per-clip img_shape, one or two persons."""
+    rng = np.random.RandomState(77)
+    out = []
+    for i, (M, T, dt, shape) in enumerate([(2, 40, np.float16, (480, 854)), (1, 21, np.float32, None),
+                                           (2, 16, np.float16, None), (1, 9, np.float32, (720, 1280)),
+                                           (2, 33, np.float32, (1080, 1920))]):
+        h, w = shape or (1080, 1920)
+        base = np.array([w * 0.5, h * 0.5]) + rng.randn(1, 1, 17, 2) * np.array([w * 0.08, h * 0.15])
+        kp = (base + np.cumsum(rng.randn(M, T, 1, 2) * 3.0, axis=1) + rng.randn(M, T, 17, 2) * 2.0).astype(dt)
+        score = (rng.rand(M, T, 17) * 0.6 + 0.4).astype(dt)
+        a = dict(frame_dir=f'pose{i}', label=(11 * i) % 400, keypoint=kp, keypoint_score=score, total_frames=T)
+        if shape is not None:
+            a['img_shape'] = shape
+        out.append(a)
+    return out
+
+
+def pipelines_2d():
+    def pipe(rot=0.0, feats=('j',), clips=1, shape=(1080, 1920)):
+        p = [dict(type='PreNormalize2D', img_shape=shape)]
+        if rot:
+            p.append(dict(type='RandomRot', theta=rot))
+        p += [dict(type='GenSkeFeat', dataset='coco', feats=list(feats)),
+              dict(type='UniformSample', clip_len=CLIP_LEN, num_clips=clips), dict(type='PoseDecode'),
+              dict(type='FormatGCNInput', num_person=2),
+              dict(type='Collect', keys=['keypoint', 'label'], meta_keys=[]), dict(type='ToTensor', keys=['keypoint'])]
+        return p
+    return {'coco_j': pipe(), 'coco_all': pipe(feats=('j', 'b', 'jm', 'bm')), 'coco_rot_b': pipe(rot=0.2, feats=('b',)),
+            'coco_test3': pipe(clips=3)}

@@ -43,8 +43,14 @@ def _worker(rank, world, port, out_dir, gather):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(1)
     model = make_model(seed=7 + rank)           # different init per rank: the param broadcast must fix it
+    with torch.no_grad():                       # ... and different buffers (a rank that loaded another checkpoint)
+        model.backbone.data_bn.running_mean.fill_(float(rank))
+        model.backbone.data_bn.num_batches_tracked.fill_(10 * rank)
     flat = D.FlatParams(model, gather=gather)
     dp = D.FlatDataParallel(flat)
+    # wrap time: rank 0's parameters AND buffers everywhere (torch DDP's constructor syncs module states incl. buffers)
+    assert float(model.backbone.data_bn.running_mean.abs().max()) == 0.0
+    assert int(model.backbone.data_bn.num_batches_tracked) == 0
     opt = D.FlatSGD(flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
     with D.kernels.use_ops(torch_ops):
         for _ in range(2):

@@ -91,7 +91,8 @@ def _reduced_model(name='model_reduced'):
     return z, m
 
 
-@pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn', 'model_reduced_stgcnpp'])
+@pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn', 'model_reduced_stgcnpp',
+                                  'model_reduced_stgcn_shipped'])
 def test_fused_wiring_against_golden_cpu(name):
     """forward_train through the deferred-BN op chain (torch op namespace) == the reference's logits / loss / grads."""
     z, m = _reduced_model(name)
@@ -237,6 +238,34 @@ def test_fuse_conv_bn_keeps_eval_outputs():
     assert len(folded) >= 20
     assert float((before - after).abs().max()) < 1e-5 * float(before.abs().max())
     assert float((before - after).abs().max()) > 0          # the arithmetic really changed (weights were rescaled)
+
+
+def test_fuse_conv_bn_folds_only_real_pairs():
+    """in dggcn / dgphgcn1 without `down`, conv2 / edge_linears are REGISTERED right before self.bn, which
+    normalises post(...): with equal widths (dggcn at ratio=None: K * mid == out_channels) a fold by registration order
+    would rescale the wrong conv.  Only declared / Sequential pairs are folded: eval outputs stay put."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from closed_form import fill_running, liven32
+    torch.manual_seed(0)
+    A = torch.randn(3, 25, 25) * 0.02 + 0.04
+    m = D.dggcn(48, 48, A, ratio=None)
+    assert m.conv2.out_channels == m.bn.num_features and m.down is None          # the trap
+    liven32(m, 3)
+    fill_running(m)
+    with torch.no_grad():
+        m.bn.weight.uniform_(0.5, 1.5)
+        m.bn.bias.normal_(0, 0.2)
+    m.eval()
+    x = torch.randn(2, 48, 6, 25)
+    w2 = m.conv2.weight.detach().clone()
+    with D.kernels.use_ops(torch_ops), torch.no_grad():
+        before = m(x)
+        D.fuse_conv_bn(m)
+        after = m(x)
+    assert torch.equal(m.conv2.weight, w2)                                       # the projection conv was left alone
+    assert float(m.bn.running_mean.abs().max()) == 0                            # post -> bn was folded
+    assert float((before - after).abs().max()) < 1e-5 * float(before.abs().max())
 
 
 def test_cat_rows_is_a_view_under_flat_params():

@@ -210,6 +210,60 @@ def test_pwconv_bf16_terms_are_fp32_class(Ci, Co, T):
         assert rel(a, r_) < bar, (name, rel(a, r_))
 
 
+@pytest.mark.parametrize('case', ['big_x_small_w', 'small_x_big_w', 'mixed_binades', 'near_subnormal', 'non_finite'])
+def test_pwconv_bf16_split_edge_cases(case):
+    """The three-term bf16 split away from O(1) operands.  bf16 has fp32's exponent range, so the split is
+    scale-free while every term stays normal: operands around 1e+-30 and rows spread over 80 binades must give the same
+    fp32-class error as O(1) data.  Below ~1e-33 the third term (2^-16 of the value) leaves the normal range; and a
+    non-finite input poisons only its own output positions (NaN where an fp32 FMA chain would keep the infinity)."""
+    n, Ci, Co, T, V = 4, 256, 256, 16, 25
+    g = torch.Generator().manual_seed(11)
+    x = _rand(g, n, Ci, T, V)
+    w = _rand(g, Co, Ci, 1, 1, scale=Ci ** -0.5)
+    gz = _rand(g, n, Co, T, V)
+    if case == 'big_x_small_w':
+        x, w, gz = x * 1e30, w * 1e-30, gz
+    elif case == 'small_x_big_w':
+        x, w, gz = x * 1e-30, w * 1e30, gz
+    elif case == 'mixed_binades':
+        k = torch.arange(Ci) % 81 - 40                       # channel c scaled by 2^k, its weight column by 2^-k
+        sc = torch.pow(torch.tensor(2.0), k.float())
+        x = x * sc.view(1, Ci, 1, 1)
+        w = w / sc.view(1, Ci, 1, 1)
+    elif case == 'near_subnormal':
+        x = x * 1e-36                                        # third bf16 term ~1e-41: subnormal
+    elif case == 'non_finite':
+        x = x.clone()
+        x[1, 7, 3, 5] = float('inf')
+        x[2, 100, 9, 0] = float('nan')
+
+    def run(mod, dt, dev):
+        tx, tw = (t.to(dev, dt).requires_grad_() for t in (x, w))
+        z = mod.pwconv(tx, None, None, None, False, tw, None, 1, False)[0]
+        (z * gz.to(dev, dt)).sum().backward()
+        return z.detach().cpu(), tx.grad.cpu(), tw.grad.cpu()
+
+    got = run(K, torch.float32, DEV)
+    if case == 'non_finite':
+        z = got[0]
+        bad = torch.zeros(n, T, V, dtype=torch.bool)
+        bad[1, 3, 5] = bad[2, 9, 0] = True
+        fin = torch.isfinite(z).all(1)                      # (n, T, V): positions whose every output channel is finite
+        assert torch.equal(~fin, bad), 'a non-finite input must poison exactly its own output positions'
+        xc = torch.where(torch.isfinite(x), x, torch.zeros_like(x))
+        zr = R.pwconv(xc.double(), None, None, None, False, w.double(), None, 1, False)[0]
+        assert rel(z.permute(0, 2, 3, 1)[fin], zr.permute(0, 2, 3, 1)[fin]) < 6e-7
+        return
+    ref = run(R, torch.float64, 'cpu')
+    errs = {nm: rel(a, r_) for nm, a, r_ in zip(('z', 'dx', 'dW'), got, ref)}
+    print(case, errs)
+    # measured on gfx950: every case 2-4e-7 except near_subnormal (the residue terms flush): still below the north_star's
+    # 1e-4 by two orders, but NOT fp32-class — documented in csrc/common.h and DESIGN §4
+    bars = dict(z=6e-7, dx=6e-7, dW=3e-7) if case != 'near_subnormal' else dict(z=2e-5, dx=2e-5, dW=2e-5)
+    for nm, e in errs.items():
+        assert e < bars[nm], (case, nm, e)
+
+
 @pytest.mark.parametrize('n,C,T,V,mode,tmean,flags', [
     (3, 64, 64, 25, 'res_plain', True, 1), (2, 128, 32, 25, 'res_affine', True, 1), (2, 64, 64, 25, 'affine', True, 1),
     (2, 256, 16, 25, 'res_plain', False, 1), (2, 12, 25, 17, 'res_affine', True, 1), (1, 5, 7, 18, 'plain', True, 1),
@@ -571,7 +625,8 @@ def test_dggcn_unit_vs_reference_fixture(i):
 
 
 @pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'MSTCNs2', 'gcn_offset_post',
-                                 'gcn_importance', 'gcn_fixed_post', 'ctrhgcn', 'ctrhgcn_same', 'msmlp', 'msmlp_s2'])
+                                 'gcn_importance', 'gcn_fixed_post', 'ctrhgcn', 'ctrhgcn_same', 'msmlp', 'msmlp_s2',
+                                 'unitmlp9', 'unitmlp9_s2'])
 def test_units_vs_reference_fixture(tag):
     """unit_gcn, unit_tcn (k=9 dense; k=1 stride 2), unit_ctrgcn / CTRGC and MSTCN at real widths on the HIP path
     against the REFERENCE's output, input gradient, parameter gradients and running statistics (fp64 run;
@@ -603,6 +658,105 @@ def test_units_vs_reference_fixture(tag):
                 assert rel(p.grad.cpu(), want) < 1e-4, (k, rel(p.grad.cpu(), want))
         elif f'{tag}_gnorm_{k}' in z:
             assert abs(float(p.grad.double().norm()) - float(z[f'{tag}_gnorm_{k}'])) < 1e-4 * float(z[f'{tag}_gnorm_{k}']), k
+    for k, v in m.state_dict().items():
+        if 'running' in k:
+            assert rel(v.cpu(), z[f'{tag}_{k}']) < 1e-5, k
+
+
+def _check_param_grads(m, z, tag, bar=1e-4):
+    """Every parameter gradient the fixture stores (full tensors, or norms for the large ones) against the module's."""
+    gmax = max([float(np.abs(z[k]).max()) for k in z if k.startswith(f'{tag}grad_')] + [1e-30])
+    seen = 0
+    for k, p in m.named_parameters():
+        if f'{tag}grad_{k}' in z:
+            want = z[f'{tag}grad_{k}']
+            seen += 1
+            if np.abs(want).max() < 1e-9 * max(gmax, 1.0):     # analytically zero (a conv bias feeding BatchNorm): fp32 noise
+                assert p.grad is None or float(p.grad.abs().max()) < 2e-4 * gmax, k
+            else:
+                assert p.grad is not None, k
+                assert rel(p.grad.cpu(), want) < bar, (k, rel(p.grad.cpu(), want))
+        elif f'{tag}gnorm_{k}' in z:
+            seen += 1
+            want = float(z[f'{tag}gnorm_{k}'])
+            assert abs(float(p.grad.double().norm()) - want) < bar * want, k
+    return seen
+
+
+@pytest.mark.parametrize('i', [0, 1, 2])
+def test_dgphgcn1_unit_vs_reference_fixture(i):
+    """The DS-GCN spatial unit (gcn.py:2074-2372) on the HIP path — K-B, K-A, K-C — against the REFERENCE's fp64 output,
+    input gradient and stored parameter gradients (tests/golden/unit_dgphgcn1.npz: 3->64 with `down`, 64->64, 64->128);
+    the module takes the reference's state_dict as is."""
+    import dsgcn_amd as D
+    from oracle import dsgcn_oracle as O
+    from test_oracle_golden import load, sd_of
+    z = load('unit_dgphgcn1.npz')
+    tag = f'u{i}_'
+    sd = sd_of(z, tag + 'sd_', torch.float32)
+    Co, Ci = sd['post.weight'].shape[0], sd['pre.0.weight'].shape[1]
+    gc = O.graph_constants('nturgb+d')
+    m = D.dgphgcn1(Ci, Co, sd['A'].clone(), torch.as_tensor(gc['edge_type']).float(), torch.as_tensor(gc['node_type']),
+                   ratio=0.125, decompose=True, node_attention=True, edge_attention=True, subset_wise=True, ctr='T', ada='T')
+    m.load_state_dict(sd)                       # strict: same keys and shapes as the reference module
+    m = m.cuda().train()
+    x = torch.from_numpy(z[tag + 'x']).cuda().requires_grad_()
+    y = m(x)
+    (y * torch.from_numpy(z[tag + 'R']).cuda()).sum().backward()
+    assert rel(y.detach().cpu(), z[tag + 'y']) < 1e-5
+    assert rel(x.grad.cpu(), z[tag + 'dx']) < 5e-5
+    assert _check_param_grads(m, z, tag) == 6
+
+
+@pytest.mark.parametrize('i,stride', [(0, 1), (1, 2)])
+def test_dgmstcn_unit_vs_reference_fixture(i, stride):
+    """The DS-GCN temporal unit (tcn.py:344-431) on the HIP path — K-C with the global-joint column, K-D, K-C — against the
+    REFERENCE's fp64 output, input gradient and add_coeff gradient (tests/golden/unit_dgmstcn.npz: 64 / stride 1, 96 /
+    stride 2)."""
+    import dsgcn_amd as D
+    from test_oracle_golden import load, sd_of
+    z = load('unit_dgmstcn.npz')
+    tag = f't{i}_'
+    sd = sd_of(z, tag + 'sd_', torch.float32)
+    C = sd['transform.2.weight'].shape[0]
+    m = D.dgmstcn(C, C, stride=stride)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x = torch.from_numpy(z[tag + 'x']).cuda().requires_grad_()
+    y = m(x)
+    (y * torch.from_numpy(z[tag + 'R']).cuda()).sum().backward()
+    assert rel(y.detach().cpu(), z[tag + 'y']) < 1e-5
+    assert rel(x.grad.cpu(), z[tag + 'dx']) < 5e-5
+    assert rel(m.add_coeff.grad.cpu(), z[tag + 'grad_add_coeff']) < 1e-4
+
+
+def _ds_unit_cases():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from closed_form import DS_UNIT_CASES
+    return list(DS_UNIT_CASES)
+
+
+@pytest.mark.parametrize('tag', _ds_unit_cases())
+def test_ds_units_all_widths_vs_reference_fixture(tag):
+    """dgphgcn1 and dgmstcn at EVERY width DS-STGCN uses (3->64 ... 256->256, stride 1 / 2, NTU and coco graphs) on the HIP
+    path against the REFERENCE's fp64 run (tests/golden/unit_ds_r3.npz): output 1e-5, input gradient 5e-5, EVERY
+    parameter gradient 1e-4 (norms for tensors > 16384 elements), BatchNorm running statistics 1e-5.  The seeded weights
+    are rebuilt here and their digest compared with the fixture's."""
+    import dsgcn_amd as D
+    from closed_form import make_ds_unit, sd_digest
+    from test_oracle_golden import load
+    z = load('unit_ds_r3.npz')
+    m, x, Rm = make_ds_unit(D, D.Graph, tag)
+    assert sd_digest(m) == str(z[f'{tag}_digest'])
+    m = m.cuda().train()
+    x = x.cuda().requires_grad_()
+    y = m(x)
+    (y * Rm.cuda()).sum().backward()
+    assert rel(y.detach().cpu(), z[f'{tag}_y']) < 1e-5
+    assert rel(x.grad.cpu(), z[f'{tag}_dx']) < 5e-5
+    assert _check_param_grads(m, z, f'{tag}_') >= 17
     for k, v in m.state_dict().items():
         if 'running' in k:
             assert rel(v.cpu(), z[f'{tag}_{k}']) < 1e-5, k

@@ -24,7 +24,7 @@ def test_native_library_is_loaded():
 
 
 @pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn', 'model_reduced_stgcnpp',
-                                  'model_reduced_dggcn', 'model_reduced_aagcn'])
+                                  'model_reduced_dggcn', 'model_reduced_aagcn', 'model_reduced_stgcn_shipped'])
 def test_reduced_model_vs_golden(name):
     """DS-STGCN, classic CTR-GCN, ST-GCN / ST-GCN++ the original DG-STGCN (gcn_type='dggcn') and AAGCN at reduced widths against
     the reference's committed outputs."""
@@ -82,7 +82,7 @@ def test_full_model_vs_oracle(layout, V, T, classes):
     assert len(dead) == 20 and all('conv2_se' in k for k in dead)          # reference quirk Q1
 
 
-@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn', 'stgcnpp', 'ctrgcn_shipped'])
+@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn', 'stgcnpp', 'ctrgcn_shipped', 'stgcn_shipped'])
 def test_full_other_backbones_vs_oracle(kind):
     """Full-width classic CTR-GCN (BASELINE config 4) and vanilla ST-GCN (config 1), 2 clips, against the CPU oracle."""
     np.random.seed(0)
@@ -135,15 +135,9 @@ def test_full_size_vs_reference_fixture(name, T, V, classes):
     ref_err = rel(z[name + '_logits'], l64)
     assert rel(logits.detach().cpu(), l64) < max(2 * ref_err, 1e-4), (rel(logits.detach().cpu(), l64), ref_err)
     assert abs(loss.item() - float(z[name + '_loss64'])) / abs(float(z[name + '_loss64'])) < 1e-4
-    # gradients: with 4 person-samples of batch statistics and these weights the fp32 gradient itself is ill-conditioned
-    # (the reference's fp32 gradient is 3.5 %..25 % off its fp64 one, stored as *_gerr32_total); per-tensor norms must
-    # be no further from fp64 than twice the reference's fp32 norms are
-    params = dict(m.named_parameters())
-    got = np.array([float(params[k].grad.double().norm()) for k in names])
-    g64 = z[name + '_gnorm64']
-    ours = np.linalg.norm(got - g64) / np.linalg.norm(g64)
-    theirs = np.linalg.norm(z[name + '_gnorm'] - g64) / np.linalg.norm(g64)
-    assert ours < max(2 * theirs, 2e-3), (ours, theirs)
+    # (gradients at full width are checked tensor by tensor in test_full_width_gradients_vs_reference_fixture; with these
+    # sine weights the reference's own fp32 gradient is 3.5-25 % off its fp64 one, so this case pins logits / loss only)
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
 
 
 @pytest.mark.parametrize('kind,T,N', [('ds', 18, 3), ('ds', 7, 1), ('ds', 33, 2), ('ctrgcn', 18, 3), ('stgcnpp', 9, 2),
@@ -212,7 +206,9 @@ R2_CONFIGS = {
     'dsstgcn_ntu60': (lambda: ds_cfg(60), 64, 25), 'dsstgcn_ntu120': (lambda: ds_cfg(120), 64, 25),
     'dsstgcn_k400_coco': (lambda: ds_cfg(400, 'coco'), 100, 17), 'ctrgcn_ntu60': (lambda: other_cfg('ctrgcn'), 64, 25),
     'stgcn_ntu60': (lambda: other_cfg('stgcn'), 64, 25), 'stgcnpp_ntu60': (lambda: other_cfg('stgcnpp'), 64, 25),
-    'ctrgcn_shipped_ntu60': (lambda: other_cfg('ctrgcn_shipped'), 64, 25)}
+    'ctrgcn_shipped_ntu60': (lambda: other_cfg('ctrgcn_shipped'), 64, 25),
+    'stgcn_shipped_ntu60': (lambda: other_cfg('stgcn_shipped'), 64, 25)}
+GRAD_CLIPS = 8
 
 
 def _r2_model(name, scale=0.5):
@@ -233,21 +229,20 @@ def _r2_model(name, scale=0.5):
 
 @pytest.mark.parametrize('name', list(R2_CONFIGS))
 def test_full_width_gradients_vs_reference_fixture(name):
-    """Full-width models of every BASELINE config (1: ST-GCN, 2: DS-STGCN NTU-60, 3: NTU-120, 4: CTR-GCN, 5: K400/coco)
-    and ST-GCN++, DEFAULT init + live alpha/beta/add_coeff, closed-form input, train mode: logits, loss, the FULL
-    gradients of a fixed selection of tensors and the BatchNorm running statistics against what the REFERENCE produced
-    (tests/golden/full_grads_*.npz; fp64 run = truth, its fp32 run = yardstick)."""
+    """Full-width models of every BASELINE config (1: ST-GCN, 2: DS-STGCN NTU-60, 3: NTU-120, 4: CTR-GCN, 5: K400/coco),
+    ST-GCN++ and the two shipped variants, DEFAULT init + live alpha/beta/add_coeff, closed-form input of 8 clips, train
+    mode: logits, loss, the FULL gradients of a fixed selection of tensors and the BatchNorm running statistics against
+    what the REFERENCE produced (tests/golden/full_grads_*.npz; fp64 run = truth, its own fp32 run = yardstick)."""
     from closed_form import counter_input
     m, cfg, T, V = _r2_model(name)
     classes = cfg['cls_head']['num_classes']
     z = load(f'full_grads_{name}.npz')
-    x, y = counter_input(2, T, V, classes)
+    x, y = counter_input(GRAD_CLIPS, T, V, classes)
     m = m.cuda().train()
     logits = m.cls_head(m.extract_feat(x.cuda()[:, 0]))
     loss = torch.nn.functional.cross_entropy(logits, y.cuda().squeeze(-1))
     loss.backward()
-    ref_err = rel(z['logits32'], z['logits64'])
-    assert rel(logits.detach().cpu(), z['logits64']) < max(2 * ref_err, 1e-4)          # north_star bar
+    assert rel(logits.detach().cpu(), z['logits64']) < 1e-4                               # north_star bar
     assert abs(loss.item() - float(z['loss64'])) / abs(float(z['loss64'])) < 1e-4
     names = json.loads(str(z['names']))
     params = dict(m.named_parameters())
@@ -256,18 +251,12 @@ def test_full_width_gradients_vs_reference_fixture(name):
         g64 = z[f'g64_{i}'].astype(np.float64)
         num += float(((params[k].grad.double().cpu().numpy() - g64) ** 2).sum())
         den += float((g64 ** 2).sum())
-    ours, theirs, noise = (num / den) ** .5, float(z['gerr32_set']), float(z['gnoise32_set'])
-    # Whole-selection relative L2 against the fp64 truth.  Yardstick: these 2-clip cases are ill-conditioned (train-mode
-    # BN over 4 person-samples, ReLU / max-pool decisions): the reference's own fp32 gradient is 0.04-0.7 % off fp64
-    # (gerr32_set) and moves by the same amount when its input is perturbed at the 2e-7 level (gnoise32_set: the
-    # amplification is ~1e3-3e4, so that is the floor for ANY fp32 evaluation order).  The deferred-BN form
-    # (z*scale + shift instead of (z-mean)*rstd*gamma + beta) perturbs activations ~2x more than the reference's
-    # arithmetic (logits 3e-7 vs 1.3e-7 from fp64).  What is compared is therefore ONE DRAW of that noise: over the seven
-    # configurations the ratio ours / max(theirs, noise) came out 0.65-3.6 with every conv on fp32 MFMAs and 0.58-5.5
-    # with the wide convs on the three-term bf16 products (tools/kc_check.py: both forms sit at 2-3e-7 of fp64 per conv;
-    # some configurations moved up, some down: the draw changed, not the accuracy; the logits stay at 3e-7 either way).
-    # Bar: within 8x the reference's noise floor — a wrong gradient is off by O(1), not by 1e-3.
-    assert ours < max(8 * max(theirs, noise), 1e-4), (ours, theirs, noise)
+    ours, theirs = (num / den) ** .5, float(z['gerr32_set'])
+    # Whole-selection relative L2 against the reference's fp64 gradients.  ONE bar: within twice the error of the
+    # reference's own fp32 run on the same case (0.05-0.8 % here: the batch-statistics backward under the mean-pooled head
+    # cancels ~4 digits in ANY fp32 evaluation order, whatever the batch size — measured at 2 and 8 clips,
+    # tests/golden/gen_golden_r2.py prints it).
+    assert ours < 2 * theirs, (ours, theirs)
     sd = m.state_dict()
     for i, k in enumerate(json.loads(str(z['running_names']))):
         assert rel(sd[k].cpu(), z[f'running_{i}']) < 1e-4, k                             # F.batch_norm's running update
@@ -347,3 +336,31 @@ def test_full_size_properties():
     lhs = K.aggregate(zp, None, False, a1 + a2)
     rhs = K.aggregate(zp, None, False, a1) + K.aggregate(zp, None, False, a2)
     assert rel(lhs.cpu(), rhs.cpu()) < 1e-6                   # linear in the adjacency
+
+
+def _run_bench_child(extra_env, *args):
+    """bench.py in a fresh child process (never re-exec a process that touched the GPU) -> its JSON line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--no-cpu-baseline', '--no-roofline', *args],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+
+
+def test_bench_step_under_rccl_group_is_bit_identical():
+    """The N > 1 code path of bench.py / TrainEngine — graph A -> RCCL all-reduce of the flat gradient buffer -> graph B —
+    under a 1-rank NCCL (= RCCL) process group (DSGCN_BENCH_FORCE_DIST=1), against the same command without a process
+    group: the parameters after warm-up + 3 steps must agree bit for bit (no 8-GPU box is available to the build; this
+    is the multi-GPU call sequence on real hardware)."""
+    port = 29500 + os.getpid() % 400
+    a = _run_bench_child({}, '--steps', '3', '--warmup', '4', '--clips-per-gpu', '8')
+    b = _run_bench_child({'DSGCN_BENCH_FORCE_DIST': '1', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
+                          'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0'},
+                         '--steps', '3', '--warmup', '4', '--clips-per-gpu', '8')
+    assert a['hip_graph'] and b['hip_graph']
+    assert a['param_sha256'] == b['param_sha256'], (a['param_sha256'], b['param_sha256'])
+    assert a['final_loss'] == b['final_loss']

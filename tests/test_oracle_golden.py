@@ -180,7 +180,7 @@ def test_reduced_model_fp64_and_fp32():
     assert abs(loss32.item() - float(z['loss_f32'])) < 1e-5
 
 
-@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn', 'stgcnpp', 'aagcn'])
+@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn', 'stgcnpp', 'aagcn', 'stgcn_shipped'])
 def test_reduced_other_backbones(kind):
     """ST-GCN (unit_gcn + unit_tcn k=9), ST-GCN++ (with_res + mstcn), classic CTR-GCN (unit_ctrgcn + MSTCN) and AAGCN
     (unit_aagcn + unit_tcn k=9, data_bn over M V C) end to end against the reference."""
@@ -314,11 +314,14 @@ def _unit_oracle(tag, x, sd):
         return O.unit_ctrgcn_forward(x, sd)
     if tag == 'MSTCN':
         return O.mstcn_msg3d_forward(x, sd, 1, 5, (1, 2))
+    if tag in ('unitmlp9', 'unitmlp9_s2'):        # unitmlp as a whole unit: its own BatchNorm closes it (tcn.py:609)
+        s2 = tag.endswith('_s2')
+        return O._bn(O.unitmlp_forward(x, sd, 9, 2 if s2 else 1, 1, True, not s2), sd, 'bn.', True)
     raise KeyError(tag)
 
 
 @pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'gcn_offset_post', 'gcn_importance',
-                                 'gcn_fixed_post', 'ctrhgcn', 'ctrhgcn_same', 'msmlp', 'msmlp_s2'])
+                                 'gcn_fixed_post', 'ctrhgcn', 'ctrhgcn_same', 'msmlp', 'msmlp_s2', 'unitmlp9', 'unitmlp9_s2'])
 def test_other_units_vs_reference_fixture(tag):
     """unit_gcn, unit_tcn (k=9; k=1 stride 2), unit_ctrgcn, MSTCN at real widths: oracle output and input gradient
     against the reference's (weights rebuilt from the shared seeded recipe; their digest is part of the fixture)."""
@@ -377,7 +380,7 @@ def test_eval_fixture_oracle(name, kind, T, V, classes, layout):
 
 
 @pytest.mark.parametrize('tag', ['gcn', 'gcn_res', 'tcn9', 'tcn1s2', 'ctrgcn', 'MSTCN', 'gcn_offset_post', 'gcn_importance',
-                                 'gcn_fixed_post', 'ctrhgcn', 'ctrhgcn_same', 'msmlp', 'msmlp_s2'])
+                                 'gcn_fixed_post', 'ctrhgcn', 'ctrhgcn_same', 'msmlp', 'msmlp_s2', 'unitmlp9', 'unitmlp9_s2'])
 def test_oracle_units_vs_reference_live(tag):
     """Build container only: every unit restated in the oracle against the IMPORTED reference module, fp64."""
     import sys
@@ -415,3 +418,54 @@ def test_oracle_temporal_units_vs_reference_live(cls, stride):
     want = m(x)
     got = (O.dgmstcn_forward if cls == 'dgmstcn' else O.mstcn_forward)(x, sd, stride)
     assert (want - got).abs().max().item() < 1e-11
+
+
+# ---- round-3 fixtures (tests/golden/gen_golden_r3.py) ------------------------------------------------------------
+
+def _ds_unit_tags():
+    import sys
+    sys.path.insert(0, GOLD)
+    from closed_form import DS_UNIT_CASES
+    return list(DS_UNIT_CASES)
+
+
+def _ds_unit_oracle(tag, x, sd):
+    import sys
+    sys.path.insert(0, GOLD)
+    from closed_form import DS_UNIT_CASES
+    cls, layout, kw, _ = DS_UNIT_CASES[tag]
+    if cls == 'dgphgcn1':
+        gc = O.graph_constants(layout)
+        return O.dgphgcn1_forward(x, sd, gc['node_type'], gc['edge_type'])
+    return O.dgmstcn_forward(x, sd, kw.get('stride', 1))
+
+
+@pytest.mark.parametrize('tag', _ds_unit_tags())
+def test_ds_units_all_widths_oracle(tag):
+    """dgphgcn1 / dgmstcn at every width DS-STGCN uses: oracle output, input gradient and EVERY parameter gradient against
+    the reference's fp64 run (tests/golden/unit_ds_r3.npz; weights rebuilt from the shared seeded recipe, digest checked)."""
+    import dsgcn_amd as D
+    from closed_form import make_ds_unit, sd_digest
+    z = load('unit_ds_r3.npz')
+    m, x, Rm = make_ds_unit(D, D.Graph, tag)
+    assert sd_digest(m) == str(z[f'{tag}_digest']), 'seeded unit weights differ from the reference build'
+    sd = {k: (v.detach().double().requires_grad_() if v.dtype.is_floating_point and 'running' not in k else v.detach().clone())
+          for k, v in m.state_dict(keep_vars=True).items()}
+    x = x.double().requires_grad_()
+    y = _ds_unit_oracle(tag, x, sd)
+    (y * Rm.double()).sum().backward()
+    assert rel(y.detach(), z[f'{tag}_y']) < 2e-6
+    assert rel(x.grad, z[f'{tag}_dx']) < 2e-6
+    checked = 0
+    for k, v in sd.items():
+        if f'{tag}_grad_{k}' in z:
+            want = z[f'{tag}_grad_{k}']
+            if np.abs(want).max() < 1e-9:
+                assert v.grad is None or float(v.grad.abs().max()) < 1e-9, k
+            else:
+                assert rel(v.grad, want) < 2e-6, k
+            checked += 1
+        elif f'{tag}_gnorm_{k}' in z:
+            assert abs(float(v.grad.norm()) - float(z[f'{tag}_gnorm_{k}'])) < 2e-6 * float(z[f'{tag}_gnorm_{k}']), k
+            checked += 1
+    assert checked >= 17

@@ -15,10 +15,11 @@ from dsgcn_amd import pipeline as P
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 sys.path.insert(0, GOLD)
-from pipeline_cases import CLIP_LEN, annotations, pipelines, raw_clips  # noqa: E402
+from pipeline_cases import CLIP_LEN, annotations, annotations_2d, pipelines, pipelines_2d, raw_clips  # noqa: E402
 
 Z = dict(np.load(os.path.join(GOLD, 'pipeline.npz')))
 NAMES = list(pipelines())
+NAMES_2D = list(pipelines_2d())
 
 
 @pytest.mark.parametrize('name', NAMES)
@@ -37,6 +38,21 @@ def test_host_pipeline_vs_reference(name):
         assert torch.is_tensor(got) and got.dtype == torch.float32 and tuple(got.shape) == want.shape
         assert res['label'] == ann['label']
         assert np.abs(got.numpy() - want).max() < 1e-6, (name, si)
+
+
+@pytest.mark.parametrize('name', NAMES_2D)
+def test_host_pipeline_2d_vs_reference(name):
+    """2-D pose pickles (coco layout): PreNormalize2D with the per-clip img_shape in the pickle's own dtype (fp16 clips
+    keep their fp16 rounding, like the reference's in-place arithmetic), the score channel appended by GenSkeFeat."""
+    pipe = P.Compose(copy.deepcopy(pipelines_2d()[name]))
+    np.random.seed(2000 + NAMES_2D.index(name))
+    for si, ann in enumerate(annotations_2d()):
+        sample = copy.deepcopy(ann)
+        sample.update(start_index=0, modality='Pose')
+        res = pipe(sample)
+        want = Z[f'{name}_{si}']
+        assert tuple(res['keypoint'].shape) == want.shape and want.shape[-1] % 3 == 0      # x, y, score per feature
+        assert np.abs(res['keypoint'].numpy() - want).max() < 1e-6, (name, si)
 
 
 def test_frame_indices_branches_and_rng_stream():
@@ -91,6 +107,25 @@ def test_batched_hip_pipeline_vs_reference(name):
     kp, label = batcher(store, list(range(len(store))))
     kp = kp.cpu().numpy()
     assert label.shape == (len(store), 1) and label[:, 0].tolist() == [a['label'] for a in annotations()]
+    for si in range(len(store)):
+        want = Z[f'{name}_{si}']
+        assert kp[si].shape == want.shape
+        assert np.abs(kp[si] - want).max() < 2e-6, (name, si, np.abs(kp[si] - want).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', NAMES_2D)
+def test_batched_hip_pipeline_2d_vs_reference(name):
+    """the batched form on 2-D pose pickles — keypoint_score carried as channel 2, PreNormalize2D with each
+    clip's own img_shape, fp16 clips' features in fp16 arithmetic — against the reference's per-sample transforms."""
+    anns = annotations_2d()
+    store = P.SkeletonStore(anns)
+    assert store.C == 3 and store.coordC == 2
+    batcher = P.SkeletonBatcher(pipelines_2d()[name])
+    np.random.seed(2000 + NAMES_2D.index(name))
+    kp, label = batcher(store, list(range(len(store))))
+    kp = kp.cpu().numpy()
+    assert label[:, 0].tolist() == [a['label'] for a in anns]
     for si in range(len(store)):
         want = Z[f'{name}_{si}']
         assert kp[si].shape == want.shape

@@ -1,0 +1,182 @@
+"""The training loop (dsgcn_amd.apis.train_model: sampler order -> batches -> train_step -> backward -> all-reduce ->
+cosine rate -> SGD-nesterov -> checkpoint) against a 6-step trajectory of the REFERENCE driven the way its runner drives
+it (tests/golden/trajectory_dsstgcn_reduced.npz, generator tests/golden/gen_golden_r3.py: torch SGD on the imported model,
+the reference's own DistributedSampler order, fp64 run = truth, its fp32 run = yardstick).
+
+CPU: the host loop over the plain-torch op namespace (tests/torch_ops.py).  -m gpu: the product path — HIP kernels, the
+step replayed from hipGraphs from the third iteration on."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dsgcn_amd as D
+import torch_ops
+from dsgcn_amd.apis import epoch_indices, train_model
+from test_oracle_golden import GOLD, load, sd_of
+
+
+def _setup(tmp_path, total_epochs=2, **extra):
+    z = load('trajectory_dsstgcn_reduced.npz')
+    cfg = json.loads(str(z['cfg']))
+    cfg['backbone']['tcn_ms_cfg'] = [tuple(c) if isinstance(c, list) else c for c in cfg['backbone']['tcn_ms_cfg']]
+    tr = json.loads(str(z['config']))
+    m = D.build_model(cfg)
+    m.load_state_dict(sd_of(z, 'sd_', torch.float32))
+    data = [dict(keypoint=z['x'][i], label=int(z['label'][i])) for i in range(tr['samples'])]
+    run_cfg = dict(data=dict(videos_per_gpu=tr['batch']), seed=tr['seed'], total_epochs=total_epochs,
+                   optimizer=dict(type='SGD', lr=tr['lr'], momentum=tr['momentum'], weight_decay=tr['weight_decay'],
+                                  nesterov=True),
+                   optimizer_config=dict(grad_clip=None), lr_config=dict(policy='CosineAnnealing', min_lr=0, by_epoch=False),
+                   checkpoint_config=dict(interval=1), log_config=dict(interval=1), work_dir=str(tmp_path), **extra)
+    return z, tr, m, data, run_cfg
+
+
+def _check(z, tr, m, runner, p0):
+    names = json.loads(str(z['names']))
+    P = dict(m.named_parameters())
+    num = den = upd = 0.0
+    for i, k in enumerate(names):
+        want = z[f'p64_{i}']
+        got = P[k].detach().double().cpu().numpy()
+        num += float(((got - want) ** 2).sum())
+        den += float((want ** 2).sum())
+        upd += float(((want - p0[k]) ** 2).sum())
+    perr, uerr = (num / den) ** .5, (num / upd) ** .5
+    # the reference's own fp32 run sits 9e-7 (parameters) / 3.4e-4 (the 6-step update) from its fp64 run; dropping the
+    # weight decay alone would move the update by 6e-3, plain momentum instead of nesterov or a constant rate by > 1e-1
+    assert perr < 1e-5, (perr, float(z['perr32']))
+    assert uerr < 3e-3, (uerr, float(z['uerr32']))
+    losses = [r['loss'] for r in runner.log]
+    assert len(losses) == len(z['loss64'])
+    for a, b in zip(losses, z['loss64']):
+        assert abs(a - b) / abs(b) < 1e-5, (losses, z['loss64'])
+    lrs = [r['lr'] for r in runner.log]
+    assert abs(lrs[0] - tr['lr']) < 1e-12 and abs(lrs[3] - tr['lr'] * 0.5) < 1e-12       # cosine over the 6 iterations
+    sd = m.state_dict()
+    for i, k in enumerate(json.loads(str(z['running_names']))):
+        ref = z[f'running64_{i}'].astype(np.float64)
+        got = sd[k].double().cpu().numpy()
+        assert np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30) < 1e-4, k      # momentum-0.1 running statistics
+    assert int(sd['backbone.data_bn.num_batches_tracked']) == int(z['nbt']) == 6
+    return perr, uerr
+
+
+def test_sampler_order_matches_reference():
+    z = load('trajectory_dsstgcn_reduced.npz')
+    tr = json.loads(str(z['config']))
+    for ep in range(tr['epochs']):
+        assert epoch_indices(tr['samples'], ep, tr['seed'], 0, 1) == list(z['order'][ep])
+    # two ranks: the padded permutation dealt round-robin (distributed_sampler.py:38-43)
+    a, b = epoch_indices(7, 0, 3, 0, 2), epoch_indices(7, 0, 3, 1, 2)
+    g = torch.Generator()
+    g.manual_seed(3)
+    perm = torch.randperm(7, generator=g).tolist()
+    perm += perm[:1]
+    assert a == perm[0::2] and b == perm[1::2]
+
+
+def test_train_model_trajectory_cpu(tmp_path):
+    z, tr, m, data, cfg = _setup(tmp_path)
+    p0 = {k: p.detach().double().numpy().copy() for k, p in m.named_parameters()}
+    with D.kernels.use_ops(torch_ops):
+        runner = train_model(m, data, cfg, device='cpu', use_graph=False)
+    _check(z, tr, m, runner, p0)
+    assert runner.epoch == 2 and runner.iter == 6
+    assert os.path.islink(tmp_path / 'latest.pth') and os.path.exists(tmp_path / 'epoch_1.pth')
+    final = {k: v.clone() for k, v in m.state_dict().items()}
+    # a run killed after its first epoch continues from epoch_1.pth to the same end state (model, momentum, counters, rate)
+    z2, _, m2, data2, cfg2 = _setup(tmp_path / 'second', resume_from=str(tmp_path / 'epoch_1.pth'))
+    with D.kernels.use_ops(torch_ops):
+        r2 = train_model(m2, data2, cfg2, device='cpu', use_graph=False)
+    assert r2.epoch == 2 and r2.iter == 6 and len(r2.log) == 3
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, final[k]), k
+
+
+def test_capturable_sgd_matches_torch_sgd():
+    """FlatSGD(capturable=True) — rate in a device scalar, momentum buffer allocated once — steps like torch.optim.SGD."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    ref = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    ref.load_state_dict(net.state_dict())
+    flat = D.FlatParams(net)
+    opt = D.FlatSGD(flat, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True, capturable=True)
+    topt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    assert opt.state_dict()['state'] == {}                      # nothing stepped yet: no momentum entries, like torch
+    buf_ptr = opt.buf.data_ptr()
+    x = torch.randn(6, 5)
+    for it in range(4):
+        lr = D.cosine_lr(0.1, it, 4)
+        opt.set_lr(lr)
+        topt.param_groups[0]['lr'] = lr
+        for model, o in ((net, opt), (ref, topt)):
+            o.zero_grad()
+            model(x).square().sum().backward()
+            o.step()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, atol=1e-6)
+    # loading a checkpoint must not re-home the momentum buffer (a captured graph holds its address)
+    opt.load_state_dict(topt.state_dict())
+    assert opt.buf.data_ptr() == buf_ptr and abs(opt.lr - topt.param_groups[0]['lr']) < 1e-12
+    assert float(opt.lr_t) == pytest.approx(opt.lr)
+    off, n = flat.slices[0]
+    assert torch.allclose(opt.buf[off:off + n], topt.state_dict()['state'][0]['momentum_buffer'].reshape(-1), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_train_model_trajectory_gpu(tmp_path):
+    """The product path: HIP kernels, iterations 3-6 replayed from hipGraphs (the first two run eagerly, then the step is
+    captured), lr fed through the device scalar, checkpoint + resume across the epoch boundary."""
+    z, tr, m, data, cfg = _setup(tmp_path)
+    p0 = {k: p.detach().double().numpy().copy() for k, p in m.named_parameters()}
+    runner = train_model(m, data, cfg, device='cuda', use_graph=True)
+    assert runner.engine.capture_error is None and len(runner.engine._graphs) == 1
+    _check(z, tr, m, runner, p0)
+    final = {k: v.clone() for k, v in m.state_dict().items()}
+    z2, _, m2, data2, cfg2 = _setup(tmp_path / 'second', resume_from=str(tmp_path / 'epoch_1.pth'))
+    r2 = train_model(m2, data2, cfg2, device='cuda', use_graph=True)
+    assert r2.epoch == 2 and r2.iter == 6
+    for k, v in m2.state_dict().items():          # every reduction on the path is ordered: eager and replayed steps agree bit for bit
+        assert torch.equal(v, final[k]), k
+    # eager run of the same loop == the graphed one
+    z3, _, m3, data3, cfg3 = _setup(tmp_path / 'third')
+    train_model(m3, data3, cfg3, device='cuda', use_graph=False)
+    for k, v in m3.state_dict().items():
+        assert torch.equal(v, final[k]), k
+
+
+def _dp_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    z, tr, m, data, cfg = _setup(os.path.join(out_dir, f'w{rank}'), total_epochs=1)
+    cfg['data']['videos_per_gpu'] = 4
+    if rank == 1:                                   # a rank that starts from other weights: the wrap-time broadcast fixes it
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.01)
+    with D.kernels.use_ops(torch_ops):
+        runner = train_model(m, data, cfg, device='cpu', use_graph=False)
+    torch.save(dict(p=runner.engine.flat.flat_p.clone(), log=runner.log, iters=runner.iter), os.path.join(out_dir, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_train_model_two_ranks_gloo(tmp_path):
+    """The N > 1 path of the loop on CPU: each rank walks its share of the reference sampler's order (24 clips -> 12 per
+    rank, 3 iterations of 4), gradients averaged by one all-reduce per step, log scalars by one per interval: the
+    replicas end bit-identical and log the same (rank-averaged) numbers."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [torch.load(tmp_path / f'r{r}.pt', weights_only=False) for r in range(2)]
+    assert r0['iters'] == r1['iters'] == 3
+    assert torch.equal(r0['p'], r1['p'])
+    assert [rec['loss'] for rec in r0['log']] == [rec['loss'] for rec in r1['log']]

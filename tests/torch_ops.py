@@ -268,3 +268,28 @@ def temporal_mlp_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, 
     mix = lambda t: torch.einsum('oc,nctv->notv', pw_w, t) + _bc(pw_b)    # noqa: E731
     out = mix(dw) + o if merge_after else mix(dw + o)
     return _bn_of(out, gamma, beta, eps, want_bn)
+
+
+def temporal_unitmlp_bn(h, dw_w, dw_b, dw_dil, tw, tb, tdil, pw_w, pw_b, merge_after, stride, gamma=None, beta=None,
+                        eps=1e-5, want_bn=False):
+    """unitmlp as a whole temporal unit (see dsgcn_amd.kernels.temporal_unitmlp_bn) in plain torch ops."""
+    n, C, T, V = h.shape
+    KM = dw_w.shape[1]
+    Tout = (T + stride - 1) // stride
+    dw = h.new_zeros(n, C, Tout, V)
+    for c in range(C):
+        dl = int(dw_dil[c])
+        if dl == 0:
+            continue
+        xp = F.pad(h[:, c], (0, 0, (KM - 1) * dl, 0))
+        acc = dw_b[c]
+        for j in range(KM):
+            acc = acc + dw_w[c, j] * xp[:, j * dl:j * dl + (Tout - 1) * stride + 1:stride]
+        dw[:, c] = acc
+    mix = lambda t: torch.einsum('oc,nctv->notv', pw_w.reshape(pw_w.shape[0], -1), t) + _bc(pw_b)    # noqa: E731
+    t = tconv(h, tw, tb, stride, tdil)[0] if tw is not None else None
+    if t is None:
+        out = mix(dw)
+    else:
+        out = mix(dw) + t if merge_after else mix(dw + t)
+    return _bn_of(out, gamma, beta, eps, want_bn)
