@@ -53,7 +53,11 @@ def _stream():
 
 _side_streams = {}
 import os as _os
-OVERLAP = _os.environ.get('DSGCN_OVERLAP', '1') != '0'     # run K-B (dynamic adjacency: one block per sample, half the CUs) beside the `pre` channel mix
+OVERLAP = _os.environ.get('DSGCN_OVERLAP', '1') != '0'
+# csrc/tms.hip, the fused temporal stage: 'auto' = where it measured faster than the staged chain (5-tap windows: CTR-GCN's
+# MSTCN, 22.3 -> 21.0 ms/step; on DS-STGCN's 3-tap units the staged wide-load kernels are still ahead, 13.6 vs 16.8 ms:
+# profiles/r03/README.md), '1' = wherever eligible, '0' = never
+FUSED_TEMPORAL = _os.environ.get('DSGCN_FUSED_TEMPORAL', 'auto')     # run K-B (dynamic adjacency: one block per sample, half the CUs) beside the `pre` channel mix
 
 
 class side_branch:
@@ -683,16 +687,149 @@ def _branch_tables(branch_cfg, widths, conv_w, conv_b):
     return KT or 3, types, c0s, bcs, dils, ws, bs
 
 
+class _TemporalFused(torch.autograd.Function):
+    """The whole multi-scale temporal stage between the unit's two 1x1 convs as ONE launch per direction (csrc/tms.hip):
+    BN affine + ReLU of the branch conv's output applied while staging, the global-joint column carried in LDS only,
+    dilated convs / max-pool / strided copy per channel window, ``f = o[..., :V] + o[..., V] * coeff`` and the batch
+    statistics of f in the epilogue.  Neither h nor o is materialised.  zaug / coeff None: no global joint (mstcn, MSTCN)."""
+
+    @staticmethod
+    def forward(ctx, z, zaug, scale, shift, coeff, gamma, beta, n_act, stride, KT, types, c0s, bcs, dils, eps, want_bn,
+                *wb):
+        _require_cuda(z)
+        z, zaug, scale, shift, coeff, gamma, beta = [_f32c(t) for t in (z, zaug, scale, shift, coeff, gamma, beta)]
+        nbr = len(types)
+        ws = [_f32c(t) for t in wb[:nbr]]
+        bs = [_f32c(t) for t in wb[nbr:]]
+        n, C, T, V = z.shape
+        Tout = (T + stride - 1) // stride
+        dev = z.device
+        lib = native.lib()
+        aug = zaug is not None
+        tabs = (_int_array(types), _int_array(c0s), _int_array(bcs), _int_array(dils))
+        rows = lib.dsgcn_tms_rows(0, n, C, T, V, stride, KT, nbr, tabs[0], tabs[2], tabs[3], int(aug))
+        assert rows > 0
+        f = torch.empty((n, C, Tout, V), device=dev, dtype=torch.float32)
+        oaug = torch.empty((n, C, Tout), device=dev, dtype=torch.float32) if aug else None
+        stats = torch.empty((rows, C, 2), device=dev, dtype=torch.float32) if want_bn else None
+        rc = lib.dsgcn_tms_fwd(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), int(n_act), _ptr(coeff), _ptr(f),
+                               _ptr(oaug), _ptr(stats), n, C, T, V, stride, KT, nbr, *tabs, _ptr_array(ws),
+                               _ptr_array(bs), _stream())
+        native.check(rc, 'dsgcn_tms_fwd')
+        scale1 = shift1 = mean = var = None
+        count = float(n * Tout * V)
+        if want_bn:
+            st = torch.empty((4, C), device=dev, dtype=torch.float32)
+            mean, var, scale1, shift1 = st[0], st[1], st[2], st[3]
+            rc = lib.dsgcn_bn_finalize(_ptr(stats), rows, C, count, _ptr(gamma), _ptr(beta), float(eps), _ptr(mean),
+                                       _ptr(var), _ptr(scale1), _ptr(shift1), C, _stream())
+            native.check(rc, 'dsgcn_bn_finalize')
+            ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(z, zaug, scale, shift, coeff, f, oaug, gamma, mean, var, *[w for w in ws if w is not None])
+        ctx.cfg = (int(n_act), int(stride), int(KT), tuple(types), tuple(c0s), tuple(bcs), tuple(dils), float(eps),
+                   bool(want_bn), count, beta is not None, tuple(b is not None for b in bs))
+        return f, scale1, shift1, mean, var
+
+    @staticmethod
+    def backward(ctx, gf, gscale, gshift, _gm, _gv):
+        z, zaug, scale, shift, coeff, f, oaug, gamma, mean, var, *wsaved = ctx.saved_tensors
+        n_act, stride, KT, types, c0s, bcs, dils, eps, want_bn, count, has_beta, has_b = ctx.cfg
+        n, C, T, V = z.shape
+        nbr = len(types)
+        dev = z.device
+        lib = native.lib()
+        st = _stream()
+        aug = zaug is not None
+        gf, gscale, gshift = _f32c(gf), _f32c(gscale), _f32c(gshift)
+        A0 = B0 = dgamma = dbeta = None
+        if want_bn and (gscale is not None or gshift is not None):
+            coef = torch.empty((4, C), device=dev, dtype=torch.float32)
+            dgamma, dbeta, A0, B0 = coef[0], coef[1], coef[2], coef[3]
+            rc = lib.dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, C, C,
+                                       _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), st)
+            native.check(rc, 'dsgcn_bn_bwd_coef')
+        if gf is None:
+            gf = torch.zeros_like(f)
+        it = iter(wsaved)
+        ws = [next(it) if t == 0 else None for t in types]
+        tabs = (_int_array(types), _int_array(c0s), _int_array(bcs), _int_array(dils))
+        rows = lib.dsgcn_tms_rows(1, n, C, T, V, stride, KT, nbr, tabs[0], tabs[2], tabs[3], int(aug))
+        paff = torch.empty((rows, C, 2), device=dev, dtype=torch.float32)
+        pcoeff = torch.empty((rows * nbr, V), device=dev, dtype=torch.float32) if aug else None
+        dz = torch.empty_like(z)
+        dzaug = torch.empty_like(zaug) if aug else None
+        rc = lib.dsgcn_tms_dgrad(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), n_act, _ptr(coeff), _ptr(gf), _ptr(f),
+                                 _ptr(A0), _ptr(B0), _ptr(oaug), _ptr(dz), _ptr(dzaug), _ptr(paff), _ptr(pcoeff), n, C, T,
+                                 V, stride, KT, nbr, *tabs, _ptr_array(ws), st)
+        native.check(rc, 'dsgcn_tms_dgrad')
+        dscale = dshift = dcoeff = None
+        if scale is not None:
+            red = colsum(paff, split_last=True)
+            dscale, dshift = red[0], red[1]
+        if aug:
+            dcoeff = colsum(pcoeff)
+        dws, dbs = [None] * nbr, [None] * nbr
+        if 0 in types:
+            offs, off = [], 0
+            for t, bc in zip(types, bcs):
+                offs.append(off)
+                if t == 0:
+                    off += bc * bc * KT + bc
+            pstride = off
+            rows2 = lib.dsgcn_tms_rows(2, n, C, T, V, stride, KT, nbr, tabs[0], tabs[2], tabs[3], int(aug))
+            part = torch.empty((rows2, pstride), device=dev, dtype=torch.float32)
+            base = part.data_ptr()
+            dwp = (_ct.c_void_p * nbr)(*[base + 4 * o if t == 0 else None for t, o in zip(types, offs)])
+            dbp = (_ct.c_void_p * nbr)(*[base + 4 * (o + bc * bc * KT) if t == 0 else None
+                                         for t, o, bc in zip(types, offs, bcs)])
+            rc = lib.dsgcn_tms_wgrad(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), n_act, _ptr(coeff), _ptr(gf), _ptr(f),
+                                     _ptr(A0), _ptr(B0), n, C, T, V, stride, KT, nbr, *tabs, dwp, dbp, pstride, st)
+            native.check(rc, 'dsgcn_tms_wgrad')
+            red = colsum(part)
+            dws = [red[o:o + bc * bc * KT].view(bc, bc, KT, 1) if t == 0 else None for t, o, bc in zip(types, offs, bcs)]
+            dbs = [red[o + bc * bc * KT:o + bc * bc * KT + bc] if (t == 0 and hb) else None
+                   for t, o, bc, hb in zip(types, offs, bcs, has_b)]
+        if dgamma is not None:
+            dgamma = dgamma if gamma is not None else None
+            dbeta = dbeta if has_beta else None
+        return (dz, dzaug, dscale, dshift, dcoeff, dgamma, dbeta, None, None, None, None, None, None, None, None, None,
+                *dws, *dbs)
+
+
+def _fused_temporal(z, zaug, scale, shift, coeff, n_act, branch_cfg, widths, conv_w, conv_b, stride, gamma, beta, eps,
+                    want_bn):
+    """-> (f, scale, shift, mean, var) through csrc/tms.hip, or None when the shape is not eligible."""
+    KT, types, c0s, bcs, dils, ws, bs = _branch_tables(branch_cfg, widths, conv_w, conv_b)
+    n, C, T, V = z.shape
+    if FUSED_TEMPORAL == '0' or (FUSED_TEMPORAL == 'auto' and KT == 3):
+        return None
+    if sum(bcs) != C or any(c0s[i] + bcs[i] != c0s[i + 1] for i in range(len(bcs) - 1)) or c0s[0] != 0:
+        return None
+    rows = native.lib().dsgcn_tms_rows(0, n, C, T, V, int(stride), KT, len(types), _int_array(types), _int_array(bcs),
+                                       _int_array(dils), int(zaug is not None))
+    if rows <= 0:
+        return None
+    return _TemporalFused.apply(z, zaug, scale, shift, coeff, gamma, beta, int(n_act), int(stride), KT, types, c0s, bcs,
+                                dils, float(eps), bool(want_bn), *ws, *bs)
+
+
 def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, add_coeff, stride, gamma=None,
                 beta=None, eps=1e-5, want_bn=False):
     """-> (f, scale, shift, mean, var): branch_act -> temporal branches (dilated convs / max-pool / copy) -> combine
     (+ statistics of transform.0's BatchNorm); three HIP stages, no torch.cat, no MIOpen."""
     _require_cuda(z)
     n, C, T, V = z.shape
+    coeff = add_coeff if add_coeff.shape[0] == V else add_coeff[:V].contiguous()
+    if FUSED_TEMPORAL != '0':
+        out = _fused_temporal(z, zaug, scale, shift, coeff, n_act, branch_cfg, widths, conv_w, conv_b, stride, gamma, beta,
+                              eps, want_bn)
+        if out is not None:
+            return out
+    # shapes the fused kernels do not take (plane sizes that are not multiples of 4 floats, ...): the staged form
     h = _BranchAct.apply(z, zaug, scale, shift, n_act)
     KT, types, c0s, bcs, dils, ws, bs = _branch_tables(branch_cfg, widths, conv_w, conv_b)
     o = _TapBranches.apply(h, int(stride), KT, C, types, c0s, c0s, bcs, bcs, dils, *ws, *bs)
-    coeff = add_coeff if add_coeff.shape[0] == V else add_coeff[:V].contiguous()
     return _TmsCombine.apply(o, coeff, gamma, beta, float(eps), bool(want_bn))
 
 
@@ -756,6 +893,11 @@ def temporal_branches_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, con
     -> (o, scale, shift, mean, var)"""
     _require_cuda(z)
     n, C, T, V = z.shape
+    if FUSED_TEMPORAL != '0':
+        out = _fused_temporal(z, None, scale, shift, None, n_act, branch_cfg, widths, conv_w, conv_b, stride, gamma, beta,
+                              eps, want_bn)
+        if out is not None:
+            return out
     h = _BranchAct.apply(z, None, scale, shift, n_act)
     KT, types, c0s, bcs, dils, ws, bs = _branch_tables(branch_cfg, widths, conv_w, conv_b)
     o = _TapBranches.apply(h, int(stride), KT, C, types, c0s, c0s, bcs, bcs, dils, *ws, *bs)

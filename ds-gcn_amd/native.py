@@ -55,6 +55,10 @@ SIGNATURES = {
     'dsgcn_tapconv_dgrad': [c_f, c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, c_st],
     'dsgcn_tapconv_wgrad_splits': [c_int] * 8 + [c_i] * 4,
     'dsgcn_tapconv_wgrad': [c_f, c_f] + [c_int] * 8 + [c_i] * 6 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_st],
+    'dsgcn_tms_rows': [c_int] * 8 + [c_i] * 3 + [c_int],
+    'dsgcn_tms_fwd': [c_f] * 4 + [c_int] + [c_f] * 4 + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_st],
+    'dsgcn_tms_dgrad': [c_f] * 4 + [c_int] + [c_f] * 10 + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, c_st],
+    'dsgcn_tms_wgrad': [c_f] * 4 + [c_int] + [c_f] * 5 + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_st],
     'dsgcn_aggsum_partial_rows': [c_int, c_int, c_int],
     'dsgcn_aggsum_bwd_piece_rows': [c_int] * 5,
     'dsgcn_aggsum_fwd': [c_f, c_f] + [ctypes.c_long] * 3 + [c_f, c_f] + [c_int] * 5 + [c_st],
@@ -87,6 +91,7 @@ LAB_SIGNATURES = {
     'dsgcn_pwconv_tuning': [c_int, c_int],
     'dsgcn_diag_mfma_probe': [c_f, c_int, c_int, c_int, c_st],
     'dsgcn_aggsum_tuning': [c_int, c_int],
+    'dsgcn_tms_tuning': [c_int, c_int],
 }
 
 

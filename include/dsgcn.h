@@ -224,6 +224,38 @@ int dsgcn_dwcausal_fwd(const float* h, const float* w, const float* b, const int
 int dsgcn_dwcausal_bwd(const float* h, const float* w, const int* dil, const float* dy, float* dh, float* part, int n,
                        int C, int T, int V, int stride, int KM, void* stream);
 
+/* K-D, fused (csrc/tms.hip): the whole multi-scale temporal stage between the two 1x1 convs of dgmstcn / mstcn / MSTCN
+ * (reference: pyskl/models/gcns/utils/tcn.py:383-396,409-420 and msg3d_utils.py:84-117) as ONE launch per direction on
+ * the (n, C, T, V) layout, any V:
+ *   h = act(z*scale + shift) [ReLU on channels < n_act] with the global-joint column act(zaug*scale + shift) appended
+ *       (zaug (n,C,T) or NULL: no global joint);  scale/shift NULL: h = z;
+ *   o = per channel window i (type 0: (KT,1) conv of dilation dil, weights w[i] (bc,bc,KT,1), bias b[i]; 1: (3,1)
+ *       max-pool, pad 1; 2: strided copy), windows [c0, c0+bc) of input and output coincide, stride 1 or 2 over frames;
+ *   f = o[..., :V] + o[..., V] * coeff  (zaug given; else f = o);  oaug (n,C,Tout) = o[..., V] kept for the backward;
+ *   stats (rows(0), C, 2): per-workgroup partial sums of f and f^2 (dsgcn_bn_finalize finishes them), or NULL.
+ * Replaces dsgcn_branch_act_* + dsgcn_tapconv_* + dsgcn_tms_combine_* and their two (V+1)-column intermediates.
+ * Backward: gf = gradient of f; A0/B0 (C) the statistics terms of the BatchNorm that consumes f (dfe = gf + A0 + B0*f),
+ *   or NULL; dz (n,C,T,V), dzaug (n,C,T);  paff (rows(1), C, 2) partials of d scale / d shift;  pcoeff (rows(1)*nbr, V)
+ *   partials of d coeff;  dsgcn_tms_wgrad: window i writes row r < rows(2) of its weight / bias partials at
+ *   dwp[i] + r*pstride / dbp[i] + r*pstride (dsgcn_colsum finishes them).
+ * dsgcn_tms_rows(which, ...) -> the partial-row counts above, or 0 when the shape is not eligible (KT 3 or 5, stride 1
+ * or 2, T*V and Tout*V multiples of 4, windows <= 64 channels, dil*(KT/2) <= 4): the staged kernels then apply. */
+int dsgcn_tms_rows(int which, int n, int C, int T, int V, int stride, int KT, int nbr, const int* type, const int* bc,
+                   const int* dil, int aug);
+int dsgcn_tms_fwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                  const float* coeff, float* f, float* oaug, float* stats, int n, int C, int T, int V, int stride, int KT,
+                  int nbr, const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
+                  const float* const* b, void* stream);
+int dsgcn_tms_dgrad(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                    const float* coeff, const float* gf, const float* f, const float* A0, const float* B0,
+                    const float* oaug, float* dz, float* dzaug, float* paff, float* pcoeff, int n, int C, int T, int V,
+                    int stride, int KT, int nbr, const int* type, const int* c0, const int* bc, const int* dil,
+                    const float* const* w, void* stream);
+int dsgcn_tms_wgrad(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                    const float* coeff, const float* gf, const float* f, const float* A0, const float* B0, int n, int C,
+                    int T, int V, int stride, int KT, int nbr, const int* type, const int* c0, const int* bc,
+                    const int* dil, float* const* dwp, float* const* dbp, int pstride, void* stream);
+
 /* Skeleton input pipeline, per-element half (csrc/skeleton.hip).  Replaces the numpy transforms of the reference's
  * loader workers — PreNormalize3D (pose_related.py:250-336), RandomRot (144-178), JointToBone / ToMotion / GenSkeFeat
  * (340-442), PoseDecode (19-54), FormatGCNInput (468-518) — for a whole batch in one launch; the per-clip decisions

@@ -27,6 +27,9 @@ int dsgcn_pwconv_tuning(int key, int value);
 /* launch-geometry knobs of K-A' (key 0: pipelined kernels on/off, 1: forward waves, 2: backward workgroups) */
 int dsgcn_aggsum_tuning(int key, int value);
 
+/* fused temporal stage (key 0: ablation mask 1 no staging / 2 no MFMA / 4 no epilogue, 1: workgroups per window, 2: frames per tile) */
+int dsgcn_tms_tuning(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif

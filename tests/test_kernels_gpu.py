@@ -308,11 +308,19 @@ def test_fuse_out(n, C, T, V, mode, tmean, flags):
 
 
 @pytest.mark.parametrize('n,C,T,V,stride', [(2, 64, 32, 25, 1), (2, 128, 32, 25, 2), (2, 48, 20, 17, 1), (1, 12, 9, 18, 2),
+                                            # the fused stage (csrc/tms.hip): full tiles, a ragged last tile, two tiles per
+                                            # sample at stride 2, three m-tiles, K400 planes
+                                            (3, 64, 64, 25, 1), (2, 64, 24, 25, 1), (2, 128, 64, 25, 2), (2, 256, 8, 25, 1),
+                                            (2, 64, 100, 17, 2), (5, 128, 32, 25, 1),
                                             # wide-load kernels at 2 MFMA row tiles / 64-channel weight-gradient tiles, both strides
                                             (2, 256, 16, 25, 1), (2, 256, 16, 25, 2),
                                             # frame counts the weight gradient's 4-frame units do not divide (mixed paths)
                                             (2, 64, 10, 25, 1), (2, 64, 12, 25, 2), (3, 64, 6, 17, 1)])
-def test_temporal_ms(n, C, T, V, stride):
+@pytest.mark.parametrize('fused', ['1', '0'])
+def test_temporal_ms(n, C, T, V, stride, fused, monkeypatch):
+    """fused '1': the one-launch-per-direction stage (csrc/tms.hip) wherever the shape is eligible; '0': the staged chain
+    (branch_act -> tapconv -> combine).  Both against the fp64 statement of the op."""
+    monkeypatch.setattr(K, 'FUSED_TEMPORAL', fused)
     g = torch.Generator().manual_seed(C + T + stride)
     cfg = [(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1']
     mid = C // 6
@@ -418,8 +426,10 @@ def test_ctr_topology(n, Ci, Co, V):
 
 @pytest.mark.parametrize('n,C,T,V,stride,ks', [(2, 64, 32, 25, 1, 5), (2, 128, 32, 25, 2, 5), (2, 256, 16, 25, 1, 5),
                                                (2, 32, 21, 17, 2, 5), (1, 16, 9, 18, 1, 3)])
-def test_temporal_branches_bn(n, C, T, V, stride, ks):
+@pytest.mark.parametrize('fused', ['1', '0'])
+def test_temporal_branches_bn(n, C, T, V, stride, ks, fused, monkeypatch):
     """MSTCN's stage: BN+ReLU, two dilated (k,1) convs, max-pool, strided copy, closing BatchNorm statistics."""
+    monkeypatch.setattr(K, 'FUSED_TEMPORAL', fused)
     g = torch.Generator().manual_seed(C + T + stride)
     cfg = [(ks, 1), (ks, 2), ('max', 3), '1x1']
     bc = C // 4
