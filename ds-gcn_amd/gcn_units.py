@@ -328,11 +328,11 @@ class unit_aagcn(nn.Module):
     """2s-AGCN / AAGCN spatial unit (reference: pyskl/models/gcns/utils/gcn.py:349-460): per subset a data-dependent
     topology ``A_i + alpha * tanh(conv_a_i(x)^T conv_b_i(x) / (inter_c * T))`` per sample, ``y = sum_i conv_d_i(x A_i)``,
     BN, + down(x), ReLU, then the spatial / temporal / channel attention gates (``y * sigmoid(.) + y`` each).
-    HIP chain for the channel mixes — the six embedding convs as ONE K-C launch over stacked weights, the three
-    ``conv_d`` as ONE K-C launch over the concatenated aggregated inputs (their sum is the conv's own K reduction) with
-    the BN statistics in its epilogue, ``down`` + BN + ReLU fused into the output pass — while the V x V Gram / aggregation
-    products (batched GEMMs with K = 25 .. inter_c*T) and the three attention gates stay ATen ops: this unit is an f-4
-    row, not a bench path."""
+    HIP chain: the embedding convs as two K-C launches (all conv_a, all conv_b), their Gram on K-A''s backward product,
+    the three ``conv_d`` as ONE K-C launch BEFORE the aggregation (the 1x1 conv and the joint mixing commute), the
+    aggregation with the per-sample topologies summed over subsets inside K-A' (BN statistics in its epilogue), ``down`` +
+    BN + ReLU fused into the output pass, the three gates as one pass each (csrc/aagcn.hip) with the next gate's mean in the
+    same launch.  Left to PyTorch: tanh / sigmoid and the convs / linears on KB-sized (N, C, V)-class tensors."""
 
     def __init__(self, in_channels, out_channels, A, coff_embedding=4, adaptive=True, attention=True):
         super().__init__()
@@ -398,32 +398,50 @@ class unit_aagcn(nn.Module):
         ops = kernels.ops()
         x_res = x if x_res is None else x_res
         N, C, T, V = x.shape
-        S, ic = self.num_subset, self.inter_c
+        S, ic, Co = self.num_subset, self.inter_c, self.out_c
         if self.adaptive:
-            wab = torch.cat([m.weight.flatten(1) for pair in zip(self.conv_a, self.conv_b) for m in pair], 0)
-            bab = torch.cat([m.bias for pair in zip(self.conv_a, self.conv_b) for m in pair], 0)
-            ab = ops.pwconv(x, None, None, None, False, wab, bab, 1, False)[0].reshape(N, S, 2, ic * T, V)
-            gram = torch.matmul(ab[:, :, 0].transpose(-1, -2), ab[:, :, 1]) / (ic * T)       # (N,S,V,V)  gcn.py:432-434
-            adj = self.A[None] + torch.tanh(gram) * self.alpha                               # gcn.py:435
+            # embeddings: two K-C launches (all conv_a, all conv_b) so that each side is one contiguous (N*S, ic, T, V)
+            wa = torch.cat([m.weight.flatten(1) for m in self.conv_a], 0)
+            wb = torch.cat([m.weight.flatten(1) for m in self.conv_b], 0)
+            ba = torch.cat([m.bias for m in self.conv_a], 0)
+            bb = torch.cat([m.bias for m in self.conv_b], 0)
+            ea = ops.pwconv(x, None, None, None, False, wa, ba, 1, False)[0].reshape(N * S, ic, T, V)
+            eb = ops.pwconv(x, None, None, None, False, wb, bb, 1, False)[0].reshape(N * S, ic, T, V)
+            gram = ops.gram(ea, eb).view(N, S, V, V) / (ic * T)                              # gcn.py:432-434
+            adj = self.A[None] + torch.tanh(gram) * self.alpha                               # gcn.py:435 (KB-sized)
         else:
-            adj = self.A[None]
-        z = torch.matmul(x.reshape(N, 1, C * T, V), adj).reshape(N, S * C, T, V)              # gcn.py:436-437 per subset
-        wd = torch.cat([m.weight.flatten(1) for m in self.conv_d], 1)                        # (Co, S*C): sum_i conv_d_i
-        bd = torch.stack([m.bias for m in self.conv_d]).sum(0)
-        zo, ao = op_bn(self.bn, lambda g, b, eps, want: _pw_bn(ops, z, wd, bd, g, b, eps, want),
-                       lambda o: N * T * V)
+            adj = self.A
+        # sum_i conv_d_i(x . A_i) = sum_i (W_i x) . A_i: the 1x1 conv acts on channels, A_i on joints, so the conv runs
+        # first, as ONE launch over the stacked weights, and the sum over subsets happens inside K-A''s accumulators
+        # (with the BN statistics in its epilogue).  The biases commute only as their sum: it is a per-channel constant
+        # under the BatchNorm that follows — it moves the running mean, not the output.
+        wd = torch.cat([m.weight.flatten(1) for m in self.conv_d], 0)                        # (S*Co, Ci)
+        bsum = torch.stack([m.bias for m in self.conv_d]).sum(0)
+        p = ops.pwconv(x, None, None, None, False, wd, None, 1, False)[0]                    # (N, S*Co, T, V)
+        if _need_stats(self.bn):
+            zo, sc, sh, mean, var = ops.aggregate_sum(p, adj, S, self.bn.weight, self.bn.bias, self.bn.eps, True,
+                                                      self.adaptive)
+            record_running(self.bn, mean + bsum.detach(), var, N * T * V)
+            ao = (sc, sh + 0.0 * bsum)            # (keeps the biases on the graph: their gradient is exactly zero here)
+        else:
+            zo = ops.aggregate_sum(p, adj, S, per_sample=self.adaptive)[0]
+            sc, sh = eval_affine(self.bn)
+            ao = (sc, sh + sc * bsum)
+        want_mean = bool(self.attention)
         if self.down is None:
-            y = Deferred(zo, ao, x_res, None, True).materialize()
+            y, r0 = ops.fuse_out(zo, ao, x_res, None, True, want_mean)
         else:
             zd, _, ad = conv_bn(x_res, None, None, None, False, self.down[0], 1, False, self.down[1])
-            y = Deferred(zo, ao, zd, ad, True).materialize()
+            y, r0 = ops.fuse_out(zo, ao, zd, ad, True, want_mean)
         if self.attention:                                                                   # gcn.py:447-459
-            se1 = torch.sigmoid(self.conv_sa(y.mean(-2)))                                    # N 1 V
-            y = y * se1.unsqueeze(-2) + y
-            se1 = torch.sigmoid(self.conv_ta(y.mean(-1)))                                    # N 1 T
-            y = y * se1.unsqueeze(-1) + y
-            se2 = torch.sigmoid(self.fc2c(torch.relu(self.fc1c(y.mean(-1).mean(-1)))))       # N C
-            y = y * se2.unsqueeze(-1).unsqueeze(-1) + y
+            # three gates y <- y * sigmoid(.) + y; each pass also emits the mean the next gate is computed from, the
+            # KB-sized convs / linears on those means stay PyTorch (like the head)
+            g1 = torch.sigmoid(self.conv_sa(r0)).squeeze(1)                                  # (N, V) from the mean over T
+            y, r1 = ops.gate(y, g1, 0, 1)
+            g2 = torch.sigmoid(self.conv_ta(r1)).squeeze(1)                                  # (N, T) from the mean over V
+            y, r2 = ops.gate(y, g2, 1, 2)
+            g3 = torch.sigmoid(self.fc2c(torch.relu(self.fc1c(r2))))                         # (N, C)
+            y, _ = ops.gate(y, g3, 2, 0)
         return as_deferred(y)
 
     def forward(self, x):

@@ -1005,14 +1005,18 @@ def tconv(h, weight, bias, stride, dilation, gamma=None, beta=None, eps=1e-5, wa
 class _AggSum(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, p, adj, K, gamma, beta, eps, want_bn):
+    def forward(ctx, p, adj, K, gamma, beta, eps, want_bn, per_sample=False):
         _require_cuda(p, adj)
         p, adj, gamma, beta = _f32c(p), _f32c(adj), _f32c(gamma), _f32c(beta)
         n, KC, T, V = p.shape
         Co = KC // K
         shared = adj.dim() == 3
-        assert adj.shape == ((K, V, V) if shared else (n, KC, V, V)), (adj.shape, p.shape)
-        astr = (0, V * V, 0) if shared else (KC * V * V, Co * V * V, V * V)
+        if per_sample:          # (n, K, V, V): one topology per sample and subset, shared by the channels (AAGCN)
+            assert adj.shape == (n, K, V, V), (adj.shape, p.shape)
+            astr = (K * V * V, V * V, 0)
+        else:
+            assert adj.shape == ((K, V, V) if shared else (n, KC, V, V)), (adj.shape, p.shape)
+            astr = (0, V * V, 0) if shared else (KC * V * V, Co * V * V, V * V)
         dev = p.device
         lib = native.lib()
         y = torch.empty((n, Co, T, V), device=dev, dtype=torch.float32)
@@ -1031,13 +1035,13 @@ class _AggSum(torch.autograd.Function):
             ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(p, adj, y, gamma, mean, var)
-        ctx.cfg = (K, float(eps), bool(want_bn), count, beta is not None, shared, astr)
+        ctx.cfg = (K, float(eps), bool(want_bn), count, beta is not None, shared, astr, bool(per_sample))
         return y, scale, shift, mean, var
 
     @staticmethod
     def backward(ctx, gy, gscale, gshift, _gm, _gv):
         p, adj, y, gamma, mean, var = ctx.saved_tensors
-        K, eps, want_bn, count, has_beta, shared, astr = ctx.cfg
+        K, eps, want_bn, count, has_beta, shared, astr, per_sample = ctx.cfg
         n, KC, T, V = p.shape
         Co = KC // K
         dev = p.device
@@ -1053,7 +1057,11 @@ class _AggSum(torch.autograd.Function):
         if gy is None:
             gy = torch.zeros_like(y)
         dp = torch.empty_like(p)
-        if shared:
+        if per_sample:
+            # channel-major per-(n, c) pieces: the ordered sum over the channels is one dsgcn_colsum over dim 0
+            dpiece = torch.empty((Co, n, K, V, V), device=dev, dtype=torch.float32)
+            dstr = (K * V * V, V * V, n * K * V * V)
+        elif shared:
             rows = lib.dsgcn_aggsum_bwd_piece_rows(n, K, Co, T, V)       # per-wave pieces, or per-(n,c) ones if 0
             dpiece = torch.empty((rows or n * Co, K, V, V), device=dev, dtype=torch.float32)
             dstr = (Co * K * V * V, V * V, K * V * V)
@@ -1063,18 +1071,105 @@ class _AggSum(torch.autograd.Function):
         rc = lib.dsgcn_aggsum_bwd(_ptr(p), _ptr(adj), *astr, _ptr(gy), _ptr(y), _ptr(A0), _ptr(B0), _ptr(dp),
                                   _ptr(dpiece), *dstr, n, K, Co, T, V, _stream())
         native.check(rc, 'dsgcn_aggsum_bwd')
-        dadj = colsum(dpiece) if shared else dpiece
+        dadj = colsum(dpiece) if (shared or per_sample) else dpiece
         if dgamma is not None:
             dgamma = dgamma if gamma is not None else None
             dbeta = dbeta if has_beta else None
-        return dp, dadj, None, dgamma, dbeta, None, None
+        return dp, dadj, None, dgamma, dbeta, None, None, None
 
 
-def aggregate_sum(p, adj, K, gamma=None, beta=None, eps=1e-5, want_bn=False):
+def aggregate_sum(p, adj, K, gamma=None, beta=None, eps=1e-5, want_bn=False, per_sample=False):
     """y[n,c,t,w] = sum_k sum_u p[n,k*Co+c,t,u] * adj_k[u,w]; adj (K,V,V) shared (ST-GCN unit_gcn) or (n,K*Co,V,V)
-    per sample and channel (CTR-GCN), plus the train-mode BN of y as a deferred affine.
-    -> (y, scale, shift, mean, var)"""
-    return _AggSum.apply(p, adj, int(K), gamma, beta, float(eps), bool(want_bn))
+    per sample and channel (CTR-GCN), or — per_sample — (n,K,V,V) per sample shared by the channels (AAGCN), plus the
+    train-mode BN of y as a deferred affine.  -> (y, scale, shift, mean, var)"""
+    return _AggSum.apply(p, adj, int(K), gamma, beta, float(eps), bool(want_bn), bool(per_sample))
+
+
+# ---------------------------------------------------------------------------------------------
+# AAGCN: embedding Gram and attention gates (gcn.py:431-437, 447-459)
+# ---------------------------------------------------------------------------------------------
+
+class _Gram(torch.autograd.Function):
+    """G[n,u,w] = sum_{c,t} a[n,c,t,u] * b[n,c,t,w] for a, b (n, C, T, V): K-A''s backward product (the per-plane
+    P^T dY pieces of dsgcn_aggsum_bwd, summed over the channels by an ordered dsgcn_colsum); its own backward is two K-A'
+    forward launches with the per-sample V x V factor shared by the channels."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_cuda(a, b)
+        a, b = _f32c(a), _f32c(b)
+        n, C, T, V = a.shape
+        dev = a.device
+        zero = torch.zeros((n, V, V), device=dev, dtype=torch.float32)
+        scratch = torch.empty_like(a)                                  # the launch also writes d p (unused here)
+        piece = torch.empty((C, n, V, V), device=dev, dtype=torch.float32)
+        rc = native.lib().dsgcn_aggsum_bwd(_ptr(a), _ptr(zero), V * V, 0, 0, _ptr(b), None, None, None, _ptr(scratch),
+                                           _ptr(piece), V * V, 0, n * V * V, n, 1, C, T, V, _stream())
+        native.check(rc, 'dsgcn_aggsum_bwd')
+        ctx.save_for_backward(a, b)
+        return colsum(piece)
+
+    @staticmethod
+    def backward(ctx, dG):
+        a, b = ctx.saved_tensors
+        n, C, T, V = a.shape
+        dG = _f32c(dG)
+        dGt = dG.transpose(1, 2).contiguous()
+        lib = native.lib()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        # da[t,u] = sum_w b[t,w] dG[u,w] = (b . dG^T);  db[t,w] = sum_u a[t,u] dG[u,w]
+        native.check(lib.dsgcn_aggsum_fwd(_ptr(b), _ptr(dGt), V * V, 0, 0, _ptr(da), None, n, 1, C, T, V, _stream()),
+                     'dsgcn_aggsum_fwd')
+        native.check(lib.dsgcn_aggsum_fwd(_ptr(a), _ptr(dG), V * V, 0, 0, _ptr(db), None, n, 1, C, T, V, _stream()),
+                     'dsgcn_aggsum_fwd')
+        return da, db
+
+
+def gram(a, b):
+    return _Gram.apply(a, b)
+
+
+class _Gate(torch.autograd.Function):
+    """out = y * (1 + g) with g broadcast per joint / frame / channel (mode 0 / 1 / 2) and the mean the next gate needs
+    (rmode 1: over joints, 2: over the plane) in the same pass (csrc/aagcn.hip)."""
+
+    @staticmethod
+    def forward(ctx, y, g, mode, rmode):
+        _require_cuda(y, g)
+        y, g = _f32c(y), _f32c(g)
+        n, C, T, V = y.shape
+        assert g.shape == ((n, V), (n, T), (n, C))[mode], (g.shape, y.shape, mode)
+        out = torch.empty_like(y)
+        rout = None
+        if rmode:
+            rout = torch.empty((n, C, T) if rmode == 1 else (n, C), device=y.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_gate_fwd(_ptr(y), _ptr(g), int(mode), _ptr(out), _ptr(rout), int(rmode), n, C, T, V, _stream())
+        native.check(rc, 'dsgcn_gate_fwd')
+        ctx.save_for_backward(y, g)
+        ctx.cfg = (int(mode), int(rmode))
+        ctx.set_materialize_grads(False)
+        return out, rout
+
+    @staticmethod
+    def backward(ctx, gout, drout):
+        y, g = ctx.saved_tensors
+        mode, rmode = ctx.cfg
+        n, C, T, V = y.shape
+        gout, drout = _f32c(gout), _f32c(drout)
+        if gout is None:
+            gout = torch.zeros_like(y)
+        dy = torch.empty_like(y)
+        dgp = torch.empty((n, C, V) if mode == 0 else ((n, C, T) if mode == 1 else (n, C)), device=y.device,
+                          dtype=torch.float32)
+        rc = native.lib().dsgcn_gate_bwd(_ptr(y), _ptr(g), mode, _ptr(gout), _ptr(drout), rmode, _ptr(dy), _ptr(dgp), n, C,
+                                         T, V, _stream())
+        native.check(rc, 'dsgcn_gate_bwd')
+        dg = dgp if mode == 2 else dgp.sum(1)              # (n, C, .) -> (n, .): KB-sized
+        return dy, dg, None, None
+
+
+def gate(y, g, mode, rmode):
+    return _Gate.apply(y, g, int(mode), int(rmode))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -76,6 +76,8 @@ SIGNATURES = {
     'dsgcn_fuse_out_bwd': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 5 + [c_st],
     'dsgcn_dwcausal_fwd': [c_f, c_f, c_f, c_i, c_f] + [c_int] * 6 + [c_st],
     'dsgcn_dwcausal_bwd': [c_f, c_f, c_i, c_f, c_f, c_f] + [c_int] * 6 + [c_st],
+    'dsgcn_gate_fwd': [c_f, c_f, c_int, c_f, c_f] + [c_int] * 5 + [c_st],
+    'dsgcn_gate_bwd': [c_f, c_f, c_int, c_f, c_f, c_int, c_f, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_skeleton_prep': [ctypes.c_void_p] * 11 + [c_int] * 10 + [c_st],
     'dsgcn_dynadj_partial_stride': [c_int, c_int, c_int],
     'dsgcn_dynadj_fwd': [c_f] * 6 + [c_i, c_i, c_f] + [c_int] * 6 + [c_st],

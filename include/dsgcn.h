@@ -165,7 +165,8 @@ int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const 
 
 /* ---- K-A': subset-summed aggregate (ST-GCN unit_gcn gcn.py:81-86, CTR-GCN unit_ctrgcn gcn.py:658,917-921) ----
  * y[n,c,t,w] = sum_k sum_u p[n,k*Co+c,t,u] * adj_k[u,w], adj_k at ahat + n*a_ns + k*a_ks + c*a_cs (element strides):
- * shared A (K,V,V): (0, V*V, 0); per sample and channel (n,K*Co,V,V): (K*Co*V*V, Co*V*V, V*V).
+ * shared A (K,V,V): (0, V*V, 0); per sample and channel (n,K*Co,V,V): (K*Co*V*V, Co*V*V, V*V); per sample, shared by
+ * the channels (n,K,V,V) — AAGCN's adaptive topology, gcn.py:431-437: (K*V*V, V*V, 0).
  * partial (n*Co, 2) or NULL: per-plane sum / sum of squares of y -> dsgcn_bn_finalize.
  * bwd: G = gy + A0[c] + B0[c]*y (y, A0, B0 may be NULL); dp (n,K*Co,T,V) fully written; dAhat_k of plane (n,c) is
  * written at dahat + n*d_ns + k*d_ks + c*d_cs (shared A: write per-plane pieces, reduce with dsgcn_colsum). */
@@ -255,6 +256,16 @@ int dsgcn_tms_wgrad(const float* z, const float* zaug, const float* scale, const
                     const float* coeff, const float* gf, const float* f, const float* A0, const float* B0, int n, int C,
                     int T, int V, int stride, int KT, int nbr, const int* type, const int* c0, const int* bc,
                     const int* dil, float* const* dwp, float* const* dbp, int pstride, void* stream);
+
+/* AAGCN attention gates (csrc/aagcn.hip; reference gcn.py:447-459: y <- y * sigmoid(.) + y, three times).
+ * out = y * (1 + g), g broadcast by mode: 0 g (n, V) per joint, 1 g (n, T) per frame, 2 g (n, C) per channel;
+ * rmode 1: rout (n, C, T) = mean over joints of out, rmode 2: rout (n, C) = mean over frames and joints of out (the input
+ * of the NEXT gate), 0: none.  Backward: G = gout + d(rout) spread back; dy = G * (1 + g); dgp = sum of G * y inside each
+ * (n, c) plane over the axes g is broadcast along — (n, C, V) / (n, C, T) / (n, C); the sum over C is the caller's. */
+int dsgcn_gate_fwd(const float* y, const float* g, int mode, float* out, float* rout, int rmode, int n, int C, int T,
+                   int V, void* stream);
+int dsgcn_gate_bwd(const float* y, const float* g, int mode, const float* gout, const float* drout, int rmode, float* dy,
+                   float* dgp, int n, int C, int T, int V, void* stream);
 
 /* Skeleton input pipeline, per-element half (csrc/skeleton.hip).  Replaces the numpy transforms of the reference's
  * loader workers — PreNormalize3D (pose_related.py:250-336), RandomRot (144-178), JointToBone / ToMotion / GenSkeFeat

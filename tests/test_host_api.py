@@ -92,7 +92,7 @@ def _reduced_model(name='model_reduced'):
 
 
 @pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn', 'model_reduced_stgcnpp',
-                                  'model_reduced_stgcn_shipped'])
+                                  'model_reduced_stgcn_shipped', 'model_reduced_aagcn', 'model_reduced_dggcn'])
 def test_fused_wiring_against_golden_cpu(name):
     """forward_train through the deferred-BN op chain (torch op namespace) == the reference's logits / loss / grads."""
     z, m = _reduced_model(name)

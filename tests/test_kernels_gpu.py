@@ -770,3 +770,51 @@ def test_ds_units_all_widths_vs_reference_fixture(tag):
     for k, v in m.state_dict().items():
         if 'running' in k:
             assert rel(v.cpu(), z[f'{tag}_{k}']) < 1e-5, k
+
+
+@pytest.mark.parametrize('n,C,T,V', [(3, 16, 64, 25), (2, 64, 16, 25), (2, 8, 100, 17), (1, 5, 7, 18)])
+def test_aagcn_gram_gates_and_per_sample_aggregate(n, C, T, V):
+    """The AAGCN pieces on the HIP path (gcn.py:431-437, 447-459): the embedding Gram (K-A''s backward product + ordered
+    channel sum), K-A' with one topology per sample shared by the channels, and the three gate passes with the next gate's
+    mean in the same launch — values and gradients against the fp64 statement of each op."""
+    g = torch.Generator().manual_seed(n + C + T)
+    a, b = _rand(g, n, C, T, V), _rand(g, n, C, T, V)
+    dG = _rand(g, n, V, V)
+    S, Co = 3, max(C // 2, 1)
+    p = _rand(g, n, S * Co, T, V)
+    adj = _rand(g, n, S, V, V, scale=0.3)
+    gam, bet = torch.rand(Co, generator=g) + 0.5, _rand(g, Co, scale=0.2)
+    gy, gsc, gsh = _rand(g, n, Co, T, V), _rand(g, Co), _rand(g, Co)
+    y = _rand(g, n, C, T, V)
+    gates = [torch.rand(n, V, generator=g), torch.rand(n, T, generator=g), torch.rand(n, C, generator=g)]
+    gout = _rand(g, n, C, T, V)
+    dr = [None, _rand(g, n, C, T), _rand(g, n, C)]
+
+    def run(mod, dt, dev):
+        mk = lambda t: t.to(dev, dt).requires_grad_()            # noqa: E731
+        res = {}
+        ta, tb = mk(a), mk(b)
+        G = mod.gram(ta, tb)
+        (G * dG.to(dev, dt)).sum().backward()
+        res.update(G=G, da=ta.grad, db=tb.grad)
+        tp, tadj, tg, tbt = mk(p), mk(adj), mk(gam), mk(bet)
+        yy, sc, sh, mean, var = mod.aggregate_sum(tp, tadj, S, tg, tbt, 1e-5, True, per_sample=True)
+        ((yy * gy.to(dev, dt)).sum() + (sc * gsc.to(dev, dt)).sum() + (sh * gsh.to(dev, dt)).sum()).backward()
+        res.update(y=yy, sc=sc, sh=sh, dp=tp.grad, dadj=tadj.grad, dgamma=tg.grad)
+        for mode in range(3):
+            for rmode in ((1, 2, 0)[mode], 0):
+                ty, tgt = mk(y), mk(gates[mode])
+                out, r = mod.gate(ty, tgt, mode, rmode)
+                loss = (out * gout.to(dev, dt)).sum()
+                if rmode:
+                    loss = loss + (r * dr[rmode].to(dev, dt)).sum()
+                    res[f'r{mode}{rmode}'] = r
+                loss.backward()
+                res.update({f'out{mode}{rmode}': out, f'dy{mode}{rmode}': ty.grad, f'dg{mode}{rmode}': tgt.grad})
+        return res
+
+    got = run(K, torch.float32, DEV)
+    ref = run(R, torch.float64, 'cpu')
+    for k, v in ref.items():
+        # fp32 sums over <= C*T (Gram) / n*T*V (statistics) terms: 2e-5 relative L2
+        assert rel(got[k].detach().cpu(), v.detach()) < 2e-5, (k, rel(got[k].detach().cpu(), v.detach()))

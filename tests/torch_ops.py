@@ -77,16 +77,33 @@ def aggregate(zp, ap, relu, ahat):
     return torch.einsum('nctu,ncuw->nctw', p, ahat)
 
 
-def aggregate_sum(p, adj, K, gamma=None, beta=None, eps=1e-5, want_bn=False):
-    """y[n,c,t,w] = sum_k sum_u p[n,k*Co+c,t,u] * adj_k[u,w]; adj (K,V,V) shared (ST-GCN, gcn.py:81-85) or
-    (n,K*Co,V,V) per sample and channel (CTR-GCN, gcn.py:658 + the sum over subsets gcn.py:917-919); + BN of y."""
+def aggregate_sum(p, adj, K, gamma=None, beta=None, eps=1e-5, want_bn=False, per_sample=False):
+    """y[n,c,t,w] = sum_k sum_u p[n,k*Co+c,t,u] * adj_k[u,w]; adj (K,V,V) shared (ST-GCN, gcn.py:81-85),
+    (n,K*Co,V,V) per sample and channel (CTR-GCN, gcn.py:658 + the sum over subsets gcn.py:917-919) or, per_sample,
+    (n,K,V,V) per sample shared by the channels (AAGCN, gcn.py:431-437); + BN of y."""
     n, KC, T, V = p.shape
     p5 = p.view(n, K, KC // K, T, V)
     if adj.dim() == 3:
         y = torch.einsum('nkctv,kvw->nctw', p5, adj)
+    elif per_sample:
+        y = torch.einsum('nkctu,nkuw->nctw', p5, adj)
     else:
         y = torch.einsum('nkctu,nkcuw->nctw', p5, adj.view(n, K, KC // K, V, V))
     return _bn_of(y, gamma, beta, eps, want_bn)
+
+
+def gram(a, b):
+    """G[n,u,w] = sum_{c,t} a[n,c,t,u] * b[n,c,t,w]  (AAGCN's embedding product, gcn.py:432-434 before the scaling)."""
+    return torch.einsum('nctu,nctw->nuw', a, b)
+
+
+def gate(y, g, mode, rmode):
+    """AAGCN attention gate (gcn.py:447-459): out = y * (1 + g) with g (n,V) / (n,T) / (n,C) for mode 0 / 1 / 2; the mean
+    the next gate needs: rmode 1 -> over joints (n,C,T), 2 -> over frames and joints (n,C), 0 -> None."""
+    gb = g[:, None, None, :] if mode == 0 else (g[:, None, :, None] if mode == 1 else g[:, :, None, None])
+    out = y * (1 + gb)
+    r = out.mean(-1) if rmode == 1 else (out.mean((-1, -2)) if rmode == 2 else None)
+    return out, r
 
 
 def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None):
