@@ -584,6 +584,28 @@ __global__ __launch_bounds__(1024) void k_colsum(ColJob a, ColJob b) {
   else colsum_body(b, blockIdx.x - a.nblk);
 }
 
+// any number of independent reductions in one launch: the partial rows of parameter gradients (weights, biases, A,
+// alpha / beta, add_coeff) feed nothing but the optimizer, so their ~55 column sums per DS-STGCN step are queued during
+// the backward and finished by ONE launch before the gradients are packed.  table: njobs x {src, out, (R, C) packed,
+// first block} as 64-bit words (device memory), blocks of a job are contiguous in the grid.
+__global__ __launch_bounds__(1024) void k_colsum_multi(const long* __restrict__ table, int njobs) {
+  // binary search of the job that owns this block (first-block column is ascending)
+  int lo = 0, hi = njobs - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)table[4 * mid + 3] <= b) lo = mid; else hi = mid - 1;
+  }
+  ColJob j;
+  j.src = reinterpret_cast<const float*>(table[4 * lo]);
+  j.out = reinterpret_cast<float*>(table[4 * lo + 1]);
+  j.R = (int)(table[4 * lo + 2] >> 32);
+  j.C = (int)(table[4 * lo + 2] & 0xffffffffL);
+  j.inner = 1;
+  j.nblk = 0;
+  colsum_body(j, b - (int)table[4 * lo + 3]);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Backward.
 //   dz_eff[co,pos] = g_z + A0[co] + B0[co]*z                     (the BN-statistics terms: d mean / d var of this conv's
@@ -1273,6 +1295,14 @@ int dsgcn_colsum2(const float* src_a, int Ra, int Ca, int inner_a, float* out_a,
     return DSGCN_EINVAL;
   ColJob a{src_a, out_a, Ra, Ca, inner_a, (Ca + 31) / 32}, b{src_b, out_b, Rb, Cb, inner_b, (Cb + 31) / 32};
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)(a.nblk + b.nblk)), dim3(1024), 0, (hipStream_t)stream, a, b);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// table (device, njobs x 4 int64): {src pointer, out pointer, (R << 32) | C, first block}; nblocks = sum of ceil(C / 32).
+int dsgcn_colsum_multi(const long* table, int njobs, int nblocks, void* stream) {
+  if (!table || njobs <= 0 || nblocks <= 0) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_colsum_multi, dim3((unsigned)nblocks), dim3(1024), 0, (hipStream_t)stream, table, njobs);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -13,6 +13,7 @@ the log scalars and a bucketed NCCL all-reduce.  Here:
 import torch
 import torch.distributed as dist
 
+from . import kernels
 from .data_parallel import FlatDataParallel, FlatParams
 from .train import FlatSGD
 
@@ -42,7 +43,12 @@ class TrainEngine:
     def _fwd_bwd(self, keypoint, label):
         self.opt.zero_grad()
         out = self.model.train_step(dict(keypoint=keypoint, label=label), None, sync_log_vars=False)
-        out['loss'].backward()
+        if self.flat.flat_p.is_cuda:
+            # parameter-gradient partial rows are summed by ONE launch at the end of the backward (kernels.param_colsum)
+            with kernels.deferred_param_sums():
+                out['loss'].backward()
+        else:
+            out['loss'].backward()
         self.flat.collect_grads()
         return {k: v.detach() for k, v in out['log_vars'].items()}
 

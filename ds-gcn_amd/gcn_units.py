@@ -295,13 +295,15 @@ class dggcn(nn.Module):
         b = self.beta if self.subset_wise else self.beta[0].expand(3)
         dyn = kernels.ops().dynadj
         # subsets 0 and 1: slots (a0, b0) and (a1, b1) of one call (its third, node-typed slot is fed zeros and dropped)
-        first = dyn(xbar, self.A, a, b, w1[:2 * m], b1[:2 * m], w2[:2 * m], b2[:2 * m], zw, zb, we, be, self._nt0, self._et0)
+        first = dyn(xbar, self.A, a, b, w1[:2 * m], b1[:2 * m], w2[:2 * m], b2[:2 * m], zw, zb, we, be, self._nt0, self._et0,
+                    single_use=False)
         # subset 2: slot (a0, b0) of a second call
         A2 = torch.cat([self.A[2:3], torch.zeros_like(self.A[:2])])
         a2 = torch.cat([a[2:3], a.new_zeros(2)])
         b2s = torch.cat([b[2:3], b.new_zeros(2)])
         second = dyn(xbar, A2, a2, b2s, torch.cat([w1[2 * m:], zw]), torch.cat([b1[2 * m:], zb]),
-                     torch.cat([w2[2 * m:], zw]), torch.cat([b2[2 * m:], zb]), zw, zb, we, be, self._nt0, self._et0)
+                     torch.cat([w2[2 * m:], zw]), torch.cat([b2[2 * m:], zb]), zw, zb, we, be, self._nt0, self._et0,
+                     single_use=False)
         return torch.cat([first[:, :2 * m], second[:, :m]], 1)
 
     def forward_deferred(self, x, xbar=None, x_res=None):

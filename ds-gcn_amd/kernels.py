@@ -173,6 +173,125 @@ def colsum_pair(ta, tb, split_last_b=False):
     return outa.view(ta.shape[1:]), (outb.view(kb, Cb // kb) if split_last_b else outb.view(tb.shape[1:]))
 
 
+# ---------------------------------------------------------------------------------------------
+# deferred column sums of parameter-gradient partials
+# ---------------------------------------------------------------------------------------------
+# The partial rows of weight / bias / A / alpha / beta / add_coeff gradients feed nothing but the optimizer.  Inside a
+# ``deferred_param_sums()`` region (TrainEngine's backward) their column sums are queued instead of launched — ~55 launches
+# of 5-6 us each per DS-STGCN step — and ``flush_param_sums()`` finishes all of them with ONE dsgcn_colsum_multi launch
+# before the gradients are packed.  The queued outputs are handed to autograd UNFILLED, so a backward may only queue when
+# every node between its parameter inputs and the leaves is a pure view (``_leafish``): nothing reads them before the flush.
+
+_deferred = None
+_VIEW_NODES = ('ViewBackward0', 'ReshapeAliasBackward0', 'UnsafeViewBackward0', 'AliasBackward0', '_CatRowsBackward')
+
+
+def _leafish(*tensors):
+    """True when every tensor is a leaf or reaches its leaves through view-only autograd nodes."""
+    def ok(fn):
+        for _ in range(8):
+            if fn is None or type(fn).__name__ == 'AccumulateGrad':
+                return True
+            if type(fn).__name__ not in _VIEW_NODES:
+                return False
+            nxt = [f for f, _ in fn.next_functions if f is not None]
+            if len(nxt) != 1:
+                return all(ok(f) for f in nxt)
+            fn = nxt[0]
+        return False
+    return all(t is None or not t.requires_grad or ok(t.grad_fn) for t in tensors)
+
+
+class deferred_param_sums:
+    """``with deferred_param_sums(): loss.backward()`` — see above; flushes on exit."""
+
+    def __enter__(self):
+        global _deferred
+        self.prev = _deferred
+        _deferred = []
+        return self
+
+    def __exit__(self, *exc):
+        global _deferred
+        try:
+            if exc[0] is None:
+                flush_param_sums()
+        finally:
+            _deferred = self.prev
+        return False
+
+
+_defer_slots = {}
+
+
+def _defer_table(k, dev):
+    """(pinned host, device) int64 table for one dsgcn_colsum_multi call; same lifetime rules as FlatParams._pack_tables:
+    eager calls rotate over a few slots guarded by events, a call under hipGraph capture gets a table of its own."""
+    cap = max(128, k)
+
+    def new_slot():
+        host = torch.empty((cap, 4), dtype=torch.int64).pin_memory()
+        return dict(host=host, dev=torch.empty_like(host, device=dev), event=None)
+
+    st = _defer_slots.setdefault(dev, dict(slots=[], next=-1, reserved=None, graph=[]))
+    if torch.cuda.is_current_stream_capturing():
+        slot = st['reserved'] or new_slot()
+        st['reserved'] = None
+        st['graph'].append(slot)                    # alive as long as the graph may replay
+        return slot
+    if st['reserved'] is None:
+        st['reserved'] = new_slot()
+    st['next'] = (st['next'] + 1) % 4
+    if len(st['slots']) <= st['next']:
+        st['slots'].append(new_slot())
+    slot = st['slots'][st['next']]
+    if slot['host'].shape[0] < cap:
+        st['slots'][st['next']] = slot = new_slot()
+    if slot['event'] is not None:
+        slot['event'].synchronize()
+    return slot
+
+
+def flush_param_sums():
+    """One launch for every queued column sum (no-op when nothing is queued)."""
+    global _deferred
+    jobs = _deferred
+    if not jobs:
+        return
+    _deferred = [] if _deferred is not None else None
+    dev = jobs[0][0].device
+    k = len(jobs)
+    slot = _defer_table(k, dev)
+    slot['keep'] = jobs                               # sources / outputs alive until the slot is reused
+    tab = slot['host'].numpy()
+    blk = 0
+    for i, (src, R, C, out) in enumerate(jobs):
+        tab[i] = (src.data_ptr(), out.data_ptr(), (R << 32) | C, blk)
+        blk += (C + 31) // 32
+    slot['dev'].copy_(slot['host'], non_blocking=True)
+    if not torch.cuda.is_current_stream_capturing():
+        slot['event'] = torch.cuda.Event()
+        slot['event'].record()
+    native.check(native.lib().dsgcn_colsum_multi(slot['dev'].data_ptr(), k, blk, _stream()), 'dsgcn_colsum_multi')
+
+
+def param_colsum(t, defer_ok=True):
+    """colsum(t) for partial rows that feed only parameter gradients: queued inside a deferred_param_sums() region (the
+    result is then filled by flush_param_sums()), immediate otherwise."""
+    if _deferred is None or not defer_ok or not t.is_cuda:
+        return colsum(t)
+    R = t.shape[0]
+    shape = t.shape[1:]
+    C = t.numel() // max(R, 1)
+    g = _fold(R, C)
+    if g > 1:                                         # tall inputs: the wide first stage now, the small second one queued
+        t = _colsum_raw(t, R // g, g * C)
+        R = g
+    out = torch.empty(C, device=t.device, dtype=torch.float32)
+    _deferred.append((t, R, C, out))
+    return out.view(shape)
+
+
 class _CatRows(torch.autograd.Function):
     """torch.cat(tensors, 0) for parameter tensors.  When the tensors already lie back to back in one storage (FlatParams
     lays the groups its modules declare in ``flat_groups()`` out that way) the result is a view of that storage — no
@@ -272,7 +391,7 @@ class _DynAdj(torch.autograd.Function):
     (K-B, one HIP launch each way)."""
 
     @staticmethod
-    def forward(ctx, proj, A, alpha, beta, we, be, node_type, edge_type):
+    def forward(ctx, proj, A, alpha, beta, we, be, node_type, edge_type, single_use=True):
         _require_cuda(proj, A)
         proj, A, alpha, beta, we, be = [_f32c(t) for t in (proj, A, alpha, beta, we, be)]
         n, R, ld = proj.shape
@@ -287,6 +406,7 @@ class _DynAdj(torch.autograd.Function):
         native.check(rc, 'dsgcn_dynadj_fwd')
         ctx.save_for_backward(proj, alpha, beta, we, be, node_type, edge_type)
         ctx.dims = (n, mid, V, ld, P, E)
+        ctx.defer_ok = bool(single_use) and _leafish(A, alpha, beta, we, be)
         return ahat
 
     @staticmethod
@@ -304,15 +424,15 @@ class _DynAdj(torch.autograd.Function):
                                   _ptr(edge_type), _ptr(dahat), _ptr(dd), _ptr(dproj), _ptr(ppar), pstride, n, mid, V, ld,
                                   P, E, _stream())
         native.check(rc, 'dsgcn_dynadj_bwd')
-        red = colsum(ppar)                                                      # ordered sum over samples: deterministic
+        red = param_colsum(ppar, ctx.defer_ok)                                  # ordered sum over samples: deterministic
         o = 3 * V * V
         dA, dalpha, dbeta = red[:o].view(3, V, V), red[o:o + 3], red[o + 3:o + 6]
         dwe = red[o + 6:o + 6 + E * mid * mid].view(E * mid, mid)
         dbe = red[o + 6 + E * mid * mid:o + 6 + E * mid * mid + E * mid]
-        return dproj, dA, dalpha, dbeta, dwe, dbe, None, None
+        return dproj, dA, dalpha, dbeta, dwe, dbe, None, None, None
 
 
-def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type):
+def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type, single_use=True):
     """Dynamic adjacency.  The three mean-pooled projections (conv1/conv2/conv1_se) are one K-C launch on xbar — viewed
     as a (n, Ci, 1, 32) "clip" with the joint rows zero-padded to 32, so that forward, data gradient and weight gradient
     all take the 16-byte-per-lane K-C kernels (an unpadded 25-joint row is odd-sized: it fell to the scalar-load kernels,
@@ -324,7 +444,10 @@ def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, ed
     # xbar arrives zero-padded to 32 joints from the previous block's fuse_out (want_tmean=32); the first block pads here
     xpad = torch.nn.functional.pad(xbar, (0, 32 - V)) if xbar.shape[-1] < 32 else xbar
     proj = pwconv(xpad.unsqueeze(2), None, None, None, False, w_all, b_all, 1, False)[0]
-    return _DynAdj.apply(proj.view(n, w_all.shape[0], xpad.shape[-1]), A, alpha, beta, we, be, node_type, edge_type)
+    # single_use: every parameter passed here is used by this call only in the step (their gradient partials may then join
+    # the end-of-backward sum, see param_colsum); dggcn feeds A to two calls and says so
+    return _DynAdj.apply(proj.view(n, w_all.shape[0], xpad.shape[-1]), A, alpha, beta, we, be, node_type, edge_type,
+                         bool(single_use))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -379,6 +502,7 @@ class _PwConv(torch.autograd.Function):
         ctx.save_for_backward(x1, s1, h1, x2, s2, h2, w2, z, zaug, gamma, mean, var)
         ctx.cfg = (int(relu), stride, int(aug), float(eps), int(n_affine), bool(want_bn), count, tuple(weight.shape),
                    bias is not None, beta is not None)
+        ctx.defer_ok = _leafish(weight, bias)
         return z, zaug, scale, shift, mean, var
 
     @staticmethod
@@ -425,7 +549,7 @@ class _PwConv(torch.autograd.Function):
                                       wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, st)
             native.check(rc, 'dsgcn_pwconv_bwd')
             return _PwConv._finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma,
-                                   has_beta, n_affine)
+                                   has_beta, n_affine, ctx.defer_ok)
         ipart = None
         if s1 is not None or s2 is not None:
             rows = lib.dsgcn_pwconv_ipart_rows(n, Ci, Co, T, V, stride)
@@ -444,15 +568,20 @@ class _PwConv(torch.autograd.Function):
                                     wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, stride, aug, st)
         native.check(rc, 'dsgcn_pwconv_wgrad')
         return _PwConv._finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma, has_beta,
-                               n_affine)
+                               n_affine, ctx.defer_ok)
 
     @staticmethod
-    def _finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma, has_beta, n_affine):
+    def _finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma, has_beta, n_affine,
+                defer_ok=False):
         """Ordered sums of the partial rows -> the gradient tuple of backward()."""
-        if ipart is not None:
+        if ipart is not None and (_deferred is None or not defer_ok):
             wsum, red = colsum_pair(wpart, ipart, split_last_b=True)
+        elif ipart is not None:
+            # the input-affine sums feed the producer's backward now; the weight sums join the end-of-backward launch
+            red = colsum(ipart, split_last=True)
+            wsum = param_colsum(wpart, True)
         else:
-            wsum = colsum(wpart)
+            wsum = param_colsum(wpart, defer_ok)
         dw = wsum[:Co * Ci].view(wshape)
         db = wsum[Co * Ci:] if has_bias else None
         ds1 = dh1 = ds2 = dh2 = None
@@ -548,6 +677,7 @@ class _TmsCombine(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(o, coeff, gamma, mean, var)
         ctx.cfg = (float(eps), bool(want_bn), count, beta is not None)
+        ctx.defer_ok = _leafish(coeff)
         return f, scale, shift, mean, var
 
     @staticmethod
@@ -571,7 +701,7 @@ class _TmsCombine(torch.autograd.Function):
         rc = lib.dsgcn_tms_combine_bwd(_ptr(o), _ptr(coeff), _ptr(gf), _ptr(A0), _ptr(B0), _ptr(do), _ptr(pcoef), n, C,
                                        T, V, _stream())
         native.check(rc, 'dsgcn_tms_combine_bwd')
-        dcoeff = colsum(pcoef)
+        dcoeff = param_colsum(pcoef, ctx.defer_ok)
         if dgamma is not None:
             dgamma = dgamma if gamma is not None else None
             dbeta = dbeta if has_beta else None
@@ -607,6 +737,7 @@ class _TapBranches(torch.autograd.Function):
         ctx.save_for_backward(h, *[w for w in ws if w is not None])
         ctx.cfg = (stride, KT, Cout, tuple(types), tuple(ci0s), tuple(co0s), tuple(cins), tuple(couts), tuple(dils),
                    tuple(b is not None for b in bs))
+        ctx.defer_ok = _leafish(*wb)
         return o
 
     @staticmethod
@@ -655,7 +786,7 @@ class _TapBranches(torch.autograd.Function):
         rc = lib.dsgcn_tapconv_wgrad(_ptr(h), _ptr(go), n, Cin, Cout, T, V1, stride, KT, nbr, *tabs, dwp, dbp, splits,
                                      pstride, _stream())
         native.check(rc, 'dsgcn_tapconv_wgrad')
-        red = colsum(part)
+        red = param_colsum(part, ctx.defer_ok)
         dws = [red[o:o + co * ci * KT].view(co, ci, KT, 1) if t == 0 else None
                for t, o, ci, co in zip(types, offs, cins, couts)]
         dbs = [red[o + co * ci * KT:o + co * ci * KT + co] if (t == 0 and hb) else None
@@ -729,6 +860,7 @@ class _TemporalFused(torch.autograd.Function):
         ctx.save_for_backward(z, zaug, scale, shift, coeff, f, oaug, gamma, mean, var, *[w for w in ws if w is not None])
         ctx.cfg = (int(n_act), int(stride), int(KT), tuple(types), tuple(c0s), tuple(bcs), tuple(dils), float(eps),
                    bool(want_bn), count, beta is not None, tuple(b is not None for b in bs))
+        ctx.defer_ok = _leafish(coeff, *wb)
         return f, scale1, shift1, mean, var
 
     @staticmethod
@@ -768,7 +900,7 @@ class _TemporalFused(torch.autograd.Function):
             red = colsum(paff, split_last=True)
             dscale, dshift = red[0], red[1]
         if aug:
-            dcoeff = colsum(pcoeff)
+            dcoeff = param_colsum(pcoeff, ctx.defer_ok)
         dws, dbs = [None] * nbr, [None] * nbr
         if 0 in types:
             offs, off = [], 0
@@ -786,7 +918,7 @@ class _TemporalFused(torch.autograd.Function):
             rc = lib.dsgcn_tms_wgrad(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), n_act, _ptr(coeff), _ptr(gf), _ptr(f),
                                      _ptr(A0), _ptr(B0), n, C, T, V, stride, KT, nbr, *tabs, dwp, dbp, pstride, st)
             native.check(rc, 'dsgcn_tms_wgrad')
-            red = colsum(part)
+            red = param_colsum(part, ctx.defer_ok)
             dws = [red[o:o + bc * bc * KT].view(bc, bc, KT, 1) if t == 0 else None for t, o, bc in zip(types, offs, bcs)]
             dbs = [red[o + bc * bc * KT:o + bc * bc * KT + bc] if (t == 0 and hb) else None
                    for t, o, bc, hb in zip(types, offs, bcs, has_b)]

@@ -133,6 +133,10 @@ int dsgcn_colsum_t(const float* src, int R, int C, int inner, float* out, void* 
 /* two such reductions in one launch (inner = 1: plain) */
 int dsgcn_colsum2(const float* src_a, int Ra, int Ca, int inner_a, float* out_a, const float* src_b, int Rb, int Cb,
                   int inner_b, float* out_b, void* stream);
+/* njobs independent column sums in ONE launch: the partial rows of parameter gradients, queued during the backward and
+ * finished together before the gradients are packed (they feed only the optimizer).  table: DEVICE array of njobs x 4
+ * int64 words {src (R, C) fp32, out (C) fp32, (R << 32) | C, first block of the job}, nblocks = sum of ceil(C / 32). */
+int dsgcn_colsum_multi(const long* table, int njobs, int nblocks, void* stream);
 /* BN-statistics backward coefficients: dz_eff = gz + A0[c] + B0[c]*z; also d gamma / d beta. */
 int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* mean, const float* var,
                       const float* gamma, float eps, double count, int C, int c_affine, float* dgamma, float* dbeta,

@@ -140,7 +140,7 @@ def tmean(x):
     return x.mean(2)
 
 
-def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type):
+def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type, single_use=True):
     """Dynamic adjacency.  xbar (n,Ci,V) -> ahat (n,K*mid,V,V), K=3.
 
     w1,w2: (2*mid,Ci); wse: (mid*P,Ci) channel index c*P+p; we: (E*mid,mid) out index e*mid+c.
