@@ -182,6 +182,24 @@ def _stage_kwargs(kwargs, num_stages):
     return lw
 
 
+def _stage_plan(in_channels, base_channels, num_stages, inflate_stages, down_stages, ch_ratio=2):
+    """(in, out, stride, residual) of every block of a 10-stage skeleton backbone: the channel / stride schedule the four
+    reference backbones share (dgstgcn.py:117-150, stgcn.py:104-128, aagcn.py:96-124, ctrgcn.py:97-108): stage 1 maps the
+    input to ``base_channels`` without a residual (skipped when the widths already agree), stage i inflates the width by
+    ``ch_ratio`` if i is in ``inflate_stages`` and halves the frames if i is in ``down_stages``."""
+    plan = []
+    if in_channels != base_channels:
+        plan.append((in_channels, base_channels, 1, False))
+    width, inflate_times = base_channels, 0
+    for i in range(2, num_stages + 1):
+        if i in inflate_stages:
+            inflate_times += 1
+        out = int(base_channels * ch_ratio ** inflate_times + EPS)
+        plan.append((width, out, 1 + (i in down_stages), True))
+        width = out
+    return plan
+
+
 class _SkeletonBackbone(nn.Module):
     """Shared forward: (N,M,T,V,C) -> data_bn -> (N*M,C,T,V) -> blocks -> (N,M,C',T',V)."""
 
@@ -244,23 +262,11 @@ class DGSTGCN(_SkeletonBackbone):
         self.ch_ratio = ch_ratio
         self.inflate_stages = inflate_stages
         self.down_stages = down_stages
-        modules = []
-        if self.in_channels != self.base_channels:
-            modules = [DGBlock(in_channels, base_channels, A.clone(), edge_type, node_type, 1, residual=False,
-                               **lw_kwargs[0])]
-        inflate_times = 0
-        for i in range(2, num_stages + 1):
-            stride = 1 + (i in down_stages)
-            in_channels = base_channels
-            if i in inflate_stages:
-                inflate_times += 1
-            out_channels = int(self.base_channels * self.ch_ratio**inflate_times + EPS)
-            base_channels = out_channels
-            modules.append(DGBlock(in_channels, out_channels, A.clone(), edge_type, node_type, stride,
-                                   **lw_kwargs[i - 1]))
-        if self.in_channels == self.base_channels:
-            num_stages -= 1
-        self.num_stages = num_stages
+        plan = _stage_plan(in_channels, base_channels, num_stages, inflate_stages, down_stages, ch_ratio)
+        first = num_stages - len(plan)              # 0, or 1 when stage 1 is skipped (its kwargs slot stays unused)
+        modules = [DGBlock(ci, co, A.clone(), edge_type, node_type, stride, residual=res, **lw_kwargs[first + j])
+                   for j, (ci, co, stride, res) in enumerate(plan)]
+        self.num_stages = len(plan)
         self.gcn = nn.ModuleList(modules)
         self.pretrained = pretrained
 
@@ -288,21 +294,11 @@ class STGCN(_SkeletonBackbone):
         self.ch_ratio = ch_ratio
         self.inflate_stages = inflate_stages
         self.down_stages = down_stages
-        modules = []
-        if self.in_channels != self.base_channels:
-            modules = [STGCNBlock(in_channels, base_channels, A.clone(), 1, residual=False, **lw_kwargs[0])]
-        inflate_times = 0
-        for i in range(2, num_stages + 1):
-            stride = 1 + (i in down_stages)
-            in_channels = base_channels
-            if i in inflate_stages:
-                inflate_times += 1
-            out_channels = int(self.base_channels * self.ch_ratio**inflate_times + EPS)
-            base_channels = out_channels
-            modules.append(STGCNBlock(in_channels, out_channels, A.clone(), stride, **lw_kwargs[i - 1]))
-        if self.in_channels == self.base_channels:
-            num_stages -= 1
-        self.num_stages = num_stages
+        plan = _stage_plan(in_channels, base_channels, num_stages, inflate_stages, down_stages, ch_ratio)
+        first = num_stages - len(plan)
+        modules = [STGCNBlock(ci, co, A.clone(), stride, residual=res, **lw_kwargs[first + j])
+                   for j, (ci, co, stride, res) in enumerate(plan)]
+        self.num_stages = len(plan)
         self.gcn = nn.ModuleList(modules)
         self.pretrained = pretrained
 
@@ -364,18 +360,11 @@ class AAGCN(_SkeletonBackbone):
         self._make_data_bn(data_bn_type, in_channels, num_person, A.size(1))
         lw_kwargs = _stage_kwargs(kwargs, num_stages)
         lw_kwargs[0].pop('tcn_dropout', None)
-        modules = []
-        if self.in_channels != self.base_channels:
-            modules = [AAGCNBlock(in_channels, base_channels, A.clone(), edge_type, node_type, 1, residual=False,
-                                  **lw_kwargs[0])]
-        for i in range(2, num_stages + 1):
-            out_channels = base_channels * (1 + (i in inflate_stages))
-            stride = 1 + (i in down_stages)
-            modules.append(AAGCNBlock(base_channels, out_channels, A.clone(), edge_type, node_type, stride=stride,
-                                      **lw_kwargs[i - 1]))
-            base_channels = out_channels
-        if self.in_channels == self.base_channels:
-            self.num_stages -= 1
+        plan = _stage_plan(in_channels, base_channels, num_stages, inflate_stages, down_stages)
+        first = num_stages - len(plan)
+        modules = [AAGCNBlock(ci, co, A.clone(), edge_type, node_type, stride, residual=res, **lw_kwargs[first + j])
+                   for j, (ci, co, stride, res) in enumerate(plan)]
+        self.num_stages = len(plan)
         self.gcn = nn.ModuleList(modules)
         self.pretrained = pretrained
 
@@ -410,14 +399,11 @@ class CTRGCN(_SkeletonBackbone):
         self.base_channels = base_channels
         self._make_data_bn('MVC', in_channels, num_person, A.size(1))
         kwargs0 = {k: v for k, v in kwargs.items() if k != 'tcn_dropout'}
-        modules = [CTRGCNBlock(in_channels, base_channels, A.clone(), edge_type, node_type, 1 in semantic_stage,
-                               residual=False, **kwargs0)]
-        for i in range(2, num_stages + 1):
-            out_channels = base_channels * (1 + (i in inflate_stages))
-            stride = 1 + (i in down_stages)
-            modules.append(CTRGCNBlock(base_channels, out_channels, A.clone(), edge_type, node_type,
-                                       i in semantic_stage, stride=stride, **kwargs))
-            base_channels = out_channels
+        plan = [(in_channels, base_channels, 1, False)] + _stage_plan(base_channels, base_channels, num_stages,
+                                                                       inflate_stages, down_stages)
+        modules = [CTRGCNBlock(ci, co, A.clone(), edge_type, node_type, (j + 1) in semantic_stage, stride=stride,
+                               residual=res, **(kwargs if j else kwargs0))
+                   for j, (ci, co, stride, res) in enumerate(plan)]
         self.net = nn.ModuleList(modules)
         self.pretrained = pretrained
 

@@ -1,5 +1,5 @@
 // Diagnostics (tools/ only): raw f32 MFMA issue-rate probe used to calibrate the roofline of K-C.
-#include "common.h"
+#include "../common.h"
 #ifdef DSGCN_LAB
 namespace {
 template <int NACC>

@@ -98,14 +98,20 @@ LAB_SIGNATURES = {
 }
 
 
-def sources():
-    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+def sources(lab=False):
+    """Product sources; lab=True adds csrc/lab/*.hip (measurement-only kernels: never part of libdsgcn.so)."""
+    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    if lab:
+        srcs += sorted(glob.glob(os.path.join(CSRC, 'lab', '*.hip')))
+    return srcs
 
 
-def _source_hash():
+def _source_hash(lab=False):
     import hashlib
     h = hashlib.sha256()
-    for path in sources() + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + sorted(glob.glob(os.path.join(INCLUDE, '*.h'))):
+    extra = sorted(glob.glob(os.path.join(CSRC, 'lab', '*.h'))) if lab else []
+    for path in (sources(lab) + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + extra +
+                 sorted(glob.glob(os.path.join(INCLUDE, '*.h')))):
         with open(path, 'rb') as f:
             h.update(os.path.basename(path).encode())
             h.update(f.read())
@@ -130,10 +136,10 @@ def build(force=False, verbose=False, lab=False):
     compiled to its own object (cached under lib/obj by content hash of the source + headers, compiled in parallel),
     then linked."""
     from concurrent.futures import ThreadPoolExecutor
-    srcs = sources()
+    srcs = sources(lab)
     lib_path = LAB_LIB_PATH if lab else LIB_PATH
     stamp = lib_path + '.srchash'
-    digest = _source_hash()
+    digest = _source_hash(lab)
     if not force and os.path.exists(lib_path) and os.path.exists(stamp):
         with open(stamp) as f:
             if f.read().strip() == digest:
@@ -142,6 +148,8 @@ def build(force=False, verbose=False, lab=False):
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     headers = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + sorted(glob.glob(os.path.join(INCLUDE, '*.h')))
+    if lab:
+        headers += sorted(glob.glob(os.path.join(CSRC, 'lab', '*.h')))
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC]
     if lab:
         flags.append('-DDSGCN_LAB')

@@ -1,4 +1,4 @@
-"""f32 MFMA issue-rate probe (lab library: csrc/diag.hip): sustained TFLOP/s of v_mfma_f32_32x32x2_f32 chains."""
+"""f32 MFMA issue-rate probe (lab library: csrc/lab/diag.hip): sustained TFLOP/s of v_mfma_f32_32x32x2_f32 chains."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
