@@ -37,6 +37,7 @@ struct Pw4Args {
   int erelu;
   float* out2; float* ipart;                                               // EPI 1: d x2 or NULL; [ngrp][M][3] or NULL
   int n, K, M, L, span, WT, cc, Kpad;
+  int Lq;                                                                  // positions per plane rounded up to a multiple of NQ (ragged planes)
 };
 
 template <int NQ> struct VQ;
@@ -83,7 +84,7 @@ __device__ __forceinline__ ACC p4_rowread(const float* Tw, int half, int l31) {
 }
 
 // MODE 0: B' = b1;  1: relu?(b1*s1+h1);  2: relu?(b1*s1+h1 + b2*s2+h2).   EPI 0: forward (bias, statistics);  1: data gradient.
-struct P4Tile { int wave, half, l31, tid, mBase, n, nrem, ds, pos, grp; bool wlive, pok; };
+struct P4Tile { int wave, half, l31, tid, mBase, n, nrem, ds, pos, grp; bool wlive, pok; int skip; };
 
 // Epilogue of a wave's (32*MT rows) x (32*NQ positions, lane-owned runs of NQ) accumulator tile, shared by k_pw4 and
 // k_pwg.  OWNROWS = false: the workgroup's four waves hold the SAME rows at different positions (their per-row sums are
@@ -97,6 +98,8 @@ __device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][
   const bool wlive = t.wlive, pok = t.pok;
   const int M = a.M, L = a.L, L4 = L * 4;
   (void)L;
+  const int skip = t.skip;                         // leading elements of the lane's run that the previous run also holds (0
+                                                   // except for the last run of a ragged plane): stored, not summed
   // Epilogue.  Stores go through a per-sample buffer resource (invalid rows / positions get an out-of-range offset
   // and are dropped by the bounds check: no branches); per-channel sums through LDS transposes of the wave's tiles.
   constexpr int NTL = EPI == 0 ? 2 : 3;            // transposed tiles per wave
@@ -117,8 +120,10 @@ __device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           val[q] = acc[m][q][r];
-          s += val[q];
-          qq = fmaf(val[q], val[q], qq);
+          if (q >= skip) {
+            s += val[q];
+            qq = fmaf(val[q], val[q], qq);
+          }
         }
         p4_store<NQ>(val, ro, co < M ? ooff : P4_OOB, co * L4);
         if (stats) {
@@ -208,9 +213,11 @@ __device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][
             const float dv = (!a.erelu || pre > 0.f) ? acc[m][q][r] : 0.f;
             d1[q] = dv * e.x;
             d2[q] = dv * e.z;
-            u0 = fmaf(dv, xa[rr][q], u0);
-            u1 += dv;
-            u2 = fmaf(dv, xb[rr][q], u2);
+            if (q >= skip) {
+              u0 = fmaf(dv, xa[rr][q], u0);
+              u1 += dv;
+              u2 = fmaf(dv, xb[rr][q], u2);
+            }
           }
           p4_store<NQ>(d1, ro, ci < M ? ooff : P4_OOB, ci * L4);
           p4_store<NQ>(d2, ro2, ci < M ? ooff : P4_OOB, ci * L4);           // zero-sized resource when there is no dx2
@@ -290,12 +297,22 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   // strides in its vector offset.
   const int wt = grp * 4 + wave;
   const bool wlive = wt < a.WT;
+  // Ragged planes (L % NQ != 0: K400's 25 x 17 and CTR-GCN's 25 x 25 planes): the tile walks Lq = L rounded up to NQ
+  // positions per plane, and the plane's last run is moved back to END at the plane's end — it overlaps the run before it
+  // by `skip` positions, which both lanes compute and store identically and only the earlier one adds to the per-channel
+  // sums.  No load or store ever leaves the plane (a run reaching into the next row would need a per-element bounds
+  // check: a 16-byte buffer load that straddles the end of its resource returns zeros from its second dword on, measured),
+  // at the price of dword-aligned 16-byte accesses (legal and within 4 % of aligned ones on gfx950:
+  // tools/probes/unaligned_b128.hip).
+  const int Lq = a.Lq;
   const int g0 = (wlive ? wt : 0) * (32 * NQ);          // < 2^31 (p4_plan)
-  const int n = g0 / L;
-  int pos = g0 - n * L + l31 * NQ;
+  const int n = g0 / Lq;
+  int pos = g0 - n * Lq + l31 * NQ;
   int ds = 0;
-  while (pos >= L) { pos -= L; ++ds; }
+  while (pos >= Lq) { pos -= Lq; ++ds; }
   const bool pok = wlive && n + ds < a.n;
+  int skip = 0;
+  if (L - pos < NQ) { skip = NQ - (L - pos); pos = L - NQ; }
   const int L4 = L * 4;
   const int nrem = a.n - n < a.span ? a.n - n : a.span;     // samples the wave can touch
   const int voff = pok ? ds * K * L4 + (half * L + pos) * 4 : P4_OOB;
@@ -412,7 +429,7 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   }
   __syncthreads();                                 // every wave is done with Ws / Ps: LDS is reused below
 
-  const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, wlive, pok};
+  const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, wlive, pok, skip};
   p4_epilogue<MT, NQ, EPI, false>(a, acc, lds, tile);
 }
 
@@ -450,12 +467,15 @@ __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
   if (grp >= ngrp) return;
   const int mBase0 = cz * PG_T, mBase = mBase0 + 32 * wave;
   const int K = a.K, M = a.M, L = a.L, Kpad = a.Kpad;
+  const int Lq = a.Lq;                             // (ragged planes: see k_pw4)
   const int g0 = grp * 128;
-  const int n = g0 / L;
-  int pos = g0 - n * L + l31 * 4;
+  const int n = g0 / Lq;
+  int pos = g0 - n * Lq + l31 * 4;
   int ds = 0;
-  while (pos >= L) { pos -= L; ++ds; }
+  while (pos >= Lq) { pos -= Lq; ++ds; }
   const bool pok = n + ds < a.n;
+  int skip = 0;
+  if (L - pos < 4) { skip = 4 - (L - pos); pos = L - 4; }
   const int L4 = L * 4;
   const int nrem = a.n - n < a.span ? a.n - n : a.span;
   const __amdgpu_buffer_rsrc_t r1 = p4_rsrc(a.b1 + (size_t)n * K * L, nrem * K * L4);
@@ -600,17 +620,18 @@ __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
   }
   if (ch0 < Kpad) chunk(ch0, bwA, bw2A);
   __syncthreads();                                 // drains the read-ahead loads before LDS is reused
-  const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, true, pok};
+  const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, true, pok, skip};
   p4_epilogue<1, 4, EPI, true>(a, acc, lds, tile);
 }
 
 int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128;
 
-struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad, gemm; size_t lds; unsigned grid; };
+struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad, gemm, Lq; size_t lds; unsigned grid; };
 
 bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
-  if (L % 2) return false;
-  int NQ = (L % 4 == 0) ? 4 : 2;
+  const bool ragged = L % 2 != 0 && L >= 4;         // odd planes: runs of 4, the last one moved back to end at the plane's end
+  if (L % 2 != 0 && !ragged) return false;
+  int NQ = (L % 4 == 0 || ragged) ? 4 : 2;
   const int mtiles = (M + 31) / 32;
   int MT = mtiles >= 2 ? 2 : 1;
   // 33..48 and 65..96 output rows (the K*mid widths of the `pre` conv and of the `post` conv's data gradient): one row
@@ -620,21 +641,22 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
   if (mtiles == 3 || (mtiles == 2 && M <= 48)) MT = 1;
   // tiny planes (the dynamic-adjacency projections: 32 padded joints per sample): the launch is a latency chain of K/2
   // k-steps on few waves, so give every wave the smallest tile (1 x 2 MFMAs per k-step) and the grid the most waves
-  if (L <= 64 && (long)n * ((L + 127) / 128) < 1024) { NQ = 2; MT = 1; }
-  if (g_p4_nq == 2 || (g_p4_nq == 4 && L % 4 == 0)) NQ = g_p4_nq;
+  if (L <= 64 && (long)n * ((L + 127) / 128) < 1024 && !ragged) { NQ = 2; MT = 1; }
+  if ((g_p4_nq == 2 && !ragged) || (g_p4_nq == 4 && L % 4 == 0)) NQ = g_p4_nq;
   if (g_p4_mt) MT = g_p4_mt < mtiles ? g_p4_mt : mtiles;
-  if (MT * NQ > 8) NQ = 2;
-  if (MT * NQ > 8) MT = 4;
+  if (MT * NQ > 8 && !ragged) NQ = 2;
+  if (MT * NQ > 8) MT = ragged ? 2 : 4;
   int PD = NQ == 4 ? 8 : 16;
   if (g_p4_pd == 8 || g_p4_pd == 16) PD = g_p4_pd;
   // samples a wave's 32*NQ-position tile can touch; its buffer resources span that many planes (32-bit offsets)
-  const int span = (32 * NQ + L - 1) / L + 1;
+  const int Lq = (L + NQ - 1) / NQ * NQ;
+  const int span = (32 * NQ + Lq - 1) / Lq + 1;
   if ((long)K * L * 4 * span >= (1L << 31) - 64 || (long)M * L * 4 * span >= (1L << 31) - 64) return false;
   if ((long)n * L >= (1L << 31) - 256) return false;
-  p->MT = MT; p->NQ = NQ; p->PD = PD;
+  p->MT = MT; p->NQ = NQ; p->PD = PD; p->Lq = Lq;
   p->cc = (mtiles + MT - 1) / MT;
   p->span = span;
-  p->WT = (int)(((long)n * L + 32 * NQ - 1) / (32 * NQ));
+  p->WT = (int)(((long)n * Lq + 32 * NQ - 1) / (32 * NQ));
   p->ngrp = (p->WT + 3) / 4;
   p->Kpad = (K + 2 * PD - 1) / (2 * PD) * (2 * PD);
   size_t f = (size_t)((32 * MT * (p->Kpad + 1) + 2 + 3) & ~3) + (size_t)4 * (p->Kpad + 2);   // + the pipeline's read-ahead pad
@@ -642,11 +664,12 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
   if (f < fe) f = fe;
   p->lds = f * sizeof(float);
   p->gemm = 0;
-  if ((g_p4_gemm & (1 << epi)) && L % 4 == 0 && K % 4 == 0 && M % 4 == 0 && K >= g_p4_gmin && M > 64 && L >= g_p4_gminl) {
+  if ((g_p4_gemm & (1 << epi)) && (L % 4 == 0 || ragged) && K % 4 == 0 && M % 4 == 0 && K >= g_p4_gmin && M > 64 &&
+      L >= g_p4_gminl) {
     p->gemm = 1; p->MT = 1; p->NQ = 4;
     p->cc = (M + PG_T - 1) / PG_T;
-    p->span = (128 + L - 1) / L + 1;               // (the tiny-plane rule above may have chosen 64-position tiles)
-    p->WT = (int)(((long)n * L + 127) / 128);
+    p->span = (128 + Lq - 1) / Lq + 1;             // (the tiny-plane rule above may have chosen 64-position tiles)
+    p->WT = (int)(((long)n * Lq + 127) / 128);
     p->ngrp = p->WT;                               // one position tile per workgroup
     p->Kpad = (K + PG_KC - 1) / PG_KC * PG_KC;
     size_t b = (size_t)3 * ((epi ? PG_TAM : PG_T) + PG_T) * PG_RB + (size_t)p->Kpad * 16;
@@ -735,7 +758,7 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const fl
   Pw4Args a = {};
   a.b1 = x1; a.b2 = x2; a.ps1 = s1; a.ph1 = h1; a.ps2 = s2; a.ph2 = h2; a.relu = relu;
   a.w = w; a.w_ldm = Ci; a.w_ldk = 1; a.bias = bias; a.out = z; a.partial = partial;
-  a.n = n; a.K = Ci; a.M = Co; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad;
+  a.n = n; a.K = Ci; a.M = Co; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad; a.Lq = p.Lq;
   const int mode = x2 ? 2 : ((s1 || relu) ? 1 : 0);
   const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 0, p, st) : p4_launch_pd<16>(a, mode, 0, p, st);
   if (!ok) return 0;
@@ -758,7 +781,7 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const 
   a.w = w; a.w_ldm = 1; a.w_ldk = Ci; a.bias = nullptr; a.out = dx1; a.partial = nullptr;
   a.ex1 = x1; a.ex2 = x2; a.es1 = s1; a.eh1 = h1; a.es2 = s2; a.eh2 = h2; a.erelu = relu;
   a.out2 = dx2; a.ipart = ipart;
-  a.n = n; a.K = Co; a.M = Ci; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad;
+  a.n = n; a.K = Co; a.M = Ci; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad; a.Lq = p.Lq;
   const int mode = A0 ? 2 : 0;
   const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 1, p, st) : p4_launch_pd<16>(a, mode, 1, p, st);
   if (!ok) return 0;

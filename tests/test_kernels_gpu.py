@@ -124,6 +124,13 @@ def _rand(g, *shape, scale=1.0):
     (5, 96, 256, 8, 17, 1, False, 'affine_relu'),    # K = 96: odd chunk count (ping-pong tail), 136-position planes
     (2, 64, 128, 8, 16, 1, False, 'plain'),          # smallest eligible plane (128), K = 64
     (2, 256, 132, 16, 25, 1, True, 'res_plain'),     # 132 rows: second row block nearly empty; global-joint column beside it
+    # ragged planes on the wide-load kernels (runs of 4 with a partly empty last run per plane, dword-aligned 16-byte loads)
+    (2, 16, 24, 7, 25, 1, False, 'plain'),           # 175 positions, narrow
+    (2, 16, 16, 7, 25, 1, True, 'res_affine'),       # two streams + global joint
+    (1, 3, 24, 7, 25, 1, False, 'plain'),            # one sample, 3 input channels
+    (3, 32, 48, 3, 25, 1, False, 'affine_relu'),     # 75 positions: a 128-position tile spans two planes
+    (2, 256, 256, 25, 17, 1, False, 'res_affine'),   # K400 last stage on the GEMM form (425 positions)
+    (2, 8, 64, 25, 25, 1, False, 'plain'),           # CTR-GCN conv4 on (V x V) planes of R channels (625 positions)
 ])
 def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
     g = torch.Generator().manual_seed(Ci * 7 + Co + T)

@@ -37,7 +37,8 @@ y = torch.randint(0, classes, (N, 1), generator=gen).cuda()
 def step():
     flat.zero_grad()
     out = m.train_step(dict(keypoint=x, label=y), None, sync_log_vars=False)
-    out['loss'].backward()
+    with D.kernels.deferred_param_sums():          # as in TrainEngine: parameter-gradient column sums in one launch
+        out['loss'].backward()
     flat.collect_grads()
 for _ in range(3):
     step()
