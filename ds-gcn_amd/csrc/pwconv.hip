@@ -549,8 +549,52 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
 // Column sums of a row-major (R, C) fp32 matrix -> out (C), accumulated in fp64 (partial-buffer reductions).
 struct ColJob { const float* src; float* out; int R, C, inner, nblk; };
 
+// 16-byte form: a thread owns 4 consecutive columns, a block 128 columns x 32 row slices, so every row visit of a wave is
+// two 512-B segments instead of two 128-B ones (the big inputs are the weight-gradient partials: 10-30 MB each, ~0.8 GB
+// per DS-STGCN step — these sums are bandwidth-bound, not launch-bound).  C % 4 == 0, rows 16-byte aligned, inner == 1.
+__host__ __device__ inline bool colsum_wide(int C, int inner, const float* src) {
+  return (C & 3) == 0 && inner == 1 && C >= 128 && ((size_t)src & 15) == 0;
+}
+__host__ __device__ inline int colsum_blocks(int C, int inner, const float* src) {
+  return colsum_wide(C, inner, src) ? (C + 127) / 128 : (C + 31) / 32;
+}
+
+__device__ __forceinline__ void colsum_body4(const ColJob& j, int bid, double (*red)[32]) {
+  const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int c = bid * 128 + 4 * cl;
+  const int R = j.R, C = j.C;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (c < C) {
+    for (int r0 = slice; r0 < R; r0 += 32 * 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = r0 + 32 * q;
+        v[q] = r < R ? *reinterpret_cast<const f32x4*>(j.src + (size_t)r * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { s0 += (double)v[q].x; s1 += (double)v[q].y; s2 += (double)v[q].z; s3 += (double)v[q].w; }
+    }
+  }
+  // four passes through the [32][32] staging array, one per column of the quad
+  double acc[4] = {s0, s1, s2, s3};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    __syncthreads();
+    red[slice][cl] = acc[e];
+    __syncthreads();
+    if (slice == 0 && c < C) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) t += red[i][cl];
+      j.out[c + e] = (float)t;
+    }
+  }
+}
+
 __device__ __forceinline__ void colsum_body(const ColJob& j, int bid) {
   __shared__ double red[32][32];
+  if (colsum_wide(j.C, j.inner, j.src)) { colsum_body4(j, bid, red); return; }
   const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
   const int c = bid * 32 + cl;
   const int R = j.R, C = j.C;
@@ -1272,7 +1316,7 @@ int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const
 // out[c] = sum_r src[r, c]  (fp64 accumulation).
 int dsgcn_colsum(const float* src, int R, int C, float* out, void* stream) {
   if (!src || !out || R <= 0 || C <= 0) return DSGCN_EINVAL;
-  ColJob a{src, out, R, C, 1, (C + 31) / 32}, b{nullptr, nullptr, 0, 0, 1, 0};
+  ColJob a{src, out, R, C, 1, colsum_blocks(C, 1, src)}, b{nullptr, nullptr, 0, 0, 1, 0};
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)a.nblk), dim3(1024), 0, (hipStream_t)stream, a, b);
   DSGCN_LAUNCH_CHECK();
   return 0;
@@ -1293,13 +1337,16 @@ int dsgcn_colsum2(const float* src_a, int Ra, int Ca, int inner_a, float* out_a,
   if (!src_a || !out_a || !src_b || !out_b || Ra <= 0 || Ca <= 0 || Rb <= 0 || Cb <= 0 || inner_a <= 0 ||
       inner_b <= 0 || Ca % inner_a || Cb % inner_b)
     return DSGCN_EINVAL;
-  ColJob a{src_a, out_a, Ra, Ca, inner_a, (Ca + 31) / 32}, b{src_b, out_b, Rb, Cb, inner_b, (Cb + 31) / 32};
+  ColJob a{src_a, out_a, Ra, Ca, inner_a, colsum_blocks(Ca, inner_a, src_a)}, b{src_b, out_b, Rb, Cb, inner_b, colsum_blocks(Cb, inner_b, src_b)};
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)(a.nblk + b.nblk)), dim3(1024), 0, (hipStream_t)stream, a, b);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
 
-// table (device, njobs x 4 int64): {src pointer, out pointer, (R << 32) | C, first block}; nblocks = sum of ceil(C / 32).
+// blocks a job of C columns takes in dsgcn_colsum_multi's grid (the caller lays the jobs' first blocks out with it)
+int dsgcn_colsum_blocks(const float* src, int C) { return colsum_blocks(C, 1, src); }
+
+// table (device, njobs x 4 int64): {src pointer, out pointer, (R << 32) | C, first block}; nblocks = sum of dsgcn_colsum_blocks.
 int dsgcn_colsum_multi(const long* table, int njobs, int nblocks, void* stream) {
   if (!table || njobs <= 0 || nblocks <= 0) return DSGCN_EINVAL;
   hipLaunchKernelGGL(k_colsum_multi, dim3((unsigned)nblocks), dim3(1024), 0, (hipStream_t)stream, table, njobs);

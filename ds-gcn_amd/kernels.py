@@ -265,9 +265,10 @@ def flush_param_sums():
     slot['keep'] = jobs                               # sources / outputs alive until the slot is reused
     tab = slot['host'].numpy()
     blk = 0
+    nblocks = native.lib().dsgcn_colsum_blocks
     for i, (src, R, C, out) in enumerate(jobs):
         tab[i] = (src.data_ptr(), out.data_ptr(), (R << 32) | C, blk)
-        blk += (C + 31) // 32
+        blk += nblocks(src.data_ptr(), C)
     slot['dev'].copy_(slot['host'], non_blocking=True)
     if not torch.cuda.is_current_stream_capturing():
         slot['event'] = torch.cuda.Event()

@@ -40,6 +40,7 @@ SIGNATURES = {
     'dsgcn_dz_eff_aug': [c_f] * 7 + [c_int] * 4 + [c_st],
     'dsgcn_colsum': [c_f, c_int, c_int, c_f, c_st],
     'dsgcn_colsum_t': [c_f, c_int, c_int, c_int, c_f, c_st],
+    'dsgcn_colsum_blocks': [c_f, c_int],
     'dsgcn_colsum_multi': [c_f, c_int, c_int, c_st],
     'dsgcn_colsum2': [c_f, c_int, c_int, c_int, c_f, c_f, c_int, c_int, c_int, c_f, c_st],
     'dsgcn_pwconv_dgrad': [c_f] * 6 + [c_int] + [c_f] * 10 + [c_int] * 7 + [c_st],

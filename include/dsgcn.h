@@ -135,7 +135,9 @@ int dsgcn_colsum2(const float* src_a, int Ra, int Ca, int inner_a, float* out_a,
                   int inner_b, float* out_b, void* stream);
 /* njobs independent column sums in ONE launch: the partial rows of parameter gradients, queued during the backward and
  * finished together before the gradients are packed (they feed only the optimizer).  table: DEVICE array of njobs x 4
- * int64 words {src (R, C) fp32, out (C) fp32, (R << 32) | C, first block of the job}, nblocks = sum of ceil(C / 32). */
+ * int64 words {src (R, C) fp32, out (C) fp32, (R << 32) | C, first block of the job}, nblocks = sum over the jobs of
+ * dsgcn_colsum_blocks(src, C) (128 columns per block when C % 4 == 0 and src is 16-byte aligned, else 32). */
+int dsgcn_colsum_blocks(const float* src, int C);
 int dsgcn_colsum_multi(const long* table, int njobs, int nblocks, void* stream);
 /* BN-statistics backward coefficients: dz_eff = gz + A0[c] + B0[c]*z; also d gamma / d beta. */
 int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* mean, const float* var,
