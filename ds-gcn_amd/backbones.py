@@ -53,10 +53,11 @@ class _FusedBlock(nn.Module):
 
     xbar_ld = True           # layout of the time mean handed to the next block: True = (n, C, V); an int = padded joint row
 
-    def forward_fused(self, x, xbar=None, want_xbar=False):
+    def forward_fused(self, x, xbar=None, want_xbar=False, tee=False):
         # the block input has up to three consumers (gcn main path, gcn residual operand, block residual): give each its
-        # own alias so that their gradients are summed in one launch instead of autograd's pairwise adds
-        xa, xb, xc = kernels.ops().tee3(x)
+        # own alias so that their gradients are summed in one place instead of autograd's pairwise adds — inside the
+        # previous block's fuse_out backward when that block handed over three aliases (tee), in one dsgcn_add3 otherwise
+        xa, xb, xc = x if isinstance(x, tuple) else kernels.ops().tee3(x)
         g = self._gcn_deferred(xa, xbar, xb)
         x = xc
         t = self.tcn.forward_deferred(g)
@@ -70,7 +71,7 @@ class _FusedBlock(nn.Module):
             x2, a2 = r.x1, r.a1
         assert t.x2 is None
         # t.relu: the temporal unit ends in its own ReLU (CTR-GCN's MSTCN) -> ReLU on the first term, then add + ReLU
-        return kernels.ops().fuse_out(t.x1, t.a1, x2, a2, 3 if t.relu else 1, want_xbar and self.xbar_ld)
+        return kernels.ops().fuse_out(t.x1, t.a1, x2, a2, 3 if t.relu else 1, want_xbar and self.xbar_ld, tee)
 
     def forward(self, x, A=None):
         out = self.forward_fused(x)[0]
@@ -226,7 +227,7 @@ class _SkeletonBackbone(nn.Module):
         xbar = None
         last = len(blocks) - 1
         for i, blk in enumerate(blocks):
-            x, xbar = blk.forward_fused(x, xbar, needs_xbar and i < last)
+            x, xbar = blk.forward_fused(x, xbar, needs_xbar and i < last, tee=i < last)
         flush_running_stats()
         return x
 

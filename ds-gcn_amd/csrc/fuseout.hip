@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
                                                      const float* __restrict__ h1, const float* __restrict__ x2,
                                                      const float* __restrict__ s2, const float* __restrict__ h2,
                                                      int relu, const float* __restrict__ dout,
+                                                     const float* __restrict__ dout2, const float* __restrict__ dout3,
                                                      const float* __restrict__ dxbar, float* __restrict__ dx1,
                                                      float* __restrict__ dx2, float* __restrict__ part, int C, int T,
                                                      int V, int ld) {
@@ -88,6 +89,8 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
   const float* __restrict__ p1 = x1 + (size_t)plane * L;
   const float* __restrict__ p2 = x2 ? x2 + (size_t)plane * L : nullptr;
   const float* __restrict__ pg = dout ? dout + (size_t)plane * L : nullptr;
+  const float* __restrict__ pg2 = dout2 ? dout2 + (size_t)plane * L : nullptr;
+  const float* __restrict__ pg3 = dout3 ? dout3 + (size_t)plane * L : nullptr;
   float* __restrict__ o1 = dx1 + (size_t)plane * L;
   float* __restrict__ o2 = dx2 ? dx2 + (size_t)plane * L : nullptr;
   float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
@@ -100,7 +103,10 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
     const float pre1 = fmaf(xa, a1, b1);
     float pre = (relu & 2) ? fmaxf(pre1, 0.f) : pre1;
     if (p2) pre += fmaf(xb, a2, b2);
-    float g = (pg ? pg[i] : 0.f) + dxb[v];
+    float g = pg ? pg[i] : 0.f;
+    if (pg2) g += pg2[i];              // (a + b) + c, then the time-mean term: the order dsgcn_add3 + this kernel had
+    if (pg3) g += pg3[i];
+    g += dxb[v];
     if ((relu & 1) && !(pre > 0.f)) g = 0.f;
     const float g1 = ((relu & 2) && !(pre1 > 0.f)) ? 0.f : g;     // gradient of the first term
     o1[i] = g1 * a1;
@@ -145,15 +151,27 @@ int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const 
 }
 
 // part: (n*C, 4) per-plane [sum dv1*x1, sum dv, sum dv*x2, sum dv1]; dout or dxbar may be NULL (treated as zero).
+// dout2 / dout3 (NULL or like dout): the gradients of the other consumers of `out` (the next block reads its input three
+// times: spatial unit, its residual operand, the block residual) — summed while loading, (dout + dout2) + dout3, instead
+// of a separate dsgcn_add3 pass (three reads and one write of the plane less per block).
+int dsgcn_fuse_out_bwd3(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                        const float* h2, int relu, const float* dout, const float* dout2, const float* dout3,
+                        const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
+                        void* stream) {
+  if (!x1 || !dx1 || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (x2 && !dx2)) return DSGCN_EINVAL;
+  if (dxbar && xbar_ld < V) return DSGCN_EINVAL;
+  if ((dout2 || dout3) && !dout) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_fuse_out_bwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, x1, s1, h1, x2,
+                     s2, h2, relu, dout, dout2, dout3, dxbar, dx1, dx2, part, C, T, V, xbar_ld);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
 int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, const float* dout, const float* dxbar, float* dx1, float* dx2,
                        float* part, int n, int C, int T, int V, int xbar_ld, void* stream) {
-  if (!x1 || !dx1 || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (x2 && !dx2)) return DSGCN_EINVAL;
-  if (dxbar && xbar_ld < V) return DSGCN_EINVAL;
-  hipLaunchKernelGGL(k_fuse_out_bwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, x1, s1, h1, x2,
-                     s2, h2, relu, dout, dxbar, dx1, dx2, part, C, T, V, xbar_ld);
-  DSGCN_LAUNCH_CHECK();
-  return 0;
+  return dsgcn_fuse_out_bwd3(x1, s1, h1, x2, s2, h2, relu, dout, nullptr, nullptr, dxbar, dx1, dx2, part, n, C, T, V,
+                             xbar_ld, stream);
 }
 
 }  // extern "C"

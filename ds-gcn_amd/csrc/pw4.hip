@@ -90,7 +90,7 @@ struct P4Tile { int wave, half, l31, tid, mBase, n, nrem, ds, pos, grp; bool wli
 // k_pwg.  OWNROWS = false: the workgroup's four waves hold the SAME rows at different positions (their per-row sums are
 // added through LDS, one partial row per workgroup); true: the waves hold different rows of one position tile (each wave
 // writes its rows of the workgroup's partial row itself).
-template <int MT, int NQ, int EPI, bool OWNROWS>
+template <int MT, int NQ, int EPI, bool OWNROWS, int NWV = 4>
 __device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][NQ], float* lds, const P4Tile& t) {
   typedef typename VQ<NQ>::T vq;
   const int wave = t.wave, half = t.half, l31 = t.l31, tid = t.tid, mBase = t.mBase, n = t.n, nrem = t.nrem, ds = t.ds,
@@ -107,7 +107,7 @@ __device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][
   const __amdgpu_buffer_rsrc_t ro = p4_rsrc(a.out + (size_t)n * M * L, wlive ? nrem * M * L4 : 0);
   const int ooff = pok ? ds * M * L4 + pos * 4 : P4_OOB;
   if (EPI == 0) {
-    double* Ss = reinterpret_cast<double*>(lds + 4 * NTL * 32 * 36);    // [4 waves][MT*32][2]
+    double* Ss = reinterpret_cast<double*>(lds + NWV * NTL * 32 * 36);  // [waves][MT*32][2]
     const bool stats = a.partial != nullptr;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -167,8 +167,8 @@ __device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][
       }
     }
   } else {
-    float* Ss = lds + 4 * NTL * 32 * 36;                                 // [4 waves][MT*32][3]
-    f32x4* Es = reinterpret_cast<f32x4*>(Ss + 4 * MT * 32 * 3);          // [MT*32] (s1, h1, s2, h2) of the block's rows
+    float* Ss = lds + NWV * NTL * 32 * 36;                               // [waves][MT*32][3]
+    f32x4* Es = reinterpret_cast<f32x4*>(Ss + NWV * MT * 32 * 3);        // [MT*32] (s1, h1, s2, h2) of the block's rows
     const bool need_x = a.erelu || a.es1 != nullptr || a.ex2 != nullptr;
     const bool has2 = a.ex2 != nullptr;
     const bool sums = a.ipart != nullptr;
@@ -624,7 +624,234 @@ __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
   p4_epilogue<1, 4, EPI, true>(a, acc, lds, tile);
 }
 
-int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128;
+
+// ---- K-C, GEMM form with the weights split ahead of the launch ("pwg2") ---------------------------------------------
+// k_pwg spends as many VALU cycles on the three-way bf16 split as the matrix core spends on the six products (rocprofv3
+// counters, profiles/r03: 9.8 M VALU instructions x 4 cycles against 39 M MFMA-busy cycles per 256 -> 256 launch, matrix
+// pipe 27 % busy) and half of that split is the WEIGHT tile, which is the same for every workgroup and every chunk
+// revisit.  Here the weights arrive already split (k_wsplit below: one small launch per conv and step, both the W and the
+// W^T image, k contiguous, zero-padded to whole tiles) and are only copied into LDS; and a conv with more than 128 output
+// rows runs 256 rows per workgroup (8 waves x 32 rows over the SAME 128-position tile), so the activation tile is loaded
+// and split once per 256 rows instead of once per 128.  Per wave and 32-channel chunk that leaves 8 activation values to
+// split (k_pwg: 16 + 16 weight values) in front of the same 48 MFMAs.
+template <int MODE, int EPI, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void k_pwg2(Pw4Args a, const unsigned short* __restrict__ wsp, int Mp) {
+  typedef VQ<4>::T vq;
+  constexpr int NTH = 64 * NWV, TA = 32 * NWV;     // threads; A rows per workgroup
+  constexpr int CPT = 32 / (NTH / 32);             // activation channels per loader thread and chunk: 4 or 2
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* Ab = reinterpret_cast<char*>(lds);                               // [3][TA rows][RB]
+  char* Bb = Ab + 3 * TA * PG_RB;                                        // [3][128 position slots][RB]
+  f32x4* Ps = reinterpret_cast<f32x4*>(Bb + 3 * PG_T * PG_RB);           // [Kpad] (s1, h1, s2, h2)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ngrp = a.WT;
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int cz = slot % a.cc;
+  const int grp = (slot / a.cc) * 8 + xcd;
+  if (grp >= ngrp) return;
+  const int mBase0 = cz * TA, mBase = mBase0 + 32 * wave;
+  const int K = a.K, M = a.M, L = a.L, Kpad = a.Kpad;
+  const int Lq = a.Lq;                             // (ragged planes: see k_pw4)
+  const int g0 = grp * 128;
+  const int n = g0 / Lq;
+  int pos = g0 - n * Lq + l31 * 4;
+  int ds = 0;
+  while (pos >= Lq) { pos -= Lq; ++ds; }
+  const bool pok = n + ds < a.n;
+  int skip = 0;
+  if (L - pos < 4) { skip = 4 - (L - pos); pos = L - 4; }
+  const int L4 = L * 4;
+  const int nrem = a.n - n < a.span ? a.n - n : a.span;
+  const __amdgpu_buffer_rsrc_t r1 = p4_rsrc(a.b1 + (size_t)n * K * L, nrem * K * L4);
+  const __amdgpu_buffer_rsrc_t r2 = p4_rsrc((MODE == 2 ? a.b2 : a.b1) + (size_t)n * K * L, MODE == 2 ? nrem * K * L4 : 0);
+  // B loader: channels CPT*cg .. of the chunk (cg = tid / 32) at the lane's own position quad
+  const int cg = tid >> 5;
+  const int voffB = pok ? ds * K * L4 + pos * 4 : P4_OOB;
+  vq bwA[CPT], bwB[CPT], bw2A[MODE == 2 ? CPT : 1], bw2B[MODE == 2 ? CPT : 1];   // two chunks of B in flight (ping-pong sets)
+  auto issueB = [&](int ch0, vq (&bw)[CPT], vq (&bw2)[MODE == 2 ? CPT : 1]) {
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) {
+      const int c = ch0 + CPT * cg + e;
+      const int vo = c < K ? voffB + c * L4 : P4_OOB;
+      bw[e] = p4_load<4>(r1, vo, 0);
+      if constexpr (MODE == 2) bw2[e] = p4_load<4>(r2, vo, 0);
+    }
+  };
+  // A loader: the chunk's image is 3 terms x TA rows x 64 B = 6 pieces of 16 B per thread; piece j of thread tid is
+  // term j/2, row (tid + NTH*(j&1)) / 4, 16-byte column (tid & 3).  The planes are padded to whole tiles: no bounds.
+  const __amdgpu_buffer_rsrc_t rw = p4_rsrc(wsp, 3 * Mp * Kpad * 2);
+  u32x4v aw[6];
+  int offA[6], ldsA[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int term = j >> 1, rem = tid + NTH * (j & 1), row = rem >> 2, piece = rem & 3;
+    offA[j] = ((term * Mp + mBase0 + row) * Kpad + piece * 8) * 2;
+    ldsA[j] = (term * TA + row) * PG_RB + piece * 16;
+  }
+  auto issueA = [&](int ch0) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      aw[j] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, ch0 < Kpad ? offA[j] + ch0 * 2 : P4_OOB, 0, 0));
+  };
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  auto commit = [&](int ch0, vq (&bw)[CPT], vq (&bw2)[MODE == 2 ? CPT : 1]) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4v*>(Ab + ldsA[j]) = aw[j];
+    f32x4 pr[CPT];
+    if (MODE != 0) {
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) pr[e] = Ps[ch0 + CPT * cg + e];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[CPT];
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) {
+        float x = bw[e][q];
+        if (MODE != 0) {
+          x = fmaf(x, pr[e].x, pr[e].y);
+          if constexpr (MODE == 2) x += fmaf(bw2[e][q], pr[e].z, pr[e].w);
+          x = fmaxf(x, lo);
+        }
+        v[e] = x;
+      }
+      char* base = Bb + (32 * q + l31) * PG_RB + cg * (2 * CPT);
+      unsigned p0, p1, p2;
+      b3_split(v[0], v[1], p0, p1, p2);
+      if constexpr (CPT == 4) {
+        unsigned q0, q1, q2;
+        b3_split(v[2], v[3], q0, q1, q2);
+        *reinterpret_cast<u32x2v*>(base) = u32x2v{p0, q0};
+        *reinterpret_cast<u32x2v*>(base + PG_T * PG_RB) = u32x2v{p1, q1};
+        *reinterpret_cast<u32x2v*>(base + 2 * PG_T * PG_RB) = u32x2v{p2, q2};
+      } else {
+        *reinterpret_cast<unsigned*>(base) = p0;
+        *reinterpret_cast<unsigned*>(base + PG_T * PG_RB) = p1;
+        *reinterpret_cast<unsigned*>(base + 2 * PG_T * PG_RB) = p2;
+      }
+    }
+  };
+
+  if (MODE != 0) {                                 // (before the operand loads: its own loads end in a vmcnt(0))
+    for (int i = tid; i < Kpad; i += NTH) {
+      f32x4 p = {0.f, 0.f, 0.f, 0.f};
+      if (i < K) {
+        p.x = a.ps1 ? a.ps1[i] : 1.f;
+        p.y = a.ph1 ? a.ph1[i] : 0.f;
+        p.z = a.ps2 ? a.ps2[i] : 1.f;
+        p.w = a.ph2 ? a.ph2[i] : 0.f;
+      }
+      Ps[i] = p;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  issueA(0);
+  issueB(0, bwA, bw2A);
+  issueB(PG_KC, bwB, bw2B);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 acc[1][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = mBase + p4_row32(i, half);
+    const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[0][q][i] = b0;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                    // Ps visible (raw barrier: the operand loads stay in flight)
+  const char* Af = Ab + (32 * wave + l31) * PG_RB + 16 * half;
+  const char* Bf = Bb + l31 * PG_RB + 16 * half;
+  auto chunk = [&](int ch0, vq (&bw)[CPT], vq (&bw2)[MODE == 2 ? CPT : 1]) {
+    commit(ch0, bw, bw2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issueA(ch0 + PG_KC);                           // (past K: an out-of-range offset, zeros)
+    issueB(ch0 + 2 * PG_KC, bw, bw2);              // this set is free again: two chunks ahead
+    __builtin_amdgcn_sched_barrier(0);             // pinned here, in this order: the next commit's vmcnt leaves this set in flight
+#pragma unroll
+    for (int ks = 0; ks < PG_KC / 16; ++ks) {
+      bf16x8 af[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        af[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Af + t * TA * PG_RB + 32 * ks));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bf16x8 bf[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          bf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Bf + (t * PG_T + 32 * q) * PG_RB + 32 * ks));
+        f32x16 c = acc[0][q];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], c, 0, 0, 0);
+        acc[0][q] = c;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // raw barrier: the loads in flight stay in flight
+  };
+  int ch0 = 0;
+  for (; ch0 + PG_KC < Kpad; ch0 += 2 * PG_KC) {
+    chunk(ch0, bwA, bw2A);
+    chunk(ch0 + PG_KC, bwB, bw2B);
+  }
+  if (ch0 < Kpad) chunk(ch0, bwA, bw2A);
+  __syncthreads();                                 // drains the read-ahead loads before LDS is reused
+  const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, true, pok, skip};
+  p4_epilogue<1, 4, EPI, true, NWV>(a, acc, lds, tile);
+}
+
+// The three bf16 terms of W (Co x Ci) as two images, k contiguous and zero-padded to whole tiles:
+//   N (forward):        rows co < MpN = ceil256(Co), k = ci < KpN = ceil32(Ci)      [3][MpN][KpN] bf16
+//   T (data gradient):  rows ci < MpT = ceil256(Ci), k = co < KpT = ceil32(Co)      [3][MpT][KpT] bf16, after N
+// One thread per (row, 4 consecutive k).
+__global__ __launch_bounds__(256) void k_wsplit(const float* __restrict__ w, int Ci, int Co, unsigned short* __restrict__ out,
+                                                int MpN, int KpN, int MpT, int KpT) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int t1 = MpN * (KpN >> 2), t2 = MpT * (KpT >> 2);
+  float v[4];
+  unsigned short* dst;
+  int pstride;                                     // elements between the term planes
+  if (i < t1) {
+    const int r = i / (KpN >> 2), k = 4 * (i - r * (KpN >> 2));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (r < Co && k + e < Ci) ? w[(size_t)r * Ci + k + e] : 0.f;
+    dst = out + (size_t)r * KpN + k;
+    pstride = MpN * KpN;
+  } else if (i - t1 < t2) {
+    const int j = i - t1;
+    const int r = j / (KpT >> 2), k = 4 * (j - r * (KpT >> 2));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (r < Ci && k + e < Co) ? w[(size_t)(k + e) * Ci + r] : 0.f;
+    dst = out + (size_t)3 * MpN * KpN + (size_t)r * KpT + k;
+    pstride = MpT * KpT;
+  } else {
+    return;
+  }
+  unsigned p0, p1, p2, q0, q1, q2;
+  b3_split(v[0], v[1], p0, p1, p2);
+  b3_split(v[2], v[3], q0, q1, q2);
+  *reinterpret_cast<u32x2v*>(dst) = u32x2v{p0, q0};
+  *reinterpret_cast<u32x2v*>(dst + pstride) = u32x2v{p1, q1};
+  *reinterpret_cast<u32x2v*>(dst + 2 * (size_t)pstride) = u32x2v{p2, q2};
+}
+
+struct WsDims { int MpN, KpN, MpT, KpT; size_t bytes; };
+WsDims ws_dims(int Ci, int Co) {
+  WsDims d;
+  d.MpN = (Co + 255) / 256 * 256; d.KpN = (Ci + 31) / 32 * 32;
+  d.MpT = (Ci + 255) / 256 * 256; d.KpT = (Co + 31) / 32 * 32;
+  d.bytes = ((size_t)3 * d.MpN * d.KpN + (size_t)3 * d.MpT * d.KpT) * 2;
+  return d;
+}
+
+int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128, g_p4_ws = 1;
 
 struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad, gemm, Lq; size_t lds; unsigned grid; };
 
@@ -694,9 +921,42 @@ void p4_launch_cfg(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStre
   }
 }
 
+// the pre-split form: NWV = 8 (256 rows per workgroup) when the conv has more than 128 output rows
+template <int NWV>
+void pwg2_launch(Pw4Args a, int mode, int epi, const P4Plan& p, const unsigned short* wsp, int Mp, hipStream_t st) {
+  constexpr int TA = 32 * NWV;
+  a.cc = (a.M + TA - 1) / TA;
+  const size_t main_b = (size_t)3 * (TA + PG_T) * PG_RB + (size_t)p.Kpad * 16;
+  const size_t epi_b = (size_t)NWV * (3 * 32 * 36 + 32 * 3 + 32 * 4) * sizeof(float);
+  const size_t lds = main_b > epi_b ? main_b : epi_b;
+  static bool raised = false;
+  if (!raised) {
+    const void* fs[5] = {reinterpret_cast<const void*>(&k_pwg2<0, 0, NWV>), reinterpret_cast<const void*>(&k_pwg2<1, 0, NWV>),
+                         reinterpret_cast<const void*>(&k_pwg2<2, 0, NWV>), reinterpret_cast<const void*>(&k_pwg2<0, 1, NWV>),
+                         reinterpret_cast<const void*>(&k_pwg2<2, 1, NWV>)};
+    for (const void* f : fs) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    raised = true;
+  }
+  const dim3 grid((unsigned)((p.ngrp + 7) / 8 * 8 * a.cc)), blk(64 * NWV);
+  if (epi == 0) {
+    if (mode == 0) hipLaunchKernelGGL((k_pwg2<0, 0, NWV>), grid, blk, lds, st, a, wsp, Mp);
+    else if (mode == 1) hipLaunchKernelGGL((k_pwg2<1, 0, NWV>), grid, blk, lds, st, a, wsp, Mp);
+    else hipLaunchKernelGGL((k_pwg2<2, 0, NWV>), grid, blk, lds, st, a, wsp, Mp);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((k_pwg2<0, 1, NWV>), grid, blk, lds, st, a, wsp, Mp);
+    else hipLaunchKernelGGL((k_pwg2<2, 1, NWV>), grid, blk, lds, st, a, wsp, Mp);
+  }
+}
+
 template <int PD>
-bool p4_launch_pd(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStream_t st) {
+bool p4_launch_pd(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStream_t st, const unsigned short* wsp = nullptr,
+                  int Mp = 0) {
   const int key = p.MT * 10 + p.NQ;
+  if (p.gemm && wsp && g_p4_ws) {
+    if (a.M > 128) pwg2_launch<8>(a, mode, epi, p, wsp, Mp, st);
+    else pwg2_launch<4>(a, mode, epi, p, wsp, Mp, st);
+    return true;
+  }
   if (p.gemm) {
     static bool raised = false;                    // 64 KB+ of dynamic LDS
     if (!raised) {
@@ -740,6 +1000,7 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_tuning(int key, int value) {
   else if (key == 3) g_p4_gemm = value;
   else if (key == 4) g_p4_gmin = value;
   else if (key == 5) g_p4_gminl = value;
+  else if (key == 6) g_p4_ws = value;
   else return DSGCN_EINVAL;
   return 0;
 }
@@ -752,15 +1013,17 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_groups(int n, int K, int M, i
 __attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const float* s1, const float* h1,
                                                         const float* x2, const float* s2, const float* h2, int relu,
                                                         const float* w, const float* bias, float* z, float* partial,
-                                                        int n, int Ci, int Co, int L, hipStream_t st) {
+                                                        int n, int Ci, int Co, int L, hipStream_t st, const void* ws) {
   P4Plan p;
   if (!p4_plan(n, Ci, Co, L, &p)) return 0;
+  const WsDims wd = ws_dims(Ci, Co);
+  const unsigned short* wsp = static_cast<const unsigned short*>(ws);
   Pw4Args a = {};
   a.b1 = x1; a.b2 = x2; a.ps1 = s1; a.ph1 = h1; a.ps2 = s2; a.ph2 = h2; a.relu = relu;
   a.w = w; a.w_ldm = Ci; a.w_ldk = 1; a.bias = bias; a.out = z; a.partial = partial;
   a.n = n; a.K = Ci; a.M = Co; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad; a.Lq = p.Lq;
   const int mode = x2 ? 2 : ((s1 || relu) ? 1 : 0);
-  const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 0, p, st) : p4_launch_pd<16>(a, mode, 0, p, st);
+  const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 0, p, st, wsp, wd.MpN) : p4_launch_pd<16>(a, mode, 0, p, st, wsp, wd.MpN);
   if (!ok) return 0;
   DSGCN_LAUNCH_CHECK();
   return 1;
@@ -771,7 +1034,8 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const 
                                                           const float* x2, const float* s2, const float* h2, int relu,
                                                           const float* w, const float* z, const float* gz,
                                                           const float* A0, const float* B0, float* dx1, float* dx2,
-                                                          float* ipart, int n, int Ci, int Co, int L, hipStream_t st) {
+                                                          float* ipart, int n, int Ci, int Co, int L, hipStream_t st,
+                                                          const void* ws) {
   P4Plan p;
   if (!gz) return 0;                               // (a conv whose output has no direct gradient: not on the fast path)
   if (!p4_plan(n, Co, Ci, L, &p, 1)) return 0;
@@ -783,8 +1047,28 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const 
   a.out2 = dx2; a.ipart = ipart;
   a.n = n; a.K = Co; a.M = Ci; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad; a.Lq = p.Lq;
   const int mode = A0 ? 2 : 0;
-  const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 1, p, st) : p4_launch_pd<16>(a, mode, 1, p, st);
+  const WsDims wd = ws_dims(Ci, Co);
+  const unsigned short* wsp = ws ? static_cast<const unsigned short*>(ws) + (size_t)3 * wd.MpN * wd.KpN : nullptr;   // the T image
+  const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 1, p, st, wsp, wd.MpT) : p4_launch_pd<16>(a, mode, 1, p, st, wsp, wd.MpT);
   if (!ok) return 0;
   DSGCN_LAUNCH_CHECK();
   return 1;
+}
+
+// Bytes of the pre-split weight image a (Ci -> Co) conv over planes of L positions wants (0: neither its forward nor its
+// data gradient takes the GEMM form), and the launch that fills it.
+__attribute__((visibility("hidden"))) size_t dsgcn_p4_ws_bytes(int n, int Ci, int Co, int L) {
+  P4Plan pf, pb;
+  const bool f = p4_plan(n, Ci, Co, L, &pf, 0) && pf.gemm, b = p4_plan(n, Co, Ci, L, &pb, 1) && pb.gemm;
+  if (!g_p4_ws || !(f || b)) return 0;
+  return ws_dims(Ci, Co).bytes;
+}
+
+__attribute__((visibility("hidden"))) int dsgcn_p4_wsplit(const float* w, int Ci, int Co, void* out, hipStream_t st) {
+  const WsDims d = ws_dims(Ci, Co);
+  const long total = (long)d.MpN * (d.KpN >> 2) + (long)d.MpT * (d.KpT >> 2);
+  hipLaunchKernelGGL(k_wsplit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Ci, Co,
+                     static_cast<unsigned short*>(out), d.MpN, d.KpN, d.MpT, d.KpT);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
 }

@@ -1175,12 +1175,15 @@ __attribute__((visibility("hidden"))) int dsgcn_wg2_tuning(int key, int value);
 __attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const float* s1, const float* h1,
                                                         const float* x2, const float* s2, const float* h2, int relu,
                                                         const float* w, const float* bias, float* z, float* partial,
-                                                        int n, int Ci, int Co, int L, hipStream_t st);
+                                                        int n, int Ci, int Co, int L, hipStream_t st, const void* ws);
+__attribute__((visibility("hidden"))) size_t dsgcn_p4_ws_bytes(int n, int Ci, int Co, int L);
+__attribute__((visibility("hidden"))) int dsgcn_p4_wsplit(const float* w, int Ci, int Co, void* out, hipStream_t st);
 __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const float* s1, const float* h1,
                                                           const float* x2, const float* s2, const float* h2, int relu,
                                                           const float* w, const float* z, const float* gz,
                                                           const float* A0, const float* B0, float* dx1, float* dx2,
-                                                          float* ipart, int n, int Ci, int Co, int L, hipStream_t st);
+                                                          float* ipart, int n, int Ci, int Co, int L, hipStream_t st,
+                                                          const void* ws);
 
 // bwd64.hip
 __attribute__((visibility("hidden"))) int dsgcn_bwd64_splits(int n, int Ci, int Co, int L);
@@ -1246,10 +1249,12 @@ int dsgcn_pwconv_partial_rows(int n, int Ci, int Co, int T, int V, int stride, i
 
 // Forward.  x2/s1/h1/s2/h2/bias/zaug/partial may be NULL as allowed by the flags.
 // partial: (dsgcn_pwconv_partial_rows(...), Co, 2).
-int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
-                     const float* h2, int relu, const float* w, const float* bias, float* z, float* zaug,
-                     float* partial, int n, int Ci, int Co, int T, int V, int stride, int aug, int stats,
-                     void* stream) {
+// ws: NULL, or the pre-split weight image of dsgcn_pwconv_wsplit (same w): the GEMM-form launches then skip the split of
+// the weight tile (csrc/pw4.hip, k_pwg2).
+int dsgcn_pwconv_fwd_ws(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                        const float* h2, int relu, const float* w, const float* bias, float* z, float* zaug,
+                        float* partial, int n, int Ci, int Co, int T, int V, int stride, int aug, int stats,
+                        const void* ws, void* stream) {
   if (!x1 || !w || !z || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0 || stride <= 0) return DSGCN_EINVAL;
   if ((aug && !zaug) || (stats && !partial) || (s1 && !h1) || (s2 && !h2)) return DSGCN_EINVAL;
   const int Tout = (T + stride - 1) / stride;
@@ -1264,7 +1269,7 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
   const int conv_rows = pw_conv_rows(n, Ci, Co, T, V, stride, 1);
   int fast = 0;
   if (stride == 1 && (g_pw4 & 1)) {
-    fast = dsgcn_p4_fwd(x1, s1, h1, x2, s2, h2, relu, w, bias, z, stats ? partial : nullptr, n, Ci, Co, L, st);
+    fast = dsgcn_p4_fwd(x1, s1, h1, x2, s2, h2, relu, w, bias, z, stats ? partial : nullptr, n, Ci, Co, L, st, ws);
     if (fast != 0 && fast != 1) return fast;
   }
   if (!fast) {
@@ -1301,6 +1306,26 @@ int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const fl
     DSGCN_LAUNCH_CHECK();
   }
   return 0;
+}
+
+int dsgcn_pwconv_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                     const float* h2, int relu, const float* w, const float* bias, float* z, float* zaug,
+                     float* partial, int n, int Ci, int Co, int T, int V, int stride, int aug, int stats,
+                     void* stream) {
+  return dsgcn_pwconv_fwd_ws(x1, s1, h1, x2, s2, h2, relu, w, bias, z, zaug, partial, n, Ci, Co, T, V, stride, aug, stats,
+                             nullptr, stream);
+}
+
+// Bytes of the pre-split weight image (three bf16 terms of W and of W^T, zero-padded to whole tiles) that the forward /
+// data gradient of this conv can use; 0 = neither takes the GEMM form (narrow convs, strided convs, tiny planes).
+size_t dsgcn_pwconv_wsplit_bytes(int n, int Ci, int Co, int T, int V, int stride) {
+  if (n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0 || stride != 1 || (g_pw4 & 3) != 3) return 0;
+  return dsgcn_p4_ws_bytes(n, Ci, Co, T * V);
+}
+
+int dsgcn_pwconv_wsplit(const float* w, int Ci, int Co, void* ws, void* stream) {
+  if (!w || !ws || Ci <= 0 || Co <= 0) return DSGCN_EINVAL;
+  return dsgcn_p4_wsplit(w, Ci, Co, ws, (hipStream_t)stream);
 }
 
 int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
@@ -1360,10 +1385,25 @@ int dsgcn_pwconv_ipart_rows(int n, int Ci, int Co, int T, int V, int stride) {
   return pw_conv_rows(n, Co, Ci, T, V, stride, 2);
 }
 
+int dsgcn_pwconv_dgrad_ws(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                          const float* h2, int relu, const float* w, const float* z, const float* zaug,
+                          const float* gz, const float* gzaug, const float* A0, const float* B0, float* dx1, float* dx2,
+                          float* ipart, int n, int Ci, int Co, int T, int V, int stride, int aug, const void* ws,
+                          void* stream);
+
 int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, const float* w, const float* z, const float* zaug,
                        const float* gz, const float* gzaug, const float* A0, const float* B0, float* dx1, float* dx2,
                        float* ipart, int n, int Ci, int Co, int T, int V, int stride, int aug, void* stream) {
+  return dsgcn_pwconv_dgrad_ws(x1, s1, h1, x2, s2, h2, relu, w, z, zaug, gz, gzaug, A0, B0, dx1, dx2, ipart, n, Ci, Co, T,
+                               V, stride, aug, nullptr, stream);
+}
+
+int dsgcn_pwconv_dgrad_ws(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                          const float* h2, int relu, const float* w, const float* z, const float* zaug,
+                          const float* gz, const float* gzaug, const float* A0, const float* B0, float* dx1, float* dx2,
+                          float* ipart, int n, int Ci, int Co, int T, int V, int stride, int aug, const void* ws,
+                          void* stream) {
   if (!x1 || !w || !dx1 || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0 || stride <= 0) return DSGCN_EINVAL;
   if ((A0 && (!B0 || !z)) || (aug && A0 && !zaug) || (x2 && !dx2)) return DSGCN_EINVAL;
   // dsgcn_pwconv_ipart_rows sizes `ipart` for the wide-load plan, which needs gz: a NULL gz would drop to the scalar
@@ -1387,7 +1427,7 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
   a.roll = ((g_pw_roll & 2) && Co % KW == 0 && (Ci & 3) == 0) ? 1 : 0;
   const int L = Tout * V;
   if (stride == 1 && !aug && (g_pw4 & 2)) {
-    const int fast = dsgcn_p4_dgrad(x1, s1, h1, x2, s2, h2, relu, w, z, gz, A0, B0, dx1, dx2, ipart, n, Ci, Co, L, st);
+    const int fast = dsgcn_p4_dgrad(x1, s1, h1, x2, s2, h2, relu, w, z, gz, A0, B0, dx1, dx2, ipart, n, Ci, Co, L, st, ws);
     if (fast == 1) return 0;
     if (fast != 0) return fast;
   }

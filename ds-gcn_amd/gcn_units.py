@@ -593,18 +593,26 @@ class unit_ctrgcn(nn.Module):
         self.soft = nn.Softmax(-2)
         self.relu = nn.ReLU(inplace=True)
 
+    def flat_groups(self):
+        """(see dgmstcn.flat_groups) the per-subset projections run as stacked convs: conv1 and conv2 of all subsets back to
+        back (ctr_topology concatenates the two stacks again), conv3 of all subsets"""
+        cs = self.convs
+        return [[c.conv1.weight for c in cs] + [c.conv2.weight for c in cs], [c.conv1.bias for c in cs] + [c.conv2.bias for c in cs],
+                [c.conv3.weight for c in cs], [c.conv3.bias for c in cs]]
+
     def forward_deferred(self, x, xbar=None, x_res=None):
         ops = kernels.ops()
         x_res = x if x_res is None else x_res
         if xbar is None:
             xbar = ops.tmean(x)
         cs = self.convs
+        cat = kernels.cat_rows                      # views of the flat parameter buffer under FlatParams (flat_groups)
         ahat = ops.ctr_topology(
-            xbar, torch.cat([c.conv1.weight.flatten(1) for c in cs], 0), torch.cat([c.conv1.bias for c in cs], 0),
-            torch.cat([c.conv2.weight.flatten(1) for c in cs], 0), torch.cat([c.conv2.bias for c in cs], 0),
+            xbar, cat([c.conv1.weight.flatten(1) for c in cs]), cat([c.conv1.bias for c in cs]),
+            cat([c.conv2.weight.flatten(1) for c in cs]), cat([c.conv2.bias for c in cs]),
             [c.conv4.weight.flatten(1) for c in cs], [c.conv4.bias for c in cs], self.alpha, self.A)
-        w3 = torch.cat([c.conv3.weight.flatten(1) for c in cs], 0)
-        b3 = torch.cat([c.conv3.bias for c in cs], 0)
+        w3 = cat([c.conv3.weight.flatten(1) for c in cs])
+        b3 = cat([c.conv3.bias for c in cs])
         x3 = ops.pwconv(x, None, None, None, False, w3, b3, 1, False)[0]
         y, ay = op_bn(self.bn, lambda g, b, eps, want: ops.aggregate_sum(x3, ahat, self.num_subset, g, b, eps, want),
                       lambda y: y.shape[0] * y.shape[2] * y.shape[3])
@@ -689,6 +697,13 @@ class unit_ctrhgcn(nn.Module):
         self.soft = nn.Softmax(-2)
         self.relu = nn.ReLU(inplace=True)
 
+    def flat_groups(self):
+        """(see dgmstcn.flat_groups) the per-subset projections run as stacked convs: conv1 and conv2 of all subsets back to
+        back (ctr_topology concatenates the two stacks again), conv3 of all subsets"""
+        cs = self.convs
+        return [[c.conv1.weight for c in cs] + [c.conv2.weight for c in cs], [c.conv1.bias for c in cs] + [c.conv2.bias for c in cs],
+                [c.conv3.weight for c in cs], [c.conv3.bias for c in cs]]
+
     def forward_deferred(self, x, xbar=None, x_res=None):
         ops = kernels.ops()
         x_res = x if x_res is None else x_res
@@ -698,12 +713,13 @@ class unit_ctrhgcn(nn.Module):
         edge = {k: (c.edge_att_conv.weight.flatten(1), c.edge_att_conv.bias, self.edge_type_idx)
                 for k, c in enumerate(cs) if hasattr(c, 'edge_att_conv')}
         beta = torch.cat([c.beta for c in cs]) if all(c.ada for c in cs) else None
+        cat = kernels.cat_rows
         ahat = ops.ctr_topology(
-            xbar, torch.cat([c.conv1.weight.flatten(1) for c in cs], 0), torch.cat([c.conv1.bias for c in cs], 0),
-            torch.cat([c.conv2.weight.flatten(1) for c in cs], 0), torch.cat([c.conv2.bias for c in cs], 0),
+            xbar, cat([c.conv1.weight.flatten(1) for c in cs]), cat([c.conv1.bias for c in cs]),
+            cat([c.conv2.weight.flatten(1) for c in cs]), cat([c.conv2.bias for c in cs]),
             [c.conv4.weight.flatten(1) for c in cs], [c.conv4.bias for c in cs], self.alpha, self.A, beta, edge)
-        w3 = torch.cat([c.conv3.weight.flatten(1) for c in cs], 0)
-        b3 = torch.cat([c.conv3.bias for c in cs], 0)
+        w3 = cat([c.conv3.weight.flatten(1) for c in cs])
+        b3 = cat([c.conv3.bias for c in cs])
         x3 = ops.pwconv(x, None, None, None, False, w3, b3, 1, False)[0]
         y, ay = op_bn(self.bn, lambda g, b, eps, want: ops.aggregate_sum(x3, ahat, self.num_subset, g, b, eps, want),
                       lambda y: y.shape[0] * y.shape[2] * y.shape[3])

@@ -53,11 +53,15 @@ def _stream():
 
 _side_streams = {}
 import os as _os
-OVERLAP = _os.environ.get('DSGCN_OVERLAP', '1') != '0'
+# K-B on a second stream beside the `pre` channel mix (side_branch below).  Off by default since round 3: with one
+# workgroup per sample K-B left half of the chip to the main stream and the overlap paid (round 2); as (sample, subset)
+# workgroups on the matrix core it fills the chip by itself and the fork / join edges only cost (13.33 ms/step with the
+# side stream, 13.07 without; profiles/r03/README.md)
+OVERLAP = _os.environ.get('DSGCN_OVERLAP', '0') != '0'
 # csrc/tms.hip, the fused temporal stage: 'auto' = where it measured faster than the staged chain (5-tap windows: CTR-GCN's
 # MSTCN, 22.3 -> 21.0 ms/step; on DS-STGCN's 3-tap units the staged wide-load kernels are still ahead, 13.6 vs 16.8 ms:
 # profiles/r03/README.md), '1' = wherever eligible, '0' = never
-FUSED_TEMPORAL = _os.environ.get('DSGCN_FUSED_TEMPORAL', 'auto')     # run K-B (dynamic adjacency: one block per sample, half the CUs) beside the `pre` channel mix
+FUSED_TEMPORAL = _os.environ.get('DSGCN_FUSED_TEMPORAL', 'auto')
 
 
 class side_branch:
@@ -486,10 +490,16 @@ class _PwConv(torch.autograd.Function):
         if want_bn:
             rows = lib.dsgcn_pwconv_partial_rows(n, Ci, Co, T, V, stride, int(aug))
             partial = torch.empty((rows, Co, 2), device=dev, dtype=torch.float32)
-        rc = lib.dsgcn_pwconv_fwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu), _ptr(w2),
-                                  _ptr(bias), _ptr(z), _ptr(zaug), _ptr(partial), n, Ci, Co, T, V, stride, int(aug),
-                                  int(want_bn), _stream())
-        native.check(rc, 'dsgcn_pwconv_fwd')
+        # wide convs: the three bf16 terms of the weights, split once here for the forward and the data gradient
+        ws = None
+        wsb = lib.dsgcn_pwconv_wsplit_bytes(n, Ci, Co, T, V, stride)
+        if wsb:
+            ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+            native.check(lib.dsgcn_pwconv_wsplit(_ptr(w2), Ci, Co, _ptr(ws), _stream()), 'dsgcn_pwconv_wsplit')
+        rc = lib.dsgcn_pwconv_fwd_ws(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu), _ptr(w2),
+                                     _ptr(bias), _ptr(z), _ptr(zaug), _ptr(partial), n, Ci, Co, T, V, stride, int(aug),
+                                     int(want_bn), _ptr(ws), _stream())
+        native.check(rc, 'dsgcn_pwconv_fwd_ws')
         scale = shift = mean = var = None
         count = float(n * Tout * (V + (1 if aug else 0)))
         if want_bn:
@@ -500,7 +510,7 @@ class _PwConv(torch.autograd.Function):
             native.check(rc, 'dsgcn_bn_finalize')
             ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)      # no zero tensors for the unused / non-differentiable outputs (mean, var)
-        ctx.save_for_backward(x1, s1, h1, x2, s2, h2, w2, z, zaug, gamma, mean, var)
+        ctx.save_for_backward(x1, s1, h1, x2, s2, h2, w2, z, zaug, gamma, mean, var, ws)
         ctx.cfg = (int(relu), stride, int(aug), float(eps), int(n_affine), bool(want_bn), count, tuple(weight.shape),
                    bias is not None, beta is not None)
         ctx.defer_ok = _leafish(weight, bias)
@@ -508,7 +518,7 @@ class _PwConv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gz, gzaug, gscale, gshift, _gm, _gv):
-        x1, s1, h1, x2, s2, h2, w2, z, zaug, gamma, mean, var = ctx.saved_tensors
+        x1, s1, h1, x2, s2, h2, w2, z, zaug, gamma, mean, var, ws = ctx.saved_tensors
         relu, stride, aug, eps, n_affine, want_bn, count, wshape, has_bias, has_beta = ctx.cfg
         n, Ci, T, V = x1.shape
         Co = w2.shape[0]
@@ -555,12 +565,12 @@ class _PwConv(torch.autograd.Function):
         if s1 is not None or s2 is not None:
             rows = lib.dsgcn_pwconv_ipart_rows(n, Ci, Co, T, V, stride)
             ipart = torch.empty((rows, Ci, 3), device=dev, dtype=torch.float32)     # every row is written by dgrad
-        rc = lib.dsgcn_pwconv_dgrad(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(w2),
-                                    _ptr(z), _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), _ptr(dx1),
-                                    _ptr(dx2), _ptr(ipart), n, Ci, Co, T, V, stride, aug, st)
-        native.check(rc, 'dsgcn_pwconv_dgrad')
-        # (the weight gradient on a second stream beside the data gradient was measured: 17.65 vs 17.68 ms/step — both
-        # launches are HBM-bound, so it stays on the one stream)
+        rc = lib.dsgcn_pwconv_dgrad_ws(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(w2),
+                                       _ptr(z), _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), _ptr(dx1),
+                                       _ptr(dx2), _ptr(ipart), n, Ci, Co, T, V, stride, aug, _ptr(ws), st)
+        native.check(rc, 'dsgcn_pwconv_dgrad_ws')
+        # (the weight gradient on a second stream beside the data gradient was measured twice: round 2 17.65 vs 17.68
+        # ms/step, round 3 13.33 vs 13.34 — it stays on the one stream)
         splits = lib.dsgcn_pwconv_wgrad_splits(n, Ci, Co, T, V, stride)
         pstride = Co * Ci + Co
         wpart = torch.empty((splits, pstride), device=dev, dtype=torch.float32)
@@ -1417,7 +1427,7 @@ def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None):
     n, Ci, V = xbar.shape
     K = A.shape[0]
     R = w1.shape[0] // K
-    proj = pwconv(xbar.unsqueeze(2), None, None, None, False, torch.cat([w1, w2], 0), torch.cat([b1, b2], 0), 1,
+    proj = pwconv(xbar.unsqueeze(2), None, None, None, False, cat_rows([w1, w2]), cat_rows([b1, b2]), 1,
                   False)[0].view(n, 2 * K * R, V)
     d = _TanhDiff.apply(proj, K, R)
     S = []
@@ -1467,9 +1477,12 @@ def tee3(x):
 
 
 class _FuseOut(torch.autograd.Function):
+    """-> (out, out', out'', xbar): with ``tee`` the output comes as three aliases, one per consumer in the next block
+    (spatial unit, its residual operand, block residual), and the backward sums their gradients while loading them —
+    autograd's own accumulation would be two more launches and a materialised sum (the round-2 dsgcn_add3 pass)."""
 
     @staticmethod
-    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, xbar_ld):
+    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, xbar_ld, tee):
         _require_cuda(x1)
         x1, s1, h1, x2, s2, h2 = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2)]
         n, C, T, V = x1.shape
@@ -1481,21 +1494,26 @@ class _FuseOut(torch.autograd.Function):
         ctx.save_for_backward(x1, s1, h1, x2, s2, h2)
         ctx.relu = int(relu)
         ctx.xbar_ld = int(xbar_ld)
-        return out, xbar
+        ctx.set_materialize_grads(False)
+        if tee:
+            return out, out.view_as(out), out.view_as(out), xbar
+        return out, None, None, xbar
 
     @staticmethod
-    def backward(ctx, dout, dxbar):
+    def backward(ctx, dout, dout2, dout3, dxbar):
         x1, s1, h1, x2, s2, h2 = ctx.saved_tensors
         n, C, T, V = x1.shape
-        dout, dxbar = _f32c(dout), _f32c(dxbar)
+        douts = [_f32c(g) for g in (dout, dout2, dout3) if g is not None]
+        douts += [None] * (3 - len(douts))
+        dxbar = _f32c(dxbar)
         dx1 = torch.empty_like(x1)
         dx2 = torch.empty_like(x2) if x2 is not None else None
         need_part = s1 is not None or s2 is not None
         part = torch.empty((n, C, 4), device=x1.device, dtype=torch.float32) if need_part else None
-        rc = native.lib().dsgcn_fuse_out_bwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
-                                             _ptr(dout), _ptr(dxbar), _ptr(dx1), _ptr(dx2), _ptr(part), n, C, T, V,
-                                             ctx.xbar_ld or V, _stream())
-        native.check(rc, 'dsgcn_fuse_out_bwd')
+        rc = native.lib().dsgcn_fuse_out_bwd3(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
+                                              _ptr(douts[0]), _ptr(douts[1]), _ptr(douts[2]), _ptr(dxbar), _ptr(dx1),
+                                              _ptr(dx2), _ptr(part), n, C, T, V, ctx.xbar_ld or V, _stream())
+        native.check(rc, 'dsgcn_fuse_out_bwd3')
         ds1 = dh1 = ds2 = dh2 = None
         if need_part:
             red = colsum(part, split_last=True)
@@ -1503,14 +1521,16 @@ class _FuseOut(torch.autograd.Function):
                 ds1, dh1 = red[0], red[3]
             if s2 is not None:
                 ds2, dh2 = red[2], red[1]
-        return dx1, ds1, dh1, dx2, ds2, dh2, None, None
+        return dx1, ds1, dh1, dx2, ds2, dh2, None, None, None
 
 
-def fuse_out(x1, a1, x2, a2, relu, want_tmean=False):
+def fuse_out(x1, a1, x2, a2, relu, want_tmean=False, tee=False):
     """relu: bool, or int flags — bit 0 the outer ReLU, bit 1 a ReLU on the first term before the add.
     want_tmean: False / True (time mean (n, C, V)) / an int ld >= V (time mean with the joint row zero-padded to ld: the
-    layout `dynadj` consumes directly)."""
+    layout `dynadj` consumes directly).
+    tee: return the output as a tuple of three aliases (see _FuseOut) for the next block's three reads."""
     s1, h1 = a1 if a1 is not None else (None, None)
     s2, h2 = a2 if a2 is not None else (None, None)
     ld = 0 if not want_tmean else (x1.shape[-1] if want_tmean is True else int(want_tmean))
-    return _FuseOut.apply(x1, s1, h1, x2, s2, h2, int(relu), ld)
+    o1, o2, o3, xbar = _FuseOut.apply(x1, s1, h1, x2, s2, h2, int(relu), ld, bool(tee))
+    return ((o1, o2, o3) if tee else o1), xbar

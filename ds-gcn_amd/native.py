@@ -33,6 +33,9 @@ SIGNATURES = {
     'dsgcn_pwconv_plan': [c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                           ctypes.POINTER(ctypes.c_int)],
     'dsgcn_pwconv_fwd': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 8 + [c_st],
+    'dsgcn_pwconv_fwd_ws': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 8 + [c_f, c_st],
+    'dsgcn_pwconv_wsplit': [c_f, c_int, c_int, c_f, c_st],
+    'dsgcn_pwconv_wsplit_bytes': [c_int] * 6,
     'dsgcn_bn_finalize': [c_f, c_int, c_int, ctypes.c_double, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f, c_int,
                           c_st],
     'dsgcn_pwconv_partial_rows': [c_int] * 7,
@@ -44,6 +47,7 @@ SIGNATURES = {
     'dsgcn_colsum_multi': [c_f, c_int, c_int, c_st],
     'dsgcn_colsum2': [c_f, c_int, c_int, c_int, c_f, c_f, c_int, c_int, c_int, c_f, c_st],
     'dsgcn_pwconv_dgrad': [c_f] * 6 + [c_int] + [c_f] * 10 + [c_int] * 7 + [c_st],
+    'dsgcn_pwconv_dgrad_ws': [c_f] * 6 + [c_int] + [c_f] * 10 + [c_int] * 7 + [c_f, c_st],
     'dsgcn_pwconv_wgrad_splits': [c_int] * 6,
     'dsgcn_pwconv_bwd_rows': [c_int] * 6,
     'dsgcn_pwconv_bwd': [c_f] * 6 + [c_int] + [c_f] * 10 + [c_int] * 6 + [c_st],
@@ -76,6 +80,7 @@ SIGNATURES = {
     'dsgcn_pack': [c_f, c_f, c_f, c_int, c_f, c_st],
     'dsgcn_fuse_out_fwd': [c_f] * 6 + [c_int] + [c_f] * 2 + [c_int] * 5 + [c_st],
     'dsgcn_fuse_out_bwd': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 5 + [c_st],
+    'dsgcn_fuse_out_bwd3': [c_f] * 6 + [c_int] + [c_f] * 7 + [c_int] * 5 + [c_st],
     'dsgcn_dwcausal_fwd': [c_f, c_f, c_f, c_i, c_f] + [c_int] * 6 + [c_st],
     'dsgcn_dwcausal_bwd': [c_f, c_f, c_i, c_f, c_f, c_f] + [c_int] * 6 + [c_st],
     'dsgcn_gate_fwd': [c_f, c_f, c_int, c_f, c_f] + [c_int] * 5 + [c_st],
@@ -87,6 +92,8 @@ SIGNATURES = {
 }
 
 
+SIZE_T_RESULTS = {'dsgcn_pwconv_wsplit_bytes'}      # everything else returns an int status / count
+
 # measurement-only entry points: exported by libdsgcn_lab.so only (include/dsgcn_lab.h)
 LAB_SIGNATURES = {
     'dsgcn_aggregate_fwd_valu': [c_f, c_f, c_f, c_int, c_f, c_f, c_int, c_int, c_int, c_int, c_st],
@@ -96,6 +103,7 @@ LAB_SIGNATURES = {
     'dsgcn_diag_mfma_probe': [c_f, c_int, c_int, c_int, c_st],
     'dsgcn_aggsum_tuning': [c_int, c_int],
     'dsgcn_tms_tuning': [c_int, c_int],
+    'dsgcn_dynadj_phases': [ctypes.c_void_p],
 }
 
 
@@ -188,7 +196,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_size_t if name in SIZE_T_RESULTS else ctypes.c_int
         _lib = handle
     return _lib
 
@@ -201,7 +209,7 @@ def lab_lib():
         for name, argtypes in {**SIGNATURES, **LAB_SIGNATURES}.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_size_t if name in SIZE_T_RESULTS else ctypes.c_int
         _lab = handle
     return _lab
 

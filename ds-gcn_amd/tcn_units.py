@@ -209,12 +209,12 @@ class mstcn(dgmstcn):
         d = as_deferred(g)
         n, _, T, V = d.x1.shape
         convs = self._first_convs()
-        wb = torch.cat([c.weight.flatten(1) for c in convs], 0)
-        bb = torch.cat([c.bias for c in convs], 0)
+        wb = kernels.cat_rows([c.weight.flatten(1) for c in convs])
+        bb = kernels.cat_rows([c.bias for c in convs])
         bns = [b[1] for b in self.branches if not isinstance(b, nn.Conv2d)]
         if any(_need_stats(bn) for bn in bns):
-            gamma = torch.cat([bn.weight for bn in bns])
-            beta = torch.cat([bn.bias for bn in bns])
+            gamma = kernels.cat_rows([bn.weight for bn in bns])
+            beta = kernels.cat_rows([bn.bias for bn in bns])
             z, _, scale, shift, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, False, gamma, beta,
                                                    bns[0].eps, self.n_act, True)
             c0 = 0
@@ -282,19 +282,28 @@ class MSTCN(nn.Module):
         self.act = nn.ReLU()
         self.drop = nn.Dropout(tcn_dropout)
 
+    def flat_groups(self):
+        """(see dgmstcn.flat_groups) the branch 1x1 convs run as one stacked conv; the BatchNorms behind them and the ones
+        that close the branches as two stacked affines"""
+        convs = [b[0] for b in self.branches]
+        bns = [b[1] for b in self.branches[:-1]]
+        post = [b[3].bn for b in self.branches[:-2]] + [self.branches[-2][4], self.branches[-1][1]]
+        return [[c.weight for c in convs], [c.bias for c in convs], [bn.weight for bn in bns], [bn.bias for bn in bns],
+                [bn.weight for bn in post], [bn.bias for bn in post]]
+
     def _branches_deferred(self, g):
         """cat of the branch outputs before the closing BatchNorms: -> (o raw, (scale, shift))."""
         ops = kernels.ops()
         d = as_deferred(g)
         n, _, T, V = d.x1.shape
         convs = [b[0] for b in self.branches]
-        wb = torch.cat([c.weight.flatten(1) for c in convs], 0)
-        bb = torch.cat([c.bias for c in convs], 0)
+        wb = kernels.cat_rows([c.weight.flatten(1) for c in convs])
+        bb = kernels.cat_rows([c.bias for c in convs])
         bns = [b[1] for b in self.branches[:-1]]
         n_act = sum(bn.num_features for bn in bns)
         if any(_need_stats(bn) for bn in bns):
-            gamma = torch.cat([bn.weight for bn in bns])
-            beta = torch.cat([bn.bias for bn in bns])
+            gamma = kernels.cat_rows([bn.weight for bn in bns])
+            beta = kernels.cat_rows([bn.bias for bn in bns])
             z, _, scale, shift, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, False, gamma, beta,
                                                    bns[0].eps, n_act, True)
             c0 = 0
@@ -311,8 +320,8 @@ class MSTCN(nn.Module):
         tw, tb = [t.conv.weight for t in tcns], [t.conv.bias for t in tcns]
         post = [t.bn for t in tcns] + [self.branches[-2][4], self.branches[-1][1]]
         if any(_need_stats(bn) for bn in post):
-            gamma = torch.cat([bn.weight for bn in post])
-            beta = torch.cat([bn.bias for bn in post])
+            gamma = kernels.cat_rows([bn.weight for bn in post])
+            beta = kernels.cat_rows([bn.bias for bn in post])
             o, s2, h2, m2, v2 = ops.temporal_branches_bn(z, scale, shift, n_act, self.branch_cfg, self.widths, tw, tb,
                                                          self.stride, gamma, beta, post[0].eps, True)
             c0 = 0
@@ -486,12 +495,12 @@ class msmlp(dgmstcn):
         d = as_deferred(g)
         n, _, T, V = d.x1.shape
         convs = self._first_convs()
-        wb = torch.cat([c.weight.flatten(1) for c in convs], 0)
-        bb = torch.cat([c.bias for c in convs], 0)
+        wb = kernels.cat_rows([c.weight.flatten(1) for c in convs])
+        bb = kernels.cat_rows([c.bias for c in convs])
         bns = [b[1] for b in self.branches if not isinstance(b, nn.Conv2d)]
         if any(_need_stats(bn) for bn in bns):
-            gamma = torch.cat([bn.weight for bn in bns])
-            beta = torch.cat([bn.bias for bn in bns])
+            gamma = kernels.cat_rows([bn.weight for bn in bns])
+            beta = kernels.cat_rows([bn.bias for bn in bns])
             z, _, scale, shift, m, var = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, wb, bb, 1, False, gamma, beta,
                                                    bns[0].eps, self.n_act, True)
             c0 = 0

@@ -18,6 +18,7 @@
 #ifndef DSGCN_H_
 #define DSGCN_H_
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -74,6 +75,13 @@ int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const 
 int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, const float* dout, const float* dxbar, float* dx1, float* dx2,
                        float* part, int n, int C, int T, int V, int xbar_ld, void* stream);
+/* the same with up to three gradients of `out`, (dout + dout2) + dout3 formed while loading: the next block reads its
+ * input three times (dgstgcn.py:63-65: gcn(x), the unit's residual operand, the block residual) and autograd would
+ * otherwise materialise the sum first (dsgcn_add3).  dout2 / dout3 may be NULL. */
+int dsgcn_fuse_out_bwd3(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                        const float* h2, int relu, const float* dout, const float* dout2, const float* dout3,
+                        const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
+                        void* stream);
 
 /* K-D: dgmstcn temporal stages (tcn.py:379-428).
  * branch_act: h (n,C,T,V+1) = act_c(z*scale+shift) with the global-joint column zaug appended (ReLU for c < n_act).
@@ -151,6 +159,22 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
                        const float* h2, int relu, const float* w, const float* z, const float* zaug,
                        const float* gz, const float* gzaug, const float* A0, const float* B0, float* dx1, float* dx2,
                        float* ipart, int n, int Ci, int Co, int T, int V, int stride, int aug, void* stream);
+/* Wide convs (GEMM form: both widths > 64): the weights split into their three bf16 terms ONCE per conv and step instead
+ * of per workgroup and K chunk.  dsgcn_pwconv_wsplit_bytes: size of that image for this shape, 0 = the shape does not
+ * use it.  dsgcn_pwconv_wsplit fills it from w (Co, Ci) (both the W and the W^T image); dsgcn_pwconv_fwd_ws /
+ * dsgcn_pwconv_dgrad_ws are dsgcn_pwconv_fwd / dsgcn_pwconv_dgrad with that image (ws = NULL: identical to them).
+ * Same results as the plain entry points (the split is the same function of w, only evaluated earlier). */
+size_t dsgcn_pwconv_wsplit_bytes(int n, int Ci, int Co, int T, int V, int stride);
+int dsgcn_pwconv_wsplit(const float* w, int Ci, int Co, void* ws, void* stream);
+int dsgcn_pwconv_fwd_ws(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                        const float* h2, int relu, const float* w, const float* bias, float* z, float* zaug,
+                        float* partial, int n, int Ci, int Co, int T, int V, int stride, int aug, int stats,
+                        const void* ws, void* stream);
+int dsgcn_pwconv_dgrad_ws(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                          const float* h2, int relu, const float* w, const float* z, const float* zaug,
+                          const float* gz, const float* gzaug, const float* A0, const float* B0, float* dx1, float* dx2,
+                          float* ipart, int n, int Ci, int Co, int T, int V, int stride, int aug, const void* ws,
+                          void* stream);
 /* Weight gradient: k-split partials, split s at dwp + s*pstride (Co*Ci floats) and dbp + s*pstride (Co floats);
  * splits from dsgcn_pwconv_wgrad_splits. */
 int dsgcn_pwconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int stride);

@@ -30,6 +30,10 @@ int dsgcn_aggsum_tuning(int key, int value);
 /* fused temporal stage (key 0: ablation mask 1 no staging / 2 no MFMA / 4 no epilogue, 1: workgroups per window, 2: frames per tile) */
 int dsgcn_tms_tuning(int key, int value);
 
+/* K-B backward: wall-clock stamps (10 ns units) at the phase boundaries of sample 0's three workgroups, out[3][8]
+ * (subset-major; phases: start, prepare, pass 1, masked sums, Gram backward, GEMMs, end). */
+int dsgcn_dynadj_phases(long long* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     with open(os.path.join(ROOT, 'include', 'dsgcn.h')) as f:
         text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
-    return sorted(set(re.findall(r'\bint\s+(dsgcn_\w+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(?:int|size_t)\s+(dsgcn_\w+)\s*\(', text)))
 
 
 def test_library_builds_and_exports_header_symbols():

@@ -246,7 +246,7 @@ def tconv(h, weight, bias, stride, dilation, gamma=None, beta=None, eps=1e-5, wa
     return _bn_of(z, gamma, beta, eps, want_bn)
 
 
-def fuse_out(x1, a1, x2, a2, relu, want_tmean=False):
+def fuse_out(x1, a1, x2, a2, relu, want_tmean=False, tee=False):
     """relu: bool or int flags (bit 0 outer ReLU, bit 1 ReLU on the first term before the add)."""
     relu = int(relu)
     if relu & 2:
@@ -260,7 +260,7 @@ def fuse_out(x1, a1, x2, a2, relu, want_tmean=False):
     xbar = out.mean(2) if want_tmean else None
     if xbar is not None and want_tmean is not True and int(want_tmean) > xbar.shape[-1]:
         xbar = F.pad(xbar, (0, int(want_tmean) - xbar.shape[-1]))         # padded joint row (kernels.fuse_out)
-    return out, xbar
+    return ((out, out, out) if tee else out), xbar
 
 
 def temporal_mlp_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, dw_w, dw_b, dw_dil, pw_w, pw_b,

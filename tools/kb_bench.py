@@ -6,10 +6,11 @@ import numpy as np, torch
 import dsgcn_amd as D
 from dsgcn_amd import native
 from bench import ds_cfg
-lib = native.lib(); st = torch.cuda.current_stream().cuda_stream
+LAB = os.environ.get('KB_LAB') == '1'      # KB_LAB=1: the lab build, prints the backward's phase times
+lib = native.lab_lib() if LAB else native.lib(); st = torch.cuda.current_stream().cuda_stream
 np.random.seed(0); torch.manual_seed(0)
 m = D.build_model(ds_cfg(60)).cuda()
-n, V = 128, 25
+n, V = int(os.environ.get("KB_N", 64)), 25
 P_ = lambda t: t.data_ptr()
 
 
@@ -47,3 +48,14 @@ for blk in m.backbone.gcn:
     b = lambda: lib.dsgcn_dynadj_bwd(P_(proj), P_(alpha), P_(beta), P_(we), P_(be), P_(nt), P_(et), P_(dahat), P_(dd), P_(dproj), P_(ppar), ps, n, mid, V, ld, Pn, E, st)
     assert f() == 0 and b() == 0
     print(f'mid={mid:3d} E={E} P={Pn}: fwd {timeit(f):6.1f} us  bwd {timeit(b):6.1f} us   (Ahat {ahat.numel()*4/1e6:.1f} MB)')
+    if LAB:
+        torch.cuda.synchronize(); b(); torch.cuda.synchronize()
+        ph = np.zeros((3, 8), dtype=np.int64)
+        assert lib.dsgcn_dynadj_phases(ph.ctypes.data) == 0
+        names = ['prepare', 'pass1', 'sums+masked', 'gram', 'gemms', 'dproj']
+        for k in range(3):
+            d = np.diff(ph[k, :7]) / 100.0
+            if k != 1:      # no stamp 4 on the plain subsets
+                d = np.array([d[0], d[1], d[2], (ph[k, 5] - ph[k, 3]) / 100.0, 0.0, d[5]])
+            print(f'   subset {k}: ' + '  '.join(f'{nm} {x:5.1f}' for nm, x in zip(names, d)) + f'   total {(ph[k, 6] - ph[k, 0]) / 100.0:.1f} us')
+
