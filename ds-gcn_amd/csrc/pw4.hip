@@ -634,12 +634,25 @@ __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
 // rows runs 256 rows per workgroup (8 waves x 32 rows over the SAME 128-position tile), so the activation tile is loaded
 // and split once per 256 rows instead of once per 128.  Per wave and 32-channel chunk that leaves 8 activation values to
 // split (k_pwg: 16 + 16 weight values) in front of the same 48 MFMAs.
+#ifdef DSGCN_LAB
+// wall-clock stamps (10 ns) of workgroup 0, thread 0: [0] start, [1] operands issued, then per chunk (commit done,
+// barrier passed, products done), the last two: main loop drained, epilogue done; [63] = count.  dsgcn_pwg2_phases reads them
+__device__ long long g_pwg_stamp[64];
+#define PWG_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0 && nst < 62) g_pwg_stamp[nst++] = wall_clock64(); } while (0)
+#else
+#define PWG_STAMP() do {} while (0)
+#endif
+
 template <int MODE, int EPI, int NWV>
 __global__ __launch_bounds__(64 * NWV, 2) void k_pwg2(Pw4Args a, const unsigned short* __restrict__ wsp, int Mp) {
   typedef VQ<4>::T vq;
   constexpr int NTH = 64 * NWV, TA = 32 * NWV;     // threads; A rows per workgroup
   constexpr int CPT = 32 / (NTH / 32);             // activation channels per loader thread and chunk: 4 or 2
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef DSGCN_LAB
+  int nst = 0;
+#endif
+  PWG_STAMP();
   char* Ab = reinterpret_cast<char*>(lds);                               // [3][TA rows][RB]
   char* Bb = Ab + 3 * TA * PG_RB;                                        // [3][128 position slots][RB]
   f32x4* Ps = reinterpret_cast<f32x4*>(Bb + 3 * PG_T * PG_RB);           // [Kpad] (s1, h1, s2, h2)
@@ -761,12 +774,15 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_pwg2(Pw4Args a, const unsigned 
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // Ps visible (raw barrier: the operand loads stay in flight)
+  PWG_STAMP();
   const char* Af = Ab + (32 * wave + l31) * PG_RB + 16 * half;
   const char* Bf = Bb + l31 * PG_RB + 16 * half;
   auto chunk = [&](int ch0, vq (&bw)[CPT], vq (&bw2)[MODE == 2 ? CPT : 1]) {
     commit(ch0, bw, bw2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PWG_STAMP();
     __builtin_amdgcn_s_barrier();
+    PWG_STAMP();
     __builtin_amdgcn_sched_barrier(0);
     issueA(ch0 + PG_KC);                           // (past K: an out-of-range offset, zeros)
     issueB(ch0 + 2 * PG_KC, bw, bw2);              // this set is free again: two chunks ahead
@@ -795,6 +811,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_pwg2(Pw4Args a, const unsigned 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // raw barrier: the loads in flight stay in flight
+    PWG_STAMP();
   };
   int ch0 = 0;
   for (; ch0 + PG_KC < Kpad; ch0 += 2 * PG_KC) {
@@ -803,8 +820,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_pwg2(Pw4Args a, const unsigned 
   }
   if (ch0 < Kpad) chunk(ch0, bwA, bw2A);
   __syncthreads();                                 // drains the read-ahead loads before LDS is reused
+  PWG_STAMP();
   const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, true, pok, skip};
   p4_epilogue<1, 4, EPI, true, NWV>(a, acc, lds, tile);
+  PWG_STAMP();
+#ifdef DSGCN_LAB
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_pwg_stamp[63] = nst;
+#endif
 }
 
 // The three bf16 terms of W (Co x Ci) as two images, k contiguous and zero-padded to whole tiles:
@@ -1072,3 +1094,9 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_wsplit(const float* w, int Ci
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef DSGCN_LAB
+extern "C" int dsgcn_pwg2_phases(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pwg_stamp), sizeof(long long) * 64);
+}
+#endif

@@ -104,6 +104,7 @@ LAB_SIGNATURES = {
     'dsgcn_aggsum_tuning': [c_int, c_int],
     'dsgcn_tms_tuning': [c_int, c_int],
     'dsgcn_dynadj_phases': [ctypes.c_void_p],
+    'dsgcn_pwg2_phases': [ctypes.c_void_p],
 }
 
 

@@ -34,6 +34,11 @@ int dsgcn_tms_tuning(int key, int value);
  * (subset-major; phases: start, prepare, pass 1, masked sums, Gram backward, GEMMs, end). */
 int dsgcn_dynadj_phases(long long* out);
 
+/* K-C pre-split GEMM form (k_pwg2): wall-clock stamps (10 ns) of workgroup 0 of the last launch, out[64]: start, operands
+ * issued, then (commit done, barrier passed, products done) per 32-channel chunk, main loop drained, epilogue done;
+ * out[63] = number of stamps. */
+int dsgcn_pwg2_phases(long long* out);
+
 #ifdef __cplusplus
 }
 #endif

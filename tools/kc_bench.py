@@ -30,7 +30,7 @@ def timeit(fn, reps=20):
 
 
 def run(variant):
-    keys = {3: 15, 4: 0, 5: 0, 6: 0, 7: 512, 8: 32, 9: 512}
+    keys = {3: 15, 4: 0, 5: 0, 6: 0, 7: 512, 8: 32, 9: 512, 14: 1}
     if variant:
         for kv in variant.split(','):
             k, v = kv.split('=')
@@ -56,14 +56,18 @@ def run(variant):
         pstride = Co * Ci + Co
         wpart = torch.empty(splits, pstride, device=dev)
         P = lambda t: None if t is None else t.data_ptr()
+        wsb = lib.dsgcn_pwconv_wsplit_bytes(n, Ci, Co, T, V, 1)      # (14=0: no pre-split weight image)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev) if wsb else None
+        if ws is not None:
+            assert lib.dsgcn_pwconv_wsplit(P(w), Ci, Co, P(ws), st) == 0
 
         def fwd():
-            assert lib.dsgcn_pwconv_fwd(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(w), P(b), P(z), None, P(part),
-                                        n, Ci, Co, T, V, 1, 0, 1, st) == 0
+            assert lib.dsgcn_pwconv_fwd_ws(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(w), P(b), P(z), None, P(part),
+                                           n, Ci, Co, T, V, 1, 0, 1, P(ws), st) == 0
 
         def dgrad():
-            assert lib.dsgcn_pwconv_dgrad(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(w), P(z), None, P(gz), None,
-                                          P(A0), P(B0), P(dx), P(dx2), P(ipart), n, Ci, Co, T, V, 1, 0, st) == 0
+            assert lib.dsgcn_pwconv_dgrad_ws(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(w), P(z), None, P(gz), None,
+                                             P(A0), P(B0), P(dx), P(dx2), P(ipart), n, Ci, Co, T, V, 1, 0, P(ws), st) == 0
 
         def wgrad():
             assert lib.dsgcn_pwconv_wgrad(P(x1), P(s1), P(h1), P(x2), None, None, relu, P(z), None, P(gz), None, P(A0),
@@ -91,6 +95,17 @@ def run(variant):
             t = timeit(fused)
             res.append(f'fused bwd {t:6.1f} us {4 * L * (2 * Co + 2 * Ci) / t / 1e6:5.2f} TB/s')
         print(f'{name:8s} {Ci:4d} {Co:4d} | ' + ' | '.join(res), flush=True)
+        if os.environ.get('KC_PHASES') and ws is not None and keys[14]:
+            import numpy as np
+            for nm, fn in (('fwd', fwd), ('dgrad', dgrad)):
+                torch.cuda.synchronize(); fn(); torch.cuda.synchronize()
+                ph = np.zeros(64, dtype=np.int64)
+                assert lib.dsgcn_pwg2_phases(ph.ctypes.data) == 0
+                k_ = int(ph[63]); d = np.diff(ph[:k_]) / 100.0
+                nchunk = (k_ - 4) // 3
+                ch = d[1:1 + 3 * nchunk].reshape(nchunk, 3)
+                print(f'    {nm}: prologue {d[0]:.1f} us | per chunk commit/barrier/products (us): ' +
+                      ' '.join(f'{a_:.2f}/{b_:.2f}/{c_:.2f}' for a_, b_, c_ in ch) + f' | drain {d[-2]:.1f} epilogue {d[-1]:.1f} | total {(ph[k_ - 1] - ph[0]) / 100.0:.1f}')
     print(f'total us: fwd {tot[0]:.0f} dgrad {tot[1]:.0f} wgrad {tot[2]:.0f}')
 
 
