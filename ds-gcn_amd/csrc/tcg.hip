@@ -1,0 +1,793 @@
+// Dense temporal conv ((KT,1) kernel, stride 1, dilation 1, "same" zero padding) as a GEMM on three-term bf16 products.
+//
+// Replaces `unit_tcn`'s Conv2d((9,1)) + BatchNorm2d statistics (pyskl/models/gcns/utils/tcn.py:21-28, used by ST-GCN
+// stgcn.py:40-46 and AAGCN aagcn.py) with the consumer-side BN / ReLU / residual of the spatial unit in front of it
+// applied while loading, and the autograd of all of that:
+//   forward        z[n,co,t,v]  = b[co] + sum_{tap,ci} W[co,ci,tap] * x'[n,ci,t+tap-pad,v]      x' = relu?(x1*s1+h1 (+ x2*s2+h2))
+//   data gradient  dx'[n,ci,t,v] = sum_{tap,co} W[co,ci,tap] * dz[n,co,t-(tap-pad),v]            dz = gz + A0[co] + B0[co]*z
+//   weight grad.   dW[co,ci,tap] = sum_{n,t,v} dz[n,co,t,v] * x'[n,ci,t+tap-pad,v],   db[co] = sum dz
+// The first-generation kernels (tapconv.hip, k_tapconv_*<9>) ran these at ~50 TF of fp32 MFMA and were 66 % of ST-GCN's
+// step (profiles/r03/stgcn_kernel_stats.csv); they also needed the input materialised and the statistics in a pass of
+// their own.
+//
+// k_tcg (forward and data gradient, one template): a workgroup (8 waves) owns 128 output rows x one tile of R = 128/V whole
+// frames of ONE sample (R*V <= 128 position slots in natural order).  Per 32-channel chunk the input tile WITH its halo
+// ((R + KT-1) frames) is loaded, activated, zeroed outside the sample's frames, split into its three bf16 terms ONCE and
+// kept in LDS as [position row][32 channels]; a tap is then nothing but a row offset (tap*V rows) of the B fragment
+// address, so the nine taps' products reuse one staging — the split costs ~1/9 of what it costs the 1x1 GEMM form per
+// MFMA.  The weights arrive pre-split per tap (k_tsplit: one launch per conv and step, the W image for the forward and
+// the tap-flipped W^T image for the data gradient) and are copied into a double-buffered LDS tile one tap ahead: one
+// barrier per (chunk, tap) step, 24 MFMAs (v_mfma_f32_32x32x16_bf16) per wave and step.  Waves: 4 row tiles x 2 halves of
+// the position slots.  Results leave with 4-byte stores (a lane's slots are 32 apart in natural order; 32 lanes of one
+// store are 128 contiguous bytes).  Statistics / input-affine sums per workgroup tile -> partial rows (ordered sums, no
+// atomics).
+//
+// k_tcw (weight gradient): workgroup = 128 co x 64 ci x all taps, wave = 32 x 32 x KT accumulators; K = positions in
+// chunks of 32 of one sample; dz is staged once per chunk, x' once per tap with the tap's frame shift folded into the
+// load address (elements outside the sample's frames are zero).  K is split over workgroups; every split writes its
+// partial row (dsgcn_colsum / the deferred parameter sums reduce them in order).
+#include "common.h"
+
+namespace {
+
+constexpr int TG_NT = 256;                       // 4 waves (k_tcg); the weight gradient brings 8
+constexpr int TG_KC = 32;                        // channels per chunk
+constexpr int TG_RB = TG_KC * 2 + 16;            // LDS row: 32 bf16 + 16 B pad (conflict-free 16-byte fragment reads)
+constexpr int TG_OOB = 0x7ffffff0;
+constexpr int TG_MAXIT = 12;                     // staging items per thread and chunk (rows <= 384, 8 channel groups each)
+constexpr int TG_PASS = 6;                       // staging items loaded together
+constexpr int TW_NT = 512;
+
+struct TcgArgs {
+  const float* b1; const float* b2;                                        // B streams (n, K, T, V); b2 NULL unless MODE 2
+  const float* ps1; const float* ph1; const float* ps2; const float* ph2;  // per-k affine (NULL = 1 / 0)
+  int relu;
+  const unsigned short* wsp;                                               // [KT][3][Mp][Kp] bf16, rows = output rows
+  const float* bias;                                                       // per output row, NULL ok (forward)
+  float* out;                                                              // (n, M, T, V)
+  float* partial;                                                          // EPI 0: [tiles][M][2] or NULL
+  const float* ex1; const float* ex2;                                      // EPI 1: the forward's operands at (n, M, T, V)
+  const float* es1; const float* eh1; const float* es2; const float* eh2;
+  int erelu;
+  float* out2; float* ipart;                                               // EPI 1: d x2 or NULL; [tiles][M][3] or NULL
+  int n, K, M, V, KT, R, tps, cc, Mp, Kp;                                  // R output frames per tile, tps tiles per sample
+  int Ts, To, st, up;          // frames of the B source / of the output; forward stride (lane row stride); source upsampling (data gradient of a strided conv)
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tg_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float tg_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ int tg_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// sum over the 32 lanes of a half-wave (lanes l and l^32 keep their own)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// MODE 0: B' = b1;  1: relu?(b1*s1+h1);  2: relu?(b1*s1+h1 + b2*s2+h2).   EPI 0: forward (bias, statistics);  1: data gradient.
+// WM: row tiles (of 32 output rows) per workgroup = 4 or 2; the four waves are WM row tiles x 4/WM groups of the position
+// slots, a wave holds 32 rows x 32*WM slots.
+template <int MODE, int EPI, int WM>
+__global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int PW = 4 / WM, NQW = WM;             // position groups per workgroup, 32-slot tiles per wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int rt = wave % WM, pg = wave / WM;        // row tile, position group (slots 32*NQW*pg ..)
+  const int K = a.K, M = a.M, V = a.V, KT = a.KT, R = a.R, Ls = a.Ts * V, L = a.To * V;   // source / output plane lengths
+  const int pad = (KT - 1) >> 1;
+  const int NR = (a.st * (R - 1) + KT) * V;        // image rows (staged; fragment reads of dead slots are clamped into them)
+  const int NRA = NR;
+  char* Bb = reinterpret_cast<char*>(lds);                               // [3][NRA rows][RB]
+  // workgroup -> (row tile column cz, position tile g): the cc workgroups that stage the same input tile are neighbours
+  const int id = blockIdx.x, xcd = id & 7, slot_ = id >> 3;
+  const int cz = slot_ % a.cc;
+  const int g = (slot_ / a.cc) * 8 + xcd;
+  if (g >= a.n * a.tps) return;
+  const int ns = g / a.tps, ti = g - ns * a.tps;
+  const int f0 = ti * R;                           // first output frame of the tile
+  const int mBase0 = cz * 32 * WM;
+  const float invV = 1.f / (float)V;
+  const __amdgpu_buffer_rsrc_t r1 = tg_rsrc(a.b1 + (size_t)ns * K * Ls, K * Ls * 4);
+  const __amdgpu_buffer_rsrc_t r2 = tg_rsrc((MODE == 2 ? a.b2 : a.b1) + (size_t)ns * K * Ls, MODE == 2 ? K * Ls * 4 : 0);
+  // staging items: (image row j, channel group cg = 4 channels); item = tid + TG_NT*i
+  const int nit = (NR * 8 + TG_NT - 1) / TG_NT;
+  int soff[TG_MAXIT], sdst[TG_MAXIT];
+#pragma unroll
+  for (int i = 0; i < TG_MAXIT; ++i) {
+    const int item = tid + TG_NT * i, cg = item & 7, j = item >> 3;
+    int fr, v;
+    divmod_small(j, V, invV, fr, v);
+    const int fv = a.st * f0 - pad + fr;           // frame on the (upsampled) source grid
+    const int f = a.up == 1 ? fv : fv / a.up;
+    const bool ok = i < nit && j < NR && fv >= 0 && f * a.up == fv && f < a.Ts;
+    soff[i] = ok ? (f * V + v + 4 * cg * Ls) * 4 : TG_OOB;              // + ch0*Ls*4 per chunk
+    sdst[i] = (i < nit && j < NR) ? j * TG_RB + cg * 8 : -1;
+  }
+  // Staging of a chunk: loads, activation, split and LDS stores in passes of TG_PASS items (the raw values are not held
+  // across the products: at two workgroups per CU the register file caps a wave at 256 VGPRs, and the partner
+  // workgroup's products cover this one's load latency).
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  auto stageB = [&](int ch0) {
+    f32x4 pr[4];
+    if (MODE != 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = ch0 + 4 * (tid & 7) + e;
+        f32x4 p = {0.f, 0.f, 0.f, 0.f};
+        if (c < K) {
+          p.x = a.ps1 ? a.ps1[c] : 1.f;
+          p.y = a.ph1 ? a.ph1[c] : 0.f;
+          p.z = a.ps2 ? a.ps2[c] : 1.f;
+          p.w = a.ph2 ? a.ph2[c] : 0.f;
+        }
+        pr[e] = p;
+      }
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < TG_MAXIT; i0 += TG_PASS) {
+      if (i0 < nit) {
+        float bw[TG_PASS][4], bw2[MODE == 2 ? TG_PASS : 1][4];
+#pragma unroll
+        for (int ii = 0; ii < TG_PASS; ++ii) {
+          const int i = i0 + ii;
+          if (i < nit) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int c = ch0 + 4 * (tid & 7) + e;                    // (item & 7 == tid & 7: TG_NT is a multiple of 8)
+              const int vo = (c < K && soff[i] != TG_OOB) ? soff[i] + e * Ls * 4 : TG_OOB;
+              bw[ii][e] = tg_load(r1, vo, ch0 * Ls * 4);
+              if constexpr (MODE == 2) bw2[ii][e] = tg_load(r2, vo, ch0 * Ls * 4);
+            }
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < TG_PASS; ++ii) {
+          const int i = i0 + ii;
+          if (i < nit && sdst[i] >= 0) {
+            float v[4];
+            const bool ok = soff[i] != TG_OOB;      // rows outside the sample's frames: zero AFTER the activation
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = bw[ii][e];
+              if (MODE != 0) {
+                x = fmaf(x, pr[e].x, pr[e].y);
+                if constexpr (MODE == 2) x += fmaf(bw2[ii][e], pr[e].z, pr[e].w);
+                x = fmaxf(x, lo);
+              }
+              v[e] = ok ? x : 0.f;
+            }
+            unsigned p0, p1, p2, q0, q1, q2;
+            b3_split(v[0], v[1], p0, p1, p2);
+            b3_split(v[2], v[3], q0, q1, q2);
+            char* base = Bb + sdst[i];
+            *reinterpret_cast<u32x2v*>(base) = u32x2v{p0, q0};
+            *reinterpret_cast<u32x2v*>(base + NRA * TG_RB) = u32x2v{p1, q1};
+            *reinterpret_cast<u32x2v*>(base + 2 * NRA * TG_RB) = u32x2v{p2, q2};
+          }
+        }
+      }
+    }
+  };
+  // A fragments straight from the pre-split image (L2): lane (l31, half) of row tile rt wants, per term and k-step, the 8
+  // consecutive k [16*ks + 8*half, +8) of row mBase0 + 32*rt + l31 — 16 contiguous bytes.  No LDS copy, no barrier per tap.
+  const unsigned short* arow = a.wsp + ((size_t)(mBase0 + 32 * rt + l31) * a.Kp + 8 * half);
+  const size_t tstride = (size_t)a.Mp * a.Kp;      // elements between the (tap, term) planes
+  u32x4v ac[2][3], an[2][3];
+  auto loadA = [&](int tap, int ch0, u32x4v (&af)[2][3]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        af[ks][t] = *reinterpret_cast<const u32x4v*>(arow + (size_t)(tap * 3 + t) * tstride + ch0 + 16 * ks);
+  };
+  f32x16 acc[NQW];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = mBase0 + 32 * rt + tg_row32(i, half);
+    const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
+#pragma unroll
+    for (int q = 0; q < NQW; ++q) acc[q][i] = b0;
+  }
+  loadA(0, 0, ac);
+  // B fragment rows: slot s = (frame offset s/V, joint s%V) sits at image row st*(s - s%V) + s%V (+ tap*V); dead slots read row 0
+  int bfo[NQW];
+#pragma unroll
+  for (int q = 0; q < NQW; ++q) {
+    const int s_ = 32 * (NQW * pg + q) + l31;
+    int fr, v;
+    divmod_small(s_, V, invV, fr, v);
+    bfo[q] = (s_ < R * V ? a.st * fr * V + v : 0) * TG_RB + 16 * half;
+  }
+  for (int ch0 = 0; ch0 < a.Kp; ch0 += TG_KC) {
+    if (ch0 > 0) {                                 // every wave is done with the previous chunk's image
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    stageB(ch0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int tap = 0; tap < KT; ++tap) {
+      {                                            // next step's weights
+        const int ntap = tap + 1 < KT ? tap + 1 : 0, nch = tap + 1 < KT ? ch0 : ch0 + TG_KC;
+        if (nch < a.Kp) loadA(ntap, nch, an);
+      }
+      const char* Bft = Bb + tap * V * TG_RB;
+#pragma unroll
+      for (int ks = 0; ks < TG_KC / 16; ++ks) {
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, ac[ks][0]), a1 = __builtin_bit_cast(bf16x8, ac[ks][1]),
+                     a2 = __builtin_bit_cast(bf16x8, ac[ks][2]);
+#pragma unroll
+        for (int q = 0; q < NQW; ++q) {
+          bf16x8 bf[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            bf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Bft + bfo[q] + t * NRA * TG_RB + 32 * ks));
+          f32x16 c = acc[q];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bf[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf[0], c, 0, 0, 0);
+          acc[q] = c;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) ac[ks][t] = an[ks][t];
+    }
+  }
+  __syncthreads();                                 // LDS is reused below
+
+  // ---- epilogue: slot = 32*(NQW*pg + q) + l31 is position f0*V + slot of sample ns (valid below R*V and inside the sample)
+  float* Ss = lds;                                 // [4 waves][32 rows][3]
+  int opos[NQW];
+  bool ovalid[NQW];
+#pragma unroll
+  for (int q = 0; q < NQW; ++q) {
+    const int s_ = 32 * (NQW * pg + q) + l31;
+    opos[q] = f0 * V + s_;
+    ovalid[q] = s_ < R * V && opos[q] < L;
+  }
+  const size_t obase = (size_t)ns * M * L;
+  if (EPI == 0) {
+    const bool stats = a.partial != nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row32 = tg_row32(r, half), row = mBase0 + 32 * rt + row32;
+      float s = 0.f, qq = 0.f;
+#pragma unroll
+      for (int q = 0; q < NQW; ++q) {
+        const float v = acc[q][r];
+        if (ovalid[q] && row < M) {
+          a.out[obase + (size_t)row * L + opos[q]] = v;
+          s += v;
+          qq = fmaf(v, v, qq);
+        }
+      }
+      if (stats) {
+        s = half_sum(s);
+        qq = half_sum(qq);
+        if (l31 == 0) { Ss[(wave * 32 + row32) * 3 + 0] = s; Ss[(wave * 32 + row32) * 3 + 1] = qq; }
+      }
+    }
+    if (stats) {
+      __syncthreads();
+      if (tid < 32 * WM) {
+        const int row = mBase0 + tid, w0 = tid >> 5, r32 = tid & 31;
+        if (row < M) {
+          float s = 0.f, qq = 0.f;
+#pragma unroll
+          for (int p = 0; p < PW; ++p) { const float* x = Ss + ((w0 + WM * p) * 32 + r32) * 3; s += x[0]; qq += x[1]; }
+          a.partial[((size_t)g * M + row) * 2 + 0] = s;
+          a.partial[((size_t)g * M + row) * 2 + 1] = qq;
+        }
+      }
+    }
+  } else {
+    const bool has2 = a.ex2 != nullptr, sums = a.ipart != nullptr;
+    const bool need_x = a.erelu || a.es1 != nullptr || has2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row32 = tg_row32(r, half), row = mBase0 + 32 * rt + row32;
+      const bool rok = row < M;
+      const float e1s = (rok && a.es1) ? a.es1[row] : 1.f, e1h = (rok && a.es1) ? a.eh1[row] : 0.f;
+      const float e2s = (rok && a.es2) ? a.es2[row] : 1.f, e2h = (rok && a.es2) ? a.eh2[row] : 0.f;
+      float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < NQW; ++q) {
+        if (ovalid[q] && rok) {
+          const size_t o = obase + (size_t)row * L + opos[q];
+          const float xa = need_x ? a.ex1[o] : 0.f;
+          const float xb = has2 ? a.ex2[o] : 0.f;
+          float pre = fmaf(xa, e1s, e1h);
+          if (has2) pre += fmaf(xb, e2s, e2h);
+          const float dv = (!a.erelu || pre > 0.f) ? acc[q][r] : 0.f;
+          a.out[o] = dv * e1s;
+          if (a.out2) a.out2[o] = dv * e2s;
+          u0 = fmaf(dv, xa, u0);
+          u1 += dv;
+          u2 = fmaf(dv, xb, u2);
+        }
+      }
+      if (sums) {
+        u0 = half_sum(u0); u1 = half_sum(u1); u2 = half_sum(u2);
+        if (l31 == 0) { float* d = Ss + (wave * 32 + row32) * 3; d[0] = u0; d[1] = u1; d[2] = u2; }
+      }
+    }
+    if (sums) {
+      __syncthreads();
+      if (tid < 32 * WM) {
+        const int row = mBase0 + tid, w0 = tid >> 5, r32 = tid & 31;
+        if (row < M) {
+          float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+          for (int p = 0; p < PW; ++p) { const float* x = Ss + ((w0 + WM * p) * 32 + r32) * 3; v0 += x[0]; v1 += x[1]; v2 += x[2]; }
+          float* o = a.ipart + ((size_t)g * M + row) * 3;
+          o[0] = v0; o[1] = v1; o[2] = v2;
+        }
+      }
+    }
+  }
+}
+
+// The three bf16 terms of W (Co, Ci, KT) per tap, rows k-contiguous and zero-padded to whole tiles:
+//   N image (forward):        [KT][3][MpN = ceil128(Co)][KpN = ceil32(Ci)]   value W[co][ci][tap]
+//   T image (data gradient):  [KT][3][MpT = ceil128(Ci)][KpT = ceil32(Co)]   value W[co][ci][KT-1-tap]     (after N)
+// One thread per (image, tap, row, 4 consecutive k).
+__global__ __launch_bounds__(256) void k_tsplit(const float* __restrict__ w, int Ci, int Co, int KT,
+                                                unsigned short* __restrict__ out, int MpN, int KpN, int MpT, int KpT) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long t1 = (long)KT * MpN * (KpN >> 2), t2 = (long)KT * MpT * (KpT >> 2);
+  float v[4];
+  unsigned short* dst;
+  long pstride;
+  if (i < t1) {
+    const int per = MpN * (KpN >> 2);
+    const int tap = (int)(i / per), rem = (int)(i - (long)tap * per);
+    const int r = rem / (KpN >> 2), k = 4 * (rem - r * (KpN >> 2));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (r < Co && k + e < Ci) ? w[((size_t)r * Ci + k + e) * KT + tap] : 0.f;
+    pstride = (long)MpN * KpN;
+    dst = out + (size_t)tap * 3 * pstride + (size_t)r * KpN + k;
+  } else if (i - t1 < t2) {
+    const long j = i - t1;
+    const int per = MpT * (KpT >> 2);
+    const int tap = (int)(j / per), rem = (int)(j - (long)tap * per);
+    const int r = rem / (KpT >> 2), k = 4 * (rem - r * (KpT >> 2));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (r < Ci && k + e < Co) ? w[((size_t)(k + e) * Ci + r) * KT + (KT - 1 - tap)] : 0.f;
+    pstride = (long)MpT * KpT;
+    dst = out + (size_t)KT * 3 * MpN * KpN + (size_t)tap * 3 * pstride + (size_t)r * KpT + k;
+  } else {
+    return;
+  }
+  unsigned p0, p1, p2, q0, q1, q2;
+  b3_split(v[0], v[1], p0, p1, p2);
+  b3_split(v[2], v[3], q0, q1, q2);
+  *reinterpret_cast<u32x2v*>(dst) = u32x2v{p0, q0};
+  *reinterpret_cast<u32x2v*>(dst + pstride) = u32x2v{p1, q1};
+  *reinterpret_cast<u32x2v*>(dst + 2 * pstride) = u32x2v{p2, q2};
+}
+
+struct TsDims { int MpN, KpN, MpT, KpT; size_t bytes; };
+TsDims ts_dims(int Ci, int Co, int KT) {
+  TsDims d;
+  d.MpN = (Co + 127) / 128 * 128; d.KpN = (Ci + 31) / 32 * 32;
+  d.MpT = (Ci + 127) / 128 * 128; d.KpT = (Co + 31) / 32 * 32;
+  d.bytes = (size_t)KT * 3 * ((size_t)d.MpN * d.KpN + (size_t)d.MpT * d.KpT) * 2;
+  return d;
+}
+
+
+// ---- weight gradient ---------------------------------------------------------------------------------------------------
+constexpr int TW_TM = 128, TW_TN = 64;             // co rows, ci columns per workgroup
+__host__ __device__ constexpr int tw_group(int KT) { return KT == 9 ? 3 : KT; }   // taps staged together (register budget: 16*KT accumulators)
+
+struct TcwArgs {
+  const float* x1; const float* x2; const float* s1; const float* h1; const float* s2; const float* h2; int relu;
+  const float* gz; const float* z; const float* A0; const float* B0;
+  float* dwp; float* dbp; int pstride;
+  int n, Ci, Co, T, To, st, V, splits, units, cpl, ccM, ccN;          // T input frames, To output frames, st stride
+};
+
+// dW[co,ci,tap] = sum_{n,p} dz[n,co,p] * x'[n,ci,p + (tap-pad)*V] (zero outside the sample's frames), db[co] = sum dz.
+// Work unit = (sample, 32 consecutive positions); a workgroup walks the units of its K split: dz (128 x 32) staged once
+// per unit, x' (64 x 32) once per tap with the tap's shift in the load address, taps in groups of tw_group(KT) per LDS image.
+// Wave (rt, ct) accumulates the 32 x 32 tile (co 32*rt.., ci 32*ct..) of every tap.  The loads of the next group / unit
+// are issued before the products of the current one.
+template <int KT>
+__global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int TW_G = tw_group(KT);
+  constexpr int NG = (KT + TW_G - 1) / TW_G;       // tap groups
+  constexpr int pad = (KT - 1) >> 1;
+  char* Ab = reinterpret_cast<char*>(lds);                               // [3][128 co][RB]   k = positions
+  char* Bb = Ab + 3 * TW_TM * TG_RB;                                     // [TW_G][3][64 ci][RB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int rt = wave & 3, ct = wave >> 2;
+  const int Ci = a.Ci, Co = a.Co, V = a.V, L = a.To * V, Lx = a.T * V;   // dz / x plane lengths
+  const float invV = 1.f / (float)V;
+  const int id = blockIdx.x;
+  const int cm = id % a.ccM, cn = (id / a.ccM) % a.ccN, sp = id / (a.ccM * a.ccN);
+  const int co0 = cm * TW_TM, ci0 = cn * TW_TN;
+  const int u0 = (int)((long)a.units * sp / a.splits), u1 = (int)((long)a.units * (sp + 1) / a.splits);
+  // A loader: row tid/4 (co), positions 8*(tid&3) ..+7;  B loader: row tid/8 (ci), positions 4*(tid&7) ..+3
+  const int arow = tid >> 2, apc = tid & 3, brow = tid >> 3, bpc = tid & 7;
+  const int aco = co0 + arow, bci = ci0 + brow;
+  const bool dz2 = a.A0 != nullptr, x2on = a.x2 != nullptr, xaff = a.s1 != nullptr;
+  const float A0v = (dz2 && aco < Co) ? a.A0[aco] : 0.f, B0v = (dz2 && aco < Co) ? a.B0[aco] : 0.f;
+  const float s1v = (xaff && bci < Ci) ? a.s1[bci] : 1.f, h1v = (xaff && bci < Ci) ? a.h1[bci] : 0.f;
+  const float s2v = (a.s2 && bci < Ci) ? a.s2[bci] : 1.f, h2v = (a.s2 && bci < Ci) ? a.h2[bci] : 0.f;
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  f32x4 ag[2], az[2];                              // raw dz operands of a unit
+  float bx[TW_G][4], bx2[TW_G][4];                 // raw x' operands of a tap group
+  auto unit_base = [&](int u, int& ns, int& p0) { ns = u / a.cpl; p0 = (u - ns * a.cpl) * 32; };
+  auto issueA = [&](int u) {
+    int ns, p0;
+    unit_base(u, ns, p0);
+    const int p = p0 + 8 * apc;
+    const size_t o = ((size_t)ns * Co + aco) * L + p;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool ok = aco < Co && p + 4 * h < L;          // (L % 4 == 0: a quad is inside or outside the plane)
+      ag[h] = ok ? *reinterpret_cast<const f32x4*>(a.gz + o + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (dz2) az[h] = ok ? *reinterpret_cast<const f32x4*>(a.z + o + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // x' position of dz position q for tap 0: (st*t' - pad)*V + v; a tap adds V.  -1: q outside the plane
+  int xq[4];
+  auto xpos = [&](int p0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = p0 + 4 * bpc + e;
+      int t_, v_;
+      divmod_small(q, V, invV, t_, v_);
+      xq[e] = q < L ? (a.st * t_ - pad) * V + v_ : -(1 << 28);
+    }
+  };
+  auto issueB = [&](int u, int grp) {
+    int ns, p0;
+    unit_base(u, ns, p0);
+    if (grp == 0) xpos(p0);
+    const size_t rowb = ((size_t)ns * Ci + bci) * Lx;
+#pragma unroll
+    for (int tl = 0; tl < TW_G; ++tl) {
+      const int tap = grp * TW_G + tl;
+      if (tap < KT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = xq[e] + tap * V;
+          const bool ok = bci < Ci && q >= 0 && q < Lx;
+          bx[tl][e] = ok ? a.x1[rowb + q] : 0.f;
+          if (x2on) bx2[tl][e] = ok ? a.x2[rowb + q] : 0.f;
+        }
+      }
+    }
+  };
+  float dbacc = 0.f;
+  auto commitA = [&](int u) {
+    int ns, p0;
+    unit_base(u, ns, p0);
+    const int p = p0 + 8 * apc;
+    float v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = aco < Co && p + 4 * h < L;
+        float x = ag[h][e];
+        if (dz2) x += fmaf(B0v, az[h][e], A0v);
+        v[4 * h + e] = ok ? x : 0.f;
+      }
+    float sv = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    sv += __shfl_xor(sv, 1, 64);
+    sv += __shfl_xor(sv, 2, 64);
+    dbacc += sv;
+    unsigned t0[4], t1[4], t2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b3_split(v[2 * j], v[2 * j + 1], t0[j], t1[j], t2[j]);
+    char* base = Ab + arow * TG_RB + apc * 16;
+    *reinterpret_cast<u32x4v*>(base) = u32x4v{t0[0], t0[1], t0[2], t0[3]};
+    *reinterpret_cast<u32x4v*>(base + TW_TM * TG_RB) = u32x4v{t1[0], t1[1], t1[2], t1[3]};
+    *reinterpret_cast<u32x4v*>(base + 2 * TW_TM * TG_RB) = u32x4v{t2[0], t2[1], t2[2], t2[3]};
+  };
+  auto commitB = [&](int u, int grp) {
+    int ns, p0;
+    unit_base(u, ns, p0);
+#pragma unroll
+    for (int tl = 0; tl < TW_G; ++tl) {
+      const int tap = grp * TW_G + tl;
+      if (tap < KT) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = xq[e] + tap * V;      // (xq belongs to this unit: the next unit's is computed after its last commit)
+          const bool ok = bci < Ci && q >= 0 && q < Lx;
+          float x = bx[tl][e];
+          if (xaff || a.relu || x2on) {
+            x = fmaf(x, s1v, h1v);
+            if (x2on) x += fmaf(bx2[tl][e], s2v, h2v);
+            x = fmaxf(x, lo);
+          }
+          v[e] = ok ? x : 0.f;                     // zero padding applies to the activated value
+        }
+        unsigned p0_, p1_, p2_, q0_, q1_, q2_;
+        b3_split(v[0], v[1], p0_, p1_, p2_);
+        b3_split(v[2], v[3], q0_, q1_, q2_);
+        char* base = Bb + (tl * 3 * TW_TN + brow) * TG_RB + bpc * 8;
+        *reinterpret_cast<u32x2v*>(base) = u32x2v{p0_, q0_};
+        *reinterpret_cast<u32x2v*>(base + TW_TN * TG_RB) = u32x2v{p1_, q1_};
+        *reinterpret_cast<u32x2v*>(base + 2 * TW_TN * TG_RB) = u32x2v{p2_, q2_};
+      }
+    }
+  };
+  f32x16 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const char* Af = Ab + (32 * rt + l31) * TG_RB + 16 * half;
+  const char* Bf = Bb + (32 * ct + l31) * TG_RB + 16 * half;
+  auto products = [&](int grp) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        af[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Af + t * TW_TM * TG_RB + 32 * ks));
+#pragma unroll
+      for (int tl = 0; tl < TW_G; ++tl) {
+        const int tap = grp * TW_G + tl;
+        if (tap < KT) {
+          bf16x8 bf[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            bf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Bf + ((tl * 3 + t) * TW_TN) * TG_RB + 32 * ks));
+          f32x16 c = acc[tap];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], c, 0, 0, 0);
+          acc[tap] = c;
+        }
+      }
+    }
+  };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  if (u0 < u1) {
+    issueA(u0);
+    issueB(u0, 0);
+  }
+  for (int u = u0; u < u1; ++u) {
+    commitA(u);
+    commitB(u, 0);
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+      // loads that land while this group's products run: the next group of this unit, or the next unit's first group
+      if (grp + 1 < NG) issueB(u, grp + 1);
+      else if (u + 1 < u1) { issueA(u + 1); issueB(u + 1, 0); }
+      lds_barrier();
+      products(grp);
+      lds_barrier();                               // every wave is done with the images before they are overwritten
+      if (grp + 1 < NG) commitB(u, grp + 1);
+    }
+  }
+  // results: row co = 32*rt + row32(r, half), column ci = 32*ct + l31 of the workgroup's tile
+  float* dw = a.dwp + (size_t)sp * a.pstride;
+  const int ci = ci0 + 32 * ct + l31;
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + 32 * rt + tg_row32(r, half);
+      if (co < Co && ci < Ci) dw[((size_t)co * Ci + ci) * KT + t] = acc[t][r];
+    }
+  if (cn == 0 && apc == 0 && aco < Co) a.dbp[(size_t)sp * a.pstride + aco] = dbacc;
+}
+
+struct TwPlan { int cpl, units, ccM, ccN, splits; size_t lds; };
+bool tw_plan(int n, int Ci, int Co, int To, int V, int KT, TwPlan* p) {
+  const long L = (long)To * V;                     // positions of dz per plane
+  if (L % 4 != 0 || (KT != 3 && KT != 5 && KT != 9)) return false;
+  p->cpl = (int)((L + 31) / 32);
+  p->units = n * p->cpl;
+  p->ccM = (Co + TW_TM - 1) / TW_TM;
+  p->ccN = (Ci + TW_TN - 1) / TW_TN;
+  const int tiles = p->ccM * p->ccN;
+  const long pstride = (long)Co * Ci * KT + Co;
+  int splits = (512 + tiles - 1) / tiles;          // ~2 workgroups' worth of work per CU
+  const long cap = (96L << 20) / (pstride * 4);    // partial buffer <= 96 MB
+  if (splits > cap) splits = (int)cap;
+  if (splits > p->units) splits = p->units;
+  if (splits < 1) splits = 1;
+  p->splits = splits;
+  p->lds = (size_t)3 * TW_TM * TG_RB + (size_t)tw_group(KT) * 3 * TW_TN * TG_RB;
+  return true;
+}
+
+struct TgPlan { int R, tps, cc, tiles, wm; size_t lds; unsigned grid; };
+// K input channels, M output rows, Ts / To frames of the source / output, st = lane row stride (forward stride)
+bool tg_plan(int n, int K, int M, int Ts, int To, int V, int KT, int st, TgPlan* p) {
+  if (V < 1 || V > 32 || KT < 1 || KT > 9 || !(KT & 1) || Ts < 1 || To < 1 || st < 1 || st > 2) return false;
+  const int T = To;
+  int R = 128 / V < T ? 128 / V : T;
+  // (strided: the input tile spans st*(R-1) + KT frames — fewer output frames per tile until its staging fits)
+  while (R > 1 && (((st * (R - 1) + KT) * V * 8 + TG_NT - 1) / TG_NT > TG_MAXIT || (size_t)3 * (st * (R - 1) + KT) * V * TG_RB > 160 * 1024)) --R;
+  const int NR = (st * (R - 1) + KT) * V;
+  if ((NR * 8 + TG_NT - 1) / TG_NT > TG_MAXIT) return false;
+  if ((long)K * Ts * V * 4 >= (1L << 31) - 64 || (long)M * To * V * 4 >= (1L << 31) - 64) return false;
+  const int Kp = (K + 31) / 32 * 32;
+  p->R = R;
+  p->tps = (T + R - 1) / R;
+  p->wm = M > 64 ? 4 : 2;                          // 128 or 64 output rows per workgroup
+  p->cc = (M + 32 * p->wm - 1) / (32 * p->wm);
+  p->tiles = n * p->tps;
+  (void)Kp;
+  p->lds = (size_t)3 * NR * TG_RB;
+  if (p->lds > 160 * 1024) return false;
+  p->grid = (unsigned)((p->tiles + 7) / 8 * 8 * p->cc);
+  return true;
+}
+
+template <int EPI, int WM>
+int tg_launch_wm(const TcgArgs& a, int mode, const TgPlan& p, hipStream_t st) {
+  static bool raised = false;
+  if (!raised) {
+    const void* fs[3] = {reinterpret_cast<const void*>(&k_tcg<0, EPI, WM>), reinterpret_cast<const void*>(&k_tcg<1, EPI, WM>),
+                         reinterpret_cast<const void*>(&k_tcg<2, EPI, WM>)};
+    for (const void* f : fs) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e != hipSuccess) return (int)e;
+    }
+    raised = true;
+  }
+  const dim3 grid(p.grid), blk(TG_NT);
+  if (mode == 0) hipLaunchKernelGGL((k_tcg<0, EPI, WM>), grid, blk, p.lds, st, a);
+  else if (mode == 1) hipLaunchKernelGGL((k_tcg<1, EPI, WM>), grid, blk, p.lds, st, a);
+  else hipLaunchKernelGGL((k_tcg<2, EPI, WM>), grid, blk, p.lds, st, a);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int EPI>
+int tg_launch(const TcgArgs& a, int mode, const TgPlan& p, hipStream_t st) {
+  return p.wm == 4 ? tg_launch_wm<EPI, 4>(a, mode, p, st) : tg_launch_wm<EPI, 2>(a, mode, p, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Bytes of the pre-split weight image of a dense (KT,1) temporal conv; 0 = the GEMM form does not take this shape
+// (then: dsgcn_tapconv_*).
+size_t dsgcn_tconv_ws_bytes(int n, int Ci, int Co, int T, int V, int KT, int stride) {
+  TgPlan pf, pb;
+  if (n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || stride < 1 || stride > 2) return 0;
+  const int To = (T + stride - 1) / stride;
+  TwPlan pw;
+  if (!tg_plan(n, Ci, Co, T, To, V, KT, stride, &pf) || !tg_plan(n, Co, Ci, To, T, V, KT, 1, &pb) ||
+      !tw_plan(n, Ci, Co, To, V, KT, &pw))
+    return 0;
+  return ts_dims(Ci, Co, KT).bytes;
+}
+
+int dsgcn_tconv_wsplit(const float* w, int Ci, int Co, int KT, void* ws, void* stream) {
+  if (!w || !ws || Ci <= 0 || Co <= 0 || KT <= 0) return DSGCN_EINVAL;
+  const TsDims d = ts_dims(Ci, Co, KT);
+  const long total = (long)KT * ((long)d.MpN * (d.KpN >> 2) + (long)d.MpT * (d.KpT >> 2));
+  hipLaunchKernelGGL(k_tsplit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Ci, Co, KT,
+                     static_cast<unsigned short*>(ws), d.MpN, d.KpN, d.MpT, d.KpT);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// rows of the forward's statistics partials (rows, Co, 2) and of the data gradient's input-affine partials (rows, Ci, 3)
+// Partial rows: forward (rows, Co, 2) over the OUTPUT frames, data gradient (rows, Ci, 3) over the INPUT frames.
+// which: 0 = forward, 1 = data gradient.
+int dsgcn_tconv_rows(int which, int n, int Ci, int Co, int T, int V, int KT, int stride) {
+  if (n <= 0 || T <= 0 || stride < 1 || stride > 2) return 0;
+  const int To = (T + stride - 1) / stride;
+  TgPlan p;
+  const bool ok = which == 0 ? tg_plan(n, Ci, Co, T, To, V, KT, stride, &p) : tg_plan(n, Co, Ci, To, T, V, KT, 1, &p);
+  return ok ? p.tiles : 0;
+}
+
+int dsgcn_tconv_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2, const float* h2,
+                    int relu, const void* ws, const float* bias, float* z, float* partial, int n, int Ci, int Co, int T,
+                    int V, int KT, int stride, void* stream) {
+  if (!x1 || !ws || !z || (s1 && !h1) || (s2 && !h2) || (x2 && !s1 && false)) return DSGCN_EINVAL;
+  TgPlan p;
+  if (stride < 1 || stride > 2 || T <= 0) return DSGCN_EUNSUPPORTED;
+  const int To = (T + stride - 1) / stride;
+  if (!tg_plan(n, Ci, Co, T, To, V, KT, stride, &p)) return DSGCN_EUNSUPPORTED;
+  const TsDims d = ts_dims(Ci, Co, KT);
+  TcgArgs a = {};
+  a.Ts = T; a.To = To; a.st = stride; a.up = 1;
+  a.b1 = x1; a.b2 = x2; a.ps1 = s1; a.ph1 = h1; a.ps2 = s2; a.ph2 = h2; a.relu = relu;
+  a.wsp = static_cast<const unsigned short*>(ws); a.bias = bias; a.out = z; a.partial = partial;
+  a.n = n; a.K = Ci; a.M = Co; a.V = V; a.KT = KT; a.R = p.R; a.tps = p.tps; a.cc = p.cc; a.Mp = d.MpN; a.Kp = d.KpN;
+  const int mode = x2 ? 2 : ((s1 || relu) ? 1 : 0);
+  return tg_launch<0>(a, mode, p, (hipStream_t)stream);
+}
+
+// dz = gz + A0 + B0*z (A0 / B0 / z may be NULL together);  x1/x2/s*/h*/relu describe the forward's virtual input (mask /
+// affine epilogue); dx1 (, dx2) fully written; ipart (dsgcn_tconv_rows, Ci, 3) = [sum dv*x1, sum dv, sum dv*x2] or NULL.
+int dsgcn_tconv_dgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                      const float* h2, int relu, const void* ws, const float* z, const float* gz, const float* A0,
+                      const float* B0, float* dx1, float* dx2, float* ipart, int n, int Ci, int Co, int T, int V, int KT,
+                      int stride, void* stream) {
+  if (!x1 || !ws || !gz || !dx1 || (A0 && (!B0 || !z)) || (x2 && !dx2)) return DSGCN_EINVAL;
+  TgPlan p;
+  if (stride < 1 || stride > 2 || T <= 0) return DSGCN_EUNSUPPORTED;
+  const int To = (T + stride - 1) / stride;        // frames of z / gz
+  if (!tg_plan(n, Co, Ci, To, T, V, KT, 1, &p)) return DSGCN_EUNSUPPORTED;
+  const TsDims d = ts_dims(Ci, Co, KT);
+  TcgArgs a = {};
+  a.Ts = To; a.To = T; a.st = 1; a.up = stride;
+  a.b1 = gz; a.b2 = A0 ? z : nullptr;
+  a.ps1 = nullptr; a.ph1 = A0; a.ps2 = B0; a.ph2 = nullptr; a.relu = 0;
+  a.wsp = static_cast<const unsigned short*>(ws) + (size_t)KT * 3 * d.MpN * d.KpN;
+  a.out = dx1; a.out2 = dx2; a.ipart = ipart;
+  a.ex1 = x1; a.ex2 = x2; a.es1 = s1; a.eh1 = h1; a.es2 = s2; a.eh2 = h2; a.erelu = relu;
+  a.n = n; a.K = Co; a.M = Ci; a.V = V; a.KT = KT; a.R = p.R; a.tps = p.tps; a.cc = p.cc; a.Mp = d.MpT; a.Kp = d.KpT;
+  return tg_launch<1>(a, A0 ? 2 : 0, p, (hipStream_t)stream);
+}
+
+// K splits of the weight gradient for this shape (0 = shape not taken); split s writes dwp + s*pstride (Co*Ci*KT floats,
+// the layout of the weight) and dbp + s*pstride (Co floats).
+int dsgcn_tconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int KT, int stride) {
+  TwPlan p;
+  if (n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || stride < 1 || stride > 2) return 0;
+  if (!tw_plan(n, Ci, Co, (T + stride - 1) / stride, V, KT, &p)) return 0;
+  return p.splits;
+}
+
+int dsgcn_tconv_wgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                      const float* h2, int relu, const float* z, const float* gz, const float* A0, const float* B0,
+                      float* dwp, float* dbp, int pstride, int n, int Ci, int Co, int T, int V, int KT, int stride,
+                      void* stream) {
+  if (!x1 || !gz || !dwp || !dbp || (s1 && !h1) || (s2 && !h2) || (A0 && (!B0 || !z))) return DSGCN_EINVAL;
+  TwPlan p;
+  if (stride < 1 || stride > 2 || T <= 0) return DSGCN_EUNSUPPORTED;
+  const int To = (T + stride - 1) / stride;
+  if (!tw_plan(n, Ci, Co, To, V, KT, &p)) return DSGCN_EUNSUPPORTED;
+  if (pstride < Co * Ci * KT) return DSGCN_EINVAL;
+  TcwArgs a = {};
+  a.x1 = x1; a.x2 = x2; a.s1 = s1; a.h1 = h1; a.s2 = s2; a.h2 = h2; a.relu = relu;
+  a.gz = gz; a.z = z; a.A0 = A0; a.B0 = B0; a.dwp = dwp; a.dbp = dbp; a.pstride = pstride;
+  a.n = n; a.Ci = Ci; a.Co = Co; a.T = T; a.To = To; a.st = stride; a.V = V; a.splits = p.splits; a.units = p.units; a.cpl = p.cpl;
+  a.ccM = p.ccM; a.ccN = p.ccN;
+  const dim3 grid((unsigned)(p.splits * p.ccM * p.ccN)), blk(TW_NT);
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    raised = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (KT == 9) hipLaunchKernelGGL((k_tcw<9>), grid, blk, p.lds, st, a);
+  else if (KT == 5) hipLaunchKernelGGL((k_tcw<5>), grid, blk, p.lds, st, a);
+  else hipLaunchKernelGGL((k_tcw<3>), grid, blk, p.lds, st, a);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1130,6 +1130,117 @@ def strided_frames(x, stride):
     return _TapBranches.apply(x, int(stride), 3, C, [2], [0], [0], [C], [C], [1], None, None)
 
 
+class _TConvGemm(torch.autograd.Function):
+    """Dense (KT,1) temporal conv of a virtual input, stride 1, as a GEMM on bf16 terms (csrc/tcg.hip), with the
+    statistics of the BatchNorm behind it: z = W * relu?(x1*s1+h1 (+ x2*s2+h2)) + b -> (z, scale, shift, mean, var)."""
+
+    @staticmethod
+    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, weight, bias, gamma, beta, eps, want_bn, stride):
+        _require_cuda(x1, weight)
+        x1, s1, h1, x2, s2, h2, bias, gamma, beta = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2, bias, gamma, beta)]
+        w = _f32c(weight)
+        n, Ci, T, V = x1.shape
+        Co, _, KT, _ = w.shape
+        To = (T + stride - 1) // stride
+        dev = x1.device
+        lib = native.lib()
+        wsb = lib.dsgcn_tconv_ws_bytes(n, Ci, Co, T, V, KT, stride)
+        assert wsb > 0
+        ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+        native.check(lib.dsgcn_tconv_wsplit(_ptr(w), Ci, Co, KT, _ptr(ws), _stream()), 'dsgcn_tconv_wsplit')
+        rows = lib.dsgcn_tconv_rows(0, n, Ci, Co, T, V, KT, stride)
+        z = torch.empty((n, Co, To, V), device=dev, dtype=torch.float32)
+        partial = torch.empty((rows, Co, 2), device=dev, dtype=torch.float32) if want_bn else None
+        rc = lib.dsgcn_tconv_fwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu), _ptr(ws),
+                                 _ptr(bias), _ptr(z), _ptr(partial), n, Ci, Co, T, V, KT, stride, _stream())
+        native.check(rc, 'dsgcn_tconv_fwd')
+        scale = shift = mean = var = None
+        count = float(n * To * V)
+        if want_bn:
+            stats = torch.empty((4, Co), device=dev, dtype=torch.float32)
+            mean, var, scale, shift = stats[0], stats[1], stats[2], stats[3]
+            rc = lib.dsgcn_bn_finalize(_ptr(partial), rows, Co, count, _ptr(gamma), _ptr(beta), float(eps), _ptr(mean),
+                                       _ptr(var), _ptr(scale), _ptr(shift), Co, _stream())
+            native.check(rc, 'dsgcn_bn_finalize')
+            ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x1, s1, h1, x2, s2, h2, z, gamma, mean, var, ws)
+        ctx.cfg = (int(relu), float(eps), bool(want_bn), count, tuple(w.shape), bias is not None, beta is not None,
+                   int(stride))
+        ctx.defer_ok = _leafish(weight, bias)
+        return z, scale, shift, mean, var
+
+    @staticmethod
+    def backward(ctx, gz, gscale, gshift, _gm, _gv):
+        x1, s1, h1, x2, s2, h2, z, gamma, mean, var, ws = ctx.saved_tensors
+        relu, eps, want_bn, count, wshape, has_bias, has_beta, stride = ctx.cfg
+        n, Ci, T, V = x1.shape
+        Co, _, KT, _ = wshape
+        dev = x1.device
+        lib = native.lib()
+        st = _stream()
+        gz, gscale, gshift = _f32c(gz), _f32c(gscale), _f32c(gshift)
+        A0 = B0 = dgamma = dbeta = None
+        if want_bn and (gscale is not None or gshift is not None):
+            coef = torch.empty((4, Co), device=dev, dtype=torch.float32)
+            dgamma, dbeta, A0, B0 = coef[0], coef[1], coef[2], coef[3]
+            rc = lib.dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, Co, Co,
+                                       _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), st)
+            native.check(rc, 'dsgcn_bn_bwd_coef')
+        if gz is None:
+            gz = torch.zeros_like(z)
+        dx1 = torch.empty_like(x1)
+        dx2 = torch.empty_like(x2) if x2 is not None else None
+        rows = lib.dsgcn_tconv_rows(1, n, Ci, Co, T, V, KT, stride)
+        ipart = (torch.empty((rows, Ci, 3), device=dev, dtype=torch.float32)
+                 if (s1 is not None or s2 is not None) else None)
+        rc = lib.dsgcn_tconv_dgrad(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(ws), _ptr(z),
+                                   _ptr(gz), _ptr(A0), _ptr(B0), _ptr(dx1), _ptr(dx2), _ptr(ipart), n, Ci, Co, T, V, KT,
+                                   stride, st)
+        native.check(rc, 'dsgcn_tconv_dgrad')
+        splits = lib.dsgcn_tconv_wgrad_splits(n, Ci, Co, T, V, KT, stride)
+        pstride = Co * Ci * KT + Co
+        part = torch.empty((splits, pstride), device=dev, dtype=torch.float32)
+        rc = lib.dsgcn_tconv_wgrad(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(z), _ptr(gz),
+                                   _ptr(A0), _ptr(B0), part.data_ptr(), part.data_ptr() + 4 * Co * Ci * KT, pstride, n,
+                                   Ci, Co, T, V, KT, stride, st)
+        native.check(rc, 'dsgcn_tconv_wgrad')
+        red = param_colsum(part, ctx.defer_ok)
+        dw = red[:Co * Ci * KT].view(wshape)
+        db = red[Co * Ci * KT:] if has_bias else None
+        ds1 = dh1 = ds2 = dh2 = None
+        if ipart is not None:
+            isum = colsum(ipart, split_last=True)
+            if s1 is not None:
+                ds1, dh1 = isum[0], isum[1]
+            if s2 is not None:
+                ds2, dh2 = isum[2], isum[1]
+        if dgamma is not None:
+            dgamma = dgamma if gamma is not None else None
+            dbeta = dbeta if has_beta else None
+        return dx1, ds1, dh1, dx2, ds2, dh2, None, dw, db, dgamma, dbeta, None, None, None
+
+
+def tconv_gemm_ok(n, Ci, Co, T, V, KT, stride=1):
+    """Does csrc/tcg.hip take this dense temporal conv shape?"""
+    return bool(native.lib().dsgcn_tconv_ws_bytes(int(n), int(Ci), int(Co), int(T), int(V), int(KT), int(stride)))
+
+
+def tconv_bn(x1, a1, x2, a2, relu, weight, bias, gamma=None, beta=None, eps=1e-5, want_bn=False, stride=1):
+    """Dense (KT,1) temporal conv, stride 1 or 2, dilation 1, of the virtual input relu?(x1*a1 (+ x2*a2)) — no materialised
+    operand, the BatchNorm statistics in the conv's epilogue.  -> (z, scale, shift, mean, var), or None when the GEMM form
+    does not take the shape (the caller then materialises the input and uses `tconv`)."""
+    _require_cuda(x1, weight)
+    n, Ci, T, V = x1.shape
+    Co, _, KT, _ = weight.shape
+    if not native.lib().dsgcn_tconv_ws_bytes(n, Ci, Co, T, V, KT, int(stride)):
+        return None
+    s1, h1 = a1 if a1 is not None else (None, None)
+    s2, h2 = a2 if a2 is not None else (None, None)
+    return _TConvGemm.apply(x1, s1, h1, x2, s2, h2, bool(relu), weight, bias, gamma, beta, float(eps), bool(want_bn),
+                            int(stride))
+
+
 def tconv(h, weight, bias, stride, dilation, gamma=None, beta=None, eps=1e-5, want_bn=False):
     """Dense (k,1) temporal conv of a materialised tensor (unit_tcn, tcn.py:21-27) + the train-mode BN of its output
     as a deferred affine.  -> (z, scale, shift, mean, var)"""

@@ -36,6 +36,13 @@ SIGNATURES = {
     'dsgcn_pwconv_fwd_ws': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 8 + [c_f, c_st],
     'dsgcn_pwconv_wsplit': [c_f, c_int, c_int, c_f, c_st],
     'dsgcn_pwconv_wsplit_bytes': [c_int] * 6,
+    'dsgcn_tconv_ws_bytes': [c_int] * 7,
+    'dsgcn_tconv_wsplit': [c_f, c_int, c_int, c_int, c_f, c_st],
+    'dsgcn_tconv_rows': [c_int] * 8,
+    'dsgcn_tconv_fwd': [c_f] * 6 + [c_int] + [c_f] * 4 + [c_int] * 7 + [c_st],
+    'dsgcn_tconv_dgrad': [c_f] * 6 + [c_int] + [c_f] * 8 + [c_int] * 7 + [c_st],
+    'dsgcn_tconv_wgrad_splits': [c_int] * 7,
+    'dsgcn_tconv_wgrad': [c_f] * 6 + [c_int] + [c_f] * 4 + [ctypes.c_void_p] * 2 + [c_int] * 8 + [c_st],
     'dsgcn_bn_finalize': [c_f, c_int, c_int, ctypes.c_double, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f, c_int,
                           c_st],
     'dsgcn_pwconv_partial_rows': [c_int] * 7,
@@ -92,7 +99,7 @@ SIGNATURES = {
 }
 
 
-SIZE_T_RESULTS = {'dsgcn_pwconv_wsplit_bytes'}      # everything else returns an int status / count
+SIZE_T_RESULTS = {'dsgcn_pwconv_wsplit_bytes', 'dsgcn_tconv_ws_bytes'}      # everything else returns an int status / count
 
 # measurement-only entry points: exported by libdsgcn_lab.so only (include/dsgcn_lab.h)
 LAB_SIGNATURES = {

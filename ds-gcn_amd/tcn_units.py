@@ -33,6 +33,12 @@ class unit_tcn(nn.Module):
     def fusable_pairs(self):
         return [(self.conv, self.bn)]
 
+    def _gemm_ok(self, d):
+        """Does the GEMM form take this shape?  (asked before op_bn records running statistics)"""
+        n, Ci, T, V = d.x1.shape
+        fn = getattr(kernels.ops(), 'tconv_gemm_ok', None)
+        return True if fn is None else fn(n, Ci, self.out_channels, T, V, self.kernel_size, self.stride)
+
     def forward_deferred(self, x):
         """x: tensor or Deferred -> Deferred(z, bn affine) (dropout must be 0 on this path)."""
         ops = kernels.ops()
@@ -51,9 +57,18 @@ class unit_tcn(nn.Module):
                 return Deferred(z, az, None, None, False)
             z = ops.pwconv(d.x1, d.a1, d.x2, d.a2, d.relu, self.conv.weight, self.conv.bias, stride, False)[0]
             return Deferred(z, None, None, None, False)
-        # the dense temporal conv reads a materialised tensor (zero padding applies to the activated values)
-        h = d.x1 if (d.a1 is None and d.x2 is None and not d.relu) else d.materialize()
         w, b = self.conv.weight, self.conv.bias
+        if self.stride in (1, 2) and self.dilation == 1 and hasattr(ops, 'tconv_bn') and self._gemm_ok(d):
+            # GEMM form (csrc/tcg.hip): the virtual input is activated while loading, statistics in the epilogue
+            if not has_bn:
+                return Deferred(ops.tconv_bn(d.x1, d.a1, d.x2, d.a2, d.relu, w, b, stride=self.stride)[0], None, None, None,
+                                False)
+            z, az = op_bn(self.bn, lambda g, be, eps, want: ops.tconv_bn(d.x1, d.a1, d.x2, d.a2, d.relu, w, b, g, be, eps,
+                                                                          want, self.stride),
+                          lambda z: z.shape[0] * z.shape[2] * z.shape[3])
+            return Deferred(z, az, None, None, False)
+        # otherwise the dense temporal conv reads a materialised tensor (zero padding applies to the activated values)
+        h = d.x1 if (d.a1 is None and d.x2 is None and not d.relu) else d.materialize()
         if not has_bn:
             return Deferred(ops.tconv(h, w, b, self.stride, self.dilation)[0], None, None, None, False)
         z, az = op_bn(self.bn, lambda g, be, eps, want: ops.tconv(h, w, b, self.stride, self.dilation, g, be, eps, want),

@@ -83,6 +83,34 @@ int dsgcn_fuse_out_bwd3(const float* x1, const float* s1, const float* h1, const
                         const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
                         void* stream);
 
+/* Dense (KT,1) temporal conv as a GEMM on bf16 terms (csrc/tcg.hip): unit_tcn's Conv2d((9,1), padding 4) + the statistics
+ * of its BatchNorm (tcn.py:21-28), stride 1 or 2 (T = input frames, z has ceil(T/stride)), dilation 1, KT odd <= 9,
+ * V <= 32; the virtual input relu?(x1*s1+h1 (+ x2*s2+h2))
+ * is formed while loading and zero-padded in time AFTER the activation.
+ *   dsgcn_tconv_ws_bytes : bytes of the pre-split weight image for this shape, 0 = shape not taken (use dsgcn_tapconv_*)
+ *   dsgcn_tconv_wsplit   : w (Co, Ci, KT) -> image (per tap the three bf16 terms of W and of the tap-flipped W^T)
+ *   dsgcn_tconv_rows     : partial rows: which = 0 forward (rows, Co, 2) [sum z, sum z^2], 1 data gradient (rows, Ci, 3)
+ *   dsgcn_tconv_fwd      : z (n, Co, T, V) = bias + conv;  dsgcn_tconv_dgrad: dz = gz + A0 + B0*z -> dx1 (, dx2), ipart
+ *                          (mask / affine of the forward's virtual input as in dsgcn_pwconv_dgrad). */
+size_t dsgcn_tconv_ws_bytes(int n, int Ci, int Co, int T, int V, int KT, int stride);
+int dsgcn_tconv_wsplit(const float* w, int Ci, int Co, int KT, void* ws, void* stream);
+int dsgcn_tconv_rows(int which, int n, int Ci, int Co, int T, int V, int KT, int stride);
+int dsgcn_tconv_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2, const float* h2,
+                    int relu, const void* ws, const float* bias, float* z, float* partial, int n, int Ci, int Co, int T,
+                    int V, int KT, int stride, void* stream);
+int dsgcn_tconv_dgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                      const float* h2, int relu, const void* ws, const float* z, const float* gz, const float* A0,
+                      const float* B0, float* dx1, float* dx2, float* ipart, int n, int Ci, int Co, int T, int V, int KT,
+                      int stride, void* stream);
+
+/* weight gradient of the same conv: K (positions) split over dsgcn_tconv_wgrad_splits workgroup groups; split s writes
+ * dwp + s*pstride (Co*Ci*KT floats in the weight's layout) and dbp + s*pstride (Co floats); T*V % 4 == 0. */
+int dsgcn_tconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int KT, int stride);
+int dsgcn_tconv_wgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                      const float* h2, int relu, const float* z, const float* gz, const float* A0, const float* B0,
+                      float* dwp, float* dbp, int pstride, int n, int Ci, int Co, int T, int V, int KT, int stride,
+                      void* stream);
+
 /* K-D: dgmstcn temporal stages (tcn.py:379-428).
  * branch_act: h (n,C,T,V+1) = act_c(z*scale+shift) with the global-joint column zaug appended (ReLU for c < n_act).
  * tapconv   : temporal windows over h (n,Cin,T,V1) -> o (n,Cout,T',V1), T' = ceil(T/stride).  Window i: type 0 =

@@ -190,6 +190,73 @@ def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
         assert err < tol, (k, err)
 
 
+@pytest.mark.parametrize('n,Ci,Co,T,V,KT,mode,stride', [(a_ + (1,)) for a_ in [
+    (2, 64, 64, 16, 25, 9, 'res_affine'),     # ST-GCN unit_tcn after unit_gcn with a conv residual
+    (3, 64, 64, 64, 25, 9, 'res_plain'),      # first stage: 13 tiles per sample, the last one partial
+    (2, 128, 128, 32, 25, 9, 'affine_relu'),
+    (2, 256, 256, 16, 25, 9, 'res_plain'),    # two row tiles per position tile, 8 channel chunks
+    (2, 48, 80, 12, 17, 9, 'plain'),          # ragged widths, coco joints (7 frames per tile)
+    (1, 32, 40, 20, 18, 5, 'affine_relu'),    # 5 taps
+    (2, 16, 24, 8, 25, 3, 'res_affine'),      # 3 taps, fewer frames than a tile holds... (R = 5 < T = 8)
+    (2, 24, 16, 4, 25, 9, 'plain'),           # T < R: one tile per sample, halo larger than the sample
+]] + [
+    (2, 64, 128, 32, 25, 9, 'res_affine', 2),  # ST-GCN's stage transitions: stride 2
+    (2, 128, 256, 16, 25, 9, 'res_plain', 2),
+    (3, 32, 48, 15, 17, 5, 'affine_relu', 2),  # odd frame count (8 output frames: 136 positions)
+    (2, 16, 16, 12, 18, 3, 'plain', 2),
+])
+def test_tconv_gemm(n, Ci, Co, T, V, KT, mode, stride):
+    """csrc/tcg.hip: the dense (KT,1) temporal conv as a GEMM on bf16 terms — forward with BatchNorm statistics, data
+    gradient with the mask / affine epilogue, weight gradient — against the fp64 evaluation of the same op."""
+    g = torch.Generator().manual_seed(Ci * 3 + Co + T + KT)
+    x1 = _rand(g, n, Ci, T, V)
+    a1 = a2 = x2 = None
+    relu = False
+    if mode in ('res_plain', 'res_affine', 'affine_relu'):
+        a1 = (torch.rand(Ci, generator=g) + 0.5, _rand(g, Ci, scale=0.3))
+        relu = True
+    if mode in ('res_plain', 'res_affine'):
+        x2 = _rand(g, n, Ci, T, V)
+    if mode == 'res_affine':
+        a2 = (torch.rand(Ci, generator=g) + 0.5, _rand(g, Ci, scale=0.3))
+    w = _rand(g, Co, Ci, KT, 1, scale=(Ci * KT) ** -0.5)
+    b = _rand(g, Co, scale=0.1)
+    gamma = torch.rand(Co, generator=g) + 0.5
+    beta = _rand(g, Co, scale=0.2)
+    gz = _rand(g, n, Co, (T + stride - 1) // stride, V)
+    gsc, gsh = _rand(g, Co), _rand(g, Co)
+    assert K.tconv_gemm_ok(n, Ci, Co, T, V, KT, stride)
+
+    def run(mod, dt, dev):
+        def mk(t):
+            return None if t is None else t.to(dev, dt).requires_grad_()
+        tx1, tx2, tw, tb, tg, tbeta = mk(x1), mk(x2), mk(w), mk(b), mk(gamma), mk(beta)
+        ta1 = None if a1 is None else (mk(a1[0]), mk(a1[1]))
+        ta2 = None if a2 is None else (mk(a2[0]), mk(a2[1]))
+        z, sc, sh, mean, var = mod.tconv_bn(tx1, ta1, tx2, ta2, relu, tw, tb, tg, tbeta, 1e-5, True, stride)
+        loss = (z * gz.to(dev, dt)).sum() + (sc * gsc.to(dev, dt)).sum() + (sh * gsh.to(dev, dt)).sum()
+        loss.backward()
+        outs = dict(z=z, sc=sc, sh=sh, mean=mean, var=var, dx1=tx1.grad, dw=tw.grad, db=tb.grad, dgamma=tg.grad,
+                    dbeta=tbeta.grad)
+        if tx2 is not None:
+            outs['dx2'] = tx2.grad
+        if ta1 is not None:
+            outs['ds1'], outs['dh1'] = ta1[0].grad, ta1[1].grad
+        if ta2 is not None:
+            outs['ds2'], outs['dh2'] = ta2[0].grad, ta2[1].grad
+        return outs
+
+    got = run(K, torch.float32, DEV)
+    ref = run(R, torch.float64, 'cpu')
+    for k, v in ref.items():
+        err = rel(got[k].detach().cpu(), v.detach())
+        if k == 'db':           # db of a conv feeding BN is ~0 analytically (cancellation): absolute, against dW's scale
+            err = maxabs(got[k].detach().cpu(), v.detach()) / (ref['dw'].abs().max().item() + 1e-30)
+        assert err < (2e-4 if k == 'db' else 2e-5), (k, err)
+    got2 = run(K, torch.float32, DEV)          # ordered partial sums: bit-reproducible
+    assert all(torch.equal(got[k], got2[k]) for k in got)
+
+
 @pytest.mark.parametrize('Ci,Co,T', [(256, 256, 16), (128, 128, 32), (96, 256, 16)])
 def test_pwconv_bf16_terms_are_fp32_class(Ci, Co, T):
     """The wide 1x1 convs carry every fp32 product as six bf16 MFMA terms of the exact three-way bf16 split of both

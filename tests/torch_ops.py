@@ -238,6 +238,11 @@ def temporal_branches_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, con
     return _bn_of(_branches(h, branch_cfg, widths, conv_w, conv_b, stride), gamma, beta, eps, want_bn)
 
 
+def tconv_bn(x1, a1, x2, a2, relu, weight, bias, gamma=None, beta=None, eps=1e-5, want_bn=False, stride=1):
+    """Dense (k,1) temporal conv (dilation 1) of the virtual input (see dsgcn_amd.kernels.tconv_bn)."""
+    return tconv(virt(x1, a1, x2, a2, relu), weight, bias, stride, 1, gamma, beta, eps, want_bn)
+
+
 def tconv(h, weight, bias, stride, dilation, gamma=None, beta=None, eps=1e-5, want_bn=False):
     """Dense temporal conv (k,1) of a materialised tensor (unit_tcn, tcn.py:21-27) + the train-mode BN of its output."""
     k = weight.shape[2]
