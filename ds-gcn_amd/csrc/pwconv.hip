@@ -1163,6 +1163,72 @@ __global__ __launch_bounds__(64) void k_bn_bwd_coef(const float* __restrict__ g_
   B0[c] = (float)(2.0 * dvar / count);
 }
 
+// The same coefficients straight from a consumer's partial rows: g_scale[c] = sum_r part[r][c][i_ds], g_shift[c] = sum_r
+// part[r][c][i_dh] (fp64, rows in order), optionally ADDED to what another consumer of the same BatchNorm already wrote —
+// the coefficients are linear in (g_scale, g_shift).  One launch instead of a column sum + k_bn_bwd_coef per consumer.
+// Block = 32 channels x 32 row slices.
+__global__ __launch_bounds__(1024) void k_bn_coef_rows(const float* __restrict__ part, int R, int C, int k, int ids, int idh,
+                                                       const float* __restrict__ mean, const float* __restrict__ var,
+                                                       const float* __restrict__ gamma, float eps, double count,
+                                                       int c_affine, float* __restrict__ coef, int accumulate) {
+  __shared__ double red[2][32][33];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  // the finishing thread's own operands first: their round trip overlaps the row sums
+  float mu_f = 0.f, var_f = 1.f, g_f = 1.f, old[4] = {0.f, 0.f, 0.f, 0.f};
+  if (sl == 0 && c < C) {
+    mu_f = mean[c]; var_f = var[c];
+    if (gamma && c < c_affine) g_f = gamma[c];
+    if (accumulate) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) old[j] = coef[(size_t)j * C + c];
+    }
+  }
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C) {
+    // four rows of the slice in flight (tall partials: up to ~50 rows per slice, each a dependent L2 round trip otherwise)
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, c0 = 0.0, c1 = 0.0, d0 = 0.0, d1 = 0.0;
+    const size_t rs = (size_t)C * k;
+    const float* p = part + (size_t)c * k;
+    int r = sl;
+    for (; r + 96 < R; r += 128) {
+      const float* q = p + (size_t)r * rs;
+      const float x0 = q[ids], y0 = q[idh], x1 = q[32 * rs + ids], y1 = q[32 * rs + idh];
+      const float x2 = q[64 * rs + ids], y2 = q[64 * rs + idh], x3 = q[96 * rs + ids], y3 = q[96 * rs + idh];
+      a0 += (double)x0; a1 += (double)y0; b0 += (double)x1; b1 += (double)y1;
+      c0 += (double)x2; c1 += (double)y2; d0 += (double)x3; d1 += (double)y3;
+    }
+    for (; r < R; r += 32) {
+      const float* q = p + (size_t)r * rs;
+      a0 += (double)q[ids];
+      a1 += (double)q[idh];
+    }
+    s0 = (a0 + b0) + (c0 + d0);
+    s1 = (a1 + b1) + (c1 + d1);
+  }
+  red[0][sl][cl] = s0;
+  red[1][sl][cl] = s1;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double gs = 0.0, gh = 0.0;
+    for (int i = 0; i < 32; ++i) { gs += red[0][i][cl]; gh += red[1][i][cl]; }
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < c_affine) {
+      const double mu = mu_f, r = 1.0 / sqrt((double)var_f + (double)eps);
+      const double g = g_f;
+      const double t = gs - mu * gh;
+      const double dmean = -gh * g * r;
+      const double dvar = -0.5 * r * r * r * g * t;
+      o[0] = (float)(r * t);
+      o[1] = (float)gh;
+      o[2] = (float)((dmean - 2.0 * dvar * mu) / count);
+      o[3] = (float)(2.0 * dvar / count);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) coef[(size_t)j * C + c] = old[j] + o[j];
+  }
+}
+
 }  // namespace
 
 int g_pw_maxmt = 2;      // measured (round-1 ablation): small per-wave tiles + more resident waves win
@@ -1553,6 +1619,20 @@ int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* m
   if (!mean || !var || !dgamma || !dbeta || !A0 || !B0 || C <= 0) return DSGCN_EINVAL;
   hipLaunchKernelGGL(k_bn_bwd_coef, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, g_scale,
                      g_shift, mean, var, gamma, eps, count, C, c_affine, dgamma, dbeta, A0, B0);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// coef (4, C) = [d gamma | d beta | A0 | B0] from partial rows part (R, C, k): column i_ds holds a consumer's partial
+// sums of d scale, column i_dh of d shift.  accumulate != 0: added to the coefficients already in coef (a second consumer
+// of the same deferred BatchNorm).
+int dsgcn_bn_coef_rows(const float* part, int R, int C, int k, int i_ds, int i_dh, const float* mean, const float* var,
+                       const float* gamma, float eps, double count, int c_affine, float* coef, int accumulate,
+                       void* stream) {
+  if (!part || !mean || !var || !coef || R <= 0 || C <= 0 || k <= 0 || i_ds < 0 || i_ds >= k || i_dh < 0 || i_dh >= k)
+    return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_bn_coef_rows, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, part, R, C, k, i_ds,
+                     i_dh, mean, var, gamma, eps, count, c_affine, coef, accumulate);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -344,6 +344,68 @@ def _f32c(t):
 
 
 # ---------------------------------------------------------------------------------------------
+# Deferred BatchNorm backward: the consumer hands the producer finished coefficients
+# ---------------------------------------------------------------------------------------------
+# A deferred BatchNorm's (scale, shift) is consumed by the next kernel's load prologue; in backward that consumer holds
+# partial rows of d scale / d shift and the producer needs (A0, B0, dgamma, dbeta) from their column sums.  Through
+# autograd alone that is a column-sum launch in the consumer plus a coefficient launch in the producer (55 + 55 per
+# DS-STGCN step, 4-5 us each).  BNCtx travels with the scale tensor (a Python attribute set where the producer returns
+# it): a consumer that finds one writes the coefficients itself with ONE launch (dsgcn_bn_coef_rows; a second consumer of
+# the same BatchNorm adds to them — the coefficients are linear in the sums) and returns no gradient for scale / shift;
+# autograd still runs the producer's backward after all of its consumers'.  Consumers without the hook (torch ops, the
+# units this has not been wired into) return ordinary gradients and the producer adds their share the old way.
+BN_FEED = _os.environ.get('DSGCN_BN_FEED', '1') != '0'
+
+
+class BNCtx:
+    __slots__ = ('mean', 'var', 'gamma', 'eps', 'count', 'C', 'n_affine', 'coef')
+
+    def __init__(self):
+        self.coef = None
+
+
+def _bn_attach(scale, bn, mean, var, gamma, eps, count, n_affine):
+    """producer side (outside its autograd Function): make the returned scale tensor carry the BatchNorm's context"""
+    if bn is None or scale is None or not BN_FEED:
+        return
+    bn.mean, bn.var, bn.gamma, bn.eps, bn.count = mean, var, gamma, float(eps), float(count)
+    bn.C, bn.n_affine = int(scale.numel()), int(n_affine)
+    scale._dsgcn_bn = bn
+
+
+def _bn_of(scale):
+    return getattr(scale, '_dsgcn_bn', None) if (scale is not None and BN_FEED) else None
+
+
+def _bn_feed(bn, part, k, i_ds, i_dh):
+    """consumer side, in backward: partial rows part (R, C, k) -> the producer's coefficients (one launch)."""
+    C = bn.C
+    R = part.numel() // (C * k)
+    acc = bn.coef is not None
+    if not acc:
+        bn.coef = torch.empty((4, C), device=part.device, dtype=torch.float32)
+    rc = native.lib().dsgcn_bn_coef_rows(_ptr(part), R, C, k, i_ds, i_dh, _ptr(bn.mean), _ptr(bn.var), _ptr(bn.gamma),
+                                         bn.eps, bn.count, bn.n_affine, _ptr(bn.coef), int(acc), _stream())
+    native.check(rc, 'dsgcn_bn_coef_rows')
+
+
+def _bn_coef(bn, gscale, gshift, mean, var, gamma, eps, count, C, n_affine):
+    """producer side, in backward: -> (dgamma, dbeta, A0, B0) or four Nones when nothing reached the BatchNorm."""
+    coef = None
+    if bn is not None:
+        coef, bn.coef = bn.coef, None
+    if gscale is not None or gshift is not None:
+        c2 = torch.empty((4, C), device=mean.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, C,
+                                            n_affine, _ptr(c2[0]), _ptr(c2[1]), _ptr(c2[2]), _ptr(c2[3]), _stream())
+        native.check(rc, 'dsgcn_bn_bwd_coef')
+        coef = c2 if coef is None else coef + c2
+    if coef is None:
+        return None, None, None, None
+    return coef[0], coef[1], coef[2], coef[3]
+
+
+# ---------------------------------------------------------------------------------------------
 # K-A  gather-aggregate
 # ---------------------------------------------------------------------------------------------
 
@@ -361,6 +423,7 @@ class _Aggregate(torch.autograd.Function):
         native.check(rc, 'dsgcn_aggregate_fwd')
         ctx.save_for_backward(zp, scale, shift, ahat)
         ctx.relu = int(relu)
+        ctx.bn = _bn_of(scale)
         return y
 
     @staticmethod
@@ -376,7 +439,9 @@ class _Aggregate(torch.autograd.Function):
                                               _ptr(dzp), _ptr(dahat), _ptr(partial), n, KC, T, V, _stream())
         native.check(rc, 'dsgcn_aggregate_bwd')
         dscale = dshift = None
-        if scale is not None:
+        if scale is not None and ctx.bn is not None:
+            _bn_feed(ctx.bn, partial, 2, 0, 1)
+        elif scale is not None:
             red = colsum(partial, split_last=True)
             dscale, dshift = red[0], red[1]
         return dzp, dscale, dshift, None, dahat
@@ -474,8 +539,10 @@ class _PwConv(torch.autograd.Function):
     (scale, shift) = (gamma*rsqrt(var+eps), beta-mean*scale) from the batch statistics of z (+zaug)."""
 
     @staticmethod
-    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, weight, bias, stride, aug, gamma, beta, eps, n_affine, want_bn):
+    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, weight, bias, stride, aug, gamma, beta, eps, n_affine, want_bn,
+                bn=None):
         _require_cuda(x1, weight)
+        ctx.bn, ctx.bn1, ctx.bn2 = bn, _bn_of(s1), _bn_of(s2)
         x1, s1, h1, x2, s2, h2, bias, gamma, beta = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2, bias, gamma, beta)]
         w2 = _f32c(weight.reshape(weight.shape[0], -1))
         n, Ci, T, V = x1.shape
@@ -527,12 +594,8 @@ class _PwConv(torch.autograd.Function):
         st = _stream()
         gz, gzaug, gscale, gshift = _f32c(gz), _f32c(gzaug), _f32c(gscale), _f32c(gshift)
         A0 = B0 = dgamma = dbeta = None
-        if want_bn and (gscale is not None or gshift is not None):
-            coef = torch.empty((4, Co), device=dev, dtype=torch.float32)
-            dgamma, dbeta, A0, B0 = coef[0], coef[1], coef[2], coef[3]
-            rc = lib.dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, Co,
-                                       n_affine, _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), st)
-            native.check(rc, 'dsgcn_bn_bwd_coef')
+        if want_bn:
+            dgamma, dbeta, A0, B0 = _bn_coef(ctx.bn, gscale, gshift, mean, var, gamma, eps, count, Co, n_affine)
         Tout = z.shape[2]
         if gz is None:
             # z itself received no gradient (only its statistics did): the kernels size their partial rows for the
@@ -560,7 +623,7 @@ class _PwConv(torch.autograd.Function):
                                       wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, st)
             native.check(rc, 'dsgcn_pwconv_bwd')
             return _PwConv._finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma,
-                                   has_beta, n_affine, ctx.defer_ok)
+                                   has_beta, n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2)
         ipart = None
         if s1 is not None or s2 is not None:
             rows = lib.dsgcn_pwconv_ipart_rows(n, Ci, Co, T, V, stride)
@@ -579,12 +642,20 @@ class _PwConv(torch.autograd.Function):
                                     wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, stride, aug, st)
         native.check(rc, 'dsgcn_pwconv_wgrad')
         return _PwConv._finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma, has_beta,
-                               n_affine, ctx.defer_ok)
+                               n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2)
 
     @staticmethod
     def _finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma, has_beta, n_affine,
-                defer_ok=False):
+                defer_ok=False, bn1=None, bn2=None):
         """Ordered sums of the partial rows -> the gradient tuple of backward()."""
+        fed = ipart is not None and (s1 is None or bn1 is not None) and (s2 is None or bn2 is not None)
+        if fed:
+            # every affine of the virtual input belongs to a deferred BatchNorm that takes its coefficients directly
+            if s1 is not None:
+                _bn_feed(bn1, ipart, 3, 0, 1)
+            if s2 is not None:
+                _bn_feed(bn2, ipart, 3, 2, 1)
+            ipart = None
         if ipart is not None and (_deferred is None or not defer_ok):
             wsum, red = colsum_pair(wpart, ipart, split_last_b=True)
         elif ipart is not None:
@@ -604,7 +675,7 @@ class _PwConv(torch.autograd.Function):
         if dgamma is not None:
             dgamma = dgamma[:n_affine] if gamma is not None else None
             dbeta = dbeta[:n_affine] if has_beta else None
-        return (dx1, ds1, dh1, dx2, ds2, dh2, None, dw, db, None, None, dgamma, dbeta, None, None, None)
+        return (dx1, ds1, dh1, dx2, ds2, dh2, None, dw, db, None, None, dgamma, dbeta, None, None, None, None)
 
 
 def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, gamma=None, beta=None, eps=1e-5, n_affine=None,
@@ -614,8 +685,14 @@ def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, gamma=None, 
     s2, h2 = a2 if a2 is not None else (None, None)
     if n_affine is None:
         n_affine = weight.shape[0] if gamma is not None else 0
-    return _PwConv.apply(x1, s1, h1, x2, s2, h2, bool(relu), weight, bias, int(stride), bool(aug), gamma, beta,
-                         float(eps), int(n_affine), bool(want_bn))
+    bn = BNCtx() if want_bn else None
+    out = _PwConv.apply(x1, s1, h1, x2, s2, h2, bool(relu), weight, bias, int(stride), bool(aug), gamma, beta,
+                        float(eps), int(n_affine), bool(want_bn), bn)
+    if want_bn:
+        Tout = out[0].shape[2]
+        count = float(x1.shape[0] * Tout * (x1.shape[3] + (1 if aug else 0)))
+        _bn_attach(out[2], bn, out[4], out[5], gamma, eps, count, n_affine)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -644,6 +721,7 @@ class _BranchAct(torch.autograd.Function):
         native.check(rc, 'dsgcn_branch_act_fwd')
         ctx.save_for_backward(z, zaug, scale, shift)
         ctx.n_act = int(n_act)
+        ctx.bn = _bn_of(scale)
         return h
 
     @staticmethod
@@ -657,6 +735,9 @@ class _BranchAct(torch.autograd.Function):
         rc = native.lib().dsgcn_branch_act_bwd(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), ctx.n_act, _ptr(dh),
                                                _ptr(dz), _ptr(dzaug), _ptr(part), n, C, T, V, _stream())
         native.check(rc, 'dsgcn_branch_act_bwd')
+        if ctx.bn is not None:
+            _bn_feed(ctx.bn, part, 2, 0, 1)
+            return dz, dzaug, None, None, None
         red = colsum(part, split_last=True)
         return dz, dzaug, red[0], red[1], None
 
@@ -665,8 +746,9 @@ class _TmsCombine(torch.autograd.Function):
     """f = o[..., :V] + o[..., V] * coeff, with the train-mode BN of f as a deferred affine (like _PwConv)."""
 
     @staticmethod
-    def forward(ctx, o, coeff, gamma, beta, eps, want_bn):
+    def forward(ctx, o, coeff, gamma, beta, eps, want_bn, bn=None):
         _require_cuda(o)
+        ctx.bn = bn
         o, coeff, gamma, beta = [_f32c(t) for t in (o, coeff, gamma, beta)]
         n, C, T, V1 = o.shape
         V = V1 - 1
@@ -701,12 +783,8 @@ class _TmsCombine(torch.autograd.Function):
         lib = native.lib()
         gf, gscale, gshift = _f32c(gf), _f32c(gscale), _f32c(gshift)
         A0 = B0 = dgamma = dbeta = None
-        if want_bn and (gscale is not None or gshift is not None):
-            coef = torch.empty((4, C), device=dev, dtype=torch.float32)
-            dgamma, dbeta, A0, B0 = coef[0], coef[1], coef[2], coef[3]
-            rc = lib.dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, C, C,
-                                       _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), _stream())
-            native.check(rc, 'dsgcn_bn_bwd_coef')
+        if want_bn:
+            dgamma, dbeta, A0, B0 = _bn_coef(ctx.bn, gscale, gshift, mean, var, gamma, eps, count, C, C)
         do = torch.empty_like(o)
         pcoef = torch.empty((n * C, V), device=dev, dtype=torch.float32)
         rc = lib.dsgcn_tms_combine_bwd(_ptr(o), _ptr(coeff), _ptr(gf), _ptr(A0), _ptr(B0), _ptr(do), _ptr(pcoef), n, C,
@@ -716,7 +794,7 @@ class _TmsCombine(torch.autograd.Function):
         if dgamma is not None:
             dgamma = dgamma if gamma is not None else None
             dbeta = dbeta if has_beta else None
-        return do, dcoeff, dgamma, dbeta, None, None
+        return do, dcoeff, dgamma, dbeta, None, None, None
 
 
 def _int_array(vals):
@@ -973,7 +1051,11 @@ def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b
     h = _BranchAct.apply(z, zaug, scale, shift, n_act)
     KT, types, c0s, bcs, dils, ws, bs = _branch_tables(branch_cfg, widths, conv_w, conv_b)
     o = _TapBranches.apply(h, int(stride), KT, C, types, c0s, c0s, bcs, bcs, dils, *ws, *bs)
-    return _TmsCombine.apply(o, coeff, gamma, beta, float(eps), bool(want_bn))
+    bn = BNCtx() if want_bn else None
+    out = _TmsCombine.apply(o, coeff, gamma, beta, float(eps), bool(want_bn), bn)
+    if want_bn:
+        _bn_attach(out[1], bn, out[3], out[4], gamma, eps, float(o.shape[0] * o.shape[2] * (o.shape[3] - 1)), o.shape[1])
+    return out
 
 
 class _PlaneStats(torch.autograd.Function):
@@ -1135,8 +1217,9 @@ class _TConvGemm(torch.autograd.Function):
     statistics of the BatchNorm behind it: z = W * relu?(x1*s1+h1 (+ x2*s2+h2)) + b -> (z, scale, shift, mean, var)."""
 
     @staticmethod
-    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, weight, bias, gamma, beta, eps, want_bn, stride):
+    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, weight, bias, gamma, beta, eps, want_bn, stride, bn=None):
         _require_cuda(x1, weight)
+        ctx.bn, ctx.bn1, ctx.bn2 = bn, _bn_of(s1), _bn_of(s2)
         x1, s1, h1, x2, s2, h2, bias, gamma, beta = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2, bias, gamma, beta)]
         w = _f32c(weight)
         n, Ci, T, V = x1.shape
@@ -1181,12 +1264,8 @@ class _TConvGemm(torch.autograd.Function):
         st = _stream()
         gz, gscale, gshift = _f32c(gz), _f32c(gscale), _f32c(gshift)
         A0 = B0 = dgamma = dbeta = None
-        if want_bn and (gscale is not None or gshift is not None):
-            coef = torch.empty((4, Co), device=dev, dtype=torch.float32)
-            dgamma, dbeta, A0, B0 = coef[0], coef[1], coef[2], coef[3]
-            rc = lib.dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, Co, Co,
-                                       _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), st)
-            native.check(rc, 'dsgcn_bn_bwd_coef')
+        if want_bn:
+            dgamma, dbeta, A0, B0 = _bn_coef(ctx.bn, gscale, gshift, mean, var, gamma, eps, count, Co, Co)
         if gz is None:
             gz = torch.zeros_like(z)
         dx1 = torch.empty_like(x1)
@@ -1209,7 +1288,12 @@ class _TConvGemm(torch.autograd.Function):
         dw = red[:Co * Ci * KT].view(wshape)
         db = red[Co * Ci * KT:] if has_bias else None
         ds1 = dh1 = ds2 = dh2 = None
-        if ipart is not None:
+        if ipart is not None and (s1 is None or ctx.bn1 is not None) and (s2 is None or ctx.bn2 is not None):
+            if s1 is not None:
+                _bn_feed(ctx.bn1, ipart, 3, 0, 1)
+            if s2 is not None:
+                _bn_feed(ctx.bn2, ipart, 3, 2, 1)
+        elif ipart is not None:
             isum = colsum(ipart, split_last=True)
             if s1 is not None:
                 ds1, dh1 = isum[0], isum[1]
@@ -1218,7 +1302,7 @@ class _TConvGemm(torch.autograd.Function):
         if dgamma is not None:
             dgamma = dgamma if gamma is not None else None
             dbeta = dbeta if has_beta else None
-        return dx1, ds1, dh1, dx2, ds2, dh2, None, dw, db, dgamma, dbeta, None, None, None
+        return dx1, ds1, dh1, dx2, ds2, dh2, None, dw, db, dgamma, dbeta, None, None, None, None
 
 
 def tconv_gemm_ok(n, Ci, Co, T, V, KT, stride=1):
@@ -1237,8 +1321,12 @@ def tconv_bn(x1, a1, x2, a2, relu, weight, bias, gamma=None, beta=None, eps=1e-5
         return None
     s1, h1 = a1 if a1 is not None else (None, None)
     s2, h2 = a2 if a2 is not None else (None, None)
-    return _TConvGemm.apply(x1, s1, h1, x2, s2, h2, bool(relu), weight, bias, gamma, beta, float(eps), bool(want_bn),
-                            int(stride))
+    bn = BNCtx() if want_bn else None
+    out = _TConvGemm.apply(x1, s1, h1, x2, s2, h2, bool(relu), weight, bias, gamma, beta, float(eps), bool(want_bn),
+                           int(stride), bn)
+    if want_bn:
+        _bn_attach(out[1], bn, out[3], out[4], gamma, eps, float(n * out[0].shape[2] * V), Co)
+    return out
 
 
 def tconv(h, weight, bias, stride, dilation, gamma=None, beta=None, eps=1e-5, want_bn=False):
@@ -1605,6 +1693,7 @@ class _FuseOut(torch.autograd.Function):
         ctx.save_for_backward(x1, s1, h1, x2, s2, h2)
         ctx.relu = int(relu)
         ctx.xbar_ld = int(xbar_ld)
+        ctx.bn1, ctx.bn2 = _bn_of(s1), _bn_of(s2)
         ctx.set_materialize_grads(False)
         if tee:
             return out, out.view_as(out), out.view_as(out), xbar
@@ -1626,7 +1715,12 @@ class _FuseOut(torch.autograd.Function):
                                               _ptr(dx2), _ptr(part), n, C, T, V, ctx.xbar_ld or V, _stream())
         native.check(rc, 'dsgcn_fuse_out_bwd3')
         ds1 = dh1 = ds2 = dh2 = None
-        if need_part:
+        if need_part and (s1 is None or ctx.bn1 is not None) and (s2 is None or ctx.bn2 is not None):
+            if s1 is not None:
+                _bn_feed(ctx.bn1, part, 4, 0, 3)
+            if s2 is not None:
+                _bn_feed(ctx.bn2, part, 4, 2, 1)
+        elif need_part:
             red = colsum(part, split_last=True)
             if s1 is not None:
                 ds1, dh1 = red[0], red[3]

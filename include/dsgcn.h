@@ -179,6 +179,12 @@ int dsgcn_colsum_multi(const long* table, int njobs, int nblocks, void* stream);
 int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* mean, const float* var,
                       const float* gamma, float eps, double count, int C, int c_affine, float* dgamma, float* dbeta,
                       float* A0, float* B0, void* stream);
+/* The same coefficients from a consumer's partial rows part (R, C, k) (column i_ds: partial sums of d scale, i_dh: of
+ * d shift), coef (4, C) = [dgamma | dbeta | A0 | B0]; accumulate: add to coef (second consumer of the same BatchNorm).
+ * One launch instead of dsgcn_colsum + dsgcn_bn_bwd_coef. */
+int dsgcn_bn_coef_rows(const float* part, int R, int C, int k, int i_ds, int i_dh, const float* mean, const float* var,
+                       const float* gamma, float eps, double count, int c_affine, float* coef, int accumulate,
+                       void* stream);
 /* dz_eff of a conv with the global-joint column, materialised once: gz + A0 + B0*z + (gzaug + A0 + B0*zaug)/V. */
 int dsgcn_dz_eff_aug(const float* gz, const float* z, const float* gzaug, const float* zaug, const float* A0,
                      const float* B0, float* out, int n, int C, int T, int V, void* stream);
