@@ -391,7 +391,7 @@ TsDims ts_dims(int Ci, int Co, int KT) {
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------------
 constexpr int TW_TM = 128, TW_TN = 64;             // co rows, ci columns per workgroup
-__host__ __device__ constexpr int tw_group(int KT) { return KT == 9 ? 3 : KT; }   // taps staged together (register budget: 16*KT accumulators)
+__host__ __device__ constexpr int tw_group(int KT) { return KT > 3 ? 3 : KT; }   // taps staged together (register budget: 16*KT accumulators)
 
 struct TcwArgs {
   const float* x1; const float* x2; const float* s1; const float* h1; const float* s2; const float* h2; int relu;
@@ -405,14 +405,29 @@ struct TcwArgs {
 // per unit, x' (64 x 32) once per tap with the tap's shift in the load address, taps in groups of tw_group(KT) per LDS image.
 // Wave (rt, ct) accumulates the 32 x 32 tile (co 32*rt.., ci 32*ct..) of every tap.  The loads of the next group / unit
 // are issued before the products of the current one.
+#ifdef DSGCN_LAB
+// wall-clock stamps (10 ns) of workgroup 0, thread 0 of the weight gradient: per unit and tap group (issue done, barrier
+// passed, products done, commit done); [63] = count.  dsgcn_tcw_phases reads them
+__device__ long long g_tcw_stamp[64];
+#define TCW_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0 && nst < 62) g_tcw_stamp[nst++] = wall_clock64(); } while (0)
+#else
+#define TCW_STAMP() do {} while (0)
+#endif
+
 template <int KT>
 __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef DSGCN_LAB
+  int nst = 0;
+#endif
   constexpr int TW_G = tw_group(KT);
   constexpr int NG = (KT + TW_G - 1) / TW_G;       // tap groups
   constexpr int pad = (KT - 1) >> 1;
-  char* Ab = reinterpret_cast<char*>(lds);                               // [3][128 co][RB]   k = positions
-  char* Bb = Ab + 3 * TW_TM * TG_RB;                                     // [TW_G][3][64 ci][RB]
+  // both images double-buffered: a step's products read one set while the next step's operands are written into the
+  // other — one barrier per tap group instead of two
+  constexpr int ASZ = 3 * TW_TM * TG_RB, BSZ = TW_G * 3 * TW_TN * TG_RB;
+  char* Ab0 = reinterpret_cast<char*>(lds);                              // [2][3][128 co][RB]   k = positions
+  char* Bb0 = Ab0 + 2 * ASZ;                                             // [2][TW_G][3][64 ci][RB]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -432,18 +447,24 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
   const float s2v = (a.s2 && bci < Ci) ? a.s2[bci] : 1.f, h2v = (a.s2 && bci < Ci) ? a.h2[bci] : 0.f;
   const float lo = a.relu ? 0.f : -__builtin_inff();
   f32x4 ag[2], az[2];                              // raw dz operands of a unit
-  float bx[TW_G][4], bx2[TW_G][4];                 // raw x' operands of a tap group
+  float bx[TW_G][4], bx2[TW_G][4];                 // raw x' operands of a tap group (aligned 16-byte quads + uniform selects
+                                                   // for stride 1 were tried: fewer address-path cycles, but the second
+                                                   // quad's registers spill next to 144 accumulators: no faster)
   auto unit_base = [&](int u, int& ns, int& p0) { ns = u / a.cpl; p0 = (u - ns * a.cpl) * 32; };
   auto issueA = [&](int u) {
     int ns, p0;
     unit_base(u, ns, p0);
     const int p = p0 + 8 * apc;
-    const size_t o = ((size_t)ns * Co + aco) * L + p;
+    // buffer loads over the sample's planes: rows / quads outside get an out-of-range offset (zeros) — a conditional
+    // load is a branch and a wait of its own (measured: 2 us to ISSUE a tap group's loads that way)
+    const __amdgpu_buffer_rsrc_t rg = tg_rsrc(a.gz + (size_t)ns * Co * L, Co * L * 4);
+    const __amdgpu_buffer_rsrc_t rz = tg_rsrc((dz2 ? a.z : a.gz) + (size_t)ns * Co * L, dz2 ? Co * L * 4 : 0);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const bool ok = aco < Co && p + 4 * h < L;          // (L % 4 == 0: a quad is inside or outside the plane)
-      ag[h] = ok ? *reinterpret_cast<const f32x4*>(a.gz + o + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (dz2) az[h] = ok ? *reinterpret_cast<const f32x4*>(a.z + o + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int vo = ok ? (aco * L + p + 4 * h) * 4 : TG_OOB;
+      ag[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo, 0, 0));
+      az[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, vo, 0, 0));
     }
   };
   // x' position of dz position q for tap 0: (st*t' - pad)*V + v; a tap adds V.  -1: q outside the plane
@@ -461,7 +482,8 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
     int ns, p0;
     unit_base(u, ns, p0);
     if (grp == 0) xpos(p0);
-    const size_t rowb = ((size_t)ns * Ci + bci) * Lx;
+    const __amdgpu_buffer_rsrc_t rx1 = tg_rsrc(a.x1 + (size_t)ns * Ci * Lx, Ci * Lx * 4);
+    const __amdgpu_buffer_rsrc_t rx2 = tg_rsrc((x2on ? a.x2 : a.x1) + (size_t)ns * Ci * Lx, x2on ? Ci * Lx * 4 : 0);
 #pragma unroll
     for (int tl = 0; tl < TW_G; ++tl) {
       const int tap = grp * TW_G + tl;
@@ -470,14 +492,16 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
         for (int e = 0; e < 4; ++e) {
           const int q = xq[e] + tap * V;
           const bool ok = bci < Ci && q >= 0 && q < Lx;
-          bx[tl][e] = ok ? a.x1[rowb + q] : 0.f;
-          if (x2on) bx2[tl][e] = ok ? a.x2[rowb + q] : 0.f;
+          const int vo = ok ? (bci * Lx + q) * 4 : TG_OOB;
+          bx[tl][e] = tg_load(rx1, vo, 0);
+          bx2[tl][e] = tg_load(rx2, vo, 0);
         }
       }
     }
   };
   float dbacc = 0.f;
-  auto commitA = [&](int u) {
+  auto commitA = [&](int u, int buf) {
+    char* Ab = Ab0 + buf * ASZ;
     int ns, p0;
     unit_base(u, ns, p0);
     const int p = p0 + 8 * apc;
@@ -503,7 +527,8 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
     *reinterpret_cast<u32x4v*>(base + TW_TM * TG_RB) = u32x4v{t1[0], t1[1], t1[2], t1[3]};
     *reinterpret_cast<u32x4v*>(base + 2 * TW_TM * TG_RB) = u32x4v{t2[0], t2[1], t2[2], t2[3]};
   };
-  auto commitB = [&](int u, int grp) {
+  auto commitB = [&](int u, int grp, int buf) {
+    char* Bb = Bb0 + buf * BSZ;
     int ns, p0;
     unit_base(u, ns, p0);
 #pragma unroll
@@ -538,9 +563,11 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
   for (int t = 0; t < KT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-  const char* Af = Ab + (32 * rt + l31) * TG_RB + 16 * half;
-  const char* Bf = Bb + (32 * ct + l31) * TG_RB + 16 * half;
-  auto products = [&](int grp) {
+  const char* Af0 = Ab0 + (32 * rt + l31) * TG_RB + 16 * half;
+  const char* Bf0 = Bb0 + (32 * ct + l31) * TG_RB + 16 * half;
+  auto products = [&](int grp, int abuf, int bbuf) {
+    const char* Af = Af0 + abuf * ASZ;
+    const char* Bf = Bf0 + bbuf * BSZ;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[3];
@@ -575,20 +602,28 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
     issueA(u0);
     issueB(u0, 0);
   }
+  int gs = 0;                                      // running tap-group step: parity = B buffer
   for (int u = u0; u < u1; ++u) {
-    commitA(u);
-    commitB(u, 0);
+    const int abuf = (u - u0) & 1;
+    commitA(u, abuf);
+    commitB(u, 0, gs & 1);
 #pragma unroll
-    for (int grp = 0; grp < NG; ++grp) {
+    for (int grp = 0; grp < NG; ++grp, ++gs) {
       // loads that land while this group's products run: the next group of this unit, or the next unit's first group
+      TCW_STAMP();
       if (grp + 1 < NG) issueB(u, grp + 1);
       else if (u + 1 < u1) { issueA(u + 1); issueB(u + 1, 0); }
-      lds_barrier();
-      products(grp);
-      lds_barrier();                               // every wave is done with the images before they are overwritten
-      if (grp + 1 < NG) commitB(u, grp + 1);
+      TCW_STAMP();
+      lds_barrier();                               // this step's images complete; the other set is free (its readers passed the previous barrier)
+      TCW_STAMP();
+      products(grp, abuf, gs & 1);
+      TCW_STAMP();
+      if (grp + 1 < NG) commitB(u, grp + 1, (gs + 1) & 1);
     }
   }
+#ifdef DSGCN_LAB
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_tcw_stamp[63] = nst;
+#endif
   // results: row co = 32*rt + row32(r, half), column ci = 32*ct + l31 of the workgroup's tile
   float* dw = a.dwp + (size_t)sp * a.pstride;
   const int ci = ci0 + 32 * ct + l31;
@@ -606,6 +641,7 @@ struct TwPlan { int cpl, units, ccM, ccN, splits; size_t lds; };
 bool tw_plan(int n, int Ci, int Co, int To, int V, int KT, TwPlan* p) {
   const long L = (long)To * V;                     // positions of dz per plane
   if (L % 4 != 0 || (KT != 3 && KT != 5 && KT != 9)) return false;
+  if ((long)Co * L * 4 >= (1L << 31) - 64 || (long)Ci * L * 2 * 4 >= (1L << 31) - 64) return false;   // (buffer resources per sample: 32-bit offsets)
   p->cpl = (int)((L + 31) / 32);
   p->units = n * p->cpl;
   p->ccM = (Co + TW_TM - 1) / TW_TM;
@@ -618,7 +654,7 @@ bool tw_plan(int n, int Ci, int Co, int To, int V, int KT, TwPlan* p) {
   if (splits > p->units) splits = p->units;
   if (splits < 1) splits = 1;
   p->splits = splits;
-  p->lds = (size_t)3 * TW_TM * TG_RB + (size_t)tw_group(KT) * 3 * TW_TN * TG_RB;
+  p->lds = 2 * ((size_t)3 * TW_TM * TG_RB + (size_t)tw_group(KT) * 3 * TW_TN * TG_RB);
   return true;
 }
 
@@ -777,9 +813,9 @@ int dsgcn_tconv_wgrad(const float* x1, const float* s1, const float* h1, const f
   const dim3 grid((unsigned)(p.splits * p.ccM * p.ccN)), blk(TW_NT);
   static bool raised = false;
   if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     raised = true;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -789,5 +825,11 @@ int dsgcn_tconv_wgrad(const float* x1, const float* s1, const float* h1, const f
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef DSGCN_LAB
+int dsgcn_tcw_phases(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tcw_stamp), sizeof(long long) * 64);
+}
+#endif
 
 }  // extern "C"

@@ -39,6 +39,10 @@ int dsgcn_dynadj_phases(long long* out);
  * out[63] = number of stamps. */
 int dsgcn_pwg2_phases(long long* out);
 
+/* temporal-conv weight gradient (k_tcw): stamps of workgroup 0, per tap group (before issue, after issue, after the
+ * barrier, after the products); out[63] = count. */
+int dsgcn_tcw_phases(long long* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as ct
 import torch
 from dsgcn_amd import native
-lib = native.lib(); dev = 'cuda'; st = torch.cuda.current_stream().cuda_stream
+LAB = os.environ.get('TC_LAB') == '1'
+lib = native.lab_lib() if LAB else native.lib(); dev = 'cuda'; st = torch.cuda.current_stream().cuda_stream
 n, V, KT = int(os.environ.get('TC_N', 128)), 25, 9
 SHAPES = [('s1', 64, 64, 64, 1), ('s2t', 64, 128, 64, 2), ('s2', 128, 128, 32, 1), ('s3t', 128, 256, 32, 2), ('s3', 256, 256, 16, 1)]
 P = lambda t: None if t is None else t.data_ptr()
@@ -68,3 +69,15 @@ for name, Ci, Co, T, s in SHAPES:
         r0 = [float('nan')] * 3
     print(f'{name:5s} {Ci:4d} {Co:4d} {T:3d} {s} | ' + '  '.join(f'{t:6.0f} ({fl / t / 1e6:5.0f})' for t in r) + ' | ' +
           '  '.join(f'{t:6.0f}' for t in r0) + f'   splits {splits}', flush=True)
+    if LAB:
+        import numpy as np
+        torch.cuda.synchronize(); g(); torch.cuda.synchronize()
+        ph = np.zeros(64, dtype=np.int64)
+        assert lib.dsgcn_tcw_phases(ph.ctypes.data) == 0
+        k_ = int(ph[63]) // 4 * 4
+        d = np.diff(ph[:k_ + 1])[:k_ - 1] / 100.0 if k_ > 4 else []
+        rows = [(ph[4 * i + 1] - ph[4 * i], ph[4 * i + 2] - ph[4 * i + 1], ph[4 * i + 3] - ph[4 * i + 2],
+                 (ph[4 * i + 4] - ph[4 * i + 3]) if 4 * i + 4 < k_ else 0) for i in range(k_ // 4)]
+        print('    k_tcw tap-group steps (us: issue / barrier wait / products / commit+loop):  ' +
+              '  '.join('/'.join(f'{x / 100.0:.2f}' for x in r) for r in rows[:9]))
+
