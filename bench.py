@@ -197,13 +197,21 @@ def measure_kc_roofline(device, n, reps=20, nsets=4):
         wpf = torch.empty(max(rows_f, 1), pstride, device=device)
         ipf = torch.empty(max(rows_f, 1), Ci, 3, device=device)
 
+        # as the product calls them: the wide convs with their pre-split weight image (prepared once, outside the timing)
+        wsb = lib.dsgcn_pwconv_wsplit_bytes(n, Ci, Co, t, V, 1)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=device)
+        if wsb:
+            assert lib.dsgcn_pwconv_wsplit(P(w), Ci, Co, P(ws), st) == 0
+        wsp = P(ws) if wsb else None
+
         def fwd(q):
-            assert lib.dsgcn_pwconv_fwd(P(q['x']), P(s1), P(h1), None, None, None, 1, P(w), P(b), P(q['z']), None, P(part),
-                                        n, Ci, Co, t, V, 1, 0, 1, st) == 0
+            assert lib.dsgcn_pwconv_fwd_ws(P(q['x']), P(s1), P(h1), None, None, None, 1, P(w), P(b), P(q['z']), None,
+                                           P(part), n, Ci, Co, t, V, 1, 0, 1, wsp, st) == 0
 
         def dgrad(q):
-            assert lib.dsgcn_pwconv_dgrad(P(q['x']), P(s1), P(h1), None, None, None, 1, P(w), P(q['z']), None, P(q['gz']),
-                                          None, P(A0), P(B0), P(q['dx']), None, P(ipart), n, Ci, Co, t, V, 1, 0, st) == 0
+            assert lib.dsgcn_pwconv_dgrad_ws(P(q['x']), P(s1), P(h1), None, None, None, 1, P(w), P(q['z']), None,
+                                             P(q['gz']), None, P(A0), P(B0), P(q['dx']), None, P(ipart), n, Ci, Co, t, V,
+                                             1, 0, wsp, st) == 0
 
         def wgrad(q):
             assert lib.dsgcn_pwconv_wgrad(P(q['x']), P(s1), P(h1), None, None, None, 1, P(q['z']), None, P(q['gz']), None,

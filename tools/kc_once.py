@@ -20,12 +20,17 @@ for (Ci, Co, T) in [(64, 64, 64), (256, 256, 16)]:
     splits = lib.dsgcn_pwconv_wgrad_splits(n, Ci, Co, T, V, 1)
     pstride = Co * Ci + Co
     wpart = torch.empty(splits, pstride, device=dev)
+    wsb = lib.dsgcn_pwconv_wsplit_bytes(n, Ci, Co, T, V, 1)      # the wide convs run with their pre-split weight image
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    if wsb:
+        assert lib.dsgcn_pwconv_wsplit(w.data_ptr(), Ci, Co, ws.data_ptr(), st) == 0
+    wsp = ws.data_ptr() if wsb else None
     for _ in range(reps):
-        assert lib.dsgcn_pwconv_fwd(x1.data_ptr(), s1.data_ptr(), h1.data_ptr(), None, None, None, 1, w.data_ptr(),
-                                    b.data_ptr(), z.data_ptr(), None, part.data_ptr(), n, Ci, Co, T, V, 1, 0, 1, st) == 0
-        assert lib.dsgcn_pwconv_dgrad(x1.data_ptr(), s1.data_ptr(), h1.data_ptr(), None, None, None, 1, w.data_ptr(),
+        assert lib.dsgcn_pwconv_fwd_ws(x1.data_ptr(), s1.data_ptr(), h1.data_ptr(), None, None, None, 1, w.data_ptr(),
+                                    b.data_ptr(), z.data_ptr(), None, part.data_ptr(), n, Ci, Co, T, V, 1, 0, 1, wsp, st) == 0
+        assert lib.dsgcn_pwconv_dgrad_ws(x1.data_ptr(), s1.data_ptr(), h1.data_ptr(), None, None, None, 1, w.data_ptr(),
                                       z.data_ptr(), None, gz.data_ptr(), None, A0.data_ptr(), B0.data_ptr(),
-                                      dx.data_ptr(), None, ipart.data_ptr(), n, Ci, Co, T, V, 1, 0, st) == 0
+                                      dx.data_ptr(), None, ipart.data_ptr(), n, Ci, Co, T, V, 1, 0, wsp, st) == 0
         assert lib.dsgcn_pwconv_wgrad(x1.data_ptr(), s1.data_ptr(), h1.data_ptr(), None, None, None, 1, z.data_ptr(),
                                       None, gz.data_ptr(), None, A0.data_ptr(), B0.data_ptr(), wpart.data_ptr(),
                                       wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, 1, 0, st) == 0
