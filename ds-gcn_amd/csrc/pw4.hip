@@ -356,6 +356,18 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
       if (e < nel) Ws[r * KP + k] = tmp[j];
     }
   }
+  // accumulators start at the bias of their output row (forward), so the epilogue has no per-row loads
+  // (loaded here, with the affine table: after the barrier they were a memory round trip of their own)
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = mBase + 32 * m + p4_row32(i, half);
+      const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[m][q][i] = b0;
+    }
+
   if (MODE != 0) {
     for (int i = tid; i < Kpad; i += P4_NT) {
       f32x4 p = {0.f, 0.f, 0.f, 0.f};
@@ -370,17 +382,6 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // raw barrier: the operand prefetch stays in flight
-
-  // accumulators start at the bias of their output row (forward), so the epilogue has no per-row loads
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = mBase + 32 * m + p4_row32(i, half);
-      const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[m][q][i] = b0;
-    }
 
   const int KS = Kpad >> 1;                        // k-steps (2 channels each), a multiple of PD
   const int KSr = (K + 1) >> 1;                    // k-steps that hold real channels
@@ -747,6 +748,15 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_pwg2(Pw4Args a, const unsigned 
     }
   };
 
+  // bias into the accumulators first: these loads and the affine table's share one round trip, the operand loads follow
+  f32x16 acc[1][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = mBase + p4_row32(i, half);
+    const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[0][q][i] = b0;
+  }
   if (MODE != 0) {                                 // (before the operand loads: its own loads end in a vmcnt(0))
     for (int i = tid; i < Kpad; i += NTH) {
       f32x4 p = {0.f, 0.f, 0.f, 0.f};
@@ -764,14 +774,6 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_pwg2(Pw4Args a, const unsigned 
   issueB(0, bwA, bw2A);
   issueB(PG_KC, bwB, bw2B);
   __builtin_amdgcn_sched_barrier(0);
-  f32x16 acc[1][4];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = mBase + p4_row32(i, half);
-    const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[0][q][i] = b0;
-  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // Ps visible (raw barrier: the operand loads stay in flight)
   PWG_STAMP();
