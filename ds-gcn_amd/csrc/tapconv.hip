@@ -1143,11 +1143,8 @@ int tc_fill(TArgs& a, int nbr, const int* type, const int* ci0, const int* co0, 
 // tap4 eligibility and launch (forward / data gradient); returns 1 = launched, 0 = not eligible, else an error code
 template <bool FWD>
 int t4_try(const TArgs& a, int KT, hipStream_t st) {
-  if (KT != 3 || (a.stride != 1 && a.stride != 2) || a.narrow <= 0 || a.narrow > 64) return 0;
+  if (KT != 3 || (a.stride != 1 && a.stride != 2) || a.narrow < 0 || a.narrow > 64) return 0;
   const long L = (long)a.T * a.V1, Lo = (long)a.Tout * a.V1;
-  if (L % 4 || Lo % 4 || (a.V1 & 1) || (a.stride == 2 && (a.T & 1))) return 0;
-  const int cmax = a.Cin > a.Cout ? a.Cin : a.Cout;
-  if ((long)a.n * cmax * L * 4 >= (1L << 31) - 4096 || (long)a.n * L >= (1L << 31) - 256) return 0;
   int nconv = 0, eplanes = 0, cpmax = 8;
   for (int i = 0; i < a.nbr; ++i) {
     const TBranch& b = a.br[i];
@@ -1158,6 +1155,13 @@ int t4_try(const TArgs& a, int KT, hipStream_t st) {
       eplanes += b.cin;
     }
   }
+  // (a launch of pooling / pass-through windows only — the strided frame copy in front of a block's residual conv — has no
+  // tap shifts to align: any joint count with 16-byte planes; it used to fall to the first-generation kernel, 33-47 us
+  // for a copy of 26 MB)
+  if (L % 4 || Lo % 4 || (nconv && (a.V1 & 1)) || (a.stride == 2 && (a.T & 1))) return 0;
+  if (nconv && a.narrow <= 0) return 0;
+  const int cmax = a.Cin > a.Cout ? a.Cin : a.Cout;
+  if ((long)a.n * cmax * L * 4 >= (1L << 31) - 4096 || (long)a.n * L >= (1L << 31) - 256) return 0;
   const size_t lds = std::max(tc_lds_conv(cpmax, 3), (size_t)4 * 2 * L * sizeof(float));
   if (lds > 64 * 1024) return 0;
   const long Ld = FWD ? Lo : L;                    // destination plane
