@@ -414,8 +414,10 @@ __device__ long long g_tcw_stamp[64];
 #define TCW_STAMP() do {} while (0)
 #endif
 
-template <int KT>
+// ST: 1 = stride 1 with NQI window quads per thread (ST = 13 / 14: 3 / 4 quads), 2 = stride 2
+template <int KT, int STQ>
 __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
+  constexpr int ST = STQ >= 10 ? 1 : STQ;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef DSGCN_LAB
   int nst = 0;
@@ -427,7 +429,14 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
   // other — one barrier per tap group instead of two
   constexpr int ASZ = 3 * TW_TM * TG_RB, BSZ = TW_G * 3 * TW_TN * TG_RB;
   char* Ab0 = reinterpret_cast<char*>(lds);                              // [2][3][128 co][RB]   k = positions
-  char* Bb0 = Ab0 + 2 * ASZ;                                             // [2][TW_G][3][64 ci][RB]
+  char* Bb0 = Ab0 + 2 * ASZ;                                             // [2][TW_G][3][64 ci][RB]  (stride 1: one set)
+  // stride 1: the activated, zero-padded x' window of a tap group as fp32, [64 ci][XP]: every x' value is loaded,
+  // activated and masked ONCE per group with coalesced 16-byte loads, the per-tap operand images are cut out of it —
+  // the first version fetched each tap's shifted copy with 4-byte loads 16 B apart per lane and was bound by the
+  // address path (1-2 us to issue a group's loads, lab stamps)
+  const int NQD = (32 + (TW_G - 1) * a.V + 3 + 3) >> 2;                  // aligned quads per window row
+  const int XP = NQD * 4 + 4;
+  float* XR = reinterpret_cast<float*>(Bb0 + BSZ);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -451,6 +460,89 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
                                                    // for stride 1 were tried: fewer address-path cycles, but the second
                                                    // quad's registers spill next to 144 accumulators: no faster)
   auto unit_base = [&](int u, int& ns, int& p0) { ns = u / a.cpl; p0 = (u - ns * a.cpl) * 32; };
+  // window loader (stride 1): quad i of this thread = (row xrow[i], aligned quad xqd[i]) of the 64 x NQD window
+  constexpr int NQI = STQ >= 10 ? STQ - 10 : 1;
+  int xrow[NQI], xqd[NQI];
+  f32x4 xw[NQI], xw2[NQI];
+  f32x4* XPs = reinterpret_cast<f32x4*>(XR + TW_TN * XP);       // [64] (s1, h1, s2, h2) of the window's channels
+  if constexpr (ST == 1) {
+#pragma unroll
+    for (int i = 0; i < NQI; ++i) {
+      const int q_ = tid + TW_NT * i;
+      const int r_ = q_ / NQD;
+      xrow[i] = (q_ < TW_TN * NQD && ci0 + r_ < Ci) ? r_ : -1;
+      xqd[i] = q_ - r_ * NQD;
+    }
+    if (tid < TW_TN) {
+      const int c_ = ci0 + tid;
+      const bool ok = c_ < Ci;
+      XPs[tid] = f32x4{(ok && xaff) ? a.s1[c_] : 1.f, (ok && xaff) ? a.h1[c_] : 0.f, (ok && a.s2) ? a.s2[c_] : 1.f,
+                       (ok && a.s2) ? a.h2[c_] : 0.f};
+    }
+  }
+  auto win = [&](int u, int grp, int& ns, int& ws, int& wa) {
+    int p0;
+    unit_base(u, ns, p0);
+    ws = p0 + (grp * TW_G - pad) * V;
+    wa = (ws >> 2) << 2;                           // floor to a quad (ws may be negative)
+  };
+  auto issueX = [&](int u, int grp) {
+    int ns, ws, wa;
+    win(u, grp, ns, ws, wa);
+    const __amdgpu_buffer_rsrc_t rx1 = tg_rsrc(a.x1 + (size_t)ns * Ci * Lx, Ci * Lx * 4);
+    const __amdgpu_buffer_rsrc_t rx2 = tg_rsrc((x2on ? a.x2 : a.x1) + (size_t)ns * Ci * Lx, x2on ? Ci * Lx * 4 : 0);
+#pragma unroll
+    for (int i = 0; i < NQI; ++i) {
+      const int xp = wa + 4 * xqd[i];
+      // (quads entirely outside the plane: out of range -> zeros; quads that straddle it are masked per element later)
+      const int vo = (xrow[i] >= 0 && xp > -4 && xp < Lx) ? ((ci0 + xrow[i]) * Lx + xp) * 4 : TG_OOB;
+      xw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx1, vo, 0, 0));
+      xw2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, vo, 0, 0));
+    }
+  };
+  auto stageX = [&](int u, int grp) {
+    int ns, ws, wa;
+    win(u, grp, ns, ws, wa);
+#pragma unroll
+    for (int i = 0; i < NQI; ++i) {
+      if (xrow[i] >= 0) {
+        const int xp = wa + 4 * xqd[i];
+        const float r1[4] = {xw[i].x, xw[i].y, xw[i].z, xw[i].w}, r2[4] = {xw2[i].x, xw2[i].y, xw2[i].z, xw2[i].w};
+        const f32x4 par = XPs[xrow[i]];
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = r1[e];
+          if (xaff || a.relu || x2on) {
+            x = fmaf(x, par.x, par.y);
+            if (x2on) x += fmaf(r2[e], par.z, par.w);
+            x = fmaxf(x, lo);
+          }
+          o[e] = (xp + e >= 0 && xp + e < Lx) ? x : 0.f;     // zero padding applies to the activated value
+        }
+        *reinterpret_cast<f32x4*>(XR + xrow[i] * XP + 4 * xqd[i]) = f32x4{o[0], o[1], o[2], o[3]};
+      }
+    }
+  };
+  auto buildB = [&](int u, int grp) {
+    int ns, ws, wa;
+    win(u, grp, ns, ws, wa);
+    const float* xr = XR + brow * XP + (ws - wa) + 4 * bpc;
+#pragma unroll
+    for (int tl = 0; tl < TW_G; ++tl) {
+      const int tap = grp * TW_G + tl;
+      if (tap < KT) {
+        const float* q_ = xr + tl * V;
+        unsigned p0_, p1_, p2_, q0_, q1_, q2_;
+        b3_split(q_[0], q_[1], p0_, p1_, p2_);
+        b3_split(q_[2], q_[3], q0_, q1_, q2_);
+        char* base = Bb0 + (tl * 3 * TW_TN + brow) * TG_RB + bpc * 8;
+        *reinterpret_cast<u32x2v*>(base) = u32x2v{p0_, q0_};
+        *reinterpret_cast<u32x2v*>(base + TW_TN * TG_RB) = u32x2v{p1_, q1_};
+        *reinterpret_cast<u32x2v*>(base + 2 * TW_TN * TG_RB) = u32x2v{p2_, q2_};
+      }
+    }
+  };
   auto issueA = [&](int u) {
     int ns, p0;
     unit_base(u, ns, p0);
@@ -598,6 +690,31 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
+  if constexpr (ST == 1) {
+    if (u0 < u1) {
+      issueA(u0);
+      issueX(u0, 0);
+    }
+    for (int u = u0; u < u1; ++u) {
+      const int abuf = (u - u0) & 1;
+      commitA(u, abuf);                            // (the other A buffer may still be read by a slower wave)
+#pragma unroll
+      for (int grp = 0; grp < NG; ++grp) {
+        TCW_STAMP();
+        lds_barrier();                             // every wave is done with the previous step's window and images
+        stageX(u, grp);
+        if (grp + 1 < NG) issueX(u, grp + 1);      // lands while this step is built and multiplied
+        else if (u + 1 < u1) { issueA(u + 1); issueX(u + 1, 0); }
+        TCW_STAMP();
+        lds_barrier();                             // window complete
+        buildB(u, grp);
+        TCW_STAMP();
+        lds_barrier();                             // images (and, first group, the dz image) complete
+        products(grp, abuf, 0);
+        TCW_STAMP();
+      }
+    }
+  } else {
   if (u0 < u1) {
     issueA(u0);
     issueB(u0, 0);
@@ -621,6 +738,7 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
       if (grp + 1 < NG) commitB(u, grp + 1, (gs + 1) & 1);
     }
   }
+  }
 #ifdef DSGCN_LAB
   if (blockIdx.x == 0 && threadIdx.x == 0) g_tcw_stamp[63] = nst;
 #endif
@@ -637,8 +755,8 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
   if (cn == 0 && apc == 0 && aco < Co) a.dbp[(size_t)sp * a.pstride + aco] = dbacc;
 }
 
-struct TwPlan { int cpl, units, ccM, ccN, splits; size_t lds; };
-bool tw_plan(int n, int Ci, int Co, int To, int V, int KT, TwPlan* p) {
+struct TwPlan { int cpl, units, ccM, ccN, splits, nqi; size_t lds; };
+bool tw_plan(int n, int Ci, int Co, int To, int V, int KT, TwPlan* p, int st = 1) {
   const long L = (long)To * V;                     // positions of dz per plane
   if (L % 4 != 0 || (KT != 3 && KT != 5 && KT != 9)) return false;
   if ((long)Co * L * 4 >= (1L << 31) - 64 || (long)Ci * L * 2 * 4 >= (1L << 31) - 64) return false;   // (buffer resources per sample: 32-bit offsets)
@@ -654,7 +772,13 @@ bool tw_plan(int n, int Ci, int Co, int To, int V, int KT, TwPlan* p) {
   if (splits > p->units) splits = p->units;
   if (splits < 1) splits = 1;
   p->splits = splits;
-  p->lds = 2 * ((size_t)3 * TW_TM * TG_RB + (size_t)tw_group(KT) * 3 * TW_TN * TG_RB);
+  {
+    const size_t asz = (size_t)3 * TW_TM * TG_RB, bsz = (size_t)tw_group(KT) * 3 * TW_TN * TG_RB;
+    const int nqd = (32 + (tw_group(KT) - 1) * V + 3 + 3) >> 2;
+    if (st == 1 && TW_TN * nqd > 4 * TW_NT) return false;         // (window quads per thread)
+    p->nqi = (TW_TN * nqd + TW_NT - 1) / TW_NT <= 3 ? 3 : 4;
+    p->lds = st == 1 ? 2 * asz + bsz + (size_t)TW_TN * (nqd * 4 + 4) * sizeof(float) + TW_TN * 16 : 2 * (asz + bsz);
+  }
   return true;
 }
 
@@ -719,7 +843,7 @@ size_t dsgcn_tconv_ws_bytes(int n, int Ci, int Co, int T, int V, int KT, int str
   const int To = (T + stride - 1) / stride;
   TwPlan pw;
   if (!tg_plan(n, Ci, Co, T, To, V, KT, stride, &pf) || !tg_plan(n, Co, Ci, To, T, V, KT, 1, &pb) ||
-      !tw_plan(n, Ci, Co, To, V, KT, &pw))
+      !tw_plan(n, Ci, Co, To, V, KT, &pw, stride))
     return 0;
   return ts_dims(Ci, Co, KT).bytes;
 }
@@ -791,7 +915,7 @@ int dsgcn_tconv_dgrad(const float* x1, const float* s1, const float* h1, const f
 int dsgcn_tconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int KT, int stride) {
   TwPlan p;
   if (n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || stride < 1 || stride > 2) return 0;
-  if (!tw_plan(n, Ci, Co, (T + stride - 1) / stride, V, KT, &p)) return 0;
+  if (!tw_plan(n, Ci, Co, (T + stride - 1) / stride, V, KT, &p, stride)) return 0;
   return p.splits;
 }
 
@@ -803,7 +927,7 @@ int dsgcn_tconv_wgrad(const float* x1, const float* s1, const float* h1, const f
   TwPlan p;
   if (stride < 1 || stride > 2 || T <= 0) return DSGCN_EUNSUPPORTED;
   const int To = (T + stride - 1) / stride;
-  if (!tw_plan(n, Ci, Co, To, V, KT, &p)) return DSGCN_EUNSUPPORTED;
+  if (!tw_plan(n, Ci, Co, To, V, KT, &p, stride)) return DSGCN_EUNSUPPORTED;
   if (pstride < Co * Ci * KT) return DSGCN_EINVAL;
   TcwArgs a = {};
   a.x1 = x1; a.x2 = x2; a.s1 = s1; a.h1 = h1; a.s2 = s2; a.h2 = h2; a.relu = relu;
@@ -813,15 +937,28 @@ int dsgcn_tconv_wgrad(const float* x1, const float* s1, const float* h1, const f
   const dim3 grid((unsigned)(p.splits * p.ccM * p.ccN)), blk(TW_NT);
   static bool raised = false;
   if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcw<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* fs[9] = {reinterpret_cast<const void*>(&k_tcw<9, 13>), reinterpret_cast<const void*>(&k_tcw<5, 13>),
+                         reinterpret_cast<const void*>(&k_tcw<3, 13>), reinterpret_cast<const void*>(&k_tcw<9, 14>),
+                         reinterpret_cast<const void*>(&k_tcw<5, 14>), reinterpret_cast<const void*>(&k_tcw<3, 14>),
+                         reinterpret_cast<const void*>(&k_tcw<9, 2>), reinterpret_cast<const void*>(&k_tcw<5, 2>),
+                         reinterpret_cast<const void*>(&k_tcw<3, 2>)};
+    for (const void* f : fs) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     raised = true;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (KT == 9) hipLaunchKernelGGL((k_tcw<9>), grid, blk, p.lds, st, a);
-  else if (KT == 5) hipLaunchKernelGGL((k_tcw<5>), grid, blk, p.lds, st, a);
-  else hipLaunchKernelGGL((k_tcw<3>), grid, blk, p.lds, st, a);
+  if (stride == 1 && p.nqi == 3) {
+    if (KT == 9) hipLaunchKernelGGL((k_tcw<9, 13>), grid, blk, p.lds, st, a);
+    else if (KT == 5) hipLaunchKernelGGL((k_tcw<5, 13>), grid, blk, p.lds, st, a);
+    else hipLaunchKernelGGL((k_tcw<3, 13>), grid, blk, p.lds, st, a);
+  } else if (stride == 1) {
+    if (KT == 9) hipLaunchKernelGGL((k_tcw<9, 14>), grid, blk, p.lds, st, a);
+    else if (KT == 5) hipLaunchKernelGGL((k_tcw<5, 14>), grid, blk, p.lds, st, a);
+    else hipLaunchKernelGGL((k_tcw<3, 14>), grid, blk, p.lds, st, a);
+  } else {
+    if (KT == 9) hipLaunchKernelGGL((k_tcw<9, 2>), grid, blk, p.lds, st, a);
+    else if (KT == 5) hipLaunchKernelGGL((k_tcw<5, 2>), grid, blk, p.lds, st, a);
+    else hipLaunchKernelGGL((k_tcw<3, 2>), grid, blk, p.lds, st, a);
+  }
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
