@@ -541,11 +541,24 @@ __global__ __launch_bounds__(64 * NW) void k_aggsum_bwd_pipe(const float* __rest
           const float a = (w < V && mi < rows) ? v : 0.f;
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt[q], acc, 0, 0, 0);
         }
+        // dP leaves through the wave's own P_k slice (dead after the dAhat product above): 16-byte row-major stores
+        // instead of sixteen 4-byte stores of 25 lanes each (the scalar stores bounded this kernel: 1.6 TB/s)
         if (mi < V) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int tt = as_row(r, mk);
-            if (tt < rows) dpo[tt * V + mi] = acc[r];
+            if (tt < rows) ldsZ[tt * V + mi] = acc[r];
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        {
+          const f32x4* lz = reinterpret_cast<const f32x4*>(ldsZ);
+          f32x4* __restrict__ dp4 = reinterpret_cast<f32x4*>(dpo);
+#pragma unroll
+          for (int q = 0; q < NP4; ++q) {
+            const int i = lane + q * 64;
+            if (i < c4) dp4[i] = lz[i];
           }
         }
       }
