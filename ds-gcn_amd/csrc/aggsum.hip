@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64) void k_aggsum_fwd_pipe(const float* __restrict_
 // K == 3) every wave keeps three running dA_k accumulators over all the units it walks and writes them once at
 // the end: pieces[(wg*NW + wave)][k][V*V] -> dsgcn_colsum.
 template <int V, int NW, bool PER_UNIT>
-__global__ __launch_bounds__(64 * NW) void k_aggsum_bwd_pipe(const float* __restrict__ p, const float* __restrict__ ahat,
+__global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(const float* __restrict__ p, const float* __restrict__ ahat,
                                                              long a_ns, long a_ks, long a_cs,
                                                              const float* __restrict__ gy, const float* __restrict__ y,
                                                              const float* __restrict__ A0, const float* __restrict__ B0,
