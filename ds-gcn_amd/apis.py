@@ -16,8 +16,13 @@ Batches come from the HIP input pipeline when the dataset is a (``SkeletonStore`
 resident in HBM, host decisions, one launch per batch — or from any map-style dataset whose items are
 ``dict(keypoint=(clips, M, T, V, C), label=int)`` (the output of the reference-style ``Compose`` pipelines).
 
-Not reproduced: validation hooks during training (``validate=True`` raises: run ``RecognizerGCN.forward_test`` over the
-val split after training), TensorBoard logging, multi-optimizer configs, gradient clipping (the shipped configs set
+``validate=True`` registers the counterpart of the reference's ``DistEvalHook`` (train.py:134-147 over mmcv's EvalHook):
+every ``evaluation.interval`` epochs the val split goes through ``forward_test`` rank-sharded in dataset order, the parts
+are gathered (``gather_results``), rank 0 computes ``evaluation.metrics`` (top-k / mean-class accuracy) and keeps
+``best_<key>_epoch_<n>.pth`` (``save_best='auto'``: the first metric returned).  ``lr_config`` policies: ``CosineAnnealing``
+by iteration (the DS-GCN configs), ``step`` by epoch (configs/stgcn/stgcn_vanilla_ntu60_xsub_3dkp/j.py:35), ``fixed``.
+
+Not reproduced: TensorBoard logging, multi-optimizer configs, gradient clipping (the shipped configs set
 ``grad_clip=None``, configs/_init_/lr_schedual.py:12).
 """
 import math
@@ -31,8 +36,9 @@ import torch.distributed as dist
 
 from .checkpoint import find_resume, load_checkpoint, resume, save_checkpoint
 from .engine import TrainEngine
-from .recognizers import reduce_log_vars
-from .train import cosine_lr
+from .evaluation import mean_class_accuracy, top_k_accuracy
+from .recognizers import gather_results, reduce_log_vars
+from .train import cosine_lr, step_lr
 
 
 def _rank_world():
@@ -102,15 +108,21 @@ class EpochRunner:
         self.seed = _get(cfg, 'seed', None)
         self.max_epochs = int(_get(cfg, 'total_epochs', 1))
         lr_cfg = dict(_get(cfg, 'lr_config', None) or dict(policy='CosineAnnealing', min_lr=0, by_epoch=False))
-        if lr_cfg.get('policy') not in ('CosineAnnealing', 'fixed', 'Fixed'):
-            raise NotImplementedError(f"lr_config policy {lr_cfg.get('policy')!r}: the skeleton configs use CosineAnnealing")
+        if lr_cfg.get('policy') not in ('CosineAnnealing', 'step', 'Step', 'fixed', 'Fixed'):
+            raise NotImplementedError(f"lr_config policy {lr_cfg.get('policy')!r}: the skeleton configs use "
+                                      'CosineAnnealing or step')
         if lr_cfg.get('by_epoch', True) and lr_cfg['policy'] == 'CosineAnnealing':
             raise NotImplementedError('CosineAnnealing by_epoch=True is not used by the skeleton configs')
+        if lr_cfg['policy'] in ('step', 'Step') and not lr_cfg.get('by_epoch', True):
+            raise NotImplementedError('step policy by_epoch=False is not used by the skeleton configs')
+        if lr_cfg.get('warmup'):
+            raise NotImplementedError('lr warm-up is not used by the skeleton configs')
         self.lr_cfg = lr_cfg
         self.log_interval = int((_get(cfg, 'log_config', None) or {}).get('interval', 20))
-        ck = _get(cfg, 'checkpoint_config', None) or {}
-        self.ckpt_interval = int(ck.get('interval', 1)) if ck is not None else 0
+        ck = _get(cfg, 'checkpoint_config', None)          # None = no CheckpointHook (mmcv register_checkpoint_hook)
+        self.ckpt_interval = 0 if ck is None else int(dict(ck).get('interval', 1))
         self.log = []
+        self.evaluator = None                              # EvalLoop, set by train_model(validate=True)
         per_rank = int(math.ceil(len(source) / self.world))
         self.iters_per_epoch = per_rank // self.batch_size if self.drop_last else int(math.ceil(per_rank / self.batch_size))
         self.max_iters = self.max_epochs * self.iters_per_epoch
@@ -119,6 +131,9 @@ class EpochRunner:
         base = self.engine.opt.base_lr
         if self.lr_cfg['policy'] == 'CosineAnnealing':
             return cosine_lr(base, self.iter, self.max_iters, float(self.lr_cfg.get('min_lr', 0) or 0))
+        if self.lr_cfg['policy'] in ('step', 'Step'):     # mmcv StepLrUpdaterHook(by_epoch=True): set before each epoch
+            return step_lr(base, self.epoch, self.lr_cfg['step'], float(self.lr_cfg.get('gamma', 0.1)),
+                           self.lr_cfg.get('min_lr', None))
         return base
 
     def train_epoch(self):
@@ -129,7 +144,9 @@ class EpochRunner:
             idx = order[b * self.batch_size:(b + 1) * self.batch_size]
             kp, lb = self.source.batch(idx)
             lr = self.current_lr()                                    # before_train_iter
-            pending.append((self.engine.step(kp, lb, lr), len(idx)))  # run_iter + after_train_iter (OptimizerHook)
+            logs = self.engine.step(kp, lb, lr)                       # run_iter + after_train_iter (OptimizerHook)
+            # a replayed hipGraph hands back the SAME static tensors every iteration: keep this iteration's values
+            pending.append(({k: v.clone() for k, v in logs.items()}, len(idx)))
             self.iter += 1
             if (b + 1) % self.log_interval == 0 or b + 1 == self.iters_per_epoch:
                 self._flush_log(pending, lr, b + 1, time.perf_counter() - t0)
@@ -137,6 +154,8 @@ class EpochRunner:
         self.epoch += 1
         if self.work_dir and self.ckpt_interval and self.epoch % self.ckpt_interval == 0 and self.rank == 0:
             self.save_checkpoint()
+        if self.evaluator is not None:                                # after_train_epoch of the EvalHook
+            self.evaluator.after_train_epoch(self)
 
     def _flush_log(self, pending, lr, inner, dt):
         """The interval's log scalars: sample-weighted means over its iterations, averaged over ranks with ONE collective
@@ -171,16 +190,135 @@ class EpochRunner:
         return self
 
 
+class EvalLoop:
+    """The reference's ``DistEvalHook`` (pyskl/core/evaluation.py:11-19 over mmcv ``EvalHook`` / ``DistEvalHook``) for the
+    epoch-based runner: after every ``interval``-th epoch (from ``start`` on) the val split is scored with ``forward_test``
+    — rank r takes samples r, r + world, ... in dataset order (``DistributedSampler(shuffle=False)``), ``videos_per_gpu``
+    of the val dataloader per call — the parts are interleaved back (``gather_results``), and rank 0 evaluates
+    ``metrics`` the way ``BaseDataset.evaluate`` does (datasets/base.py:111-199: ``top_k_accuracy`` -> ``top{k}_acc``,
+    ``mean_class_accuracy``).  ``save_best='auto'`` takes the first key returned; the rule (greater / less) follows the
+    key name as in mmcv (``acc`` / ``top`` greater, ``loss`` less); the best checkpoint is ``best_<key>_epoch_<n>.pth`` and
+    the previous best file is removed.  ``results`` holds one record per evaluation."""
+    greater_keys = ('acc', 'top', 'AR@', 'auc', 'precision', 'mAP@', 'Recall@')
+    less_keys = ('loss',)
+
+    def __init__(self, dataset, batch_size=1, interval=1, start=None, metrics='top_k_accuracy',
+                 metric_options=None, save_best='auto', rule=None, by_epoch=True, device='cuda', **unsupported):
+        if not by_epoch:
+            raise NotImplementedError('evaluation by iteration is not used by the skeleton configs')
+        unsupported.pop('key_indicator', None)
+        unsupported.pop('gpu_collect', None)
+        unsupported.pop('tmpdir', None)
+        if unsupported:
+            raise NotImplementedError(f'evaluation options {sorted(unsupported)} are not supported')
+        self.source = _BatchSource(dataset, device)
+        self.batch_size, self.interval, self.start = int(batch_size), int(interval), start
+        self.metrics = list(metrics) if isinstance(metrics, (list, tuple)) else [metrics]
+        for m in self.metrics:
+            if m not in ('top_k_accuracy', 'mean_class_accuracy', 'confusion_matrix'):
+                raise KeyError(f'metric {m} is not supported')
+        self.metric_options = dict(metric_options or dict(top_k_accuracy=dict(topk=(1, 5))))
+        self.save_best, self.rule = save_best, rule
+        self.key_indicator = None if save_best in ('auto', None, True) else save_best
+        self.best_score = self.best_ckpt = None
+        self.results = []
+
+    def labels(self):
+        if self.source.store is not None:
+            return [int(v) for v in self.source.store.labels]
+        ds = self.source.dataset
+        if hasattr(ds, 'video_infos'):
+            return [int(np.asarray(a['label']).reshape(-1)[0]) for a in ds.video_infos]
+        return [int(np.asarray(ds[i]['label']).reshape(-1)[0]) for i in range(len(ds))]
+
+    @torch.no_grad()
+    def predict(self, model, rank, world):
+        """This rank's share of the val scores, in its sampler order."""
+        n = len(self.source)
+        order = epoch_indices(n, 0, 0, rank, world, shuffle=False)
+        was_training = model.training
+        model.eval()
+        part = []
+        for b in range(0, len(order), self.batch_size):
+            kp, _ = self.source.batch(order[b:b + self.batch_size])
+            part.extend(model(keypoint=kp, return_loss=False))
+        model.train(was_training)
+        return part
+
+    def evaluate(self, scores, labels):
+        out = OrderedDict()
+        for metric in self.metrics:
+            if metric == 'top_k_accuracy':
+                topk = self.metric_options.get('top_k_accuracy', {}).get('topk', (1, 5))
+                topk = (topk,) if isinstance(topk, int) else tuple(topk)
+                for k, acc in zip(topk, top_k_accuracy(scores, labels, topk)):
+                    out[f'top{k}_acc'] = float(acc)
+            elif metric == 'mean_class_accuracy':
+                out['mean_class_accuracy'] = float(mean_class_accuracy(scores, labels)[0])
+            elif metric == 'confusion_matrix':
+                out['confusion_matrix'] = mean_class_accuracy(scores, labels)[1]
+        return out
+
+    def _better(self, key, value):
+        if self.best_score is None:
+            return True
+        rule = self.rule
+        if rule is None:
+            low = key.lower()
+            if any(k.lower() in low for k in self.greater_keys):
+                rule = 'greater'
+            elif any(k.lower() in low for k in self.less_keys):
+                rule = 'less'
+            else:
+                raise ValueError(f'Cannot infer the rule for key {key}, thus a specific rule must be specified.')
+        return value > self.best_score if rule == 'greater' else value < self.best_score
+
+    def should_run(self, epoch):
+        """``epoch`` = completed epochs (mmcv ``_should_evaluate``: every ``interval`` epochs, from ``start`` on)."""
+        if self.start is None:
+            return epoch % self.interval == 0
+        return epoch >= self.start and (epoch - self.start) % self.interval == 0
+
+    def after_train_epoch(self, runner):
+        if not self.should_run(runner.epoch):
+            return None
+        part = self.predict(runner.model, runner.rank, runner.world)
+        scores = gather_results(part, len(self.source))
+        rec = None
+        if runner.rank == 0:
+            vals = self.evaluate(np.stack(scores), self.labels())
+            rec = dict(epoch=runner.epoch, **vals)
+            self.results.append(rec)
+            if runner.logger is not None:
+                runner.logger.info('Epoch(val) [%d]\t%s', runner.epoch,
+                                   ', '.join(f'{k}: {v:.4f}' for k, v in vals.items() if np.ndim(v) == 0))
+            if self.save_best and vals and runner.work_dir:
+                key = self.key_indicator or next(iter(vals))
+                self.key_indicator = key
+                if self._better(key, vals[key]):
+                    self.best_score = vals[key]
+                    if self.best_ckpt and os.path.isfile(self.best_ckpt):
+                        os.remove(self.best_ckpt)
+                    os.makedirs(runner.work_dir, exist_ok=True)
+                    self.best_ckpt = os.path.join(runner.work_dir, f'best_{key}_epoch_{runner.epoch}.pth')
+                    meta = dict(runner.meta, epoch=runner.epoch, iter=runner.iter,
+                                hook_msgs=dict(best_score=self.best_score, best_ckpt=self.best_ckpt))
+                    save_checkpoint(runner.model, self.best_ckpt, optimizer=runner.engine.opt, meta=meta)
+        if runner.world > 1:
+            dist.barrier()
+        return rec
+
+
 def train_model(model, dataset, cfg, distributed=None, validate=False, test=None, timestamp=None, meta=None,
-                device='cuda', logger=None, use_graph=True):
+                device='cuda', logger=None, use_graph=True, val_dataset=None):
     """Train ``model`` on ``dataset`` the way the reference's ``train_model`` does for the skeleton configs; returns the
     ``EpochRunner`` (its ``.log`` holds the interval records, ``.engine`` the optimizer state).
 
     cfg (``Config`` or dict) keys read: ``data.videos_per_gpu`` / ``data.train_dataloader``, ``optimizer`` (SGD), ``lr_config``,
     ``total_epochs``, ``checkpoint_config``, ``log_config.interval``, ``work_dir``, ``seed``, ``resume_from`` / ``load_from`` /
-    ``auto_resume``."""
-    if validate:
-        raise NotImplementedError('evaluation hooks during training are outside this path: run forward_test after training')
+    ``auto_resume``; with ``validate=True`` also ``evaluation`` and ``data.val`` / ``data.val_dataloader`` (``val_dataset``
+    overrides ``data.val``: a map-style dataset or a (``SkeletonStore``, ``SkeletonBatcher``) pair built for the val
+    pipeline).  ``runner.evaluator.results`` holds the evaluation records."""
     if isinstance(dataset, list) and len(dataset) == 1:
         dataset = dataset[0]
     opt_cfg = dict(_get(cfg, 'optimizer', None) or dict(type='SGD', lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True))
@@ -197,6 +335,18 @@ def train_model(model, dataset, cfg, distributed=None, validate=False, test=None
     source = _BatchSource(dataset, next(model.parameters()).device)
     work_dir = _get(cfg, 'work_dir', None)
     runner = EpochRunner(model, engine, source, cfg, work_dir=work_dir, meta=meta, logger=logger)
+    if validate:
+        data = _get(cfg, 'data', {}) or {}
+        if val_dataset is None:
+            from .pipeline import build_dataset
+            val_cfg = dict(data['val'])
+            val_cfg.setdefault('test_mode', True)
+            val_dataset = build_dataset(val_cfg)
+        vloader = dict(videos_per_gpu=data.get('videos_per_gpu', 1))
+        vloader.update(data.get('val_dataloader', {}) or {})
+        eval_cfg = dict(_get(cfg, 'evaluation', None) or {})
+        runner.evaluator = EvalLoop(val_dataset, batch_size=vloader['videos_per_gpu'],
+                                    device=next(model.parameters()).device, **eval_cfg)
     ckpt = find_resume(work_dir, _get(cfg, 'resume_from', None), bool(_get(cfg, 'auto_resume', False))) if work_dir else \
         _get(cfg, 'resume_from', None)
     if ckpt:

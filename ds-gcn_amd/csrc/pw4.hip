@@ -17,6 +17,7 @@
 // weight block of the workgroup's 32*MT output channels sits in LDS).  Sample base folded into the buffer resource:
 // offsets stay 32-bit for any batch size and channels past K read as zero through the bounds check.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -639,7 +640,9 @@ __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
 // wall-clock stamps (10 ns) of workgroup 0, thread 0: [0] start, [1] operands issued, then per chunk (commit done,
 // barrier passed, products done), the last two: main loop drained, epilogue done; [63] = count.  dsgcn_pwg2_phases reads them
 __device__ long long g_pwg_stamp[64];
-#define PWG_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0 && nst < 62) g_pwg_stamp[nst++] = wall_clock64(); } while (0)
+__device__ int g_pwg_stamp_block = 0;            // which workgroup stamps (dsgcn_pwg2_phases_block)
+#define PWG_STAMP_BLOCK g_pwg_stamp_block
+#define PWG_STAMP() do { if (blockIdx.x == PWG_STAMP_BLOCK && threadIdx.x == 0 && nst < 62) g_pwg_stamp[nst++] = wall_clock64(); } while (0)
 #else
 #define PWG_STAMP() do {} while (0)
 #endif
@@ -827,7 +830,242 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_pwg2(Pw4Args a, const unsigned 
   p4_epilogue<1, 4, EPI, true, NWV>(a, acc, lds, tile);
   PWG_STAMP();
 #ifdef DSGCN_LAB
-  if (blockIdx.x == 0 && threadIdx.x == 0) g_pwg_stamp[63] = nst;
+  if (blockIdx.x == PWG_STAMP_BLOCK && threadIdx.x == 0) g_pwg_stamp[63] = nst;
+#endif
+}
+
+// ---- K-C, GEMM form, third generation ("pwg3"): two independent workgroups per CU, one barrier per chunk ------------
+// What the lab stamps of k_pwg2 showed (profiles/r03/README.md): a workgroup's life is prologue -> 8 x (commit + barrier +
+// products + barrier) -> epilogue with all eight waves of the CU in lockstep; the matrix pipe idles through every commit
+// and through the HBM-bound epilogue (15 us of 45 in the data gradient), and 400 position tiles on 256 one-workgroup CUs
+// make two rounds.  Here:
+//   * a workgroup is FOUR waves that own 32*MT rows each (MT = 2: 256 rows) of the same 128-position tile: 8 accumulator
+//     tiles per wave, two workgroups resident per CU (2 x 66 KB of LDS, <= 256 registers), so one workgroup's prologue /
+//     epilogue / barrier waits run under the other's products — the tiles of a launch fit in one round;
+//   * the weight terms never touch LDS: the image is written once per conv in FRAGMENT order (k_wsplit, frag = 1:
+//     [term][row tile][k-step][lane][8 bf16], a wave's A fragment is one contiguous 1 KB) and every wave loads its own
+//     rows' fragments straight into registers one k-step ahead (k_pwg2 tried this on the row-major image — 64 row
+//     segments of 32 B per load — and lost);
+//   * the activation chunk (32 channels x 128 positions, three bf16 terms) is double-buffered in LDS: chunk i+1 is split
+//     and written while chunk i is multiplied (the split's VALU work sits in the MFMA shadow), ONE barrier per chunk.
+// vmcnt is in order, so a wave's wait for its next A fragments also completes the older activation loads: the
+// activation prefetch distance is one chunk by construction (a second register set would buy nothing).
+constexpr int G3_BBUF = 3 * PG_T * PG_RB;          // one activation buffer: [3 terms][128 position slots][RB]
+
+template <int MODE, int EPI, int MT>
+__global__ __launch_bounds__(256, 2) void k_pwg3(Pw4Args a, const unsigned short* __restrict__ wfr, int RT) {
+  typedef VQ<4>::T vq;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef DSGCN_LAB
+  int nst = 0;
+#endif
+  PWG_STAMP();
+  char* Bb = reinterpret_cast<char*>(lds);                               // [2][3][128 position slots][RB]
+  f32x4* Ps = reinterpret_cast<f32x4*>(Bb + 2 * G3_BBUF);                // [Kpad] (s1, h1, s2, h2)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ngrp = a.WT;
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int cz = slot % a.cc;
+  const int grp = (slot / a.cc) * 8 + xcd;
+  if (grp >= ngrp) return;
+  const int mBase0 = cz * (128 * MT), mBase = mBase0 + 32 * MT * wave;
+  const int K = a.K, M = a.M, L = a.L, Kpad = a.Kpad;
+  const int Lq = a.Lq;                             // (ragged planes: see k_pw4)
+  const int g0 = grp * 128;
+  const int n = g0 / Lq;
+  int pos = g0 - n * Lq + l31 * 4;
+  int ds = 0;
+  while (pos >= Lq) { pos -= Lq; ++ds; }
+  const bool pok = n + ds < a.n;
+  int skip = 0;
+  if (L - pos < 4) { skip = 4 - (L - pos); pos = L - 4; }
+  const int L4 = L * 4;
+  const int nrem = a.n - n < a.span ? a.n - n : a.span;
+  const __amdgpu_buffer_rsrc_t r1 = p4_rsrc(a.b1 + (size_t)n * K * L, nrem * K * L4);
+  const __amdgpu_buffer_rsrc_t r2 = p4_rsrc((MODE == 2 ? a.b2 : a.b1) + (size_t)n * K * L, MODE == 2 ? nrem * K * L4 : 0);
+  // B loader: channels 4*cg .. 4*cg+3 of the chunk (cg = tid / 32) at the lane's own position quad
+  const int cg = tid >> 5;
+  const int voffB = pok ? ds * K * L4 + pos * 4 : P4_OOB;
+  vq bw[4], bw2[MODE == 2 ? 4 : 1];
+  auto issueB = [&](int ch0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = ch0 + 4 * cg + e;
+      const int vo = c < K ? voffB + c * L4 : P4_OOB;
+      bw[e] = p4_load<4>(r1, vo, 0);
+      if constexpr (MODE == 2) bw2[e] = p4_load<4>(r2, vo, 0);
+    }
+  };
+  // A fragments: (term t, row tile m of this wave, k-step ks) = 1 KB at ((t*RT + rt)*KS + ks) KB of the image
+  const int KS = Kpad >> 4;
+  const __amdgpu_buffer_rsrc_t rw = p4_rsrc(wfr, 3 * RT * KS * 1024);
+  int offA[MT][3];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) offA[m][t] = ((t * RT + (mBase >> 5) + m) * KS) * 1024 + lane * 16;
+  u32x4v af0[MT][3], af1[MT][3];                   // k-steps of even / odd index
+  auto issueA = [&](int ks, u32x4v (&af)[MT][3]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        af[m][t] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, offA[m][t], ks * 1024, 0));
+  };
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  // position sub-tile q of the chunk in registers -> its three term rows of buffer `dst`
+  auto commit_q = [&](char* dst, int q, const f32x4 (&pr)[4]) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = bw[e][q];
+      if (MODE != 0) {
+        x = fmaf(x, pr[e].x, pr[e].y);
+        if constexpr (MODE == 2) x += fmaf(bw2[e][q], pr[e].z, pr[e].w);
+        x = fmaxf(x, lo);
+      }
+      v[e] = x;
+    }
+    char* base = dst + (32 * q + l31) * PG_RB + cg * 8;
+    unsigned p0, p1, p2, q0, q1, q2;
+    b3_split(v[0], v[1], p0, p1, p2);
+    b3_split(v[2], v[3], q0, q1, q2);
+    *reinterpret_cast<u32x2v*>(base) = u32x2v{p0, q0};
+    *reinterpret_cast<u32x2v*>(base + PG_T * PG_RB) = u32x2v{p1, q1};
+    *reinterpret_cast<u32x2v*>(base + 2 * PG_T * PG_RB) = u32x2v{p2, q2};
+  };
+  auto load_pr = [&](int ch0, f32x4 (&pr)[4]) {
+    if (MODE != 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pr[e] = Ps[ch0 + 4 * cg + e];
+    }
+  };
+
+  // prologue: the first TWO activation chunks are requested before anything else (the second into a register set that is
+  // dead once the loop starts), so the affine table, the bias and chunk 0's split all wait on one memory round trip
+  vq bwN[4], bw2N[MODE == 2 ? 4 : 1];
+  __builtin_amdgcn_sched_barrier(0);
+  issueB(0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = PG_KC + 4 * cg + e;
+    const int vo = c < K ? voffB + c * L4 : P4_OOB;
+    bwN[e] = p4_load<4>(r1, vo, 0);
+    if constexpr (MODE == 2) bw2N[e] = p4_load<4>(r2, vo, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 acc[MT][4];
+  const __amdgpu_buffer_rsrc_t rbias = p4_rsrc(a.bias, (EPI == 0 && a.bias) ? M * 4 : 0);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = mBase + 32 * m + p4_row32(i, half);
+      float b0 = 0.f;                              // (rows past M / no bias: the bounds check returns zero, no branches)
+      if constexpr (EPI == 0) b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, row * 4, 0, 0));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[m][q][i] = b0;
+    }
+  if (MODE != 0) {
+    for (int i = tid; i < Kpad; i += 256) {
+      f32x4 p = {0.f, 0.f, 0.f, 0.f};
+      if (i < K) {
+        p.x = a.ps1 ? a.ps1[i] : 1.f;
+        p.y = a.ph1 ? a.ph1[i] : 0.f;
+        p.z = a.ps2 ? a.ps2[i] : 1.f;
+        p.w = a.ph2 ? a.ph2[i] : 0.f;
+      }
+      Ps[i] = p;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  issueA(0, af0);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                    // Ps visible (raw barrier: the operand loads stay in flight)
+  PWG_STAMP();
+  {
+    f32x4 pr[4];
+    load_pr(0, pr);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) commit_q(Bb, q, pr);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bw[e] = bwN[e];
+    if constexpr (MODE == 2) bw2[e] = bw2N[e];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  PWG_STAMP();
+
+  const int fragoff = l31 * PG_RB + 16 * half;
+  // one k-step of products on buffer `cur` (ksl = 0 / 1: the chunk's first / second 16 channels); `fill(q)` runs after
+  // the products of position sub-tile q (the next chunk's split: VALU + LDS stores in the MFMA shadow)
+  auto products = [&](const char* cur, int ksl, u32x4v (&af)[MT][3], auto&& fill) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bf16x8 bf[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        bf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(cur + fragoff + (t * PG_T + 32 * q) * PG_RB + 32 * ksl));
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[m][0]), a1 = __builtin_bit_cast(bf16x8, af[m][1]),
+                     a2 = __builtin_bit_cast(bf16x8, af[m][2]);
+        f32x16 c = acc[m][q];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf[0], c, 0, 0, 0);
+        acc[m][q] = c;
+      }
+      fill(q);
+    }
+  };
+  const int NC = Kpad / PG_KC;
+  // ACT = false: a wave whose rows lie past M (M = 96: the fourth wave) only loads and splits
+  auto mainloop = [&](auto act) {
+    constexpr bool ACT = decltype(act)::value;
+    char* cur = Bb;
+    char* nxt = Bb + G3_BBUF;
+    for (int i = 0; i < NC; ++i) {
+      const int ch1 = (i + 1) * PG_KC;             // the chunk committed in this pass (past K: zeros, never multiplied)
+      f32x4 pr[4];
+      load_pr(ch1 < Kpad ? ch1 : 0, pr);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ACT) issueA(2 * i + 1, af1);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ACT) products(cur, 0, af0, [&](int q) { commit_q(nxt, q, pr); });
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) commit_q(nxt, q, pr);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ACT) issueA(2 * i + 2, af0);
+      issueB(ch1 + PG_KC);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ACT) products(cur, 1, af1, [&](int) {});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PWG_STAMP();
+      __builtin_amdgcn_s_barrier();                // raw barrier: the loads in flight stay in flight
+      PWG_STAMP();
+      char* t = cur; cur = nxt; nxt = t;
+    }
+  };
+  if (mBase < M) mainloop(std::true_type{});
+  else mainloop(std::false_type{});
+  __syncthreads();                                 // drains the read-ahead loads before LDS is reused
+  PWG_STAMP();
+  const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, true, pok, skip};
+  p4_epilogue<MT, 4, EPI, true, 4>(a, acc, lds, tile);
+  PWG_STAMP();
+#ifdef DSGCN_LAB
+  if (blockIdx.x == PWG_STAMP_BLOCK && threadIdx.x == 0) g_pwg_stamp[63] = nst;
 #endif
 }
 
@@ -835,8 +1073,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_pwg2(Pw4Args a, const unsigned 
 //   N (forward):        rows co < MpN = ceil256(Co), k = ci < KpN = ceil32(Ci)      [3][MpN][KpN] bf16
 //   T (data gradient):  rows ci < MpT = ceil256(Ci), k = co < KpT = ceil32(Co)      [3][MpT][KpT] bf16, after N
 // One thread per (row, 4 consecutive k).
+// frag = 1 (k_pwg3): each plane in MFMA-fragment order instead, [row tile][k-step][lane = 32*(k%16 / 8) + row%32][k%8].
 __global__ __launch_bounds__(256) void k_wsplit(const float* __restrict__ w, int Ci, int Co, unsigned short* __restrict__ out,
-                                                int MpN, int KpN, int MpT, int KpT) {
+                                                int MpN, int KpN, int MpT, int KpT, int frag) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int t1 = MpN * (KpN >> 2), t2 = MpT * (KpT >> 2);
   float v[4];
@@ -846,14 +1085,17 @@ __global__ __launch_bounds__(256) void k_wsplit(const float* __restrict__ w, int
     const int r = i / (KpN >> 2), k = 4 * (i - r * (KpN >> 2));
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (r < Co && k + e < Ci) ? w[(size_t)r * Ci + k + e] : 0.f;
-    dst = out + (size_t)r * KpN + k;
+    dst = out + (frag ? ((size_t)(r >> 5) * (KpN >> 4) + (k >> 4)) * 512 + (((k >> 3) & 1) * 32 + (r & 31)) * 8 + (k & 7)
+                      : (size_t)r * KpN + k);
     pstride = MpN * KpN;
   } else if (i - t1 < t2) {
     const int j = i - t1;
     const int r = j / (KpT >> 2), k = 4 * (j - r * (KpT >> 2));
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (r < Ci && k + e < Co) ? w[(size_t)(k + e) * Ci + r] : 0.f;
-    dst = out + (size_t)3 * MpN * KpN + (size_t)r * KpT + k;
+    dst = out + (size_t)3 * MpN * KpN +
+          (frag ? ((size_t)(r >> 5) * (KpT >> 4) + (k >> 4)) * 512 + (((k >> 3) & 1) * 32 + (r & 31)) * 8 + (k & 7)
+                : (size_t)r * KpT + k);
     pstride = MpT * KpT;
   } else {
     return;
@@ -875,7 +1117,7 @@ WsDims ws_dims(int Ci, int Co) {
   return d;
 }
 
-int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128, g_p4_ws = 1;
+int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128, g_p4_ws = 2;   // ws: 1 = k_pwg2 (row-major image), 2 = k_pwg3 (fragment-order image)
 
 struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad, gemm, Lq; size_t lds; unsigned grid; };
 
@@ -972,10 +1214,43 @@ void pwg2_launch(Pw4Args a, int mode, int epi, const P4Plan& p, const unsigned s
   }
 }
 
+// the fragment-image form: MT = 2 (256 rows per workgroup) when the conv has more than 128 output rows
+template <int MT>
+void pwg3_launch(Pw4Args a, int mode, int epi, const P4Plan& p, const unsigned short* wfr, int Mp, hipStream_t st) {
+  constexpr int TA = 128 * MT;
+  a.cc = (a.M + TA - 1) / TA;
+  const size_t main_b = (size_t)2 * G3_BBUF + (size_t)p.Kpad * 16;
+  const size_t epi_b = (size_t)4 * (3 * 32 * 36 + MT * 32 * 3 + MT * 32 * 4) * sizeof(float);
+  const size_t lds = main_b > epi_b ? main_b : epi_b;
+  static bool raised = false;
+  if (!raised) {
+    const void* fs[5] = {reinterpret_cast<const void*>(&k_pwg3<0, 0, MT>), reinterpret_cast<const void*>(&k_pwg3<1, 0, MT>),
+                         reinterpret_cast<const void*>(&k_pwg3<2, 0, MT>), reinterpret_cast<const void*>(&k_pwg3<0, 1, MT>),
+                         reinterpret_cast<const void*>(&k_pwg3<2, 1, MT>)};
+    for (const void* f : fs) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    raised = true;
+  }
+  const dim3 grid((unsigned)((p.ngrp + 7) / 8 * 8 * a.cc)), blk(256);
+  const int RT = Mp / 32;
+  if (epi == 0) {
+    if (mode == 0) hipLaunchKernelGGL((k_pwg3<0, 0, MT>), grid, blk, lds, st, a, wfr, RT);
+    else if (mode == 1) hipLaunchKernelGGL((k_pwg3<1, 0, MT>), grid, blk, lds, st, a, wfr, RT);
+    else hipLaunchKernelGGL((k_pwg3<2, 0, MT>), grid, blk, lds, st, a, wfr, RT);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((k_pwg3<0, 1, MT>), grid, blk, lds, st, a, wfr, RT);
+    else hipLaunchKernelGGL((k_pwg3<2, 1, MT>), grid, blk, lds, st, a, wfr, RT);
+  }
+}
+
 template <int PD>
 bool p4_launch_pd(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStream_t st, const unsigned short* wsp = nullptr,
                   int Mp = 0) {
   const int key = p.MT * 10 + p.NQ;
+  if (p.gemm && wsp && g_p4_ws == 2) {
+    if (a.M > 128) pwg3_launch<2>(a, mode, epi, p, wsp, Mp, st);
+    else pwg3_launch<1>(a, mode, epi, p, wsp, Mp, st);
+    return true;
+  }
   if (p.gemm && wsp && g_p4_ws) {
     if (a.M > 128) pwg2_launch<8>(a, mode, epi, p, wsp, Mp, st);
     else pwg2_launch<4>(a, mode, epi, p, wsp, Mp, st);
@@ -1092,7 +1367,7 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_wsplit(const float* w, int Ci
   const WsDims d = ws_dims(Ci, Co);
   const long total = (long)d.MpN * (d.KpN >> 2) + (long)d.MpT * (d.KpT >> 2);
   hipLaunchKernelGGL(k_wsplit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Ci, Co,
-                     static_cast<unsigned short*>(out), d.MpN, d.KpN, d.MpT, d.KpT);
+                     static_cast<unsigned short*>(out), d.MpN, d.KpN, d.MpT, d.KpT, g_p4_ws == 2 ? 1 : 0);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -1100,5 +1375,8 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_wsplit(const float* w, int Ci
 #ifdef DSGCN_LAB
 extern "C" int dsgcn_pwg2_phases(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pwg_stamp), sizeof(long long) * 64);
+}
+extern "C" int dsgcn_pwg2_phases_block(int block) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pwg_stamp_block), &block, sizeof(int));
 }
 #endif

@@ -45,8 +45,10 @@ def confusion_matrix(y_pred, y_real, normalize=None):
 
 
 def mean_class_accuracy(scores, labels):
+    """-> (mean class accuracy, confusion matrix): this fork returns the pair (pyskl/core/evaluation.py:85-104; the
+    dataset's ``evaluate`` unpacks it, datasets/base.py:194,201)."""
     pred = np.argmax(scores, axis=1)
     cm = confusion_matrix(pred, labels).astype(float)
     cls_cnt = cm.sum(axis=1)
     cls_hit = np.diag(cm)
-    return np.mean([hit / cnt if cnt else 0.0 for cnt, hit in zip(cls_cnt, cls_hit)])
+    return np.mean([hit / cnt if cnt else 0.0 for cnt, hit in zip(cls_cnt, cls_hit)]), cm

@@ -113,6 +113,7 @@ LAB_SIGNATURES = {
     'dsgcn_tms_tuning': [c_int, c_int],
     'dsgcn_dynadj_phases': [ctypes.c_void_p],
     'dsgcn_pwg2_phases': [ctypes.c_void_p],
+    'dsgcn_pwg2_phases_block': [c_int],
     'dsgcn_tcw_phases': [ctypes.c_void_p],
 }
 

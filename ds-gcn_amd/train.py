@@ -98,3 +98,20 @@ class FlatSGD:
 def cosine_lr(base_lr, it, total_iters, min_lr=0.0):
     """mmcv CosineAnnealingLrUpdaterHook(by_epoch=False)."""
     return min_lr + 0.5 * (base_lr - min_lr) * (1 + math.cos(math.pi * it / max(total_iters, 1)))
+
+
+def step_lr(base_lr, progress, step, gamma=0.1, min_lr=None):
+    """mmcv StepLrUpdaterHook.get_lr: ``progress`` = the 0-based epoch about to run (by_epoch=True); ``step`` an int
+    (decay every ``step`` epochs) or a list of milestones (configs/stgcn/stgcn_vanilla_ntu60_xsub_3dkp/j.py:35)."""
+    if isinstance(step, int):
+        exp = progress // step
+    else:
+        exp = len(step)
+        for i, s in enumerate(step):
+            if progress < s:
+                exp = i
+                break
+    lr = base_lr * gamma ** exp
+    if min_lr is not None:
+        lr = max(lr, min_lr)
+    return lr

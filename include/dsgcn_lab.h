@@ -38,6 +38,9 @@ int dsgcn_dynadj_phases(long long* out);
  * issued, then (commit done, barrier passed, products done) per 32-channel chunk, main loop drained, epilogue done;
  * out[63] = number of stamps. */
 int dsgcn_pwg2_phases(long long* out);
+/* k_pwg3 stamps through the same buffer: start, affine table visible, chunk 0 committed, then (products done, barrier passed)
+ * per chunk, loop drained, epilogue done.  dsgcn_pwg2_phases_block selects the stamping workgroup (default 0). */
+int dsgcn_pwg2_phases_block(int block);
 
 /* temporal-conv weight gradient (k_tcw): stamps of workgroup 0, per tap group (before issue, after issue, after the
  * barrier, after the products); out[63] = count. */

@@ -180,3 +180,163 @@ def test_train_model_two_ranks_gloo(tmp_path):
     assert r0['iters'] == r1['iters'] == 3
     assert torch.equal(r0['p'], r1['p'])
     assert [rec['loss'] for rec in r0['log']] == [rec['loss'] for rec in r1['log']]
+
+
+# ---- round 4: step LR + validation during training, against the reference-generated fixture ---------------------------
+
+def _setup_step(tmp_path, **extra):
+    z = load('trajectory_stgcn_steplr.npz')
+    cfg = json.loads(str(z['cfg']))
+    tr = json.loads(str(z['config']))
+    m = D.build_model(cfg)
+    m.load_state_dict(sd_of(z, 'sd_', torch.float32))
+    data = [dict(keypoint=z['x'][i], label=int(z['label'][i])) for i in range(tr['samples'])]
+    val = [dict(keypoint=z['xv'][i], label=int(z['label_v'][i])) for i in range(tr['val_samples'])]
+    run_cfg = dict(data=dict(videos_per_gpu=tr['batch'], val_dataloader=dict(videos_per_gpu=5)), seed=tr['seed'],
+                   total_epochs=tr['epochs'],
+                   optimizer=dict(type='SGD', lr=tr['lr'], momentum=tr['momentum'], weight_decay=tr['weight_decay'],
+                                  nesterov=True),
+                   optimizer_config=dict(grad_clip=None), lr_config=dict(policy='step', step=tr['step']),
+                   evaluation=dict(interval=1, metrics=['top_k_accuracy', 'mean_class_accuracy']),
+                   checkpoint_config=None, log_config=dict(interval=1), work_dir=str(tmp_path), **extra)
+    return z, tr, m, data, val, run_cfg
+
+
+def _check_step(z, tr, m, runner, p0, tmp_path):
+    names = json.loads(str(z['names']))
+    P = dict(m.named_parameters())
+    num = den = upd = 0.0
+    for i, k in enumerate(names):
+        want = z[f'p64_{i}']
+        got = P[k].detach().double().cpu().numpy()
+        num += float(((got - want) ** 2).sum())
+        den += float((want ** 2).sum())
+        upd += float(((want - p0[k]) ** 2).sum())
+    perr, uerr = (num / den) ** .5, (num / upd) ** .5
+    assert perr < 1e-5 and uerr < 3e-3, (perr, uerr, float(z['perr32']), float(z['uerr32']))
+    # the rate of every iteration: mmcv's StepLrUpdaterHook by epoch (0.03, then x0.1 from epoch 1, x0.01 from epoch 3)
+    assert [r['lr'] for r in runner.log] == pytest.approx(list(z['lr64']), rel=1e-12)
+    for a, b in zip([r['loss'] for r in runner.log], z['loss64']):
+        assert abs(a - b) / abs(b) < 1e-5
+    # validation after every epoch: forward_test scores (two clips averaged as probabilities) and the reference's metrics
+    ev = runner.evaluator
+    assert [r['epoch'] for r in ev.results] == [1, 2, 3, 4]
+    for e, rec in enumerate(ev.results):
+        assert rec['top1_acc'] == pytest.approx(z['val64'][e, 0]) and rec['top5_acc'] == pytest.approx(z['val64'][e, 1])
+        assert rec['mean_class_accuracy'] == pytest.approx(z['val64'][e, 2])
+    # save_best='auto': the first metric (top1_acc), strictly greater replaces — the fixture's top-1 never improves
+    best = [f for f in os.listdir(tmp_path) if f.startswith('best_')]
+    assert best == ['best_top1_acc_epoch_1.pth']
+    # checkpoint_config=None: no CheckpointHook, so no epoch_N.pth / latest.pth
+    assert not any(f.startswith('epoch_') or f == 'latest.pth' for f in os.listdir(tmp_path))
+
+
+def test_train_model_step_lr_and_validation_cpu(tmp_path):
+    z, tr, m, data, val, cfg = _setup_step(tmp_path)
+    p0 = {k: p.detach().double().numpy().copy() for k, p in m.named_parameters()}
+    with D.kernels.use_ops(torch_ops):
+        runner = train_model(m, data, cfg, device='cpu', use_graph=False, validate=True, val_dataset=val)
+        part = runner.evaluator.predict(m, 0, 1)
+    _check_step(z, tr, m, runner, p0, tmp_path)
+    assert np.abs(np.stack(part) - z['vscores64'][-1]).max() < 1e-5      # the last epoch's scores, sample by sample
+    assert m.training                                                    # the loop hands the model back in train mode
+
+
+@pytest.mark.gpu
+def test_train_model_step_lr_and_validation_gpu(tmp_path):
+    z, tr, m, data, val, cfg = _setup_step(tmp_path)
+    p0 = {k: p.detach().double().numpy().copy() for k, p in m.named_parameters()}
+    runner = train_model(m, data, cfg, device='cuda', use_graph=True, validate=True, val_dataset=val)
+    assert runner.engine.capture_error is None and len(runner.engine._graphs) == 1
+    _check_step(z, tr, m, runner, p0, tmp_path)
+    part = runner.evaluator.predict(m, 0, 1)
+    assert np.abs(np.stack(part) - z['vscores64'][-1]).max() < 1e-5
+
+
+def test_log_interval_means_cpu(tmp_path):
+    """log_config.interval > 1: a record is the sample-weighted mean over ITS iterations (on the hipGraph path the
+    engine hands back the same static tensors every replay — the loop must keep per-iteration values)."""
+    z, tr, m, data, cfg = _setup(tmp_path)
+    cfg['log_config'] = dict(interval=2)
+    cfg['checkpoint_config'] = None
+    with D.kernels.use_ops(torch_ops):
+        runner = train_model(m, data, cfg, device='cpu', use_graph=False)
+    z2, _, m2, data2, cfg2 = _setup(tmp_path / 'b')
+    cfg2['checkpoint_config'] = None
+    with D.kernels.use_ops(torch_ops):
+        r1 = train_model(m2, data2, cfg2, device='cpu', use_graph=False)
+    per_iter = [r['loss'] for r in r1.log]                                # 3 iterations per epoch, 2 epochs
+    want = [(per_iter[0] + per_iter[1]) / 2, per_iter[2], (per_iter[3] + per_iter[4]) / 2, per_iter[5]]
+    assert [r['loss'] for r in runner.log] == pytest.approx(want, rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_log_interval_means_graph_gpu(tmp_path):
+    """The same on the product path: iterations 3-6 are hipGraph replays whose log tensors alias one static buffer."""
+    z, tr, m, data, cfg = _setup(tmp_path)
+    cfg['log_config'] = dict(interval=3)
+    runner = train_model(m, data, cfg, device='cuda', use_graph=True)
+    assert len(runner.engine._graphs) == 1
+    z2, _, m2, data2, cfg2 = _setup(tmp_path / 'b')
+    r1 = train_model(m2, data2, cfg2, device='cuda', use_graph=False)     # eager, one record per iteration
+    per_iter = [r['loss'] for r in r1.log]
+    want = [sum(per_iter[:3]) / 3, sum(per_iter[3:]) / 3]
+    assert [r['loss'] for r in runner.log] == pytest.approx(want, rel=1e-6)
+    top1 = [r['top1_acc'] for r in r1.log]
+    assert [r['top1_acc'] for r in runner.log] == pytest.approx([sum(top1[:3]) / 3, sum(top1[3:]) / 3], rel=1e-6)
+
+
+def test_eval_loop_schedule_and_best(tmp_path):
+    """EvalLoop by itself: mmcv's interval / start rule and save_best bookkeeping (greater for accuracies, less for losses;
+    the previous best file is removed)."""
+    from dsgcn_amd.apis import EvalLoop
+    ev = EvalLoop([dict(keypoint=np.zeros((1, 1, 2, 2, 3), np.float32), label=0)], interval=2, device='cpu')
+    assert [e for e in range(1, 9) if ev.should_run(e)] == [2, 4, 6, 8]
+    ev = EvalLoop([dict(keypoint=np.zeros((1, 1, 2, 2, 3), np.float32), label=0)], interval=2, start=3, device='cpu')
+    assert [e for e in range(1, 9) if ev.should_run(e)] == [3, 5, 7]
+    scores = np.array([[.1, .7, .2], [.6, .3, .1], [.2, .3, .5], [.3, .4, .3]])
+    ev2 = EvalLoop([dict(keypoint=np.zeros((1, 1, 2, 2, 3), np.float32), label=0)], device='cpu',
+                   metrics=['top_k_accuracy', 'mean_class_accuracy'], metric_options=dict(top_k_accuracy=dict(topk=(1, 2))))
+    got = ev2.evaluate(scores, [1, 0, 1, 1])
+    assert got['top1_acc'] == pytest.approx(0.75) and got['top2_acc'] == pytest.approx(1.0)
+    assert got['mean_class_accuracy'] == pytest.approx((1.0 + 2 / 3) / 2)
+    assert ev._better('top1_acc', 0.5) and not (setattr(ev, 'best_score', 0.5) or ev._better('top1_acc', 0.5))
+    assert ev._better('top1_acc', 0.6) and ev._better('loss_cls', 0.4) and not ev._better('loss_cls', 0.6)
+    with pytest.raises(ValueError):
+        ev._better('mystery', 1.0)
+
+
+def _val_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    z, tr, m, data, val, cfg = _setup_step(os.path.join(out_dir, f'w{rank}'))
+    cfg['total_epochs'] = 1
+    cfg['data']['videos_per_gpu'] = 4
+    val = val[:11]                                   # odd split: rank 0 scores 6 clips, rank 1 scores 5 + one wrapped
+    with D.kernels.use_ops(torch_ops):
+        runner = train_model(m, data, cfg, device='cpu', use_graph=False, validate=True, val_dataset=val)
+        if rank == 0:
+            single = runner.evaluator.predict(m, 0, 1)
+            torch.save(dict(res=runner.evaluator.results, single=np.stack(single), labels=[v['label'] for v in val]),
+                       os.path.join(out_dir, 'val.pt'))
+    dist.destroy_process_group()
+
+
+def test_validation_two_ranks_gloo(tmp_path):
+    """DistEvalHook across ranks: each rank scores its share of the val split in sampler order, the parts are interleaved
+    back into dataset order and cut to the dataset length; rank 0's metrics equal a single-process pass over the split."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_val_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = torch.load(tmp_path / 'val.pt', weights_only=False)
+    from dsgcn_amd.evaluation import mean_class_accuracy, top_k_accuracy
+    top = top_k_accuracy(r['single'], r['labels'], (1, 5))
+    rec = r['res'][0]
+    assert rec['epoch'] == 1 and rec['top1_acc'] == pytest.approx(top[0]) and rec['top5_acc'] == pytest.approx(top[1])
+    assert rec['mean_class_accuracy'] == pytest.approx(mean_class_accuracy(r['single'], r['labels'])[0])
