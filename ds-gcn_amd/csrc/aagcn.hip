@@ -64,7 +64,7 @@ __global__ __launch_bounds__(GT_NT) void k_gate_bwd(const float* __restrict__ y,
   float* pl = lds + (size_t)wave * L;
   const int n = (int)(plane / C), c = (int)(plane - (long)n * C);
   const float* py = y + plane * L;
-  const float* pg = gout + plane * L;
+  const float* pg = gout ? gout + plane * L : nullptr;        // (no direct gradient of the gated output: only the reduced one)
   float* pd = dy + plane * L;
   const float invV = 1.f / (float)V;
   const float dplane = (rmode == 2 && drout) ? drout[plane] / (float)L : 0.f;

@@ -42,10 +42,11 @@ class TrainEngine:
     # ---- pieces --------------------------------------------------------------------------------------------
     def _fwd_bwd(self, keypoint, label):
         self.opt.zero_grad()
+        kernels.reset_leaf_uses()
         out = self.model.train_step(dict(keypoint=keypoint, label=label), None, sync_log_vars=False)
         if self.flat.flat_p.is_cuda:
             # parameter-gradient partial rows are summed by ONE launch at the end of the backward (kernels.param_colsum)
-            with kernels.deferred_param_sums():
+            with kernels.deferred_param_sums(self.flat):
                 out['loss'].backward()
         else:
             out['loss'].backward()

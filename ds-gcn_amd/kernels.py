@@ -188,13 +188,37 @@ def colsum_pair(ta, tb, split_last_b=False):
 
 _deferred = None
 _VIEW_NODES = ('ViewBackward0', 'ReshapeAliasBackward0', 'UnsafeViewBackward0', 'AliasBackward0', '_CatRowsBackward')
+_leaf_uses = {}          # id(leaf parameter) -> calls that asked to defer its gradient since the last deferred backward
+
+
+class _LeafUse:
+    """Result of ``_leafish``: truthy when every tensor reaches its leaves through view-only nodes AND — asked at BACKWARD
+    time, when every forward of the step has registered — no leaf was registered by a second call.  A parameter shared by two
+    deferring calls would have autograd ADD two unfilled gradients before the flush; those calls fall back to the
+    immediate column sum instead (``dggcn`` shares ``A`` and says so with ``single_use=False``; this catches the ones that
+    do not say)."""
+    __slots__ = ('ok', 'leaves')
+
+    def __init__(self, ok, leaves):
+        self.ok, self.leaves = ok, tuple(leaves)
+        if ok:
+            for i in self.leaves:
+                _leaf_uses[i] = _leaf_uses.get(i, 0) + 1
+
+    def __bool__(self):
+        return self.ok and all(_leaf_uses.get(i, 1) <= 1 for i in self.leaves)
 
 
 def _leafish(*tensors):
-    """True when every tensor is a leaf or reaches its leaves through view-only autograd nodes."""
+    """Truthy (a ``_LeafUse``) when every tensor is a leaf or reaches its leaves through view-only autograd nodes."""
+    leaves = []
+
     def ok(fn):
         for _ in range(8):
-            if fn is None or type(fn).__name__ == 'AccumulateGrad':
+            if fn is None:
+                return True
+            if type(fn).__name__ == 'AccumulateGrad':
+                leaves.append(id(fn.variable))
                 return True
             if type(fn).__name__ not in _VIEW_NODES:
                 return False
@@ -203,14 +227,41 @@ def _leafish(*tensors):
                 return all(ok(f) for f in nxt)
             fn = nxt[0]
         return False
-    return all(t is None or not t.requires_grad or ok(t.grad_fn) for t in tensors)
+
+    good = True
+    for t in tensors:
+        if t is None or not t.requires_grad:
+            continue
+        if t.grad_fn is None:
+            leaves.append(id(t))
+        elif not ok(t.grad_fn):
+            good = False
+            break
+    return _LeafUse(good, leaves)
+
+
+def reset_leaf_uses():
+    """Start of a step (TrainEngine._fwd_bwd): forget which leaves the previous step's forward registered."""
+    _leaf_uses.clear()
 
 
 class deferred_param_sums:
-    """``with deferred_param_sums(): loss.backward()`` — see above; flushes on exit."""
+    """``with deferred_param_sums(flat): loss.backward()`` — see above; flushes on exit.  The queued outputs reach autograd
+    unfilled, so the region insists on what makes that safe: ``FlatParams(gather=True)`` (no in-place accumulation into
+    pre-assigned ``.grad`` views) and no ``.grad`` present on entry (AccumulateGrad would add the unfilled tensor to it)."""
+
+    def __init__(self, flat=None):
+        self.flat = flat
 
     def __enter__(self):
         global _deferred
+        if self.flat is not None:
+            if not self.flat.gather:
+                raise RuntimeError('deferred_param_sums needs FlatParams(gather=True): with gradient views autograd '
+                                   'accumulates in place, before the deferred sums are filled')
+            if any(p.grad is not None for p in self.flat.params):
+                raise RuntimeError('deferred_param_sums: a parameter already holds a .grad — call zero_grad() first '
+                                   '(gradient accumulation over several backward passes is not supported here)')
         self.prev = _deferred
         _deferred = []
         return self
@@ -222,6 +273,7 @@ class deferred_param_sums:
                 flush_param_sums()
         finally:
             _deferred = self.prev
+            _leaf_uses.clear()
         return False
 
 
@@ -1637,10 +1689,10 @@ def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None):
             dk = _EdgeSelect.apply(pwconv(dk, None, None, None, False, we, be, 1, False)[0], et, R)
         S.append(pwconv(dk, None, None, None, False, w4[k], b4[k], 1, False)[0])
     G = None
-    if beta is not None:      # Gram of the mean-pooled projections per subset: a plain batched GEMM (rocBLAS via torch.bmm)
-        x1 = proj[:, :K * R].reshape(n * K, R, V)
-        x2 = proj[:, K * R:].reshape(n * K, R, V)
-        G = torch.bmm(x1.transpose(1, 2), x2).view(n, K, V, V)
+    if beta is not None:      # Gram of the mean-pooled projections per subset (gcn.py:826-835): kernels.gram with one-frame planes
+        x1 = proj[:, :K * R].reshape(n * K, R, 1, V)
+        x2 = proj[:, K * R:].reshape(n * K, R, 1, V)
+        G = ops().gram(x1, x2).view(n, K, V, V)
     return _CtrAffine.apply(alpha, A, beta, G, *S)
 
 

@@ -383,11 +383,30 @@ class PoseDataset(torch.utils.data.Dataset):
     'keypoint' (M, T, V, C), 'total_frames', ...}]}`` (or a bare annotation list).  ``dataset[i]`` runs the pipeline on a
     copy of sample i with ``start_index=0`` and ``modality='Pose'`` added, like BaseDataset.prepare_*_frames."""
 
-    def __init__(self, ann_file, pipeline, split=None, valid_rate=1, test_mode=False, data_prefix='', **unsupported):
-        for key in ('valid_ratio', 'box_thr', 'class_prob', 'memcached'):
-            if unsupported.pop(key, None):
-                raise NotImplementedError(f'PoseDataset({key}=...) belongs to the 2-D pose pickles, outside this path')
+    def __init__(self, ann_file, pipeline, split=None, valid_rate=1, valid_ratio=None, box_thr=0.5, class_prob=None,
+                 memcached=False, mc_cfg=('localhost', 22077), test_mode=False, data_prefix='', **unsupported):
+        """``valid_ratio`` / ``box_thr`` (the Kinetics pose pickles, pose_dataset.py:66-83,
+        configs/dsstgcn/kinetics400_hrnet/j.py:22-23,80-82): a clip stays when ``valid[box_thr] / total_frames >=
+        valid_ratio``; its ``anno_inds`` = ``box_score >= box_thr`` (what ``DecompressPose`` filters by); ``valid`` and
+        ``box_score`` are dropped from every record.  ``memcached`` needs a memcached server holding the keypoints:
+        rejected (load the pickle with its keypoints instead)."""
+        if memcached:
+            raise NotImplementedError('PoseDataset(memcached=True): no memcached client on this path — use an annotation '
+                                      'file that carries the keypoints')
+        if class_prob is not None:
+            raise NotImplementedError('PoseDataset(class_prob=...) (class-balanced resampling) is not used by the '
+                                      'skeleton configs')
+        for key in list(unsupported):
+            if key in ('num_classes', 'start_index', 'modality', 'multi_class', 'sample_by_class', 'power'):
+                if unsupported[key] not in (None, False, 0, 'Pose'):
+                    raise NotImplementedError(f'PoseDataset({key}={unsupported[key]!r}) is outside this path')
+                unsupported.pop(key)
+        if unsupported:
+            raise TypeError(f'PoseDataset got unexpected arguments {sorted(unsupported)}')
+        if box_thr is not None and box_thr not in (.5, .6, .7, .8, .9):
+            raise AssertionError('box_thr must be one of 0.5, 0.6, 0.7, 0.8, 0.9 or None')
         self.ann_file, self.split, self.test_mode = ann_file, split, test_mode
+        self.valid_rate, self.valid_ratio, self.box_thr, self.data_prefix = valid_rate, valid_ratio, box_thr, data_prefix
         self.pipeline = pipeline if callable(pipeline) else Compose(pipeline)
         self.start_index, self.modality = 0, 'Pose'
         with open(ann_file, 'rb') as f:
@@ -399,6 +418,20 @@ class PoseDataset(torch.utils.data.Dataset):
             names = set(names)
             key = 'filename' if 'filename' in data[0] else 'frame_dir'
             data = [x for x in data if x[key] in names]
+        if data_prefix:
+            import os.path as osp
+            for item in data:
+                for key in ('filename', 'frame_dir'):
+                    if key in item:
+                        item[key] = osp.join(data_prefix, item[key])
+        if valid_ratio is not None:
+            assert isinstance(valid_ratio, float)
+            data = [x for x in data if x['valid'][box_thr] / x['total_frames'] >= valid_ratio]
+            for item in data:
+                item['anno_inds'] = item['box_score'] >= box_thr
+        for item in data:
+            item.pop('valid', None)
+            item.pop('box_score', None)
         self.video_infos = data
 
     def __len__(self):

@@ -303,3 +303,33 @@ def test_cat_rows_is_a_view_under_flat_params():
     assert torch.equal(m.b.bias.grad, torch.tensor([3., 4.]))
     flat.collect_grads()
     assert flat.check_views() and torch.equal(m.b.weight.grad.flatten(1), g[3:])
+
+
+def test_deferred_param_sums_guards():
+    """the deferred parameter-gradient sums hand autograd unfilled tensors, so the conditions that make that safe
+    are checked instead of assumed — a leaf registered by two deferring calls turns deferral off for both (asked at backward
+    time), a non-view path to the leaf never defers, and the region refuses gradient views / a pre-existing .grad."""
+    import torch.nn as nn
+    from dsgcn_amd import kernels as K
+    w = nn.Parameter(torch.randn(4, 4))
+    b = nn.Parameter(torch.randn(4))
+    K.reset_leaf_uses()
+    first = K._leafish(w, b)
+    assert first                                         # single use so far
+    second = K._leafish(w.view(16), None)
+    assert not first and not second                      # w shared: neither call may queue an unfilled gradient
+    K.reset_leaf_uses()
+    assert K._leafish(w, b)
+    assert not K._leafish(w * 2.0)                       # a computed tensor: something reads the gradient before the flush
+    K.reset_leaf_uses()
+    net = nn.Linear(3, 2)
+    flat = D.FlatParams(net, gather=False)
+    with pytest.raises(RuntimeError, match='gather=True'):
+        with K.deferred_param_sums(flat):
+            pass
+    net2 = nn.Linear(3, 2)
+    flat2 = D.FlatParams(net2, gather=True)
+    net2(torch.randn(1, 3)).sum().backward()
+    with pytest.raises(RuntimeError, match='zero_grad'):
+        with K.deferred_param_sums(flat2):
+            pass

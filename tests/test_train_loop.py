@@ -299,7 +299,8 @@ def test_eval_loop_schedule_and_best(tmp_path):
                    metrics=['top_k_accuracy', 'mean_class_accuracy'], metric_options=dict(top_k_accuracy=dict(topk=(1, 2))))
     got = ev2.evaluate(scores, [1, 0, 1, 1])
     assert got['top1_acc'] == pytest.approx(0.75) and got['top2_acc'] == pytest.approx(1.0)
-    assert got['mean_class_accuracy'] == pytest.approx((1.0 + 2 / 3) / 2)
+    # (the label set includes predicted classes: class 2 has no samples and counts as 0, evaluation.py:96-101)
+    assert got['mean_class_accuracy'] == pytest.approx((1.0 + 2 / 3 + 0.0) / 3)
     assert ev._better('top1_acc', 0.5) and not (setattr(ev, 'best_score', 0.5) or ev._better('top1_acc', 0.5))
     assert ev._better('top1_acc', 0.6) and ev._better('loss_cls', 0.4) and not ev._better('loss_cls', 0.6)
     with pytest.raises(ValueError):
