@@ -95,23 +95,28 @@ def ka_alg_bytes(n, KC, t, v, bwd):
 
 
 def _pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction +
-    WRITE_SIZE, tools/ka_once.py as the profiled program); None when no summary is committed."""
+    """(HBM bytes per launch, where the figure comes from): the PMC counters cannot be read from inside this process, so
+    `traffic` is the latest COMMITTED rocprofv3 --pmc result (two passes, FETCH_SIZE x2 per the gfx950 correction +
+    WRITE_SIZE, tools/ka_once.py as the profiled program, tools/gpu/ka_pmc.sh) — not a measurement of this run, and
+    `traffic_source` says so; (None, None) when no summary is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'ka_traffic.json')))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
         d = json.load(f)
     for k, v in d.items():
         if k.startswith(kernel):
-            return v.get('hbm_bytes_per_launch')
-    return None
+            return v.get('hbm_bytes_per_launch'), ('committed PMC passes ' + os.path.relpath(files[-1], ROOT) +
+                                                   ' (rocprofv3 --pmc, separate run of the same kernels; not measured by this process)')
+    return None, None
 
 
-def measure_ka_roofline(device, n, reps=20):
+def measure_ka_roofline(device, n, reps=20, blocks=5):
     """HIP-event timing of K-A fwd and bwd over the model's layer mix (distinct buffers per layer so the
-    working set, 0.64 GB fwd / 1.05 GB bwd, exceeds the 256 MiB Infinity Cache)."""
+    working set, 0.64 GB fwd / 1.05 GB bwd, exceeds the 256 MiB Infinity Cache).  `blocks` timed blocks of `reps`
+    repetitions each: `achieved` / `frac` / `avg_launch_us` are the MEDIAN block, `frac_min` / `frac_max` the spread (a
+    26 us launch moves by a few percent between blocks and between boxes of the pool)."""
     from dsgcn_amd import native
     lib = native.lib()
     st = torch.cuda.current_stream().cuda_stream
@@ -143,21 +148,28 @@ def measure_ka_roofline(device, n, reps=20):
         for b in bufs:
             fn(b)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            for b in bufs:
-                fn(b)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        times = []
+        for _ in range(blocks):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                for b in bufs:
+                    fn(b)
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / reps)
+        times.sort()
+        ms = times[len(times) // 2]
         nbytes = sum(ka_alg_bytes(*b['dims'], V, is_bwd) for b in bufs)
         launches = len(bufs)
         gbs = nbytes / (ms * 1e-3) / 1e9
+        traffic, src = _pmc_traffic(name)
         out[name] = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                         frac=round(gbs / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(name),
+                         frac=round(gbs / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=src,
                          avg_launch_us=round(ms * 1e3 / launches, 2), alg_bytes_per_launch=nbytes // launches,
-                         launches_per_step=launches)
+                         launches_per_step=launches, blocks=blocks, reps_per_block=reps,
+                         frac_min=round(nbytes / (times[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         frac_max=round(nbytes / (times[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     return out
 
 
@@ -445,7 +457,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rank_elapsed = [elapsed]
     if world > 1:
+        mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_elapsed = [float(t.item()) for t in every]
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
@@ -467,6 +484,12 @@ def main():
                        'clips_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
             'final_loss': round(loss_val, 5), 'hip_graph': bool(use_graph),
         }
+        if world > 1 or force_dist:
+            per = [round(t / args.steps * 1e3, 3) for t in rank_elapsed]
+            result['dist'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                              'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()),
+                              'rank_ms_per_step': per, 'rank_ms_min': min(per), 'rank_ms_max': max(per),
+                              'grad_bytes': int(flat.flat_g.numel() * flat.flat_g.element_size())}
     # the optimizer update reported separately (the metric is fwd+bwd; the step above includes the update)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -482,6 +505,24 @@ def main():
     if rank == 0:
         result['optimizer_ms'] = round(e0.elapsed_time(e1) / 10, 3)
         result['fwd_bwd_ms'] = round(result['ms_per_step'] - result['optimizer_ms'], 3)
+    if world > 1 or force_dist:
+        # the gradient exchange by itself (the RCCL all-reduce of the flat buffer between the two graphs), after the timed
+        # region: HIP events on the stream the collective is enqueued on, max over ranks
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(10):
+            engine._exchange()
+        a1.record()
+        torch.cuda.synchronize()
+        ar = torch.tensor([a0.elapsed_time(a1) / 10], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            result['dist']['allreduce_ms'] = round(float(ar.item()), 4)
+            result['dist']['allreduce_note'] = '10 back-to-back exchanges of the flat gradient buffer, max over ranks'
     if rank == 0:
         # fingerprint of the parameters after the run (W + K steps + the 10 update replays above): two runs of the same
         # command must agree bit for bit, with or without the RCCL group (tests/test_model_gpu.py spawns both)

@@ -60,6 +60,14 @@ __device__ __forceinline__ typename VQ<NQ>::T p4_load(__amdgpu_buffer_rsrc_t r, 
 
 __device__ __forceinline__ int p4_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// Vector offset of row `row` (rowoff = row * plane bytes) for the epilogue's per-row accesses.  The row depends on the
+// lane's half, so it must NOT go into the scalar offset: hipcc then wraps every access in a readfirstlane loop that runs
+// once per distinct value (two passes with half the lanes each — found in the round-4 disassembly: 35-195 such loops per
+// kernel).  An invalid row / position keeps an out-of-range offset (unsigned sum: no wrap below 2^32).
+__device__ __forceinline__ int p4_rowoff(bool ok, int ooff, int rowoff) {
+  return (int)((unsigned)(ok ? ooff : P4_OOB) + (unsigned)rowoff);
+}
+
 template <int NQ>
 __device__ __forceinline__ void p4_store(typename VQ<NQ>::T v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -91,7 +99,11 @@ struct P4Tile { int wave, half, l31, tid, mBase, n, nrem, ds, pos, grp; bool wli
 // k_pwg.  OWNROWS = false: the workgroup's four waves hold the SAME rows at different positions (their per-row sums are
 // added through LDS, one partial row per workgroup); true: the waves hold different rows of one position tile (each wave
 // writes its rows of the workgroup's partial row itself).
-template <int MT, int NQ, int EPI, bool OWNROWS, int NWV = 4>
+// EPD > 0 (data gradient): the forward operands of the ReLU mask / affine sums are fetched EPD row groups (4 rows each)
+// ahead of the group being finished, X2 saying at compile time whether a second stream exists — left to itself the loop
+// is load -> wait -> compute -> store per group, eight dependent memory round trips per wave (the 15-27 us epilogue of the
+// lab stamps, profiles/r03 / r04).  EPD = 0: the original form (the compiler's own schedule).
+template <int MT, int NQ, int EPI, bool OWNROWS, int NWV = 4, int EPD = 0, bool X2 = true>
 __device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][NQ], float* lds, const P4Tile& t) {
   typedef typename VQ<NQ>::T vq;
   const int wave = t.wave, half = t.half, l31 = t.l31, tid = t.tid, mBase = t.mBase, n = t.n, nrem = t.nrem, ds = t.ds,
@@ -126,7 +138,7 @@ __device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][
             qq = fmaf(val[q], val[q], qq);
           }
         }
-        p4_store<NQ>(val, ro, co < M ? ooff : P4_OOB, co * L4);
+        p4_store<NQ>(val, ro, p4_rowoff(co < M, ooff, co * L4), 0);
         if (stats) {
           const bool ok = co < M && pok;
           Tw[row * 36 + l31] = ok ? s : 0.f;
@@ -188,49 +200,68 @@ __device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][
     const __amdgpu_buffer_rsrc_t rx1 = p4_rsrc(a.ex1 + (size_t)n * M * L, (wlive && need_x) ? nrem * M * L4 : 0);
     const __amdgpu_buffer_rsrc_t rx2 = p4_rsrc((has2 ? a.ex2 : a.ex1) + (size_t)n * M * L, (wlive && has2) ? nrem * M * L4 : 0);
     const __amdgpu_buffer_rsrc_t ro2 = p4_rsrc((a.out2 ? a.out2 : a.out) + (size_t)n * M * L, (wlive && a.out2) ? nrem * M * L4 : 0);
+    constexpr int G = MT * 4;                       // row groups of the wave's tile
+    constexpr int PD = EPD > 0 ? (EPD < G ? EPD : G) : 1;
+    vq xa[PD][4], xb[(X2 || EPD == 0) ? PD : 1][4];
+    auto fetch = [&](int g, int slot) {
+      const int m = g >> 2, rb = (g & 3) * 4;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+      for (int rr = 0; rr < 4; ++rr) {
+        const int ci = mBase + 32 * m + p4_row32(rb + rr, half);
+        xa[slot][rr] = p4_load<NQ>(rx1, p4_rowoff(ci < M, ooff, ci * L4), 0);      // zeros when the input is not needed
+        if constexpr (X2 || EPD == 0) xb[slot][rr] = p4_load<NQ>(rx2, p4_rowoff(ci < M, ooff, ci * L4), 0);
+      }
+    };
+    if constexpr (EPD > 0) {
 #pragma unroll
-      for (int rb = 0; rb < 16; rb += 4) {
-        vq xa[4], xb[4];
+      for (int g = 0; g < PD; ++g) fetch(g, g);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int ci = mBase + 32 * m + p4_row32(rb + rr, half);
-          xa[rr] = p4_load<NQ>(rx1, ci < M ? ooff : P4_OOB, ci * L4);      // zeros when the input is not needed
-          xb[rr] = p4_load<NQ>(rx2, ci < M ? ooff : P4_OOB, ci * L4);
+    for (int g = 0; g < G; ++g) {
+      const int m = g >> 2, rb = (g & 3) * 4;
+      const int slot = EPD > 0 ? g % PD : 0;
+      if constexpr (EPD == 0) fetch(g, 0);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = rb + rr;
+        const int row = p4_row32(r, half);
+        const int ci = mBase + 32 * m + row;
+        const f32x4 e = Es[32 * m + row];
+        float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+        vq d1, d2;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          float pre = fmaf(xa[slot][rr][q], e.x, e.y);
+          float xbq = 0.f;
+          if constexpr (X2 || EPD == 0) {
+            xbq = xb[slot][rr][q];
+            if (has2) pre += fmaf(xbq, e.z, e.w);
+          }
+          const float dv = (!a.erelu || pre > 0.f) ? acc[m][q][r] : 0.f;
+          d1[q] = dv * e.x;
+          d2[q] = dv * e.z;
+          if (q >= skip) {
+            u0 = fmaf(dv, xa[slot][rr][q], u0);
+            u1 += dv;
+            u2 = fmaf(dv, xbq, u2);
+          }
         }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int r = rb + rr;
-          const int row = p4_row32(r, half);
-          const int ci = mBase + 32 * m + row;
-          const f32x4 e = Es[32 * m + row];
-          float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-          vq d1, d2;
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            float pre = fmaf(xa[rr][q], e.x, e.y);
-            if (has2) pre += fmaf(xb[rr][q], e.z, e.w);
-            const float dv = (!a.erelu || pre > 0.f) ? acc[m][q][r] : 0.f;
-            d1[q] = dv * e.x;
-            d2[q] = dv * e.z;
-            if (q >= skip) {
-              u0 = fmaf(dv, xa[rr][q], u0);
-              u1 += dv;
-              u2 = fmaf(dv, xb[rr][q], u2);
-            }
-          }
-          p4_store<NQ>(d1, ro, ci < M ? ooff : P4_OOB, ci * L4);
-          p4_store<NQ>(d2, ro2, ci < M ? ooff : P4_OOB, ci * L4);           // zero-sized resource when there is no dx2
-          if (sums) {
-            const bool ok = ci < M && pok;
-            Tw[row * 36 + l31] = ok ? u0 : 0.f;
-            Tw[32 * 36 + row * 36 + l31] = ok ? u1 : 0.f;
-            Tw[2 * 32 * 36 + row * 36 + l31] = ok ? u2 : 0.f;
-          }
+        p4_store<NQ>(d1, ro, p4_rowoff(ci < M, ooff, ci * L4), 0);
+        if constexpr (X2 || EPD == 0) p4_store<NQ>(d2, ro2, p4_rowoff(ci < M, ooff, ci * L4), 0);   // zero-sized resource when there is no dx2
+        if (sums) {
+          const bool ok = ci < M && pok;
+          Tw[row * 36 + l31] = ok ? u0 : 0.f;
+          Tw[32 * 36 + row * 36 + l31] = ok ? u1 : 0.f;
+          Tw[2 * 32 * 36 + row * 36 + l31] = ok ? u2 : 0.f;
         }
       }
-      if (sums) {
+      if constexpr (EPD > 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + PD < G) fetch(g + PD, slot);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if ((g & 3) == 3 && sums) {
         wave_lds_sync();
         float s0 = p4_rowread<float>(Tw, half, l31);
         float s1 = p4_rowread<float>(Tw + 32 * 36, half, l31);
@@ -901,46 +932,44 @@ __global__ __launch_bounds__(256, 2) void k_pwg3(Pw4Args a, const unsigned short
   // A fragments: (term t, row tile m of this wave, k-step ks) = 1 KB at ((t*RT + rt)*KS + ks) KB of the image
   const int KS = Kpad >> 4;
   const __amdgpu_buffer_rsrc_t rw = p4_rsrc(wfr, 3 * RT * KS * 1024);
-  int offA[MT][3];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < 3; ++t) offA[m][t] = ((t * RT + (mBase >> 5) + m) * KS) * 1024 + lane * 16;
+  // (the fragment's KB index is wave-uniform: it rides in the scalar offset, one vector register addresses all of them)
+  const int fragA0 = __builtin_amdgcn_readfirstlane(mBase >> 5);
   u32x4v af0[MT][3], af1[MT][3];                   // k-steps of even / odd index
   auto issueA = [&](int ks, u32x4v (&af)[MT][3]) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int t = 0; t < 3; ++t)
-        af[m][t] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, offA[m][t], ks * 1024, 0));
+        af[m][t] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, ((t * RT + fragA0 + m) * KS + ks) * 1024, 0));
   };
   const float lo = a.relu ? 0.f : -__builtin_inff();
-  // position sub-tile q of the chunk in registers -> its three term rows of buffer `dst`
-  auto commit_q = [&](char* dst, int q, const f32x4 (&pr)[4]) {
-    float v[4];
+  // the chunk in registers -> the operand values, in place (deferred-BatchNorm affine, second stream, ReLU): done as soon
+  // as the loads land, so the affine table's rows and the second stream's registers are dead before the products start
+  // (with them alive next to 128 accumulator + 48 fragment registers the two-stream kernels spilled INSIDE the loop, and a
+  // scratch reload waits, in order, for every prefetch issued before it)
+  auto combine = [&](int ch0) {
+    if constexpr (MODE != 0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float x = bw[e][q];
-      if (MODE != 0) {
-        x = fmaf(x, pr[e].x, pr[e].y);
-        if constexpr (MODE == 2) x += fmaf(bw2[e][q], pr[e].z, pr[e].w);
-        x = fmaxf(x, lo);
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 pr = Ps[ch0 + 4 * cg + e];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x = fmaf(bw[e][q], pr.x, pr.y);
+          if constexpr (MODE == 2) x += fmaf(bw2[e][q], pr.z, pr.w);
+          bw[e][q] = fmaxf(x, lo);
+        }
       }
-      v[e] = x;
     }
+  };
+  // position sub-tile q of the (combined) chunk -> its three term rows of buffer `dst`
+  auto commit_q = [&](char* dst, int q) {
     char* base = dst + (32 * q + l31) * PG_RB + cg * 8;
     unsigned p0, p1, p2, q0, q1, q2;
-    b3_split(v[0], v[1], p0, p1, p2);
-    b3_split(v[2], v[3], q0, q1, q2);
+    b3_split(bw[0][q], bw[1][q], p0, p1, p2);
+    b3_split(bw[2][q], bw[3][q], q0, q1, q2);
     *reinterpret_cast<u32x2v*>(base) = u32x2v{p0, q0};
     *reinterpret_cast<u32x2v*>(base + PG_T * PG_RB) = u32x2v{p1, q1};
     *reinterpret_cast<u32x2v*>(base + 2 * PG_T * PG_RB) = u32x2v{p2, q2};
-  };
-  auto load_pr = [&](int ch0, f32x4 (&pr)[4]) {
-    if (MODE != 0) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pr[e] = Ps[ch0 + 4 * cg + e];
-    }
   };
 
   // prologue: the first TWO activation chunks are requested before anything else (the second into a register set that is
@@ -986,12 +1015,9 @@ __global__ __launch_bounds__(256, 2) void k_pwg3(Pw4Args a, const unsigned short
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // Ps visible (raw barrier: the operand loads stay in flight)
   PWG_STAMP();
-  {
-    f32x4 pr[4];
-    load_pr(0, pr);
+  combine(0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) commit_q(Bb, q, pr);
-  }
+  for (int q = 0; q < 4; ++q) commit_q(Bb, q);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     bw[e] = bwN[e];
@@ -1035,15 +1061,14 @@ __global__ __launch_bounds__(256, 2) void k_pwg3(Pw4Args a, const unsigned short
     char* nxt = Bb + G3_BBUF;
     for (int i = 0; i < NC; ++i) {
       const int ch1 = (i + 1) * PG_KC;             // the chunk committed in this pass (past K: zeros, never multiplied)
-      f32x4 pr[4];
-      load_pr(ch1 < Kpad ? ch1 : 0, pr);
-      __builtin_amdgcn_sched_barrier(0);
       if constexpr (ACT) issueA(2 * i + 1, af1);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (ACT) products(cur, 0, af0, [&](int q) { commit_q(nxt, q, pr); });
+      combine(ch1 < Kpad ? ch1 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ACT) products(cur, 0, af0, [&](int q) { commit_q(nxt, q); });
       else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) commit_q(nxt, q, pr);
+        for (int q = 0; q < 4; ++q) commit_q(nxt, q);
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (ACT) issueA(2 * i + 2, af0);
@@ -1062,7 +1087,13 @@ __global__ __launch_bounds__(256, 2) void k_pwg3(Pw4Args a, const unsigned short
   __syncthreads();                                 // drains the read-ahead loads before LDS is reused
   PWG_STAMP();
   const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, true, pok, skip};
-  p4_epilogue<MT, 4, EPI, true, 4>(a, acc, lds, tile);
+  if constexpr (EPI == 1) {
+    // operand prefetch depth of the epilogue: what the registers freed by the main loop hold next to the accumulators
+    if (a.ex2) p4_epilogue<MT, 4, EPI, true, 4, MT == 2 ? 2 : 4, true>(a, acc, lds, tile);
+    else p4_epilogue<MT, 4, EPI, true, 4, 4, false>(a, acc, lds, tile);
+  } else {
+    p4_epilogue<MT, 4, EPI, true, 4>(a, acc, lds, tile);
+  }
   PWG_STAMP();
 #ifdef DSGCN_LAB
   if (blockIdx.x == PWG_STAMP_BLOCK && threadIdx.x == 0) g_pwg_stamp[63] = nst;

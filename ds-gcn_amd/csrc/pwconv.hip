@@ -1289,7 +1289,8 @@ int dsgcn_pwconv_tuning(int key, int value) {
   if (key >= 7 && key <= 9) return dsgcn_wg2_tuning(key - 7, value);
   if (key >= 10 && key <= 12) return dsgcn_p4_tuning(key - 7, value);      // GEMM form: bits, min K, min plane
   if (key == 13) return dsgcn_wg2_tuning(3, value);                        // weight gradient: bf16 terms on / off
-  if (key == 14) return dsgcn_p4_tuning(6, value);                         // pre-split weight image on / off
+  if (key == 14) return dsgcn_p4_tuning(6, value);                         // pre-split weight image: 0 off, 1 k_pwg2, 2 k_pwg3
+  if (key >= 15 && key <= 17) return dsgcn_wg2_tuning(key - 11, value);    // wide weight gradient (k_wg3) on / off, split target, co tile
   return DSGCN_EINVAL;
 }
 #endif

@@ -279,12 +279,281 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
   }
 }
 
-int g_wg2_target4 = 512, g_wg2_kc128 = 32, g_wg2_target1 = 512, g_wg2_b3 = 1;    // lab knobs (dsgcn_pwconv_tuning keys 7, 8); the values are the product's
+// ---- wide convs (more than 128 channels on either side): the whole dW tile in one workgroup ("wg3") ------------------
+// k_wg2<128,128,32,B3> at 256 -> 256 runs 2 x 2 output tiles x 128 K-splits: every dz_eff / input value is split into its
+// three bf16 terms TWICE (42 values per MFMA), in lockstep phases (commit, barrier, 48 products, barrier) on one LDS
+// buffer — 75 us against a 20 us HBM / matrix roof (profiles/r03).  Here a workgroup of EIGHT waves owns a 256 x 256 (or
+// 256 x 128 / 128 x 256) tile: every value is split once (21 per MFMA), the chunk is 16 positions (one MFMA k-step) in a
+// DOUBLE-buffered LDS image (rows of 16 bf16 + 16 B pad per term: conflict-free 16-byte fragment reads), chunk c+1 is
+// split and written while chunk c is multiplied, ONE barrier per chunk, two chunks of operand loads in flight in ping-pong
+// register sets.  One workgroup per CU (150 KB of LDS), ~256 K-splits: one round.
+constexpr int W3_NT = 512, W3_KC = 16, W3_RB = 48;
 
-struct Wg2Plan { int TM, TN, KC, cpn, chunks, tm_tiles, tn_tiles, splits, cps, b3; size_t lds; };
+template <int TM, int TN, bool HAS2, bool HASC>
+__global__ __launch_bounds__(W3_NT, 2) void k_wg3(Wg2Args a) {
+  constexpr int JD = TM * 4 / W3_NT, JX = TN * 4 / W3_NT;          // float4 slots per thread and chunk
+  constexpr int MI = TM / 128, NI = TN / 64;                       // wave tile: (TM/4) x (TN/2) = MI x NI MFMA tiles
+  constexpr int BUF = 3 * (TM + TN) * W3_RB;
+  // operand chunks in flight ahead of the one being split: 2 (ping-pong register sets) except where 256 accumulator +
+  // fragment registers leave room for one set only (two input streams AND a BatchNorm term on the full tile)
+  constexpr int DEPTH = (HAS2 && HASC && TM == 256 && TN == 256) ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* B0p = reinterpret_cast<char*>(lds);                        // buffer: [3][TM][RB] dz_eff terms, [3][TN][RB] input terms
+  char* B1p = B0p + BUF;
+  f32x2* Cs = reinterpret_cast<f32x2*>(B1p + BUF);                 // [TM] (A0, B0)
+  f32x4* Ps = reinterpret_cast<f32x4*>(Cs + TM);                   // [TN] (s1, h1, s2, h2)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles = a.tm_tiles * a.tn_tiles;
+  int split, tile;
+  if (tiles > 1) {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    tile = slot % tiles;
+    split = (slot / tiles) * 8 + xcd;
+  } else {
+    tile = 0;
+    split = blockIdx.x;
+  }
+  const int ch0 = split * a.cps;
+  const int ch1 = min(a.total_chunks, ch0 + a.cps);
+  if (ch0 >= ch1) return;
+  const int coBase = (tile % a.tm_tiles) * TM, ciBase = (tile / a.tm_tiles) * TN;
+  const int Co = a.Co, Ci = a.Ci, L = a.L;
+  const int L4 = L * 4;
+  for (int i = tid; i < TM; i += W3_NT) {
+    const int co = coBase + i;
+    Cs[i] = (HASC && co < Co) ? f32x2{a.A0[co], a.B0[co]} : f32x2{0.f, 0.f};
+  }
+  for (int i = tid; i < TN; i += W3_NT) {
+    const int ci = ciBase + i;
+    f32x4 p = {1.f, 0.f, 1.f, 0.f};
+    if (ci < Ci) {
+      if (a.s1) { p.x = a.s1[ci]; p.y = a.h1[ci]; }
+      if (a.s2) { p.z = a.s2[ci]; p.w = a.h2[ci]; }
+    }
+    Ps[i] = p;
+  }
+  // staging slots: slot f = tid + 512*j -> row f / 4, positions 4*(f % 4) ..+3 of the chunk
+  const int col = (tid & 3) * 4;
+  const int row0 = tid >> 2;                       // + 128*j
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  struct Regs { f32x4 g[JD], z[HASC ? JD : 1], x[JX], y[HAS2 ? JX : 1]; };
+  Regs RA, RB;
+  auto issue = [&](int ch, Regs& r) {
+    const int n = ch / a.cpn;
+    const int c0 = (ch - n * a.cpn) * W3_KC;
+    const bool pv = (ch < ch1) & (c0 + col < L);
+    const __amdgpu_buffer_rsrc_t rg = wg_rsrc((a.gz ? a.gz : a.x1) + (size_t)(a.gz ? n : 0) * Co * L, a.gz ? Co * L4 : 0);
+    const __amdgpu_buffer_rsrc_t rz = wg_rsrc((HASC ? a.z : a.x1) + (size_t)(HASC ? n : 0) * Co * L, HASC ? Co * L4 : 0);
+    const __amdgpu_buffer_rsrc_t rx = wg_rsrc(a.x1 + (size_t)n * Ci * L, Ci * L4);
+    const __amdgpu_buffer_rsrc_t ry = wg_rsrc((HAS2 ? a.x2 : a.x1) + (size_t)n * Ci * L, Ci * L4);
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      const int co = coBase + row0 + 128 * j;
+      const bool ok = pv & (co < Co);              // (bitwise: a short-circuit turns the load into a branch + vmcnt(0))
+      const int voff = ok ? (co * L + c0 + col) * 4 : WG_OOB;
+      r.g[j] = wg_load(rg, voff);
+      if constexpr (HASC) r.z[j] = wg_load(rz, voff);
+    }
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const int ci = ciBase + row0 + 128 * j;
+      const bool ok = pv & (ci < Ci);
+      const int voff = ok ? (ci * L + c0 + col) * 4 : WG_OOB;
+      r.x[j] = wg_load(rx, voff);
+      if constexpr (HAS2) r.y[j] = wg_load(ry, voff);
+    }
+  };
+  float dsum[JD];
+#pragma unroll
+  for (int j = 0; j < JD; ++j) dsum[j] = 0.f;
+  // piece j < JD: dz_eff rows; piece JD + j: input rows
+  auto commit_piece = [&](int ch, const Regs& r, char* dst, int piece) {
+    const int n = ch / a.cpn;
+    const int c0 = (ch - n * a.cpn) * W3_KC;
+    const bool pv = (ch < ch1) & (c0 + col < L);
+    const int nv = L - (c0 + col);                 // valid elements of this thread's float4 (planes need not be x4 long)
+    unsigned p0, p1, p2, q0, q1, q2;
+    char* base;
+    int tstride;
+    if (piece < JD) {
+      const int j = piece;
+      const int row = row0 + 128 * j;
+      const bool ok = pv & (coBase + row < Co);
+      f32x4 d = r.g[j];
+      if constexpr (HASC) {
+        const f32x2 c = Cs[row];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] += fmaf(c.y, r.z[j][e], c.x);
+      }
+      if (!ok) d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 1; e < 4; ++e) d[e] = e < nv ? d[e] : 0.f;
+      dsum[j] += (d.x + d.y) + (d.z + d.w);
+      b3_split(d.x, d.y, p0, p1, p2);
+      b3_split(d.z, d.w, q0, q1, q2);
+      base = dst + row * W3_RB + col * 2;
+      tstride = TM * W3_RB;
+    } else {
+      const int j = piece - JD;
+      const int row = row0 + 128 * j;
+      const bool ok = pv & (ciBase + row < Ci);
+      const f32x4 p = Ps[row];
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = fmaf(r.x[j][e], p.x, p.y);
+        if constexpr (HAS2) t += fmaf(r.y[j][e], p.z, p.w);
+        v[e] = (ok & (e < nv)) ? fmaxf(t, lo) : 0.f;
+      }
+      b3_split(v.x, v.y, p0, p1, p2);
+      b3_split(v.z, v.w, q0, q1, q2);
+      base = dst + 3 * TM * W3_RB + row * W3_RB + col * 2;
+      tstride = TN * W3_RB;
+    }
+    *reinterpret_cast<u32x2v*>(base) = u32x2v{p0, q0};
+    *reinterpret_cast<u32x2v*>(base + tstride) = u32x2v{p1, q1};
+    *reinterpret_cast<u32x2v*>(base + 2 * tstride) = u32x2v{p2, q2};
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+  const int m0 = (wave >> 1) * (TM / 4), n0 = (wave & 1) * (TN / 2);
+  const int aoff = (m0 + l31) * W3_RB + 16 * half;
+  const int boff = 3 * TM * W3_RB + (n0 + l31) * W3_RB + 16 * half;
+
+  __builtin_amdgcn_sched_barrier(0);
+  issue(ch0, RA);
+  if constexpr (DEPTH == 2) issue(ch0 + 1, RB);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();                                 // Cs / Ps visible (and the first loads landed)
+#pragma unroll
+  for (int pc = 0; pc < JD + JX; ++pc) commit_piece(ch0, RA, B0p, pc);
+  __builtin_amdgcn_sched_barrier(0);
+  issue(ch0 + DEPTH, RA);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // one chunk: its 16 positions' products on `cur` with chunk ch+1's split (register set r) written to `nxt` in between
+  auto step = [&](int ch, const char* cur, char* nxt, Regs& r) {
+    bf16x8 af[MI][3];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        af[mi][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(cur + aoff + (t * TM + 32 * mi) * W3_RB));
+    // input fragments one position sub-block ahead, in two register sets pinned by scheduling barriers (left alone the
+    // compiler hoists all NI x 3 fragment reads to the top: 48 registers it does not have)
+    bf16x8 bfs[2][3];
+    auto loadB = [&](int ni, bf16x8 (&bf)[3]) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        bf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(cur + boff + (t * TN + 32 * ni) * W3_RB));
+    };
+    loadB(0, bfs[0]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      bf16x8 (&bf)[3] = bfs[ni & 1];
+      if (ni + 1 < NI) loadB(ni + 1, bfs[(ni + 1) & 1]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        f32x16 c = acc[mi][ni];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][2], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[0], c, 0, 0, 0);
+        acc[mi][ni] = c;
+      }
+      // the next chunk's split, a piece per position sub-block of products (VALU + LDS stores in the MFMA shadow)
+#pragma unroll
+      for (int pc = ni; pc < JD + JX; pc += NI) commit_piece(ch + 1, r, nxt, pc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issue(ch + 1 + DEPTH, r);                      // this set is free again
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // raw barrier: the loads in flight stay in flight
+  };
+  if constexpr (DEPTH == 2) {
+    // (pairs in the loop, an odd last chunk outside it: a conditional second call would make the compiler allow a
+    // first -> first path and drain the set it has just refilled)
+    int ch = ch0;
+    for (; ch + 1 < ch1; ch += 2) {
+      step(ch, B0p, B1p, RB);
+      step(ch + 1, B1p, B0p, RA);
+    }
+    if (ch < ch1) step(ch, B0p, B1p, RB);
+  } else {
+    char* cur = B0p;
+    char* nxt = B1p;
+    for (int ch = ch0; ch < ch1; ++ch) {
+      step(ch, cur, nxt, RA);
+      char* t = cur; cur = nxt; nxt = t;
+    }
+  }
+
+  // D[i = co][j = ci] -> partial dW of this split
+  float* dw = a.dwp + (size_t)split * a.pstride;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int ci = ciBase + n0 + 32 * ni + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = coBase + m0 + 32 * mi + wg_row32(r, half);
+        if (co < Co && ci < Ci) dw[(size_t)co * Ci + ci] = acc[mi][ni][r];
+      }
+    }
+  // db: the 4 threads that stage one row hold its pieces
+  if (tile / a.tm_tiles == 0) {
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      float s = dsum[j];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      const int co = coBase + row0 + 128 * j;
+      if ((tid & 3) == 0 && co < Co) a.dbp[(size_t)split * a.pstride + co] = s;
+    }
+  }
+}
+
+int g_wg2_target4 = 512, g_wg2_kc128 = 32, g_wg2_target1 = 512, g_wg2_b3 = 1, g_wg3 = 1, g_wg3_target = 256, g_wg3_tm = 128;    // lab knobs (dsgcn_pwconv_tuning keys 7, 8); the values are the product's
+
+struct Wg2Plan { int TM, TN, KC, cpn, chunks, tm_tiles, tn_tiles, splits, cps, b3, v3; size_t lds; };
 
 bool wg2_plan(int n, int Ci, int Co, int L, Wg2Plan* p) {
   if ((long)Ci * L * 4 >= (1L << 31) - 64 || (long)Co * L * 4 >= (1L << 31) - 64) return false;
+  p->v3 = 0;
+  if (g_wg3 && g_wg2_b3 && (Co > 128 || Ci > 128) && Co > 64 && Ci > 64) {     // wide: one workgroup per CU owns the whole tile
+    p->v3 = 1; p->b3 = 1;
+    p->TM = (Co > 128 && (g_wg3_tm == 256 || Ci <= 128)) ? 256 : 128;     // (g_wg3_tm = 128: two 128 x 256 tiles, half the partial rows)
+    p->TN = Ci > 128 ? 256 : 128;
+    p->KC = W3_KC;
+    p->cpn = (L + p->KC - 1) / p->KC;
+    p->chunks = n * p->cpn;
+    p->tm_tiles = (Co + p->TM - 1) / p->TM;
+    p->tn_tiles = (Ci + p->TN - 1) / p->TN;
+    const int tiles = p->tm_tiles * p->tn_tiles;
+    int target = g_wg3_target / tiles;
+    if (target < 1) target = 1;
+    if (tiles > 1) target = (target + 7) / 8 * 8;
+    if (target > p->chunks) target = p->chunks;
+    p->cps = (p->chunks + target - 1) / target;
+    p->splits = (p->chunks + p->cps - 1) / p->cps;
+    p->lds = (size_t)2 * 3 * (p->TM + p->TN) * W3_RB + (size_t)p->TM * 8 + (size_t)p->TN * 16;
+    return true;
+  }
   p->TM = Co > 64 ? 128 : 64;
   p->TN = Ci > 64 ? 128 : 64;
   p->KC = (p->TM == 128 && p->TN == 128) ? g_wg2_kc128 : ((p->TM == 64 && p->TN == 64) ? 128 : 64);
@@ -317,6 +586,24 @@ void wg2_launch(const Wg2Args& a, bool has2, bool hasc, dim3 grid, size_t lds, h
   }
 }
 
+template <int TM, int TN>
+void wg3_launch(const Wg2Args& a, bool has2, bool hasc, dim3 grid, size_t lds, hipStream_t st) {
+  static bool raised = false;
+  if (!raised) {
+    const void* fs[4] = {reinterpret_cast<const void*>(&k_wg3<TM, TN, false, false>), reinterpret_cast<const void*>(&k_wg3<TM, TN, false, true>),
+                         reinterpret_cast<const void*>(&k_wg3<TM, TN, true, false>), reinterpret_cast<const void*>(&k_wg3<TM, TN, true, true>)};
+    for (const void* f : fs) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = true;
+  }
+  if (has2) {
+    if (hasc) hipLaunchKernelGGL((k_wg3<TM, TN, true, true>), grid, dim3(W3_NT), lds, st, a);
+    else hipLaunchKernelGGL((k_wg3<TM, TN, true, false>), grid, dim3(W3_NT), lds, st, a);
+  } else {
+    if (hasc) hipLaunchKernelGGL((k_wg3<TM, TN, false, true>), grid, dim3(W3_NT), lds, st, a);
+    else hipLaunchKernelGGL((k_wg3<TM, TN, false, false>), grid, dim3(W3_NT), lds, st, a);
+  }
+}
+
 }  // namespace
 
 __attribute__((visibility("hidden"))) int dsgcn_wg2_tuning(int key, int value) {
@@ -324,6 +611,9 @@ __attribute__((visibility("hidden"))) int dsgcn_wg2_tuning(int key, int value) {
   else if (key == 1) g_wg2_kc128 = value;
   else if (key == 2) g_wg2_target1 = value;
   else if (key == 3) g_wg2_b3 = value;
+  else if (key == 4) g_wg3 = value;
+  else if (key == 5) g_wg3_target = value;
+  else if (key == 6) g_wg3_tm = value;
   else return DSGCN_EINVAL;
   return 0;
 }
@@ -350,6 +640,13 @@ __attribute__((visibility("hidden"))) int dsgcn_wg2(const float* x1, const float
   const int tiles = p.tm_tiles * p.tn_tiles;
   const dim3 grid(tiles > 1 ? (unsigned)((p.splits + 7) / 8 * 8 * tiles) : (unsigned)p.splits);
   const bool has2 = x2 != nullptr, hasc = A0 != nullptr;
+  if (p.v3) {
+    if (p.TM == 256 && p.TN == 256) wg3_launch<256, 256>(a, has2, hasc, grid, p.lds, st);
+    else if (p.TM == 256) wg3_launch<256, 128>(a, has2, hasc, grid, p.lds, st);
+    else wg3_launch<128, 256>(a, has2, hasc, grid, p.lds, st);
+    DSGCN_LAUNCH_CHECK();
+    return 1;
+  }
   if (p.TM == 128 && p.TN == 128 && p.KC == 64) wg2_launch<128, 128, 64>(a, has2, hasc, grid, p.lds, st);
   else if (p.b3) wg2_launch<128, 128, 32, true>(a, has2, hasc, grid, p.lds, st);
   else if (p.TM == 128 && p.TN == 128) wg2_launch<128, 128, 32>(a, has2, hasc, grid, p.lds, st);

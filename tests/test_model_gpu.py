@@ -365,6 +365,33 @@ def test_bench_step_under_rccl_group_is_bit_identical():
     assert a['hip_graph'] and b['hip_graph']
     assert a['param_sha256'] == b['param_sha256'], (a['param_sha256'], b['param_sha256'])
     assert a['final_loss'] == b['final_loss']
+    d = b['dist']                                   # the fields a multi-GPU run is diagnosed by
+    assert d['backend'] == 'nccl' and d['world_size'] == 1 and len(d['rank_ms_per_step']) == 1
+    assert d['allreduce_ms'] > 0 and d['grad_bytes'] > 5_000_000 and d['rccl_version'].count('.') == 2
+
+
+def test_bench_through_torch_distributed_run():
+    """The driver's launch path at N > 1, on the one GPU a test box has: ``python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 1 --master-addr 127.0.0.1 --master-port P bench.py --gpus 1 ...`` (reference tools/dist_train.sh:9-11) —
+    the launcher is a fresh child started before anything touches the GPU, the rank reads RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* from the environment it sets, builds the RCCL group (forced at one rank) and must end bit-identical to the
+    plain run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29900 + os.getpid() % 90
+    a = _run_bench_child({}, '--steps', '2', '--warmup', '4', '--clips-per-gpu', '8')
+    env = dict(os.environ, DSGCN_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+                          '--gpus', '1', '--steps', '2', '--warmup', '4', '--clips-per-gpu', '8', '--no-cpu-baseline',
+                          '--no-roofline'], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    b = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert b['hip_graph'] and b['n_gpus'] == 1 and b['dist']['world_size'] == 1
+    assert a['param_sha256'] == b['param_sha256'] and a['final_loss'] == b['final_loss']
 
 
 @pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_dggcn', 'model_reduced_stgcnpp'])

@@ -147,7 +147,72 @@ def bench(keys, n, reps=20, nsets=4):
         print(f'k14={k}: total fwd {tot[k][0]:.0f} us, dgrad {tot[k][1]:.0f} us')
 
 
+def wgrad(n_check, n_bench, reps=20, nsets=4):
+    """Weight gradient: k_wg2 (lab key 15 = 0) against k_wg3 (15 = 1): accuracy vs fp64 at n_check, HBM-cold times at n_bench."""
+    print(f'weight gradient: relative L2 of dW, db vs fp64 (n = {n_check}) | HBM-cold us (n = {n_bench})')
+    for name, Ci, Co, T, mode in SHAPES:
+        torch.manual_seed(Ci * 3 + Co)
+        s1 = (torch.rand(Ci, device=dev) + .5) if mode else None
+        h1 = (torch.randn(Ci, device=dev) * .1) if mode else None
+        A0 = torch.randn(Co, device=dev) * 1e-1; B0 = torch.randn(Co, device=dev) * 1e-1
+        relu = 1 if mode else 0
+        line = f'{name:8s} {Ci:4d}->{Co:4d} T={T:2d} m{mode}'
+        for key in (0, 1):
+            assert lib.dsgcn_pwconv_tuning(15, key) == 0
+            for hasc in ((True,) if mode != 0 else (True, False)):
+                res = []
+                for n, timed in ((n_check, False), (n_bench, True)):
+                    sets = [operands(n, Ci, Co, T, mode, 20 + i) for i in range(nsets if timed else 1)]
+                    for q in sets:
+                        q['z'].normal_()
+                    splits = lib.dsgcn_pwconv_wgrad_splits(n, Ci, Co, T, V, 1)
+                    pstride = Co * Ci + Co
+                    wpart = torch.zeros(splits, pstride, device=dev)
+
+                    def fn(q):
+                        assert lib.dsgcn_pwconv_wgrad(P(q['x1']), P(s1), P(h1), P(q['x2']), None, None, relu, P(q['z']) if hasc else None,
+                                                      None, P(q['gz']), None, P(A0) if hasc else None, P(B0) if hasc else None,
+                                                      wpart.data_ptr(), wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, 1, 0, st) == 0
+                    if not timed:
+                        q = sets[0]
+                        fn(q)
+                        torch.cuda.synchronize()
+                        v = q['x1'].double()
+                        if mode:
+                            v = v * s1.double().view(1, -1, 1, 1) + h1.double().view(1, -1, 1, 1)
+                            if mode == 2:
+                                v = v + q['x2'].double()
+                            v = v.clamp_min(0)
+                        dze = q['gz'].double()
+                        if hasc:
+                            dze = dze + A0.double().view(1, -1, 1, 1) + B0.double().view(1, -1, 1, 1) * q['z'].double()
+                        dwr = torch.einsum('notv,nctv->oc', dze, v)
+                        dw = wpart.double().sum(0)
+                        e1, e2 = rel(dw[:Co * Ci].view(Co, Ci), dwr), rel(dw[Co * Ci:], dze.sum((0, 2, 3)))
+                        res.append(f'{e1:.1e} {e2:.1e}' + ('' if e1 < 3e-7 and e2 < 2e-5 else ' <-- FAIL'))
+                    else:
+                        for q in sets:
+                            fn(q)
+                        torch.cuda.synchronize()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for r in range(reps):
+                            fn(sets[r % nsets])
+                        e1.record()
+                        torch.cuda.synchronize()
+                        us = e0.elapsed_time(e1) / reps * 1e3
+                        nb = 4 * n * T * V * ((2 if hasc else 1) * Co + Ci * (2 if mode == 2 else 1))
+                        res.append(f'{us:6.1f} us {nb / us / 1e6:4.2f} TB/s splits {splits}')
+                line += f' | wg3={key}{"" if hasc else " noBN"}: ' + ' | '.join(res)
+        print(line, flush=True)
+    assert lib.dsgcn_pwconv_tuning(15, 1) == 0
+
+
 if __name__ == '__main__':
-    keys = [int(a) for a in sys.argv[1:]] or [1, 2]
-    check(keys, int(os.environ.get('KC_CHECK_N', 6)))
-    bench(keys, int(os.environ.get('KC_N', 128)))
+    args = [a for a in sys.argv[1:] if a != 'wgrad']
+    if 'wgrad' in sys.argv[1:]:
+        wgrad(int(os.environ.get('KC_CHECK_N', 6)), int(os.environ.get('KC_N', 128)))
+    if args or 'wgrad' not in sys.argv[1:]:
+        keys = [int(a) for a in args] or [1, 2]
+        check(keys, int(os.environ.get('KC_CHECK_N', 6)))
+        bench(keys, int(os.environ.get('KC_N', 128)))
