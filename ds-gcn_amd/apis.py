@@ -68,14 +68,25 @@ def epoch_indices(n, epoch, seed, rank, world, shuffle=True):
 
 
 class _BatchSource:
-    """index list -> (keypoint (B, clips, M, T, V, C) float32, label (B, 1) int64) on the device."""
+    """index list -> (keypoint (B, clips, M, T, V, C) float32, label (B, 1) int64) on the device.
 
-    def __init__(self, dataset, device):
+    With the resident (``SkeletonStore``, ``SkeletonBatcher``) pair the host half of a batch (``plan``: RNG draws + index
+    gathers) is made ONE BATCH AHEAD on a feeder thread while the device runs the current step: ``batch(idx, nxt)`` hands
+    back the batch for ``idx`` and starts the plan for ``nxt``.  One worker, one plan at a time, in loop order: numpy's
+    global RNG is consumed in exactly the order of the unthreaded loop."""
+
+    def __init__(self, dataset, device, prefetch=True):
         self.device = device
         self.store = self.batcher = None
+        self._pool = self._pending = self._pending_key = None
         if isinstance(dataset, (tuple, list)) and len(dataset) == 2 and hasattr(dataset[1], 'plan'):
             self.store, self.batcher = dataset
             self.n = len(self.store)
+            if hasattr(self.batcher, 'prepare'):
+                self.batcher.prepare(self.store)          # the per-clip decisions, once (first epoch at full rate)
+            if prefetch:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='dsgcn-feeder')
         else:
             self.dataset = dataset
             self.n = len(dataset)
@@ -83,9 +94,25 @@ class _BatchSource:
     def __len__(self):
         return self.n
 
-    def batch(self, indices):
+    def _plan(self, indices):
+        key = tuple(indices)
+        if self._pending is not None:
+            fut, pkey = self._pending, self._pending_key
+            self._pending = self._pending_key = None
+            plan = fut.result()                           # (also orders the RNG: the feeder has finished its draws)
+            if pkey == key:
+                return plan
+            raise RuntimeError('_BatchSource: the batch asked for is not the one announced as next')
+        return self.batcher.plan(self.store, indices)
+
+    def batch(self, indices, next_indices=None):
         if self.store is not None:
-            return self.batcher(self.store, indices)
+            plan = self._plan(indices)
+            if self._pool is not None and next_indices is not None and len(next_indices):
+                nxt = list(next_indices)
+                self._pending_key = tuple(nxt)
+                self._pending = self._pool.submit(self.batcher.plan, self.store, nxt)
+            return self.batcher.run(self.store, plan)
         items = [self.dataset[i] for i in indices]
         kp = torch.stack([torch.as_tensor(np.asarray(it['keypoint']), dtype=torch.float32) for it in items])
         lb = torch.as_tensor([int(np.asarray(it['label']).reshape(-1)[0]) for it in items], dtype=torch.int64).view(-1, 1)
@@ -142,7 +169,8 @@ class EpochRunner:
         pending, t0 = [], time.perf_counter()
         for b in range(self.iters_per_epoch):
             idx = order[b * self.batch_size:(b + 1) * self.batch_size]
-            kp, lb = self.source.batch(idx)
+            nxt = order[(b + 1) * self.batch_size:(b + 2) * self.batch_size] if b + 1 < self.iters_per_epoch else None
+            kp, lb = self.source.batch(idx, nxt)
             lr = self.current_lr()                                    # before_train_iter
             logs = self.engine.step(kp, lb, lr)                       # run_iter + after_train_iter (OptimizerHook)
             # a replayed hipGraph hands back the SAME static tensors every iteration: keep this iteration's values
@@ -310,7 +338,7 @@ class EvalLoop:
 
 
 def train_model(model, dataset, cfg, distributed=None, validate=False, test=None, timestamp=None, meta=None,
-                device='cuda', logger=None, use_graph=True, val_dataset=None):
+                device='cuda', logger=None, use_graph=True, val_dataset=None, prefetch=True):
     """Train ``model`` on ``dataset`` the way the reference's ``train_model`` does for the skeleton configs; returns the
     ``EpochRunner`` (its ``.log`` holds the interval records, ``.engine`` the optimizer state).
 
@@ -318,7 +346,8 @@ def train_model(model, dataset, cfg, distributed=None, validate=False, test=None
     ``total_epochs``, ``checkpoint_config``, ``log_config.interval``, ``work_dir``, ``seed``, ``resume_from`` / ``load_from`` /
     ``auto_resume``; with ``validate=True`` also ``evaluation`` and ``data.val`` / ``data.val_dataloader`` (``val_dataset``
     overrides ``data.val``: a map-style dataset or a (``SkeletonStore``, ``SkeletonBatcher``) pair built for the val
-    pipeline).  ``runner.evaluator.results`` holds the evaluation records."""
+    pipeline).  ``runner.evaluator.results`` holds the evaluation records.  ``prefetch``: plan the next batch of a resident
+    store on a feeder thread while the device runs the current step (same RNG stream either way)."""
     if isinstance(dataset, list) and len(dataset) == 1:
         dataset = dataset[0]
     opt_cfg = dict(_get(cfg, 'optimizer', None) or dict(type='SGD', lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True))
@@ -332,7 +361,7 @@ def train_model(model, dataset, cfg, distributed=None, validate=False, test=None
     engine = TrainEngine(model, lr=opt_cfg.get('lr', 0.1), momentum=opt_cfg.get('momentum', 0),
                          weight_decay=opt_cfg.get('weight_decay', 0), nesterov=opt_cfg.get('nesterov', False),
                          use_graph=use_graph, strict_graph=world > 1)
-    source = _BatchSource(dataset, next(model.parameters()).device)
+    source = _BatchSource(dataset, next(model.parameters()).device, prefetch=prefetch)
     work_dir = _get(cfg, 'work_dir', None)
     runner = EpochRunner(model, engine, source, cfg, work_dir=work_dir, meta=meta, logger=logger)
     if validate:

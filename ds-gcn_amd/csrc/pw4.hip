@@ -658,18 +658,15 @@ __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
 }
 
 
-// ---- K-C, GEMM form with the weights split ahead of the launch ("pwg2") ---------------------------------------------
+// ---- K-C, GEMM form with the weights split ahead of the launch -----------------------------------------------------------
 // k_pwg spends as many VALU cycles on the three-way bf16 split as the matrix core spends on the six products (rocprofv3
 // counters, profiles/r03: 9.8 M VALU instructions x 4 cycles against 39 M MFMA-busy cycles per 256 -> 256 launch, matrix
-// pipe 27 % busy) and half of that split is the WEIGHT tile, which is the same for every workgroup and every chunk
-// revisit.  Here the weights arrive already split (k_wsplit below: one small launch per conv and step, both the W and the
-// W^T image, k contiguous, zero-padded to whole tiles) and are only copied into LDS; and a conv with more than 128 output
-// rows runs 256 rows per workgroup (8 waves x 32 rows over the SAME 128-position tile), so the activation tile is loaded
-// and split once per 256 rows instead of once per 128.  Per wave and 32-channel chunk that leaves 8 activation values to
-// split (k_pwg: 16 + 16 weight values) in front of the same 48 MFMAs.
+// pipe 27 % busy) and half of that split is the WEIGHT tile, the same for every workgroup and every chunk revisit: the
+// weights are therefore split once per conv and step (k_wsplit below, the W and the W^T image).  Round 3's consumer of
+// that image (k_pwg2: eight waves on one position tile, the weight chunk copied through LDS, two barriers per chunk) is
+// gone; k_pwg3 below replaced it (same-box A/B of the step: 13.03 -> 12.55 ms, profiles/r04).
 #ifdef DSGCN_LAB
-// wall-clock stamps (10 ns) of workgroup 0, thread 0: [0] start, [1] operands issued, then per chunk (commit done,
-// barrier passed, products done), the last two: main loop drained, epilogue done; [63] = count.  dsgcn_pwg2_phases reads them
+// wall-clock stamps (10 ns) of one workgroup's thread 0 (include/dsgcn_lab.h: dsgcn_pwg2_phases), [63] = count
 __device__ long long g_pwg_stamp[64];
 __device__ int g_pwg_stamp_block = 0;            // which workgroup stamps (dsgcn_pwg2_phases_block)
 #define PWG_STAMP_BLOCK g_pwg_stamp_block
@@ -678,195 +675,8 @@ __device__ int g_pwg_stamp_block = 0;            // which workgroup stamps (dsgc
 #define PWG_STAMP() do {} while (0)
 #endif
 
-template <int MODE, int EPI, int NWV>
-__global__ __launch_bounds__(64 * NWV, 2) void k_pwg2(Pw4Args a, const unsigned short* __restrict__ wsp, int Mp) {
-  typedef VQ<4>::T vq;
-  constexpr int NTH = 64 * NWV, TA = 32 * NWV;     // threads; A rows per workgroup
-  constexpr int CPT = 32 / (NTH / 32);             // activation channels per loader thread and chunk: 4 or 2
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-#ifdef DSGCN_LAB
-  int nst = 0;
-#endif
-  PWG_STAMP();
-  char* Ab = reinterpret_cast<char*>(lds);                               // [3][TA rows][RB]
-  char* Bb = Ab + 3 * TA * PG_RB;                                        // [3][128 position slots][RB]
-  f32x4* Ps = reinterpret_cast<f32x4*>(Bb + 3 * PG_T * PG_RB);           // [Kpad] (s1, h1, s2, h2)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  const int ngrp = a.WT;
-  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-  const int cz = slot % a.cc;
-  const int grp = (slot / a.cc) * 8 + xcd;
-  if (grp >= ngrp) return;
-  const int mBase0 = cz * TA, mBase = mBase0 + 32 * wave;
-  const int K = a.K, M = a.M, L = a.L, Kpad = a.Kpad;
-  const int Lq = a.Lq;                             // (ragged planes: see k_pw4)
-  const int g0 = grp * 128;
-  const int n = g0 / Lq;
-  int pos = g0 - n * Lq + l31 * 4;
-  int ds = 0;
-  while (pos >= Lq) { pos -= Lq; ++ds; }
-  const bool pok = n + ds < a.n;
-  int skip = 0;
-  if (L - pos < 4) { skip = 4 - (L - pos); pos = L - 4; }
-  const int L4 = L * 4;
-  const int nrem = a.n - n < a.span ? a.n - n : a.span;
-  const __amdgpu_buffer_rsrc_t r1 = p4_rsrc(a.b1 + (size_t)n * K * L, nrem * K * L4);
-  const __amdgpu_buffer_rsrc_t r2 = p4_rsrc((MODE == 2 ? a.b2 : a.b1) + (size_t)n * K * L, MODE == 2 ? nrem * K * L4 : 0);
-  // B loader: channels CPT*cg .. of the chunk (cg = tid / 32) at the lane's own position quad
-  const int cg = tid >> 5;
-  const int voffB = pok ? ds * K * L4 + pos * 4 : P4_OOB;
-  vq bwA[CPT], bwB[CPT], bw2A[MODE == 2 ? CPT : 1], bw2B[MODE == 2 ? CPT : 1];   // two chunks of B in flight (ping-pong sets)
-  auto issueB = [&](int ch0, vq (&bw)[CPT], vq (&bw2)[MODE == 2 ? CPT : 1]) {
-#pragma unroll
-    for (int e = 0; e < CPT; ++e) {
-      const int c = ch0 + CPT * cg + e;
-      const int vo = c < K ? voffB + c * L4 : P4_OOB;
-      bw[e] = p4_load<4>(r1, vo, 0);
-      if constexpr (MODE == 2) bw2[e] = p4_load<4>(r2, vo, 0);
-    }
-  };
-  // A loader: the chunk's image is 3 terms x TA rows x 64 B = 6 pieces of 16 B per thread; piece j of thread tid is
-  // term j/2, row (tid + NTH*(j&1)) / 4, 16-byte column (tid & 3).  The planes are padded to whole tiles: no bounds.
-  const __amdgpu_buffer_rsrc_t rw = p4_rsrc(wsp, 3 * Mp * Kpad * 2);
-  u32x4v aw[6];
-  int offA[6], ldsA[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int term = j >> 1, rem = tid + NTH * (j & 1), row = rem >> 2, piece = rem & 3;
-    offA[j] = ((term * Mp + mBase0 + row) * Kpad + piece * 8) * 2;
-    ldsA[j] = (term * TA + row) * PG_RB + piece * 16;
-  }
-  auto issueA = [&](int ch0) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      aw[j] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, ch0 < Kpad ? offA[j] + ch0 * 2 : P4_OOB, 0, 0));
-  };
-  const float lo = a.relu ? 0.f : -__builtin_inff();
-  auto commit = [&](int ch0, vq (&bw)[CPT], vq (&bw2)[MODE == 2 ? CPT : 1]) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4v*>(Ab + ldsA[j]) = aw[j];
-    f32x4 pr[CPT];
-    if (MODE != 0) {
-#pragma unroll
-      for (int e = 0; e < CPT; ++e) pr[e] = Ps[ch0 + CPT * cg + e];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v[CPT];
-#pragma unroll
-      for (int e = 0; e < CPT; ++e) {
-        float x = bw[e][q];
-        if (MODE != 0) {
-          x = fmaf(x, pr[e].x, pr[e].y);
-          if constexpr (MODE == 2) x += fmaf(bw2[e][q], pr[e].z, pr[e].w);
-          x = fmaxf(x, lo);
-        }
-        v[e] = x;
-      }
-      char* base = Bb + (32 * q + l31) * PG_RB + cg * (2 * CPT);
-      unsigned p0, p1, p2;
-      b3_split(v[0], v[1], p0, p1, p2);
-      if constexpr (CPT == 4) {
-        unsigned q0, q1, q2;
-        b3_split(v[2], v[3], q0, q1, q2);
-        *reinterpret_cast<u32x2v*>(base) = u32x2v{p0, q0};
-        *reinterpret_cast<u32x2v*>(base + PG_T * PG_RB) = u32x2v{p1, q1};
-        *reinterpret_cast<u32x2v*>(base + 2 * PG_T * PG_RB) = u32x2v{p2, q2};
-      } else {
-        *reinterpret_cast<unsigned*>(base) = p0;
-        *reinterpret_cast<unsigned*>(base + PG_T * PG_RB) = p1;
-        *reinterpret_cast<unsigned*>(base + 2 * PG_T * PG_RB) = p2;
-      }
-    }
-  };
-
-  // bias into the accumulators first: these loads and the affine table's share one round trip, the operand loads follow
-  f32x16 acc[1][4];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = mBase + p4_row32(i, half);
-    const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[0][q][i] = b0;
-  }
-  if (MODE != 0) {                                 // (before the operand loads: its own loads end in a vmcnt(0))
-    for (int i = tid; i < Kpad; i += NTH) {
-      f32x4 p = {0.f, 0.f, 0.f, 0.f};
-      if (i < K) {
-        p.x = a.ps1 ? a.ps1[i] : 1.f;
-        p.y = a.ph1 ? a.ph1[i] : 0.f;
-        p.z = a.ps2 ? a.ps2[i] : 1.f;
-        p.w = a.ph2 ? a.ph2[i] : 0.f;
-      }
-      Ps[i] = p;
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  issueA(0);
-  issueB(0, bwA, bw2A);
-  issueB(PG_KC, bwB, bw2B);
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                    // Ps visible (raw barrier: the operand loads stay in flight)
-  PWG_STAMP();
-  const char* Af = Ab + (32 * wave + l31) * PG_RB + 16 * half;
-  const char* Bf = Bb + l31 * PG_RB + 16 * half;
-  auto chunk = [&](int ch0, vq (&bw)[CPT], vq (&bw2)[MODE == 2 ? CPT : 1]) {
-    commit(ch0, bw, bw2);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    PWG_STAMP();
-    __builtin_amdgcn_s_barrier();
-    PWG_STAMP();
-    __builtin_amdgcn_sched_barrier(0);
-    issueA(ch0 + PG_KC);                           // (past K: an out-of-range offset, zeros)
-    issueB(ch0 + 2 * PG_KC, bw, bw2);              // this set is free again: two chunks ahead
-    __builtin_amdgcn_sched_barrier(0);             // pinned here, in this order: the next commit's vmcnt leaves this set in flight
-#pragma unroll
-    for (int ks = 0; ks < PG_KC / 16; ++ks) {
-      bf16x8 af[3];
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-        af[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Af + t * TA * PG_RB + 32 * ks));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        bf16x8 bf[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-          bf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Bf + (t * PG_T + 32 * q) * PG_RB + 32 * ks));
-        f32x16 c = acc[0][q];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], c, 0, 0, 0);
-        acc[0][q] = c;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                  // raw barrier: the loads in flight stay in flight
-    PWG_STAMP();
-  };
-  int ch0 = 0;
-  for (; ch0 + PG_KC < Kpad; ch0 += 2 * PG_KC) {
-    chunk(ch0, bwA, bw2A);
-    chunk(ch0 + PG_KC, bwB, bw2B);
-  }
-  if (ch0 < Kpad) chunk(ch0, bwA, bw2A);
-  __syncthreads();                                 // drains the read-ahead loads before LDS is reused
-  PWG_STAMP();
-  const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, true, pok, skip};
-  p4_epilogue<1, 4, EPI, true, NWV>(a, acc, lds, tile);
-  PWG_STAMP();
-#ifdef DSGCN_LAB
-  if (blockIdx.x == PWG_STAMP_BLOCK && threadIdx.x == 0) g_pwg_stamp[63] = nst;
-#endif
-}
-
 // ---- K-C, GEMM form, third generation ("pwg3"): two independent workgroups per CU, one barrier per chunk ------------
-// What the lab stamps of k_pwg2 showed (profiles/r03/README.md): a workgroup's life is prologue -> 8 x (commit + barrier +
+// What the lab stamps of round 3's k_pwg2 showed (profiles/r03/README.md): a workgroup's life is prologue -> 8 x (commit + barrier +
 // products + barrier) -> epilogue with all eight waves of the CU in lockstep; the matrix pipe idles through every commit
 // and through the HBM-bound epilogue (15 us of 45 in the data gradient), and 400 position tiles on 256 one-workgroup CUs
 // make two rounds.  Here:
@@ -1148,7 +958,7 @@ WsDims ws_dims(int Ci, int Co) {
   return d;
 }
 
-int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128, g_p4_ws = 2;   // ws: 1 = k_pwg2 (row-major image), 2 = k_pwg3 (fragment-order image)
+int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128, g_p4_ws = 2;   // ws: 2 = k_pwg3 on the fragment-order image; 1 = row-major image (lab A/B: no consumer left, k_pwg runs); g_p4_pd unused
 
 struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad, gemm, Lq; size_t lds; unsigned grid; };
 
@@ -1170,8 +980,7 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
   if (g_p4_mt) MT = g_p4_mt < mtiles ? g_p4_mt : mtiles;
   if (MT * NQ > 8 && !ragged) NQ = 2;
   if (MT * NQ > 8) MT = ragged ? 2 : 4;
-  int PD = NQ == 4 ? 8 : 16;
-  if (g_p4_pd == 8 || g_p4_pd == 16) PD = g_p4_pd;
+  const int PD = NQ == 4 ? 8 : 16;
   // samples a wave's 32*NQ-position tile can touch; its buffer resources span that many planes (32-bit offsets)
   const int Lq = (L + NQ - 1) / NQ * NQ;
   const int span = (32 * NQ + Lq - 1) / Lq + 1;
@@ -1218,33 +1027,6 @@ void p4_launch_cfg(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStre
   }
 }
 
-// the pre-split form: NWV = 8 (256 rows per workgroup) when the conv has more than 128 output rows
-template <int NWV>
-void pwg2_launch(Pw4Args a, int mode, int epi, const P4Plan& p, const unsigned short* wsp, int Mp, hipStream_t st) {
-  constexpr int TA = 32 * NWV;
-  a.cc = (a.M + TA - 1) / TA;
-  const size_t main_b = (size_t)3 * (TA + PG_T) * PG_RB + (size_t)p.Kpad * 16;
-  const size_t epi_b = (size_t)NWV * (3 * 32 * 36 + 32 * 3 + 32 * 4) * sizeof(float);
-  const size_t lds = main_b > epi_b ? main_b : epi_b;
-  static bool raised = false;
-  if (!raised) {
-    const void* fs[5] = {reinterpret_cast<const void*>(&k_pwg2<0, 0, NWV>), reinterpret_cast<const void*>(&k_pwg2<1, 0, NWV>),
-                         reinterpret_cast<const void*>(&k_pwg2<2, 0, NWV>), reinterpret_cast<const void*>(&k_pwg2<0, 1, NWV>),
-                         reinterpret_cast<const void*>(&k_pwg2<2, 1, NWV>)};
-    for (const void* f : fs) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    raised = true;
-  }
-  const dim3 grid((unsigned)((p.ngrp + 7) / 8 * 8 * a.cc)), blk(64 * NWV);
-  if (epi == 0) {
-    if (mode == 0) hipLaunchKernelGGL((k_pwg2<0, 0, NWV>), grid, blk, lds, st, a, wsp, Mp);
-    else if (mode == 1) hipLaunchKernelGGL((k_pwg2<1, 0, NWV>), grid, blk, lds, st, a, wsp, Mp);
-    else hipLaunchKernelGGL((k_pwg2<2, 0, NWV>), grid, blk, lds, st, a, wsp, Mp);
-  } else {
-    if (mode == 0) hipLaunchKernelGGL((k_pwg2<0, 1, NWV>), grid, blk, lds, st, a, wsp, Mp);
-    else hipLaunchKernelGGL((k_pwg2<2, 1, NWV>), grid, blk, lds, st, a, wsp, Mp);
-  }
-}
-
 // the fragment-image form: MT = 2 (256 rows per workgroup) when the conv has more than 128 output rows
 template <int MT>
 void pwg3_launch(Pw4Args a, int mode, int epi, const P4Plan& p, const unsigned short* wfr, int Mp, hipStream_t st) {
@@ -1282,11 +1064,6 @@ bool p4_launch_pd(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStrea
     else pwg3_launch<1>(a, mode, epi, p, wsp, Mp, st);
     return true;
   }
-  if (p.gemm && wsp && g_p4_ws) {
-    if (a.M > 128) pwg2_launch<8>(a, mode, epi, p, wsp, Mp, st);
-    else pwg2_launch<4>(a, mode, epi, p, wsp, Mp, st);
-    return true;
-  }
   if (p.gemm) {
     static bool raised = false;                    // 64 KB+ of dynamic LDS
     if (!raised) {
@@ -1308,13 +1085,20 @@ bool p4_launch_pd(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStrea
     }
     return true;
   }
-  switch (key) {
-    case 14: p4_launch_cfg<1, 4, PD>(a, mode, epi, p, st); return true;
-    case 24: p4_launch_cfg<2, 4, PD>(a, mode, epi, p, st); return true;
-    case 12: p4_launch_cfg<1, 2, PD>(a, mode, epi, p, st); return true;
-    case 22: p4_launch_cfg<2, 2, PD>(a, mode, epi, p, st); return true;
-    case 32: p4_launch_cfg<3, 2, PD>(a, mode, epi, p, st); return true;
-    case 42: p4_launch_cfg<4, 2, PD>(a, mode, epi, p, st); return true;
+  // only the prefetch depth the plan chooses for each quad width is instantiated (4-position quads: 8 k-steps, 2-position
+  // quads: 16): the other combinations were never launched and compiled to 140-VGPR-spill code objects
+  if constexpr (PD == 8) {
+    switch (key) {
+      case 14: p4_launch_cfg<1, 4, PD>(a, mode, epi, p, st); return true;
+      case 24: p4_launch_cfg<2, 4, PD>(a, mode, epi, p, st); return true;
+    }
+  } else {
+    switch (key) {
+      case 12: p4_launch_cfg<1, 2, PD>(a, mode, epi, p, st); return true;
+      case 22: p4_launch_cfg<2, 2, PD>(a, mode, epi, p, st); return true;
+      case 32: p4_launch_cfg<3, 2, PD>(a, mode, epi, p, st); return true;
+      case 42: p4_launch_cfg<4, 2, PD>(a, mode, epi, p, st); return true;
+    }
   }
   return false;
 }

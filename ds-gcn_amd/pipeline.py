@@ -119,6 +119,19 @@ def euler_rotation(theta):
     return rz @ ry @ rx
 
 
+def euler_rotations(thetas):
+    """``euler_rotation`` for a stack of angle triples (N, 3) -> (N, 3, 3) in one pass (batched matmul: the last bit of a
+    float64 entry may differ from the 2-D product's, far below the fp32 the kernel receives)."""
+    th = np.asarray(thetas, dtype=np.float64).reshape(-1, 3)
+    c, s = np.cos(th), np.sin(th)
+    n = len(th)
+    rx = np.zeros((n, 3, 3)); ry = np.zeros((n, 3, 3)); rz = np.zeros((n, 3, 3))
+    rx[:, 0, 0] = 1; rx[:, 1, 1] = c[:, 0]; rx[:, 1, 2] = s[:, 0]; rx[:, 2, 1] = -s[:, 0]; rx[:, 2, 2] = c[:, 0]
+    ry[:, 1, 1] = 1; ry[:, 0, 0] = c[:, 1]; ry[:, 0, 2] = -s[:, 1]; ry[:, 2, 0] = s[:, 1]; ry[:, 2, 2] = c[:, 1]
+    rz[:, 2, 2] = 1; rz[:, 0, 0] = c[:, 2]; rz[:, 0, 1] = s[:, 2]; rz[:, 1, 0] = -s[:, 2]; rz[:, 1, 1] = c[:, 2]
+    return rz @ ry @ rx
+
+
 def uniform_frame_indices(num_frames, clip_len, num_clips=1, test_mode=False, p_interval=(1, 1), seed=255):
     """Frame indices of UniformSampleFrames (sampling.py:49-151), consuming numpy's global RNG draw for draw like the
     reference: per clip one rand() (crop ratio), one randint (crop offset), then the case-specific draws.
@@ -143,7 +156,7 @@ def uniform_frame_indices(num_frames, clip_len, num_clips=1, test_mode=False, p_
             bump[picks] = 1
             inds = np.arange(clip_len) + np.cumsum(bump)[:-1]
         else:
-            edges = np.array([i * nf // clip_len for i in range(clip_len + 1)])
+            edges = np.arange(clip_len + 1) * nf // clip_len            # (= [i * nf // clip_len for i in ...])
             inds = edges[:clip_len] + np.random.randint(np.diff(edges))
         out.append(inds + off)
     return np.mod(np.concatenate(out), num_frames).astype(np.int64)
@@ -212,11 +225,19 @@ class RandomRot:
     def __init__(self, theta=0.3):
         self.theta = theta
 
+    def draw_angles(self, C):
+        """The RNG draws of one call, as the reference makes them: three angles (C = 3) or one (C = 2) -> (3,) float64."""
+        if C == 3:
+            return np.random.uniform(-self.theta, self.theta, size=3)
+        th = np.random.uniform(-self.theta)          # sic: the reference passes only `low` (high defaults to 1.0)
+        return np.array([th, 0.0, 0.0])
+
     def draw(self, C):
         """The rotation matrix of one call (C x C), consuming the RNG as the reference does."""
+        ang = self.draw_angles(C)
         if C == 3:
-            return euler_rotation(np.random.uniform(-self.theta, self.theta, size=3))
-        th = np.random.uniform(-self.theta)          # sic: the reference passes only `low` (high defaults to 1.0)
+            return euler_rotation(ang)
+        th = ang[0]
         return np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
 
     def __call__(self, results):
@@ -557,53 +578,100 @@ class SkeletonBatcher:
         if [rank[t] for t in want] != sorted(rank[t] for t in want):
             raise NotImplementedError('SkeletonBatcher: transforms must come in the order normalise, rotate, features, sample')
 
-    def plan(self, store, indices):
-        """Host decisions for the clips ``indices`` of ``store`` -> dict of small numpy arrays (see dsgcn_skeleton_prep)."""
-        N = len(indices)
-        clip_len, num_clips = self.sample.clip_len, self.sample.num_clips
-        F = num_clips * clip_len
+    # ---- host decisions ---------------------------------------------------------------------------------------------
+    # A clip's geometry decisions (kept frames, person order, centre, alignment matrix, "nothing to rotate") depend on the
+    # clip alone: they are made once per clip and kept on the store; what a batch costs on the host afterwards is the RNG
+    # draws — clip by clip, in the reference's order — and a few array gathers over the whole batch.  (Round 3 redid the
+    # per-clip numpy work every epoch: 3.4 k clips/s on one thread, below the 5 k clips/s step; profiles/r04/pipeline.txt.)
+
+    def _table(self, store):
+        n3 = self.norm3d
+        key = ('none',) if n3 is None else ('norm3d', tuple(n3.zaxis), tuple(n3.xaxis), bool(n3.align_spine),
+                                            bool(n3.align_center))
+        cache = store.__dict__.setdefault('_decisions', {})
+        if key not in cache:
+            n, tmax = len(store.host), int(max(k.shape[1] for k in store.host))
+            cache[key] = dict(done=np.zeros(n, bool), frames=np.zeros((n, tmax), np.int32), nf=np.zeros(n, np.int32),
+                              swap=np.zeros(n, bool), masked=np.zeros(n, bool), allzero=np.zeros(n, bool),
+                              center=np.zeros((n, 3)), matrix=np.tile(np.eye(3), (n, 1, 1)),
+                              f16=np.array([k.dtype == np.float16 for k in store.src]))
+        return cache[key]
+
+    def _decide(self, store, tab, idx):
+        """The deterministic decisions of clip ``idx`` (what round 3's plan() recomputed per batch)."""
+        kp = store.host[idx][..., :store.coordC]          # coordinates only: a score channel is not geometry
+        T = kp.shape[1]
+        frames, swap, masked = np.arange(T), False, False
+        center, mat = np.zeros(3), np.eye(3)
+        allzero = bool(np.all(np.isclose(kp, 0)))
+        if self.norm3d is not None:
+            n = self.norm3d
+            d = normalize3d_decision(kp, n.zaxis, n.xaxis, n.align_spine, n.align_center)
+            if d['active']:
+                frames, swap = d['frames'], d['swap']
+                if n.align_center:
+                    center, masked = d['center'], True
+                    kept = kp[:, frames]            # RandomRot's "nothing to rotate" test sees the centred clip
+                    allzero = bool(np.all(np.isclose((kept - center) * ((kept != 0).sum(-1) > 0)[..., None], 0)))
+                mat = d['matrix']
+        tab['frames'][idx, :len(frames)] = frames
+        tab['nf'][idx], tab['swap'][idx], tab['masked'][idx], tab['allzero'][idx] = len(frames), swap, masked, allzero
+        tab['center'][idx], tab['matrix'][idx] = center, mat
+        tab['done'][idx] = True
+
+    def prepare(self, store, indices=None):
+        """Make the per-clip decisions ahead of time (all clips, or ``indices``): the first epoch then runs at the rate of
+        the later ones."""
         if self.norm2d is not None:
             store.normalize2d(self.norm2d.img_shape)      # once per store (deterministic): per-clip img_shape, source dtype
         if self.norm3d is not None and store.coordC != 3:
             raise ValueError('PreNormalize3D needs 3-D keypoints')
-        p = dict(offset=np.zeros(N, np.int64), M=np.zeros(N, np.int32), T=np.zeros(N, np.int32),
-                 flags=np.zeros(N, np.int32), center=np.zeros((N, 3), np.float32), matrix=np.zeros((N, 9), np.float32),
-                 f0=np.zeros((N, F), np.int32), f1=np.zeros((N, F), np.int32), label=np.zeros(N, np.int64))
-        for row, idx in enumerate(indices):
-            kp = store.host[idx][..., :store.coordC]          # coordinates only: a score channel is not geometry
-            M, T = kp.shape[:2]
-            frames, swap, masked = np.arange(T), False, False
-            center, mat = np.zeros(3), np.eye(3)
-            allzero = bool(np.all(np.isclose(kp, 0)))
-            if self.norm3d is not None:
-                n = self.norm3d
-                d = normalize3d_decision(kp, n.zaxis, n.xaxis, n.align_spine, n.align_center)
-                if d['active']:
-                    frames, swap = d['frames'], d['swap']
-                    if n.align_center:
-                        center, masked = d['center'], True
-                        kept = kp[:, frames]            # RandomRot's "nothing to rotate" test sees the centred clip
-                        allzero = bool(np.all(np.isclose((kept - center) * ((kept != 0).sum(-1) > 0)[..., None], 0)))
-                    mat = d['matrix']
-            if self.rot is not None and not allzero:
-                r = self.rot.draw(store.coordC)
-                if store.coordC == 2:
-                    r3 = np.eye(3)
-                    r3[:2, :2] = r
-                    r = r3
-                mat = r @ mat
-            inds = uniform_frame_indices(len(frames), clip_len, num_clips, self.sample.test_mode, self.sample.p_interval,
-                                         self.sample.seed)
-            nxt = np.where(inds + 1 < len(frames), inds + 1, -1)
-            p['offset'][row], p['M'][row], p['T'][row] = store.offset[idx], M, T
-            rotated = self.rot is not None and not allzero
-            half = store.src[idx].dtype == np.float16 and not rotated and self.norm3d is None   # fp16 feature arithmetic
-            p['flags'][row] = (1 if swap else 0) | (2 if masked else 0) | (4 if half else 0)
-            p['center'][row], p['matrix'][row] = center, mat.reshape(-1)
-            p['f0'][row] = frames[inds]
-            p['f1'][row] = np.where(nxt >= 0, frames[np.maximum(nxt, 0)], -1)
-            p['label'][row] = store.labels[idx]
-        return p
+        tab = self._table(store)
+        todo = np.arange(len(tab['done'])) if indices is None else np.unique(np.asarray(indices, dtype=np.int64))
+        for i in todo[~tab['done'][todo]]:
+            self._decide(store, tab, int(i))
+        return tab
+
+    def plan(self, store, indices):
+        """Host decisions for the clips ``indices`` of ``store`` -> dict of small numpy arrays (see dsgcn_skeleton_prep).
+        numpy's global RNG is consumed exactly as running the reference's ``Compose`` clip by clip would: per clip the
+        rotation angles (unless there is nothing to rotate), then the sampler's draws."""
+        idx = np.asarray(indices, dtype=np.int64)
+        N = len(idx)
+        clip_len, num_clips = self.sample.clip_len, self.sample.num_clips
+        F = num_clips * clip_len
+        tab = self.prepare(store, idx)
+        nf = tab['nf'][idx]
+        C = store.coordC
+        rotated = np.zeros(N, bool)
+        if self.rot is not None:
+            rotated = ~tab['allzero'][idx]
+        thetas = np.zeros((N, 3))
+        inds = np.empty((N, F), np.int64)
+        smp = self.sample
+        for row in range(N):                              # the RNG stream: nothing else happens clip by clip
+            if rotated[row]:
+                thetas[row] = self.rot.draw_angles(C)
+            inds[row] = uniform_frame_indices(int(nf[row]), clip_len, num_clips, smp.test_mode, smp.p_interval, smp.seed)
+        mat = tab['matrix'][idx]
+        if rotated.any():
+            if C == 3:
+                rot = euler_rotations(thetas)
+            else:
+                c, s_ = np.cos(thetas[:, 0]), np.sin(thetas[:, 0])
+                rot = np.tile(np.eye(3), (N, 1, 1))
+                rot[:, 0, 0], rot[:, 0, 1], rot[:, 1, 0], rot[:, 1, 1] = c, -s_, s_, c
+            mat = np.where(rotated[:, None, None], rot @ mat, mat)
+        frames = tab['frames'][idx]                       # (N, Tmax), valid up to nf
+        nxt = inds + 1
+        has_next = nxt < nf[:, None]
+        f0 = np.take_along_axis(frames, inds, 1)
+        f1 = np.where(has_next, np.take_along_axis(frames, np.where(has_next, nxt, 0), 1), -1)
+        half = tab['f16'][idx] & ~rotated & (self.norm3d is None)      # fp16 feature arithmetic
+        flags = tab['swap'][idx].astype(np.int32) | (tab['masked'][idx].astype(np.int32) << 1) | (half.astype(np.int32) << 2)
+        return dict(offset=store.offset[idx].astype(np.int64), M=store.M[idx].astype(np.int32), T=store.T[idx].astype(np.int32),
+                    flags=flags, center=tab['center'][idx].astype(np.float32), matrix=mat.reshape(N, 9).astype(np.float32),
+                    f0=f0.astype(np.int32), f1=f1.astype(np.int32), label=store.labels[idx].astype(np.int64))
 
     def run(self, store, plan):
         """-> (keypoint (N, clips, num_person, clip_len, V, C_out) float32 on the store's device, label (N, 1) int64)."""

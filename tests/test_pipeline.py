@@ -151,3 +151,74 @@ def test_batched_pipeline_feeds_the_recognizer():
     kp10, _ = P.SkeletonBatcher(pipelines()['test10_j'])(store, [0, 5])
     probs = m(keypoint=kp10, return_loss=False)
     assert probs.shape == (2, 60) and np.allclose(probs.sum(1), 1, atol=1e-5)
+
+
+class _HostStore:
+    """What SkeletonBatcher.plan() reads of a SkeletonStore, without the device buffer (the plan is host arithmetic)."""
+
+    def __init__(self, anns):
+        self.src = [np.ascontiguousarray(a['keypoint']) for a in anns]
+        self.host = [k.astype(np.float32) for k in self.src]
+        self.V, self.coordC = self.src[0].shape[2], self.src[0].shape[3]
+        self.C = self.coordC
+        self.M = np.array([k.shape[0] for k in self.src], dtype=np.int32)
+        self.T = np.array([k.shape[1] for k in self.src], dtype=np.int32)
+        sizes = np.array([k.size for k in self.src], dtype=np.int64)
+        self.offset = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        self.labels = np.array([int(a.get('label', -1)) for a in anns], dtype=np.int64)
+
+    def __len__(self):
+        return len(self.src)
+
+
+def _plan_clip_by_clip(b, store, indices):
+    """The decisions made one clip at a time, transform by transform, the way the reference's Compose visits a sample
+    (PreNormalize3D -> RandomRot -> UniformSample): the yardstick for the batched plan()."""
+    rows = []
+    for idx in indices:
+        kp = store.host[idx][..., :store.coordC]
+        T = kp.shape[1]
+        frames, swap, masked, center, mat = np.arange(T), False, False, np.zeros(3), np.eye(3)
+        allzero = bool(np.all(np.isclose(kp, 0)))
+        if b.norm3d is not None:
+            n = b.norm3d
+            d = P.normalize3d_decision(kp, n.zaxis, n.xaxis, n.align_spine, n.align_center)
+            if d['active']:
+                frames, swap = d['frames'], d['swap']
+                if n.align_center:
+                    center, masked = d['center'], True
+                    kept = kp[:, frames]
+                    allzero = bool(np.all(np.isclose((kept - center) * ((kept != 0).sum(-1) > 0)[..., None], 0)))
+                mat = d['matrix']
+        rotated = b.rot is not None and not allzero
+        if rotated:
+            mat = b.rot.draw(3) @ mat
+        inds = P.uniform_frame_indices(len(frames), b.sample.clip_len, b.sample.num_clips, b.sample.test_mode,
+                                       b.sample.p_interval, b.sample.seed)
+        nxt = np.where(inds + 1 < len(frames), inds + 1, -1)
+        rows.append(dict(f0=frames[inds], f1=np.where(nxt >= 0, frames[np.maximum(nxt, 0)], -1), mat=mat, center=center,
+                         flags=(1 if swap else 0) | (2 if masked else 0)))
+    return rows
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_batched_plan_matches_clip_by_clip_decisions(name):
+    """plan() makes the per-clip geometry decisions once (cached on the store) and the rest for the whole batch at once; the
+    RNG stream, every frame index and flag must equal the clip-by-clip walk bit for bit — on a first visit, on a revisit
+    from the cache, and for a permuted batch — and the matrices to the last fp32 bit but one."""
+    store = _HostStore(annotations())
+    b = P.SkeletonBatcher(pipelines()[name])
+    for order in (list(range(len(store))), list(range(len(store)))[::-1], [2, 0, 2, 1]):
+        np.random.seed(77)
+        got = b.plan(store, order)
+        after = np.random.rand()                         # the stream position after the batch
+        np.random.seed(77)
+        want = _plan_clip_by_clip(b, store, order)
+        assert np.random.rand() == after
+        for r, w in enumerate(want):
+            assert np.array_equal(got['f0'][r], w['f0']) and np.array_equal(got['f1'][r], w['f1'])
+            assert int(got['flags'][r]) & 3 == w['flags']
+            assert np.allclose(got['matrix'][r], w['mat'].reshape(-1).astype(np.float32), rtol=0, atol=2e-7)
+            assert np.array_equal(got['center'][r], np.asarray(w['center'], dtype=np.float32))
+        assert got['label'].tolist() == [int(store.labels[i]) for i in order]
+        assert got['offset'].tolist() == [int(store.offset[i]) for i in order]

@@ -341,3 +341,34 @@ def test_validation_two_ranks_gloo(tmp_path):
     rec = r['res'][0]
     assert rec['epoch'] == 1 and rec['top1_acc'] == pytest.approx(top[0]) and rec['top5_acc'] == pytest.approx(top[1])
     assert rec['mean_class_accuracy'] == pytest.approx(mean_class_accuracy(r['single'], r['labels'])[0])
+
+
+@pytest.mark.gpu
+def test_train_model_on_resident_store_feeder_is_deterministic(tmp_path):
+    """train_model fed by the HIP input pipeline (clips resident in HBM, host plan + one launch per batch): with the plan
+    made one batch ahead on the feeder thread or inline, the same numpy RNG stream is consumed — bit-identical weights."""
+    import sys
+    sys.path.insert(0, GOLD)
+    from pipeline_cases import annotations, pipelines
+    from dsgcn_amd import pipeline as P
+    anns = [dict(a, label=a['label'] % 12) for a in annotations() * 6]      # 18+ clips, the reduced model's 12 classes
+    cfg_m = json.loads(str(load('trajectory_dsstgcn_reduced.npz')['cfg']))
+    cfg_m['backbone']['tcn_ms_cfg'] = [tuple(c) if isinstance(c, list) else c for c in cfg_m['backbone']['tcn_ms_cfg']]
+    name = 'train_j'
+    finals = []
+    for prefetch in (True, False):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        m = D.build_model(cfg_m)
+        store = P.SkeletonStore(anns)
+        batcher = P.SkeletonBatcher(pipelines()[name])
+        run_cfg = dict(data=dict(videos_per_gpu=4), seed=1, total_epochs=2,
+                       optimizer=dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=5e-4, nesterov=True),
+                       lr_config=dict(policy='CosineAnnealing', min_lr=0, by_epoch=False), checkpoint_config=None,
+                       log_config=dict(interval=2), work_dir=None)
+        np.random.seed(5)
+        r = train_model(m, (store, batcher), run_cfg, device='cuda', use_graph=True, prefetch=prefetch)
+        assert r.iter == 2 * ((len(anns) + 3) // 4) and all(np.isfinite(rec['loss']) for rec in r.log)
+        finals.append({k: v.clone() for k, v in m.state_dict().items()})
+    for k, v in finals[0].items():
+        assert torch.equal(v, finals[1][k]), k
