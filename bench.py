@@ -173,6 +173,66 @@ def measure_ka_roofline(device, n, reps=20, blocks=5):
     return out
 
 
+def ctr_layer_shapes(n):
+    """(n, Co, T at the spatial unit) of the 10 CTR-GCN blocks (BASELINE config 4: 64/64/64/64/128/128/128/256/256/256
+    channels, temporal stride 2 in blocks 5 and 8)."""
+    return [(n, 64, 64)] * 4 + [(n, 128, 64)] + [(n, 128, 32)] * 2 + [(n, 256, 32)] + [(n, 256, 16)] * 2
+
+
+def measure_kap_roofline(device, n, reps=10, blocks=3, K=3):
+    """K-A' (csrc/aggsum.hip: y[n,c] = sum_k P[n,k,c] . Ahat[n,k,c], the CTR-GCN gather-aggregate with its per-sample,
+    per-channel adjacency) over CTR-GCN's own layer mix, HIP-event timed like K-A.  Algorithmic bytes per (n, c) plane
+    (SURVEY §8 a10): forward 4*((K+1)*T*V + K*V*V), backward 4*((2K+1)*T*V + 2*K*V*V) (P_k, G in; dP_k, dAhat_k out)."""
+    from dsgcn_amd import native
+    lib = native.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    bufs = []
+    for (nn, Co, t) in ctr_layer_shapes(n):
+        p = torch.randn(nn, K * Co, t, V, device=device)
+        ah = torch.randn(nn, K * Co, V, V, device=device) * 0.2
+        bufs.append(dict(p=p, ah=ah, y=torch.empty(nn, Co, t, V, device=device), gy=torch.randn(nn, Co, t, V, device=device),
+                         dp=torch.empty_like(p), dah=torch.empty_like(ah),
+                         part=torch.empty(lib.dsgcn_aggsum_partial_rows(nn, t, V), Co, 2, device=device), dims=(nn, Co, t)))
+
+    def fwd(b):
+        nn, Co, t = b['dims']
+        rc = lib.dsgcn_aggsum_fwd(b['p'].data_ptr(), b['ah'].data_ptr(), K * Co * V * V, Co * V * V, V * V, b['y'].data_ptr(),
+                                  b['part'].data_ptr(), nn, K, Co, t, V, st)
+        assert rc == 0, rc
+
+    def bwd(b):
+        nn, Co, t = b['dims']
+        rc = lib.dsgcn_aggsum_bwd(b['p'].data_ptr(), b['ah'].data_ptr(), K * Co * V * V, Co * V * V, V * V, b['gy'].data_ptr(),
+                                  None, None, None, b['dp'].data_ptr(), b['dah'].data_ptr(), K * Co * V * V, Co * V * V, V * V,
+                                  nn, K, Co, t, V, st)
+        assert rc == 0, rc
+
+    out = {}
+    for name, fn, is_bwd in (('k_aggsum_fwd_ctr', fwd, False), ('k_aggsum_bwd_ctr', bwd, True)):
+        for b in bufs:
+            fn(b)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(blocks):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                for b in bufs:
+                    fn(b)
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / reps)
+        times.sort()
+        ms = times[len(times) // 2]
+        nbytes = sum(4 * nn * Co * (((2 * K + 1) if is_bwd else (K + 1)) * t * V + (2 if is_bwd else 1) * K * V * V)
+                     for nn, Co, t in (b['dims'] for b in bufs))
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[name] = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
+                         traffic=None, avg_launch_us=round(ms * 1e3 / len(bufs), 2), alg_bytes_per_launch=nbytes // len(bufs),
+                         launches_per_step=len(bufs), workload='CTR-GCN (BASELINE config 4) layer mix, K = 3, per-sample adjacency')
+    return out
+
+
 MFMA_F32_PEAK_TF = 157.3        # MI355X_MICROARCH.md: f32-input MFMA = vector f32 rate
 MFMA_BF16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA
 
@@ -531,7 +591,8 @@ def main():
     if rank == 0 and not args.no_roofline:
         rf = measure_ka_roofline(device, B * M)
         result['roofline'] = rf['k_aggregate_bwd'] | {'kernel': 'k_aggregate_bwd'}
-        result['roofline_other'] = {'k_aggregate_fwd': rf['k_aggregate_fwd']} | measure_kc_roofline(device, B * M)
+        result['roofline_other'] = ({'k_aggregate_fwd': rf['k_aggregate_fwd']} | measure_kc_roofline(device, B * M) |
+                                    measure_kap_roofline(device, B * M))
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

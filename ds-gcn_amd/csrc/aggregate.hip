@@ -23,6 +23,20 @@
 
 namespace {
 
+// The persistent kernels' operand prefetch (planes and adjacency are read exactly once per launch).  KA_NT_LOADS: issue
+// them as non-temporal loads (streamed data need not displace what the next launch will find in L2 / Infinity Cache).
+#ifndef KA_NT_LOADS
+#define KA_NT_LOADS 0
+#endif
+template <typename TT>
+__device__ __forceinline__ TT ka_ld(const TT* p) {
+#if KA_NT_LOADS
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 template <int V>
 __device__ __forceinline__ void load_plane_to_lds(const float* __restrict__ src, float* lds, int cnt, int lane,
                                                   bool vec) {
@@ -165,12 +179,12 @@ __global__ __launch_bounds__(64 * KA_WPB) void k_aggregate_fwd_pipe(const float*
 #pragma unroll
     for (int q = 0; q < NP4; ++q) {
       const int i = lane + q * 64;
-      if (i < c4) pre[q] = s4[i];
+      if (i < c4) pre[q] = ka_ld(&s4[i]);
     }
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       const int i = lane + q * 64;
-      if (i < V * V) prea[q] = A[i];
+      if (i < V * V) prea[q] = ka_ld(&A[i]);
     }
   };
 
@@ -425,12 +439,12 @@ __global__ __launch_bounds__(64 * KA_WPB) void k_aggregate_bwd_pipe(const float*
 #pragma unroll
     for (int q = 0; q < NP4; ++q) {
       const int i = lane + q * 64;
-      if (i < c4) { prez[q] = z4[i]; preg[q] = g4[i]; }
+      if (i < c4) { prez[q] = ka_ld(&z4[i]); preg[q] = ka_ld(&g4[i]); }
     }
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       const int i = lane + q * 64;
-      if (i < V * V) prea[q] = A[i];
+      if (i < V * V) prea[q] = ka_ld(&A[i]);
     }
   };
 
@@ -613,12 +627,12 @@ __global__ __launch_bounds__(64 * NW) void k_aggregate_bwd_pair(const float* __r
 #pragma unroll
     for (int q = 0; q < NP4; ++q) {
       const int i = lane + q * 64;
-      if (i < c4) { prez[q] = z4[i]; preg[q] = g4[i]; }
+      if (i < c4) { prez[q] = ka_ld(&z4[i]); preg[q] = ka_ld(&g4[i]); }
     }
 #pragma unroll
     for (int q = 0; q < NAH; ++q) {
       const int i = a0 + lane + q * 64;
-      if (i < a1) prea[q] = A[i];
+      if (i < a1) prea[q] = ka_ld(&A[i]);
     }
   };
 

@@ -173,6 +173,7 @@ def build(force=False, verbose=False, lab=False):
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC]
     if lab:
         flags.append('-DDSGCN_LAB')
+        flags += [f for f in os.environ.get('DSGCN_LAB_FLAGS', '').split() if f]      # e.g. -DKA_NT_LOADS=1 for an A/B build
     jobs, objs = [], []
     for src in srcs:
         base = os.path.splitext(os.path.basename(src))[0]

@@ -247,11 +247,18 @@ def test_full_width_gradients_vs_reference_fixture(name):
     names = json.loads(str(z['names']))
     params = dict(m.named_parameters())
     num = den = 0.0
+    per = []
     for i, k in enumerate(names):
         g64 = z[f'g64_{i}'].astype(np.float64)
-        num += float(((params[k].grad.double().cpu().numpy() - g64) ** 2).sum())
+        e2 = float(((params[k].grad.double().cpu().numpy() - g64) ** 2).sum())
+        num += e2
         den += float((g64 ** 2).sum())
+        per.append((e2, k, float((g64 ** 2).sum())))
     ours, theirs = (num / den) ** .5, float(z['gerr32_set'])
+    # which tensors carry the error (share of the squared error of the selection; -s shows it: profiles/r04/parity_numbers.txt)
+    per.sort(reverse=True)
+    print(f'full_grads {name}: error carried by ' + ', '.join(f'{k} {e2 / max(num, 1e-300):.0%} (own rel {(e2 / max(d, 1e-300)) ** .5:.1e})'
+                                                               for e2, k, d in per[:3]))
     # Whole-selection relative L2 against the reference's fp64 gradients.  ONE bar: within twice the error of the
     # reference's own fp32 run on the same case (0.05-0.8 % here: the batch-statistics backward under the mean-pooled head
     # cancels ~4 digits in ANY fp32 evaluation order, whatever the batch size — measured at 2 and 8 clips,

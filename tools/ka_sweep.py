@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from dsgcn_amd import native
-lib = native.lab_lib(); dev = torch.device('cuda'); st = torch.cuda.current_stream().cuda_stream
+lib = native.lib() if os.environ.get('KA_LIB') == 'product' else native.lab_lib(); dev = torch.device('cuda'); st = torch.cuda.current_stream().cuda_stream
 V = 25; n = 128
 bufs = []
 for (nn, KC, t) in bench.ka_layer_shapes(n):
@@ -28,7 +28,10 @@ def timeit(fn, reps=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 fb = sum(bench.ka_alg_bytes(*b['dims'], V, False) for b in bufs); bb = sum(bench.ka_alg_bytes(*b['dims'], V, True) for b in bufs)
-print('default fwd', fb / timeit(fwd) / 1e3, 'GB/s  bwd', bb / timeit(bwd) / 1e3, 'GB/s')
+for _ in range(int(os.environ.get('KA_REPEAT', 1))):
+    print(os.environ.get('KA_LIB', 'lab'), 'default fwd %.0f GB/s  bwd %.0f GB/s' % (fb / timeit(fwd, 20) / 1e3, bb / timeit(bwd, 20) / 1e3), flush=True)
+if os.environ.get('KA_SWEEP', '1') == '0':
+    sys.exit(0)
 for waves, chunk, direct in itertools.product((1024, 2048, 3072, 4096, 6144, 8192), (32, 64), (0, 1)):
     lib.dsgcn_set_tuning(0, waves); lib.dsgcn_set_tuning(5, chunk); lib.dsgcn_set_tuning(4, direct)
     print(f'fwd waves {waves} chunk {chunk} direct {direct}: {fb / timeit(fwd) / 1e3:.0f} GB/s', flush=True)
