@@ -222,3 +222,37 @@ def test_batched_plan_matches_clip_by_clip_decisions(name):
             assert np.array_equal(got['center'][r], np.asarray(w['center'], dtype=np.float32))
         assert got['label'].tolist() == [int(store.labels[i]) for i in order]
         assert got['offset'].tolist() == [int(store.offset[i]) for i in order]
+
+
+def test_pose_dataset_valid_ratio_and_box_thr(tmp_path):
+    """The Kinetics pose pickles' options (reference pose_dataset.py:66-83, configs/dsstgcn/kinetics400_hrnet/j.py:22-23,80-82):
+    a clip stays when valid[box_thr] / total_frames >= valid_ratio, gets anno_inds = box_score >= box_thr, and loses its
+    'valid' / 'box_score' bookkeeping; without valid_ratio nothing is filtered (the val / test splits of that config)."""
+    rng = np.random.RandomState(0)
+    anns = []
+    for i, (valid5, total) in enumerate([(8, 10), (5, 10), (10, 10), (0, 12)]):
+        anns.append(dict(frame_dir=f'v{i}', label=i, total_frames=total, img_shape=(240, 320), original_shape=(240, 320),
+                         keypoint=rng.rand(6, 17, 3).astype(np.float16), frame_inds=np.array([0, 0, 1, 2, 3, 3], dtype=np.int16),
+                         box_score=np.array([.9, .55, .45, .7, .2, .5], dtype=np.float32),
+                         valid={0.5: valid5, 0.6: max(valid5 - 2, 0), 0.7: 1, 0.8: 0, 0.9: 0}))
+    path = tmp_path / 'k.pkl'
+    with open(path, 'wb') as f:
+        pickle.dump(anns, f)
+    ident = lambda r: r       # noqa: E731
+    ds = D.PoseDataset(str(path), ident, valid_ratio=0.6, box_thr=0.5)
+    assert [a['frame_dir'] for a in ds.video_infos] == ['v0', 'v2']                     # 8/10 and 10/10 pass, 5/10 and 0/12 do not
+    for a in ds.video_infos:
+        assert a['anno_inds'].tolist() == [True, True, False, True, False, True]
+        assert 'valid' not in a and 'box_score' not in a
+    item = ds[1]
+    assert item['label'] == 2 and item['modality'] == 'Pose' and item['start_index'] == 0 and 'anno_inds' in item
+    ds6 = D.PoseDataset(str(path), ident, valid_ratio=0.3, box_thr=0.6)
+    assert [a['frame_dir'] for a in ds6.video_infos] == ['v0', 'v1', 'v2'] and ds6.video_infos[0]['anno_inds'].sum() == 2
+    with open(path, 'wb') as f:
+        pickle.dump(anns, f)
+    plain = D.PoseDataset(str(path), ident, box_thr=0.5)                                # val / test: box_thr given, no valid_ratio
+    assert len(plain) == 4 and all('anno_inds' not in a and 'valid' not in a for a in plain.video_infos)
+    with pytest.raises(AssertionError):
+        D.PoseDataset(str(path), ident, box_thr=0.55)
+    with pytest.raises(NotImplementedError):
+        D.PoseDataset(str(path), ident, memcached=True, mc_cfg=('localhost', 11211))

@@ -15,6 +15,7 @@ SHAPES = [('pre5', 128, 48, 32, 0), ('post5', 48, 128, 32, 1), ('branch5', 128, 
 if os.environ.get('KC_SHAPES'):
     SHAPES = [(a, int(b), int(c), int(d), int(e)) for a, b, c, d, e in (x.split(',') for x in os.environ['KC_SHAPES'].split(';'))]
 P = lambda t: None if t is None else t.data_ptr()
+_seen_stamps = set()
 
 
 def rel(a, b):
@@ -137,8 +138,9 @@ def bench(keys, n, reps=20, nsets=4):
                     ph = np.zeros(64, dtype=np.int64)
                     assert lib.dsgcn_pwg2_phases(ph.ctypes.data) == 0
                     k_ = int(ph[63]); d = np.diff(ph[:k_]) / 100.0
-                    if k_ < 6:
+                    if k_ < 6 or int(ph[0]) in _seen_stamps:      # (not a k_pwg3 launch / fewer workgroups than `blk`: stale stamps)
                         continue
+                    _seen_stamps.add(int(ph[0]))
                     ch = d[2:-2].reshape(-1, 2)
                     print(f'    wg {blk} {nm}: table {d[0]:.2f} | chunk 0 in LDS {d[1]:.2f} | per chunk products/barrier: ' +
                           ' '.join(f'{a_:.2f}/{b_:.2f}' for a_, b_ in ch) + f' | drain {d[-2]:.2f} epilogue {d[-1]:.2f} | total {(ph[k_ - 1] - ph[0]) / 100.0:.1f} us')
