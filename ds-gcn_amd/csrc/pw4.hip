@@ -463,7 +463,14 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   __syncthreads();                                 // every wave is done with Ws / Ps: LDS is reused below
 
   const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, wlive, pok, skip};
-  p4_epilogue<MT, NQ, EPI, false>(a, acc, lds, tile);
+  if constexpr (EPI == 1) {
+    // (operand prefetch of the data-gradient epilogue: two row groups ahead — k_pw4's waves keep their PD operand slots
+    // next to MT*NQ accumulator tiles, there is room for two)
+    if (a.ex2) p4_epilogue<MT, NQ, EPI, false, 4, 2, true>(a, acc, lds, tile);
+    else p4_epilogue<MT, NQ, EPI, false, 4, 2, false>(a, acc, lds, tile);
+  } else {
+    p4_epilogue<MT, NQ, EPI, false>(a, acc, lds, tile);
+  }
 }
 
 
@@ -654,7 +661,12 @@ __global__ __launch_bounds__(P4_NT, 2) void k_pwg(Pw4Args a) {
   if (ch0 < Kpad) chunk(ch0, bwA, bw2A);
   __syncthreads();                                 // drains the read-ahead loads before LDS is reused
   const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, true, pok, skip};
-  p4_epilogue<1, 4, EPI, true>(a, acc, lds, tile);
+  if constexpr (EPI == 1) {
+    if (a.ex2) p4_epilogue<1, 4, EPI, true, 4, 4, true>(a, acc, lds, tile);
+    else p4_epilogue<1, 4, EPI, true, 4, 4, false>(a, acc, lds, tile);
+  } else {
+    p4_epilogue<1, 4, EPI, true>(a, acc, lds, tile);
+  }
 }
 
 
