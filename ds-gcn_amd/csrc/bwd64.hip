@@ -38,10 +38,23 @@ __device__ __forceinline__ f32x4 bf_load(__amdgpu_buffer_rsrc_t r, int voff) {
 }
 __device__ __forceinline__ int bf_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+#ifdef DSGCN_LAB
+// wall-clock stamps (10 ns) of workgroup 0, thread 0: start, tables ready, then per unit (committed + barrier, products +
+// barrier, finished), partial rows written; [63] = count (dsgcn_bwd64_phases)
+__device__ long long g_bf_stamp[64];
+#define BF_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0 && nst < 62) g_bf_stamp[nst++] = wall_clock64(); } while (0)
+#else
+#define BF_STAMP() do {} while (0)
+#endif
+
 // HASC: batch-statistics terms (A0, B0);  AFF: the input carries an affine and / or a ReLU;  HAS2: second input stream.
 template <bool HASC, bool AFF, bool HAS2>
 __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef DSGCN_LAB
+  int nst = 0;
+#endif
+  BF_STAMP();
   float* Ds = lds;                                  // [64][LS] dz_eff (zero rows >= Co)
   float* Xs = lds + 64 * BF_LS;                     // [64][LS] the ACTIVATED virtual input v (zero rows >= Ci)
   float* Os = lds + 128 * BF_LS;                    // [64][LS] dv tile of the unit (before mask / scale)
@@ -149,11 +162,13 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
   const bool dg_on = 32 * cit < Ci && !(narrow_i && wave < 2);
 
   __syncthreads();
+  BF_STAMP();
   if (ch0 < ch1) issue(ch0);
   for (int ch = ch0; ch < ch1; ++ch) {
     commit(ch);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    BF_STAMP();
     if (ch + 1 < ch1) issue(ch + 1);
     // ---- weight gradient ---- (two accumulators: a single one is a chain of dependent MFMAs, and only two waves
     // share a SIMD here)
@@ -185,6 +200,7 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                 // raw barrier: the next unit's loads stay in flight
+    BF_STAMP();
     {
       // finish the data gradient in the staging layout (16 B per lane, the raw inputs are still in registers):
       // dx = dv * 1[pre > 0] * s;  (Os is rewritten only after the NEXT unit's first barrier)
@@ -219,6 +235,7 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
     }
   }
 
+  BF_STAMP();
   // ---- partial rows of this split ----
   float* dw = a.dwp + (size_t)split * a.pstride;
   {
@@ -247,6 +264,10 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
       }
     }
   }
+#ifdef DSGCN_LAB
+  BF_STAMP();
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_bf_stamp[63] = nst;
+#endif
 }
 
 struct BfPlan { int cpn, chunks, splits, cps; };
@@ -309,3 +330,9 @@ __attribute__((visibility("hidden"))) int dsgcn_bwd64(const float* x1, const flo
   DSGCN_LAUNCH_CHECK();
   return 1;
 }
+
+#ifdef DSGCN_LAB
+extern "C" int dsgcn_bwd64_phases(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf_stamp), sizeof(long long) * 64);
+}
+#endif

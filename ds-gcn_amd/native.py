@@ -114,6 +114,7 @@ LAB_SIGNATURES = {
     'dsgcn_dynadj_phases': [ctypes.c_void_p],
     'dsgcn_pwg2_phases': [ctypes.c_void_p],
     'dsgcn_pwg2_phases_block': [c_int],
+    'dsgcn_bwd64_phases': [ctypes.c_void_p],
     'dsgcn_tcw_phases': [ctypes.c_void_p],
 }
 

@@ -42,6 +42,10 @@ int dsgcn_pwg2_phases(long long* out);
  * per chunk, loop drained, epilogue done.  dsgcn_pwg2_phases_block selects the stamping workgroup (default 0). */
 int dsgcn_pwg2_phases_block(int block);
 
+/* one-pass narrow backward (k_bwd64): stamps of workgroup 0: start, tables ready, then per 64-position unit (committed, products
+ * done), loop done, partial rows written; out[63] = count. */
+int dsgcn_bwd64_phases(long long* out);
+
 /* temporal-conv weight gradient (k_tcw): stamps of workgroup 0, per tap group (before issue, after issue, after the
  * barrier, after the products); out[63] = count. */
 int dsgcn_tcw_phases(long long* out);

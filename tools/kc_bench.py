@@ -94,6 +94,14 @@ def run(variant):
         if rows_f:
             t = timeit(fused)
             res.append(f'fused bwd {t:6.1f} us {4 * L * (2 * Co + 2 * Ci) / t / 1e6:5.2f} TB/s')
+            if os.environ.get('KC_PHASES'):
+                import numpy as np
+                torch.cuda.synchronize(); fused(); torch.cuda.synchronize()
+                ph = np.zeros(64, dtype=np.int64)
+                assert lib.dsgcn_bwd64_phases(ph.ctypes.data) == 0
+                k_ = int(ph[63]); d = np.diff(ph[:k_]) / 100.0
+                un = d[1:-2].reshape(-1, 2)
+                res.append('| wg0: tables %.1f; per unit (previous finish + commit)/products: ' % d[0] + ' '.join(f'{a_:.2f}/{b_:.2f}' for a_, b_ in un) + f'; last finish {d[-2]:.2f}; rows {d[-1]:.1f}; total {(ph[k_ - 1] - ph[0]) / 100.0:.1f} us')
         print(f'{name:8s} {Ci:4d} {Co:4d} | ' + ' | '.join(res), flush=True)
         if os.environ.get('KC_PHASES') and ws is not None and keys[14]:
             import numpy as np
