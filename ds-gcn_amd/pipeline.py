@@ -17,8 +17,10 @@ Two ways to run the same pipeline config:
   does all per-element work — centre + mask, rotation, bone / motion features, frame gather, person padding, clip
   layout — writing the network input ``(N, clips, M, T, V, C)`` directly.  There is no CPU fallback for this form.
 
-Not implemented (raise): 2-D heat-map transforms, ``DecompressPose`` / ``PoseCompact`` (the HRNet-pose K400 pickle path),
-``float_ok`` sampling, memcached loading."""
+``DecompressPose`` (pose_related.py:521-607) and ``PoseCompact`` (augmentations.py:21-116) — the two extra transforms of the
+HRNet-pose Kinetics-400 config (configs/dsstgcn/kinetics400_hrnet/j.py:25-39) — exist in the host (``Compose``) form only.
+
+Not implemented (raise): 2-D heat-map transforms, ``float_ok`` sampling, memcached loading."""
 import copy
 import pickle
 
@@ -294,6 +296,104 @@ class GenSkeFeat:
             assert results['keypoint'].shape[-1] == 2, 'Only 2D keypoints have keypoint_score. '
             results['keypoint'] = np.concatenate([results.pop('keypoint'), results.pop('keypoint_score')[..., None]], -1)
         results['keypoint'] = skeleton_features(results['keypoint'], self.dataset, self.feats)
+        return results
+
+
+@PIPELINES.register_module()
+class DecompressPose:
+    """Kinetics pose pickles store one row per DETECTION: ``keypoint (D, V, 3)`` = (x, y, score) with ``frame_inds (D,)``
+    saying which frame a detection belongs to (and ``anno_inds``, the detections a dataset's ``box_thr`` keeps).  ->
+    ``keypoint (M, T, V, 2)`` / ``keypoint_score (M, T, V)`` in fp16 with the persons of a frame in detection order, M =
+    the largest number of detections in one frame, capped at ``max_person`` by total score.  ``squeeze``: frames without
+    a detection are dropped (frame indices renumbered densely).  Reference: pose_related.py:521-607."""
+
+    def __init__(self, squeeze=True, max_person=10):
+        self.squeeze, self.max_person = squeeze, max_person
+
+    def __call__(self, results):
+        for k in ('total_frames', 'frame_inds', 'keypoint'):
+            assert k in results
+        total_frames = results['total_frames']
+        frame_inds = results.pop('frame_inds')
+        keypoint = results['keypoint']
+        if 'anno_inds' in results:
+            frame_inds = frame_inds[results['anno_inds']]
+            keypoint = keypoint[results['anno_inds']]
+        assert np.all(np.diff(frame_inds) >= 0), 'frame_inds should be monotonical increasing'
+        if self.squeeze:
+            uni = np.unique(frame_inds)
+            frame_inds = np.searchsorted(uni, frame_inds).astype(np.int16)
+            total_frames = np.max(frame_inds) + 1
+        results['total_frames'] = total_frames
+        num_joints = keypoint.shape[1]
+        num_person = int(np.bincount(np.asarray(frame_inds, dtype=np.int64)).max())      # = scipy.stats.mode(...).count
+        new_kp = np.zeros([num_person, total_frames, num_joints, 2], dtype=np.float16)
+        new_kpscore = np.zeros([num_person, total_frames, num_joints], dtype=np.float16)
+        nperson_per_frame = np.zeros([total_frames], dtype=np.int16)
+        for frame_ind, kp in zip(frame_inds, keypoint):
+            person_ind = nperson_per_frame[frame_ind]
+            new_kp[person_ind, frame_ind] = kp[:, :2]
+            new_kpscore[person_ind, frame_ind] = kp[:, 2]
+            nperson_per_frame[frame_ind] += 1
+        if num_person > self.max_person:
+            for i in range(total_frames):
+                nperson = nperson_per_frame[i]
+                score_sum = new_kpscore[:nperson, i].sum(-1)
+                inds = sorted(range(nperson), key=lambda x: -score_sum[x])
+                new_kpscore[:nperson, i] = new_kpscore[inds, i]
+                new_kp[:nperson, i] = new_kp[inds, i]
+            num_person = self.max_person
+            results['num_person'] = num_person
+        results['keypoint'] = new_kp[:num_person]
+        results['keypoint_score'] = new_kpscore[:num_person]
+        return results
+
+
+@PIPELINES.register_module()
+class PoseCompact:
+    """Crop the coordinate frame to the tight box around all non-zero joints of the (sampled) clip, grown by ``padding``
+    and to the ``hw_ratio`` asked for: joints are shifted by the box origin, ``img_shape`` becomes the box size,
+    ``crop_quadruple`` records it.  Boxes narrower than ``threshold`` pixels leave the sample untouched.  Reference:
+    augmentations.py:21-116."""
+
+    def __init__(self, padding=0.25, threshold=10, hw_ratio=None, allow_imgpad=True):
+        self.padding, self.threshold, self.allow_imgpad = padding, threshold, allow_imgpad
+        if hw_ratio is not None and not isinstance(hw_ratio, (tuple, list)):
+            hw_ratio = (hw_ratio, hw_ratio)
+        self.hw_ratio = tuple(hw_ratio) if hw_ratio is not None else None
+        assert self.padding >= 0
+
+    def __call__(self, results):
+        h, w = results['img_shape']
+        kp = results['keypoint']
+        kp[np.isnan(kp)] = 0.
+        kp_x, kp_y = kp[..., 0], kp[..., 1]
+        min_x = np.min(kp_x[kp_x != 0], initial=np.inf)
+        min_y = np.min(kp_y[kp_y != 0], initial=np.inf)
+        max_x = np.max(kp_x[kp_x != 0], initial=-np.inf)
+        max_y = np.max(kp_y[kp_y != 0], initial=-np.inf)
+        if max_x - min_x < self.threshold or max_y - min_y < self.threshold:
+            return results
+        center = ((max_x + min_x) / 2, (max_y + min_y) / 2)
+        half_width = (max_x - min_x) / 2 * (1 + self.padding)
+        half_height = (max_y - min_y) / 2 * (1 + self.padding)
+        if self.hw_ratio is not None:
+            half_height = max(self.hw_ratio[0] * half_width, half_height)
+            half_width = max(1 / self.hw_ratio[1] * half_height, half_width)
+        min_x, max_x = center[0] - half_width, center[0] + half_width
+        min_y, max_y = center[1] - half_height, center[1] + half_height
+        if not self.allow_imgpad:
+            min_x, min_y = int(max(0, min_x)), int(max(0, min_y))
+            max_x, max_y = int(min(w, max_x)), int(min(h, max_y))
+        else:
+            min_x, min_y = int(min_x), int(min_y)
+            max_x, max_y = int(max_x), int(max_y)
+        kp_x[kp_x != 0] -= min_x
+        kp_y[kp_y != 0] -= min_y
+        results['img_shape'] = (max_y - min_y, max_x - min_x)
+        a = results.get('crop_quadruple', (0., 0., 1., 1.))
+        b = (min_x / w, min_y / h, (max_x - min_x) / w, (max_y - min_y) / h)
+        results['crop_quadruple'] = (a[0] + a[2] * b[0], a[1] + a[3] * b[1], a[2] * b[2], a[3] * b[3])
         return results
 
 

@@ -90,3 +90,43 @@ def pipelines_2d():
         return p
     return {'coco_j': pipe(), 'coco_all': pipe(feats=('j', 'b', 'jm', 'bm')), 'coco_rot_b': pipe(rot=0.2, feats=('b',)),
             'coco_test3': pipe(clips=3)}
+
+
+# ---- compressed Kinetics pose annotations (HRNet detections: one row per detection) --------------------------------------
+
+def annotations_k400():
+    """Four clips in the compressed layout of data/k400/k400_hrnet.pkl: keypoint (D, 17, 3) fp16 = (x, y, score) per
+    detection, frame_inds (D,), box_score (D,), valid {thr: frames with a box above thr}; some frames without any
+    detection (squeeze), one clip with more persons in a frame than DecompressPose(max_person=2) keeps."""
+    rng = np.random.RandomState(91)
+    out = []
+    for i, (T, maxp) in enumerate([(30, 2), (22, 1), (40, 3), (18, 2)]):
+        frames, kps, bs = [], [], []
+        for t in range(T):
+            if (t + i) % 7 == 3:
+                continue                                        # a frame without detections
+            for _ in range(int(rng.randint(1, maxp + 1))):
+                xy = rng.rand(17, 2) * np.array([180, 120]) + np.array([60 + 3 * i, 40])
+                sc = rng.rand(17, 1) * 0.6 + 0.3
+                k = np.concatenate([xy, sc], 1)
+                if rng.rand() < 0.1:
+                    k[rng.randint(17)] = 0                      # a missing joint
+                frames.append(t); kps.append(k); bs.append(rng.rand() * 0.6 + 0.4)
+        bs = np.array(bs, dtype=np.float32)
+        fi = np.array(frames, dtype=np.int16)
+        valid = {thr: int(len(np.unique(fi[bs >= thr]))) for thr in (0.5, 0.6, 0.7, 0.8, 0.9)}
+        out.append(dict(frame_dir=f'k{i}', label=(37 * i) % 400, img_shape=(240, 320), original_shape=(240, 320),
+                        total_frames=T, frame_inds=fi, keypoint=np.stack(kps).astype(np.float16), box_score=bs, valid=valid))
+    return out
+
+
+def pipelines_k400():
+    """The transform chains of configs/dsstgcn/kinetics400_hrnet/j.py:25-72 (clip_len shortened)."""
+    def pipe(clips=1, max_person=10, **compact):
+        return [dict(type='DecompressPose', squeeze=True, max_person=max_person),
+                dict(type='UniformSampleFrames', clip_len=CLIP_LEN, num_clips=clips), dict(type='PoseDecode'),
+                dict(type='PoseCompact', **(compact or dict(hw_ratio=1., allow_imgpad=True))),
+                dict(type='GenSkeFeat', dataset='coco', feats=['j']), dict(type='FormatGCNInput', num_person=2),
+                dict(type='Collect', keys=['keypoint', 'label'], meta_keys=[]), dict(type='ToTensor', keys=['keypoint'])]
+    return {'k400_train': pipe(), 'k400_test3': pipe(clips=3), 'k400_cap2': pipe(max_person=2),
+            'k400_nopad': pipe(padding=0.1, threshold=10, hw_ratio=(0.8, 1.2), allow_imgpad=False)}

@@ -79,7 +79,7 @@ def load():
     _shell('pyskl.datasets.pipelines.Neural_GC_master.models', 'pyskl/datasets/pipelines/Neural_GC_master/models')
     _mod('pyskl.datasets.pipelines.Neural_GC_master.models.clstm', cLSTM=None, train_model_ista=None)
     mods = {n: importlib.import_module('pyskl.datasets.pipelines.' + n)
-            for n in ('compose', 'formatting', 'sampling', 'pose_related')}
+            for n in ('compose', 'formatting', 'sampling', 'pose_related', 'augmentations')}
     for k, v in saved.items():            # leave the model-side stubs of ref_shim.py as they were
         if v is not None:
             sys.modules[k] = v

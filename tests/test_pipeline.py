@@ -256,3 +256,40 @@ def test_pose_dataset_valid_ratio_and_box_thr(tmp_path):
         D.PoseDataset(str(path), ident, box_thr=0.55)
     with pytest.raises(NotImplementedError):
         D.PoseDataset(str(path), ident, memcached=True, mc_cfg=('localhost', 11211))
+
+
+from pipeline_cases import annotations_k400, pipelines_k400  # noqa: E402
+NAMES_K400 = list(pipelines_k400())
+
+
+@pytest.mark.parametrize('name', NAMES_K400)
+def test_host_pipeline_k400_vs_reference(name):
+    """The HRNet-pose Kinetics-400 chain of BASELINE config 5's data section (configs/dsstgcn/kinetics400_hrnet/j.py:25-72):
+    DecompressPose (detections -> (M, T, V) persons, frames without a detection squeezed out, the person cap) ->
+    UniformSampleFrames -> PoseDecode -> PoseCompact (tight box, padding, hw_ratio, with and without image padding) ->
+    GenSkeFeat(coco) -> FormatGCNInput, against the reference's own transforms on the same seeded RNG stream."""
+    pipe = P.Compose(copy.deepcopy(pipelines_k400()[name]))
+    np.random.seed(3000 + NAMES_K400.index(name))
+    for si, ann in enumerate(annotations_k400()):
+        sample = copy.deepcopy(ann)
+        sample['anno_inds'] = sample.pop('box_score') >= 0.5
+        sample.pop('valid')
+        sample.update(start_index=0, modality='Pose')
+        got = pipe(sample)['keypoint'].numpy()
+        want = Z[f'{name}_{si}']
+        assert got.shape == want.shape and got.dtype == want.dtype
+        assert np.array_equal(got, want), (name, si, np.abs(got - want).max())      # fp16 storage, integer crops: bit-exact
+
+
+def test_k400_dataset_builds_from_the_config_section(tmp_path):
+    """config 5's `data.train` dict (PoseDataset with box_thr / valid_ratio over the compressed pickle + the pipeline above)
+    builds through the registry and yields network inputs."""
+    path = tmp_path / 'k400.pkl'
+    with open(path, 'wb') as f:
+        pickle.dump(annotations_k400(), f)
+    ds = D.build_dataset(dict(type='PoseDataset', ann_file=str(path), pipeline=pipelines_k400()['k400_train'], box_thr=0.5,
+                              valid_ratio=0.0))
+    assert len(ds) == 4
+    np.random.seed(0)
+    item = ds[2]
+    assert tuple(item['keypoint'].shape) == (1, 2, CLIP_LEN, 17, 3) and item['label'] == annotations_k400()[2]['label']
