@@ -72,7 +72,8 @@ __device__ __forceinline__ float half_sum(float v) {
 // MODE 0: B' = b1;  1: relu?(b1*s1+h1);  2: relu?(b1*s1+h1 + b2*s2+h2).   EPI 0: forward (bias, statistics);  1: data gradient.
 // WM: row tiles (of 32 output rows) per workgroup = 4 or 2; the four waves are WM row tiles x 4/WM groups of the position
 // slots, a wave holds 32 rows x 32*WM slots.
-template <int MODE, int EPI, int WM>
+// QS: stride-1 staging with 16-byte loads (launcher: st == 1, up == 1, source planes a multiple of 4 floats long)
+template <int MODE, int EPI, int WM, bool QS = false>
 __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int PW = 4 / WM, NQW = WM;             // position groups per workgroup, 32-slot tiles per wave
@@ -98,9 +99,9 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
   const __amdgpu_buffer_rsrc_t r2 = tg_rsrc((MODE == 2 ? a.b2 : a.b1) + (size_t)ns * K * Ls, MODE == 2 ? K * Ls * 4 : 0);
   // staging items: (image row j, channel group cg = 4 channels); item = tid + TG_NT*i
   const int nit = (NR * 8 + TG_NT - 1) / TG_NT;
-  int soff[TG_MAXIT], sdst[TG_MAXIT];
+  int soff[QS ? 1 : TG_MAXIT], sdst[QS ? 1 : TG_MAXIT];
 #pragma unroll
-  for (int i = 0; i < TG_MAXIT; ++i) {
+  for (int i = 0; i < (QS ? 0 : TG_MAXIT); ++i) {
     const int item = tid + TG_NT * i, cg = item & 7, j = item >> 3;
     int fr, v;
     divmod_small(j, V, invV, fr, v);
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
   // workgroup's products cover this one's load latency).
   const float lo = a.relu ? 0.f : -__builtin_inff();
   auto stageB = [&](int ch0) {
+    if constexpr (QS) return;
     f32x4 pr[4];
     if (MODE != 0) {
 #pragma unroll
@@ -175,6 +177,86 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
       }
     }
   };
+  // Stride-1 staging with 16-byte loads (round 4): the image rows are CONSECUTIVE source positions starting at s0 =
+  // (f0 - pad)*V, so the tile is covered by the aligned quads [4*q0, 4*q0 + 4*nqd) of every channel's plane.  An item is
+  // (quad, group of 4 channels): four 16-byte loads give the thread a 4 x 4 block (channel x position) whose columns are
+  // whole 8-byte pieces of the image rows — 12 loads per thread and chunk where the scalar form above issues 48 (96 with
+  // two streams), each wave instruction covering 512 contiguous bytes per channel instead of eight 32-byte pieces.  Plane
+  // lengths are multiples of 4 here, so a quad is entirely inside or outside its plane (outside: zero AFTER the activation).
+  const int s0 = (f0 - pad) * V;
+  const int q0 = s0 >> 2;                          // floor (s0 may be negative)
+  const int nqd = ((s0 + NR - 1) >> 2) - q0 + 1;
+  constexpr int TG_MAXQ = 4, TG_QPASS = MODE == 2 ? 1 : 2;   // <= 98 quads x 8 channel groups = 784 items over 256 threads
+  auto stageBq = [&](int ch0) {
+    f32x4 pr[4];
+    if (MODE != 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = ch0 + 4 * (tid & 7) + e;
+        f32x4 p = {0.f, 0.f, 0.f, 0.f};
+        if (c < K) {
+          p.x = a.ps1 ? a.ps1[c] : 1.f;
+          p.y = a.ph1 ? a.ph1[c] : 0.f;
+          p.z = a.ps2 ? a.ps2[c] : 1.f;
+          p.w = a.ph2 ? a.ph2[c] : 0.f;
+        }
+        pr[e] = p;
+      }
+    }
+    const int nitq = (nqd * 8 + TG_NT - 1) / TG_NT;
+#pragma unroll
+    for (int i0 = 0; i0 < TG_MAXQ; i0 += TG_QPASS) {
+      if (i0 < nitq) {
+        f32x4 bw[TG_QPASS][4], bw2[MODE == 2 ? TG_QPASS : 1][4];
+#pragma unroll
+        for (int ii = 0; ii < TG_QPASS; ++ii) {
+          const int item = tid + TG_NT * (i0 + ii), qi = item >> 3;
+          const int p4 = 4 * (q0 + qi);
+          const bool qok = (qi < nqd) & (p4 >= 0) & (p4 < Ls);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = ch0 + 4 * (tid & 7) + e;
+            const int vo = ((c < K) & qok) ? ((4 * (tid & 7) + e) * Ls + p4) * 4 : TG_OOB;
+            bw[ii][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, vo, ch0 * Ls * 4, 0));
+            if constexpr (MODE == 2)
+              bw2[ii][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, vo, ch0 * Ls * 4, 0));
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < TG_QPASS; ++ii) {
+          const int item = tid + TG_NT * (i0 + ii), qi = item >> 3;
+          const int p4 = 4 * (q0 + qi);
+          const bool qin = (p4 >= 0) & (p4 < Ls);                       // inside the sample's frames
+          if (qi < nqd) {
+#pragma unroll
+            for (int pe = 0; pe < 4; ++pe) {
+              const int j = p4 + pe - s0;                                // image row of this position
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float x = bw[ii][e][pe];
+                if (MODE != 0) {
+                  x = fmaf(x, pr[e].x, pr[e].y);
+                  if constexpr (MODE == 2) x += fmaf(bw2[ii][e][pe], pr[e].z, pr[e].w);
+                  x = fmaxf(x, lo);
+                }
+                v[e] = qin ? x : 0.f;
+              }
+              if (j >= 0 && j < NR) {
+                unsigned p0, p1, p2, q0_, q1, q2;
+                b3_split(v[0], v[1], p0, p1, p2);
+                b3_split(v[2], v[3], q0_, q1, q2);
+                char* base = Bb + j * TG_RB + (tid & 7) * 8;
+                *reinterpret_cast<u32x2v*>(base) = u32x2v{p0, q0_};
+                *reinterpret_cast<u32x2v*>(base + NRA * TG_RB) = u32x2v{p1, q1};
+                *reinterpret_cast<u32x2v*>(base + 2 * NRA * TG_RB) = u32x2v{p2, q2};
+              }
+            }
+          }
+        }
+      }
+    }
+  };
   // A fragments straight from the pre-split image (L2): lane (l31, half) of row tile rt wants, per term and k-step, the 8
   // consecutive k [16*ks + 8*half, +8) of row mBase0 + 32*rt + l31 — 16 contiguous bytes.  No LDS copy, no barrier per tap.
   const unsigned short* arow = a.wsp + ((size_t)(mBase0 + 32 * rt + l31) * a.Kp + 8 * half);
@@ -210,7 +292,8 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    stageB(ch0);
+    if constexpr (QS) stageBq(ch0);
+    else stageB(ch0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll 1
@@ -261,18 +344,19 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
   const size_t obase = (size_t)ns * M * L;
   if (EPI == 0) {
     const bool stats = a.partial != nullptr;
+    const __amdgpu_buffer_rsrc_t ro = tg_rsrc(a.out + obase, M * L * 4);      // dead slots / rows: out-of-range offsets, no branches
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row32 = tg_row32(r, half), row = mBase0 + 32 * rt + row32;
       float s = 0.f, qq = 0.f;
 #pragma unroll
       for (int q = 0; q < NQW; ++q) {
-        const float v = acc[q][r];
-        if (ovalid[q] && row < M) {
-          a.out[obase + (size_t)row * L + opos[q]] = v;
-          s += v;
-          qq = fmaf(v, v, qq);
-        }
+        const bool ok = ovalid[q] && row < M;
+        const float v = ok ? acc[q][r] : 0.f;
+        const int vo = (int)((unsigned)(ok ? opos[q] * 4 : TG_OOB) + (unsigned)(row * L * 4));
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, vo, 0, 0);
+        s += v;
+        qq = fmaf(v, v, qq);
       }
       if (stats) {
         s = half_sum(s);
@@ -296,33 +380,65 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
   } else {
     const bool has2 = a.ex2 != nullptr, sums = a.ipart != nullptr;
     const bool need_x = a.erelu || a.es1 != nullptr || has2;
+    // The forward's operands (ReLU mask, affine sums) come through buffer loads with out-of-range offsets for dead slots /
+    // rows — no branches — and are fetched one group of four rows AHEAD of the group being finished: as a per-element
+    // `if (valid) { load; use; store }` the epilogue was sixteen dependent round trips per wave (the data gradient ran at
+    // 1.5x the forward's time; round 4).
+    const __amdgpu_buffer_rsrc_t rx1 = tg_rsrc(a.ex1 + obase, need_x ? M * L * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rx2 = tg_rsrc((has2 ? a.ex2 : a.ex1) + obase, has2 ? M * L * 4 : 0);
+    const __amdgpu_buffer_rsrc_t ro1 = tg_rsrc(a.out + obase, M * L * 4);
+    const __amdgpu_buffer_rsrc_t ro2 = tg_rsrc((a.out2 ? a.out2 : a.out) + obase, a.out2 ? M * L * 4 : 0);
+    int ooff[NQW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row32 = tg_row32(r, half), row = mBase0 + 32 * rt + row32;
-      const bool rok = row < M;
-      const float e1s = (rok && a.es1) ? a.es1[row] : 1.f, e1h = (rok && a.es1) ? a.eh1[row] : 0.f;
-      const float e2s = (rok && a.es2) ? a.es2[row] : 1.f, e2h = (rok && a.es2) ? a.eh2[row] : 0.f;
-      float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+    for (int q = 0; q < NQW; ++q) ooff[q] = ovalid[q] ? opos[q] * 4 : TG_OOB;
+    float xa[2][4][NQW], xb[2][4][NQW];
+    auto fetch = [&](int g, int slot) {
 #pragma unroll
-      for (int q = 0; q < NQW; ++q) {
-        if (ovalid[q] && rok) {
-          const size_t o = obase + (size_t)row * L + opos[q];
-          const float xa = need_x ? a.ex1[o] : 0.f;
-          const float xb = has2 ? a.ex2[o] : 0.f;
-          float pre = fmaf(xa, e1s, e1h);
-          if (has2) pre += fmaf(xb, e2s, e2h);
-          const float dv = (!a.erelu || pre > 0.f) ? acc[q][r] : 0.f;
-          a.out[o] = dv * e1s;
-          if (a.out2) a.out2[o] = dv * e2s;
-          u0 = fmaf(dv, xa, u0);
-          u1 += dv;
-          u2 = fmaf(dv, xb, u2);
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = mBase0 + 32 * rt + tg_row32(4 * g + rr, half);
+#pragma unroll
+        for (int q = 0; q < NQW; ++q) {
+          const int vo = (int)((unsigned)(row < M ? ooff[q] : TG_OOB) + (unsigned)(row * L * 4));
+          xa[slot][rr][q] = tg_load(rx1, vo, 0);
+          xb[slot][rr][q] = tg_load(rx2, vo, 0);
         }
       }
-      if (sums) {
-        u0 = half_sum(u0); u1 = half_sum(u1); u2 = half_sum(u2);
-        if (l31 == 0) { float* d = Ss + (wave * 32 + row32) * 3; d[0] = u0; d[1] = u1; d[2] = u2; }
+    };
+    fetch(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int slot = g & 1;
+      if (g + 1 < 4) fetch(g + 1, slot ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = 4 * g + rr;
+        const int row32 = tg_row32(r, half), row = mBase0 + 32 * rt + row32;
+        const bool rok = row < M;
+        const float e1s = (rok && a.es1) ? a.es1[row] : 1.f, e1h = (rok && a.es1) ? a.eh1[row] : 0.f;
+        const float e2s = (rok && a.es2) ? a.es2[row] : 1.f, e2h = (rok && a.es2) ? a.eh2[row] : 0.f;
+        float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQW; ++q) {
+          const bool ok = ovalid[q] && rok;
+          const float xav = xa[slot][rr][q], xbv = xb[slot][rr][q];
+          float pre = fmaf(xav, e1s, e1h);
+          if (has2) pre += fmaf(xbv, e2s, e2h);
+          const float dv = (ok && (!a.erelu || pre > 0.f)) ? acc[q][r] : 0.f;
+          const int vo = (int)((unsigned)(rok ? ooff[q] : TG_OOB) + (unsigned)(row * L * 4));
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dv * e1s), ro1, vo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dv * e2s), ro2, vo, 0, 0);   // zero-sized resource: no dx2
+          u0 = fmaf(dv, xav, u0);
+          u1 += dv;
+          u2 = fmaf(dv, xbv, u2);
+        }
+        if (sums) {
+          u0 = half_sum(u0); u1 = half_sum(u1); u2 = half_sum(u2);
+          if (l31 == 0) { float* d = Ss + (wave * 32 + row32) * 3; d[0] = u0; d[1] = u1; d[2] = u2; }
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (sums) {
       __syncthreads();
@@ -806,12 +922,14 @@ bool tg_plan(int n, int K, int M, int Ts, int To, int V, int KT, int st, TgPlan*
   return true;
 }
 
-template <int EPI, int WM>
-int tg_launch_wm(const TcgArgs& a, int mode, const TgPlan& p, hipStream_t st) {
+int g_tg_quad = 1;                                 // lab knob (dsgcn_tconv_tuning): stride-1 staging with 16-byte loads on / off
+
+template <int EPI, int WM, bool QS>
+int tg_launch_qs(const TcgArgs& a, int mode, const TgPlan& p, hipStream_t st) {
   static bool raised = false;
   if (!raised) {
-    const void* fs[3] = {reinterpret_cast<const void*>(&k_tcg<0, EPI, WM>), reinterpret_cast<const void*>(&k_tcg<1, EPI, WM>),
-                         reinterpret_cast<const void*>(&k_tcg<2, EPI, WM>)};
+    const void* fs[3] = {reinterpret_cast<const void*>(&k_tcg<0, EPI, WM, QS>), reinterpret_cast<const void*>(&k_tcg<1, EPI, WM, QS>),
+                         reinterpret_cast<const void*>(&k_tcg<2, EPI, WM, QS>)};
     for (const void* f : fs) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       if (e != hipSuccess) return (int)e;
@@ -819,11 +937,18 @@ int tg_launch_wm(const TcgArgs& a, int mode, const TgPlan& p, hipStream_t st) {
     raised = true;
   }
   const dim3 grid(p.grid), blk(TG_NT);
-  if (mode == 0) hipLaunchKernelGGL((k_tcg<0, EPI, WM>), grid, blk, p.lds, st, a);
-  else if (mode == 1) hipLaunchKernelGGL((k_tcg<1, EPI, WM>), grid, blk, p.lds, st, a);
-  else hipLaunchKernelGGL((k_tcg<2, EPI, WM>), grid, blk, p.lds, st, a);
+  if (mode == 0) hipLaunchKernelGGL((k_tcg<0, EPI, WM, QS>), grid, blk, p.lds, st, a);
+  else if (mode == 1) hipLaunchKernelGGL((k_tcg<1, EPI, WM, QS>), grid, blk, p.lds, st, a);
+  else hipLaunchKernelGGL((k_tcg<2, EPI, WM, QS>), grid, blk, p.lds, st, a);
   DSGCN_LAUNCH_CHECK();
   return 0;
+}
+
+template <int EPI, int WM>
+int tg_launch_wm(const TcgArgs& a, int mode, const TgPlan& p, hipStream_t st) {
+  // stride 1 on both sides and source planes a multiple of 4 floats long: the 16-byte staging
+  const bool qs = g_tg_quad && a.st == 1 && a.up == 1 && ((a.Ts * a.V) & 3) == 0;
+  return qs ? tg_launch_qs<EPI, WM, true>(a, mode, p, st) : tg_launch_qs<EPI, WM, false>(a, mode, p, st);
 }
 
 template <int EPI>
@@ -966,6 +1091,10 @@ int dsgcn_tconv_wgrad(const float* x1, const float* s1, const float* h1, const f
 #ifdef DSGCN_LAB
 int dsgcn_tcw_phases(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tcw_stamp), sizeof(long long) * 64);
+}
+int dsgcn_tconv_tuning(int key, int value) {
+  if (key == 0) { g_tg_quad = value; return 0; }
+  return DSGCN_EINVAL;
 }
 #endif
 

@@ -116,6 +116,7 @@ LAB_SIGNATURES = {
     'dsgcn_pwg2_phases_block': [c_int],
     'dsgcn_bwd64_phases': [ctypes.c_void_p],
     'dsgcn_tcw_phases': [ctypes.c_void_p],
+    'dsgcn_tconv_tuning': [c_int, c_int],
 }
 
 

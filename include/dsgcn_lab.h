@@ -49,6 +49,8 @@ int dsgcn_bwd64_phases(long long* out);
 /* temporal-conv weight gradient (k_tcw): stamps of workgroup 0, per tap group (before issue, after issue, after the
  * barrier, after the products); out[63] = count. */
 int dsgcn_tcw_phases(long long* out);
+/* dense temporal conv (k_tcg): key 0 = stride-1 staging with 16-byte loads on (1, default) / off (0: the 4-byte form) */
+int dsgcn_tconv_tuning(int key, int value);
 
 #ifdef __cplusplus
 }

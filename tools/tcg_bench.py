@@ -8,6 +8,8 @@ import torch
 from dsgcn_amd import native
 LAB = os.environ.get('TC_LAB') == '1'
 lib = native.lab_lib() if LAB else native.lib(); dev = 'cuda'; st = torch.cuda.current_stream().cuda_stream
+if LAB and os.environ.get('TC_QUAD') is not None:
+    assert lib.dsgcn_tconv_tuning(0, int(os.environ['TC_QUAD'])) == 0      # 0: the 4-byte staging of k_tcg (round 3)
 n, V, KT = int(os.environ.get('TC_N', 128)), 25, 9
 SHAPES = [('s1', 64, 64, 64, 1), ('s2t', 64, 128, 64, 2), ('s2', 128, 128, 32, 1), ('s3t', 128, 256, 32, 2), ('s3', 256, 256, 16, 1)]
 P = lambda t: None if t is None else t.data_ptr()
@@ -63,6 +65,8 @@ for name, Ci, Co, T, s in SHAPES:
     fl = 2.0 * n * To * V * Ci * Co * KT
     r = [timeit(k) for k in (f, d, g)]
     try:
+        if os.environ.get('TC_SKIP_GEN1'):
+            raise RuntimeError('skipped')
         assert f0() == 0 and d0() == 0 and g0() == 0
         r0 = [timeit(k) for k in (f0, d0, g0)]
     except Exception as e:
