@@ -344,16 +344,29 @@ __global__ __launch_bounds__(64) void k_aggsum_fwd_pipe(const float* __restrict_
     if (k == K - 1) {
       float* __restrict__ yo = y + ((size_t)unit * T + t0) * V;
       float sum = 0.f, sq = 0.f;
+      // Y leaves through the wave's P slice (dead after the last subset's products): 16-byte row-major stores instead of
+      // sixteen 4-byte stores of 25 lanes each (what the backward got in round 3)
+      wave_lds_sync();
       if (mi < V) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int t = as_row(r, mk);
           if (t < rows) {
             const float v = acc[r];
-            yo[t * V + mi] = v;
+            ldsP[t * V + mi] = v;
             sum += v;
             sq = fmaf(v, v, sq);
           }
+        }
+      }
+      wave_lds_sync();
+      {
+        const f32x4* l4 = reinterpret_cast<const f32x4*>(ldsP);
+        f32x4* __restrict__ y4 = reinterpret_cast<f32x4*>(yo);
+#pragma unroll
+        for (int q = 0; q < NP4; ++q) {
+          const int i = lane + q * 64;
+          if (i < c4) y4[i] = l4[i];
         }
       }
       if (partial) {

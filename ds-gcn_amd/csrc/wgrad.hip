@@ -528,14 +528,15 @@ __global__ __launch_bounds__(W3_NT, 2) void k_wg3(Wg2Args a) {
   }
 }
 
-int g_wg2_target4 = 512, g_wg2_kc128 = 32, g_wg2_target1 = 512, g_wg2_b3 = 1, g_wg3 = 1, g_wg3_target = 256, g_wg3_tm = 128;    // lab knobs (dsgcn_pwconv_tuning keys 7, 8); the values are the product's
+int g_wg2_target4 = 512, g_wg2_kc128 = 32, g_wg2_target1 = 512, g_wg2_b3 = 1, g_wg3 = 3, g_wg3_target = 256, g_wg3_tm = 128;    // lab knobs (dsgcn_pwconv_tuning keys 7, 8); the values are the product's
 
 struct Wg2Plan { int TM, TN, KC, cpn, chunks, tm_tiles, tn_tiles, splits, cps, b3, v3; size_t lds; };
 
 bool wg2_plan(int n, int Ci, int Co, int L, Wg2Plan* p) {
   if ((long)Ci * L * 4 >= (1L << 31) - 64 || (long)Co * L * 4 >= (1L << 31) - 64) return false;
   p->v3 = 0;
-  if (g_wg3 && g_wg2_b3 && (Co > 128 || Ci > 128) && Co > 64 && Ci > 64) {     // wide: one workgroup per CU owns the whole tile
+  if (g_wg3 && g_wg2_b3 && (Co > 128 || Ci > 128) && ((Co > 64 && Ci > 64) || (g_wg3 & 2))) {     // wide: one workgroup per CU owns the whole tile
+    // (g_wg3 bit 1, lab: also the lop-sided convs — CTR-GCN's conv4, R <= 32 -> 128..256 channels — measured below)
     p->v3 = 1; p->b3 = 1;
     p->TM = (Co > 128 && (g_wg3_tm == 256 || Ci <= 128)) ? 256 : 128;     // (g_wg3_tm = 128: two 128 x 256 tiles, half the partial rows)
     p->TN = Ci > 128 ? 256 : 128;
