@@ -306,7 +306,7 @@ __device__ __forceinline__ void tm_commit(const TmArgs& a, const TmBranch& br, c
 // forward
 // ---------------------------------------------------------------------------------------------------------------
 template <int KT, int MTL>
-__global__ __launch_bounds__(TM_NT, 4) void k_tms_fwd(TmArgs a) {
+__global__ __launch_bounds__(TM_NT, MTL >= 3 ? 3 : 4) void k_tms_fwd(TmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const TmBranch& br = a.br[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63;
