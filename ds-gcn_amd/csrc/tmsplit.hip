@@ -1,0 +1,1338 @@
+// K-D, split layout: the multi-scale temporal stage of dgmstcn (reference: pyskl/models/gcns/utils/tcn.py:379-428) between
+// the unit's two 1x1 convs WITHOUT its (V+1)-column intermediates.  tcn.py:409 appends the global joint (the mean over the
+// joints) as a 26th column, runs BatchNorm + ReLU and the six temporal branches on the widened tensor and folds the extra
+// column back with `x[..., :V] + einsum(x[..., V], add_coeff)` (tcn.py:416-420).  Every stage in between is column-wise, so
+// the stage splits exactly into a V-column part and a one-column part:
+//
+//   forward   k_tsp_aug_fwd : the one-column part of the conv windows, oaug (n,C,T)           (tiny; zero-fills the
+//                             statistics rows the main launch does not write)
+//             k_tsp<true>   : conv windows on the f32 matrix core, B operand = relu(z*scale+shift) formed while loading z
+//                             (V columns: 16-byte planes; a tap shifts by dil*V positions, an ODD shift is read with two
+//                             4-byte-aligned 8-byte loads per side tap and the two plane-end cases fixed up by select),
+//                             epilogue f = acc + bias + oaug[t]*coeff[v] + the batch statistics of f (transform.0's
+//                             BatchNorm, tcn.py:401) — h, o and the old branch_act / combine passes never exist;
+//                             max-pool / pass-through windows as whole-plane passes through LDS in the same launch
+//   backward  k_tsp_prep    : ge = gf + A0 + B0*f (one materialised copy: it feeds the data AND the weight gradient), its
+//                             global-joint column doaug = sum_v ge*coeff, d coeff partials
+//             k_tsp_aug_bwd : the one-column part of the data gradient (dzaug + its share of the BatchNorm sums)
+//             k_tsp<false>  : transposed windows over ge; epilogue dz = relu'(z*scale+shift) * acc * scale and the
+//                             sums of the branch BatchNorm's backward (sum dpre*z, sum dpre) — dh / branch_act_bwd gone
+//             k_tspw        : weight gradient; the staging step reads ge / z in V-column rows (16-byte loads), applies
+//                             the affine + ReLU and lays the tile out in LDS at V+1 columns with the global-joint column
+//                             in place, so the matrix loop of k_tapw (csrc/tapconv.hip) runs unchanged and dW / db carry
+//                             the one-column part too
+// Stride 1, kernel 3, windows <= 64 channels, dilation <= 4, T % 4 == 0; everything else stays on the staged path
+// (branch_act -> tapconv -> combine).  The matrix loops are tapconv.hip's tap4 / tapw forms.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TS_NT = 256;
+constexpr int TS_MAXBR = 8;
+constexpr int TS_OOB = 0x7ffffff0;
+constexpr int TS_R = 4, TS_H = 4;                 // weight gradient: frames per unit, halo frames per side (max dilation)
+
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+
+struct TSBranch {
+  int type;            // 0 conv, 1 max (3,1), 2 pass-through
+  int c0, bc, dil;     // channel window (input and output coincide), dilation
+  const float* w;      // (bc, bc, 3, 1)
+  const float* b;      // (bc) or NULL
+  float* dwp;          // (splits, bc*bc*3) partials
+  float* dbp;          // (splits, bc)
+};
+
+struct TSArgs {
+  const float* z; const float* zaug; const float* scale; const float* shift;
+  const float* coeff;
+  float* f; float* oaug; float* stats;            // forward outputs ((n,C,T,V), (n,C,T)+1 float, (rows,C,2))
+  const float* ge; const float* doaug;            // backward inputs
+  float* dz; float* dzaug; float* part;           // backward outputs ((rows,C,2): sum dpre*x, sum dpre)
+  int n_act, n, C, T, V, nbr, ngrp, nconv, eplanes, sboff, splits, pstride;
+  int exp;             // lab builds only: timing experiments that skip parts of the work (0 in the product)
+  TSBranch br[TS_MAXBR];
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ts_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ts_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x2s ts_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x2s, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void ts_store4(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ int ts_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// vector offset of a per-row access (the row depends on the lane's half: it must not reach the scalar operand)
+__device__ __forceinline__ int ts_rowoff(bool ok, int base, int rowoff) {
+  return (int)((unsigned)(ok ? base : TS_OOB) + (unsigned)rowoff);
+}
+__device__ __forceinline__ int ts_cp(int bc) { return (min(64, max(bc, 1)) + 7) & ~7; }
+
+__device__ __forceinline__ const TSBranch& ts_conv_window(const TSArgs& a, int w) {
+  int bi = 0;
+  for (int i = 0, k = 0; i < a.nbr; ++i)
+    if (a.br[i].type == 0) { if (k == w) bi = i; ++k; }
+  return a.br[bi];
+}
+
+// Sum of half of row l31 of a wave's [32][36] LDS tile (lane (half, l31); the caller adds the two halves).
+template <typename ACC>
+__device__ __forceinline__ ACC ts_rowread(const float* Tw, int half, int l31) {
+  const f32x4* rowp = reinterpret_cast<const f32x4*>(Tw + l31 * 36 + half * 16);
+  ACC s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = rowp[q];
+    s += ((ACC)v.x + (ACC)v.y) + ((ACC)v.z + (ACC)v.w);
+  }
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv window, forward (FWD) or data gradient: four waves x 128 positions of the V-column planes, all samples back to
+// back; a lane owns four consecutive positions of one channel row (tap4's scheme).
+// LDS: [0, sboff) = the weight tile [co][tap*CP + ci], reused by the epilogue's transposes; [sboff, +192) = per-channel
+// (scale, shift) pairs and bias of the window.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool FWD, int MT, bool ODD>
+__device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, float* lds, int grp, int lane, int wave) {
+  constexpr int KT = 3, PDK = 2, NS = KT * PDK;
+  const int tid = threadIdx.x;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int V = a.V, T = a.T, L = T * V, L4 = L * 4, C = a.C, bc = br.bc;
+  const int CP = ts_cp(bc), S = KT * CP + 1;
+  float* Ws = lds;
+  f32x2s* SB = reinterpret_cast<f32x2s*>(lds + a.sboff);   // [64] (scale, shift): zero past the window
+  float* BI = lds + a.sboff + 128;                         // [64] bias
+  const bool relu = br.c0 < a.n_act;
+  const int wt = grp * 4 + wave;
+  const long total = (long)a.n * L;
+  const bool wlive = (long)wt * 128 < total;
+  const int g0 = wlive ? wt * 128 : 0;
+  const int n0 = g0 / L;
+  int p = g0 - n0 * L + 4 * l31, ds = 0;
+  while (p >= L) { p -= L; ++ds; }
+  const bool pok = wlive && n0 + ds < a.n;
+  const __amdgpu_buffer_rsrc_t rs = ts_rsrc(FWD ? a.z : a.ge, (size_t)a.n * C * L4);
+  const int rowbase = ((n0 + ds) * C + br.c0 + half) * L;
+  // A side tap shifts by +-dil*V positions.  Even shift: two aligned 8-byte pairs, each wholly inside or outside the plane.
+  // Odd shift: the pairs are only 4-byte aligned and one of them can straddle a plane end — (-1, 0) is read as (0, 1) and
+  // (L-1, L) as (L-2, L-1), both wholly inside the tensor, and the wanted element moved over by a select.
+  const int sh = (FWD ? br.dil : -br.dil) * V;
+  int vP[KT][2];
+  float mk[KT][4];
+  bool fS[KT][2], fE[KT][2];
+#pragma unroll
+  for (int tap = 0; tap < KT; ++tap)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = p + (tap - 1) * sh + 2 * j;
+      const bool e0 = q >= 0 && q < L, e1 = q + 1 >= 0 && q + 1 < L;
+      const bool s = ODD && !e0 && e1, e = ODD && e0 && !e1;
+      const int qa = s ? q + 1 : (e ? q - 1 : q);
+      fS[tap][j] = s;
+      fE[tap][j] = e;
+      vP[tap][j] = (pok && (e0 || e1)) ? (rowbase + qa) * 4 : TS_OOB;
+      mk[tap][2 * j] = (pok && e0) ? 1.f : 0.f;
+      mk[tap][2 * j + 1] = (pok && e1) ? 1.f : 0.f;
+    }
+  auto load = [&](int tap, int ks) -> f32x4 {
+    const int soff = 2 * ks * L4;
+    if (tap == 1) return ts_load4(rs, vP[1][0], soff);
+    const f32x2s lo = ts_load2(rs, vP[tap][0], soff), hi = ts_load2(rs, vP[tap][1], soff);
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+  };
+
+  // forward epilogue: frame of the lane's first position, add_coeff of its four joints (the run may cross into frame t0+1)
+  int t0 = 0;
+  float cf[4] = {0.f, 0.f, 0.f, 0.f};
+  bool nx[4] = {false, false, false, false};
+  if constexpr (FWD) {
+    int v0;
+    divmod_small(p, V, 1.f / (float)V, t0, v0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int vv = v0 + k;
+      nx[k] = vv >= V;
+      cf[k] = a.coeff[nx[k] ? vv - V : vv];
+    }
+  }
+  const int KS2 = ((bc + 3) >> 2) << 1;                      // k-steps of two channels, even (weights are zero past bc)
+  f32x4 buf[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    buf[u] = load(u % KT, u / KT);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // Staging (the operand prefetch above is already in flight: the block pays ONE memory round trip before its first
+  // product, not one per stage): weights [co][tap*CP + ci] zero padded, per-channel (scale, shift) and bias.
+  {
+    const int run = bc * KT, wtotal = bc * run;
+    float wv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = tid + q * TS_NT;
+      wv[q] = i < wtotal ? br.w[i] : 0.f;
+    }
+    f32x2s sb = {0.f, 0.f};
+    float bi = 0.f;
+    if (tid < bc) {
+      const int c = br.c0 + tid;
+      sb = f32x2s{a.scale ? a.scale[c] : 1.f, a.shift ? a.shift[c] : 0.f};
+      if (br.b) bi = br.b[tid];
+    }
+    for (int i = tid; i < 64 * S + 64; i += TS_NT) Ws[i] = 0.f;
+    if (tid < 64) {
+      SB[tid] = sb;
+      BI[tid] = bi;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = tid + q * TS_NT;
+      if (i < wtotal) {
+        const int co = i / run, r = i - co * run, ci = r / KT, tap = r - ci * KT;
+        Ws[co * S + tap * CP + ci] = wv[q];
+      }
+    }
+    for (int i0 = 8 * TS_NT; i0 < wtotal; i0 += 8 * TS_NT) {     // windows wider than 26 channels: the rest of the tile
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = i0 + tid + q * TS_NT;
+        wv[q] = i < wtotal ? br.w[i] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = i0 + tid + q * TS_NT;
+        if (i < wtotal) {
+          const int co = i / run, r = i - co * run, ci = r / KT, tap = r - ci * KT;
+          Ws[co * S + tap * CP + ci] = wv[q];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  f32x16 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+  auto afrag = [&](int tap, int ks, int m) -> float {
+    const int kl = 2 * ks + half;
+    return FWD ? Ws[(32 * m + l31) * S + tap * CP + kl] : Ws[kl * S + tap * CP + 32 * m + l31];
+  };
+  float avb[2][MT];
+  f32x2s sbv[2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) avb[0][m] = afrag(0, 0, m);
+  sbv[0] = SB[half];
+  for (int base = 0; base < KS2; base += PDK) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int tap = u % KT, ks = base + u / KT;
+      const int cur = u & 1, nxt = cur ^ 1;
+      const int tn = (u + 1) % KT, kn = base + (u + 1) / KT;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) avb[nxt][m] = afrag(tn, kn < 32 ? kn : 31, m);
+      if (FWD) sbv[nxt] = SB[2 * (kn < 32 ? kn : 31) + half];
+      f32x4 b = buf[u];
+      if (tap != 1) {
+        if (ODD) {
+          const float x0 = b.x, y0 = b.y, x1 = b.z, y1 = b.w;
+          b.x = fE[tap][0] ? y0 : x0;
+          b.y = fS[tap][0] ? x0 : y0;
+          b.z = fE[tap][1] ? y1 : x1;
+          b.w = fS[tap][1] ? x1 : y1;
+        }
+      }
+      if (FWD && !(a.exp & 4)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = fmaf(b[q], sbv[cur].x, sbv[cur].y);
+          if (relu) v = fmaxf(v, 0.f);
+          if (tap != 1) v *= mk[tap][q];
+          b[q] = v;
+        }
+      } else if (ODD && tap != 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] *= mk[tap][q];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(avb[cur][m], b[q], acc[m][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      buf[u] = load(tap, min(ks + PDK, KS2 - 1));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // The epilogue's first operands (forward: the global-joint column of the lane's rows; data gradient: z) are requested
+  // before the barrier that hands the weight tile's LDS to the transposes, so that their round trip overlaps it.
+  float* Tw = lds + wave * (2 * 32 * 36);
+  const int ooff = pok ? (((n0 + ds) * C + br.c0) * L + p) * 4 : TS_OOB;
+  if constexpr (FWD) {
+    double* Ss = reinterpret_cast<double*>(lds + 4 * 2 * 32 * 36);   // [4][MT*32][2]
+    const __amdgpu_buffer_rsrc_t ra = ts_rsrc(a.oaug, ((size_t)a.n * C * T + 1) * 4);
+    const __amdgpu_buffer_rsrc_t ro = ts_rsrc(a.f, (size_t)a.n * C * L4);
+    const int aoff = pok ? (((n0 + ds) * C + br.c0) * T + t0) * 4 : TS_OOB;
+    const bool stats = a.stats != nullptr && !(a.exp & 2);
+    f32x2s oa[MT][16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = 32 * m + ts_row32(r, half);
+        oa[m][r] = ts_load2(ra, ts_rowoff(ch < bc, aoff, ch * T * 4), 0);
+      }
+    __syncthreads();                                // the weight tile is dead: its LDS carries the transposes
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = ts_row32(r, half);
+        const int ch = 32 * m + row;
+        const float bias = BI[ch];
+        f32x4 val;
+        float s = 0.f, qq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          val[k] = fmaf(nx[k] ? oa[m][r].y : oa[m][r].x, cf[k], acc[m][k][r] + bias);
+          s += val[k];
+          qq = fmaf(val[k], val[k], qq);
+        }
+        ts_store4(val, ro, ts_rowoff(ch < bc, ooff, ch * L4));
+        if (stats) {
+          const bool ok = ch < bc && pok;
+          Tw[row * 36 + l31] = ok ? s : 0.f;
+          Tw[32 * 36 + row * 36 + l31] = ok ? qq : 0.f;
+        }
+      }
+      if (stats) {
+        wave_lds_sync();
+        double sd = ts_rowread<double>(Tw, half, l31);
+        double qd = ts_rowread<double>(Tw + 32 * 36, half, l31);
+        wave_lds_sync();
+        sd += __shfl_xor(sd, 32, 64);
+        qd += __shfl_xor(qd, 32, 64);
+        if (half == 0) {
+          Ss[((wave * MT + m) * 32 + l31) * 2 + 0] = sd;
+          Ss[((wave * MT + m) * 32 + l31) * 2 + 1] = qd;
+        }
+      }
+    }
+    if (stats) {
+      __syncthreads();
+      if (tid < 32 * MT && tid < bc) {
+        double s4 = 0.0, q4 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s4 += Ss[((w * MT * 32) + tid) * 2]; q4 += Ss[((w * MT * 32) + tid) * 2 + 1]; }
+        a.stats[((size_t)grp * C + br.c0 + tid) * 2 + 0] = (float)s4;
+        a.stats[((size_t)grp * C + br.c0 + tid) * 2 + 1] = (float)q4;
+      }
+    }
+  } else {
+    float* Ss = lds + 4 * 2 * 32 * 36;                                 // [4][MT*32][2]
+    const __amdgpu_buffer_rsrc_t rx = ts_rsrc(a.z, (size_t)a.n * C * L4);
+    const __amdgpu_buffer_rsrc_t ro = ts_rsrc(a.dz, (size_t)a.n * C * L4);
+    constexpr int G = MT * 4, PD = 4;
+    f32x4 xa[PD][4];
+    auto fetch = [&](int g, int slot) {
+      const int m = g >> 2, rb = (g & 3) * 4;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int ch = 32 * m + ts_row32(rb + rr, half);
+        xa[slot][rr] = ts_load4(rx, ts_rowoff(ch < bc, ooff, ch * L4), 0);
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < PD; ++g) fetch(g, g);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                // the weight tile is dead: its LDS carries the transposes
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int m = g >> 2, rb = (g & 3) * 4;
+      const int slot = g % PD;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = rb + rr;
+        const int row = ts_row32(r, half);
+        const int ch = 32 * m + row;
+        const f32x2s e = SB[ch];
+        float u0 = 0.f, u1 = 0.f;
+        f32x4 d;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float x = xa[slot][rr][q];
+          const float pre = fmaf(x, e.x, e.y);
+          const float dv = (!relu || pre > 0.f) ? acc[m][q][r] : 0.f;
+          d[q] = dv * e.x;
+          u0 = fmaf(dv, x, u0);
+          u1 += dv;
+        }
+        ts_store4(d, ro, ts_rowoff(ch < bc, ooff, ch * L4));
+        const bool ok = ch < bc && pok;
+        Tw[row * 36 + l31] = ok ? u0 : 0.f;
+        Tw[32 * 36 + row * 36 + l31] = ok ? u1 : 0.f;
+      }
+      if (MT == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + PD < G) fetch(g + PD, slot);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if ((g & 3) == 3) {
+        wave_lds_sync();
+        float s0 = ts_rowread<float>(Tw, half, l31);
+        float s1 = ts_rowread<float>(Tw + 32 * 36, half, l31);
+        wave_lds_sync();
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if (half == 0) {
+          Ss[((wave * MT + m) * 32 + l31) * 2 + 0] = s0;
+          Ss[((wave * MT + m) * 32 + l31) * 2 + 1] = s1;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 32 * MT && tid < bc) {
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { v0 += Ss[((w * MT * 32) + tid) * 2]; v1 += Ss[((w * MT * 32) + tid) * 2 + 1]; }
+      a.part[((size_t)grp * C + br.c0 + tid) * 2 + 0] = v0;
+      a.part[((size_t)grp * C + br.c0 + tid) * 2 + 1] = v1;
+    }
+  }
+}
+
+// max-pool / pass-through window, one wave per (n, c) plane.  Every global operand of the wave (the plane(s), the
+// global-joint columns) is requested before the first LDS write.  lw: [L] z (forward: h = act(z)), [L] ge (backward),
+// then [T] act(zaug), [T] pooled column / doaug, [32] coeff.  Planes up to 8 float4 per lane (T*V <= 2048).
+constexpr int TS_PQ = 8;
+
+template <bool FWD>
+__device__ __forceinline__ void ts_elem(const TSArgs& a, const TSBranch& br, float* lw, int n, int c, int lane) {
+  const int V = a.V, T = a.T, L = T * V, L4n = L >> 2, C = a.C;
+  const int cc = br.c0 + c;
+  const size_t plane = (size_t)n * C + cc;
+  const bool relu = cc < a.n_act;
+  const bool pool = br.type == 1;
+  const float invV = 1.f / (float)V;
+  const int Tp = (T + 3) & ~3;
+  float* hp = lw;
+  float* gp = lw + L;
+  float* ha = lw + (FWD ? 1 : 2) * L;
+  float* oa = ha + Tp;
+  float* cf = oa + Tp;
+  const float* za = a.zaug + plane * T;
+  const f32x4* z4 = reinterpret_cast<const f32x4*>(a.z + plane * L);
+  const f32x4* g4 = FWD ? nullptr : reinterpret_cast<const f32x4*>(a.ge + plane * L);
+  auto act = [&](float x, float s, float b) -> float {
+    const float y = fmaf(x, s, b);
+    return relu ? fmaxf(y, 0.f) : y;
+  };
+  // ---- requests ------------------------------------------------------------------------------------------------
+  const float s = a.scale ? a.scale[cc] : 1.f, b = a.shift ? a.shift[cc] : 0.f;
+  f32x4 zr[TS_PQ], gr[FWD ? 1 : TS_PQ];
+#pragma unroll
+  for (int q = 0; q < TS_PQ; ++q) {
+    const int i = q * 64 + lane;
+    if (i < L4n) {
+      zr[q] = z4[i];
+      if (!FWD) gr[q] = g4[i];
+    }
+  }
+  float zav[2], gav[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int t = lane + 64 * q;
+    zav[q] = t < T ? za[t] : 0.f;
+    gav[q] = (!FWD && t < T) ? a.doaug[plane * T + t] : 0.f;
+  }
+  const float cfv = (FWD && lane < V) ? a.coeff[lane] : 0.f;
+  // ---- LDS -----------------------------------------------------------------------------------------------------
+  if (pool) {
+    f32x4* h4 = reinterpret_cast<f32x4*>(hp);
+    f32x4* gl4 = reinterpret_cast<f32x4*>(gp);
+#pragma unroll
+    for (int q = 0; q < TS_PQ; ++q) {
+      const int i = q * 64 + lane;
+      if (i < L4n) {
+        f32x4 v = zr[q];
+        if (FWD) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = act(v[k], s, b);
+        }
+        h4[i] = v;
+        if (!FWD) gl4[i] = gr[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int t = lane + 64 * q;
+    if (t < T) {
+      ha[t] = act(zav[q], s, b);
+      if (!FWD) oa[t] = gav[q];
+    }
+  }
+  for (int t = lane + 128; t < T; t += 64) {          // T > 128: the rest of the columns
+    ha[t] = act(za[t], s, b);
+    if (!FWD) oa[t] = a.doaug[plane * T + t];
+  }
+  if (FWD && lane < V) cf[lane] = cfv;
+  wave_lds_sync();
+  if constexpr (FWD) {
+    for (int t = lane; t < T; t += 64) {
+      float v = ha[t];
+      if (pool) {
+        if (t >= 1) v = fmaxf(v, ha[t - 1]);
+        if (t + 1 < T) v = fmaxf(v, ha[t + 1]);
+      }
+      a.oaug[plane * T + t] = v;
+    }
+    f32x4* fp = reinterpret_cast<f32x4*>(a.f + plane * L);
+    double sv = 0.0, qv = 0.0;
+#pragma unroll
+    for (int q = 0; q < TS_PQ; ++q) {
+      const int i = q * 64 + lane;
+      if (i < L4n) {
+        int t, v;
+        divmod_small(4 * i, V, invV, t, v);
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float x, o;
+          if (pool) {
+            const int e = t * V + v;
+            x = hp[e];
+            o = ha[t];
+            if (t >= 1) { x = fmaxf(x, hp[e - V]); o = fmaxf(o, ha[t - 1]); }
+            if (t + 1 < T) { x = fmaxf(x, hp[e + V]); o = fmaxf(o, ha[t + 1]); }
+          } else {
+            x = act(zr[q][k], s, b);
+            o = ha[t];
+          }
+          r[k] = fmaf(o, cf[v], x);
+          if (++v == V) { v = 0; ++t; }
+        }
+        fp[i] = f32x4{r[0], r[1], r[2], r[3]};
+        const float s4 = (r[0] + r[1]) + (r[2] + r[3]);
+        const float q4 = fmaf(r[0], r[0], r[1] * r[1]) + fmaf(r[2], r[2], r[3] * r[3]);
+        sv += (double)s4;
+        qv += (double)q4;
+      }
+    }
+    if (a.stats) {
+      sv = wave_sum_d(sv);
+      qv = wave_sum_d(qv);
+      if (lane == 0) {
+        a.stats[((size_t)(a.ngrp + n) * C + cc) * 2 + 0] = (float)sv;
+        a.stats[((size_t)(a.ngrp + n) * C + cc) * 2 + 1] = (float)qv;
+      }
+    }
+  } else {
+    // gradient of row t of a column: pass-through = g[t]; max-pool = the windows whose FIRST maximal valid row is t (ATen
+    // max_pool2d_with_indices order; rows outside the plane count as -inf).  hcol holds raw z: the pooled values are act(.)
+    auto route = [&](const float* hcol, const float* gcol, int t, int st) -> float {
+      auto row = [&](int r) -> float { return (r >= 0 && r < T) ? act(hcol[r * st], s, b) : -INFINITY; };
+      const float v = act(hcol[t * st], s, b);
+      const float m2 = row(t - 2), m1 = row(t - 1), p1 = row(t + 1), p2 = row(t + 2);
+      float g = 0.f;
+      if (t >= 1 && v > m2 && v > m1) g += gcol[(t - 1) * st];
+      if (v > m1 && v >= p1) g += gcol[t * st];
+      if (t + 1 < T && v >= p1 && v >= p2) g += gcol[(t + 1) * st];
+      return g;
+    };
+    f32x4* dp = reinterpret_cast<f32x4*>(a.dz + plane * L);
+    float u0 = 0.f, u1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < TS_PQ; ++q) {
+      const int i = q * 64 + lane;
+      if (i < L4n) {
+        int t, v;
+        divmod_small(4 * i, V, invV, t, v);
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float x = zr[q][k];
+          float g = pool ? route(hp + v, gp + v, t, V) : gr[q][k];
+          if (relu && !(fmaf(x, s, b) > 0.f)) g = 0.f;
+          r[k] = g * s;
+          u0 = fmaf(g, x, u0);
+          u1 += g;
+          if (++v == V) { v = 0; ++t; }
+        }
+        dp[i] = f32x4{r[0], r[1], r[2], r[3]};
+      }
+    }
+    // the column: ha holds act(zaug); the pooled values are ha itself, the pre-activation sign is ha > 0 under ReLU
+    auto route1 = [&](int t) -> float {
+      if (!pool) return oa[t];
+      auto row = [&](int r) -> float { return (r >= 0 && r < T) ? ha[r] : -INFINITY; };
+      const float v = ha[t];
+      const float m2 = row(t - 2), m1 = row(t - 1), p1 = row(t + 1), p2 = row(t + 2);
+      float g = 0.f;
+      if (t >= 1 && v > m2 && v > m1) g += oa[t - 1];
+      if (v > m1 && v >= p1) g += oa[t];
+      if (t + 1 < T && v >= p1 && v >= p2) g += oa[t + 1];
+      return g;
+    };
+    for (int t = lane; t < T; t += 64) {
+      const float x = t < 128 ? zav[t >> 6] : za[t];
+      float g = route1(t);
+      if (relu && !(fmaf(x, s, b) > 0.f)) g = 0.f;
+      a.dzaug[plane * T + t] = g * s;
+      u0 = fmaf(g, x, u0);
+      u1 += g;
+    }
+    u0 = wave_sum(u0);
+    u1 = wave_sum(u1);
+    if (lane == 0) {
+      a.part[((size_t)(a.ngrp + n) * C + cc) * 2 + 0] = u0;
+      a.part[((size_t)(a.ngrp + n) * C + cc) * 2 + 1] = u1;
+    }
+  }
+}
+
+// grid.x = [conv blocks: (position group, conv window)] ++ [plane blocks: 4 planes each]
+template <bool FWD, int MT>
+__global__ __launch_bounds__(TS_NT, MT == 1 ? 3 : 2) void k_tsp(TSArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cb = a.nconv * a.ngrp, b = blockIdx.x;
+  if (b < cb) {
+    if (a.exp & 8) return;
+    const int w = b % a.nconv, grp = b / a.nconv;
+    const TSBranch& br = ts_conv_window(a, w);
+    if (((br.dil * a.V) & 1) && !(a.exp & 16)) ts_conv<FWD, MT, true>(a, br, lds, grp, lane, wave);
+    else ts_conv<FWD, MT, false>(a, br, lds, grp, lane, wave);
+    return;
+  }
+  int pl = (b - cb) * 4 + wave;
+  if (pl >= a.n * a.eplanes || (a.exp & 1)) return;
+  const int n = pl / a.eplanes;
+  int c = pl - n * a.eplanes;
+  const int per = (FWD ? 1 : 2) * a.T * a.V + 2 * ((a.T + 3) & ~3) + 32;
+  for (int i = 0; i < a.nbr; ++i) {
+    if (a.br[i].type == 0) continue;
+    if (c < a.br[i].bc) {
+      ts_elem<FWD>(a, a.br[i], lds + (size_t)wave * per, n, c, lane);
+      return;
+    }
+    c -= a.br[i].bc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The one-column part of the conv windows: per (sample, window) a (bc x 3bc) x (3bc x T) product on the f32 matrix core
+// — out[i][t] = sum_{tap,k} W(i,k,tap) * col[k][t -+ (tap-1)*dil] with the column zero-padded by four frames on either
+// side in LDS.  grid = (n, conv windows), one 32 x 32 output tile per wave.  FWD: oaug = bias + conv(relu(zaug*scale +
+// shift));  data gradient: dzaug = relu'(.) * convT(doaug) * scale and the column's share of the branch BatchNorm's sums
+// (part rows [ngrp + n, ngrp + 2n)).  (A scalar version of these launches took 20 us each: ~800 dependent LDS reads per
+// thread.)  The blocks also zero the rows of the partial table that the main launch leaves unwritten (conv rows: the
+// pooling channels; plane rows: the conv channels).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ts_zero_rows(float* tab, const TSArgs& a) {
+  // rows [0, ngrp + n) x C x 2, spread over the grid
+  const long total = (long)(a.ngrp + a.n) * a.C * 2;
+  const long nb = (long)gridDim.x * gridDim.y, me = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  const long per = (total + nb - 1) / nb;
+  const long lo = me * per, hi = min(total, lo + per);
+  for (long i = lo + threadIdx.x; i < hi; i += TS_NT) tab[i] = 0.f;
+}
+
+// global -> LDS copy of a short run with every load of a 2048-float chunk in flight before the first LDS write
+template <typename F, typename G>
+__device__ __forceinline__ void ts_fill_lds(float* dst, int count, F&& src, G&& at) {
+  for (int base = 0; base < count; base += 8 * TS_NT) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = base + q * TS_NT + threadIdx.x;
+      v[q] = i < count ? src(i) : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = base + q * TS_NT + threadIdx.x;
+      if (i < count) dst[at(i)] = v[q];
+    }
+  }
+}
+
+__host__ __device__ inline int tsa_row(int T) { return ((T + 31) & ~31) + 2 * TS_H; }     // padded column row (floats)
+
+template <bool FWD>
+__global__ __launch_bounds__(TS_NT) void k_tsp_aug(TSArgs a) {
+  constexpr int KT = 3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int n = blockIdx.x;
+  const TSBranch& br = ts_conv_window(a, blockIdx.y);
+  const int T = a.T, C = a.C, bc = br.bc;
+  const int CP = ts_cp(bc), S = KT * CP + 1, TR = tsa_row(T);
+  float* tab = FWD ? a.stats : a.part;
+  if (tab) ts_zero_rows(tab, a);
+  if (a.exp & 32) return;
+  float* Ws = lds;                       // [64][S] + 64: weights [co][tap*CP + ci], zero padded
+  float* Hl = Ws + 64 * S + 64;          // [CP][TR]: the column operand (FWD: relu(zaug*scale+shift); else doaug)
+  float* Sl = Hl + CP * TR;              // [3][64] scale, shift, bias
+  float* Xl = Sl + 192;                  // data gradient: [bc][T] zaug, then [bc][T] dpre*x, [bc][T] dpre
+  const bool relu = br.c0 < a.n_act;
+  const size_t base = ((size_t)n * C + br.c0) * T;
+  // every global operand of the block is requested before the first LDS write (the launch is a chain of memory round trips,
+  // not bandwidth): per thread 1 table value, 4 + 4 column values, 26 weights; longer runs take the loops below
+  constexpr int HQ = 4, WQ = 26;
+  const float* col = (FWD ? a.zaug : a.doaug) + base;
+  const float* za = a.zaug + base;
+  const int run = bc * KT, wtot = bc * run, htot = bc * T;
+  auto tabv = [&](int i) -> float {
+    const int k = i >> 6, c = i & 63;
+    if (c >= bc) return 0.f;
+    return k == 0 ? (a.scale ? a.scale[br.c0 + c] : 1.f) : k == 1 ? (a.shift ? a.shift[br.c0 + c] : 0.f) : (br.b ? br.b[c] : 0.f);
+  };
+  auto hat = [&](int i) { const int c = i / T; return c * TR + TS_H + (i - c * T); };
+  auto wat = [&](int i) {
+    const int co = i / run, r = i - co * run, ci = r / KT, tap = r - ci * KT;
+    return co * S + tap * CP + ci;
+  };
+  const float tv = tid < 192 ? tabv(tid) : 0.f;
+  float vh[HQ], vx[HQ], vw[WQ];
+#pragma unroll
+  for (int q = 0; q < HQ; ++q) {
+    const int i = tid + q * TS_NT;
+    vh[q] = i < htot ? col[i] : 0.f;
+    vx[q] = (!FWD && i < htot) ? za[i] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < WQ; ++q) {
+    const int i = tid + q * TS_NT;
+    vw[q] = i < wtot ? br.w[i] : 0.f;
+  }
+  for (int i = tid; i < 64 * S + 64 + CP * TR; i += TS_NT) lds[i] = 0.f;
+  __syncthreads();
+  if (tid < 192) Sl[tid] = tv;
+#pragma unroll
+  for (int q = 0; q < HQ; ++q) {
+    const int i = tid + q * TS_NT;
+    if (i < htot) {
+      Hl[hat(i)] = vh[q];
+      if (!FWD) Xl[i] = vx[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < WQ; ++q) {
+    const int i = tid + q * TS_NT;
+    if (i < wtot) Ws[wat(i)] = vw[q];
+  }
+  if (htot > HQ * TS_NT) {
+    ts_fill_lds(Hl, htot - HQ * TS_NT, [&](int i) -> float { return col[i + HQ * TS_NT]; },
+                [&](int i) { return hat(i + HQ * TS_NT); });
+    if (!FWD)
+      ts_fill_lds(Xl + HQ * TS_NT, htot - HQ * TS_NT, [&](int i) -> float { return za[i + HQ * TS_NT]; }, [](int i) { return i; });
+  }
+  if (wtot > WQ * TS_NT)
+    ts_fill_lds(Ws, wtot - WQ * TS_NT, [&](int i) -> float { return br.w[i + WQ * TS_NT]; },
+                [&](int i) { return wat(i + WQ * TS_NT); });
+  __syncthreads();
+  if (FWD) {
+    for (int i = tid; i < bc * T; i += TS_NT) {
+      const int c = i / T, t = i - c * T;
+      const float y = fmaf(Hl[c * TR + TS_H + t], Sl[c], Sl[64 + c]);
+      Hl[c * TR + TS_H + t] = relu ? fmaxf(y, 0.f) : y;
+    }
+    __syncthreads();
+  }
+  const int MTn = (bc + 31) >> 5, TTn = (T + 31) >> 5;
+  for (int tile = wave; tile < ((a.exp & 64) ? 0 : MTn * TTn); tile += 4) {
+    const int m = tile % MTn, tt = tile / MTn;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < KT; ++tap) {
+      const int sh = (FWD ? (tap - 1) : (1 - tap)) * br.dil;
+      const float* bp = Hl + half * TR + TS_H + 32 * tt + l31 + sh;
+      const float* ap = FWD ? Ws + (32 * m + l31) * S + tap * CP + half : Ws + half * S + tap * CP + 32 * m + l31;
+      for (int ks = 0; ks < CP / 2; ++ks) {
+        const float av = FWD ? ap[2 * ks] : ap[2 * ks * S];
+        const float bv = bp[2 * ks * TR];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      }
+    }
+    const int t = 32 * tt + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = 32 * m + ts_row32(r, half);
+      if (i < bc && t < T) {
+        if (FWD) {
+          a.oaug[base + (size_t)i * T + t] = acc[r] + Sl[128 + i];
+        } else {
+          const float s = Sl[i], b = Sl[64 + i];
+          const float x = Xl[i * T + t];
+          const float dv = (relu && !(fmaf(x, s, b) > 0.f)) ? 0.f : acc[r];
+          a.dzaug[base + (size_t)i * T + t] = dv * s;
+          Xl[(bc + i) * T + t] = dv * x;
+          Xl[(2 * bc + i) * T + t] = dv;
+        }
+      }
+    }
+  }
+  if (!FWD) {
+    __syncthreads();
+    const size_t row = (size_t)(a.ngrp + a.n + n) * C;
+    if (tid < bc) {
+      float v0 = 0.f, v1 = 0.f;
+      for (int t = 0; t < T; ++t) { v0 += Xl[(bc + tid) * T + t]; v1 += Xl[(2 * bc + tid) * T + t]; }
+      a.part[(row + br.c0 + tid) * 2 + 0] = v0;
+      a.part[(row + br.c0 + tid) * 2 + 1] = v1;
+    }
+    if (blockIdx.y == 0) {               // the pooling / pass-through channels of this row: their planes carry the column
+      for (int i = 0; i < a.nbr; ++i)
+        if (a.br[i].type != 0)
+          for (int k = tid; k < a.br[i].bc * 2; k += TS_NT) a.part[(row + a.br[i].c0) * 2 + k] = 0.f;
+    }
+  }
+}
+
+// ge = gf + A0[c] + B0[c]*f ;  doaug[t] = sum_v ge[t,v]*coeff[v] ;  pcoef (n*C, V): sum_t ge[t,v]*oaug[t]
+// one wave per (n, c) plane; LDS: [L] ge, [T] oaug, [32] coeff
+__global__ __launch_bounds__(64) void k_tsp_prep(const float* __restrict__ gf, const float* __restrict__ f,
+                                                 const float* __restrict__ oaug, const float* __restrict__ coeff,
+                                                 const float* __restrict__ A0, const float* __restrict__ B0,
+                                                 float* __restrict__ ge, float* __restrict__ doaug,
+                                                 float* __restrict__ pcoef, int C, int T, int V) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const int L = T * V, L4n = L >> 2, Tp = (T + 3) & ~3;
+  float* gl = lds;
+  float* ol = lds + L;
+  float* cf = ol + Tp;
+  if (lane < V) cf[lane] = coeff[lane];
+  for (int t = lane; t < T; t += 64) ol[t] = oaug[plane * T + t];
+  const float a0 = A0 ? A0[c] : 0.f, b0 = B0 ? B0[c] : 0.f;
+  const f32x4* g4 = gf ? reinterpret_cast<const f32x4*>(gf + plane * L) : nullptr;
+  const f32x4* f4 = reinterpret_cast<const f32x4*>(f + plane * L);
+  f32x4* o4 = reinterpret_cast<f32x4*>(ge + plane * L);
+  f32x4* l4 = reinterpret_cast<f32x4*>(gl);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (int base = 0; base < L4n; base += 256) {
+    f32x4 gv[4], fv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = base + q * 64 + lane;
+      const bool ok = i < L4n;
+      gv[q] = (ok && g4) ? g4[i] : zero4;
+      fv[q] = (ok && A0) ? f4[i] : zero4;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = base + q * 64 + lane;
+      if (i < L4n) {
+        f32x4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = gv[q][k] + fmaf(b0, fv[q][k], a0);
+        o4[i] = r;
+        l4[i] = r;
+      }
+    }
+  }
+  wave_lds_sync();
+  for (int t = lane; t < T; t += 64) {
+    float acc = 0.f;
+    for (int v = 0; v < V; ++v) acc = fmaf(gl[t * V + v], cf[v], acc);
+    doaug[plane * T + t] = acc;
+  }
+  {
+    const int v = lane & 31, hf = lane >> 5;
+    float acc = 0.f;
+    if (v < V)
+      for (int t = hf; t < T; t += 2) acc = fmaf(gl[t * V + v], ol[t], acc);
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < V) pcoef[plane * V + lane] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient: k_tapw's scheme (csrc/tapconv.hip) on the split operands.  Work unit = (sample, 4 frames); the
+// workgroup stages ge (4 frames) and h = relu(z*scale+shift) (the 4 frames plus a 4-frame halo on either side) with
+// 16-byte loads into LDS rows [V-column part | one-column part] of stride = 2 mod 4 floats; the matrix loop walks the
+// V-column part in groups of four positions (a tap shifts by dil*V: an odd shift reads its operand with two 4-byte LDS
+// reads instead of one 8-byte read) and then the one group of the unit's four global-joint values (shift dil), so dW / db
+// carry both parts.  grid = (K-splits, conv windows); every split writes its partial row (dsgcn_colsum).
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline int tsw_ls(int w) { return ((w + 1) & ~3) + 2; }      // >= w, = 2 mod 4
+
+template <int CH>
+__global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
+  constexpr int KT = 3;
+  constexpr int JD = CH == 32 ? 4 : 7, JX = CH == 32 ? 10 : 20;     // float4 staging slots per thread (V <= 25)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const TSBranch& br = ts_conv_window(a, blockIdx.y);
+  const int V = a.V, T = a.T, L = T * V, C = a.C;
+  const int bc = br.bc;
+  const int GM = TS_R * V, XM = (TS_R + 2 * TS_H) * V;              // V-column part of a row (floats; multiples of 4)
+  const int GS4 = GM >> 2, XS4 = XM >> 2, SEG4 = (TS_H * V) >> 2;   // float4 per row; float4 per 4-frame segment
+  const int LSd = tsw_ls(GM + TS_R), LSx = tsw_ls(XM + TS_R + 2 * TS_H);
+  float* Ds = lds;                                                   // [CH][LSd]
+  float* Xs = lds + CH * LSd;                                        // [CH][LSx]
+  f32x2s* SB = reinterpret_cast<f32x2s*>(Xs + CH * LSx);             // [CH] (scale, shift)
+  for (int i = tid; i < CH * (LSd + LSx); i += TS_NT) lds[i] = 0.f;  // rows >= bc and the pad columns stay zero
+  if (tid < CH) {
+    const int c = br.c0 + tid;
+    SB[tid] = tid < bc ? f32x2s{a.scale ? a.scale[c] : 1.f, a.shift ? a.shift[c] : 0.f} : f32x2s{0.f, 0.f};
+  }
+  const bool relu = br.c0 < a.n_act;
+
+  const int units = a.n * (T / TS_R);
+  const int per = (units + a.splits - 1) / a.splits;
+  const int u0 = blockIdx.x * per, u1 = min(units, u0 + per);
+
+  const __amdgpu_buffer_rsrc_t rg = ts_rsrc(a.ge, (size_t)a.n * C * L * 4);
+  const __amdgpu_buffer_rsrc_t rz = ts_rsrc(a.z, (size_t)a.n * C * L * 4);
+  const __amdgpu_buffer_rsrc_t rga = ts_rsrc(a.doaug, (size_t)a.n * C * T * 4);
+  const __amdgpu_buffer_rsrc_t rza = ts_rsrc(a.zaug, (size_t)a.n * C * T * 4);
+  // staging slots: f = tid + 256*j -> (row, float4 column); fixed per thread
+  int vD[JD], lD[JD], vX[JX], lX[JX];          // lX: LDS index | segment << 20 | row << 22 | valid << 28
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int f = tid + TS_NT * j, row = f / GS4, c4 = f - row * GS4;
+    const bool ok = row < bc;
+    vD[j] = ok ? (row * L + 4 * c4) * 4 : TS_OOB;
+    lD[j] = ok ? row * LSd + 4 * c4 : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < JX; ++j) {
+    const int f = tid + TS_NT * j, row = f / XS4, c4 = f - row * XS4;
+    const bool ok = row < bc;
+    vX[j] = ok ? (row * L + 4 * c4) * 4 : TS_OOB;
+    const int seg = c4 / SEG4;                  // 0 = halo before (needs bit 1 of `inval` clear), 1 = the unit, 2 = halo after (bit 2)
+    lX[j] = (row * LSx + 4 * c4) | ((seg == 0 ? 1 : seg == 2 ? 2 : 0) << 20) | ((row & 63) << 22) | (ok ? 1 << 28 : 0);
+  }
+  // the one-column operands: thread < CH: doaug of row tid (4 frames); thread < 3*CH: zaug of row tid/3, segment tid%3
+  const int arow = tid / 3, aseg = tid - arow * 3;
+  const bool aokD = tid < CH && tid < bc && !(a.exp & 256), aokX = tid < 3 * CH && arow < bc && !(a.exp & 256);
+  const int aneed = aseg == 0 ? 1 : aseg == 2 ? 2 : 0;
+  f32x4 gr[JD], xr[JX], ga, xa;
+  float dsum[JD], dsa = 0.f;
+#pragma unroll
+  for (int j = 0; j < JD; ++j) dsum[j] = 0.f;
+  int inval = 0;                              // bit 1: the unit has no halo before it (t0 < 4), bit 2: none after it
+  auto issue = [&](int u) {
+    const int n = u / (T / TS_R), t0 = (u - n * (T / TS_R)) * TS_R;
+    const int sg = ((n * C + br.c0) * L + t0 * V) * 4;
+    const int sx = ((n * C + br.c0) * L + (t0 - TS_H) * V) * 4;          // may be negative: only used with valid slots
+    inval = (t0 >= TS_H ? 0 : 1) | (t0 + TS_R < T ? 0 : 2);
+#pragma unroll
+    for (int j = 0; j < JD; ++j) gr[j] = ts_load4(rg, vD[j], sg);
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const bool ok = (((lX[j] >> 20) & 3) & inval) == 0;
+      xr[j] = ts_load4(rz, ok ? vX[j] + sx : TS_OOB, 0);
+    }
+    ga = ts_load4(rga, aokD ? ((n * C + br.c0 + tid) * T + t0) * 4 : TS_OOB, 0);
+    const bool oka = aokX & ((aneed & inval) == 0);
+    xa = ts_load4(rza, oka ? ((n * C + br.c0 + arow) * T + t0 + (aseg - 1) * TS_H) * 4 : TS_OOB, 0);
+  };
+  const bool noact = a.exp & 128;
+  auto act = [&](float x, f32x2s sb) -> float {
+    if (noact) return x;
+    const float y = fmaf(x, sb.x, sb.y);
+    return relu ? fmaxf(y, 0.f) : y;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      if (lD[j] >= 0) {
+        f32x2s* d = reinterpret_cast<f32x2s*>(Ds + lD[j]);
+        d[0] = f32x2s{gr[j].x, gr[j].y};
+        d[1] = f32x2s{gr[j].z, gr[j].w};
+        dsum[j] += (gr[j].x + gr[j].y) + (gr[j].z + gr[j].w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      if (lX[j] & (1 << 28)) {
+        const bool ok = (((lX[j] >> 20) & 3) & inval) == 0;
+        const f32x2s sb = SB[(lX[j] >> 22) & 63];
+        f32x2s* d = reinterpret_cast<f32x2s*>(Xs + (lX[j] & 0xfffff));
+        d[0] = ok ? f32x2s{act(xr[j].x, sb), act(xr[j].y, sb)} : f32x2s{0.f, 0.f};
+        d[1] = ok ? f32x2s{act(xr[j].z, sb), act(xr[j].w, sb)} : f32x2s{0.f, 0.f};
+      }
+    }
+    if (aokD) {
+      f32x2s* d = reinterpret_cast<f32x2s*>(Ds + tid * LSd + GM);
+      d[0] = f32x2s{ga.x, ga.y};
+      d[1] = f32x2s{ga.z, ga.w};
+      dsa += (ga.x + ga.y) + (ga.z + ga.w);
+    }
+    if (aokX) {
+      const bool ok = (aneed & inval) == 0;
+      const f32x2s sb = SB[arow];
+      f32x2s* d = reinterpret_cast<f32x2s*>(Xs + arow * LSx + XM + aseg * TS_H);
+      d[0] = ok ? f32x2s{act(xa.x, sb), act(xa.y, sb)} : f32x2s{0.f, 0.f};
+      d[1] = ok ? f32x2s{act(xa.z, sb), act(xa.w, sb)} : f32x2s{0.f, 0.f};
+    }
+  };
+
+  f32x16 acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+  // CH = 32: wave w takes the position groups [g0, g1) of the unit's GS4 groups of 4 (wave 0 also the global-joint group);
+  // CH = 64: wave = (mt, nt), all groups
+  const int mt = CH == 64 ? (wave >> 1) : 0, nt = CH == 64 ? (wave & 1) : 0;
+  const int g0 = CH == 32 ? (GS4 * wave) / 4 : 0, g1 = CH == 32 ? (GS4 * (wave + 1)) / 4 : GS4;
+  const bool augw = CH == 64 || wave == 0;
+  const int sh = br.dil * V;
+  const bool oddsh = (sh & 1) && !(a.exp & 512);
+  const float* Ap = Ds + (32 * mt + l31) * LSd + 2 * half;
+  const float* Bp = Xs + (32 * nt + l31) * LSx + TS_H * V + 2 * half;
+  const float* Aq = Ds + (32 * mt + l31) * LSd + GM + 2 * half;
+  const float* Bq = Xs + (32 * nt + l31) * LSx + XM + TS_H + 2 * half;
+  auto mm = [&](f32x2s av, f32x2s b0, f32x2s b1, f32x2s b2) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b2.x, acc[2], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b2.y, acc[2], 0, 0, 0);
+  };
+
+  __syncthreads();                                  // zero fill done
+  if (u0 < u1) issue(u0);
+  for (int u = u0; u < u1; ++u) {
+    commit();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (u + 1 < u1) issue(u + 1);
+    if (oddsh) {
+#pragma unroll 2
+      for (int g = g0; g < g1; ++g) {
+        const f32x2s av = *reinterpret_cast<const f32x2s*>(Ap + 4 * g);
+        const f32x2s b1 = *reinterpret_cast<const f32x2s*>(Bp + 4 * g);
+        const f32x2s b0 = {Bp[4 * g - sh], Bp[4 * g - sh + 1]};
+        const f32x2s b2 = {Bp[4 * g + sh], Bp[4 * g + sh + 1]};
+        mm(av, b0, b1, b2);
+      }
+    } else {
+#pragma unroll 2
+      for (int g = g0; g < g1; ++g) {
+        const f32x2s av = *reinterpret_cast<const f32x2s*>(Ap + 4 * g);
+        const f32x2s b0 = *reinterpret_cast<const f32x2s*>(Bp + 4 * g - sh);
+        const f32x2s b1 = *reinterpret_cast<const f32x2s*>(Bp + 4 * g);
+        const f32x2s b2 = *reinterpret_cast<const f32x2s*>(Bp + 4 * g + sh);
+        mm(av, b0, b1, b2);
+      }
+    }
+    if (augw) {
+      const f32x2s av = *reinterpret_cast<const f32x2s*>(Aq);
+      const f32x2s b1 = *reinterpret_cast<const f32x2s*>(Bq);
+      const f32x2s b0 = {Bq[-br.dil], Bq[1 - br.dil]};
+      const f32x2s b2 = {Bq[br.dil], Bq[1 + br.dil]};
+      mm(av, b0, b1, b2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // raw barrier: the next unit's loads stay in flight
+  }
+
+  float* dw = br.dwp + (size_t)blockIdx.x * a.pstride;
+  float* db = br.dbp + (size_t)blockIdx.x * a.pstride;
+  if (CH == 32) {
+    float* Rs = lds;                                 // [wave][tap][co][33]
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Rs[((wave * KT + k) * 32 + ts_row32(r, half)) * 33 + l31] = acc[k][r];
+    __syncthreads();
+    for (int o = tid; o < KT * bc * bc; o += TS_NT) {
+      const int co = o / (bc * KT), r2 = o - co * bc * KT, ci = r2 / KT, k = r2 - ci * KT;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += Rs[((w * KT + k) * 32 + co) * 33 + ci];
+      dw[o] = v;                                     // (co*bc + ci)*KT + tap
+    }
+    __syncthreads();
+  } else {
+    const int ci = 32 * nt + l31;
+    if (ci < bc) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * mt + ts_row32(r, half);
+        if (co < bc) {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) dw[((size_t)co * bc + ci) * KT + k] = acc[k][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // db: per-thread row pieces -> LDS -> one thread per row
+  float* Bs = lds;                                   // [CH][GS4 + 2]
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int f = tid + TS_NT * j, row = f / GS4, c4 = f - row * GS4;
+    if (row < bc) Bs[row * (GS4 + 2) + c4] = dsum[j];
+  }
+  if (aokD) Bs[tid * (GS4 + 2) + GS4] = dsa;
+  __syncthreads();
+  if (tid < bc) {
+    float v = 0.f;
+    for (int c = 0; c <= GS4; ++c) v += Bs[tid * (GS4 + 2) + c];
+    db[tid] = v;
+  }
+}
+
+int g_ts_exp = 0;                                 // lab builds: dsgcn_tms_split_tuning
+constexpr size_t TS_LDS_MAX = 156 * 1024;
+
+template <typename F>
+int ts_raise_lds(F* kernel, size_t lds, size_t* have) {
+  if (lds > TS_LDS_MAX) return DSGCN_EUNSUPPORTED;
+  if (lds > *have) {       // not a stream op: done once per kernel, outside any graph capture (first eager call)
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TS_LDS_MAX);
+    if (e != hipSuccess) return (int)e;
+    *have = TS_LDS_MAX;
+  }
+  return 0;
+}
+
+// fills the window table and the launch geometry; 1 = eligible, 0 = not, < 0 = bad arguments
+int ts_fill(TSArgs& a, int n, int C, int T, int V, int stride, int KT, int nbr, const int* type, const int* c0,
+            const int* bc, const int* dil) {
+  if (n <= 0 || C <= 0 || T <= 0 || V <= 0 || nbr <= 0 || nbr > TS_MAXBR || !type || !c0 || !bc || !dil) return DSGCN_EINVAL;
+  a.n = n; a.C = C; a.T = T; a.V = V; a.nbr = nbr; a.exp = g_ts_exp;
+  int nconv = 0, eplanes = 0, wmax = 0, next = 0;
+  for (int i = 0; i < nbr; ++i) {
+    TSBranch& b = a.br[i];
+    b.type = type[i]; b.c0 = c0[i]; b.bc = bc[i]; b.dil = dil[i];
+    if (b.bc <= 0 || b.c0 != next) return b.bc <= 0 ? DSGCN_EINVAL : 0;     // windows tile the channels in order
+    next += b.bc;
+    if (b.type == 0) {
+      ++nconv;
+      wmax = std::max(wmax, b.bc);
+      if (b.dil < 1 || b.dil > TS_H) return 0;
+    } else if (b.type == 1 || b.type == 2) {
+      eplanes += b.bc;
+    } else {
+      return DSGCN_EINVAL;
+    }
+  }
+  if (next != C) return 0;
+  if (KT != 3 || stride != 1 || nconv == 0 || wmax > 64 || (V & 1) == 0 || V < 5 || V > 25 || T % 4 || (long)T * V > 2048) return 0;
+  const long L = (long)T * V;
+  if ((long)n * C * L * 4 >= (1L << 31) - 4096 || (long)n * L >= (1L << 31) - 256) return 0;
+  if (n > 32768) return 0;
+  a.nconv = nconv;
+  a.eplanes = eplanes;
+  const int WT = (int)(((long)n * L + 127) / 128);
+  a.ngrp = (WT + 3) / 4;
+  return wmax <= 32 ? 1 : 2;                          // = MT
+}
+
+// LDS of the main launch: conv blocks (weight tile | epilogue transposes, then the per-channel table) vs plane blocks
+size_t ts_lds_main(TSArgs& a, int MT, bool fwd) {
+  int cpmax = 8;
+  for (int i = 0; i < a.nbr; ++i)
+    if (a.br[i].type == 0) cpmax = std::max(cpmax, (std::min(64, a.br[i].bc) + 7) & ~7);
+  const size_t wsf = (size_t)64 * (3 * cpmax + 1) + 64;
+  const size_t epf = (size_t)4 * 2 * 32 * 36 + (size_t)4 * MT * 32 * 2 * 2;      // transposes + [4][MT*32][2] doubles
+  const size_t convf = (std::max(wsf, epf) + 3) & ~(size_t)3;
+  a.sboff = (int)convf;
+  const size_t planef = (size_t)4 * ((fwd ? 1 : 2) * a.T * a.V + 2 * ((a.T + 3) & ~3) + 32);
+  return std::max(convf + 192, planef) * sizeof(float);
+}
+
+template <bool FWD>
+int ts_launch_main(TSArgs& a, int MT, hipStream_t st) {
+  const size_t lds = ts_lds_main(a, MT, FWD);
+  const long blocks = (long)a.nconv * a.ngrp + ((long)a.n * a.eplanes + 3) / 4;
+  if (blocks <= 0 || blocks >= (1L << 31)) return DSGCN_EUNSUPPORTED;
+  const dim3 grid((unsigned)blocks), blk(TS_NT);
+  if (MT == 1) {
+    static size_t have = 64 * 1024;
+    const int rc = ts_raise_lds(k_tsp<FWD, 1>, lds, &have);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_tsp<FWD, 1>), grid, blk, lds, st, a);
+  } else {
+    static size_t have = 64 * 1024;
+    const int rc = ts_raise_lds(k_tsp<FWD, 2>, lds, &have);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_tsp<FWD, 2>), grid, blk, lds, st, a);
+  }
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t ts_lds_aug(const TSArgs& a, bool fwd) {
+  int wmax = 1;
+  for (int i = 0; i < a.nbr; ++i)
+    if (a.br[i].type == 0) wmax = std::max(wmax, a.br[i].bc);
+  const int cp = (std::min(64, wmax) + 7) & ~7;
+  return ((size_t)64 * (3 * cp + 1) + 64 + (size_t)cp * tsa_row(a.T) + 192 + (fwd ? 0 : (size_t)3 * wmax * a.T)) * sizeof(float);
+}
+
+template <bool FWD>
+int ts_launch_aug(const TSArgs& a, hipStream_t st) {
+  const size_t lds = ts_lds_aug(a, FWD);
+  static size_t have = 64 * 1024;
+  const int rc = ts_raise_lds(k_tsp_aug<FWD>, lds, &have);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tsp_aug<FWD>, dim3((unsigned)a.n, (unsigned)a.nconv), dim3(TS_NT), lds, st, a);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+#ifdef DSGCN_LAB
+// timing experiments (include/dsgcn_lab.h): key 0 = bit mask of parts of k_tsp to skip (1 plane blocks, 2 epilogue
+// statistics, 4 the affine + ReLU of the forward operand, 8 conv blocks); results are WRONG with any bit set
+int dsgcn_tms_split_tuning(int key, int value) {
+  if (key != 0) return DSGCN_EINVAL;
+  g_ts_exp = value;
+  return 0;
+}
+#endif
+
+// which: -1 -> 1 when the shape takes the split-layout path, 0 when it does not;  0 -> rows of the forward statistics
+// table (rows, C, 2);  1 -> rows of the data gradient's BatchNorm partial table (rows, C, 2);  2 -> K-splits (rows of the
+// weight partials) of the weight gradient.  0 for every `which` when the shape is not eligible.
+int dsgcn_tms_split_rows(int which, int n, int C, int T, int V, int stride, int KT, int nbr, const int* type,
+                         const int* c0, const int* bc, const int* dil) {
+  TSArgs a = {};
+  const int mt = ts_fill(a, n, C, T, V, stride, KT, nbr, type, c0, bc, dil);
+  if (mt <= 0) return 0;
+  if (ts_lds_main(a, mt, false) > TS_LDS_MAX || ts_lds_aug(a, false) > TS_LDS_MAX) return 0;
+  if (which == -1) return 1;
+  if (which == 0) return a.ngrp + n;
+  if (which == 1) return a.ngrp + 2 * n;
+  if (which == 2) {
+    const int units = n * (T / TS_R);
+    int splits = (mt == 1 ? 512 : 256) / a.nconv;
+    if (splits < 1) splits = 1;
+    return std::min(splits, units);
+  }
+  return 0;
+}
+
+// f (n,C,T,V), oaug (n,C,T) + ONE extra float (the epilogue reads frame pairs), stats (rows(0), C, 2) or NULL.
+int dsgcn_tms_split_fwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                        const float* coeff, float* f, float* oaug, float* stats, int n, int C, int T, int V, int nbr,
+                        const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
+                        const float* const* b, void* stream) {
+  if (!z || !zaug || !coeff || !f || !oaug || !w) return DSGCN_EINVAL;
+  TSArgs a = {};
+  const int mt = ts_fill(a, n, C, T, V, 1, 3, nbr, type, c0, bc, dil);
+  if (mt < 0) return mt;
+  if (mt == 0) return DSGCN_EUNSUPPORTED;
+  a.z = z; a.zaug = zaug; a.scale = scale; a.shift = shift; a.n_act = n_act; a.coeff = coeff;
+  a.f = f; a.oaug = oaug; a.stats = stats;
+  for (int i = 0; i < nbr; ++i) {
+    a.br[i].w = w[i]; a.br[i].b = b ? b[i] : nullptr;
+    if (type[i] == 0 && !a.br[i].w) return DSGCN_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  {
+    const int rc = ts_launch_aug<true>(a, st);
+    if (rc) return rc;
+  }
+  return ts_launch_main<true>(a, mt, st);
+}
+
+// ge (n,C,T,V), doaug (n,C,T), pcoef (n*C, V).  gf NULL = zero upstream gradient; A0/B0 NULL = no BatchNorm terms.
+int dsgcn_tms_split_prep(const float* gf, const float* f, const float* oaug, const float* coeff, const float* A0,
+                         const float* B0, float* ge, float* doaug, float* pcoef, int n, int C, int T, int V,
+                         void* stream) {
+  if (!f || !oaug || !coeff || !ge || !doaug || !pcoef || n <= 0 || C <= 0 || T <= 0 || V <= 0) return DSGCN_EINVAL;
+  if ((T * V) % 4 || V > 32 || (A0 && !B0)) return DSGCN_EUNSUPPORTED;
+  const size_t lds = ((size_t)T * V + ((T + 3) & ~3) + 32) * sizeof(float);
+  if (lds > 64 * 1024) return DSGCN_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_tsp_prep, dim3((unsigned)((long)n * C)), dim3(64), lds, (hipStream_t)stream, gf, f, oaug, coeff,
+                     A0, B0, ge, doaug, pcoef, C, T, V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// dz (n,C,T,V), dzaug (n,C,T), part (rows(1), C, 2): [sum dpre*x, sum dpre] of the branch BatchNorm's backward.
+int dsgcn_tms_split_dgrad(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                          const float* ge, const float* doaug, float* dz, float* dzaug, float* part, int n, int C, int T,
+                          int V, int nbr, const int* type, const int* c0, const int* bc, const int* dil,
+                          const float* const* w, void* stream) {
+  if (!z || !zaug || !ge || !doaug || !dz || !dzaug || !part || !w) return DSGCN_EINVAL;
+  TSArgs a = {};
+  const int mt = ts_fill(a, n, C, T, V, 1, 3, nbr, type, c0, bc, dil);
+  if (mt < 0) return mt;
+  if (mt == 0) return DSGCN_EUNSUPPORTED;
+  a.z = z; a.zaug = zaug; a.scale = scale; a.shift = shift; a.n_act = n_act;
+  a.ge = ge; a.doaug = doaug; a.dz = dz; a.dzaug = dzaug; a.part = part;
+  for (int i = 0; i < nbr; ++i) {
+    a.br[i].w = w[i];
+    if (type[i] == 0 && !a.br[i].w) return DSGCN_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  {
+    const int rc = ts_launch_aug<false>(a, st);
+    if (rc) return rc;
+  }
+  return ts_launch_main<false>(a, mt, st);
+}
+
+// Conv window i writes split s of its weight / bias partials at dwp[i] + s*pstride / dbp[i] + s*pstride, s < splits =
+// rows(2); NULL entries for the other window types.
+int dsgcn_tms_split_wgrad(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                          const float* ge, const float* doaug, int n, int C, int T, int V, int nbr, const int* type,
+                          const int* c0, const int* bc, const int* dil, float* const* dwp, float* const* dbp, int splits,
+                          int pstride, void* stream) {
+  if (!z || !zaug || !ge || !doaug || !dwp || !dbp || splits <= 0) return DSGCN_EINVAL;
+  TSArgs a = {};
+  const int mt = ts_fill(a, n, C, T, V, 1, 3, nbr, type, c0, bc, dil);
+  if (mt < 0) return mt;
+  if (mt == 0) return DSGCN_EUNSUPPORTED;
+  a.z = z; a.zaug = zaug; a.scale = scale; a.shift = shift; a.n_act = n_act;
+  a.ge = ge; a.doaug = doaug; a.splits = splits; a.pstride = pstride;
+  for (int i = 0; i < nbr; ++i) {
+    a.br[i].dwp = dwp[i]; a.br[i].dbp = dbp[i];
+    if (type[i] == 0 && (!a.br[i].dwp || !a.br[i].dbp)) return DSGCN_EINVAL;
+  }
+  const int ch = mt == 1 ? 32 : 64;
+  const size_t tile = (size_t)ch * (tsw_ls(TS_R * (V + 1)) + tsw_ls((TS_R + 2 * TS_H) * (V + 1))) + 2 * ch;
+  const size_t red = (size_t)4 * 3 * 32 * 33;
+  const size_t lds = std::max(tile, ch == 32 ? red : (size_t)0) * sizeof(float);
+  const dim3 grid((unsigned)splits, (unsigned)a.nconv);
+  if (ch == 32) {
+    static size_t have = 64 * 1024;
+    const int rc = ts_raise_lds(k_tspw<32>, lds, &have);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tspw<32>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a);
+  } else {
+    static size_t have = 64 * 1024;
+    const int rc = ts_raise_lds(k_tspw<64>, lds, &have);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tspw<64>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a);
+  }
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -390,11 +390,13 @@ def test_fuse_out(n, C, T, V, mode, tmean, flags):
                                             (2, 256, 16, 25, 1), (2, 256, 16, 25, 2),
                                             # frame counts the weight gradient's 4-frame units do not divide (mixed paths)
                                             (2, 64, 10, 25, 1), (2, 64, 12, 25, 2), (3, 64, 6, 17, 1)])
-@pytest.mark.parametrize('fused', ['1', '0'])
+@pytest.mark.parametrize('fused', ['1', '0', 'split'])
 def test_temporal_ms(n, C, T, V, stride, fused, monkeypatch):
     """fused '1': the one-launch-per-direction stage (csrc/tms.hip) wherever the shape is eligible; '0': the staged chain
-    (branch_act -> tapconv -> combine).  Both against the fp64 statement of the op."""
-    monkeypatch.setattr(K, 'FUSED_TEMPORAL', fused)
+    (branch_act -> tapconv -> combine); 'split': the split layout (csrc/tmsplit.hip: no (V+1)-column tensors) wherever
+    the shape is eligible (stride 1, T % 4 == 0).  All against the fp64 statement of the op."""
+    monkeypatch.setattr(K, 'FUSED_TEMPORAL', '0' if fused == 'split' else fused)
+    monkeypatch.setattr(K, 'SPLIT_TEMPORAL', '1' if fused == 'split' else '0')
     g = torch.Generator().manual_seed(C + T + stride)
     cfg = [(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1']
     mid = C // 6
@@ -425,6 +427,7 @@ def test_temporal_ms(n, C, T, V, stride, fused, monkeypatch):
                    dcoeff=tco.grad[:V], dgamma=tga.grad, dbeta=tbe.grad)
         for i in range(4):
             res[f'dw{i}'] = tw[i].grad
+            res[f'db{i}'] = tb[i].grad
         return res
 
     got = run(K, torch.float32, DEV)

@@ -1,0 +1,89 @@
+"""The temporal stage of a dgmstcn unit (between its two 1x1 convs) at the DS-STGCN layer shapes, staged form (branch_act ->
+tapconv -> combine) against the split layout (csrc/tmsplit.hip): forward and backward time per layer (HIP events over `reps`
+repetitions on rotating operands larger than the Infinity Cache would need too much memory here: the planes are L2-cold but
+MALL-warm, as in the step) and the agreement of every output / gradient between the two.
+    python tools/tsp_bench.py [n=128] [reps=20]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dsgcn_amd import kernels as K, native
+
+if os.environ.get('TS_EXP'):
+    native._lib = native.lab_lib()
+    assert native._lib.dsgcn_tms_split_tuning(0, int(os.environ['TS_EXP'])) == 0
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device('cuda')
+cfg = [(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1']
+
+
+def make(C, T, V, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    mid = C // 6
+    widths = [C - 5 * mid] + [mid] * 5
+    n_act = C - mid
+    r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dev)
+    d = dict(z=r(n, C, T, V), zaug=r(n, C, T), scale=torch.cat([torch.rand(n_act, generator=g) + 0.5, torch.ones(mid)]).to(dev),
+             shift=torch.cat([torch.randn(n_act, generator=g) * 0.3, torch.zeros(mid)]).to(dev),
+             cw=[r(w, w, 3, 1, scale=(3 * w) ** -0.5) for w in widths[:4]], cb=[r(w, scale=0.1) for w in widths[:4]],
+             coeff=r(25, scale=0.5), gamma=(torch.rand(C, generator=g) + 0.5).to(dev), beta=r(C, scale=0.2),
+             gf=r(n, C, T, V), gsc=r(C), gsh=r(C), widths=widths, n_act=n_act)
+    return d
+
+
+def run(d, split, time_it):
+    K.SPLIT_TEMPORAL = '1' if split else '0'
+    K.FUSED_TEMPORAL = '0'
+    leaves = {k: d[k].clone().requires_grad_() for k in ('z', 'zaug', 'scale', 'shift', 'coeff', 'gamma', 'beta')}
+    tw = [w.clone().requires_grad_() for w in d['cw']]
+    tb = [b.clone().requires_grad_() for b in d['cb']]
+
+    def fwd():
+        return K.temporal_ms(leaves['z'], leaves['zaug'], leaves['scale'], leaves['shift'], d['n_act'], cfg, d['widths'], tw, tb,
+                             leaves['coeff'], 1, leaves['gamma'], leaves['beta'], 1e-5, True)
+
+    def loss(out):
+        f, sc, sh = out[0], out[1], out[2]
+        return (f * d['gf']).sum() + (sc * d['gsc']).sum() + (sh * d['gsh']).sum()
+
+    out = fwd()
+    loss(out).backward()
+    res = dict(f=out[0], sc=out[1], sh=out[2], mean=out[3], var=out[4])
+    for k, t in leaves.items():
+        res['d' + k] = t.grad.clone()
+    for i in range(4):
+        res[f'dw{i}'], res[f'db{i}'] = tw[i].grad.clone(), tb[i].grad.clone()
+    tf = tb_ = None
+    if time_it:
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        tf = tb_ = 0.0
+        for _ in range(reps):
+            for t in list(leaves.values()) + tw + tb:
+                t.grad = None
+            e[0].record()
+            out = fwd()
+            l = loss(out)
+            e[1].record()
+            l.backward()
+            e[2].record()
+            torch.cuda.synchronize()
+            tf += e[0].elapsed_time(e[1])
+            tb_ += e[1].elapsed_time(e[2])
+        tf, tb_ = tf / reps * 1e3, tb_ / reps * 1e3
+    return res, tf, tb_
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+for C, T in ((64, 64), (128, 32), (256, 16)):
+    d = make(C, T, 25, seed=C)
+    ok = native.lib().dsgcn_tms_split_rows(-1, n, C, T, 25, 1, 3, 6, K._int_array([0, 0, 0, 0, 1, 2]),
+                                           K._int_array([sum(d['widths'][:i]) for i in range(6)]), K._int_array(d['widths']),
+                                           K._int_array([1, 2, 3, 4, 1, 1]))
+    r0, f0, b0 = run(d, False, True)
+    r1, f1, b1 = run(d, True, True)
+    worst = max((rel(r1[k], r0[k]), k) for k in r0)
+    print(f'C={C:3d} T={T:2d} eligible={ok}  staged fwd {f0:7.1f} bwd {b0:7.1f} us   split fwd {f1:7.1f} bwd {b1:7.1f} us   '
+          f'max rel diff {worst[0]:.2e} ({worst[1]})', flush=True)
