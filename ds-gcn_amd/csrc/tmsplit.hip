@@ -52,7 +52,7 @@ struct TSArgs {
   float* f; float* oaug; float* stats;            // forward outputs ((n,C,T,V), (n,C,T)+1 float, (rows,C,2))
   const float* ge; const float* doaug;            // backward inputs
   float* dz; float* dzaug; float* part;           // backward outputs ((rows,C,2): sum dpre*x, sum dpre)
-  int n_act, n, C, T, V, nbr, ngrp, nconv, eplanes, sboff, splits, pstride;
+  int n_act, n, C, T, V, nbr, ngrp, ngrpa, nconv, eplanes, sboff, haw, splits, pstride;
   int exp;             // lab builds only: timing experiments that skip parts of the work (0 in the product)
   TSBranch br[TS_MAXBR];
 };
@@ -97,21 +97,34 @@ __device__ __forceinline__ ACC ts_rowread(const float* Tw, int half, int l31) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// conv window, forward (FWD) or data gradient: four waves x 128 positions of the V-column planes, all samples back to
-// back; a lane owns four consecutive positions of one channel row (tap4's scheme).
-// LDS: [0, sboff) = the weight tile [co][tap*CP + ci], reused by the epilogue's transposes; [sboff, +192) = per-channel
-// (scale, shift) pairs and bias of the window.
+// conv window, forward (FWD) or data gradient: four waves x 128 positions of the planes, all samples back to back; a lane
+// owns four consecutive positions of one channel row (tap4's scheme).  AUG = false: the V-column planes (n, C, T, V);
+// AUG = true: the same code on the global-joint column, "planes" of T x 1 (zaug -> oaug, doaug -> dzaug), as extra
+// blocks of the same launch.
+//
+// Forward, V columns: the conv is linear and add_coeff multiplies whole columns, so
+//       o[..., v] + oaug * coeff[v] = conv(h[..., v] + haug * coeff[v]) + bias * (1 + coeff[v]):
+// the global-joint term is folded into the OPERAND (haug of the block's <= 22 frames + halo, activated, sits in LDS) and
+// the epilogue needs no second tensor — f = acc + bias * (1 + coeff[v]) and the statistics of f.  (oaug, which only the
+// backward's d coeff needs, comes from the AUG blocks.)
+//
+// LDS: [0, sboff) = the weight tile [co][tap*CP + ci], reused by the epilogue's transposes; then [64] (scale, shift),
+// [64] bias, [64][32] haug.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool FWD, int MT, bool ODD>
-__device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, float* lds, int grp, int lane, int wave) {
+
+template <bool FWD, int MT, bool ODD, bool AUG>
+__device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, bool first, float* lds, int grp, int lane, int wave) {
   constexpr int KT = 3, PDK = 2, NS = KT * PDK;
+  constexpr bool FOLD = FWD && !AUG;               // the operand carries haug * coeff
   const int tid = threadIdx.x;
   const int half = lane >> 5, l31 = lane & 31;
-  const int V = a.V, T = a.T, L = T * V, L4 = L * 4, C = a.C, bc = br.bc;
+  const int V = AUG ? 1 : a.V, T = a.T, L = T * V, L4 = L * 4, C = a.C, bc = br.bc;
   const int CP = ts_cp(bc), S = KT * CP + 1;
   float* Ws = lds;
   f32x2s* SB = reinterpret_cast<f32x2s*>(lds + a.sboff);   // [64] (scale, shift): zero past the window
   float* BI = lds + a.sboff + 128;                         // [64] bias
+  float* HA = lds + a.sboff + 192;                         // [64][haw]: frames Gs .. Gs + haw of the block's channels
+  const int HAW = a.haw;
   const bool relu = br.c0 < a.n_act;
   const int wt = grp * 4 + wave;
   const long total = (long)a.n * L;
@@ -121,7 +134,8 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
   int p = g0 - n0 * L + 4 * l31, ds = 0;
   while (p >= L) { p -= L; ++ds; }
   const bool pok = wlive && n0 + ds < a.n;
-  const __amdgpu_buffer_rsrc_t rs = ts_rsrc(FWD ? a.z : a.ge, (size_t)a.n * C * L4);
+  const float* srcp = FWD ? (AUG ? a.zaug : a.z) : (AUG ? a.doaug : a.ge);
+  const __amdgpu_buffer_rsrc_t rs = ts_rsrc(srcp, (size_t)a.n * C * L4);
   const int rowbase = ((n0 + ds) * C + br.c0 + half) * L;
   // A side tap shifts by +-dil*V positions.  Even shift: two aligned 8-byte pairs, each wholly inside or outside the plane.
   // Odd shift: the pairs are only 4-byte aligned and one of them can straddle a plane end — (-1, 0) is read as (0, 1) and
@@ -151,12 +165,14 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
     return f32x4{lo.x, lo.y, hi.x, hi.y};
   };
 
-  // forward epilogue: frame of the lane's first position, add_coeff of its four joints (the run may cross into frame t0+1)
-  int t0 = 0;
+  // V columns, forward: add_coeff of the lane's four joints (the run may cross into the next frame: nx) and the lane's
+  // frame inside the block's haug window
   float cf[4] = {0.f, 0.f, 0.f, 0.f};
   bool nx[4] = {false, false, false, false};
-  if constexpr (FWD) {
-    int v0;
+  int gl = 0;
+  const int Gs = (grp * 512) / V - TS_H;           // first frame of the window, in frames counted over all samples
+  if constexpr (FOLD) {
+    int t0, v0;
     divmod_small(p, V, 1.f / (float)V, t0, v0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -164,6 +180,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
       nx[k] = vv >= V;
       cf[k] = a.coeff[nx[k] ? vv - V : vv];
     }
+    gl = pok ? (n0 + ds) * T + t0 - Gs : TS_H;
   }
   const int KS2 = ((bc + 3) >> 2) << 1;                      // k-steps of two channels, even (weights are zero past bc)
   f32x4 buf[NS];
@@ -173,10 +190,10 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
     __builtin_amdgcn_sched_barrier(0);
   }
   // Staging (the operand prefetch above is already in flight: the block pays ONE memory round trip before its first
-  // product, not one per stage): weights [co][tap*CP + ci] zero padded, per-channel (scale, shift) and bias.
+  // product, not one per stage): weights [co][tap*CP + ci] zero padded, per-channel (scale, shift) and bias, haug.
   {
     const int run = bc * KT, wtotal = bc * run;
-    float wv[8];
+    float wv[8], hv[FOLD ? 8 : 1];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int i = tid + q * TS_NT;
@@ -188,6 +205,19 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
       const int c = br.c0 + tid;
       sb = f32x2s{a.scale ? a.scale[c] : 1.f, a.shift ? a.shift[c] : 0.f};
       if (br.b) bi = br.b[tid];
+    }
+    // haug: haw is a power of two (32 at V >= 23), thread = (frame tid % haw, channels tid / haw + k * 256 / haw): the
+    // frame, hence the sample and the address arithmetic, is fixed per thread
+    const int he = tid & (HAW - 1), hc0 = tid / HAW, hcs = TS_NT / HAW;
+    const int hG = Gs + he, hn = hG / T, ht = hG - hn * T;
+    const bool hok = hG >= 0 && hn < a.n;
+    const float* hsrc = a.zaug + ((size_t)(hok ? hn : 0) * C + br.c0) * T + (hok ? ht : 0);
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int ci = hc0 + q * hcs;
+        hv[q] = (hok && ci < bc) ? hsrc[(size_t)ci * T] : 0.f;
+      }
     }
     for (int i = tid; i < 64 * S + 64; i += TS_NT) Ws[i] = 0.f;
     if (tid < 64) {
@@ -202,6 +232,21 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
         const int co = i / run, r = i - co * run, ci = r / KT, tap = r - ci * KT;
         Ws[co * S + tap * CP + ci] = wv[q];
       }
+    }
+    if constexpr (FOLD) {
+      auto put = [&](int ci, float x) {
+        const f32x2s e = SB[ci];
+        float y = fmaf(x, e.x, e.y);
+        if (relu) y = fmaxf(y, 0.f);
+        HA[ci * HAW + he] = (hok && ci < bc) ? y : 0.f;
+      };
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int ci = hc0 + q * hcs;
+        if (ci < 64) put(ci, hv[q]);
+      }
+      for (int ci = hc0 + 8 * hcs; ci < 64; ci += hcs)               // haw > 32 (V < 23): the rest of the channels
+        put(ci, (hok && ci < bc) ? hsrc[(size_t)ci * T] : 0.f);
     }
     for (int i0 = 8 * TS_NT; i0 < wtotal; i0 += 8 * TS_NT) {     // windows wider than 26 channels: the rest of the tile
 #pragma unroll
@@ -231,11 +276,17 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
     const int kl = 2 * ks + half;
     return FWD ? Ws[(32 * m + l31) * S + tap * CP + kl] : Ws[kl * S + tap * CP + 32 * m + l31];
   };
+  // haug of channel 2ks+half at the lane's frame shifted by the tap, and the frame after it
+  auto hfrag = [&](int tap, int ks) -> f32x2s {
+    const float* hp = HA + (2 * ks + half) * HAW + gl + (tap - 1) * br.dil;
+    return f32x2s{hp[0], hp[1]};
+  };
   float avb[2][MT];
-  f32x2s sbv[2];
+  f32x2s sbv[2], hab[2];
 #pragma unroll
   for (int m = 0; m < MT; ++m) avb[0][m] = afrag(0, 0, m);
   sbv[0] = SB[half];
+  if constexpr (FOLD) hab[0] = hfrag(0, 0);
   for (int base = 0; base < KS2; base += PDK) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
@@ -245,6 +296,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
 #pragma unroll
       for (int m = 0; m < MT; ++m) avb[nxt][m] = afrag(tn, kn < 32 ? kn : 31, m);
       if (FWD) sbv[nxt] = SB[2 * (kn < 32 ? kn : 31) + half];
+      if constexpr (FOLD) hab[nxt] = hfrag(tn, kn < 32 ? kn : 31);
       f32x4 b = buf[u];
       if (tap != 1) {
         if (ODD) {
@@ -260,6 +312,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
         for (int q = 0; q < 4; ++q) {
           float v = fmaf(b[q], sbv[cur].x, sbv[cur].y);
           if (relu) v = fmaxf(v, 0.f);
+          if constexpr (FOLD) v = fmaf(nx[q] ? hab[cur].y : hab[cur].x, cf[q], v);
           if (tap != 1) v *= mk[tap][q];
           b[q] = v;
         }
@@ -277,24 +330,15 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // The epilogue's first operands (forward: the global-joint column of the lane's rows; data gradient: z) are requested
-  // before the barrier that hands the weight tile's LDS to the transposes, so that their round trip overlaps it.
   float* Tw = lds + wave * (2 * 32 * 36);
   const int ooff = pok ? (((n0 + ds) * C + br.c0) * L + p) * 4 : TS_OOB;
   if constexpr (FWD) {
     double* Ss = reinterpret_cast<double*>(lds + 4 * 2 * 32 * 36);   // [4][MT*32][2]
-    const __amdgpu_buffer_rsrc_t ra = ts_rsrc(a.oaug, ((size_t)a.n * C * T + 1) * 4);
-    const __amdgpu_buffer_rsrc_t ro = ts_rsrc(a.f, (size_t)a.n * C * L4);
-    const int aoff = pok ? (((n0 + ds) * C + br.c0) * T + t0) * 4 : TS_OOB;
-    const bool stats = a.stats != nullptr && !(a.exp & 2);
-    f32x2s oa[MT][16];
+    const __amdgpu_buffer_rsrc_t ro = ts_rsrc(AUG ? a.oaug : a.f, (size_t)a.n * C * L4);
+    const bool stats = !AUG && a.stats != nullptr && !(a.exp & 2);
+    float bmul[4];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = 32 * m + ts_row32(r, half);
-        oa[m][r] = ts_load2(ra, ts_rowoff(ch < bc, aoff, ch * T * 4), 0);
-      }
+    for (int k = 0; k < 4; ++k) bmul[k] = 1.f + cf[k];           // AUG: cf = 0
     __syncthreads();                                // the weight tile is dead: its LDS carries the transposes
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -307,7 +351,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
         float s = 0.f, qq = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          val[k] = fmaf(nx[k] ? oa[m][r].y : oa[m][r].x, cf[k], acc[m][k][r] + bias);
+          val[k] = fmaf(bias, bmul[k], acc[m][k][r]);
           s += val[k];
           qq = fmaf(val[k], val[k], qq);
         }
@@ -343,8 +387,8 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
     }
   } else {
     float* Ss = lds + 4 * 2 * 32 * 36;                                 // [4][MT*32][2]
-    const __amdgpu_buffer_rsrc_t rx = ts_rsrc(a.z, (size_t)a.n * C * L4);
-    const __amdgpu_buffer_rsrc_t ro = ts_rsrc(a.dz, (size_t)a.n * C * L4);
+    const __amdgpu_buffer_rsrc_t rx = ts_rsrc(AUG ? a.zaug : a.z, (size_t)a.n * C * L4);
+    const __amdgpu_buffer_rsrc_t ro = ts_rsrc(AUG ? a.dzaug : a.dz, (size_t)a.n * C * L4);
     constexpr int G = MT * 4, PD = 4;
     f32x4 xa[PD][4];
     auto fetch = [&](int g, int slot) {
@@ -404,13 +448,22 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, flo
       }
     }
     __syncthreads();
+    const size_t prow = (size_t)(AUG ? a.ngrp + a.n + grp : grp) * C;
     if (tid < 32 * MT && tid < bc) {
       float v0 = 0.f, v1 = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { v0 += Ss[((w * MT * 32) + tid) * 2]; v1 += Ss[((w * MT * 32) + tid) * 2 + 1]; }
-      a.part[((size_t)grp * C + br.c0 + tid) * 2 + 0] = v0;
-      a.part[((size_t)grp * C + br.c0 + tid) * 2 + 1] = v1;
+      a.part[(prow + br.c0 + tid) * 2 + 0] = v0;
+      a.part[(prow + br.c0 + tid) * 2 + 1] = v1;
     }
+  }
+  // the table rows of this block hold nothing for the pooling / pass-through channels: the first window's block zeroes them
+  float* tab = FWD ? (AUG ? nullptr : a.stats) : a.part;
+  if (tab && first) {
+    const size_t trow = (size_t)((!FWD && AUG) ? a.ngrp + a.n + grp : grp) * C;
+    for (int i = 0; i < a.nbr; ++i)
+      if (a.br[i].type != 0)
+        for (int k = tid; k < a.br[i].bc * 2; k += TS_NT) tab[(trow + a.br[i].c0) * 2 + k] = 0.f;
   }
 }
 
@@ -502,6 +555,22 @@ __device__ __forceinline__ void ts_elem(const TSArgs& a, const TSBranch& br, flo
     }
     f32x4* fp = reinterpret_cast<f32x4*>(a.f + plane * L);
     double sv = 0.0, qv = 0.0;
+    if (pool) {
+      // lane = consecutive elements: the three rows of a window are conflict-free LDS reads (a lane owning four consecutive
+      // elements reads at a stride of four banks: four lanes per bank)
+      float* fo = a.f + plane * L;
+      for (int e = lane; e < L; e += 64) {
+        int t, v;
+        divmod_small(e, V, invV, t, v);
+        float x = hp[e], o = ha[t];
+        if (t >= 1) { x = fmaxf(x, hp[e - V]); o = fmaxf(o, ha[t - 1]); }
+        if (t + 1 < T) { x = fmaxf(x, hp[e + V]); o = fmaxf(o, ha[t + 1]); }
+        const float r = fmaf(o, cf[v], x);
+        fo[e] = r;
+        sv += (double)r;
+        qv = fma((double)r, (double)r, qv);
+      }
+    } else
 #pragma unroll
     for (int q = 0; q < TS_PQ; ++q) {
       const int i = q * 64 + lane;
@@ -555,6 +624,19 @@ __device__ __forceinline__ void ts_elem(const TSArgs& a, const TSBranch& br, flo
     };
     f32x4* dp = reinterpret_cast<f32x4*>(a.dz + plane * L);
     float u0 = 0.f, u1 = 0.f;
+    if (pool) {
+      float* dzo = a.dz + plane * L;
+      for (int e = lane; e < L; e += 64) {
+        int t, v;
+        divmod_small(e, V, invV, t, v);
+        const float x = hp[e];
+        float g = route(hp + v, gp + v, t, V);
+        if (relu && !(fmaf(x, s, b) > 0.f)) g = 0.f;
+        dzo[e] = g * s;
+        u0 = fmaf(g, x, u0);
+        u1 += g;
+      }
+    } else
 #pragma unroll
     for (int q = 0; q < TS_PQ; ++q) {
       const int i = q * 64 + lane;
@@ -604,25 +686,39 @@ __device__ __forceinline__ void ts_elem(const TSArgs& a, const TSBranch& br, flo
   }
 }
 
-// grid.x = [conv blocks: (position group, conv window)] ++ [plane blocks: 4 planes each]
+// grid.x = [conv blocks of the V columns: (position group, conv window)] ++ [conv blocks of the global-joint column] ++
+// [plane blocks: 4 planes each]
 template <bool FWD, int MT>
 __global__ __launch_bounds__(TS_NT, MT == 1 ? 3 : 2) void k_tsp(TSArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int cb = a.nconv * a.ngrp, b = blockIdx.x;
+  const int cb = a.nconv * a.ngrp, cba = a.nconv * a.ngrpa, b = blockIdx.x;
   if (b < cb) {
     if (a.exp & 8) return;
     const int w = b % a.nconv, grp = b / a.nconv;
     const TSBranch& br = ts_conv_window(a, w);
-    if (((br.dil * a.V) & 1) && !(a.exp & 16)) ts_conv<FWD, MT, true>(a, br, lds, grp, lane, wave);
-    else ts_conv<FWD, MT, false>(a, br, lds, grp, lane, wave);
+    if (((br.dil * a.V) & 1) && !(a.exp & 16)) ts_conv<FWD, MT, true, false>(a, br, w == 0, lds, grp, lane, wave);
+    else ts_conv<FWD, MT, false, false>(a, br, w == 0, lds, grp, lane, wave);
     return;
   }
-  int pl = (b - cb) * 4 + wave;
+  if (b < cb + cba) {
+    const int w = (b - cb) % a.nconv, grp = (b - cb) / a.nconv;
+    const TSBranch& br = ts_conv_window(a, w);
+    if (br.dil & 1) ts_conv<FWD, MT, true, true>(a, br, w == 0, lds, grp, lane, wave);
+    else ts_conv<FWD, MT, false, true>(a, br, w == 0, lds, grp, lane, wave);
+    return;
+  }
+  int pl = (b - cb - cba) * 4 + wave;
   if (pl >= a.n * a.eplanes || (a.exp & 1)) return;
   const int n = pl / a.eplanes;
   int c = pl - n * a.eplanes;
+  float* tab = FWD ? a.stats : a.part;
+  if (c == 0 && tab) {                  // the plane rows hold nothing for the conv channels: the first plane's wave zeroes them
+    for (int i = 0; i < a.nbr; ++i)
+      if (a.br[i].type == 0)
+        for (int k = lane; k < a.br[i].bc * 2; k += 64) tab[((size_t)(a.ngrp + n) * a.C + a.br[i].c0) * 2 + k] = 0.f;
+  }
   const int per = (FWD ? 1 : 2) * a.T * a.V + 2 * ((a.T + 3) & ~3) + 32;
   for (int i = 0; i < a.nbr; ++i) {
     if (a.br[i].type == 0) continue;
@@ -631,179 +727,6 @@ __global__ __launch_bounds__(TS_NT, MT == 1 ? 3 : 2) void k_tsp(TSArgs a) {
       return;
     }
     c -= a.br[i].bc;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The one-column part of the conv windows: per (sample, window) a (bc x 3bc) x (3bc x T) product on the f32 matrix core
-// — out[i][t] = sum_{tap,k} W(i,k,tap) * col[k][t -+ (tap-1)*dil] with the column zero-padded by four frames on either
-// side in LDS.  grid = (n, conv windows), one 32 x 32 output tile per wave.  FWD: oaug = bias + conv(relu(zaug*scale +
-// shift));  data gradient: dzaug = relu'(.) * convT(doaug) * scale and the column's share of the branch BatchNorm's sums
-// (part rows [ngrp + n, ngrp + 2n)).  (A scalar version of these launches took 20 us each: ~800 dependent LDS reads per
-// thread.)  The blocks also zero the rows of the partial table that the main launch leaves unwritten (conv rows: the
-// pooling channels; plane rows: the conv channels).
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ts_zero_rows(float* tab, const TSArgs& a) {
-  // rows [0, ngrp + n) x C x 2, spread over the grid
-  const long total = (long)(a.ngrp + a.n) * a.C * 2;
-  const long nb = (long)gridDim.x * gridDim.y, me = (long)blockIdx.y * gridDim.x + blockIdx.x;
-  const long per = (total + nb - 1) / nb;
-  const long lo = me * per, hi = min(total, lo + per);
-  for (long i = lo + threadIdx.x; i < hi; i += TS_NT) tab[i] = 0.f;
-}
-
-// global -> LDS copy of a short run with every load of a 2048-float chunk in flight before the first LDS write
-template <typename F, typename G>
-__device__ __forceinline__ void ts_fill_lds(float* dst, int count, F&& src, G&& at) {
-  for (int base = 0; base < count; base += 8 * TS_NT) {
-    float v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = base + q * TS_NT + threadIdx.x;
-      v[q] = i < count ? src(i) : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = base + q * TS_NT + threadIdx.x;
-      if (i < count) dst[at(i)] = v[q];
-    }
-  }
-}
-
-__host__ __device__ inline int tsa_row(int T) { return ((T + 31) & ~31) + 2 * TS_H; }     // padded column row (floats)
-
-template <bool FWD>
-__global__ __launch_bounds__(TS_NT) void k_tsp_aug(TSArgs a) {
-  constexpr int KT = 3;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  const int n = blockIdx.x;
-  const TSBranch& br = ts_conv_window(a, blockIdx.y);
-  const int T = a.T, C = a.C, bc = br.bc;
-  const int CP = ts_cp(bc), S = KT * CP + 1, TR = tsa_row(T);
-  float* tab = FWD ? a.stats : a.part;
-  if (tab) ts_zero_rows(tab, a);
-  if (a.exp & 32) return;
-  float* Ws = lds;                       // [64][S] + 64: weights [co][tap*CP + ci], zero padded
-  float* Hl = Ws + 64 * S + 64;          // [CP][TR]: the column operand (FWD: relu(zaug*scale+shift); else doaug)
-  float* Sl = Hl + CP * TR;              // [3][64] scale, shift, bias
-  float* Xl = Sl + 192;                  // data gradient: [bc][T] zaug, then [bc][T] dpre*x, [bc][T] dpre
-  const bool relu = br.c0 < a.n_act;
-  const size_t base = ((size_t)n * C + br.c0) * T;
-  // every global operand of the block is requested before the first LDS write (the launch is a chain of memory round trips,
-  // not bandwidth): per thread 1 table value, 4 + 4 column values, 26 weights; longer runs take the loops below
-  constexpr int HQ = 4, WQ = 26;
-  const float* col = (FWD ? a.zaug : a.doaug) + base;
-  const float* za = a.zaug + base;
-  const int run = bc * KT, wtot = bc * run, htot = bc * T;
-  auto tabv = [&](int i) -> float {
-    const int k = i >> 6, c = i & 63;
-    if (c >= bc) return 0.f;
-    return k == 0 ? (a.scale ? a.scale[br.c0 + c] : 1.f) : k == 1 ? (a.shift ? a.shift[br.c0 + c] : 0.f) : (br.b ? br.b[c] : 0.f);
-  };
-  auto hat = [&](int i) { const int c = i / T; return c * TR + TS_H + (i - c * T); };
-  auto wat = [&](int i) {
-    const int co = i / run, r = i - co * run, ci = r / KT, tap = r - ci * KT;
-    return co * S + tap * CP + ci;
-  };
-  const float tv = tid < 192 ? tabv(tid) : 0.f;
-  float vh[HQ], vx[HQ], vw[WQ];
-#pragma unroll
-  for (int q = 0; q < HQ; ++q) {
-    const int i = tid + q * TS_NT;
-    vh[q] = i < htot ? col[i] : 0.f;
-    vx[q] = (!FWD && i < htot) ? za[i] : 0.f;
-  }
-#pragma unroll
-  for (int q = 0; q < WQ; ++q) {
-    const int i = tid + q * TS_NT;
-    vw[q] = i < wtot ? br.w[i] : 0.f;
-  }
-  for (int i = tid; i < 64 * S + 64 + CP * TR; i += TS_NT) lds[i] = 0.f;
-  __syncthreads();
-  if (tid < 192) Sl[tid] = tv;
-#pragma unroll
-  for (int q = 0; q < HQ; ++q) {
-    const int i = tid + q * TS_NT;
-    if (i < htot) {
-      Hl[hat(i)] = vh[q];
-      if (!FWD) Xl[i] = vx[q];
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < WQ; ++q) {
-    const int i = tid + q * TS_NT;
-    if (i < wtot) Ws[wat(i)] = vw[q];
-  }
-  if (htot > HQ * TS_NT) {
-    ts_fill_lds(Hl, htot - HQ * TS_NT, [&](int i) -> float { return col[i + HQ * TS_NT]; },
-                [&](int i) { return hat(i + HQ * TS_NT); });
-    if (!FWD)
-      ts_fill_lds(Xl + HQ * TS_NT, htot - HQ * TS_NT, [&](int i) -> float { return za[i + HQ * TS_NT]; }, [](int i) { return i; });
-  }
-  if (wtot > WQ * TS_NT)
-    ts_fill_lds(Ws, wtot - WQ * TS_NT, [&](int i) -> float { return br.w[i + WQ * TS_NT]; },
-                [&](int i) { return wat(i + WQ * TS_NT); });
-  __syncthreads();
-  if (FWD) {
-    for (int i = tid; i < bc * T; i += TS_NT) {
-      const int c = i / T, t = i - c * T;
-      const float y = fmaf(Hl[c * TR + TS_H + t], Sl[c], Sl[64 + c]);
-      Hl[c * TR + TS_H + t] = relu ? fmaxf(y, 0.f) : y;
-    }
-    __syncthreads();
-  }
-  const int MTn = (bc + 31) >> 5, TTn = (T + 31) >> 5;
-  for (int tile = wave; tile < ((a.exp & 64) ? 0 : MTn * TTn); tile += 4) {
-    const int m = tile % MTn, tt = tile / MTn;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int tap = 0; tap < KT; ++tap) {
-      const int sh = (FWD ? (tap - 1) : (1 - tap)) * br.dil;
-      const float* bp = Hl + half * TR + TS_H + 32 * tt + l31 + sh;
-      const float* ap = FWD ? Ws + (32 * m + l31) * S + tap * CP + half : Ws + half * S + tap * CP + 32 * m + l31;
-      for (int ks = 0; ks < CP / 2; ++ks) {
-        const float av = FWD ? ap[2 * ks] : ap[2 * ks * S];
-        const float bv = bp[2 * ks * TR];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-      }
-    }
-    const int t = 32 * tt + l31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = 32 * m + ts_row32(r, half);
-      if (i < bc && t < T) {
-        if (FWD) {
-          a.oaug[base + (size_t)i * T + t] = acc[r] + Sl[128 + i];
-        } else {
-          const float s = Sl[i], b = Sl[64 + i];
-          const float x = Xl[i * T + t];
-          const float dv = (relu && !(fmaf(x, s, b) > 0.f)) ? 0.f : acc[r];
-          a.dzaug[base + (size_t)i * T + t] = dv * s;
-          Xl[(bc + i) * T + t] = dv * x;
-          Xl[(2 * bc + i) * T + t] = dv;
-        }
-      }
-    }
-  }
-  if (!FWD) {
-    __syncthreads();
-    const size_t row = (size_t)(a.ngrp + a.n + n) * C;
-    if (tid < bc) {
-      float v0 = 0.f, v1 = 0.f;
-      for (int t = 0; t < T; ++t) { v0 += Xl[(bc + tid) * T + t]; v1 += Xl[(2 * bc + tid) * T + t]; }
-      a.part[(row + br.c0 + tid) * 2 + 0] = v0;
-      a.part[(row + br.c0 + tid) * 2 + 1] = v1;
-    }
-    if (blockIdx.y == 0) {               // the pooling / pass-through channels of this row: their planes carry the column
-      for (int i = 0; i < a.nbr; ++i)
-        if (a.br[i].type != 0)
-          for (int k = tid; k < a.br[i].bc * 2; k += TS_NT) a.part[(row + a.br[i].c0) * 2 + k] = 0.f;
-    }
   }
 }
 
@@ -1145,6 +1068,9 @@ int ts_fill(TSArgs& a, int n, int C, int T, int V, int stride, int KT, int nbr, 
   a.eplanes = eplanes;
   const int WT = (int)(((long)n * L + 127) / 128);
   a.ngrp = (WT + 3) / 4;
+  a.ngrpa = (int)(((long)n * T + 511) / 512);
+  a.haw = 32;                                       // frames of haug per block (511 / V + 2, a halo of 4 either side, the pair read), a power of two
+  while (a.haw < 511 / V + 2 + 2 * TS_H + 1) a.haw *= 2;
   return wmax <= 32 ? 1 : 2;                          // = MT
 }
 
@@ -1158,13 +1084,13 @@ size_t ts_lds_main(TSArgs& a, int MT, bool fwd) {
   const size_t convf = (std::max(wsf, epf) + 3) & ~(size_t)3;
   a.sboff = (int)convf;
   const size_t planef = (size_t)4 * ((fwd ? 1 : 2) * a.T * a.V + 2 * ((a.T + 3) & ~3) + 32);
-  return std::max(convf + 192, planef) * sizeof(float);
+  return std::max(convf + 192 + (fwd ? (size_t)64 * a.haw : 0), planef) * sizeof(float);
 }
 
 template <bool FWD>
 int ts_launch_main(TSArgs& a, int MT, hipStream_t st) {
   const size_t lds = ts_lds_main(a, MT, FWD);
-  const long blocks = (long)a.nconv * a.ngrp + ((long)a.n * a.eplanes + 3) / 4;
+  const long blocks = (long)a.nconv * (a.ngrp + a.ngrpa) + ((long)a.n * a.eplanes + 3) / 4;
   if (blocks <= 0 || blocks >= (1L << 31)) return DSGCN_EUNSUPPORTED;
   const dim3 grid((unsigned)blocks), blk(TS_NT);
   if (MT == 1) {
@@ -1178,25 +1104,6 @@ int ts_launch_main(TSArgs& a, int MT, hipStream_t st) {
     if (rc) return rc;
     hipLaunchKernelGGL((k_tsp<FWD, 2>), grid, blk, lds, st, a);
   }
-  DSGCN_LAUNCH_CHECK();
-  return 0;
-}
-
-size_t ts_lds_aug(const TSArgs& a, bool fwd) {
-  int wmax = 1;
-  for (int i = 0; i < a.nbr; ++i)
-    if (a.br[i].type == 0) wmax = std::max(wmax, a.br[i].bc);
-  const int cp = (std::min(64, wmax) + 7) & ~7;
-  return ((size_t)64 * (3 * cp + 1) + 64 + (size_t)cp * tsa_row(a.T) + 192 + (fwd ? 0 : (size_t)3 * wmax * a.T)) * sizeof(float);
-}
-
-template <bool FWD>
-int ts_launch_aug(const TSArgs& a, hipStream_t st) {
-  const size_t lds = ts_lds_aug(a, FWD);
-  static size_t have = 64 * 1024;
-  const int rc = ts_raise_lds(k_tsp_aug<FWD>, lds, &have);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_tsp_aug<FWD>, dim3((unsigned)a.n, (unsigned)a.nconv), dim3(TS_NT), lds, st, a);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -1223,10 +1130,10 @@ int dsgcn_tms_split_rows(int which, int n, int C, int T, int V, int stride, int 
   TSArgs a = {};
   const int mt = ts_fill(a, n, C, T, V, stride, KT, nbr, type, c0, bc, dil);
   if (mt <= 0) return 0;
-  if (ts_lds_main(a, mt, false) > TS_LDS_MAX || ts_lds_aug(a, false) > TS_LDS_MAX) return 0;
+  if (ts_lds_main(a, mt, false) > TS_LDS_MAX || ts_lds_main(a, mt, true) > TS_LDS_MAX) return 0;
   if (which == -1) return 1;
   if (which == 0) return a.ngrp + n;
-  if (which == 1) return a.ngrp + 2 * n;
+  if (which == 1) return a.ngrp + n + a.ngrpa;
   if (which == 2) {
     const int units = n * (T / TS_R);
     int splits = (mt == 1 ? 512 : 256) / a.nconv;
@@ -1253,10 +1160,6 @@ int dsgcn_tms_split_fwd(const float* z, const float* zaug, const float* scale, c
     if (type[i] == 0 && !a.br[i].w) return DSGCN_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  {
-    const int rc = ts_launch_aug<true>(a, st);
-    if (rc) return rc;
-  }
   return ts_launch_main<true>(a, mt, st);
 }
 
@@ -1291,10 +1194,6 @@ int dsgcn_tms_split_dgrad(const float* z, const float* zaug, const float* scale,
     if (type[i] == 0 && !a.br[i].w) return DSGCN_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  {
-    const int rc = ts_launch_aug<false>(a, st);
-    if (rc) return rc;
-  }
   return ts_launch_main<false>(a, mt, st);
 }
 
