@@ -2,27 +2,27 @@
 // the unit's two 1x1 convs WITHOUT its (V+1)-column intermediates.  tcn.py:409 appends the global joint (the mean over the
 // joints) as a 26th column, runs BatchNorm + ReLU and the six temporal branches on the widened tensor and folds the extra
 // column back with `x[..., :V] + einsum(x[..., V], add_coeff)` (tcn.py:416-420).  Every stage in between is column-wise, so
-// the stage splits exactly into a V-column part and a one-column part:
+// the stage splits exactly into a V-column part on the (n,C,T,V) layout and a one-column part on (n,C,T) tensors, and the
+// conv windows being linear, the one-column part of their forward folds into the operand:
+//       o[..., v] + oaug * coeff[v] = conv(h[..., v] + haug * coeff[v]) + bias * (1 + coeff[v]).
 //
-//   forward   k_tsp_aug_fwd : the one-column part of the conv windows, oaug (n,C,T)           (tiny; zero-fills the
-//                             statistics rows the main launch does not write)
-//             k_tsp<true>   : conv windows on the f32 matrix core, B operand = relu(z*scale+shift) formed while loading z
-//                             (V columns: 16-byte planes; a tap shifts by dil*V positions, an ODD shift is read with two
-//                             4-byte-aligned 8-byte loads per side tap and the two plane-end cases fixed up by select),
-//                             epilogue f = acc + bias + oaug[t]*coeff[v] + the batch statistics of f (transform.0's
-//                             BatchNorm, tcn.py:401) — h, o and the old branch_act / combine passes never exist;
-//                             max-pool / pass-through windows as whole-plane passes through LDS in the same launch
+//   forward   k_tsp<true>   : ONE launch.  Conv windows on the f32 matrix core, B operand = relu(z*scale+shift) + haug*coeff
+//                             formed while loading z (16-byte planes; a tap shifts by dil*V positions, an ODD shift is read
+//                             with two 4-byte-aligned 8-byte loads per side tap and the two plane-end cases fixed up by
+//                             select; haug of the block's frames sits in LDS), epilogue f = acc + bias*(1 + coeff) + the batch
+//                             statistics of f (transform.0's BatchNorm, tcn.py:401) — h, o and the old branch_act / combine
+//                             passes never exist; the same code on T x 1 "planes" as extra blocks gives oaug (kept for the
+//                             backward's d coeff); max-pool / pass-through windows as whole-plane waves in the same launch
 //   backward  k_tsp_prep    : ge = gf + A0 + B0*f (one materialised copy: it feeds the data AND the weight gradient), its
 //                             global-joint column doaug = sum_v ge*coeff, d coeff partials
-//             k_tsp_aug_bwd : the one-column part of the data gradient (dzaug + its share of the BatchNorm sums)
-//             k_tsp<false>  : transposed windows over ge; epilogue dz = relu'(z*scale+shift) * acc * scale and the
-//                             sums of the branch BatchNorm's backward (sum dpre*z, sum dpre) — dh / branch_act_bwd gone
-//             k_tspw        : weight gradient; the staging step reads ge / z in V-column rows (16-byte loads), applies
-//                             the affine + ReLU and lays the tile out in LDS at V+1 columns with the global-joint column
-//                             in place, so the matrix loop of k_tapw (csrc/tapconv.hip) runs unchanged and dW / db carry
-//                             the one-column part too
-// Stride 1, kernel 3, windows <= 64 channels, dilation <= 4, T % 4 == 0; everything else stays on the staged path
-// (branch_act -> tapconv -> combine).  The matrix loops are tapconv.hip's tap4 / tapw forms.
+//             k_tsp<false>  : ONE launch.  Transposed windows over ge; epilogue dz = relu'(z*scale+shift) * acc * scale and
+//                             the sums of the branch BatchNorm's backward (sum dpre*z, sum dpre) — dh / branch_act_bwd gone;
+//                             extra blocks do the same for the one-column part (doaug -> dzaug)
+//             k_tspw        : weight gradient, k_tapw's scheme (csrc/tapconv.hip) on the split operands: h is formed from z
+//                             on the way into LDS, the unit's four global-joint values ride as one more group of the
+//                             matrix loop, consecutive windows that fit one 32 x 32 tile share a block (per-lane tap shift)
+// Stride 1, kernel 3, windows <= 64 channels, dilation <= 4, V odd, T % 4 == 0, T*V <= 2048; everything else stays on the
+// staged path (branch_act -> tapconv -> combine).  Measured: profiles/r04/README.md.
 #include <algorithm>
 
 #include "common.h"
@@ -53,6 +53,7 @@ struct TSArgs {
   const float* ge; const float* doaug;            // backward inputs
   float* dz; float* dzaug; float* part;           // backward outputs ((rows,C,2): sum dpre*x, sum dpre)
   int n_act, n, C, T, V, nbr, ngrp, ngrpa, nconv, eplanes, sboff, haw, splits, pstride;
+  int ngroups, gfirst[TS_MAXBR], gcount[TS_MAXBR];   // weight gradient: consecutive conv windows sharing one (co x ci) tile
   int exp;             // lab builds only: timing experiments that skip parts of the work (0 in the product)
   TSBranch br[TS_MAXBR];
 };
@@ -112,10 +113,24 @@ __device__ __forceinline__ ACC ts_rowread(const float* Tw, int half, int l31) {
 // [64] bias, [64][32] haug.
 // ---------------------------------------------------------------------------------------------------------------
 
+#ifdef DSGCN_LAB
+// wall-clock stamps (10 ns) of one V-column conv block of k_tsp (block g_tsc_block, thread 0): start, operand prefetch +
+// staging requests issued, staging done (barrier), main loop done, epilogue done; [15] = count (dsgcn_tms_split_phases(1))
+__device__ long long g_tsc_stamp[16];
+__device__ int g_tsc_block = 0;
+#define TSC_STAMP() do { if (!AUG && (int)blockIdx.x == g_tsc_block && threadIdx.x == 0 && nst < 14) g_tsc_stamp[nst++] = wall_clock64(); } while (0)
+#else
+#define TSC_STAMP() do {} while (0)
+#endif
+
 template <bool FWD, int MT, bool ODD, bool AUG>
 __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, bool first, float* lds, int grp, int lane, int wave) {
   constexpr int KT = 3, PDK = 2, NS = KT * PDK;
   constexpr bool FOLD = FWD && !AUG;               // the operand carries haug * coeff
+#ifdef DSGCN_LAB
+  int nst = 0;
+#endif
+  TSC_STAMP();
   const int tid = threadIdx.x;
   const int half = lane >> 5, l31 = lane & 31;
   const int V = AUG ? 1 : a.V, T = a.T, L = T * V, L4 = L * 4, C = a.C, bc = br.bc;
@@ -219,12 +234,14 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
         hv[q] = (hok && ci < bc) ? hsrc[(size_t)ci * T] : 0.f;
       }
     }
+    TSC_STAMP();
     for (int i = tid; i < 64 * S + 64; i += TS_NT) Ws[i] = 0.f;
     if (tid < 64) {
       SB[tid] = sb;
       BI[tid] = bi;
     }
     __syncthreads();
+    TSC_STAMP();
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int i = tid + q * TS_NT;
@@ -265,6 +282,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
     }
     __syncthreads();
   }
+  TSC_STAMP();
   f32x16 acc[MT][4];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -330,10 +348,11 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  float* Tw = lds + wave * (2 * 32 * 36);
+  TSC_STAMP();
+  float* Tw = lds + wave * (32 * 36);               // one transpose tile per wave: the two sums of a row tile go through it in turn
   const int ooff = pok ? (((n0 + ds) * C + br.c0) * L + p) * 4 : TS_OOB;
   if constexpr (FWD) {
-    double* Ss = reinterpret_cast<double*>(lds + 4 * 2 * 32 * 36);   // [4][MT*32][2]
+    double* Ss = reinterpret_cast<double*>(lds + 4 * 32 * 36);       // [4][MT*32][2]
     const __amdgpu_buffer_rsrc_t ro = ts_rsrc(AUG ? a.oaug : a.f, (size_t)a.n * C * L4);
     const bool stats = !AUG && a.stats != nullptr && !(a.exp & 2);
     float bmul[4];
@@ -342,6 +361,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
     __syncthreads();                                // the weight tile is dead: its LDS carries the transposes
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
+      float sq[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = ts_row32(r, half);
@@ -359,13 +379,17 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
         if (stats) {
           const bool ok = ch < bc && pok;
           Tw[row * 36 + l31] = ok ? s : 0.f;
-          Tw[32 * 36 + row * 36 + l31] = ok ? qq : 0.f;
+          sq[r] = ok ? qq : 0.f;
         }
       }
       if (stats) {
         wave_lds_sync();
         double sd = ts_rowread<double>(Tw, half, l31);
-        double qd = ts_rowread<double>(Tw + 32 * 36, half, l31);
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Tw[ts_row32(r, half) * 36 + l31] = sq[r];
+        wave_lds_sync();
+        double qd = ts_rowread<double>(Tw, half, l31);
         wave_lds_sync();
         sd += __shfl_xor(sd, 32, 64);
         qd += __shfl_xor(qd, 32, 64);
@@ -386,11 +410,12 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
       }
     }
   } else {
-    float* Ss = lds + 4 * 2 * 32 * 36;                                 // [4][MT*32][2]
+    float* Ss = lds + 4 * 32 * 36;                                     // [4][MT*32][2]
     const __amdgpu_buffer_rsrc_t rx = ts_rsrc(AUG ? a.zaug : a.z, (size_t)a.n * C * L4);
     const __amdgpu_buffer_rsrc_t ro = ts_rsrc(AUG ? a.dzaug : a.dz, (size_t)a.n * C * L4);
     constexpr int G = MT * 4, PD = 4;
     f32x4 xa[PD][4];
+    float su[16];
     auto fetch = [&](int g, int slot) {
       const int m = g >> 2, rb = (g & 3) * 4;
 #pragma unroll
@@ -427,7 +452,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
         ts_store4(d, ro, ts_rowoff(ch < bc, ooff, ch * L4));
         const bool ok = ch < bc && pok;
         Tw[row * 36 + l31] = ok ? u0 : 0.f;
-        Tw[32 * 36 + row * 36 + l31] = ok ? u1 : 0.f;
+        su[r] = ok ? u1 : 0.f;
       }
       if (MT == 2) {
         __builtin_amdgcn_sched_barrier(0);
@@ -437,7 +462,11 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
       if ((g & 3) == 3) {
         wave_lds_sync();
         float s0 = ts_rowread<float>(Tw, half, l31);
-        float s1 = ts_rowread<float>(Tw + 32 * 36, half, l31);
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Tw[ts_row32(r, half) * 36 + l31] = su[r];
+        wave_lds_sync();
+        float s1 = ts_rowread<float>(Tw, half, l31);
         wave_lds_sync();
         s0 += __shfl_xor(s0, 32, 64);
         s1 += __shfl_xor(s1, 32, 64);
@@ -457,6 +486,10 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
       a.part[(prow + br.c0 + tid) * 2 + 1] = v1;
     }
   }
+#ifdef DSGCN_LAB
+  TSC_STAMP();
+  if (!AUG && (int)blockIdx.x == g_tsc_block && threadIdx.x == 0) g_tsc_stamp[15] = nst;
+#endif
   // the table rows of this block hold nothing for the pooling / pass-through channels: the first window's block zeroes them
   float* tab = FWD ? (AUG ? nullptr : a.stats) : a.part;
   if (tab && first) {
@@ -800,29 +833,49 @@ __global__ __launch_bounds__(64) void k_tsp_prep(const float* __restrict__ gf, c
 // ---------------------------------------------------------------------------------------------------------------
 __host__ __device__ inline int tsw_ls(int w) { return ((w + 1) & ~3) + 2; }      // >= w, = 2 mod 4
 
+#ifdef DSGCN_LAB
+// wall-clock stamps (10 ns) of workgroup (0, 0), thread 0 of k_tspw: start, LDS cleared, then per unit (committed + barrier,
+// next unit requested, products + barrier), partial rows written; [63] = count (dsgcn_tms_split_phases)
+__device__ long long g_tsw_stamp[64];
+#define TSW_STAMP() do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && nst < 62) g_tsw_stamp[nst++] = wall_clock64(); } while (0)
+#else
+#define TSW_STAMP() do {} while (0)
+#endif
+
 template <int CH>
 __global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
   constexpr int KT = 3;
   constexpr int JD = CH == 32 ? 4 : 7, JX = CH == 32 ? 10 : 20;     // float4 staging slots per thread (V <= 25)
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef DSGCN_LAB
+  int nst = 0;
+#endif
+  TSW_STAMP();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const TSBranch& br = ts_conv_window(a, blockIdx.y);
+  // the block's windows: group blockIdx.y = `gcnt` consecutive conv windows (channel-contiguous, together <= CH channels:
+  // DS-STGCN's 64-channel layers have windows of 14 + 10 and 10 + 10).  One (co x ci) tile carries them all — its
+  // off-diagonal blocks are never read — with the tap shift a per-LANE quantity (the lane's ci row knows its window);
+  // per-block cost (staging, barriers, the LDS round trips) is then paid once for the group.
+  const int gw0 = a.gfirst[blockIdx.y], gcnt = a.gcount[blockIdx.y];
+  const TSBranch& br = ts_conv_window(a, gw0);
   const int V = a.V, T = a.T, L = T * V, C = a.C;
-  const int bc = br.bc;
+  int bc = 0, ldil = br.dil;                       // channels of the group; dilation of the window holding row l31
+  for (int w = 0; w < gcnt; ++w) {
+    const TSBranch& bw = ts_conv_window(a, gw0 + w);
+    if (l31 >= bc) ldil = bw.dil;
+    bc += bw.bc;
+  }
   const int GM = TS_R * V, XM = (TS_R + 2 * TS_H) * V;              // V-column part of a row (floats; multiples of 4)
   const int GS4 = GM >> 2, XS4 = XM >> 2, SEG4 = (TS_H * V) >> 2;   // float4 per row; float4 per 4-frame segment
   const int LSd = tsw_ls(GM + TS_R), LSx = tsw_ls(XM + TS_R + 2 * TS_H);
   float* Ds = lds;                                                   // [CH][LSd]
   float* Xs = lds + CH * LSd;                                        // [CH][LSx]
   f32x2s* SB = reinterpret_cast<f32x2s*>(Xs + CH * LSx);             // [CH] (scale, shift)
-  for (int i = tid; i < CH * (LSd + LSx); i += TS_NT) lds[i] = 0.f;  // rows >= bc and the pad columns stay zero
-  if (tid < CH) {
-    const int c = br.c0 + tid;
-    SB[tid] = tid < bc ? f32x2s{a.scale ? a.scale[c] : 1.f, a.shift ? a.shift[c] : 0.f} : f32x2s{0.f, 0.f};
-  }
-  const bool relu = br.c0 < a.n_act;
+  const f32x2s sb0 = (tid < CH && tid < bc) ? f32x2s{a.scale ? a.scale[br.c0 + tid] : 1.f, a.shift ? a.shift[br.c0 + tid] : 0.f}
+                                            : f32x2s{0.f, 0.f};
+  const int rel0 = br.c0;                          // ReLU on channels < n_act (per row: a group may straddle)
 
   const int units = a.n * (T / TS_R);
   const int per = (units + a.splits - 1) / a.splits;
@@ -875,10 +928,10 @@ __global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
     xa = ts_load4(rza, oka ? ((n * C + br.c0 + arow) * T + t0 + (aseg - 1) * TS_H) * 4 : TS_OOB, 0);
   };
   const bool noact = a.exp & 128;
-  auto act = [&](float x, f32x2s sb) -> float {
+  auto act = [&](float x, f32x2s sb, bool rl) -> float {
     if (noact) return x;
     const float y = fmaf(x, sb.x, sb.y);
-    return relu ? fmaxf(y, 0.f) : y;
+    return rl ? fmaxf(y, 0.f) : y;
   };
   auto commit = [&]() {
 #pragma unroll
@@ -894,10 +947,12 @@ __global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
     for (int j = 0; j < JX; ++j) {
       if (lX[j] & (1 << 28)) {
         const bool ok = (((lX[j] >> 20) & 3) & inval) == 0;
-        const f32x2s sb = SB[(lX[j] >> 22) & 63];
+        const int row = (lX[j] >> 22) & 63;
+        const f32x2s sb = SB[row];
+        const bool rl = rel0 + row < a.n_act;
         f32x2s* d = reinterpret_cast<f32x2s*>(Xs + (lX[j] & 0xfffff));
-        d[0] = ok ? f32x2s{act(xr[j].x, sb), act(xr[j].y, sb)} : f32x2s{0.f, 0.f};
-        d[1] = ok ? f32x2s{act(xr[j].z, sb), act(xr[j].w, sb)} : f32x2s{0.f, 0.f};
+        d[0] = ok ? f32x2s{act(xr[j].x, sb, rl), act(xr[j].y, sb, rl)} : f32x2s{0.f, 0.f};
+        d[1] = ok ? f32x2s{act(xr[j].z, sb, rl), act(xr[j].w, sb, rl)} : f32x2s{0.f, 0.f};
       }
     }
     if (aokD) {
@@ -909,9 +964,10 @@ __global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
     if (aokX) {
       const bool ok = (aneed & inval) == 0;
       const f32x2s sb = SB[arow];
+      const bool rl = rel0 + arow < a.n_act;
       f32x2s* d = reinterpret_cast<f32x2s*>(Xs + arow * LSx + XM + aseg * TS_H);
-      d[0] = ok ? f32x2s{act(xa.x, sb), act(xa.y, sb)} : f32x2s{0.f, 0.f};
-      d[1] = ok ? f32x2s{act(xa.z, sb), act(xa.w, sb)} : f32x2s{0.f, 0.f};
+      d[0] = ok ? f32x2s{act(xa.x, sb, rl), act(xa.y, sb, rl)} : f32x2s{0.f, 0.f};
+      d[1] = ok ? f32x2s{act(xa.z, sb, rl), act(xa.w, sb, rl)} : f32x2s{0.f, 0.f};
     }
   };
 
@@ -925,8 +981,8 @@ __global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
   const int mt = CH == 64 ? (wave >> 1) : 0, nt = CH == 64 ? (wave & 1) : 0;
   const int g0 = CH == 32 ? (GS4 * wave) / 4 : 0, g1 = CH == 32 ? (GS4 * (wave + 1)) / 4 : GS4;
   const bool augw = CH == 64 || wave == 0;
-  const int sh = br.dil * V;
-  const bool oddsh = (sh & 1) && !(a.exp & 512);
+  const int sh = ldil * V;
+  const bool oddsh = gcnt > 1 || ((sh & 1) && !(a.exp & 512));   // per-lane shifts: the 4-byte form takes any parity
   const float* Ap = Ds + (32 * mt + l31) * LSd + 2 * half;
   const float* Bp = Xs + (32 * nt + l31) * LSx + TS_H * V + 2 * half;
   const float* Aq = Ds + (32 * mt + l31) * LSd + GM + 2 * half;
@@ -940,13 +996,21 @@ __global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
     acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b2.y, acc[2], 0, 0, 0);
   };
 
-  __syncthreads();                                  // zero fill done
-  if (u0 < u1) issue(u0);
+  if (u0 < u1) issue(u0);                           // the first unit travels while the tile is cleared
+  {
+    f32x4* l4 = reinterpret_cast<f32x4*>(lds);      // rows >= bc and the pad columns stay zero (CH * (LSd + LSx) is a multiple of 4)
+    for (int i = tid; i < (CH * (LSd + LSx)) >> 2; i += TS_NT) l4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < CH) SB[tid] = sb0;
+  }
+  __syncthreads();
+  TSW_STAMP();
   for (int u = u0; u < u1; ++u) {
     commit();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    TSW_STAMP();
     if (u + 1 < u1) issue(u + 1);
+    TSW_STAMP();
     if (oddsh) {
 #pragma unroll 2
       for (int g = g0; g < g1; ++g) {
@@ -969,16 +1033,15 @@ __global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
     if (augw) {
       const f32x2s av = *reinterpret_cast<const f32x2s*>(Aq);
       const f32x2s b1 = *reinterpret_cast<const f32x2s*>(Bq);
-      const f32x2s b0 = {Bq[-br.dil], Bq[1 - br.dil]};
-      const f32x2s b2 = {Bq[br.dil], Bq[1 + br.dil]};
+      const f32x2s b0 = {Bq[-ldil], Bq[1 - ldil]};
+      const f32x2s b2 = {Bq[ldil], Bq[1 + ldil]};
       mm(av, b0, b1, b2);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                   // raw barrier: the next unit's loads stay in flight
+    TSW_STAMP();
   }
 
-  float* dw = br.dwp + (size_t)blockIdx.x * a.pstride;
-  float* db = br.dbp + (size_t)blockIdx.x * a.pstride;
   if (CH == 32) {
     float* Rs = lds;                                 // [wave][tap][co][33]
 #pragma unroll
@@ -986,15 +1049,22 @@ __global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) Rs[((wave * KT + k) * 32 + ts_row32(r, half)) * 33 + l31] = acc[k][r];
     __syncthreads();
-    for (int o = tid; o < KT * bc * bc; o += TS_NT) {
-      const int co = o / (bc * KT), r2 = o - co * bc * KT, ci = r2 / KT, k = r2 - ci * KT;
-      float v = 0.f;
+    for (int w = 0, r0 = 0; w < gcnt; ++w) {         // the diagonal block of every window of the group
+      const TSBranch& bw = ts_conv_window(a, gw0 + w);
+      const int wb = bw.bc;
+      float* dw = bw.dwp + (size_t)blockIdx.x * a.pstride;
+      for (int o = tid; o < KT * wb * wb; o += TS_NT) {
+        const int co = o / (wb * KT), r2 = o - co * wb * KT, ci = r2 / KT, k = r2 - ci * KT;
+        float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) v += Rs[((w * KT + k) * 32 + co) * 33 + ci];
-      dw[o] = v;                                     // (co*bc + ci)*KT + tap
+        for (int wv = 0; wv < 4; ++wv) v += Rs[((wv * KT + k) * 32 + r0 + co) * 33 + r0 + ci];
+        dw[o] = v;                                   // (co*bc + ci)*KT + tap
+      }
+      r0 += wb;
     }
     __syncthreads();
   } else {
+    float* dw = br.dwp + (size_t)blockIdx.x * a.pstride;      // (CH = 64: one window per group)
     const int ci = 32 * nt + l31;
     if (ci < bc) {
 #pragma unroll
@@ -1020,8 +1090,17 @@ __global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
   if (tid < bc) {
     float v = 0.f;
     for (int c = 0; c <= GS4; ++c) v += Bs[tid * (GS4 + 2) + c];
-    db[tid] = v;
+    int r0 = 0;
+    for (int w = 0; w < gcnt; ++w) {
+      const TSBranch& bw = ts_conv_window(a, gw0 + w);
+      if (tid >= r0 && tid < r0 + bw.bc) bw.dbp[(size_t)blockIdx.x * a.pstride + tid - r0] = v;
+      r0 += bw.bc;
+    }
   }
+#ifdef DSGCN_LAB
+  TSW_STAMP();
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_tsw_stamp[63] = nst;
+#endif
 }
 
 int g_ts_exp = 0;                                 // lab builds: dsgcn_tms_split_tuning
@@ -1066,6 +1145,22 @@ int ts_fill(TSArgs& a, int n, int C, int T, int V, int stride, int KT, int nbr, 
   if (n > 32768) return 0;
   a.nconv = nconv;
   a.eplanes = eplanes;
+  // weight-gradient groups: consecutive conv windows (channel-contiguous, the same ReLU flag) that fit one 32 x 32 tile
+  a.ngroups = 0;
+  for (int i = 0, k = 0, prev = -2, gsum = 0; i < nbr; ++i) {
+    if (a.br[i].type != 0) continue;
+    if (a.ngroups > 0 && prev == i - 1 && wmax <= 32 && gsum + a.br[i].bc <= 32) {
+      ++a.gcount[a.ngroups - 1];
+      gsum += a.br[i].bc;
+    } else {
+      a.gfirst[a.ngroups] = k;
+      a.gcount[a.ngroups] = 1;
+      ++a.ngroups;
+      gsum = a.br[i].bc;
+    }
+    prev = i;
+    ++k;
+  }
   const int WT = (int)(((long)n * L + 127) / 128);
   a.ngrp = (WT + 3) / 4;
   a.ngrpa = (int)(((long)n * T + 511) / 512);
@@ -1080,7 +1175,7 @@ size_t ts_lds_main(TSArgs& a, int MT, bool fwd) {
   for (int i = 0; i < a.nbr; ++i)
     if (a.br[i].type == 0) cpmax = std::max(cpmax, (std::min(64, a.br[i].bc) + 7) & ~7);
   const size_t wsf = (size_t)64 * (3 * cpmax + 1) + 64;
-  const size_t epf = (size_t)4 * 2 * 32 * 36 + (size_t)4 * MT * 32 * 2 * 2;      // transposes + [4][MT*32][2] doubles
+  const size_t epf = (size_t)4 * 32 * 36 + (size_t)4 * MT * 32 * 2 * 2;          // transposes + [4][MT*32][2] doubles
   const size_t convf = (std::max(wsf, epf) + 3) & ~(size_t)3;
   a.sboff = (int)convf;
   const size_t planef = (size_t)4 * ((fwd ? 1 : 2) * a.T * a.V + 2 * ((a.T + 3) & ~3) + 32);
@@ -1113,12 +1208,19 @@ int ts_launch_main(TSArgs& a, int MT, hipStream_t st) {
 extern "C" {
 
 #ifdef DSGCN_LAB
-// timing experiments (include/dsgcn_lab.h): key 0 = bit mask of parts of k_tsp to skip (1 plane blocks, 2 epilogue
-// statistics, 4 the affine + ReLU of the forward operand, 8 conv blocks); results are WRONG with any bit set
+// timing experiments (include/dsgcn_lab.h): key 0 = bit mask of parts to skip (k_tsp: 1 plane blocks, 2 epilogue statistics,
+// 4 the affine + ReLU of the forward operand, 8 V-column conv blocks, 16 odd-shift loads read as even; k_tspw: 128 the
+// affine + ReLU, 256 the global-joint column, 512 odd shifts read as even); results are WRONG with any bit set; key 1 = the
+// conv block whose phases are stamped
 int dsgcn_tms_split_tuning(int key, int value) {
+  if (key == 1) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tsc_block), &value, sizeof(int));
   if (key != 0) return DSGCN_EINVAL;
   g_ts_exp = value;
   return 0;
+}
+int dsgcn_tms_split_phases(int which, long long* out) {
+  if (which == 1) return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tsc_stamp), sizeof(long long) * 16);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tsw_stamp), sizeof(long long) * 64);
 }
 #endif
 
@@ -1136,14 +1238,14 @@ int dsgcn_tms_split_rows(int which, int n, int C, int T, int V, int stride, int 
   if (which == 1) return a.ngrp + n + a.ngrpa;
   if (which == 2) {
     const int units = n * (T / TS_R);
-    int splits = (mt == 1 ? 512 : 256) / a.nconv;
+    int splits = (mt == 1 ? 512 : 256) / a.ngroups;
     if (splits < 1) splits = 1;
     return std::min(splits, units);
   }
   return 0;
 }
 
-// f (n,C,T,V), oaug (n,C,T) + ONE extra float (the epilogue reads frame pairs), stats (rows(0), C, 2) or NULL.
+// f (n,C,T,V), oaug (n,C,T), stats (rows(0), C, 2) or NULL.
 int dsgcn_tms_split_fwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
                         const float* coeff, float* f, float* oaug, float* stats, int n, int C, int T, int V, int nbr,
                         const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
@@ -1218,7 +1320,7 @@ int dsgcn_tms_split_wgrad(const float* z, const float* zaug, const float* scale,
   const size_t tile = (size_t)ch * (tsw_ls(TS_R * (V + 1)) + tsw_ls((TS_R + 2 * TS_H) * (V + 1))) + 2 * ch;
   const size_t red = (size_t)4 * 3 * 32 * 33;
   const size_t lds = std::max(tile, ch == 32 ? red : (size_t)0) * sizeof(float);
-  const dim3 grid((unsigned)splits, (unsigned)a.nconv);
+  const dim3 grid((unsigned)splits, (unsigned)a.ngroups);
   if (ch == 32) {
     static size_t have = 64 * 1024;
     const int rc = ts_raise_lds(k_tspw<32>, lds, &have);

@@ -1095,7 +1095,7 @@ class _TemporalSplit(torch.autograd.Function):
         rows = lib.dsgcn_tms_split_rows(0, n, C, T, V, 1, 3, nbr, *tabs)
         assert rows > 0
         f = torch.empty((n, C, T, V), device=dev, dtype=torch.float32)
-        oaug = torch.empty(n * C * T + 4, device=dev, dtype=torch.float32)     # + the spare float the frame pairs need
+        oaug = torch.empty((n, C, T), device=dev, dtype=torch.float32)
         stats = torch.empty((rows, C, 2), device=dev, dtype=torch.float32) if want_bn else None
         rc = lib.dsgcn_tms_split_fwd(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), int(n_act), _ptr(coeff), _ptr(f),
                                      _ptr(oaug), _ptr(stats), n, C, T, V, nbr, *tabs, _ptr_array(ws), _ptr_array(bs),

@@ -322,19 +322,20 @@ int dsgcn_tms_wgrad(const float* z, const float* zaug, const float* scale, const
                     const int* dil, float* const* dwp, float* const* dbp, int pstride, void* stream);
 
 /* K-D, split layout (csrc/tmsplit.hip): the same stage as dsgcn_tms_* for dgmstcn units with the global joint
- * (reference: pyskl/models/gcns/utils/tcn.py:379-428), kernel 3, stride 1, V odd (5..25), T % 4 == 0, windows <= 64
- * channels tiling [0, C) in order, dilation <= 4.  The (V+1)-column intermediates of tcn.py:409-420 are never formed: the
- * V columns run through the matrix-core window kernels on the (n,C,T,V) layout (BatchNorm affine + ReLU while loading z;
- * f = o + oaug*coeff, its batch statistics, resp. dz = relu'(.)*dh*scale and the BatchNorm backward sums in the epilogue),
- * the global-joint column through two small launches on (n,C,T) tensors.
+ * (reference: pyskl/models/gcns/utils/tcn.py:379-428), kernel 3, stride 1, V odd (5..25), T % 4 == 0, T*V <= 2048, windows
+ * <= 64 channels tiling [0, C) in order, dilation <= 4.  The (V+1)-column intermediates of tcn.py:409-420 are never formed:
+ * the V columns run through the matrix-core window kernels on the (n,C,T,V) layout (BatchNorm affine + ReLU + the
+ * global-joint term haug*coeff while loading z — the windows are linear, so o + oaug*coeff = conv(h + haug*coeff) +
+ * bias*(1 + coeff) —, the batch statistics of f, resp. dz = relu'(.)*dh*scale and the BatchNorm backward sums, in the
+ * epilogue), the global-joint column as extra blocks of the same launches on (n,C,T) tensors.
  *   dsgcn_tms_split_rows(which): -1 -> 1 / 0 eligible;  0 -> rows of stats;  1 -> rows of part;  2 -> K-splits of the
  *     weight gradient;  0 whenever the shape is not eligible (the staged kernels then apply).
- *   fwd  : f (n,C,T,V);  oaug (n,C,T) followed by ONE spare float (frame pairs are read);  stats (rows(0), C, 2) partial
- *          sums of f, f^2 (dsgcn_bn_finalize, count n*T*V) or NULL.
+ *   fwd  : f (n,C,T,V);  oaug (n,C,T) = the windows' output on the global-joint column (kept for prep);  stats
+ *          (rows(0), C, 2) partial sums of f, f^2 (dsgcn_bn_finalize, count n*T*V) or NULL.  One launch.
  *   prep : ge = gf + A0 + B0*f (gf NULL = 0; A0/B0 NULL = no BatchNorm terms), doaug (n,C,T) = sum_v ge*coeff,
  *          pcoef (n*C, V) = sum_t ge[t,v]*oaug[t] (dsgcn_colsum finishes d coeff).
  *   dgrad: dz (n,C,T,V), dzaug (n,C,T), part (rows(1), C, 2) = [sum dpre*x, sum dpre] over z AND zaug (the sums
- *          dsgcn_bn_coef_rows takes).
+ *          dsgcn_bn_coef_rows takes).  One launch.
  *   wgrad: window i writes split s < rows(2) of its weight / bias partials at dwp[i] + s*pstride / dbp[i] + s*pstride. */
 int dsgcn_tms_split_rows(int which, int n, int C, int T, int V, int stride, int KT, int nbr, const int* type,
                          const int* c0, const int* bc, const int* dil);

@@ -52,8 +52,14 @@ int dsgcn_tcw_phases(long long* out);
 /* dense temporal conv (k_tcg): key 0 = stride-1 staging with 16-byte loads on (1, default) / off (0: the 4-byte form) */
 int dsgcn_tconv_tuning(int key, int value);
 /* split-layout temporal stage (k_tsp): key 0 = bit mask of parts to SKIP for timing (1 plane blocks, 2 epilogue statistics,
- * 4 the affine + ReLU of the forward operand, 8 conv blocks); results are wrong with any bit set */
+ * 4 the affine + ReLU of the forward operand, 8 conv blocks, ...; results are wrong with any bit set); key 1 = the conv
+ * block whose phases are stamped */
 int dsgcn_tms_split_tuning(int key, int value);
+/* which 0: weight gradient (k_tspw), stamps of workgroup (0, 0): start, then per unit (committed + barrier, next unit
+ * requested, products + barrier), partial rows written; out[63] = count (64 values).
+ * which 1: one V-column conv block of the LAST k_tsp launch: start, requests issued, staging barrier, staged, main loop done,
+ * epilogue done; out[15] = count (16 values). */
+int dsgcn_tms_split_phases(int which, long long* out);
 
 #ifdef __cplusplus
 }

@@ -85,5 +85,30 @@ for C, T in ((64, 64), (128, 32), (256, 16)):
     r0, f0, b0 = run(d, False, True)
     r1, f1, b1 = run(d, True, True)
     worst = max((rel(r1[k], r0[k]), k) for k in r0)
+    if os.environ.get('TS_PHASES'):
+        import numpy as np
+        ph = np.zeros(64, dtype=np.int64)
+        assert native._lib.dsgcn_tms_split_phases(0, ph.ctypes.data) == 0
+        k = int(ph[63])
+        d_ = np.diff(ph[:k]) * 10e-3
+        print(f'  k_tspw stamps (us): start->cleared {d_[0]:.2f}; per unit [commit+barrier, issue, products+barrier]: ' +
+              ' '.join(f'[{d_[i]:.2f} {d_[i + 1]:.2f} {d_[i + 2]:.2f}]' for i in range(1, k - 2, 3)) + f'; tail {d_[k - 2]:.2f}')
+    if os.environ.get('TS_CONV_BLOCK'):
+        import numpy as np
+        for blk in [int(x) for x in os.environ['TS_CONV_BLOCK'].split(',')]:
+            assert native._lib.dsgcn_tms_split_tuning(1, blk) == 0
+            for split_dir in ('fwd', 'bwd'):
+                r_, _, _ = run(d, True, False)      # fwd then bwd launch: the stamps are of the LAST k_tsp launch = backward
+                ph = np.zeros(16, dtype=np.int64)
+                if split_dir == 'fwd':
+                    K.SPLIT_TEMPORAL = '1'; K.FUSED_TEMPORAL = '0'
+                    with torch.no_grad():
+                        K.temporal_ms(d['z'], d['zaug'], d['scale'], d['shift'], d['n_act'], cfg, d['widths'], d['cw'], d['cb'],
+                                      d['coeff'], 1, d['gamma'], d['beta'], 1e-5, True)
+                torch.cuda.synchronize()
+                assert native._lib.dsgcn_tms_split_phases(1, ph.ctypes.data) == 0
+                k = int(ph[15])
+                print(f'  k_tsp {split_dir} conv block {blk} (us): ' + ' '.join(f'{x:.2f}' for x in np.diff(ph[:k]) * 10e-3) +
+                      f'  total {(ph[k - 1] - ph[0]) * 10e-3:.2f}')
     print(f'C={C:3d} T={T:2d} eligible={ok}  staged fwd {f0:7.1f} bwd {b0:7.1f} us   split fwd {f1:7.1f} bwd {b1:7.1f} us   '
           f'max rel diff {worst[0]:.2e} ({worst[1]})', flush=True)
