@@ -53,6 +53,7 @@ struct TSArgs {
   const float* ge; const float* doaug;            // backward inputs
   float* dz; float* dzaug; float* part;           // backward outputs ((rows,C,2): sum dpre*x, sum dpre)
   int n_act, n, C, T, V, nbr, ngrp, ngrpa, nconv, eplanes, sboff, haw, splits, pstride;
+  int cw[TS_MAXBR];    // table index of conv window w
   int ngroups, gfirst[TS_MAXBR], gcount[TS_MAXBR];   // weight gradient: consecutive conv windows sharing one (co x ci) tile
   int exp;             // lab builds only: timing experiments that skip parts of the work (0 in the product)
   TSBranch br[TS_MAXBR];
@@ -77,12 +78,7 @@ __device__ __forceinline__ int ts_rowoff(bool ok, int base, int rowoff) {
 }
 __device__ __forceinline__ int ts_cp(int bc) { return (min(64, max(bc, 1)) + 7) & ~7; }
 
-__device__ __forceinline__ const TSBranch& ts_conv_window(const TSArgs& a, int w) {
-  int bi = 0;
-  for (int i = 0, k = 0; i < a.nbr; ++i)
-    if (a.br[i].type == 0) { if (k == w) bi = i; ++k; }
-  return a.br[bi];
-}
+__device__ __forceinline__ const TSBranch& ts_conv_window(const TSArgs& a, int w) { return a.br[a.cw[w]]; }
 
 // Sum of half of row l31 of a wave's [32][36] LDS tile (lane (half, l31); the caller adds the two halves).
 template <typename ACC>
@@ -223,7 +219,8 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
     }
     // haug: haw is a power of two (32 at V >= 23), thread = (frame tid % haw, channels tid / haw + k * 256 / haw): the
     // frame, hence the sample and the address arithmetic, is fixed per thread
-    const int he = tid & (HAW - 1), hc0 = tid / HAW, hcs = TS_NT / HAW;
+    const int hsh = 31 - __builtin_clz(HAW);
+    const int he = tid & (HAW - 1), hc0 = tid >> hsh, hcs = TS_NT >> hsh;
     const int hG = Gs + he, hn = hG / T, ht = hG - hn * T;
     const bool hok = hG >= 0 && hn < a.n;
     const float* hsrc = a.zaug + ((size_t)(hok ? hn : 0) * C + br.c0) * T + (hok ? ht : 0);
@@ -235,7 +232,17 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
       }
     }
     TSC_STAMP();
-    for (int i = tid; i < 64 * S + 64; i += TS_NT) Ws[i] = 0.f;
+    {
+      f32x4* w4 = reinterpret_cast<f32x4*>(Ws);     // 64 * S + 64 floats: a multiple of 4 (S odd, 64 * S = 0 mod 4)
+      for (int i = tid; i < (64 * S + 64) >> 2; i += TS_NT) w4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float invrun = 1.f / (float)run;
+    auto wat = [&](int i) -> int {                 // (co*bc + ci)*3 + tap -> co*S + tap*CP + ci  (i < 2^22: exact)
+      int co, r;
+      divmod_small(i, run, invrun, co, r);
+      const int ci = (r * 43691) >> 17, tap = r - ci * KT;
+      return co * S + tap * CP + ci;
+    };
     if (tid < 64) {
       SB[tid] = sb;
       BI[tid] = bi;
@@ -245,10 +252,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int i = tid + q * TS_NT;
-      if (i < wtotal) {
-        const int co = i / run, r = i - co * run, ci = r / KT, tap = r - ci * KT;
-        Ws[co * S + tap * CP + ci] = wv[q];
-      }
+      if (i < wtotal) Ws[wat(i)] = wv[q];
     }
     if constexpr (FOLD) {
       auto put = [&](int ci, float x) {
@@ -274,10 +278,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int i = i0 + tid + q * TS_NT;
-        if (i < wtotal) {
-          const int co = i / run, r = i - co * run, ci = r / KT, tap = r - ci * KT;
-          Ws[co * S + tap * CP + ci] = wv[q];
-        }
+        if (i < wtotal) Ws[wat(i)] = wv[q];
       }
     }
     __syncthreads();
@@ -383,16 +384,18 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
         }
       }
       if (stats) {
+        // (sums of a wave's 128 values of one row in fp32: 1e-7-class; everything across waves / blocks is fp64)
         wave_lds_sync();
-        double sd = ts_rowread<double>(Tw, half, l31);
+        float sf = ts_rowread<float>(Tw, half, l31);
         wave_lds_sync();
 #pragma unroll
         for (int r = 0; r < 16; ++r) Tw[ts_row32(r, half) * 36 + l31] = sq[r];
         wave_lds_sync();
-        double qd = ts_rowread<double>(Tw, half, l31);
+        float qf = ts_rowread<float>(Tw, half, l31);
         wave_lds_sync();
-        sd += __shfl_xor(sd, 32, 64);
-        qd += __shfl_xor(qd, 32, 64);
+        sf += __shfl_xor(sf, 32, 64);
+        qf += __shfl_xor(qf, 32, 64);
+        const double sd = (double)sf, qd = (double)qf;
         if (half == 0) {
           Ss[((wave * MT + m) * 32 + l31) * 2 + 0] = sd;
           Ss[((wave * MT + m) * 32 + l31) * 2 + 1] = qd;
@@ -1129,6 +1132,7 @@ int ts_fill(TSArgs& a, int n, int C, int T, int V, int stride, int KT, int nbr, 
     if (b.bc <= 0 || b.c0 != next) return b.bc <= 0 ? DSGCN_EINVAL : 0;     // windows tile the channels in order
     next += b.bc;
     if (b.type == 0) {
+      a.cw[nconv] = i;
       ++nconv;
       wmax = std::max(wmax, b.bc);
       if (b.dil < 1 || b.dil > TS_H) return 0;

@@ -25,7 +25,7 @@ while i < len(args):
 variants = variants or ['']
 lab = native.lab_lib()
 native._lib = lab                                   # the package now launches through the lab build (same kernels + knobs)
-DEFAULTS = {14: 2, 15: 1, 16: 256, 17: 128}
+DEFAULTS = {14: 2, 15: 3, 16: 256, 17: 128}
 
 
 def set_keys(variant):
