@@ -389,7 +389,10 @@ def test_fuse_out(n, C, T, V, mode, tmean, flags):
                                             # wide-load kernels at 2 MFMA row tiles / 64-channel weight-gradient tiles, both strides
                                             (2, 256, 16, 25, 1), (2, 256, 16, 25, 2),
                                             # frame counts the weight gradient's 4-frame units do not divide (mixed paths)
-                                            (2, 64, 10, 25, 1), (2, 64, 12, 25, 2), (3, 64, 6, 17, 1)])
+                                            (2, 64, 10, 25, 1), (2, 64, 12, 25, 2), (3, 64, 6, 17, 1),
+                                            # split layout (csrc/tmsplit.hip): a single 4-frame unit (every halo outside the plane), the
+                                            # smallest joint count (128 frames of haug per block), K400's stride-1 planes
+                                            (1, 64, 4, 25, 1), (2, 36, 8, 5, 1), (2, 64, 100, 17, 1)])
 @pytest.mark.parametrize('fused', ['1', '0', 'split'])
 def test_temporal_ms(n, C, T, V, stride, fused, monkeypatch):
     """fused '1': the one-launch-per-direction stage (csrc/tms.hip) wherever the shape is eligible; '0': the staged chain
