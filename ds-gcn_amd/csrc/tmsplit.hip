@@ -52,7 +52,7 @@ struct TSArgs {
   float* f; float* oaug; float* stats;            // forward outputs ((n,C,T,V), (n,C,T)+1 float, (rows,C,2))
   const float* ge; const float* doaug;            // backward inputs
   float* dz; float* dzaug; float* part;           // backward outputs ((rows,C,2): sum dpre*x, sum dpre)
-  int n_act, n, C, T, V, nbr, ngrp, ngrpa, nconv, eplanes, sboff, haw, splits, pstride;
+  int n_act, n, C, T, Tout, V, nbr, ngrp, ngrpa, nconv, eplanes, sboff, haw, splits, pstride;   // T: input frames; Tout = T / stride
   int cw[TS_MAXBR];    // table index of conv window w
   int ngroups, gfirst[TS_MAXBR], gcount[TS_MAXBR];   // weight gradient: consecutive conv windows sharing one (co x ci) tile
   int exp;             // lab builds only: timing experiments that skip parts of the work (0 in the product)
@@ -119,17 +119,33 @@ __device__ int g_tsc_block = 0;
 #define TSC_STAMP() do {} while (0)
 #endif
 
-template <bool FWD, int MT, bool ODD, bool AUG>
+// S2: the stage at stride 2 (T' = T / 2 output frames; forward tiles / stores run over the OUTPUT planes and read input
+// frame 2t' + (tap-1)*dil, the data gradient tiles the INPUT planes and reads output frame (t - (tap-1)*dil) / 2 where that is
+// whole).  A lane's four consecutive positions lie in at most two frames (nx marks the second):
+//   forward, V columns: per tap two 16-byte loads — LA at the first frame's source row, LB one source frame pair further —
+//     element k comes from LB where nx[k], LA otherwise (buffer loads are range-checked per dword: a run past the tensor's
+//     end reads zeros for the dwords outside, tools/lab/oob_check.hip; a run that STARTS before the tensor does not, so
+//     sources are never addressed below their first element);
+//   data gradient, V columns: consecutive frames have opposite parity, so per tap only the lane's first-frame elements OR
+//     its second-frame elements have a source: ONE 16-byte load, the others masked (ge / doaug carry a front pad of 32
+//     floats so that the second-frame run of a plane's first row may start before the plane);
+//   the one-column part (V = 1: four consecutive frames): four 4-byte loads per tap.
+template <bool FWD, int MT, bool ODD, bool AUG, bool S2 = false>
 __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, bool first, float* lds, int grp, int lane, int wave) {
   constexpr int KT = 3, PDK = 2, NS = KT * PDK;
   constexpr bool FOLD = FWD && !AUG;               // the operand carries haug * coeff
+  constexpr int FP = 32;                           // front pad (floats) of the data gradient's sources at stride 2
+  static_assert(!(S2 && ODD), "stride 2 has its own load forms");
 #ifdef DSGCN_LAB
   int nst = 0;
 #endif
   TSC_STAMP();
   const int tid = threadIdx.x;
   const int half = lane >> 5, l31 = lane & 31;
-  const int V = AUG ? 1 : a.V, T = a.T, L = T * V, L4 = L * 4, C = a.C, bc = br.bc;
+  const int V = AUG ? 1 : a.V, C = a.C, bc = br.bc;
+  const int T = (S2 && FWD) ? a.Tout : a.T;        // frames of the tiled / destination planes
+  const int Ts = S2 ? (FWD ? a.T : a.Tout) : T;    // frames of the source planes
+  const int L = T * V, L4 = L * 4, Ls = Ts * V, Ls4 = Ls * 4;
   const int CP = ts_cp(bc), S = KT * CP + 1;
   float* Ws = lds;
   f32x2s* SB = reinterpret_cast<f32x2s*>(lds + a.sboff);   // [64] (scale, shift): zero past the window
@@ -146,58 +162,118 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
   while (p >= L) { p -= L; ++ds; }
   const bool pok = wlive && n0 + ds < a.n;
   const float* srcp = FWD ? (AUG ? a.zaug : a.z) : (AUG ? a.doaug : a.ge);
-  const __amdgpu_buffer_rsrc_t rs = ts_rsrc(srcp, (size_t)a.n * C * L4);
-  const int rowbase = ((n0 + ds) * C + br.c0 + half) * L;
-  // A side tap shifts by +-dil*V positions.  Even shift: two aligned 8-byte pairs, each wholly inside or outside the plane.
-  // Odd shift: the pairs are only 4-byte aligned and one of them can straddle a plane end — (-1, 0) is read as (0, 1) and
-  // (L-1, L) as (L-2, L-1), both wholly inside the tensor, and the wanted element moved over by a select.
-  const int sh = (FWD ? br.dil : -br.dil) * V;
-  int vP[KT][2];
-  float mk[KT][4];
-  bool fS[KT][2], fE[KT][2];
-#pragma unroll
-  for (int tap = 0; tap < KT; ++tap)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int q = p + (tap - 1) * sh + 2 * j;
-      const bool e0 = q >= 0 && q < L, e1 = q + 1 >= 0 && q + 1 < L;
-      const bool s = ODD && !e0 && e1, e = ODD && e0 && !e1;
-      const int qa = s ? q + 1 : (e ? q - 1 : q);
-      fS[tap][j] = s;
-      fE[tap][j] = e;
-      vP[tap][j] = (pok && (e0 || e1)) ? (rowbase + qa) * 4 : TS_OOB;
-      mk[tap][2 * j] = (pok && e0) ? 1.f : 0.f;
-      mk[tap][2 * j + 1] = (pok && e1) ? 1.f : 0.f;
-    }
-  auto load = [&](int tap, int ks) -> f32x4 {
-    const int soff = 2 * ks * L4;
-    if (tap == 1) return ts_load4(rs, vP[1][0], soff);
-    const f32x2s lo = ts_load2(rs, vP[tap][0], soff), hi = ts_load2(rs, vP[tap][1], soff);
-    return f32x4{lo.x, lo.y, hi.x, hi.y};
-  };
-
-  // V columns, forward: add_coeff of the lane's four joints (the run may cross into the next frame: nx) and the lane's
-  // frame inside the block's haug window
-  float cf[4] = {0.f, 0.f, 0.f, 0.f};
-  bool nx[4] = {false, false, false, false};
-  int gl = 0;
-  const int Gs = (grp * 512) / V - TS_H;           // first frame of the window, in frames counted over all samples
-  if constexpr (FOLD) {
-    int t0, v0;
+  const int spad = (S2 && !FWD) ? FP : 0;
+  const __amdgpu_buffer_rsrc_t rs = ts_rsrc(srcp - spad, ((size_t)a.n * C * Ls + spad) * 4);
+  const int rowbase = ((n0 + ds) * C + br.c0 + half) * Ls + spad;
+  int t0 = 0, v0 = 0;                              // frame / joint of the lane's first position
+  bool nx[4] = {false, false, false, false};       // element k lies in frame t0 + 1
+  if constexpr (FOLD || S2) {
     divmod_small(p, V, 1.f / (float)V, t0, v0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int vv = v0 + k;
-      nx[k] = vv >= V;
-      cf[k] = a.coeff[nx[k] ? vv - V : vv];
+    for (int k = 0; k < 4; ++k) nx[k] = v0 + k >= V;
+  }
+  // Stride 1.  A side tap shifts by +-dil*V positions.  Even shift: two aligned 8-byte pairs, each wholly inside or outside
+  // the plane.  Odd shift: the pairs are only 4-byte aligned and one of them can straddle a plane end — (-1, 0) is read as
+  // (0, 1) and (L-1, L) as (L-2, L-1), both wholly inside the tensor, and the wanted element moved over by a select.
+  const int sh = (FWD ? br.dil : -br.dil) * V;
+  int vP[KT][S2 ? 4 : 2];                          // S2: [0] = LA / the one load, [1] = LB; one-column part: four elements
+  float mk[KT][4];
+  bool fS[KT][2], fE[KT][2];
+  if constexpr (!S2) {
+#pragma unroll
+    for (int tap = 0; tap < KT; ++tap)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = p + (tap - 1) * sh + 2 * j;
+        const bool e0 = q >= 0 && q < L, e1 = q + 1 >= 0 && q + 1 < L;
+        const bool s = ODD && !e0 && e1, e = ODD && e0 && !e1;
+        const int qa = s ? q + 1 : (e ? q - 1 : q);
+        fS[tap][j] = s;
+        fE[tap][j] = e;
+        vP[tap][j] = (pok && (e0 || e1)) ? (rowbase + qa) * 4 : TS_OOB;
+        mk[tap][2 * j] = (pok && e0) ? 1.f : 0.f;
+        mk[tap][2 * j + 1] = (pok && e1) ? 1.f : 0.f;
+      }
+  } else {
+#pragma unroll
+    for (int tap = 0; tap < KT; ++tap) {
+      const int sft = (tap - 1) * br.dil;
+      fS[tap][0] = fS[tap][1] = fE[tap][0] = fE[tap][1] = false;
+      if constexpr (AUG) {
+        // four consecutive frames p + k of a T x 1 plane
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int src;
+          bool ok;
+          if (FWD) {
+            src = 2 * (p + k) + sft;
+            ok = src >= 0 && src < Ts;
+          } else {
+            const int num = p + k - sft;
+            src = num >> 1;
+            ok = num >= 0 && !(num & 1) && src < Ts;
+          }
+          ok = ok && pok;
+          vP[tap][k] = ok ? (rowbase + src) * 4 : TS_OOB;
+          mk[tap][k] = ok ? 1.f : 0.f;
+        }
+      } else if (FWD) {
+        const int fA = 2 * t0 + sft, fB = fA + 2;
+        const bool okA = pok && fA >= 0 && fA < Ts, okB = pok && fB >= 0 && fB < Ts;
+        vP[tap][0] = okA ? (rowbase + fA * V + v0) * 4 : TS_OOB;
+        vP[tap][1] = okB ? (rowbase + fA * V + v0 + V) * 4 : TS_OOB;       // element k of frame t0 + 1: (fA + 2)*V + v0 + k - V
+        vP[tap][2] = vP[tap][3] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mk[tap][k] = (nx[k] ? okB : okA) ? 1.f : 0.f;
+      } else {
+        const int numA = t0 - sft, numB = t0 + 1 - sft;
+        const bool useA = !(numA & 1);
+        const int num = useA ? numA : numB;
+        const int fs = num >> 1;
+        const bool ok = pok && num >= 0 && fs < Ts;
+        // first-frame elements: source index fs*V + v0 + k;  second-frame elements: fs*V + v0 + k - V
+        vP[tap][0] = ok ? (rowbase + fs * V + v0 - (useA ? 0 : V)) * 4 : TS_OOB;
+        vP[tap][1] = vP[tap][2] = vP[tap][3] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mk[tap][k] = (ok && (nx[k] != useA)) ? 1.f : 0.f;
+      }
     }
-    gl = pok ? (n0 + ds) * T + t0 - Gs : TS_H;
+  }
+  auto load = [&](int tap, int ks) -> f32x4 {
+    const int soff = 2 * ks * Ls4;
+    if constexpr (S2) {
+      if constexpr (AUG)
+        return f32x4{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vP[tap][0], soff, 0)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vP[tap][1], soff, 0)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vP[tap][2], soff, 0)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vP[tap][3], soff, 0))};
+      else
+        return ts_load4(rs, vP[tap][0], soff);
+    } else {
+      if (tap == 1) return ts_load4(rs, vP[1][0], soff);
+      const f32x2s lo = ts_load2(rs, vP[tap][0], soff), hi = ts_load2(rs, vP[tap][1], soff);
+      return f32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+  };
+  auto loadB = [&](int tap, int ks) -> f32x4 { return ts_load4(rs, vP[tap][1], 2 * ks * Ls4); };   // forward, stride 2, V columns
+  constexpr bool TWO = S2 && FWD && !AUG;
+
+  // V columns, forward: add_coeff of the lane's four joints and the lane's frame inside the block's haug window
+  float cf[4] = {0.f, 0.f, 0.f, 0.f};
+  int gl = 0;
+  // first frame of the window, in SOURCE frames counted over all samples (stride 2: source frame = 2 * output frame)
+  const int Gs = (S2 ? 2 : 1) * ((grp * 512) / V) - TS_H;
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cf[k] = a.coeff[nx[k] ? v0 + k - V : v0 + k];
+    gl = pok ? (S2 ? 2 : 1) * ((n0 + ds) * T + t0) - Gs : TS_H;
   }
   const int KS2 = ((bc + 3) >> 2) << 1;                      // k-steps of two channels, even (weights are zero past bc)
-  f32x4 buf[NS];
+  f32x4 buf[NS], bufB[TWO ? NS : 1];
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
     buf[u] = load(u % KT, u / KT);
+    if constexpr (TWO) bufB[u] = loadB(u % KT, u / KT);
     __builtin_amdgcn_sched_barrier(0);
   }
   // Staging (the operand prefetch above is already in flight: the block pays ONE memory round trip before its first
@@ -221,14 +297,14 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
     // frame, hence the sample and the address arithmetic, is fixed per thread
     const int hsh = 31 - __builtin_clz(HAW);
     const int he = tid & (HAW - 1), hc0 = tid >> hsh, hcs = TS_NT >> hsh;
-    const int hG = Gs + he, hn = hG / T, ht = hG - hn * T;
+    const int hG = Gs + he, hn = hG / Ts, ht = hG - hn * Ts;          // (source frames: Ts = T at stride 1)
     const bool hok = hG >= 0 && hn < a.n;
-    const float* hsrc = a.zaug + ((size_t)(hok ? hn : 0) * C + br.c0) * T + (hok ? ht : 0);
+    const float* hsrc = a.zaug + ((size_t)(hok ? hn : 0) * C + br.c0) * Ts + (hok ? ht : 0);
     if constexpr (FOLD) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int ci = hc0 + q * hcs;
-        hv[q] = (hok && ci < bc) ? hsrc[(size_t)ci * T] : 0.f;
+        hv[q] = (hok && ci < bc) ? hsrc[(size_t)ci * Ts] : 0.f;
       }
     }
     TSC_STAMP();
@@ -267,7 +343,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
         if (ci < 64) put(ci, hv[q]);
       }
       for (int ci = hc0 + 8 * hcs; ci < 64; ci += hcs)               // haw > 32 (V < 23): the rest of the channels
-        put(ci, (hok && ci < bc) ? hsrc[(size_t)ci * T] : 0.f);
+        put(ci, (hok && ci < bc) ? hsrc[(size_t)ci * Ts] : 0.f);
     }
     for (int i0 = 8 * TS_NT; i0 < wtotal; i0 += 8 * TS_NT) {     // windows wider than 26 channels: the rest of the tile
 #pragma unroll
@@ -298,7 +374,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
   // haug of channel 2ks+half at the lane's frame shifted by the tap, and the frame after it
   auto hfrag = [&](int tap, int ks) -> f32x2s {
     const float* hp = HA + (2 * ks + half) * HAW + gl + (tap - 1) * br.dil;
-    return f32x2s{hp[0], hp[1]};
+    return f32x2s{hp[0], hp[S2 ? 2 : 1]};          // (stride 2: the lane's second frame is two source frames on)
   };
   float avb[2][MT];
   f32x2s sbv[2], hab[2];
@@ -317,6 +393,10 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
       if (FWD) sbv[nxt] = SB[2 * (kn < 32 ? kn : 31) + half];
       if constexpr (FOLD) hab[nxt] = hfrag(tn, kn < 32 ? kn : 31);
       f32x4 b = buf[u];
+      if constexpr (TWO) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = nx[q] ? bufB[u][q] : b[q];
+      }
       if (tap != 1) {
         if (ODD) {
           const float x0 = b.x, y0 = b.y, x1 = b.z, y1 = b.w;
@@ -332,10 +412,10 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
           float v = fmaf(b[q], sbv[cur].x, sbv[cur].y);
           if (relu) v = fmaxf(v, 0.f);
           if constexpr (FOLD) v = fmaf(nx[q] ? hab[cur].y : hab[cur].x, cf[q], v);
-          if (tap != 1) v *= mk[tap][q];
+          if (S2 || tap != 1) v *= mk[tap][q];
           b[q] = v;
         }
-      } else if (ODD && tap != 1) {
+      } else if (S2 || (ODD && tap != 1)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) b[q] *= mk[tap][q];
       }
@@ -346,6 +426,7 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
         for (int q = 0; q < 4; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(avb[cur][m], b[q], acc[m][q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       buf[u] = load(tap, min(ks + PDK, KS2 - 1));
+      if constexpr (TWO) bufB[u] = loadB(tap, min(ks + PDK, KS2 - 1));
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -508,6 +589,156 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
 // then [T] act(zaug), [T] pooled column / doaug, [32] coeff.  Planes up to 8 float4 per lane (T*V <= 2048).
 constexpr int TS_PQ = 8;
 
+// Stride 2 (S2): the pooled / copied output has T / 2 frames — out[t'] = max(h[2t'-1], h[2t'], h[2t'+1]) resp. h[2t'].  The
+// planes are short (<= 2048 floats): both directions run one element per lane and step through LDS; lw: [Lin] z (forward:
+// h), [Lout] ge (backward), [Tin] act(zaug), [Tout] pooled column / doaug, [32] coeff.
+template <bool FWD>
+__device__ __forceinline__ void ts_elem2(const TSArgs& a, const TSBranch& br, float* lw, int n, int c, int lane) {
+  const int V = a.V, Ti = a.T, To = a.Tout, Li = Ti * V, Lo = To * V, C = a.C;
+  const int cc = br.c0 + c;
+  const size_t plane = (size_t)n * C + cc;
+  const bool relu = cc < a.n_act;
+  const bool pool = br.type == 1;
+  const float invV = 1.f / (float)V;
+  const int Tpi = (Ti + 3) & ~3, Tpo = (To + 3) & ~3;
+  float* hp = lw;                // forward: act(z); backward: raw z
+  float* gp = lw + Li;           // backward: ge plane
+  float* ha = gp + Lo;           // act(zaug)
+  float* oa = ha + Tpi;          // forward: pooled column; backward: doaug
+  float* cf = oa + Tpo;
+  const float s = a.scale ? a.scale[cc] : 1.f, b = a.shift ? a.shift[cc] : 0.f;
+  auto act = [&](float x) -> float {
+    const float y = fmaf(x, s, b);
+    return relu ? fmaxf(y, 0.f) : y;
+  };
+  const f32x4* z4 = reinterpret_cast<const f32x4*>(a.z + plane * Li);
+  const f32x4* g4 = FWD ? nullptr : reinterpret_cast<const f32x4*>(a.ge + plane * Lo);
+  const float* za = a.zaug + plane * Ti;
+  f32x4 zr[TS_PQ], gr[FWD ? 1 : TS_PQ / 2];
+#pragma unroll
+  for (int q = 0; q < TS_PQ; ++q) {
+    zr[q] = z4[min(q * 64 + lane, (Li >> 2) - 1)];            // (clamped, not predicated: a predicated load becomes a branch and a wait)
+  }
+  if constexpr (!FWD) {
+#pragma unroll
+    for (int q = 0; q < TS_PQ / 2; ++q) {
+      gr[q] = g4[min(q * 64 + lane, (Lo >> 2) - 1)];
+    }
+  }
+  float zav[2], gav = 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int t = lane + 64 * q;
+    zav[q] = za[min(t, Ti - 1)];
+  }
+  if (!FWD) gav = a.doaug[plane * To + min(lane, To - 1)];
+  const float cfv = FWD ? a.coeff[min(lane, V - 1)] : 0.f;
+#pragma unroll
+  for (int q = 0; q < TS_PQ; ++q) {
+    const int i = q * 64 + lane;
+    if (i < (Li >> 2)) {
+      f32x4 v = zr[q];
+      if (FWD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = act(v[k]);
+      }
+      reinterpret_cast<f32x4*>(hp)[i] = v;
+    }
+  }
+  if constexpr (!FWD) {
+#pragma unroll
+    for (int q = 0; q < TS_PQ / 2; ++q) {
+      const int i = q * 64 + lane;
+      if (i < (Lo >> 2)) reinterpret_cast<f32x4*>(gp)[i] = gr[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int t = lane + 64 * q;
+    if (t < Ti) ha[t] = act(zav[q]);
+  }
+  if (!FWD && lane < To) oa[lane] = gav;
+  if (FWD && lane < V) cf[lane] = cfv;
+  wave_lds_sync();
+  if constexpr (FWD) {
+    for (int tp = lane; tp < To; tp += 64) {
+      const int t = 2 * tp;
+      float v = ha[t];
+      if (pool) {
+        if (t >= 1) v = fmaxf(v, ha[t - 1]);
+        if (t + 1 < Ti) v = fmaxf(v, ha[t + 1]);
+      }
+      oa[tp] = v;
+      a.oaug[plane * To + tp] = v;
+    }
+    wave_lds_sync();
+    float* fo = a.f + plane * Lo;
+    double sv = 0.0, qv = 0.0;
+    for (int e = lane; e < Lo; e += 64) {
+      int tp, v;
+      divmod_small(e, V, invV, tp, v);
+      const int t = 2 * tp, ei = t * V + v;
+      float x = hp[ei];
+      if (pool) {
+        if (t >= 1) x = fmaxf(x, hp[ei - V]);
+        if (t + 1 < Ti) x = fmaxf(x, hp[ei + V]);
+      }
+      const float r = fmaf(oa[tp], cf[v], x);
+      fo[e] = r;
+      sv += (double)r;
+      qv = fma((double)r, (double)r, qv);
+    }
+    if (a.stats) {
+      sv = wave_sum_d(sv);
+      qv = wave_sum_d(qv);
+      if (lane == 0) {
+        a.stats[((size_t)(a.ngrp + n) * C + cc) * 2 + 0] = (float)sv;
+        a.stats[((size_t)(a.ngrp + n) * C + cc) * 2 + 1] = (float)qv;
+      }
+    }
+  } else {
+    // gradient of source row t of a column: pass-through: g[t / 2] on even rows; max-pool: the windows (centres = the even
+    // rows) whose FIRST maximal valid row is t.  hcol: the pooled values are actf(hcol[.])
+    auto route = [&](auto&& hval, const float* gcol, int t, int st) -> float {
+      if (!pool) return (!(t & 1) && (t >> 1) < To) ? gcol[(t >> 1) * st] : 0.f;
+      auto row = [&](int r) -> float { return (r >= 0 && r < Ti) ? hval(r) : -INFINITY; };
+      const float v = hval(t);
+      const float m2 = row(t - 2), m1 = row(t - 1), p1 = row(t + 1), p2 = row(t + 2);
+      float g = 0.f;
+      if (t >= 1 && !((t - 1) & 1) && ((t - 1) >> 1) < To && v > m2 && v > m1) g += gcol[((t - 1) >> 1) * st];
+      if (!(t & 1) && (t >> 1) < To && v > m1 && v >= p1) g += gcol[(t >> 1) * st];
+      if (((t + 1) & 1) == 0 && ((t + 1) >> 1) < To && v >= p1 && v >= p2) g += gcol[((t + 1) >> 1) * st];
+      return g;
+    };
+    float* dzo = a.dz + plane * Li;
+    float u0 = 0.f, u1 = 0.f;
+    for (int e = lane; e < Li; e += 64) {
+      int t, v;
+      divmod_small(e, V, invV, t, v);
+      const float x = hp[e];
+      float g = route([&](int r) { return act(hp[r * V + v]); }, gp + v, t, V);
+      if (relu && !(fmaf(x, s, b) > 0.f)) g = 0.f;
+      dzo[e] = g * s;
+      u0 = fmaf(g, x, u0);
+      u1 += g;
+    }
+    for (int t = lane; t < Ti; t += 64) {
+      const float x = za[t];
+      float g = route([&](int r) { return ha[r]; }, oa, t, 1);
+      if (relu && !(fmaf(x, s, b) > 0.f)) g = 0.f;
+      a.dzaug[plane * Ti + t] = g * s;
+      u0 = fmaf(g, x, u0);
+      u1 += g;
+    }
+    u0 = wave_sum(u0);
+    u1 = wave_sum(u1);
+    if (lane == 0) {
+      a.part[((size_t)(a.ngrp + n) * C + cc) * 2 + 0] = u0;
+      a.part[((size_t)(a.ngrp + n) * C + cc) * 2 + 1] = u1;
+    }
+  }
+}
+
 template <bool FWD>
 __device__ __forceinline__ void ts_elem(const TSArgs& a, const TSBranch& br, float* lw, int n, int c, int lane) {
   const int V = a.V, T = a.T, L = T * V, L4n = L >> 2, C = a.C;
@@ -534,20 +765,20 @@ __device__ __forceinline__ void ts_elem(const TSArgs& a, const TSBranch& br, flo
   f32x4 zr[TS_PQ], gr[FWD ? 1 : TS_PQ];
 #pragma unroll
   for (int q = 0; q < TS_PQ; ++q) {
-    const int i = q * 64 + lane;
-    if (i < L4n) {
-      zr[q] = z4[i];
-      if (!FWD) gr[q] = g4[i];
-    }
+    // (clamped, not predicated: a predicated load becomes a branch, and the compiler then waits for each load in turn —
+    // seven serial round trips per plane in the first version's disassembly)
+    const int i = min(q * 64 + lane, L4n - 1);
+    zr[q] = z4[i];
+    if (!FWD) gr[q] = g4[i];
   }
   float zav[2], gav[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int t = lane + 64 * q;
-    zav[q] = t < T ? za[t] : 0.f;
-    gav[q] = (!FWD && t < T) ? a.doaug[plane * T + t] : 0.f;
+    zav[q] = za[min(t, T - 1)];
+    gav[q] = FWD ? 0.f : a.doaug[plane * T + min(t, T - 1)];
   }
-  const float cfv = (FWD && lane < V) ? a.coeff[lane] : 0.f;
+  const float cfv = FWD ? a.coeff[min(lane, V - 1)] : 0.f;
   // ---- LDS -----------------------------------------------------------------------------------------------------
   if (pool) {
     f32x4* h4 = reinterpret_cast<f32x4*>(hp);
@@ -724,8 +955,8 @@ __device__ __forceinline__ void ts_elem(const TSArgs& a, const TSBranch& br, flo
 
 // grid.x = [conv blocks of the V columns: (position group, conv window)] ++ [conv blocks of the global-joint column] ++
 // [plane blocks: 4 planes each]
-template <bool FWD, int MT>
-__global__ __launch_bounds__(TS_NT, MT == 1 ? 3 : 2) void k_tsp(TSArgs a) {
+template <bool FWD, int MT, bool S2 = false>
+__global__ __launch_bounds__(TS_NT, (MT == 1 && !S2) ? 3 : 2) void k_tsp(TSArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -734,14 +965,16 @@ __global__ __launch_bounds__(TS_NT, MT == 1 ? 3 : 2) void k_tsp(TSArgs a) {
     if (a.exp & 8) return;
     const int w = b % a.nconv, grp = b / a.nconv;
     const TSBranch& br = ts_conv_window(a, w);
-    if (((br.dil * a.V) & 1) && !(a.exp & 16)) ts_conv<FWD, MT, true, false>(a, br, w == 0, lds, grp, lane, wave);
+    if constexpr (S2) ts_conv<FWD, MT, false, false, true>(a, br, w == 0, lds, grp, lane, wave);
+    else if (((br.dil * a.V) & 1) && !(a.exp & 16)) ts_conv<FWD, MT, true, false>(a, br, w == 0, lds, grp, lane, wave);
     else ts_conv<FWD, MT, false, false>(a, br, w == 0, lds, grp, lane, wave);
     return;
   }
   if (b < cb + cba) {
     const int w = (b - cb) % a.nconv, grp = (b - cb) / a.nconv;
     const TSBranch& br = ts_conv_window(a, w);
-    if (br.dil & 1) ts_conv<FWD, MT, true, true>(a, br, w == 0, lds, grp, lane, wave);
+    if constexpr (S2) ts_conv<FWD, MT, false, true, true>(a, br, w == 0, lds, grp, lane, wave);
+    else if (br.dil & 1) ts_conv<FWD, MT, true, true>(a, br, w == 0, lds, grp, lane, wave);
     else ts_conv<FWD, MT, false, true>(a, br, w == 0, lds, grp, lane, wave);
     return;
   }
@@ -755,11 +988,13 @@ __global__ __launch_bounds__(TS_NT, MT == 1 ? 3 : 2) void k_tsp(TSArgs a) {
       if (a.br[i].type == 0)
         for (int k = lane; k < a.br[i].bc * 2; k += 64) tab[((size_t)(a.ngrp + n) * a.C + a.br[i].c0) * 2 + k] = 0.f;
   }
-  const int per = (FWD ? 1 : 2) * a.T * a.V + 2 * ((a.T + 3) & ~3) + 32;
+  const int per = S2 ? a.T * a.V + a.Tout * a.V + ((a.T + 3) & ~3) + ((a.Tout + 3) & ~3) + 32
+                     : (FWD ? 1 : 2) * a.T * a.V + 2 * ((a.T + 3) & ~3) + 32;
   for (int i = 0; i < a.nbr; ++i) {
     if (a.br[i].type == 0) continue;
     if (c < a.br[i].bc) {
-      ts_elem<FWD>(a, a.br[i], lds + (size_t)wave * per, n, c, lane);
+      if constexpr (S2) ts_elem2<FWD>(a, a.br[i], lds + (size_t)wave * per, n, c, lane);
+      else ts_elem<FWD>(a, a.br[i], lds + (size_t)wave * per, n, c, lane);
       return;
     }
     c -= a.br[i].bc;
@@ -1106,6 +1341,247 @@ __global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
 #endif
 }
 
+// Stride-2 form of the weight gradient:  dW[co,ci,tap] = sum ge[n,co,t',v] * h[n,ci, 2t' + (tap-1)*dil, v].  The source rows a
+// unit of four output frames needs are every second frame, so the haloed tile does not apply: every tap gets its own
+// decimated tile Xs[tap][ci][4 frames | 4 global-joint values] (a frame row is V floats at a 4-byte-aligned address: seven
+// 16-byte loads per 25-float row, the dwords past the row dropped when the tile is written) and the matrix loop reads ge
+// and h at the SAME tile position.  Same grid, groups, splits and epilogue as k_tspw.
+template <int CH>
+__global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw2(TSArgs a) {
+  constexpr int KT = 3;
+  constexpr int JD = CH == 32 ? 4 : 7, JX = CH == 32 ? 11 : 21, JA = CH == 32 ? 2 : 3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int gw0 = a.gfirst[blockIdx.y], gcnt = a.gcount[blockIdx.y];
+  const TSBranch& br = ts_conv_window(a, gw0);
+  const int V = a.V, Ti = a.T, To = a.Tout, Li = Ti * V, Lo = To * V, C = a.C;
+  int bc = 0;
+  for (int w = 0; w < gcnt; ++w) bc += ts_conv_window(a, gw0 + w).bc;
+  auto row_dil = [&](int row) -> int {             // dilation of the window that holds row `row` of the group
+    int d = br.dil, r0 = 0;
+    for (int w = 0; w < gcnt; ++w) {
+      const TSBranch& bw = ts_conv_window(a, gw0 + w);
+      if (row >= r0) d = bw.dil;
+      r0 += bw.bc;
+    }
+    return d;
+  };
+  const int GM = TS_R * V;                                           // V-column part of a row (floats; a multiple of 4)
+  const int GS4 = GM >> 2, Q = (V + 3) >> 2;                         // float4 per ge row piece; 16-byte loads per frame row of h
+  const int LSd = tsw_ls(GM + TS_R);
+  float* Ds = lds;                                                   // [CH][LSd]
+  float* Xs = lds + CH * LSd;                                        // [3][CH][LSd]
+  f32x2s* SB = reinterpret_cast<f32x2s*>(Xs + 3 * CH * LSd);         // [CH] (scale, shift)
+  const f32x2s sb0 = (tid < CH && tid < bc) ? f32x2s{a.scale ? a.scale[br.c0 + tid] : 1.f, a.shift ? a.shift[br.c0 + tid] : 0.f}
+                                            : f32x2s{0.f, 0.f};
+  const int rel0 = br.c0;
+  const int units = a.n * (To / TS_R);
+  const int per = (units + a.splits - 1) / a.splits;
+  const int u0 = blockIdx.x * per, u1 = min(units, u0 + per);
+  const __amdgpu_buffer_rsrc_t rg = ts_rsrc(a.ge, (size_t)a.n * C * Lo * 4);
+  const __amdgpu_buffer_rsrc_t rz = ts_rsrc(a.z, (size_t)a.n * C * Li * 4);
+  const __amdgpu_buffer_rsrc_t rga = ts_rsrc(a.doaug, (size_t)a.n * C * To * 4);
+  const __amdgpu_buffer_rsrc_t rza = ts_rsrc(a.zaug, (size_t)a.n * C * Ti * 4);
+  int vD[JD], lD[JD];
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int f = tid + TS_NT * j, row = f / GS4, c4 = f - row * GS4;
+    const bool ok = row < bc;
+    vD[j] = ok ? (row * Lo + 4 * c4) * 4 : TS_OOB;
+    lD[j] = ok ? row * LSd + 4 * c4 : -1;
+  }
+  // h slots: f = tid + 256*j -> (row, tap, frame of the unit, 16-byte piece of the frame row)
+  int vX[JX], lX[JX], fX[JX];        // source offset inside the sample (bytes, before the unit's frame), LDS index | count << 20 | row << 23 | valid << 29, frame offset
+#pragma unroll
+  for (int j = 0; j < JX; ++j) {
+    const int f = tid + TS_NT * j, row = f / (12 * Q), r1 = f - row * 12 * Q, tap = r1 / (4 * Q), r2 = r1 - tap * 4 * Q,
+              fr = r2 / Q, q = r2 - fr * Q;
+    const bool ok = row < bc;
+    const int fo = 2 * fr + (tap - 1) * row_dil(row);               // source frame minus 2 * (first output frame of the unit)
+    fX[j] = fo;
+    vX[j] = ok ? (row * Li + fo * V + 4 * q) * 4 : TS_OOB;
+    lX[j] = ((tap * CH + row) * LSd + fr * V + 4 * q) | (min(4, V - 4 * q) << 20) | ((row & 63) << 23) | (ok ? 1 << 29 : 0);
+  }
+  // the one-column operands: thread < CH: doaug of row tid (4 frames); slots tid + 256*j < CH*12: (row, tap, frame) of zaug
+  const bool aokD = tid < CH && tid < bc;
+  int vA[JA], lA[JA], fA[JA];
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const int f = tid + TS_NT * j, row = f / 12, r1 = f - row * 12, tap = r1 >> 2, fr = r1 & 3;
+    const bool ok = f < CH * 12 && row < bc;
+    const int fo = 2 * fr + (tap - 1) * row_dil(row);
+    fA[j] = fo;
+    vA[j] = ok ? (row * Ti + fo) * 4 : TS_OOB;
+    lA[j] = ((tap * CH + row) * LSd + GM + fr) | ((row & 63) << 23) | (ok ? 1 << 29 : 0);
+  }
+  f32x4 gr[JD], xr[JX], ga;
+  float xa[JA];
+  float dsum[JD], dsa = 0.f;
+#pragma unroll
+  for (int j = 0; j < JD; ++j) dsum[j] = 0.f;
+  int t2 = 0;                                      // 2 * (first output frame) of the unit being committed
+  auto issue = [&](int u) {
+    const int n = u / (To / TS_R), tp0 = (u - n * (To / TS_R)) * TS_R;
+    t2 = 2 * tp0;
+    const int sg = ((n * C + br.c0) * Lo + tp0 * V) * 4;
+    const int sx = ((n * C + br.c0) * Li + t2 * V) * 4;
+    const int sa = ((n * C + br.c0) * Ti + t2) * 4;
+#pragma unroll
+    for (int j = 0; j < JD; ++j) gr[j] = ts_load4(rg, vD[j], sg);
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const int fr = t2 + fX[j];
+      const bool ok = fr >= 0 && fr < Ti;
+      xr[j] = ts_load4(rz, ok ? vX[j] + sx : TS_OOB, 0);
+    }
+    ga = ts_load4(rga, aokD ? ((n * C + br.c0 + tid) * To + tp0) * 4 : TS_OOB, 0);
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      const int fr = t2 + fA[j];
+      const bool ok = fr >= 0 && fr < Ti;
+      xa[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rza, ok ? vA[j] + sa : TS_OOB, 0, 0));
+    }
+  };
+  auto act = [&](float x, f32x2s sb, bool rl) -> float {
+    const float y = fmaf(x, sb.x, sb.y);
+    return rl ? fmaxf(y, 0.f) : y;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+      if (lD[j] >= 0) {
+        f32x2s* d = reinterpret_cast<f32x2s*>(Ds + lD[j]);
+        d[0] = f32x2s{gr[j].x, gr[j].y};
+        d[1] = f32x2s{gr[j].z, gr[j].w};
+        dsum[j] += (gr[j].x + gr[j].y) + (gr[j].z + gr[j].w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      if (lX[j] & (1 << 29)) {
+        const int fr = t2 + fX[j];
+        const bool ok = fr >= 0 && fr < Ti;
+        const int row = (lX[j] >> 23) & 63, cnt = (lX[j] >> 20) & 7;
+        const f32x2s sb = SB[row];
+        const bool rl = rel0 + row < a.n_act;
+        float* d = Xs + (lX[j] & 0xfffff);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < cnt) d[k] = ok ? act(xr[j][k], sb, rl) : 0.f;
+      }
+    }
+    if (aokD) {
+      f32x2s* d = reinterpret_cast<f32x2s*>(Ds + tid * LSd + GM);
+      d[0] = f32x2s{ga.x, ga.y};
+      d[1] = f32x2s{ga.z, ga.w};
+      dsa += (ga.x + ga.y) + (ga.z + ga.w);
+    }
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      if (lA[j] & (1 << 29)) {
+        const int fr = t2 + fA[j];
+        const bool ok = fr >= 0 && fr < Ti;
+        const int row = (lA[j] >> 23) & 63;
+        Xs[lA[j] & 0xfffff] = ok ? act(xa[j], SB[row], rel0 + row < a.n_act) : 0.f;
+      }
+    }
+  };
+  f32x16 acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+  const int mt = CH == 64 ? (wave >> 1) : 0, nt = CH == 64 ? (wave & 1) : 0;
+  const int G1 = GS4 + 1;                                             // groups of four positions: the V columns, then the global joint
+  const int g0 = CH == 32 ? (G1 * wave) / 4 : 0, g1 = CH == 32 ? (G1 * (wave + 1)) / 4 : G1;
+  const float* Ap = Ds + (32 * mt + l31) * LSd + 2 * half;
+  const float* Bp = Xs + (32 * nt + l31) * LSd + 2 * half;
+  if (u0 < u1) issue(u0);
+  {
+    f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+    for (int i = tid; i < (4 * CH * LSd) >> 2; i += TS_NT) l4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < CH) SB[tid] = sb0;
+  }
+  __syncthreads();
+  for (int u = u0; u < u1; ++u) {
+    commit();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (u + 1 < u1) issue(u + 1);
+#pragma unroll 2
+    for (int g = g0; g < g1; ++g) {
+      const f32x2s av = *reinterpret_cast<const f32x2s*>(Ap + 4 * g);
+      const f32x2s b0 = *reinterpret_cast<const f32x2s*>(Bp + 4 * g);
+      const f32x2s b1 = *reinterpret_cast<const f32x2s*>(Bp + CH * LSd + 4 * g);
+      const f32x2s b2 = *reinterpret_cast<const f32x2s*>(Bp + 2 * CH * LSd + 4 * g);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b2.x, acc[2], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b2.y, acc[2], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (CH == 32) {
+    float* Rs = lds;                                 // [wave][tap][co][33]
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Rs[((wave * KT + k) * 32 + ts_row32(r, half)) * 33 + l31] = acc[k][r];
+    __syncthreads();
+    for (int w = 0, r0 = 0; w < gcnt; ++w) {
+      const TSBranch& bw = ts_conv_window(a, gw0 + w);
+      const int wb = bw.bc;
+      float* dw = bw.dwp + (size_t)blockIdx.x * a.pstride;
+      for (int o = tid; o < KT * wb * wb; o += TS_NT) {
+        const int co = o / (wb * KT), r2 = o - co * wb * KT, ci = r2 / KT, k = r2 - ci * KT;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) v += Rs[((wv * KT + k) * 32 + r0 + co) * 33 + r0 + ci];
+        dw[o] = v;
+      }
+      r0 += wb;
+    }
+    __syncthreads();
+  } else {
+    float* dw = br.dwp + (size_t)blockIdx.x * a.pstride;
+    const int ci = 32 * nt + l31;
+    if (ci < bc) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * mt + ts_row32(r, half);
+        if (co < bc) {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) dw[((size_t)co * bc + ci) * KT + k] = acc[k][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* Bs = lds;                                   // [CH][GS4 + 2]
+#pragma unroll
+  for (int j = 0; j < JD; ++j) {
+    const int f = tid + TS_NT * j, row = f / GS4, c4 = f - row * GS4;
+    if (row < bc) Bs[row * (GS4 + 2) + c4] = dsum[j];
+  }
+  if (aokD) Bs[tid * (GS4 + 2) + GS4] = dsa;
+  __syncthreads();
+  if (tid < bc) {
+    float v = 0.f;
+    for (int c = 0; c <= GS4; ++c) v += Bs[tid * (GS4 + 2) + c];
+    int r0 = 0;
+    for (int w = 0; w < gcnt; ++w) {
+      const TSBranch& bw = ts_conv_window(a, gw0 + w);
+      if (tid >= r0 && tid < r0 + bw.bc) bw.dbp[(size_t)blockIdx.x * a.pstride + tid - r0] = v;
+      r0 += bw.bc;
+    }
+  }
+}
+
 int g_ts_exp = 0;                                 // lab builds: dsgcn_tms_split_tuning
 constexpr size_t TS_LDS_MAX = 156 * 1024;
 
@@ -1125,6 +1601,7 @@ int ts_fill(TSArgs& a, int n, int C, int T, int V, int stride, int KT, int nbr, 
             const int* bc, const int* dil) {
   if (n <= 0 || C <= 0 || T <= 0 || V <= 0 || nbr <= 0 || nbr > TS_MAXBR || !type || !c0 || !bc || !dil) return DSGCN_EINVAL;
   a.n = n; a.C = C; a.T = T; a.V = V; a.nbr = nbr; a.exp = g_ts_exp;
+  a.Tout = stride == 2 ? T / 2 : T;
   int nconv = 0, eplanes = 0, wmax = 0, next = 0;
   for (int i = 0; i < nbr; ++i) {
     TSBranch& b = a.br[i];
@@ -1143,7 +1620,10 @@ int ts_fill(TSArgs& a, int n, int C, int T, int V, int stride, int KT, int nbr, 
     }
   }
   if (next != C) return 0;
-  if (KT != 3 || stride != 1 || nconv == 0 || wmax > 64 || (V & 1) == 0 || V < 5 || V > 25 || T % 4 || (long)T * V > 2048) return 0;
+  if (KT != 3 || (stride != 1 && stride != 2) || nconv == 0 || wmax > 64 || (V & 1) == 0 || V < 5 || V > 25 || T % 4 ||
+      (long)T * V > 2048)
+    return 0;
+  if (stride == 2 && (T % 8 || T > 128)) return 0;   // (four-frame units of the output; the plane waves hold a column in two registers)
   const long L = (long)T * V;
   if ((long)n * C * L * 4 >= (1L << 31) - 4096 || (long)n * L >= (1L << 31) - 256) return 0;
   if (n > 32768) return 0;
@@ -1165,12 +1645,16 @@ int ts_fill(TSArgs& a, int n, int C, int T, int V, int stride, int KT, int nbr, 
     prev = i;
     ++k;
   }
-  const int WT = (int)(((long)n * L + 127) / 128);
-  a.ngrp = (WT + 3) / 4;
-  a.ngrpa = (int)(((long)n * T + 511) / 512);
-  a.haw = 32;                                       // frames of haug per block (511 / V + 2, a halo of 4 either side, the pair read), a power of two
-  while (a.haw < 511 / V + 2 + 2 * TS_H + 1) a.haw *= 2;
+  a.haw = 32;                                       // source frames of haug per block ((511 / V + 2) x stride, a halo of 4 either side, the pair read), a power of two
+  while (a.haw < (511 / V + 2) * stride + 2 * TS_H + 3) a.haw *= 2;
   return wmax <= 32 ? 1 : 2;                          // = MT
+}
+
+// position groups of the launch of one direction: the forward tiles the OUTPUT planes, the data gradient the INPUT planes
+void ts_groups(TSArgs& a, bool fwd) {
+  const int Tt = fwd ? a.Tout : a.T;
+  a.ngrp = (int)(((long)a.n * Tt * a.V + 511) / 512);
+  a.ngrpa = (int)(((long)a.n * Tt + 511) / 512);
 }
 
 // LDS of the main launch: conv blocks (weight tile | epilogue transposes, then the per-channel table) vs plane blocks
@@ -1182,17 +1666,31 @@ size_t ts_lds_main(TSArgs& a, int MT, bool fwd) {
   const size_t epf = (size_t)4 * 32 * 36 + (size_t)4 * MT * 32 * 2 * 2;          // transposes + [4][MT*32][2] doubles
   const size_t convf = (std::max(wsf, epf) + 3) & ~(size_t)3;
   a.sboff = (int)convf;
-  const size_t planef = (size_t)4 * ((fwd ? 1 : 2) * a.T * a.V + 2 * ((a.T + 3) & ~3) + 32);
+  const size_t planef = a.Tout != a.T ? (size_t)4 * (a.T * a.V + a.Tout * a.V + ((a.T + 3) & ~3) + ((a.Tout + 3) & ~3) + 32)
+                                      : (size_t)4 * ((fwd ? 1 : 2) * a.T * a.V + 2 * ((a.T + 3) & ~3) + 32);
   return std::max(convf + 192 + (fwd ? (size_t)64 * a.haw : 0), planef) * sizeof(float);
 }
 
 template <bool FWD>
 int ts_launch_main(TSArgs& a, int MT, hipStream_t st) {
   const size_t lds = ts_lds_main(a, MT, FWD);
+  ts_groups(a, FWD);
   const long blocks = (long)a.nconv * (a.ngrp + a.ngrpa) + ((long)a.n * a.eplanes + 3) / 4;
   if (blocks <= 0 || blocks >= (1L << 31)) return DSGCN_EUNSUPPORTED;
   const dim3 grid((unsigned)blocks), blk(TS_NT);
-  if (MT == 1) {
+  if (a.Tout != a.T) {
+    if (MT == 1) {
+      static size_t have = 64 * 1024;
+      const int rc = ts_raise_lds(k_tsp<FWD, 1, true>, lds, &have);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_tsp<FWD, 1, true>), grid, blk, lds, st, a);
+    } else {
+      static size_t have = 64 * 1024;
+      const int rc = ts_raise_lds(k_tsp<FWD, 2, true>, lds, &have);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_tsp<FWD, 2, true>), grid, blk, lds, st, a);
+    }
+  } else if (MT == 1) {
     static size_t have = 64 * 1024;
     const int rc = ts_raise_lds(k_tsp<FWD, 1>, lds, &have);
     if (rc) return rc;
@@ -1238,10 +1736,10 @@ int dsgcn_tms_split_rows(int which, int n, int C, int T, int V, int stride, int 
   if (mt <= 0) return 0;
   if (ts_lds_main(a, mt, false) > TS_LDS_MAX || ts_lds_main(a, mt, true) > TS_LDS_MAX) return 0;
   if (which == -1) return 1;
-  if (which == 0) return a.ngrp + n;
-  if (which == 1) return a.ngrp + n + a.ngrpa;
+  if (which == 0) { ts_groups(a, true); return a.ngrp + n; }
+  if (which == 1) { ts_groups(a, false); return a.ngrp + n + a.ngrpa; }
   if (which == 2) {
-    const int units = n * (T / TS_R);
+    const int units = n * (a.Tout / TS_R);
     int splits = (mt == 1 ? 512 : 256) / a.ngroups;
     if (splits < 1) splits = 1;
     return std::min(splits, units);
@@ -1251,12 +1749,12 @@ int dsgcn_tms_split_rows(int which, int n, int C, int T, int V, int stride, int 
 
 // f (n,C,T,V), oaug (n,C,T), stats (rows(0), C, 2) or NULL.
 int dsgcn_tms_split_fwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
-                        const float* coeff, float* f, float* oaug, float* stats, int n, int C, int T, int V, int nbr,
-                        const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
+                        const float* coeff, float* f, float* oaug, float* stats, int n, int C, int T, int V, int stride,
+                        int nbr, const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
                         const float* const* b, void* stream) {
   if (!z || !zaug || !coeff || !f || !oaug || !w) return DSGCN_EINVAL;
   TSArgs a = {};
-  const int mt = ts_fill(a, n, C, T, V, 1, 3, nbr, type, c0, bc, dil);
+  const int mt = ts_fill(a, n, C, T, V, stride, 3, nbr, type, c0, bc, dil);
   if (mt < 0) return mt;
   if (mt == 0) return DSGCN_EUNSUPPORTED;
   a.z = z; a.zaug = zaug; a.scale = scale; a.shift = shift; a.n_act = n_act; a.coeff = coeff;
@@ -1286,11 +1784,11 @@ int dsgcn_tms_split_prep(const float* gf, const float* f, const float* oaug, con
 // dz (n,C,T,V), dzaug (n,C,T), part (rows(1), C, 2): [sum dpre*x, sum dpre] of the branch BatchNorm's backward.
 int dsgcn_tms_split_dgrad(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
                           const float* ge, const float* doaug, float* dz, float* dzaug, float* part, int n, int C, int T,
-                          int V, int nbr, const int* type, const int* c0, const int* bc, const int* dil,
+                          int V, int stride, int nbr, const int* type, const int* c0, const int* bc, const int* dil,
                           const float* const* w, void* stream) {
   if (!z || !zaug || !ge || !doaug || !dz || !dzaug || !part || !w) return DSGCN_EINVAL;
   TSArgs a = {};
-  const int mt = ts_fill(a, n, C, T, V, 1, 3, nbr, type, c0, bc, dil);
+  const int mt = ts_fill(a, n, C, T, V, stride, 3, nbr, type, c0, bc, dil);
   if (mt < 0) return mt;
   if (mt == 0) return DSGCN_EUNSUPPORTED;
   a.z = z; a.zaug = zaug; a.scale = scale; a.shift = shift; a.n_act = n_act;
@@ -1306,12 +1804,12 @@ int dsgcn_tms_split_dgrad(const float* z, const float* zaug, const float* scale,
 // Conv window i writes split s of its weight / bias partials at dwp[i] + s*pstride / dbp[i] + s*pstride, s < splits =
 // rows(2); NULL entries for the other window types.
 int dsgcn_tms_split_wgrad(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
-                          const float* ge, const float* doaug, int n, int C, int T, int V, int nbr, const int* type,
-                          const int* c0, const int* bc, const int* dil, float* const* dwp, float* const* dbp, int splits,
-                          int pstride, void* stream) {
+                          const float* ge, const float* doaug, int n, int C, int T, int V, int stride, int nbr,
+                          const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp, float* const* dbp,
+                          int splits, int pstride, void* stream) {
   if (!z || !zaug || !ge || !doaug || !dwp || !dbp || splits <= 0) return DSGCN_EINVAL;
   TSArgs a = {};
-  const int mt = ts_fill(a, n, C, T, V, 1, 3, nbr, type, c0, bc, dil);
+  const int mt = ts_fill(a, n, C, T, V, stride, 3, nbr, type, c0, bc, dil);
   if (mt < 0) return mt;
   if (mt == 0) return DSGCN_EUNSUPPORTED;
   a.z = z; a.zaug = zaug; a.scale = scale; a.shift = shift; a.n_act = n_act;
@@ -1321,11 +1819,24 @@ int dsgcn_tms_split_wgrad(const float* z, const float* zaug, const float* scale,
     if (type[i] == 0 && (!a.br[i].dwp || !a.br[i].dbp)) return DSGCN_EINVAL;
   }
   const int ch = mt == 1 ? 32 : 64;
-  const size_t tile = (size_t)ch * (tsw_ls(TS_R * (V + 1)) + tsw_ls((TS_R + 2 * TS_H) * (V + 1))) + 2 * ch;
+  const size_t tile = stride == 2 ? (size_t)4 * ch * tsw_ls(TS_R * (V + 1)) + 2 * ch
+                                  : (size_t)ch * (tsw_ls(TS_R * (V + 1)) + tsw_ls((TS_R + 2 * TS_H) * (V + 1))) + 2 * ch;
   const size_t red = (size_t)4 * 3 * 32 * 33;
   const size_t lds = std::max(tile, ch == 32 ? red : (size_t)0) * sizeof(float);
   const dim3 grid((unsigned)splits, (unsigned)a.ngroups);
-  if (ch == 32) {
+  if (stride == 2) {
+    if (ch == 32) {
+      static size_t have = 64 * 1024;
+      const int rc = ts_raise_lds(k_tspw2<32>, lds, &have);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_tspw2<32>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a);
+    } else {
+      static size_t have = 64 * 1024;
+      const int rc = ts_raise_lds(k_tspw2<64>, lds, &have);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_tspw2<64>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a);
+    }
+  } else if (ch == 32) {
     static size_t have = 64 * 1024;
     const int rc = ts_raise_lds(k_tspw<32>, lds, &have);
     if (rc) return rc;

@@ -62,8 +62,9 @@ OVERLAP = _os.environ.get('DSGCN_OVERLAP', '0') != '0'
 # MSTCN, 22.3 -> 21.0 ms/step; on DS-STGCN's 3-tap units the staged wide-load kernels are still ahead, 13.6 vs 16.8 ms:
 # profiles/r03/README.md), '1' = wherever eligible, '0' = never
 FUSED_TEMPORAL = _os.environ.get('DSGCN_FUSED_TEMPORAL', 'auto')
-# '1': dgmstcn units (kernel 3, stride 1) run on the split layout of csrc/tmsplit.hip; '0': the staged three-kernel form
-SPLIT_TEMPORAL = _os.environ.get('DSGCN_SPLIT_TEMPORAL', '1')
+# dgmstcn units (kernel 3) on the split layout of csrc/tmsplit.hip: '2' (default) = stride 1 and 2, '1' = stride 1 only,
+# '0' = the staged three-kernel form everywhere
+SPLIT_TEMPORAL = _os.environ.get('DSGCN_SPLIT_TEMPORAL', '2')
 
 
 class side_branch:
@@ -1074,14 +1075,15 @@ class _TemporalFused(torch.autograd.Function):
 
 class _TemporalSplit(torch.autograd.Function):
     """dgmstcn's temporal stage on the split layout (csrc/tmsplit.hip): the V joint columns through the matrix-core window
-    kernels straight from z to f (BatchNorm affine + ReLU while loading, ``f = o + oaug * coeff`` and the statistics of f in
-    the epilogue), the global-joint column through two small launches on (n, C, T) tensors.  The (V+1)-column tensors of
-    tcn.py:409-420 (h, o and their gradients) and the branch_act / combine passes do not exist; backward materialises
-    ``ge = gf + A0 + B0*f`` once (it feeds the data AND the weight gradient) and finishes ``dz`` / the branch BatchNorm's
-    sums in the data gradient's epilogue."""
+    kernels straight from z to f (BatchNorm affine + ReLU and the global-joint term while loading, the statistics of f in
+    the epilogue), the global-joint column as extra blocks of the same launches on (n, C, T) tensors.  The (V+1)-column
+    tensors of tcn.py:409-420 (h, o and their gradients) and the branch_act / combine passes do not exist; backward
+    materialises ``ge = gf + A0 + B0*f`` once (it feeds the data AND the weight gradient) and finishes ``dz`` / the branch
+    BatchNorm's sums in the data gradient's epilogue.  stride 1 or 2 over frames."""
+    FRONT = 32           # floats in front of ge / doaug: the stride-2 data gradient may start a run before a plane
 
     @staticmethod
-    def forward(ctx, z, zaug, scale, shift, coeff, gamma, beta, n_act, types, c0s, bcs, dils, eps, want_bn, bn, *wb):
+    def forward(ctx, z, zaug, scale, shift, coeff, gamma, beta, n_act, stride, types, c0s, bcs, dils, eps, want_bn, bn, *wb):
         _require_cuda(z)
         ctx.bn = bn
         z, zaug, scale, shift, coeff, gamma, beta = [_f32c(t) for t in (z, zaug, scale, shift, coeff, gamma, beta)]
@@ -1089,20 +1091,21 @@ class _TemporalSplit(torch.autograd.Function):
         ws = [_f32c(t) for t in wb[:nbr]]
         bs = [_f32c(t) for t in wb[nbr:]]
         n, C, T, V = z.shape
+        To = T // stride
         dev = z.device
         lib = native.lib()
         tabs = (_int_array(types), _int_array(c0s), _int_array(bcs), _int_array(dils))
-        rows = lib.dsgcn_tms_split_rows(0, n, C, T, V, 1, 3, nbr, *tabs)
+        rows = lib.dsgcn_tms_split_rows(0, n, C, T, V, stride, 3, nbr, *tabs)
         assert rows > 0
-        f = torch.empty((n, C, T, V), device=dev, dtype=torch.float32)
-        oaug = torch.empty((n, C, T), device=dev, dtype=torch.float32)
+        f = torch.empty((n, C, To, V), device=dev, dtype=torch.float32)
+        oaug = torch.empty((n, C, To), device=dev, dtype=torch.float32)
         stats = torch.empty((rows, C, 2), device=dev, dtype=torch.float32) if want_bn else None
         rc = lib.dsgcn_tms_split_fwd(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), int(n_act), _ptr(coeff), _ptr(f),
-                                     _ptr(oaug), _ptr(stats), n, C, T, V, nbr, *tabs, _ptr_array(ws), _ptr_array(bs),
+                                     _ptr(oaug), _ptr(stats), n, C, T, V, stride, nbr, *tabs, _ptr_array(ws), _ptr_array(bs),
                                      _stream())
         native.check(rc, 'dsgcn_tms_split_fwd')
         scale1 = shift1 = mean = var = None
-        count = float(n * T * V)
+        count = float(n * To * V)
         if want_bn:
             st = torch.empty((4, C), device=dev, dtype=torch.float32)
             mean, var, scale1, shift1 = st[0], st[1], st[2], st[3]
@@ -1112,8 +1115,8 @@ class _TemporalSplit(torch.autograd.Function):
             ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(z, zaug, scale, shift, coeff, f, oaug, gamma, mean, var, *[w for w in ws if w is not None])
-        ctx.cfg = (int(n_act), tuple(types), tuple(c0s), tuple(bcs), tuple(dils), float(eps), bool(want_bn), count,
-                   beta is not None, tuple(b is not None for b in bs))
+        ctx.cfg = (int(n_act), int(stride), tuple(types), tuple(c0s), tuple(bcs), tuple(dils), float(eps), bool(want_bn),
+                   count, beta is not None, tuple(b is not None for b in bs))
         ctx.bn_in = _bn_of(scale)
         ctx.defer_ok = _leafish(coeff, *wb)
         return f, scale1, shift1, mean, var
@@ -1121,8 +1124,9 @@ class _TemporalSplit(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gf, gscale, gshift, _gm, _gv):
         z, zaug, scale, shift, coeff, f, oaug, gamma, mean, var, *wsaved = ctx.saved_tensors
-        n_act, types, c0s, bcs, dils, eps, want_bn, count, has_beta, has_b = ctx.cfg
+        n_act, stride, types, c0s, bcs, dils, eps, want_bn, count, has_beta, has_b = ctx.cfg
         n, C, T, V = z.shape
+        To = f.shape[2]
         nbr = len(types)
         dev = z.device
         lib = native.lib()
@@ -1131,22 +1135,24 @@ class _TemporalSplit(torch.autograd.Function):
         A0 = B0 = dgamma = dbeta = None
         if want_bn:
             dgamma, dbeta, A0, B0 = _bn_coef(ctx.bn, gscale, gshift, mean, var, gamma, eps, count, C, C)
-        ge = torch.empty_like(f)
-        doaug = torch.empty((n, C, T), device=dev, dtype=torch.float32)
+        FR = _TemporalSplit.FRONT
+        gbuf = torch.empty(FR + f.numel() + FR + n * C * To, device=dev, dtype=torch.float32)
+        ge = gbuf[FR:FR + f.numel()].view(f.shape)
+        doaug = gbuf[2 * FR + f.numel():].view(n, C, To)
         pcoef = torch.empty((n * C, V), device=dev, dtype=torch.float32)
         rc = lib.dsgcn_tms_split_prep(_ptr(gf), _ptr(f), _ptr(oaug), _ptr(coeff), _ptr(A0), _ptr(B0), _ptr(ge), _ptr(doaug),
-                                      _ptr(pcoef), n, C, T, V, st)
+                                      _ptr(pcoef), n, C, To, V, st)
         native.check(rc, 'dsgcn_tms_split_prep')
         dcoeff = param_colsum(pcoef, ctx.defer_ok)
         it = iter(wsaved)
         ws = [next(it) if t == 0 else None for t in types]
         tabs = (_int_array(types), _int_array(c0s), _int_array(bcs), _int_array(dils))
-        rows = lib.dsgcn_tms_split_rows(1, n, C, T, V, 1, 3, nbr, *tabs)
+        rows = lib.dsgcn_tms_split_rows(1, n, C, T, V, stride, 3, nbr, *tabs)
         part = torch.empty((rows, C, 2), device=dev, dtype=torch.float32)
         dz = torch.empty_like(z)
         dzaug = torch.empty_like(zaug)
         rc = lib.dsgcn_tms_split_dgrad(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), n_act, _ptr(ge), _ptr(doaug), _ptr(dz),
-                                       _ptr(dzaug), _ptr(part), n, C, T, V, nbr, *tabs, _ptr_array(ws), st)
+                                       _ptr(dzaug), _ptr(part), n, C, T, V, stride, nbr, *tabs, _ptr_array(ws), st)
         native.check(rc, 'dsgcn_tms_split_dgrad')
         dscale = dshift = None
         if ctx.bn_in is not None:
@@ -1160,14 +1166,14 @@ class _TemporalSplit(torch.autograd.Function):
             if t == 0:
                 off += bc * bc * 3 + bc
         pstride = off
-        splits = lib.dsgcn_tms_split_rows(2, n, C, T, V, 1, 3, nbr, *tabs)
+        splits = lib.dsgcn_tms_split_rows(2, n, C, T, V, stride, 3, nbr, *tabs)
         wpart = torch.empty((splits, pstride), device=dev, dtype=torch.float32)
         base = wpart.data_ptr()
         dwp = (_ct.c_void_p * nbr)(*[base + 4 * o if t == 0 else None for t, o in zip(types, offs)])
         dbp = (_ct.c_void_p * nbr)(*[base + 4 * (o + bc * bc * 3) if t == 0 else None
                                      for t, o, bc in zip(types, offs, bcs)])
         rc = lib.dsgcn_tms_split_wgrad(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), n_act, _ptr(ge), _ptr(doaug), n, C, T,
-                                       V, nbr, *tabs, dwp, dbp, splits, pstride, st)
+                                       V, stride, nbr, *tabs, dwp, dbp, splits, pstride, st)
         native.check(rc, 'dsgcn_tms_split_wgrad')
         red = param_colsum(wpart, ctx.defer_ok)
         dws = [red[o:o + bc * bc * 3].view(bc, bc, 3, 1) if t == 0 else None for t, o, bc in zip(types, offs, bcs)]
@@ -1176,7 +1182,7 @@ class _TemporalSplit(torch.autograd.Function):
         if dgamma is not None:
             dgamma = dgamma if gamma is not None else None
             dbeta = dbeta if has_beta else None
-        return (dz, dzaug, dscale, dshift, dcoeff, dgamma, dbeta, None, None, None, None, None, None, None, None,
+        return (dz, dzaug, dscale, dshift, dcoeff, dgamma, dbeta, None, None, None, None, None, None, None, None, None,
                 *dws, *dbs)
 
 
@@ -1185,16 +1191,18 @@ def _split_temporal(z, zaug, scale, shift, coeff, n_act, branch_cfg, widths, con
     """-> (f, scale, shift, mean, var) through csrc/tmsplit.hip, or None when the shape is not eligible."""
     if zaug is None or any(not isinstance(c, str) and c[0] != 'max' and c[0] != 3 for c in branch_cfg):
         return None
+    if int(stride) != 1 and SPLIT_TEMPORAL == '1':
+        return None
     KT, types, c0s, bcs, dils, ws, bs = _branch_tables(branch_cfg, widths, conv_w, conv_b)
     n, C, T, V = z.shape
     if native.lib().dsgcn_tms_split_rows(-1, n, C, T, V, int(stride), KT, len(types), _int_array(types), _int_array(c0s),
                                          _int_array(bcs), _int_array(dils)) != 1:
         return None
     bn = BNCtx() if want_bn else None
-    out = _TemporalSplit.apply(z, zaug, scale, shift, coeff, gamma, beta, int(n_act), types, c0s, bcs, dils, float(eps),
-                               bool(want_bn), bn, *ws, *bs)
+    out = _TemporalSplit.apply(z, zaug, scale, shift, coeff, gamma, beta, int(n_act), int(stride), types, c0s, bcs, dils,
+                               float(eps), bool(want_bn), bn, *ws, *bs)
     if want_bn:
-        _bn_attach(out[1], bn, out[3], out[4], gamma, eps, float(n * T * V), C)
+        _bn_attach(out[1], bn, out[3], out[4], gamma, eps, float(n * (T // int(stride)) * V), C)
     return out
 
 

@@ -74,10 +74,10 @@ SIGNATURES = {
     'dsgcn_tms_dgrad': [c_f] * 4 + [c_int] + [c_f] * 10 + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, c_st],
     'dsgcn_tms_wgrad': [c_f] * 4 + [c_int] + [c_f] * 5 + [c_int] * 7 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_st],
     'dsgcn_tms_split_rows': [c_int] * 8 + [c_i] * 4,
-    'dsgcn_tms_split_fwd': [c_f] * 4 + [c_int] + [c_f] * 4 + [c_int] * 5 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_st],
+    'dsgcn_tms_split_fwd': [c_f] * 4 + [c_int] + [c_f] * 4 + [c_int] * 6 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_st],
     'dsgcn_tms_split_prep': [c_f] * 9 + [c_int] * 4 + [c_st],
-    'dsgcn_tms_split_dgrad': [c_f] * 4 + [c_int] + [c_f] * 5 + [c_int] * 5 + [c_i] * 4 + [ctypes.c_void_p, c_st],
-    'dsgcn_tms_split_wgrad': [c_f] * 4 + [c_int] + [c_f] * 2 + [c_int] * 5 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_st],
+    'dsgcn_tms_split_dgrad': [c_f] * 4 + [c_int] + [c_f] * 5 + [c_int] * 6 + [c_i] * 4 + [ctypes.c_void_p, c_st],
+    'dsgcn_tms_split_wgrad': [c_f] * 4 + [c_int] + [c_f] * 2 + [c_int] * 6 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, c_st],
     'dsgcn_aggsum_partial_rows': [c_int, c_int, c_int],
     'dsgcn_aggsum_bwd_piece_rows': [c_int] * 5,
     'dsgcn_aggsum_fwd': [c_f, c_f] + [ctypes.c_long] * 3 + [c_f, c_f] + [c_int] * 5 + [c_st],

@@ -340,20 +340,20 @@ int dsgcn_tms_wgrad(const float* z, const float* zaug, const float* scale, const
 int dsgcn_tms_split_rows(int which, int n, int C, int T, int V, int stride, int KT, int nbr, const int* type,
                          const int* c0, const int* bc, const int* dil);
 int dsgcn_tms_split_fwd(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
-                        const float* coeff, float* f, float* oaug, float* stats, int n, int C, int T, int V, int nbr,
-                        const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
+                        const float* coeff, float* f, float* oaug, float* stats, int n, int C, int T, int V, int stride,
+                        int nbr, const int* type, const int* c0, const int* bc, const int* dil, const float* const* w,
                         const float* const* b, void* stream);
 int dsgcn_tms_split_prep(const float* gf, const float* f, const float* oaug, const float* coeff, const float* A0,
                          const float* B0, float* ge, float* doaug, float* pcoef, int n, int C, int T, int V,
                          void* stream);
 int dsgcn_tms_split_dgrad(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
                           const float* ge, const float* doaug, float* dz, float* dzaug, float* part, int n, int C, int T,
-                          int V, int nbr, const int* type, const int* c0, const int* bc, const int* dil,
+                          int V, int stride, int nbr, const int* type, const int* c0, const int* bc, const int* dil,
                           const float* const* w, void* stream);
 int dsgcn_tms_split_wgrad(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
-                          const float* ge, const float* doaug, int n, int C, int T, int V, int nbr, const int* type,
-                          const int* c0, const int* bc, const int* dil, float* const* dwp, float* const* dbp, int splits,
-                          int pstride, void* stream);
+                          const float* ge, const float* doaug, int n, int C, int T, int V, int stride, int nbr,
+                          const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp, float* const* dbp,
+                          int splits, int pstride, void* stream);
 
 /* AAGCN attention gates (csrc/aagcn.hip; reference gcn.py:447-459: y <- y * sigmoid(.) + y, three times).
  * out = y * (1 + g), g broadcast by mode: 0 g (n, V) per joint, 1 g (n, T) per frame, 2 g (n, C) per channel;

@@ -399,7 +399,7 @@ def test_temporal_ms(n, C, T, V, stride, fused, monkeypatch):
     (branch_act -> tapconv -> combine); 'split': the split layout (csrc/tmsplit.hip: no (V+1)-column tensors) wherever
     the shape is eligible (stride 1, T % 4 == 0).  All against the fp64 statement of the op."""
     monkeypatch.setattr(K, 'FUSED_TEMPORAL', '0' if fused == 'split' else fused)
-    monkeypatch.setattr(K, 'SPLIT_TEMPORAL', '1' if fused == 'split' else '0')
+    monkeypatch.setattr(K, 'SPLIT_TEMPORAL', '2' if fused == 'split' else '0')
     g = torch.Generator().manual_seed(C + T + stride)
     cfg = [(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1']
     mid = C // 6

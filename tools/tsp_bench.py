@@ -13,6 +13,7 @@ if os.environ.get('TS_EXP'):
     assert native._lib.dsgcn_tms_split_tuning(0, int(os.environ['TS_EXP'])) == 0
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+STRIDE = int(os.environ.get('TS_STRIDE', 1))      # 2: the two stride-2 units of the network (128 ch: T 64 -> 32, 256 ch: T 32 -> 16)
 dev = torch.device('cuda')
 cfg = [(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1']
 
@@ -27,12 +28,12 @@ def make(C, T, V, seed=0):
              shift=torch.cat([torch.randn(n_act, generator=g) * 0.3, torch.zeros(mid)]).to(dev),
              cw=[r(w, w, 3, 1, scale=(3 * w) ** -0.5) for w in widths[:4]], cb=[r(w, scale=0.1) for w in widths[:4]],
              coeff=r(25, scale=0.5), gamma=(torch.rand(C, generator=g) + 0.5).to(dev), beta=r(C, scale=0.2),
-             gf=r(n, C, T, V), gsc=r(C), gsh=r(C), widths=widths, n_act=n_act)
+             gf=r(n, C, T // STRIDE, V), gsc=r(C), gsh=r(C), widths=widths, n_act=n_act)
     return d
 
 
 def run(d, split, time_it):
-    K.SPLIT_TEMPORAL = '1' if split else '0'
+    K.SPLIT_TEMPORAL = '2' if split else '0'
     K.FUSED_TEMPORAL = '0'
     leaves = {k: d[k].clone().requires_grad_() for k in ('z', 'zaug', 'scale', 'shift', 'coeff', 'gamma', 'beta')}
     tw = [w.clone().requires_grad_() for w in d['cw']]
@@ -40,7 +41,7 @@ def run(d, split, time_it):
 
     def fwd():
         return K.temporal_ms(leaves['z'], leaves['zaug'], leaves['scale'], leaves['shift'], d['n_act'], cfg, d['widths'], tw, tb,
-                             leaves['coeff'], 1, leaves['gamma'], leaves['beta'], 1e-5, True)
+                             leaves['coeff'], STRIDE, leaves['gamma'], leaves['beta'], 1e-5, True)
 
     def loss(out):
         f, sc, sh = out[0], out[1], out[2]
@@ -77,9 +78,9 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-for C, T in ((64, 64), (128, 32), (256, 16)):
+for C, T in (((64, 64), (128, 32), (256, 16)) if STRIDE == 1 else ((128, 64), (256, 32))):
     d = make(C, T, 25, seed=C)
-    ok = native.lib().dsgcn_tms_split_rows(-1, n, C, T, 25, 1, 3, 6, K._int_array([0, 0, 0, 0, 1, 2]),
+    ok = native.lib().dsgcn_tms_split_rows(-1, n, C, T, 25, STRIDE, 3, 6, K._int_array([0, 0, 0, 0, 1, 2]),
                                            K._int_array([sum(d['widths'][:i]) for i in range(6)]), K._int_array(d['widths']),
                                            K._int_array([1, 2, 3, 4, 1, 1]))
     r0, f0, b0 = run(d, False, True)
@@ -101,7 +102,7 @@ for C, T in ((64, 64), (128, 32), (256, 16)):
                 r_, _, _ = run(d, True, False)      # fwd then bwd launch: the stamps are of the LAST k_tsp launch = backward
                 ph = np.zeros(16, dtype=np.int64)
                 if split_dir == 'fwd':
-                    K.SPLIT_TEMPORAL = '1'; K.FUSED_TEMPORAL = '0'
+                    K.SPLIT_TEMPORAL = '2'; K.FUSED_TEMPORAL = '0'
                     with torch.no_grad():
                         K.temporal_ms(d['z'], d['zaug'], d['scale'], d['shift'], d['n_act'], cfg, d['widths'], d['cw'], d['cb'],
                                       d['coeff'], 1, d['gamma'], d['beta'], 1e-5, True)
