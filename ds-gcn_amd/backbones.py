@@ -53,6 +53,13 @@ class _FusedBlock(nn.Module):
 
     xbar_ld = True           # layout of the time mean handed to the next block: True = (n, C, V); an int = padded joint row
 
+    def wants_prestrided(self):
+        """True when the block residual is a 1x1 conv at stride 2 on the plain block input (dgstgcn.py:35-40): the previous
+        block's fuse_out then writes the even frames as a tensor of their own (kernels._FuseOut, tee = 2)."""
+        r = self.residual if self.residual_kind == 'conv' else None
+        return (isinstance(r, unit_tcn) and r.kernel_size == 1 and r.stride == 2 and kernels.ops() is kernels
+                and kernels.PRESTRIDED)
+
     def forward_fused(self, x, xbar=None, want_xbar=False, tee=False):
         # the block input has up to three consumers (gcn main path, gcn residual operand, block residual): give each its
         # own alias so that their gradients are summed in one place instead of autograd's pairwise adds — inside the
@@ -227,7 +234,10 @@ class _SkeletonBackbone(nn.Module):
         xbar = None
         last = len(blocks) - 1
         for i, blk in enumerate(blocks):
-            x, xbar = blk.forward_fused(x, xbar, needs_xbar and i < last, tee=i < last)
+            tee = i < last
+            if tee and getattr(blocks[i + 1], 'wants_prestrided', lambda: False)():
+                tee = 2                     # the next block's residual conv reads the even frames only: hand them over as a tensor
+            x, xbar = blk.forward_fused(x, xbar, needs_xbar and i < last, tee=tee)
         flush_running_stats()
         return x
 

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
                                                      const float* __restrict__ h1, const float* __restrict__ x2,
                                                      const float* __restrict__ s2, const float* __restrict__ h2,
                                                      int relu, float* __restrict__ out, float* __restrict__ xbar, int C,
-                                                     int T, int V, int vec, int ld) {
+                                                     int T, int V, int vec, int ld, float* __restrict__ out_s2) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   const long plane = blockIdx.x;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
       }
       if (relu & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       qo[i] = v;
-      if (xbar) ql[i] = v;
+      if (xbar || out_s2) ql[i] = v;
     }
   } else {
     for (int i = lane; i < L; i += 64) {
@@ -55,11 +55,38 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
       if (p2) v += fmaf(p2[i], a2, b2);
       if (relu & 1) v = fmaxf(v, 0.f);
       po[i] = v;
-      if (xbar) lds[i] = v;
+      if (xbar || out_s2) lds[i] = v;
+    }
+  }
+  if (xbar || out_s2) wave_lds_sync();
+  if (out_s2) {
+    // the even frames as a tensor of their own, (n, C, ceil(T/2), V): what a stride-2 block's residual conv reads (it used to
+    // be a strided-copy launch of its own, and its backward a scatter into a zero-filled full-size tensor)
+    const int T2 = (T + 1) >> 1, L2 = T2 * V;
+    float* ps = out_s2 + (size_t)plane * L2;
+    const float invV = 1.f / (float)V;
+    if ((L2 & 3) == 0) {
+      f32x4* q4 = reinterpret_cast<f32x4*>(ps);
+      for (int i = lane; i < (L2 >> 2); i += 64) {
+        int t, v;
+        divmod_small(4 * i, V, invV, t, v);
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          r[k] = lds[2 * t * V + v];
+          if (++v == V) { v = 0; ++t; }
+        }
+        q4[i] = f32x4{r[0], r[1], r[2], r[3]};
+      }
+    } else {
+      for (int i = lane; i < L2; i += 64) {
+        int t, v;
+        divmod_small(i, V, invV, t, v);
+        ps[i] = lds[2 * t * V + v];
+      }
     }
   }
   if (xbar) {
-    wave_lds_sync();
     if (lane < ld) {                              // ld >= V: the joint row is zero-padded to ld (ld <= 64)
       float s = 0.f;
       if (lane < V)
@@ -76,7 +103,7 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
                                                      const float* __restrict__ dout2, const float* __restrict__ dout3,
                                                      const float* __restrict__ dxbar, float* __restrict__ dx1,
                                                      float* __restrict__ dx2, float* __restrict__ part, int C, int T,
-                                                     int V, int ld) {
+                                                     int V, int ld, int s3) {
   __shared__ float dxb[32];
   const int lane = threadIdx.x;
   const long plane = blockIdx.x;
@@ -90,12 +117,13 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
   const float* __restrict__ p2 = x2 ? x2 + (size_t)plane * L : nullptr;
   const float* __restrict__ pg = dout ? dout + (size_t)plane * L : nullptr;
   const float* __restrict__ pg2 = dout2 ? dout2 + (size_t)plane * L : nullptr;
-  const float* __restrict__ pg3 = dout3 ? dout3 + (size_t)plane * L : nullptr;
+  // s3 = 2: dout3 is the gradient of the even-frame copy (n, C, ceil(T/2), V): it reaches the even frames only
+  const float* __restrict__ pg3 = dout3 ? dout3 + (size_t)plane * (s3 == 2 ? ((T + 1) >> 1) * V : L) : nullptr;
   float* __restrict__ o1 = dx1 + (size_t)plane * L;
   float* __restrict__ o2 = dx2 ? dx2 + (size_t)plane * L : nullptr;
   float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
-  int v = lane % V;                      // joint index of element `lane`; advances by 64 % V per iteration
-  const int step = 64 % V;
+  int v = lane % V, t = lane / V;        // joint / frame of element `lane`; advance by 64 % V / 64 / V per iteration
+  const int step = 64 % V, tstep = 64 / V;
 #pragma unroll 5
   for (int i = lane; i < L; i += 64) {
     const float xa = p1[i];
@@ -105,7 +133,10 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
     if (p2) pre += fmaf(xb, a2, b2);
     float g = pg ? pg[i] : 0.f;
     if (pg2) g += pg2[i];              // (a + b) + c, then the time-mean term: the order dsgcn_add3 + this kernel had
-    if (pg3) g += pg3[i];
+    if (pg3) {
+      if (s3 == 2) { if (!(t & 1)) g += pg3[(t >> 1) * V + v]; }
+      else g += pg3[i];
+    }
     g += dxb[v];
     if ((relu & 1) && !(pre > 0.f)) g = 0.f;
     const float g1 = ((relu & 2) && !(pre1 > 0.f)) ? 0.f : g;     // gradient of the first term
@@ -116,7 +147,8 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
     u2 = fmaf(g, xb, u2);
     u3 += g1;
     v += step;
-    if (v >= V) v -= V;
+    t += tstep;
+    if (v >= V) { v -= V; ++t; }
   }
   if (part) {
     u0 = wave_sum(u0);
@@ -136,16 +168,34 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
 
 extern "C" {
 
+int dsgcn_fuse_out_fwd2(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                        const float* h2, int relu, float* out, float* out_s2, float* xbar, int n, int C, int T, int V,
+                        int xbar_ld, void* stream);
+int dsgcn_fuse_out_bwd3s(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                         const float* h2, int relu, const float* dout, const float* dout2, const float* dout3, int stride3,
+                         const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
+                         void* stream);
+
 int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, float* out, float* xbar, int n, int C, int T, int V, int xbar_ld,
                        void* stream) {
   if (!x1 || !out || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (s1 && !h1) || (s2 && !h2)) return DSGCN_EINVAL;
   if (xbar && (xbar_ld < V || xbar_ld > 64)) return DSGCN_EINVAL;
+  return dsgcn_fuse_out_fwd2(x1, s1, h1, x2, s2, h2, relu, out, nullptr, xbar, n, C, T, V, xbar_ld, stream);
+}
+
+// out_s2 (NULL or (n, C, ceil(T/2), V)): the even frames of `out` as a second, contiguous output — the operand of a
+// stride-2 block's 1x1 residual conv (reference: unit_tcn(kernel_size=1, stride=2) of the block residual, dgstgcn.py:35-40)
+int dsgcn_fuse_out_fwd2(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                        const float* h2, int relu, float* out, float* out_s2, float* xbar, int n, int C, int T, int V,
+                        int xbar_ld, void* stream) {
+  if (!x1 || !out || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (s1 && !h1) || (s2 && !h2)) return DSGCN_EINVAL;
+  if (xbar && (xbar_ld < V || xbar_ld > 64)) return DSGCN_EINVAL;
   const int vec = ((T * V) % 4 == 0) ? 1 : 0;
-  const size_t lds = xbar ? (size_t)T * V * sizeof(float) : 0;
+  const size_t lds = (xbar || out_s2) ? (size_t)T * V * sizeof(float) : 0;
   if (lds > 64 * 1024) return DSGCN_EUNSUPPORTED;
   hipLaunchKernelGGL(k_fuse_out_fwd, dim3((unsigned)((long)n * C)), dim3(64), lds, (hipStream_t)stream, x1, s1, h1, x2,
-                     s2, h2, relu, out, xbar, C, T, V, vec, xbar_ld);
+                     s2, h2, relu, out, xbar, C, T, V, vec, xbar_ld, out_s2);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -158,11 +208,21 @@ int dsgcn_fuse_out_bwd3(const float* x1, const float* s1, const float* h1, const
                         const float* h2, int relu, const float* dout, const float* dout2, const float* dout3,
                         const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
                         void* stream) {
+  return dsgcn_fuse_out_bwd3s(x1, s1, h1, x2, s2, h2, relu, dout, dout2, dout3, 1, dxbar, dx1, dx2, part, n, C, T, V, xbar_ld,
+                              stream);
+}
+
+// stride3 = 2: dout3 is the gradient of dsgcn_fuse_out_fwd2's even-frame output, (n, C, ceil(T/2), V)
+int dsgcn_fuse_out_bwd3s(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                         const float* h2, int relu, const float* dout, const float* dout2, const float* dout3, int stride3,
+                         const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
+                         void* stream) {
   if (!x1 || !dx1 || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (x2 && !dx2)) return DSGCN_EINVAL;
   if (dxbar && xbar_ld < V) return DSGCN_EINVAL;
   if ((dout2 || dout3) && !dout) return DSGCN_EINVAL;
+  if (stride3 != 1 && stride3 != 2) return DSGCN_EINVAL;
   hipLaunchKernelGGL(k_fuse_out_bwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, x1, s1, h1, x2,
-                     s2, h2, relu, dout, dout2, dout3, dxbar, dx1, dx2, part, C, T, V, xbar_ld);
+                     s2, h2, relu, dout, dout2, dout3, dxbar, dx1, dx2, part, C, T, V, xbar_ld, stride3);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -415,7 +415,11 @@ __device__ __forceinline__ void ts_conv(const TSArgs& a, const TSBranch& br, boo
           if (S2 || tap != 1) v *= mk[tap][q];
           b[q] = v;
         }
-      } else if (S2 || (ODD && tap != 1)) {
+      } else if (S2) {
+        // (a select, not a product: the masked elements of the one load may come from the uninitialised front pad)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = mk[tap][q] != 0.f ? b[q] : 0.f;
+      } else if (ODD && tap != 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) b[q] *= mk[tap][q];
       }
@@ -673,7 +677,7 @@ __device__ __forceinline__ void ts_elem2(const TSArgs& a, const TSBranch& br, fl
     }
     wave_lds_sync();
     float* fo = a.f + plane * Lo;
-    double sv = 0.0, qv = 0.0;
+    float sf = 0.f, qf = 0.f;                      // (<= 32 values per lane: fp32; the wave's sum in fp64)
     for (int e = lane; e < Lo; e += 64) {
       int tp, v;
       divmod_small(e, V, invV, tp, v);
@@ -685,12 +689,12 @@ __device__ __forceinline__ void ts_elem2(const TSArgs& a, const TSBranch& br, fl
       }
       const float r = fmaf(oa[tp], cf[v], x);
       fo[e] = r;
-      sv += (double)r;
-      qv = fma((double)r, (double)r, qv);
+      sf += r;
+      qf = fmaf(r, r, qf);
     }
     if (a.stats) {
-      sv = wave_sum_d(sv);
-      qv = wave_sum_d(qv);
+      const double sv = wave_sum_d((double)sf);
+      const double qv = wave_sum_d((double)qf);
       if (lane == 0) {
         a.stats[((size_t)(a.ngrp + n) * C + cc) * 2 + 0] = (float)sv;
         a.stats[((size_t)(a.ngrp + n) * C + cc) * 2 + 1] = (float)qv;
@@ -712,15 +716,28 @@ __device__ __forceinline__ void ts_elem2(const TSArgs& a, const TSBranch& br, fl
     };
     float* dzo = a.dz + plane * Li;
     float u0 = 0.f, u1 = 0.f;
-    for (int e = lane; e < Li; e += 64) {
-      int t, v;
-      divmod_small(e, V, invV, t, v);
-      const float x = hp[e];
-      float g = route([&](int r) { return act(hp[r * V + v]); }, gp + v, t, V);
-      if (relu && !(fmaf(x, s, b) > 0.f)) g = 0.f;
-      dzo[e] = g * s;
-      u0 = fmaf(g, x, u0);
-      u1 += g;
+    if (pool) {
+      for (int e = lane; e < Li; e += 64) {
+        int t, v;
+        divmod_small(e, V, invV, t, v);
+        const float x = hp[e];
+        float g = route([&](int r) { return act(hp[r * V + v]); }, gp + v, t, V);
+        if (relu && !(fmaf(x, s, b) > 0.f)) g = 0.f;
+        dzo[e] = g * s;
+        u0 = fmaf(g, x, u0);
+        u1 += g;
+      }
+    } else {
+      for (int e = lane; e < Li; e += 64) {
+        int t, v;
+        divmod_small(e, V, invV, t, v);
+        const float x = hp[e];
+        float g = (t & 1) ? 0.f : gp[(t >> 1) * V + v];
+        if (relu && !(fmaf(x, s, b) > 0.f)) g = 0.f;
+        dzo[e] = g * s;
+        u0 = fmaf(g, x, u0);
+        u1 += g;
+      }
     }
     for (int t = lane; t < Ti; t += 64) {
       const float x = za[t];

@@ -65,6 +65,9 @@ FUSED_TEMPORAL = _os.environ.get('DSGCN_FUSED_TEMPORAL', 'auto')
 # dgmstcn units (kernel 3) on the split layout of csrc/tmsplit.hip: '2' (default) = stride 1 and 2, '1' = stride 1 only,
 # '0' = the staged three-kernel form everywhere
 SPLIT_TEMPORAL = _os.environ.get('DSGCN_SPLIT_TEMPORAL', '2')
+# '1': a block whose stride-2 residual conv reads the plain block input gets the even frames from the previous block's
+# fuse_out (a second output of that launch) instead of a strided-copy launch of its own
+PRESTRIDED = _os.environ.get('DSGCN_PRESTRIDED', '1') != '0'
 
 
 class side_branch:
@@ -1871,7 +1874,10 @@ def tee3(x):
 class _FuseOut(torch.autograd.Function):
     """-> (out, out', out'', xbar): with ``tee`` the output comes as three aliases, one per consumer in the next block
     (spatial unit, its residual operand, block residual), and the backward sums their gradients while loading them —
-    autograd's own accumulation would be two more launches and a materialised sum (the round-2 dsgcn_add3 pass)."""
+    autograd's own accumulation would be two more launches and a materialised sum (the round-2 dsgcn_add3 pass).
+    ``tee`` = 2: the third output is not an alias but the EVEN FRAMES of out as a tensor of their own — what the 1x1
+    residual conv of a stride-2 block reads (dgstgcn.py:35-40); its gradient comes back in that shape and is added on
+    the even frames inside the same backward launch (no strided-copy launch, no scatter into a zero-filled tensor)."""
 
     @staticmethod
     def forward(ctx, x1, s1, h1, x2, s2, h2, relu, xbar_ld, tee):
@@ -1879,15 +1885,19 @@ class _FuseOut(torch.autograd.Function):
         x1, s1, h1, x2, s2, h2 = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2)]
         n, C, T, V = x1.shape
         out = torch.empty_like(x1)
+        out_s2 = torch.empty((n, C, (T + 1) // 2, V), device=x1.device, dtype=torch.float32) if tee == 2 else None
         xbar = torch.empty((n, C, xbar_ld), device=x1.device, dtype=torch.float32) if xbar_ld else None
-        rc = native.lib().dsgcn_fuse_out_fwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu),
-                                             _ptr(out), _ptr(xbar), n, C, T, V, int(xbar_ld), _stream())
-        native.check(rc, 'dsgcn_fuse_out_fwd')
+        rc = native.lib().dsgcn_fuse_out_fwd2(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu),
+                                              _ptr(out), _ptr(out_s2), _ptr(xbar), n, C, T, V, int(xbar_ld), _stream())
+        native.check(rc, 'dsgcn_fuse_out_fwd2')
         ctx.save_for_backward(x1, s1, h1, x2, s2, h2)
         ctx.relu = int(relu)
         ctx.xbar_ld = int(xbar_ld)
+        ctx.tee = int(tee)
         ctx.bn1, ctx.bn2 = _bn_of(s1), _bn_of(s2)
         ctx.set_materialize_grads(False)
+        if tee == 2:
+            return out, out.view_as(out), out_s2, xbar
         if tee:
             return out, out.view_as(out), out.view_as(out), xbar
         return out, None, None, xbar
@@ -1896,17 +1906,27 @@ class _FuseOut(torch.autograd.Function):
     def backward(ctx, dout, dout2, dout3, dxbar):
         x1, s1, h1, x2, s2, h2 = ctx.saved_tensors
         n, C, T, V = x1.shape
-        douts = [_f32c(g) for g in (dout, dout2, dout3) if g is not None]
-        douts += [None] * (3 - len(douts))
+        stride3 = 1
+        if ctx.tee == 2:
+            # the third stream has the even-frame shape: it keeps its slot (the kernel needs a first stream to add it to)
+            d3 = _f32c(dout3)
+            full = [_f32c(g) for g in (dout, dout2) if g is not None]
+            if d3 is not None and not full:
+                full = [torch.zeros_like(x1)]
+            douts = full + [None] * (2 - len(full)) + [d3]
+            stride3 = 2 if d3 is not None else 1
+        else:
+            douts = [_f32c(g) for g in (dout, dout2, dout3) if g is not None]
+            douts += [None] * (3 - len(douts))
         dxbar = _f32c(dxbar)
         dx1 = torch.empty_like(x1)
         dx2 = torch.empty_like(x2) if x2 is not None else None
         need_part = s1 is not None or s2 is not None
         part = torch.empty((n, C, 4), device=x1.device, dtype=torch.float32) if need_part else None
-        rc = native.lib().dsgcn_fuse_out_bwd3(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
-                                              _ptr(douts[0]), _ptr(douts[1]), _ptr(douts[2]), _ptr(dxbar), _ptr(dx1),
-                                              _ptr(dx2), _ptr(part), n, C, T, V, ctx.xbar_ld or V, _stream())
-        native.check(rc, 'dsgcn_fuse_out_bwd3')
+        rc = native.lib().dsgcn_fuse_out_bwd3s(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
+                                               _ptr(douts[0]), _ptr(douts[1]), _ptr(douts[2]), stride3, _ptr(dxbar),
+                                               _ptr(dx1), _ptr(dx2), _ptr(part), n, C, T, V, ctx.xbar_ld or V, _stream())
+        native.check(rc, 'dsgcn_fuse_out_bwd3s')
         ds1 = dh1 = ds2 = dh2 = None
         if need_part and (s1 is None or ctx.bn1 is not None) and (s2 is None or ctx.bn2 is not None):
             if s1 is not None:
@@ -1926,9 +1946,12 @@ def fuse_out(x1, a1, x2, a2, relu, want_tmean=False, tee=False):
     """relu: bool, or int flags — bit 0 the outer ReLU, bit 1 a ReLU on the first term before the add.
     want_tmean: False / True (time mean (n, C, V)) / an int ld >= V (time mean with the joint row zero-padded to ld: the
     layout `dynadj` consumes directly).
-    tee: return the output as a tuple of three aliases (see _FuseOut) for the next block's three reads."""
+    tee: return the output as a tuple of three aliases (see _FuseOut) for the next block's three reads; tee = 2: the third
+    one is the even-frame tensor (n, C, ceil(T/2), V), marked ``_dsgcn_prestrided = 2`` for the stride-2 residual conv."""
     s1, h1 = a1 if a1 is not None else (None, None)
     s2, h2 = a2 if a2 is not None else (None, None)
     ld = 0 if not want_tmean else (x1.shape[-1] if want_tmean is True else int(want_tmean))
-    o1, o2, o3, xbar = _FuseOut.apply(x1, s1, h1, x2, s2, h2, int(relu), ld, bool(tee))
+    o1, o2, o3, xbar = _FuseOut.apply(x1, s1, h1, x2, s2, h2, int(relu), ld, int(tee))
+    if int(tee) == 2:
+        o3._dsgcn_prestrided = 2
     return ((o1, o2, o3) if tee else o1), xbar

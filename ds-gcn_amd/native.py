@@ -94,6 +94,8 @@ SIGNATURES = {
     'dsgcn_fuse_out_fwd': [c_f] * 6 + [c_int] + [c_f] * 2 + [c_int] * 5 + [c_st],
     'dsgcn_fuse_out_bwd': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 5 + [c_st],
     'dsgcn_fuse_out_bwd3': [c_f] * 6 + [c_int] + [c_f] * 7 + [c_int] * 5 + [c_st],
+    'dsgcn_fuse_out_fwd2': [c_f] * 6 + [c_int] + [c_f] * 3 + [c_int] * 5 + [c_st],
+    'dsgcn_fuse_out_bwd3s': [c_f] * 6 + [c_int] + [c_f] * 3 + [c_int] + [c_f] * 4 + [c_int] * 5 + [c_st],
     'dsgcn_dwcausal_fwd': [c_f, c_f, c_f, c_i, c_f] + [c_int] * 6 + [c_st],
     'dsgcn_dwcausal_bwd': [c_f, c_f, c_i, c_f, c_f, c_f] + [c_int] * 6 + [c_st],
     'dsgcn_gate_fwd': [c_f, c_f, c_int, c_f, c_f] + [c_int] * 5 + [c_st],

@@ -46,7 +46,9 @@ class unit_tcn(nn.Module):
         has_bn = isinstance(self.bn, nn.BatchNorm2d)
         if self.kernel_size == 1:
             stride = self.stride
-            if stride > 1 and d.a1 is None and d.x2 is None and not d.relu and hasattr(ops, 'strided_frames'):
+            if stride > 1 and d.a1 is None and d.x2 is None and not d.relu and getattr(d.x1, '_dsgcn_prestrided', 0) == stride:
+                stride = 1                      # the producer already handed over the kept frames (kernels._FuseOut, tee = 2)
+            elif stride > 1 and d.a1 is None and d.x2 is None and not d.relu and hasattr(ops, 'strided_frames'):
                 # a plain input (the block residual): pick the kept frames first (one strided-copy launch, tapconv's
                 # pass-through window) and run the channel mix on the compact tensor — the strided 1x1 conv has only the
                 # scalar-load kernels (planes of every other 25-joint row are not 16-byte runs): 290 -> ~125 us per block

@@ -82,6 +82,17 @@ int dsgcn_fuse_out_bwd3(const float* x1, const float* s1, const float* h1, const
                         const float* h2, int relu, const float* dout, const float* dout2, const float* dout3,
                         const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
                         void* stream);
+/* The even frames as a second output / as the shape of the third gradient stream: a stride-2 block's 1x1 residual conv
+ * (reference: the block residual unit_tcn(kernel_size=1, stride=2), dgstgcn.py:35-40 + tcn.py:21-28) reads out[:, :, ::2];
+ * dsgcn_fuse_out_fwd2 writes that tensor, out_s2 (n, C, ceil(T/2), V) or NULL, beside `out`, and dsgcn_fuse_out_bwd3s with
+ * stride3 = 2 takes dout3 in that shape (added on the even frames) — no strided-copy launch, no zero-filled scatter. */
+int dsgcn_fuse_out_fwd2(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                        const float* h2, int relu, float* out, float* out_s2, float* xbar, int n, int C, int T, int V,
+                        int xbar_ld, void* stream);
+int dsgcn_fuse_out_bwd3s(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                         const float* h2, int relu, const float* dout, const float* dout2, const float* dout3, int stride3,
+                         const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
+                         void* stream);
 
 /* Dense (KT,1) temporal conv as a GEMM on bf16 terms (csrc/tcg.hip): unit_tcn's Conv2d((9,1), padding 4) + the statistics
  * of its BatchNorm (tcn.py:21-28), stride 1 or 2 (T = input frames, z has ceil(T/stride)), dilation 1, KT odd <= 9,

@@ -416,6 +416,7 @@ def test_deferred_parameter_sums_are_bit_identical(name):
     x, y = torch.from_numpy(z['x']).cuda(), torch.from_numpy(z['label']).cuda()
     grads = []
     for deferred in (False, True):
+        K.reset_leaf_uses()            # what TrainEngine does at the start of every step (leaf ids of a freed model may come back)
         m = D.build_model(cfg)
         m.load_state_dict(sd_of(z, 'sd_', torch.float32))
         m = m.cuda().train()
