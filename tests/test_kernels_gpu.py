@@ -381,6 +381,44 @@ def test_fuse_out(n, C, T, V, mode, tmean, flags):
         assert rel(got[k].detach().cpu(), v.detach()) < 1e-5, (k, rel(got[k].detach().cpu(), v.detach()))
 
 
+@pytest.mark.parametrize('n,C,T,V', [(2, 16, 16, 25), (3, 8, 9, 25), (2, 12, 7, 17), (1, 64, 64, 25)])
+@pytest.mark.parametrize('streams', [3, 2, 1])
+def test_fuse_out_even_frame_output(n, C, T, V, streams):
+    """fuse_out(tee=2): the third output is out[:, :, ::2] as a tensor of its own (what a stride-2 block's 1x1 residual conv
+    reads, dgstgcn.py:35-40) and its gradient comes back in that shape — against the three-alias form with the strided
+    slice taken by torch (odd frame counts, planes that are not multiples of four floats, missing alias gradients)."""
+    g = torch.Generator().manual_seed(C + T + streams)
+    x1, x2 = _rand(g, n, C, T, V), _rand(g, n, C, T, V)
+    a1 = (torch.rand(C, generator=g) + 0.5, _rand(g, C, scale=0.3))
+    T2 = (T + 1) // 2
+    ga, gb, gc, gx = _rand(g, n, C, T, V), _rand(g, n, C, T, V), _rand(g, n, C, T2, V), _rand(g, n, C, V)
+
+    def run(even):
+        tx1, tx2 = x1.to(DEV).requires_grad_(), x2.to(DEV).requires_grad_()
+        ta1 = (a1[0].to(DEV).requires_grad_(), a1[1].to(DEV).requires_grad_())
+        (oa, ob, oc), xbar = K.fuse_out(tx1, ta1, tx2, None, True, True, 2 if even else True)
+        if even:
+            assert oc.shape == (n, C, T2, V) and getattr(oc, '_dsgcn_prestrided', 0) == 2
+            oc_s = oc
+        else:
+            oc_s = oc[:, :, ::2]
+        loss = (oc_s * gc.to(DEV)).sum() + (xbar * gx.to(DEV)).sum()
+        if streams >= 2:
+            loss = loss + (oa * ga.to(DEV)).sum()
+        if streams >= 3:
+            loss = loss + (ob * gb.to(DEV)).sum()
+        loss.backward()
+        return dict(out=oa, oc=oc_s, xbar=xbar, dx1=tx1.grad, dx2=tx2.grad, ds1=ta1[0].grad, dh1=ta1[1].grad)
+
+    got, ref = run(True), run(False)
+    for k, v in ref.items():
+        if k in ('out', 'oc', 'xbar'):
+            assert torch.equal(got[k], v), k
+        else:
+            # the alias form adds the zero-interleaved slice gradient through autograd (a different order of the adds)
+            assert rel(got[k].cpu(), v.cpu().double()) < 1e-6, (k, rel(got[k].cpu(), v.cpu().double()))
+
+
 @pytest.mark.parametrize('n,C,T,V,stride', [(2, 64, 32, 25, 1), (2, 128, 32, 25, 2), (2, 48, 20, 17, 1), (1, 12, 9, 18, 2),
                                             # the fused stage (csrc/tms.hip): full tiles, a ragged last tile, two tiles per
                                             # sample at stride 2, three m-tiles, K400 planes
