@@ -164,6 +164,83 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
   }
 }
 
+// 16-byte form of k_fuse_out_bwd for planes of T*V % 4 == 0: every stream moves as float4, the loads of an iteration
+// are all issued before its arithmetic, absent streams are compile-time (no predicated loads: those become branches and
+// serial waits).  NG = number of full-size gradient streams (1..3); S3 = the even-frame third stream of fuse_out_fwd2.
+template <int NG, bool S3, bool X2>
+__global__ __launch_bounds__(64) void k_fuse_out_bwd4(const float* __restrict__ x1, const float* __restrict__ s1,
+                                                      const float* __restrict__ h1, const float* __restrict__ x2,
+                                                      const float* __restrict__ s2, const float* __restrict__ h2,
+                                                      int relu, const float* __restrict__ dout,
+                                                      const float* __restrict__ dout2, const float* __restrict__ dout3,
+                                                      const float* __restrict__ dxbar, float* __restrict__ dx1,
+                                                      float* __restrict__ dx2, float* __restrict__ part, int C, int T,
+                                                      int V, int ld) {
+  __shared__ float dxb[32];
+  const int lane = threadIdx.x;
+  const long plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const int L = T * V, L4 = L >> 2;
+  const float a1 = s1 ? s1[c] : 1.f, b1 = s1 ? h1[c] : 0.f;
+  const float a2 = s2 ? s2[c] : 1.f, b2 = s2 ? h2[c] : 0.f;
+  if (lane < V) dxb[lane] = dxbar ? dxbar[(size_t)plane * ld + lane] / (float)T : 0.f;
+  wave_lds_sync();
+  const f32x4* __restrict__ p1 = reinterpret_cast<const f32x4*>(x1 + (size_t)plane * L);
+  const f32x4* __restrict__ p2 = X2 ? reinterpret_cast<const f32x4*>(x2 + (size_t)plane * L) : nullptr;
+  const f32x4* __restrict__ pg = reinterpret_cast<const f32x4*>(dout + (size_t)plane * L);
+  const f32x4* __restrict__ pg2 = NG >= 2 ? reinterpret_cast<const f32x4*>(dout2 + (size_t)plane * L) : nullptr;
+  const f32x4* __restrict__ pg3 = (NG >= 3 && !S3) ? reinterpret_cast<const f32x4*>(dout3 + (size_t)plane * L) : nullptr;
+  const float* __restrict__ ps3 = S3 ? dout3 + (size_t)plane * (((T + 1) >> 1) * V) : nullptr;
+  f32x4* __restrict__ o1 = reinterpret_cast<f32x4*>(dx1 + (size_t)plane * L);
+  f32x4* __restrict__ o2 = X2 ? reinterpret_cast<f32x4*>(dx2 + (size_t)plane * L) : nullptr;
+  const float invV = 1.f / (float)V;
+  float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+  for (int i = lane; i < L4; i += 64) {
+    const f32x4 xa = p1[i];
+    f32x4 xb = {0.f, 0.f, 0.f, 0.f}, g = pg[i];
+    if constexpr (X2) xb = p2[i];
+    if constexpr (NG >= 2) { const f32x4 w = pg2[i]; g.x += w.x; g.y += w.y; g.z += w.z; g.w += w.w; }
+    if constexpr (NG >= 3 && !S3) { const f32x4 w = pg3[i]; g.x += w.x; g.y += w.y; g.z += w.z; g.w += w.w; }
+    int t, v;
+    divmod_small(4 * i, V, invV, t, v);
+    f32x4 r1, r2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gg = g[k];
+      if constexpr (S3) { if (!(t & 1)) gg += ps3[(t >> 1) * V + v]; }
+      gg += dxb[v];
+      const float pre1 = fmaf(xa[k], a1, b1);
+      float pre = (relu & 2) ? fmaxf(pre1, 0.f) : pre1;
+      if constexpr (X2) pre += fmaf(xb[k], a2, b2);
+      if ((relu & 1) && !(pre > 0.f)) gg = 0.f;
+      const float g1 = ((relu & 2) && !(pre1 > 0.f)) ? 0.f : gg;
+      r1[k] = g1 * a1;
+      r2[k] = gg * a2;
+      u0 = fmaf(g1, xa[k], u0);
+      u1 += gg;
+      u2 = fmaf(gg, xb[k], u2);
+      u3 += g1;
+      if (++v == V) { v = 0; ++t; }
+    }
+    o1[i] = r1;
+    if constexpr (X2) o2[i] = r2;
+  }
+  if (part) {
+    u0 = wave_sum(u0);
+    u1 = wave_sum(u1);
+    u2 = wave_sum(u2);
+    u3 = wave_sum(u3);
+    if (lane == 0) {
+      part[(size_t)plane * 4 + 0] = u0;
+      part[(size_t)plane * 4 + 1] = u1;
+      part[(size_t)plane * 4 + 2] = u2;
+      part[(size_t)plane * 4 + 3] = u3;
+    }
+  }
+}
+
+int g_fo_vec = 1;        // 16-byte backward where the plane allows it (lab A/B: 0 = the scalar form everywhere)
+
 }  // namespace
 
 extern "C" {
@@ -221,11 +298,42 @@ int dsgcn_fuse_out_bwd3s(const float* x1, const float* s1, const float* h1, cons
   if (dxbar && xbar_ld < V) return DSGCN_EINVAL;
   if ((dout2 || dout3) && !dout) return DSGCN_EINVAL;
   if (stride3 != 1 && stride3 != 2) return DSGCN_EINVAL;
-  hipLaunchKernelGGL(k_fuse_out_bwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, x1, s1, h1, x2,
-                     s2, h2, relu, dout, dout2, dout3, dxbar, dx1, dx2, part, C, T, V, xbar_ld, stride3);
+  const dim3 grid((unsigned)((long)n * C)), blk(64);
+  hipStream_t st = (hipStream_t)stream;
+  // the summation order of the scalar form: ((dout + dout2) + dout3) + the time-mean term
+  if (g_fo_vec && dout && (T * V) % 4 == 0 && !(dout3 && !dout2 && stride3 == 1)) {
+    const int ng = dout3 && stride3 == 1 ? 3 : (dout2 ? 2 : 1);
+    const bool s3 = dout3 && stride3 == 2;
+#define FO4(NGV, S3V, X2V) hipLaunchKernelGGL((k_fuse_out_bwd4<NGV, S3V, X2V>), grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, \
+                                              dout, dout2, dout3, dxbar, dx1, dx2, part, C, T, V, xbar_ld)
+    if (x2) {
+      if (s3) { if (ng == 2) FO4(2, true, true); else FO4(1, true, true); }
+      else if (ng == 3) FO4(3, false, true);
+      else if (ng == 2) FO4(2, false, true);
+      else FO4(1, false, true);
+    } else {
+      if (s3) { if (ng == 2) FO4(2, true, false); else FO4(1, true, false); }
+      else if (ng == 3) FO4(3, false, false);
+      else if (ng == 2) FO4(2, false, false);
+      else FO4(1, false, false);
+    }
+#undef FO4
+    DSGCN_LAUNCH_CHECK();
+    return 0;
+  }
+  hipLaunchKernelGGL(k_fuse_out_bwd, grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, dout, dout2, dout3, dxbar, dx1, dx2,
+                     part, C, T, V, xbar_ld, stride3);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef DSGCN_LAB
+int dsgcn_fuse_out_tuning(int key, int value) {      // key 0: 16-byte backward on (1) / off (0)
+  if (key != 0) return DSGCN_EINVAL;
+  g_fo_vec = value;
+  return 0;
+}
+#endif
 
 int dsgcn_fuse_out_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, const float* dout, const float* dxbar, float* dx1, float* dx2,

@@ -125,6 +125,7 @@ LAB_SIGNATURES = {
     'dsgcn_tcw_phases': [ctypes.c_void_p],
     'dsgcn_tconv_tuning': [c_int, c_int],
     'dsgcn_tms_split_tuning': [c_int, c_int],
+    'dsgcn_fuse_out_tuning': [c_int, c_int],
     'dsgcn_tms_split_phases': [c_int, ctypes.c_void_p],
 }
 

@@ -51,6 +51,8 @@ int dsgcn_bwd64_phases(long long* out);
 int dsgcn_tcw_phases(long long* out);
 /* dense temporal conv (k_tcg): key 0 = stride-1 staging with 16-byte loads on (1, default) / off (0: the 4-byte form) */
 int dsgcn_tconv_tuning(int key, int value);
+/* fuse_out backward: key 0 = the 16-byte form on (1, default) / off (0: the 4-byte form everywhere) */
+int dsgcn_fuse_out_tuning(int key, int value);
 /* split-layout temporal stage (k_tsp): key 0 = bit mask of parts to SKIP for timing (1 plane blocks, 2 epilogue statistics,
  * 4 the affine + ReLU of the forward operand, 8 conv blocks, ...; results are wrong with any bit set); key 1 = the conv
  * block whose phases are stamped */

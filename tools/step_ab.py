@@ -34,8 +34,12 @@ def set_keys(variant):
         for kv in variant.split(','):
             k, v = kv.split('=')
             keys[int(k)] = int(v)
+    keys.setdefault(100, 1)
     for k, v in keys.items():
-        assert lab.dsgcn_pwconv_tuning(k, v) == 0, (k, v)
+        if k == 100:                                    # 100 = fuse_out backward: 16-byte form on / off
+            assert lab.dsgcn_fuse_out_tuning(0, v) == 0
+        else:
+            assert lab.dsgcn_pwconv_tuning(k, v) == 0, (k, v)
 
 
 def run(variant):
