@@ -1166,14 +1166,16 @@ __global__ __launch_bounds__(64) void k_bn_bwd_coef(const float* __restrict__ g_
 // The same coefficients straight from a consumer's partial rows: g_scale[c] = sum_r part[r][c][i_ds], g_shift[c] = sum_r
 // part[r][c][i_dh] (fp64, rows in order), optionally ADDED to what another consumer of the same BatchNorm already wrote —
 // the coefficients are linear in (g_scale, g_shift).  One launch instead of a column sum + k_bn_bwd_coef per consumer.
-// Block = 32 channels x 32 row slices.
+// Block = 8 channels x 128 row slices (as k_bn_finalize: the launch is a latency chain over up to ~1600 partial rows, so the
+// rows are spread over many threads and C / 8 blocks: 6.6 -> 4.x us per launch, 55 launches per DS-STGCN step).
 __global__ __launch_bounds__(1024) void k_bn_coef_rows(const float* __restrict__ part, int R, int C, int k, int ids, int idh,
                                                        const float* __restrict__ mean, const float* __restrict__ var,
                                                        const float* __restrict__ gamma, float eps, double count,
                                                        int c_affine, float* __restrict__ coef, int accumulate) {
-  __shared__ double red[2][32][33];
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  constexpr int CB = 8, NS = 128;
+  __shared__ double red[NS][CB][2];
+  const int cl = threadIdx.x & (CB - 1), sl = threadIdx.x / CB;
+  const int c = blockIdx.x * CB + cl;
   // the finishing thread's own operands first: their round trip overlaps the row sums
   float mu_f = 0.f, var_f = 1.f, g_f = 1.f, old[4] = {0.f, 0.f, 0.f, 0.f};
   if (sl == 0 && c < C) {
@@ -1186,32 +1188,33 @@ __global__ __launch_bounds__(1024) void k_bn_coef_rows(const float* __restrict__
   }
   double s0 = 0.0, s1 = 0.0;
   if (c < C) {
-    // four rows of the slice in flight (tall partials: up to ~50 rows per slice, each a dependent L2 round trip otherwise)
-    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, c0 = 0.0, c1 = 0.0, d0 = 0.0, d1 = 0.0;
     const size_t rs = (size_t)C * k;
     const float* p = part + (size_t)c * k;
-    int r = sl;
-    for (; r + 96 < R; r += 128) {
-      const float* q = p + (size_t)r * rs;
-      const float x0 = q[ids], y0 = q[idh], x1 = q[32 * rs + ids], y1 = q[32 * rs + idh];
-      const float x2 = q[64 * rs + ids], y2 = q[64 * rs + idh], x3 = q[96 * rs + ids], y3 = q[96 * rs + idh];
-      a0 += (double)x0; a1 += (double)y0; b0 += (double)x1; b1 += (double)y1;
-      c0 += (double)x2; c1 += (double)y2; d0 += (double)x3; d1 += (double)y3;
+    for (int r0 = sl; r0 < R; r0 += NS * 4) {
+      float x[4], y[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = r0 + NS * j;
+        const float* q = p + (size_t)(r < R ? r : r0) * rs;           // (clamped: no predicated loads)
+        x[j] = q[ids]; y[j] = q[idh];
+        if (r >= R) { x[j] = 0.f; y[j] = 0.f; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s0 += (double)x[j]; s1 += (double)y[j]; }
     }
-    for (; r < R; r += 32) {
-      const float* q = p + (size_t)r * rs;
-      a0 += (double)q[ids];
-      a1 += (double)q[idh];
-    }
-    s0 = (a0 + b0) + (c0 + d0);
-    s1 = (a1 + b1) + (c1 + d1);
   }
-  red[0][sl][cl] = s0;
-  red[1][sl][cl] = s1;
+  red[sl][cl][0] = s0;
+  red[sl][cl][1] = s1;
   __syncthreads();
+  for (int h = NS / 2; h >= 1; h >>= 1) {          // tree over the slices (fixed order: deterministic)
+    if (sl < h) {
+      red[sl][cl][0] += red[sl + h][cl][0];
+      red[sl][cl][1] += red[sl + h][cl][1];
+    }
+    __syncthreads();
+  }
   if (sl == 0 && c < C) {
-    double gs = 0.0, gh = 0.0;
-    for (int i = 0; i < 32; ++i) { gs += red[0][i][cl]; gh += red[1][i][cl]; }
+    const double gs = red[0][cl][0], gh = red[0][cl][1];
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < c_affine) {
       const double mu = mu_f, r = 1.0 / sqrt((double)var_f + (double)eps);
@@ -1632,7 +1635,7 @@ int dsgcn_bn_coef_rows(const float* part, int R, int C, int k, int i_ds, int i_d
                        void* stream) {
   if (!part || !mean || !var || !coef || R <= 0 || C <= 0 || k <= 0 || i_ds < 0 || i_ds >= k || i_dh < 0 || i_dh >= k)
     return DSGCN_EINVAL;
-  hipLaunchKernelGGL(k_bn_coef_rows, dim3((unsigned)((C + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, part, R, C, k, i_ds,
+  hipLaunchKernelGGL(k_bn_coef_rows, dim3((unsigned)((C + 7) / 8)), dim3(1024), 0, (hipStream_t)stream, part, R, C, k, i_ds,
                      i_dh, mean, var, gamma, eps, count, c_affine, coef, accumulate);
   DSGCN_LAUNCH_CHECK();
   return 0;
