@@ -478,6 +478,43 @@ def test_temporal_ms(n, C, T, V, stride, fused, monkeypatch):
         assert rel(got[k].detach().cpu(), v.detach()) < 5e-5, (k, rel(got[k].detach().cpu(), v.detach()))
 
 
+@pytest.mark.parametrize('C,T,stride', [(64, 64, 1), (128, 32, 1), (256, 16, 1), (128, 64, 2), (256, 32, 2)])
+def test_temporal_ms_split_at_full_size(C, T, stride, monkeypatch):
+    """The split layout at BASELINE's size (128 person-samples, the five unit shapes of DS-STGCN): thousands of position
+    tiles, tiles that cross samples, the window pairs of the 64-channel weight gradient — against the staged chain (which
+    the cases above pin to the fp64 statement of the op) on every output and gradient."""
+    n, V = 128, 25
+    g = torch.Generator().manual_seed(C + T)
+    cfg = [(3, 1), (3, 2), (3, 3), (3, 4), ('max', 3), '1x1']
+    mid = C // 6
+    widths = [C - 5 * mid] + [mid] * 5
+    n_act = C - mid
+    z, zaug = _rand(g, n, C, T, V).to(DEV), _rand(g, n, C, T).to(DEV)
+    scale = torch.cat([torch.rand(n_act, generator=g) + 0.5, torch.ones(mid)]).to(DEV)
+    shift = torch.cat([_rand(g, n_act, scale=0.3), torch.zeros(mid)]).to(DEV)
+    cw = [_rand(g, w, w, 3, 1, scale=(3 * w) ** -0.5).to(DEV) for w in widths[:4]]
+    cb = [_rand(g, w, scale=0.1).to(DEV) for w in widths[:4]]
+    coeff, gamma, beta = _rand(g, 25, scale=0.5).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV), _rand(g, C, scale=0.2).to(DEV)
+    gf, gsc, gsh = _rand(g, n, C, T // stride, V).to(DEV), _rand(g, C).to(DEV), _rand(g, C).to(DEV)
+
+    def run(split):
+        monkeypatch.setattr(K, 'FUSED_TEMPORAL', '0')
+        monkeypatch.setattr(K, 'SPLIT_TEMPORAL', '2' if split else '0')
+        lv = [t.clone().requires_grad_() for t in (z, zaug, scale, shift, coeff, gamma, beta)]
+        tw, tb = [w.clone().requires_grad_() for w in cw], [b.clone().requires_grad_() for b in cb]
+        f, sc, sh, mean, var = K.temporal_ms(lv[0], lv[1], lv[2], lv[3], n_act, cfg, widths, tw, tb, lv[4], stride, lv[5], lv[6],
+                                             1e-5, True)
+        ((f * gf).sum() + (sc * gsc).sum() + (sh * gsh).sum()).backward()
+        return [f, sc, sh, mean, var] + [t.grad for t in lv] + [w.grad for w in tw] + [b.grad for b in tb]
+
+    assert dsgcn_amd.native.lib().dsgcn_tms_split_rows(-1, n, C, T, V, stride, 3, 6, K._int_array([0, 0, 0, 0, 1, 2]),
+                                             K._int_array([sum(widths[:i]) for i in range(6)]), K._int_array(widths),
+                                             K._int_array([1, 2, 3, 4, 1, 1])) == 1
+    got, ref = run(True), run(False)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert rel(a.detach().cpu(), b.detach().cpu().double()) < 2e-6, (i, rel(a.detach().cpu(), b.detach().cpu().double()))
+
+
 @pytest.mark.parametrize('n,K,Co,T,V,shared,bn', [
     (2, 3, 16, 64, 25, True, True), (2, 3, 64, 16, 25, True, True), (3, 3, 8, 100, 17, True, False),
     (2, 3, 16, 64, 25, False, True), (2, 3, 32, 32, 25, False, True), (2, 3, 8, 130, 17, False, True),
