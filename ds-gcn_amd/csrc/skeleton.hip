@@ -4,8 +4,9 @@
 //   spine / shoulder alignment), 144-178 (RandomRot), 340-442 (JointToBone / ToMotion / GenSkeFeat: j, b, jm, bm),
 //   19-54 (PoseDecode: frame gather), 468-518 (FormatGCNInput: person padding, clip layout),
 //   pipelines/sampling.py:10-192 (UniformSample: the frame indices arrive in f0 / f1).
-// The per-clip DECISIONS (kept frames, person order, body centre, total linear map = rotation x alignment, sampled frame
-// indices) are made on the host with the reference's RNG draws (ds-gcn_amd/pipeline.py: SkeletonBatcher.plan) and arrive
+//   pipelines/augmentations.py:21-116 (PoseCompact: the shift by the box origin; the box itself is a host decision).
+// The per-clip DECISIONS (kept frames, person order, body centre / box origin, total linear map = rotation x alignment,
+// sampled frame indices) are made on the host with the reference's RNG draws (ds-gcn_amd/pipeline.py: SkeletonBatcher.plan) and arrive
 // as a few hundred bytes per clip; everything proportional to the clip size happens here.  Pure gather / byte-moving work:
 // HBM-bound, one thread per output joint (all its feature channels), coalesced stores.
 #include "common.h"
@@ -20,11 +21,16 @@ struct SkArgs {
 };
 
 // joint v of person pm, original frame f of clip n, after centre / mask / linear map; score channel passes through
+// masked: 0 plain shift, 1 PreNormalize3D (a joint that is zero in every coordinate stays zero), 2 PoseCompact (every
+// coordinate that is zero stays zero: augmentations.py:104-105 shifts `kp_x[kp_x != 0]` and `kp_y[kp_y != 0]` separately)
 __device__ __forceinline__ void sk_joint(const SkArgs& a, const float* __restrict__ base, int T, int pm, int f, int v,
-                                         bool masked, const float* c, const float* m, float (&o)[3]) {
+                                         int masked, const float* c, const float* m, float (&o)[3]) {
   const float* p = base + (((size_t)pm * T + f) * a.V + v) * a.C;
   float x[3] = {p[0], p[1], a.C == 3 ? p[2] : 0.f};
-  if (masked) {
+  if (masked == 2) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x[i] = x[i] != 0.f ? x[i] - c[i] : x[i];
+  } else if (masked) {
     const bool nz = x[0] != 0.f || x[1] != 0.f || x[2] != 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) x[i] = nz ? x[i] - c[i] : 0.f;
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256) void k_skeleton_prep(SkArgs a) {
     return;
   }
   const int pm = (fl & 1) ? 1 - m_src : m_src;    // swap: the formatted person 0 is raw person 1
-  const bool masked = (fl & 2) != 0;
+  const int masked = (fl & 8) ? 2 : ((fl & 2) ? 1 : 0);
   const float* c = a.center + 3 * n;
   const float* m = a.matrix + 9 * n;
   const float* base = a.raw + a.offset[n];

@@ -17,8 +17,10 @@ Two ways to run the same pipeline config:
   does all per-element work — centre + mask, rotation, bone / motion features, frame gather, person padding, clip
   layout — writing the network input ``(N, clips, M, T, V, C)`` directly.  There is no CPU fallback for this form.
 
-``DecompressPose`` (pose_related.py:521-607) and ``PoseCompact`` (augmentations.py:21-116) — the two extra transforms of the
-HRNet-pose Kinetics-400 config (configs/dsstgcn/kinetics400_hrnet/j.py:25-39) — exist in the host (``Compose``) form only.
+The HRNet-pose Kinetics-400 chain (configs/dsstgcn/kinetics400_hrnet/j.py:25-39: ``DecompressPose`` -> sample -> decode ->
+``PoseCompact`` -> features) runs in both forms: a compressed pickle is unpacked ONCE when the store is built
+(``decompress_detections``, vectorised), the per-frame joint extents are cached on the store, a batch's compact boxes are one
+gather + min / max over the sampled frames (``compact_boxes``), and the shift rides in ``dsgcn_skeleton_prep``.
 
 Not implemented (raise): 2-D heat-map transforms, ``float_ok`` sampling, memcached loading."""
 import copy
@@ -299,101 +301,128 @@ class GenSkeFeat:
         return results
 
 
+def decompress_detections(det, frame_of, total_frames, squeeze=True, max_person=10):
+    """Detection rows -> person-major arrays, for one clip, without a Python loop over detections.
+
+    ``det (D, V, 3)`` = (x, y, score) per detection, ``frame_of (D,)`` non-decreasing frame ids.  -> ``(xy (M, T, V, 2) fp16,
+    score (M, T, V) fp16, T, capped)``: detection d lands in person slot ``d - (first detection of its frame)``; with
+    ``squeeze`` the frames that hold a detection are renumbered 0..T-1; M = the busiest frame's detection count, and when
+    that exceeds ``max_person`` every frame's detections are re-ranked by their fp16 score total (high first, ties in
+    detection order) and only the first ``max_person`` ranks stay.  Contract: pose_related.py:521-607."""
+    fr = np.asarray(frame_of).astype(np.int64)
+    D = len(fr)
+    if D == 0:
+        raise ValueError('DecompressPose: a clip without detections')
+    if D > 1 and (fr[1:] < fr[:-1]).any():
+        raise AssertionError('DecompressPose: detections must be ordered by frame (frame_inds non-decreasing)')
+    if squeeze:
+        fr = np.cumsum(np.concatenate([[0], fr[1:] != fr[:-1]]))          # rank of the frame among the occupied ones
+        total_frames = int(fr[-1]) + 1
+    total_frames = int(total_frames)
+    slot = np.arange(D) - np.searchsorted(fr, fr, side='left')
+    crowd, capped = int(slot.max()) + 1, False
+    det = np.asarray(det)
+    if crowd > max_person:
+        # the reference ranks a frame's persons by the row sums of its fp16 score table: same dtype, same row length
+        strength = np.ascontiguousarray(det[:, :, 2], dtype=np.float16).sum(-1)
+        det = det[np.lexsort((-strength.astype(np.float32), fr))]          # stable: by frame, then score high -> low
+        keep = slot < max_person                                          # (fr and slot are unchanged by that order)
+        det, fr, slot, crowd, capped = det[keep], fr[keep], slot[keep], max_person, True
+    V = det.shape[1]
+    xy = np.zeros((crowd, total_frames, V, 2), dtype=np.float16)
+    score = np.zeros((crowd, total_frames, V), dtype=np.float16)
+    xy[slot, fr] = det[:, :, :2]
+    score[slot, fr] = det[:, :, 2]
+    return xy, score, total_frames, capped
+
+
 @PIPELINES.register_module()
 class DecompressPose:
-    """Kinetics pose pickles store one row per DETECTION: ``keypoint (D, V, 3)`` = (x, y, score) with ``frame_inds (D,)``
-    saying which frame a detection belongs to (and ``anno_inds``, the detections a dataset's ``box_thr`` keeps).  ->
-    ``keypoint (M, T, V, 2)`` / ``keypoint_score (M, T, V)`` in fp16 with the persons of a frame in detection order, M =
-    the largest number of detections in one frame, capped at ``max_person`` by total score.  ``squeeze``: frames without
-    a detection are dropped (frame indices renumbered densely).  Reference: pose_related.py:521-607."""
+    """The Kinetics pose pickles hold one row per DETECTION (``keypoint (D, V, 3)``, ``frame_inds (D,)``, optionally
+    ``anno_inds`` = the detections a dataset's ``box_thr`` keeps); this unpacks a clip into ``keypoint (M, T, V, 2)`` +
+    ``keypoint_score (M, T, V)`` (fp16).  See ``decompress_detections``; reference pose_related.py:521-607."""
 
     def __init__(self, squeeze=True, max_person=10):
         self.squeeze, self.max_person = squeeze, max_person
 
     def __call__(self, results):
-        for k in ('total_frames', 'frame_inds', 'keypoint'):
-            assert k in results
-        total_frames = results['total_frames']
-        frame_inds = results.pop('frame_inds')
-        keypoint = results['keypoint']
-        if 'anno_inds' in results:
-            frame_inds = frame_inds[results['anno_inds']]
-            keypoint = keypoint[results['anno_inds']]
-        assert np.all(np.diff(frame_inds) >= 0), 'frame_inds should be monotonical increasing'
-        if self.squeeze:
-            uni = np.unique(frame_inds)
-            frame_inds = np.searchsorted(uni, frame_inds).astype(np.int16)
-            total_frames = np.max(frame_inds) + 1
-        results['total_frames'] = total_frames
-        num_joints = keypoint.shape[1]
-        num_person = int(np.bincount(np.asarray(frame_inds, dtype=np.int64)).max())      # = scipy.stats.mode(...).count
-        new_kp = np.zeros([num_person, total_frames, num_joints, 2], dtype=np.float16)
-        new_kpscore = np.zeros([num_person, total_frames, num_joints], dtype=np.float16)
-        nperson_per_frame = np.zeros([total_frames], dtype=np.int16)
-        for frame_ind, kp in zip(frame_inds, keypoint):
-            person_ind = nperson_per_frame[frame_ind]
-            new_kp[person_ind, frame_ind] = kp[:, :2]
-            new_kpscore[person_ind, frame_ind] = kp[:, 2]
-            nperson_per_frame[frame_ind] += 1
-        if num_person > self.max_person:
-            for i in range(total_frames):
-                nperson = nperson_per_frame[i]
-                score_sum = new_kpscore[:nperson, i].sum(-1)
-                inds = sorted(range(nperson), key=lambda x: -score_sum[x])
-                new_kpscore[:nperson, i] = new_kpscore[inds, i]
-                new_kp[:nperson, i] = new_kp[inds, i]
-            num_person = self.max_person
-            results['num_person'] = num_person
-        results['keypoint'] = new_kp[:num_person]
-        results['keypoint_score'] = new_kpscore[:num_person]
+        missing = [k for k in ('total_frames', 'frame_inds', 'keypoint') if k not in results]
+        assert not missing, f'DecompressPose needs {missing}'
+        det, frame_of = results['keypoint'], results.pop('frame_inds')
+        chosen = results.get('anno_inds')
+        if chosen is not None:
+            det, frame_of = det[chosen], frame_of[chosen]
+        xy, score, T, capped = decompress_detections(det, frame_of, results['total_frames'], self.squeeze, self.max_person)
+        results.update(keypoint=xy, keypoint_score=score, total_frames=T)
+        if capped:
+            results['num_person'] = self.max_person
         return results
+
+
+def nonzero_extent(xy, axes):
+    """(…, 2) coordinates -> (lo_x, lo_y, hi_x, hi_y) over ``axes``, zeros not counted (+inf / -inf where nothing is)."""
+    live = xy != 0
+    lo = np.where(live, xy, np.inf).min(axis=axes)
+    hi = np.where(live, xy, -np.inf).max(axis=axes)
+    return np.concatenate([lo, hi], -1).astype(xy.dtype)
+
+
+def compact_boxes(extent, img_hw, padding=0.25, threshold=10, hw_ratio=None, allow_imgpad=True):
+    """PoseCompact's box for a stack of clips at once.  ``extent (N, 4)`` = (lo_x, lo_y, hi_x, hi_y) of the non-zero joints
+    in each clip's precision (fp32 after PoseDecode), ``img_hw (N, 2)``.  -> ``(apply (N,) bool, box (N, 4) int64 = x0, y0,
+    x1, y1)``: the tight box grown by ``padding`` about its centre, stretched to ``hw_ratio``, truncated to integers (and to
+    the image unless ``allow_imgpad``); ``apply`` False where the tight box is narrower than ``threshold`` either way.  All
+    arithmetic stays in the extent's dtype, the way the scalar code of augmentations.py:60-116 runs on numpy scalars."""
+    e = np.asarray(extent)
+    lo, hi = e[:, :2], e[:, 2:]
+    with np.errstate(invalid='ignore'):
+        span = hi - lo
+        apply = ~((span[:, 0] < threshold) | (span[:, 1] < threshold))
+        mid = (hi + lo) / 2
+        half = span / 2 * (1 + padding)
+        if hw_ratio is not None:
+            half_h = np.maximum(hw_ratio[0] * half[:, 0], half[:, 1])
+            half_w = np.maximum(1 / hw_ratio[1] * half_h, half[:, 0])
+            half = np.stack([half_w, half_h], 1)
+        lo, hi = mid - half, mid + half
+        if not allow_imgpad:
+            wh = np.asarray(img_hw)[:, ::-1]
+            lo, hi = np.maximum(0, lo), np.minimum(wh, hi)
+        ok = apply[:, None]
+        box = np.concatenate([np.trunc(np.where(ok, lo, 0)), np.trunc(np.where(ok, hi, 0))], 1).astype(np.int64)
+    return apply, box
 
 
 @PIPELINES.register_module()
 class PoseCompact:
-    """Crop the coordinate frame to the tight box around all non-zero joints of the (sampled) clip, grown by ``padding``
-    and to the ``hw_ratio`` asked for: joints are shifted by the box origin, ``img_shape`` becomes the box size,
-    ``crop_quadruple`` records it.  Boxes narrower than ``threshold`` pixels leave the sample untouched.  Reference:
-    augmentations.py:21-116."""
+    """Move the coordinate origin to the corner of the box around all non-zero joints of the (sampled) clip — see
+    ``compact_boxes`` — and record it: non-zero x / y are shifted, ``img_shape`` becomes the box size, ``crop_quadruple``
+    composes with an earlier crop.  NaN coordinates become 0 first.  Reference: augmentations.py:21-116."""
 
     def __init__(self, padding=0.25, threshold=10, hw_ratio=None, allow_imgpad=True):
-        self.padding, self.threshold, self.allow_imgpad = padding, threshold, allow_imgpad
+        assert padding >= 0
         if hw_ratio is not None and not isinstance(hw_ratio, (tuple, list)):
             hw_ratio = (hw_ratio, hw_ratio)
-        self.hw_ratio = tuple(hw_ratio) if hw_ratio is not None else None
-        assert self.padding >= 0
+        self.padding, self.threshold, self.allow_imgpad = padding, threshold, allow_imgpad
+        self.hw_ratio = None if hw_ratio is None else tuple(hw_ratio)
+
+    def boxes(self, extent, img_hw):
+        return compact_boxes(extent, img_hw, self.padding, self.threshold, self.hw_ratio, self.allow_imgpad)
 
     def __call__(self, results):
-        h, w = results['img_shape']
         kp = results['keypoint']
-        kp[np.isnan(kp)] = 0.
-        kp_x, kp_y = kp[..., 0], kp[..., 1]
-        min_x = np.min(kp_x[kp_x != 0], initial=np.inf)
-        min_y = np.min(kp_y[kp_y != 0], initial=np.inf)
-        max_x = np.max(kp_x[kp_x != 0], initial=-np.inf)
-        max_y = np.max(kp_y[kp_y != 0], initial=-np.inf)
-        if max_x - min_x < self.threshold or max_y - min_y < self.threshold:
+        np.nan_to_num(kp, copy=False, nan=0.0, posinf=np.inf, neginf=-np.inf)
+        h, w = results['img_shape']
+        apply, box = self.boxes(nonzero_extent(kp[..., :2], tuple(range(kp.ndim - 1)))[None], [(h, w)])
+        if not apply[0]:
             return results
-        center = ((max_x + min_x) / 2, (max_y + min_y) / 2)
-        half_width = (max_x - min_x) / 2 * (1 + self.padding)
-        half_height = (max_y - min_y) / 2 * (1 + self.padding)
-        if self.hw_ratio is not None:
-            half_height = max(self.hw_ratio[0] * half_width, half_height)
-            half_width = max(1 / self.hw_ratio[1] * half_height, half_width)
-        min_x, max_x = center[0] - half_width, center[0] + half_width
-        min_y, max_y = center[1] - half_height, center[1] + half_height
-        if not self.allow_imgpad:
-            min_x, min_y = int(max(0, min_x)), int(max(0, min_y))
-            max_x, max_y = int(min(w, max_x)), int(min(h, max_y))
-        else:
-            min_x, min_y = int(min_x), int(min_y)
-            max_x, max_y = int(max_x), int(max_y)
-        kp_x[kp_x != 0] -= min_x
-        kp_y[kp_y != 0] -= min_y
-        results['img_shape'] = (max_y - min_y, max_x - min_x)
-        a = results.get('crop_quadruple', (0., 0., 1., 1.))
-        b = (min_x / w, min_y / h, (max_x - min_x) / w, (max_y - min_y) / h)
-        results['crop_quadruple'] = (a[0] + a[2] * b[0], a[1] + a[3] * b[1], a[2] * b[2], a[3] * b[3])
+        x0, y0, x1, y1 = (int(b) for b in box[0])
+        for axis, origin in ((0, x0), (1, y0)):
+            col = kp[..., axis]
+            col[col != 0] -= origin
+        results['img_shape'] = (y1 - y0, x1 - x0)
+        ox, oy, sw, sh = results.get('crop_quadruple', (0., 0., 1., 1.))
+        results['crop_quadruple'] = (ox + sw * (x0 / w), oy + sh * (y0 / h), sw * ((x1 - x0) / w), sh * ((y1 - y0) / h))
         return results
 
 
@@ -577,9 +606,29 @@ class SkeletonStore:
     ``annotations``: sequence of dicts with 'keypoint' (M, T, V, C) [+ 'label', 'total_frames'] and, for 2-D pose pickles,
     'keypoint_score' (M, T, V) and 'img_shape' (h, w).  A score rides as channel 2 behind the two coordinates (what
     ``GenSkeFeat`` builds, pose_related.py:427-432); ``coordC`` is the number of coordinate channels the geometric
-    transforms act on, ``C`` the channels per joint in the buffer."""
+    transforms act on, ``C`` the channels per joint in the buffer.
 
-    def __init__(self, annotations, device='cuda'):
+    Compressed Kinetics annotations (``keypoint (D, V, 3)`` per DETECTION + ``frame_inds`` [+ ``anno_inds``]) are unpacked
+    here, once per clip, by ``decompress_detections(**decompress)`` (default: ``DecompressPose``'s own defaults); the
+    parameters are remembered in ``self.decompressed`` and a batcher whose pipeline asks for other ones refuses the store.
+    ``plan_only``: host tables without the device buffer (``SkeletonBatcher.plan`` works, ``run`` does not)."""
+
+    def __init__(self, annotations, device='cuda', decompress=None, plan_only=False):
+        self.decompressed = None
+        if len(annotations) and np.asarray(annotations[0]['keypoint']).ndim == 3:
+            opt = dict(squeeze=True, max_person=10)
+            opt.update(decompress or {})
+            self.decompressed = (bool(opt['squeeze']), int(opt['max_person']))
+            unpacked = []
+            for a in annotations:
+                det, frame_of = np.asarray(a['keypoint']), np.asarray(a['frame_inds'])
+                if a.get('anno_inds') is not None:
+                    det, frame_of = det[a['anno_inds']], frame_of[a['anno_inds']]
+                xy, score, _, _ = decompress_detections(det, frame_of, a['total_frames'], *self.decompressed)
+                unpacked.append(dict(a, keypoint=xy, keypoint_score=score))
+            annotations = unpacked
+        elif decompress is not None:
+            raise ValueError('SkeletonStore(decompress=...): the annotations are not in the per-detection layout')
         self.src = [np.ascontiguousarray(a['keypoint']) for a in annotations]          # original dtype (see normalize2d)
         self.scores = [a.get('keypoint_score') for a in annotations]
         self.img_shapes = [tuple(a['img_shape']) if a.get('img_shape') is not None else None for a in annotations]
@@ -597,7 +646,9 @@ class SkeletonStore:
         self.labels = np.array([int(a.get('label', -1)) for a in annotations], dtype=np.int64)
         self.device = device
         self.norm2d_shape = None
-        if not torch.device(device).type == 'cuda':
+        self.plan_only = bool(plan_only)
+        self._extent = None
+        if not plan_only and not torch.device(device).type == 'cuda':
             raise RuntimeError('SkeletonStore keeps the clips in HBM: it needs a CUDA/ROCm device (no CPU fallback)')
         self._upload(self.src)
 
@@ -609,6 +660,10 @@ class SkeletonStore:
                 k32 = np.concatenate([k32, np.asarray(sc, dtype=np.float32)[..., None]], -1)
             host.append(np.ascontiguousarray(k32))
         self.host = host                      # the decisions read a few frames of the clip on the host
+        self._extent = None
+        if self.plan_only:
+            self.data = None
+            return
         self.data = torch.from_numpy(np.concatenate([k.reshape(-1) for k in host])).to(self.device)
         if not self.data.is_cuda:
             raise RuntimeError('SkeletonStore keeps the clips in HBM: it needs a CUDA/ROCm device (no CPU fallback)')
@@ -635,6 +690,22 @@ class SkeletonStore:
         self.norm2d_shape = shape
         self._upload(out)
 
+    def frame_extents(self):
+        """What ``PoseCompact`` needs of a clip, made once: NaN coordinates zeroed in the resident copy (the transform does
+        that to every sample it sees) and, per frame, (lo_x, lo_y, hi_x, hi_y) of the non-zero coordinates over all persons
+        and joints.  -> (rows (sum T, 4) float32, first_row (n,) int64): the box of ANY set of sampled frames is a gather +
+        min / max over these rows."""
+        if self._extent is None:
+            if self.coordC != 2:
+                raise ValueError('PoseCompact applies to 2-D keypoints')
+            if any(np.isnan(k[..., :2]).any() for k in self.host):
+                self.src = [np.where(np.isnan(k), np.zeros((), k.dtype), k) for k in self.src]
+                self._upload(self.src)
+            rows = [nonzero_extent(k[..., :2], (0, 2)) for k in self.host]
+            first = np.concatenate([[0], np.cumsum(self.T.astype(np.int64))[:-1]])
+            self._extent = (np.concatenate(rows).astype(np.float32), first)
+        return self._extent
+
     def __len__(self):
         return len(self.src)
 
@@ -642,13 +713,22 @@ class SkeletonStore:
 class SkeletonBatcher:
     """Runs a reference-style skeleton pipeline config for a whole batch with one HIP launch.
 
-    Understood transforms, in the reference's order: [PreNormalize3D | PreNormalize2D] -> [RandomRot] -> GenSkeFeat ->
-    UniformSample(Frames) -> PoseDecode -> FormatGCNInput -> Collect -> ToTensor (the last three only fix the output
-    layout).  ``plan(store, indices)`` makes the per-clip decisions on the host (same numpy RNG draws, in the same order,
-    as running ``Compose`` clip by clip); ``run(store, plan)`` launches the kernel."""
+    Two transform orders are understood (the last three transforms of either only fix the output layout):
+    * the 3-D / pre-extracted 2-D configs: [PreNormalize3D | PreNormalize2D] -> [RandomRot] -> GenSkeFeat ->
+      UniformSample(Frames) -> PoseDecode -> FormatGCNInput -> Collect -> ToTensor;
+    * the compressed Kinetics config: DecompressPose -> UniformSampleFrames -> PoseDecode -> [PoseCompact] -> GenSkeFeat ->
+      FormatGCNInput -> Collect -> ToTensor — the features are built from the SAMPLED frames here (a motion feature
+      differences neighbours of the sampled sequence) in fp32 (PoseDecode has cast the clip).
+    ``plan(store, indices)`` makes the per-clip decisions on the host (same numpy RNG draws, in the same order, as running
+    ``Compose`` clip by clip); ``run(store, plan)`` launches the kernel."""
+
+    _GEOMETRY = {'PreNormalize3D': 0, 'PreNormalize2D': 0, 'RandomRot': 1, 'GenSkeFeat': 2, 'UniformSample': 3,
+                 'UniformSampleFrames': 3}
+    _SAMPLED = {'DecompressPose': 0, 'UniformSample': 1, 'UniformSampleFrames': 1, 'PoseDecode': 2, 'PoseCompact': 3,
+                'GenSkeFeat': 4}
 
     def __init__(self, pipeline):
-        self.norm3d = self.norm2d = self.rot = self.feat = self.sample = None
+        self.norm3d = self.norm2d = self.rot = self.feat = self.sample = self.decompress = self.compact = None
         self.num_person, self.person_mode = 2, 'zero'
         order = []
         for cfg in pipeline:
@@ -665,18 +745,27 @@ class SkeletonBatcher:
                 self.feat = GenSkeFeat(**kw)
             elif typ in ('UniformSample', 'UniformSampleFrames'):
                 self.sample = UniformSampleFrames(**kw)
+            elif typ == 'DecompressPose':
+                self.decompress = DecompressPose(**kw)
+            elif typ == 'PoseCompact':
+                self.compact = PoseCompact(**kw)
             elif typ == 'FormatGCNInput':
                 self.num_person, self.person_mode = kw.get('num_person', 2), kw.get('mode', 'zero')
             elif typ not in ('PoseDecode', 'Collect', 'ToTensor'):
                 raise NotImplementedError(f'SkeletonBatcher: transform {typ} has no batched HIP form')
         if self.feat is None or self.sample is None:
             raise ValueError('SkeletonBatcher needs GenSkeFeat and UniformSample in the pipeline')
-        want = [t for t in order if t in ('PreNormalize3D', 'PreNormalize2D', 'RandomRot', 'GenSkeFeat', 'UniformSample',
-                                          'UniformSampleFrames')]
-        rank = {'PreNormalize3D': 0, 'PreNormalize2D': 0, 'RandomRot': 1, 'GenSkeFeat': 2, 'UniformSample': 3,
-                'UniformSampleFrames': 3}
-        if [rank[t] for t in want] != sorted(rank[t] for t in want):
-            raise NotImplementedError('SkeletonBatcher: transforms must come in the order normalise, rotate, features, sample')
+        # features of the sampled sequence (Kinetics order) or of the source clip (every other shipped config)?
+        self.sampled_first = order.index('GenSkeFeat') > min(order.index(t) for t in order if t.startswith('UniformSample'))
+        rank = self._SAMPLED if self.sampled_first else self._GEOMETRY
+        seen = [t for t in order if t not in ('FormatGCNInput', 'Collect', 'ToTensor') and not
+                (t == 'PoseDecode' and not self.sampled_first)]
+        if any(t not in rank for t in seen) or [rank[t] for t in seen] != sorted(rank[t] for t in seen):
+            raise NotImplementedError(
+                'SkeletonBatcher: transforms must come as normalise, rotate, features, sample — or, for compressed pose '
+                'pickles, decompress, sample, decode, compact, features')
+        if self.sampled_first and 'PoseDecode' not in order:
+            raise NotImplementedError('SkeletonBatcher: features of the sampled frames need PoseDecode in front of them')
 
     # ---- host decisions ---------------------------------------------------------------------------------------------
     # A clip's geometry decisions (kept frames, person order, centre, alignment matrix, "nothing to rotate") depend on the
@@ -691,6 +780,8 @@ class SkeletonBatcher:
         cache = store.__dict__.setdefault('_decisions', {})
         if key not in cache:
             n, tmax = len(store.host), int(max(k.shape[1] for k in store.host))
+            if n3 is None:
+                tmax = 0                                  # every frame is kept: no per-clip frame list to remember
             cache[key] = dict(done=np.zeros(n, bool), frames=np.zeros((n, tmax), np.int32), nf=np.zeros(n, np.int32),
                               swap=np.zeros(n, bool), masked=np.zeros(n, bool), allzero=np.zeros(n, bool),
                               center=np.zeros((n, 3)), matrix=np.tile(np.eye(3), (n, 1, 1)),
@@ -714,7 +805,8 @@ class SkeletonBatcher:
                     kept = kp[:, frames]            # RandomRot's "nothing to rotate" test sees the centred clip
                     allzero = bool(np.all(np.isclose((kept - center) * ((kept != 0).sum(-1) > 0)[..., None], 0)))
                 mat = d['matrix']
-        tab['frames'][idx, :len(frames)] = frames
+        if self.norm3d is not None:
+            tab['frames'][idx, :len(frames)] = frames
         tab['nf'][idx], tab['swap'][idx], tab['masked'][idx], tab['allzero'][idx] = len(frames), swap, masked, allzero
         tab['center'][idx], tab['matrix'][idx] = center, mat
         tab['done'][idx] = True
@@ -726,6 +818,14 @@ class SkeletonBatcher:
             store.normalize2d(self.norm2d.img_shape)      # once per store (deterministic): per-clip img_shape, source dtype
         if self.norm3d is not None and store.coordC != 3:
             raise ValueError('PreNormalize3D needs 3-D keypoints')
+        want = None if self.decompress is None else (bool(self.decompress.squeeze), int(self.decompress.max_person))
+        if want != getattr(store, 'decompressed', None):
+            raise ValueError(f'SkeletonBatcher: the pipeline asks for DecompressPose{want}, the store was built with '
+                             f'{getattr(store, "decompressed", None)} (SkeletonStore(annotations, decompress=dict(...)))')
+        if self.compact is not None:
+            store.frame_extents()                         # once per store: NaN -> 0, per-frame joint extents
+            if not self.compact.allow_imgpad and any(s is None for s in store.img_shapes):
+                raise ValueError('PoseCompact(allow_imgpad=False) needs every clip\'s img_shape')
         tab = self._table(store)
         todo = np.arange(len(tab['done'])) if indices is None else np.unique(np.asarray(indices, dtype=np.int64))
         for i in todo[~tab['done'][todo]]:
@@ -762,20 +862,47 @@ class SkeletonBatcher:
                 rot = np.tile(np.eye(3), (N, 1, 1))
                 rot[:, 0, 0], rot[:, 0, 1], rot[:, 1, 0], rot[:, 1, 1] = c, -s_, s_, c
             mat = np.where(rotated[:, None, None], rot @ mat, mat)
-        frames = tab['frames'][idx]                       # (N, Tmax), valid up to nf
-        nxt = inds + 1
-        has_next = nxt < nf[:, None]
-        f0 = np.take_along_axis(frames, inds, 1)
-        f1 = np.where(has_next, np.take_along_axis(frames, np.where(has_next, nxt, 0), 1), -1)
-        half = tab['f16'][idx] & ~rotated & (self.norm3d is None)      # fp16 feature arithmetic
+        if self.norm3d is not None:
+            frames = tab['frames'][idx]                   # (N, Tmax), valid up to nf
+            f0 = np.take_along_axis(frames, inds, 1)
+        else:
+            frames, f0 = None, inds
+        if self.sampled_first:
+            # the difference partner of a sampled frame is the NEXT SAMPLED frame (clips still concatenated: ToMotion runs
+            # in front of FormatGCNInput's split), the last one has none
+            f1 = np.concatenate([f0[:, 1:], np.full((N, 1), -1, f0.dtype)], 1)
+        else:
+            nxt = inds + 1
+            has_next = nxt < nf[:, None]
+            nxt = np.where(has_next, nxt, 0)
+            f1 = np.where(has_next, nxt if frames is None else np.take_along_axis(frames, nxt, 1), -1)
+        half = tab['f16'][idx] & ~rotated & (self.norm3d is None) & (not self.sampled_first)      # fp16 feature arithmetic
         flags = tab['swap'][idx].astype(np.int32) | (tab['masked'][idx].astype(np.int32) << 1) | (half.astype(np.int32) << 2)
+        center = tab['center'][idx].astype(np.float32)
+        extra = {}
+        if self.compact is not None:
+            # the box of the SAMPLED frames: per-frame extents gathered and reduced for the whole batch, integer origin
+            # subtracted from every non-zero coordinate by the kernel (flag bit 3)
+            rows, first = store.frame_extents()
+            ext = rows[first[idx][:, None] + f0]          # (N, F, 4)
+            extent = np.concatenate([ext[..., :2].min(1), ext[..., 2:].max(1)], 1)
+            hw = np.array([s if s is not None else (0, 0) for s in (store.img_shapes[i] for i in idx)], dtype=np.int64)
+            apply, box = self.compact.boxes(extent, hw)
+            if (np.abs(box) >= 1 << 24).any():
+                raise ValueError('PoseCompact: box origin beyond fp32 integer range')
+            center = np.zeros((N, 3), np.float32)
+            center[:, :2] = box[:, :2]
+            flags = flags | (apply.astype(np.int32) << 3)
+            extra = dict(box=box, compacted=apply)
         return dict(offset=store.offset[idx].astype(np.int64), M=store.M[idx].astype(np.int32), T=store.T[idx].astype(np.int32),
-                    flags=flags, center=tab['center'][idx].astype(np.float32), matrix=mat.reshape(N, 9).astype(np.float32),
-                    f0=f0.astype(np.int32), f1=f1.astype(np.int32), label=store.labels[idx].astype(np.int64))
+                    flags=flags, center=center, matrix=mat.reshape(N, 9).astype(np.float32),
+                    f0=f0.astype(np.int32), f1=f1.astype(np.int32), label=store.labels[idx].astype(np.int64), **extra)
 
     def run(self, store, plan):
         """-> (keypoint (N, clips, num_person, clip_len, V, C_out) float32 on the store's device, label (N, 1) int64)."""
         from . import native
+        if store.data is None:
+            raise RuntimeError('SkeletonStore(plan_only=True) holds no device buffer: nothing to run the kernel on')
         dev = store.data.device
         N, F = plan['f0'].shape
         feats = self.feat.feats

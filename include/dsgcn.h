@@ -389,7 +389,10 @@ int dsgcn_gate_bwd(const float* y, const float* g, int mode, const float* gout, 
  *   than slots every slot after the first repeats person 0 (FormatGCNInput mode='loop', pose_related.py:492-497);
  *   flags[n] bit 2: the clip came from an fp16 pickle and is not rotated — its bone / motion differences are rounded to
  *   fp16 like the reference's in-place numpy arithmetic on the pickle's dtype (GenSkeFeat runs before PoseDecode's cast
- *   to fp32, pose_related.py:340-412).   out (N, clips, Mout, clip_len, V, C*nfeat). */
+ *   to fp32, pose_related.py:340-412).   flags[n] bit 3: PoseCompact (augmentations.py:21-116) — center[n] is the integer
+ *   origin of the clip's compact box and is subtracted from every NON-ZERO coordinate, x and y tested separately
+ *   (`kp_x[kp_x != 0] -= min_x`); f1 is then the next SAMPLED frame (the Kinetics config builds its features after
+ *   sampling).   out (N, clips, Mout, clip_len, V, C*nfeat). */
 int dsgcn_skeleton_prep(const float* raw, const long* offset, const int* M, const int* T, const int* flags,
                         const int* f0, const int* f1, const float* center, const float* matrix, const int* parent,
                         float* out, int N, int clips, int Mout, int clip_len, int V, int C, int nfeat, int fmask,

@@ -133,6 +133,50 @@ def test_batched_hip_pipeline_2d_vs_reference(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', ['k400_train', 'k400_test3', 'k400_cap2', 'k400_nopad'])
+def test_batched_hip_pipeline_k400_vs_reference(name):
+    """BASELINE config 5's data section in the resident form: compressed detections unpacked into HBM once,
+    compact boxes from cached per-frame extents, the shift inside dsgcn_skeleton_prep — bit-exact against the reference's
+    per-sample DecompressPose -> UniformSampleFrames -> PoseDecode -> PoseCompact -> GenSkeFeat -> FormatGCNInput."""
+    from pipeline_cases import pipelines_k400
+    names = list(pipelines_k400())
+    store = _k400_store(name)
+    batcher = P.SkeletonBatcher(pipelines_k400()[name])
+    np.random.seed(3000 + names.index(name))
+    kp, label = batcher(store, list(range(len(store))))
+    kp = kp.cpu().numpy()
+    for si in range(len(store)):
+        want = Z[f'{name}_{si}']
+        assert kp[si].shape == want.shape
+        assert np.array_equal(kp[si], want), (name, si, np.abs(kp[si] - want).max())
+
+
+@pytest.mark.gpu
+def test_batched_hip_pipeline_k400_motion_features_follow_the_sampled_frames():
+    """With the features built AFTER sampling (the Kinetics order), jm / bm difference neighbours of the SAMPLED sequence:
+    the launch against the host Compose form of the same chain (itself pinned to the reference by the k400 fixtures for j and
+    by skeleton_features' fixtures for b / jm / bm)."""
+    from pipeline_cases import pipelines_k400
+    pipe = copy.deepcopy(pipelines_k400()['k400_test3'])
+    for t in pipe:
+        if t['type'] == 'GenSkeFeat':
+            t['feats'] = ['j', 'b', 'jm', 'bm']
+    store = _k400_store('k400_test3')
+    np.random.seed(5)
+    kp, _ = P.SkeletonBatcher(pipe)(store, [3, 0, 2])
+    np.random.seed(5)
+    host = P.Compose(copy.deepcopy(pipe))
+    anns = annotations_k400()
+    for row, si in enumerate([3, 0, 2]):
+        sample = copy.deepcopy(anns[si])
+        sample['anno_inds'] = sample.pop('box_score') >= 0.5
+        sample.pop('valid')
+        sample.update(start_index=0, modality='Pose')
+        want = host(sample)['keypoint'].numpy()
+        assert np.array_equal(kp[row].cpu().numpy(), want), (si, np.abs(kp[row].cpu().numpy() - want).max())
+
+
+@pytest.mark.gpu
 def test_batched_pipeline_feeds_the_recognizer():
     """(N, clips, M, T, V, C) straight from the HIP pipeline into RecognizerGCN.train_step / forward_test."""
     from bench import ds_cfg
@@ -279,6 +323,86 @@ def test_host_pipeline_k400_vs_reference(name):
         want = Z[f'{name}_{si}']
         assert got.shape == want.shape and got.dtype == want.dtype
         assert np.array_equal(got, want), (name, si, np.abs(got - want).max())      # fp16 storage, integer crops: bit-exact
+
+
+def _k400_store(name, **kw):
+    """The compressed clips the way PoseDataset(box_thr=0.5, valid_ratio=0.0) hands them over (anno_inds set), unpacked into a
+    resident store with the DecompressPose parameters of pipeline `name`."""
+    anns = []
+    for ann in annotations_k400():
+        a = copy.deepcopy(ann)
+        a['anno_inds'] = a.pop('box_score') >= 0.5
+        a.pop('valid')
+        anns.append(a)
+    dec = {k: v for k, v in pipelines_k400()[name][0].items() if k != 'type'}
+    return P.SkeletonStore(anns, decompress=dec, **kw)
+
+
+@pytest.mark.parametrize('name', NAMES_K400)
+def test_batched_plan_k400_vs_reference(name):
+    """The resident / batched form of config 5's chain, host half: the store unpacks the detections once, plan() draws the
+    sampler's RNG clip by clip and gets every clip's compact box from the cached per-frame extents.  A numpy statement of
+    what the launch does with those decisions (gather f0, shift the non-zero coordinates by the box origin, pad / cut the
+    persons, split the clips) must reproduce the reference's transforms bit for bit — and leave the RNG where they do."""
+    store = _k400_store(name, plan_only=True)
+    b = P.SkeletonBatcher(pipelines_k400()[name])
+    assert b.sampled_first and store.C == 3 and store.coordC == 2
+    np.random.seed(3000 + NAMES_K400.index(name))
+    plan = b.plan(store, list(range(len(store))))
+    after = np.random.rand()
+    np.random.seed(3000 + NAMES_K400.index(name))
+    host = P.Compose(copy.deepcopy(pipelines_k400()[name]))
+    for si, ann in enumerate(annotations_k400()):
+        sample = copy.deepcopy(ann)
+        sample['anno_inds'] = sample.pop('box_score') >= 0.5
+        sample.pop('valid')
+        sample.update(start_index=0, modality='Pose')
+        res = host(sample)
+    assert np.random.rand() == after
+    nc = b.sample.num_clips
+    for si in range(len(store)):
+        kp = store.host[si][:, plan['f0'][si]].copy()                       # (M, F, V, 3)
+        assert np.array_equal(plan['f1'][si][:-1], plan['f0'][si][1:]) and plan['f1'][si][-1] == -1
+        if plan['flags'][si] & 8:
+            for c in (0, 1):
+                col = kp[..., c]
+                col[col != 0] -= plan['center'][si][c]
+        else:
+            assert not plan['center'][si].any()
+        kp = P.format_persons(kp, 2, 'zero')
+        M, F, V, C = kp.shape
+        got = kp.reshape(M, nc, F // nc, V, C).transpose(1, 0, 2, 3, 4)
+        assert np.array_equal(got, Z[f'{name}_{si}']), (name, si)
+    assert plan['compacted'].all()
+    with pytest.raises(ValueError):                                          # other DecompressPose parameters than the store's
+        P.SkeletonBatcher([dict(pipelines_k400()[name][0], max_person=7)] + pipelines_k400()[name][1:]).plan(store, [0])
+    with pytest.raises(RuntimeError):
+        b.run(store, plan)                                                   # plan_only: no device buffer
+
+
+def test_decompress_and_compact_edge_cases():
+    """What the fixtures do not reach: score ties under the person cap keep detection order; squeeze=False keeps the frame
+    axis; boxes under the threshold leave the clip alone; an all-zero clip has no box; out-of-order detections raise."""
+    det = np.zeros((5, 17, 3), np.float16)
+    det[:, :, 2] = np.array([.5, .75, .5, .75, .25], np.float16)[:, None]
+    det[:, :, 0] = np.arange(1, 6, dtype=np.float16)[:, None]
+    fr = np.array([2, 2, 2, 2, 5], np.int16)
+    xy, sc, T, capped = P.decompress_detections(det, fr, 9, squeeze=True, max_person=3)
+    assert (T, capped, xy.shape) == (2, True, (3, 2, 17, 2))
+    assert xy[:, 0, 0, 0].tolist() == [2., 4., 1.] and xy[:, 1, 0, 0].tolist() == [5., 0., 0.]      # .75 .75 then the first .5
+    xy, sc, T, capped = P.decompress_detections(det, fr, 9, squeeze=False, max_person=10)
+    assert (T, capped, xy.shape) == (9, False, (4, 9, 17, 2)) and xy[:, 2, 0, 0].tolist() == [1., 2., 3., 4.]
+    with pytest.raises(AssertionError):
+        P.decompress_detections(det, fr[::-1], 9)
+    pc = P.PoseCompact(hw_ratio=1.)
+    ext = np.array([[10, 10, 15, 200], [np.inf, np.inf, -np.inf, -np.inf], [10, 20, 110, 60]], np.float32)
+    apply, box = pc.boxes(ext, [(240, 320)] * 3)
+    assert apply.tolist() == [False, False, True] and not box[:2].any()
+    assert box[2].tolist() == [-2, -22, 122, 102]                       # 100 x 40 grown to 125 x 50, squared up to 125 x 125
+    kp = np.zeros((1, 4, 17, 2), np.float32)
+    kp[0, 1, 3] = [np.nan, 50.]
+    r = pc(dict(keypoint=kp, img_shape=(240, 320)))
+    assert r['img_shape'] == (240, 320) and r['keypoint'][0, 1, 3].tolist() == [0., 50.]           # NaN -> 0, too narrow
 
 
 def test_k400_dataset_builds_from_the_config_section(tmp_path):
