@@ -210,6 +210,10 @@ class EpochRunner:
     def resume(self, path):
         meta = resume(self.model, self.engine.opt, path)
         self.epoch, self.iter = int(meta.get('epoch', 0)), int(meta.get('iter', 0))
+        if meta.get('hook_msgs'):
+            self.meta['hook_msgs'] = dict(meta['hook_msgs'])
+        if self.evaluator is not None:
+            self.evaluator.restore(self.meta)
         return meta
 
     def run(self):
@@ -231,7 +235,8 @@ class EvalLoop:
     less_keys = ('loss',)
 
     def __init__(self, dataset, batch_size=1, interval=1, start=None, metrics='top_k_accuracy',
-                 metric_options=None, save_best='auto', rule=None, by_epoch=True, device='cuda', **unsupported):
+                 metric_options=None, save_best='auto', rule=None, by_epoch=True, device='cuda',
+                 broadcast_bn_buffer=True, **unsupported):
         if not by_epoch:
             raise NotImplementedError('evaluation by iteration is not used by the skeleton configs')
         unsupported.pop('key_indicator', None)
@@ -249,7 +254,37 @@ class EvalLoop:
         self.save_best, self.rule = save_best, rule
         self.key_indicator = None if save_best in ('auto', None, True) else save_best
         self.best_score = self.best_ckpt = None
+        self.broadcast_bn_buffer = bool(broadcast_bn_buffer)
         self.results = []
+
+    def restore(self, meta):
+        """After a resume: the best score / file so far ride in the checkpoint's ``meta['hook_msgs']`` (mmcv EvalHook reads
+        them back in ``before_run`` / ``_save_ckpt``), so the first evaluation of the resumed run competes with them."""
+        msgs = (meta or {}).get('hook_msgs') or {}
+        if msgs.get('best_score') is not None:
+            self.best_score, self.best_ckpt = msgs['best_score'], msgs.get('best_ckpt')
+            self.key_indicator = msgs.get('key_indicator', self.key_indicator)
+
+    @torch.no_grad()
+    def sync_bn_buffers(self, model, world):
+        """mmcv ``DistEvalHook._do_evaluate`` with ``broadcast_bn_buffer=True`` (its default): BatchNorm running statistics
+        evolve rank-locally during training (no per-step buffer sync, pyskl/apis/train.py:98-102), so before a validation
+        pass every rank takes rank 0's — the scores then describe the weights AND buffers rank 0 saves.  One packed
+        collective for all layers."""
+        if world <= 1 or not self.broadcast_bn_buffer:
+            return
+        bufs = []
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats:
+                bufs += [m.running_var, m.running_mean]
+        if not bufs:
+            return
+        packed = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+        dist.broadcast(packed, src=0)
+        off = 0
+        for b in bufs:
+            b.copy_(packed[off:off + b.numel()].view_as(b).to(b.dtype))
+            off += b.numel()
 
     def labels(self):
         if self.source.store is not None:
@@ -267,9 +302,15 @@ class EvalLoop:
         was_training = model.training
         model.eval()
         part = []
-        for b in range(0, len(order), self.batch_size):
-            kp, _ = self.source.batch(order[b:b + self.batch_size])
-            part.extend(model(keypoint=kp, return_loss=False))
+        # the reference samples val clips in loader worker processes: the test-mode sampler's np.random.seed(255) never
+        # touches the TRAINING process's stream.  Here both run in one process, so the stream is put back afterwards.
+        rng = np.random.get_state()
+        try:
+            for b in range(0, len(order), self.batch_size):
+                kp, _ = self.source.batch(order[b:b + self.batch_size])
+                part.extend(model(keypoint=kp, return_loss=False))
+        finally:
+            np.random.set_state(rng)
         model.train(was_training)
         return part
 
@@ -310,6 +351,7 @@ class EvalLoop:
     def after_train_epoch(self, runner):
         if not self.should_run(runner.epoch):
             return None
+        self.sync_bn_buffers(runner.model, runner.world)
         part = self.predict(runner.model, runner.rank, runner.world)
         scores = gather_results(part, len(self.source))
         rec = None
@@ -329,8 +371,9 @@ class EvalLoop:
                         os.remove(self.best_ckpt)
                     os.makedirs(runner.work_dir, exist_ok=True)
                     self.best_ckpt = os.path.join(runner.work_dir, f'best_{key}_epoch_{runner.epoch}.pth')
-                    meta = dict(runner.meta, epoch=runner.epoch, iter=runner.iter,
-                                hook_msgs=dict(best_score=self.best_score, best_ckpt=self.best_ckpt))
+                    # kept in the runner's meta as mmcv does: every later epoch_N.pth carries it, a resume reads it back
+                    runner.meta['hook_msgs'] = dict(best_score=self.best_score, best_ckpt=self.best_ckpt, key_indicator=key)
+                    meta = dict(runner.meta, epoch=runner.epoch, iter=runner.iter)
                     save_checkpoint(runner.model, self.best_ckpt, optimizer=runner.engine.opt, meta=meta)
         if runner.world > 1:
             dist.barrier()

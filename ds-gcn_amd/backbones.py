@@ -235,7 +235,8 @@ class _SkeletonBackbone(nn.Module):
         last = len(blocks) - 1
         for i, blk in enumerate(blocks):
             tee = i < last
-            if tee and getattr(blocks[i + 1], 'wants_prestrided', lambda: False)():
+            T, V = (x[0] if isinstance(x, tuple) else x).shape[2:]
+            if tee and getattr(blocks[i + 1], 'wants_prestrided', lambda: False)() and kernels.prestrided_fits(T, V):
                 tee = 2                     # the next block's residual conv reads the even frames only: hand them over as a tensor
             x, xbar = blk.forward_fused(x, xbar, needs_xbar and i < last, tee=tee)
         flush_running_stats()

@@ -5,7 +5,7 @@ Reference behaviour (pyskl/apis/train.py:94-102): mmcv ``MMDistributedDataParall
 gradient), BatchNorm statistics stay rank-local.  Here: parameters and gradients live in two flat fp32
 buffers (5.5 MB each for DS-STGCN), every ``p.grad`` is a view into the gradient buffer (autograd
 accumulates in place; unused parameters simply stay zero), and the exchange step is one RCCL
-all-reduce of that buffer over xGMI followed by a scale — latency-bound (~50 us), no bucketing needed.
+all-reduce (mean) of that buffer over xGMI — latency-bound (~50 us), no bucketing needed.
 """
 import torch
 import torch.distributed as dist
@@ -183,9 +183,14 @@ class FlatDataParallel:
                 off += b.numel()
 
     def allreduce_grads(self):
+        """The step's ONE collective.  On RCCL the mean is the collective's own reduction (``ReduceOp.AVG``): no scale
+        launch in the only un-graphed stretch of the step.  gloo (the CPU tests) has no AVG: sum, then scale."""
         if self.world > 1:
-            dist.all_reduce(self.flat.flat_g, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.flat_g.mul_(1.0 / self.world)
+            if dist.get_backend(self.group) == 'nccl':
+                dist.all_reduce(self.flat.flat_g, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(self.flat.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat.flat_g.mul_(1.0 / self.world)
 
 
 def shard_batch(batch_size, rank, world):

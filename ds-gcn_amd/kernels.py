@@ -1871,6 +1871,27 @@ def tee3(x):
     return _Tee3.apply(x)
 
 
+class Prestrided:
+    """The even frames of a block output, handed to the next block's stride-2 residual conv as a tensor of their own
+    (_FuseOut, tee = 2).  An explicit wrapper rather than an attribute on the tensor: anything that makes a new tensor
+    object (detach, alias, a subclass's forward) would drop an attribute silently and the conv would stride the already
+    halved tensor.  ``frames``: the frame count of the full-rate tensor the kept frames came from."""
+    __slots__ = ('x', 'stride', 'frames')
+
+    def __init__(self, x, stride, frames):
+        if x.shape[2] != (frames + stride - 1) // stride:
+            raise ValueError(f'Prestrided: {x.shape[2]} frames are not every {stride}-th of {frames}')
+        self.x, self.stride, self.frames = x, int(stride), int(frames)
+
+
+FUSE_OUT_LDS_BYTES = 64 * 1024        # k_fuse_out_fwd keeps the whole (T, V) plane in LDS for the time mean / even frames
+
+
+def prestrided_fits(T, V):
+    """Can fuse_out(tee=2) take planes of this size?  (longer planes go through strided_frames as before)"""
+    return T * V * 4 <= FUSE_OUT_LDS_BYTES
+
+
 class _FuseOut(torch.autograd.Function):
     """-> (out, out', out'', xbar): with ``tee`` the output comes as three aliases, one per consumer in the next block
     (spatial unit, its residual operand, block residual), and the backward sums their gradients while loading them —
@@ -1884,6 +1905,8 @@ class _FuseOut(torch.autograd.Function):
         _require_cuda(x1)
         x1, s1, h1, x2, s2, h2 = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2)]
         n, C, T, V = x1.shape
+        if x2 is not None and x2.shape != x1.shape:
+            raise ValueError(f'fuse_out: the two terms differ in shape: {tuple(x1.shape)} vs {tuple(x2.shape)}')
         out = torch.empty_like(x1)
         out_s2 = torch.empty((n, C, (T + 1) // 2, V), device=x1.device, dtype=torch.float32) if tee == 2 else None
         xbar = torch.empty((n, C, xbar_ld), device=x1.device, dtype=torch.float32) if xbar_ld else None
@@ -1907,6 +1930,9 @@ class _FuseOut(torch.autograd.Function):
         x1, s1, h1, x2, s2, h2 = ctx.saved_tensors
         n, C, T, V = x1.shape
         stride3 = 1
+        for g, frames in ((dout, T), (dout2, T), (dout3, (T + 1) // 2 if ctx.tee == 2 else T)):
+            if g is not None and tuple(g.shape) != (n, C, frames, V):
+                raise ValueError(f'fuse_out backward: gradient of shape {tuple(g.shape)}, expected {(n, C, frames, V)}')
         if ctx.tee == 2:
             # the third stream has the even-frame shape: it keeps its slot (the kernel needs a first stream to add it to)
             d3 = _f32c(dout3)
@@ -1947,11 +1973,11 @@ def fuse_out(x1, a1, x2, a2, relu, want_tmean=False, tee=False):
     want_tmean: False / True (time mean (n, C, V)) / an int ld >= V (time mean with the joint row zero-padded to ld: the
     layout `dynadj` consumes directly).
     tee: return the output as a tuple of three aliases (see _FuseOut) for the next block's three reads; tee = 2: the third
-    one is the even-frame tensor (n, C, ceil(T/2), V), marked ``_dsgcn_prestrided = 2`` for the stride-2 residual conv."""
+    one is the even-frame tensor (n, C, ceil(T/2), V) wrapped as ``Prestrided`` for the stride-2 residual conv."""
     s1, h1 = a1 if a1 is not None else (None, None)
     s2, h2 = a2 if a2 is not None else (None, None)
     ld = 0 if not want_tmean else (x1.shape[-1] if want_tmean is True else int(want_tmean))
     o1, o2, o3, xbar = _FuseOut.apply(x1, s1, h1, x2, s2, h2, int(relu), ld, int(tee))
     if int(tee) == 2:
-        o3._dsgcn_prestrided = 2
+        o3 = Prestrided(o3, 2, x1.shape[2])
     return ((o1, o2, o3) if tee else o1), xbar

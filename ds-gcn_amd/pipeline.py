@@ -775,8 +775,8 @@ class SkeletonBatcher:
 
     def _table(self, store):
         n3 = self.norm3d
-        key = ('none',) if n3 is None else ('norm3d', tuple(n3.zaxis), tuple(n3.xaxis), bool(n3.align_spine),
-                                            bool(n3.align_center))
+        key = ('none', self.rot is not None) if n3 is None else ('norm3d', tuple(n3.zaxis), tuple(n3.xaxis),
+                                                                  bool(n3.align_spine), bool(n3.align_center))
         cache = store.__dict__.setdefault('_decisions', {})
         if key not in cache:
             n, tmax = len(store.host), int(max(k.shape[1] for k in store.host))
@@ -794,7 +794,7 @@ class SkeletonBatcher:
         T = kp.shape[1]
         frames, swap, masked = np.arange(T), False, False
         center, mat = np.zeros(3), np.eye(3)
-        allzero = bool(np.all(np.isclose(kp, 0)))
+        allzero = self.rot is not None and bool(np.all(np.isclose(kp, 0)))       # only RandomRot asks
         if self.norm3d is not None:
             n = self.norm3d
             d = normalize3d_decision(kp, n.zaxis, n.xaxis, n.align_spine, n.align_center)

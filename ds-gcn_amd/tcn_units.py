@@ -42,11 +42,17 @@ class unit_tcn(nn.Module):
     def forward_deferred(self, x):
         """x: tensor or Deferred -> Deferred(z, bn affine) (dropout must be 0 on this path)."""
         ops = kernels.ops()
+        pre = x if isinstance(x, kernels.Prestrided) else None
+        if pre is not None:
+            if self.kernel_size != 1 or pre.stride != self.stride:
+                raise ValueError(f'unit_tcn(kernel_size={self.kernel_size}, stride={self.stride}) was handed frames '
+                                 f'pre-strided by {pre.stride}')
+            x = pre.x
         d = as_deferred(x)
         has_bn = isinstance(self.bn, nn.BatchNorm2d)
         if self.kernel_size == 1:
             stride = self.stride
-            if stride > 1 and d.a1 is None and d.x2 is None and not d.relu and getattr(d.x1, '_dsgcn_prestrided', 0) == stride:
+            if pre is not None:
                 stride = 1                      # the producer already handed over the kept frames (kernels._FuseOut, tee = 2)
             elif stride > 1 and d.a1 is None and d.x2 is None and not d.relu and hasattr(ops, 'strided_frames'):
                 # a plain input (the block residual): pick the kept frames first (one strided-copy launch, tapconv's

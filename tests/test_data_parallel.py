@@ -110,6 +110,47 @@ def test_two_rank_dp_equals_microbatch_average(tmp_path, gather):
     assert torch.allclose(flat.flat_p, r0['p'], rtol=0, atol=2e-6), (flat.flat_p - r0['p']).abs().max()
 
 
+def _engine_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from dsgcn_amd.engine import TrainEngine
+    model = make_model(seed=7 + rank)
+    calls = []
+    real = {name: getattr(dist, name) for name in ('all_reduce', 'broadcast', 'all_gather', 'reduce', 'barrier',
+                                                   'all_gather_into_tensor', 'reduce_scatter_tensor')}
+    for name, fn in real.items():
+        setattr(dist, name, (lambda fn, name: lambda *a, **k: (calls.append((name, a[0].numel() if a and torch.is_tensor(a[0]) else 0)),
+                                                                fn(*a, **k))[1])(fn, name))
+    try:
+        with D.kernels.use_ops(torch_ops):
+            eng = TrainEngine(model, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True, use_graph=False)
+            wrap = list(calls)
+            del calls[:]
+            b = batch_for(rank)
+            for _ in range(3):
+                eng.step(b['keypoint'], b['label'])
+    finally:
+        for name, fn in real.items():
+            setattr(dist, name, fn)
+    torch.save(dict(wrap=wrap, steps=list(calls), n=eng.flat.numel, p=eng.flat.flat_p.clone()), os.path.join(out_dir, f'e{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_engine_step_is_one_collective():
+    """TrainEngine itself (the object bench.py and train_model drive) under a 2-rank group, eager: wrapping
+    costs the parameter broadcast + two packed buffer broadcasts, and a step is EXACTLY one collective — the all-reduce of
+    the whole flat gradient buffer (no per-tensor buckets, no log-scalar reductions inside the step)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_engine_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+        r0, r1 = [torch.load(os.path.join(tmp, f'e{r}.pt')) for r in range(2)]
+    for r in (r0, r1):
+        assert [c[0] for c in r['wrap']] == ['broadcast'] * 3 and r['wrap'][0][1] == r['n']
+        assert r['steps'] == [('all_reduce', r['n'])] * 3
+    assert torch.equal(r0['p'], r1['p'])
+
+
 @pytest.mark.parametrize('gather', [False, True])
 def test_flat_sgd_matches_torch_sgd(gather):
     torch.manual_seed(0)

@@ -333,3 +333,20 @@ def test_deferred_param_sums_guards():
     with pytest.raises(RuntimeError, match='zero_grad'):
         with K.deferred_param_sums(flat2):
             pass
+
+
+def test_prestrided_handoff_is_explicit():
+    """the even-frame tensor between fuse_out(tee=2) and the stride-2 residual conv is a wrapper object, not a
+    Python attribute on a tensor — a frame count that does not fit, or a conv with another stride / kernel, raises instead
+    of reading T/4 frames; planes too long for fuse_out's LDS copy are not handed over at all."""
+    from dsgcn_amd import kernels as K
+    from dsgcn_amd.tcn_units import unit_tcn
+    x = torch.zeros(1, 4, 5, 3)
+    with pytest.raises(ValueError):
+        K.Prestrided(x, 2, 12)
+    p = K.Prestrided(x, 2, 10)
+    assert K.Prestrided(x, 2, 9).frames == 9
+    for tcn in (unit_tcn(4, 8, kernel_size=1, stride=1), unit_tcn(4, 8, kernel_size=3, stride=2)):
+        with pytest.raises(ValueError):
+            tcn.forward_deferred(p)
+    assert K.prestrided_fits(64, 25) and K.prestrided_fits(100, 17) and not K.prestrided_fits(1000, 25)

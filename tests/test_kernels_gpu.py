@@ -398,8 +398,8 @@ def test_fuse_out_even_frame_output(n, C, T, V, streams):
         ta1 = (a1[0].to(DEV).requires_grad_(), a1[1].to(DEV).requires_grad_())
         (oa, ob, oc), xbar = K.fuse_out(tx1, ta1, tx2, None, True, True, 2 if even else True)
         if even:
-            assert oc.shape == (n, C, T2, V) and getattr(oc, '_dsgcn_prestrided', 0) == 2
-            oc_s = oc
+            assert isinstance(oc, K.Prestrided) and (oc.stride, oc.frames) == (2, T) and oc.x.shape == (n, C, T2, V)
+            oc_s = oc.x
         else:
             oc_s = oc[:, :, ::2]
         loss = (oc_s * gc.to(DEV)).sum() + (xbar * gx.to(DEV)).sum()

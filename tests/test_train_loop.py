@@ -343,6 +343,109 @@ def test_validation_two_ranks_gloo(tmp_path):
     assert rec['mean_class_accuracy'] == pytest.approx(mean_class_accuracy(r['single'], r['labels'])[0])
 
 
+def _bn_sync_worker(rank, world, port, out_dir):
+    import types
+    import torch.distributed as dist
+    from dsgcn_amd.apis import EvalLoop
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    z, tr, m, data, val, cfg = _setup_step(os.path.join(out_dir, f'w{rank}'))
+    val = val[:11]
+    bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm)]
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for bn in bns:                                   # rank-local statistics that have drifted apart: rank 1's are far off
+            bn.running_mean.copy_(torch.randn(bn.running_mean.shape, generator=g) * (0.1 if rank == 0 else 3.0))
+            bn.running_var.copy_(torch.rand(bn.running_var.shape, generator=g) + (0.5 if rank == 0 else 5.0))
+    out = {}
+    with D.kernels.use_ops(torch_ops):
+        for flag in (True, False):                       # mmcv's default first: afterwards rank 1 holds rank 0's buffers
+            if not flag:
+                with torch.no_grad():
+                    for bn in bns:
+                        if rank == 1:
+                            bn.running_mean.add_(2.0)
+            ev = EvalLoop(val, batch_size=5, device='cpu', metrics=['top_k_accuracy'], broadcast_bn_buffer=flag)
+            runner = types.SimpleNamespace(model=m, rank=rank, world=world, epoch=1, iter=0, logger=None, work_dir=None,
+                                           meta={}, engine=None)
+            part = ev.predict(m, rank, world) if not flag else None
+            ev.after_train_epoch(runner)
+            out[flag] = dict(res=ev.results, part=None if part is None else np.stack(part),
+                             stats=torch.cat([bn.running_mean for bn in bns]).clone())
+        if rank == 0:
+            out['single'] = np.stack(ev.predict(m, 0, 1))
+            out['labels'] = [v['label'] for v in val]
+    torch.save(out, os.path.join(out_dir, f'bn{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_validation_broadcasts_bn_buffers_two_ranks_gloo(tmp_path):
+    """mmcv's DistEvalHook broadcasts rank 0's BatchNorm running statistics before a validation pass
+    (broadcast_bn_buffer=True by default); training keeps them rank-local, so without it rank 1 scores its shard with its
+    own drifted statistics.  With the ranks' statistics made to differ: after the pass every rank holds rank 0's buffers and
+    the gathered metrics equal a single-process pass with rank 0's model; with the option off rank 1 keeps its own."""
+    import socket
+    import torch.multiprocessing as mp
+    from dsgcn_amd.evaluation import top_k_accuracy
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_bn_sync_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [torch.load(tmp_path / f'bn{r}.pt', weights_only=False) for r in range(2)]
+    assert torch.equal(r0[True]['stats'], r1[True]['stats'])
+    top = top_k_accuracy(r0['single'], r0['labels'], (1, 5))
+    assert r0[True]['res'][0]['top1_acc'] == pytest.approx(top[0]) and r0[True]['res'][0]['top5_acc'] == pytest.approx(top[1])
+    assert not torch.equal(r0[False]['stats'], r1[False]['stats'])              # off: rank-local statistics stay
+    # ... and rank 1's shard was then scored with ITS statistics: its scores differ from rank 0's model on the same clips
+    assert np.abs(r1[False]['part'][:5] - r0['single'][1::2]).max() > 1e-3       # (its 6th entry is the wrapped sample 0)
+
+
+def test_resume_restores_the_best_score(tmp_path):
+    """the best score / file so far ride in every epoch checkpoint's meta['hook_msgs'] (mmcv EvalHook), so the
+    first evaluation after a resume competes with them instead of always counting as 'better'.  The fixture's top-1 never
+    improves after epoch 1: a run resumed from epoch_2.pth must leave best_top1_acc_epoch_1.pth the only best file."""
+    z, tr, m, data, val, cfg = _setup_step(tmp_path)
+    cfg.update(total_epochs=2, checkpoint_config=dict(interval=1))
+    with D.kernels.use_ops(torch_ops):
+        train_model(m, data, cfg, device='cpu', use_graph=False, validate=True, val_dataset=val)
+    meta = torch.load(tmp_path / 'epoch_2.pth', weights_only=False)['meta']
+    assert meta['hook_msgs']['best_ckpt'].endswith('best_top1_acc_epoch_1.pth') and meta['hook_msgs']['key_indicator'] == 'top1_acc'
+    z, tr, m2, data, val, cfg = _setup_step(tmp_path)
+    cfg.update(total_epochs=3, checkpoint_config=dict(interval=1), resume_from=str(tmp_path / 'epoch_2.pth'))
+    with D.kernels.use_ops(torch_ops):
+        runner = train_model(m2, data, cfg, device='cpu', use_graph=False, validate=True, val_dataset=val)
+    assert [r['epoch'] for r in runner.evaluator.results] == [3]
+    assert runner.evaluator.best_score == meta['hook_msgs']['best_score']
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith('best_')) == ['best_top1_acc_epoch_1.pth']
+
+
+def test_validation_leaves_the_training_rng_stream_alone():
+    """the test-mode sampler reseeds numpy's global RNG for every val clip; run inside the training process that
+    must not move the training augmentation stream (the reference samples val clips in separate loader workers)."""
+    from dsgcn_amd.apis import EvalLoop
+    from dsgcn_amd import pipeline as P
+
+    class _Val:
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, i):
+            P.uniform_frame_indices(20, 8, 2, test_mode=True)                 # np.random.seed(255) inside
+            return dict(keypoint=np.zeros((2, 2, 8, 25, 3), np.float32), label=0)
+
+    class _Model(torch.nn.Module):
+        def forward(self, keypoint, return_loss=False):
+            return [np.ones(4) / 4] * len(keypoint)
+
+    np.random.seed(11)
+    want = np.random.rand(3)
+    np.random.seed(11)
+    EvalLoop(_Val(), batch_size=2, device='cpu').predict(_Model(), 0, 1)
+    assert np.array_equal(np.random.rand(3), want)
+
+
 @pytest.mark.gpu
 def test_train_model_on_resident_store_feeder_is_deterministic(tmp_path):
     """train_model fed by the HIP input pipeline (clips resident in HBM, host plan + one launch per batch): with the plan
