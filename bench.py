@@ -10,7 +10,10 @@ clips per GPU.  The line also carries
   roofline     — the gather-aggregate kernel (K-A) timed live with HIP events on the launch stream over the
                  model's own 10-layer shape mix, against the 8 TB/s HBM peak (algorithmic bytes only);
   cpu_baseline — the CPU oracle (op-for-op PyTorch restatement of the reference path) timed on this box's
-                 host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                 host cores on a bounded sample of the same workload (rank 0, N=1 only);
+  roofline_step — the whole step against the HBM peak: algorithmic bytes from the layer table below, the committed PMC
+                 total of a step, and this run's ms_per_step;
+  other_configs — BASELINE configs 1 / 3 / 4 / 5 (per GPU) through the same engine, 10 hipGraph steps each (N=1 only).
 """
 import argparse
 import json
@@ -331,6 +334,119 @@ def measure_kc_roofline(device, n, reps=20, nsets=4):
     return out
 
 
+DS_PLAN = [(3, 64, 64, 1), (64, 64, 64, 1), (64, 64, 64, 1), (64, 64, 64, 1), (64, 128, 64, 2), (128, 128, 32, 1),
+           (128, 128, 32, 1), (128, 256, 32, 2), (256, 256, 16, 1), (256, 256, 16, 1)]     # (Ci, Co, T at the block, stride)
+
+
+def step_algorithmic_elements(plan=DS_PLAN, v=V):
+    """The tensors of one DS-STGCN training step that HAVE to exist in HBM, per person-sample and per family:
+    every tensor that sits behind a train-mode BatchNorm's global reduction (the raw conv outputs z), the dynamic adjacency,
+    the gather-aggregate's output (the north_star's kernel boundary) and the block outputs.  Elements, not bytes."""
+    rows = {'input': 3 * plan[0][2] * v}
+
+    def add(k, e):
+        rows[k] = rows.get(k, 0) + e
+    for ci, co, t, s in plan:
+        mid, L = co // 8, t * v
+        Lo = L // s
+        add('z_pre', 3 * mid * L)              # pre conv out, BN + ReLU applied by K-A while loading
+        add('Ahat', 3 * mid * v * v)           # K-B out
+        add('Y', 3 * mid * L)                  # K-A out
+        add('z_post', co * L)                  # post conv out (BN + residual + ReLU applied by the branch convs' load)
+        if ci != co:
+            add('z_down', co * L)              # the spatial unit's residual conv + BN
+        add('z_branch', co * L)                # the six branch 1x1 convs (BN + ReLU applied by the window kernels' load)
+        add('f', co * Lo)                      # windows + global-joint combine (transform.0 BN + ReLU applied by the next load)
+        add('z_transform', co * Lo)            # transform conv out (BN applied by fuse_out)
+        if s != 1:
+            add('z_res', co * Lo)              # the block residual's strided 1x1 conv + BN
+        add('out', co * Lo)                    # block output
+    return rows
+
+
+def step_roofline(n, ms_per_step):
+    """Whole-step roofline.  Algorithmic bytes = 4 B x 5 touches x the tensors of step_algorithmic_elements:
+    written once and read once forward, read once more in the backward, its gradient written once and read once.  `traffic` =
+    the HBM bytes of one step from the latest COMMITTED PMC passes (profiles/rNN/step_hbm_traffic.csv, FETCH_SIZE x2 +
+    WRITE_SIZE over an eager step of this same workload)."""
+    import glob
+    rows = step_algorithmic_elements()
+    per_family = {k: 20 * n * e for k, e in rows.items()}
+    alg = sum(per_family.values())
+    out = dict(bound='hbm', alg_bytes=alg, alg_bytes_by_family={k: round(b / 1e9, 3) for k, b in per_family.items()},
+               alg_unit='GB per step per family; 4 B x 5 touches (fwd write + read, bwd read, gradient write + read)',
+               achieved=round(alg / (ms_per_step * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+               alg_frac=round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=None, traffic_ratio=None)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'step_hbm_traffic.csv')))
+    if files:
+        import csv
+        with open(files[-1]) as f:
+            for row in csv.reader(f):
+                if row and row[0] == 'TOTAL':
+                    traffic = (float(row[2]) + float(row[3])) * 1e6
+                    out.update(traffic=int(traffic), traffic_ratio=round(traffic / alg, 3),
+                               traffic_frac=round(traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               traffic_source='committed PMC passes ' + os.path.relpath(files[-1], ROOT) +
+                                              ' (rocprofv3 --pmc over an eager step; not measured by this process)')
+    return out
+
+
+OTHER_CONFIGS = (('stgcn', 'BASELINE config 1: ST-GCN NTU-60 (vanilla, stgcn_spatial graph)', 64),
+                 ('ds120', 'BASELINE config 3 per GPU: DS-STGCN NTU-120', 64),
+                 ('ctrgcn', 'BASELINE config 4: CTR-GCN NTU-60 (unit_ctrgcn + MSTCN)', 64),
+                 ('ds_k400', 'BASELINE config 5 per GPU: DS-STGCN Kinetics-400 2D keypoints (V=17, T=100)', 32))
+
+
+def measure_other_configs(device, steps=10, warmup=3):
+    """The other BASELINE configurations through the same TrainEngine step (fwd + bwd + SGD-nesterov, two hipGraphs), `steps`
+    timed steps each on synthetic clips of their own shape — so that the driver's clock sees them too."""
+    import gc
+    import dsgcn_amd
+    out = {}
+    for kind, what, clips in OTHER_CONFIGS:
+        t_, v_, classes = 64, 25, 60
+        if kind == 'ds_k400':
+            cfg, t_, v_, classes = ds_cfg(400, 'coco'), 100, 17, 400
+        elif kind == 'ds120':
+            cfg, classes = ds_cfg(120), 120
+        else:
+            cfg = other_cfg(kind)
+        try:
+            np.random.seed(0)
+            torch.manual_seed(0)
+            m = dsgcn_amd.build_model(cfg)
+            gen = torch.Generator().manual_seed(1)
+            with torch.no_grad():
+                for k, p in m.named_parameters():
+                    if k.endswith(('alpha', 'beta', 'add_coeff')):
+                        p.copy_(torch.randn(p.shape, generator=gen) * 0.5)
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0               # ST-GCN's tcn dropout (p = 0.5) draws from the RNG: not capturable; noted below
+            m = m.to(device).train()
+            eng = dsgcn_amd.TrainEngine(m, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True, use_graph=True,
+                                        warmup_eager=2, strict_graph=False)
+            x = torch.randn(clips, 1, M, t_, v_, C, generator=gen).to(device)
+            y = torch.randint(0, classes, (clips, 1), generator=gen).to(device)
+            for _ in range(max(warmup, 3)):
+                eng.step(x, y)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = eng.step(x, y)['loss']
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out[kind] = dict(workload=what, clips_per_gpu=clips, ms_per_step=round(dt * 1e3, 3), clips_per_s=round(clips / dt, 1),
+                             steps=steps, hip_graph=bool(eng.graphed(x, y)), final_loss=round(float(loss.item()), 5),
+                             step='fwd+bwd+SGD-nesterov (TrainEngine), dropout p=0')
+            del eng, m, x, y
+        except Exception as exc:        # a secondary figure must never take the bench line down
+            out[kind] = dict(workload=what, error=f'{type(exc).__name__}: {exc}')
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def _cpu_topology():
     """(physical cores, hw threads, model name) from /proc/cpuinfo."""
     cores, threads, model, phys, core = set(), 0, 'unknown CPU', None, None
@@ -441,6 +557,7 @@ def main():
     ap.add_argument('--clips-per-gpu', type=int, default=CLIPS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the BASELINE configs 1 / 3 / 4 / 5 step times')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying captured hipGraphs')
     ap.add_argument('--cpu-budget', type=float, default=12.0)
     args = ap.parse_args()
@@ -593,6 +710,10 @@ def main():
         result['roofline'] = rf['k_aggregate_bwd'] | {'kernel': 'k_aggregate_bwd'}
         result['roofline_other'] = ({'k_aggregate_fwd': rf['k_aggregate_fwd']} | measure_kc_roofline(device, B * M) |
                                     measure_kap_roofline(device, B * M))
+    if rank == 0:
+        result['roofline_step'] = step_roofline(B * M, result['ms_per_step'])
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        result['other_configs'] = measure_other_configs(device)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
