@@ -29,6 +29,23 @@ def ref_dev(n):
     return DEV if n >= 64 else 'cpu'
 
 
+def relu_knife_edge(x1, a1, x2, a2, relu, tol=1e-5):
+    """Mask (True = keep) of the input elements whose pre-activation v = x1*s1+h1 (+ x2*s2+h2) is NOT within `tol` of zero.
+    An fp32 and an fp64 evaluation of relu'(v) disagree where |v| is at rounding level; at full size (13-52 M elements) one
+    or two such elements exist, each wrong by a whole gradient value (1e-4 of the tensor's L2 norm: tools/tcg_diag.py found
+    exactly one, the same in dx1 and dx2) — a property of the comparison, not of the kernel."""
+    if not relu:
+        return None
+    v = x1.double() * (a1[0].double().view(1, -1, 1, 1) if a1 is not None else 1.0)
+    if a1 is not None:
+        v = v + a1[1].double().view(1, -1, 1, 1)
+    if x2 is not None:
+        v = v + x2.double() * (a2[0].double().view(1, -1, 1, 1) if a2 is not None else 1.0)
+        if a2 is not None:
+            v = v + a2[1].double().view(1, -1, 1, 1)
+    return v.abs() > tol
+
+
 @pytest.mark.parametrize('n,KC,T,V,relu,affine', [
     (3, 24, 64, 25, True, True), (2, 48, 32, 25, True, True), (2, 96, 16, 25, True, True),
     (2, 24, 100, 17, True, True), (2, 10, 25, 17, True, True), (2, 6, 64, 25, False, False),
@@ -222,10 +239,15 @@ def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
 
     got = run(K, torch.float32, DEV)
     ref = run(R, torch.float64, ref_dev(n))
+    keep = relu_knife_edge(x1, a1, x2, a2, relu)
     for k, v in ref.items():
         # fp32 MFMA dot products over <=256 channels, sums over <= n*T*V positions: 1e-5 relative L2
         tol = 2e-5 if k not in ('db',) else 2e-4      # db of a conv feeding BN is ~0 analytically (cancellation)
-        err = rel(got[k].detach().cpu(), v.detach())
+        if k in ('dx1', 'dx2') and keep is not None:
+            assert int((~keep).sum()) <= 1e-5 * keep.numel() + 4
+            err = rel(got[k].detach().cpu() * keep, v.detach().cpu() * keep)
+        else:
+            err = rel(got[k].detach().cpu(), v.detach())
         if k == 'db':
             err = maxabs(got[k].detach().cpu(), v.detach()) / (ref['dw'].abs().max().item() + 1e-30)
         assert err < tol, (k, err)
@@ -292,8 +314,13 @@ def test_tconv_gemm(n, Ci, Co, T, V, KT, mode, stride):
 
     got = run(K, torch.float32, DEV)
     ref = run(R, torch.float64, ref_dev(n))
+    keep = relu_knife_edge(x1, a1, x2, a2, relu)
     for k, v in ref.items():
-        err = rel(got[k].detach().cpu(), v.detach())
+        if k in ('dx1', 'dx2') and keep is not None:
+            assert int((~keep).sum()) <= 1e-5 * keep.numel() + 4
+            err = rel(got[k].detach().cpu() * keep, v.detach().cpu() * keep)
+        else:
+            err = rel(got[k].detach().cpu(), v.detach())
         if k == 'db':           # db of a conv feeding BN is ~0 analytically (cancellation): absolute, against dW's scale
             err = maxabs(got[k].detach().cpu(), v.detach()) / (ref['dw'].abs().max().item() + 1e-30)
         assert err < (2e-4 if k == 'db' else 2e-5), (k, err)
