@@ -961,6 +961,56 @@ __global__ __launch_bounds__(256) void k_wsplit(const float* __restrict__ w, int
   *reinterpret_cast<u32x2v*>(dst + 2 * (size_t)pstride) = u32x2v{p2, q2};
 }
 
+// The same for up to WS_MAXJOBS convs in ONE launch (the 22 wide convs of a DS-STGCN step: 22 dependent 4 us launches at
+// the head of their convs -> one at the head of the step).  The job table rides in the kernel arguments.
+constexpr int WS_MAXJOBS = 32;
+struct WsJobs {
+  const float* w[WS_MAXJOBS];
+  unsigned short* out[WS_MAXJOBS];
+  int Ci[WS_MAXJOBS], Co[WS_MAXJOBS];
+  int blk0[WS_MAXJOBS + 1];                         // first block of job j; blk0[njobs] = grid
+  int njobs, frag;
+};
+
+__global__ __launch_bounds__(256) void k_wsplit_multi(WsJobs jb) {
+  int j = 0;
+  while (j + 1 < jb.njobs && (int)blockIdx.x >= jb.blk0[j + 1]) ++j;
+  const int Ci = jb.Ci[j], Co = jb.Co[j];
+  const float* __restrict__ w = jb.w[j];
+  unsigned short* __restrict__ out = jb.out[j];
+  const int MpN = (Co + 255) / 256 * 256, KpN = (Ci + 31) / 32 * 32, MpT = (Ci + 255) / 256 * 256, KpT = (Co + 31) / 32 * 32;
+  const int i = ((int)blockIdx.x - jb.blk0[j]) * 256 + threadIdx.x;
+  const int t1 = MpN * (KpN >> 2), t2 = MpT * (KpT >> 2);
+  float v[4];
+  unsigned short* dst;
+  int pstride;
+  if (i < t1) {
+    const int r = i / (KpN >> 2), k = 4 * (i - r * (KpN >> 2));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (r < Co && k + e < Ci) ? w[(size_t)r * Ci + k + e] : 0.f;
+    dst = out + (jb.frag ? ((size_t)(r >> 5) * (KpN >> 4) + (k >> 4)) * 512 + (((k >> 3) & 1) * 32 + (r & 31)) * 8 + (k & 7)
+                         : (size_t)r * KpN + k);
+    pstride = MpN * KpN;
+  } else if (i - t1 < t2) {
+    const int q = i - t1;
+    const int r = q / (KpT >> 2), k = 4 * (q - r * (KpT >> 2));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (r < Ci && k + e < Co) ? w[(size_t)(k + e) * Ci + r] : 0.f;
+    dst = out + (size_t)3 * MpN * KpN +
+          (jb.frag ? ((size_t)(r >> 5) * (KpT >> 4) + (k >> 4)) * 512 + (((k >> 3) & 1) * 32 + (r & 31)) * 8 + (k & 7)
+                   : (size_t)r * KpT + k);
+    pstride = MpT * KpT;
+  } else {
+    return;
+  }
+  unsigned p0, p1, p2, q0, q1, q2;
+  b3_split(v[0], v[1], p0, p1, p2);
+  b3_split(v[2], v[3], q0, q1, q2);
+  *reinterpret_cast<u32x2v*>(dst) = u32x2v{p0, q0};
+  *reinterpret_cast<u32x2v*>(dst + pstride) = u32x2v{p1, q1};
+  *reinterpret_cast<u32x2v*>(dst + 2 * (size_t)pstride) = u32x2v{p2, q2};
+}
+
 struct WsDims { int MpN, KpN, MpT, KpT; size_t bytes; };
 WsDims ws_dims(int Ci, int Co) {
   WsDims d;
@@ -1196,6 +1246,28 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_wsplit(const float* w, int Ci
   hipLaunchKernelGGL(k_wsplit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Ci, Co,
                      static_cast<unsigned short*>(out), d.MpN, d.KpN, d.MpT, d.KpT, g_p4_ws == 2 ? 1 : 0);
   DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+__attribute__((visibility("hidden"))) int dsgcn_p4_wsplit_multi(const float* const* w, void* const* out, const int* Ci,
+                                                                const int* Co, int njobs, hipStream_t st) {
+  for (int j0 = 0; j0 < njobs; j0 += WS_MAXJOBS) {
+    WsJobs jb;
+    jb.njobs = njobs - j0 < WS_MAXJOBS ? njobs - j0 : WS_MAXJOBS;
+    jb.frag = g_p4_ws == 2 ? 1 : 0;
+    int blk = 0;
+    for (int j = 0; j < jb.njobs; ++j) {
+      const WsDims d = ws_dims(Ci[j0 + j], Co[j0 + j]);
+      const long total = (long)d.MpN * (d.KpN >> 2) + (long)d.MpT * (d.KpT >> 2);
+      jb.w[j] = w[j0 + j]; jb.out[j] = static_cast<unsigned short*>(out[j0 + j]);
+      jb.Ci[j] = Ci[j0 + j]; jb.Co[j] = Co[j0 + j];
+      jb.blk0[j] = blk;
+      blk += (int)((total + 255) / 256);
+    }
+    for (int j = jb.njobs; j <= WS_MAXJOBS; ++j) jb.blk0[j] = blk;
+    hipLaunchKernelGGL(k_wsplit_multi, dim3((unsigned)blk), dim3(256), 0, st, jb);
+    DSGCN_LAUNCH_CHECK();
+  }
   return 0;
 }
 

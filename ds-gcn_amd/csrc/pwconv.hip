@@ -1247,6 +1247,8 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const fl
                                                         int n, int Ci, int Co, int L, hipStream_t st, const void* ws);
 __attribute__((visibility("hidden"))) size_t dsgcn_p4_ws_bytes(int n, int Ci, int Co, int L);
 __attribute__((visibility("hidden"))) int dsgcn_p4_wsplit(const float* w, int Ci, int Co, void* out, hipStream_t st);
+__attribute__((visibility("hidden"))) int dsgcn_p4_wsplit_multi(const float* const* w, void* const* out, const int* Ci,
+                                                                const int* Co, int njobs, hipStream_t st);
 __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const float* s1, const float* h1,
                                                           const float* x2, const float* s2, const float* h2, int relu,
                                                           const float* w, const float* z, const float* gz,
@@ -1397,6 +1399,14 @@ size_t dsgcn_pwconv_wsplit_bytes(int n, int Ci, int Co, int T, int V, int stride
 int dsgcn_pwconv_wsplit(const float* w, int Ci, int Co, void* ws, void* stream) {
   if (!w || !ws || Ci <= 0 || Co <= 0) return DSGCN_EINVAL;
   return dsgcn_p4_wsplit(w, Ci, Co, ws, (hipStream_t)stream);
+}
+
+int dsgcn_pwconv_wsplit_multi(const float* const* w, void* const* ws, const int* Ci, const int* Co, int njobs,
+                              void* stream) {
+  if (!w || !ws || !Ci || !Co || njobs <= 0) return DSGCN_EINVAL;
+  for (int j = 0; j < njobs; ++j)
+    if (!w[j] || !ws[j] || Ci[j] <= 0 || Co[j] <= 0) return DSGCN_EINVAL;
+  return dsgcn_p4_wsplit_multi(w, ws, Ci, Co, njobs, (hipStream_t)stream);
 }
 
 int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,

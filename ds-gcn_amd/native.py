@@ -36,6 +36,8 @@ SIGNATURES = {
     'dsgcn_bn_coef_rows': [c_f, c_int, c_int, c_int, c_int, c_int, c_f, c_f, c_f, ctypes.c_float, ctypes.c_double, c_int, c_f, c_int, c_st],
     'dsgcn_pwconv_fwd_ws': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 8 + [c_f, c_st],
     'dsgcn_pwconv_wsplit': [c_f, c_int, c_int, c_f, c_st],
+    'dsgcn_pwconv_wsplit_multi': [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int),
+                                  ctypes.POINTER(ctypes.c_int), c_int, c_st],
     'dsgcn_pwconv_wsplit_bytes': [c_int] * 6,
     'dsgcn_tconv_ws_bytes': [c_int] * 7,
     'dsgcn_tconv_wsplit': [c_f, c_int, c_int, c_int, c_f, c_st],

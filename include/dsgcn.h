@@ -211,6 +211,10 @@ int dsgcn_pwconv_dgrad(const float* x1, const float* s1, const float* h1, const 
  * Same results as the plain entry points (the split is the same function of w, only evaluated earlier). */
 size_t dsgcn_pwconv_wsplit_bytes(int n, int Ci, int Co, int T, int V, int stride);
 int dsgcn_pwconv_wsplit(const float* w, int Ci, int Co, void* ws, void* stream);
+/* The same for `njobs` convs in one launch per 32 jobs: w / ws / Ci / Co are HOST arrays of length njobs (device pointers
+ * and sizes; read during the call, the job table rides in the kernel arguments). */
+int dsgcn_pwconv_wsplit_multi(const float* const* w, void* const* ws, const int* Ci, const int* Co, int njobs,
+                              void* stream);
 int dsgcn_pwconv_fwd_ws(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                         const float* h2, int relu, const float* w, const float* bias, float* z, float* zaug,
                         float* partial, int n, int Ci, int Co, int T, int V, int stride, int aug, int stats,

@@ -250,6 +250,8 @@ def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
             err = rel(got[k].detach().cpu(), v.detach())
         if k == 'db':
             err = maxabs(got[k].detach().cpu(), v.detach()) / (ref['dw'].abs().max().item() + 1e-30)
+        if n >= 64 and k in ('ds1', 'dh1', 'ds2', 'dh2', 'dgamma', 'dbeta', 'dw'):
+            tol = 5e-5           # sums over 2e5 positions in fp32 (sqrt(N) * 2^-24 = 2.7e-5) + the knife-edge element
         assert err < tol, (k, err)
 
 
@@ -323,7 +325,10 @@ def test_tconv_gemm(n, Ci, Co, T, V, KT, mode, stride):
             err = rel(got[k].detach().cpu(), v.detach())
         if k == 'db':           # db of a conv feeding BN is ~0 analytically (cancellation): absolute, against dW's scale
             err = maxabs(got[k].detach().cpu(), v.detach()) / (ref['dw'].abs().max().item() + 1e-30)
-        assert err < (2e-4 if k == 'db' else 2e-5), (k, err)
+        # full size: the per-channel sums run over 2e5 positions in fp32 (sqrt(N) * 2^-24 = 2.7e-5) and carry the
+        # knife-edge element too: 5e-5 for them, the small cases and every elementwise output keep 2e-5
+        bar = 5e-5 if (n >= 64 and k in ('ds1', 'dh1', 'ds2', 'dh2', 'dgamma', 'dbeta', 'dw')) else 2e-5
+        assert err < (2e-4 if k == 'db' else bar), (k, err)
     got2 = run(K, torch.float32, DEV)          # ordered partial sums: bit-reproducible
     assert all(torch.equal(got[k], got2[k]) for k in got)
 
@@ -1059,3 +1064,44 @@ def test_aagcn_gram_gates_and_per_sample_aggregate(n, C, T, V):
     for k, v in ref.items():
         # fp32 sums over <= C*T (Gram) / n*T*V (statistics) terms: 2e-5 relative L2
         assert rel(got[k].detach().cpu(), v.detach()) < 2e-5, (k, rel(got[k].detach().cpu(), v.detach()))
+
+
+def test_wsplit_images_batched_per_step_and_never_stale():
+    """The bf16-term weight images of the wide convs are rebuilt by ONE launch at the first wide conv of a step
+    (kernels._wsplit_image); an image is trusted only for the step and weight version it was built at.  Two convs, weights
+    changed in place between forwards, with and without a step boundary: every output must match the current weights."""
+    g = torch.Generator().manual_seed(3)
+    x = _rand(g, 2, 128, 16, 25).to(DEV)
+    ws = [(_rand(g, 256, 128, 1, 1, scale=128 ** -0.5).to(DEV).requires_grad_()), (_rand(g, 160, 128, 1, 1, scale=128 ** -0.5).to(DEV).requires_grad_())]
+    K._wsplit_state['jobs'].clear()
+
+    def check(tag):
+        for w in ws:
+            z = K.pwconv(x, None, None, None, False, w, None, 1, False)[0]
+            want = torch.einsum('oc,nctv->notv', w.detach().double().view(w.shape[0], -1), x.double())
+            assert rel(z, want) < 2e-6, (tag, rel(z, want))
+
+    K.reset_leaf_uses()
+    check('first visit: split on the spot')
+    assert len(K._wsplit_state['jobs']) == 2
+    with torch.no_grad():
+        ws[0].mul_(1.5)
+    check('same step, weight version moved: re-split on the spot')
+    K.reset_leaf_uses()
+    with torch.no_grad():
+        ws[1].add_(0.25)
+    check('new step: one batched launch')
+    assert K._wsplit_state['batched'] == K._wsplit_state['epoch']
+    stamps = [j['stamp'] for j in K._wsplit_state['jobs'].values()]
+    assert all(s[0] == K._wsplit_state['epoch'] for s in stamps)
+    with torch.no_grad():
+        ws[0].add_(-0.5)
+    check('after the batched launch, a later in-place change')
+    # a backward through the saved image
+    K.reset_leaf_uses()
+    z = K.pwconv(x, None, None, None, False, ws[0], None, 1, False)[0]
+    xg = x.clone().requires_grad_()
+    z = K.pwconv(xg, None, None, None, False, ws[0], None, 1, False)[0]
+    z.sum().backward()
+    want = ws[0].detach().double().view(256, -1).sum(0).view(1, -1, 1, 1).expand_as(x)
+    assert rel(xg.grad, want) < 2e-6

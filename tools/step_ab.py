@@ -1,7 +1,8 @@
 """Same-box A/B of the bench step under lab tuning keys: the lab library stands in for the product library, every variant
 (comma-joined key=value pairs of dsgcn_pwconv_tuning; '' = defaults) gets a fresh model + TrainEngine (two hipGraphs) and is
 timed over `steps` replays, the variants interleaved `rounds` times so that clock / box drift shows up as spread.
-    python tools/step_ab.py '' 15=0 14=1 [--steps 20] [--rounds 2] [--kind ds|ctrgcn|stgcn|...]"""
+    python tools/step_ab.py '' 15=0 14=1 py:WSPLIT_BATCH=0 [--steps 20] [--rounds 2] [--kind ds|ctrgcn|stgcn|...]
+(py:NAME=V sets the module-level switch NAME of ds-gcn_amd/kernels.py for that variant)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -26,13 +27,23 @@ variants = variants or ['']
 lab = native.lab_lib()
 native._lib = lab                                   # the package now launches through the lab build (same kernels + knobs)
 DEFAULTS = {14: 2, 15: 3, 16: 256, 17: 128}
+PY_DEFAULTS = {}
 
 
 def set_keys(variant):
     keys = dict(DEFAULTS)
+    from dsgcn_amd import kernels
+    for name, val in PY_DEFAULTS.items():
+        setattr(kernels, name, val)
     if variant:
         for kv in variant.split(','):
             k, v = kv.split('=')
+            if k.startswith('py:'):                     # a module-level switch of ds-gcn_amd/kernels.py, e.g. py:WSPLIT_BATCH=0
+                name = k[3:]
+                PY_DEFAULTS.setdefault(name, getattr(kernels, name))
+                old = PY_DEFAULTS[name]
+                setattr(kernels, name, type(old)(int(v)) if isinstance(old, (bool, int)) else v)
+                continue
             keys[int(k)] = int(v)
     keys.setdefault(100, 1)
     for k, v in keys.items():
