@@ -360,6 +360,42 @@ def test_full_size_properties():
     assert rel(lhs.cpu(), rhs.cpu()) < 1e-6                   # linear in the adjacency
 
 
+@pytest.mark.parametrize('kind', ['ctrgcn', 'stgcn'])
+def test_full_size_properties_other_configs(kind):
+    """The same properties at BASELINE size (64 clips) for config 4 (CTR-GCN: K-A', the refinement chain on 625-position
+    planes, the 5-tap fused temporal stage) and config 1 (ST-GCN: K-A' with the shared adjacency, the 9-tap GEMM-form conv at
+    both strides): finite loss and gradients, logits permute with the clips, and the parameter gradients stay put up to
+    summation-order noise — a tile form that drops or double-counts positions at full size is an O(1) error here."""
+    np.random.seed(0)
+    torch.manual_seed(0)
+    m = D.build_model(other_cfg(kind))
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith(('alpha', 'beta')):
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.5)
+    m = m.cuda().train()
+    flat = D.FlatParams(m)
+    x = torch.randn(64, 1, 2, 64, 25, 3, generator=gen).cuda()
+    y = torch.randint(0, 60, (64, 1), generator=gen).cuda()
+    out = m.train_step(dict(keypoint=x, label=y), None)
+    out['loss'].backward()
+    assert np.isfinite(out['log_vars']['loss']) and flat.check_views() and torch.isfinite(flat.flat_g).all()
+    assert float(flat.flat_g.abs().max()) > 0
+    perm = torch.randperm(64, generator=gen).cuda()
+    with torch.no_grad():
+        l0 = m.cls_head(m.extract_feat(x[:, 0]))
+        l1 = m.cls_head(m.extract_feat(x[perm][:, 0]))
+    assert rel(l1.cpu(), l0[perm].cpu()) < 1e-5
+    g0 = flat.flat_g.clone()
+    flat.zero_grad()
+    m.train_step(dict(keypoint=x[perm], label=y[perm]), None)['loss'].backward()
+    assert rel(flat.flat_g.cpu(), g0.cpu()) < 2e-2, rel(flat.flat_g.cpu(), g0.cpu())
+
+
 def _run_bench_child(extra_env, *args):
     """bench.py in a fresh child process (never re-exec a process that touched the GPU) -> its JSON line."""
     import subprocess
@@ -367,7 +403,8 @@ def _run_bench_child(extra_env, *args):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, **extra_env)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--no-cpu-baseline', '--no-roofline', *args],
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--no-cpu-baseline', '--no-roofline',
+                          '--no-other-configs', *args],
                          cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
@@ -408,7 +445,7 @@ def test_bench_through_torch_distributed_run():
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
                           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
                           '--gpus', '1', '--steps', '2', '--warmup', '4', '--clips-per-gpu', '8', '--no-cpu-baseline',
-                          '--no-roofline'], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+                          '--no-roofline', '--no-other-configs'], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     b = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert b['hip_graph'] and b['n_gpus'] == 1 and b['dist']['world_size'] == 1
