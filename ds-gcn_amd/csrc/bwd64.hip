@@ -173,12 +173,25 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
     // ---- weight gradient ---- (two accumulators: a single one is a chain of dependent MFMAs, and only two waves
     // share a SIMD here)
     if (wg_on) {
-#pragma unroll 4
-      for (int w = 0; w < BF_Q; ++w) {
-        const bf_f2 av = *reinterpret_cast<const bf_f2*>(Ap + 4 * w);
-        const bf_f2 bv = *reinterpret_cast<const bf_f2*>(Bp + 4 * w);
-        accw = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, accw, 0, 0, 0);
-        accw2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, accw2, 0, 0, 0);
+      // operands of steps w+2, w+3 are read from LDS BEFORE the four products of steps w, w+1 are issued (pinned): left to
+      // itself hipcc emits read, read, s_waitcnt lgkmcnt(0), four MFMAs — every pair of steps pays an LDS round trip in
+      // series with its 256 matrix cycles (round-5 disassembly), and the co-resident workgroup does not always cover it
+      bf_f2 av0 = *reinterpret_cast<const bf_f2*>(Ap), bv0 = *reinterpret_cast<const bf_f2*>(Bp);
+      bf_f2 av1 = *reinterpret_cast<const bf_f2*>(Ap + 4), bv1 = *reinterpret_cast<const bf_f2*>(Bp + 4);
+#pragma unroll
+      for (int w = 0; w < BF_Q; w += 2) {
+        bf_f2 an0 = av0, bn0 = bv0, an1 = av1, bn1 = bv1;
+        if (w + 2 < BF_Q) {
+          an0 = *reinterpret_cast<const bf_f2*>(Ap + 4 * (w + 2)); bn0 = *reinterpret_cast<const bf_f2*>(Bp + 4 * (w + 2));
+          an1 = *reinterpret_cast<const bf_f2*>(Ap + 4 * (w + 3)); bn1 = *reinterpret_cast<const bf_f2*>(Bp + 4 * (w + 3));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        accw = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, bv0.x, accw, 0, 0, 0);
+        accw2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, bv0.y, accw2, 0, 0, 0);
+        accw = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, bv1.x, accw, 0, 0, 0);
+        accw2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, bv1.y, accw2, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        av0 = an0; bv0 = bn0; av1 = an1; bv1 = bn1;
       }
     }
     // ---- data gradient: dv tile -> Os ----
@@ -187,13 +200,28 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
       for (int i = 0; i < 16; ++i) { accd[i] = 0.f; accd2[i] = 0.f; }
       const float* Wa = Ws + half * 65 + 32 * cit + l31;          // A[i = ci][k = co] = W[co][ci]
       const float* Db = Ds + half * BF_LS + 32 * pt + l31;        // B[k = co][j = position]
-      int ks = 0;
-#pragma unroll 2
-      for (; ks + 1 < KSd; ks += 2) {
-        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(Wa[2 * ks * 65], Db[2 * ks * BF_LS], accd, 0, 0, 0);
-        accd2 = __builtin_amdgcn_mfma_f32_32x32x2f32(Wa[(2 * ks + 2) * 65], Db[(2 * ks + 2) * BF_LS], accd2, 0, 0, 0);
+      // the same pinning: four k-steps per pass, the next pass's eight operands read ahead of this pass's products.  Rows
+      // past Co are zero in BOTH images (Ws is zero padded, commit() zeroes the dz_eff rows), so the step count is rounded
+      // up to a multiple of four instead of branching on the tail; the read-ahead of the last pass stays inside the
+      // weight image / the Xs tile that follows Ds (values never used).
+      const int KS4 = (KSd + 3) & ~3;
+      float wa[4], db[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { wa[i] = Wa[2 * i * 65]; db[i] = Db[2 * i * BF_LS]; }
+      for (int ks = 0; ks < KS4; ks += 4) {
+        float wn[4], dn[4];
+        const int kn = ks + 4 < 32 ? ks + 4 : 28;                   // (clamped: never past the 64-row images)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { wn[i] = Wa[2 * (kn + i) * 65]; dn[i] = Db[2 * (kn + i) * BF_LS]; }
+        __builtin_amdgcn_sched_barrier(0);
+        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0], db[0], accd, 0, 0, 0);
+        accd2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1], db[1], accd2, 0, 0, 0);
+        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2], db[2], accd, 0, 0, 0);
+        accd2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[3], db[3], accd2, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { wa[i] = wn[i]; db[i] = dn[i]; }
       }
-      if (ks < KSd) accd = __builtin_amdgcn_mfma_f32_32x32x2f32(Wa[2 * ks * 65], Db[2 * ks * BF_LS], accd, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         Os[(32 * cit + bf_row32(r, half)) * BF_LS + 32 * pt + l31] = accd[r] + accd2[r];

@@ -231,7 +231,8 @@ def lab_lib():
     """``libdsgcn_lab.so`` (product + measurement-only entry points), built on first use.  tools/ only."""
     global _lab
     if _lab is None:
-        handle = ctypes.CDLL(build(lab=True))
+        # DSGCN_LAB_LIB: an A/B run of tools/ against another build of the lab library (e.g. the previous round's kernels)
+        handle = ctypes.CDLL(os.environ.get('DSGCN_LAB_LIB') or build(lab=True))
         for name, argtypes in {**SIGNATURES, **LAB_SIGNATURES}.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
