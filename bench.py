@@ -383,7 +383,7 @@ def step_roofline(n, ms_per_step):
         with open(files[-1]) as f:
             for row in csv.reader(f):
                 if row and row[0] == 'TOTAL':
-                    traffic = (float(row[2]) + float(row[3])) * 1e6
+                    traffic = (float(row[2]) + float(row[3])) * 2 ** 20       # the csv's 'MB' are MiB (counter KB / 1024)
                     out.update(traffic=int(traffic), traffic_ratio=round(traffic / alg, 3),
                                traffic_frac=round(traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                traffic_source='committed PMC passes ' + os.path.relpath(files[-1], ROOT) +

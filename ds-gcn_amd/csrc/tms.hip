@@ -1081,15 +1081,17 @@ int dsgcn_tms_wgrad(const float* z, const float* zaug, const float* scale, const
   }
   const int mtl = (maxconv + 15) / 16;
   const dim3 grid((unsigned)p.gx_w, (unsigned)p.nconv);
-#define TM_W(KTV)                                                                              \
+  // five taps x four row tiles: with two input-channel tiles per wave the 160 accumulator registers spilled (71 VGPRs,
+  // round-4 metadata); one tile per wave — four wave groups over the input tiles, two waves sharing the positions — holds 80
+#define TM_W(KTV, NPW4)                                                                        \
   switch (mtl) {                                                                               \
     case 1: TM_LAUNCH((k_tms_wgrad<KTV, 1, 1>), grid, p.lds_w, a, p.nconv); break;             \
     case 2: TM_LAUNCH((k_tms_wgrad<KTV, 2, 2>), grid, p.lds_w, a, p.nconv); break;             \
     case 3: TM_LAUNCH((k_tms_wgrad<KTV, 3, 3>), grid, p.lds_w, a, p.nconv); break;             \
-    case 4: TM_LAUNCH((k_tms_wgrad<KTV, 4, 2>), grid, p.lds_w, a, p.nconv); break;             \
+    case 4: TM_LAUNCH((k_tms_wgrad<KTV, 4, NPW4>), grid, p.lds_w, a, p.nconv); break;          \
     default: return DSGCN_EUNSUPPORTED;                                                        \
   }
-  if (KT == 3) { TM_W(3) } else { TM_W(5) }
+  if (KT == 3) { TM_W(3, 2) } else { TM_W(5, 1) }
 #undef TM_W
   DSGCN_LAUNCH_CHECK();
   return 0;

@@ -6,8 +6,8 @@ timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench.err
 cd /tmp; export TMPDIR=/tmp
 S() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats -d $O/raw_$name -o p --output-format csv -- "$@" > $O/$name.log 2>&1
       f=$(find $O/raw_$name -name 'p_kernel_stats.csv' | head -1); cp "$f" $O/$name.csv; rm -rf $O/raw_$name; }
-S g_bench_cmd_kernel_stats python3 $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline
-S f_kernel_stats python3 $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-graph --no-roofline
+S g_bench_cmd_kernel_stats python3 $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-other-configs
+S f_kernel_stats python3 $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-graph --no-roofline --no-other-configs
 P() { name=$1; prog=$2; shift; shift; timeout 400 rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o p --output-format csv -- python3 $R/$prog > $O/$name.log 2>&1; }
 P pmc1 tools/kc_once.py SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA
 P pmc2 tools/kc_once.py SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VMEM_RD
@@ -18,7 +18,7 @@ P pmc6 tools/kc_once.py WRITE_SIZE
 P pmc7 tools/kc_once.py SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU
 P kaf tools/ka_once.py FETCH_SIZE
 P kaw tools/ka_once.py WRITE_SIZE
-Q() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc $1 -d $O/$name -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-graph --no-roofline --no-cpu-baseline > $O/$name.log 2>&1; }
+Q() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc $1 -d $O/$name -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-graph --no-roofline --no-cpu-baseline --no-other-configs > $O/$name.log 2>&1; }
 Q stf FETCH_SIZE
 Q stw WRITE_SIZE
 cd $R
