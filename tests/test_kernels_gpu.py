@@ -29,21 +29,28 @@ def ref_dev(n):
     return DEV if n >= 64 else 'cpu'
 
 
-def relu_knife_edge(x1, a1, x2, a2, relu, tol=1e-5):
-    """Mask (True = keep) of the input elements whose pre-activation v = x1*s1+h1 (+ x2*s2+h2) is NOT within `tol` of zero.
-    An fp32 and an fp64 evaluation of relu'(v) disagree where |v| is at rounding level; at full size (13-52 M elements) one
-    or two such elements exist, each wrong by a whole gradient value (1e-4 of the tensor's L2 norm: tools/tcg_diag.py found
-    exactly one, the same in dx1 and dx2) — a property of the comparison, not of the kernel."""
+def off_knife_edge(x1, a1, x2, a2, relu, tol=1e-4):
+    """Nudge x1 (in place) wherever the pre-activation v = x1*s1+h1 (+ x2*s2+h2) lies within `tol` of zero.  An fp32 and an
+    fp64 evaluation of relu'(v) disagree where |v| is at rounding level; at full size (13-52 M elements) one or two such
+    elements exist and each is wrong by a whole gradient value — 1e-4 of dx's L2 norm, and of the per-channel sums d scale /
+    d shift it enters (tools/tcg_diag.py found exactly one, the same in dx1 and dx2).  That is a property of comparing two
+    precisions at a discontinuity, not of the kernel: the inputs are moved off the edge instead."""
     if not relu:
-        return None
-    v = x1.double() * (a1[0].double().view(1, -1, 1, 1) if a1 is not None else 1.0)
+        return
+    s1 = a1[0].double().view(1, -1, 1, 1) if a1 is not None else 1.0
+    v = x1.double() * s1
     if a1 is not None:
         v = v + a1[1].double().view(1, -1, 1, 1)
     if x2 is not None:
         v = v + x2.double() * (a2[0].double().view(1, -1, 1, 1) if a2 is not None else 1.0)
         if a2 is not None:
             v = v + a2[1].double().view(1, -1, 1, 1)
-    return v.abs() > tol
+    near = v.abs() < tol
+    if near.any():
+        step = torch.where(v >= 0, 1.0, -1.0) * (2 * tol) / s1
+        x1 += (step * near).float()
+        v = v + step * near * s1
+    assert float(v.abs().min()) >= 0.9 * tol
 
 
 @pytest.mark.parametrize('n,KC,T,V,relu,affine', [
@@ -202,6 +209,7 @@ def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
         x2 = _rand(g, n, Ci, T, V)
     if mode == 'res_affine':
         a2 = (torch.rand(Ci, generator=g) + 0.5, _rand(g, Ci, scale=0.3))
+    off_knife_edge(x1, a1, x2, a2, relu)
     w = _rand(g, Co, Ci, 1, 1, scale=Ci ** -0.5)
     b = _rand(g, Co, scale=0.1)
     n_aff = Co - Co // 6 if aug else Co
@@ -239,19 +247,14 @@ def test_pwconv(n, Ci, Co, T, V, stride, aug, mode):
 
     got = run(K, torch.float32, DEV)
     ref = run(R, torch.float64, ref_dev(n))
-    keep = relu_knife_edge(x1, a1, x2, a2, relu)
     for k, v in ref.items():
         # fp32 MFMA dot products over <=256 channels, sums over <= n*T*V positions: 1e-5 relative L2
         tol = 2e-5 if k not in ('db',) else 2e-4      # db of a conv feeding BN is ~0 analytically (cancellation)
-        if k in ('dx1', 'dx2') and keep is not None:
-            assert int((~keep).sum()) <= 1e-5 * keep.numel() + 4
-            err = rel(got[k].detach().cpu() * keep, v.detach().cpu() * keep)
-        else:
-            err = rel(got[k].detach().cpu(), v.detach())
+        err = rel(got[k].detach().cpu(), v.detach())
         if k == 'db':
             err = maxabs(got[k].detach().cpu(), v.detach()) / (ref['dw'].abs().max().item() + 1e-30)
         if n >= 64 and k in ('ds1', 'dh1', 'ds2', 'dh2', 'dgamma', 'dbeta', 'dw'):
-            tol = 5e-5           # sums over 2e5 positions in fp32 (sqrt(N) * 2^-24 = 2.7e-5) + the knife-edge element
+            tol = 5e-5           # sums over 2e5 positions in fp32 (sqrt(N) * 2^-24 = 2.7e-5)
         assert err < tol, (k, err)
 
 
@@ -287,6 +290,7 @@ def test_tconv_gemm(n, Ci, Co, T, V, KT, mode, stride):
         x2 = _rand(g, n, Ci, T, V)
     if mode == 'res_affine':
         a2 = (torch.rand(Ci, generator=g) + 0.5, _rand(g, Ci, scale=0.3))
+    off_knife_edge(x1, a1, x2, a2, relu)
     w = _rand(g, Co, Ci, KT, 1, scale=(Ci * KT) ** -0.5)
     b = _rand(g, Co, scale=0.1)
     gamma = torch.rand(Co, generator=g) + 0.5
@@ -316,17 +320,12 @@ def test_tconv_gemm(n, Ci, Co, T, V, KT, mode, stride):
 
     got = run(K, torch.float32, DEV)
     ref = run(R, torch.float64, ref_dev(n))
-    keep = relu_knife_edge(x1, a1, x2, a2, relu)
     for k, v in ref.items():
-        if k in ('dx1', 'dx2') and keep is not None:
-            assert int((~keep).sum()) <= 1e-5 * keep.numel() + 4
-            err = rel(got[k].detach().cpu() * keep, v.detach().cpu() * keep)
-        else:
-            err = rel(got[k].detach().cpu(), v.detach())
+        err = rel(got[k].detach().cpu(), v.detach())
         if k == 'db':           # db of a conv feeding BN is ~0 analytically (cancellation): absolute, against dW's scale
             err = maxabs(got[k].detach().cpu(), v.detach()) / (ref['dw'].abs().max().item() + 1e-30)
-        # full size: the per-channel sums run over 2e5 positions in fp32 (sqrt(N) * 2^-24 = 2.7e-5) and carry the
-        # knife-edge element too: 5e-5 for them, the small cases and every elementwise output keep 2e-5
+        # full size: the per-channel sums run over 2e5 positions in fp32 (sqrt(N) * 2^-24 = 2.7e-5): 5e-5 for them, the
+        # small cases and every elementwise output keep 2e-5
         bar = 5e-5 if (n >= 64 and k in ('ds1', 'dh1', 'ds2', 'dh2', 'dgamma', 'dbeta', 'dw')) else 2e-5
         assert err < (2e-4 if k == 'db' else bar), (k, err)
     got2 = run(K, torch.float32, DEV)          # ordered partial sums: bit-reproducible
