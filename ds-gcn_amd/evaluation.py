@@ -1,54 +1,44 @@
-"""Accuracy metrics used on the training path (reference: pyskl/core/evaluation.py:85-126)."""
+"""Accuracy metrics used on the training / validation path.  Contract: pyskl/core/evaluation.py:21-126 — ``top_k_accuracy``
+(a sample counts when its label is among the k best scores), ``confusion_matrix`` (rows = true class, columns = predicted,
+over the classes that OCCUR in either list, in sorted order), ``mean_class_accuracy`` (this fork returns the pair
+(mean of the per-class recalls over those classes, confusion matrix); datasets/base.py:194,201 unpacks it)."""
 import numpy as np
 
 
 def top_k_accuracy(scores, labels, topk=(1, )):
-    """Fraction of samples whose label is among the k highest scores, per k."""
+    """-> list, per k: the fraction of samples whose label is one of their k highest-scoring classes (ties resolved the
+    way a stable ascending argsort resolves them: the later class wins)."""
     scores = np.asarray(scores)
-    labels = np.array(labels)[:, np.newaxis]
-    res = []
-    for k in topk:
-        max_k_preds = np.argsort(scores, axis=1)[:, -k:][:, ::-1]
-        match = np.logical_or.reduce(max_k_preds == labels, axis=1)
-        res.append(match.sum() / match.shape[0])
-    return res
+    want = np.asarray(labels).reshape(-1, 1)
+    ranked = np.argsort(scores, axis=1)                     # ascending: the best k are the last k columns
+    return [float((ranked[:, scores.shape[1] - k:] == want).any(axis=1).mean()) for k in topk]
 
 
 def confusion_matrix(y_pred, y_real, normalize=None):
-    if normalize not in ['true', 'pred', 'all', None]:
+    """Counts[i, j] = samples of the i-th occurring class predicted as the j-th occurring class (classes = sorted union of
+    both inputs).  ``normalize``: None | 'true' (rows sum to 1) | 'pred' (columns) | 'all'; empty rows / columns give 0."""
+    if normalize not in ('true', 'pred', 'all', None):
         raise ValueError("normalize must be one of {'true', 'pred', 'all', None}")
-    y_pred = np.asarray(y_pred)
-    y_real = np.asarray(y_real)
-    if y_pred.dtype == np.int32:
-        y_pred = y_pred.astype(np.int64)
-    if y_real.dtype == np.int32:
-        y_real = y_real.astype(np.int64)
-    if not np.issubdtype(y_pred.dtype, np.integer) or not np.issubdtype(y_real.dtype, np.integer):
-        raise TypeError('y_pred and y_real must be integer arrays')
-    label_set = np.unique(np.concatenate((y_pred, y_real)))
-    num_labels = len(label_set)
-    max_label = label_set[-1]
-    label_map = np.zeros(max_label + 1, dtype=np.int64)
-    for i, label in enumerate(label_set):
-        label_map[label] = i
-    cm = np.bincount(num_labels * label_map[y_real] + label_map[y_pred],
-                     minlength=num_labels**2).reshape(num_labels, num_labels)
+    pred, real = np.asarray(y_pred), np.asarray(y_real)
+    for name, a in (('y_pred', pred), ('y_real', real)):
+        if not np.issubdtype(a.dtype, np.integer):
+            raise TypeError(f'{name} must hold integer class ids, got {a.dtype}')
+    classes, codes = np.unique(np.concatenate([real.ravel(), pred.ravel()]), return_inverse=True)
+    k = len(classes)
+    row, col = codes[:real.size], codes[real.size:]
+    counts = np.zeros((k, k), dtype=np.int64)
+    np.add.at(counts, (row, col), 1)
+    if normalize is None:
+        return counts
+    total = {'true': counts.sum(1, keepdims=True), 'pred': counts.sum(0, keepdims=True), 'all': counts.sum()}[normalize]
     with np.errstate(all='ignore'):
-        if normalize == 'true':
-            cm = cm / cm.sum(axis=1, keepdims=True)
-        elif normalize == 'pred':
-            cm = cm / cm.sum(axis=0, keepdims=True)
-        elif normalize == 'all':
-            cm = cm / cm.sum()
-        cm = np.nan_to_num(cm)
-    return cm
+        return np.nan_to_num(counts / total)
 
 
 def mean_class_accuracy(scores, labels):
-    """-> (mean class accuracy, confusion matrix): this fork returns the pair (pyskl/core/evaluation.py:85-104; the
-    dataset's ``evaluate`` unpacks it, datasets/base.py:194,201)."""
-    pred = np.argmax(scores, axis=1)
-    cm = confusion_matrix(pred, labels).astype(float)
-    cls_cnt = cm.sum(axis=1)
-    cls_hit = np.diag(cm)
-    return np.mean([hit / cnt if cnt else 0.0 for cnt, hit in zip(cls_cnt, cls_hit)]), cm
+    """-> (mean over the occurring classes of hits / samples of that class — a class that only occurs as a prediction
+    counts as 0 —, confusion matrix as float)."""
+    counts = confusion_matrix(np.argmax(scores, axis=1), labels).astype(float)
+    seen = counts.sum(axis=1)
+    recall = np.divide(np.diag(counts), seen, out=np.zeros_like(seen), where=seen > 0)
+    return float(recall.mean()), counts
