@@ -497,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
   // 8 channels x 128 row slices per block: the kernel is a latency chain over the partial rows (up to ~1800 of them),
   // so the rows are spread over many threads and C/8 blocks rather than walked by 32 slices in C/32 blocks
   constexpr int CB = 8, NS = 128;
-  __shared__ double red[NS][CB][2];
+  __shared__ double red[NS / 8][CB][2];
   const int cl = threadIdx.x & (CB - 1), slice = threadIdx.x / CB;
   const int c = blockIdx.x * CB + cl;
   double s = 0.0, q = 0.0;
@@ -514,20 +514,24 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
       for (int j = 0; j < 4; ++j) { s += (double)v[j].x; q += (double)v[j].y; }
     }
   }
-  red[slice][cl][0] = s;
-  red[slice][cl][1] = q;
-  __syncthreads();
-  // tree over the slices (fixed order: deterministic)
-  for (int h = NS / 2; h >= 1; h >>= 1) {
-    if (slice < h) {
-      red[slice][cl][0] += red[slice + h][cl][0];
-      red[slice][cl][1] += red[slice + h][cl][1];
-    }
-    __syncthreads();
+  // the 8 slices of a wave (lanes cl + 8*j) meet through three lane exchanges, the 16 waves through ONE LDS hand-off
+  // (round 5: the seven-level LDS tree with a workgroup barrier per level was ~1 us of a 4 us launch); fixed order:
+  // deterministic
+#pragma unroll
+  for (int off = 8; off < 64; off <<= 1) {
+    s += __shfl_xor(s, off, 64);
+    q += __shfl_xor(q, off, 64);
   }
+  if ((threadIdx.x & 63) < CB) {
+    red[threadIdx.x >> 6][cl][0] = s;
+    red[threadIdx.x >> 6][cl][1] = q;
+  }
+  __syncthreads();
   if (slice == 0 && c < C) {
-    s = red[0][cl][0];
-    q = red[0][cl][1];
+    s = 0.0;
+    q = 0.0;
+#pragma unroll
+    for (int w = 0; w < NS / 8; ++w) { s += red[w][cl][0]; q += red[w][cl][1]; }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -1173,7 +1177,7 @@ __global__ __launch_bounds__(1024) void k_bn_coef_rows(const float* __restrict__
                                                        const float* __restrict__ gamma, float eps, double count,
                                                        int c_affine, float* __restrict__ coef, int accumulate) {
   constexpr int CB = 8, NS = 128;
-  __shared__ double red[NS][CB][2];
+  __shared__ double red[NS / 8][CB][2];
   const int cl = threadIdx.x & (CB - 1), sl = threadIdx.x / CB;
   const int c = blockIdx.x * CB + cl;
   // the finishing thread's own operands first: their round trip overlaps the row sums
@@ -1203,18 +1207,20 @@ __global__ __launch_bounds__(1024) void k_bn_coef_rows(const float* __restrict__
       for (int j = 0; j < 4; ++j) { s0 += (double)x[j]; s1 += (double)y[j]; }
     }
   }
-  red[sl][cl][0] = s0;
-  red[sl][cl][1] = s1;
-  __syncthreads();
-  for (int h = NS / 2; h >= 1; h >>= 1) {          // tree over the slices (fixed order: deterministic)
-    if (sl < h) {
-      red[sl][cl][0] += red[sl + h][cl][0];
-      red[sl][cl][1] += red[sl + h][cl][1];
-    }
-    __syncthreads();
+#pragma unroll
+  for (int off = 8; off < 64; off <<= 1) {          // a wave's 8 slices by lane exchange, the 16 waves through one LDS hand-off
+    s0 += __shfl_xor(s0, off, 64);
+    s1 += __shfl_xor(s1, off, 64);
   }
+  if ((threadIdx.x & 63) < CB) {
+    red[threadIdx.x >> 6][cl][0] = s0;
+    red[threadIdx.x >> 6][cl][1] = s1;
+  }
+  __syncthreads();
   if (sl == 0 && c < C) {
-    const double gs = red[0][cl][0], gh = red[0][cl][1];
+    double gs = 0.0, gh = 0.0;
+#pragma unroll
+    for (int w = 0; w < NS / 8; ++w) { gs += red[w][cl][0]; gh += red[w][cl][1]; }
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < c_affine) {
       const double mu = mu_f, r = 1.0 / sqrt((double)var_f + (double)eps);
