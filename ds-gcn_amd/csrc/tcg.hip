@@ -507,6 +507,7 @@ TsDims ts_dims(int Ci, int Co, int KT) {
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------------
 constexpr int TW_TM = 128, TW_TN = 64;             // co rows, ci columns per workgroup
+constexpr int TW_RING = 256;                       // stride 1: positions per row of the x' ring (>= 32 + 2*pad*V + 6)
 __host__ __device__ constexpr int tw_group(int KT) { return KT > 3 ? 3 : KT; }   // taps staged together (register budget: 16*KT accumulators)
 
 struct TcwArgs {
@@ -530,10 +531,9 @@ __device__ long long g_tcw_stamp[64];
 #define TCW_STAMP() do {} while (0)
 #endif
 
-// ST: 1 = stride 1 with NQI window quads per thread (ST = 13 / 14: 3 / 4 quads), 2 = stride 2
-template <int KT, int STQ>
+// ST: 1 = stride 1 (the x' ring), 2 = stride 2
+template <int KT, int ST>
 __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
-  constexpr int ST = STQ >= 10 ? 1 : STQ;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef DSGCN_LAB
   int nst = 0;
@@ -544,14 +544,15 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
   // both images double-buffered: a step's products read one set while the next step's operands are written into the
   // other — one barrier per tap group instead of two
   constexpr int ASZ = 3 * TW_TM * TG_RB, BSZ = TW_G * 3 * TW_TN * TG_RB;
-  char* Ab0 = reinterpret_cast<char*>(lds);                              // [2][3][128 co][RB]   k = positions
-  char* Bb0 = Ab0 + 2 * ASZ;                                             // [2][TW_G][3][64 ci][RB]  (stride 1: one set)
-  // stride 1: the activated, zero-padded x' window of a tap group as fp32, [64 ci][XP]: every x' value is loaded,
-  // activated and masked ONCE per group with coalesced 16-byte loads, the per-tap operand images are cut out of it —
-  // the first version fetched each tap's shifted copy with 4-byte loads 16 B apart per lane and was bound by the
-  // address path (1-2 us to issue a group's loads, lab stamps)
-  const int NQD = (32 + (TW_G - 1) * a.V + 3 + 3) >> 2;                  // aligned quads per window row
-  const int XP = NQD * 4 + 4;
+  char* Ab0 = reinterpret_cast<char*>(lds);                              // [2][3][128 co][RB]   k = positions (stride 1: one set)
+  char* Bb0 = Ab0 + (ST == 1 ? 1 : 2) * ASZ;                             // [2][TW_G][3][64 ci][RB]  (stride 1: one set)
+  // stride 1: the activated, zero-padded x' values of the unit's WHOLE tap span live in LDS as fp32, [64 ci][ring of
+  // TW_RING positions]: a unit needs positions [p0 - pad*V, p0 + 32 + pad*V) and the next unit of the sample the same span
+  // moved by 32, so a unit loads, activates and masks only its 32 NEW positions per row (one 16-byte load per thread and
+  // stream) and the per-tap operand images are cut out of the ring.  (Round 3 loaded a fresh window per tap group: 3 x 88
+  // positions per row and unit = 8.25x every x' value through L2, and the lab stamps of round 5 showed the load / activate
+  // step as the longest of a tap group's three: profiles/r05.)
+  constexpr int XP = TW_RING + 28;                                       // row stride (floats): 28 mod 64 spreads a wave's 8 rows over the banks
   float* XR = reinterpret_cast<float*>(Bb0 + BSZ);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -576,19 +577,11 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
                                                    // for stride 1 were tried: fewer address-path cycles, but the second
                                                    // quad's registers spill next to 144 accumulators: no faster)
   auto unit_base = [&](int u, int& ns, int& p0) { ns = u / a.cpl; p0 = (u - ns * a.cpl) * 32; };
-  // window loader (stride 1): quad i of this thread = (row xrow[i], aligned quad xqd[i]) of the 64 x NQD window
-  constexpr int NQI = STQ >= 10 ? STQ - 10 : 1;
-  int xrow[NQI], xqd[NQI];
-  f32x4 xw[NQI], xw2[NQI];
+  // ring loader (stride 1).  Incremental: thread -> (row tid / 8, quad tid % 8) of the 32 new positions of a unit.
+  f32x4 xn = {0.f, 0.f, 0.f, 0.f}, xn2 = {0.f, 0.f, 0.f, 0.f};
   f32x4* XPs = reinterpret_cast<f32x4*>(XR + TW_TN * XP);       // [64] (s1, h1, s2, h2) of the window's channels
+  const int padV = pad * V;
   if constexpr (ST == 1) {
-#pragma unroll
-    for (int i = 0; i < NQI; ++i) {
-      const int q_ = tid + TW_NT * i;
-      const int r_ = q_ / NQD;
-      xrow[i] = (q_ < TW_TN * NQD && ci0 + r_ < Ci) ? r_ : -1;
-      xqd[i] = q_ - r_ * NQD;
-    }
     if (tid < TW_TN) {
       const int c_ = ci0 + tid;
       const bool ok = c_ < Ci;
@@ -596,62 +589,83 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
                        (ok && a.s2) ? a.h2[c_] : 0.f};
     }
   }
-  auto win = [&](int u, int grp, int& ns, int& ws, int& wa) {
-    int p0;
-    unit_base(u, ns, p0);
-    ws = p0 + (grp * TW_G - pad) * V;
-    wa = (ws >> 2) << 2;                           // floor to a quad (ws may be negative)
-  };
-  auto issueX = [&](int u, int grp) {
-    int ns, ws, wa;
-    win(u, grp, ns, ws, wa);
-    const __amdgpu_buffer_rsrc_t rx1 = tg_rsrc(a.x1 + (size_t)ns * Ci * Lx, Ci * Lx * 4);
-    const __amdgpu_buffer_rsrc_t rx2 = tg_rsrc((x2on ? a.x2 : a.x1) + (size_t)ns * Ci * Lx, x2on ? Ci * Lx * 4 : 0);
+  const bool xact = xaff || a.relu || x2on;
+  // activated, masked quad at plane position xp (a multiple of 4) of row r -> its ring slot
+  auto ring_put = [&](int r, int xp, const f32x4& v1, const f32x4& v2) {
+    const f32x4 par = XPs[r];
+    const float r1[4] = {v1.x, v1.y, v1.z, v1.w}, r2[4] = {v2.x, v2.y, v2.z, v2.w};
+    float o[4];
 #pragma unroll
-    for (int i = 0; i < NQI; ++i) {
-      const int xp = wa + 4 * xqd[i];
-      // (quads entirely outside the plane: out of range -> zeros; quads that straddle it are masked per element later)
-      const int vo = (xrow[i] >= 0 && xp > -4 && xp < Lx) ? ((ci0 + xrow[i]) * Lx + xp) * 4 : TG_OOB;
-      xw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx1, vo, 0, 0));
-      xw2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, vo, 0, 0));
+    for (int e = 0; e < 4; ++e) {
+      float x = r1[e];
+      if (xact) {
+        x = fmaf(x, par.x, par.y);
+        if (x2on) x += fmaf(r2[e], par.z, par.w);
+        x = fmaxf(x, lo);
+      }
+      o[e] = (xp + e >= 0 && xp + e < Lx && ci0 + r < Ci) ? x : 0.f;     // zero padding applies to the activated value
     }
+    *reinterpret_cast<f32x4*>(XR + r * XP + ((xp + 4 * TW_RING) & (TW_RING - 1))) = f32x4{o[0], o[1], o[2], o[3]};
   };
-  auto stageX = [&](int u, int grp) {
-    int ns, ws, wa;
-    win(u, grp, ns, ws, wa);
+  auto x_rsrc = [&](int ns, __amdgpu_buffer_rsrc_t& rx1, __amdgpu_buffer_rsrc_t& rx2) {
+    rx1 = tg_rsrc(a.x1 + (size_t)ns * Ci * Lx, Ci * Lx * 4);
+    rx2 = tg_rsrc((x2on ? a.x2 : a.x1) + (size_t)ns * Ci * Lx, x2on ? Ci * Lx * 4 : 0);
+  };
+  // aligned end of the span of the unit at p0
+  auto span_hi = [&](int p0) { return (p0 + 32 + padV + 3) & ~3; };
+  auto issueNew = [&](int u) {                     // the 32 new positions of unit u (a continuation of its sample's previous unit)
+    int ns, p0;
+    unit_base(u, ns, p0);
+    __amdgpu_buffer_rsrc_t rx1, rx2;
+    x_rsrc(ns, rx1, rx2);
+    const int r = tid >> 3, xp = span_hi(p0) - 32 + 4 * (tid & 7);
+    // (quads are 4-aligned and the plane length is a multiple of 4: a quad is entirely inside or outside the plane)
+    const int vo = (ci0 + r < Ci && xp >= 0 && xp < Lx) ? ((ci0 + r) * Lx + xp) * 4 : TG_OOB;
+    xn = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx1, vo, 0, 0));
+    xn2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, vo, 0, 0));
+  };
+  auto stageNew = [&](int u) {
+    int ns, p0;
+    unit_base(u, ns, p0);
+    ring_put(tid >> 3, span_hi(p0) - 32 + 4 * (tid & 7), xn, xn2);
+  };
+  auto reload = [&](int u) {                       // the whole span of unit u (first unit of a workgroup / of a sample)
+    int ns, p0;
+    unit_base(u, ns, p0);
+    __amdgpu_buffer_rsrc_t rx1, rx2;
+    x_rsrc(ns, rx1, rx2);
+    const int lo4 = (p0 - padV) & ~3, nq = (span_hi(p0) - lo4) >> 2;     // (floor: also for negative starts)
+    for (int q0 = tid; q0 < TW_TN * nq; q0 += 4 * TW_NT) {
+      f32x4 w1[4], w2[4];
 #pragma unroll
-    for (int i = 0; i < NQI; ++i) {
-      if (xrow[i] >= 0) {
-        const int xp = wa + 4 * xqd[i];
-        const float r1[4] = {xw[i].x, xw[i].y, xw[i].z, xw[i].w}, r2[4] = {xw2[i].x, xw2[i].y, xw2[i].z, xw2[i].w};
-        const f32x4 par = XPs[xrow[i]];
-        float o[4];
+      for (int i = 0; i < 4; ++i) {
+        const int q_ = q0 + TW_NT * i, r = q_ / nq, xp = lo4 + 4 * (q_ - r * nq);
+        const int vo = (q_ < TW_TN * nq && ci0 + r < Ci && xp >= 0 && xp < Lx) ? ((ci0 + r) * Lx + xp) * 4 : TG_OOB;
+        w1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx1, vo, 0, 0));
+        w2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, vo, 0, 0));
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = r1[e];
-          if (xaff || a.relu || x2on) {
-            x = fmaf(x, par.x, par.y);
-            if (x2on) x += fmaf(r2[e], par.z, par.w);
-            x = fmaxf(x, lo);
-          }
-          o[e] = (xp + e >= 0 && xp + e < Lx) ? x : 0.f;     // zero padding applies to the activated value
-        }
-        *reinterpret_cast<f32x4*>(XR + xrow[i] * XP + 4 * xqd[i]) = f32x4{o[0], o[1], o[2], o[3]};
+      for (int i = 0; i < 4; ++i) {
+        const int q_ = q0 + TW_NT * i, r = q_ / nq;
+        if (q_ < TW_TN * nq) ring_put(r, lo4 + 4 * (q_ - r * nq), w1[i], w2[i]);
       }
     }
   };
   auto buildB = [&](int u, int grp) {
-    int ns, ws, wa;
-    win(u, grp, ns, ws, wa);
-    const float* xr = XR + brow * XP + (ws - wa) + 4 * bpc;
+    int ns, p0;
+    unit_base(u, ns, p0);
+    const int ws = p0 + (grp * TW_G - pad) * V + 4 * bpc + 4 * TW_RING;   // (+ a multiple of the ring: non-negative)
+    const float* xr = XR + brow * XP;
 #pragma unroll
     for (int tl = 0; tl < TW_G; ++tl) {
       const int tap = grp * TW_G + tl;
       if (tap < KT) {
-        const float* q_ = xr + tl * V;
+        const int q_ = ws + tl * V;
+        const float v0 = xr[q_ & (TW_RING - 1)], v1 = xr[(q_ + 1) & (TW_RING - 1)], v2 = xr[(q_ + 2) & (TW_RING - 1)],
+                    v3 = xr[(q_ + 3) & (TW_RING - 1)];
         unsigned p0_, p1_, p2_, q0_, q1_, q2_;
-        b3_split(q_[0], q_[1], p0_, p1_, p2_);
-        b3_split(q_[2], q_[3], q0_, q1_, q2_);
+        b3_split(v0, v1, p0_, p1_, p2_);
+        b3_split(v2, v3, q0_, q1_, q2_);
         char* base = Bb0 + (tl * 3 * TW_TN + brow) * TG_RB + bpc * 8;
         *reinterpret_cast<u32x2v*>(base) = u32x2v{p0_, q0_};
         *reinterpret_cast<u32x2v*>(base + TW_TN * TG_RB) = u32x2v{p1_, q1_};
@@ -807,26 +821,36 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
     __builtin_amdgcn_s_barrier();
   };
   if constexpr (ST == 1) {
-    if (u0 < u1) {
-      issueA(u0);
-      issueX(u0, 0);
-    }
+    // Units in order; `fresh` = the first unit of this workgroup or of a sample (the ring holds nothing of it yet).
+    auto sample_of = [&](int u_) { return u_ / a.cpl; };
+    lds_barrier();                                 // the affine table of the window's channels is visible
+    if (u0 < u1) issueA(u0);
     for (int u = u0; u < u1; ++u) {
-      const int abuf = (u - u0) & 1;
-      commitA(u, abuf);                            // (the other A buffer may still be read by a slower wave)
+      const bool fresh = u == u0 || sample_of(u) != sample_of(u - 1);
+      const bool cont1 = u + 1 < u1 && sample_of(u + 1) == sample_of(u);          // u + 1 continues this sample's ring
+      const bool cont2 = cont1 && u + 2 < u1 && sample_of(u + 2) == sample_of(u);
+      if (fresh) {
+        // (every wave is past the second barrier of the previous unit's last tap group: nobody reads the ring any more)
+        reload(u);
+        if (cont1) issueNew(u + 1);
+      }
 #pragma unroll
-      for (int grp = 0; grp < NG; ++grp) {
+      for (int grp = 0; grp < NG; ++grp) {           // (unrolled: the tap indices of the accumulators are compile-time)
         TCW_STAMP();
-        lds_barrier();                             // every wave is done with the previous step's window and images
-        stageX(u, grp);
-        if (grp + 1 < NG) issueX(u, grp + 1);      // lands while this step is built and multiplied
-        else if (u + 1 < u1) { issueA(u + 1); issueX(u + 1, 0); }
-        TCW_STAMP();
-        lds_barrier();                             // window complete
+        lds_barrier();                               // every wave is done with the previous step's products: images and dz image are free
+        if (grp == 0) commitA(u, 0);
         buildB(u, grp);
         TCW_STAMP();
-        lds_barrier();                             // images (and, first group, the dz image) complete
-        products(grp, abuf, 0);
+        lds_barrier();                               // images (and the dz image) complete
+        products(grp, 0, 0);
+        TCW_STAMP();
+        if (grp == 0) {
+          // the next unit's 32 new positions go into ring slots no tap group of THIS unit reads after its first one
+          // (new: [p0 + 32 + pad*V, + 32); still to be read: [p0 + (TW_G - pad)*V, p0 + 32 + pad*V))
+          if (cont1) stageNew(u + 1);
+          if (cont2) issueNew(u + 2);
+          if (u + 1 < u1) issueA(u + 1);
+        }
         TCW_STAMP();
       }
     }
@@ -890,10 +914,9 @@ bool tw_plan(int n, int Ci, int Co, int To, int V, int KT, TwPlan* p, int st = 1
   p->splits = splits;
   {
     const size_t asz = (size_t)3 * TW_TM * TG_RB, bsz = (size_t)tw_group(KT) * 3 * TW_TN * TG_RB;
-    const int nqd = (32 + (tw_group(KT) - 1) * V + 3 + 3) >> 2;
-    if (st == 1 && TW_TN * nqd > 4 * TW_NT) return false;         // (window quads per thread)
-    p->nqi = (TW_TN * nqd + TW_NT - 1) / TW_NT <= 3 ? 3 : 4;
-    p->lds = st == 1 ? 2 * asz + bsz + (size_t)TW_TN * (nqd * 4 + 4) * sizeof(float) + TW_TN * 16 : 2 * (asz + bsz);
+    if (st == 1 && 32 + (KT - 1) * V + 6 > TW_RING) return false;  // (the unit's tap span must fit the x' ring)
+    p->nqi = 3;
+    p->lds = st == 1 ? asz + bsz + (size_t)TW_TN * (TW_RING + 28) * sizeof(float) + TW_TN * 16 : 2 * (asz + bsz);
   }
   return true;
 }
@@ -1062,23 +1085,17 @@ int dsgcn_tconv_wgrad(const float* x1, const float* s1, const float* h1, const f
   const dim3 grid((unsigned)(p.splits * p.ccM * p.ccN)), blk(TW_NT);
   static bool raised = false;
   if (!raised) {
-    const void* fs[9] = {reinterpret_cast<const void*>(&k_tcw<9, 13>), reinterpret_cast<const void*>(&k_tcw<5, 13>),
-                         reinterpret_cast<const void*>(&k_tcw<3, 13>), reinterpret_cast<const void*>(&k_tcw<9, 14>),
-                         reinterpret_cast<const void*>(&k_tcw<5, 14>), reinterpret_cast<const void*>(&k_tcw<3, 14>),
-                         reinterpret_cast<const void*>(&k_tcw<9, 2>), reinterpret_cast<const void*>(&k_tcw<5, 2>),
-                         reinterpret_cast<const void*>(&k_tcw<3, 2>)};
+    const void* fs[6] = {reinterpret_cast<const void*>(&k_tcw<9, 1>), reinterpret_cast<const void*>(&k_tcw<5, 1>),
+                         reinterpret_cast<const void*>(&k_tcw<3, 1>), reinterpret_cast<const void*>(&k_tcw<9, 2>),
+                         reinterpret_cast<const void*>(&k_tcw<5, 2>), reinterpret_cast<const void*>(&k_tcw<3, 2>)};
     for (const void* f : fs) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     raised = true;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (stride == 1 && p.nqi == 3) {
-    if (KT == 9) hipLaunchKernelGGL((k_tcw<9, 13>), grid, blk, p.lds, st, a);
-    else if (KT == 5) hipLaunchKernelGGL((k_tcw<5, 13>), grid, blk, p.lds, st, a);
-    else hipLaunchKernelGGL((k_tcw<3, 13>), grid, blk, p.lds, st, a);
-  } else if (stride == 1) {
-    if (KT == 9) hipLaunchKernelGGL((k_tcw<9, 14>), grid, blk, p.lds, st, a);
-    else if (KT == 5) hipLaunchKernelGGL((k_tcw<5, 14>), grid, blk, p.lds, st, a);
-    else hipLaunchKernelGGL((k_tcw<3, 14>), grid, blk, p.lds, st, a);
+  if (stride == 1) {
+    if (KT == 9) hipLaunchKernelGGL((k_tcw<9, 1>), grid, blk, p.lds, st, a);
+    else if (KT == 5) hipLaunchKernelGGL((k_tcw<5, 1>), grid, blk, p.lds, st, a);
+    else hipLaunchKernelGGL((k_tcw<3, 1>), grid, blk, p.lds, st, a);
   } else {
     if (KT == 9) hipLaunchKernelGGL((k_tcw<9, 2>), grid, blk, p.lds, st, a);
     else if (KT == 5) hipLaunchKernelGGL((k_tcw<5, 2>), grid, blk, p.lds, st, a);
