@@ -42,7 +42,7 @@ struct TcgArgs {
   const float* b1; const float* b2;                                        // B streams (n, K, T, V); b2 NULL unless MODE 2
   const float* ps1; const float* ph1; const float* ps2; const float* ph2;  // per-k affine (NULL = 1 / 0)
   int relu;
-  const unsigned short* wsp;                                               // [KT][3][Mp][Kp] bf16, rows = output rows
+  const unsigned short* wsp;                                               // [KT][3][Mp x Kp in fragment order] bf16, rows = output rows
   const float* bias;                                                       // per output row, NULL ok (forward)
   float* out;                                                              // (n, M, T, V)
   float* partial;                                                          // EPI 0: [tiles][M][2] or NULL
@@ -259,7 +259,11 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
   };
   // A fragments straight from the pre-split image (L2): lane (l31, half) of row tile rt wants, per term and k-step, the 8
   // consecutive k [16*ks + 8*half, +8) of row mBase0 + 32*rt + l31 — 16 contiguous bytes.  No LDS copy, no barrier per tap.
-  const unsigned short* arow = a.wsp + ((size_t)(mBase0 + 32 * rt + l31) * a.Kp + 8 * half);
+  // (round 5) The image is in MFMA-FRAGMENT order inside every (tap, term) plane — [row tile][k-step][lane = 32*(k%16 / 8) +
+  // row%32][k%8] — so a wave's fragment is ONE contiguous 1 KB.  On the row-major image a fragment load touched 32 rows x 32 B:
+  // the weight fragments were 10-11 GB of L2 requests per ST-GCN step (86-92 % hits, profiles/r05/l2_requests_stgcn.csv), with
+  // one tap of products (0.3-0.6 us) to hide each of them behind.
+  const unsigned short* arow = a.wsp + ((size_t)((mBase0 >> 5) + rt) * (a.Kp >> 4)) * 512 + (half * 32 + l31) * 8;
   const size_t tstride = (size_t)a.Mp * a.Kp;      // elements between the (tap, term) planes
   u32x4v ac[2][3], an[2][3];
   auto loadA = [&](int tap, int ch0, u32x4v (&af)[2][3]) {
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int t = 0; t < 3; ++t)
-        af[ks][t] = *reinterpret_cast<const u32x4v*>(arow + (size_t)(tap * 3 + t) * tstride + ch0 + 16 * ks);
+        af[ks][t] = *reinterpret_cast<const u32x4v*>(arow + (size_t)(tap * 3 + t) * tstride + ((ch0 >> 4) + ks) * 512);
   };
   f32x16 acc[NQW];
 #pragma unroll
@@ -456,9 +460,10 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
   }
 }
 
-// The three bf16 terms of W (Co, Ci, KT) per tap, rows k-contiguous and zero-padded to whole tiles:
-//   N image (forward):        [KT][3][MpN = ceil128(Co)][KpN = ceil32(Ci)]   value W[co][ci][tap]
-//   T image (data gradient):  [KT][3][MpT = ceil128(Ci)][KpT = ceil32(Co)]   value W[co][ci][KT-1-tap]     (after N)
+// The three bf16 terms of W (Co, Ci, KT) per tap, zero-padded to whole tiles, every (tap, term) plane in MFMA-fragment
+// order [row tile of 32][k-step of 16][lane = 32*(k%16 / 8) + row%32][k%8] (a wave's A fragment = one contiguous 1 KB):
+//   N image (forward):        [KT][3][MpN = ceil128(Co) x KpN = ceil32(Ci)]   value W[co][ci][tap]
+//   T image (data gradient):  [KT][3][MpT = ceil128(Ci) x KpT = ceil32(Co)]   value W[co][ci][KT-1-tap]     (after N)
 // One thread per (image, tap, row, 4 consecutive k).
 __global__ __launch_bounds__(256) void k_tsplit(const float* __restrict__ w, int Ci, int Co, int KT,
                                                 unsigned short* __restrict__ out, int MpN, int KpN, int MpT, int KpT) {
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(256) void k_tsplit(const float* __restrict__ w, int
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (r < Co && k + e < Ci) ? w[((size_t)r * Ci + k + e) * KT + tap] : 0.f;
     pstride = (long)MpN * KpN;
-    dst = out + (size_t)tap * 3 * pstride + (size_t)r * KpN + k;
+    dst = out + (size_t)tap * 3 * pstride + ((size_t)(r >> 5) * (KpN >> 4) + (k >> 4)) * 512 + (((k >> 3) & 1) * 32 + (r & 31)) * 8 + (k & 7);
   } else if (i - t1 < t2) {
     const long j = i - t1;
     const int per = MpT * (KpT >> 2);
@@ -483,7 +488,8 @@ __global__ __launch_bounds__(256) void k_tsplit(const float* __restrict__ w, int
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (r < Ci && k + e < Co) ? w[((size_t)(k + e) * Ci + r) * KT + (KT - 1 - tap)] : 0.f;
     pstride = (long)MpT * KpT;
-    dst = out + (size_t)KT * 3 * MpN * KpN + (size_t)tap * 3 * pstride + (size_t)r * KpT + k;
+    dst = out + (size_t)KT * 3 * MpN * KpN + (size_t)tap * 3 * pstride + ((size_t)(r >> 5) * (KpT >> 4) + (k >> 4)) * 512 +
+          (((k >> 3) & 1) * 32 + (r & 31)) * 8 + (k & 7);
   } else {
     return;
   }
