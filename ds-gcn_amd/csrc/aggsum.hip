@@ -619,7 +619,10 @@ int as_launch_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
   if (as_pipe_ok<V>(T)) {
     const int chunks = (T + 31) / 32;
     const long units = (long)n * Co, items = units * chunks;
-    const long g = as_grid(items, g_as_waves_fwd > 0 ? g_as_waves_fwd : 3072);
+    // persistent waves: 120 VGPRs allow four per SIMD; with a per-channel adjacency (CTR-GCN) 4096 beat 3072 at 64 and 16
+    // frames and tied at 32 (tools/kap_sweep.py, round 5: 67.8 -> 58.9, 124 -> 113, 123 -> 105 us per layer); the shared
+    // adjacency (ST-GCN) keeps the geometry it was measured with
+    const long g = as_grid(items, g_as_waves_fwd > 0 ? g_as_waves_fwd : (a_cs != 0 ? 4096 : 3072));
     const size_t lds = (size_t)(32 * V + V * V) * sizeof(float);
     hipLaunchKernelGGL((k_aggsum_fwd_pipe<V>), dim3((unsigned)g), dim3(64), lds, st, p, ahat, a_ns, a_ks, a_cs, y,
                        partial, K, Co, T, chunks, items, units);
@@ -649,7 +652,11 @@ int as_launch_bwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
   const long units = (long)n * Co;
   if (as_pipe_ok<V>(T) && T <= 64 && (!shared || K == 3)) {
     const int nw = T > 32 ? 2 : 1;
-    const long g = as_grid(units, g_as_wgs_bwd > 0 ? g_as_wgs_bwd : (nw == 2 ? 1536 : 2048));
+    // per-(n,c) adjacency (CTR-GCN): 140 VGPRs = three waves per SIMD, which 2048 single-wave workgroups left one short of
+    // (tools/kap_sweep.py, round 5: 3072 workgroups 210 -> 158, 373 -> 286, 315 -> 249 us on the 32- / 16-frame layers,
+    // 142 -> 130, 252 -> 245 on the 64-frame ones).  The shared-adjacency form (190 / 168 VGPRs: two per SIMD) keeps its
+    // geometry — dsgcn_aggsum_bwd_piece_rows sizes its pieces by it.
+    const long g = as_grid(units, g_as_wgs_bwd > 0 ? g_as_wgs_bwd : (shared ? (nw == 2 ? 1536 : 2048) : 3072));
     const size_t lds = (size_t)(2 * nw * 32 * V + 2 * V * V) * sizeof(float);
 #define AS_BWD(NWV, PU)                                                                                             \
   hipLaunchKernelGGL((k_aggsum_bwd_pipe<V, NWV, PU>), dim3((unsigned)g), dim3(64 * NWV), lds, st, p, ahat, a_ns, a_ks, \
