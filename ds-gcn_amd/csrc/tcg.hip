@@ -917,6 +917,14 @@ bool tw_plan(int n, int Ci, int Co, int To, int V, int KT, TwPlan* p, int st = 1
   if (splits > cap) splits = (int)cap;
   if (splits > p->units) splits = p->units;
   if (splits < 1) splits = 1;
+  // One workgroup per CU (150 KB of LDS): a grid that is not a whole number of 256-workgroup rounds leaves most of the chip
+  // idle for its last round.  The 96 MB cap used to produce exactly that — 42 x 8, 170 x 2, 340 x 1, 85 x 4 = 336-340
+  // workgroups, 1.3 rounds for the time of two (round 5) — so the split count is rounded down to whole rounds.
+  if ((long)splits * tiles > 256) {
+    const int rounds = (int)((long)splits * tiles / 256);
+    splits = rounds * 256 / tiles;
+    if (splits < 1) splits = 1;
+  }
   p->splits = splits;
   {
     const size_t asz = (size_t)3 * TW_TM * TG_RB, bsz = (size_t)tw_group(KT) * 3 * TW_TN * TG_RB;
