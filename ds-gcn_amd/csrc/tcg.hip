@@ -281,7 +281,16 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
 #pragma unroll
     for (int q = 0; q < NQW; ++q) acc[q][i] = b0;
   }
+  // weight fragments in flight: the next tap's, and for the 64-row workgroups (WM = 2: 24 MFMAs per tap — 0.32 us of
+  // products, less than an L2 round trip under load) also the one after it (round 5; the 128-row kernels have no registers
+  // left for a third set)
+  constexpr bool PF2 = WM == 2;
+  u32x4v an2[PF2 ? 2 : 1][3];
   loadA(0, 0, ac);
+  if constexpr (PF2) {
+    if (KT > 1) loadA(1, 0, an);
+    else if (TG_KC < a.Kp) loadA(0, TG_KC, an);
+  }
   // B fragment rows: slot s = (frame offset s/V, joint s%V) sits at image row st*(s - s%V) + s%V (+ tap*V); dead slots read row 0
   int bfo[NQW];
 #pragma unroll
@@ -302,7 +311,11 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
     __builtin_amdgcn_s_barrier();
 #pragma unroll 1
     for (int tap = 0; tap < KT; ++tap) {
-      {                                            // next step's weights
+      if constexpr (PF2) {                         // the weights of the step after next
+        const int t2 = tap + 2;
+        const int ntap = t2 < KT ? t2 : t2 - KT, nch = t2 < KT ? ch0 : ch0 + TG_KC;      // (KT >= 2 here; KT = 1 wraps once too)
+        if (nch < a.Kp) loadA(ntap < KT ? ntap : 0, nch, an2);
+      } else {                                     // next step's weights
         const int ntap = tap + 1 < KT ? tap + 1 : 0, nch = tap + 1 < KT ? ch0 : ch0 + TG_KC;
         if (nch < a.Kp) loadA(ntap, nch, an);
       }
@@ -330,7 +343,10 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) ac[ks][t] = an[ks][t];
+        for (int t = 0; t < 3; ++t) {
+          ac[ks][t] = an[ks][t];
+          if constexpr (PF2) an[ks][t] = an2[ks][t];
+        }
     }
   }
   __syncthreads();                                 // LDS is reused below
