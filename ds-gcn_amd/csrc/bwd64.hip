@@ -298,11 +298,282 @@ __global__ __launch_bounds__(BF_NT, 2) void k_bwd64(BfArgs a) {
 #endif
 }
 
+// ---- round 5: the same pass on three-term bf16 products ---------------------------------------------------------------
+// The fp32 form above is bound by the matrix pipe: 64 v_mfma_f32_32x32x2_f32 per wave and 64-position unit = 4 096 cycles,
+// 43 us per 64 -> 64 launch at the chip's 157 TF against 26 us of HBM time.  Here both products run as six
+// v_mfma_f32_32x32x16_bf16 per 16-deep k-step on the exact three-way bf16 split of both operands (common.h: fp32-class
+// error, what the wide convs have used since round 2): 24 MFMAs of 32 cycles per wave and 32-position unit.
+// Work unit = (sample, 32 positions).  LDS (79.5 KB: two workgroups per CU), every image as [term][row][k contiguous]:
+//   Dk [64 co][32 pos]  dz_eff           A of the weight gradient (i = co, k = position)
+//   Xk [64 ci][32 pos]  activated input  B of the weight gradient (j = ci, k = position)
+//   Dt [32 pos][64 co]  dz_eff again     B of the data gradient   (j = position, k = co)
+//   Wt [64 ci][64 co]   W^T, once        A of the data gradient   (i = ci, k = co)
+//   Os [64 ci][32 pos]  fp32 dv tile, left by the two data-gradient waves for the staging threads to finish.
+// A thread stages row tid / 4, positions 8*(tid % 4) ..+7 of both operand rows (two 16-byte loads per stream, split once);
+// the transposed image takes its 2-byte elements in pairs: lanes of rows r, r^1 trade halves and each writes a dword.
+constexpr int BB_RB = 80, BB_RT = 144, BB_OS = 36;       // bytes per Dk / Xk row, per Dt / Wt row; floats per Os row
+constexpr int BB_DK = 0, BB_XK = 3 * 64 * BB_RB, BB_DT = 2 * 3 * 64 * BB_RB, BB_WT = BB_DT + 3 * 32 * BB_RT,
+              BB_OSO = BB_WT + 3 * 64 * BB_RT, BB_LDS = BB_OSO + 64 * BB_OS * 4;
+
+template <bool HASC, bool AFF>
+__global__ __launch_bounds__(BF_NT, 2) void k_bwd64b(BfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+#ifdef DSGCN_LAB
+  int nst = 0;
+#endif
+  BF_STAMP();
+  char* Dk = ldsb + BB_DK;
+  char* Xk = ldsb + BB_XK;
+  char* Dt = ldsb + BB_DT;
+  char* Wt = ldsb + BB_WT;
+  float* Os = reinterpret_cast<float*>(ldsb + BB_OSO);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int Ci = a.Ci, Co = a.Co, L = a.L, L4 = L * 4;
+  const int split = blockIdx.x;
+  const int ch0 = split * a.cps, ch1 = min(a.total_chunks, ch0 + a.cps);
+  // staging role: row (a dz row AND an input row), positions 8*q ..+7 of the unit
+  const int row = tid >> 2, q = tid & 3;
+  const bool rd = row < Co, rx = row < Ci;
+  const float A0v = (HASC && rd) ? a.A0[row] : 0.f, B0v = (HASC && rd) ? a.B0[row] : 0.f;
+  float s1v = 1.f, h1v = 0.f;
+  if (AFF && rx && a.s1) { s1v = a.s1[row]; h1v = a.h1[row]; }
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+  // W^T image (pairs of co per thread) and the zeroed dv tile
+  for (int i = tid; i < 64 * 32; i += BF_NT) {
+    const int ci = i >> 5, co = 2 * (i & 31);
+    const float w0 = (ci < Ci && co < Co) ? a.w[(size_t)co * Ci + ci] : 0.f;
+    const float w1 = (ci < Ci && co + 1 < Co) ? a.w[(size_t)(co + 1) * Ci + ci] : 0.f;
+    unsigned p0, p1, p2;
+    b3_split(w0, w1, p0, p1, p2);
+    char* base = Wt + ci * BB_RT + co * 2;
+    *reinterpret_cast<unsigned*>(base) = p0;
+    *reinterpret_cast<unsigned*>(base + 64 * BB_RT) = p1;
+    *reinterpret_cast<unsigned*>(base + 2 * 64 * BB_RT) = p2;
+  }
+
+  // two units of raw operands in flight (sets A / B by unit parity): with one, a unit's loads had only the ~1 us of the
+  // previous unit's products to land in and every commit waited 1-2 us for them (lab stamps, round 5)
+  struct Raw { f32x4 g[2], z[HASC ? 2 : 1], x[2]; };
+  Raw ra, rb;
+  f32x4 xk[AFF ? 2 : 1];
+  float dsum = 0.f, r0 = 0.f, r1 = 0.f;
+  auto issue = [&](int ch, Raw& R) {
+    const int n = ch / a.cpn, c0 = (ch - n * a.cpn) * 32;
+    const __amdgpu_buffer_rsrc_t rg = bf_rsrc(a.gz + (size_t)n * Co * L, Co * L4);
+    const __amdgpu_buffer_rsrc_t rz = bf_rsrc((HASC ? a.z : a.gz) + (size_t)n * Co * L, HASC ? Co * L4 : 0);
+    const __amdgpu_buffer_rsrc_t r1_ = bf_rsrc(a.x1 + (size_t)n * Ci * L, Ci * L4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int p = c0 + 8 * q + 4 * h;                              // (L % 4 == 0: a quad is inside or outside the plane)
+      const int vd = (rd && p < L) ? (row * L + p) * 4 : BF_OOB;
+      const int vx = (rx && p < L) ? (row * L + p) * 4 : BF_OOB;
+      R.g[h] = bf_load(rg, vd);
+      if constexpr (HASC) R.z[h] = bf_load(rz, vd);
+      R.x[h] = bf_load(r1_, vx);
+    }
+  };
+  auto commit = [&](int ch, const Raw& R) {
+    const int n = ch / a.cpn, c0 = (ch - n * a.cpn) * 32;
+    float d[8], v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool in = c0 + 8 * q + 4 * h < L;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = R.g[h][e];
+        if constexpr (HASC) x += fmaf(B0v, R.z[h][e], A0v);
+        d[4 * h + e] = (rd && in) ? x : 0.f;
+        float t = R.x[h][e];
+        if constexpr (AFF) {
+          t = fmaf(t, s1v, h1v);
+          t = fmaxf(t, lo);
+        }
+        v[4 * h + e] = (rx && in) ? t : 0.f;
+      }
+      if constexpr (AFF) xk[h] = R.x[h];
+    }
+    dsum += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+    unsigned t0[4], t1[4], t2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b3_split(d[2 * j], d[2 * j + 1], t0[j], t1[j], t2[j]);
+    {
+      char* base = Dk + row * BB_RB + q * 16;
+      *reinterpret_cast<u32x4v*>(base) = u32x4v{t0[0], t0[1], t0[2], t0[3]};
+      *reinterpret_cast<u32x4v*>(base + 64 * BB_RB) = u32x4v{t1[0], t1[1], t1[2], t1[3]};
+      *reinterpret_cast<u32x4v*>(base + 2 * 64 * BB_RB) = u32x4v{t2[0], t2[1], t2[2], t2[3]};
+    }
+    // transposed image: word j holds positions (8q + 2j, 8q + 2j + 1) of this row; the lane of row^1 (4 lanes away) holds
+    // the same positions of its row.  Even rows write the pair (row, row + 1) of the first position, odd rows of the second.
+    {
+      const int odd = row & 1;
+      char* base = Dt + (8 * q + odd) * BB_RT + (row & ~1) * 2;
+      // (v_perm_b32 byte selects instead of a select between two forms: hipcc turned the ternaries into twelve divergent
+      // branch diamonds, each waiting for its lane exchange)
+      // v_perm_b32 over {src0 = mine : src1 = the other row's}: odd rows take both HIGH halves (other's below mine), even
+      // rows both LOW halves (mine below the other's)
+      const unsigned sel = odd ? 0x07060302u : 0x01000504u;
+      unsigned o0[4], o1[4], o2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o0[j] = __shfl_xor(t0[j], 4, 64); o1[j] = __shfl_xor(t1[j], 4, 64); o2[j] = __shfl_xor(t2[j], 4, 64);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned w0 = __builtin_amdgcn_perm(t0[j], o0[j], sel);
+        const unsigned w1 = __builtin_amdgcn_perm(t1[j], o1[j], sel);
+        const unsigned w2 = __builtin_amdgcn_perm(t2[j], o2[j], sel);
+        char* pj = base + 2 * j * BB_RT;
+        *reinterpret_cast<unsigned*>(pj) = w0;
+        *reinterpret_cast<unsigned*>(pj + 32 * BB_RT) = w1;
+        *reinterpret_cast<unsigned*>(pj + 2 * 32 * BB_RT) = w2;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b3_split(v[2 * j], v[2 * j + 1], t0[j], t1[j], t2[j]);
+    {
+      char* base = Xk + row * BB_RB + q * 16;
+      *reinterpret_cast<u32x4v*>(base) = u32x4v{t0[0], t0[1], t0[2], t0[3]};
+      *reinterpret_cast<u32x4v*>(base + 64 * BB_RB) = u32x4v{t1[0], t1[1], t1[2], t1[3]};
+      *reinterpret_cast<u32x4v*>(base + 2 * 64 * BB_RB) = u32x4v{t2[0], t2[1], t2[2], t2[3]};
+    }
+    (void)n;
+  };
+
+  // waves 0, 1: weight gradient — wave mt owns the co tile mt of dW, both ci tiles (K = the unit's 32 positions);
+  // waves 2, 3: data gradient   — wave 2 + cit owns ci tile cit of the 64 x 32 dv tile over all of co.
+  // (24 MFMAs per wave either way.  The first version split the data gradient's K over wave pairs and added the halves
+  // into Os with ds_add_f32: 16 LDS float atomics per lane and unit took 6-10 us — the lab stamps.)
+  const bool wgw = wave < 2;
+  const int mt = wave & 1, cit = wave & 1;
+  const bool wg0 = wgw && 32 * mt < Co, wg1 = wg0 && Ci > 32;
+  const bool dg_on = !wgw && 32 * cit < Ci;
+  const int KSD = (Co + 15) >> 4;                                 // data-gradient k-steps that hold real channels
+  f32x16 accw, accw1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { accw[i] = 0.f; accw1[i] = 0.f; }
+  const char* Af = Dk + (32 * mt + l31) * BB_RB + 16 * half;
+  const char* Bf = Xk + l31 * BB_RB + 16 * half;
+  const char* Wf = Wt + (32 * cit + l31) * BB_RT + 16 * half;
+  const char* Df = Dt + l31 * BB_RT + 16 * half;
+  auto six = [&](f32x16 c, const char* pa, int sa, const char* pb, int sb) {
+    const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pa)),
+                 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pa + sa)),
+                 a2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pa + 2 * sa));
+    const bf16x8 b0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pb)),
+                 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pb + sb)),
+                 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pb + 2 * sb));
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+    return c;
+  };
+
+  __syncthreads();
+  BF_STAMP();
+  auto unit = [&](int ch, Raw& R) {
+    commit(ch, R);
+    if (ch + 2 < ch1) issue(ch + 2, R);                            // (the set is free: commit kept what the finish needs)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                 // images complete (raw barrier: loads stay in flight)
+    BF_STAMP();
+    if (wg0) {
+      accw = six(accw, Af, 64 * BB_RB, Bf, 64 * BB_RB);
+      accw = six(accw, Af + 32, 64 * BB_RB, Bf + 32, 64 * BB_RB);
+      if (wg1) {
+        accw1 = six(accw1, Af, 64 * BB_RB, Bf + 32 * BB_RB, 64 * BB_RB);
+        accw1 = six(accw1, Af + 32, 64 * BB_RB, Bf + 32 * BB_RB + 32, 64 * BB_RB);
+      }
+    }
+    if (dg_on) {
+      f32x16 accd;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accd[i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        if (ks < KSD) accd = six(accd, Wf + 32 * ks, 64 * BB_RT, Df + 32 * ks, 32 * BB_RT);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Os[(32 * cit + bf_row32(r, half)) * BB_OS + l31] = accd[r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                 // dv tile complete; the images are free
+    BF_STAMP();
+    {
+      const int n = ch / a.cpn, c0 = (ch - n * a.cpn) * 32;
+      f32x4* o = reinterpret_cast<f32x4*>(Os + row * BB_OS + 8 * q);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 dv = o[h];
+        if (rx && c0 + 8 * q + 4 * h < L) {
+          float sx = 1.f;
+          if constexpr (AFF) {
+            sx = s1v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = fmaf(xk[h][e], s1v, h1v);
+              if (a.relu && !(t > 0.f)) dv[e] = 0.f;
+              r0 = fmaf(dv[e], xk[h][e], r0);
+              r1 += dv[e];
+            }
+          }
+          const size_t go = ((size_t)n * Ci + row) * L + c0 + 8 * q + 4 * h;
+          __builtin_nontemporal_store(f32x4{dv.x * sx, dv.y * sx, dv.z * sx, dv.w * sx}, reinterpret_cast<f32x4*>(a.dx + go));
+        }
+      }
+    }
+  };
+  if (ch0 < ch1) issue(ch0, ra);
+  if (ch0 + 1 < ch1) issue(ch0 + 1, rb);
+  for (int ch = ch0; ch < ch1; ch += 2) {
+    unit(ch, ra);
+    if (ch + 1 < ch1) unit(ch + 1, rb);
+  }
+
+  BF_STAMP();
+  // ---- partial rows of this split ----
+  float* dw = a.dwp + (size_t)split * a.pstride;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = 32 * mt + bf_row32(r, half);
+    if (wg0 && co < Co && l31 < Ci) dw[(size_t)co * Ci + l31] = accw[r];
+    if (wg1 && co < Co && 32 + l31 < Ci) dw[(size_t)co * Ci + 32 + l31] = accw1[r];
+  }
+  {
+    float s = dsum, s0 = r0, s1 = r1;
+#pragma unroll
+    for (int off = 1; off < 4; off <<= 1) {
+      s += __shfl_xor(s, off, 64);
+      if (AFF) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+    }
+    if (q == 0) {
+      if (rd) a.dbp[(size_t)split * a.pstride + row] = s;
+      if (AFF && a.ipart && rx) {
+        float* o = a.ipart + ((size_t)split * Ci + row) * 3;
+        o[0] = s0; o[1] = s1; o[2] = 0.f;
+      }
+    }
+  }
+#ifdef DSGCN_LAB
+  BF_STAMP();
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_bf_stamp[63] = nst;
+#endif
+}
+
 struct BfPlan { int cpn, chunks, splits, cps; };
+
+// 1: one-stream convs with Ci >= 16 take the three-term bf16 form (k_bwd64b, 32-position units); 0: always the fp32 MFMA
+// form (lab A/B).  Round-5 same-box timings, fp32 -> bf16 form: 64->24 38.5 -> 37.2 us, 24->64 42.7 -> 39.6, 64->64 59.8 ->
+// 52.0; the two-stream 64->64 (72.6 -> 81.0) and the 3->24 input conv (25.7 -> 27.7) are slower there and stay on fp32.
+int g_bf_b3 = 1;
 
 bool bf_plan(int n, int Ci, int Co, int L, BfPlan* p) {
   if (Ci <= 0 || Co <= 0 || Ci > 64 || Co > 64 || L % 4) return false;
   if ((long)64 * L * 4 >= (1L << 31) - 64) return false;
+  // (the partial-row count is the fp32 form's for both forms: dsgcn_pwconv_bwd_rows does not know the stream count)
   p->cpn = (L + BF_KC - 1) / BF_KC;
   p->chunks = n * p->cpn;
   int target = 512;                                               // two workgroups per CU
@@ -331,9 +602,36 @@ __attribute__((visibility("hidden"))) int dsgcn_bwd64(const float* x1, const flo
   a.x1 = x1; a.s1 = s1; a.h1 = h1; a.x2 = x2; a.s2 = s2; a.h2 = h2; a.relu = relu; a.w = w; a.z = z; a.gz = gz;
   a.A0 = A0; a.B0 = B0; a.dx = dx; a.dx2 = dx2; a.dwp = dwp; a.dbp = dbp; a.ipart = ipart; a.pstride = pstride;
   a.n = n; a.Ci = Ci; a.Co = Co; a.L = L; a.cpn = p.cpn; a.total_chunks = p.chunks; a.cps = p.cps;
-  const size_t lds = (size_t)(192 * BF_LS + 64 * 65 + 2 * 64 + 4 * 64) * sizeof(float);
+  const bool b3 = g_bf_b3 && x2 == nullptr && Ci >= 16;
+  if (b3) {                                           // 32-position units over the same splits (a split with none writes zero rows)
+    a.cpn = (L + 31) / 32;
+    a.total_chunks = n * a.cpn;
+    a.cps = (a.total_chunks + p.splits - 1) / p.splits;
+  }
+  const size_t lds = b3 ? (size_t)BB_LDS : (size_t)(192 * BF_LS + 64 * 65 + 2 * 64 + 4 * 64) * sizeof(float);
   const dim3 grid((unsigned)p.splits), blk(BF_NT);
   const bool hasc = A0 != nullptr, has2 = x2 != nullptr, aff = s1 != nullptr || s2 != nullptr || relu != 0 || has2;
+  if (b3) {
+#define BB_LAUNCH(HC, AF)                                                                                               \
+  {                                                                                                                   \
+    static bool raised = false;                                                                                       \
+    if (!raised) {                                                                                                    \
+      hipError_t e = hipFuncSetAttribute((const void*)k_bwd64b<HC, AF>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)lds);                                                                   \
+      if (e != hipSuccess) return (int)e;                                                                             \
+      raised = true;                                                                                                  \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((k_bwd64b<HC, AF>), grid, blk, lds, st, a);                                                \
+  }
+    if (hasc) {
+      if (aff) BB_LAUNCH(true, true) else BB_LAUNCH(true, false)
+    } else {
+      if (aff) BB_LAUNCH(false, true) else BB_LAUNCH(false, false)
+    }
+#undef BB_LAUNCH
+    DSGCN_LAUNCH_CHECK();
+    return 1;
+  }
   // the LDS image (69 KB) is above the default dynamic limit: raised once per instantiation (not a stream operation:
   // the first call of a shape class is an eager one, outside any graph capture)
 #define BF_LAUNCH(HC, AF, H2)                                                                                          \
@@ -358,6 +656,8 @@ __attribute__((visibility("hidden"))) int dsgcn_bwd64(const float* x1, const flo
   DSGCN_LAUNCH_CHECK();
   return 1;
 }
+
+__attribute__((visibility("hidden"))) int dsgcn_bwd64_tuning(int value) { g_bf_b3 = value; return 0; }
 
 #ifdef DSGCN_LAB
 extern "C" int dsgcn_bwd64_phases(long long* out) {

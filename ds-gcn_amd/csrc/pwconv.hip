@@ -1252,6 +1252,7 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const fl
                                                         const float* w, const float* bias, float* z, float* partial,
                                                         int n, int Ci, int Co, int L, hipStream_t st, const void* ws);
 __attribute__((visibility("hidden"))) size_t dsgcn_p4_ws_bytes(int n, int Ci, int Co, int L);
+__attribute__((visibility("hidden"))) int dsgcn_bwd64_tuning(int value);
 __attribute__((visibility("hidden"))) int dsgcn_p4_wsplit(const float* w, int Ci, int Co, void* out, hipStream_t st);
 __attribute__((visibility("hidden"))) int dsgcn_p4_wsplit_multi(const float* const* w, void* const* out, const int* Ci,
                                                                 const int* Co, int njobs, hipStream_t st);
@@ -1302,6 +1303,7 @@ int dsgcn_pwconv_tuning(int key, int value) {
   if (key == 13) return dsgcn_wg2_tuning(3, value);                        // weight gradient: bf16 terms on / off
   if (key == 14) return dsgcn_p4_tuning(6, value);                         // pre-split weight image: 0 off, 1 k_pwg2, 2 k_pwg3
   if (key >= 15 && key <= 17) return dsgcn_wg2_tuning(key - 11, value);    // wide weight gradient (k_wg3) on / off, split target, co tile
+  if (key == 18) return dsgcn_bwd64_tuning(value);                         // one-pass narrow backward: 1 bf16 terms, 0 fp32 MFMA
   return DSGCN_EINVAL;
 }
 #endif
