@@ -47,12 +47,16 @@ def record_running(bn, mean, var, count):
 @torch.no_grad()
 def flush_running_stats():
     """Apply the running-statistics updates of every BatchNorm touched since the last flush, the way
-    ``F.batch_norm(training=True)`` does (momentum, unbiased variance, num_batches_tracked) — batched into a few
-    multi-tensor launches instead of three tiny kernels per layer."""
+    ``F.batch_norm(training=True)`` does (momentum, unbiased variance, num_batches_tracked): ONE launch for all layers
+    (``kernels.bn_running_update``; three tiny kernels per layer in the reference)."""
     if not _pending_running:
         return
     items = list(_pending_running)
     _pending_running.clear()
+    if kernels.FUSED_ENDS and all(bn.momentum is not None for bn, _, _, _ in items):
+        kernels.ops().bn_running_update(items)
+        return
+    # the multi-tensor form (A/B switch; momentum=None = cumulative average, which needs the count on the host)
     torch._foreach_add_([bn.num_batches_tracked for bn, _, _, _ in items], 1)
     groups = {}
     for it in items:
@@ -62,10 +66,9 @@ def flush_running_stats():
     for m, its in groups.items():
         rm = [bn.running_mean for bn, _, _, _ in its]
         rv = [bn.running_var for bn, _, _, _ in its]
-        means = [mean for _, mean, _, _ in its]
         unb = torch._foreach_mul([var for _, _, var, _ in its], [c / max(c - 1.0, 1.0) for _, _, _, c in its])
         torch._foreach_mul_(rm, 1.0 - m)
-        torch._foreach_add_(rm, means, alpha=m)
+        torch._foreach_add_(rm, [mean for _, mean, _, _ in its], alpha=m)
         torch._foreach_mul_(rv, 1.0 - m)
         torch._foreach_add_(rv, unb, alpha=m)
 

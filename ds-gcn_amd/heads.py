@@ -6,10 +6,12 @@ What the path computes: global average over (T, V), mean over the M persons, ``L
 reference's host code: (i) the ranking runs on the device (one small ``topk``) instead of a device->host copy and a
 numpy argsort per step (heads/base.py:67-72 syncs every iteration); the numbers are the same, ties aside; (ii) the
 2D/3D pooling modes, list inputs, multi-label and label-smoothing branches are not reached by any skeleton config
-and are rejected rather than carried along."""
+and are rejected rather than carried along; (iii) ``forward_loss`` is the fused form of ``loss(forward(x), label)`` that
+``RecognizerGCN.forward_train`` calls (the two methods stay for everything else)."""
 import torch
 import torch.nn as nn
 
+from . import kernels
 from .builder import HEADS, build_loss
 
 
@@ -50,6 +52,26 @@ class SimpleHead(nn.Module):
         if self.dropout is not None:
             x = self.dropout(x)
         return self.fc_cls(x)
+
+    def forward_loss(self, x, label):
+        """``loss(forward(x), label)`` as the training step runs it: person mean, ``fc_cls``, the cross entropy and both
+        accuracies in three launches (``kernels.head_loss``) instead of ~25.  Heads with dropout or another loss take the
+        two calls."""
+        from .losses import CrossEntropyLoss
+        if (not kernels.FUSED_ENDS or x.dim() != 5 or self.dropout is not None or type(self.loss_cls) is not CrossEntropyLoss
+                or label.is_floating_point()):
+            return self.loss(self(x), label)
+        if label.dim() == 0:
+            label = label[None]
+        N, M, C = x.shape[:3]
+        assert C == self.in_c
+        if label.shape != (N,):
+            raise NotImplementedError(f'CrossEntropyLoss: expects (N,) integer labels for (N, classes) scores, got '
+                                      f'{tuple(label.shape)} for {N} clips')
+        feat = x.reshape(N * M, C, -1).mean(-1)
+        loss, acc, _ = kernels.ops().head_loss(feat, self.fc_cls.weight, self.fc_cls.bias, label, M,
+                                               self.loss_cls.loss_weight)
+        return dict(top1_acc=acc[0], top5_acc=acc[1], loss_cls=loss)
 
     def loss(self, cls_score, label):
         """-> dict(top1_acc, top5_acc, loss_cls), all device tensors (no host sync)."""

@@ -68,6 +68,9 @@ SPLIT_TEMPORAL = _os.environ.get('DSGCN_SPLIT_TEMPORAL', '2')
 # '1': a block whose stride-2 residual conv reads the plain block input gets the even frames from the previous block's
 # fuse_out (a second output of that launch) instead of a strided-copy launch of its own
 PRESTRIDED = _os.environ.get('DSGCN_PRESTRIDED', '1') != '0'
+# '1': the small ends of the step on csrc/head.hip (head + loss + accuracies in three launches, all BatchNorm buffers in
+# one); '0': the framework's own launches (A/B switch)
+FUSED_ENDS = _os.environ.get('DSGCN_FUSED_ENDS', '1') != '0'
 
 
 class side_branch:
@@ -345,14 +348,17 @@ def _defer_table(k, dev):
         host = torch.empty((cap, 4), dtype=torch.int64).pin_memory()
         return dict(host=host, dev=torch.empty_like(host, device=dev), event=None)
 
-    st = _defer_slots.setdefault(dev, dict(slots=[], next=-1, reserved=None, graph=[]))
+    st = _defer_slots.setdefault(dev, dict(slots=[], next=-1, reserved=[], graph=[], epoch=-1, calls=0))
     if torch.cuda.is_current_stream_capturing():
-        slot = st['reserved'] or new_slot()
-        st['reserved'] = None
+        slot = st['reserved'].pop() if st['reserved'] else new_slot()
         st['graph'].append(slot)                    # alive as long as the graph may replay
         return slot
-    if st['reserved'] is None:
-        st['reserved'] = new_slot()
+    # (pinned allocation invalidates a capture: the eager steps before it set aside one table per flush of a step)
+    if st['epoch'] != _wsplit_state['epoch']:
+        st['epoch'], st['calls'] = _wsplit_state['epoch'], 0
+    st['calls'] += 1
+    while len(st['reserved']) < st['calls']:
+        st['reserved'].append(new_slot())
     st['next'] = (st['next'] + 1) % 4
     if len(st['slots']) <= st['next']:
         st['slots'].append(new_slot())
@@ -2030,3 +2036,80 @@ def fuse_out(x1, a1, x2, a2, relu, want_tmean=False, tee=False):
     if int(tee) == 2:
         o3 = Prestrided(o3, 2, x1.shape[2])
     return ((o1, o2, o3) if tee else o1), xbar
+
+
+# ---------------------------------------------------------------------------------------------
+# the small ends of the step (csrc/head.hip)
+# ---------------------------------------------------------------------------------------------
+class _HeadLoss(torch.autograd.Function):
+    """(feat (N*M, C) per-person plane means, weight (K, C), bias (K), label (N) int64) -> (loss scalar, acc (2) fp64,
+    score (N, K)); only the loss is differentiable.  Two launches forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, label, M, loss_weight):
+        _require_cuda(feat, weight, label)
+        feat, weight, bias = _f32c(feat), _f32c(weight), _f32c(bias)
+        if label.dtype != torch.int64 or not label.is_contiguous():
+            label = label.to(torch.int64).contiguous()
+        R, C = feat.shape
+        K = weight.shape[0]
+        if R % M or weight.shape[1] != C or label.numel() * M != R:
+            raise ValueError(f'head_loss: feat {tuple(feat.shape)}, weight {tuple(weight.shape)}, {label.numel()} labels, '
+                             f'{M} persons do not fit together')
+        N = R // M
+        dev = feat.device
+        pooled = torch.empty((N, C), device=dev, dtype=torch.float32)
+        score = torch.empty((N, K), device=dev, dtype=torch.float32)
+        prob = torch.empty((N, K), device=dev, dtype=torch.float32)
+        clip = torch.empty((N, 3), device=dev, dtype=torch.float32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        acc = torch.empty(2, device=dev, dtype=torch.float64)
+        rc = native.lib().dsgcn_head_loss_fwd(_ptr(feat), _ptr(weight), _ptr(bias), _ptr(label), N, M, C, K,
+                                              float(loss_weight), _ptr(pooled), _ptr(score), _ptr(prob), _ptr(clip),
+                                              _ptr(loss), _ptr(acc), _stream())
+        native.check(rc, 'dsgcn_head_loss_fwd')
+        ctx.save_for_backward(prob, pooled, weight, label)
+        ctx.dims = (N, M, C, K, float(loss_weight), bias is not None)
+        ctx.mark_non_differentiable(acc, score)
+        return loss, acc, score
+
+    @staticmethod
+    def backward(ctx, gloss, _gacc, _gscore):
+        prob, pooled, weight, label = ctx.saved_tensors
+        N, M, C, K, lw, has_bias = ctx.dims
+        dev = prob.device
+        gloss = _f32c(gloss)
+        dfeat = torch.empty((N * M, C), device=dev, dtype=torch.float32)
+        dw = torch.empty((K, C), device=dev, dtype=torch.float32)
+        db = torch.empty(K, device=dev, dtype=torch.float32)
+        rc = native.lib().dsgcn_head_loss_bwd(_ptr(prob), _ptr(pooled), _ptr(weight), _ptr(label), _ptr(gloss), N, M, C, K,
+                                              lw, _ptr(dfeat), _ptr(dw), _ptr(db), _stream())
+        native.check(rc, 'dsgcn_head_loss_bwd')
+        return dfeat, dw, (db if has_bias else None), None, None, None
+
+
+def head_loss(feat, weight, bias, label, persons, loss_weight=1.0):
+    """Person mean + Linear + softmax cross entropy (mean over the clips, times loss_weight) + top-1 / top-5 accuracy.
+    -> (loss 0-dim fp32, acc (2,) fp64, score (N, K))."""
+    return _HeadLoss.apply(feat, weight, bias, label, int(persons), float(loss_weight))
+
+
+def bn_running_update(items):
+    """items: (bn module, mean, var, count) of the BatchNorm layers a training forward went through (momentum form only):
+    their buffers updated in ONE launch."""
+    import ctypes as _c
+    k = len(items)
+    ptrs = lambda ts: (_c.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
+    for bn, mean, var, _ in items:
+        _require_cuda(bn.running_mean, mean, var)
+        for t in (bn.running_mean, bn.running_var, mean, var):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != bn.num_features:
+                raise ValueError('bn_running_update: fp32 contiguous per-channel vectors expected')
+    nbt = [bn.num_batches_tracked for bn, _, _, _ in items]
+    rc = native.lib().dsgcn_bn_running_multi(
+        ptrs([bn.running_mean for bn, _, _, _ in items]), ptrs([bn.running_var for bn, _, _, _ in items]),
+        ptrs([m for _, m, _, _ in items]), ptrs([v for _, _, v, _ in items]), ptrs(nbt),
+        _int_array([bn.num_features for bn, _, _, _ in items]),
+        (_c.c_float * k)(*[c / max(c - 1.0, 1.0) for _, _, _, c in items]),
+        (_c.c_float * k)(*[float(bn.momentum) for bn, _, _, _ in items]), k, _stream())
+    native.check(rc, 'dsgcn_bn_running_multi')

@@ -106,6 +106,10 @@ SIGNATURES = {
     'dsgcn_dynadj_partial_stride': [c_int, c_int, c_int],
     'dsgcn_dynadj_fwd': [c_f] * 6 + [c_i, c_i, c_f] + [c_int] * 6 + [c_st],
     'dsgcn_dynadj_bwd': [c_f] * 5 + [c_i, c_i] + [c_f] * 4 + [c_int] * 7 + [c_st],
+    'dsgcn_head_loss_fwd': [c_f, c_f, c_f, c_i] + [c_int] * 4 + [ctypes.c_float] + [c_f] * 6 + [c_st],
+    'dsgcn_head_loss_bwd': [c_f, c_f, c_f, c_i, c_f] + [c_int] * 4 + [ctypes.c_float] + [c_f] * 3 + [c_st],
+    'dsgcn_bn_running_multi': [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float),
+                               ctypes.POINTER(ctypes.c_float), c_int, c_st],
 }
 
 

@@ -81,13 +81,19 @@ class RecognizerGCN(nn.Module):
     def forward_train(self, keypoint, label):
         assert self.cls_head is not None
         assert keypoint.shape[1] == 1, 'training batches carry one clip per sample'
-        scores = self.cls_head(self.extract_feat(keypoint[:, 0].float()))
-        return self.cls_head.loss(scores, label.squeeze(-1))
+        feat = self.extract_feat(keypoint[:, 0].float())
+        if hasattr(self.cls_head, 'forward_loss'):
+            return self.cls_head.forward_loss(feat, label.squeeze(-1))
+        return self.cls_head.loss(self.cls_head(feat), label.squeeze(-1))
 
     def train_step(self, data_batch, optimizer=None, sync_log_vars=True, **_runner_kwargs):
         losses = self(**data_batch, return_loss=True)
-        log_vars = OrderedDict((k, v.mean()) for k, v in losses.items())
-        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        # (recognizers/base.py:128-143 `_parse_losses`; the mean of a scalar and the `0 +` of sum() are launches here)
+        log_vars = OrderedDict((k, v if v.dim() == 0 else v.mean()) for k, v in losses.items())
+        loss = None
+        for k, v in log_vars.items():
+            if 'loss' in k:
+                loss = v if loss is None else loss + v
         log_vars['loss'] = loss
         if sync_log_vars:
             log_vars = reduce_log_vars(log_vars)

@@ -402,6 +402,30 @@ int dsgcn_skeleton_prep(const float* raw, const long* offset, const int* M, cons
                         float* out, int N, int clips, int Mout, int clip_len, int V, int C, int nfeat, int fmask,
                         int scored, int loop, void* stream);
 
+/* Classification head of the training step (csrc/head.hip).  Replaces, for the 'GCN' pooling mode, the person mean +
+ * nn.Linear of SimpleHead.forward (pyskl/models/heads/simple_head.py:88-98 after the plane mean), BaseHead.loss
+ * (heads/base.py:50-84: top-1 / top-5 accuracy, computed there on the host with numpy, + the loss) and CrossEntropyLoss
+ * (losses/cross_entropy_loss.py:75-82, scaled by loss_weight: losses/base.py:38-44) — ~25 framework launches per step.
+ *   feat (N*M, C): per-person plane means;  w (K, C), b (K) or NULL;  label (N) int64.
+ *   pooled (N, C) = mean over the M persons;  score (N, K) = pooled w^T + b;  prob (N, K) = softmax(score);
+ *   loss (1) = loss_weight * mean_n -log prob[n, label[n]] (NaN if a label is outside [0, K));
+ *   acc (2) fp64 = share of clips whose label is among the 1 / 5 best scores, ties as a stable ascending argsort orders
+ *   them (core/evaluation.py:63-88);  clip (N, 3): scratch (per-clip loss and hits).   Two launches.
+ * dsgcn_head_loss_bwd: gloss (1) = gradient of the loss scalar; dfeat (N*M, C), dw (K, C), db (K).  One launch. */
+int dsgcn_head_loss_fwd(const float* feat, const float* w, const float* b, const long long* label, int N, int M, int C,
+                        int K, float loss_weight, float* pooled, float* score, float* prob, float* clip, float* loss,
+                        double* acc, void* stream);
+int dsgcn_head_loss_bwd(const float* prob, const float* pooled, const float* w, const long long* label, const float* gloss,
+                        int N, int M, int C, int K, float loss_weight, float* dfeat, float* dw, float* db, void* stream);
+
+/* Training-mode buffer update of njobs BatchNorm layers in one launch (what F.batch_norm(training=True) does to its
+ * buffers, momentum form): running_mean = (1 - m) running_mean + m mean; running_var = (1 - m) running_var + m var *
+ * unbias (unbias = count / (count - 1)); num_batches_tracked += 1 (entries may be NULL).  The arrays are HOST arrays of
+ * njobs device pointers / values. */
+int dsgcn_bn_running_multi(float* const* running_mean, float* const* running_var, const float* const* mean,
+                           const float* const* var, long long* const* num_batches_tracked, const int* C,
+                           const float* unbias, const float* momentum, int njobs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

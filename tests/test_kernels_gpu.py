@@ -1104,3 +1104,74 @@ def test_wsplit_images_batched_per_step_and_never_stale():
     z.sum().backward()
     want = ws[0].detach().double().view(256, -1).sum(0).view(1, -1, 1, 1).expand_as(x)
     assert rel(xg.grad, want) < 2e-6
+
+
+@pytest.mark.parametrize('N,M,C,K,lw,bias', [(64, 2, 256, 60, 1.0, True), (64, 2, 256, 120, 1.0, True),
+                                             (32, 2, 256, 400, 0.5, True), (5, 1, 96, 3, 1.0, False),
+                                             (7, 3, 70, 11, 2.0, True), (1, 2, 256, 60, 1.0, True)])
+def test_head_loss(N, M, C, K, lw, bias):
+    """Person mean + Linear + cross entropy + accuracies (csrc/head.hip) against torch in fp64: loss and gradients to 2e-6
+    of their norm, the accuracies EXACT (a rank is an integer; ties are planted to pin the stable-argsort rule)."""
+    g = torch.Generator().manual_seed(N * 31 + K)
+    feat = torch.randn(N * M, C, generator=g)
+    w = torch.randn(K, C, generator=g) * 0.2
+    b = torch.randn(K, generator=g) * 0.1 if bias else None
+    label = torch.randint(0, K, (N,), generator=g)
+    gl = torch.tensor(0.7)
+
+    def run(mod, dt, dev):
+        f, ww = feat.to(dev, dt).requires_grad_(), w.to(dev, dt).requires_grad_()
+        bb = b.to(dev, dt).requires_grad_() if bias else None
+        loss, acc, score = mod.head_loss(f, ww, bb, label.to(dev), M, lw)
+        loss.backward(gl.to(dev, dt))
+        return dict(loss=loss, acc=acc, score=score, dfeat=f.grad, dw=ww.grad, **({'db': bb.grad} if bias else {}))
+
+    got, ref = run(K_, torch.float32, DEV), run(R, torch.float64, 'cpu')
+    assert got['loss'].dtype == torch.float32 and got['acc'].dtype == torch.float64 and got['loss'].dim() == 0
+    for k in ref:
+        if k == 'acc':
+            assert torch.equal(got[k].cpu(), ref[k]), (got[k], ref[k])
+        else:
+            assert rel(got[k], ref[k]) < 2e-6, (k, rel(got[k], ref[k]))
+    # twice the same launch: bit-identical (fixed-order sums)
+    again = run(K_, torch.float32, DEV)
+    assert all(torch.equal(got[k], again[k]) for k in got)
+
+
+def test_head_loss_ties_and_bad_label():
+    """Equal scores: the label counts as a hit when a stable ascending argsort leaves it among the last k — classes with
+    an equal score and a GREATER index outrank it.  A label outside [0, K) gives a NaN loss (torch asserts on the device)."""
+    K = 8
+    w = torch.zeros(K, 4, device=DEV)
+    b = torch.tensor([1., 1., 1., 1., 1., 1., 0., 0.], device=DEV)           # six classes tie at the top
+    feat = torch.zeros(6, 4, device=DEV)
+    label = torch.tensor([0, 1, 4, 5, 6, 7], device=DEV)
+    _, acc, _ = K_.head_loss(feat, w, b, label, 1)
+    # ranks: label 0 -> 5 (five equal scores with a greater index), 1 -> 4, 4 -> 1, 5 -> 0, 6 -> 7 (6 greater + index 7), 7 -> 6
+    assert acc.tolist() == [1 / 6, 3 / 6]
+    _, acc_ref, _ = R.head_loss(feat.cpu().double(), w.cpu().double(), b.cpu().double(), label.cpu(), 1)
+    assert acc_ref.tolist() == acc.tolist()
+    loss, acc, _ = K_.head_loss(feat, w, b, torch.tensor([0, 1, 4, 5, 6, 99], device=DEV), 1)
+    assert torch.isnan(loss) and acc.tolist() == [1 / 6, 3 / 6]
+
+
+def test_bn_running_update_matches_batch_norm():
+    """One launch for the buffers of many BatchNorm layers == what F.batch_norm(training=True) does to each of them."""
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(5)
+    widths = [64] * 30 + [128] * 30 + [256] * 20 + [24, 7, 300]
+    items, refs = [], []
+    for i, C in enumerate(widths):
+        bn = nn.BatchNorm2d(C, momentum=0.1 if i % 3 else 0.25).to(DEV)
+        ref = nn.BatchNorm2d(C, momentum=bn.momentum).to(DEV)
+        with torch.no_grad():
+            bn.running_mean.copy_(torch.randn(C, generator=g)); bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+        ref.load_state_dict(bn.state_dict())
+        x = torch.randn(4, C, 3, 5, generator=g).to(DEV)
+        ref.train()(x)
+        items.append((bn, x.mean((0, 2, 3)), x.var((0, 2, 3), unbiased=False), float(4 * 3 * 5)))
+        refs.append(ref)
+    K_.bn_running_update(items)
+    for (bn, _, _, _), ref in zip(items, refs):
+        assert int(bn.num_batches_tracked) == 1 == int(ref.num_batches_tracked)
+        assert maxabs(bn.running_mean, ref.running_mean) < 1e-6 and maxabs(bn.running_var, ref.running_var) < 2e-6

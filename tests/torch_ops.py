@@ -315,3 +315,27 @@ def temporal_unitmlp_bn(h, dw_w, dw_b, dw_dil, tw, tb, tdil, pw_w, pw_b, merge_a
     else:
         out = mix(dw) + t if merge_after else mix(dw + t)
     return _bn_of(out, gamma, beta, eps, want_bn)
+
+
+def bn_running_update(items):
+    """kernels.bn_running_update in plain torch ops."""
+    with torch.no_grad():
+        for bn, mean, var, c in items:
+            m = float(bn.momentum)
+            bn.num_batches_tracked += 1
+            bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1.0 - m).add_(var * (c / max(c - 1.0, 1.0)), alpha=m)
+
+
+def head_loss(feat, weight, bias, label, persons, loss_weight=1.0):
+    """kernels.head_loss in plain torch ops: person mean, Linear, cross entropy, top-1 / top-5 accuracy (the rank of the
+    label under a stable ascending argsort)."""
+    N = feat.shape[0] // persons
+    score = F.linear(feat.reshape(N, persons, -1).mean(1), weight, bias)
+    loss = F.cross_entropy(score, label) * loss_weight
+    with torch.no_grad():
+        sl = score.gather(1, label.view(-1, 1))
+        idx = torch.arange(score.shape[1], device=score.device)[None]
+        rank = ((score > sl) | ((score == sl) & (idx > label.view(-1, 1)))).sum(1)
+        acc = torch.stack([(rank < 1).double().mean(), (rank < 5).double().mean()])
+    return loss, acc, score.detach()
