@@ -60,7 +60,7 @@ class _FusedBlock(nn.Module):
         return (isinstance(r, unit_tcn) and r.kernel_size == 1 and r.stride == 2 and kernels.ops() is kernels
                 and kernels.PRESTRIDED)
 
-    def forward_fused(self, x, xbar=None, want_xbar=False, tee=False):
+    def forward_fused(self, x, xbar=None, want_xbar=False, tee=False, pool=False):
         # the block input has up to three consumers (gcn main path, gcn residual operand, block residual): give each its
         # own alias so that their gradients are summed in one place instead of autograd's pairwise adds — inside the
         # previous block's fuse_out backward when that block handed over three aliases (tee), in one dsgcn_add3 otherwise
@@ -78,6 +78,8 @@ class _FusedBlock(nn.Module):
             x2, a2 = r.x1, r.a1
         assert t.x2 is None
         # t.relu: the temporal unit ends in its own ReLU (CTR-GCN's MSTCN) -> ReLU on the first term, then add + ReLU
+        if pool:                # the last block under a pooling head: only the plane means (n, C) leave the block
+            return kernels.ops().fuse_out_pool(t.x1, t.a1, x2, a2, 3 if t.relu else 1), None
         return kernels.ops().fuse_out(t.x1, t.a1, x2, a2, 3 if t.relu else 1, want_xbar and self.xbar_ld, tee)
 
     def forward(self, x, A=None):
@@ -209,7 +211,10 @@ def _stage_plan(in_channels, base_channels, num_stages, inflate_stages, down_sta
 
 
 class _SkeletonBackbone(nn.Module):
-    """Shared forward: (N,M,T,V,C) -> data_bn -> (N*M,C,T,V) -> blocks -> (N,M,C',T',V)."""
+    """Shared forward: (N,M,T,V,C) -> data_bn -> (N*M,C,T,V) -> blocks -> (N,M,C',T',V).  ``forward(x, pool=True)`` (what
+    ``RecognizerGCN.forward_train`` asks for under a 'GCN' pooling head) returns the (T', V) plane means (N, M, C') instead:
+    the last block's activation is then never written (``kernels.fuse_out_pool``)."""
+    supports_pool = True
 
     def _make_data_bn(self, data_bn_type, in_channels, num_person, V):
         self.data_bn_type = data_bn_type
@@ -230,7 +235,7 @@ class _SkeletonBackbone(nn.Module):
             x = self.data_bn(x.view(N * M, V * C, T))
         return x.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
 
-    def _run_blocks(self, x, blocks, needs_xbar):
+    def _run_blocks(self, x, blocks, needs_xbar, pool=False):
         xbar = None
         last = len(blocks) - 1
         for i, blk in enumerate(blocks):
@@ -238,9 +243,13 @@ class _SkeletonBackbone(nn.Module):
             T, V = (x[0] if isinstance(x, tuple) else x).shape[2:]
             if tee and getattr(blocks[i + 1], 'wants_prestrided', lambda: False)() and kernels.prestrided_fits(T, V):
                 tee = 2                     # the next block's residual conv reads the even frames only: hand them over as a tensor
-            x, xbar = blk.forward_fused(x, xbar, needs_xbar and i < last, tee=tee)
+            x, xbar = blk.forward_fused(x, xbar, needs_xbar and i < last, tee=tee, pool=pool and i == last)
         flush_running_stats()
         return x
+
+    def _shape_out(self, x, N, M):
+        """(N*M, C, T, V) -> (N, M, C, T, V); plane means (N*M, C) (``forward(x, pool=True)``) -> (N, M, C)."""
+        return x.reshape((N, M) + x.shape[1:])
 
     def init_weights(self):
         if isinstance(getattr(self, 'pretrained', None), str):
@@ -282,11 +291,11 @@ class DGSTGCN(_SkeletonBackbone):
         self.gcn = nn.ModuleList(modules)
         self.pretrained = pretrained
 
-    def forward(self, x):
+    def forward(self, x, pool=False):
         N, M = x.shape[:2]
         x = self._normalize_input(x)
-        x = self._run_blocks(x, self.gcn[:self.num_stages], True)
-        return x.reshape((N, M) + x.shape[1:])
+        x = self._run_blocks(x, self.gcn[:self.num_stages], True, pool)
+        return self._shape_out(x, N, M)
 
 
 @BACKBONES.register_module()
@@ -314,11 +323,11 @@ class STGCN(_SkeletonBackbone):
         self.gcn = nn.ModuleList(modules)
         self.pretrained = pretrained
 
-    def forward(self, x):
+    def forward(self, x, pool=False):
         N, M = x.shape[:2]
         x = self._normalize_input(x.float())
-        x = self._run_blocks(x, self.gcn[:self.num_stages], False)
-        return x.reshape((N, M) + x.shape[1:])
+        x = self._run_blocks(x, self.gcn[:self.num_stages], False, pool)
+        return self._shape_out(x, N, M)
 
 
 class AAGCNBlock(_FusedBlock):
@@ -388,11 +397,11 @@ class AAGCN(_SkeletonBackbone):
             module.init_weights()
         super().init_weights()
 
-    def forward(self, x):
+    def forward(self, x, pool=False):
         N, M = x.shape[:2]
         x = self._normalize_input(x)
-        x = self._run_blocks(x, self.gcn[:self.num_stages], False)
-        return x.reshape((N, M) + x.shape[1:])
+        x = self._run_blocks(x, self.gcn[:self.num_stages], False, pool)
+        return self._shape_out(x, N, M)
 
 
 @BACKBONES.register_module()
@@ -419,8 +428,8 @@ class CTRGCN(_SkeletonBackbone):
         self.net = nn.ModuleList(modules)
         self.pretrained = pretrained
 
-    def forward(self, x):
+    def forward(self, x, pool=False):
         N, M = x.shape[:2]
         x = self._normalize_input(x)
-        x = self._run_blocks(x, self.net, True)
-        return x.reshape((N, M) + x.shape[1:])
+        x = self._run_blocks(x, self.net, True, pool)
+        return self._shape_out(x, N, M)

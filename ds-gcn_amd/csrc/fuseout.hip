@@ -18,7 +18,8 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
                                                      const float* __restrict__ h1, const float* __restrict__ x2,
                                                      const float* __restrict__ s2, const float* __restrict__ h2,
                                                      int relu, float* __restrict__ out, float* __restrict__ xbar, int C,
-                                                     int T, int V, int vec, int ld, float* __restrict__ out_s2) {
+                                                     int T, int V, int vec, int ld, float* __restrict__ out_s2,
+                                                     float* __restrict__ pmean) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   const long plane = blockIdx.x;
@@ -28,7 +29,8 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
   const float a2 = s2 ? s2[c] : 1.f, b2 = s2 ? h2[c] : 0.f;
   const float* p1 = x1 + (size_t)plane * L;
   const float* p2 = x2 ? x2 + (size_t)plane * L : nullptr;
-  float* po = out + (size_t)plane * L;
+  float* po = out ? out + (size_t)plane * L : nullptr;      // (out == NULL: only the plane mean is wanted — the last block)
+  float psum = 0.f;
   if (vec) {
     const int L4 = L >> 2;
     const f32x4* q1 = reinterpret_cast<const f32x4*>(p1);
@@ -45,7 +47,8 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
         v.x += fmaf(r.x, a2, b2); v.y += fmaf(r.y, a2, b2); v.z += fmaf(r.z, a2, b2); v.w += fmaf(r.w, a2, b2);
       }
       if (relu & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      qo[i] = v;
+      if (po) qo[i] = v;
+      psum += (v.x + v.y) + (v.z + v.w);
       if (xbar || out_s2) ql[i] = v;
     }
   } else {
@@ -54,9 +57,14 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
       if (relu & 2) v = fmaxf(v, 0.f);
       if (p2) v += fmaf(p2[i], a2, b2);
       if (relu & 1) v = fmaxf(v, 0.f);
-      po[i] = v;
+      if (po) po[i] = v;
+      psum += v;
       if (xbar || out_s2) lds[i] = v;
     }
+  }
+  if (pmean) {
+    psum = wave_sum(psum);
+    if (lane == 0) pmean[plane] = psum / (float)L;
   }
   if (xbar || out_s2) wave_lds_sync();
   if (out_s2) {
@@ -115,7 +123,8 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
   wave_lds_sync();
   const float* __restrict__ p1 = x1 + (size_t)plane * L;
   const float* __restrict__ p2 = x2 ? x2 + (size_t)plane * L : nullptr;
-  const float* __restrict__ pg = dout ? dout + (size_t)plane * L : nullptr;
+  const float* __restrict__ pg = (dout && s3 != 3) ? dout + (size_t)plane * L : nullptr;
+  const float gpl = s3 == 3 ? dout[plane] / (float)L : 0.f;       // s3 = 3: dout is (n*C), the gradient of the plane mean
   const float* __restrict__ pg2 = dout2 ? dout2 + (size_t)plane * L : nullptr;
   // s3 = 2: dout3 is the gradient of the even-frame copy (n, C, ceil(T/2), V): it reaches the even frames only
   const float* __restrict__ pg3 = dout3 ? dout3 + (size_t)plane * (s3 == 2 ? ((T + 1) >> 1) * V : L) : nullptr;
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
     const float pre1 = fmaf(xa, a1, b1);
     float pre = (relu & 2) ? fmaxf(pre1, 0.f) : pre1;
     if (p2) pre += fmaf(xb, a2, b2);
-    float g = pg ? pg[i] : 0.f;
+    float g = s3 == 3 ? gpl : (pg ? pg[i] : 0.f);
     if (pg2) g += pg2[i];              // (a + b) + c, then the time-mean term: the order dsgcn_add3 + this kernel had
     if (pg3) {
       if (s3 == 2) { if (!(t & 1)) g += pg3[(t >> 1) * V + v]; }
@@ -187,7 +196,9 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd4(const float* __restrict__ 
   wave_lds_sync();
   const f32x4* __restrict__ p1 = reinterpret_cast<const f32x4*>(x1 + (size_t)plane * L);
   const f32x4* __restrict__ p2 = X2 ? reinterpret_cast<const f32x4*>(x2 + (size_t)plane * L) : nullptr;
-  const f32x4* __restrict__ pg = reinterpret_cast<const f32x4*>(dout + (size_t)plane * L);
+  // NG = 0: the gradient is one value per plane (dout (n*C): the backward of the plane mean, already divided by T*V)
+  const f32x4* __restrict__ pg = NG >= 1 ? reinterpret_cast<const f32x4*>(dout + (size_t)plane * L) : nullptr;
+  const float gplane = NG == 0 ? dout[plane] / (float)L : 0.f;
   const f32x4* __restrict__ pg2 = NG >= 2 ? reinterpret_cast<const f32x4*>(dout2 + (size_t)plane * L) : nullptr;
   const f32x4* __restrict__ pg3 = (NG >= 3 && !S3) ? reinterpret_cast<const f32x4*>(dout3 + (size_t)plane * L) : nullptr;
   const float* __restrict__ ps3 = S3 ? dout3 + (size_t)plane * (((T + 1) >> 1) * V) : nullptr;
@@ -197,7 +208,8 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd4(const float* __restrict__ 
   float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
   for (int i = lane; i < L4; i += 64) {
     const f32x4 xa = p1[i];
-    f32x4 xb = {0.f, 0.f, 0.f, 0.f}, g = pg[i];
+    f32x4 xb = {0.f, 0.f, 0.f, 0.f}, g = {gplane, gplane, gplane, gplane};
+    if constexpr (NG >= 1) g = pg[i];
     if constexpr (X2) xb = p2[i];
     if constexpr (NG >= 2) { const f32x4 w = pg2[i]; g.x += w.x; g.y += w.y; g.z += w.z; g.w += w.w; }
     if constexpr (NG >= 3 && !S3) { const f32x4 w = pg3[i]; g.x += w.x; g.y += w.y; g.z += w.z; g.w += w.w; }
@@ -272,7 +284,42 @@ int dsgcn_fuse_out_fwd2(const float* x1, const float* s1, const float* h1, const
   const size_t lds = (xbar || out_s2) ? (size_t)T * V * sizeof(float) : 0;
   if (lds > 64 * 1024) return DSGCN_EUNSUPPORTED;
   hipLaunchKernelGGL(k_fuse_out_fwd, dim3((unsigned)((long)n * C)), dim3(64), lds, (hipStream_t)stream, x1, s1, h1, x2,
-                     s2, h2, relu, out, xbar, C, T, V, vec, xbar_ld, out_s2);
+                     s2, h2, relu, out, xbar, C, T, V, vec, xbar_ld, out_s2, (float*)nullptr);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// The LAST block's output is only ever averaged over its (T, V) planes by the head (simple_head.py:88-93): pmean (n, C) =
+// plane means of the block output, which is never written (one 82 MB write, its read by the pooling launch, and in the
+// backward the broadcast of the pooled gradient and its read are gone).
+int dsgcn_fuse_out_pool_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                            const float* h2, int relu, float* pmean, int n, int C, int T, int V, void* stream) {
+  if (!x1 || !pmean || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (s1 && !h1) || (s2 && !h2)) return DSGCN_EINVAL;
+  const int vec = ((T * V) % 4 == 0) ? 1 : 0;
+  hipLaunchKernelGGL(k_fuse_out_fwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, x1, s1, h1, x2, s2,
+                     h2, relu, (float*)nullptr, (float*)nullptr, C, T, V, vec, V, (float*)nullptr, pmean);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// dpmean (n, C): gradient of the plane means; dx1 / dx2 / part as in dsgcn_fuse_out_bwd.
+int dsgcn_fuse_out_pool_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                            const float* h2, int relu, const float* dpmean, float* dx1, float* dx2, float* part, int n,
+                            int C, int T, int V, void* stream) {
+  if (!x1 || !dx1 || !dpmean || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (x2 && !dx2)) return DSGCN_EINVAL;
+  const dim3 grid((unsigned)((long)n * C)), blk(64);
+  hipStream_t st = (hipStream_t)stream;
+  if ((T * V) % 4 == 0) {
+    if (x2)
+      hipLaunchKernelGGL((k_fuse_out_bwd4<0, false, true>), grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, dpmean,
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dx1, dx2, part, C, T, V, V);
+    else
+      hipLaunchKernelGGL((k_fuse_out_bwd4<0, false, false>), grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, dpmean,
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dx1, dx2, part, C, T, V, V);
+  } else {
+    hipLaunchKernelGGL(k_fuse_out_bwd, grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, dpmean, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, dx1, dx2, part, C, T, V, V, 3);
+  }
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -4,6 +4,7 @@
 //   k_head_fwd / k_head_fin / k_head_bwd   person mean + Linear + softmax cross entropy + top-1 / top-5 accuracy
 //       (pyskl/models/heads/simple_head.py:60-98 'GCN' mode after the plane mean, heads/base.py:50-84,
 //       losses/cross_entropy_loss.py:75-82 with base.py:38-44's loss_weight, core/evaluation.py:63-88 top_k_accuracy)
+//   k_sgd                                  the optimizer's five elementwise passes over the flat buffers as one
 //   k_bn_running_multi                     running_mean / running_var / num_batches_tracked of every BatchNorm of a
 //       forward in one launch (torch.nn.functional.batch_norm's training-mode buffer update, momentum form)
 // All sums run in a fixed order (no atomics): the step stays bit-reproducible.
@@ -192,9 +193,57 @@ __global__ __launch_bounds__(256) void k_bn_running_multi(RnJobs jb) {
   if (threadIdx.x == 0 && jb.nbt[j]) jb.nbt[j][0] += 1;
 }
 
+// SGD with momentum (dampening 0) over the flat buffers, torch.optim.SGD's update order:
+//   g' = g + wd p;  buf = mom buf + g';  step = nesterov ? g' + mom buf : buf;  p -= lr step      (lr read on the device)
+__global__ __launch_bounds__(256) void k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                             const float* __restrict__ lr, float mom, float wd, int nesterov, long n4,
+                                             long n) {
+  const float rate = lr[0];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  auto one = [&](float pv, float gv, float& bv) {
+    gv = gv + wd * pv;
+    float st = gv;
+    if (buf) {
+      bv = bv * mom + gv;
+      st = nesterov ? gv + mom * bv : bv;
+    }
+    return pv - rate * st;
+  };
+  if (i < n4) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 bv = buf ? reinterpret_cast<f32x4*>(buf)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float be = bv[e];
+      pv[e] = one(pv[e], gv[e], be);
+      bv[e] = be;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    if (buf) reinterpret_cast<f32x4*>(buf)[i] = bv;
+  } else if (i == n4) {                                             // the tail (n % 4 elements)
+    for (long j = 4 * n4; j < n; ++j) {
+      float bv = buf ? buf[j] : 0.f;
+      p[j] = one(p[j], g[j], bv);
+      if (buf) buf[j] = bv;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int dsgcn_sgd_step(float* p, const float* g, float* buf, const float* lr, float momentum, float weight_decay,
+                   int nesterov, long long n, void* stream) {
+  if (!p || !g || !lr || n <= 0 || (momentum != 0.f && !buf)) return DSGCN_EINVAL;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) return DSGCN_EINVAL;
+  const long n4 = (long)(n / 4);
+  hipLaunchKernelGGL(k_sgd, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g,
+                     momentum != 0.f ? buf : nullptr, lr, momentum, weight_decay, nesterov, n4, (long)n);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
 
 int dsgcn_head_loss_fwd(const float* feat, const float* w, const float* b, const long long* label, int N, int M, int C,
                         int K, float loss_weight, float* pooled, float* score, float* prob, float* clip, float* loss,

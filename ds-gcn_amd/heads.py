@@ -42,12 +42,14 @@ class SimpleHead(nn.Module):
         nn.init.constant_(self.fc_cls.bias, 0)
 
     def forward(self, x):
-        """x (N, M, C, T, V) backbone features (or already pooled (N, C)) -> class scores (N, classes)."""
+        """x (N, M, C, T, V) backbone features (or their plane means (N, M, C), or pooled (N, C)) -> scores (N, classes)."""
         if x.dim() == 5:
             N, M, C = x.shape[:3]
             x = x.reshape(N * M, C, -1).mean(-1).reshape(N, M, C).mean(1)
+        elif x.dim() == 3:                          # per-person plane means from ``backbone(x, pool=True)``
+            x = x.mean(1)
         elif x.dim() != 2:
-            raise NotImplementedError(f'GCN head expects (N, M, C, T, V) or (N, C) features, got {tuple(x.shape)}')
+            raise NotImplementedError(f'GCN head expects (N, M, C, T, V), (N, M, C) or (N, C) features, got {tuple(x.shape)}')
         assert x.shape[1] == self.in_c
         if self.dropout is not None:
             x = self.dropout(x)
@@ -58,7 +60,7 @@ class SimpleHead(nn.Module):
         accuracies in three launches (``kernels.head_loss``) instead of ~25.  Heads with dropout or another loss take the
         two calls."""
         from .losses import CrossEntropyLoss
-        if (not kernels.FUSED_ENDS or x.dim() != 5 or self.dropout is not None or type(self.loss_cls) is not CrossEntropyLoss
+        if (not kernels.FUSED_ENDS or x.dim() not in (3, 5) or self.dropout is not None or type(self.loss_cls) is not CrossEntropyLoss
                 or label.is_floating_point()):
             return self.loss(self(x), label)
         if label.dim() == 0:
@@ -68,7 +70,7 @@ class SimpleHead(nn.Module):
         if label.shape != (N,):
             raise NotImplementedError(f'CrossEntropyLoss: expects (N,) integer labels for (N, classes) scores, got '
                                       f'{tuple(label.shape)} for {N} clips')
-        feat = x.reshape(N * M, C, -1).mean(-1)
+        feat = x.reshape(N * M, C, -1).mean(-1) if x.dim() == 5 else x.reshape(N * M, C)
         loss, acc, _ = kernels.ops().head_loss(feat, self.fc_cls.weight, self.fc_cls.bias, label, M,
                                                self.loss_cls.loss_weight)
         return dict(top1_acc=acc[0], top5_acc=acc[1], loss_cls=loss)

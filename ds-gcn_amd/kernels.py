@@ -2023,6 +2023,60 @@ class _FuseOut(torch.autograd.Function):
         return dx1, ds1, dh1, dx2, ds2, dh2, None, None, None
 
 
+class _FuseOutPool(torch.autograd.Function):
+    """The block output as its plane means (n, C) only — the LAST block, whose activation nothing but the head's pooling
+    reads (_FuseOut without the write; the backward spreads the pooled gradient while it loads its operands)."""
+
+    @staticmethod
+    def forward(ctx, x1, s1, h1, x2, s2, h2, relu):
+        _require_cuda(x1)
+        x1, s1, h1, x2, s2, h2 = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2)]
+        n, C, T, V = x1.shape
+        if x2 is not None and x2.shape != x1.shape:
+            raise ValueError(f'fuse_out_pool: the two terms differ in shape: {tuple(x1.shape)} vs {tuple(x2.shape)}')
+        pm = torch.empty((n, C), device=x1.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_fuse_out_pool_fwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu),
+                                                  _ptr(pm), n, C, T, V, _stream())
+        native.check(rc, 'dsgcn_fuse_out_pool_fwd')
+        ctx.save_for_backward(x1, s1, h1, x2, s2, h2)
+        ctx.relu = int(relu)
+        ctx.bn1, ctx.bn2 = _bn_of(s1), _bn_of(s2)
+        return pm
+
+    @staticmethod
+    def backward(ctx, dpm):
+        x1, s1, h1, x2, s2, h2 = ctx.saved_tensors
+        n, C, T, V = x1.shape
+        dpm = _f32c(dpm)
+        dx1 = torch.empty_like(x1)
+        dx2 = torch.empty_like(x2) if x2 is not None else None
+        need_part = s1 is not None or s2 is not None
+        part = torch.empty((n, C, 4), device=x1.device, dtype=torch.float32) if need_part else None
+        rc = native.lib().dsgcn_fuse_out_pool_bwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
+                                                  _ptr(dpm), _ptr(dx1), _ptr(dx2), _ptr(part), n, C, T, V, _stream())
+        native.check(rc, 'dsgcn_fuse_out_pool_bwd')
+        ds1 = dh1 = ds2 = dh2 = None
+        if need_part and (s1 is None or ctx.bn1 is not None) and (s2 is None or ctx.bn2 is not None):
+            if s1 is not None:
+                _bn_feed(ctx.bn1, part, 4, 0, 3)
+            if s2 is not None:
+                _bn_feed(ctx.bn2, part, 4, 2, 1)
+        elif need_part:
+            red = colsum(part, split_last=True)
+            if s1 is not None:
+                ds1, dh1 = red[0], red[3]
+            if s2 is not None:
+                ds2, dh2 = red[2], red[1]
+        return dx1, ds1, dh1, dx2, ds2, dh2, None
+
+
+def fuse_out_pool(x1, a1, x2, a2, relu):
+    """mean over (T, V) of ``fuse_out(x1, a1, x2, a2, relu)`` -> (n, C), without materialising the activation."""
+    s1, h1 = a1 if a1 is not None else (None, None)
+    s2, h2 = a2 if a2 is not None else (None, None)
+    return _FuseOutPool.apply(x1, s1, h1, x2, s2, h2, int(relu))
+
+
 def fuse_out(x1, a1, x2, a2, relu, want_tmean=False, tee=False):
     """relu: bool, or int flags — bit 0 the outer ReLU, bit 1 a ReLU on the first term before the add.
     want_tmean: False / True (time mean (n, C, V)) / an int ld >= V (time mean with the joint row zero-padded to ld: the

@@ -24,7 +24,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import builder
+from . import builder, kernels
 from .builder import RECOGNIZERS
 
 
@@ -81,8 +81,13 @@ class RecognizerGCN(nn.Module):
     def forward_train(self, keypoint, label):
         assert self.cls_head is not None
         assert keypoint.shape[1] == 1, 'training batches carry one clip per sample'
-        feat = self.extract_feat(keypoint[:, 0].float())
-        if hasattr(self.cls_head, 'forward_loss'):
+        fused = hasattr(self.cls_head, 'forward_loss')
+        # a pooling head only reads the plane means of the features: ask the backbone for those
+        pool = (fused and kernels.FUSED_ENDS and getattr(self.backbone, 'supports_pool', False)
+                and getattr(self.cls_head, 'mode', None) == 'GCN')
+        x = keypoint[:, 0].float()
+        feat = self.backbone(x, pool=True) if pool else self.extract_feat(x)
+        if fused:
             return self.cls_head.forward_loss(feat, label.squeeze(-1))
         return self.cls_head.loss(self.cls_head(feat), label.squeeze(-1))
 

@@ -5,6 +5,8 @@ import math
 
 import torch
 
+from . import kernels, native
+
 
 class FlatSGD:
     """Nesterov SGD over ``FlatParams`` buffers: a handful of elementwise launches per step regardless of
@@ -36,6 +38,14 @@ class FlatSGD:
     @torch.no_grad()
     def step(self):
         p, g = self.flat.flat_p, self.flat.flat_g
+        if self.capturable and p.is_cuda and p.dtype == torch.float32 and kernels.FUSED_ENDS:
+            # one launch (csrc/head.hip k_sgd) instead of five elementwise passes over the flat buffers
+            rc = native.lib().dsgcn_sgd_step(p.data_ptr(), g.data_ptr(), self.buf.data_ptr() if self.momentum else None,
+                                             self.lr_t.data_ptr(), float(self.momentum), float(self.weight_decay),
+                                             int(bool(self.nesterov)), p.numel(),
+                                             torch.cuda.current_stream().cuda_stream)
+            native.check(rc, 'dsgcn_sgd_step')
+            return
         if self.weight_decay:
             g = g.add(p, alpha=self.weight_decay)
         if self.momentum:

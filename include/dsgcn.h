@@ -94,6 +94,15 @@ int dsgcn_fuse_out_bwd3s(const float* x1, const float* s1, const float* h1, cons
                          const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
                          void* stream);
 
+/* The last block's output as its (T, V) plane means only (what the head's pooling reads, simple_head.py:88-93): pmean
+ * (n, C) = mean_tv relu?(x1*s1+h1 (+ x2*s2+h2 | + x2)) — the activation itself is never written.  Backward: dpmean
+ * (n, C), dx1 / dx2 / part as dsgcn_fuse_out_bwd. */
+int dsgcn_fuse_out_pool_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                            const float* h2, int relu, float* pmean, int n, int C, int T, int V, void* stream);
+int dsgcn_fuse_out_pool_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                            const float* h2, int relu, const float* dpmean, float* dx1, float* dx2, float* part, int n,
+                            int C, int T, int V, void* stream);
+
 /* Dense (KT,1) temporal conv as a GEMM on bf16 terms (csrc/tcg.hip): unit_tcn's Conv2d((9,1), padding 4) + the statistics
  * of its BatchNorm (tcn.py:21-28), stride 1 or 2 (T = input frames, z has ceil(T/stride)), dilation 1, KT odd <= 9,
  * V <= 32; the virtual input relu?(x1*s1+h1 (+ x2*s2+h2))
@@ -425,6 +434,13 @@ int dsgcn_head_loss_bwd(const float* prob, const float* pooled, const float* w, 
 int dsgcn_bn_running_multi(float* const* running_mean, float* const* running_var, const float* const* mean,
                            const float* const* var, long long* const* num_batches_tracked, const int* C,
                            const float* unbias, const float* momentum, int njobs, void* stream);
+
+/* One SGD step over flat fp32 buffers of n elements (16-byte aligned), torch.optim.SGD's update with dampening 0 — the
+ * reference's optimizer (configs/_init_/lr_schedual.py:11-15: momentum 0.9, weight decay 5e-4, nesterov):
+ *   g' = g + weight_decay p;  buf = momentum buf + g';  p -= lr[0] * (nesterov ? g' + momentum buf : buf);
+ * lr: ONE device float (a captured launch follows the schedule on replay); buf may be NULL when momentum == 0. */
+int dsgcn_sgd_step(float* p, const float* g, float* buf, const float* lr, float momentum, float weight_decay,
+                   int nesterov, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1175,3 +1175,83 @@ def test_bn_running_update_matches_batch_norm():
     for (bn, _, _, _), ref in zip(items, refs):
         assert int(bn.num_batches_tracked) == 1 == int(ref.num_batches_tracked)
         assert maxabs(bn.running_mean, ref.running_mean) < 1e-6 and maxabs(bn.running_var, ref.running_var) < 2e-6
+
+
+@pytest.mark.parametrize('n,C,T,V,mode,flags', [
+    (3, 64, 64, 25, 'res_plain', 1), (2, 128, 32, 25, 'res_affine', 1), (2, 64, 64, 25, 'affine', 1),
+    (2, 12, 25, 17, 'res_affine', 1), (1, 5, 7, 18, 'plain', 1), (2, 64, 32, 25, 'res_plain', 3),
+    (2, 16, 9, 17, 'res_affine', 3), (2, 16, 8, 25, 'res_affine', 0),
+    (128, 256, 25, 25, 'res_plain', 1)])                     # the bench step's last block
+def test_fuse_out_pool(n, C, T, V, mode, flags):
+    """The last block's output as plane means only (no activation written) against mean(fuse_out) in fp64, and — same
+    launches, same order of operations — bit-identical to the mean the full kernel's output gives when summed the same way
+    is NOT claimed: torch's mean runs in another order, so 2e-6 of the norm."""
+    g = torch.Generator().manual_seed(C + T + flags)
+    x1 = _rand(g, n, C, T, V)
+    a1 = None if mode == 'plain' else (torch.rand(C, generator=g) + 0.5, _rand(g, C, scale=0.3))
+    x2 = _rand(g, n, C, T, V) if mode.startswith('res') else None
+    a2 = (torch.rand(C, generator=g) + 0.5, _rand(g, C, scale=0.3)) if mode == 'res_affine' else None
+    gp = _rand(g, n, C)
+    if flags == 1:
+        off_knife_edge(x1, a1, x2, a2, True)
+
+    def run(mod, dt, dev):
+        def mk(t):
+            return None if t is None else t.to(dev, dt).requires_grad_()
+        tx1, tx2 = mk(x1), mk(x2)
+        ta1 = None if a1 is None else (mk(a1[0]), mk(a1[1]))
+        ta2 = None if a2 is None else (mk(a2[0]), mk(a2[1]))
+        pm = mod.fuse_out_pool(tx1, ta1, tx2, ta2, flags)
+        (pm * gp.to(dev, dt)).sum().backward()
+        res = dict(pm=pm, dx1=tx1.grad)
+        if tx2 is not None:
+            res['dx2'] = tx2.grad
+        if ta1 is not None:
+            res['ds1'], res['dh1'] = ta1[0].grad, ta1[1].grad
+        if ta2 is not None:
+            res['ds2'], res['dh2'] = ta2[0].grad, ta2[1].grad
+        return res
+
+    got = run(K, torch.float32, DEV)
+    ref = run(R, torch.float64, ref_dev(n))
+    assert got['pm'].shape == (n, C)
+    for k, v in ref.items():
+        assert rel(got[k], v) < (1e-5 if k[0] == 'd' and k[1] in 'sh' else 2e-6), (k, rel(got[k], v))
+    # against the materialising kernel: the same gradients to rounding (the only difference is where the pooled
+    # gradient is divided by T*V)
+    tx1 = x1.to(DEV).requires_grad_()
+    tx2 = None if x2 is None else x2.to(DEV).requires_grad_()
+    ta1 = None if a1 is None else (a1[0].to(DEV), a1[1].to(DEV))
+    ta2 = None if a2 is None else (a2[0].to(DEV), a2[1].to(DEV))
+    out, _ = K.fuse_out(tx1, ta1, tx2, ta2, flags)
+    (out.mean((2, 3)) * gp.to(DEV)).sum().backward()
+    assert rel(got['dx1'], tx1.grad) < 1e-6
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 1027, 1378101])
+@pytest.mark.parametrize('mom,wd,nesterov', [(0.9, 5e-4, True), (0.9, 0.0, False), (0.0, 1e-3, False)])
+def test_sgd_step_matches_torch(n, mom, wd, nesterov):
+    """csrc/head.hip k_sgd == torch.optim.SGD, three steps with a changing rate (the reference's optimizer:
+    configs/_init_/lr_schedual.py:11-15); elementwise fp32: 1e-6 absolute on O(1) values."""
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) for _ in range(3)]
+    ref = torch.nn.Parameter(p0.clone().to(DEV))
+    topt = torch.optim.SGD([ref], lr=0.1, momentum=mom, weight_decay=wd, nesterov=nesterov)
+    p = p0.clone().to(DEV)
+    buf = torch.zeros_like(p) if mom else None
+    lr_t = torch.zeros(1, device=DEV)
+    from dsgcn_amd import native
+    for it, gr in enumerate(grads):
+        lr = 0.1 / (it + 1)
+        topt.param_groups[0]['lr'] = lr
+        ref.grad = gr.to(DEV)
+        topt.step()
+        lr_t.fill_(lr)
+        gd = gr.to(DEV)
+        rc = native.lib().dsgcn_sgd_step(p.data_ptr(), gd.data_ptr(), None if buf is None else buf.data_ptr(), lr_t.data_ptr(),
+                                         mom, wd, int(nesterov), n, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+    assert maxabs(p, ref) < 1e-6
+    if mom:
+        assert maxabs(buf, topt.state[ref]['momentum_buffer']) < 1e-6

@@ -268,6 +268,10 @@ def fuse_out(x1, a1, x2, a2, relu, want_tmean=False, tee=False):
     return ((out, out, out) if tee else out), xbar
 
 
+def fuse_out_pool(x1, a1, x2, a2, relu):
+    return fuse_out(x1, a1, x2, a2, relu)[0].mean((2, 3))
+
+
 def temporal_mlp_bn(z, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, dw_w, dw_b, dw_dil, pw_w, pw_b,
                     merge_after, stride, gamma=None, beta=None, eps=1e-5, want_bn=False):
     """msmlp's temporal stage (see dsgcn_amd.kernels.temporal_mlp_bn) in plain torch ops."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the step's small ends on csrc/head.hip: tests + same-box A/B (py:FUSED_ENDS=0 = the framework's own launches)
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r5_ends; mkdir -p $O; cd $R
-timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu -x -k "head_loss or bn_running or data_bn or fuse_out" > $O/test_k.log 2>&1; tail -4 $O/test_k.log
-timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_train_loop.py tests/test_host_api.py -q -m gpu -x > $O/test_m.log 2>&1; tail -4 $O/test_m.log
-timeout 900 python tools/step_ab.py "" py:FUSED_ENDS=0 py:PARAM_FLUSH_BYTES=134217728 --rounds 3 2>&1 | grep -v amdgpu | tee $O/step_ab.txt
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu -x -k "head_loss or bn_running or data_bn or fuse_out or sgd" > $O/test_k.log 2>&1; tail -4 $O/test_k.log
+timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_train_loop.py tests/test_host_api.py tests/test_data_parallel.py -q -m gpu -x > $O/test_m.log 2>&1; tail -4 $O/test_m.log
+timeout 900 python tools/step_ab.py "" py:FUSED_ENDS=0 --rounds 3 2>&1 | grep -v amdgpu | tee $O/step_ab.txt
