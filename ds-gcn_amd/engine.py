@@ -37,6 +37,7 @@ class TrainEngine:
         self._graphs = {}          # batch shape -> (graph A, graph B, static keypoint, static label, static outputs)
         self._seen = {}            # batch shape -> eager steps taken
         self.capture_error = None
+        self._seed = None
         self.iter = 0
 
     # ---- pieces --------------------------------------------------------------------------------------------
@@ -44,12 +45,15 @@ class TrainEngine:
         self.opt.zero_grad()
         kernels.reset_leaf_uses()
         out = self.model.train_step(dict(keypoint=keypoint, label=label), None, sync_log_vars=False)
+        loss = out['loss']
+        if self._seed is None or self._seed.dtype != loss.dtype or self._seed.device != loss.device:
+            self._seed = torch.ones((), dtype=loss.dtype, device=loss.device)     # (backward() fills a fresh one per step)
         if self.flat.flat_p.is_cuda:
             # parameter-gradient partial rows are summed by ONE launch at the end of the backward (kernels.param_colsum)
             with kernels.deferred_param_sums(self.flat):
-                out['loss'].backward()
+                loss.backward(self._seed)
         else:
-            out['loss'].backward()
+            loss.backward(self._seed)
         self.flat.collect_grads()
         return {k: v.detach() for k, v in out['log_vars'].items()}
 

@@ -201,8 +201,8 @@ class dgphgcn1(nn.Module):
         separately, see kernels.tee3)."""
         ops = kernels.ops()
         x_res = x if x_res is None else x_res
-        if xbar is None:
-            xbar = ops.tmean(x)
+        if xbar is None:                          # first block: joint rows padded to 32 like fuse_out(want_tmean=32)'s
+            xbar = ops.tmean(x, 32) if x.shape[-1] <= 32 else ops.tmean(x)
         fork = getattr(ops, 'side_branch', None)
         if fork is None:
             ahat = self.adjacency(xbar)

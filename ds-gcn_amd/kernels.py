@@ -373,10 +373,17 @@ def _defer_table(k, dev):
 def flush_param_sums():
     """One launch for every queued column sum (no-op when nothing is queued)."""
     global _deferred
-    jobs = _deferred
-    if not jobs:
+    queued = _deferred
+    if not queued:
         return
     _deferred = [] if _deferred is not None else None
+    for level in (0, 1):                              # level 1 = second stages of tall inputs: read what level 0 wrote
+        jobs = [j[:4] for j in queued if j[4] == level]
+        if jobs:
+            _flush_jobs(jobs)
+
+
+def _flush_jobs(jobs):
     dev = jobs[0][0].device
     k = len(jobs)
     slot = _defer_table(k, dev)
@@ -403,11 +410,13 @@ def param_colsum(t, defer_ok=True):
     shape = t.shape[1:]
     C = t.numel() // max(R, 1)
     g = _fold(R, C)
-    if g > 1:                                         # tall inputs: the wide first stage now, the small second one queued
-        t = _colsum_raw(t, R // g, g * C)
-        R = g
     out = torch.empty(C, device=t.device, dtype=torch.float32)
-    _deferred.append((t, R, C, out))
+    if g > 1:                                         # tall inputs: the wide first stage in the flush's first launch, the
+        mid = torch.empty(g * C, device=t.device, dtype=torch.float32)         # small second one in its second
+        _deferred.append((t, R // g, g * C, mid, 0))
+        _deferred.append((mid, g, C, out, 1))
+    else:
+        _deferred.append((t, R, C, out, 0))
     return out.view(shape)
 
 
@@ -812,11 +821,12 @@ def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, gamma=None, 
 # K-D  temporal units
 # ---------------------------------------------------------------------------------------------
 
-def tmean(x):
+def tmean(x, ld=True):
     """Mean over frames of the network input (n,C,T,V) -> (n,C,V): the x.mean(-2) of the first block's adjacency
-    (gcn.py:2246 / gcn.py:651); later blocks get it from the previous block's fuse_out."""
+    (gcn.py:2246 / gcn.py:651); later blocks get it from the previous block's fuse_out.  ld: an int >= V pads the joint
+    rows with zeros to that length (the layout ``dynadj`` reads: no pad launches in front of it)."""
     _require_cuda(x)
-    return fuse_out(x, None, None, None, 0, True)[1]
+    return fuse_out(x, None, None, None, 0, ld)[1]
 
 
 class _BranchAct(torch.autograd.Function):
@@ -2125,10 +2135,13 @@ class _HeadLoss(torch.autograd.Function):
         ctx.save_for_backward(prob, pooled, weight, label)
         ctx.dims = (N, M, C, K, float(loss_weight), bias is not None)
         ctx.mark_non_differentiable(acc, score)
+        ctx.set_materialize_grads(False)            # (zero gradients for acc / score would be two fill launches)
         return loss, acc, score
 
     @staticmethod
     def backward(ctx, gloss, _gacc, _gscore):
+        if gloss is None:
+            return None, None, None, None, None, None
         prob, pooled, weight, label = ctx.saved_tensors
         N, M, C, K, lw, has_bias = ctx.dims
         dev = prob.device

@@ -136,8 +136,11 @@ def tee3(x):
     return x, x, x
 
 
-def tmean(x):
-    return x.mean(2)
+def tmean(x, ld=True):
+    xbar = x.mean(2)
+    if ld is not True and int(ld) > xbar.shape[-1]:
+        xbar = F.pad(xbar, (0, int(ld) - xbar.shape[-1]))
+    return xbar
 
 
 def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type, single_use=True):
