@@ -45,7 +45,8 @@ __global__ __launch_bounds__(64) void k_tanhdiff_fwd(const float* __restrict__ p
 }
 
 // dproj rows: x1 gets sum_v dd*(1-d^2), x2 gets -sum_u dd*(1-d^2)
-__global__ __launch_bounds__(64) void k_tanhdiff_bwd(const float* __restrict__ d, const float* __restrict__ dd,
+// (dd: one gradient tensor (n, R, V, V) per subset, NULL = none reached it)
+__global__ __launch_bounds__(64) void k_tanhdiff_bwd(const float* __restrict__ d, CtrPtrs dd,
                                                      float* __restrict__ dproj, int n, int K, int R, int V) {
   extern __shared__ float ts[];                // [V*V]
   const int lane = threadIdx.x;
@@ -54,10 +55,10 @@ __global__ __launch_bounds__(64) void k_tanhdiff_bwd(const float* __restrict__ d
   const long ki = row / R;
   const int i = (int)(ki % n), k = (int)(ki / n);
   const float* __restrict__ pd = d + (size_t)row * V * V;
-  const float* __restrict__ pg = dd + (size_t)row * V * V;
+  const float* __restrict__ pg = dd.s[k] ? dd.s[k] + ((size_t)i * R + r) * V * V : nullptr;
   for (int e = lane; e < V * V; e += 64) {
     const float t = pd[e];
-    ts[e] = pg[e] * (1.f - t * t);
+    ts[e] = pg ? pg[e] * (1.f - t * t) : 0.f;
   }
   wave_lds_sync();
   float* __restrict__ o1 = dproj + ((size_t)i * 2 * K * R + (size_t)k * R + r) * V;
@@ -213,9 +214,23 @@ int dsgcn_tanhdiff_fwd(const float* proj, float* d, int n, int K, int R, int V, 
 }
 
 int dsgcn_tanhdiff_bwd(const float* d, const float* dd, float* dproj, int n, int K, int R, int V, void* stream) {
-  if (!d || !dd || !dproj || n <= 0 || K <= 0 || R <= 0 || V <= 0 || V > 32) return DSGCN_EINVAL;
+  if (!d || !dd || !dproj || n <= 0 || K <= 0 || K > CTR_MAXK || R <= 0 || V <= 0 || V > 32) return DSGCN_EINVAL;
+  CtrPtrs p = {};
+  for (int k = 0; k < K; ++k) p.s[k] = dd + (size_t)k * n * R * V * V;
   hipLaunchKernelGGL(k_tanhdiff_bwd, dim3((unsigned)((long)K * n * R)), dim3(64), (size_t)V * V * sizeof(float),
-                     (hipStream_t)stream, d, dd, dproj, n, K, R, V);
+                     (hipStream_t)stream, d, p, dproj, n, K, R, V);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// dd: K pointers, each the gradient (n, R, V, V) of one subset's slice of d or NULL (no gradient reached that slice): the
+// K conv4 backward passes hand their results over as they are (stacking them was a fill + copy + add per subset)
+int dsgcn_tanhdiff_bwd_k(const float* d, const float* const* dd, float* dproj, int n, int K, int R, int V, void* stream) {
+  if (!d || !dd || !dproj || n <= 0 || K <= 0 || K > CTR_MAXK || R <= 0 || V <= 0 || V > 32) return DSGCN_EINVAL;
+  CtrPtrs p = {};
+  for (int k = 0; k < K; ++k) p.s[k] = dd[k];
+  hipLaunchKernelGGL(k_tanhdiff_bwd, dim3((unsigned)((long)K * n * R)), dim3(64), (size_t)V * V * sizeof(float),
+                     (hipStream_t)stream, d, p, dproj, n, K, R, V);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -427,7 +427,10 @@ class unit_aagcn(nn.Module):
             zo, sc, sh, mean, var = ops.aggregate_sum(p, adj, S, self.bn.weight, self.bn.bias, self.bn.eps, True,
                                                       self.adaptive)
             record_running(self.bn, mean + bsum.detach(), var, N * T * V)
-            ao = (sc, sh + 0.0 * bsum)            # (keeps the biases on the graph: their gradient is exactly zero here)
+            # (keeps the biases on the graph: their gradient is exactly zero here.  The scale goes on as a fresh alias: the
+            # BatchNorm context that rides on `sc` would let the consumer hand its sums straight to the producer and return
+            # no gradient for the shift — the biases would end up without one)
+            ao = (sc.view_as(sc), sh + 0.0 * bsum)
         else:
             zo = ops.aggregate_sum(p, adj, S, per_sample=self.adaptive)[0]
             sc, sh = eval_affine(self.bn)

@@ -1038,8 +1038,9 @@ class _TemporalFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, zaug, scale, shift, coeff, gamma, beta, n_act, stride, KT, types, c0s, bcs, dils, eps, want_bn,
-                *wb):
+                bn, *wb):
         _require_cuda(z)
+        ctx.bn, ctx.bn_in = bn, _bn_of(scale)
         z, zaug, scale, shift, coeff, gamma, beta = [_f32c(t) for t in (z, zaug, scale, shift, coeff, gamma, beta)]
         nbr = len(types)
         ws = [_f32c(t) for t in wb[:nbr]]
@@ -1087,12 +1088,8 @@ class _TemporalFused(torch.autograd.Function):
         aug = zaug is not None
         gf, gscale, gshift = _f32c(gf), _f32c(gscale), _f32c(gshift)
         A0 = B0 = dgamma = dbeta = None
-        if want_bn and (gscale is not None or gshift is not None):
-            coef = torch.empty((4, C), device=dev, dtype=torch.float32)
-            dgamma, dbeta, A0, B0 = coef[0], coef[1], coef[2], coef[3]
-            rc = lib.dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, C, C,
-                                       _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), st)
-            native.check(rc, 'dsgcn_bn_bwd_coef')
+        if want_bn:
+            dgamma, dbeta, A0, B0 = _bn_coef(ctx.bn, gscale, gshift, mean, var, gamma, eps, count, C, C)
         if gf is None:
             gf = torch.zeros_like(f)
         it = iter(wsaved)
@@ -1108,7 +1105,9 @@ class _TemporalFused(torch.autograd.Function):
                                  V, stride, KT, nbr, *tabs, _ptr_array(ws), st)
         native.check(rc, 'dsgcn_tms_dgrad')
         dscale = dshift = dcoeff = None
-        if scale is not None:
+        if scale is not None and ctx.bn_in is not None:
+            _bn_feed(ctx.bn_in, paff, 2, 0, 1)
+        elif scale is not None:
             red = colsum(paff, split_last=True)
             dscale, dshift = red[0], red[1]
         if aug:
@@ -1138,7 +1137,7 @@ class _TemporalFused(torch.autograd.Function):
             dgamma = dgamma if gamma is not None else None
             dbeta = dbeta if has_beta else None
         return (dz, dzaug, dscale, dshift, dcoeff, dgamma, dbeta, None, None, None, None, None, None, None, None, None,
-                *dws, *dbs)
+                None, *dws, *dbs)
 
 
 class _TemporalSplit(torch.autograd.Function):
@@ -1287,8 +1286,13 @@ def _fused_temporal(z, zaug, scale, shift, coeff, n_act, branch_cfg, widths, con
                                        _int_array(dils), int(zaug is not None))
     if rows <= 0:
         return None
-    return _TemporalFused.apply(z, zaug, scale, shift, coeff, gamma, beta, int(n_act), int(stride), KT, types, c0s, bcs,
-                                dils, float(eps), bool(want_bn), *ws, *bs)
+    bn = BNCtx() if want_bn else None
+    out = _TemporalFused.apply(z, zaug, scale, shift, coeff, gamma, beta, int(n_act), int(stride), KT, types, c0s, bcs,
+                               dils, float(eps), bool(want_bn), bn, *ws, *bs)
+    if want_bn:
+        Tout = (T + int(stride) - 1) // int(stride)
+        _bn_attach(out[1], bn, out[3], out[4], gamma, eps, float(n * Tout * V), C)
+    return out
 
 
 def temporal_ms(z, zaug, scale, shift, n_act, branch_cfg, widths, conv_w, conv_b, add_coeff, stride, gamma=None,
@@ -1608,8 +1612,9 @@ def tconv(h, weight, bias, stride, dilation, gamma=None, beta=None, eps=1e-5, wa
 class _AggSum(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, p, adj, K, gamma, beta, eps, want_bn, per_sample=False):
+    def forward(ctx, p, adj, K, gamma, beta, eps, want_bn, per_sample=False, bn=None):
         _require_cuda(p, adj)
+        ctx.bn = bn
         p, adj, gamma, beta = _f32c(p), _f32c(adj), _f32c(gamma), _f32c(beta)
         n, KC, T, V = p.shape
         Co = KC // K
@@ -1651,12 +1656,8 @@ class _AggSum(torch.autograd.Function):
         lib = native.lib()
         gy, gscale, gshift = _f32c(gy), _f32c(gscale), _f32c(gshift)
         A0 = B0 = dgamma = dbeta = None
-        if want_bn and (gscale is not None or gshift is not None):
-            coef = torch.empty((4, Co), device=dev, dtype=torch.float32)
-            dgamma, dbeta, A0, B0 = coef[0], coef[1], coef[2], coef[3]
-            rc = lib.dsgcn_bn_bwd_coef(_ptr(gscale), _ptr(gshift), _ptr(mean), _ptr(var), _ptr(gamma), eps, count, Co,
-                                       Co, _ptr(dgamma), _ptr(dbeta), _ptr(A0), _ptr(B0), _stream())
-            native.check(rc, 'dsgcn_bn_bwd_coef')
+        if want_bn:
+            dgamma, dbeta, A0, B0 = _bn_coef(ctx.bn, gscale, gshift, mean, var, gamma, eps, count, Co, Co)
         if gy is None:
             gy = torch.zeros_like(y)
         dp = torch.empty_like(p)
@@ -1678,14 +1679,19 @@ class _AggSum(torch.autograd.Function):
         if dgamma is not None:
             dgamma = dgamma if gamma is not None else None
             dbeta = dbeta if has_beta else None
-        return dp, dadj, None, dgamma, dbeta, None, None, None
+        return dp, dadj, None, dgamma, dbeta, None, None, None, None
 
 
 def aggregate_sum(p, adj, K, gamma=None, beta=None, eps=1e-5, want_bn=False, per_sample=False):
     """y[n,c,t,w] = sum_k sum_u p[n,k*Co+c,t,u] * adj_k[u,w]; adj (K,V,V) shared (ST-GCN unit_gcn) or (n,K*Co,V,V)
     per sample and channel (CTR-GCN), or — per_sample — (n,K,V,V) per sample shared by the channels (AAGCN), plus the
     train-mode BN of y as a deferred affine.  -> (y, scale, shift, mean, var)"""
-    return _AggSum.apply(p, adj, int(K), gamma, beta, float(eps), bool(want_bn), bool(per_sample))
+    bn = BNCtx() if want_bn else None
+    out = _AggSum.apply(p, adj, int(K), gamma, beta, float(eps), bool(want_bn), bool(per_sample), bn)
+    if want_bn:
+        n, KC, T, V = p.shape
+        _bn_attach(out[1], bn, out[3], out[4], gamma, eps, float(n * T * V), KC // int(K))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1780,7 +1786,9 @@ def gate(y, g, mode, rmode):
 # ---------------------------------------------------------------------------------------------
 
 class _TanhDiff(torch.autograd.Function):
-    """proj (n, 2*K*R, V) -> d (K, n, R, V, V) = tanh(x1[..., u] - x2[..., v])."""
+    """proj (n, 2*K*R, V) -> K tensors d_k (n, R, V, V) = tanh(x1_k[..., u] - x2_k[..., v]) (slices of one buffer).  One
+    output per subset: their gradients arrive one by one and go to the kernel as they are — indexing a stacked output made
+    autograd build the stacked gradient with a fill, a copy and an add per subset (nine launches per CTR-GCN block)."""
 
     @staticmethod
     def forward(ctx, proj, K, R):
@@ -1791,16 +1799,19 @@ class _TanhDiff(torch.autograd.Function):
         native.check(native.lib().dsgcn_tanhdiff_fwd(_ptr(proj), _ptr(d), n, K, R, V, _stream()), 'dsgcn_tanhdiff_fwd')
         ctx.save_for_backward(d)
         ctx.dims = (n, K, R, V)
-        return d
+        ctx.set_materialize_grads(False)
+        return tuple(d[k] for k in range(K))
 
     @staticmethod
-    def backward(ctx, dd):
+    def backward(ctx, *dds):
         d, = ctx.saved_tensors
         n, K, R, V = ctx.dims
-        dd = _f32c(dd)
+        if all(g is None for g in dds):
+            return None, None, None
+        dds = [_f32c(g) for g in dds]
         dproj = torch.empty((n, 2 * K * R, V), device=d.device, dtype=torch.float32)
-        native.check(native.lib().dsgcn_tanhdiff_bwd(_ptr(d), _ptr(dd), _ptr(dproj), n, K, R, V, _stream()),
-                     'dsgcn_tanhdiff_bwd')
+        native.check(native.lib().dsgcn_tanhdiff_bwd_k(_ptr(d), _ptr_array(dds), _ptr(dproj), n, K, R, V, _stream()),
+                     'dsgcn_tanhdiff_bwd_k')
         return dproj, None, None
 
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     'dsgcn_aggsum_bwd': [c_f, c_f] + [ctypes.c_long] * 3 + [c_f] * 6 + [ctypes.c_long] * 3 + [c_int] * 5 + [c_st],
     'dsgcn_tanhdiff_fwd': [c_f, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_tanhdiff_bwd': [c_f, c_f, c_f] + [c_int] * 4 + [c_st],
+    'dsgcn_tanhdiff_bwd_k': [c_f, ctypes.c_void_p, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_ctr_affine_fwd': [ctypes.c_void_p, c_f, c_int, c_f, c_f, c_f, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_ctr_affine_bwd': [ctypes.c_void_p, c_f, c_int, c_f, ctypes.c_void_p, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_edge_select_fwd': [c_f, c_i, c_f] + [c_int] * 4 + [c_st],

@@ -279,6 +279,8 @@ int dsgcn_aggsum_bwd(const float* p, const float* ahat, long a_ns, long a_ks, lo
  * plane_stats: partial (planes, 2) = per-plane [sum, sum of squares] of x (planes, L). */
 int dsgcn_tanhdiff_fwd(const float* proj, float* d, int n, int K, int R, int V, void* stream);
 int dsgcn_tanhdiff_bwd(const float* d, const float* dd, float* dproj, int n, int K, int R, int V, void* stream);
+/* the same with the gradient as K separate tensors (n, R, V, V) (host array of K device pointers, NULL = zero) */
+int dsgcn_tanhdiff_bwd_k(const float* d, const float* const* dd, float* dproj, int n, int K, int R, int V, void* stream);
 int dsgcn_ctr_affine_fwd(const float* const* s, const float* alpha, int alpha_stride, const float* A, const float* beta,
                          const float* G, float* ahat, int n, int K, int Co, int V, void* stream);
 int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, int alpha_stride, const float* dahat,
