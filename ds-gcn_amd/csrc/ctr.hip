@@ -24,20 +24,28 @@ struct CtrPtrs {
 };
 
 // one wave per (k, n, r)
+// Rd = R: d (K, n, R, V, V).  Rd = R + 2 (the augmented form): d (K, n, R + 2, V, V) with two constant channels behind the
+// R difference channels — A[k] and ones — so that alpha * conv4(d) + A[k] is ONE 1x1 conv over R + 2 channels
+// (weights [W | 1 | b], input scale [alpha .. alpha, 1, alpha]): the refinement's affine pass and its backward disappear.
 __global__ __launch_bounds__(64) void k_tanhdiff_fwd(const float* __restrict__ proj, float* __restrict__ d, int n, int K,
-                                                     int R, int V) {
+                                                     int R, int V, int Rd, const float* __restrict__ A) {
   __shared__ float xs[64];
   const int lane = threadIdx.x;
-  const long row = blockIdx.x;                 // (k*n + i)*R + r
-  const int r = (int)(row % R);
-  const long ki = row / R;
+  const long row = blockIdx.x;                 // (k*n + i)*Rd + r
+  const int r = (int)(row % Rd);
+  const long ki = row / Rd;
   const int i = (int)(ki % n), k = (int)(ki / n);
+  float* __restrict__ out = d + (size_t)row * V * V;
+  if (r >= R) {
+    const float* __restrict__ a = A + (size_t)k * V * V;
+    for (int e = lane; e < V * V; e += 64) out[e] = r == R ? a[e] : 1.f;
+    return;
+  }
   const float* __restrict__ p1 = proj + ((size_t)i * 2 * K * R + (size_t)k * R + r) * V;
   const float* __restrict__ p2 = p1 + (size_t)K * R * V;
   if (lane < V) xs[lane] = p1[lane];
   else if (lane >= 32 && lane - 32 < V) xs[lane] = p2[lane - 32];
   wave_lds_sync();
-  float* __restrict__ out = d + (size_t)row * V * V;
   for (int e = lane; e < V * V; e += 64) {
     const int u = e / V, v = e - u * V;
     out[e] = tanhf(xs[u] - xs[32 + v]);
@@ -46,16 +54,25 @@ __global__ __launch_bounds__(64) void k_tanhdiff_fwd(const float* __restrict__ p
 
 // dproj rows: x1 gets sum_v dd*(1-d^2), x2 gets -sum_u dd*(1-d^2)
 // (dd: one gradient tensor (n, R, V, V) per subset, NULL = none reached it)
+// (Rd = R + 2, the augmented form: rows r == R carry the gradient of the A[k] channel = sum_c dAhat of sample i — copied
+// to dAp (n, K, V, V), whose column sum over n is dA)
 __global__ __launch_bounds__(64) void k_tanhdiff_bwd(const float* __restrict__ d, CtrPtrs dd,
-                                                     float* __restrict__ dproj, int n, int K, int R, int V) {
+                                                     float* __restrict__ dproj, int n, int K, int R, int V, int Rd,
+                                                     float* __restrict__ dAp) {
   extern __shared__ float ts[];                // [V*V]
   const int lane = threadIdx.x;
+  const int rows = Rd > R ? R + 1 : R;         // (the ones channel's gradient is not needed)
   const long row = blockIdx.x;
-  const int r = (int)(row % R);
-  const long ki = row / R;
+  const int r = (int)(row % rows);
+  const long ki = row / rows;
   const int i = (int)(ki % n), k = (int)(ki / n);
-  const float* __restrict__ pd = d + (size_t)row * V * V;
-  const float* __restrict__ pg = dd.s[k] ? dd.s[k] + ((size_t)i * R + r) * V * V : nullptr;
+  const float* __restrict__ pd = d + ((size_t)ki * Rd + r) * V * V;
+  const float* __restrict__ pg = dd.s[k] ? dd.s[k] + ((size_t)i * Rd + r) * V * V : nullptr;
+  if (r == R) {
+    float* __restrict__ o = dAp + ((size_t)i * K + k) * V * V;
+    for (int e = lane; e < V * V; e += 64) o[e] = pg ? pg[e] : 0.f;
+    return;
+  }
   for (int e = lane; e < V * V; e += 64) {
     const float t = pd[e];
     ts[e] = pg ? pg[e] * (1.f - t * t) : 0.f;
@@ -201,6 +218,53 @@ __global__ __launch_bounds__(64) void k_plane_stats(const float* __restrict__ x,
   }
 }
 
+// The augmented conv4 operands of a CTR-GCN unit (see k_tanhdiff_fwd): block k builds W'_k (Co, R + 2) = [W_k | 1 | b_k]
+// and its input affine (scale [alpha x R, 1, alpha], shift 0) at sh + k*2*(R+2).
+__global__ __launch_bounds__(256) void k_ctr_wprep(CtrPtrs w, CtrPtrs b, const float* __restrict__ alpha,
+                                                   float* __restrict__ wout, float* __restrict__ sh, int Co, int R) {
+  const int k = blockIdx.x, R2 = R + 2;
+  const float* __restrict__ wk = w.s[k];
+  const float* __restrict__ bk = b.s[k];
+  float* __restrict__ o = wout + (size_t)k * Co * R2;
+  for (int e = threadIdx.x; e < Co * R2; e += 256) {
+    const int c = e / R2, r = e - c * R2;
+    o[e] = r < R ? wk[(size_t)c * R + r] : (r == R ? 1.f : (bk ? bk[c] : 0.f));
+  }
+  const float al = alpha[0];
+  for (int r = threadIdx.x; r < R2; r += 256) {
+    sh[(size_t)k * 2 * R2 + r] = r == R ? 1.f : al;
+    sh[(size_t)k * 2 * R2 + R2 + r] = 0.f;
+  }
+}
+
+// Its backward: dW_k = dW'_k[:, :R], db_k = dW'_k[:, R + 1] (the input scale already put alpha on those columns), and
+// block K: dalpha = sum_k (sum_{r<R} ds_k[r] + ds_k[R + 1]) from the input-scale gradients (fixed order).
+__global__ __launch_bounds__(256) void k_ctr_wfin(CtrPtrs dwp, CtrPtrs dsv, CtrPtrs out, float* __restrict__ dalpha, int K,
+                                                  int Co, int R) {
+  const int R2 = R + 2;
+  if ((int)blockIdx.x == K) {
+    if (threadIdx.x == 0) {
+      float a = 0.f;
+      for (int k = 0; k < K; ++k)
+        if (dsv.s[k]) {
+          for (int r = 0; r < R; ++r) a += dsv.s[k][r];
+          a += dsv.s[k][R + 1];
+        }
+      dalpha[0] = a;
+    }
+    return;
+  }
+  const int k = blockIdx.x;
+  const float* __restrict__ g = dwp.s[k];
+  float* __restrict__ dw = out.ds[k];
+  float* __restrict__ db = out.ds[k] + (size_t)Co * R;
+  for (int e = threadIdx.x; e < Co * R; e += 256) {
+    const int c = e / R, r = e - c * R;
+    dw[e] = g ? g[(size_t)c * R2 + r] : 0.f;
+  }
+  for (int c = threadIdx.x; c < Co; c += 256) db[c] = g ? g[(size_t)c * R2 + R + 1] : 0.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -208,7 +272,60 @@ extern "C" {
 int dsgcn_tanhdiff_fwd(const float* proj, float* d, int n, int K, int R, int V, void* stream) {
   if (!proj || !d || n <= 0 || K <= 0 || R <= 0 || V <= 0 || V > 32) return DSGCN_EINVAL;
   hipLaunchKernelGGL(k_tanhdiff_fwd, dim3((unsigned)((long)K * n * R)), dim3(64), 0, (hipStream_t)stream, proj, d, n, K,
-                     R, V);
+                     R, V, R, (const float*)nullptr);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// d (K, n, R + 2, V, V): the R tanh-difference channels, then A[k] (A (K, V, V)) and a channel of ones.
+int dsgcn_tanhdiff_aug_fwd(const float* proj, const float* A, float* d, int n, int K, int R, int V, void* stream) {
+  if (!proj || !A || !d || n <= 0 || K <= 0 || R <= 0 || V <= 0 || V > 32) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_tanhdiff_fwd, dim3((unsigned)((long)K * n * (R + 2))), dim3(64), 0, (hipStream_t)stream, proj, d, n,
+                     K, R, V, R + 2, A);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// dd: K gradients (n, R + 2, V, V) (NULL = zero); dproj as dsgcn_tanhdiff_bwd; dAp (n, K, V, V) = the A-channel rows.
+int dsgcn_tanhdiff_aug_bwd(const float* d, const float* const* dd, float* dproj, float* dAp, int n, int K, int R, int V,
+                           void* stream) {
+  if (!d || !dd || !dproj || !dAp || n <= 0 || K <= 0 || K > CTR_MAXK || R <= 0 || V <= 0 || V > 32) return DSGCN_EINVAL;
+  CtrPtrs p = {};
+  for (int k = 0; k < K; ++k) p.s[k] = dd[k];
+  hipLaunchKernelGGL(k_tanhdiff_bwd, dim3((unsigned)((long)K * n * (R + 1))), dim3(64), (size_t)V * V * sizeof(float),
+                     (hipStream_t)stream, d, p, dproj, n, K, R, V, R + 2, dAp);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// w / b: K device pointers (Co, R) / (Co) or NULL; wout (K, Co, R + 2); sh (K, 2, R + 2) = per subset [scale; shift].
+int dsgcn_ctr_wprep(const float* const* w, const float* const* b, const float* alpha, float* wout, float* sh, int K,
+                    int Co, int R, void* stream) {
+  if (!w || !b || !alpha || !wout || !sh || K <= 0 || K > CTR_MAXK || Co <= 0 || R <= 0) return DSGCN_EINVAL;
+  CtrPtrs pw = {}, pb = {};
+  for (int k = 0; k < K; ++k) {
+    if (!w[k]) return DSGCN_EINVAL;
+    pw.s[k] = w[k];
+    pb.s[k] = b[k];
+  }
+  hipLaunchKernelGGL(k_ctr_wprep, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, pw, pb, alpha, wout, sh, Co, R);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// dwp: K gradients of W'_k (Co, R + 2) or NULL; ds: K gradients of the input scales (R + 2) or NULL;
+// out: K buffers (Co*R + Co) = [dW_k | db_k]; dalpha (1).
+int dsgcn_ctr_wfin(const float* const* dwp, const float* const* ds, float* const* out, float* dalpha, int K, int Co, int R,
+                   void* stream) {
+  if (!dwp || !ds || !out || !dalpha || K <= 0 || K > CTR_MAXK || Co <= 0 || R <= 0) return DSGCN_EINVAL;
+  CtrPtrs pg = {}, pd = {}, po = {};
+  for (int k = 0; k < K; ++k) {
+    if (!out[k]) return DSGCN_EINVAL;
+    pg.s[k] = dwp[k];
+    pd.s[k] = ds[k];
+    po.ds[k] = out[k];
+  }
+  hipLaunchKernelGGL(k_ctr_wfin, dim3((unsigned)(K + 1)), dim3(256), 0, (hipStream_t)stream, pg, pd, po, dalpha, K, Co, R);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -218,7 +335,7 @@ int dsgcn_tanhdiff_bwd(const float* d, const float* dd, float* dproj, int n, int
   CtrPtrs p = {};
   for (int k = 0; k < K; ++k) p.s[k] = dd + (size_t)k * n * R * V * V;
   hipLaunchKernelGGL(k_tanhdiff_bwd, dim3((unsigned)((long)K * n * R)), dim3(64), (size_t)V * V * sizeof(float),
-                     (hipStream_t)stream, d, p, dproj, n, K, R, V);
+                     (hipStream_t)stream, d, p, dproj, n, K, R, V, R, (float*)nullptr);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -230,7 +347,7 @@ int dsgcn_tanhdiff_bwd_k(const float* d, const float* const* dd, float* dproj, i
   CtrPtrs p = {};
   for (int k = 0; k < K; ++k) p.s[k] = dd[k];
   hipLaunchKernelGGL(k_tanhdiff_bwd, dim3((unsigned)((long)K * n * R)), dim3(64), (size_t)V * V * sizeof(float),
-                     (hipStream_t)stream, d, p, dproj, n, K, R, V);
+                     (hipStream_t)stream, d, p, dproj, n, K, R, V, R, (float*)nullptr);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -616,7 +616,7 @@ class unit_ctrgcn(nn.Module):
         ahat = ops.ctr_topology(
             xbar, cat([c.conv1.weight.flatten(1) for c in cs]), cat([c.conv1.bias for c in cs]),
             cat([c.conv2.weight.flatten(1) for c in cs]), cat([c.conv2.bias for c in cs]),
-            [c.conv4.weight.flatten(1) for c in cs], [c.conv4.bias for c in cs], self.alpha, self.A)
+            [c.conv4.weight.flatten(1) for c in cs], [c.conv4.bias for c in cs], self.alpha, self.A, subset_major=True)
         w3 = cat([c.conv3.weight.flatten(1) for c in cs])
         b3 = cat([c.conv3.bias for c in cs])
         x3 = ops.pwconv(x, None, None, None, False, w3, b3, 1, False)[0]

@@ -377,10 +377,8 @@ def flush_param_sums():
     if not queued:
         return
     _deferred = [] if _deferred is not None else None
-    for level in (0, 1):                              # level 1 = second stages of tall inputs: read what level 0 wrote
-        jobs = [j[:4] for j in queued if j[4] == level]
-        if jobs:
-            _flush_jobs(jobs)
+    for level in sorted({j[4] for j in queued}):      # level 1 = second stages of tall inputs: read what level 0 wrote
+        _flush_jobs([j[:4] for j in queued if j[4] == level])
 
 
 def _flush_jobs(jobs):
@@ -401,9 +399,10 @@ def _flush_jobs(jobs):
     native.check(native.lib().dsgcn_colsum_multi(slot['dev'].data_ptr(), k, blk, _stream()), 'dsgcn_colsum_multi')
 
 
-def param_colsum(t, defer_ok=True):
+def param_colsum(t, defer_ok=True, level=0):
     """colsum(t) for partial rows that feed only parameter gradients: queued inside a deferred_param_sums() region (the
-    result is then filled by flush_param_sums()), immediate otherwise."""
+    result is then filled by flush_param_sums()), immediate otherwise.  level: 1 for an input that is itself the (still
+    unfilled) result of a level-0 call — the flush runs its launches level by level."""
     if _deferred is None or not defer_ok or not t.is_cuda:
         return colsum(t)
     R = t.shape[0]
@@ -413,10 +412,10 @@ def param_colsum(t, defer_ok=True):
     out = torch.empty(C, device=t.device, dtype=torch.float32)
     if g > 1:                                         # tall inputs: the wide first stage in the flush's first launch, the
         mid = torch.empty(g * C, device=t.device, dtype=torch.float32)         # small second one in its second
-        _deferred.append((t, R // g, g * C, mid, 0))
-        _deferred.append((mid, g, C, out, 1))
+        _deferred.append((t, R // g, g * C, mid, level))
+        _deferred.append((mid, g, C, out, level + 1))
     else:
-        _deferred.append((t, R, C, out, 0))
+        _deferred.append((t, R, C, out, level))
     return out.view(shape)
 
 
@@ -663,7 +662,7 @@ class _PwConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, s1, h1, x2, s2, h2, relu, weight, bias, stride, aug, gamma, beta, eps, n_affine, want_bn,
-                bn=None):
+                bn=None, out=None):
         _require_cuda(x1, weight)
         ctx.bn, ctx.bn1, ctx.bn2 = bn, _bn_of(s1), _bn_of(s2)
         x1, s1, h1, x2, s2, h2, bias, gamma, beta = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2, bias, gamma, beta)]
@@ -673,7 +672,13 @@ class _PwConv(torch.autograd.Function):
         assert w2.shape[1] == Ci, (w2.shape, x1.shape)
         Tout = (T + stride - 1) // stride
         dev = x1.device
-        z = torch.empty((n, Co, Tout, V), device=dev, dtype=torch.float32)
+        if out is not None:
+            z = out.t
+            if (tuple(z.shape) != (n, Co, Tout, V) or z.dtype != torch.float32 or not z.is_contiguous() or z.device != dev
+                    or z.requires_grad):
+                raise ValueError(f'pwconv(out=): expected a contiguous fp32 {(n, Co, Tout, V)} slice without history')
+        else:
+            z = torch.empty((n, Co, Tout, V), device=dev, dtype=torch.float32)
         zaug = torch.empty((n, Co, Tout), device=dev, dtype=torch.float32) if aug else None
         lib = native.lib()
         partial = None
@@ -797,11 +802,20 @@ class _PwConv(torch.autograd.Function):
         if dgamma is not None:
             dgamma = dgamma[:n_affine] if gamma is not None else None
             dbeta = dbeta[:n_affine] if has_beta else None
-        return (dx1, ds1, dh1, dx2, ds2, dh2, None, dw, db, None, None, dgamma, dbeta, None, None, None, None)
+        return (dx1, ds1, dh1, dx2, ds2, dh2, None, dw, db, None, None, dgamma, dbeta, None, None, None, None, None)
+
+
+class OutSlot:
+    """A preallocated output (a slice of a larger buffer) for ``pwconv(..., out=OutSlot(t))``: the kernel writes z there
+    instead of a fresh tensor.  A wrapper, not a tensor argument: autograd must not see the buffer as an input."""
+    __slots__ = ('t',)
+
+    def __init__(self, t):
+        self.t = t
 
 
 def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, gamma=None, beta=None, eps=1e-5, n_affine=None,
-           want_bn=False):
+           want_bn=False, out=None):
     """-> (z, zaug, scale, shift, mean, var); scale/shift/mean/var are None unless want_bn."""
     s1, h1 = a1 if a1 is not None else (None, None)
     s2, h2 = a2 if a2 is not None else (None, None)
@@ -809,7 +823,7 @@ def pwconv(x1, a1, x2, a2, relu, weight, bias, stride=1, aug=False, gamma=None, 
         n_affine = weight.shape[0] if gamma is not None else 0
     bn = BNCtx() if want_bn else None
     out = _PwConv.apply(x1, s1, h1, x2, s2, h2, bool(relu), weight, bias, int(stride), bool(aug), gamma, beta,
-                        float(eps), int(n_affine), bool(want_bn), bn)
+                        float(eps), int(n_affine), bool(want_bn), bn, out)
     if want_bn:
         Tout = out[0].shape[2]
         count = float(x1.shape[0] * Tout * (x1.shape[3] + (1 if aug else 0)))
@@ -1622,6 +1636,9 @@ class _AggSum(torch.autograd.Function):
         if per_sample:          # (n, K, V, V): one topology per sample and subset, shared by the channels (AAGCN)
             assert adj.shape == (n, K, V, V), (adj.shape, p.shape)
             astr = (K * V * V, V * V, 0)
+        elif adj.dim() == 5:    # (K, n, Co, V, V): per sample and channel, subset-major (ctr_topology's one-conv form)
+            assert adj.shape == (K, n, Co, V, V), (adj.shape, p.shape)
+            astr = (Co * V * V, n * Co * V * V, V * V)
         else:
             assert adj.shape == ((K, V, V) if shared else (n, KC, V, V)), (adj.shape, p.shape)
             astr = (0, V * V, 0) if shared else (KC * V * V, Co * V * V, V * V)
@@ -1815,6 +1832,101 @@ class _TanhDiff(torch.autograd.Function):
         return dproj, None, None
 
 
+class _TanhDiffAug(torch.autograd.Function):
+    """proj (n, 2*K*R, V), A (K, V, V) -> K tensors (n, R + 2, V, V) = [tanh(x1_k - x2_k) | A[k] | 1]: the operands of the
+    one-conv form of the classic refinement (ctr_topology).  Backward: the first R channels' gradients -> dproj, the A
+    channel's -> dA (its sum over the samples rides in the deferred parameter sums)."""
+
+    @staticmethod
+    def forward(ctx, proj, A, K, R):
+        _require_cuda(proj, A)
+        proj, A = _f32c(proj), _f32c(A)
+        n, _, V = proj.shape
+        d = torch.empty((K, n, R + 2, V, V), device=proj.device, dtype=torch.float32)
+        native.check(native.lib().dsgcn_tanhdiff_aug_fwd(_ptr(proj), _ptr(A), _ptr(d), n, K, R, V, _stream()),
+                     'dsgcn_tanhdiff_aug_fwd')
+        ctx.save_for_backward(d)
+        ctx.dims = (n, K, R, V)
+        ctx.defer_ok = _leafish(A)
+        ctx.set_materialize_grads(False)
+        return tuple(d[k] for k in range(K))
+
+    @staticmethod
+    def backward(ctx, *dds):
+        d, = ctx.saved_tensors
+        n, K, R, V = ctx.dims
+        if all(g is None for g in dds):
+            return None, None, None, None
+        dds = [_f32c(g) for g in dds]
+        dproj = torch.empty((n, 2 * K * R, V), device=d.device, dtype=torch.float32)
+        dAp = torch.empty((n, K * V * V), device=d.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_tanhdiff_aug_bwd(_ptr(d), _ptr_array(dds), _ptr(dproj), _ptr(dAp), n, K, R, V, _stream())
+        native.check(rc, 'dsgcn_tanhdiff_aug_bwd')
+        return dproj, param_colsum(dAp, ctx.defer_ok).view(K, V, V), None, None
+
+
+class _CtrWPrep(torch.autograd.Function):
+    """(alpha (1), W_0 .. W_{K-1} (Co, R), b_0 .. b_{K-1} (Co) | None) -> K augmented weights [W_k | 1 | b_k] (Co, R + 2), K
+    input scales [alpha x R, 1, alpha] and K zero shifts (one launch; one launch back: dW_k, db_k, dalpha)."""
+
+    @staticmethod
+    def forward(ctx, alpha, *wb):
+        K = len(wb) // 2
+        w = [_f32c(t) for t in wb[:K]]
+        b = [_f32c(t) for t in wb[K:]]
+        _require_cuda(alpha, *w)
+        alpha = _f32c(alpha)
+        Co, R = w[0].shape
+        dev = alpha.device
+        wout = torch.empty((K, Co, R + 2), device=dev, dtype=torch.float32)
+        sh = torch.empty((K, 2, R + 2), device=dev, dtype=torch.float32)
+        rc = native.lib().dsgcn_ctr_wprep(_ptr_array(w), _ptr_array(b), _ptr(alpha), _ptr(wout), _ptr(sh), K, Co, R, _stream())
+        native.check(rc, 'dsgcn_ctr_wprep')
+        ctx.dims = (K, Co, R, tuple(t is not None for t in b), alpha.shape)
+        shifts = tuple(sh[k, 1] for k in range(K))
+        ctx.mark_non_differentiable(*shifts)
+        ctx.set_materialize_grads(False)
+        return tuple(wout[k] for k in range(K)) + tuple(sh[k, 0] for k in range(K)) + shifts
+
+    @staticmethod
+    def backward(ctx, *grads):
+        K, Co, R, has_b, ashape = ctx.dims
+        dwp = [_f32c(g) for g in grads[:K]]
+        ds = [_f32c(g) for g in grads[K:2 * K]]
+        live = next((g for g in dwp + ds if g is not None), None)
+        if live is None:
+            return (None,) * (1 + 2 * K)
+        out = torch.empty((K, Co * R + Co), device=live.device, dtype=torch.float32)
+        dalpha = torch.empty(1, device=live.device, dtype=torch.float32)
+        outs = [out[k] for k in range(K)]
+        rc = native.lib().dsgcn_ctr_wfin(_ptr_array(dwp), _ptr_array(ds), _ptr_array(outs), _ptr(dalpha), K, Co, R, _stream())
+        native.check(rc, 'dsgcn_ctr_wfin')
+        return (dalpha.view(ashape), *[o[:Co * R].view(Co, R) for o in outs],
+                *[(o[Co * R:] if hb else None) for o, hb in zip(outs, has_b)])
+
+
+class _JoinSlices(torch.autograd.Function):
+    """K tensors that are the slices buf[0..K-1] of one buffer -> the buffer itself (no copy); the gradient goes back as its
+    K slices.  (pwconv(out=OutSlot(buf[k])) fills such slices.)"""
+
+    @staticmethod
+    def forward(ctx, slot, *parts):
+        buf = slot.t
+        step = buf[0].numel() * buf.element_size()
+        if len(parts) != buf.shape[0] or any(p.data_ptr() != buf.data_ptr() + k * step or p.shape != buf.shape[1:]
+                                              for k, p in enumerate(parts)):
+            raise ValueError('_JoinSlices: the parts are not the slices of the buffer')
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32c(g)
+        return (None, *[g[k] for k in range(g.shape[0])])
+
+
+CTR_ONE_CONV = _os.environ.get('DSGCN_CTR_ONE_CONV', '1') != '0'     # classic refinement: conv4 + affine as one conv (A/B)
+
+
 class _CtrAffine(torch.autograd.Function):
     """Ahat (n, K*Co, V, V) = alpha_k * S_k + A[k] (+ beta_k * G[:, k])  for the K per-subset conv4 outputs S_k
     (n, Co, V, V).  alpha: 1 element (classic CTR-GCN: shared) or K elements (CTRHGC: per subset); G (n, K, V, V) with
@@ -1835,6 +1947,7 @@ class _CtrAffine(torch.autograd.Function):
         native.check(rc, 'dsgcn_ctr_affine_fwd')
         ctx.save_for_backward(alpha, beta, G, *S)
         ctx.astride = astride
+        ctx.defer_ok = _leafish(alpha, A) if G is None else False
         return ahat
 
     @staticmethod
@@ -1848,10 +1961,10 @@ class _CtrAffine(torch.autograd.Function):
         rc = native.lib().dsgcn_ctr_affine_bwd(_ptr_array(S), _ptr(alpha), ctx.astride, _ptr(dahat), _ptr_array(dS),
                                                _ptr(prow), n, K, Co, V, _stream())
         native.check(rc, 'dsgcn_ctr_affine_bwd')
-        red = colsum(prow)
+        red = param_colsum(prow, ctx.defer_ok)          # (A and alpha are parameters: both sums ride in the flush)
         dA = red[:K * V * V].view(K, V, V)
         ds_k = red[K * V * V:]                                      # sum dAhat * S per subset
-        dalpha = ds_k.view_as(alpha) if ctx.astride else colsum(ds_k.reshape(K, 1)).view_as(alpha)
+        dalpha = ds_k.view_as(alpha) if ctx.astride else param_colsum(ds_k.reshape(K, 1), ctx.defer_ok, 1).view_as(alpha)
         dbeta = dG = None
         if G is not None:
             # per-sample sum over channels of dAhat (the 4 channel slices of each sample added): KB-sized host-side algebra
@@ -1888,18 +2001,31 @@ class _EdgeSelect(torch.autograd.Function):
         return din, None, None
 
 
-def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None):
+def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None, subset_major=False):
     """CTR-GCN refined topology.  xbar (n,Ci,V) = mean_T x; w1,w2 (K*R,Ci) / b1,b2 (K*R): conv1/conv2 of the K
     subsets stacked (their mean over T commutes with the 1x1 conv); w4[k] (Co,R), b4[k] (Co); A (K,V,V).
     alpha (1): classic unit_ctrgcn;  alpha (K) [+ beta (K)]: unit_ctrhgcn — per-subset scale and the Gram term
     beta_k * x1_k^T x2_k;  edge = {k: (w_edge (E*R,R), b_edge (E*R), edge_type (V*V) int32)}: subsets whose tanh-difference
     first passes the edge-typed attention conv + select (gcn.py:737-745).
-    -> Ahat (n, K*Co, V, V) = alpha_k * conv4_k(sel_k(tanh(x1_k[u] - x2_k[v]))) + A[k] (+ beta_k G_k)."""
+    -> Ahat (n, K*Co, V, V) = alpha_k * conv4_k(sel_k(tanh(x1_k[u] - x2_k[v]))) + A[k] (+ beta_k G_k).
+    subset_major: the caller also takes Ahat as (K, n, Co, V, V) (``aggregate_sum`` does, by strides); the classic unit
+    then comes through the one-conv form below and in that layout."""
     n, Ci, V = xbar.shape
     K = A.shape[0]
     R = w1.shape[0] // K
     proj = pwconv(xbar.unsqueeze(2), None, None, None, False, cat_rows([w1, w2]), cat_rows([b1, b2]), 1,
                   False)[0].view(n, 2 * K * R, V)
+    if subset_major and CTR_ONE_CONV and beta is None and not edge and alpha.numel() == 1 and K <= 4:
+        # classic unit: Ahat_k = alpha * conv4_k(d_k) + A[k] as ONE conv per subset over [d_k | A[k] | 1] (include/dsgcn.h,
+        # dsgcn_tanhdiff_aug_fwd) writing straight into its slice of Ahat (K, n, Co, V, V) — the layout aggregate_sum
+        # takes by strides
+        d = _TanhDiffAug.apply(proj, A, K, R)
+        prep = _CtrWPrep.apply(alpha, *w4, *b4)
+        Co = w4[0].shape[0]
+        buf = torch.empty((K, n, Co, V, V), device=xbar.device, dtype=torch.float32)
+        parts = [pwconv(d[k], (prep[K + k], prep[2 * K + k]), None, None, False, prep[k], None, 1, False,
+                        out=OutSlot(buf[k]))[0] for k in range(K)]
+        return _JoinSlices.apply(OutSlot(buf), *parts)
     d = _TanhDiff.apply(proj, K, R)
     S = []
     for k in range(K):

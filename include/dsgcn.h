@@ -281,6 +281,26 @@ int dsgcn_tanhdiff_fwd(const float* proj, float* d, int n, int K, int R, int V, 
 int dsgcn_tanhdiff_bwd(const float* d, const float* dd, float* dproj, int n, int K, int R, int V, void* stream);
 /* the same with the gradient as K separate tensors (n, R, V, V) (host array of K device pointers, NULL = zero) */
 int dsgcn_tanhdiff_bwd_k(const float* d, const float* const* dd, float* dproj, int n, int K, int R, int V, void* stream);
+/* Classic CTR-GCN refinement as ONE conv per subset (round 5).  Ahat_k = alpha * conv4_k(d_k) + A[k] (ctrgcn's unit:
+ * pyskl/models/gcns/utils/gcn.py unit_ctrgcn, `x1 = conv4(tanh(x1 - x2)) * alpha + A[i]`) equals a 1x1 conv over R + 2
+ * channels [d_k | A[k] | 1] with weights [W_k | 1 | b_k] and the per-channel input scale [alpha .. alpha, 1, alpha]: the
+ * separate affine pass over the (n, K*Co, V, V) tensor, its backward and their intermediate tensors are gone, and the
+ * gradients of alpha (from the input-scale sums), A (the A channel's data gradient), W and b (columns of the weight
+ * gradient) fall out of the conv's own backward.
+ *   dsgcn_tanhdiff_aug_fwd: d (K, n, R + 2, V, V) = [tanh(x1 - x2) | A[k] | 1].
+ *   dsgcn_tanhdiff_aug_bwd: dd = K gradients (n, R + 2, V, V) (host array, NULL = zero) -> dproj as dsgcn_tanhdiff_bwd and
+ *     dAp (n, K, V, V) = the A-channel rows (their column sum over n is dA).
+ *   dsgcn_ctr_wprep: w / b = K device pointers (Co, R) / (Co) (b[k] may be NULL) -> wout (K, Co, R + 2), sh (K, 2, R + 2) =
+ *     per subset [input scale; input shift = 0].
+ *   dsgcn_ctr_wfin: dwp = K gradients of wout[k] (NULL = zero), ds = K gradients of the input scales (NULL = zero) ->
+ *     out[k] (Co*R + Co) = [dW_k | db_k], dalpha (1). */
+int dsgcn_tanhdiff_aug_fwd(const float* proj, const float* A, float* d, int n, int K, int R, int V, void* stream);
+int dsgcn_tanhdiff_aug_bwd(const float* d, const float* const* dd, float* dproj, float* dAp, int n, int K, int R, int V,
+                           void* stream);
+int dsgcn_ctr_wprep(const float* const* w, const float* const* b, const float* alpha, float* wout, float* sh, int K,
+                    int Co, int R, void* stream);
+int dsgcn_ctr_wfin(const float* const* dwp, const float* const* ds, float* const* out, float* dalpha, int K, int Co, int R,
+                   void* stream);
 int dsgcn_ctr_affine_fwd(const float* const* s, const float* alpha, int alpha_stride, const float* A, const float* beta,
                          const float* G, float* ahat, int n, int K, int Co, int V, void* stream);
 int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, int alpha_stride, const float* dahat,

@@ -638,8 +638,35 @@ def test_aggregate_sum(n, K, Co, T, V, shared, bn):
         assert rel(got[k].detach().cpu(), v.detach()) < 1e-5, (k, rel(got[k].detach().cpu(), v.detach()))
 
 
+@pytest.mark.parametrize('n,K,Co,T,V', [(2, 3, 16, 64, 25), (3, 3, 32, 32, 25), (2, 3, 8, 130, 17), (128, 3, 64, 64, 25),
+                                        (128, 3, 256, 16, 25)])
+def test_aggregate_sum_subset_major_adjacency(n, K, Co, T, V):
+    """The per-sample, per-channel adjacency handed over as (K, n, Co, V, V) (what ctr_topology's one-conv form writes): the
+    same launches with other strides — bit-identical to the (n, K*Co, V, V) call on the permuted tensor, gradient included."""
+    g = torch.Generator().manual_seed(Co + T)
+    p = _rand(g, n, K * Co, T, V).to(DEV)
+    adj = _rand(g, n, K * Co, V, V, scale=0.3).to(DEV)
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).to(DEV), _rand(g, Co, scale=0.2).to(DEV)
+    gy = _rand(g, n, Co, T, V).to(DEV)
+
+    def run(major):
+        tp = p.clone().requires_grad_()
+        ta = (adj.view(n, K, Co, V, V).permute(1, 0, 2, 3, 4).contiguous() if major else adj.clone()).requires_grad_()
+        y, sc, sh, mean, var = K_.aggregate_sum(tp, ta, K, gamma, beta, 1e-5, True)
+        ((y * gy).sum() + sc.sum() + (sh * sh).sum()).backward()
+        da = ta.grad.permute(1, 0, 2, 3, 4).reshape(n, K * Co, V, V) if major else ta.grad
+        return dict(y=y, sc=sc, sh=sh, dp=tp.grad, dadj=da)
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize('n,Ci,Co,V', [(2, 3, 64, 25), (2, 64, 64, 25), (3, 128, 256, 25), (2, 256, 256, 17)])
-def test_ctr_topology(n, Ci, Co, V):
+@pytest.mark.parametrize('subset_major', [False, True])
+def test_ctr_topology(n, Ci, Co, V, subset_major):
+    """subset_major: Ahat as (K, n, Co, V, V) through the one-conv form of the classic refinement (conv4 + alpha + A as one
+    1x1 conv over [d | A[k] | 1]); the plain call keeps the (n, K*Co, V, V) contract and the separate affine pass."""
     g = torch.Generator().manual_seed(Ci + Co)
     K = 3
     Rr = 8 if Ci <= 16 else Ci // 8
@@ -654,7 +681,13 @@ def test_ctr_topology(n, Ci, Co, V):
         tt = {k: v.to(dev, dt).requires_grad_() for k, v in t.items()}
         tw4 = [w.to(dev, dt).requires_grad_() for w in w4]
         tb4 = [b.to(dev, dt).requires_grad_() for b in b4]
-        ah = mod.ctr_topology(tt['xbar'], tt['w1'], tt['b1'], tt['w2'], tt['b2'], tw4, tb4, tt['alpha'], tt['A'])
+        ah = mod.ctr_topology(tt['xbar'], tt['w1'], tt['b1'], tt['w2'], tt['b2'], tw4, tb4, tt['alpha'], tt['A'],
+                              subset_major=subset_major)
+        if ah.dim() == 5:
+            assert mod is K_ and ah.shape == (K, n, Co, V, V)
+            ah = ah.permute(1, 0, 2, 3, 4).reshape(n, K * Co, V, V)
+        else:
+            assert not (mod is K_ and subset_major)
         ah.backward(gah.to(dev, dt))
         res = {'ahat': ah}
         res.update({'d' + k: v.grad for k, v in tt.items()})

@@ -106,7 +106,7 @@ def gate(y, g, mode, rmode):
     return out, r
 
 
-def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None):
+def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None, subset_major=False):
     """CTR-GCN refined topology (gcn.py:651-657) and its CTRHGC form (gcn.py:719-760: per-subset alpha, edge-typed
     attention on chosen subsets, Gram term scaled by beta): -> Ahat (n, K*Co, V, V)."""
     n, Ci, V = xbar.shape
