@@ -346,7 +346,7 @@ def step_algorithmic_elements(plan=DS_PLAN, v=V):
 
     def add(k, e):
         rows[k] = rows.get(k, 0) + e
-    for ci, co, t, s in plan:
+    for i, (ci, co, t, s) in enumerate(plan):
         mid, L = co // 8, t * v
         Lo = L // s
         add('z_pre', 3 * mid * L)              # pre conv out, BN + ReLU applied by K-A while loading
@@ -360,7 +360,8 @@ def step_algorithmic_elements(plan=DS_PLAN, v=V):
         add('z_transform', co * Lo)            # transform conv out (BN applied by fuse_out)
         if s != 1:
             add('z_res', co * Lo)              # the block residual's strided 1x1 conv + BN
-        add('out', co * Lo)                    # block output
+        if i + 1 < len(plan):
+            add('out', co * Lo)                # block output (the last block's is only ever pooled: its plane means suffice)
     return rows
 
 
