@@ -228,6 +228,9 @@ class _SkeletonBackbone(nn.Module):
     def _normalize_input(self, x):
         # 2.4 MB/step of host-side PyTorch plumbing (reference: dgstgcn.py:158-164)
         N, M, T, V, C = x.size()
+        ops = kernels.ops()
+        if self.data_bn_type in ('MVC', 'VC') and ops.data_bn_eligible(x, self.data_bn):
+            return ops.data_bn(x, self.data_bn, self.data_bn_type)         # two launches, no permute copies
         x = x.permute(0, 1, 3, 4, 2).contiguous()
         if self.data_bn_type == 'MVC':
             x = self.data_bn(x.view(N, M * V * C, T))

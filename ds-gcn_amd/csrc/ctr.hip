@@ -226,14 +226,17 @@ __global__ __launch_bounds__(256) void k_ctr_wprep(CtrPtrs w, CtrPtrs b, const f
   const float* __restrict__ wk = w.s[k];
   const float* __restrict__ bk = b.s[k];
   float* __restrict__ o = wout + (size_t)k * Co * R2;
-  for (int e = threadIdx.x; e < Co * R2; e += 256) {
+  const int e = blockIdx.y * 256 + threadIdx.x;                    // (grid.y covers Co * (R + 2): one element per thread)
+  if (e < Co * R2) {
     const int c = e / R2, r = e - c * R2;
     o[e] = r < R ? wk[(size_t)c * R + r] : (r == R ? 1.f : (bk ? bk[c] : 0.f));
   }
-  const float al = alpha[0];
-  for (int r = threadIdx.x; r < R2; r += 256) {
-    sh[(size_t)k * 2 * R2 + r] = r == R ? 1.f : al;
-    sh[(size_t)k * 2 * R2 + R2 + r] = 0.f;
+  if (blockIdx.y == 0) {
+    const float al = alpha[0];
+    for (int r = threadIdx.x; r < R2; r += 256) {
+      sh[(size_t)k * 2 * R2 + r] = r == R ? 1.f : al;
+      sh[(size_t)k * 2 * R2 + R2 + r] = 0.f;
+    }
   }
 }
 
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void k_ctr_wfin(CtrPtrs dwp, CtrPtrs dsv, CtrP
                                                   int Co, int R) {
   const int R2 = R + 2;
   if ((int)blockIdx.x == K) {
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
       float a = 0.f;
       for (int k = 0; k < K; ++k)
         if (dsv.s[k]) {
@@ -258,11 +261,12 @@ __global__ __launch_bounds__(256) void k_ctr_wfin(CtrPtrs dwp, CtrPtrs dsv, CtrP
   const float* __restrict__ g = dwp.s[k];
   float* __restrict__ dw = out.ds[k];
   float* __restrict__ db = out.ds[k] + (size_t)Co * R;
-  for (int e = threadIdx.x; e < Co * R; e += 256) {
+  const int e = blockIdx.y * 256 + threadIdx.x;                    // (grid.y covers Co * R)
+  if (e < Co * R) {
     const int c = e / R, r = e - c * R;
     dw[e] = g ? g[(size_t)c * R2 + r] : 0.f;
   }
-  for (int c = threadIdx.x; c < Co; c += 256) db[c] = g ? g[(size_t)c * R2 + R + 1] : 0.f;
+  if (e < Co) db[e] = g ? g[(size_t)e * R2 + R + 1] : 0.f;
 }
 
 }  // namespace
@@ -308,7 +312,8 @@ int dsgcn_ctr_wprep(const float* const* w, const float* const* b, const float* a
     pw.s[k] = w[k];
     pb.s[k] = b[k];
   }
-  hipLaunchKernelGGL(k_ctr_wprep, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, pw, pb, alpha, wout, sh, Co, R);
+  hipLaunchKernelGGL(k_ctr_wprep, dim3((unsigned)K, (unsigned)((Co * (R + 2) + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, pw, pb, alpha, wout, sh, Co, R);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -325,7 +330,8 @@ int dsgcn_ctr_wfin(const float* const* dwp, const float* const* ds, float* const
     pd.s[k] = ds[k];
     po.ds[k] = out[k];
   }
-  hipLaunchKernelGGL(k_ctr_wfin, dim3((unsigned)(K + 1)), dim3(256), 0, (hipStream_t)stream, pg, pd, po, dalpha, K, Co, R);
+  hipLaunchKernelGGL(k_ctr_wfin, dim3((unsigned)(K + 1), (unsigned)((Co * R + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, pg, pd, po, dalpha, K, Co, R);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -313,3 +313,232 @@ int dsgcn_bn_running_multi(float* const* running_mean, float* const* running_var
 }
 
 }  // extern "C"
+
+// ---- the input BatchNorm (data_bn) ---------------------------------------------------------------------------------
+// pyskl/models/gcns/dgstgcn.py:158-164 (stgcn.py:132-139, ctrgcn.py:112-118, aagcn.py:128-135): the clip (N, M, T, V, C) is
+// permuted to (N*M, V*C, T) ['VC'] or (N, M*V*C, T) ['MVC'], normalised by a BatchNorm1d over its V*C resp. M*V*C channels
+// and permuted to (N*M, C, T, V).  There: a permute copy, the BatchNorm (+ its buffer updates), a permute copy; the same
+// again backwards.  Here: per-sample channel sums (k_dbn_stats), then ONE launch that finishes the statistics (every
+// workgroup for itself: the table is NM x VC x 2 floats), updates the buffers and writes the normalised clip straight in
+// the (N*M, C, T, V) layout through an LDS transpose (k_dbn_apply); backward: one launch of per-sample partial sums of
+// dgamma / dbeta (the clip itself needs no gradient).
+namespace {
+
+constexpr int DB_NT = 256;
+
+struct DbnArgs {
+  const float* x;          // (NM, T, VC)
+  double* psum;            // (NM, VC)   fp64: the variance below is E[x^2] - mean^2, which cancels in fp32 when the clip's
+  double* psq;             // (NM, VC)   mean is large against its spread (raw pixel coordinates)
+  int NM, M, T, V, C, mvc;
+};
+
+// thread (slot, col): col = tid % VC, rows slot, slot + slots, ...  (threads beyond slots * VC idle)
+__global__ __launch_bounds__(DB_NT) void k_dbn_stats(DbnArgs a) {
+  __shared__ double red[2 * DB_NT];
+  const int VC = a.V * a.C, slots = DB_NT / VC, tid = threadIdx.x;
+  const int slot = tid / VC, col = tid - slot * VC;
+  const int nm = blockIdx.x;
+  double s = 0., q = 0.;
+  if (slot < slots) {
+    const float* __restrict__ p = a.x + (size_t)nm * a.T * VC + col;
+#pragma unroll 8
+    for (int t = slot; t < a.T; t += slots) {
+      const double v = (double)p[(size_t)t * VC];
+      s += v;
+      q = fma(v, v, q);
+    }
+  }
+  red[tid] = s;
+  red[DB_NT + tid] = q;
+  __syncthreads();
+  if (tid < VC) {
+    double ts = 0., tq = 0.;
+    for (int j = 0; j < slots; ++j) { ts += red[j * VC + tid]; tq += red[DB_NT + j * VC + tid]; }
+    a.psum[(size_t)nm * VC + tid] = ts;
+    a.psq[(size_t)nm * VC + tid] = tq;
+  }
+}
+
+struct DbnApply {
+  const float* x;
+  const double* psum;
+  const double* psq;
+  const float* gamma;      // (Ch) or NULL
+  const float* beta;       // (Ch) or NULL
+  float* rmean;            // running buffers (Ch) or NULL
+  float* rvar;
+  long long* nbt;          // or NULL
+  float* y;                // (NM, C, T, V)
+  float* save_mean;        // (Ch)   (training: batch statistics for the backward)
+  float* save_invstd;      // (Ch)
+  int NM, M, T, V, C, mvc, training;
+  float eps, momentum;
+};
+
+__global__ __launch_bounds__(DB_NT) void k_dbn_apply(DbnApply a) {
+  extern __shared__ float tile[];                 // [T][VC] normalised values
+  __shared__ double dred[2 * DB_NT];
+  __shared__ float sc[DB_NT], sf[DB_NT];
+  const int VC = a.V * a.C, slots = DB_NT / VC, tid = threadIdx.x;
+  const int slot = tid / VC, col = tid - slot * VC;
+  const int nm = blockIdx.x, m = nm % a.M;
+  const int ch = a.mvc ? m * VC + col : col;      // BatchNorm channel of this thread's column
+  // 1. statistics of this sample's channels
+  if (a.training) {
+    double s = 0., q = 0.;
+    if (slot < slots) {
+      // 'VC': every sample contributes; 'MVC': the samples of person m
+      const int first = a.mvc ? m : 0, step = a.mvc ? a.M : 1;
+#pragma unroll 8
+      for (int r = first + slot * step; r < a.NM; r += slots * step) {
+        s += a.psum[(size_t)r * VC + col];
+        q += a.psq[(size_t)r * VC + col];
+      }
+    }
+    dred[tid] = s;
+    dred[DB_NT + tid] = q;
+    __syncthreads();
+    if (tid < VC) {
+      double ts = 0., tq = 0.;
+      for (int j = 0; j < slots; ++j) { ts += dred[j * VC + tid]; tq += dred[DB_NT + j * VC + tid]; }
+      const double cnt = (double)(a.mvc ? a.NM / a.M : a.NM) * a.T;
+      const double mean = ts / cnt;
+      double var = tq / cnt - mean * mean;
+      var = var > 0. ? var : 0.;
+      const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+      const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
+      sc[tid] = g * invstd;
+      sf[tid] = (float)((double)b - mean * (double)(g * invstd));
+      // one workgroup per BatchNorm channel set keeps the books: sample m ('MVC') / sample 0 ('VC')
+      if (nm == (a.mvc ? m : 0)) {
+        a.save_mean[ch] = (float)mean;
+        a.save_invstd[ch] = invstd;
+        if (a.rmean) {
+          const double unb = cnt > 1. ? var * cnt / (cnt - 1.) : var;
+          a.rmean[ch] = a.rmean[ch] * (1.f - a.momentum) + a.momentum * (float)mean;
+          a.rvar[ch] = a.rvar[ch] * (1.f - a.momentum) + a.momentum * (float)unb;
+        }
+      }
+    }
+    if (nm == 0 && tid == 0 && a.nbt) a.nbt[0] += 1;
+  } else if (tid < VC) {
+    const float invstd = rsqrtf(a.rvar[ch] + a.eps);
+    const float g = a.gamma ? a.gamma[ch] : 1.f, b = a.beta ? a.beta[ch] : 0.f;
+    sc[tid] = g * invstd;
+    sf[tid] = b - a.rmean[ch] * g * invstd;
+  }
+  __syncthreads();
+  // 2. normalise into LDS as [t][v*C + c] ...
+  const int TV = a.T * VC;
+  const float* __restrict__ px = a.x + (size_t)nm * TV;
+  const int NA = slots * VC;                      // active threads: a thread keeps its column
+  if (tid < NA) {
+    const float s_ = sc[col], f_ = sf[col];
+#pragma unroll 8
+    for (int e = tid; e < TV; e += NA) tile[e] = fmaf(px[e], s_, f_);
+  }
+  __syncthreads();
+  // 3. ... and out as (C, T, V): consecutive threads write consecutive addresses
+  float* __restrict__ py = a.y + (size_t)nm * TV;
+  const int TVv = a.T * a.V;
+#pragma unroll 4
+  for (int o = tid; o < TV; o += DB_NT) {
+    const int c = o / TVv, r = o - c * TVv;       // r = t*V + v
+    py[o] = tile[r * a.C + c];
+  }
+}
+
+struct DbnBwd {
+  const float* x;          // (NM, T, VC)
+  const float* dy;         // (NM, C, T, V)
+  const float* mean;       // (Ch)
+  const float* invstd;     // (Ch)
+  float* pg;               // (NM, VC) partial sums of dy * xhat
+  float* pb;               // (NM, VC) partial sums of dy
+  int NM, M, T, V, C, mvc;
+};
+
+__global__ __launch_bounds__(DB_NT) void k_dbn_bwd(DbnBwd a) {
+  extern __shared__ float tile[];                 // dy as [t][v*C + c]
+  __shared__ float red[2 * DB_NT];
+  const int VC = a.V * a.C, slots = DB_NT / VC, tid = threadIdx.x;
+  const int slot = tid / VC, col = tid - slot * VC;
+  const int nm = blockIdx.x, m = nm % a.M;
+  const int TV = a.T * VC, TVv = a.T * a.V;
+  const float* __restrict__ pd = a.dy + (size_t)nm * TV;
+#pragma unroll 4
+  for (int o = tid; o < TV; o += DB_NT) {
+    const int c = o / TVv, r = o - c * TVv;
+    tile[r * a.C + c] = pd[o];
+  }
+  __syncthreads();
+  float g = 0.f, b = 0.f;
+  if (slot < slots) {
+    const int ch = a.mvc ? m * VC + col : col;
+    const float mu = a.mean[ch], is = a.invstd[ch];
+    const float* __restrict__ px = a.x + (size_t)nm * TV + col;
+#pragma unroll 8
+    for (int t = slot; t < a.T; t += slots) {
+      const float d = tile[t * VC + col];
+      g = fmaf(d, (px[(size_t)t * VC] - mu) * is, g);
+      b += d;
+    }
+  }
+  red[tid] = g;
+  red[DB_NT + tid] = b;
+  __syncthreads();
+  if (tid < VC) {
+    float tg = 0.f, tb = 0.f;
+    for (int j = 0; j < slots; ++j) { tg += red[j * VC + tid]; tb += red[DB_NT + j * VC + tid]; }
+    a.pg[(size_t)nm * VC + tid] = tg;
+    a.pb[(size_t)nm * VC + tid] = tb;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// x (N, M, T, V, C) -> y (N*M, C, T, V).  mvc: 0 = 'VC' (V*C channels, statistics over N*M samples and T), 1 = 'MVC'
+// (M*V*C channels, over N and T).  training: batch statistics (saved to save_mean / save_invstd; running_mean /
+// running_var / num_batches_tracked updated with `momentum` when given), else the running statistics.
+// scratch: 4 * N*M * V*C floats (two fp64 tables), 8-byte aligned.  Two launches (training) / one (eval).
+int dsgcn_data_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      long long* num_batches_tracked, float* y, float* save_mean, float* save_invstd, float* scratch,
+                      int N, int M, int T, int V, int C, int mvc, int training, float eps, float momentum,
+                      void* stream) {
+  if (!x || !y || N <= 0 || M <= 0 || T <= 0 || V <= 0 || C <= 0) return DSGCN_EINVAL;
+  if (training ? (!save_mean || !save_invstd || !scratch) : (!running_mean || !running_var)) return DSGCN_EINVAL;
+  const int VC = V * C, NM = N * M;
+  if (VC > DB_NT || (size_t)T * VC * sizeof(float) > 60 * 1024) return DSGCN_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  double* tab = reinterpret_cast<double*>(scratch);
+  if (training) {
+    if ((uintptr_t)scratch & 7) return DSGCN_EINVAL;
+    DbnArgs s = {x, tab, tab + (size_t)NM * VC, NM, M, T, V, C, mvc};
+    hipLaunchKernelGGL(k_dbn_stats, dim3((unsigned)NM), dim3(DB_NT), 0, st, s);
+    DSGCN_LAUNCH_CHECK();
+  }
+  DbnApply a = {x, tab, tab ? tab + (size_t)NM * VC : nullptr, gamma, beta, running_mean, running_var,
+                num_batches_tracked, y, save_mean, save_invstd, NM, M, T, V, C, mvc, training, eps, momentum};
+  hipLaunchKernelGGL(k_dbn_apply, dim3((unsigned)NM), dim3(DB_NT), (size_t)T * VC * sizeof(float), st, a);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// pg / pb (N*M, V*C): per-sample partial sums of dgamma / dbeta; their column sum over the samples ('VC': all N*M rows;
+// 'MVC': view them as (N, M*V*C)) finishes them.  The clip needs no gradient.  One launch.
+int dsgcn_data_bn_bwd(const float* x, const float* dy, const float* save_mean, const float* save_invstd, float* pg,
+                      float* pb, int N, int M, int T, int V, int C, int mvc, void* stream) {
+  if (!x || !dy || !save_mean || !save_invstd || !pg || !pb || N <= 0 || M <= 0 || T <= 0 || V <= 0 || C <= 0)
+    return DSGCN_EINVAL;
+  const int VC = V * C;
+  if (VC > DB_NT || (size_t)T * VC * sizeof(float) > 60 * 1024) return DSGCN_EUNSUPPORTED;
+  DbnBwd a = {x, dy, save_mean, save_invstd, pg, pb, N * M, M, T, V, C, mvc};
+  hipLaunchKernelGGL(k_dbn_bwd, dim3((unsigned)(N * M)), dim3(DB_NT), (size_t)T * VC * sizeof(float), (hipStream_t)stream, a);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

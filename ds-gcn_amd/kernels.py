@@ -2317,3 +2317,63 @@ def bn_running_update(items):
         (_c.c_float * k)(*[c / max(c - 1.0, 1.0) for _, _, _, c in items]),
         (_c.c_float * k)(*[float(bn.momentum) for bn, _, _, _ in items]), k, _stream())
     native.check(rc, 'dsgcn_bn_running_multi')
+
+
+class _DataBN(torch.autograd.Function):
+    """x (N, M, T, V, C) (no gradient), gamma, beta -> BatchNorm1d over the (v, c) / (m, v, c) channels, as (N*M, C, T, V)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, mvc, training):
+        _require_cuda(x)
+        x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
+        N, M, T, V, C = x.shape
+        Ch = (M if mvc else 1) * V * C
+        dev = x.device
+        y = torch.empty((N * M, C, T, V), device=dev, dtype=torch.float32)
+        track = bn.track_running_stats and bn.running_mean is not None
+        save = torch.empty((2, Ch), device=dev, dtype=torch.float32) if training else None
+        scratch = torch.empty(2 * N * M * V * C, device=dev, dtype=torch.float64) if training else None
+        upd = training and track
+        rc = native.lib().dsgcn_data_bn_fwd(
+            _ptr(x), _ptr(gamma), _ptr(beta), _ptr(bn.running_mean) if (upd or not training) else None,
+            _ptr(bn.running_var) if (upd or not training) else None, _ptr(bn.num_batches_tracked) if upd else None, _ptr(y),
+            _ptr(save[0]) if training else None, _ptr(save[1]) if training else None, _ptr(scratch), N, M, T, V, C, int(mvc),
+            int(training), float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.0), _stream())
+        native.check(rc, 'dsgcn_data_bn_fwd')
+        ctx.save_for_backward(x, save)
+        ctx.cfg = (int(mvc), bool(training), gamma is not None, beta is not None)
+        ctx.defer_ok = _leafish(gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, save = ctx.saved_tensors
+        mvc, training, has_g, has_b = ctx.cfg
+        if not training:
+            raise NotImplementedError('data_bn: backward through the eval-mode BatchNorm is not on this path')
+        N, M, T, V, C = x.shape
+        dy = _f32c(dy)
+        part = torch.empty((2, N * M, V * C), device=x.device, dtype=torch.float32)
+        rc = native.lib().dsgcn_data_bn_bwd(_ptr(x), _ptr(dy), _ptr(save[0]), _ptr(save[1]), _ptr(part[0]), _ptr(part[1]), N,
+                                            M, T, V, C, mvc, _stream())
+        native.check(rc, 'dsgcn_data_bn_bwd')
+        rows = (N, M * V * C) if mvc else (N * M, V * C)
+        dg = param_colsum(part[0].view(rows), ctx.defer_ok) if has_g else None
+        db = param_colsum(part[1].view(rows), ctx.defer_ok) if has_b else None
+        return None, dg, db, None, None, None
+
+
+def data_bn_eligible(x, bn):
+    """Can the input BatchNorm take the two-launch form?  (fp32 CUDA clip that needs no gradient, momentum-form buffers,
+    V*C <= 256 channels per person, a (T, V*C) tile that fits LDS)"""
+    return (FUSED_ENDS and isinstance(bn, torch.nn.BatchNorm1d) and x.is_cuda and x.dtype == torch.float32
+            and not x.requires_grad and x.dim() == 5 and x.shape[3] * x.shape[4] <= 256
+            and x.shape[2] * x.shape[3] * x.shape[4] * 4 <= 60 * 1024
+            and (bn.momentum is not None or not bn.training or not bn.track_running_stats)
+            and (bn.training or bn.running_mean is not None))
+
+
+def data_bn(x, bn, bn_type):
+    """x (N, M, T, V, C) -> (N*M, C, T, V): the backbones' input BatchNorm1d ('VC' | 'MVC') without the permute copies."""
+    training = bn.training or not bn.track_running_stats or bn.running_mean is None
+    return _DataBN.apply(x, bn.weight, bn.bias, bn, bn_type == 'MVC', training)

@@ -115,6 +115,8 @@ SIGNATURES = {
     'dsgcn_dynadj_bwd': [c_f] * 5 + [c_i, c_i] + [c_f] * 4 + [c_int] * 7 + [c_st],
     'dsgcn_head_loss_fwd': [c_f, c_f, c_f, c_i] + [c_int] * 4 + [ctypes.c_float] + [c_f] * 6 + [c_st],
     'dsgcn_head_loss_bwd': [c_f, c_f, c_f, c_i, c_f] + [c_int] * 4 + [ctypes.c_float] + [c_f] * 3 + [c_st],
+    'dsgcn_data_bn_fwd': [c_f] * 10 + [c_int] * 7 + [ctypes.c_float, ctypes.c_float, c_st],
+    'dsgcn_data_bn_bwd': [c_f] * 6 + [c_int] * 6 + [c_st],
     'dsgcn_sgd_step': [c_f, c_f, c_f, c_f, ctypes.c_float, ctypes.c_float, c_int, ctypes.c_longlong, c_st],
     'dsgcn_bn_running_multi': [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float),
                                ctypes.POINTER(ctypes.c_float), c_int, c_st],

@@ -457,6 +457,21 @@ int dsgcn_bn_running_multi(float* const* running_mean, float* const* running_var
                            const float* const* var, long long* const* num_batches_tracked, const int* C,
                            const float* unbias, const float* momentum, int njobs, void* stream);
 
+/* The input BatchNorm of the skeleton backbones (pyskl/models/gcns/dgstgcn.py:158-164; stgcn.py, ctrgcn.py, aagcn.py
+ * alike): x (N, M, T, V, C) is normalised per (v, c) ['VC': mvc = 0, statistics over the N*M person-samples and T] or per
+ * (m, v, c) ['MVC': mvc = 1, over N and T] channel — nn.BatchNorm1d on the permuted clip — and written as (N*M, C, T, V).
+ * training != 0: batch statistics (biased variance; saved in save_mean / save_invstd (channels)), running_mean /
+ * running_var (unbiased) / num_batches_tracked updated with `momentum` when the pointers are given; training == 0: the
+ * running statistics.  gamma / beta may be NULL.  scratch: 4 * N*M * V*C floats (two fp64 tables; training).  V*C <= 256.
+ * dsgcn_data_bn_bwd: dy (N*M, C, T, V) -> pg / pb (N*M, V*C), per-sample partial sums of dgamma / dbeta (summed over the
+ * samples of a channel by the caller's column sum); the clip gets no gradient. */
+int dsgcn_data_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      long long* num_batches_tracked, float* y, float* save_mean, float* save_invstd, float* scratch,
+                      int N, int M, int T, int V, int C, int mvc, int training, float eps, float momentum,
+                      void* stream);
+int dsgcn_data_bn_bwd(const float* x, const float* dy, const float* save_mean, const float* save_invstd, float* pg,
+                      float* pb, int N, int M, int T, int V, int C, int mvc, void* stream);
+
 /* One SGD step over flat fp32 buffers of n elements (16-byte aligned), torch.optim.SGD's update with dampening 0 — the
  * reference's optimizer (configs/_init_/lr_schedual.py:11-15: momentum 0.9, weight decay 5e-4, nesterov):
  *   g' = g + weight_decay p;  buf = momentum buf + g';  p -= lr[0] * (nesterov ? g' + momentum buf : buf);

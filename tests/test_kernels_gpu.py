@@ -1288,3 +1288,46 @@ def test_sgd_step_matches_torch(n, mom, wd, nesterov):
     assert maxabs(p, ref) < 1e-6
     if mom:
         assert maxabs(buf, topt.state[ref]['momentum_buffer']) < 1e-6
+
+
+@pytest.mark.parametrize('N,M,T,V,C,bn_type', [(4, 2, 64, 25, 3, 'VC'), (3, 2, 100, 17, 3, 'MVC'), (64, 2, 64, 25, 3, 'VC'),
+                                               (5, 1, 7, 18, 2, 'MVC'), (2, 3, 30, 25, 9, 'VC')])
+@pytest.mark.parametrize('affine', [True, False])
+def test_data_bn(N, M, T, V, C, bn_type, affine):
+    """The backbones' input BatchNorm1d (dgstgcn.py:158-164) in two launches, no permute copies: output, parameter
+    gradients and the buffer updates against nn.BatchNorm1d in fp64 on the permuted clip; then eval mode on the buffers."""
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(N * T + V)
+    x = torch.randn(N, M, T, V, C, generator=g) * 2 + 0.5
+    Ch = (M if bn_type == 'MVC' else 1) * V * C
+    gy = torch.randn(N * M, C, T, V, generator=g)
+
+    def make(dt, dev):
+        bn = nn.BatchNorm1d(Ch, affine=affine).to(dev, dt)
+        with torch.no_grad():
+            bn.running_mean.copy_(torch.linspace(-1, 1, Ch)); bn.running_var.copy_(torch.linspace(0.5, 2, Ch))
+            if affine:
+                bn.weight.copy_(torch.linspace(0.5, 1.5, Ch)); bn.bias.copy_(torch.linspace(-0.3, 0.3, Ch))
+        return bn
+
+    def run(mod, dt, dev):
+        bn = make(dt, dev).train()
+        xx = x.to(dev, dt)
+        assert mod.data_bn_eligible(xx, bn)
+        y = mod.data_bn(xx, bn, bn_type)
+        res = dict(y=y)
+        if affine:
+            (y * gy.to(dev, dt)).sum().backward()
+            res.update(dgamma=bn.weight.grad, dbeta=bn.bias.grad)
+        res.update(rm=bn.running_mean.clone(), rv=bn.running_var.clone(), nbt=bn.num_batches_tracked.clone())
+        with torch.no_grad():
+            res['y_eval'] = mod.data_bn(xx, bn.eval(), bn_type)
+        return res
+
+    got, ref = run(K_, torch.float32, DEV), run(R, torch.float64, 'cpu')
+    assert got['y'].shape == (N * M, C, T, V) and int(got['nbt']) == 1 == int(ref['nbt'])
+    for k in ('y', 'y_eval', 'rm', 'rv', 'dgamma', 'dbeta'):
+        if k in ref:
+            assert rel(got[k], ref[k]) < 3e-6, (k, rel(got[k], ref[k]))
+    again = run(K_, torch.float32, DEV)
+    assert all(torch.equal(got[k], again[k]) for k in got)

@@ -346,3 +346,15 @@ def head_loss(feat, weight, bias, label, persons, loss_weight=1.0):
         rank = ((score > sl) | ((score == sl) & (idx > label.view(-1, 1)))).sum(1)
         acc = torch.stack([(rank < 1).double().mean(), (rank < 5).double().mean()])
     return loss, acc, score.detach()
+
+
+def data_bn_eligible(x, bn):
+    return isinstance(bn, torch.nn.BatchNorm1d) and x.dim() == 5
+
+
+def data_bn(x, bn, bn_type):
+    """kernels.data_bn as the reference writes it (dgstgcn.py:158-164)."""
+    N, M, T, V, C = x.shape
+    x = x.permute(0, 1, 3, 4, 2).contiguous()
+    x = bn(x.view(N, M * V * C, T)) if bn_type == 'MVC' else bn(x.view(N * M, V * C, T))
+    return x.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
