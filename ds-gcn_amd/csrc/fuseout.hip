@@ -404,6 +404,32 @@ __global__ __launch_bounds__(256) void k_pack(const float* const* __restrict__ s
 }
 }  // namespace
 
+namespace {
+// the same with 64-bit lengths and a NULL source meaning "zero-fill": one launch writes the WHOLE flat buffer (parameters
+// that received no gradient included), so no fill pass and no length-conversion launch precede it
+__global__ __launch_bounds__(256) void k_pack_fill(const float* const* __restrict__ src, const long* __restrict__ off,
+                                                   const long* __restrict__ numel, float* __restrict__ dst) {
+  const int i = blockIdx.x;
+  const float* __restrict__ s = src[i];
+  float* __restrict__ d = dst + off[i];
+  const long n = numel[i];
+  if (s) {
+    for (long j = blockIdx.y * 256 + threadIdx.x; j < n; j += gridDim.y * 256) d[j] = s[j];
+  } else {
+    for (long j = blockIdx.y * 256 + threadIdx.x; j < n; j += gridDim.y * 256) d[j] = 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int dsgcn_pack_fill(const float* const* src_table, const long* dst_offsets, const long* numels, int count,
+                               float* dst, void* stream) {
+  if (!src_table || !dst_offsets || !numels || !dst || count <= 0) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)count, 8), dim3(256), 0, (hipStream_t)stream, src_table, dst_offsets,
+                     numels, dst);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dsgcn_pack(const float* const* src_table, const long* dst_offsets, const int* numels, int count,
                           float* dst, void* stream) {
   if (!src_table || !dst_offsets || !numels || !dst || count <= 0) return DSGCN_EINVAL;

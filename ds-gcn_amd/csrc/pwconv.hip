@@ -654,6 +654,31 @@ __global__ __launch_bounds__(1024) void k_colsum_multi(const long* __restrict__ 
   colsum_body(j, b - (int)table[4 * lo + 3]);
 }
 
+// the same with the table in the kernel arguments (<= CM_MAXJOBS jobs per launch): no table upload in front of the launch,
+// the job lookup runs on scalar loads
+constexpr int CM_MAXJOBS = 112;
+struct ColTable {
+  long w[4 * CM_MAXJOBS];
+  int njobs;
+};
+
+__global__ __launch_bounds__(1024) void k_colsum_multi_arg(ColTable t) {
+  int lo = 0, hi = t.njobs - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)t.w[4 * mid + 3] <= b) lo = mid; else hi = mid - 1;
+  }
+  ColJob j;
+  j.src = reinterpret_cast<const float*>(t.w[4 * lo]);
+  j.out = reinterpret_cast<float*>(t.w[4 * lo + 1]);
+  j.R = (int)(t.w[4 * lo + 2] >> 32);
+  j.C = (int)(t.w[4 * lo + 2] & 0xffffffffL);
+  j.inner = 1;
+  j.nblk = 0;
+  colsum_body(j, b - (int)t.w[4 * lo + 3]);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Backward.
 //   dz_eff[co,pos] = g_z + A0[co] + B0[co]*z                     (the BN-statistics terms: d mean / d var of this conv's
@@ -1465,6 +1490,27 @@ int dsgcn_colsum_multi(const long* table, int njobs, int nblocks, void* stream) 
   if (!table || njobs <= 0 || nblocks <= 0) return DSGCN_EINVAL;
   hipLaunchKernelGGL(k_colsum_multi, dim3((unsigned)nblocks), dim3(1024), 0, (hipStream_t)stream, table, njobs);
   DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same from a HOST table (njobs x 4 int64, layout as above): the jobs ride in the kernel arguments, CM_MAXJOBS per
+// launch (first-block columns are rebased per launch).
+int dsgcn_colsum_multi_host(const long* table, int njobs, void* stream) {
+  if (!table || njobs <= 0) return DSGCN_EINVAL;
+  for (int j0 = 0; j0 < njobs; j0 += CM_MAXJOBS) {
+    ColTable t;
+    t.njobs = njobs - j0 < CM_MAXJOBS ? njobs - j0 : CM_MAXJOBS;
+    const long base = table[4 * j0 + 3];
+    for (int j = 0; j < t.njobs; ++j) {
+      for (int q = 0; q < 3; ++q) t.w[4 * j + q] = table[4 * (j0 + j) + q];
+      t.w[4 * j + 3] = table[4 * (j0 + j) + 3] - base;
+    }
+    const int jl = j0 + t.njobs - 1;
+    const float* lsrc = reinterpret_cast<const float*>(table[4 * jl]);
+    const long end = table[4 * jl + 3] + colsum_blocks((int)(table[4 * jl + 2] & 0xffffffffL), 1, lsrc);
+    hipLaunchKernelGGL(k_colsum_multi_arg, dim3((unsigned)(end - base)), dim3(1024), 0, (hipStream_t)stream, t);
+    DSGCN_LAUNCH_CHECK();
+  }
   return 0;
 }
 

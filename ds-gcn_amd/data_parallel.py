@@ -78,12 +78,14 @@ class FlatParams:
             raise RuntimeError('FlatParams(gather=True): a gradient still aliases the flat buffer — call zero_grad() '
                                'before every backward (a second backward would accumulate into the views and this '
                                'call would wipe it)')
-        self.flat_g.zero_()
-        live = [(p.grad, off, n) for p, (off, n) in zip(self.params, self.slices) if p.grad is not None]
-        if live and self.flat_g.is_cuda:
-            self._pack_cuda(live)
-        elif live:
-            torch._foreach_copy_([self.flat_g[off:off + n] for _, off, n in live], [g.reshape(-1) for g, _, _ in live])
+        if self.flat_g.is_cuda:
+            # one launch writes the whole buffer: a copy per gradient, zeros where none arrived
+            self._pack_cuda([(p.grad, off, n) for p, (off, n) in zip(self.params, self.slices)])
+        else:
+            self.flat_g.zero_()
+            live = [(p.grad, off, n) for p, (off, n) in zip(self.params, self.slices) if p.grad is not None]
+            if live:
+                torch._foreach_copy_([self.flat_g[off:off + n] for _, off, n in live], [g.reshape(-1) for g, _, _ in live])
         for p, v in zip(self.params, self.views):
             p.grad = v
 
@@ -107,8 +109,7 @@ class FlatParams:
 
         def new_slot():
             host = torch.empty((3, cap), dtype=torch.int64).pin_memory()
-            return dict(host=host, dev=torch.empty_like(host, device=dev),
-                        len=torch.empty(cap, dtype=torch.int32, device=dev), event=None)
+            return dict(host=host, dev=torch.empty_like(host, device=dev), event=None)
 
         if torch.cuda.is_current_stream_capturing():
             # the slot reserved by an earlier eager call (pinned allocation is not a capturable operation in the
@@ -130,26 +131,25 @@ class FlatParams:
         return slot
 
     def _pack_cuda(self, live):
-        """One HIP launch (dsgcn_pack) instead of one blit per tensor: a (pointer, offset, length) table goes to the
-        device through pinned staging memory (see _pack_tables for its lifetime rules)."""
+        """One HIP launch (dsgcn_pack_fill) instead of one blit per tensor and a fill: a (pointer, offset, length) table of
+        EVERY parameter goes to the device through pinned staging memory (see _pack_tables for its lifetime rules)."""
         from . import native
         k = len(live)
-        grads = [g if g.is_contiguous() else g.contiguous() for g, _, _ in live]
+        grads = [g if (g is None or g.is_contiguous()) else g.contiguous() for g, _, _ in live]
         slot = self._pack_tables(k)
         slot['keep'] = grads                                      # alive until the slot is reused (>= one full step)
         tab = slot['host'].numpy()
-        tab[0, :k] = [g.data_ptr() for g in grads]
+        tab[0, :k] = [0 if g is None else g.data_ptr() for g in grads]         # 0: no gradient arrived -> zeros
         tab[1, :k] = [off for _, off, _ in live]
         tab[2, :k] = [n for _, _, n in live]
         slot['dev'].copy_(slot['host'], non_blocking=True)
         if not torch.cuda.is_current_stream_capturing():
             slot['event'] = torch.cuda.Event()
             slot['event'].record()
-        slot['len'].copy_(slot['dev'][2])
         st = torch.cuda.current_stream().cuda_stream
-        rc = native.lib().dsgcn_pack(slot['dev'][0].data_ptr(), slot['dev'][1].data_ptr(), slot['len'].data_ptr(), k,
-                                     self.flat_g.data_ptr(), st)
-        native.check(rc, 'dsgcn_pack')
+        rc = native.lib().dsgcn_pack_fill(slot['dev'][0].data_ptr(), slot['dev'][1].data_ptr(), slot['dev'][2].data_ptr(), k,
+                                          self.flat_g.data_ptr(), st)
+        native.check(rc, 'dsgcn_pack_fill')
 
 
 class FlatDataParallel:

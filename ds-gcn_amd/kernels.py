@@ -336,40 +336,6 @@ class deferred_param_sums:
         return False
 
 
-_defer_slots = {}
-
-
-def _defer_table(k, dev):
-    """(pinned host, device) int64 table for one dsgcn_colsum_multi call; same lifetime rules as FlatParams._pack_tables:
-    eager calls rotate over a few slots guarded by events, a call under hipGraph capture gets a table of its own."""
-    cap = max(128, k)
-
-    def new_slot():
-        host = torch.empty((cap, 4), dtype=torch.int64).pin_memory()
-        return dict(host=host, dev=torch.empty_like(host, device=dev), event=None)
-
-    st = _defer_slots.setdefault(dev, dict(slots=[], next=-1, reserved=[], graph=[], epoch=-1, calls=0))
-    if torch.cuda.is_current_stream_capturing():
-        slot = st['reserved'].pop() if st['reserved'] else new_slot()
-        st['graph'].append(slot)                    # alive as long as the graph may replay
-        return slot
-    # (pinned allocation invalidates a capture: the eager steps before it set aside one table per flush of a step)
-    if st['epoch'] != _wsplit_state['epoch']:
-        st['epoch'], st['calls'] = _wsplit_state['epoch'], 0
-    st['calls'] += 1
-    while len(st['reserved']) < st['calls']:
-        st['reserved'].append(new_slot())
-    st['next'] = (st['next'] + 1) % 4
-    if len(st['slots']) <= st['next']:
-        st['slots'].append(new_slot())
-    slot = st['slots'][st['next']]
-    if slot['host'].shape[0] < cap:
-        st['slots'][st['next']] = slot = new_slot()
-    if slot['event'] is not None:
-        slot['event'].synchronize()
-    return slot
-
-
 def flush_param_sums():
     """One launch for every queued column sum (no-op when nothing is queued)."""
     global _deferred
@@ -382,21 +348,17 @@ def flush_param_sums():
 
 
 def _flush_jobs(jobs):
-    dev = jobs[0][0].device
+    """One dsgcn_colsum_multi_host call: the job table rides in the kernel arguments (no device table, no upload — the
+    pinned staging slots, their events and the copy launch of the first version are gone)."""
+    import numpy as _np
     k = len(jobs)
-    slot = _defer_table(k, dev)
-    slot['keep'] = jobs                               # sources / outputs alive until the slot is reused
-    tab = slot['host'].numpy()
+    tab = _np.empty((k, 4), dtype=_np.int64)
     blk = 0
     nblocks = native.lib().dsgcn_colsum_blocks
     for i, (src, R, C, out) in enumerate(jobs):
         tab[i] = (src.data_ptr(), out.data_ptr(), (R << 32) | C, blk)
         blk += nblocks(src.data_ptr(), C)
-    slot['dev'].copy_(slot['host'], non_blocking=True)
-    if not torch.cuda.is_current_stream_capturing():
-        slot['event'] = torch.cuda.Event()
-        slot['event'].record()
-    native.check(native.lib().dsgcn_colsum_multi(slot['dev'].data_ptr(), k, blk, _stream()), 'dsgcn_colsum_multi')
+    native.check(native.lib().dsgcn_colsum_multi_host(tab.ctypes.data, k, _stream()), 'dsgcn_colsum_multi_host')
 
 
 def param_colsum(t, defer_ok=True, level=0):

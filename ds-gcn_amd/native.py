@@ -98,6 +98,8 @@ SIGNATURES = {
     'dsgcn_plane_stats': [c_f, c_f, ctypes.c_long, c_int, c_st],
     'dsgcn_add3': [c_f, c_f, c_f, c_f, ctypes.c_long, c_st],
     'dsgcn_pack': [c_f, c_f, c_f, c_int, c_f, c_st],
+    'dsgcn_pack_fill': [c_f, c_f, c_f, c_int, c_f, c_st],
+    'dsgcn_colsum_multi_host': [ctypes.c_void_p, c_int, c_st],
     'dsgcn_fuse_out_fwd': [c_f] * 6 + [c_int] + [c_f] * 2 + [c_int] * 5 + [c_st],
     'dsgcn_fuse_out_bwd': [c_f] * 6 + [c_int] + [c_f] * 5 + [c_int] * 5 + [c_st],
     'dsgcn_fuse_out_bwd3': [c_f] * 6 + [c_int] + [c_f] * 7 + [c_int] * 5 + [c_st],

@@ -195,6 +195,8 @@ int dsgcn_colsum2(const float* src_a, int Ra, int Ca, int inner_a, float* out_a,
  * dsgcn_colsum_blocks(src, C) (128 columns per block when C % 4 == 0 and src is 16-byte aligned, else 32). */
 int dsgcn_colsum_blocks(const float* src, int C);
 int dsgcn_colsum_multi(const long* table, int njobs, int nblocks, void* stream);
+/* The same with the table in HOST memory: the jobs travel in the kernel arguments (no upload, no device table). */
+int dsgcn_colsum_multi_host(const long* table, int njobs, void* stream);
 /* BN-statistics backward coefficients: dz_eff = gz + A0[c] + B0[c]*z; also d gamma / d beta. */
 int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* mean, const float* var,
                       const float* gamma, float eps, double count, int C, int c_affine, float* dgamma, float* dbeta,
@@ -325,6 +327,10 @@ int dsgcn_add3(const float* a, const float* b, const float* c, float* out, long 
  * are DEVICE arrays (pointers to the tensors, element offsets into dst, element counts). */
 int dsgcn_pack(const float* const* src_table, const long* dst_offsets, const int* numels, int count, float* dst,
                void* stream);
+/* dsgcn_pack with 64-bit lengths and src_table[i] == NULL meaning "fill that range with zeros": given every parameter of
+ * the flat buffer it writes the whole buffer in one launch. */
+int dsgcn_pack_fill(const float* const* src_table, const long* dst_offsets, const long* numels, int count, float* dst,
+                    void* stream);
 
 /* Depthwise causal temporal taps of unitmlp (tcn.py:525-614: left zero pad + grouped Conv1d, groups = channels):
  *   y[n,c,t',v] = b[c] + sum_{j<KM} w[c,j] * h[n,c, t'*stride - (KM-1-j)*dil[c], v]   (frames < 0 read as zero), KM <= 5;
