@@ -255,6 +255,9 @@ __global__ __launch_bounds__(64) void k_aggsum_bwd(const float* __restrict__ p, 
 // stream through LDS one after the other into the same accumulator tile, and the NEXT plane / adjacency (of this
 // item or of the wave's next item) is already in flight while the matrix core works on the current one.
 // partial has one row per chunk: [chunk][unit][2].
+// (Round 5: a variant that keeps a SHARED adjacency's fragments in registers for the whole launch measured the same —
+// 69 vs 66-72 us per ST-GCN layer; the forward is bound by its loads in flight, see the geometry note at the launch.  The
+// backward does gain from it, below.)
 template <int V>
 __global__ __launch_bounds__(64) void k_aggsum_fwd_pipe(const float* __restrict__ p, const float* __restrict__ ahat,
                                                         long a_ns, long a_ks, long a_cs, float* __restrict__ y,
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(64) void k_aggsum_fwd_pipe(const float* __restrict_
 // PER_UNIT: dAhat_k is summed over the waves through LDS and written per (n,c) (CTR-GCN).  Otherwise (shared A,
 // K == 3) every wave keeps three running dA_k accumulators over all the units it walks and writes them once at
 // the end: pieces[(wg*NW + wave)][k][V*V] -> dsgcn_colsum.
-template <int V, int NW, bool PER_UNIT>
+template <int V, int NW, bool PER_UNIT, bool SHR = false>
 __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(const float* __restrict__ p, const float* __restrict__ ahat,
                                                              long a_ns, long a_ks, long a_cs,
                                                              const float* __restrict__ gy, const float* __restrict__ y,
@@ -419,6 +422,18 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
   const bool has_y = (y != nullptr) && (B0 != nullptr);
   f32x4 prez[NP4], preg[NP4], prey[NP4];
   float prea[NAH];
+  // shared adjacency (PER_UNIT == false, K == 3): the three A_k^T fragment sets stay in registers (see k_aggsum_fwd_pipe)
+  const bool shreg = !PER_UNIT && SHR;
+  float btS[PER_UNIT ? 1 : 3][KS];
+  if (!PER_UNIT) {
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        const int w = 2 * q + mk;
+        btS[kk][q] = (SHR && kk < K && w < V && mi < V) ? ahat[(size_t)kk * a_ks + mi * V + w] : 0.f;
+      }
+  }
   f32x16 accS[KACC];
 #pragma unroll
   for (int j = 0; j < KACC; ++j)
@@ -446,10 +461,12 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
       const int i = lane + q * 64;
       if (i < c4) prez[q] = z4[i];
     }
+    if (!shreg) {
 #pragma unroll
-    for (int q = 0; q < NAH; ++q) {
-      const int i = a0 + lane + q * 64;
-      if (i < a1) prea[q] = A[i];
+      for (int q = 0; q < NAH; ++q) {
+        const int i = a0 + lane + q * 64;
+        if (i < a1) prea[q] = A[i];
+      }
     }
   };
 
@@ -486,10 +503,12 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
           const int i = lane + q * 64;
           if (i < c4) lz[i] = prez[q];
         }
+        if (!shreg) {
 #pragma unroll
-        for (int q = 0; q < NAH; ++q) {
-          const int i = a0 + lane + q * 64;
-          if (i < a1) ldsA[i] = prea[q];
+          for (int q = 0; q < NAH; ++q) {
+            const int i = a0 + lane + q * 64;
+            if (i < a1) ldsA[i] = prea[q];
+          }
         }
       }
       if (k + 1 < K) {
@@ -501,11 +520,17 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (NW > 1) __builtin_amdgcn_s_barrier(); else __builtin_amdgcn_wave_barrier();
       float bt[KS];
+      if (shreg) {
 #pragma unroll
-      for (int q = 0; q < KS; ++q) {
-        const int w = 2 * q + mk;
-        const float v = ldsA[mic * V + (w < V ? w : V - 1)];
-        bt[q] = (w < V && mi < V) ? v : 0.f;
+        for (int q = 0; q < KS; ++q)
+          bt[q] = k == 0 ? btS[0][q] : (k == 1 ? btS[PER_UNIT ? 0 : 1][q] : btS[PER_UNIT ? 0 : 2][q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const int w = 2 * q + mk;
+          const float v = ldsA[mic * V + (w < V ? w : V - 1)];
+          bt[q] = (w < V && mi < V) ? v : 0.f;
+        }
       }
       f32x16 accA;
       if (PER_UNIT) {
@@ -601,6 +626,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
 }
 
 int g_as_pipe = 1;         // 0: one-shot kernels only (A/B)
+int g_as_shreg = 1;        // shared adjacency: its MFMA fragments held in registers (0: reloaded per unit and subset, A/B)
 int g_as_waves_fwd = 0;
 int g_as_wgs_bwd = 0;
 
@@ -619,10 +645,11 @@ int as_launch_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
   if (as_pipe_ok<V>(T)) {
     const int chunks = (T + 31) / 32;
     const long units = (long)n * Co, items = units * chunks;
-    // persistent waves: 120 VGPRs allow four per SIMD; with a per-channel adjacency (CTR-GCN) 4096 beat 3072 at 64 and 16
-    // frames and tied at 32 (tools/kap_sweep.py, round 5: 67.8 -> 58.9, 124 -> 113, 123 -> 105 us per layer); the shared
-    // adjacency (ST-GCN) keeps the geometry it was measured with
-    const long g = as_grid(items, g_as_waves_fwd > 0 ? g_as_waves_fwd : (a_cs != 0 ? 4096 : 3072));
+    // persistent waves: 120 VGPRs allow four per SIMD = 4096 waves, a whole number of rounds.  Per-channel adjacency
+    // (CTR-GCN): 4096 beat 3072 at 64 and 16 frames and tied at 32 (tools/kap_sweep.py, round 5: 67.8 -> 58.9, 124 -> 113,
+    // 123 -> 105 us per layer); shared adjacency (ST-GCN; tools/kap_shared.py): 69 -> 56, 69 -> 56, 117 -> 100 us (2048:
+    // 78 / 78 / 143; 6144 = one and a half rounds: 66 / 66 / 119; 8192: 58 / 57 / 101)
+    const long g = as_grid(items, g_as_waves_fwd > 0 ? g_as_waves_fwd : 4096);
     const size_t lds = (size_t)(32 * V + V * V) * sizeof(float);
     hipLaunchKernelGGL((k_aggsum_fwd_pipe<V>), dim3((unsigned)g), dim3(64), lds, st, p, ahat, a_ns, a_ks, a_cs, y,
                        partial, K, Co, T, chunks, items, units);
@@ -658,11 +685,13 @@ int as_launch_bwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
     // geometry — dsgcn_aggsum_bwd_piece_rows sizes its pieces by it.
     const long g = as_grid(units, g_as_wgs_bwd > 0 ? g_as_wgs_bwd : (shared ? (nw == 2 ? 1536 : 2048) : 3072));
     const size_t lds = (size_t)(2 * nw * 32 * V + 2 * V * V) * sizeof(float);
-#define AS_BWD(NWV, PU)                                                                                             \
-  hipLaunchKernelGGL((k_aggsum_bwd_pipe<V, NWV, PU>), dim3((unsigned)g), dim3(64 * NWV), lds, st, p, ahat, a_ns, a_ks, \
+#define AS_BWD(NWV, PU, SR)                                                                                         \
+  hipLaunchKernelGGL((k_aggsum_bwd_pipe<V, NWV, PU, SR>), dim3((unsigned)g), dim3(64 * NWV), lds, st, p, ahat, a_ns, a_ks, \
                      a_cs, gy, y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, K, Co, T, units)
-    if (nw == 2) { if (shared) AS_BWD(2, false); else AS_BWD(2, true); }
-    else { if (shared) AS_BWD(1, false); else AS_BWD(1, true); }
+    // (shared adjacency: its fragments in registers for one-wave workgroups — 170 -> 143, 233 -> 196 us on ST-GCN's 32- and
+    // 16-frame layers; with two waves per workgroup it measured the same, 172 vs 172-178, and stays on the LDS form)
+    if (nw == 2) { if (shared) AS_BWD(2, false, false); else AS_BWD(2, true, false); }
+    else { if (shared) { if (g_as_shreg) AS_BWD(1, false, true); else AS_BWD(1, false, false); } else AS_BWD(1, true, false); }
 #undef AS_BWD
   } else {
     const size_t lds = (size_t)(128 * V + V * V) * sizeof(float);
@@ -731,6 +760,7 @@ int dsgcn_aggsum_tuning(int key, int value) {
   if (key == 0) { g_as_pipe = value; return 0; }
   if (key == 1) { g_as_waves_fwd = value; return 0; }
   if (key == 2) { g_as_wgs_bwd = value; return 0; }
+  if (key == 3) { g_as_shreg = value; return 0; }
   return DSGCN_EINVAL;
 }
 #endif
