@@ -401,7 +401,10 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
                                                              const float* __restrict__ A0, const float* __restrict__ B0,
                                                              float* __restrict__ dp, float* __restrict__ dahat,
                                                              long d_ns, long d_ks, long d_cs, int K, int Co, int T,
-                                                             long units) {
+                                                             long units, int CHK) {
+  // CHK > 1 (shared adjacency, NW == 1): a plane's 32-frame chunks are items of their own — with the running dA accumulators
+  // nothing ties the two halves of a 64-frame plane to one workgroup (the two-wave form measured 172 us where the same
+  // bytes as one-wave items take 143)
   constexpr int KS = (V + 1) / 2;
   constexpr int HR = 32;
   constexpr int NP4 = (HR * V / 4 + 63) / 64;
@@ -416,8 +419,9 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
   float* ldsD = ldsA + V * V;
   const int mi = lane & 31, mk = lane >> 5;
   const int mic = mi < V ? mi : V - 1;
-  const int rows = min(HR, T - wave * HR);
-  const int c4 = (rows * V) >> 2;
+  int ch = 0;                                     // chunk of the current item (CHK > 1 only)
+  int rows = min(HR, T - wave * HR);
+  int c4 = (rows * V) >> 2;
   const int a0 = wave * AH, a1 = min(V * V, a0 + AH);
   const bool has_y = (y != nullptr) && (B0 != nullptr);
   f32x4 prez[NP4], preg[NP4], prey[NP4];
@@ -440,8 +444,9 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
 #pragma unroll
     for (int i = 0; i < 16; ++i) accS[j][i] = 0.f;
 
-  auto issueG = [&](long unit) {
-    const size_t off = ((size_t)unit * T + wave * HR) * V;
+  auto issueG = [&](long unit, int chn) {
+    const int c4 = (min(HR, T - (wave + chn) * HR) * V) >> 2;
+    const size_t off = ((size_t)unit * T + (wave + chn) * HR) * V;
     const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(gy + off);
     const f32x4* __restrict__ y4 = reinterpret_cast<const f32x4*>((has_y ? y : gy) + off);
 #pragma unroll
@@ -450,11 +455,12 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
       if (i < c4) { preg[q] = g4[i]; if (has_y) prey[q] = y4[i]; }
     }
   };
-  auto issueK = [&](long unit, int k) {
+  auto issueK = [&](long unit, int chn, int k) {
+    const int c4 = (min(HR, T - (wave + chn) * HR) * V) >> 2;
     const long n = unit / Co;
     const int c = (int)(unit - n * Co);
     const size_t plane = ((size_t)n * K + k) * Co + c;
-    const f32x4* __restrict__ z4 = reinterpret_cast<const f32x4*>(p + (plane * T + wave * HR) * V);
+    const f32x4* __restrict__ z4 = reinterpret_cast<const f32x4*>(p + (plane * T + (wave + chn) * HR) * V);
     const float* __restrict__ A = ahat + n * a_ns + k * a_ks + c * a_cs;
 #pragma unroll
     for (int q = 0; q < NP4; ++q) {
@@ -470,9 +476,14 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
     }
   };
 
-  long unit = blockIdx.x;
-  if (unit < units) { issueG(unit); issueK(unit, 0); }
-  while (unit < units) {
+  const long items = units * CHK;
+  long item = blockIdx.x;
+  if (item < items) { issueG(item / CHK, (int)(item % CHK)); issueK(item / CHK, (int)(item % CHK), 0); }
+  while (item < items) {
+    const long unit = item / CHK;
+    ch = (int)(item - unit * CHK);
+    rows = min(HR, T - (wave + ch) * HR);
+    c4 = (rows * V) >> 2;
     const long n = unit / Co;
     const int c = (int)(unit - n * Co);
     const float ca = A0 ? A0[c] : 0.f, cb = has_y ? B0[c] : 0.f;
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
         }
       }
     }
-    const long next = unit + gridDim.x;
+    const long next = item + gridDim.x;
 #pragma unroll 1
     for (int k = 0; k < K; ++k) {
       {
@@ -512,10 +523,10 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
         }
       }
       if (k + 1 < K) {
-        issueK(unit, k + 1);
-      } else if (next < units) {
-        issueG(next);
-        issueK(next, 0);
+        issueK(unit, ch, k + 1);
+      } else if (next < items) {
+        issueG(next / CHK, (int)(next % CHK));
+        issueK(next / CHK, (int)(next % CHK), 0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (NW > 1) __builtin_amdgcn_s_barrier(); else __builtin_amdgcn_wave_barrier();
@@ -567,7 +578,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
       }
       {
         const size_t plane = ((size_t)n * K + k) * Co + c;
-        float* __restrict__ dpo = dp + (plane * T + wave * HR) * V;
+        float* __restrict__ dpo = dp + (plane * T + (wave + ch) * HR) * V;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
         }
       }
     }
-    unit = next;
+    item = next;
   }
   if (!PER_UNIT && mi < V) {
     float* __restrict__ out = dahat + ((size_t)blockIdx.x * NW + wave) * 3 * V * V;
@@ -666,8 +677,7 @@ int as_launch_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
 template <int V>
 long as_bwd_piece_rows(int n, int K, int Co, int T) {
   if (!as_pipe_ok<V>(T) || T > 64 || K != 3) return 0;
-  const int nw = T > 32 ? 2 : 1;
-  return as_grid((long)n * Co, g_as_wgs_bwd > 0 ? g_as_wgs_bwd : (nw == 2 ? 1536 : 2048)) * nw;
+  return as_grid((long)n * Co * ((T + 31) / 32), g_as_wgs_bwd > 0 ? g_as_wgs_bwd : 2048);      // one-wave workgroups
 }
 
 template <int V>
@@ -678,19 +688,20 @@ int as_launch_bwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
   const bool shared = (a_ns == 0 && a_cs == 0);
   const long units = (long)n * Co;
   if (as_pipe_ok<V>(T) && T <= 64 && (!shared || K == 3)) {
-    const int nw = T > 32 ? 2 : 1;
+    const int nw = (T > 32 && !shared) ? 2 : 1;
+    const int chk = shared ? (T + 31) / 32 : 1;       // shared adjacency: 32-frame chunks as one-wave items
     // per-(n,c) adjacency (CTR-GCN): 140 VGPRs = three waves per SIMD, which 2048 single-wave workgroups left one short of
     // (tools/kap_sweep.py, round 5: 3072 workgroups 210 -> 158, 373 -> 286, 315 -> 249 us on the 32- / 16-frame layers,
     // 142 -> 130, 252 -> 245 on the 64-frame ones).  The shared-adjacency form (190 / 168 VGPRs: two per SIMD) keeps its
     // geometry — dsgcn_aggsum_bwd_piece_rows sizes its pieces by it.
-    const long g = as_grid(units, g_as_wgs_bwd > 0 ? g_as_wgs_bwd : (shared ? (nw == 2 ? 1536 : 2048) : 3072));
+    const long g = as_grid(units * chk, g_as_wgs_bwd > 0 ? g_as_wgs_bwd : (shared ? 2048 : 3072));
     const size_t lds = (size_t)(2 * nw * 32 * V + 2 * V * V) * sizeof(float);
 #define AS_BWD(NWV, PU, SR)                                                                                         \
   hipLaunchKernelGGL((k_aggsum_bwd_pipe<V, NWV, PU, SR>), dim3((unsigned)g), dim3(64 * NWV), lds, st, p, ahat, a_ns, a_ks, \
-                     a_cs, gy, y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, K, Co, T, units)
-    // (shared adjacency: its fragments in registers for one-wave workgroups — 170 -> 143, 233 -> 196 us on ST-GCN's 32- and
-    // 16-frame layers; with two waves per workgroup it measured the same, 172 vs 172-178, and stays on the LDS form)
-    if (nw == 2) { if (shared) AS_BWD(2, false, false); else AS_BWD(2, true, false); }
+                     a_cs, gy, y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, K, Co, T, units, chk)
+    // (shared adjacency: its fragments in registers — 170 -> 143, 233 -> 196 us on ST-GCN's 32- and 16-frame layers; the
+    // two-wave form of the 64-frame layers measured the same with it, 172 vs 172-178, and was replaced by chunk items)
+    if (nw == 2) AS_BWD(2, true, false);
     else { if (shared) { if (g_as_shreg) AS_BWD(1, false, true); else AS_BWD(1, false, false); } else AS_BWD(1, true, false); }
 #undef AS_BWD
   } else {
