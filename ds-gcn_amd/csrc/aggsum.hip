@@ -262,7 +262,10 @@ template <int V>
 __global__ __launch_bounds__(64) void k_aggsum_fwd_pipe(const float* __restrict__ p, const float* __restrict__ ahat,
                                                         long a_ns, long a_ks, long a_cs, float* __restrict__ y,
                                                         float* __restrict__ partial, int K, int Co, int T, int chunks,
-                                                        long items, long units) {
+                                                        long items, long units, int half) {
+  // half (shared adjacency, 16-frame planes): the launch sees pairs of channels as 32-frame planes (Co / 2 "channels" of
+  // T = 32: the rows of channels 2c and 2c + 1 are adjacent in memory and share A), so no MFMA tile is half empty; only the
+  // statistics know — rows 0-15 belong to channel 2c, rows 16-31 to 2c + 1
   constexpr int KS = (V + 1) / 2;
   constexpr int CH = 32;
   constexpr int NP4 = (CH * V / 4 + 63) / 64;
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(64) void k_aggsum_fwd_pipe(const float* __restrict_
     }
     if (k == K - 1) {
       float* __restrict__ yo = y + ((size_t)unit * T + t0) * V;
-      float sum = 0.f, sq = 0.f;
+      float sum = 0.f, sq = 0.f, sum1 = 0.f, sq1 = 0.f;
       // Y leaves through the wave's P slice (dead after the last subset's products): 16-byte row-major stores instead of
       // sixteen 4-byte stores of 25 lanes each (what the backward got in round 3)
       wave_lds_sync();
@@ -357,8 +360,13 @@ __global__ __launch_bounds__(64) void k_aggsum_fwd_pipe(const float* __restrict_
           if (t < rows) {
             const float v = acc[r];
             ldsP[t * V + mi] = v;
-            sum += v;
-            sq = fmaf(v, v, sq);
+            if (half && r >= 8) {                  // (rows 16-31: accumulator registers 8-15)
+              sum1 += v;
+              sq1 = fmaf(v, v, sq1);
+            } else {
+              sum += v;
+              sq = fmaf(v, v, sq);
+            }
           }
         }
       }
@@ -375,7 +383,16 @@ __global__ __launch_bounds__(64) void k_aggsum_fwd_pipe(const float* __restrict_
       if (partial) {
         sum = wave_sum(sum);
         sq = wave_sum(sq);
-        if (lane == 0) {
+        if (half) {
+          sum1 = wave_sum(sum1);
+          sq1 = wave_sum(sq1);
+          if (lane == 0) {
+            partial[(size_t)unit * 4 + 0] = sum;
+            partial[(size_t)unit * 4 + 1] = sq;
+            partial[(size_t)unit * 4 + 2] = sum1;
+            partial[(size_t)unit * 4 + 3] = sq1;
+          }
+        } else if (lane == 0) {
           partial[((size_t)ch * units + unit) * 2 + 0] = sum;
           partial[((size_t)ch * units + unit) * 2 + 1] = sq;
         }
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
                                                              const float* __restrict__ A0, const float* __restrict__ B0,
                                                              float* __restrict__ dp, float* __restrict__ dahat,
                                                              long d_ns, long d_ks, long d_cs, int K, int Co, int T,
-                                                             long units, int CHK) {
+                                                             long units, int CHK, int half) {
   // CHK > 1 (shared adjacency, NW == 1): a plane's 32-frame chunks are items of their own — with the running dA accumulators
   // nothing ties the two halves of a 64-frame plane to one workgroup (the two-wave form measured 172 us where the same
   // bytes as one-wave items take 143)
@@ -486,7 +503,11 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
     c4 = (rows * V) >> 2;
     const long n = unit / Co;
     const int c = (int)(unit - n * Co);
-    const float ca = A0 ? A0[c] : 0.f, cb = has_y ? B0[c] : 0.f;
+    // half: this "channel" is the pair (2c, 2c + 1) of 16-frame planes — float4 i of the tile belongs to the first while
+    // 4 i < 16 V (the launcher checks 16 V % 4 == 0)
+    const float ca = A0 ? A0[half ? 2 * c : c] : 0.f, cb = has_y ? B0[half ? 2 * c : c] : 0.f;
+    const float ca1 = (half && A0) ? A0[2 * c + 1] : ca, cb1 = (half && has_y) ? B0[2 * c + 1] : cb;
+    const int split4 = half ? 4 * V : (1 << 30);
     {
       f32x4* lg = reinterpret_cast<f32x4*>(ldsG);
 #pragma unroll
@@ -494,11 +515,12 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
         const int i = lane + q * 64;
         if (i < c4) {
           f32x4 g = preg[q];
+          const float ca_ = i < split4 ? ca : ca1, cb_ = i < split4 ? cb : cb1;
           if (has_y) {
             const f32x4 yy = prey[q];
-            g.x += fmaf(cb, yy.x, ca); g.y += fmaf(cb, yy.y, ca); g.z += fmaf(cb, yy.z, ca); g.w += fmaf(cb, yy.w, ca);
+            g.x += fmaf(cb_, yy.x, ca_); g.y += fmaf(cb_, yy.y, ca_); g.z += fmaf(cb_, yy.z, ca_); g.w += fmaf(cb_, yy.w, ca_);
           } else {
-            g.x += ca; g.y += ca; g.z += ca; g.w += ca;
+            g.x += ca_; g.y += ca_; g.z += ca_; g.w += ca_;
           }
           lg[i] = g;
         }
@@ -637,6 +659,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 2) void k_aggsum_bwd_pipe(co
 }
 
 int g_as_pipe = 1;         // 0: one-shot kernels only (A/B)
+int g_as_half = 1;         // shared adjacency, 16-frame planes: channel pairs as 32-frame planes (0: half-empty tiles, A/B)
 int g_as_shreg = 1;        // shared adjacency: its MFMA fragments held in registers (0: reloaded per unit and subset, A/B)
 int g_as_waves_fwd = 0;
 int g_as_wgs_bwd = 0;
@@ -654,6 +677,9 @@ int as_launch_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
                   int K, int Co, int T, hipStream_t st) {
   const int vec = ((T * V) % 4 == 0) ? 1 : 0;
   if (as_pipe_ok<V>(T)) {
+    // shared adjacency on 16-frame planes: pairs of channels as one 32-frame plane (see the kernel)
+    const int half = (a_ns == 0 && a_cs == 0 && T == 16 && Co % 2 == 0 && (16 * V) % 4 == 0 && g_as_half) ? 1 : 0;
+    if (half) { Co /= 2; T = 32; }
     const int chunks = (T + 31) / 32;
     const long units = (long)n * Co, items = units * chunks;
     // persistent waves: 120 VGPRs allow four per SIMD = 4096 waves, a whole number of rounds.  Per-channel adjacency
@@ -663,7 +689,7 @@ int as_launch_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
     const long g = as_grid(items, g_as_waves_fwd > 0 ? g_as_waves_fwd : 4096);
     const size_t lds = (size_t)(32 * V + V * V) * sizeof(float);
     hipLaunchKernelGGL((k_aggsum_fwd_pipe<V>), dim3((unsigned)g), dim3(64), lds, st, p, ahat, a_ns, a_ks, a_cs, y,
-                       partial, K, Co, T, chunks, items, units);
+                       partial, K, Co, T, chunks, items, units, half);
   } else {
     const size_t lds = (size_t)(64 * V + V * V) * sizeof(float);
     hipLaunchKernelGGL((k_aggsum_fwd<V>), dim3((unsigned)((long)n * Co)), dim3(64), lds, st, p, ahat, a_ns, a_ks, a_cs,
@@ -677,6 +703,7 @@ int as_launch_fwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
 template <int V>
 long as_bwd_piece_rows(int n, int K, int Co, int T) {
   if (!as_pipe_ok<V>(T) || T > 64 || K != 3) return 0;
+  if (T == 16 && Co % 2 == 0 && (16 * V) % 4 == 0 && g_as_half) { Co /= 2; T = 32; }
   return as_grid((long)n * Co * ((T + 31) / 32), g_as_wgs_bwd > 0 ? g_as_wgs_bwd : 2048);      // one-wave workgroups
 }
 
@@ -686,6 +713,8 @@ int as_launch_bwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
                   int K, int Co, int T, hipStream_t st) {
   const int vec = ((T * V) % 4 == 0) ? 1 : 0;
   const bool shared = (a_ns == 0 && a_cs == 0);
+  const int half = (shared && K == 3 && T == 16 && Co % 2 == 0 && (16 * V) % 4 == 0 && as_pipe_ok<V>(T) && g_as_half) ? 1 : 0;
+  if (half) { Co /= 2; T = 32; }                      // channel pairs as 32-frame planes (see k_aggsum_fwd_pipe)
   const long units = (long)n * Co;
   if (as_pipe_ok<V>(T) && T <= 64 && (!shared || K == 3)) {
     const int nw = (T > 32 && !shared) ? 2 : 1;
@@ -698,7 +727,7 @@ int as_launch_bwd(const float* p, const float* ahat, long a_ns, long a_ks, long 
     const size_t lds = (size_t)(2 * nw * 32 * V + 2 * V * V) * sizeof(float);
 #define AS_BWD(NWV, PU, SR)                                                                                         \
   hipLaunchKernelGGL((k_aggsum_bwd_pipe<V, NWV, PU, SR>), dim3((unsigned)g), dim3(64 * NWV), lds, st, p, ahat, a_ns, a_ks, \
-                     a_cs, gy, y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, K, Co, T, units, chk)
+                     a_cs, gy, y, A0, B0, dp, dahat, d_ns, d_ks, d_cs, K, Co, T, units, chk, half)
     // (shared adjacency: its fragments in registers — 170 -> 143, 233 -> 196 us on ST-GCN's 32- and 16-frame layers; the
     // two-wave form of the 64-frame layers measured the same with it, 172 vs 172-178, and was replaced by chunk items)
     if (nw == 2) AS_BWD(2, true, false);
@@ -772,6 +801,7 @@ int dsgcn_aggsum_tuning(int key, int value) {
   if (key == 1) { g_as_waves_fwd = value; return 0; }
   if (key == 2) { g_as_wgs_bwd = value; return 0; }
   if (key == 3) { g_as_shreg = value; return 0; }
+  if (key == 4) { g_as_half = value; return 0; }
   return DSGCN_EINVAL;
 }
 #endif
