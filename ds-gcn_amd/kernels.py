@@ -1623,6 +1623,7 @@ class _AggSum(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(p, adj, y, gamma, mean, var)
         ctx.cfg = (K, float(eps), bool(want_bn), count, beta is not None, shared, astr, bool(per_sample))
+        ctx.defer_ok = _leafish(adj) if shared else False
         return y, scale, shift, mean, var
 
     @staticmethod
@@ -1654,7 +1655,10 @@ class _AggSum(torch.autograd.Function):
         rc = lib.dsgcn_aggsum_bwd(_ptr(p), _ptr(adj), *astr, _ptr(gy), _ptr(y), _ptr(A0), _ptr(B0), _ptr(dp),
                                   _ptr(dpiece), *dstr, n, K, Co, T, V, _stream())
         native.check(rc, 'dsgcn_aggsum_bwd')
-        dadj = colsum(dpiece) if (shared or per_sample) else dpiece
+        if shared:      # (a parameter's gradient when A is used as is — unit_gcn 'init': its sum joins the deferred launches)
+            dadj = param_colsum(dpiece, ctx.defer_ok)
+        else:
+            dadj = colsum(dpiece) if per_sample else dpiece
         if dgamma is not None:
             dgamma = dgamma if gamma is not None else None
             dbeta = dbeta if has_beta else None
