@@ -243,15 +243,15 @@ __global__ __launch_bounds__(256) void k_ctr_wprep(CtrPtrs w, CtrPtrs b, const f
 // Its backward: dW_k = dW'_k[:, :R], db_k = dW'_k[:, R + 1] (the input scale already put alpha on those columns), and
 // block K: dalpha = sum_k (sum_{r<R} ds_k[r] + ds_k[R + 1]) from the input-scale gradients (fixed order).
 __global__ __launch_bounds__(256) void k_ctr_wfin(CtrPtrs dwp, CtrPtrs dsv, CtrPtrs out, float* __restrict__ dalpha, int K,
-                                                  int Co, int R) {
+                                                  int Co, int R, int dss) {
   const int R2 = R + 2;
   if ((int)blockIdx.x == K) {
     if (threadIdx.x == 0 && blockIdx.y == 0) {
       float a = 0.f;
       for (int k = 0; k < K; ++k)
         if (dsv.s[k]) {
-          for (int r = 0; r < R; ++r) a += dsv.s[k][r];
-          a += dsv.s[k][R + 1];
+          for (int r = 0; r < R; ++r) a += dsv.s[k][(size_t)r * dss];
+          a += dsv.s[k][(size_t)(R + 1) * dss];
         }
       dalpha[0] = a;
     }
@@ -318,11 +318,12 @@ int dsgcn_ctr_wprep(const float* const* w, const float* const* b, const float* a
   return 0;
 }
 
-// dwp: K gradients of W'_k (Co, R + 2) or NULL; ds: K gradients of the input scales (R + 2) or NULL;
+// dwp: K gradients of W'_k (Co, R + 2) or NULL; ds: K gradients of the input scales (R + 2 elements, ds_stride floats
+// apart: 3 when they are read straight out of the K-C backward's summed (channel, 3) rows) or NULL;
 // out: K buffers (Co*R + Co) = [dW_k | db_k]; dalpha (1).
-int dsgcn_ctr_wfin(const float* const* dwp, const float* const* ds, float* const* out, float* dalpha, int K, int Co, int R,
-                   void* stream) {
-  if (!dwp || !ds || !out || !dalpha || K <= 0 || K > CTR_MAXK || Co <= 0 || R <= 0) return DSGCN_EINVAL;
+int dsgcn_ctr_wfin(const float* const* dwp, const float* const* ds, int ds_stride, float* const* out, float* dalpha, int K,
+                   int Co, int R, void* stream) {
+  if (!dwp || !ds || !out || !dalpha || K <= 0 || K > CTR_MAXK || Co <= 0 || R <= 0 || ds_stride <= 0) return DSGCN_EINVAL;
   CtrPtrs pg = {}, pd = {}, po = {};
   for (int k = 0; k < K; ++k) {
     if (!out[k]) return DSGCN_EINVAL;
@@ -331,7 +332,7 @@ int dsgcn_ctr_wfin(const float* const* dwp, const float* const* ds, float* const
     po.ds[k] = out[k];
   }
   hipLaunchKernelGGL(k_ctr_wfin, dim3((unsigned)(K + 1), (unsigned)((Co * R + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, pg, pd, po, dalpha, K, Co, R);
+                     (hipStream_t)stream, pg, pd, po, dalpha, K, Co, R, ds_stride);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -336,15 +336,22 @@ class deferred_param_sums:
         return False
 
 
+_post_flush = []         # finishing launches that read deferred sums (run by flush_param_sums after the last level)
+
+
 def flush_param_sums():
-    """One launch for every queued column sum (no-op when nothing is queued)."""
+    """One launch per level for every queued column sum, then the finishing launches registered in ``_post_flush``
+    (no-op when nothing is queued)."""
     global _deferred
     queued = _deferred
-    if not queued:
-        return
-    _deferred = [] if _deferred is not None else None
-    for level in sorted({j[4] for j in queued}):      # level 1 = second stages of tall inputs: read what level 0 wrote
-        _flush_jobs([j[:4] for j in queued if j[4] == level])
+    if queued:
+        _deferred = [] if _deferred is not None else None
+        for level in sorted({j[4] for j in queued}):  # level 1 = second stages of tall inputs: read what level 0 wrote
+            _flush_jobs([j[:4] for j in queued if j[4] == level])
+    hooks = list(_post_flush)
+    _post_flush.clear()
+    for h in hooks:
+        h()
 
 
 def _flush_jobs(jobs):
@@ -670,6 +677,9 @@ class _PwConv(torch.autograd.Function):
         ctx.cfg = (int(relu), stride, int(aug), float(eps), int(n_affine), bool(want_bn), count, tuple(weight.shape),
                    bias is not None, beta is not None)
         ctx.defer_ok = _leafish(weight, bias)
+        # the weight (and input scale) come from a producer that finishes their gradients after the deferred sums
+        # (_CtrWPrep): both partial-row sums of this conv may then join the end-of-backward launches
+        ctx.sink = bool(getattr(weight, '_dsgcn_sink', False)) and bias is None and (s1 is None or getattr(s1, '_dsgcn_sink', False)) and s2 is None
         return z, zaug, scale, shift, mean, var
 
     @staticmethod
@@ -712,7 +722,7 @@ class _PwConv(torch.autograd.Function):
                                       wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, st)
             native.check(rc, 'dsgcn_pwconv_bwd')
             return _PwConv._finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma,
-                                   has_beta, n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2)
+                                   has_beta, n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2, ctx.sink)
         ipart = None
         if s1 is not None or s2 is not None:
             rows = lib.dsgcn_pwconv_ipart_rows(n, Ci, Co, T, V, stride)
@@ -731,12 +741,21 @@ class _PwConv(torch.autograd.Function):
                                     wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, stride, aug, st)
         native.check(rc, 'dsgcn_pwconv_wgrad')
         return _PwConv._finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma, has_beta,
-                               n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2)
+                               n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2, ctx.sink)
 
     @staticmethod
     def _finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma, has_beta, n_affine,
-                defer_ok=False, bn1=None, bn2=None):
+                defer_ok=False, bn1=None, bn2=None, sink=False):
         """Ordered sums of the partial rows -> the gradient tuple of backward()."""
+        if sink and _deferred is not None:
+            # both sums deferred; the input-scale gradient goes on as the strided column 0 of the summed (Ci, 3) rows
+            wsum = param_colsum(wpart, True)
+            ds1 = dh1 = None
+            if ipart is not None:
+                red = param_colsum(ipart.view(ipart.shape[0], -1), True).view(Ci, 3)
+                ds1, dh1 = red[:, 0], red[:, 1]
+            return (dx1, ds1, dh1, dx2, None, None, None, wsum[:Co * Ci].view(wshape), None, None, None, None, None, None,
+                    None, None, None, None)
         fed = ipart is not None and (s1 is None or bn1 is not None) and (s2 is None or bn2 is not None)
         if fed:
             # every affine of the virtual input belongs to a deferred BatchNorm that takes its coefficients directly
@@ -1849,6 +1868,7 @@ class _CtrWPrep(torch.autograd.Function):
         rc = native.lib().dsgcn_ctr_wprep(_ptr_array(w), _ptr_array(b), _ptr(alpha), _ptr(wout), _ptr(sh), K, Co, R, _stream())
         native.check(rc, 'dsgcn_ctr_wprep')
         ctx.dims = (K, Co, R, tuple(t is not None for t in b), alpha.shape)
+        ctx.defer_ok = _leafish(alpha, *wb)
         shifts = tuple(sh[k, 1] for k in range(K))
         ctx.mark_non_differentiable(*shifts)
         ctx.set_materialize_grads(False)
@@ -1858,15 +1878,26 @@ class _CtrWPrep(torch.autograd.Function):
     def backward(ctx, *grads):
         K, Co, R, has_b, ashape = ctx.dims
         dwp = [_f32c(g) for g in grads[:K]]
-        ds = [_f32c(g) for g in grads[K:2 * K]]
+        ds = list(grads[K:2 * K])                   # (R + 2,) each: contiguous, or column 0 of deferred (R + 2, 3) sums
+        strides = {g.stride(0) for g in ds if g is not None}
+        if len(strides) > 1:
+            ds = [None if g is None else g.contiguous() for g in ds]
+            strides = {1}
         live = next((g for g in dwp + ds if g is not None), None)
         if live is None:
             return (None,) * (1 + 2 * K)
         out = torch.empty((K, Co * R + Co), device=live.device, dtype=torch.float32)
         dalpha = torch.empty(1, device=live.device, dtype=torch.float32)
         outs = [out[k] for k in range(K)]
-        rc = native.lib().dsgcn_ctr_wfin(_ptr_array(dwp), _ptr_array(ds), _ptr_array(outs), _ptr(dalpha), K, Co, R, _stream())
-        native.check(rc, 'dsgcn_ctr_wfin')
+
+        def finish(dwp=dwp, ds=ds, outs=outs, dalpha=dalpha, stride=(strides.pop() if strides else 1)):
+            rc = native.lib().dsgcn_ctr_wfin(_ptr_array(dwp), _ptr_array(ds), int(stride), _ptr_array(outs), _ptr(dalpha), K, Co,
+                                             R, _stream())
+            native.check(rc, 'dsgcn_ctr_wfin')
+        if _deferred is not None and ctx.defer_ok:
+            _post_flush.append(finish)      # its inputs are deferred sums: filled by the flush, which then runs this
+        else:
+            finish()
         return (dalpha.view(ashape), *[o[:Co * R].view(Co, R) for o in outs],
                 *[(o[Co * R:] if hb else None) for o, hb in zip(outs, has_b)])
 
@@ -1987,6 +2018,8 @@ def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None, s
         # takes by strides
         d = _TanhDiffAug.apply(proj, A, K, R)
         prep = _CtrWPrep.apply(alpha, *w4, *b4)
+        for t in prep[:2 * K]:
+            t._dsgcn_sink = True                # their gradients are only read by _CtrWPrep's finishing launch
         Co = w4[0].shape[0]
         buf = torch.empty((K, n, Co, V, V), device=xbar.device, dtype=torch.float32)
         parts = [pwconv(d[k], (prep[K + k], prep[2 * K + k]), None, None, False, prep[k], None, 1, False,

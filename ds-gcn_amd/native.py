@@ -90,7 +90,7 @@ SIGNATURES = {
     'dsgcn_tanhdiff_aug_fwd': [c_f, c_f, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_tanhdiff_aug_bwd': [c_f, ctypes.c_void_p, c_f, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_ctr_wprep': [ctypes.c_void_p, ctypes.c_void_p, c_f, c_f, c_f] + [c_int] * 3 + [c_st],
-    'dsgcn_ctr_wfin': [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f] + [c_int] * 3 + [c_st],
+    'dsgcn_ctr_wfin': [ctypes.c_void_p, ctypes.c_void_p, c_int, ctypes.c_void_p, c_f] + [c_int] * 3 + [c_st],
     'dsgcn_ctr_affine_fwd': [ctypes.c_void_p, c_f, c_int, c_f, c_f, c_f, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_ctr_affine_bwd': [ctypes.c_void_p, c_f, c_int, c_f, ctypes.c_void_p, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_edge_select_fwd': [c_f, c_i, c_f] + [c_int] * 4 + [c_st],

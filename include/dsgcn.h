@@ -294,15 +294,16 @@ int dsgcn_tanhdiff_bwd_k(const float* d, const float* const* dd, float* dproj, i
  *     dAp (n, K, V, V) = the A-channel rows (their column sum over n is dA).
  *   dsgcn_ctr_wprep: w / b = K device pointers (Co, R) / (Co) (b[k] may be NULL) -> wout (K, Co, R + 2), sh (K, 2, R + 2) =
  *     per subset [input scale; input shift = 0].
- *   dsgcn_ctr_wfin: dwp = K gradients of wout[k] (NULL = zero), ds = K gradients of the input scales (NULL = zero) ->
+ *   dsgcn_ctr_wfin: dwp = K gradients of wout[k] (NULL = zero), ds = K gradients of the input scales (NULL = zero; their
+ *     R + 2 elements ds_stride floats apart) ->
  *     out[k] (Co*R + Co) = [dW_k | db_k], dalpha (1). */
 int dsgcn_tanhdiff_aug_fwd(const float* proj, const float* A, float* d, int n, int K, int R, int V, void* stream);
 int dsgcn_tanhdiff_aug_bwd(const float* d, const float* const* dd, float* dproj, float* dAp, int n, int K, int R, int V,
                            void* stream);
 int dsgcn_ctr_wprep(const float* const* w, const float* const* b, const float* alpha, float* wout, float* sh, int K,
                     int Co, int R, void* stream);
-int dsgcn_ctr_wfin(const float* const* dwp, const float* const* ds, float* const* out, float* dalpha, int K, int Co, int R,
-                   void* stream);
+int dsgcn_ctr_wfin(const float* const* dwp, const float* const* ds, int ds_stride, float* const* out, float* dalpha, int K,
+                   int Co, int R, void* stream);
 int dsgcn_ctr_affine_fwd(const float* const* s, const float* alpha, int alpha_stride, const float* A, const float* beta,
                          const float* G, float* ahat, int n, int K, int Co, int V, void* stream);
 int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, int alpha_stride, const float* dahat,

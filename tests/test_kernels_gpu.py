@@ -662,7 +662,9 @@ def test_aggregate_sum_subset_major_adjacency(n, K, Co, T, V):
         assert torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize('n,Ci,Co,V', [(2, 3, 64, 25), (2, 64, 64, 25), (3, 128, 256, 25), (2, 256, 256, 17)])
+@pytest.mark.parametrize('n,Ci,Co,V', [(2, 3, 64, 25), (2, 64, 64, 25), (3, 128, 256, 25), (2, 256, 256, 17),
+                                       # full size: CTR-GCN's first and last stage at 128 person-samples
+                                       (128, 64, 64, 25), (128, 256, 256, 25)])
 @pytest.mark.parametrize('subset_major', [False, True])
 def test_ctr_topology(n, Ci, Co, V, subset_major):
     """subset_major: Ahat as (K, n, Co, V, V) through the one-conv form of the classic refinement (conv4 + alpha + A as one
@@ -696,7 +698,7 @@ def test_ctr_topology(n, Ci, Co, V, subset_major):
         return res
 
     got = run(K_, torch.float32, DEV)
-    ref = run(R, torch.float64, 'cpu')
+    ref = run(R, torch.float64, ref_dev(n))
     for k, v in ref.items():
         # tanhf + fp32 MFMA accumulation over <= 32 (fwd) / n*V*V*Co (grads) terms: 2e-5 relative L2
         assert rel(got[k].detach().cpu(), v.detach()) < 2e-5, (k, rel(got[k].detach().cpu(), v.detach()))
