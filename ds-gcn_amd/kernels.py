@@ -333,6 +333,7 @@ class deferred_param_sums:
         finally:
             _deferred = self.prev
             _leaf_uses.clear()
+            _post_flush.clear()                     # (a failed backward must not leave finishing launches behind)
         return False
 
 
