@@ -121,6 +121,34 @@ def test_fused_wiring_against_golden_cpu(name):
     assert ours < max(2 * theirs, 1e-4), (ours, theirs)
 
 
+@pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_stgcn', 'model_reduced_aagcn'])
+def test_training_entry_pools_in_the_backbone_and_fuses_head_and_loss(name, monkeypatch):
+    """RecognizerGCN.forward_train asks a pooling head's backbone for plane means (backbone(x, pool=True) -> (N, M, C)) and
+    hands them to cls_head.forward_loss: same loss / accuracies / gradients as loss(forward(extract_feat(x))) — the form the
+    golden vectors pin — through the op seam on CPU; with kernels.FUSED_ENDS off the two-call form runs."""
+    z, m = _reduced_model(name)
+    m.train()
+    x, y = torch.from_numpy(z['x']), torch.from_numpy(z['label'])
+    res = []
+    with D.kernels.use_ops(torch_ops):
+        feat = m.backbone(x[:, 0].float(), pool=True)
+        assert feat.dim() == 3 and feat.shape[:2] == (x.shape[0], x.shape[2])
+        for fused in (True, False):
+            monkeypatch.setattr(D.kernels, 'FUSED_ENDS', fused)
+            m.zero_grad()
+            losses = m(keypoint=x, label=y, return_loss=True)
+            assert set(losses) == {'top1_acc', 'top5_acc', 'loss_cls'} and losses['top1_acc'].dtype == torch.float64
+            losses['loss_cls'].backward()
+            res.append((losses, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    (la, ga), (lb, gb) = res
+    assert abs(la['loss_cls'].item() - float(z['loss_f64'])) < 1e-5
+    for k in la:
+        assert abs(float(la[k].detach()) - float(lb[k].detach())) < 1e-6, k
+    assert set(ga) == set(gb)
+    for k in ga:
+        assert rel(ga[k], gb[k]) < 1e-5 or float((ga[k] - gb[k]).abs().max()) < 1e-9, k
+
+
 def test_product_has_no_cpu_fallback():
     z, m = _reduced_model()
     with pytest.raises(RuntimeError, match='no CPU fallback'):

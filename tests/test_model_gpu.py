@@ -485,3 +485,50 @@ def test_deferred_parameter_sums_are_bit_identical(name):
         grads.append(flat.flat_g.clone())
     assert float(grads[0].abs().max()) > 0
     assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize('kind', ['ds', 'ctrgcn', 'stgcn', 'aagcn'])
+def test_fused_step_ends_match_the_framework_ops(kind, monkeypatch):
+    """The step's ends on csrc/head.hip (input BatchNorm, last block as plane means, head + loss + accuracies, BatchNorm
+    buffers, SGD) against the framework's own launches for the same pieces (kernels.FUSED_ENDS = False): one TrainEngine step
+    each from identical weights.  The two differ in summation order only (pooling, statistics), which ten train-mode
+    BatchNorm blocks on 8 clips amplify to ~3e-5 of the loss: loss within 2e-4 (the north_star's bar is 1e-4 against fp64),
+    accuracies equal, the whole gradient within 1e-2 of its norm, parameters after the step and buffers 1e-4 — a wiring
+    error (a missing scale, a dropped term) is O(1) in every one of them."""
+    from dsgcn_amd import kernels as K
+    cfg = ds_cfg(60, 'nturgb+d') if kind == 'ds' else other_cfg(kind)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(8, 1, 2, 64, 25, 3, generator=g).cuda()
+    y = torch.randint(0, 60, (8, 1), generator=g).cuda()
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(K, 'FUSED_ENDS', fused)
+        np.random.seed(3)
+        torch.manual_seed(3)
+        m = D.build_model(cfg)
+        gen = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if k.endswith(('alpha', 'beta', 'add_coeff')):
+                    p.copy_(torch.randn(p.shape, generator=gen) * 0.5)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        m = m.cuda().train()
+        eng = D.TrainEngine(m, lr=0.05, momentum=0.9, weight_decay=5e-4, nesterov=True, use_graph=False)
+        logs = eng.step(x, y)
+        torch.cuda.synchronize()
+        outs.append(dict(logs={k: float(v) for k, v in logs.items()}, p=eng.flat.flat_p.clone(), g=eng.flat.flat_g.clone(),
+                         bufs={k: b.clone().double() for k, b in m.named_buffers()}))
+    a, b = outs
+    assert set(a['logs']) == set(b['logs']) == {'top1_acc', 'top5_acc', 'loss_cls', 'loss'}
+    for k in a['logs']:
+        bar = 2e-4 * abs(b['logs'][k]) if 'loss' in k else 0.0
+        assert abs(a['logs'][k] - b['logs'][k]) <= bar, (k, a['logs'][k], b['logs'][k])
+    assert float(b['g'].abs().max()) > 0
+    assert rel(a['g'].cpu(), b['g'].cpu()) < 1e-2, rel(a['g'].cpu(), b['g'].cpu())
+    assert rel(a['p'].cpu(), b['p'].cpu()) < 1e-4
+    for k, v in b['bufs'].items():
+        # (absolute floor: some running means are ~1e-11 — statistics of a sum that cancels analytically)
+        diff = float((a['bufs'][k] - v).norm())
+        assert diff <= 1e-4 * float(v.norm()) + 1e-6 * v.numel() ** 0.5, (k, diff, float(v.norm()))

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dsgcn_amd import native
 lib = native.lab_lib(); dev = 'cuda'; st = torch.cuda.current_stream().cuda_stream
-n, V = 128, 25
+n, V = 128, int(os.environ.get('KC_V', '25'))
 SHAPES = [('pre1', 64, 24, 64, 0), ('post1', 24, 64, 64, 1), ('branch1', 64, 64, 64, 2), ('transf1', 64, 64, 64, 1),
           ('pre5', 128, 48, 32, 0), ('post5', 48, 128, 32, 1), ('branch5', 128, 128, 32, 2), ('transf5', 128, 128, 32, 1),
           ('pre8', 256, 96, 16, 0), ('post8', 96, 256, 16, 1), ('branch8', 256, 256, 16, 2), ('transf8', 256, 256, 16, 1)]
