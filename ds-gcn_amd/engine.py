@@ -44,17 +44,21 @@ class TrainEngine:
     def _fwd_bwd(self, keypoint, label):
         self.opt.zero_grad()
         kernels.reset_leaf_uses()
-        out = self.model.train_step(dict(keypoint=keypoint, label=label), None, sync_log_vars=False)
-        loss = out['loss']
-        if self._seed is None or self._seed.dtype != loss.dtype or self._seed.device != loss.device:
-            self._seed = torch.ones((), dtype=loss.dtype, device=loss.device)     # (backward() fills a fresh one per step)
-        if self.flat.flat_p.is_cuda:
-            # parameter-gradient partial rows are summed by ONE launch at the end of the backward (kernels.param_colsum)
-            with kernels.deferred_param_sums(self.flat):
+        try:
+            out = self.model.train_step(dict(keypoint=keypoint, label=label), None, sync_log_vars=False)
+            loss = out['loss']
+            if self._seed is None or self._seed.dtype != loss.dtype or self._seed.device != loss.device:
+                self._seed = torch.ones((), dtype=loss.dtype, device=loss.device)  # (backward() fills a fresh one per step)
+            if self.flat.flat_p.is_cuda:
+                # parameter-gradient partial rows are summed by ONE launch at the end of the backward (kernels.param_colsum)
+                with kernels.deferred_param_sums(self.flat):
+                    loss.backward(self._seed)
+            else:
                 loss.backward(self._seed)
-        else:
-            loss.backward(self._seed)
-        self.flat.collect_grads()
+            self.flat.collect_grads()
+        finally:
+            # the update that follows rewrites the weights through raw pointers: cached weight images are stale from here
+            kernels.end_step()
         return {k: v.detach() for k, v in out['log_vars'].items()}
 
     def _exchange(self):

@@ -11,7 +11,7 @@ def top_k_accuracy(scores, labels, topk=(1, )):
     scores = np.asarray(scores)
     want = np.asarray(labels).reshape(-1, 1)
     ranked = np.argsort(scores, axis=1)                     # ascending: the best k are the last k columns
-    return [float((ranked[:, scores.shape[1] - k:] == want).any(axis=1).mean()) for k in topk]
+    return [float((ranked[:, max(scores.shape[1] - k, 0):] == want).any(axis=1).mean()) for k in topk]
 
 
 def confusion_matrix(y_pred, y_real, normalize=None):

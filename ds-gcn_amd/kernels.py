@@ -253,17 +253,28 @@ def reset_leaf_uses():
     """Start of a step (TrainEngine._fwd_bwd): forget which leaves the previous step's forward registered."""
     _leaf_uses.clear()
     _wsplit_state['epoch'] += 1
+    _wsplit_state['in_step'] = True
+
+
+def end_step():
+    """End of a step's forward + backward (TrainEngine._fwd_bwd): from here on the optimizer may rewrite the weights
+    through raw pointers (dsgcn_sgd_step on the flat buffer: no version counter moves), so no cached weight image is
+    trusted until the next reset_leaf_uses()."""
+    _wsplit_state['in_step'] = False
 
 
 # ---- pre-split weight images of the wide 1x1 convs: one launch per step ------------------------------------------------
 # A wide conv's forward and data gradient read the three bf16 terms of W / W^T from an image that is rebuilt from the
 # weights every step (csrc/pw4.hip k_wsplit): 22 dependent ~4 us launches per DS-STGCN step, each at the head of its conv.
 # The images live here, keyed by (weight address, shape), and the first wide conv of a step (a step = reset_leaf_uses(),
-# i.e. TrainEngine) rebuilds ALL known images with one dsgcn_pwconv_wsplit_multi launch.  An image is trusted only while
-# the step AND the weight tensor's version counter are the ones it was built at; anything else (a conv not seen before, a
-# forward outside a TrainEngine step, weights changed in between) is split on the spot as before.
+# i.e. TrainEngine) rebuilds ALL known images with one dsgcn_pwconv_wsplit_multi launch.  An image is trusted only INSIDE
+# a step (between reset_leaf_uses() and end_step(): the optimizer writes the weights through raw pointers, which moves no
+# version counter) and only while the step AND the weight tensor's version counter are the ones it was built at; anything
+# else (a conv not seen before, a forward outside a TrainEngine step — validation, inference —, weights changed in between)
+# is split on the spot.  Images that were live while a hipGraph was being captured are pinned: the graph holds their
+# addresses, so they are never pruned.
 WSPLIT_BATCH = _os.environ.get('DSGCN_WSPLIT_BATCH', '1') == '1'
-_wsplit_state = dict(epoch=0, batched=-1, jobs={})
+_wsplit_state = dict(epoch=0, batched=-1, jobs={}, in_step=False)
 
 
 def _wsplit_image(w2, Ci, Co, nbytes):
@@ -271,22 +282,27 @@ def _wsplit_image(w2, Ci, Co, nbytes):
     jobs = st['jobs']
     key = (w2.data_ptr(), Ci, Co, nbytes, w2.device.index)
     job = jobs.get(key)
+    capturing = w2.is_cuda and torch.cuda.is_current_stream_capturing()
     if job is None:
         if len(jobs) > 512:
-            jobs.clear()
-        job = jobs[key] = dict(w=w2, img=torch.empty(nbytes, device=w2.device, dtype=torch.uint8), stamp=None, used=0)
+            for k in [k for k, j in jobs.items() if not j['pinned']]:
+                del jobs[k]
+        job = jobs[key] = dict(w=w2, img=torch.empty(nbytes, device=w2.device, dtype=torch.uint8), stamp=None, used=0,
+                               pinned=False)
     else:
         job['w'] = w2
+    if capturing:
+        job['pinned'] = True
     stamp = (st['epoch'], w2._version)
-    if job['stamp'] == stamp:
+    if st['in_step'] and job['stamp'] == stamp:
         job['used'] = st['epoch']
         return job['img']
     lib = native.lib()
-    if WSPLIT_BATCH and st['batched'] != st['epoch'] and job['stamp'] is not None:
+    if WSPLIT_BATCH and st['in_step'] and st['batched'] != st['epoch'] and job['stamp'] is not None:
         st['batched'] = st['epoch']
         # the convs of the previous step are the ones this step will run; images nobody asked for since (another model's,
-        # a shape no longer in use) are dropped
-        for k in [k for k, j in jobs.items() if j['used'] < st['epoch'] - 1 and j is not job]:
+        # a shape no longer in use) are dropped — unless a captured graph holds their address
+        for k in [k for k, j in jobs.items() if j['used'] < st['epoch'] - 1 and j is not job and not j['pinned']]:
             del jobs[k]
         keys = [k for k, j in jobs.items() if k[4] == key[4] and j['stamp'] is not None]
         todo = [jobs[k] for k in keys]
@@ -296,6 +312,8 @@ def _wsplit_image(w2, Ci, Co, nbytes):
                                                    len(todo), _stream()), 'dsgcn_pwconv_wsplit_multi')
         for j in todo:
             j['stamp'] = (st['epoch'], j['w']._version)
+            if capturing:
+                j['pinned'] = True
         if job['stamp'] == stamp:
             job['used'] = st['epoch']
             return job['img']
@@ -680,7 +698,12 @@ class _PwConv(torch.autograd.Function):
         ctx.defer_ok = _leafish(weight, bias)
         # the weight (and input scale) come from a producer that finishes their gradients after the deferred sums
         # (_CtrWPrep): both partial-row sums of this conv may then join the end-of-backward launches
-        ctx.sink = bool(getattr(weight, '_dsgcn_sink', False)) and bias is None and (s1 is None or getattr(s1, '_dsgcn_sink', False)) and s2 is None
+        # The decision is the PRODUCER's _LeafUse object, asked again at backward time (when _CtrWPrep.backward asks it): one
+        # answer for both sides — a conv4 leaf registered by two deferring calls makes both fall back to immediate sums.
+        sink = getattr(weight, '_dsgcn_sink', None)
+        if sink is not None and not (bias is None and s2 is None and (s1 is None or getattr(s1, '_dsgcn_sink', None) is sink)):
+            sink = None
+        ctx.sink = sink
         return z, zaug, scale, shift, mean, var
 
     @staticmethod
@@ -723,7 +746,7 @@ class _PwConv(torch.autograd.Function):
                                       wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, st)
             native.check(rc, 'dsgcn_pwconv_bwd')
             return _PwConv._finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma,
-                                   has_beta, n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2, ctx.sink)
+                                   has_beta, n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2, ctx.sink is not None and bool(ctx.sink))
         ipart = None
         if s1 is not None or s2 is not None:
             rows = lib.dsgcn_pwconv_ipart_rows(n, Ci, Co, T, V, stride)
@@ -742,7 +765,7 @@ class _PwConv(torch.autograd.Function):
                                     wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, stride, aug, st)
         native.check(rc, 'dsgcn_pwconv_wgrad')
         return _PwConv._finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma, has_beta,
-                               n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2, ctx.sink)
+                               n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2, ctx.sink is not None and bool(ctx.sink))
 
     @staticmethod
     def _finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma, has_beta, n_affine,
@@ -1856,7 +1879,9 @@ class _CtrWPrep(torch.autograd.Function):
     input scales [alpha x R, 1, alpha] and K zero shifts (one launch; one launch back: dW_k, db_k, dalpha)."""
 
     @staticmethod
-    def forward(ctx, alpha, *wb):
+    def forward(ctx, use, alpha, *wb):
+        """use: the ``_leafish(alpha, *wb)`` of the caller — the same object rides on the outputs as ``_dsgcn_sink`` so that
+        the consuming convs and this node's backward take ONE decision about deferring."""
         K = len(wb) // 2
         w = [_f32c(t) for t in wb[:K]]
         b = [_f32c(t) for t in wb[K:]]
@@ -1869,7 +1894,7 @@ class _CtrWPrep(torch.autograd.Function):
         rc = native.lib().dsgcn_ctr_wprep(_ptr_array(w), _ptr_array(b), _ptr(alpha), _ptr(wout), _ptr(sh), K, Co, R, _stream())
         native.check(rc, 'dsgcn_ctr_wprep')
         ctx.dims = (K, Co, R, tuple(t is not None for t in b), alpha.shape)
-        ctx.defer_ok = _leafish(alpha, *wb)
+        ctx.defer_ok = use
         shifts = tuple(sh[k, 1] for k in range(K))
         ctx.mark_non_differentiable(*shifts)
         ctx.set_materialize_grads(False)
@@ -1886,7 +1911,7 @@ class _CtrWPrep(torch.autograd.Function):
             strides = {1}
         live = next((g for g in dwp + ds if g is not None), None)
         if live is None:
-            return (None,) * (1 + 2 * K)
+            return (None,) * (2 + 2 * K)
         out = torch.empty((K, Co * R + Co), device=live.device, dtype=torch.float32)
         dalpha = torch.empty(1, device=live.device, dtype=torch.float32)
         outs = [out[k] for k in range(K)]
@@ -1899,7 +1924,7 @@ class _CtrWPrep(torch.autograd.Function):
             _post_flush.append(finish)      # its inputs are deferred sums: filled by the flush, which then runs this
         else:
             finish()
-        return (dalpha.view(ashape), *[o[:Co * R].view(Co, R) for o in outs],
+        return (None, dalpha.view(ashape), *[o[:Co * R].view(Co, R) for o in outs],
                 *[(o[Co * R:] if hb else None) for o, hb in zip(outs, has_b)])
 
 
@@ -2018,9 +2043,10 @@ def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None, s
         # dsgcn_tanhdiff_aug_fwd) writing straight into its slice of Ahat (K, n, Co, V, V) — the layout aggregate_sum
         # takes by strides
         d = _TanhDiffAug.apply(proj, A, K, R)
-        prep = _CtrWPrep.apply(alpha, *w4, *b4)
+        use = _leafish(alpha, *w4, *b4)
+        prep = _CtrWPrep.apply(use, alpha, *w4, *b4)
         for t in prep[:2 * K]:
-            t._dsgcn_sink = True                # their gradients are only read by _CtrWPrep's finishing launch
+            t._dsgcn_sink = use                 # their gradients are only read by _CtrWPrep's finishing launch
         Co = w4[0].shape[0]
         buf = torch.empty((K, n, Co, V, V), device=xbar.device, dtype=torch.float32)
         parts = [pwconv(d[k], (prep[K + k], prep[2 * K + k]), None, None, False, prep[k], None, 1, False,

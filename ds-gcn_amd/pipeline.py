@@ -367,19 +367,29 @@ def nonzero_extent(xy, axes):
     return np.concatenate([lo, hi], -1).astype(xy.dtype)
 
 
-def compact_boxes(extent, img_hw, padding=0.25, threshold=10, hw_ratio=None, allow_imgpad=True):
+def compact_boxes(extent, img_hw, padding=0.25, threshold=10, hw_ratio=None, allow_imgpad=True, promotion='legacy'):
     """PoseCompact's box for a stack of clips at once.  ``extent (N, 4)`` = (lo_x, lo_y, hi_x, hi_y) of the non-zero joints
     in each clip's precision (fp32 after PoseDecode), ``img_hw (N, 2)``.  -> ``(apply (N,) bool, box (N, 4) int64 = x0, y0,
     x1, y1)``: the tight box grown by ``padding`` about its centre, stretched to ``hw_ratio``, truncated to integers (and to
-    the image unless ``allow_imgpad``); ``apply`` False where the tight box is narrower than ``threshold`` either way.  All
-    arithmetic stays in the extent's dtype, the way the scalar code of augmentations.py:60-116 runs on numpy scalars."""
+    the image unless ``allow_imgpad``); ``apply`` False where the tight box is narrower than ``threshold`` either way.
+
+    ``promotion``: the scalar code of augmentations.py:60-116 runs on numpy SCALARS, so its precision follows numpy's scalar
+    promotion rule.  'legacy' (default) = NumPy 1.x — the only line the reference runs on (it uses ``np.Inf``, removed in
+    2.0): centre and half extent are fp32, but ``fp32 scalar * (1 + padding)`` (a Python float) is float64, and so is
+    everything after it.  'nep50' = NumPy >= 2: the Python floats adopt fp32 and the whole box stays fp32.  The two differ
+    only when a box edge lies within an fp32 ulp of an integer (the ``int()`` truncation then lands a pixel apart)."""
+    if promotion not in ('legacy', 'nep50'):
+        raise ValueError("promotion must be 'legacy' or 'nep50'")
     e = np.asarray(extent)
     lo, hi = e[:, :2], e[:, 2:]
     with np.errstate(invalid='ignore'):
         span = hi - lo
         apply = ~((span[:, 0] < threshold) | (span[:, 1] < threshold))
         mid = (hi + lo) / 2
-        half = span / 2 * (1 + padding)
+        half = span / 2
+        if promotion == 'legacy':
+            half = half.astype(np.float64)
+        half = half * (1 + padding)
         if hw_ratio is not None:
             half_h = np.maximum(hw_ratio[0] * half[:, 0], half[:, 1])
             half_w = np.maximum(1 / hw_ratio[1] * half_h, half[:, 0])

@@ -175,6 +175,10 @@ def test_train_step_api_and_eval_numpy():
 def test_top_k_accuracy():
     s = np.array([[.1, .7, .2], [.5, .3, .2], [.2, .3, .5]])
     assert D.top_k_accuracy(s, [1, 1, 2], (1, 2)) == [2 / 3, 1.0]
+    # k above the class count selects every class (core/evaluation.py:121 slices [:, -k:]), as the fused head kernel does
+    assert D.top_k_accuracy(s, [0, 2, 1], (1, 5)) == [0.0, 1.0]
+    from oracle import dsgcn_oracle as O
+    assert O.top_k_accuracy(s, [0, 2, 1], (1, 5)) == [0.0, 1.0]
 
 
 def test_checkpoint_roundtrip_mmcv_format(tmp_path):

@@ -704,6 +704,57 @@ def test_ctr_topology(n, Ci, Co, V, subset_major):
         assert rel(got[k].detach().cpu(), v.detach()) < 2e-5, (k, rel(got[k].detach().cpu(), v.detach()))
 
 
+@pytest.mark.parametrize('shared', [False, True])
+def test_ctr_one_conv_deferred_sums_with_shared_leaves(shared):
+    """inside a deferred_param_sums() region the one-conv refinement defers the conv's partial-row sums
+    and _CtrWPrep's finishing launch to the flush — both sides must take the SAME decision.  With conv4 / alpha shared by
+    two units (leaves registered by two deferring calls) both fall back to immediate sums; either way the gradients equal
+    the ones computed without the region."""
+    g = torch.Generator().manual_seed(11)
+    K, n, Ci, Co, V = 3, 4, 64, 64, 25
+    Rr = Ci // 8
+    mk = lambda *sh, scale=1.0: _rand(g, *sh, scale=scale).to(DEV)
+    xb = [mk(n, Ci, V), mk(n, Ci, V)]
+    base = dict(w1=mk(K * Rr, Ci, scale=Ci ** -0.5), b1=mk(K * Rr, scale=0.1), w2=mk(K * Rr, Ci, scale=Ci ** -0.5),
+                b2=mk(K * Rr, scale=0.1), alpha=mk(1, scale=0.7), A=mk(K, V, V, scale=0.2))
+    w4 = [mk(Co, Rr, scale=Rr ** -0.5) for _ in range(K)]
+    b4 = [mk(Co, scale=0.1) for _ in range(K)]
+    gah = [mk(K, n, Co, V, V), mk(K, n, Co, V, V)]
+
+    def run(deferred):
+        K_.reset_leaf_uses()
+        sets = []
+        for u in range(2):
+            if u == 0 or not shared:
+                tt = {k: v.clone().requires_grad_() for k, v in base.items()}
+                tw4 = [w.clone().requires_grad_() for w in w4]
+                tb4 = [b.clone().requires_grad_() for b in b4]
+            sets.append((tt, tw4, tb4))
+        outs = [K_.ctr_topology(x, tt['w1'], tt['b1'], tt['w2'], tt['b2'], tw4, tb4, tt['alpha'], tt['A'],
+                                subset_major=True) for x, (tt, tw4, tb4) in zip(xb, sets)]
+        loss = sum((o * gg).sum() for o, gg in zip(outs, gah))
+        if deferred:
+            with K_.deferred_param_sums():
+                loss.backward()
+        else:
+            loss.backward()
+        K_.end_step()
+        res = {}
+        for u, (tt, tw4, tb4) in enumerate(sets[:1] if shared else sets):
+            res.update({f'{u}.d{k}': v.grad.clone() for k, v in tt.items()})
+            for k in range(K):
+                res[f'{u}.dw4_{k}'], res[f'{u}.db4_{k}'] = tw4[k].grad.clone(), tb4[k].grad.clone()
+        return res
+
+    want = run(False)
+    got = run(True)
+    for k, v in want.items():
+        assert torch.isfinite(got[k]).all(), k
+        # not shared: the same ordered sums either way, bit for bit; shared: autograd adds the two calls' gradients in the
+        # same order in both runs as well
+        assert torch.equal(got[k], v), (k, rel(got[k].cpu(), v.cpu()))
+
+
 @pytest.mark.parametrize('n,C,T,V,stride,ks', [(2, 64, 32, 25, 1, 5), (2, 128, 32, 25, 2, 5), (2, 256, 16, 25, 1, 5),
                                                (2, 32, 21, 17, 2, 5), (1, 16, 9, 18, 1, 3)])
 @pytest.mark.parametrize('fused', ['1', '0'])
@@ -1131,6 +1182,15 @@ def test_wsplit_images_batched_per_step_and_never_stale():
     with torch.no_grad():
         ws[0].add_(-0.5)
     check('after the batched launch, a later in-place change')
+    # a write that moves NO version counter (what dsgcn_sgd_step does to the flat buffer): inside a step the image is
+    # trusted (nothing writes weights there), after end_step() it never is
+    K.end_step()
+    for w in ws:
+        w.data.mul_(0.75)
+    assert all(j['stamp'][1] == j['w']._version for j in K._wsplit_state['jobs'].values())
+    check('outside a step: raw-pointer weight update, split on the spot')
+    K.reset_leaf_uses()
+    check('next step after a raw-pointer update')
     # a backward through the saved image
     K.reset_leaf_uses()
     z = K.pwconv(x, None, None, None, False, ws[0], None, 1, False)[0]

@@ -452,6 +452,41 @@ def test_bench_through_torch_distributed_run():
     assert a['param_sha256'] == b['param_sha256'] and a['final_loss'] == b['final_loss']
 
 
+@pytest.mark.parametrize('graph', [False, True])
+def test_forward_after_engine_step_sees_the_updated_weights(graph):
+    """the cached bf16 weight images of the wide convs (kernels._wsplit_image) must not outlive the
+    optimizer update — dsgcn_sgd_step writes the flat parameter buffer through raw pointers, no version counter moves.
+    Engine steps (eager, and captured + replayed), then an eval-mode forward of the engine's model against a FRESH model
+    loaded with the same state_dict (other addresses: no cache entry): the same kernels on the same weights, so equal."""
+    cfg = ds_cfg(60)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = D.build_model(cfg).cuda().train()
+    eng = D.TrainEngine(m, lr=0.1, use_graph=graph, warmup_eager=2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 1, 2, 32, 25, 3, generator=g).cuda()          # 32 frames: stages 2 and 3 take the wide-conv form
+    y = torch.randint(0, 60, (4, 1), generator=g).cuda()
+    for _ in range(5 if graph else 2):
+        eng.step(x, y)
+    assert eng.graphed(x, y) == graph
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    fresh = D.build_model(cfg).cuda()
+    fresh.load_state_dict(sd)
+    m.eval()
+    fresh.eval()
+    with torch.no_grad():
+        got = m.cls_head(m.extract_feat(x[:, 0]))
+        want = fresh.cls_head(fresh.extract_feat(x[:, 0]))
+    assert torch.equal(got, want), rel(got.cpu(), want.cpu())
+    # and against an fp64 evaluation of the CURRENT weights by the oracle
+    gc = O.graph_constants('nturgb+d')
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd_cpu.items()}
+    ref = O.recognizer_forward_train(x.cpu().double(), y.cpu(), sd64, gc['node_type'], gc['edge_type'], O.dgstgcn_plan(),
+                                     training=False)[0]
+    assert rel(got.cpu(), ref) < 1e-4, rel(got.cpu(), ref)
+
+
 @pytest.mark.parametrize('name', ['model_reduced', 'model_reduced_ctrgcn', 'model_reduced_dggcn', 'model_reduced_stgcnpp'])
 def test_deferred_parameter_sums_are_bit_identical(name):
     """kernels.deferred_param_sums(): the column sums of parameter-gradient partial rows queued during the backward and

@@ -405,6 +405,59 @@ def test_decompress_and_compact_edge_cases():
     assert r['img_shape'] == (240, 320) and r['keypoint'][0, 1, 3].tolist() == [0., 50.]           # NaN -> 0, too narrow
 
 
+def _compact_box_scalar(ext, hw, padding, hw_ratio, allow_imgpad, legacy):
+    """The contract of augmentations.py:72-99 evaluated value by value with EXPLICIT precisions: ``legacy`` = NumPy 1.x
+    scalar promotion (fp32 scalar op Python float -> float64), otherwise NEP 50 (the Python float adopts fp32)."""
+    f32 = np.float32
+    wide = np.float64 if legacy else np.float32
+    lo_x, lo_y, hi_x, hi_y = (f32(v) for v in ext)
+    cx, cy = f32(f32(hi_x + lo_x) / f32(2)), f32(f32(hi_y + lo_y) / f32(2))
+    hw_, hh_ = wide(f32(f32(hi_x - lo_x) / f32(2))) * wide(1 + padding), wide(f32(f32(hi_y - lo_y) / f32(2))) * wide(1 + padding)
+    if hw_ratio is not None:
+        hh_ = max(wide(hw_ratio[0]) * hw_, hh_)
+        hw_ = max(wide(1 / hw_ratio[1]) * hh_, hw_)
+    x0, x1, y0, y1 = wide(cx) - hw_, wide(cx) + hw_, wide(cy) - hh_, wide(cy) + hh_
+    if not allow_imgpad:
+        x0, y0, x1, y1 = max(0, x0), max(0, y0), min(hw[1], x1), min(hw[0], y1)
+    return [int(x0), int(y0), int(x1), int(y1)]
+
+
+def test_compact_boxes_promotion_rules_on_boundary_values():
+    """PoseCompact's scalar arithmetic promotes differently under NumPy 1.x (the reference's line: it uses
+    np.Inf) and NumPy >= 2.  ``compact_boxes(promotion=)`` states which rule it follows; both are checked value by value
+    against the explicit-precision evaluation above, on extents whose padded edges sit at / next to integers (where the
+    int() truncation can land a pixel apart) and on random ones; the default is the reference's own line ('legacy')."""
+    rng = np.random.default_rng(7)
+    ext = []
+    for _ in range(4000):
+        lo = rng.uniform(0, 200, 2).astype(np.float32)
+        span = rng.uniform(10, 300, 2).astype(np.float32)
+        ext.append([lo[0], lo[1], lo[0] + span[0], lo[1] + span[1]])
+    # edges constructed to hit integers after padding 0.25: span = 8k/5 * ... ; and fp32 neighbours of such values
+    for k in range(16, 400, 7):
+        base = np.float32(k)
+        for d in (0, 1, -1):
+            hi = np.nextafter(np.float32(base + 0.8 * k), np.float32(np.inf if d > 0 else -np.inf)) if d else np.float32(base + 0.8 * k)
+            ext.append([base, base, hi, hi])
+            ext.append([np.float32(base + 0.1), np.float32(base + 0.3), hi, np.float32(hi + 12.7)])
+    ext = np.asarray(ext, np.float32)
+    hw = [(240, 320)] * len(ext)
+    differ = 0
+    for padding, ratio, pad in ((0.25, None, True), (0.25, (1., 1.), True), (0.1, (0.75, 1.25), False), (1 / 3, None, False)):
+        got = {}
+        for rule in ('legacy', 'nep50'):
+            apply, box = P.compact_boxes(ext, hw, padding, 10, ratio, pad, promotion=rule)
+            assert apply.all()
+            want = np.array([_compact_box_scalar(e, (240, 320), padding, ratio, pad, rule == 'legacy') for e in ext])
+            assert np.array_equal(box, want), (rule, padding, ratio, pad, np.flatnonzero((box != want).any(1))[:5])
+            got[rule] = box
+        differ += int((got['legacy'] != got['nep50']).any(1).sum())
+    assert differ > 0                                  # the boundary cases really separate the two rules
+    assert np.array_equal(P.compact_boxes(ext, hw)[1], P.compact_boxes(ext, hw, promotion='legacy')[1])
+    with pytest.raises(ValueError):
+        P.compact_boxes(ext, hw, promotion='numpy')
+
+
 def test_k400_dataset_builds_from_the_config_section(tmp_path):
     """config 5's `data.train` dict (PoseDataset with box_thr / valid_ratio over the compressed pickle + the pipeline above)
     builds through the registry and yields network inputs."""
