@@ -2,7 +2,8 @@
 """bench.py — clips/sec forward+backward, DS-STGCN NTU-60 (3x64x25x2 clips), on N MI355X.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 it is launched through
-``torch.distributed.run`` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+``torch.distributed.run`` (one rank per GPU, RCCL) — by the driver, or, when called plainly with N>1, by itself
+(``self_launch``: a child launcher started before anything touches the GPU).  Rank 0 prints ONE JSON line.
 
 A "step" = one pass of the hot path over one batch of synthetic clips resident in HBM: forward (train-mode
 BatchNorm, CE loss) + backward + gradient all-reduce (N>1) + the SGD-nesterov update.  Weak scaling: 64
@@ -550,7 +551,42 @@ def cpu_baseline(budget_s=12.0, batch=16):
     return res
 
 
-def main():
+def self_launch(n_gpus, argv):
+    """``python bench.py --gpus N`` without a launcher around it: start ``python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>`` as a CHILD process (never exec: a
+    process must not be replaced once anything could have touched the GPU — and this one has not: no ``torch.cuda.*`` call
+    is made before this point, not even ``is_available()``), relay its stdout (rank 0's JSON line) and return its exit
+    code.  The reference's launcher is tools/dist_train.sh:9-11 (``python -m torch.distributed.launch --nproc_per_node``).
+    At N = 1 (``DSGCN_BENCH_SELF_LAUNCH=1``: the test of this path on a one-GPU box) the rank builds a 1-rank RCCL group."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL across processes needs it on this driver
+    env['DSGCN_BENCH_SELF_LAUNCHED'] = '1'
+    if n_gpus == 1:
+        env['DSGCN_BENCH_FORCE_DIST'] = '1'
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *argv]
+    print(f'[bench] self-launch: {" ".join(cmd)}', file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    try:
+        for line in child.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        return child.wait()
+    except BaseException:
+        child.kill()           # the exact child we started, nothing by pattern
+        child.wait()
+        raise
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
@@ -561,13 +597,21 @@ def main():
     ap.add_argument('--no-other-configs', action='store_true', help='skip the BASELINE configs 1 / 3 / 4 / 5 step times')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying captured hipGraphs')
     ap.add_argument('--cpu-budget', type=float, default=12.0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or os.environ.get('DSGCN_BENCH_SELF_LAUNCH') == '1'):
+        # the driver's N = 1 form (`python bench.py --gpus N`) asked for N > 1: become the launcher's parent — BEFORE any
+        # GPU call — and hand back the children's line and exit code
+        raise SystemExit(self_launch(args.gpus, argv))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+    if args.gpus != world:
+        if world == 1:
+            raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE=1 is set: unset it (bench.py then launches its own ranks) or '
+                             f'launch through python -m torch.distributed.run --nproc-per-node {args.gpus}')
+        if rank == 0:
+            print(f'[bench] --gpus {args.gpus} but the launcher started {world} ranks: measuring {world}', file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the hot path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -665,6 +709,7 @@ def main():
         if world > 1 or force_dist:
             per = [round(t / args.steps * 1e3, 3) for t in rank_elapsed]
             result['dist'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                              'self_launched': os.environ.get('DSGCN_BENCH_SELF_LAUNCHED') == '1',
                               'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()),
                               'rank_ms_per_step': per, 'rank_ms_min': min(per), 'rank_ms_max': max(per),
                               'grad_bytes': int(flat.flat_g.numel() * flat.flat_g.element_size())}

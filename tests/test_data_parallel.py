@@ -175,3 +175,61 @@ def test_flat_sgd_matches_torch_sgd(gather):
         assert torch.allclose(a, b, atol=1e-6)
     assert D.shard_batch(512, 3, 8) == (192, 256)
     assert abs(D.cosine_lr(0.1, 50, 100) - 0.05) < 1e-12
+
+
+def test_bench_self_launch_spawns_before_any_gpu_call(monkeypatch):
+    """``python bench.py --gpus N`` (N > 1, no launcher around it — the form the driver uses at N = 1) must become the
+    PARENT of ``python -m torch.distributed.run`` before anything touches the GPU runtime: no
+    torch.cuda.* call — not even is_available() — and a child process, never an exec.  The spawn is intercepted here; every
+    torch.cuda entry point that initialises or queries the runtime is booby-trapped."""
+    import subprocess
+    import sys
+    import bench
+
+    def trap(name):
+        def f(*a, **k):
+            raise AssertionError(f'torch.cuda.{name} called before the launcher was spawned')
+        return f
+    for name in ('is_available', 'init', '_lazy_init', 'set_device', 'current_device', 'synchronize', 'device_count'):
+        monkeypatch.setattr(torch.cuda, name, trap(name))
+    for name in ('execv', 'execve', 'execvp', 'execvpe', 'execl', 'execlp'):
+        monkeypatch.setattr(os, name, trap('os.' + name))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'DSGCN_BENCH_SELF_LAUNCH'):
+        monkeypatch.delenv(k, raising=False)
+    seen = {}
+
+    class FakeChild:
+        def __init__(self, cmd, env=None, cwd=None, stdout=None, text=None):
+            seen.update(cmd=cmd, env=env, cwd=cwd)
+            self.stdout = iter(['{"metric": "x", "n_gpus": 8}\n'])
+
+        def wait(self):
+            return 7
+
+        def kill(self):
+            seen['killed'] = True
+
+    monkeypatch.setattr(subprocess, 'Popen', FakeChild)
+    with pytest.raises(SystemExit) as exc:
+        bench.main(['--gpus', '8', '--steps', '5', '--warmup', '2'])
+    assert exc.value.code == 7                                   # the children's exit code is the parent's
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '8' and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ['--gpus', '8', '--steps', '5', '--warmup', '2']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and 'WORLD_SIZE' not in seen['env']
+    assert seen['env']['DSGCN_BENCH_SELF_LAUNCHED'] == '1' and 'DSGCN_BENCH_FORCE_DIST' not in seen['env']
+    # N = 1 through the same path (the GPU test's knob): a 1-rank RCCL group is forced in the child
+    monkeypatch.setenv('DSGCN_BENCH_SELF_LAUNCH', '1')
+    with pytest.raises(SystemExit):
+        bench.main(['--steps', '1'])
+    assert seen['env']['DSGCN_BENCH_FORCE_DIST'] == '1' and seen['cmd'][seen['cmd'].index('--nproc-per-node') + 1] == '1'
+    # under a launcher (WORLD_SIZE set) nothing is spawned: the rank path runs — and stops at the first GPU call here
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    monkeypatch.setenv('RANK', '0')
+    seen.clear()
+    with pytest.raises(AssertionError, match='is_available'):
+        bench.main(['--gpus', '2'])
+    assert not seen

@@ -452,6 +452,30 @@ def test_bench_through_torch_distributed_run():
     assert a['param_sha256'] == b['param_sha256'] and a['final_loss'] == b['final_loss']
 
 
+def test_bench_self_launch_path():
+    """``python bench.py`` with ``DSGCN_BENCH_SELF_LAUNCH=1`` and no launcher: the parent spawns ``torch.distributed.run``
+    (one rank on this box, a 1-rank RCCL group) before touching the GPU and relays rank 0's line — what
+    ``python bench.py --gpus 8`` does on an 8-GPU node.  Same parameters as the plain run."""
+    a = _run_bench_child({}, '--steps', '2', '--warmup', '4', '--clips-per-gpu', '8')
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSGCN_BENCH_SELF_LAUNCH='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'DSGCN_BENCH_FORCE_DIST'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '4',
+                          '--clips-per-gpu', '8', '--no-cpu-baseline', '--no-roofline', '--no-other-configs'],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'self-launch' in out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                          # ONE JSON line reaches the driver
+    b = json.loads(lines[0])
+    assert b['hip_graph'] and b['n_gpus'] == 1
+    assert b['dist']['world_size'] == 1 and b['dist']['self_launched'] and b['dist']['backend'] == 'nccl'
+    assert a['param_sha256'] == b['param_sha256'] and a['final_loss'] == b['final_loss']
+
+
 @pytest.mark.parametrize('graph', [False, True])
 def test_forward_after_engine_step_sees_the_updated_weights(graph):
     """the cached bf16 weight images of the wide convs (kernels._wsplit_image) must not outlive the
