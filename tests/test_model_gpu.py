@@ -272,6 +272,22 @@ def test_full_width_gradients_vs_reference_fixture(name):
     print(f'full_grads {name}: ours {ours:.3e}  reference fp32 {theirs:.3e} (stored run {float(z["gerr32_set"]):.3e}, run-to-run / '
           f'sqrt2 {float(z["gnoise32_set"]) / 2 ** .5:.3e})  ratio {ours / theirs:.2f}')
     assert ours < 2 * theirs, (ours, theirs)
+    # The frozen mark: the ratio this configuration achieved when the marks were recorded on the GPU
+    # (tests/golden/grad_ratio_marks.json, written by THIS test under DSGCN_RECORD_GRAD_RATIOS=<file> — generated, not
+    # typed).  The step is bit-reproducible, so a kernel change that moves a ratio by more than 15 % — even inside the 2x
+    # bar — fails here and has to be looked at.  `theirs` above is not to be redefined again.
+    ratio = ours / theirs
+    rec = os.environ.get('DSGCN_RECORD_GRAD_RATIOS')
+    if rec:
+        marks = json.load(open(rec)) if os.path.exists(rec) else {}
+        marks[name] = dict(ratio=round(ratio, 4), ours=ours, theirs=theirs)
+        with open(rec, 'w') as f:
+            json.dump(marks, f, indent=1, sort_keys=True)
+    else:
+        with open(os.path.join(GOLD, 'grad_ratio_marks.json')) as f:
+            mark = json.load(f)[name]
+        assert mark['theirs'] == theirs, 'the yardstick moved: grad_ratio_marks.json was recorded against another one'
+        assert ratio <= mark['ratio'] * 1.15, (name, ratio, mark['ratio'])
     sd = m.state_dict()
     for i, k in enumerate(json.loads(str(z['running_names']))):
         assert rel(sd[k].cpu(), z[f'running_{i}']) < 1e-4, k                             # F.batch_norm's running update
