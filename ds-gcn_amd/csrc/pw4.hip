@@ -466,8 +466,8 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   if constexpr (EPI == 1) {
     // (operand prefetch of the data-gradient epilogue: two row groups ahead — k_pw4's waves keep their PD operand slots
     // next to MT*NQ accumulator tiles, there is room for two)
-    if (a.ex2) p4_epilogue<MT, NQ, EPI, false, 4, 2, true>(a, acc, lds, tile);
-    else p4_epilogue<MT, NQ, EPI, false, 4, 2, false>(a, acc, lds, tile);
+    if (a.ex2) p4_epilogue<MT, NQ, EPI, false, 4, (MT * NQ >= 8 || (MT == 2 && NQ == 2) ? 1 : 2), true>(a, acc, lds, tile);
+    else p4_epilogue<MT, NQ, EPI, false, 4, (MT * NQ >= 8 || (MT == 2 && NQ == 2) ? 1 : 2), false>(a, acc, lds, tile);
   } else {
     p4_epilogue<MT, NQ, EPI, false>(a, acc, lds, tile);
   }
@@ -911,8 +911,8 @@ __global__ __launch_bounds__(256, 2) void k_pwg3(Pw4Args a, const unsigned short
   const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, true, pok, skip};
   if constexpr (EPI == 1) {
     // operand prefetch depth of the epilogue: what the registers freed by the main loop hold next to the accumulators
-    if (a.ex2) p4_epilogue<MT, 4, EPI, true, 4, MT == 2 ? 2 : 4, true>(a, acc, lds, tile);
-    else p4_epilogue<MT, 4, EPI, true, 4, 4, false>(a, acc, lds, tile);
+    if (a.ex2) p4_epilogue<MT, 4, EPI, true, 4, MT == 2 ? 1 : 4, true>(a, acc, lds, tile);
+    else p4_epilogue<MT, 4, EPI, true, 4, MT == 2 ? 3 : 4, false>(a, acc, lds, tile);
   } else {
     p4_epilogue<MT, 4, EPI, true, 4>(a, acc, lds, tile);
   }

@@ -132,12 +132,14 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
         pr[e] = p;
       }
     }
+    // (two streams on the 128-row tile: four items per pass — with six the 256-register cap spilled 9-14 values)
+    constexpr int PASS = (MODE == 2 && WM == 4) ? 4 : TG_PASS;
 #pragma unroll
-    for (int i0 = 0; i0 < TG_MAXIT; i0 += TG_PASS) {
+    for (int i0 = 0; i0 < TG_MAXIT; i0 += PASS) {
       if (i0 < nit) {
-        float bw[TG_PASS][4], bw2[MODE == 2 ? TG_PASS : 1][4];
+        float bw[PASS][4], bw2[MODE == 2 ? PASS : 1][4];
 #pragma unroll
-        for (int ii = 0; ii < TG_PASS; ++ii) {
+        for (int ii = 0; ii < PASS; ++ii) {
           const int i = i0 + ii;
           if (i < nit) {
 #pragma unroll
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
           }
         }
 #pragma unroll
-        for (int ii = 0; ii < TG_PASS; ++ii) {
+        for (int ii = 0; ii < PASS; ++ii) {
           const int i = i0 + ii;
           if (i < nit && sdst[i] >= 0) {
             float v[4];
@@ -914,7 +916,10 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
       const int co = co0 + 32 * rt + tg_row32(r, half);
       if (co < Co && ci < Ci) dw[((size_t)co * Ci + ci) * KT + t] = acc[t][r];
     }
-  if (cn == 0 && apc == 0 && aco < Co) a.dbp[(size_t)sp * a.pstride + aco] = dbacc;
+  int tide = tid;
+  asm volatile("" : "+v"(tide));                 // (same: aco's sign-extended copy is not kept across the loop)
+  const int acoe = co0 + (tide >> 2);
+  if (cn == 0 && (tide & 3) == 0 && acoe < Co) a.dbp[(size_t)sp * a.pstride + acoe] = dbacc;
 }
 
 struct TwPlan { int cpl, units, ccM, ccN, splits, nqi; size_t lds; };

@@ -1063,7 +1063,7 @@ int dsgcn_tms_wgrad(const float* z, const float* zaug, const float* scale, const
                     int T, int V, int stride, int KT, int nbr, const int* type, const int* c0, const int* bc,
                     const int* dil, float* const* dwp, float* const* dbp, int pstride, void* stream) {
   if (!z || !gf || !dwp || !dbp || (zaug && !coeff) || (A0 && (!B0 || !f)) || (scale && !shift)) return DSGCN_EINVAL;
-  const TmPlan p = tm_plan(n, C, T, V, stride, KT, nbr, type, bc, dil, zaug != nullptr);
+  TmPlan p = tm_plan(n, C, T, V, stride, KT, nbr, type, bc, dil, zaug != nullptr);
   if (!p.ok || !p.nconv) return DSGCN_EUNSUPPORTED;
   TmArgs a = {};
   a.z = z; a.zaug = zaug; a.scale = scale; a.shift = shift; a.coeff = coeff; a.gf = gf; a.fin = f; a.A0 = A0; a.B0 = B0;
@@ -1081,13 +1081,20 @@ int dsgcn_tms_wgrad(const float* z, const float* zaug, const float* scale, const
   }
   const int mtl = (maxconv + 15) / 16;
   const dim3 grid((unsigned)p.gx_w, (unsigned)p.nconv);
+  if (mtl == 3 && KT == 5) {                         // runs on the four-tile kernel (below): its LDS rows are 64 wide
+    const int VLw = V + (zaug ? 1 : 0), RINw = p.Rw * stride + 2 * TM_H;
+    const size_t need = ((size_t)64 * (((p.Rw * VLw) | 1) + ((RINw * VLw) | 1)) + ((p.Rw * VLw + 3) & ~3) + 32) * sizeof(float);
+    if (need > TM_LDS_MAX) return DSGCN_EUNSUPPORTED;
+    if (need > p.lds_w) p.lds_w = need;
+  }
   // five taps x four row tiles: with two input-channel tiles per wave the 160 accumulator registers spilled (71 VGPRs,
   // round-4 metadata); one tile per wave — four wave groups over the input tiles, two waves sharing the positions — holds 80
 #define TM_W(KTV, NPW4)                                                                        \
   switch (mtl) {                                                                               \
     case 1: TM_LAUNCH((k_tms_wgrad<KTV, 1, 1>), grid, p.lds_w, a, p.nconv); break;             \
     case 2: TM_LAUNCH((k_tms_wgrad<KTV, 2, 2>), grid, p.lds_w, a, p.nconv); break;             \
-    case 3: TM_LAUNCH((k_tms_wgrad<KTV, 3, 3>), grid, p.lds_w, a, p.nconv); break;             \
+    case 3: if (KTV == 3) { TM_LAUNCH((k_tms_wgrad<3, 3, 3>), grid, p.lds_w, a, p.nconv); break; }   \
+            /* five taps x three tiles per wave spilled 100 registers: 33..48-channel windows take the four-tile form */ \
     case 4: TM_LAUNCH((k_tms_wgrad<KTV, 4, NPW4>), grid, p.lds_w, a, p.nconv); break;          \
     default: return DSGCN_EUNSUPPORTED;                                                        \
   }

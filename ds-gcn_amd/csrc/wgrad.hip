@@ -642,14 +642,20 @@ __attribute__((visibility("hidden"))) int dsgcn_wg2(const float* x1, const float
   const dim3 grid(tiles > 1 ? (unsigned)((p.splits + 7) / 8 * 8 * tiles) : (unsigned)p.splits);
   const bool has2 = x2 != nullptr, hasc = A0 != nullptr;
   if (p.v3) {
+#ifdef DSGCN_LAB                                   // the full 256 x 256 tile (key 17 = 256) measured slower in the step: lab builds only
     if (p.TM == 256 && p.TN == 256) wg3_launch<256, 256>(a, has2, hasc, grid, p.lds, st);
-    else if (p.TM == 256) wg3_launch<256, 128>(a, has2, hasc, grid, p.lds, st);
+    else
+#endif
+    if (p.TM == 256) wg3_launch<256, 128>(a, has2, hasc, grid, p.lds, st);
     else wg3_launch<128, 256>(a, has2, hasc, grid, p.lds, st);
     DSGCN_LAUNCH_CHECK();
     return 1;
   }
+#ifdef DSGCN_LAB                                   // KC = 64 staging of the 128 x 128 tile (key 8 = 64) spills: lab builds only
   if (p.TM == 128 && p.TN == 128 && p.KC == 64) wg2_launch<128, 128, 64>(a, has2, hasc, grid, p.lds, st);
-  else if (p.b3) wg2_launch<128, 128, 32, true>(a, has2, hasc, grid, p.lds, st);
+  else
+#endif
+  if (p.b3) wg2_launch<128, 128, 32, true>(a, has2, hasc, grid, p.lds, st);
   else if (p.TM == 128 && p.TN == 128) wg2_launch<128, 128, 32>(a, has2, hasc, grid, p.lds, st);
   else if (p.TM == 128) wg2_launch<128, 64, 64>(a, has2, hasc, grid, p.lds, st);
   else if (p.TN == 128) wg2_launch<64, 128, 64>(a, has2, hasc, grid, p.lds, st);

@@ -63,6 +63,19 @@ def kernels(lib=DEFAULT_LIB):
                     out[val] = cur
                 elif cur is not None and key in FIELDS:
                     cur[key] = int(val)
+            # scratch INSTRUCTIONS per kernel (the spill count of the notes also counts VGPR -> AGPR moves, which touch no
+            # memory; a private segment can be reserved without a single access): what actually goes to scratch memory
+            dis = subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', os.path.join(tmp, f)], check=True,
+                                 capture_output=True, text=True).stdout
+            sym = None
+            for line in dis.splitlines():
+                m = re.match(r'^[0-9a-f]+ <(\w+)>:', line)
+                if m:
+                    sym = m.group(1)
+                    if sym in out:
+                        out[sym].setdefault('scratch_instructions', 0)
+                elif sym in out and 'scratch_' in line:
+                    out[sym]['scratch_instructions'] += 1
         names = list(out)
         dem = subprocess.run(['c++filt'], input='\n'.join(names), capture_output=True, text=True,
                              check=True).stdout.splitlines()
@@ -79,15 +92,16 @@ def main():
     a = ap.parse_args()
     ks = kernels(a.lib)
     if a.spills:
-        ks = {k: v for k, v in ks.items() if v.get('vgpr_spill_count', 0) or v.get('private_segment_fixed_size', 0)}
+        ks = {k: v for k, v in ks.items() if v.get('vgpr_spill_count', 0) or v.get('private_segment_fixed_size', 0) or
+              v.get('scratch_instructions', 0)}
     if a.json:
         json.dump(ks, sys.stdout, indent=1, sort_keys=True)
         return
     print(f'{len(ks)} kernels')
     for k in sorted(ks):
         v = ks[k]
-        print(f"{v.get('vgpr_count', 0):4d} v {v.get('agpr_count', 0):4d} a  spill {v.get('vgpr_spill_count', 0):4d}  "
-              f"scratch {v.get('private_segment_fixed_size', 0):5d} B  lds {v.get('group_segment_fixed_size', 0):6d} B  {k}")
+        print(f"{v.get('vgpr_count', 0):4d} v {v.get('agpr_count', 0) or 0:4d} a  spill {v.get('vgpr_spill_count', 0):4d}  "
+              f"scratch {v.get('private_segment_fixed_size', 0):5d} B / {v.get('scratch_instructions', 0):3d} instr  {k}")
 
 
 if __name__ == '__main__':
