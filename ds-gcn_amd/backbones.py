@@ -67,14 +67,26 @@ class _FusedBlock(nn.Module):
         xa, xb, xc = x if isinstance(x, tuple) else kernels.ops().tee3(x)
         g = self._gcn_deferred(xa, xbar, xb)
         x = xc
-        t = self.tcn.forward_deferred(g)
+        r = hold = None
+        batch = getattr(kernels.ops(), 'bn_batch', None)
+        if self.residual_kind == 'conv' and batch is not None and type(self.tcn) is dgmstcn:
+            # the residual conv reads only the block input: issued FIRST, its BatchNorm finalize waits (kernels.bn_batch) for
+            # the transform conv's at the end of the temporal unit — one launch for the two (and one coefficient launch for
+            # the two in fuse_out's backward)
+            hold = batch()
+            with hold.hold():
+                r = self.residual.forward_deferred(x)
+            t = self.tcn.forward_deferred(g, hold=hold)
+        else:
+            t = self.tcn.forward_deferred(g)
         if getattr(self.tcn, 'drop', None) is not None and self.tcn.drop.p > 0 and self.training:
             t = type(t)(self.tcn.drop(t.materialize()), None, None, None, False)
         x2 = a2 = None
         if self.residual_kind == 'identity':
             x2 = x
         elif self.residual_kind == 'conv':
-            r = self.residual.forward_deferred(x)
+            if r is None:
+                r = self.residual.forward_deferred(x)
             x2, a2 = r.x1, r.a1
         assert t.x2 is None
         # t.relu: the temporal unit ends in its own ReLU (CTR-GCN's MSTCN) -> ReLU on the first term, then add + ReLU

@@ -21,6 +21,7 @@
 // per-thread dot products over LDS.
 // Bound: HBM writes of Ahat forward, reads of dAhat backward.
 #include "common.h"
+#include "bn_jobs.h"
 
 namespace {
 
@@ -262,8 +263,16 @@ __global__ __launch_bounds__(NT) void k_dynadj_fwd(DynDims d_, const float* __re
                                                    const float* __restrict__ A, const float* __restrict__ alpha,
                                                    const float* __restrict__ beta, const float* __restrict__ we,
                                                    const float* __restrict__ be, const int* __restrict__ node_type,
-                                                   const int* __restrict__ edge_type, float* __restrict__ ahat) {
+                                                   const int* __restrict__ edge_type, float* __restrict__ ahat,
+                                                   BnFinTable jobs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x >= d_.n) {                   // hosted BatchNorm finalize jobs (bn_jobs.h): extra workgroups past the samples
+    if (blockIdx.y == 0 && blockIdx.z == 0) {
+      double (*jred)[8][2] = reinterpret_cast<double (*)[8][2]>(lds);        // 2 KB of the launch's dynamic LDS (>= 4 KB)
+      bnj_dispatch(jobs, (int)blockIdx.x - d_.n, [&](const BnFinJob& J, int b) { bn_finalize_block(J, b, jred); });
+    }
+    return;
+  }
   DynDims d = d_;
   if (VT) d.V = VT;
   if (MD) d.mid = MD;
@@ -306,9 +315,16 @@ __global__ __launch_bounds__(NT) void k_dynadj_bwd(
     DynDims d_, const float* __restrict__ proj, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ we, const float* __restrict__ be, const int* __restrict__ node_type,
     const int* __restrict__ edge_type, const float* __restrict__ dahat, float* dd, float* __restrict__ dproj,
-    float* __restrict__ ppar, int pstride) {
+    float* __restrict__ ppar, int pstride, BnCoefTable jobs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[2][NW];
+  if ((int)blockIdx.x >= d_.n) {                   // hosted BatchNorm coefficient jobs: extra workgroups past the samples
+    if (blockIdx.y == 0) {
+      double (*jred)[8][2] = reinterpret_cast<double (*)[8][2]>(lds);
+      bnj_dispatch(jobs, (int)blockIdx.x - d_.n, [&](const BnCoefJob& J, int b) { bn_coef_rows_block(J, b, jred); });
+    }
+    return;
+  }
   DynDims d = d_;
   if (VT) d.V = VT;
   if (MD) d.mid = MD;
@@ -517,15 +533,25 @@ extern "C" {
 // floats per sample of the backward's parameter-partial buffer
 int dsgcn_dynadj_partial_stride(int mid, int V, int E) { return KSUB * V * V + 6 + E * mid * mid + E * mid; }
 
-int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, const float* beta, const float* we,
-                     const float* be, const int* node_type, const int* edge_type, float* ahat, int n, int mid, int V,
-                     int ld, int P, int E, void* stream) {
+int dsgcn_dynadj_fwd_jobs(const float* proj, const float* A, const float* alpha, const float* beta, const float* we,
+                          const float* be, const int* node_type, const int* edge_type, float* ahat, int n, int mid, int V,
+                          int ld, int P, int E, const dsgcn_bn_fin_job* jobs, int njobs, void* stream) {
   if (!proj || !A || !alpha || !beta || !ahat || !we || !be || !node_type || !edge_type || n <= 0 || mid <= 0)
     return DSGCN_EINVAL;
+  if (njobs < 0 || njobs > BNJ_MAX || (njobs > 0 && !jobs)) return DSGCN_EINVAL;
+  BnFinTable jt = {};
+  jt.n = njobs;
+  for (int i = 0; i < njobs; ++i) {
+    const dsgcn_bn_fin_job& q = jobs[i];
+    jt.j[i] = BnFinJob{q.partial, q.gamma, q.beta, q.mean, q.var, q.scale, q.shift, q.count, q.eps, q.nblk, q.C, q.c_affine};
+  }
+  if (!bnj_fin_ok(jt)) return DSGCN_EINVAL;
+  const int jblocks = bnj_total_blocks(jt);
   if (V > 32 || mid > 64 || ld < V) return DSGCN_EUNSUPPORTED;      // (the LDS check below is what bounds mid for a given E)
   // channel windows per (sample, subset): enough workgroups to fill the chip at small batches, windows of >= 8 channels
   int split = (n <= 128 && mid >= 16) ? 2 : 1;
-  const size_t lds = dyn_lds_bytes(mid, V, E, false, (mid + split - 1) / split);
+  size_t lds = dyn_lds_bytes(mid, V, E, false, (mid + split - 1) / split);
+  if (njobs && lds < 2048) lds = 2048;          // the hosted job blocks reduce through 2 KB of it
   if (lds > 158 * 1024) return DSGCN_EUNSUPPORTED;
   DynDims d{n, ld, mid, V, P, E, 0, mid};
 #define DYN_FWD(VT, MD)                                                                                               \
@@ -537,8 +563,8 @@ int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, cons
       if (e != hipSuccess) return (int)e;                                                                             \
       attr = 158 * 1024;                                                                                              \
     }                                                                                                                 \
-    hipLaunchKernelGGL((k_dynadj_fwd<VT, MD>), dim3(n, KSUB, split), dim3(NT), lds, (hipStream_t)stream, d, proj, A,  \
-                       alpha, beta, we, be, node_type, edge_type, ahat);                                               \
+    hipLaunchKernelGGL((k_dynadj_fwd<VT, MD>), dim3(n + jblocks, KSUB, split), dim3(NT), lds, (hipStream_t)stream, d, proj, A,  \
+                       alpha, beta, we, be, node_type, edge_type, ahat, jt);                                           \
   }
   DYN_DISPATCH(DYN_FWD)
 #undef DYN_FWD
@@ -546,15 +572,33 @@ int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, cons
   return 0;
 }
 
-int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
-                     const int* node_type, const int* edge_type, const float* dahat, float* dd_ws, float* dproj,
-                     float* ppar, int pstride, int n, int mid, int V, int ld, int P, int E, void* stream) {
+int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, const float* beta, const float* we,
+                     const float* be, const int* node_type, const int* edge_type, float* ahat, int n, int mid, int V,
+                     int ld, int P, int E, void* stream) {
+  return dsgcn_dynadj_fwd_jobs(proj, A, alpha, beta, we, be, node_type, edge_type, ahat, n, mid, V, ld, P, E, nullptr, 0, stream);
+}
+
+int dsgcn_dynadj_bwd_jobs(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
+                          const int* node_type, const int* edge_type, const float* dahat, float* dd_ws, float* dproj,
+                          float* ppar, int pstride, int n, int mid, int V, int ld, int P, int E,
+                          const dsgcn_bn_coef_job* jobs, int njobs, void* stream) {
   if (!proj || !alpha || !beta || !we || !be || !node_type || !edge_type || !dahat || !dd_ws || !dproj || !ppar ||
       n <= 0 || mid <= 0)
     return DSGCN_EINVAL;
+  if (njobs < 0 || njobs > BNJ_MAX || (njobs > 0 && !jobs)) return DSGCN_EINVAL;
+  BnCoefTable jt = {};
+  jt.n = njobs;
+  for (int i = 0; i < njobs; ++i) {
+    const dsgcn_bn_coef_job& q = jobs[i];
+    jt.j[i] = BnCoefJob{q.part, q.mean, q.var, q.gamma, q.coef, q.count, q.eps, q.R, q.C, q.k, q.i_ds, q.i_dh, q.c_affine,
+                        q.accumulate};
+  }
+  if (!bnj_coef_ok(jt)) return DSGCN_EINVAL;
+  const int jblocks = bnj_total_blocks(jt);
   if (V > 32 || mid > 64 || ld < V) return DSGCN_EUNSUPPORTED;      // (the LDS check below is what bounds mid for a given E)
   if (pstride < dsgcn_dynadj_partial_stride(mid, V, E)) return DSGCN_EINVAL;
-  const size_t lds = dyn_lds_bytes(mid, V, E, true, mid);
+  size_t lds = dyn_lds_bytes(mid, V, E, true, mid);
+  if (njobs && lds < 2048) lds = 2048;
   if (lds > 158 * 1024) return DSGCN_EUNSUPPORTED;
   DynDims d{n, ld, mid, V, P, E, 0, mid};
 #define DYN_BWD(VT, MD)                                                                                               \
@@ -566,13 +610,20 @@ int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, c
       if (e != hipSuccess) return (int)e;                                                                             \
       attr = 158 * 1024;                                                                                              \
     }                                                                                                                 \
-    hipLaunchKernelGGL((k_dynadj_bwd<VT, MD>), dim3(n, KSUB), dim3(NT), lds, (hipStream_t)stream, d, proj, alpha, beta, we, \
-                       be, node_type, edge_type, dahat, dd_ws, dproj, ppar, pstride);                                 \
+    hipLaunchKernelGGL((k_dynadj_bwd<VT, MD>), dim3(n + jblocks, KSUB), dim3(NT), lds, (hipStream_t)stream, d, proj, alpha, beta, we, \
+                       be, node_type, edge_type, dahat, dd_ws, dproj, ppar, pstride, jt);                             \
   }
   DYN_DISPATCH(DYN_BWD)
 #undef DYN_BWD
   DSGCN_LAUNCH_CHECK();
   return 0;
+}
+
+int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
+                     const int* node_type, const int* edge_type, const float* dahat, float* dd_ws, float* dproj,
+                     float* ppar, int pstride, int n, int mid, int V, int ld, int P, int E, void* stream) {
+  return dsgcn_dynadj_bwd_jobs(proj, alpha, beta, we, be, node_type, edge_type, dahat, dd_ws, dproj, ppar, pstride, n, mid,
+                               V, ld, P, E, nullptr, 0, stream);
 }
 
 #ifdef DSGCN_LAB

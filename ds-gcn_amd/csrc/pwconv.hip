@@ -16,6 +16,7 @@
 // (deterministic two-stage BN statistics, finalised in fp64 by k_bn_finalize).  wgrad stages both operands in LDS.
 // Bound: HBM for Ci,Co <= 64 (16 FLOP/B), f32 MFMA above (32-64 FLOP/B vs ridge ~20).
 #include "common.h"
+#include "bn_jobs.h"
 
 namespace {
 
@@ -495,59 +496,21 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
                                                      float* __restrict__ var_out, float* __restrict__ scale_out,
                                                      float* __restrict__ shift_out, int c_affine) {
   // 8 channels x 128 row slices per block: the kernel is a latency chain over the partial rows (up to ~1800 of them),
-  // so the rows are spread over many threads and C/8 blocks rather than walked by 32 slices in C/32 blocks
-  constexpr int CB = 8, NS = 128;
-  __shared__ double red[NS / 8][CB][2];
-  const int cl = threadIdx.x & (CB - 1), slice = threadIdx.x / CB;
-  const int c = blockIdx.x * CB + cl;
-  double s = 0.0, q = 0.0;
-  if (c < C) {
-    const float2* p2 = reinterpret_cast<const float2*>(partial);
-    for (int b0 = slice; b0 < nblk; b0 += NS * 4) {
-      float2 v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int b = b0 + NS * j;
-        v[j] = b < nblk ? p2[(size_t)b * C + c] : float2{0.f, 0.f};
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { s += (double)v[j].x; q += (double)v[j].y; }
-    }
-  }
-  // the 8 slices of a wave (lanes cl + 8*j) meet through three lane exchanges, the 16 waves through ONE LDS hand-off
-  // (round 5: the seven-level LDS tree with a workgroup barrier per level was ~1 us of a 4 us launch); fixed order:
-  // deterministic
-#pragma unroll
-  for (int off = 8; off < 64; off <<= 1) {
-    s += __shfl_xor(s, off, 64);
-    q += __shfl_xor(q, off, 64);
-  }
-  if ((threadIdx.x & 63) < CB) {
-    red[threadIdx.x >> 6][cl][0] = s;
-    red[threadIdx.x >> 6][cl][1] = q;
-  }
-  __syncthreads();
-  if (slice == 0 && c < C) {
-    s = 0.0;
-    q = 0.0;
-#pragma unroll
-    for (int w = 0; w < NS / 8; ++w) { s += red[w][cl][0]; q += red[w][cl][1]; }
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    mean_out[c] = (float)mean;
-    var_out[c] = (float)var;
-    if (c < c_affine) {
-      const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-      const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-      const float sc = g * rstd;
-      scale_out[c] = sc;
-      shift_out[c] = bt - (float)mean * sc;
-    } else {
-      scale_out[c] = 1.f;
-      shift_out[c] = 0.f;
-    }
-  }
+  // so the rows are spread over many threads and C/8 blocks rather than walked by 32 slices in C/32 blocks (bn_jobs.h)
+  __shared__ double red[16][8][2];
+  const BnFinJob J = {partial, gamma, beta, mean_out, var_out, scale_out, shift_out, count, eps, nblk, C, c_affine};
+  bn_finalize_block(J, blockIdx.x, red);
+}
+
+// several finalize / coefficient jobs in one launch (bn_jobs.h): blocks = the jobs' blocks back to back
+__global__ __launch_bounds__(1024) void k_bn_finalize_multi(BnFinTable t) {
+  __shared__ double red[16][8][2];
+  bnj_dispatch(t, blockIdx.x, [&](const BnFinJob& J, int b) { bn_finalize_block(J, b, red); });
+}
+
+__global__ __launch_bounds__(1024) void k_bn_coef_rows_multi(BnCoefTable t) {
+  __shared__ double red[16][8][2];
+  bnj_dispatch(t, blockIdx.x, [&](const BnCoefJob& J, int b) { bn_coef_rows_block(J, b, red); });
 }
 
 // Column sums of a row-major (R, C) fp32 matrix -> out (C), accumulated in fp64 (partial-buffer reductions).
@@ -1201,66 +1164,9 @@ __global__ __launch_bounds__(1024) void k_bn_coef_rows(const float* __restrict__
                                                        const float* __restrict__ mean, const float* __restrict__ var,
                                                        const float* __restrict__ gamma, float eps, double count,
                                                        int c_affine, float* __restrict__ coef, int accumulate) {
-  constexpr int CB = 8, NS = 128;
-  __shared__ double red[NS / 8][CB][2];
-  const int cl = threadIdx.x & (CB - 1), sl = threadIdx.x / CB;
-  const int c = blockIdx.x * CB + cl;
-  // the finishing thread's own operands first: their round trip overlaps the row sums
-  float mu_f = 0.f, var_f = 1.f, g_f = 1.f, old[4] = {0.f, 0.f, 0.f, 0.f};
-  if (sl == 0 && c < C) {
-    mu_f = mean[c]; var_f = var[c];
-    if (gamma && c < c_affine) g_f = gamma[c];
-    if (accumulate) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) old[j] = coef[(size_t)j * C + c];
-    }
-  }
-  double s0 = 0.0, s1 = 0.0;
-  if (c < C) {
-    const size_t rs = (size_t)C * k;
-    const float* p = part + (size_t)c * k;
-    for (int r0 = sl; r0 < R; r0 += NS * 4) {
-      float x[4], y[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = r0 + NS * j;
-        const float* q = p + (size_t)(r < R ? r : r0) * rs;           // (clamped: no predicated loads)
-        x[j] = q[ids]; y[j] = q[idh];
-        if (r >= R) { x[j] = 0.f; y[j] = 0.f; }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { s0 += (double)x[j]; s1 += (double)y[j]; }
-    }
-  }
-#pragma unroll
-  for (int off = 8; off < 64; off <<= 1) {          // a wave's 8 slices by lane exchange, the 16 waves through one LDS hand-off
-    s0 += __shfl_xor(s0, off, 64);
-    s1 += __shfl_xor(s1, off, 64);
-  }
-  if ((threadIdx.x & 63) < CB) {
-    red[threadIdx.x >> 6][cl][0] = s0;
-    red[threadIdx.x >> 6][cl][1] = s1;
-  }
-  __syncthreads();
-  if (sl == 0 && c < C) {
-    double gs = 0.0, gh = 0.0;
-#pragma unroll
-    for (int w = 0; w < NS / 8; ++w) { gs += red[w][cl][0]; gh += red[w][cl][1]; }
-    float o[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < c_affine) {
-      const double mu = mu_f, r = 1.0 / sqrt((double)var_f + (double)eps);
-      const double g = g_f;
-      const double t = gs - mu * gh;
-      const double dmean = -gh * g * r;
-      const double dvar = -0.5 * r * r * r * g * t;
-      o[0] = (float)(r * t);
-      o[1] = (float)gh;
-      o[2] = (float)((dmean - 2.0 * dvar * mu) / count);
-      o[3] = (float)(2.0 * dvar / count);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) coef[(size_t)j * C + c] = old[j] + o[j];
-  }
+  __shared__ double red[16][8][2];
+  const BnCoefJob J = {part, mean, var, gamma, coef, count, eps, R, C, k, ids, idh, c_affine, accumulate};
+  bn_coef_rows_block(J, blockIdx.x, red);
 }
 
 }  // namespace
@@ -1302,7 +1208,7 @@ __attribute__((visibility("hidden"))) int dsgcn_wg2(const float* x1, const float
                                                      const float* s2, const float* h2, int relu, const float* z,
                                                      const float* gz, const float* A0, const float* B0, float* dwp,
                                                      float* dbp, int pstride, int n, int Ci, int Co, int L,
-                                                     hipStream_t st);
+                                                     hipStream_t st, const BnCoefTable* jobs);
 
 // workgroup rows of the statistics / input-affine partial buffers for a (K -> M) mix over n planes of L positions
 static int pw_conv_rows(int n, int K, int M, int T, int V, int stride, int which) {
@@ -1448,6 +1354,38 @@ int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const
   if (!partial || !mean_out || !var_out || !scale_out || !shift_out || nblk <= 0 || C <= 0) return DSGCN_EINVAL;
   hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)((C + 7) / 8)), dim3(1024), 0, (hipStream_t)stream, partial, nblk,
                      C, count, gamma, beta, eps, mean_out, var_out, scale_out, shift_out, c_affine);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// njobs <= 4 finalize jobs (include/dsgcn.h: dsgcn_bn_fin_job, the arguments of dsgcn_bn_finalize as a struct) in ONE
+// launch — BatchNorms whose producers are independent of one another and both done (gcn.py:2165-2169 `post` + `down`).
+int dsgcn_bn_finalize_multi(const dsgcn_bn_fin_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs <= 0 || njobs > BNJ_MAX) return DSGCN_EINVAL;
+  BnFinTable t = {};
+  t.n = njobs;
+  for (int i = 0; i < njobs; ++i) {
+    const dsgcn_bn_fin_job& q = jobs[i];
+    t.j[i] = BnFinJob{q.partial, q.gamma, q.beta, q.mean, q.var, q.scale, q.shift, q.count, q.eps, q.nblk, q.C, q.c_affine};
+  }
+  if (!bnj_fin_ok(t)) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_bn_finalize_multi, dim3((unsigned)bnj_total_blocks(t)), dim3(BNJ_NT), 0, (hipStream_t)stream, t);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// njobs <= 4 coefficient jobs (dsgcn_bn_coef_job = the arguments of dsgcn_bn_coef_rows) in one launch.
+int dsgcn_bn_coef_rows_multi(const dsgcn_bn_coef_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs <= 0 || njobs > BNJ_MAX) return DSGCN_EINVAL;
+  BnCoefTable t = {};
+  t.n = njobs;
+  for (int i = 0; i < njobs; ++i) {
+    const dsgcn_bn_coef_job& q = jobs[i];
+    t.j[i] = BnCoefJob{q.part, q.mean, q.var, q.gamma, q.coef, q.count, q.eps, q.R, q.C, q.k, q.i_ds, q.i_dh, q.c_affine,
+                       q.accumulate};
+  }
+  if (!bnj_coef_ok(t)) return DSGCN_EINVAL;
+  hipLaunchKernelGGL(k_bn_coef_rows_multi, dim3((unsigned)bnj_total_blocks(t)), dim3(BNJ_NT), 0, (hipStream_t)stream, t);
   DSGCN_LAUNCH_CHECK();
   return 0;
 }
@@ -1616,18 +1554,36 @@ int dsgcn_pwconv_wgrad_splits(int n, int Ci, int Co, int T, int V, int stride) {
 
 // Backward, weight path.  Partial sums per k-split: split s writes dW at dwp + s*pstride (Co*Ci floats) and db at
 // dbp + s*pstride (Co floats); one dsgcn_colsum over (splits, pstride) rows finishes both when they share a buffer.
-int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
-                       const float* h2, int relu, const float* z, const float* zaug, const float* gz,
-                       const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int pstride, int n,
-                       int Ci, int Co, int T, int V, int stride, int aug, void* stream) {
+// The weight gradient carrying BatchNorm coefficient jobs (dsgcn_jobs.h) of the conv's INPUT BatchNorms: their partial rows
+// were written by the data gradient launched before this call, nothing on the critical chain waits for the weight gradient,
+// so the jobs ride in its launch as extra workgroups (the blocked kernels) or go out as one launch ahead of it (the
+// first-generation kernels).  njobs = 0: dsgcn_pwconv_wgrad.
+int dsgcn_pwconv_wgrad_jobs(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                            const float* h2, int relu, const float* z, const float* zaug, const float* gz,
+                            const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int pstride, int n,
+                            int Ci, int Co, int T, int V, int stride, int aug, const dsgcn_bn_coef_job* jobs, int njobs,
+                            void* stream) {
   if (!x1 || !dwp || !dbp || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0 || stride <= 0) return DSGCN_EINVAL;
   if ((A0 && (!B0 || !z)) || (aug && A0 && !zaug)) return DSGCN_EINVAL;
+  if (njobs < 0 || njobs > BNJ_MAX || (njobs > 0 && !jobs)) return DSGCN_EINVAL;
+  BnCoefTable jt = {};
+  jt.n = njobs;
+  for (int i = 0; i < njobs; ++i) {
+    const dsgcn_bn_coef_job& q = jobs[i];
+    jt.j[i] = BnCoefJob{q.part, q.mean, q.var, q.gamma, q.coef, q.count, q.eps, q.R, q.C, q.k, q.i_ds, q.i_dh, q.c_affine,
+                        q.accumulate};
+  }
+  if (!bnj_coef_ok(jt)) return DSGCN_EINVAL;
   if (stride == 1 && !aug && (g_pw4 & 4)) {
     if (pstride < Co * Ci) return DSGCN_EINVAL;
     const int fast = dsgcn_wg2(x1, s1, h1, x2, s2, h2, relu, z, gz, A0, B0, dwp, dbp, pstride, n, Ci, Co, T * V,
-                               (hipStream_t)stream);
+                               (hipStream_t)stream, &jt);
     if (fast == 1) return 0;
     if (fast != 0) return fast;
+  }
+  if (njobs) {                                     // not hosted: one launch for the jobs, then the weight gradient
+    hipLaunchKernelGGL(k_bn_coef_rows_multi, dim3((unsigned)bnj_total_blocks(jt)), dim3(BNJ_NT), 0, (hipStream_t)stream, jt);
+    DSGCN_LAUNCH_CHECK();
   }
   // the first-generation kernels address the whole tensor with 32-bit byte offsets (the wide-load kernels above carry
   // the sample base in the buffer resource): refuse what they cannot address instead of wrapping silently
@@ -1663,6 +1619,14 @@ int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const 
   else hipLaunchKernelGGL((k_pwconv_wgrad<false, false>), grid, dim3(PW_NT), lds, st, a);
   DSGCN_LAUNCH_CHECK();
   return 0;
+}
+
+int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                       const float* h2, int relu, const float* z, const float* zaug, const float* gz,
+                       const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int pstride, int n,
+                       int Ci, int Co, int T, int V, int stride, int aug, void* stream) {
+  return dsgcn_pwconv_wgrad_jobs(x1, s1, h1, x2, s2, h2, relu, z, zaug, gz, gzaug, A0, B0, dwp, dbp, pstride, n, Ci, Co, T, V,
+                                 stride, aug, nullptr, 0, stream);
 }
 
 // out (n,Co,T,V) = gz + A0 + B0*z + (gzaug + A0 + B0*zaug)/V   (gz, gzaug, A0/B0 may be NULL = zero)

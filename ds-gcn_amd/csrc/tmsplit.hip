@@ -26,6 +26,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "bn_jobs.h"
 
 namespace {
 
@@ -1098,10 +1099,16 @@ __device__ long long g_tsw_stamp[64];
 #endif
 
 template <int CH>
-__global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
+__global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a, BnCoefTable jobs) {
   constexpr int KT = 3;
   constexpr int JD = CH == 32 ? 4 : 7, JX = CH == 32 ? 10 : 20;     // float4 staging slots per thread (V <= 25)
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x >= a.splits) {               // hosted BatchNorm coefficient jobs (bn_jobs.h): workgroups past the K-splits
+    if (blockIdx.y == 0)
+      bnj_dispatch(jobs, (int)blockIdx.x - a.splits,
+                   [&](const BnCoefJob& J, int b) { bn_coef_rows_block<TS_NT>(J, b, reinterpret_cast<double (*)[8][2]>(lds)); });
+    return;
+  }
 #ifdef DSGCN_LAB
   int nst = 0;
 #endif
@@ -1364,10 +1371,16 @@ __global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw(TSArgs a) {
 // 16-byte loads per 25-float row, the dwords past the row dropped when the tile is written) and the matrix loop reads ge
 // and h at the SAME tile position.  Same grid, groups, splits and epilogue as k_tspw.
 template <int CH>
-__global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw2(TSArgs a) {
+__global__ __launch_bounds__(TS_NT, CH == 32 ? 2 : 1) void k_tspw2(TSArgs a, BnCoefTable jobs) {
   constexpr int KT = 3;
   constexpr int JD = CH == 32 ? 4 : 7, JX = CH == 32 ? 11 : 21, JA = CH == 32 ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x >= a.splits) {               // hosted BatchNorm coefficient jobs (bn_jobs.h): workgroups past the K-splits
+    if (blockIdx.y == 0)
+      bnj_dispatch(jobs, (int)blockIdx.x - a.splits,
+                   [&](const BnCoefJob& J, int b) { bn_coef_rows_block<TS_NT>(J, b, reinterpret_cast<double (*)[8][2]>(lds)); });
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -1820,11 +1833,21 @@ int dsgcn_tms_split_dgrad(const float* z, const float* zaug, const float* scale,
 
 // Conv window i writes split s of its weight / bias partials at dwp[i] + s*pstride / dbp[i] + s*pstride, s < splits =
 // rows(2); NULL entries for the other window types.
-int dsgcn_tms_split_wgrad(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
-                          const float* ge, const float* doaug, int n, int C, int T, int V, int stride, int nbr,
-                          const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp, float* const* dbp,
-                          int splits, int pstride, void* stream) {
+int dsgcn_tms_split_wgrad_jobs(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                               const float* ge, const float* doaug, int n, int C, int T, int V, int stride, int nbr,
+                               const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp,
+                               float* const* dbp, int splits, int pstride, const dsgcn_bn_coef_job* jobs, int njobs,
+                               void* stream) {
   if (!z || !zaug || !ge || !doaug || !dwp || !dbp || splits <= 0) return DSGCN_EINVAL;
+  if (njobs < 0 || njobs > BNJ_MAX || (njobs > 0 && !jobs)) return DSGCN_EINVAL;
+  BnCoefTable jt = {};
+  jt.n = njobs;
+  for (int i = 0; i < njobs; ++i) {
+    const dsgcn_bn_coef_job& q = jobs[i];
+    jt.j[i] = BnCoefJob{q.part, q.mean, q.var, q.gamma, q.coef, q.count, q.eps, q.R, q.C, q.k, q.i_ds, q.i_dh, q.c_affine,
+                        q.accumulate};
+  }
+  if (!bnj_coef_ok(jt)) return DSGCN_EINVAL;
   TSArgs a = {};
   const int mt = ts_fill(a, n, C, T, V, stride, 3, nbr, type, c0, bc, dil);
   if (mt < 0) return mt;
@@ -1840,32 +1863,40 @@ int dsgcn_tms_split_wgrad(const float* z, const float* zaug, const float* scale,
                                   : (size_t)ch * (tsw_ls(TS_R * (V + 1)) + tsw_ls((TS_R + 2 * TS_H) * (V + 1))) + 2 * ch;
   const size_t red = (size_t)4 * 3 * 32 * 33;
   const size_t lds = std::max(tile, ch == 32 ? red : (size_t)0) * sizeof(float);
-  const dim3 grid((unsigned)splits, (unsigned)a.ngroups);
+  const dim3 grid((unsigned)(splits + bnj_total_blocks(jt)), (unsigned)a.ngroups);
   if (stride == 2) {
     if (ch == 32) {
       static size_t have = 64 * 1024;
       const int rc = ts_raise_lds(k_tspw2<32>, lds, &have);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_tspw2<32>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(k_tspw2<32>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a, jt);
     } else {
       static size_t have = 64 * 1024;
       const int rc = ts_raise_lds(k_tspw2<64>, lds, &have);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_tspw2<64>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(k_tspw2<64>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a, jt);
     }
   } else if (ch == 32) {
     static size_t have = 64 * 1024;
     const int rc = ts_raise_lds(k_tspw<32>, lds, &have);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tspw<32>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_tspw<32>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a, jt);
   } else {
     static size_t have = 64 * 1024;
     const int rc = ts_raise_lds(k_tspw<64>, lds, &have);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tspw<64>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_tspw<64>, grid, dim3(TS_NT), lds, (hipStream_t)stream, a, jt);
   }
   DSGCN_LAUNCH_CHECK();
   return 0;
+}
+
+int dsgcn_tms_split_wgrad(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                          const float* ge, const float* doaug, int n, int C, int T, int V, int stride, int nbr,
+                          const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp, float* const* dbp,
+                          int splits, int pstride, void* stream) {
+  return dsgcn_tms_split_wgrad_jobs(z, zaug, scale, shift, n_act, ge, doaug, n, C, T, V, stride, nbr, type, c0, bc, dil, dwp,
+                                    dbp, splits, pstride, nullptr, 0, stream);
 }
 
 }  // extern "C"

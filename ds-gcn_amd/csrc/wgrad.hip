@@ -10,6 +10,7 @@
 // two of the first version, and a 128x128 tile reads each operand row once for 128 output columns instead of 64).
 // K (positions) is split over workgroups; each split writes its partial dW / db (deterministic: summed by dsgcn_colsum).
 #include "common.h"
+#include "bn_jobs.h"
 
 namespace {
 
@@ -23,6 +24,8 @@ struct Wg2Args {
   const float* z; const float* gz; const float* A0; const float* B0;
   float* dwp; float* dbp; int pstride;
   int n, Ci, Co, L, cpn, total_chunks, cps, tm_tiles, tn_tiles;
+  int main_blocks;                 // workgroups of the weight gradient; the ones past them run the hosted BatchNorm jobs
+  BnCoefTable jobs;                // (bn_jobs.h) coefficient jobs of BatchNorms whose rows the DATA gradient before this launch wrote
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* p, int bytes) {
@@ -53,6 +56,11 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
   char* Xb = Db + 3 * TM * RB;                    // B3: [3][TN][RB] virtual-input terms
   f32x2* Cs = reinterpret_cast<f32x2*>(lds + TF);          // [TM] (A0, B0)
   f32x4* Ps = reinterpret_cast<f32x4*>(lds + TF + 2 * TM);  // [TN] (s1, h1, s2, h2)
+  if ((int)blockIdx.x >= a.main_blocks) {          // hosted BatchNorm coefficient jobs: the weight gradient is off the critical chain
+    bnj_dispatch(a.jobs, (int)blockIdx.x - a.main_blocks,
+                 [&](const BnCoefJob& J, int b) { bn_coef_rows_block<WG_NT>(J, b, reinterpret_cast<double (*)[8][2]>(lds)); });
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -302,6 +310,11 @@ __global__ __launch_bounds__(W3_NT, 2) void k_wg3(Wg2Args a) {
   char* B1p = B0p + BUF;
   f32x2* Cs = reinterpret_cast<f32x2*>(B1p + BUF);                 // [TM] (A0, B0)
   f32x4* Ps = reinterpret_cast<f32x4*>(Cs + TM);                   // [TN] (s1, h1, s2, h2)
+  if ((int)blockIdx.x >= a.main_blocks) {          // hosted BatchNorm coefficient jobs (see k_wg2)
+    bnj_dispatch(a.jobs, (int)blockIdx.x - a.main_blocks,
+                 [&](const BnCoefJob& J, int b) { bn_coef_rows_block<W3_NT>(J, b, reinterpret_cast<double (*)[8][2]>(lds)); });
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -630,16 +643,18 @@ __attribute__((visibility("hidden"))) int dsgcn_wg2(const float* x1, const float
                                                      const float* s2, const float* h2, int relu, const float* z,
                                                      const float* gz, const float* A0, const float* B0, float* dwp,
                                                      float* dbp, int pstride, int n, int Ci, int Co, int L,
-                                                     hipStream_t st) {
+                                                     hipStream_t st, const BnCoefTable* jobs) {
   Wg2Plan p;
   if (!wg2_plan(n, Ci, Co, L, &p)) return 0;
   Wg2Args a = {};
+  if (jobs) a.jobs = *jobs;
   a.x1 = x1; a.s1 = s1; a.h1 = h1; a.x2 = x2; a.s2 = s2; a.h2 = h2; a.relu = relu;
   a.z = z; a.gz = gz; a.A0 = A0; a.B0 = B0; a.dwp = dwp; a.dbp = dbp; a.pstride = pstride;
   a.n = n; a.Ci = Ci; a.Co = Co; a.L = L; a.cpn = p.cpn; a.total_chunks = p.chunks; a.cps = p.cps;
   a.tm_tiles = p.tm_tiles; a.tn_tiles = p.tn_tiles;
   const int tiles = p.tm_tiles * p.tn_tiles;
-  const dim3 grid(tiles > 1 ? (unsigned)((p.splits + 7) / 8 * 8 * tiles) : (unsigned)p.splits);
+  a.main_blocks = tiles > 1 ? (p.splits + 7) / 8 * 8 * tiles : p.splits;
+  const dim3 grid((unsigned)(a.main_blocks + bnj_total_blocks(a.jobs)));
   const bool has2 = x2 != nullptr, hasc = A0 != nullptr;
   if (p.v3) {
 #ifdef DSGCN_LAB                                   // the full 256 x 256 tile (key 17 = 256) measured slower in the step: lab builds only

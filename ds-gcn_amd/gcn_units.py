@@ -17,6 +17,8 @@ from typing import NamedTuple, Optional, Tuple
 import torch
 import torch.nn as nn
 
+import contextlib
+
 from . import kernels
 
 
@@ -188,13 +190,15 @@ class dgphgcn1(nn.Module):
         `down` are Sequential(conv, bn)."""
         return [(self.post, self.bn)]
 
-    def adjacency(self, xbar):
-        """Ahat (n, K*mid, V, V) from the time-averaged input xbar (n, Ci, V)."""
+    def adjacency(self, xbar, host=None):
+        """Ahat (n, K*mid, V, V) from the time-averaged input xbar (n, Ci, V).  host: a kernels.bn_batch whose waiting
+        finalize jobs K-B's launch carries."""
         c1, c2, cs, el = self.conv1, self.conv2, self.conv1_se, self.edge_linears
+        kw = {} if host is None else dict(host=host)
         return kernels.ops().dynadj(
             xbar, self.A, self.alpha, self.beta,
             c1.weight.flatten(1), c1.bias, c2.weight.flatten(1), c2.bias, cs.weight.flatten(1), cs.bias,
-            el.weight.flatten(1), el.bias, self.node_type_idx, self.edge_type_idx)
+            el.weight.flatten(1), el.bias, self.node_type_idx, self.edge_type_idx, **kw)
 
     def forward_deferred(self, x, xbar=None, x_res=None):
         """x_res: an alias of x for the residual operand (lets the caller route the gradients of the two uses of x
@@ -204,7 +208,18 @@ class dgphgcn1(nn.Module):
         if xbar is None:                          # first block: joint rows padded to 32 like fuse_out(want_tmean=32)'s
             xbar = ops.tmean(x, 32) if x.shape[-1] <= 32 else ops.tmean(x)
         fork = getattr(ops, 'side_branch', None)
-        if fork is None:
+        batch = getattr(ops, 'bn_batch', None)
+        if batch is not None and not getattr(ops, 'OVERLAP', False):
+            # `pre` conv first, K-B behind it: K-B (and its projection conv) read nothing of the `pre` BatchNorm, so its
+            # finalize rides in K-B's launch as extra workgroups (kernels.bn_batch) instead of a launch of its own between
+            # the conv and K-A; the backward mirrors it (K-A's rows -> the coefficient job hosted by K-B's backward)
+            with batch() as q:
+                zp, _, ap = conv_bn(x, None, None, None, False, self.pre[0], 1, False, self.pre[1])
+                ahat = self.adjacency(xbar, host=q)
+            ctxbn = getattr(ap[0], '_dsgcn_bn', None)
+            if ctxbn is not None:
+                ctxbn.host = True
+        elif fork is None:
             ahat = self.adjacency(xbar)
             zp, _, ap = conv_bn(x, None, None, None, False, self.pre[0], 1, False, self.pre[1])
         else:
@@ -213,10 +228,13 @@ class dgphgcn1(nn.Module):
             zp, _, ap = conv_bn(x, None, None, None, False, self.pre[0], 1, False, self.pre[1])
             br.join(ahat)
         y = ops.aggregate(zp, ap, True, ahat)
-        zo, _, ao = conv_bn(y, None, None, None, False, self.post, 1, False, self.bn)
         if self.down is None:
+            zo, _, ao = conv_bn(y, None, None, None, False, self.post, 1, False, self.bn)
             return Deferred(zo, ao, x_res, None, True)
-        zd, _, ad = conv_bn(x_res, None, None, None, False, self.down[0], 1, False, self.down[1])
+        # `post` and `down` are independent of one another: their two finalizes are one launch
+        with (batch() if batch is not None else contextlib.nullcontext()):
+            zo, _, ao = conv_bn(y, None, None, None, False, self.post, 1, False, self.bn)
+            zd, _, ad = conv_bn(x_res, None, None, None, False, self.down[0], 1, False, self.down[1])
         return Deferred(zo, ao, zd, ad, True)
 
     def forward(self, x, A=None):

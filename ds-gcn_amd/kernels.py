@@ -252,6 +252,7 @@ def _leafish(*tensors):
 def reset_leaf_uses():
     """Start of a step (TrainEngine._fwd_bwd): forget which leaves the previous step's forward registered."""
     _leaf_uses.clear()
+    _coef_wait.clear()                # (jobs a failed backward left waiting)
     _wsplit_state['epoch'] += 1
     _wsplit_state['in_step'] = True
 
@@ -468,10 +469,12 @@ BN_FEED = _os.environ.get('DSGCN_BN_FEED', '1') != '0'
 
 
 class BNCtx:
-    __slots__ = ('mean', 'var', 'gamma', 'eps', 'count', 'C', 'n_affine', 'coef')
+    __slots__ = ('mean', 'var', 'gamma', 'eps', 'count', 'C', 'n_affine', 'coef', 'host', 'queued')
 
     def __init__(self):
         self.coef = None
+        self.host = False           # its backward coefficients may wait for a hosting launch (K-B's backward)
+        self.queued = None          # the coefficient job that waits
 
 
 def _bn_attach(scale, bn, mean, var, gamma, eps, count, n_affine):
@@ -487,22 +490,170 @@ def _bn_of(scale):
     return getattr(scale, '_dsgcn_bn', None) if (scale is not None and BN_FEED) else None
 
 
-def _bn_feed(bn, part, k, i_ds, i_dh):
-    """consumer side, in backward: partial rows part (R, C, k) -> the producer's coefficients (one launch)."""
+# ---- BatchNorm micro-launches as jobs (csrc/bn_jobs.h; round 6) ---------------------------------------------------------
+# A step had ~110 dependent 4-5 us launches of k_bn_finalize / k_bn_coef_rows.  A job = the arguments of one of them; jobs
+# whose producers are independent of one another go out in ONE launch (`post` + `down`, transform + the block's residual
+# conv), and the `pre` BatchNorm's jobs ride as extra workgroups of K-B's launches, which sit between the `pre` conv and K-A
+# anyway.  Same blocks, same summation order: bit-identical to the single launches.  DSGCN_BN_BATCH=0 restores them.
+BN_BATCH = _os.environ.get('DSGCN_BN_BATCH', '1') == '1'
+_fin_queue = None            # list while a bn_batch() region is open: finalize jobs wait there
+_coef_wait = []              # coefficient jobs that wait for a hosting launch (see BNCtx.host)
+
+
+def _fin_job(partial, rows, Co, count, gamma, beta, eps, mean, var, scale, shift, n_affine):
+    j = native.BnFinJob(_ptr(partial), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), _ptr(scale), _ptr(shift), float(count),
+                        float(eps), int(rows), int(Co), int(n_affine))
+    j._keep = (partial, gamma, beta, mean, var, scale, shift)
+    return j
+
+
+def _launch_fin(jobs):
+    lib = native.lib()
+    for i in range(0, len(jobs), native.BN_JOBS_MAX):
+        chunk = jobs[i:i + native.BN_JOBS_MAX]
+        arr = (native.BnFinJob * len(chunk))(*chunk)
+        native.check(lib.dsgcn_bn_finalize_multi(arr, len(chunk), _stream()), 'dsgcn_bn_finalize_multi')
+
+
+def bn_finalize(partial, rows, Co, count, gamma, beta, eps, mean, var, scale, shift, n_affine):
+    """partial rows -> (mean, var, scale, shift): queued inside a bn_batch() region, launched otherwise."""
+    if _fin_queue is not None:
+        _fin_queue.append(_fin_job(partial, rows, Co, count, gamma, beta, eps, mean, var, scale, shift, n_affine))
+        return
+    rc = native.lib().dsgcn_bn_finalize(_ptr(partial), rows, Co, count, _ptr(gamma), _ptr(beta), float(eps), _ptr(mean),
+                                        _ptr(var), _ptr(scale), _ptr(shift), int(n_affine), _stream())
+    native.check(rc, 'dsgcn_bn_finalize')
+
+
+class bn_batch:
+    """``with bn_batch() as q:`` — the BatchNorm finalizes of the convs launched inside wait in ``q`` and go out as ONE launch
+    when the region closes (or as extra workgroups of a launch that takes them: ``dynadj(..., host=q)``).  ``with q.hold():``
+    is a region that closes WITHOUT launching: the jobs wait for a later ``with q:`` (the block's residual conv is issued
+    first, its finalize joins the transform conv's).  NOTHING between a conv and the launch of its job may read that conv's
+    (scale, shift): the caller states the independence by writing the region."""
+
+    def __init__(self):
+        self.jobs = []
+        self._stack = []
+
+    def _enter(self, flush):
+        global _fin_queue
+        self._stack.append((_fin_queue, flush))
+        if BN_BATCH:
+            _fin_queue = self.jobs
+        return self
+
+    def __enter__(self):
+        return self._enter(True)
+
+    def hold(self):
+        outer = self
+
+        class _Hold:
+            def __enter__(self):
+                return outer._enter(False)
+
+            def __exit__(self, *exc):
+                return outer.__exit__(*exc)
+        return _Hold()
+
+    def take(self):
+        jobs, self.jobs[:] = list(self.jobs), []
+        return jobs
+
+    def flush(self):
+        jobs = self.take()
+        if jobs:
+            _launch_fin(jobs)
+
+    def __exit__(self, *exc):
+        global _fin_queue
+        _fin_queue, flush = self._stack.pop()
+        if exc[0] is not None:
+            self.jobs[:] = []
+        elif flush:
+            self.flush()
+        return False
+
+
+def _coef_job(bn, part, k, i_ds, i_dh):
     C = bn.C
     R = part.numel() // (C * k)
     acc = bn.coef is not None
     if not acc:
         bn.coef = torch.empty((4, C), device=part.device, dtype=torch.float32)
-    rc = native.lib().dsgcn_bn_coef_rows(_ptr(part), R, C, k, i_ds, i_dh, _ptr(bn.mean), _ptr(bn.var), _ptr(bn.gamma),
-                                         bn.eps, bn.count, bn.n_affine, _ptr(bn.coef), int(acc), _stream())
-    native.check(rc, 'dsgcn_bn_coef_rows')
+    j = native.BnCoefJob(_ptr(part), _ptr(bn.mean), _ptr(bn.var), _ptr(bn.gamma), _ptr(bn.coef), float(bn.count),
+                         float(bn.eps), int(R), int(C), int(k), int(i_ds), int(i_dh), int(bn.n_affine), int(acc))
+    j._keep = (part, bn.mean, bn.var, bn.gamma, bn.coef)
+    return j
+
+
+def _launch_coef(jobs):
+    lib = native.lib()
+    for i in range(0, len(jobs), native.BN_JOBS_MAX):
+        chunk = jobs[i:i + native.BN_JOBS_MAX]
+        arr = (native.BnCoefJob * len(chunk))(*chunk)
+        native.check(lib.dsgcn_bn_coef_rows_multi(arr, len(chunk), _stream()), 'dsgcn_bn_coef_rows_multi')
+
+
+def _flush_coef_wait():
+    if _coef_wait:
+        jobs = [j for _, j in _coef_wait]
+        for bn, _ in _coef_wait:
+            bn.queued = None
+        _coef_wait.clear()
+        _launch_coef(jobs)
+
+
+def _bn_feed(bn, part, k, i_ds, i_dh):
+    """consumer side, in backward: partial rows part (R, C, k) -> the producer's coefficients (one launch; for a BatchNorm
+    marked ``host`` the job waits for K-B's backward launch, or for the producer's own backward, whichever comes first)."""
+    _bn_feed_multi([(bn, part, k, i_ds, i_dh)])
+
+
+def _job_array(jobs):
+    """-> (ctypes array | None, count) for the `jobs, njobs` arguments of a hosting entry point"""
+    return ((native.BnCoefJob * len(jobs))(*jobs) if jobs else None), len(jobs)
+
+
+def _bn_feed_multi(feeds, launch=True):
+    """several consumers' rows in one launch (the two BatchNorms of a two-stream operand: `post` + `down`, ...).
+    launch=False: -> the jobs, for a caller whose NEXT launch hosts them (a weight gradient: nothing on the critical chain
+    waits for it, and the rows come from the data gradient before it) — [] when batching is off (launched here then)."""
+    if not BN_BATCH:
+        for bn, part, k, i_ds, i_dh in feeds:
+            C = bn.C
+            R = part.numel() // (C * k)
+            acc = bn.coef is not None
+            if not acc:
+                bn.coef = torch.empty((4, C), device=part.device, dtype=torch.float32)
+            rc = native.lib().dsgcn_bn_coef_rows(_ptr(part), R, C, k, i_ds, i_dh, _ptr(bn.mean), _ptr(bn.var), _ptr(bn.gamma),
+                                                 bn.eps, bn.count, bn.n_affine, _ptr(bn.coef), int(acc), _stream())
+            native.check(rc, 'dsgcn_bn_coef_rows')
+        return []
+    now = []
+    for bn, part, k, i_ds, i_dh in feeds:
+        if bn.queued is not None:            # a second consumer adds to what the first one's job writes: keep the order
+            _flush_coef_wait()
+        job = _coef_job(bn, part, k, i_ds, i_dh)
+        if bn.host:
+            bn.queued = job
+            _coef_wait.append((bn, job))
+        else:
+            now.append(job)
+    if not launch and len(now) <= native.BN_JOBS_MAX:
+        return now
+    if now:
+        _launch_coef(now)
+    return []
 
 
 def _bn_coef(bn, gscale, gshift, mean, var, gamma, eps, count, C, n_affine):
     """producer side, in backward: -> (dgamma, dbeta, A0, B0) or four Nones when nothing reached the BatchNorm."""
     coef = None
     if bn is not None:
+        if bn.queued is not None:           # no hosting launch came by: the job goes out now
+            _flush_coef_wait()
         coef, bn.coef = bn.coef, None
     if gscale is not None or gshift is not None:
         c2 = torch.empty((4, C), device=mean.device, dtype=torch.float32)
@@ -571,7 +722,8 @@ class _DynAdj(torch.autograd.Function):
     (K-B, one HIP launch each way)."""
 
     @staticmethod
-    def forward(ctx, proj, A, alpha, beta, we, be, node_type, edge_type, single_use=True):
+    def forward(ctx, proj, A, alpha, beta, we, be, node_type, edge_type, single_use=True, host=None):
+        """host: a ``bn_batch`` whose waiting finalize jobs ride in this launch as extra workgroups."""
         _require_cuda(proj, A)
         proj, A, alpha, beta, we, be = [_f32c(t) for t in (proj, A, alpha, beta, we, be)]
         n, R, ld = proj.shape
@@ -581,9 +733,15 @@ class _DynAdj(torch.autograd.Function):
         P = (R // mid - 4)
         assert A.shape[0] == 3 and node_type.dtype == torch.int32 and edge_type.dtype == torch.int32
         ahat = torch.empty((n, 3 * mid, V, V), device=proj.device, dtype=torch.float32)
-        rc = native.lib().dsgcn_dynadj_fwd(_ptr(proj), _ptr(A), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be),
-                                           _ptr(node_type), _ptr(edge_type), _ptr(ahat), n, mid, V, ld, P, E, _stream())
-        native.check(rc, 'dsgcn_dynadj_fwd')
+        jobs = host.take() if host is not None else []
+        if len(jobs) > native.BN_JOBS_MAX:
+            _launch_fin(jobs)
+            jobs = []
+        arr = (native.BnFinJob * len(jobs))(*jobs) if jobs else None
+        rc = native.lib().dsgcn_dynadj_fwd_jobs(_ptr(proj), _ptr(A), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be),
+                                                _ptr(node_type), _ptr(edge_type), _ptr(ahat), n, mid, V, ld, P, E, arr,
+                                                len(jobs), _stream())
+        native.check(rc, 'dsgcn_dynadj_fwd_jobs')
         ctx.save_for_backward(proj, alpha, beta, we, be, node_type, edge_type)
         ctx.dims = (n, mid, V, ld, P, E)
         ctx.defer_ok = bool(single_use) and _leafish(A, alpha, beta, we, be)
@@ -600,19 +758,26 @@ class _DynAdj(torch.autograd.Function):
         dproj = torch.empty_like(proj)
         pstride = lib.dsgcn_dynadj_partial_stride(mid, V, E)
         ppar = torch.empty((n, pstride), device=dev, dtype=torch.float32)      # per-sample parameter-gradient partials
-        rc = lib.dsgcn_dynadj_bwd(_ptr(proj), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be), _ptr(node_type),
-                                  _ptr(edge_type), _ptr(dahat), _ptr(dd), _ptr(dproj), _ptr(ppar), pstride, n, mid, V, ld,
-                                  P, E, _stream())
-        native.check(rc, 'dsgcn_dynadj_bwd')
+        # coefficient jobs that wait for a hosting launch (the `pre` BatchNorm's, queued by K-A's backward) ride here
+        waiting = _coef_wait[:native.BN_JOBS_MAX]
+        del _coef_wait[:len(waiting)]
+        for bn, _ in waiting:
+            bn.queued = None
+        jobs = [j for _, j in waiting]
+        arr = (native.BnCoefJob * len(jobs))(*jobs) if jobs else None
+        rc = lib.dsgcn_dynadj_bwd_jobs(_ptr(proj), _ptr(alpha), _ptr(beta), _ptr(we), _ptr(be), _ptr(node_type),
+                                       _ptr(edge_type), _ptr(dahat), _ptr(dd), _ptr(dproj), _ptr(ppar), pstride, n, mid, V,
+                                       ld, P, E, arr, len(jobs), _stream())
+        native.check(rc, 'dsgcn_dynadj_bwd_jobs')
         red = param_colsum(ppar, ctx.defer_ok)                                  # ordered sum over samples: deterministic
         o = 3 * V * V
         dA, dalpha, dbeta = red[:o].view(3, V, V), red[o:o + 3], red[o + 3:o + 6]
         dwe = red[o + 6:o + 6 + E * mid * mid].view(E * mid, mid)
         dbe = red[o + 6 + E * mid * mid:o + 6 + E * mid * mid + E * mid]
-        return dproj, dA, dalpha, dbeta, dwe, dbe, None, None, None
+        return dproj, dA, dalpha, dbeta, dwe, dbe, None, None, None, None
 
 
-def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type, single_use=True):
+def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, edge_type, single_use=True, host=None):
     """Dynamic adjacency.  The three mean-pooled projections (conv1/conv2/conv1_se) are one K-C launch on xbar — viewed
     as a (n, Ci, 1, 32) "clip" with the joint rows zero-padded to 32, so that forward, data gradient and weight gradient
     all take the 16-byte-per-lane K-C kernels (an unpadded 25-joint row is odd-sized: it fell to the scalar-load kernels,
@@ -627,7 +792,7 @@ def dynadj(xbar, A, alpha, beta, w1, b1, w2, b2, wse, bse, we, be, node_type, ed
     # single_use: every parameter passed here is used by this call only in the step (their gradient partials may then join
     # the end-of-backward sum, see param_colsum); dggcn feeds A to two calls and says so
     return _DynAdj.apply(proj.view(n, w_all.shape[0], xpad.shape[-1]), A, alpha, beta, we, be, node_type, edge_type,
-                         bool(single_use))
+                         bool(single_use), host)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -687,9 +852,7 @@ class _PwConv(torch.autograd.Function):
         if want_bn:
             stats = torch.empty((4, Co), device=dev, dtype=torch.float32)
             mean, var, scale, shift = stats[0], stats[1], stats[2], stats[3]
-            rc = lib.dsgcn_bn_finalize(_ptr(partial), partial.shape[0], Co, count, _ptr(gamma), _ptr(beta), float(eps),
-                                       _ptr(mean), _ptr(var), _ptr(scale), _ptr(shift), int(n_affine), _stream())
-            native.check(rc, 'dsgcn_bn_finalize')
+            bn_finalize(partial, partial.shape[0], Co, count, gamma, beta, eps, mean, var, scale, shift, n_affine)
             ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)      # no zero tensors for the unused / non-differentiable outputs (mean, var)
         ctx.save_for_backward(x1, s1, h1, x2, s2, h2, w2, z, zaug, gamma, mean, var, ws)
@@ -760,17 +923,27 @@ class _PwConv(torch.autograd.Function):
         splits = lib.dsgcn_pwconv_wgrad_splits(n, Ci, Co, T, V, stride)
         pstride = Co * Ci + Co
         wpart = torch.empty((splits, pstride), device=dev, dtype=torch.float32)
-        rc = lib.dsgcn_pwconv_wgrad(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(z),
-                                    _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), wpart.data_ptr(),
-                                    wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, stride, aug, st)
-        native.check(rc, 'dsgcn_pwconv_wgrad')
+        sink = ctx.sink is not None and bool(ctx.sink)
+        # the input BatchNorms' coefficient jobs (rows: the data gradient above) ride in the weight gradient's launch
+        hosted, fed = [], False
+        if (ipart is not None and not (sink and _deferred is not None) and (s1 is None or ctx.bn1 is not None) and
+                (s2 is None or ctx.bn2 is not None)):
+            hosted = _bn_feed_multi(([(ctx.bn1, ipart, 3, 0, 1)] if s1 is not None else []) +
+                                    ([(ctx.bn2, ipart, 3, 2, 1)] if s2 is not None else []), launch=False)
+            fed = True
+        rc = lib.dsgcn_pwconv_wgrad_jobs(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), relu, _ptr(z),
+                                         _ptr(zaug), _ptr(gz), _ptr(gzaug), _ptr(A0), _ptr(B0), wpart.data_ptr(),
+                                         wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, stride, aug,
+                                         *_job_array(hosted), st)
+        native.check(rc, 'dsgcn_pwconv_wgrad_jobs')
         return _PwConv._finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma, has_beta,
-                               n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2, ctx.sink is not None and bool(ctx.sink))
+                               n_affine, ctx.defer_ok, ctx.bn1, ctx.bn2, sink, fed)
 
     @staticmethod
     def _finish(wpart, ipart, dx1, dx2, s1, s2, Co, Ci, wshape, has_bias, dgamma, dbeta, gamma, has_beta, n_affine,
-                defer_ok=False, bn1=None, bn2=None, sink=False):
-        """Ordered sums of the partial rows -> the gradient tuple of backward()."""
+                defer_ok=False, bn1=None, bn2=None, sink=False, already_fed=False):
+        """Ordered sums of the partial rows -> the gradient tuple of backward().  already_fed: the caller has handed the
+        input BatchNorms' coefficient jobs to a hosting launch."""
         if sink and _deferred is not None:
             # both sums deferred; the input-scale gradient goes on as the strided column 0 of the summed (Ci, 3) rows
             wsum = param_colsum(wpart, True)
@@ -781,12 +954,11 @@ class _PwConv(torch.autograd.Function):
             return (dx1, ds1, dh1, dx2, None, None, None, wsum[:Co * Ci].view(wshape), None, None, None, None, None, None,
                     None, None, None, None)
         fed = ipart is not None and (s1 is None or bn1 is not None) and (s2 is None or bn2 is not None)
-        if fed:
+        if fed and already_fed:
+            ipart = None
+        elif fed:
             # every affine of the virtual input belongs to a deferred BatchNorm that takes its coefficients directly
-            if s1 is not None:
-                _bn_feed(bn1, ipart, 3, 0, 1)
-            if s2 is not None:
-                _bn_feed(bn2, ipart, 3, 2, 1)
+            _bn_feed_multi(([(bn1, ipart, 3, 0, 1)] if s1 is not None else []) + ([(bn2, ipart, 3, 2, 1)] if s2 is not None else []))
             ipart = None
         if ipart is not None and (_deferred is None or not defer_ok):
             wsum, red = colsum_pair(wpart, ipart, split_last_b=True)
@@ -1241,8 +1413,10 @@ class _TemporalSplit(torch.autograd.Function):
                                        _ptr(dzaug), _ptr(part), n, C, T, V, stride, nbr, *tabs, _ptr_array(ws), st)
         native.check(rc, 'dsgcn_tms_split_dgrad')
         dscale = dshift = None
+        hosted = []
         if ctx.bn_in is not None:
-            _bn_feed(ctx.bn_in, part, 2, 0, 1)
+            # the branch BatchNorm's coefficient job rides in the weight gradient's launch below (nothing waits for that one)
+            hosted = _bn_feed_multi([(ctx.bn_in, part, 2, 0, 1)], launch=False)
         elif scale is not None:
             red = colsum(part, split_last=True)
             dscale, dshift = red[0], red[1]
@@ -1258,9 +1432,9 @@ class _TemporalSplit(torch.autograd.Function):
         dwp = (_ct.c_void_p * nbr)(*[base + 4 * o if t == 0 else None for t, o in zip(types, offs)])
         dbp = (_ct.c_void_p * nbr)(*[base + 4 * (o + bc * bc * 3) if t == 0 else None
                                      for t, o, bc in zip(types, offs, bcs)])
-        rc = lib.dsgcn_tms_split_wgrad(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), n_act, _ptr(ge), _ptr(doaug), n, C, T,
-                                       V, stride, nbr, *tabs, dwp, dbp, splits, pstride, st)
-        native.check(rc, 'dsgcn_tms_split_wgrad')
+        rc = lib.dsgcn_tms_split_wgrad_jobs(_ptr(z), _ptr(zaug), _ptr(scale), _ptr(shift), n_act, _ptr(ge), _ptr(doaug), n, C,
+                                            T, V, stride, nbr, *tabs, dwp, dbp, splits, pstride, *_job_array(hosted), st)
+        native.check(rc, 'dsgcn_tms_split_wgrad_jobs')
         red = param_colsum(wpart, ctx.defer_ok)
         dws = [red[o:o + bc * bc * 3].view(bc, bc, 3, 1) if t == 0 else None for t, o, bc in zip(types, offs, bcs)]
         dbs = [red[o + bc * bc * 3:o + bc * bc * 3 + bc] if (t == 0 and hb) else None
@@ -1573,10 +1747,8 @@ class _TConvGemm(torch.autograd.Function):
         db = red[Co * Ci * KT:] if has_bias else None
         ds1 = dh1 = ds2 = dh2 = None
         if ipart is not None and (s1 is None or ctx.bn1 is not None) and (s2 is None or ctx.bn2 is not None):
-            if s1 is not None:
-                _bn_feed(ctx.bn1, ipart, 3, 0, 1)
-            if s2 is not None:
-                _bn_feed(ctx.bn2, ipart, 3, 2, 1)
+            _bn_feed_multi(([(ctx.bn1, ipart, 3, 0, 1)] if s1 is not None else []) +
+                           ([(ctx.bn2, ipart, 3, 2, 1)] if s2 is not None else []))
         elif ipart is not None:
             isum = colsum(ipart, split_last=True)
             if s1 is not None:
@@ -2183,10 +2355,8 @@ class _FuseOut(torch.autograd.Function):
         native.check(rc, 'dsgcn_fuse_out_bwd3s')
         ds1 = dh1 = ds2 = dh2 = None
         if need_part and (s1 is None or ctx.bn1 is not None) and (s2 is None or ctx.bn2 is not None):
-            if s1 is not None:
-                _bn_feed(ctx.bn1, part, 4, 0, 3)
-            if s2 is not None:
-                _bn_feed(ctx.bn2, part, 4, 2, 1)
+            _bn_feed_multi(([(ctx.bn1, part, 4, 0, 3)] if s1 is not None else []) +
+                           ([(ctx.bn2, part, 4, 2, 1)] if s2 is not None else []))
         elif need_part:
             red = colsum(part, split_last=True)
             if s1 is not None:
@@ -2230,10 +2400,8 @@ class _FuseOutPool(torch.autograd.Function):
         native.check(rc, 'dsgcn_fuse_out_pool_bwd')
         ds1 = dh1 = ds2 = dh2 = None
         if need_part and (s1 is None or ctx.bn1 is not None) and (s2 is None or ctx.bn2 is not None):
-            if s1 is not None:
-                _bn_feed(ctx.bn1, part, 4, 0, 3)
-            if s2 is not None:
-                _bn_feed(ctx.bn2, part, 4, 2, 1)
+            _bn_feed_multi(([(ctx.bn1, part, 4, 0, 3)] if s1 is not None else []) +
+                           ([(ctx.bn2, part, 4, 2, 1)] if s2 is not None else []))
         elif need_part:
             red = colsum(part, split_last=True)
             if s1 is not None:

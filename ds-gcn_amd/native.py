@@ -115,6 +115,12 @@ SIGNATURES = {
     'dsgcn_dynadj_partial_stride': [c_int, c_int, c_int],
     'dsgcn_dynadj_fwd': [c_f] * 6 + [c_i, c_i, c_f] + [c_int] * 6 + [c_st],
     'dsgcn_dynadj_bwd': [c_f] * 5 + [c_i, c_i] + [c_f] * 4 + [c_int] * 7 + [c_st],
+    'dsgcn_pwconv_wgrad_jobs': [c_f] * 6 + [c_int] + [c_f] * 8 + [c_int] * 8 + [ctypes.c_void_p, c_int, c_st],
+    'dsgcn_tms_split_wgrad_jobs': [c_f] * 4 + [c_int] + [c_f] * 2 + [c_int] * 6 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, ctypes.c_void_p, c_int, c_st],
+    'dsgcn_bn_finalize_multi': [ctypes.c_void_p, c_int, c_st],
+    'dsgcn_bn_coef_rows_multi': [ctypes.c_void_p, c_int, c_st],
+    'dsgcn_dynadj_fwd_jobs': [c_f] * 6 + [c_i, c_i, c_f] + [c_int] * 6 + [ctypes.c_void_p, c_int, c_st],
+    'dsgcn_dynadj_bwd_jobs': [c_f] * 5 + [c_i, c_i] + [c_f] * 4 + [c_int] * 7 + [ctypes.c_void_p, c_int, c_st],
     'dsgcn_head_loss_fwd': [c_f, c_f, c_f, c_i] + [c_int] * 4 + [ctypes.c_float] + [c_f] * 6 + [c_st],
     'dsgcn_head_loss_bwd': [c_f, c_f, c_f, c_i, c_f] + [c_int] * 4 + [ctypes.c_float] + [c_f] * 3 + [c_st],
     'dsgcn_data_bn_fwd': [c_f] * 10 + [c_int] * 7 + [ctypes.c_float, ctypes.c_float, c_st],
@@ -124,6 +130,26 @@ SIGNATURES = {
                                ctypes.POINTER(ctypes.c_float), c_int, c_st],
 }
 
+
+
+
+class BnFinJob(ctypes.Structure):
+    """include/dsgcn_jobs.h: dsgcn_bn_fin_job"""
+    _fields_ = [('partial', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p),
+                ('mean', ctypes.c_void_p), ('var', ctypes.c_void_p), ('scale', ctypes.c_void_p), ('shift', ctypes.c_void_p),
+                ('count', ctypes.c_double), ('eps', ctypes.c_float), ('nblk', ctypes.c_int), ('C', ctypes.c_int),
+                ('c_affine', ctypes.c_int)]
+
+
+class BnCoefJob(ctypes.Structure):
+    """include/dsgcn_jobs.h: dsgcn_bn_coef_job"""
+    _fields_ = [('part', ctypes.c_void_p), ('mean', ctypes.c_void_p), ('var', ctypes.c_void_p), ('gamma', ctypes.c_void_p),
+                ('coef', ctypes.c_void_p), ('count', ctypes.c_double), ('eps', ctypes.c_float), ('R', ctypes.c_int),
+                ('C', ctypes.c_int), ('k', ctypes.c_int), ('i_ds', ctypes.c_int), ('i_dh', ctypes.c_int),
+                ('c_affine', ctypes.c_int), ('accumulate', ctypes.c_int)]
+
+
+BN_JOBS_MAX = 4
 
 SIZE_T_RESULTS = {'dsgcn_pwconv_wsplit_bytes', 'dsgcn_tconv_ws_bytes'}      # everything else returns an int status / count
 

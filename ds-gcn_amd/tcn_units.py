@@ -7,6 +7,8 @@ statistics; one K-D kernel then does BN+ReLU, the four dilated 3-tap convs, the 
 strided pass-through and the local + global*add_coeff combine (tcn.py:416-420).
 ``unit_tcn`` (tcn.py:10-37): k=1 (block residual) is a strided channel mix; k>1 the dense temporal conv.
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -166,8 +168,10 @@ class dgmstcn(nn.Module):
         bns = [b[1] for b in self.branches if not isinstance(b, nn.Conv2d)]
         return [[c.weight for c in convs], [c.bias for c in convs], [bn.weight for bn in bns], [bn.bias for bn in bns]]
 
-    def forward_deferred(self, g):
-        """g: tensor or Deferred (the gcn output) -> Deferred(zt, affine of self.bn)."""
+    def forward_deferred(self, g, hold=None):
+        """g: tensor or Deferred (the gcn output) -> Deferred(zt, affine of self.bn).  hold: a kernels.bn_batch that already
+        holds the finalize job of an independent conv (the block's residual conv, issued first): the transform conv's job
+        joins it and the two go out as one launch."""
         ops = kernels.ops()
         d = as_deferred(g)
         n, _, T, V = d.x1.shape
@@ -204,7 +208,8 @@ class dgmstcn(nn.Module):
             f = ops.temporal_ms(z, zaug, scale, shift, self.n_act, self.ms_cfg, self.widths, tw, tb, self.add_coeff,
                                 self.stride)[0]
             a1 = eval_affine(bn1)
-        zt, _, a2 = conv_bn(f, a1, None, None, True, self.transform[2], 1, False, self.bn)
+        with (hold if hold is not None else contextlib.nullcontext()):
+            zt, _, a2 = conv_bn(f, a1, None, None, True, self.transform[2], 1, False, self.bn)
         return Deferred(zt, a2, None, None, False)
 
     def forward(self, x):

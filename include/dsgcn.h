@@ -19,6 +19,7 @@
 #define DSGCN_H_
 
 #include <stddef.h>
+#include "dsgcn_jobs.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -62,6 +63,16 @@ int dsgcn_dynadj_fwd(const float* proj, const float* A, const float* alpha, cons
 int dsgcn_dynadj_bwd(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
                      const int* node_type, const int* edge_type, const float* dahat, float* dd_ws, float* dproj,
                      float* ppar, int pstride, int n, int mid, int V, int ld, int P, int E, void* stream);
+/* The same launches carrying BatchNorm jobs as extra workgroups (njobs <= DSGCN_BN_JOBS_MAX, host records): K-B runs between
+ * the `pre` conv and K-A (gcn.py:2236-2352), so the `pre` BatchNorm's finalize rides in dsgcn_dynadj_fwd_jobs and its
+ * backward coefficients (from K-A's partial rows) in dsgcn_dynadj_bwd_jobs — no launch of their own.  njobs = 0: the plain call. */
+int dsgcn_dynadj_fwd_jobs(const float* proj, const float* A, const float* alpha, const float* beta, const float* we,
+                          const float* be, const int* node_type, const int* edge_type, float* ahat, int n, int mid, int V,
+                          int ld, int P, int E, const dsgcn_bn_fin_job* jobs, int njobs, void* stream);
+int dsgcn_dynadj_bwd_jobs(const float* proj, const float* alpha, const float* beta, const float* we, const float* be,
+                          const int* node_type, const int* edge_type, const float* dahat, float* dd_ws, float* dproj,
+                          float* ppar, int pstride, int n, int mid, int V, int ld, int P, int E,
+                          const dsgcn_bn_coef_job* jobs, int njobs, void* stream);
 
 /* Block output (materialise once): out = relu?(x1*s1+h1 (+ x2*s2+h2 | + x2)), xbar = mean_t out (optional).
  * Replaces BN + residual add + ReLU of dgstgcn.py:63-65 / tcn.py:427 and x.mean(-2) of gcn.py:2246.
@@ -207,6 +218,12 @@ int dsgcn_bn_bwd_coef(const float* g_scale, const float* g_shift, const float* m
 int dsgcn_bn_coef_rows(const float* part, int R, int C, int k, int i_ds, int i_dh, const float* mean, const float* var,
                        const float* gamma, float eps, double count, int c_affine, float* coef, int accumulate,
                        void* stream);
+/* Up to DSGCN_BN_JOBS_MAX finalize / coefficient jobs (dsgcn_jobs.h: the argument lists above as records, in HOST memory —
+ * they travel in the kernel arguments) in ONE launch: BatchNorms whose producers are independent of one another (`post` and
+ * `down`, gcn.py:2165-2169,2215; transform and the block's residual conv, tcn.py:401-404 / dgstgcn.py:55-61).  Bit-identical
+ * to the single launches (same blocks, same summation order). */
+int dsgcn_bn_finalize_multi(const dsgcn_bn_fin_job* jobs, int njobs, void* stream);
+int dsgcn_bn_coef_rows_multi(const dsgcn_bn_coef_job* jobs, int njobs, void* stream);
 /* dz_eff of a conv with the global-joint column, materialised once: gz + A0 + B0*z + (gzaug + A0 + B0*zaug)/V. */
 int dsgcn_dz_eff_aug(const float* gz, const float* z, const float* gzaug, const float* zaug, const float* A0,
                      const float* B0, float* out, int n, int C, int T, int V, void* stream);
@@ -252,6 +269,13 @@ int dsgcn_pwconv_wgrad(const float* x1, const float* s1, const float* h1, const 
                        const float* h2, int relu, const float* z, const float* zaug, const float* gz,
                        const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int pstride, int n,
                        int Ci, int Co, int T, int V, int stride, int aug, void* stream);
+/* The same carrying BatchNorm coefficient jobs of the conv's INPUT BatchNorms (their partial rows come from the data gradient
+ * launched before): extra workgroups of the blocked kernels, one launch ahead of the first-generation ones. */
+int dsgcn_pwconv_wgrad_jobs(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                            const float* h2, int relu, const float* z, const float* zaug, const float* gz,
+                            const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int pstride, int n,
+                            int Ci, int Co, int T, int V, int stride, int aug, const dsgcn_bn_coef_job* jobs, int njobs,
+                            void* stream);
 
 /* ---- K-A': subset-summed aggregate (ST-GCN unit_gcn gcn.py:81-86, CTR-GCN unit_ctrgcn gcn.py:658,917-921) ----
  * y[n,c,t,w] = sum_k sum_u p[n,k*Co+c,t,u] * adj_k[u,w], adj_k at ahat + n*a_ns + k*a_ks + c*a_cs (element strides):
@@ -407,6 +431,13 @@ int dsgcn_tms_split_wgrad(const float* z, const float* zaug, const float* scale,
                           const float* ge, const float* doaug, int n, int C, int T, int V, int stride, int nbr,
                           const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp, float* const* dbp,
                           int splits, int pstride, void* stream);
+/* The weight gradient carrying BatchNorm coefficient jobs (njobs <= DSGCN_BN_JOBS_MAX, host records) as extra workgroups:
+ * the branch BatchNorm's rows come from dsgcn_tms_split_dgrad, nothing waits for the weight gradient. */
+int dsgcn_tms_split_wgrad_jobs(const float* z, const float* zaug, const float* scale, const float* shift, int n_act,
+                               const float* ge, const float* doaug, int n, int C, int T, int V, int stride, int nbr,
+                               const int* type, const int* c0, const int* bc, const int* dil, float* const* dwp,
+                               float* const* dbp, int splits, int pstride, const dsgcn_bn_coef_job* jobs, int njobs,
+                               void* stream);
 
 /* AAGCN attention gates (csrc/aagcn.hip; reference gcn.py:447-459: y <- y * sigmoid(.) + y, three times).
  * out = y * (1 + g), g broadcast by mode: 0 g (n, V) per joint, 1 g (n, T) per frame, 2 g (n, C) per channel;

@@ -1,0 +1,32 @@
+/* Job records of the batched BatchNorm micro-reductions (included by dsgcn.h; plain C, no dependencies).
+ * A record is the argument list of dsgcn_bn_finalize / dsgcn_bn_coef_rows as a struct, so that several of them can ride
+ * in one launch (dsgcn_bn_finalize_multi, dsgcn_bn_coef_rows_multi) or as extra workgroups of a launch that sits between
+ * the BatchNorm's producer and its consumer anyway (dsgcn_dynadj_fwd_jobs / _bwd_jobs). */
+#ifndef DSGCN_JOBS_H
+#define DSGCN_JOBS_H
+
+#define DSGCN_BN_JOBS_MAX 4
+
+typedef struct {
+  const float* partial;            /* (nblk, C, 2) per-block sums of z and z^2 */
+  const float* gamma;              /* (C) or NULL = 1 */
+  const float* beta;               /* (C) or NULL = 0 */
+  float* mean; float* var;         /* (C) out: batch mean, biased variance */
+  float* scale; float* shift;      /* (C) out: gamma*rsqrt(var+eps), beta - mean*scale (identity for c >= c_affine) */
+  double count;                    /* elements per channel */
+  float eps;
+  int nblk, C, c_affine;
+} dsgcn_bn_fin_job;
+
+typedef struct {
+  const float* part;               /* (R, C, k) a consumer's partial rows */
+  const float* mean; const float* var;
+  const float* gamma;              /* (C) or NULL = 1 */
+  float* coef;                     /* (4, C) out / in-out: [d gamma | d beta | A0 | B0] */
+  double count;
+  float eps;
+  int R, C, k, i_ds, i_dh;         /* columns of part holding the partial sums of d scale / d shift */
+  int c_affine, accumulate;        /* accumulate != 0: add to coef (a second consumer of the same BatchNorm) */
+} dsgcn_bn_coef_job;
+
+#endif

@@ -136,6 +136,133 @@ def _rand(g, *shape, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
+def test_bn_jobs_batched_and_hosted_are_bit_identical():
+    """Round 6 (csrc/bn_jobs.h): BatchNorm finalize / coefficient launches as jobs.  (i) dsgcn_bn_finalize_multi and
+    dsgcn_bn_coef_rows_multi with jobs of different widths and row counts (and an accumulating second consumer) against the
+    single launches; (ii) the same jobs hosted as extra workgroups of K-B's launches (dsgcn_dynadj_fwd_jobs / _bwd_jobs) —
+    outputs AND K-B's own results bit-identical to the plain calls."""
+    from dsgcn_amd import native
+    lib = native.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(21)
+    P = lambda t: None if t is None else t.data_ptr()
+    specs = [(400, 24, 24, True), (1600, 256, 200, True), (37, 70, 70, False), (800, 96, 96, True)]    # rows, C, c_affine, gamma?
+    fin = []
+    for rows, C, ca, hasg in specs:
+        part = (_rand(g, rows, C, 2).abs() + 0.1).to(DEV)
+        part[..., 1] += part[..., 0] ** 2 + 1.0
+        gamma = (torch.rand(C, generator=g) + 0.5).to(DEV) if hasg else None
+        beta = _rand(g, C, scale=0.2).to(DEV) if hasg else None
+        fin.append(dict(part=part, gamma=gamma, beta=beta, rows=rows, C=C, ca=ca, count=float(rows * 97)))
+
+    def fin_single(f):
+        out = torch.empty(4, f['C'], device=DEV)
+        native.check(lib.dsgcn_bn_finalize(P(f['part']), f['rows'], f['C'], f['count'], P(f['gamma']), P(f['beta']), 1e-5,
+                                           P(out[0]), P(out[1]), P(out[2]), P(out[3]), f['ca'], st), 'fin')
+        return out
+
+    def fin_jobs(outs):
+        return (native.BnFinJob * len(fin))(*[native.BnFinJob(P(f['part']), P(f['gamma']), P(f['beta']), P(o[0]), P(o[1]), P(o[2]),
+                                                              P(o[3]), f['count'], 1e-5, f['rows'], f['C'], f['ca'])
+                                              for f, o in zip(fin, outs)])
+    want = [fin_single(f) for f in fin]
+    got = [torch.full((4, f['C']), float('nan'), device=DEV) for f in fin]
+    native.check(lib.dsgcn_bn_finalize_multi(fin_jobs(got), len(fin), st), 'fin_multi')
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert lib.dsgcn_bn_finalize_multi(fin_jobs(got), 5, st) == -1 and lib.dsgcn_bn_finalize_multi(None, 1, st) == -1
+
+    # coefficient jobs: k = 2 / 3 / 4 columns, the last one accumulating into coefficients that already hold a consumer's share
+    cspecs = [(400, 24, 2, 0, 1, 0), (1200, 256, 3, 2, 1, 0), (55, 70, 4, 0, 3, 0), (800, 96, 3, 0, 1, 1)]
+    coef = []
+    for (R_, C, k, ids, idh, acc), w in zip(cspecs, want):
+        coef.append(dict(part=_rand(g, R_, C, k).to(DEV), R=R_, C=C, k=k, ids=ids, idh=idh, acc=acc, mean=w[0].clone(),
+                         var=w[1].clone(), gamma=(torch.rand(C, generator=g) + 0.5).to(DEV), init=_rand(g, 4, C).to(DEV)))
+
+    def coef_single(c):
+        out = c['init'].clone()
+        native.check(lib.dsgcn_bn_coef_rows(P(c['part']), c['R'], c['C'], c['k'], c['ids'], c['idh'], P(c['mean']), P(c['var']),
+                                            P(c['gamma']), 1e-5, float(c['R'] * 31), c['C'], P(out), c['acc'], st), 'coef')
+        return out
+
+    def coef_jobs(outs):
+        return (native.BnCoefJob * len(coef))(*[native.BnCoefJob(P(c['part']), P(c['mean']), P(c['var']), P(c['gamma']), P(o),
+                                                                 float(c['R'] * 31), 1e-5, c['R'], c['C'], c['k'], c['ids'],
+                                                                 c['idh'], c['C'], c['acc']) for c, o in zip(coef, outs)])
+    cwant = [coef_single(c) for c in coef]
+    cgot = [c['init'].clone() for c in coef]
+    native.check(lib.dsgcn_bn_coef_rows_multi(coef_jobs(cgot), len(coef), st), 'coef_multi')
+    for a, b in zip(cgot, cwant):
+        assert torch.equal(a, b)
+
+    # hosted in K-B's launches
+    n, Ci, mid, V = 6, 64, 16, 25
+    t, nt, et = _dyn_inputs(n, Ci, mid, V, 'nturgb+d', seed=5)
+    E, Pn = 15, 5
+    proj = _rand(g, n, (4 + Pn) * mid, 32).to(DEV)
+    A, alpha, beta = t['A'].to(DEV), t['alpha'].to(DEV), t['beta'].to(DEV)
+    we, be = t['we'].to(DEV).contiguous(), t['be'].to(DEV).contiguous()
+    nt, et = nt.to(DEV), et.to(DEV)
+    ah0 = torch.empty(n, 3 * mid, V, V, device=DEV)
+    native.check(lib.dsgcn_dynadj_fwd(P(proj), P(A), P(alpha), P(beta), P(we), P(be), P(nt), P(et), P(ah0), n, mid, V, 32, Pn, E,
+                                      st), 'dyn')
+    ah1 = torch.empty_like(ah0)
+    got = [torch.full((4, f['C']), float('nan'), device=DEV) for f in fin]
+    native.check(lib.dsgcn_dynadj_fwd_jobs(P(proj), P(A), P(alpha), P(beta), P(we), P(be), P(nt), P(et), P(ah1), n, mid, V, 32,
+                                           Pn, E, fin_jobs(got), len(fin), st), 'dyn_jobs')
+    assert torch.equal(ah0, ah1)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    dah = _rand(g, n, 3 * mid, V, V).to(DEV)
+    ps = lib.dsgcn_dynadj_partial_stride(mid, V, E)
+
+    def bwd(jobs, nj):
+        dd, dproj, ppar = torch.empty_like(dah), torch.empty_like(proj), torch.empty(n, ps, device=DEV)
+        native.check(lib.dsgcn_dynadj_bwd_jobs(P(proj), P(alpha), P(beta), P(we), P(be), P(nt), P(et), P(dah), P(dd), P(dproj),
+                                               P(ppar), ps, n, mid, V, 32, Pn, E, jobs, nj, st), 'dyn_bwd_jobs')
+        return dproj, ppar
+    d0 = bwd(None, 0)
+    cgot = [c['init'].clone() for c in coef]
+    d1 = bwd(coef_jobs(cgot), len(coef))
+    assert torch.equal(d0[0], d1[0]) and torch.equal(d0[1], d1[1])
+    for a, b in zip(cgot, cwant):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('kind', ['ds', 'ds_k400'])
+def test_bn_batching_leaves_the_step_bit_identical(kind, monkeypatch):
+    """The model with DSGCN_BN_BATCH on (jobs batched / hosted, `pre` conv ahead of K-B, the block's residual conv ahead of
+    the temporal unit) against the single launches: logits, loss and EVERY gradient bit for bit — the jobs run the same
+    blocks in the same summation order, and no kernel's inputs change."""
+    from bench import ds_cfg
+    import numpy as np
+    cfg = ds_cfg(60) if kind == 'ds' else ds_cfg(400, 'coco')
+    T, V = (32, 25) if kind == 'ds' else (20, 17)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 1, 2, T, V, 3, generator=g).to(DEV)
+    y = torch.randint(0, 60, (3, 1), generator=g).to(DEV)
+    res = []
+    for flag in (False, True):
+        monkeypatch.setattr(K, 'BN_BATCH', flag)
+        np.random.seed(0)
+        torch.manual_seed(0)
+        m = dsgcn_amd.build_model(cfg).to(DEV).train()
+        with torch.no_grad():
+            for k_, p_ in m.named_parameters():
+                if k_.endswith(('alpha', 'beta', 'add_coeff')):
+                    p_.normal_(0, 0.5)
+        out = m.train_step(dict(keypoint=x, label=y), None, sync_log_vars=False)
+        out['loss'].backward()
+        res.append((out['loss'].detach().clone(), {k_: p_.grad.clone() for k_, p_ in m.named_parameters() if p_.grad is not None},
+                    {k_: b_.clone() for k_, b_ in m.named_buffers()}))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys()
+    for k_ in res[0][1]:
+        assert torch.equal(res[0][1][k_], res[1][1][k_]), k_
+    for k_ in res[0][2]:
+        assert torch.equal(res[0][2][k_], res[1][2][k_]), k_
+
+
 @pytest.mark.parametrize('n,Ci,Co,T,V,stride,aug,mode', [
     (3, 3, 24, 64, 25, 1, False, 'plain'),        # block-0 pre conv
     (2, 64, 64, 64, 25, 1, True, 'res_plain'),    # tcn branch conv: relu(bn(zo)+x), global joint
