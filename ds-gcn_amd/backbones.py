@@ -79,8 +79,12 @@ class _FusedBlock(nn.Module):
             t = self.tcn.forward_deferred(g, hold=hold)
         else:
             t = self.tcn.forward_deferred(g)
+        drop_p = 0.0
         if getattr(self.tcn, 'drop', None) is not None and self.tcn.drop.p > 0 and self.training:
-            t = type(t)(self.tcn.drop(t.materialize()), None, None, None, False)
+            if getattr(kernels.ops(), 'DROPOUT_FUSED', False) and self.tcn.drop.p < 1:
+                drop_p = float(self.tcn.drop.p)      # applied inside fuse_out below: no mask tensor, no pass of its own
+            else:
+                t = type(t)(self.tcn.drop(t.materialize()), None, None, None, False)
         x2 = a2 = None
         if self.residual_kind == 'identity':
             x2 = x
@@ -90,9 +94,10 @@ class _FusedBlock(nn.Module):
             x2, a2 = r.x1, r.a1
         assert t.x2 is None
         # t.relu: the temporal unit ends in its own ReLU (CTR-GCN's MSTCN) -> ReLU on the first term, then add + ReLU
+        kw = dict(dropout=drop_p) if drop_p > 0 else {}
         if pool:                # the last block under a pooling head: only the plane means (n, C) leave the block
-            return kernels.ops().fuse_out_pool(t.x1, t.a1, x2, a2, 3 if t.relu else 1), None
-        return kernels.ops().fuse_out(t.x1, t.a1, x2, a2, 3 if t.relu else 1, want_xbar and self.xbar_ld, tee)
+            return kernels.ops().fuse_out_pool(t.x1, t.a1, x2, a2, 3 if t.relu else 1, **kw), None
+        return kernels.ops().fuse_out(t.x1, t.a1, x2, a2, 3 if t.relu else 1, want_xbar and self.xbar_ld, tee, **kw)
 
     def forward(self, x, A=None):
         out = self.forward_fused(x)[0]

@@ -11,6 +11,8 @@
 //           per-plane partial sums of dv1*x1, dv, dv*x2, dv1  (-> d s1, d h2, d s2, d h1 after the sum over n;
 //           dv1 = dv unless the first term has its own ReLU).
 #include "common.h"
+#include "dropout.h"
+#include "dsgcn_jobs.h"
 
 namespace {
 
@@ -19,12 +21,14 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
                                                      const float* __restrict__ s2, const float* __restrict__ h2,
                                                      int relu, float* __restrict__ out, float* __restrict__ xbar, int C,
                                                      int T, int V, int vec, int ld, float* __restrict__ out_s2,
-                                                     float* __restrict__ pmean) {
+                                                     float* __restrict__ pmean, DropArgs dr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   const long plane = blockIdx.x;
   const int c = (int)(plane % C);
   const int L = T * V;
+  const bool drop = dr.thresh != 0;                // (wave-uniform)
+  const unsigned long long dstep = (drop && dr.step) ? (unsigned long long)*dr.step : 0ull;
   const float a1 = s1 ? s1[c] : 1.f, b1 = s1 ? h1[c] : 0.f;
   const float a2 = s2 ? s2[c] : 1.f, b2 = s2 ? h2[c] : 0.f;
   const float* p1 = x1 + (size_t)plane * L;
@@ -42,6 +46,12 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
       f32x4 v = q1[i];
       v.x = fmaf(v.x, a1, b1); v.y = fmaf(v.y, a1, b1); v.z = fmaf(v.z, a1, b1); v.w = fmaf(v.w, a1, b1);
       if (relu & 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (drop) {                                 // dropout on the first term (the temporal unit's output), before the residual
+        unsigned rw[4];
+        drop_words(dr, dstep, (unsigned long long)plane * L4 + i, rw);
+        v.x *= rw[0] >= dr.thresh ? dr.inv : 0.f; v.y *= rw[1] >= dr.thresh ? dr.inv : 0.f;
+        v.z *= rw[2] >= dr.thresh ? dr.inv : 0.f; v.w *= rw[3] >= dr.thresh ? dr.inv : 0.f;
+      }
       if (p2) {
         const f32x4 r = q2[i];
         v.x += fmaf(r.x, a2, b2); v.y += fmaf(r.y, a2, b2); v.z += fmaf(r.z, a2, b2); v.w += fmaf(r.w, a2, b2);
@@ -55,6 +65,7 @@ __global__ __launch_bounds__(64) void k_fuse_out_fwd(const float* __restrict__ x
     for (int i = lane; i < L; i += 64) {
       float v = fmaf(p1[i], a1, b1);
       if (relu & 2) v = fmaxf(v, 0.f);
+      if (drop) v *= drop_mult(dr, dstep, (unsigned long long)plane * L + i);
       if (p2) v += fmaf(p2[i], a2, b2);
       if (relu & 1) v = fmaxf(v, 0.f);
       if (po) po[i] = v;
@@ -111,12 +122,14 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
                                                      const float* __restrict__ dout2, const float* __restrict__ dout3,
                                                      const float* __restrict__ dxbar, float* __restrict__ dx1,
                                                      float* __restrict__ dx2, float* __restrict__ part, int C, int T,
-                                                     int V, int ld, int s3) {
+                                                     int V, int ld, int s3, DropArgs dr) {
   __shared__ float dxb[32];
   const int lane = threadIdx.x;
   const long plane = blockIdx.x;
   const int c = (int)(plane % C);
   const int L = T * V;
+  const bool drop = dr.thresh != 0;
+  const unsigned long long dstep = (drop && dr.step) ? (unsigned long long)*dr.step : 0ull;
   const float a1 = s1 ? s1[c] : 1.f, b1 = s1 ? h1[c] : 0.f;
   const float a2 = s2 ? s2[c] : 1.f, b2 = s2 ? h2[c] : 0.f;
   if (lane < V) dxb[lane] = dxbar ? dxbar[(size_t)plane * ld + lane] / (float)T : 0.f;
@@ -139,6 +152,8 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
     const float xb = p2 ? p2[i] : 0.f;
     const float pre1 = fmaf(xa, a1, b1);
     float pre = (relu & 2) ? fmaxf(pre1, 0.f) : pre1;
+    const float dm = drop ? drop_mult(dr, dstep, (unsigned long long)plane * L + i) : 1.f;     // the forward's dropout multiplier
+    pre *= dm;
     if (p2) pre += fmaf(xb, a2, b2);
     float g = s3 == 3 ? gpl : (pg ? pg[i] : 0.f);
     if (pg2) g += pg2[i];              // (a + b) + c, then the time-mean term: the order dsgcn_add3 + this kernel had
@@ -148,7 +163,7 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd(const float* __restrict__ x
     }
     g += dxb[v];
     if ((relu & 1) && !(pre > 0.f)) g = 0.f;
-    const float g1 = ((relu & 2) && !(pre1 > 0.f)) ? 0.f : g;     // gradient of the first term
+    const float g1 = (((relu & 2) && !(pre1 > 0.f)) ? 0.f : g) * dm;     // gradient of the first term (through its dropout)
     o1[i] = g1 * a1;
     if (o2) o2[i] = g * a2;
     u0 = fmaf(g1, xa, u0);
@@ -184,12 +199,14 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd4(const float* __restrict__ 
                                                       const float* __restrict__ dout2, const float* __restrict__ dout3,
                                                       const float* __restrict__ dxbar, float* __restrict__ dx1,
                                                       float* __restrict__ dx2, float* __restrict__ part, int C, int T,
-                                                      int V, int ld) {
+                                                      int V, int ld, DropArgs dr) {
   __shared__ float dxb[32];
   const int lane = threadIdx.x;
   const long plane = blockIdx.x;
   const int c = (int)(plane % C);
   const int L = T * V, L4 = L >> 2;
+  const bool drop = dr.thresh != 0;
+  const unsigned long long dstep = (drop && dr.step) ? (unsigned long long)*dr.step : 0ull;
   const float a1 = s1 ? s1[c] : 1.f, b1 = s1 ? h1[c] : 0.f;
   const float a2 = s2 ? s2[c] : 1.f, b2 = s2 ? h2[c] : 0.f;
   if (lane < V) dxb[lane] = dxbar ? dxbar[(size_t)plane * ld + lane] / (float)T : 0.f;
@@ -216,16 +233,23 @@ __global__ __launch_bounds__(64) void k_fuse_out_bwd4(const float* __restrict__ 
     int t, v;
     divmod_small(4 * i, V, invV, t, v);
     f32x4 r1, r2;
+    float dm[4] = {1.f, 1.f, 1.f, 1.f};            // the forward's dropout multipliers of these four elements
+    if (drop) {
+      unsigned rw[4];
+      drop_words(dr, dstep, (unsigned long long)plane * L4 + i, rw);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dm[k] = rw[k] >= dr.thresh ? dr.inv : 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float gg = g[k];
       if constexpr (S3) { if (!(t & 1)) gg += ps3[(t >> 1) * V + v]; }
       gg += dxb[v];
       const float pre1 = fmaf(xa[k], a1, b1);
-      float pre = (relu & 2) ? fmaxf(pre1, 0.f) : pre1;
+      float pre = ((relu & 2) ? fmaxf(pre1, 0.f) : pre1) * dm[k];
       if constexpr (X2) pre += fmaf(xb[k], a2, b2);
       if ((relu & 1) && !(pre > 0.f)) gg = 0.f;
-      const float g1 = ((relu & 2) && !(pre1 > 0.f)) ? 0.f : gg;
+      const float g1 = (((relu & 2) && !(pre1 > 0.f)) ? 0.f : gg) * dm[k];
       r1[k] = g1 * a1;
       r2[k] = gg * a2;
       u0 = fmaf(g1, xa[k], u0);
@@ -255,22 +279,56 @@ int g_fo_vec = 1;        // 16-byte backward where the plane allows it (lab A/B:
 
 }  // namespace
 
+namespace {
+
+// p <= 0 (or no record): dropout off
+DropArgs drop_args(const dsgcn_dropout* d) {
+  DropArgs a = {};
+  if (d && d->p > 0.f) {
+    a.step = d->step; a.seed = d->seed; a.call = d->call;
+    double t = (double)d->p * 4294967296.0;
+    a.thresh = t >= 4294967295.0 ? 4294967295u : (t < 1.0 ? 1u : (unsigned)t);
+    a.inv = 1.f / (1.f - d->p);
+  }
+  return a;
+}
+
+__global__ __launch_bounds__(256) void k_dropout_mask(float* __restrict__ mask, long numel, DropArgs dr) {
+  const unsigned long long step = dr.step ? (unsigned long long)*dr.step : 0ull;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < numel; e += (long)gridDim.x * 256)
+    mask[e] = dr.thresh ? drop_mult(dr, step, (unsigned long long)e) : 1.f;
+}
+
+}  // namespace
+
 extern "C" {
 
-int dsgcn_fuse_out_fwd2(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
-                        const float* h2, int relu, float* out, float* out_s2, float* xbar, int n, int C, int T, int V,
-                        int xbar_ld, void* stream);
-int dsgcn_fuse_out_bwd3s(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
-                         const float* h2, int relu, const float* dout, const float* dout2, const float* dout3, int stride3,
-                         const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
-                         void* stream);
+// The block output with dropout on its first term: out = relu?( D * relu2?(x1*s1+h1) + (x2*s2+h2 | x2) ), D = keep / (1 - p)
+// from the counter-based generator of csrc/dropout.h (reference: the Dropout behind the temporal unit's BatchNorm,
+// tcn.py:30,33, MSTCN msg3d_utils.py:141-146, then dgstgcn.py:63-65 / stgcn.py:64-66 add the residual and apply ReLU).
+// Any of out / out_s2 / xbar / pmean may be NULL (pmean (n*C): the plane means for a pooling head, the last block);
+// d NULL or d->p <= 0: no dropout — the plain fuse_out.
+int dsgcn_fuse_out_fwd_drop(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                            const float* h2, int relu, float* out, float* out_s2, float* xbar, float* pmean, int n, int C,
+                            int T, int V, int xbar_ld, const dsgcn_dropout* d, void* stream) {
+  if (!x1 || (!out && !pmean) || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (s1 && !h1) || (s2 && !h2)) return DSGCN_EINVAL;
+  if ((out_s2 || xbar) && !out) return DSGCN_EINVAL;
+  if (xbar && (xbar_ld < V || xbar_ld > 64)) return DSGCN_EINVAL;
+  if (d && !(d->p >= 0.f && d->p < 1.f)) return DSGCN_EINVAL;
+  const int vec = ((T * V) % 4 == 0) ? 1 : 0;
+  const size_t lds = (xbar || out_s2) ? (size_t)T * V * sizeof(float) : 0;
+  if (lds > 64 * 1024) return DSGCN_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_fuse_out_fwd, dim3((unsigned)((long)n * C)), dim3(64), lds, (hipStream_t)stream, x1, s1, h1, x2,
+                     s2, h2, relu, out, xbar, C, T, V, vec, xbar ? xbar_ld : V, out_s2, pmean, drop_args(d));
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
 
 int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                        const float* h2, int relu, float* out, float* xbar, int n, int C, int T, int V, int xbar_ld,
                        void* stream) {
-  if (!x1 || !out || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (s1 && !h1) || (s2 && !h2)) return DSGCN_EINVAL;
-  if (xbar && (xbar_ld < V || xbar_ld > 64)) return DSGCN_EINVAL;
-  return dsgcn_fuse_out_fwd2(x1, s1, h1, x2, s2, h2, relu, out, nullptr, xbar, n, C, T, V, xbar_ld, stream);
+  if (!out) return DSGCN_EINVAL;
+  return dsgcn_fuse_out_fwd_drop(x1, s1, h1, x2, s2, h2, relu, out, nullptr, xbar, nullptr, n, C, T, V, xbar_ld, nullptr, stream);
 }
 
 // out_s2 (NULL or (n, C, ceil(T/2), V)): the even frames of `out` as a second, contiguous output — the operand of a
@@ -278,15 +336,8 @@ int dsgcn_fuse_out_fwd(const float* x1, const float* s1, const float* h1, const 
 int dsgcn_fuse_out_fwd2(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                         const float* h2, int relu, float* out, float* out_s2, float* xbar, int n, int C, int T, int V,
                         int xbar_ld, void* stream) {
-  if (!x1 || !out || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (s1 && !h1) || (s2 && !h2)) return DSGCN_EINVAL;
-  if (xbar && (xbar_ld < V || xbar_ld > 64)) return DSGCN_EINVAL;
-  const int vec = ((T * V) % 4 == 0) ? 1 : 0;
-  const size_t lds = (xbar || out_s2) ? (size_t)T * V * sizeof(float) : 0;
-  if (lds > 64 * 1024) return DSGCN_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_fuse_out_fwd, dim3((unsigned)((long)n * C)), dim3(64), lds, (hipStream_t)stream, x1, s1, h1, x2,
-                     s2, h2, relu, out, xbar, C, T, V, vec, xbar_ld, out_s2, (float*)nullptr);
-  DSGCN_LAUNCH_CHECK();
-  return 0;
+  if (!out) return DSGCN_EINVAL;
+  return dsgcn_fuse_out_fwd_drop(x1, s1, h1, x2, s2, h2, relu, out, out_s2, xbar, nullptr, n, C, T, V, xbar_ld, nullptr, stream);
 }
 
 // The LAST block's output is only ever averaged over its (T, V) planes by the head (simple_head.py:88-93): pmean (n, C) =
@@ -294,65 +345,48 @@ int dsgcn_fuse_out_fwd2(const float* x1, const float* s1, const float* h1, const
 // backward the broadcast of the pooled gradient and its read are gone).
 int dsgcn_fuse_out_pool_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                             const float* h2, int relu, float* pmean, int n, int C, int T, int V, void* stream) {
-  if (!x1 || !pmean || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (s1 && !h1) || (s2 && !h2)) return DSGCN_EINVAL;
-  const int vec = ((T * V) % 4 == 0) ? 1 : 0;
-  hipLaunchKernelGGL(k_fuse_out_fwd, dim3((unsigned)((long)n * C)), dim3(64), 0, (hipStream_t)stream, x1, s1, h1, x2, s2,
-                     h2, relu, (float*)nullptr, (float*)nullptr, C, T, V, vec, V, (float*)nullptr, pmean);
-  DSGCN_LAUNCH_CHECK();
-  return 0;
+  if (!pmean) return DSGCN_EINVAL;
+  return dsgcn_fuse_out_fwd_drop(x1, s1, h1, x2, s2, h2, relu, nullptr, nullptr, nullptr, pmean, n, C, T, V, V, nullptr, stream);
 }
 
-// dpmean (n, C): gradient of the plane means; dx1 / dx2 / part as in dsgcn_fuse_out_bwd.
-int dsgcn_fuse_out_pool_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
-                            const float* h2, int relu, const float* dpmean, float* dx1, float* dx2, float* part, int n,
-                            int C, int T, int V, void* stream) {
-  if (!x1 || !dx1 || !dpmean || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (x2 && !dx2)) return DSGCN_EINVAL;
-  const dim3 grid((unsigned)((long)n * C)), blk(64);
-  hipStream_t st = (hipStream_t)stream;
-  if ((T * V) % 4 == 0) {
-    if (x2)
-      hipLaunchKernelGGL((k_fuse_out_bwd4<0, false, true>), grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, dpmean,
-                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dx1, dx2, part, C, T, V, V);
-    else
-      hipLaunchKernelGGL((k_fuse_out_bwd4<0, false, false>), grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, dpmean,
-                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dx1, dx2, part, C, T, V, V);
-  } else {
-    hipLaunchKernelGGL(k_fuse_out_bwd, grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, dpmean, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, dx1, dx2, part, C, T, V, V, 3);
-  }
-  DSGCN_LAUNCH_CHECK();
-  return 0;
-}
-
-// part: (n*C, 4) per-plane [sum dv1*x1, sum dv, sum dv*x2, sum dv1]; dout or dxbar may be NULL (treated as zero).
-// dout2 / dout3 (NULL or like dout): the gradients of the other consumers of `out` (the next block reads its input three
-// times: spatial unit, its residual operand, the block residual) — summed while loading, (dout + dout2) + dout3, instead
-// of a separate dsgcn_add3 pass (three reads and one write of the plane less per block).
-int dsgcn_fuse_out_bwd3(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
-                        const float* h2, int relu, const float* dout, const float* dout2, const float* dout3,
-                        const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
-                        void* stream) {
-  return dsgcn_fuse_out_bwd3s(x1, s1, h1, x2, s2, h2, relu, dout, dout2, dout3, 1, dxbar, dx1, dx2, part, n, C, T, V, xbar_ld,
-                              stream);
-}
-
-// stride3 = 2: dout3 is the gradient of dsgcn_fuse_out_fwd2's even-frame output, (n, C, ceil(T/2), V)
-int dsgcn_fuse_out_bwd3s(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
-                         const float* h2, int relu, const float* dout, const float* dout2, const float* dout3, int stride3,
-                         const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
-                         void* stream) {
+// Backward of dsgcn_fuse_out_fwd_drop (the same dropout record: the masks are regenerated).  part: (n*C, 4) per-plane
+// [sum dv1*x1, sum dv, sum dv*x2, sum dv1]; dout or dxbar may be NULL (treated as zero).  dout2 / dout3 (NULL or like dout):
+// the gradients of the other consumers of `out` (the next block reads its input three times) — summed while loading,
+// (dout + dout2) + dout3.  stride3 = 2: dout3 is the gradient of the even-frame output, (n, C, ceil(T/2), V);
+// stride3 = 3: dout is (n*C), the gradient of the plane means (dsgcn_fuse_out_pool_fwd), dout2 / dout3 / dxbar NULL.
+int dsgcn_fuse_out_bwd_drop(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                            const float* h2, int relu, const float* dout, const float* dout2, const float* dout3,
+                            int stride3, const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V,
+                            int xbar_ld, const dsgcn_dropout* d, void* stream) {
   if (!x1 || !dx1 || n <= 0 || C <= 0 || T <= 0 || V <= 0 || V > 32 || (x2 && !dx2)) return DSGCN_EINVAL;
   if (dxbar && xbar_ld < V) return DSGCN_EINVAL;
   if ((dout2 || dout3) && !dout) return DSGCN_EINVAL;
-  if (stride3 != 1 && stride3 != 2) return DSGCN_EINVAL;
+  if (stride3 < 1 || stride3 > 3 || (stride3 == 3 && (!dout || dout2 || dout3 || dxbar))) return DSGCN_EINVAL;
+  if (d && !(d->p >= 0.f && d->p < 1.f)) return DSGCN_EINVAL;
+  const DropArgs dr = drop_args(d);
   const dim3 grid((unsigned)((long)n * C)), blk(64);
   hipStream_t st = (hipStream_t)stream;
+  if (stride3 == 3) {
+    if ((T * V) % 4 == 0) {
+      if (x2)
+        hipLaunchKernelGGL((k_fuse_out_bwd4<0, false, true>), grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, dout,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dx1, dx2, part, C, T, V, V, dr);
+      else
+        hipLaunchKernelGGL((k_fuse_out_bwd4<0, false, false>), grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, dout,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dx1, dx2, part, C, T, V, V, dr);
+    } else {
+      hipLaunchKernelGGL(k_fuse_out_bwd, grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, dout, (const float*)nullptr,
+                         (const float*)nullptr, (const float*)nullptr, dx1, dx2, part, C, T, V, V, 3, dr);
+    }
+    DSGCN_LAUNCH_CHECK();
+    return 0;
+  }
   // the summation order of the scalar form: ((dout + dout2) + dout3) + the time-mean term
   if (g_fo_vec && dout && (T * V) % 4 == 0 && !(dout3 && !dout2 && stride3 == 1)) {
     const int ng = dout3 && stride3 == 1 ? 3 : (dout2 ? 2 : 1);
     const bool s3 = dout3 && stride3 == 2;
 #define FO4(NGV, S3V, X2V) hipLaunchKernelGGL((k_fuse_out_bwd4<NGV, S3V, X2V>), grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, \
-                                              dout, dout2, dout3, dxbar, dx1, dx2, part, C, T, V, xbar_ld)
+                                              dout, dout2, dout3, dxbar, dx1, dx2, part, C, T, V, xbar_ld, dr)
     if (x2) {
       if (s3) { if (ng == 2) FO4(2, true, true); else FO4(1, true, true); }
       else if (ng == 3) FO4(3, false, true);
@@ -369,7 +403,45 @@ int dsgcn_fuse_out_bwd3s(const float* x1, const float* s1, const float* h1, cons
     return 0;
   }
   hipLaunchKernelGGL(k_fuse_out_bwd, grid, blk, 0, st, x1, s1, h1, x2, s2, h2, relu, dout, dout2, dout3, dxbar, dx1, dx2,
-                     part, C, T, V, xbar_ld, stride3);
+                     part, C, T, V, xbar_ld, stride3, dr);
+  DSGCN_LAUNCH_CHECK();
+  return 0;
+}
+
+// dpmean (n, C): gradient of the plane means; dx1 / dx2 / part as in dsgcn_fuse_out_bwd.
+int dsgcn_fuse_out_pool_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                            const float* h2, int relu, const float* dpmean, float* dx1, float* dx2, float* part, int n,
+                            int C, int T, int V, void* stream) {
+  if (!dpmean) return DSGCN_EINVAL;
+  return dsgcn_fuse_out_bwd_drop(x1, s1, h1, x2, s2, h2, relu, dpmean, nullptr, nullptr, 3, nullptr, dx1, dx2, part, n, C, T, V,
+                                 V, nullptr, stream);
+}
+
+int dsgcn_fuse_out_bwd3(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                        const float* h2, int relu, const float* dout, const float* dout2, const float* dout3,
+                        const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
+                        void* stream) {
+  return dsgcn_fuse_out_bwd_drop(x1, s1, h1, x2, s2, h2, relu, dout, dout2, dout3, 1, dxbar, dx1, dx2, part, n, C, T, V,
+                                 xbar_ld, nullptr, stream);
+}
+
+// stride3 = 2: dout3 is the gradient of dsgcn_fuse_out_fwd2's even-frame output, (n, C, ceil(T/2), V)
+int dsgcn_fuse_out_bwd3s(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                         const float* h2, int relu, const float* dout, const float* dout2, const float* dout3, int stride3,
+                         const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V, int xbar_ld,
+                         void* stream) {
+  if (stride3 != 1 && stride3 != 2) return DSGCN_EINVAL;
+  return dsgcn_fuse_out_bwd_drop(x1, s1, h1, x2, s2, h2, relu, dout, dout2, dout3, stride3, dxbar, dx1, dx2, part, n, C, T, V,
+                                 xbar_ld, nullptr, stream);
+}
+
+// mask (numel) = the multipliers dsgcn_fuse_out_fwd_drop applies to the first term of a tensor of numel elements under
+// record d: 1/(1-p) or 0 (tests and debugging: the product never materialises it)
+int dsgcn_dropout_mask(float* mask, long numel, const dsgcn_dropout* d, void* stream) {
+  if (!mask || numel <= 0 || (d && !(d->p >= 0.f && d->p < 1.f))) return DSGCN_EINVAL;
+  const long blocks = (numel + 255) / 256;
+  hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, mask,
+                     numel, drop_args(d));
   DSGCN_LAUNCH_CHECK();
   return 0;
 }

@@ -56,6 +56,7 @@ class TrainEngine:
             else:
                 loss.backward(self._seed)
             self.flat.collect_grads()
+            kernels.dropout_step_advance()       # (fused dropout: the next step draws other masks; no-op without it)
         finally:
             # the update that follows rewrites the weights through raw pointers: cached weight images are stale from here
             kernels.end_step()

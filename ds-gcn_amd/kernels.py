@@ -2292,6 +2292,44 @@ def prestrided_fits(T, V):
     return T * V * 4 <= FUSE_OUT_LDS_BYTES
 
 
+# ---- dropout inside fuse_out (csrc/dropout.h) --------------------------------------------------------------------------
+# The reference's temporal units end in nn.Dropout(p, inplace=True) behind their BatchNorm (tcn.py:30,33); vanilla ST-GCN
+# trains with p = 0.5.  Here the mask is never a tensor: fuse_out multiplies its first term by keep / (1 - p) from a
+# counter-based generator keyed by (seed, training step, call), and its backward regenerates the same multipliers.
+#   seed  = torch.initial_seed() (torch.manual_seed governs it);
+#   call  = a host counter, one value per fuse_out call (distinct masks per layer and per eager call);
+#   step  = a DEVICE counter (a captured graph freezes `call`: the replays differ through it), advanced once per training
+#           step by TrainEngine (dropout_step_advance) — never between a forward and its backward.
+_drop_state = {'call': 0, 'step': {}, 'used': False}
+
+
+def _dropout_record(p, device):
+    """-> (native.Dropout, keep-alive tuple) for one fuse_out call with drop probability p"""
+    st = _drop_state
+    if device not in st['step']:
+        st['step'][device] = torch.zeros((), dtype=torch.int64, device=device)
+    st['call'] = (st['call'] + 1) & 0x7fffffff
+    st['used'] = True
+    step = st['step'][device]
+    return native.Dropout(step.data_ptr(), int(torch.initial_seed()) & 0xffffffffffffffff, st['call'], float(p)), step
+
+
+def dropout_step_advance():
+    """End of a training step (TrainEngine): the next step's masks differ.  One tiny launch, and only in models that use
+    fused dropout."""
+    if _drop_state['used']:
+        for step in _drop_state['step'].values():
+            step.add_(1)
+
+
+def dropout_mask(numel, rec):
+    """The multipliers (numel,) a tensor of numel elements gets under record ``rec`` (tests)."""
+    dev = next(iter(_drop_state['step']))
+    out = torch.empty(numel, device=dev, dtype=torch.float32)
+    native.check(native.lib().dsgcn_dropout_mask(_ptr(out), numel, _ct.byref(rec), _stream()), 'dsgcn_dropout_mask')
+    return out
+
+
 class _FuseOut(torch.autograd.Function):
     """-> (out, out', out'', xbar): with ``tee`` the output comes as three aliases, one per consumer in the next block
     (spatial unit, its residual operand, block residual), and the backward sums their gradients while loading them —
@@ -2301,7 +2339,7 @@ class _FuseOut(torch.autograd.Function):
     the even frames inside the same backward launch (no strided-copy launch, no scatter into a zero-filled tensor)."""
 
     @staticmethod
-    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, xbar_ld, tee):
+    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, xbar_ld, tee, dropout=0.0):
         _require_cuda(x1)
         x1, s1, h1, x2, s2, h2 = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2)]
         n, C, T, V = x1.shape
@@ -2310,9 +2348,11 @@ class _FuseOut(torch.autograd.Function):
         out = torch.empty_like(x1)
         out_s2 = torch.empty((n, C, (T + 1) // 2, V), device=x1.device, dtype=torch.float32) if tee == 2 else None
         xbar = torch.empty((n, C, xbar_ld), device=x1.device, dtype=torch.float32) if xbar_ld else None
-        rc = native.lib().dsgcn_fuse_out_fwd2(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu),
-                                              _ptr(out), _ptr(out_s2), _ptr(xbar), n, C, T, V, int(xbar_ld), _stream())
-        native.check(rc, 'dsgcn_fuse_out_fwd2')
+        ctx.drop = _dropout_record(dropout, x1.device) if dropout > 0 else None
+        rc = native.lib().dsgcn_fuse_out_fwd_drop(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu),
+                                                  _ptr(out), _ptr(out_s2), _ptr(xbar), None, n, C, T, V, int(xbar_ld),
+                                                  _ct.byref(ctx.drop[0]) if ctx.drop else None, _stream())
+        native.check(rc, 'dsgcn_fuse_out_fwd_drop')
         ctx.save_for_backward(x1, s1, h1, x2, s2, h2)
         ctx.relu = int(relu)
         ctx.xbar_ld = int(xbar_ld)
@@ -2349,10 +2389,11 @@ class _FuseOut(torch.autograd.Function):
         dx2 = torch.empty_like(x2) if x2 is not None else None
         need_part = s1 is not None or s2 is not None
         part = torch.empty((n, C, 4), device=x1.device, dtype=torch.float32) if need_part else None
-        rc = native.lib().dsgcn_fuse_out_bwd3s(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
-                                               _ptr(douts[0]), _ptr(douts[1]), _ptr(douts[2]), stride3, _ptr(dxbar),
-                                               _ptr(dx1), _ptr(dx2), _ptr(part), n, C, T, V, ctx.xbar_ld or V, _stream())
-        native.check(rc, 'dsgcn_fuse_out_bwd3s')
+        rc = native.lib().dsgcn_fuse_out_bwd_drop(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
+                                                  _ptr(douts[0]), _ptr(douts[1]), _ptr(douts[2]), stride3, _ptr(dxbar),
+                                                  _ptr(dx1), _ptr(dx2), _ptr(part), n, C, T, V, ctx.xbar_ld or V,
+                                                  _ct.byref(ctx.drop[0]) if ctx.drop else None, _stream())
+        native.check(rc, 'dsgcn_fuse_out_bwd_drop')
         ds1 = dh1 = ds2 = dh2 = None
         if need_part and (s1 is None or ctx.bn1 is not None) and (s2 is None or ctx.bn2 is not None):
             _bn_feed_multi(([(ctx.bn1, part, 4, 0, 3)] if s1 is not None else []) +
@@ -2363,7 +2404,7 @@ class _FuseOut(torch.autograd.Function):
                 ds1, dh1 = red[0], red[3]
             if s2 is not None:
                 ds2, dh2 = red[2], red[1]
-        return dx1, ds1, dh1, dx2, ds2, dh2, None, None, None
+        return dx1, ds1, dh1, dx2, ds2, dh2, None, None, None, None
 
 
 class _FuseOutPool(torch.autograd.Function):
@@ -2371,16 +2412,18 @@ class _FuseOutPool(torch.autograd.Function):
     reads (_FuseOut without the write; the backward spreads the pooled gradient while it loads its operands)."""
 
     @staticmethod
-    def forward(ctx, x1, s1, h1, x2, s2, h2, relu):
+    def forward(ctx, x1, s1, h1, x2, s2, h2, relu, dropout=0.0):
         _require_cuda(x1)
         x1, s1, h1, x2, s2, h2 = [_f32c(t) for t in (x1, s1, h1, x2, s2, h2)]
         n, C, T, V = x1.shape
         if x2 is not None and x2.shape != x1.shape:
             raise ValueError(f'fuse_out_pool: the two terms differ in shape: {tuple(x1.shape)} vs {tuple(x2.shape)}')
         pm = torch.empty((n, C), device=x1.device, dtype=torch.float32)
-        rc = native.lib().dsgcn_fuse_out_pool_fwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu),
-                                                  _ptr(pm), n, C, T, V, _stream())
-        native.check(rc, 'dsgcn_fuse_out_pool_fwd')
+        ctx.drop = _dropout_record(dropout, x1.device) if dropout > 0 else None
+        rc = native.lib().dsgcn_fuse_out_fwd_drop(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), int(relu),
+                                                  None, None, None, _ptr(pm), n, C, T, V, V,
+                                                  _ct.byref(ctx.drop[0]) if ctx.drop else None, _stream())
+        native.check(rc, 'dsgcn_fuse_out_fwd_drop')
         ctx.save_for_backward(x1, s1, h1, x2, s2, h2)
         ctx.relu = int(relu)
         ctx.bn1, ctx.bn2 = _bn_of(s1), _bn_of(s2)
@@ -2395,9 +2438,10 @@ class _FuseOutPool(torch.autograd.Function):
         dx2 = torch.empty_like(x2) if x2 is not None else None
         need_part = s1 is not None or s2 is not None
         part = torch.empty((n, C, 4), device=x1.device, dtype=torch.float32) if need_part else None
-        rc = native.lib().dsgcn_fuse_out_pool_bwd(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
-                                                  _ptr(dpm), _ptr(dx1), _ptr(dx2), _ptr(part), n, C, T, V, _stream())
-        native.check(rc, 'dsgcn_fuse_out_pool_bwd')
+        rc = native.lib().dsgcn_fuse_out_bwd_drop(_ptr(x1), _ptr(s1), _ptr(h1), _ptr(x2), _ptr(s2), _ptr(h2), ctx.relu,
+                                                  _ptr(dpm), None, None, 3, None, _ptr(dx1), _ptr(dx2), _ptr(part), n, C, T, V,
+                                                  V, _ct.byref(ctx.drop[0]) if ctx.drop else None, _stream())
+        native.check(rc, 'dsgcn_fuse_out_bwd_drop')
         ds1 = dh1 = ds2 = dh2 = None
         if need_part and (s1 is None or ctx.bn1 is not None) and (s2 is None or ctx.bn2 is not None):
             _bn_feed_multi(([(ctx.bn1, part, 4, 0, 3)] if s1 is not None else []) +
@@ -2408,26 +2452,31 @@ class _FuseOutPool(torch.autograd.Function):
                 ds1, dh1 = red[0], red[3]
             if s2 is not None:
                 ds2, dh2 = red[2], red[1]
-        return dx1, ds1, dh1, dx2, ds2, dh2, None
+        return dx1, ds1, dh1, dx2, ds2, dh2, None, None
 
 
-def fuse_out_pool(x1, a1, x2, a2, relu):
+DROPOUT_FUSED = _os.environ.get('DSGCN_DROPOUT_FUSED', '1') != '0'     # '0': materialise + torch dropout (the round-5 path)
+
+
+def fuse_out_pool(x1, a1, x2, a2, relu, dropout=0.0):
     """mean over (T, V) of ``fuse_out(x1, a1, x2, a2, relu)`` -> (n, C), without materialising the activation."""
     s1, h1 = a1 if a1 is not None else (None, None)
     s2, h2 = a2 if a2 is not None else (None, None)
-    return _FuseOutPool.apply(x1, s1, h1, x2, s2, h2, int(relu))
+    return _FuseOutPool.apply(x1, s1, h1, x2, s2, h2, int(relu), float(dropout))
 
 
-def fuse_out(x1, a1, x2, a2, relu, want_tmean=False, tee=False):
+def fuse_out(x1, a1, x2, a2, relu, want_tmean=False, tee=False, dropout=0.0):
     """relu: bool, or int flags — bit 0 the outer ReLU, bit 1 a ReLU on the first term before the add.
     want_tmean: False / True (time mean (n, C, V)) / an int ld >= V (time mean with the joint row zero-padded to ld: the
     layout `dynadj` consumes directly).
     tee: return the output as a tuple of three aliases (see _FuseOut) for the next block's three reads; tee = 2: the third
-    one is the even-frame tensor (n, C, ceil(T/2), V) wrapped as ``Prestrided`` for the stride-2 residual conv."""
+    one is the even-frame tensor (n, C, ceil(T/2), V) wrapped as ``Prestrided`` for the stride-2 residual conv.
+    dropout: drop probability of the FIRST term (after its own ReLU, before the second term is added): the temporal unit's
+    nn.Dropout (tcn.py:30,33) without a mask tensor or a pass of its own."""
     s1, h1 = a1 if a1 is not None else (None, None)
     s2, h2 = a2 if a2 is not None else (None, None)
     ld = 0 if not want_tmean else (x1.shape[-1] if want_tmean is True else int(want_tmean))
-    o1, o2, o3, xbar = _FuseOut.apply(x1, s1, h1, x2, s2, h2, int(relu), ld, int(tee))
+    o1, o2, o3, xbar = _FuseOut.apply(x1, s1, h1, x2, s2, h2, int(relu), ld, int(tee), float(dropout))
     if int(tee) == 2:
         o3 = Prestrided(o3, 2, x1.shape[2])
     return ((o1, o2, o3) if tee else o1), xbar

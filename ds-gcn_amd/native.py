@@ -117,6 +117,9 @@ SIGNATURES = {
     'dsgcn_dynadj_bwd': [c_f] * 5 + [c_i, c_i] + [c_f] * 4 + [c_int] * 7 + [c_st],
     'dsgcn_pwconv_wgrad_jobs': [c_f] * 6 + [c_int] + [c_f] * 8 + [c_int] * 8 + [ctypes.c_void_p, c_int, c_st],
     'dsgcn_tms_split_wgrad_jobs': [c_f] * 4 + [c_int] + [c_f] * 2 + [c_int] * 6 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, ctypes.c_void_p, c_int, c_st],
+    'dsgcn_fuse_out_fwd_drop': [c_f] * 6 + [c_int] + [c_f] * 4 + [c_int] * 5 + [ctypes.c_void_p, c_st],
+    'dsgcn_fuse_out_bwd_drop': [c_f] * 6 + [c_int] + [c_f] * 3 + [c_int] + [c_f] * 4 + [c_int] * 5 + [ctypes.c_void_p, c_st],
+    'dsgcn_dropout_mask': [c_f, ctypes.c_long, ctypes.c_void_p, c_st],
     'dsgcn_bn_finalize_multi': [ctypes.c_void_p, c_int, c_st],
     'dsgcn_bn_coef_rows_multi': [ctypes.c_void_p, c_int, c_st],
     'dsgcn_dynadj_fwd_jobs': [c_f] * 6 + [c_i, c_i, c_f] + [c_int] * 6 + [ctypes.c_void_p, c_int, c_st],
@@ -150,6 +153,11 @@ class BnCoefJob(ctypes.Structure):
 
 
 BN_JOBS_MAX = 4
+
+
+class Dropout(ctypes.Structure):
+    """include/dsgcn_jobs.h: dsgcn_dropout"""
+    _fields_ = [('step', ctypes.c_void_p), ('seed', ctypes.c_ulonglong), ('call', ctypes.c_uint), ('p', ctypes.c_float)]
 
 SIZE_T_RESULTS = {'dsgcn_pwconv_wsplit_bytes', 'dsgcn_tconv_ws_bytes'}      # everything else returns an int status / count
 

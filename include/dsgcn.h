@@ -113,6 +113,21 @@ int dsgcn_fuse_out_pool_fwd(const float* x1, const float* s1, const float* h1, c
 int dsgcn_fuse_out_pool_bwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
                             const float* h2, int relu, const float* dpmean, float* dx1, float* dx2, float* part, int n,
                             int C, int T, int V, void* stream);
+/* The block output with DROPOUT on its first term (the temporal unit's output: nn.Dropout behind its BatchNorm, tcn.py:30,33;
+ * MSTCN msg3d_utils.py:141-146), masks from a counter-based generator (dsgcn_jobs.h: dsgcn_dropout) — no mask tensor, the
+ * backward regenerates it:  out = relu?( D * relu2?(x1*s1+h1) + (x2*s2+h2 | x2) ), D = keep/(1-p).  One entry point per
+ * direction covers every output form: out / out_s2 / xbar / pmean may be NULL (pmean (n*C): the plane means of
+ * dsgcn_fuse_out_pool_fwd); backward stride3 = 1 | 2 as dsgcn_fuse_out_bwd3s, 3 = dout is the (n*C) gradient of the plane
+ * means.  d NULL or p = 0: exactly the plain calls.  dsgcn_dropout_mask writes the multipliers a tensor of numel elements
+ * gets under d (tests only: the product never materialises them). */
+int dsgcn_fuse_out_fwd_drop(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                            const float* h2, int relu, float* out, float* out_s2, float* xbar, float* pmean, int n, int C,
+                            int T, int V, int xbar_ld, const dsgcn_dropout* d, void* stream);
+int dsgcn_fuse_out_bwd_drop(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2,
+                            const float* h2, int relu, const float* dout, const float* dout2, const float* dout3,
+                            int stride3, const float* dxbar, float* dx1, float* dx2, float* part, int n, int C, int T, int V,
+                            int xbar_ld, const dsgcn_dropout* d, void* stream);
+int dsgcn_dropout_mask(float* mask, long numel, const dsgcn_dropout* d, void* stream);
 
 /* Dense (KT,1) temporal conv as a GEMM on bf16 terms (csrc/tcg.hip): unit_tcn's Conv2d((9,1), padding 4) + the statistics
  * of its BatchNorm (tcn.py:21-28), stride 1 or 2 (T = input frames, z has ceil(T/stride)), dilation 1, KT odd <= 9,

@@ -29,4 +29,14 @@ typedef struct {
   int c_affine, accumulate;        /* accumulate != 0: add to coef (a second consumer of the same BatchNorm) */
 } dsgcn_bn_coef_job;
 
+/* Dropout of the fused block output's first term (dsgcn_fuse_out_fwd_drop / _bwd_drop): counter-based masks, no mask
+ * tensor.  step: DEVICE counter of training steps (NULL = 0; the same value must be in it for a step's forward and its
+ * backward); seed: the run's seed; call: which fuse_out call of the step; p in [0, 1): drop probability (0 = off). */
+typedef struct {
+  const long long* step;
+  unsigned long long seed;
+  unsigned int call;
+  float p;
+} dsgcn_dropout;
+
 #endif

@@ -583,6 +583,119 @@ def test_fuse_out(n, C, T, V, mode, tmean, flags):
         assert rel(got[k].detach().cpu(), v.detach()) < 1e-5, (k, rel(got[k].detach().cpu(), v.detach()))
 
 
+def _drop_record_of_last_call(p):
+    """the record the LAST fuse_out(dropout=p) call used (kernels._drop_state: its call number, this device's step counter)"""
+    from dsgcn_amd import native
+    st = K._drop_state
+    step = next(iter(st['step'].values()))
+    return native.Dropout(step.data_ptr(), int(torch.initial_seed()) & 0xffffffffffffffff, st['call'], float(p))
+
+
+@pytest.mark.parametrize('n,C,T,V,mode,flags,form', [
+    (2, 64, 16, 25, 'res_plain', 1, 'plain'),       # ST-GCN's block: relu(drop(bn(conv)) + x), 16-byte planes
+    (3, 12, 9, 25, 'res_affine', 1, 'tmean'),       # odd planes (scalar kernels), residual through its own BatchNorm
+    (2, 32, 16, 25, 'res_plain', 3, 'tee2'),        # CTR-GCN's MSTCN: its own ReLU first, even-frame second output
+    (2, 48, 8, 17, 'affine', 1, 'pool'),            # the last block under the pooling head, no residual
+    (2, 16, 7, 18, 'res_plain', 3, 'pool')])
+@pytest.mark.parametrize('p', [0.5, 0.1])
+def test_fuse_out_dropout(n, C, T, V, mode, flags, form, p):
+    """Dropout inside fuse_out (csrc/dropout.h; reference: nn.Dropout behind the temporal unit's BatchNorm, tcn.py:30,33):
+    no mask tensor exists in the product — the test asks dsgcn_dropout_mask for the multipliers the call used and checks
+    (i) the multipliers: {0, 1/(1-p)}, keep rate within 5 sigma; (ii) forward AND backward (regenerated masks) against fp64
+    torch given the same multipliers: relu(m * relu2?(x1*s1+h1) + residual); (iii) another call draws another mask."""
+    torch.manual_seed(1234)
+    g = torch.Generator().manual_seed(C + T + flags)
+    x1 = _rand(g, n, C, T, V)
+    a1 = (torch.rand(C, generator=g) + 0.5, _rand(g, C, scale=0.3))
+    x2 = _rand(g, n, C, T, V) if mode.startswith('res') else None
+    a2 = (torch.rand(C, generator=g) + 0.5, _rand(g, C, scale=0.3)) if mode == 'res_affine' else None
+    T2 = (T + 1) // 2
+    go, ge, gb, gp = _rand(g, n, C, T, V), _rand(g, n, C, T2, V), _rand(g, n, C, V), _rand(g, n, C)
+
+    def mk(t, dev, dt):
+        return None if t is None else t.to(dev, dt).requires_grad_()
+    tx1, tx2 = mk(x1, DEV, torch.float32), mk(x2, DEV, torch.float32)
+    ta1 = (mk(a1[0], DEV, torch.float32), mk(a1[1], DEV, torch.float32))
+    ta2 = None if a2 is None else (mk(a2[0], DEV, torch.float32), mk(a2[1], DEV, torch.float32))
+    if form == 'pool':
+        pm = K.fuse_out_pool(tx1, ta1, tx2, ta2, flags, dropout=p)
+        loss = (pm * gp.to(DEV)).sum()
+        outs = dict(pm=pm)
+    else:
+        out, xbar = K.fuse_out(tx1, ta1, tx2, ta2, flags, form == 'tmean', 2 if form == 'tee2' else False, dropout=p)
+        if form == 'tee2':
+            oa, ob, oc = out
+            loss = (oa * go.to(DEV)).sum() + (oc.x * ge.to(DEV)).sum()
+            outs = dict(out=oa, even=oc.x)
+        else:
+            loss = (out * go.to(DEV)).sum()
+            outs = dict(out=out)
+            if form == 'tmean':
+                loss = loss + (xbar * gb.to(DEV)).sum()
+                outs['xbar'] = xbar
+    rec = _drop_record_of_last_call(p)
+    loss.backward()                                               # regenerates the masks from the same record
+    m = K.dropout_mask(x1.numel(), rec).view(n, C, T, V)
+    keep = (m > 0)
+    assert torch.all((m == 0) | ((m - 1 / (1 - p)).abs() < 1e-6))
+    N = m.numel()
+    assert abs(keep.float().mean().item() - (1 - p)) < 5 * (p * (1 - p) / N) ** 0.5
+    # fp64 reference with the same multipliers
+    md = m.double().cpu()
+    rx1, rx2 = mk(x1, 'cpu', torch.float64), mk(x2, 'cpu', torch.float64)
+    ra1 = (mk(a1[0], 'cpu', torch.float64), mk(a1[1], 'cpu', torch.float64))
+    ra2 = None if a2 is None else (mk(a2[0], 'cpu', torch.float64), mk(a2[1], 'cpu', torch.float64))
+    v = rx1 * ra1[0].view(1, -1, 1, 1) + ra1[1].view(1, -1, 1, 1)
+    if flags & 2:
+        v = v.relu()
+    v = v * md
+    if rx2 is not None:
+        v = v + (rx2 * ra2[0].view(1, -1, 1, 1) + ra2[1].view(1, -1, 1, 1) if ra2 is not None else rx2)
+    ro = v.relu() if flags & 1 else v
+    if form == 'pool':
+        rloss = (ro.mean((2, 3)) * gp.double()).sum()
+        refs = dict(pm=ro.mean((2, 3)))
+    elif form == 'tee2':
+        rloss = (ro * go.double()).sum() + (ro[:, :, ::2] * ge.double()).sum()
+        refs = dict(out=ro, even=ro[:, :, ::2])
+    else:
+        rloss = (ro * go.double()).sum()
+        refs = dict(out=ro)
+        if form == 'tmean':
+            rloss = rloss + (ro.mean(2) * gb.double()).sum()
+            refs['xbar'] = ro.mean(2)
+    rloss.backward()
+    for k, want in refs.items():
+        assert rel(outs[k].detach().cpu(), want.detach()) < 1e-6, (k, rel(outs[k].detach().cpu(), want.detach()))
+    pairs = [('dx1', tx1, rx1), ('ds1', ta1[0], ra1[0]), ('dh1', ta1[1], ra1[1])]
+    if tx2 is not None:
+        pairs.append(('dx2', tx2, rx2))
+    if ta2 is not None:
+        pairs += [('ds2', ta2[0], ra2[0]), ('dh2', ta2[1], ra2[1])]
+    for k, a, b in pairs:
+        assert rel(a.grad.cpu(), b.grad) < 1e-5, (k, rel(a.grad.cpu(), b.grad))
+    # the next call (another layer / another eager forward) draws another mask; so does the next training step
+    K.fuse_out(tx1.detach(), None, None, None, 0, False, False, dropout=p)
+    m2 = K.dropout_mask(x1.numel(), _drop_record_of_last_call(p)).view_as(m)
+    agree = ((m2 > 0) == keep).float().mean().item()
+    assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 6 * (0.25 / N) ** 0.5, agree
+    K.dropout_step_advance()
+    m3 = K.dropout_mask(x1.numel(), rec).view_as(m)
+    agree = ((m3 > 0) == keep).float().mean().item()
+    assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 6 * (0.25 / N) ** 0.5, agree
+    # p = 0 through the dropout entry points is exactly the plain call
+    o0 = K.fuse_out(tx1.detach(), (ta1[0].detach(), ta1[1].detach()), None, None, 1, False, False)[0]
+    lib = __import__('dsgcn_amd').native.lib()
+    o1 = torch.empty_like(o0)
+    st = torch.cuda.current_stream().cuda_stream
+    x1d, s1d, h1d = tx1.detach(), ta1[0].detach(), ta1[1].detach()
+    z = __import__('dsgcn_amd').native.Dropout(0, 5, 7, 0.0)
+    import ctypes
+    assert lib.dsgcn_fuse_out_fwd_drop(x1d.data_ptr(), s1d.data_ptr(), h1d.data_ptr(), None, None, None, 1, o1.data_ptr(), None,
+                                       None, None, n, C, T, V, V, ctypes.byref(z), st) == 0
+    assert torch.equal(o0, o1)
+
+
 @pytest.mark.parametrize('n,C,T,V', [(2, 16, 16, 25), (3, 8, 9, 25), (2, 12, 7, 17), (1, 64, 64, 25)])
 @pytest.mark.parametrize('streams', [3, 2, 1])
 def test_fuse_out_even_frame_output(n, C, T, V, streams):

@@ -468,6 +468,56 @@ def test_bench_through_torch_distributed_run():
     assert a['param_sha256'] == b['param_sha256'] and a['final_loss'] == b['final_loss']
 
 
+@pytest.mark.parametrize('graph', [False, True])
+def test_stgcn_training_step_with_fused_dropout(graph):
+    """BASELINE config 1's shipped training config (configs/stgcn/stgcn_vanilla_ntu60_xsub_3dkp/j.py:5, tcn_dropout = 0.5):
+    the temporal unit's Dropout runs inside fuse_out (no materialised block, no ATen pass).  Engine steps, eager and as
+    replayed hipGraphs: finite losses, the device step counter advances once per step (the replays draw new masks: the
+    loss of a FIXED batch keeps changing beyond what the weight update explains is not asserted — the counter is), the same
+    seed gives the same trajectory, and eval mode is untouched by dropout."""
+    from dsgcn_amd import kernels as K
+
+    def run():
+        torch.manual_seed(7)
+        np.random.seed(7)
+        m = D.build_model(other_cfg('stgcn', tcn_dropout=0.5)).cuda().train()
+        drops = [mod for mod in m.modules() if isinstance(mod, torch.nn.Dropout) and mod.p > 0]
+        assert len(drops) == 9                                  # stgcn.py:105: block 0 has no dropout
+        eng = D.TrainEngine(m, lr=0.05, use_graph=graph, warmup_eager=2)
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(4, 1, 2, 32, 25, 3, generator=g).cuda()
+        y = torch.randint(0, 60, (4, 1), generator=g).cuda()
+        step0 = None
+        losses = []
+        for i in range(6 if graph else 3):
+            losses.append(eng.step(x, y)['loss'])
+            cnt = int(next(iter(K._drop_state['step'].values())).item())
+            step0 = cnt - 1 if step0 is None else step0
+            assert cnt == step0 + i + 1
+        assert eng.graphed(x, y) == graph
+        losses = torch.stack(losses).cpu()
+        assert torch.isfinite(losses).all()
+        m.eval()
+        with torch.no_grad():
+            a = m.cls_head(m.extract_feat(x[:, 0]))
+            b = m.cls_head(m.extract_feat(x[:, 0]))
+        assert torch.equal(a, b)
+        return losses, a
+    (l1, a1), (l2, a2) = run(), run()
+    # the device counter keeps running between the two runs, so the masks of run 2 are other draws: the trajectories differ
+    # — unless the counter is put back, which is what makes a run repeatable
+    assert not torch.equal(l1, l2)
+    for stp in K._drop_state['step'].values():
+        stp.fill_(0)
+    K._drop_state['call'] = 0
+    (l3, a3) = run()
+    for stp in K._drop_state['step'].values():
+        stp.fill_(0)
+    K._drop_state['call'] = 0
+    (l4, a4) = run()
+    assert torch.equal(l3, l4) and torch.equal(a3, a4)
+
+
 def test_bench_self_launch_path():
     """``python bench.py`` with ``DSGCN_BENCH_SELF_LAUNCH=1`` and no launcher: the parent spawns ``torch.distributed.run``
     (one rank on this box, a 1-rank RCCL group) before touching the GPU and relays rank 0's line — what
