@@ -116,6 +116,32 @@ def _pmc_traffic(kernel):
     return None, None
 
 
+def _in_step_frac(prefix, n, bwd):
+    """The same kernels INSIDE the replayed step: (frac, avg us, source) from the latest committed step sequence
+    (profiles/rNN/step_sequence.txt: the kernels of one graph replay in launch order, rocprofv3 --kernel-trace of
+    `bench.py` — tools/step_sequence.py).  Like `traffic`: a committed profile of this code, not a measurement of this run.
+    Behind the kernels that precede them in the step (dirty lines, cold operands) the launches run a few percent slower
+    than in the isolated loop `frac` is measured on."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'step_sequence.txt')))
+    if not files:
+        return None, None, None
+    us = []
+    with open(files[-1]) as f:
+        for line in f:
+            m = re.match(r'\s*([\d.]+) us\s+(\S+)', line)
+            if m and m.group(2).startswith(prefix):
+                us.append(float(m.group(1)))
+    shapes = ka_layer_shapes(n)
+    if len(us) != len(shapes):
+        return None, None, None
+    nbytes = sum(ka_alg_bytes(*sh, V, bwd) for sh in shapes)
+    total = sum(us)
+    return (round(nbytes / (total * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), round(total / len(us), 2),
+            'committed graph-replay kernel trace ' + os.path.relpath(files[-1], ROOT) + ' (not measured by this process)')
+
+
 def measure_ka_roofline(device, n, reps=20, blocks=5):
     """HIP-event timing of K-A fwd and bwd over the model's layer mix (distinct buffers per layer so the
     working set, 0.64 GB fwd / 1.05 GB bwd, exceeds the 256 MiB Infinity Cache).  `blocks` timed blocks of `reps`
@@ -168,8 +194,10 @@ def measure_ka_roofline(device, n, reps=20, blocks=5):
         launches = len(bufs)
         gbs = nbytes / (ms * 1e-3) / 1e9
         traffic, src = _pmc_traffic(name)
+        isf, isus, issrc = _in_step_frac(name, n, is_bwd)
         out[name] = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                          frac=round(gbs / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=src,
+                         in_step_frac=isf, in_step_avg_launch_us=isus, in_step_source=issrc,
                          avg_launch_us=round(ms * 1e3 / launches, 2), alg_bytes_per_launch=nbytes // launches,
                          launches_per_step=launches, blocks=blocks, reps_per_block=reps,
                          frac_min=round(nbytes / (times[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -405,14 +433,22 @@ def measure_other_configs(device, steps=10, warmup=3):
     import gc
     import dsgcn_amd
     out = {}
-    for kind, what, clips in OTHER_CONFIGS:
+    # (kind, workload, clips, dropout kept?): ST-GCN a second time with its shipped tcn_dropout = 0.5
+    # (configs/stgcn/stgcn_vanilla_ntu60_xsub_3dkp/j.py:5) — fused into fuse_out since round 6, graph-capturable
+    runs = [(k, w, c, False) for k, w, c in OTHER_CONFIGS]
+    runs.insert(1, ('stgcn', 'BASELINE config 1 with its shipped training dropout (tcn_dropout=0.5, fused into fuse_out)',
+                    dict((k, c) for k, _, c in OTHER_CONFIGS)['stgcn'], True))
+    for kind, what, clips, keep_drop in runs:
         t_, v_, classes = 64, 25, 60
         if kind == 'ds_k400':
             cfg, t_, v_, classes = ds_cfg(400, 'coco'), 100, 17, 400
         elif kind == 'ds120':
             cfg, classes = ds_cfg(120), 120
+        elif keep_drop:
+            cfg = other_cfg(kind, tcn_dropout=0.5)
         else:
             cfg = other_cfg(kind)
+        key = kind + '_dropout' if keep_drop else kind
         try:
             np.random.seed(0)
             torch.manual_seed(0)
@@ -423,8 +459,8 @@ def measure_other_configs(device, steps=10, warmup=3):
                     if k.endswith(('alpha', 'beta', 'add_coeff')):
                         p.copy_(torch.randn(p.shape, generator=gen) * 0.5)
             for mod in m.modules():
-                if isinstance(mod, torch.nn.Dropout):
-                    mod.p = 0.0               # ST-GCN's tcn dropout (p = 0.5) draws from the RNG: not capturable; noted below
+                if isinstance(mod, torch.nn.Dropout) and not keep_drop:
+                    mod.p = 0.0
             m = m.to(device).train()
             eng = dsgcn_amd.TrainEngine(m, lr=0.1, momentum=0.9, weight_decay=5e-4, nesterov=True, use_graph=True,
                                         warmup_eager=2, strict_graph=False)
@@ -438,12 +474,12 @@ def measure_other_configs(device, steps=10, warmup=3):
                 loss = eng.step(x, y)['loss']
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
-            out[kind] = dict(workload=what, clips_per_gpu=clips, ms_per_step=round(dt * 1e3, 3), clips_per_s=round(clips / dt, 1),
-                             steps=steps, hip_graph=bool(eng.graphed(x, y)), final_loss=round(float(loss.item()), 5),
-                             step='fwd+bwd+SGD-nesterov (TrainEngine), dropout p=0')
+            out[key] = dict(workload=what, clips_per_gpu=clips, ms_per_step=round(dt * 1e3, 3), clips_per_s=round(clips / dt, 1),
+                            steps=steps, hip_graph=bool(eng.graphed(x, y)), final_loss=round(float(loss.item()), 5),
+                            step='fwd+bwd+SGD-nesterov (TrainEngine), dropout p=' + ('0.5' if keep_drop else '0'))
             del eng, m, x, y
         except Exception as exc:        # a secondary figure must never take the bench line down
-            out[kind] = dict(workload=what, error=f'{type(exc).__name__}: {exc}')
+            out[key] = dict(workload=what, error=f'{type(exc).__name__}: {exc}')
         gc.collect()
         torch.cuda.empty_cache()
     return out

@@ -303,7 +303,11 @@ __device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][
   }
 }
 
-template <int MT, int NQ, int MODE, int PD, int EPI>
+// KSP (round 6): the four waves of a workgroup share ONE position tile and split the K loop (whole prefetch rounds each);
+// their accumulators meet in LDS and wave 0 runs the epilogue.  For the tiny-plane launches (the dynamic-adjacency
+// projections: n x 32 positions, K = 128 .. 288): 64 wave tiles x 9 row blocks left the chip at 576 waves each walking
+// K / 2 dependent k-steps (18-21 us for 0.6 GFLOP); split four ways the chain is a quarter as long on four times the waves.
+template <int MT, int NQ, int MODE, int PD, int EPI, bool KSP = false>
 __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4))) void k_pw4(Pw4Args a) {
   typedef typename VQ<NQ>::T vq;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   const int half = lane >> 5, l31 = lane & 31;
   // XCD-aware decode: the cc workgroups that read the same position tiles (one per 32*MT output channels) take
   // consecutive slots of one XCD (blockIdx % 8), so the re-reads are served by that XCD's L2
-  const int ngrp = (a.WT + 3) >> 2;
+  const int ngrp = KSP ? a.WT : (a.WT + 3) >> 2;
   const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
   const int cz = slot % a.cc;
   const int grp = (slot / a.cc) * 8 + xcd;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   // NQ positions never do): no per-sample tail tile — at L = 400 (256 channels, 16 frames) per-sample tiling left
   // 22 % of the MFMA work on padding.  The wave's buffer resources start at its first sample n; a lane adds ds sample
   // strides in its vector offset.
-  const int wt = grp * 4 + wave;
+  const int wt = KSP ? grp : grp * 4 + wave;
   const bool wlive = wt < a.WT;
   // Ragged planes (L % NQ != 0: K400's 25 x 17 and CTR-GCN's 25 x 25 planes): the tile walks Lq = L rounded up to NQ
   // positions per plane, and the plane's last run is moved back to END at the plane's end — it overlaps the run before it
@@ -353,6 +357,16 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
 
   f32x16 acc[MT][NQ];
   const float lo = a.relu ? 0.f : -__builtin_inff();
+  // this wave's k-steps: all of them, or (KSP) its share of the Kpad / (2 PD) prefetch rounds
+  const int KS = a.Kpad >> 1;                      // k-steps (2 channels each), a multiple of PD
+  const int KSr = (K + 1) >> 1;                    // k-steps that hold real channels
+  int ks0 = 0, ks1 = KS;
+  if constexpr (KSP) {
+    const int U = KS / PD;
+    ks0 = (U * wave / 4) * PD;
+    ks1 = (U * (wave + 1) / 4) * PD;
+  }
+  const int kse = ks1 < KSr ? ks1 : KSr;           // loads past it: out of range (zeros, no traffic)
   // ---- weights: global -> registers (all loads of a batch issued together), operand prefetch, then LDS ----
   constexpr int WB = 16;
   const bool mfast = a.w_ldm == 1;                 // A = W^T (data gradient): m is the contiguous index of w
@@ -374,7 +388,7 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
     if (e0 == 0) {
 #pragma unroll
       for (int u = 0; u < PD; ++u) {
-        const int s0 = 2 * u < K ? 2 * u * L4 : P4_OOB;               // (channels past K: out of range, zeros)
+        const int s0 = ks0 + u < kse ? 2 * (ks0 + u) * L4 : P4_OOB;   // (channels past K: out of range, zeros)
         buf1[u] = p4_load<NQ>(r1, voff, s0);
         if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, s0);
       }
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = mBase + 32 * m + p4_row32(i, half);
-      const float b0 = (EPI == 0 && a.bias && row < M) ? a.bias[row] : 0.f;
+      const float b0 = (EPI == 0 && a.bias && row < M && (!KSP || wave == 0)) ? a.bias[row] : 0.f;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) acc[m][q][i] = b0;
     }
@@ -415,8 +429,6 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // raw barrier: the operand prefetch stays in flight
 
-  const int KS = Kpad >> 1;                        // k-steps (2 channels each), a multiple of PD
-  const int KSr = (K + 1) >> 1;                    // k-steps that hold real channels
   // Software pipeline, pinned with scheduling barriers.  Step ks: start the LDS reads of step ks+1 (A fragment, affine
   // row; double-buffered by step parity), apply the affine to the operand loaded PD steps ago, run the MT*NQ MFMAs, then
   // re-issue that operand buffer's load for step ks+PD (after the MFMAs: the buffer registers are dead by then, so the
@@ -426,9 +438,9 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   float avb[2][MT];
   f32x4 pb[2] = {{1.f, 0.f, 1.f, 0.f}, {1.f, 0.f, 1.f, 0.f}};
 #pragma unroll
-  for (int m = 0; m < MT; ++m) avb[0][m] = Ws[(32 * m + l31) * KP + half];
-  if (MODE != 0) pb[0] = Ps[half];
-  for (int base = 0; base < KS; base += PD) {
+  for (int m = 0; m < MT; ++m) avb[0][m] = Ws[(32 * m + l31) * KP + 2 * ks0 + half];
+  if (MODE != 0) pb[0] = Ps[2 * ks0 + half];
+  for (int base = ks0; base < ks1; base += PD) {
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
       const int ks = base + u;
@@ -454,7 +466,7 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
         for (int q = 0; q < NQ; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(avb[cur][m], b[q], acc[m][q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       // past K: the scalar offset jumps out of the buffer's range (zeros, no traffic: the bounds check covers it)
-      const int sn = ks + PD < KSr ? 2 * (ks + PD) * L4 : P4_OOB;
+      const int sn = ks + PD < kse ? 2 * (ks + PD) * L4 : P4_OOB;
       buf1[u] = p4_load<NQ>(r1, voff, sn);
       if constexpr (MODE == 2) buf2[u] = p4_load<NQ>(r2, voff, sn);
       __builtin_amdgcn_sched_barrier(0);
@@ -462,7 +474,34 @@ __global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4)))
   }
   __syncthreads();                                 // every wave is done with Ws / Ps: LDS is reused below
 
-  const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, wlive, pok, skip};
+  if constexpr (KSP) {
+    // the K shares meet: waves 1..3 park their accumulators ([wave][register][lane]: conflict-free), wave 0 adds them in
+    // a fixed order (deterministic) and alone runs the epilogue — the others go through it as dead waves (no stores,
+    // zero sums: what a partly empty last workgroup's waves do)
+    float* Rs = lds;                               // [3][MT * NQ * 16][64]
+    if (wave != 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Rs[(((wave - 1) * MT * NQ + m * NQ + q) * 16 + i) * 64 + lane] = acc[m][q][i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][q][i] += Rs[((w * MT * NQ + m * NQ + q) * 16 + i) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  const bool elive = KSP ? (wlive && wave == 0) : wlive;
+  const P4Tile tile = {wave, half, l31, tid, mBase, n, nrem, ds, pos, grp, elive, KSP ? (pok && wave == 0) : pok, skip};
   if constexpr (EPI == 1) {
     // (operand prefetch of the data-gradient epilogue: two row groups ahead — k_pw4's waves keep their PD operand slots
     // next to MT*NQ accumulator tiles, there is room for two)
@@ -1020,9 +1059,10 @@ WsDims ws_dims(int Ci, int Co) {
   return d;
 }
 
+int g_p4_ksp = 1;       // K-split form of the tiny-plane launches (lab key 19)
 int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128, g_p4_ws = 2;   // ws: 2 = k_pwg3 on the fragment-order image; 1 = row-major image (lab A/B: no consumer left, k_pwg runs); g_p4_pd unused
 
-struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad, gemm, Lq; size_t lds; unsigned grid; };
+struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad, gemm, Lq, ksp; size_t lds; unsigned grid; };
 
 bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
   const bool ragged = L % 2 != 0 && L >= 4;         // odd planes: runs of 4, the last one moved back to end at the plane's end
@@ -1037,7 +1077,8 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
   if (mtiles == 3 || (mtiles == 2 && M <= 48)) MT = 1;
   // tiny planes (the dynamic-adjacency projections: 32 padded joints per sample): the launch is a latency chain of K/2
   // k-steps on few waves, so give every wave the smallest tile (1 x 2 MFMAs per k-step) and the grid the most waves
-  if (L <= 64 && (long)n * ((L + 127) / 128) < 1024 && !ragged) { NQ = 2; MT = 1; }
+  const bool tiny = L <= 64 && (long)n * ((L + 127) / 128) < 1024 && !ragged;
+  if (tiny) { NQ = 2; MT = 1; }
   if ((g_p4_nq == 2 && !ragged) || (g_p4_nq == 4 && L % 4 == 0)) NQ = g_p4_nq;
   if (g_p4_mt) MT = g_p4_mt < mtiles ? g_p4_mt : mtiles;
   if (MT * NQ > 8 && !ragged) NQ = 2;
@@ -1058,6 +1099,11 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
   const size_t fe = (size_t)4 * 3 * 32 * 36 + (size_t)4 * MT * 32 * 4 + (size_t)MT * 32 * 4;    // epilogue image
   if (f < fe) f = fe;
   p->lds = f * sizeof(float);
+  // the K-split form of the tiny-plane launches (k_pw4<.., KSP>): at least one prefetch round per wave; the launcher takes
+  // it for plain operands without statistics / input-affine sums (the projections) and then needs room for three waves'
+  // accumulators
+  p->ksp = (g_p4_ksp && tiny && MT == 1 && NQ == 2 && p->Kpad / (2 * PD) >= 4) ? 1 : 0;
+  if (p->ksp && p->lds < (size_t)3 * MT * NQ * 16 * 64 * sizeof(float)) p->lds = (size_t)3 * MT * NQ * 16 * 64 * sizeof(float);
   p->gemm = 0;
   if ((g_p4_gemm & (1 << epi)) && (L % 4 == 0 || ragged) && K % 4 == 0 && M % 4 == 0 && K >= g_p4_gmin && M > 64 &&
       L >= g_p4_gminl) {
@@ -1177,6 +1223,7 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_tuning(int key, int value) {
   else if (key == 4) g_p4_gmin = value;
   else if (key == 5) g_p4_gminl = value;
   else if (key == 6) g_p4_ws = value;
+  else if (key == 7) g_p4_ksp = value;
   else return DSGCN_EINVAL;
   return 0;
 }
@@ -1199,6 +1246,11 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_fwd(const float* x1, const fl
   a.w = w; a.w_ldm = Ci; a.w_ldk = 1; a.bias = bias; a.out = z; a.partial = partial;
   a.n = n; a.K = Ci; a.M = Co; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad; a.Lq = p.Lq;
   const int mode = x2 ? 2 : ((s1 || relu) ? 1 : 0);
+  if (p.ksp && !p.gemm && mode == 0 && !partial) {
+    hipLaunchKernelGGL((k_pw4<1, 2, 0, 16, 0, true>), dim3((unsigned)((p.WT + 7) / 8 * 8 * p.cc)), dim3(P4_NT), p.lds, st, a);
+    DSGCN_LAUNCH_CHECK();
+    return 1;
+  }
   const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 0, p, st, wsp, wd.MpN) : p4_launch_pd<16>(a, mode, 0, p, st, wsp, wd.MpN);
   if (!ok) return 0;
   DSGCN_LAUNCH_CHECK();
@@ -1223,6 +1275,11 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const 
   a.out2 = dx2; a.ipart = ipart;
   a.n = n; a.K = Co; a.M = Ci; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad; a.Lq = p.Lq;
   const int mode = A0 ? 2 : 0;
+  if (p.ksp && !p.gemm && mode == 0 && !ipart) {
+    hipLaunchKernelGGL((k_pw4<1, 2, 0, 16, 1, true>), dim3((unsigned)((p.WT + 7) / 8 * 8 * p.cc)), dim3(P4_NT), p.lds, st, a);
+    DSGCN_LAUNCH_CHECK();
+    return 1;
+  }
   const WsDims wd = ws_dims(Ci, Co);
   const unsigned short* wsp = ws ? static_cast<const unsigned short*>(ws) + (size_t)3 * wd.MpN * wd.KpN : nullptr;   // the T image
   const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 1, p, st, wsp, wd.MpT) : p4_launch_pd<16>(a, mode, 1, p, st, wsp, wd.MpT);
