@@ -1060,6 +1060,7 @@ WsDims ws_dims(int Ci, int Co) {
 }
 
 int g_p4_ksp = 1;       // K-split form of the tiny-plane launches (lab key 19)
+int g_p4_fill = 1;      // under-filled launches take one row tile per wave (lab key 20)
 int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128, g_p4_ws = 2;   // ws: 2 = k_pwg3 on the fragment-order image; 1 = row-major image (lab A/B: no consumer left, k_pwg runs); g_p4_pd unused
 
 struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad, gemm, Lq, ksp; size_t lds; unsigned grid; };
@@ -1079,6 +1080,9 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
   // k-steps on few waves, so give every wave the smallest tile (1 x 2 MFMAs per k-step) and the grid the most waves
   const bool tiny = L <= 64 && (long)n * ((L + 127) / 128) < 1024 && !ragged;
   if (tiny) { NQ = 2; MT = 1; }
+  // (round 6) a launch that would not even put one workgroup on every CU: one row tile per wave doubles the workgroups
+  // (CTR-GCN's conv4 at 64 output channels: 157 position groups x 1 row block on 256 CUs)
+  if (g_p4_fill && MT == 2 && ((((long)n * ((L + NQ - 1) / NQ * NQ) + 32 * NQ - 1) / (32 * NQ) + 3) / 4) * ((mtiles + 1) / 2) < 256) MT = 1;
   if ((g_p4_nq == 2 && !ragged) || (g_p4_nq == 4 && L % 4 == 0)) NQ = g_p4_nq;
   if (g_p4_mt) MT = g_p4_mt < mtiles ? g_p4_mt : mtiles;
   if (MT * NQ > 8 && !ragged) NQ = 2;
@@ -1224,6 +1228,7 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_tuning(int key, int value) {
   else if (key == 5) g_p4_gminl = value;
   else if (key == 6) g_p4_ws = value;
   else if (key == 7) g_p4_ksp = value;
+  else if (key == 8) g_p4_fill = value;
   else return DSGCN_EINVAL;
   return 0;
 }
