@@ -1,6 +1,6 @@
 #!/bin/bash
 # profile set of a round: bench line, rocprof stats of the bench command, K-C SQ counters, K-A and whole-step HBM traffic
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/profile_set; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/profile_set_r6; mkdir -p $O
 cd $R
 timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench.err
 cd /tmp; export TMPDIR=/tmp
@@ -27,3 +27,8 @@ python tools/ka_traffic.py $(find $O/kaf -name '*counter_collection.csv' | head 
 python tools/step_traffic.py $O/stf $O/stw 2 $O/step_hbm_traffic.csv > $O/step_traffic.log 2>&1
 for d in pmc1 pmc2 pmc3 pmc4 pmc5 pmc6 pmc7 kaf kaw stf stw; do rm -rf $O/$d; done
 cat $O/bench_n1.json | cut -c1-1500; cat $O/summary.log $O/ka_traffic.log $O/step_traffic.log; tail -2 $O/bench.err
+# (round 6) the kernel sequences of one replayed step of the three BASELINE single-GPU configurations
+for k in ds stgcn ctrgcn; do bash $R/tools/gpu/r6_seq.sh $k > $O/seq_$k.log 2>&1; cp $R/gpurun_out/r6_seq_$k/sequence.txt $O/step_sequence_$k.txt; done
+cd /tmp
+S stgcn_kernel_stats python3 $R/tools/bench_other.py stgcn 64 8
+S ctrgcn_kernel_stats python3 $R/tools/bench_other.py ctrgcn 64 8
