@@ -552,6 +552,33 @@ def cpu_baseline(budget_s=12.0, batch=16):
                sample=f'{iters} fwd+bwd iterations of a {batch}-clip batch (3x{T}x{V}x{M}), oracle/dsgcn_oracle.py, '
                       f'torch {torch.__version__} CPU, {best_thr} intra-op threads (best of 8/16/32); host: {cpu_model}, '
                       f'{phys} physical cores, {hw} hw threads (SMT {"on" if hw > phys else "off"}), {el:.1f} s')
+    # The BASELINE batch itself (N = 64) at the best thread count: the 16-clip figure above keeps the sample
+    # bounded; this one says what the CPU path does on the very batch the GPU step is timed on (2 timed iterations when one
+    # fits a quarter of the budget by the 16-clip rate, else skipped and said so).  
+    try:
+        est = 64.0 / max(res['value'], 1e-9)
+        if est <= 0.6 * budget_s:
+            g64 = torch.Generator().manual_seed(1234)
+            xb = torch.randn(64, 1, M, T, V, C, generator=g64)
+            yb = torch.randint(0, CLASSES, (64, 1), generator=g64)
+
+            def step64():
+                for v in leaves.values():
+                    v.grad = None
+                _, loss = O.recognizer_forward_train(xb, yb, sd, gc['node_type'], gc['edge_type'], plan)
+                loss.backward()
+            step64()
+            t0 = time.perf_counter()
+            step64()
+            step64()
+            t64 = (time.perf_counter() - t0) / 2
+            res['batch64'] = dict(value=round(64 / t64, 2), unit='clips/s', cores=best_thr,
+                                  sample=f'2 fwd+bwd iterations of the 64-clip BASELINE batch at {best_thr} threads, {t64:.1f} s each')
+            del xb, yb
+        else:
+            res['batch64'] = dict(value=None, note=f'one 64-clip iteration would take ~{est:.0f} s at the 16-clip rate: not run')
+    except Exception as exc:
+        res['batch64'] = dict(value=None, error=f'{type(exc).__name__}: {exc}')
     # SURVEY §8(d) also asks for the BASELINE batch (N=64) on ALL physical cores.  With hundreds of small ATen ops per
     # step that configuration is far slower than the best thread count; it is timed only if a short probe says one
     # iteration fits the budget, otherwise the probe-scaled figure is reported and marked as such.
