@@ -1059,7 +1059,11 @@ WsDims ws_dims(int Ci, int Co) {
   return d;
 }
 
-int g_p4_ksp = 1;       // K-split form of the tiny-plane launches (lab key 19)
+// K-split form of the tiny-plane launches (lab key 19).  OFF in the product: measured −0.02 ms/step (profiles/r06/
+// small_launch_ab.txt) — and it changes the summation order of the projection convs, which moved the frozen whole-gradient
+// ratios of the DS-STGCN configurations by 5-20 % (chaotic amplification, every per-kernel test unchanged): not worth a
+// re-recording of the marks.
+int g_p4_ksp = 0;
 int g_p4_fill = 1;      // under-filled launches take one row tile per wave (lab key 20)
 int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128, g_p4_ws = 2;   // ws: 2 = k_pwg3 on the fragment-order image; 1 = row-major image (lab A/B: no consumer left, k_pwg runs); g_p4_pd unused
 
