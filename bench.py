@@ -776,6 +776,19 @@ def main(argv=None):
                               'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()),
                               'rank_ms_per_step': per, 'rank_ms_min': min(per), 'rank_ms_max': max(per),
                               'grad_bytes': int(flat.flat_g.numel() * flat.flat_g.element_size())}
+    # host time per step: how long the Python thread takes to ENQUEUE a step (batch copies, two graph
+    # replays, the collective) against the GPU time of the step — the margin the host has before jitter reaches the GPU;
+    # at N > 1 this is what decides weak-scaling efficiency, and it is measurable at N = 1
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    host_enqueue = (time.perf_counter() - h0) / 10
+    torch.cuda.synchronize()
+    if rank == 0:
+        result['host_enqueue_ms'] = round(host_enqueue * 1e3, 3)
+        result['host_enqueue_note'] = ('wall time of the Python thread per engine.step() call with no synchronisation (10 calls '
+                                       'after the timed region); the GPU step takes ms_per_step')
     # the optimizer update reported separately (the metric is fwd+bwd; the step above includes the update)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

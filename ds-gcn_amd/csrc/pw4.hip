@@ -1065,6 +1065,7 @@ WsDims ws_dims(int Ci, int Co) {
 // re-recording of the marks.
 int g_p4_ksp = 0;
 int g_p4_fill = 1;      // under-filled launches take one row tile per wave (lab key 20)
+int g_p4_mt1 = 0;       // lab key 22: 128-row workgroups also for convs with more than 128 rows (bit 0 forward, bit 1 data gradient)
 int g_p4_nq = 0, g_p4_mt = 0, g_p4_pd = 0, g_p4_gemm = 3, g_p4_gmin = 64, g_p4_gminl = 128, g_p4_ws = 2;   // ws: 2 = k_pwg3 on the fragment-order image; 1 = row-major image (lab A/B: no consumer left, k_pwg runs); g_p4_pd unused
 
 struct P4Plan { int MT, NQ, PD, cc, span, WT, ngrp, Kpad, gemm, Lq, ksp; size_t lds; unsigned grid; };
@@ -1176,7 +1177,7 @@ bool p4_launch_pd(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStrea
                   int Mp = 0) {
   const int key = p.MT * 10 + p.NQ;
   if (p.gemm && wsp && g_p4_ws == 2) {
-    if (a.M > 128) pwg3_launch<2>(a, mode, epi, p, wsp, Mp, st);
+    if (a.M > 128 && !(g_p4_mt1 & (1 << epi))) pwg3_launch<2>(a, mode, epi, p, wsp, Mp, st);
     else pwg3_launch<1>(a, mode, epi, p, wsp, Mp, st);
     return true;
   }
@@ -1233,6 +1234,7 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_tuning(int key, int value) {
   else if (key == 6) g_p4_ws = value;
   else if (key == 7) g_p4_ksp = value;
   else if (key == 8) g_p4_fill = value;
+  else if (key == 9) g_p4_mt1 = value;
   else return DSGCN_EINVAL;
   return 0;
 }

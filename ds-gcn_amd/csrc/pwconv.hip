@@ -1236,6 +1236,7 @@ int dsgcn_pwconv_tuning(int key, int value) {
   if (key >= 15 && key <= 17) return dsgcn_wg2_tuning(key - 11, value);    // wide weight gradient (k_wg3) on / off, split target, co tile
   if (key == 18) return dsgcn_bwd64_tuning(value);                         // one-pass narrow backward: 1 bf16 terms, 0 fp32 MFMA
   if (key == 19) return dsgcn_p4_tuning(7, value);                         // tiny-plane launches: K split over the four waves on / off
+  if (key == 22) return dsgcn_p4_tuning(9, value);                         // wide convs on 128-row workgroups (lab)
   if (key == 20) return dsgcn_p4_tuning(8, value);                         // under-filled launches: one row tile per wave on / off
   return DSGCN_EINVAL;
 }
