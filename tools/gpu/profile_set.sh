@@ -24,7 +24,8 @@ Q stw WRITE_SIZE
 cd $R
 python tools/pmc_summary.py $O/kc_pmc_summary.csv $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4 $O/pmc5 $O/pmc6 $O/pmc7 > $O/summary.log 2>&1
 python tools/ka_traffic.py $(find $O/kaf -name '*counter_collection.csv' | head -1) $(find $O/kaw -name '*counter_collection.csv' | head -1) $O/ka_traffic.json > $O/ka_traffic.log 2>&1
-python tools/step_traffic.py $O/stf $O/stw 2 $O/step_hbm_traffic.csv > $O/step_traffic.log 2>&1
+# 12 = 1 warm-up + 1 timed + the 10 host-enqueue steps bench.py runs
+python tools/step_traffic.py $O/stf $O/stw 12 $O/step_hbm_traffic.csv > $O/step_traffic.log 2>&1
 for d in pmc1 pmc2 pmc3 pmc4 pmc5 pmc6 pmc7 kaf kaw stf stw; do rm -rf $O/$d; done
 cat $O/bench_n1.json | cut -c1-1500; cat $O/summary.log $O/ka_traffic.log $O/step_traffic.log; tail -2 $O/bench.err
 # (round 6) the kernel sequences of one replayed step of the three BASELINE single-GPU configurations
