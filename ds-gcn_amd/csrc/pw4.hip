@@ -39,6 +39,11 @@ struct Pw4Args {
   float* out2; float* ipart;                                               // EPI 1: d x2 or NULL; [ngrp][M][3] or NULL
   int n, K, M, L, span, WT, cc, Kpad;
   int Lq;                                                                  // positions per plane rounded up to a multiple of NQ (ragged planes)
+  // (round 6) up to three convs of ONE shape in a launch (blockIdx.y = which): CTR-GCN refines its topology with three
+  // conv4's per unit, each too small to fill the chip (k_pw4 only; the GEMM forms ignore it)
+  int ngroup;
+  struct Grp { const float* b1; const float* ps1; const float* ph1; const float* w; float* out;
+               const float* ex1; const float* es1; const float* eh1; float* ipart; } g[3];
 };
 
 template <int NQ> struct VQ;
@@ -308,9 +313,15 @@ __device__ __forceinline__ void p4_epilogue(const Pw4Args& a, f32x16 (&acc)[MT][
 // projections: n x 32 positions, K = 128 .. 288): 64 wave tiles x 9 row blocks left the chip at 576 waves each walking
 // K / 2 dependent k-steps (18-21 us for 0.6 GFLOP); split four ways the chain is a quarter as long on four times the waves.
 template <int MT, int NQ, int MODE, int PD, int EPI, bool KSP = false>
-__global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4))) void k_pw4(Pw4Args a) {
+__global__ __launch_bounds__(P4_NT, (MT * NQ >= 6 ? 2 : (MT * NQ >= 4 ? 3 : 4))) void k_pw4(Pw4Args a_) {
   typedef typename VQ<NQ>::T vq;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  Pw4Args a = a_;
+  if (a_.ngroup > 1) {                             // grouped launch: this workgroup's conv
+    const Pw4Args::Grp& q = a_.g[blockIdx.y];
+    a.b1 = q.b1; a.ps1 = q.ps1; a.ph1 = q.ph1; a.w = q.w; a.out = q.out;
+    a.ex1 = q.ex1; a.es1 = q.es1; a.eh1 = q.eh1; a.ipart = q.ipart;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -1133,7 +1144,7 @@ bool p4_plan(int n, int K, int M, int L, P4Plan* p, int epi = 0) {
 
 template <int MT, int NQ, int PD>
 void p4_launch_cfg(const Pw4Args& a, int mode, int epi, const P4Plan& p, hipStream_t st) {
-  const dim3 grid(p.grid), blk(P4_NT);
+  const dim3 grid(p.grid, a.ngroup > 1 ? (unsigned)a.ngroup : 1u), blk(P4_NT);
   if (epi == 0) {
     if (mode == 0) hipLaunchKernelGGL((k_pw4<MT, NQ, 0, PD, 0>), grid, blk, p.lds, st, a);
     else if (mode == 1) hipLaunchKernelGGL((k_pw4<MT, NQ, 1, PD, 0>), grid, blk, p.lds, st, a);
@@ -1294,6 +1305,57 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const 
   const WsDims wd = ws_dims(Ci, Co);
   const unsigned short* wsp = ws ? static_cast<const unsigned short*>(ws) + (size_t)3 * wd.MpN * wd.KpN : nullptr;   // the T image
   const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 1, p, st, wsp, wd.MpT) : p4_launch_pd<16>(a, mode, 1, p, st, wsp, wd.MpT);
+  if (!ok) return 0;
+  DSGCN_LAUNCH_CHECK();
+  return 1;
+}
+
+// Up to three convs of one shape in ONE launch (k_pw4 only: plain / affine operand, no second stream, no statistics).
+// Return 1 = launched, 0 = not eligible (the caller launches them one by one).
+__attribute__((visibility("hidden"))) int dsgcn_p4_group_ok(int n, int Ci, int Co, int L) {
+  P4Plan pf, pb;
+  return (p4_plan(n, Ci, Co, L, &pf, 0) && !pf.gemm && p4_plan(n, Co, Ci, L, &pb, 1) && !pb.gemm) ? 1 : 0;
+}
+
+__attribute__((visibility("hidden"))) int dsgcn_p4_fwd_group(const float* const* x1, const float* const* s1,
+                                                              const float* const* h1, int relu, const float* const* w,
+                                                              float* const* z, int ng, int n, int Ci, int Co, int L,
+                                                              hipStream_t st) {
+  P4Plan p;
+  if (ng < 1 || ng > 3 || !p4_plan(n, Ci, Co, L, &p) || p.gemm) return 0;
+  Pw4Args a = {};
+  a.b1 = x1[0]; a.ps1 = s1[0]; a.ph1 = h1[0]; a.relu = relu;
+  a.w = w[0]; a.w_ldm = Ci; a.w_ldk = 1; a.out = z[0];
+  a.n = n; a.K = Ci; a.M = Co; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad; a.Lq = p.Lq;
+  a.ngroup = ng;
+  for (int g = 0; g < ng; ++g) {
+    if ((s1[g] == nullptr) != (s1[0] == nullptr)) return DSGCN_EINVAL;
+    a.g[g] = Pw4Args::Grp{x1[g], s1[g], h1[g], w[g], z[g], nullptr, nullptr, nullptr, nullptr};
+  }
+  const int mode = (s1[0] || relu) ? 1 : 0;
+  const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, mode, 0, p, st) : p4_launch_pd<16>(a, mode, 0, p, st);
+  if (!ok) return 0;
+  DSGCN_LAUNCH_CHECK();
+  return 1;
+}
+
+__attribute__((visibility("hidden"))) int dsgcn_p4_dgrad_group(const float* const* x1, const float* const* s1,
+                                                                const float* const* h1, int relu, const float* const* w,
+                                                                const float* const* gz, float* const* dx1, float* const* ipart,
+                                                                int ng, int n, int Ci, int Co, int L, hipStream_t st) {
+  P4Plan p;
+  if (ng < 1 || ng > 3 || !p4_plan(n, Co, Ci, L, &p, 1) || p.gemm) return 0;
+  Pw4Args a = {};
+  a.b1 = gz[0]; a.relu = 0;
+  a.w = w[0]; a.w_ldm = 1; a.w_ldk = Ci; a.out = dx1[0];
+  a.ex1 = x1[0]; a.es1 = s1[0]; a.eh1 = h1[0]; a.erelu = relu; a.ipart = ipart[0];
+  a.n = n; a.K = Co; a.M = Ci; a.L = L; a.span = p.span; a.WT = p.WT; a.cc = p.cc; a.Kpad = p.Kpad; a.Lq = p.Lq;
+  a.ngroup = ng;
+  for (int g = 0; g < ng; ++g) {
+    if ((s1[g] == nullptr) != (s1[0] == nullptr) || (ipart[g] == nullptr) != (ipart[0] == nullptr)) return DSGCN_EINVAL;
+    a.g[g] = Pw4Args::Grp{gz[g], nullptr, nullptr, w[g], dx1[g], x1[g], s1[g], h1[g], ipart[g]};
+  }
+  const bool ok = p.PD == 8 ? p4_launch_pd<8>(a, 0, 1, p, st) : p4_launch_pd<16>(a, 0, 1, p, st);
   if (!ok) return 0;
   DSGCN_LAUNCH_CHECK();
   return 1;

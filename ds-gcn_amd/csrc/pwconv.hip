@@ -1194,6 +1194,16 @@ __attribute__((visibility("hidden"))) int dsgcn_p4_dgrad(const float* x1, const 
                                                           float* ipart, int n, int Ci, int Co, int L, hipStream_t st,
                                                           const void* ws);
 
+__attribute__((visibility("hidden"))) int dsgcn_p4_group_ok(int n, int Ci, int Co, int L);
+__attribute__((visibility("hidden"))) int dsgcn_p4_fwd_group(const float* const* x1, const float* const* s1,
+                                                              const float* const* h1, int relu, const float* const* w,
+                                                              float* const* z, int ng, int n, int Ci, int Co, int L,
+                                                              hipStream_t st);
+__attribute__((visibility("hidden"))) int dsgcn_p4_dgrad_group(const float* const* x1, const float* const* s1,
+                                                                const float* const* h1, int relu, const float* const* w,
+                                                                const float* const* gz, float* const* dx1, float* const* ipart,
+                                                                int ng, int n, int Ci, int Co, int L, hipStream_t st);
+
 // bwd64.hip
 __attribute__((visibility("hidden"))) int dsgcn_bwd64_splits(int n, int Ci, int Co, int L);
 __attribute__((visibility("hidden"))) int dsgcn_bwd64(const float* x1, const float* s1, const float* h1, const float* x2,
@@ -1359,6 +1369,40 @@ int dsgcn_bn_finalize(const float* partial, int nblk, int C, double count, const
                      C, count, gamma, beta, eps, mean_out, var_out, scale_out, shift_out, c_affine);
   DSGCN_LAUNCH_CHECK();
   return 0;
+}
+
+// Up to three 1x1 convs of ONE shape in one launch each way (host arrays of ngroup device pointers): z_g = W_g . (x1_g * s1_g +
+// h1_g), no bias / second stream / statistics, stride 1 — CTR-GCN's three conv4's per unit (gcn.py:655-657, one per subset),
+// each of which alone leaves the chip under-filled.  dsgcn_pwconv_group_ok: 1 when the shape takes the grouped form (else
+// the caller launches the convs one by one); the data gradient writes dx1_g and the input-scale rows ipart_g
+// (dsgcn_pwconv_ipart_rows, or NULL for all).  The weight gradients stay per conv (dsgcn_pwconv_wgrad).
+int dsgcn_pwconv_group_ok(int n, int Ci, int Co, int T, int V) {
+  if (n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0) return 0;
+  return ((g_pw4 & 3) == 3) ? dsgcn_p4_group_ok(n, Ci, Co, T * V) : 0;
+}
+
+int dsgcn_pwconv_fwd_group(const float* const* x1, const float* const* s1, const float* const* h1, int relu,
+                           const float* const* w, float* const* z, int ngroup, int n, int Ci, int Co, int T, int V,
+                           void* stream) {
+  if (!x1 || !s1 || !h1 || !w || !z || ngroup < 1 || ngroup > 3 || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0) return DSGCN_EINVAL;
+  for (int g = 0; g < ngroup; ++g)
+    if (!x1[g] || !w[g] || !z[g] || ((s1[g] == nullptr) != (h1[g] == nullptr))) return DSGCN_EINVAL;
+  if (!dsgcn_pwconv_group_ok(n, Ci, Co, T, V)) return DSGCN_EUNSUPPORTED;
+  const int rc = dsgcn_p4_fwd_group(x1, s1, h1, relu, w, z, ngroup, n, Ci, Co, T * V, (hipStream_t)stream);
+  return rc == 1 ? 0 : (rc == 0 ? DSGCN_EUNSUPPORTED : rc);
+}
+
+int dsgcn_pwconv_dgrad_group(const float* const* x1, const float* const* s1, const float* const* h1, int relu,
+                             const float* const* w, const float* const* gz, float* const* dx1, float* const* ipart,
+                             int ngroup, int n, int Ci, int Co, int T, int V, void* stream) {
+  if (!x1 || !s1 || !h1 || !w || !gz || !dx1 || !ipart || ngroup < 1 || ngroup > 3 || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 ||
+      V <= 0)
+    return DSGCN_EINVAL;
+  for (int g = 0; g < ngroup; ++g)
+    if (!x1[g] || !w[g] || !gz[g] || !dx1[g] || ((s1[g] == nullptr) != (h1[g] == nullptr))) return DSGCN_EINVAL;
+  if (!dsgcn_pwconv_group_ok(n, Ci, Co, T, V)) return DSGCN_EUNSUPPORTED;
+  const int rc = dsgcn_p4_dgrad_group(x1, s1, h1, relu, w, gz, dx1, ipart, ngroup, n, Ci, Co, T * V, (hipStream_t)stream);
+  return rc == 1 ? 0 : (rc == 0 ? DSGCN_EUNSUPPORTED : rc);
 }
 
 // njobs <= 4 finalize jobs (include/dsgcn.h: dsgcn_bn_fin_job, the arguments of dsgcn_bn_finalize as a struct) in ONE

@@ -982,6 +982,96 @@ class _PwConv(torch.autograd.Function):
         return (dx1, ds1, dh1, dx2, ds2, dh2, None, dw, db, None, None, dgamma, dbeta, None, None, None, None, None)
 
 
+class _PwConvGroup(torch.autograd.Function):
+    """K <= 3 1x1 convs of ONE shape in one launch each way: z_k = W_k . (x_k * s_k + h_k), no bias, second stream,
+    statistics or stride — CTR-GCN's conv4 per subset in its one-conv form (ctr_topology below), each of which alone leaves
+    the chip under-filled (157 position groups x 1..4 row blocks).  forward(K, slots, x_0.., s_0.., h_0.., w_0..) -> z_0..;
+    backward: ONE grouped data gradient (dx_k, the input-scale rows), the weight gradients per conv, the partial-row sums
+    through _PwConv._finish (same deferral rules: the `sink` decision of _CtrWPrep)."""
+
+    @staticmethod
+    def forward(ctx, K, slots, *ts):
+        xs, ss, hs, ws = ts[:K], ts[K:2 * K], ts[2 * K:3 * K], ts[3 * K:4 * K]
+        _require_cuda(*xs, *ws)
+        xs = [_f32c(t) for t in xs]
+        ss = [_f32c(t) for t in ss]
+        hs = [_f32c(t) for t in hs]
+        w2 = [_f32c(w.reshape(w.shape[0], -1)) for w in ws]
+        n, Ci, T, V = xs[0].shape
+        Co = w2[0].shape[0]
+        zs = [sl.t for sl in slots]
+        for z in zs:
+            if tuple(z.shape) != (n, Co, T, V) or z.dtype != torch.float32 or not z.is_contiguous() or z.requires_grad:
+                raise ValueError(f'pwconv_group(out=): expected contiguous fp32 {(n, Co, T, V)} slices without history')
+        rc = native.lib().dsgcn_pwconv_fwd_group(_ptr_array(xs), _ptr_array(ss), _ptr_array(hs), 0, _ptr_array(w2),
+                                                 _ptr_array(zs), K, n, Ci, Co, T, V, _stream())
+        native.check(rc, 'dsgcn_pwconv_fwd_group')
+        ctx.save_for_backward(*xs, *ss, *hs, *w2)
+        ctx.K = K
+        ctx.wshapes = [tuple(w.shape) for w in ws]
+        ctx.defer_ok = [_leafish(w) for w in ws]
+        sinks = []
+        for w, s1 in zip(ws, ss):
+            sink = getattr(w, '_dsgcn_sink', None)
+            if sink is not None and not (s1 is None or getattr(s1, '_dsgcn_sink', None) is sink):
+                sink = None
+            sinks.append(sink)
+        ctx.sinks = sinks
+        ctx.set_materialize_grads(False)
+        return tuple(zs)
+
+    @staticmethod
+    def backward(ctx, *gzs):
+        K = ctx.K
+        sv = ctx.saved_tensors
+        xs, ss, hs, w2 = sv[:K], sv[K:2 * K], sv[2 * K:3 * K], sv[3 * K:4 * K]
+        n, Ci, T, V = xs[0].shape
+        Co = w2[0].shape[0]
+        dev = xs[0].device
+        lib = native.lib()
+        st = _stream()
+        gzs = [_f32c(g) if g is not None else torch.zeros((n, Co, T, V), device=dev, dtype=torch.float32) for g in gzs]
+        dxs = [torch.empty_like(x) for x in xs]
+        has_s = ss[0] is not None
+        rows = lib.dsgcn_pwconv_ipart_rows(n, Ci, Co, T, V, 1) if has_s else 0
+        iparts = [torch.empty((rows, Ci, 3), device=dev, dtype=torch.float32) if has_s else None for _ in range(K)]
+        rc = lib.dsgcn_pwconv_dgrad_group(_ptr_array(xs), _ptr_array(ss), _ptr_array(hs), 0, _ptr_array(w2), _ptr_array(gzs),
+                                          _ptr_array(dxs), _ptr_array(iparts), K, n, Ci, Co, T, V, st)
+        native.check(rc, 'dsgcn_pwconv_dgrad_group')
+        splits = lib.dsgcn_pwconv_wgrad_splits(n, Ci, Co, T, V, 1)
+        pstride = Co * Ci + Co
+        out_x, out_s, out_h, out_w = [], [], [], []
+        for k in range(K):
+            wpart = torch.empty((splits, pstride), device=dev, dtype=torch.float32)
+            rc = lib.dsgcn_pwconv_wgrad(_ptr(xs[k]), _ptr(ss[k]), _ptr(hs[k]), None, None, None, 0, None, None, _ptr(gzs[k]),
+                                        None, None, None, wpart.data_ptr(), wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co,
+                                        T, V, 1, 0, st)
+            native.check(rc, 'dsgcn_pwconv_wgrad')
+            sink = ctx.sinks[k] is not None and bool(ctx.sinks[k])
+            r = _PwConv._finish(wpart, iparts[k], dxs[k], None, ss[k], None, Co, Ci, ctx.wshapes[k], False, None, None, None,
+                                False, 0, ctx.defer_ok[k], None, None, sink)
+            out_x.append(r[0]); out_s.append(r[1]); out_h.append(r[2]); out_w.append(r[7])
+        return (None, None, *out_x, *out_s, *out_h, *out_w)
+
+
+def pwconv_group(xs, affs, ws, slots):
+    """The K convs ``pwconv(x_k, aff_k, None, None, False, w_k, None, out=slot_k)`` as one launch each way when the shape
+    takes the grouped form, one by one otherwise.  -> [z_k]"""
+    K = len(xs)
+    n, Ci, T, V = xs[0].shape
+    Co = ws[0].shape[0]
+    same = all(x.shape == xs[0].shape for x in xs) and all(w.shape == ws[0].shape for w in ws)
+    if (GROUP_CONVS and 2 <= K <= 3 and same and xs[0].is_cuda and
+            native.lib().dsgcn_pwconv_group_ok(n, Ci, Co, T, V) == 1):
+        ss = [a[0] if a is not None else None for a in affs]
+        hs = [a[1] if a is not None else None for a in affs]
+        return list(_PwConvGroup.apply(K, list(slots), *xs, *ss, *hs, *ws))
+    return [pwconv(x, a, None, None, False, w, None, 1, False, out=sl)[0] for x, a, w, sl in zip(xs, affs, ws, slots)]
+
+
+GROUP_CONVS = _os.environ.get('DSGCN_GROUP_CONVS', '1') == '1'
+
+
 class OutSlot:
     """A preallocated output (a slice of a larger buffer) for ``pwconv(..., out=OutSlot(t))``: the kernel writes z there
     instead of a fresh tensor.  A wrapper, not a tensor argument: autograd must not see the buffer as an input."""
@@ -2221,8 +2311,8 @@ def ctr_topology(xbar, w1, b1, w2, b2, w4, b4, alpha, A, beta=None, edge=None, s
             t._dsgcn_sink = use                 # their gradients are only read by _CtrWPrep's finishing launch
         Co = w4[0].shape[0]
         buf = torch.empty((K, n, Co, V, V), device=xbar.device, dtype=torch.float32)
-        parts = [pwconv(d[k], (prep[K + k], prep[2 * K + k]), None, None, False, prep[k], None, 1, False,
-                        out=OutSlot(buf[k]))[0] for k in range(K)]
+        parts = pwconv_group([d[k] for k in range(K)], [(prep[K + k], prep[2 * K + k]) for k in range(K)],
+                             [prep[k] for k in range(K)], [OutSlot(buf[k]) for k in range(K)])
         return _JoinSlices.apply(OutSlot(buf), *parts)
     d = _TanhDiff.apply(proj, K, R)
     S = []

@@ -115,6 +115,9 @@ SIGNATURES = {
     'dsgcn_dynadj_partial_stride': [c_int, c_int, c_int],
     'dsgcn_dynadj_fwd': [c_f] * 6 + [c_i, c_i, c_f] + [c_int] * 6 + [c_st],
     'dsgcn_dynadj_bwd': [c_f] * 5 + [c_i, c_i] + [c_f] * 4 + [c_int] * 7 + [c_st],
+    'dsgcn_pwconv_group_ok': [c_int] * 5,
+    'dsgcn_pwconv_fwd_group': [ctypes.c_void_p] * 3 + [c_int] + [ctypes.c_void_p] * 2 + [c_int] * 6 + [c_st],
+    'dsgcn_pwconv_dgrad_group': [ctypes.c_void_p] * 3 + [c_int] + [ctypes.c_void_p] * 4 + [c_int] * 6 + [c_st],
     'dsgcn_pwconv_wgrad_jobs': [c_f] * 6 + [c_int] + [c_f] * 8 + [c_int] * 8 + [ctypes.c_void_p, c_int, c_st],
     'dsgcn_tms_split_wgrad_jobs': [c_f] * 4 + [c_int] + [c_f] * 2 + [c_int] * 6 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, ctypes.c_void_p, c_int, c_st],
     'dsgcn_fuse_out_fwd_drop': [c_f] * 6 + [c_int] + [c_f] * 4 + [c_int] * 5 + [ctypes.c_void_p, c_st],
@@ -282,8 +285,11 @@ def lab_lib():
     global _lab
     if _lab is None:
         # DSGCN_LAB_LIB: an A/B run of tools/ against another build of the lab library (e.g. the previous round's kernels)
-        handle = ctypes.CDLL(os.environ.get('DSGCN_LAB_LIB') or build(lab=True))
+        other = os.environ.get('DSGCN_LAB_LIB')
+        handle = ctypes.CDLL(other or build(lab=True))
         for name, argtypes in {**SIGNATURES, **LAB_SIGNATURES}.items():
+            if other and not hasattr(handle, name):
+                continue                                # (an older build under A/B: entry points added since are simply absent)
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_size_t if name in SIZE_T_RESULTS else ctypes.c_int

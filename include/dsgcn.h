@@ -291,6 +291,18 @@ int dsgcn_pwconv_wgrad_jobs(const float* x1, const float* s1, const float* h1, c
                             const float* gzaug, const float* A0, const float* B0, float* dwp, float* dbp, int pstride, int n,
                             int Ci, int Co, int T, int V, int stride, int aug, const dsgcn_bn_coef_job* jobs, int njobs,
                             void* stream);
+/* Up to three 1x1 convs of ONE shape in one launch each way (host arrays of ngroup <= 3 device pointers):
+ * z_g = W_g . (x1_g * s1_g[ci] + h1_g[ci]) (s1_g / h1_g NULL for all or none), no bias, second stream or statistics, stride 1
+ * — the three conv4's of a CTR-GCN unit (gcn.py:655-657 per subset), each too small to fill the chip alone.
+ * dsgcn_pwconv_group_ok = 1 when the shape takes the grouped form (otherwise DSGCN_EUNSUPPORTED: launch them one by one).
+ * The data gradient writes dx1_g and, when ipart_g is given, the input-scale rows (dsgcn_pwconv_ipart_rows each). */
+int dsgcn_pwconv_group_ok(int n, int Ci, int Co, int T, int V);
+int dsgcn_pwconv_fwd_group(const float* const* x1, const float* const* s1, const float* const* h1, int relu,
+                           const float* const* w, float* const* z, int ngroup, int n, int Ci, int Co, int T, int V,
+                           void* stream);
+int dsgcn_pwconv_dgrad_group(const float* const* x1, const float* const* s1, const float* const* h1, int relu,
+                             const float* const* w, const float* const* gz, float* const* dx1, float* const* ipart,
+                             int ngroup, int n, int Ci, int Co, int T, int V, void* stream);
 
 /* ---- K-A': subset-summed aggregate (ST-GCN unit_gcn gcn.py:81-86, CTR-GCN unit_ctrgcn gcn.py:658,917-921) ----
  * y[n,c,t,w] = sum_k sum_u p[n,k*Co+c,t,u] * adj_k[u,w], adj_k at ahat + n*a_ns + k*a_ks + c*a_cs (element strides):
