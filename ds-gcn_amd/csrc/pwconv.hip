@@ -1218,7 +1218,10 @@ __attribute__((visibility("hidden"))) int dsgcn_wg2(const float* x1, const float
                                                      const float* s2, const float* h2, int relu, const float* z,
                                                      const float* gz, const float* A0, const float* B0, float* dwp,
                                                      float* dbp, int pstride, int n, int Ci, int Co, int L,
-                                                     hipStream_t st, const BnCoefTable* jobs);
+                                                     hipStream_t st, const BnCoefTable* jobs, int ngroup = 0,
+                                                     const float* const* gx1 = nullptr, const float* const* gs1 = nullptr,
+                                                     const float* const* gh1 = nullptr, const float* const* ggz = nullptr,
+                                                     float* const* gdwp = nullptr, float* const* gdbp = nullptr);
 
 // workgroup rows of the statistics / input-affine partial buffers for a (K -> M) mix over n planes of L positions
 static int pw_conv_rows(int n, int K, int M, int T, int V, int stride, int which) {
@@ -1403,6 +1406,23 @@ int dsgcn_pwconv_dgrad_group(const float* const* x1, const float* const* s1, con
   if (!dsgcn_pwconv_group_ok(n, Ci, Co, T, V)) return DSGCN_EUNSUPPORTED;
   const int rc = dsgcn_p4_dgrad_group(x1, s1, h1, relu, w, gz, dx1, ipart, ngroup, n, Ci, Co, T * V, (hipStream_t)stream);
   return rc == 1 ? 0 : (rc == 0 ? DSGCN_EUNSUPPORTED : rc);
+}
+
+// the weight gradients of the same group (dwp_g / dbp_g: partial rows as dsgcn_pwconv_wgrad, dsgcn_pwconv_wgrad_splits rows each)
+int dsgcn_pwconv_wgrad_group(const float* const* x1, const float* const* s1, const float* const* h1, int relu,
+                             const float* const* gz, float* const* dwp, float* const* dbp, int pstride, int ngroup, int n,
+                             int Ci, int Co, int T, int V, void* stream) {
+  if (!x1 || !s1 || !h1 || !gz || !dwp || !dbp || ngroup < 1 || ngroup > 3 || n <= 0 || Ci <= 0 || Co <= 0 || T <= 0 || V <= 0)
+    return DSGCN_EINVAL;
+  for (int g = 0; g < ngroup; ++g)
+    if (!x1[g] || !gz[g] || !dwp[g] || !dbp[g] || ((s1[g] == nullptr) != (h1[g] == nullptr)) ||
+        ((s1[g] == nullptr) != (s1[0] == nullptr)))
+      return DSGCN_EINVAL;
+  if (pstride < Co * Ci || !(g_pw4 & 4)) return pstride < Co * Ci ? DSGCN_EINVAL : DSGCN_EUNSUPPORTED;
+  BnCoefTable none = {};
+  const int fast = dsgcn_wg2(x1[0], s1[0], h1[0], nullptr, nullptr, nullptr, relu, nullptr, gz[0], nullptr, nullptr, dwp[0],
+                             dbp[0], pstride, n, Ci, Co, T * V, (hipStream_t)stream, &none, ngroup, x1, s1, h1, gz, dwp, dbp);
+  return fast == 1 ? 0 : (fast == 0 ? DSGCN_EUNSUPPORTED : fast);
 }
 
 // njobs <= 4 finalize jobs (include/dsgcn.h: dsgcn_bn_fin_job, the arguments of dsgcn_bn_finalize as a struct) in ONE

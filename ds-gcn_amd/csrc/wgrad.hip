@@ -26,6 +26,9 @@ struct Wg2Args {
   int n, Ci, Co, L, cpn, total_chunks, cps, tm_tiles, tn_tiles;
   int main_blocks;                 // workgroups of the weight gradient; the ones past them run the hosted BatchNorm jobs
   BnCoefTable jobs;                // (bn_jobs.h) coefficient jobs of BatchNorms whose rows the DATA gradient before this launch wrote
+  // (round 6) up to three weight gradients of ONE shape in a launch (blockIdx.y = which): CTR-GCN's conv4 per subset
+  int ngroup;
+  struct Grp { const float* x1; const float* s1; const float* h1; const float* gz; float* dwp; float* dbp; } g[3];
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* p, int bytes) {
@@ -42,7 +45,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // in place of eight fp32 ones at twice the cycles each); rows of KC bf16 + 16 B of pad per term (conflict-free 16-byte
 // fragment reads: a lane reads 8 consecutive positions of its channel row).
 template <int TM, int TN, int KC, bool HAS2, bool HASC, bool B3 = false>
-__global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
+__global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a_) {
+  Wg2Args a = a_;
+  if (a_.ngroup > 1) {                             // grouped launch: this workgroup's conv
+    const Wg2Args::Grp& q = a_.g[blockIdx.y];
+    a.x1 = q.x1; a.s1 = q.s1; a.h1 = q.h1; a.gz = q.gz; a.dwp = q.dwp; a.dbp = q.dbp;
+  }
   constexpr int LS = KC + 2;
   constexpr int RB = KC * 2 + 16;                 // B3: bytes per row per term
   constexpr int Q = KC / 4;                       // float4 slots per row
@@ -298,7 +306,12 @@ __global__ __launch_bounds__(WG_NT, 2) void k_wg2(Wg2Args a) {
 constexpr int W3_NT = 512, W3_KC = 16, W3_RB = 48;
 
 template <int TM, int TN, bool HAS2, bool HASC>
-__global__ __launch_bounds__(W3_NT, 2) void k_wg3(Wg2Args a) {
+__global__ __launch_bounds__(W3_NT, 2) void k_wg3(Wg2Args a_) {
+  Wg2Args a = a_;
+  if (a_.ngroup > 1) {                             // grouped launch: this workgroup's conv
+    const Wg2Args::Grp& q = a_.g[blockIdx.y];
+    a.x1 = q.x1; a.s1 = q.s1; a.h1 = q.h1; a.gz = q.gz; a.dwp = q.dwp; a.dbp = q.dbp;
+  }
   constexpr int JD = TM * 4 / W3_NT, JX = TN * 4 / W3_NT;          // float4 slots per thread and chunk
   constexpr int MI = TM / 128, NI = TN / 64;                       // wave tile: (TM/4) x (TN/2) = MI x NI MFMA tiles
   constexpr int BUF = 3 * (TM + TN) * W3_RB;
@@ -643,18 +656,26 @@ __attribute__((visibility("hidden"))) int dsgcn_wg2(const float* x1, const float
                                                      const float* s2, const float* h2, int relu, const float* z,
                                                      const float* gz, const float* A0, const float* B0, float* dwp,
                                                      float* dbp, int pstride, int n, int Ci, int Co, int L,
-                                                     hipStream_t st, const BnCoefTable* jobs) {
+                                                     hipStream_t st, const BnCoefTable* jobs, int ngroup,
+                                                     const float* const* gx1, const float* const* gs1,
+                                                     const float* const* gh1, const float* const* ggz, float* const* gdwp,
+                                                     float* const* gdbp) {
   Wg2Plan p;
   if (!wg2_plan(n, Ci, Co, L, &p)) return 0;
   Wg2Args a = {};
   if (jobs) a.jobs = *jobs;
+  if (ngroup > 1) {
+    if (ngroup > 3 || x2 || A0) return 0;
+    a.ngroup = ngroup;
+    for (int g = 0; g < ngroup; ++g) a.g[g] = Wg2Args::Grp{gx1[g], gs1[g], gh1[g], ggz[g], gdwp[g], gdbp[g]};
+  }
   a.x1 = x1; a.s1 = s1; a.h1 = h1; a.x2 = x2; a.s2 = s2; a.h2 = h2; a.relu = relu;
   a.z = z; a.gz = gz; a.A0 = A0; a.B0 = B0; a.dwp = dwp; a.dbp = dbp; a.pstride = pstride;
   a.n = n; a.Ci = Ci; a.Co = Co; a.L = L; a.cpn = p.cpn; a.total_chunks = p.chunks; a.cps = p.cps;
   a.tm_tiles = p.tm_tiles; a.tn_tiles = p.tn_tiles;
   const int tiles = p.tm_tiles * p.tn_tiles;
   a.main_blocks = tiles > 1 ? (p.splits + 7) / 8 * 8 * tiles : p.splits;
-  const dim3 grid((unsigned)(a.main_blocks + bnj_total_blocks(a.jobs)));
+  const dim3 grid((unsigned)(a.main_blocks + bnj_total_blocks(a.jobs)), ngroup > 1 ? (unsigned)ngroup : 1u);
   const bool has2 = x2 != nullptr, hasc = A0 != nullptr;
   if (p.v3) {
 #ifdef DSGCN_LAB                                   // the full 256 x 256 tile (key 17 = 256) measured slower in the step: lab builds only

@@ -1041,12 +1041,23 @@ class _PwConvGroup(torch.autograd.Function):
         splits = lib.dsgcn_pwconv_wgrad_splits(n, Ci, Co, T, V, 1)
         pstride = Co * Ci + Co
         out_x, out_s, out_h, out_w = [], [], [], []
+        wparts = [torch.empty((splits, pstride), device=dev, dtype=torch.float32) for _ in range(K)]
+        dwp = (_ct.c_void_p * K)(*[w.data_ptr() for w in wparts])
+        dbp = (_ct.c_void_p * K)(*[w.data_ptr() + 4 * Co * Ci for w in wparts])
+        rc = -2
+        if GROUP_WGRAD:
+            rc = lib.dsgcn_pwconv_wgrad_group(_ptr_array(xs), _ptr_array(ss), _ptr_array(hs), 0, _ptr_array(gzs), dwp, dbp,
+                                              pstride, K, n, Ci, Co, T, V, st)
+        if rc == -2:                                 # not on the blocked kernels: one by one
+            for k in range(K):
+                rc = lib.dsgcn_pwconv_wgrad(_ptr(xs[k]), _ptr(ss[k]), _ptr(hs[k]), None, None, None, 0, None, None,
+                                            _ptr(gzs[k]), None, None, None, wparts[k].data_ptr(),
+                                            wparts[k].data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co, T, V, 1, 0, st)
+                native.check(rc, 'dsgcn_pwconv_wgrad')
+        else:
+            native.check(rc, 'dsgcn_pwconv_wgrad_group')
         for k in range(K):
-            wpart = torch.empty((splits, pstride), device=dev, dtype=torch.float32)
-            rc = lib.dsgcn_pwconv_wgrad(_ptr(xs[k]), _ptr(ss[k]), _ptr(hs[k]), None, None, None, 0, None, None, _ptr(gzs[k]),
-                                        None, None, None, wpart.data_ptr(), wpart.data_ptr() + 4 * Co * Ci, pstride, n, Ci, Co,
-                                        T, V, 1, 0, st)
-            native.check(rc, 'dsgcn_pwconv_wgrad')
+            wpart = wparts[k]
             sink = ctx.sinks[k] is not None and bool(ctx.sinks[k])
             r = _PwConv._finish(wpart, iparts[k], dxs[k], None, ss[k], None, Co, Ci, ctx.wshapes[k], False, None, None, None,
                                 False, 0, ctx.defer_ok[k], None, None, sink)
@@ -1070,6 +1081,7 @@ def pwconv_group(xs, affs, ws, slots):
 
 
 GROUP_CONVS = _os.environ.get('DSGCN_GROUP_CONVS', '1') == '1'
+GROUP_WGRAD = _os.environ.get('DSGCN_GROUP_WGRAD', '1') == '1'      # the group's weight gradients in one launch too
 
 
 class OutSlot:

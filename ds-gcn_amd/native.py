@@ -118,6 +118,7 @@ SIGNATURES = {
     'dsgcn_pwconv_group_ok': [c_int] * 5,
     'dsgcn_pwconv_fwd_group': [ctypes.c_void_p] * 3 + [c_int] + [ctypes.c_void_p] * 2 + [c_int] * 6 + [c_st],
     'dsgcn_pwconv_dgrad_group': [ctypes.c_void_p] * 3 + [c_int] + [ctypes.c_void_p] * 4 + [c_int] * 6 + [c_st],
+    'dsgcn_pwconv_wgrad_group': [ctypes.c_void_p] * 3 + [c_int] + [ctypes.c_void_p] * 3 + [c_int] * 7 + [c_st],
     'dsgcn_pwconv_wgrad_jobs': [c_f] * 6 + [c_int] + [c_f] * 8 + [c_int] * 8 + [ctypes.c_void_p, c_int, c_st],
     'dsgcn_tms_split_wgrad_jobs': [c_f] * 4 + [c_int] + [c_f] * 2 + [c_int] * 6 + [c_i] * 4 + [ctypes.c_void_p, ctypes.c_void_p, c_int, c_int, ctypes.c_void_p, c_int, c_st],
     'dsgcn_fuse_out_fwd_drop': [c_f] * 6 + [c_int] + [c_f] * 4 + [c_int] * 5 + [ctypes.c_void_p, c_st],

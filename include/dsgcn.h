@@ -303,6 +303,12 @@ int dsgcn_pwconv_fwd_group(const float* const* x1, const float* const* s1, const
 int dsgcn_pwconv_dgrad_group(const float* const* x1, const float* const* s1, const float* const* h1, int relu,
                              const float* const* w, const float* const* gz, float* const* dx1, float* const* ipart,
                              int ngroup, int n, int Ci, int Co, int T, int V, void* stream);
+/* The weight gradients of the same group in one launch: dwp_g / dbp_g take the partial rows of conv g
+ * (dsgcn_pwconv_wgrad_splits rows of pstride floats each, as dsgcn_pwconv_wgrad); DSGCN_EUNSUPPORTED when the shape is not on
+ * the blocked weight-gradient kernels (launch them one by one then). */
+int dsgcn_pwconv_wgrad_group(const float* const* x1, const float* const* s1, const float* const* h1, int relu,
+                             const float* const* gz, float* const* dwp, float* const* dbp, int pstride, int ngroup, int n,
+                             int Ci, int Co, int T, int V, void* stream);
 
 /* ---- K-A': subset-summed aggregate (ST-GCN unit_gcn gcn.py:81-86, CTR-GCN unit_ctrgcn gcn.py:658,917-921) ----
  * y[n,c,t,w] = sum_k sum_u p[n,k*Co+c,t,u] * adj_k[u,w], adj_k at ahat + n*a_ns + k*a_ks + c*a_cs (element strides):
