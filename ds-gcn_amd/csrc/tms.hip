@@ -540,16 +540,37 @@ __global__ __launch_bounds__(TM_NT, 2) void k_tms_dgrad(TmArgs a) {
   float* Cl = Ol + TM_CK * RG;                       // coeff[V]
   float* Rl = Cl + 32;                               // [16][32] d coeff reduction
   const int DS = tm_xs(R * VL);
-  const int NP = R * VL, NTU = (NP + 15) >> 4;
+  const int NP = R * VL;
   const float invVL = 1.f / (float)VL, invV = 1.f / (float)V;
+  // Stride 2 (round 6): a tap reaches an input frame only when (frame - shift) is even, so with the tile's positions in
+  // plane order half of every tile's lanes multiplied zeros for every tap.  The 16-position MFMA tiles now hold frames of
+  // ONE parity (even frames first, then odd): a (tile, tap) pair is wholly live or wholly dead, the dead half is skipped
+  // (CTR-GCN's stride-2 blocks: 339 / 286 us per launch before).  PAR = that mapping; it needs tiles_e + tiles_o <= 32.
+  const int Re = (R + 1) >> 1, Ro = R >> 1;
+  const int tiles_e = (Re * VL + 15) >> 4, tiles_o = (Ro * VL + 15) >> 4;
+  const bool PAR = s == 2 && tiles_e + tiles_o <= 8 * TM_NTW;
+  const int NTU = PAR ? tiles_e + tiles_o : (NP + 15) >> 4;
   if (br.type == 0) tm_stage_w<KT, false>(br, Wl, CKW, MP, tid);
   if (AUG) for (int i = tid; i < V; i += TM_NT) Cl[i] = a.coeff[i];
   int rP[TM_NTW], xP[TM_NTW];
+  bool vP[TM_NTW];                                   // this lane's position of tile i exists
 #pragma unroll
   for (int i = 0; i < TM_NTW; ++i) {
-    int P = 16 * (wave + 8 * i) + (lane & 15);
-    if (P >= NP) P = NP - 1;
-    divmod_small(P, VL, invVL, rP[i], xP[i]);
+    const int tile = wave + 8 * i;
+    if (PAR) {
+      const int cls = tile >= tiles_e ? 1 : 0, nc = (cls ? Ro : Re) * VL;
+      int jj = 16 * (tile - cls * tiles_e) + (lane & 15);
+      vP[i] = jj < nc;
+      if (jj >= nc) jj = nc > 0 ? nc - 1 : 0;
+      int fr;
+      divmod_small(jj, VL, invVL, fr, xP[i]);
+      rP[i] = 2 * fr + cls;
+    } else {
+      int P = 16 * tile + (lane & 15);
+      vP[i] = P < NP;
+      if (P >= NP) P = NP - 1;
+      divmod_small(P, VL, invVL, rP[i], xP[i]);
+    }
   }
   const int ci_l = tid >> 5, sub = tid & 31;
   float ps[MTL], pb[MTL];                            // partial sums: d scale, d shift of channel 16 m + ci_l
@@ -642,12 +663,15 @@ __global__ __launch_bounds__(TM_NT, 2) void k_tms_dgrad(TmArgs a) {
         for (int tap = 0; tap < KT; ++tap) {
           const int shr = (tap - KT / 2) * br.dil;                  // input frame = output frame * s + shr
           int offs[TM_NTW];
-          bool okp[TM_NTW];
+          bool okp[TM_NTW], livet[TM_NTW];
 #pragma unroll
           for (int i = 0; i < TM_NTW; ++i) {
             const int num = rP[i] - shr;                            // (t0 is a multiple of s: the tile offset drops out)
             okp[i] = s == 1 || !(num & 1);
             offs[i] = ((s == 1 ? num : (num >> 1)) + TM_H) * VL + xP[i];
+            // PAR: the parity of (frame - shift) is the tile's (wave-uniform): a dead (tile, tap) pair is skipped whole
+            const int tile = wave + 8 * i;
+            livet[i] = !PAR || !(((tile >= tiles_e ? 1 : 0) - shr) & 1);
           }
 #pragma unroll 1
           for (int ks = 0; ks < TM_CK / 4; ++ks) {
@@ -657,7 +681,7 @@ __global__ __launch_bounds__(TM_NT, 2) void k_tms_dgrad(TmArgs a) {
             const float* grow = Gl + (4 * ks + kq) * XS;
 #pragma unroll
             for (int i = 0; i < TM_NTW; ++i) {
-              if (wave + 8 * i < NTU) {
+              if (wave + 8 * i < NTU && livet[i]) {
                 const float bv = okp[i] ? grow[offs[i]] : 0.f;
 #pragma unroll
                 for (int m = 0; m < MTL; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv, acc[i][m], 0, 0, 0);
@@ -699,8 +723,8 @@ __global__ __launch_bounds__(TM_NT, 2) void k_tms_dgrad(TmArgs a) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM_NTW; ++i) {
-          const int P = 16 * (wave + 8 * i) + (lane & 15);
-          if (wave + 8 * i < NTU && P < NP) {
+          const int P = rP[i] * VL + xP[i];                           // plane order, whatever order the tiles hold
+          if (wave + 8 * i < NTU && vP[i]) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) Gl[(4 * kq + r) * DS + P] = acc[i][m][r];
           }
