@@ -12,6 +12,7 @@
 //                MSTCN, msg3d_utils.py:101-117) -> dsgcn_bn_finalize
 // All are HBM-bound streaming passes, one wave per V*V (or T*V) plane.
 #include "common.h"
+#include "dsgcn_jobs.h"
 
 namespace {
 
@@ -218,49 +219,60 @@ __global__ __launch_bounds__(64) void k_plane_stats(const float* __restrict__ x,
   }
 }
 
-// The augmented conv4 operands of a CTR-GCN unit (see k_tanhdiff_fwd): block k builds W'_k (Co, R + 2) = [W_k | 1 | b_k]
-// and its input affine (scale [alpha x R, 1, alpha], shift 0) at sh + k*2*(R+2).
-__global__ __launch_bounds__(256) void k_ctr_wprep(CtrPtrs w, CtrPtrs b, const float* __restrict__ alpha,
-                                                   float* __restrict__ wout, float* __restrict__ sh, int Co, int R) {
-  const int k = blockIdx.x, R2 = R + 2;
-  const float* __restrict__ wk = w.s[k];
-  const float* __restrict__ bk = b.s[k];
-  float* __restrict__ o = wout + (size_t)k * Co * R2;
+// The augmented conv4 operands of a CTR-GCN unit (see k_tanhdiff_fwd), as JOBS (include/dsgcn_jobs.h: one record per
+// unit, blockIdx.z = record — every unit of a model in one launch at the head of the step, they depend on parameters
+// only): block k of a record builds W'_k (Co, R + 2) = [W_k | 1 | b_k] and its input affine (scale [alpha x R, 1, alpha],
+// shift 0) at sh + k*2*(R+2).
+struct CtrPrepTable {
+  dsgcn_ctr_prep_job j[DSGCN_CTR_JOBS_MAX];
+};
+struct CtrFinTable {
+  dsgcn_ctr_fin_job j[DSGCN_CTR_JOBS_MAX];
+};
+
+__global__ __launch_bounds__(256) void k_ctr_wprep(CtrPrepTable t) {
+  const dsgcn_ctr_prep_job& a = t.j[blockIdx.z];
+  const int k = blockIdx.x, R = a.R, Co = a.Co, R2 = R + 2;
+  if (k >= a.K) return;
+  const float* __restrict__ wk = a.w[k];
+  const float* __restrict__ bk = a.b[k];
+  float* __restrict__ o = a.wout + (size_t)k * Co * R2;
   const int e = blockIdx.y * 256 + threadIdx.x;                    // (grid.y covers Co * (R + 2): one element per thread)
   if (e < Co * R2) {
     const int c = e / R2, r = e - c * R2;
     o[e] = r < R ? wk[(size_t)c * R + r] : (r == R ? 1.f : (bk ? bk[c] : 0.f));
   }
   if (blockIdx.y == 0) {
-    const float al = alpha[0];
+    const float al = a.alpha[0];
     for (int r = threadIdx.x; r < R2; r += 256) {
-      sh[(size_t)k * 2 * R2 + r] = r == R ? 1.f : al;
-      sh[(size_t)k * 2 * R2 + R2 + r] = 0.f;
+      a.sh[(size_t)k * 2 * R2 + r] = r == R ? 1.f : al;
+      a.sh[(size_t)k * 2 * R2 + R2 + r] = 0.f;
     }
   }
 }
 
 // Its backward: dW_k = dW'_k[:, :R], db_k = dW'_k[:, R + 1] (the input scale already put alpha on those columns), and
 // block K: dalpha = sum_k (sum_{r<R} ds_k[r] + ds_k[R + 1]) from the input-scale gradients (fixed order).
-__global__ __launch_bounds__(256) void k_ctr_wfin(CtrPtrs dwp, CtrPtrs dsv, CtrPtrs out, float* __restrict__ dalpha, int K,
-                                                  int Co, int R, int dss) {
-  const int R2 = R + 2;
+__global__ __launch_bounds__(256) void k_ctr_wfin(CtrFinTable t) {
+  const dsgcn_ctr_fin_job& a = t.j[blockIdx.z];
+  const int K = a.K, Co = a.Co, R = a.R, dss = a.ds_stride, R2 = R + 2;
+  if ((int)blockIdx.x > K) return;
   if ((int)blockIdx.x == K) {
     if (threadIdx.x == 0 && blockIdx.y == 0) {
-      float a = 0.f;
+      float s = 0.f;
       for (int k = 0; k < K; ++k)
-        if (dsv.s[k]) {
-          for (int r = 0; r < R; ++r) a += dsv.s[k][(size_t)r * dss];
-          a += dsv.s[k][(size_t)(R + 1) * dss];
+        if (a.ds[k]) {
+          for (int r = 0; r < R; ++r) s += a.ds[k][(size_t)r * dss];
+          s += a.ds[k][(size_t)(R + 1) * dss];
         }
-      dalpha[0] = a;
+      a.dalpha[0] = s;
     }
     return;
   }
   const int k = blockIdx.x;
-  const float* __restrict__ g = dwp.s[k];
-  float* __restrict__ dw = out.ds[k];
-  float* __restrict__ db = out.ds[k] + (size_t)Co * R;
+  const float* __restrict__ g = a.dwp[k];
+  float* __restrict__ dw = a.out[k];
+  float* __restrict__ db = a.out[k] + (size_t)Co * R;
   const int e = blockIdx.y * 256 + threadIdx.x;                    // (grid.y covers Co * R)
   if (e < Co * R) {
     const int c = e / R, r = e - c * R;
@@ -302,19 +314,68 @@ int dsgcn_tanhdiff_aug_bwd(const float* d, const float* const* dd, float* dproj,
   return 0;
 }
 
+// The augmented conv4 operands of njobs units in one launch (records: include/dsgcn_jobs.h).
+int dsgcn_ctr_wprep_multi(const dsgcn_ctr_prep_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs <= 0) return DSGCN_EINVAL;
+  for (int i = 0; i < njobs; ++i) {
+    const dsgcn_ctr_prep_job& a = jobs[i];
+    if (!a.alpha || !a.wout || !a.sh || a.K <= 0 || a.K > CTR_MAXK || a.Co <= 0 || a.R <= 0) return DSGCN_EINVAL;
+    for (int k = 0; k < a.K; ++k)
+      if (!a.w[k]) return DSGCN_EINVAL;
+  }
+  for (int i0 = 0; i0 < njobs; i0 += DSGCN_CTR_JOBS_MAX) {
+    const int m = njobs - i0 < DSGCN_CTR_JOBS_MAX ? njobs - i0 : DSGCN_CTR_JOBS_MAX;
+    CtrPrepTable t = {};
+    int kmax = 0, ymax = 0;
+    for (int i = 0; i < m; ++i) {
+      t.j[i] = jobs[i0 + i];
+      const int y = (t.j[i].Co * (t.j[i].R + 2) + 255) / 256;
+      kmax = t.j[i].K > kmax ? t.j[i].K : kmax;
+      ymax = y > ymax ? y : ymax;
+    }
+    hipLaunchKernelGGL(k_ctr_wprep, dim3((unsigned)kmax, (unsigned)ymax, (unsigned)m), dim3(256), 0, (hipStream_t)stream,
+                       t);
+    DSGCN_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 // w / b: K device pointers (Co, R) / (Co) or NULL; wout (K, Co, R + 2); sh (K, 2, R + 2) = per subset [scale; shift].
 int dsgcn_ctr_wprep(const float* const* w, const float* const* b, const float* alpha, float* wout, float* sh, int K,
                     int Co, int R, void* stream) {
-  if (!w || !b || !alpha || !wout || !sh || K <= 0 || K > CTR_MAXK || Co <= 0 || R <= 0) return DSGCN_EINVAL;
-  CtrPtrs pw = {}, pb = {};
+  if (!w || !b || K <= 0 || K > CTR_MAXK) return DSGCN_EINVAL;
+  dsgcn_ctr_prep_job j = {};
   for (int k = 0; k < K; ++k) {
-    if (!w[k]) return DSGCN_EINVAL;
-    pw.s[k] = w[k];
-    pb.s[k] = b[k];
+    j.w[k] = w[k];
+    j.b[k] = b[k];
   }
-  hipLaunchKernelGGL(k_ctr_wprep, dim3((unsigned)K, (unsigned)((Co * (R + 2) + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, pw, pb, alpha, wout, sh, Co, R);
-  DSGCN_LAUNCH_CHECK();
+  j.alpha = alpha, j.wout = wout, j.sh = sh, j.K = K, j.Co = Co, j.R = R;
+  return dsgcn_ctr_wprep_multi(&j, 1, stream);
+}
+
+// The finishing launches of njobs units as one (records: include/dsgcn_jobs.h).
+int dsgcn_ctr_wfin_multi(const dsgcn_ctr_fin_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs <= 0) return DSGCN_EINVAL;
+  for (int i = 0; i < njobs; ++i) {
+    const dsgcn_ctr_fin_job& a = jobs[i];
+    if (!a.dalpha || a.K <= 0 || a.K > CTR_MAXK || a.Co <= 0 || a.R <= 0 || a.ds_stride <= 0) return DSGCN_EINVAL;
+    for (int k = 0; k < a.K; ++k)
+      if (!a.out[k]) return DSGCN_EINVAL;
+  }
+  for (int i0 = 0; i0 < njobs; i0 += DSGCN_CTR_JOBS_MAX) {
+    const int m = njobs - i0 < DSGCN_CTR_JOBS_MAX ? njobs - i0 : DSGCN_CTR_JOBS_MAX;
+    CtrFinTable t = {};
+    int kmax = 0, ymax = 0;
+    for (int i = 0; i < m; ++i) {
+      t.j[i] = jobs[i0 + i];
+      const int y = (t.j[i].Co * t.j[i].R + 255) / 256;
+      kmax = t.j[i].K > kmax ? t.j[i].K : kmax;
+      ymax = y > ymax ? y : ymax;
+    }
+    hipLaunchKernelGGL(k_ctr_wfin, dim3((unsigned)(kmax + 1), (unsigned)ymax, (unsigned)m), dim3(256), 0,
+                       (hipStream_t)stream, t);
+    DSGCN_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -323,18 +384,15 @@ int dsgcn_ctr_wprep(const float* const* w, const float* const* b, const float* a
 // out: K buffers (Co*R + Co) = [dW_k | db_k]; dalpha (1).
 int dsgcn_ctr_wfin(const float* const* dwp, const float* const* ds, int ds_stride, float* const* out, float* dalpha, int K,
                    int Co, int R, void* stream) {
-  if (!dwp || !ds || !out || !dalpha || K <= 0 || K > CTR_MAXK || Co <= 0 || R <= 0 || ds_stride <= 0) return DSGCN_EINVAL;
-  CtrPtrs pg = {}, pd = {}, po = {};
+  if (!dwp || !ds || !out || K <= 0 || K > CTR_MAXK) return DSGCN_EINVAL;
+  dsgcn_ctr_fin_job j = {};
   for (int k = 0; k < K; ++k) {
-    if (!out[k]) return DSGCN_EINVAL;
-    pg.s[k] = dwp[k];
-    pd.s[k] = ds[k];
-    po.ds[k] = out[k];
+    j.dwp[k] = dwp[k];
+    j.ds[k] = ds[k];
+    j.out[k] = out[k];
   }
-  hipLaunchKernelGGL(k_ctr_wfin, dim3((unsigned)(K + 1), (unsigned)((Co * R + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, pg, pd, po, dalpha, K, Co, R, ds_stride);
-  DSGCN_LAUNCH_CHECK();
-  return 0;
+  j.dalpha = dalpha, j.K = K, j.Co = Co, j.R = R, j.ds_stride = ds_stride;
+  return dsgcn_ctr_wfin_multi(&j, 1, stream);
 }
 
 int dsgcn_tanhdiff_bwd(const float* d, const float* dd, float* dproj, int n, int K, int R, int V, void* stream) {

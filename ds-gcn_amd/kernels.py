@@ -353,6 +353,7 @@ class deferred_param_sums:
             _deferred = self.prev
             _leaf_uses.clear()
             _post_flush.clear()                     # (a failed backward must not leave finishing launches behind)
+            _ctr_fin_queue.clear()
         return False
 
 
@@ -2148,9 +2149,108 @@ class _TanhDiffAug(torch.autograd.Function):
         return dproj, param_colsum(dAp, ctx.defer_ok).view(K, V, V), None, None
 
 
+# The augmented operands depend on parameters only: inside a step (reset_leaf_uses() .. end_step(), as the weight images
+# above) the first unit that asks rebuilds the operands of ALL units seen in the previous step with one
+# dsgcn_ctr_wprep_multi launch (10 dependent ~5 us launches per CTR-GCN step -> 1), and the finishing launches of the
+# backward ride in one dsgcn_ctr_wfin_multi behind the deferred column sums.  Same trust rule as _wsplit_image: a cached
+# operand is used only inside the step it was built in and only while the version counters of alpha / W / b are the ones
+# it was built at; outside a step every call builds its own.
+CTR_PREP_BATCH = _os.environ.get('DSGCN_CTR_PREP_BATCH', '1') == '1'
+CTR_FIN_BATCH = _os.environ.get('DSGCN_CTR_FIN_BATCH', '1') == '1'
+_ctr_prep_state = dict(batched=-1, jobs={})
+_ctr_fin_queue = []
+
+
+def _ctr_prep_record(job):
+    K, Co, R = job['dims']
+    rec = native.CtrPrepJob()
+    for k in range(K):
+        rec.w[k] = job['w'][k].data_ptr()
+        rec.b[k] = job['b'][k].data_ptr() if job['b'][k] is not None else None
+    rec.alpha, rec.wout, rec.sh = job['alpha'].data_ptr(), job['wout'].data_ptr(), job['sh'].data_ptr()
+    rec.K, rec.Co, rec.R = K, Co, R
+    return rec
+
+
+def _ctr_prep_launch(todo):
+    tab = (native.CtrPrepJob * len(todo))(*[_ctr_prep_record(j) for j in todo])
+    native.check(native.lib().dsgcn_ctr_wprep_multi(tab, len(todo), _stream()), 'dsgcn_ctr_wprep_multi')
+
+
+def _ctr_prep_operands(alpha, w, b):
+    """-> (wout (K, Co, R + 2), sh (K, 2, R + 2)) for this unit, built now or taken from this step's batched launch."""
+    st, ws = _ctr_prep_state, _wsplit_state
+    # what the cache keeps must not hold autograd history: a kept `conv4.weight.view(...)` would keep last step's
+    # AccumulateGrad nodes (and the stream they were made on) alive into a graph capture.  detach() shares the storage and
+    # the version counter.
+    alpha, w, b = alpha.detach(), [t.detach() for t in w], [None if t is None else t.detach() for t in b]
+    K = len(w)
+    Co, R = w[0].shape
+    dev = alpha.device
+    tensors = [alpha, *w, *[t for t in b if t is not None]]
+    if not (CTR_PREP_BATCH and ws['in_step']):
+        job = dict(alpha=alpha, w=w, b=b, dims=(K, Co, R), wout=torch.empty((K, Co, R + 2), device=dev, dtype=torch.float32),
+                   sh=torch.empty((K, 2, R + 2), device=dev, dtype=torch.float32))
+        _ctr_prep_launch([job])
+        return job['wout'], job['sh']
+    jobs = st['jobs']
+    key = (tuple(t.data_ptr() for t in tensors), tuple(t is None for t in b), Co, R, dev.index)
+    capturing = torch.cuda.is_current_stream_capturing()
+    job = jobs.get(key)
+    if job is None:
+        if len(jobs) > 256:
+            for k in [k for k, j in jobs.items() if not j['pinned']]:
+                del jobs[k]
+        job = jobs[key] = dict(dims=(K, Co, R), wout=torch.empty((K, Co, R + 2), device=dev, dtype=torch.float32),
+                               sh=torch.empty((K, 2, R + 2), device=dev, dtype=torch.float32), stamp=None, used=0,
+                               pinned=False)
+    job.update(alpha=alpha, w=w, b=b)
+    if capturing:
+        job['pinned'] = True
+    stamp = (ws['epoch'], tuple(t._version for t in tensors))
+    job['used'] = ws['epoch']
+    if job['stamp'] == stamp:
+        return job['wout'], job['sh']
+    if st['batched'] != ws['epoch'] and job['stamp'] is not None:
+        st['batched'] = ws['epoch']
+        for k in [k for k, j in jobs.items() if j['used'] < ws['epoch'] - 1 and j is not job and not j['pinned']]:
+            del jobs[k]
+        todo = [j for k, j in jobs.items() if k[4] == key[4] and j['stamp'] is not None]
+        _ctr_prep_launch(todo)
+        for j in todo:
+            j['stamp'] = (ws['epoch'], tuple(t._version for t in [j['alpha'], *j['w'], *[t for t in j['b'] if t is not None]]))
+            if capturing:
+                j['pinned'] = True
+        if job['stamp'] == stamp:
+            return job['wout'], job['sh']
+    _ctr_prep_launch([job])
+    job['stamp'] = stamp
+    return job['wout'], job['sh']
+
+
+def _ctr_fin_flush():
+    """One dsgcn_ctr_wfin_multi for every finishing launch queued since the last flush."""
+    queued = list(_ctr_fin_queue)
+    _ctr_fin_queue.clear()
+    if queued:
+        _ctr_fin_launch(queued)
+
+
+def _ctr_fin_launch(queued):
+    tab = (native.CtrFinJob * len(queued))()
+    for rec, (dwp, ds, stride, outs, dalpha, K, Co, R) in zip(tab, queued):
+        for k in range(K):
+            rec.dwp[k] = dwp[k].data_ptr() if dwp[k] is not None else None
+            rec.ds[k] = ds[k].data_ptr() if ds[k] is not None else None
+            rec.out[k] = outs[k].data_ptr()
+        rec.dalpha, rec.K, rec.Co, rec.R, rec.ds_stride = dalpha.data_ptr(), K, Co, R, int(stride)
+    native.check(native.lib().dsgcn_ctr_wfin_multi(tab, len(queued), _stream()), 'dsgcn_ctr_wfin_multi')
+
+
 class _CtrWPrep(torch.autograd.Function):
     """(alpha (1), W_0 .. W_{K-1} (Co, R), b_0 .. b_{K-1} (Co) | None) -> K augmented weights [W_k | 1 | b_k] (Co, R + 2), K
-    input scales [alpha x R, 1, alpha] and K zero shifts (one launch; one launch back: dW_k, db_k, dalpha)."""
+    input scales [alpha x R, 1, alpha] and K zero shifts (one launch per step for all units: _ctr_prep_operands; one launch
+    back for all units: dW_k, db_k, dalpha)."""
 
     @staticmethod
     def forward(ctx, use, alpha, *wb):
@@ -2162,11 +2262,7 @@ class _CtrWPrep(torch.autograd.Function):
         _require_cuda(alpha, *w)
         alpha = _f32c(alpha)
         Co, R = w[0].shape
-        dev = alpha.device
-        wout = torch.empty((K, Co, R + 2), device=dev, dtype=torch.float32)
-        sh = torch.empty((K, 2, R + 2), device=dev, dtype=torch.float32)
-        rc = native.lib().dsgcn_ctr_wprep(_ptr_array(w), _ptr_array(b), _ptr(alpha), _ptr(wout), _ptr(sh), K, Co, R, _stream())
-        native.check(rc, 'dsgcn_ctr_wprep')
+        wout, sh = _ctr_prep_operands(alpha, w, b)
         ctx.dims = (K, Co, R, tuple(t is not None for t in b), alpha.shape)
         ctx.defer_ok = use
         shifts = tuple(sh[k, 1] for k in range(K))
@@ -2189,15 +2285,15 @@ class _CtrWPrep(torch.autograd.Function):
         out = torch.empty((K, Co * R + Co), device=live.device, dtype=torch.float32)
         dalpha = torch.empty(1, device=live.device, dtype=torch.float32)
         outs = [out[k] for k in range(K)]
-
-        def finish(dwp=dwp, ds=ds, outs=outs, dalpha=dalpha, stride=(strides.pop() if strides else 1)):
-            rc = native.lib().dsgcn_ctr_wfin(_ptr_array(dwp), _ptr_array(ds), int(stride), _ptr_array(outs), _ptr(dalpha), K, Co,
-                                             R, _stream())
-            native.check(rc, 'dsgcn_ctr_wfin')
-        if _deferred is not None and ctx.defer_ok:
-            _post_flush.append(finish)      # its inputs are deferred sums: filled by the flush, which then runs this
+        rec = (dwp, ds, strides.pop() if strides else 1, outs, dalpha, K, Co, R)
+        if _deferred is not None and ctx.defer_ok and not CTR_FIN_BATCH:
+            _post_flush.append(lambda rec=rec: _ctr_fin_launch([rec]))
+        elif _deferred is not None and ctx.defer_ok:
+            _ctr_fin_queue.append(rec)                  # its inputs are deferred sums: filled by the flush, which then
+            if _ctr_fin_flush not in _post_flush:       # runs ONE finishing launch for every unit queued by then
+                _post_flush.append(_ctr_fin_flush)
         else:
-            finish()
+            _ctr_fin_launch([rec])
         return (None, dalpha.view(ashape), *[o[:Co * R].view(Co, R) for o in outs],
                 *[(o[Co * R:] if hb else None) for o, hb in zip(outs, has_b)])
 

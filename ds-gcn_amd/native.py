@@ -90,6 +90,8 @@ SIGNATURES = {
     'dsgcn_tanhdiff_aug_fwd': [c_f, c_f, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_tanhdiff_aug_bwd': [c_f, ctypes.c_void_p, c_f, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_ctr_wprep': [ctypes.c_void_p, ctypes.c_void_p, c_f, c_f, c_f] + [c_int] * 3 + [c_st],
+    'dsgcn_ctr_wprep_multi': [ctypes.c_void_p, c_int, c_st],
+    'dsgcn_ctr_wfin_multi': [ctypes.c_void_p, c_int, c_st],
     'dsgcn_ctr_wfin': [ctypes.c_void_p, ctypes.c_void_p, c_int, ctypes.c_void_p, c_f] + [c_int] * 3 + [c_st],
     'dsgcn_ctr_affine_fwd': [ctypes.c_void_p, c_f, c_int, c_f, c_f, c_f, c_f] + [c_int] * 4 + [c_st],
     'dsgcn_ctr_affine_bwd': [ctypes.c_void_p, c_f, c_int, c_f, ctypes.c_void_p, c_f] + [c_int] * 4 + [c_st],
@@ -162,6 +164,21 @@ BN_JOBS_MAX = 4
 class Dropout(ctypes.Structure):
     """include/dsgcn_jobs.h: dsgcn_dropout"""
     _fields_ = [('step', ctypes.c_void_p), ('seed', ctypes.c_ulonglong), ('call', ctypes.c_uint), ('p', ctypes.c_float)]
+
+
+class CtrPrepJob(ctypes.Structure):
+    """include/dsgcn_jobs.h: dsgcn_ctr_prep_job"""
+    _fields_ = [('w', ctypes.c_void_p * 4), ('b', ctypes.c_void_p * 4), ('alpha', ctypes.c_void_p), ('wout', ctypes.c_void_p),
+                ('sh', ctypes.c_void_p), ('K', ctypes.c_int), ('Co', ctypes.c_int), ('R', ctypes.c_int),
+                ('reserved', ctypes.c_int)]
+
+
+class CtrFinJob(ctypes.Structure):
+    """include/dsgcn_jobs.h: dsgcn_ctr_fin_job"""
+    _fields_ = [('dwp', ctypes.c_void_p * 4), ('ds', ctypes.c_void_p * 4), ('out', ctypes.c_void_p * 4),
+                ('dalpha', ctypes.c_void_p), ('K', ctypes.c_int), ('Co', ctypes.c_int), ('R', ctypes.c_int),
+                ('ds_stride', ctypes.c_int)]
+
 
 SIZE_T_RESULTS = {'dsgcn_pwconv_wsplit_bytes', 'dsgcn_tconv_ws_bytes'}      # everything else returns an int status / count
 

@@ -353,7 +353,10 @@ int dsgcn_tanhdiff_bwd_k(const float* d, const float* const* dd, float* dproj, i
  *     per subset [input scale; input shift = 0].
  *   dsgcn_ctr_wfin: dwp = K gradients of wout[k] (NULL = zero), ds = K gradients of the input scales (NULL = zero; their
  *     R + 2 elements ds_stride floats apart) ->
- *     out[k] (Co*R + Co) = [dW_k | db_k], dalpha (1). */
+ *     out[k] (Co*R + Co) = [dW_k | db_k], dalpha (1).
+ *   dsgcn_ctr_wprep_multi / dsgcn_ctr_wfin_multi: the same for njobs units in one launch per 16 records (dsgcn_jobs.h) —
+ *     both depend on parameters / finished parameter-gradient sums only, so a training step runs them once for the
+ *     whole model. */
 int dsgcn_tanhdiff_aug_fwd(const float* proj, const float* A, float* d, int n, int K, int R, int V, void* stream);
 int dsgcn_tanhdiff_aug_bwd(const float* d, const float* const* dd, float* dproj, float* dAp, int n, int K, int R, int V,
                            void* stream);
@@ -361,6 +364,8 @@ int dsgcn_ctr_wprep(const float* const* w, const float* const* b, const float* a
                     int Co, int R, void* stream);
 int dsgcn_ctr_wfin(const float* const* dwp, const float* const* ds, int ds_stride, float* const* out, float* dalpha, int K,
                    int Co, int R, void* stream);
+int dsgcn_ctr_wprep_multi(const dsgcn_ctr_prep_job* jobs, int njobs, void* stream);
+int dsgcn_ctr_wfin_multi(const dsgcn_ctr_fin_job* jobs, int njobs, void* stream);
 int dsgcn_ctr_affine_fwd(const float* const* s, const float* alpha, int alpha_stride, const float* A, const float* beta,
                          const float* G, float* ahat, int n, int K, int Co, int V, void* stream);
 int dsgcn_ctr_affine_bwd(const float* const* s, const float* alpha, int alpha_stride, const float* dahat,

@@ -39,4 +39,26 @@ typedef struct {
   float p;
 } dsgcn_dropout;
 
+/* The parameter-only launches of the CTR-GCN units (dsgcn_ctr_wprep / dsgcn_ctr_wfin, dsgcn.h) as records, so that all
+ * units of a model share one launch at the head of the step (dsgcn_ctr_wprep_multi) and one at the end of the backward
+ * (dsgcn_ctr_wfin_multi).  Fields as the arguments of the single-unit entry points; K <= 4. */
+#define DSGCN_CTR_JOBS_MAX 16
+
+typedef struct {
+  const float* w[4];               /* K weights (Co, R) */
+  const float* b[4];               /* K biases (Co) or NULL */
+  const float* alpha;              /* (1) */
+  float* wout;                     /* (K, Co, R + 2) out */
+  float* sh;                       /* (K, 2, R + 2) out */
+  int K, Co, R, reserved;
+} dsgcn_ctr_prep_job;
+
+typedef struct {
+  const float* dwp[4];             /* K gradients of W'_k (Co, R + 2) or NULL */
+  const float* ds[4];              /* K gradients of the input scales (R + 2 elements, ds_stride apart) or NULL */
+  float* out[4];                   /* K buffers (Co*R + Co) = [dW_k | db_k] */
+  float* dalpha;                   /* (1) out */
+  int K, Co, R, ds_stride;
+} dsgcn_ctr_fin_job;
+
 #endif

@@ -995,6 +995,95 @@ def test_ctr_one_conv_deferred_sums_with_shared_leaves(shared):
         assert torch.equal(got[k], v), (k, rel(got[k].cpu(), v.cpu()))
 
 
+def test_ctr_operands_one_launch_per_step_is_bit_identical(monkeypatch):
+    """The augmented conv4 operands of all CTR-GCN units come from ONE launch per step (rebuilt from the weights at the first
+    unit's call) and their finishing launches ride in one launch behind the deferred sums: three units, three steps with the
+    parameters rewritten between steps the way dsgcn_sgd_step does (through .data — no version counter moves), against the
+    same steps with every unit building its own operands.  Outputs and gradients must match bit for bit, and the
+    second and third steps must really have taken the batched path."""
+    from dsgcn_amd import native
+    g = torch.Generator().manual_seed(23)
+    K, n, Ci, V = 3, 4, 64, 25
+    Rr = Ci // 8
+    mk = lambda *sh, scale=1.0: _rand(g, *sh, scale=scale).to(DEV)
+    units = []
+    for Co in (64, 64, 128):
+        base = dict(w1=mk(K * Rr, Ci, scale=Ci ** -0.5), b1=mk(K * Rr, scale=0.1), w2=mk(K * Rr, Ci, scale=Ci ** -0.5),
+                    b2=mk(K * Rr, scale=0.1), alpha=mk(1, scale=0.7), A=mk(K, V, V, scale=0.2))
+        units.append((base, [mk(Co, Rr, scale=Rr ** -0.5) for _ in range(K)], [mk(Co, scale=0.1) for _ in range(K)],
+                      mk(n, Ci, V), mk(K, n, Co, V, V)))
+
+    def steps(batch):
+        monkeypatch.setattr(K_, 'CTR_PREP_BATCH', batch)
+        K_._ctr_prep_state.update(batched=-1, jobs={})
+        leaves = [({k: v.clone().requires_grad_() for k, v in base.items()}, [w.clone().requires_grad_() for w in w4],
+                   [b.clone().requires_grad_() for b in b4]) for base, w4, b4, _, _ in units]
+        out, took = [], []
+        for step in range(3):
+            K_.reset_leaf_uses()
+            ahat = [K_.ctr_topology(x, tt['w1'], tt['b1'], tt['w2'], tt['b2'], tw4, tb4, tt['alpha'], tt['A'],
+                                    subset_major=True) for (tt, tw4, tb4), (_, _, _, x, _) in zip(leaves, units)]
+            took.append(K_._ctr_prep_state['batched'] == K_._wsplit_state['epoch'])
+            loss = sum((o * u[4]).sum() for o, u in zip(ahat, units))
+            with K_.deferred_param_sums():
+                loss.backward()
+            K_.end_step()
+            res = {f'{i}.ahat': o.detach().clone() for i, o in enumerate(ahat)}
+            for i, (tt, tw4, tb4) in enumerate(leaves):
+                res.update({f'{i}.d{k}': v.grad.clone() for k, v in tt.items()})
+                for k in range(K):
+                    res[f'{i}.dw4_{k}'], res[f'{i}.db4_{k}'] = tw4[k].grad.clone(), tb4[k].grad.clone()
+                for p in [*tt.values(), *tw4, *tb4]:
+                    p.data.mul_(0.9).add_(0.01)              # the optimizer's raw write
+                    p.grad = None
+            out.append(res)
+        return out, took
+
+    want, took0 = steps(False)
+    got, took1 = steps(True)
+    assert took0 == [False] * 3 and took1 == [False, True, True], (took0, took1)
+    for a, b in zip(want, got):
+        for k, v in a.items():
+            assert torch.equal(b[k], v), k
+    assert not torch.equal(want[0]['0.ahat'], want[1]['0.ahat'])       # (the rewritten weights were seen)
+    # more records than one launch holds (DSGCN_CTR_JOBS_MAX = 16): the entry points chunk
+    nj, Co = 19, 32
+    w = [[mk(Co, Rr) for _ in range(K)] for _ in range(nj)]
+    b = [[mk(Co) for _ in range(K)] for _ in range(nj)]
+    al = [mk(1) for _ in range(nj)]
+    wout = torch.zeros(nj, K, Co, Rr + 2, device=DEV)
+    sh = torch.zeros(nj, K, 2, Rr + 2, device=DEV)
+    tab = (native.CtrPrepJob * nj)()
+    for i, rec in enumerate(tab):
+        for k in range(K):
+            rec.w[k], rec.b[k] = w[i][k].data_ptr(), (b[i][k].data_ptr() if (i + k) % 3 else None)
+        rec.alpha, rec.wout, rec.sh, rec.K, rec.Co, rec.R = al[i].data_ptr(), wout[i].data_ptr(), sh[i].data_ptr(), K, Co, Rr
+    native.check(native.lib().dsgcn_ctr_wprep_multi(tab, nj, K_._stream()), 'dsgcn_ctr_wprep_multi')
+    for i in range(nj):
+        for k in range(K):
+            bias = b[i][k] if (i + k) % 3 else torch.zeros(Co, device=DEV)
+            assert torch.equal(wout[i, k], torch.cat([w[i][k], torch.ones(Co, 1, device=DEV), bias[:, None]], 1)), (i, k)
+            assert torch.equal(sh[i, k, 0], torch.cat([al[i].expand(Rr), torch.ones(1, device=DEV), al[i]])), (i, k)
+            assert not sh[i, k, 1].any()
+    dwp = [[mk(Co, Rr + 2) for _ in range(K)] for _ in range(nj)]
+    ds = [[mk(Rr + 2, 3) for _ in range(K)] for _ in range(nj)]
+    out = torch.zeros(nj, K, Co * Rr + Co, device=DEV)
+    dal = torch.zeros(nj, device=DEV)
+    ftab = (native.CtrFinJob * nj)()
+    for i, rec in enumerate(ftab):
+        for k in range(K):
+            rec.dwp[k], rec.ds[k], rec.out[k] = dwp[i][k].data_ptr(), ds[i][k].data_ptr(), out[i, k].data_ptr()
+        rec.dalpha, rec.K, rec.Co, rec.R, rec.ds_stride = dal[i:].data_ptr(), K, Co, Rr, 3
+    native.check(native.lib().dsgcn_ctr_wfin_multi(ftab, nj, K_._stream()), 'dsgcn_ctr_wfin_multi')
+    for i in range(nj):
+        a = 0.0
+        for k in range(K):
+            assert torch.equal(out[i, k, :Co * Rr].view(Co, Rr), dwp[i][k][:, :Rr]) and \
+                torch.equal(out[i, k, Co * Rr:], dwp[i][k][:, Rr + 1]), (i, k)
+            a += float(ds[i][k][:Rr, 0].double().sum() + ds[i][k][Rr + 1, 0].double())
+        assert abs(float(dal[i]) - a) <= 1e-5 * max(1.0, abs(a)), (i, float(dal[i]), a)
+
+
 @pytest.mark.parametrize('n,C,T,V,stride,ks', [(2, 64, 32, 25, 1, 5), (2, 128, 32, 25, 2, 5), (2, 256, 16, 25, 1, 5),
                                                (2, 32, 21, 17, 2, 5), (1, 16, 9, 18, 1, 3)])
 @pytest.mark.parametrize('fused', ['1', '0'])

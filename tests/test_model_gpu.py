@@ -474,6 +474,37 @@ def test_bench_through_torch_distributed_run():
     assert a['param_sha256'] == b['param_sha256'] and a['final_loss'] == b['final_loss']
 
 
+def test_ctrgcn_engine_steps_graph_and_batched_operands_are_bit_identical(monkeypatch):
+    """BASELINE config 4 through TrainEngine: the units' augmented conv4 operands come from one launch per step and their
+    finishing launches from one launch per backward (kernels._ctr_prep_operands / _ctr_fin_flush).  Six steps on a fixed
+    batch as replayed hipGraphs and eagerly, with the batched launches and with one launch per unit: the four loss
+    trajectories and the final parameters are the same bits (and the capture itself must survive the cache holding
+    tensors across steps: a kept tensor with autograd history once took a default-stream dependency into the capture)."""
+    from dsgcn_amd import kernels as K
+
+    def run(graph, batch):
+        monkeypatch.setattr(K, 'CTR_PREP_BATCH', batch)
+        monkeypatch.setattr(K, 'CTR_FIN_BATCH', batch)
+        K._ctr_prep_state.update(batched=-1, jobs={})
+        torch.manual_seed(5)
+        np.random.seed(5)
+        m = D.build_model(other_cfg('ctrgcn')).cuda().train()
+        eng = D.TrainEngine(m, lr=0.05, momentum=0.9, weight_decay=5e-4, nesterov=True, use_graph=graph, warmup_eager=2)
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(4, 1, 2, 32, 25, 3, generator=g).cuda()
+        y = torch.randint(0, 60, (4, 1), generator=g).cuda()
+        losses = torch.stack([eng.step(x, y)['loss'].clone() for _ in range(6)]).cpu()   # (a replay rewrites the tensor it returned)
+        assert eng.graphed(x, y) == graph and torch.isfinite(losses).all()
+        if batch:
+            assert K._ctr_prep_state['batched'] == K._wsplit_state['epoch'] and len(K._ctr_prep_state['jobs']) == 10
+        return losses, eng.flat.flat_p.detach().clone()
+    want = run(False, False)
+    for graph, batch in ((False, True), (True, False), (True, True)):
+        got = run(graph, batch)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (graph, batch, got[0], want[0])
+    assert float(want[0][0]) != float(want[0][-1])
+
+
 @pytest.mark.parametrize('graph', [False, True])
 def test_stgcn_training_step_with_fused_dropout(graph):
     """BASELINE config 1's shipped training config (configs/stgcn/stgcn_vanilla_ntu60_xsub_3dkp/j.py:5, tcn_dropout = 0.5):

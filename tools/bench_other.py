@@ -36,10 +36,14 @@ x = torch.randn(N, 1, 2, T, V, 3, generator=gen).cuda()
 y = torch.randint(0, classes, (N, 1), generator=gen).cuda()
 def step():
     flat.zero_grad()
-    out = m.train_step(dict(keypoint=x, label=y), None, sync_log_vars=False)
-    with D.kernels.deferred_param_sums():          # as in TrainEngine: parameter-gradient column sums in one launch
-        out['loss'].backward()
-    flat.collect_grads()
+    D.kernels.reset_leaf_uses()                    # the step bracket of TrainEngine._fwd_bwd: the parameter-only launches
+    try:                                           # (weight images, CTR operands) are batched only inside it
+        out = m.train_step(dict(keypoint=x, label=y), None, sync_log_vars=False)
+        with D.kernels.deferred_param_sums():      # parameter-gradient column sums in one launch
+            out['loss'].backward()
+        flat.collect_grads()
+    finally:
+        D.kernels.end_step()
 for _ in range(3):
     step()
 torch.cuda.synchronize()
