@@ -27,6 +27,7 @@
 // load address (elements outside the sample's frames are zero).  K is split over workgroups; every split writes its
 // partial row (dsgcn_colsum / the deferred parameter sums reduce them in order).
 #include "common.h"
+#include "dsgcn_jobs.h"
 
 namespace {
 
@@ -483,8 +484,16 @@ __global__ __launch_bounds__(TG_NT, 2) void k_tcg(TcgArgs a) {
 //   N image (forward):        [KT][3][MpN = ceil128(Co) x KpN = ceil32(Ci)]   value W[co][ci][tap]
 //   T image (data gradient):  [KT][3][MpT = ceil128(Ci) x KpT = ceil32(Co)]   value W[co][ci][KT-1-tap]     (after N)
 // One thread per (image, tap, row, 4 consecutive k).
-__global__ __launch_bounds__(256) void k_tsplit(const float* __restrict__ w, int Ci, int Co, int KT,
-                                                unsigned short* __restrict__ out, int MpN, int KpN, int MpT, int KpT) {
+// (jobs: one record per conv, blockIdx.y = record — every dense temporal conv of a model in one launch at the head of the
+// step, dsgcn_tconv_wsplit_multi.)
+struct TsJob { const float* w; unsigned short* out; int Ci, Co, KT, MpN, KpN, MpT, KpT, pad; };
+struct TsTable { TsJob j[DSGCN_TSPLIT_JOBS_MAX]; };
+
+__global__ __launch_bounds__(256) void k_tsplit(TsTable tab) {
+  const TsJob& jb = tab.j[blockIdx.y];
+  const float* __restrict__ w = jb.w;
+  unsigned short* __restrict__ out = jb.out;
+  const int Ci = jb.Ci, Co = jb.Co, KT = jb.KT, MpN = jb.MpN, KpN = jb.KpN, MpT = jb.MpT, KpT = jb.KpT;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long t1 = (long)KT * MpN * (KpN >> 2), t2 = (long)KT * MpT * (KpT >> 2);
   float v[4];
@@ -1031,14 +1040,31 @@ size_t dsgcn_tconv_ws_bytes(int n, int Ci, int Co, int T, int V, int KT, int str
   return ts_dims(Ci, Co, KT).bytes;
 }
 
-int dsgcn_tconv_wsplit(const float* w, int Ci, int Co, int KT, void* ws, void* stream) {
-  if (!w || !ws || Ci <= 0 || Co <= 0 || KT <= 0) return DSGCN_EINVAL;
-  const TsDims d = ts_dims(Ci, Co, KT);
-  const long total = (long)KT * ((long)d.MpN * (d.KpN >> 2) + (long)d.MpT * (d.KpT >> 2));
-  hipLaunchKernelGGL(k_tsplit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Ci, Co, KT,
-                     static_cast<unsigned short*>(ws), d.MpN, d.KpN, d.MpT, d.KpT);
-  DSGCN_LAUNCH_CHECK();
+// The weight images of njobs convs in one launch per DSGCN_TSPLIT_JOBS_MAX records (include/dsgcn_jobs.h).
+int dsgcn_tconv_wsplit_multi(const dsgcn_tsplit_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs <= 0) return DSGCN_EINVAL;
+  for (int i = 0; i < njobs; ++i)
+    if (!jobs[i].w || !jobs[i].ws || jobs[i].Ci <= 0 || jobs[i].Co <= 0 || jobs[i].KT <= 0) return DSGCN_EINVAL;
+  for (int i0 = 0; i0 < njobs; i0 += DSGCN_TSPLIT_JOBS_MAX) {
+    const int m = njobs - i0 < DSGCN_TSPLIT_JOBS_MAX ? njobs - i0 : DSGCN_TSPLIT_JOBS_MAX;
+    TsTable t = {};
+    long most = 0;
+    for (int i = 0; i < m; ++i) {
+      const dsgcn_tsplit_job& a = jobs[i0 + i];
+      const TsDims d = ts_dims(a.Ci, a.Co, a.KT);
+      t.j[i] = TsJob{a.w, static_cast<unsigned short*>(a.ws), a.Ci, a.Co, a.KT, d.MpN, d.KpN, d.MpT, d.KpT, 0};
+      const long total = (long)a.KT * ((long)d.MpN * (d.KpN >> 2) + (long)d.MpT * (d.KpT >> 2));
+      most = total > most ? total : most;
+    }
+    hipLaunchKernelGGL(k_tsplit, dim3((unsigned)((most + 255) / 256), (unsigned)m), dim3(256), 0, (hipStream_t)stream, t);
+    DSGCN_LAUNCH_CHECK();
+  }
   return 0;
+}
+
+int dsgcn_tconv_wsplit(const float* w, int Ci, int Co, int KT, void* ws, void* stream) {
+  const dsgcn_tsplit_job j = {w, ws, Ci, Co, KT, 0};
+  return dsgcn_tconv_wsplit_multi(&j, 1, stream);
 }
 
 // rows of the forward's statistics partials (rows, Co, 2) and of the data gradient's input-affine partials (rows, Ci, 3)

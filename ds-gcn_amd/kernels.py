@@ -323,6 +323,69 @@ def _wsplit_image(w2, Ci, Co, nbytes):
     return job['img']
 
 
+class _StepBuilt:
+    """Buffers derived from PARAMETERS only (CTR-GCN's augmented conv4 operands, the per-tap weight images of the dense
+    temporal conv), rebuilt once per step: the first asker of a step rebuilds everything the previous step asked for with
+    ONE launch.  The trust rule is _wsplit_image's: a cached buffer is used only inside the step it was built in
+    (reset_leaf_uses() .. end_step(): the optimizer rewrites the weights through raw pointers) and only while the version
+    counters of its source tensors are the ones it was built at; outside a step, or with the switch off, every call builds
+    its own.  What the cache keeps is detached: a kept `conv.weight.view(...)` would keep last step's AccumulateGrad nodes —
+    and the stream they were made on — alive into a graph capture (detach() shares storage and version counter).
+    launch(jobs): one launch building every job's buffers; a job is a dict with 'src' (the source tensors, None allowed)
+    plus whatever `alloc()` returned."""
+
+    def __init__(self, launch, enabled, limit=256):
+        self.launch, self.enabled, self.limit = launch, enabled, limit
+        self.jobs, self.batched = {}, -1
+
+    def clear(self):
+        self.jobs, self.batched = {}, -1
+
+    @staticmethod
+    def _versions(src):
+        return tuple(-1 if t is None else t._version for t in src)
+
+    def get(self, shape_key, src, alloc):
+        ws = _wsplit_state
+        src = [None if t is None else t.detach() for t in src]
+        if not (self.enabled() and ws['in_step']):
+            job = dict(src=src, **alloc())
+            self.launch([job])
+            return job
+        dev = next(t for t in src if t is not None).device.index
+        key = (tuple(0 if t is None else t.data_ptr() for t in src), shape_key, dev)
+        capturing = torch.cuda.is_current_stream_capturing()
+        jobs = self.jobs
+        job = jobs.get(key)
+        if job is None:
+            if len(jobs) > self.limit:
+                for k in [k for k, j in jobs.items() if not j['pinned']]:
+                    del jobs[k]
+            job = jobs[key] = dict(stamp=None, used=0, pinned=False, **alloc())
+        job['src'] = src
+        if capturing:
+            job['pinned'] = True                  # the graph holds the buffers' addresses: never pruned
+        stamp = (ws['epoch'], self._versions(src))
+        job['used'] = ws['epoch']
+        if job['stamp'] == stamp:
+            return job
+        if self.batched != ws['epoch'] and job['stamp'] is not None:
+            self.batched = ws['epoch']
+            for k in [k for k, j in jobs.items() if j['used'] < ws['epoch'] - 1 and j is not job and not j['pinned']]:
+                del jobs[k]
+            todo = [j for k, j in jobs.items() if k[2] == dev and j['stamp'] is not None]
+            self.launch(todo)
+            for j in todo:
+                j['stamp'] = (ws['epoch'], self._versions(j['src']))
+                if capturing:
+                    j['pinned'] = True
+            if job['stamp'] == stamp:
+                return job
+        self.launch([job])
+        job['stamp'] = stamp
+        return job
+
+
 class deferred_param_sums:
     """``with deferred_param_sums(flat): loss.backward()`` — see above; flushes on exit.  The queued outputs reach autograd
     unfilled, so the region insists on what makes that safe: ``FlatParams(gather=True)`` (no in-place accumulation into
@@ -1773,6 +1836,21 @@ def strided_frames(x, stride):
     return _TapBranches.apply(x, int(stride), 3, C, [2], [0], [0], [C], [C], [1], None, None)
 
 
+# the per-tap weight images of the dense temporal convs: one launch per step for all of them (ST-GCN: 10 -> 1)
+TSPLIT_BATCH = _os.environ.get('DSGCN_TSPLIT_BATCH', '1') == '1'
+
+
+def _tsplit_launch(todo):
+    tab = (native.TsplitJob * len(todo))()
+    for rec, job in zip(tab, todo):
+        rec.w, rec.ws = job['src'][0].data_ptr(), job['img'].data_ptr()
+        rec.Ci, rec.Co, rec.KT = job['dims']
+    native.check(native.lib().dsgcn_tconv_wsplit_multi(tab, len(todo), _stream()), 'dsgcn_tconv_wsplit_multi')
+
+
+_tconv_images = _StepBuilt(_tsplit_launch, lambda: TSPLIT_BATCH)
+
+
 class _TConvGemm(torch.autograd.Function):
     """Dense (KT,1) temporal conv of a virtual input, stride 1, as a GEMM on bf16 terms (csrc/tcg.hip), with the
     statistics of the BatchNorm behind it: z = W * relu?(x1*s1+h1 (+ x2*s2+h2)) + b -> (z, scale, shift, mean, var)."""
@@ -1790,8 +1868,8 @@ class _TConvGemm(torch.autograd.Function):
         lib = native.lib()
         wsb = lib.dsgcn_tconv_ws_bytes(n, Ci, Co, T, V, KT, stride)
         assert wsb > 0
-        ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-        native.check(lib.dsgcn_tconv_wsplit(_ptr(w), Ci, Co, KT, _ptr(ws), _stream()), 'dsgcn_tconv_wsplit')
+        ws = _tconv_images.get((Ci, Co, KT, wsb), [w], lambda: dict(
+            dims=(Ci, Co, KT), img=torch.empty(wsb, device=dev, dtype=torch.uint8)))['img']
         rows = lib.dsgcn_tconv_rows(0, n, Ci, Co, T, V, KT, stride)
         z = torch.empty((n, Co, To, V), device=dev, dtype=torch.float32)
         partial = torch.empty((rows, Co, 2), device=dev, dtype=torch.float32) if want_bn else None
@@ -2149,82 +2227,39 @@ class _TanhDiffAug(torch.autograd.Function):
         return dproj, param_colsum(dAp, ctx.defer_ok).view(K, V, V), None, None
 
 
-# The augmented operands depend on parameters only: inside a step (reset_leaf_uses() .. end_step(), as the weight images
-# above) the first unit that asks rebuilds the operands of ALL units seen in the previous step with one
-# dsgcn_ctr_wprep_multi launch (10 dependent ~5 us launches per CTR-GCN step -> 1), and the finishing launches of the
-# backward ride in one dsgcn_ctr_wfin_multi behind the deferred column sums.  Same trust rule as _wsplit_image: a cached
-# operand is used only inside the step it was built in and only while the version counters of alpha / W / b are the ones
-# it was built at; outside a step every call builds its own.
+# The augmented operands depend on parameters only: inside a step the first unit that asks rebuilds the operands of ALL
+# units seen in the previous step with one dsgcn_ctr_wprep_multi launch (_StepBuilt: 10 dependent ~5 us launches per
+# CTR-GCN step -> 1), and the finishing launches of the backward ride in one dsgcn_ctr_wfin_multi behind the deferred
+# column sums.
 CTR_PREP_BATCH = _os.environ.get('DSGCN_CTR_PREP_BATCH', '1') == '1'
 CTR_FIN_BATCH = _os.environ.get('DSGCN_CTR_FIN_BATCH', '1') == '1'
-_ctr_prep_state = dict(batched=-1, jobs={})
 _ctr_fin_queue = []
 
 
-def _ctr_prep_record(job):
-    K, Co, R = job['dims']
-    rec = native.CtrPrepJob()
-    for k in range(K):
-        rec.w[k] = job['w'][k].data_ptr()
-        rec.b[k] = job['b'][k].data_ptr() if job['b'][k] is not None else None
-    rec.alpha, rec.wout, rec.sh = job['alpha'].data_ptr(), job['wout'].data_ptr(), job['sh'].data_ptr()
-    rec.K, rec.Co, rec.R = K, Co, R
-    return rec
-
-
 def _ctr_prep_launch(todo):
-    tab = (native.CtrPrepJob * len(todo))(*[_ctr_prep_record(j) for j in todo])
+    tab = (native.CtrPrepJob * len(todo))()
+    for rec, job in zip(tab, todo):
+        K, Co, R = job['dims']
+        alpha, wb = job['src'][0], job['src'][1:]
+        for k in range(K):
+            rec.w[k] = wb[k].data_ptr()
+            rec.b[k] = wb[K + k].data_ptr() if wb[K + k] is not None else None
+        rec.alpha, rec.wout, rec.sh = alpha.data_ptr(), job['wout'].data_ptr(), job['sh'].data_ptr()
+        rec.K, rec.Co, rec.R = K, Co, R
     native.check(native.lib().dsgcn_ctr_wprep_multi(tab, len(todo), _stream()), 'dsgcn_ctr_wprep_multi')
+
+
+_ctr_prep_cache = _StepBuilt(_ctr_prep_launch, lambda: CTR_PREP_BATCH)
 
 
 def _ctr_prep_operands(alpha, w, b):
     """-> (wout (K, Co, R + 2), sh (K, 2, R + 2)) for this unit, built now or taken from this step's batched launch."""
-    st, ws = _ctr_prep_state, _wsplit_state
-    # what the cache keeps must not hold autograd history: a kept `conv4.weight.view(...)` would keep last step's
-    # AccumulateGrad nodes (and the stream they were made on) alive into a graph capture.  detach() shares the storage and
-    # the version counter.
-    alpha, w, b = alpha.detach(), [t.detach() for t in w], [None if t is None else t.detach() for t in b]
     K = len(w)
     Co, R = w[0].shape
     dev = alpha.device
-    tensors = [alpha, *w, *[t for t in b if t is not None]]
-    if not (CTR_PREP_BATCH and ws['in_step']):
-        job = dict(alpha=alpha, w=w, b=b, dims=(K, Co, R), wout=torch.empty((K, Co, R + 2), device=dev, dtype=torch.float32),
-                   sh=torch.empty((K, 2, R + 2), device=dev, dtype=torch.float32))
-        _ctr_prep_launch([job])
-        return job['wout'], job['sh']
-    jobs = st['jobs']
-    key = (tuple(t.data_ptr() for t in tensors), tuple(t is None for t in b), Co, R, dev.index)
-    capturing = torch.cuda.is_current_stream_capturing()
-    job = jobs.get(key)
-    if job is None:
-        if len(jobs) > 256:
-            for k in [k for k, j in jobs.items() if not j['pinned']]:
-                del jobs[k]
-        job = jobs[key] = dict(dims=(K, Co, R), wout=torch.empty((K, Co, R + 2), device=dev, dtype=torch.float32),
-                               sh=torch.empty((K, 2, R + 2), device=dev, dtype=torch.float32), stamp=None, used=0,
-                               pinned=False)
-    job.update(alpha=alpha, w=w, b=b)
-    if capturing:
-        job['pinned'] = True
-    stamp = (ws['epoch'], tuple(t._version for t in tensors))
-    job['used'] = ws['epoch']
-    if job['stamp'] == stamp:
-        return job['wout'], job['sh']
-    if st['batched'] != ws['epoch'] and job['stamp'] is not None:
-        st['batched'] = ws['epoch']
-        for k in [k for k, j in jobs.items() if j['used'] < ws['epoch'] - 1 and j is not job and not j['pinned']]:
-            del jobs[k]
-        todo = [j for k, j in jobs.items() if k[4] == key[4] and j['stamp'] is not None]
-        _ctr_prep_launch(todo)
-        for j in todo:
-            j['stamp'] = (ws['epoch'], tuple(t._version for t in [j['alpha'], *j['w'], *[t for t in j['b'] if t is not None]]))
-            if capturing:
-                j['pinned'] = True
-        if job['stamp'] == stamp:
-            return job['wout'], job['sh']
-    _ctr_prep_launch([job])
-    job['stamp'] = stamp
+    job = _ctr_prep_cache.get((Co, R), [alpha, *w, *b], lambda: dict(
+        dims=(K, Co, R), wout=torch.empty((K, Co, R + 2), device=dev, dtype=torch.float32),
+        sh=torch.empty((K, 2, R + 2), device=dev, dtype=torch.float32)))
     return job['wout'], job['sh']
 
 

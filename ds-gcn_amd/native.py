@@ -41,6 +41,7 @@ SIGNATURES = {
     'dsgcn_pwconv_wsplit_bytes': [c_int] * 6,
     'dsgcn_tconv_ws_bytes': [c_int] * 7,
     'dsgcn_tconv_wsplit': [c_f, c_int, c_int, c_int, c_f, c_st],
+    'dsgcn_tconv_wsplit_multi': [ctypes.c_void_p, c_int, c_st],
     'dsgcn_tconv_rows': [c_int] * 8,
     'dsgcn_tconv_fwd': [c_f] * 6 + [c_int] + [c_f] * 4 + [c_int] * 7 + [c_st],
     'dsgcn_tconv_dgrad': [c_f] * 6 + [c_int] + [c_f] * 8 + [c_int] * 7 + [c_st],
@@ -178,6 +179,12 @@ class CtrFinJob(ctypes.Structure):
     _fields_ = [('dwp', ctypes.c_void_p * 4), ('ds', ctypes.c_void_p * 4), ('out', ctypes.c_void_p * 4),
                 ('dalpha', ctypes.c_void_p), ('K', ctypes.c_int), ('Co', ctypes.c_int), ('R', ctypes.c_int),
                 ('ds_stride', ctypes.c_int)]
+
+
+class TsplitJob(ctypes.Structure):
+    """include/dsgcn_jobs.h: dsgcn_tsplit_job"""
+    _fields_ = [('w', ctypes.c_void_p), ('ws', ctypes.c_void_p), ('Ci', ctypes.c_int), ('Co', ctypes.c_int),
+                ('KT', ctypes.c_int), ('reserved', ctypes.c_int)]
 
 
 SIZE_T_RESULTS = {'dsgcn_pwconv_wsplit_bytes', 'dsgcn_tconv_ws_bytes'}      # everything else returns an int status / count

@@ -134,12 +134,14 @@ int dsgcn_dropout_mask(float* mask, long numel, const dsgcn_dropout* d, void* st
  * V <= 32; the virtual input relu?(x1*s1+h1 (+ x2*s2+h2))
  * is formed while loading and zero-padded in time AFTER the activation.
  *   dsgcn_tconv_ws_bytes : bytes of the pre-split weight image for this shape, 0 = shape not taken (use dsgcn_tapconv_*)
- *   dsgcn_tconv_wsplit   : w (Co, Ci, KT) -> image (per tap the three bf16 terms of W and of the tap-flipped W^T)
+ *   dsgcn_tconv_wsplit   : w (Co, Ci, KT) -> image (per tap the three bf16 terms of W and of the tap-flipped W^T);
+ *                          dsgcn_tconv_wsplit_multi: the images of njobs convs in one launch (records: dsgcn_jobs.h)
  *   dsgcn_tconv_rows     : partial rows: which = 0 forward (rows, Co, 2) [sum z, sum z^2], 1 data gradient (rows, Ci, 3)
  *   dsgcn_tconv_fwd      : z (n, Co, T, V) = bias + conv;  dsgcn_tconv_dgrad: dz = gz + A0 + B0*z -> dx1 (, dx2), ipart
  *                          (mask / affine of the forward's virtual input as in dsgcn_pwconv_dgrad). */
 size_t dsgcn_tconv_ws_bytes(int n, int Ci, int Co, int T, int V, int KT, int stride);
 int dsgcn_tconv_wsplit(const float* w, int Ci, int Co, int KT, void* ws, void* stream);
+int dsgcn_tconv_wsplit_multi(const dsgcn_tsplit_job* jobs, int njobs, void* stream);
 int dsgcn_tconv_rows(int which, int n, int Ci, int Co, int T, int V, int KT, int stride);
 int dsgcn_tconv_fwd(const float* x1, const float* s1, const float* h1, const float* x2, const float* s2, const float* h2,
                     int relu, const void* ws, const float* bias, float* z, float* partial, int n, int Ci, int Co, int T,

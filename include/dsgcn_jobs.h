@@ -61,4 +61,14 @@ typedef struct {
   int K, Co, R, ds_stride;
 } dsgcn_ctr_fin_job;
 
+/* The per-tap weight images of the dense temporal conv (dsgcn_tconv_wsplit, dsgcn.h) as records: all convs of a model in
+ * one launch at the head of the step (dsgcn_tconv_wsplit_multi). */
+#define DSGCN_TSPLIT_JOBS_MAX 16
+
+typedef struct {
+  const float* w;                  /* (Co, Ci, KT, 1) */
+  void* ws;                        /* dsgcn_tconv_ws_bytes(...) bytes out */
+  int Ci, Co, KT, reserved;
+} dsgcn_tsplit_job;
+
 #endif

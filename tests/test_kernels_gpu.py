@@ -1015,7 +1015,7 @@ def test_ctr_operands_one_launch_per_step_is_bit_identical(monkeypatch):
 
     def steps(batch):
         monkeypatch.setattr(K_, 'CTR_PREP_BATCH', batch)
-        K_._ctr_prep_state.update(batched=-1, jobs={})
+        K_._ctr_prep_cache.clear()
         leaves = [({k: v.clone().requires_grad_() for k, v in base.items()}, [w.clone().requires_grad_() for w in w4],
                    [b.clone().requires_grad_() for b in b4]) for base, w4, b4, _, _ in units]
         out, took = [], []
@@ -1023,7 +1023,7 @@ def test_ctr_operands_one_launch_per_step_is_bit_identical(monkeypatch):
             K_.reset_leaf_uses()
             ahat = [K_.ctr_topology(x, tt['w1'], tt['b1'], tt['w2'], tt['b2'], tw4, tb4, tt['alpha'], tt['A'],
                                     subset_major=True) for (tt, tw4, tb4), (_, _, _, x, _) in zip(leaves, units)]
-            took.append(K_._ctr_prep_state['batched'] == K_._wsplit_state['epoch'])
+            took.append(K_._ctr_prep_cache.batched == K_._wsplit_state['epoch'])
             loss = sum((o * u[4]).sum() for o, u in zip(ahat, units))
             with K_.deferred_param_sums():
                 loss.backward()

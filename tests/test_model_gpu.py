@@ -474,21 +474,24 @@ def test_bench_through_torch_distributed_run():
     assert a['param_sha256'] == b['param_sha256'] and a['final_loss'] == b['final_loss']
 
 
-def test_ctrgcn_engine_steps_graph_and_batched_operands_are_bit_identical(monkeypatch):
-    """BASELINE config 4 through TrainEngine: the units' augmented conv4 operands come from one launch per step and their
-    finishing launches from one launch per backward (kernels._ctr_prep_operands / _ctr_fin_flush).  Six steps on a fixed
-    batch as replayed hipGraphs and eagerly, with the batched launches and with one launch per unit: the four loss
-    trajectories and the final parameters are the same bits (and the capture itself must survive the cache holding
-    tensors across steps: a kept tensor with autograd history once took a default-stream dependency into the capture)."""
+@pytest.mark.parametrize('kind,switches,cache,njobs', [('ctrgcn', ('CTR_PREP_BATCH', 'CTR_FIN_BATCH'), '_ctr_prep_cache', 10),
+                                                       ('stgcn', ('TSPLIT_BATCH',), '_tconv_images', 10)])
+def test_engine_steps_graph_and_per_step_launches_are_bit_identical(kind, switches, cache, njobs, monkeypatch):
+    """BASELINE configs 4 and 1 through TrainEngine: what depends on parameters only is built by ONE launch per step
+    (kernels._StepBuilt: CTR-GCN's augmented conv4 operands — and their finishing launches, one per backward —, ST-GCN's
+    per-tap weight images).  Six steps on a fixed batch as replayed hipGraphs and eagerly, with the batched launches and
+    with one launch per unit: the four loss trajectories and the final parameters are the same bits (and the capture
+    itself must survive the cache holding tensors across steps: a kept tensor with autograd history once took a
+    default-stream dependency into the capture)."""
     from dsgcn_amd import kernels as K
 
     def run(graph, batch):
-        monkeypatch.setattr(K, 'CTR_PREP_BATCH', batch)
-        monkeypatch.setattr(K, 'CTR_FIN_BATCH', batch)
-        K._ctr_prep_state.update(batched=-1, jobs={})
+        for name in switches:
+            monkeypatch.setattr(K, name, batch)
+        getattr(K, cache).clear()
         torch.manual_seed(5)
         np.random.seed(5)
-        m = D.build_model(other_cfg('ctrgcn')).cuda().train()
+        m = D.build_model(other_cfg(kind)).cuda().train()
         eng = D.TrainEngine(m, lr=0.05, momentum=0.9, weight_decay=5e-4, nesterov=True, use_graph=graph, warmup_eager=2)
         g = torch.Generator().manual_seed(3)
         x = torch.randn(4, 1, 2, 32, 25, 3, generator=g).cuda()
@@ -496,7 +499,7 @@ def test_ctrgcn_engine_steps_graph_and_batched_operands_are_bit_identical(monkey
         losses = torch.stack([eng.step(x, y)['loss'].clone() for _ in range(6)]).cpu()   # (a replay rewrites the tensor it returned)
         assert eng.graphed(x, y) == graph and torch.isfinite(losses).all()
         if batch:
-            assert K._ctr_prep_state['batched'] == K._wsplit_state['epoch'] and len(K._ctr_prep_state['jobs']) == 10
+            assert getattr(K, cache).batched == K._wsplit_state['epoch'] and len(getattr(K, cache).jobs) == njobs
         return losses, eng.flat.flat_p.detach().clone()
     want = run(False, False)
     for graph, batch in ((False, True), (True, False), (True, True)):
