@@ -548,6 +548,7 @@ struct TcwArgs {
   const float* gz; const float* z; const float* A0; const float* B0;
   float* dwp; float* dbp; int pstride;
   int n, Ci, Co, T, To, st, V, splits, units, cpl, ccM, ccN;          // T input frames, To output frames, st stride
+  int narrow;                  // 1: a co tile with <= 64 live rows gives its dead row tiles' waves half of the taps (below)
 };
 
 // dW[co,ci,tap] = sum_{n,p} dz[n,co,p] * x'[n,ci,p + (tap-pad)*V] (zero outside the sample's frames), db[co] = sum dz.
@@ -590,12 +591,20 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int rt = wave & 3, ct = wave >> 2;
   const int Ci = a.Ci, Co = a.Co, V = a.V, L = a.To * V, Lx = a.T * V;   // dz / x plane lengths
   const float invV = 1.f / (float)V;
   const int id = blockIdx.x;
   const int cm = id % a.ccM, cn = (id / a.ccM) % a.ccN, sp = id / (a.ccM * a.ccN);
   const int co0 = cm * TW_TM, ci0 = cn * TW_TN;
+  // Wave -> (row tile rt, column tile ct) of the 128 x 64 tile, every tap.  A co tile with <= 64 live rows (the 64-channel
+  // layers) would leave the waves of row tiles 2 and 3 — SIMDs 2 and 3 — multiplying zeros while SIMDs 0 and 1 carry two
+  // live waves each: there the eight waves are (rt in {0,1}) x (ct) x (tap set ts), waves w and w + 4 (one SIMD) share a
+  // tile and split every tap group (ts 0: its first two taps, ts 1: the third), so every SIMD carries one tile's products.
+  // Every (co, ci, tap) still has ONE wave walking the same units and k-steps in the same order: bit-identical.
+  const bool narrow = a.narrow && Co - co0 <= 64;
+  const int rt = narrow ? (wave & 1) : (wave & 3), ct = narrow ? ((wave >> 1) & 1) : (wave >> 2);
+  const int ts = narrow ? (wave >> 2) : -1;        // -1: every tap
+  auto owns = [&](int tl) { return ts < 0 || (ts == 0) == (tl < 2); };
   const int u0 = (int)((long)a.units * sp / a.splits), u1 = (int)((long)a.units * (sp + 1) / a.splits);
   // A loader: row tid/4 (co), positions 8*(tid&3) ..+7;  B loader: row tid/8 (ci), positions 4*(tid&7) ..+3
   const int arow = tid >> 2, apc = tid & 3, brow = tid >> 3, bpc = tid & 7;
@@ -832,7 +841,7 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
 #pragma unroll
       for (int tl = 0; tl < TW_G; ++tl) {
         const int tap = grp * TW_G + tl;
-        if (tap < KT) {
+        if (tap < KT && owns(tl)) {
           bf16x8 bf[3];
 #pragma unroll
           for (int t = 0; t < 3; ++t)
@@ -920,10 +929,12 @@ __global__ __launch_bounds__(TW_NT, 2) void k_tcw(TcwArgs a) {
   const int ci = ci0 + 32 * ct + l31;
 #pragma unroll
   for (int t = 0; t < KT; ++t)
+    if (owns(t % TW_G)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + 32 * rt + tg_row32(r, half);
-      if (co < Co && ci < Ci) dw[((size_t)co * Ci + ci) * KT + t] = acc[t][r];
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 32 * rt + tg_row32(r, half);
+        if (co < Co && ci < Ci) dw[((size_t)co * Ci + ci) * KT + t] = acc[t][r];
+      }
     }
   int tide = tid;
   asm volatile("" : "+v"(tide));                 // (same: aco's sign-extended copy is not kept across the loop)
@@ -990,6 +1001,7 @@ bool tg_plan(int n, int K, int M, int Ts, int To, int V, int KT, int st, TgPlan*
 }
 
 int g_tg_quad = 1;                                 // lab knob (dsgcn_tconv_tuning): stride-1 staging with 16-byte loads on / off
+int g_tw_narrow = 1;                               // lab knob 1: k_tcw's wave mapping for co tiles of <= 64 rows on / off
 
 template <int EPI, int WM, bool QS>
 int tg_launch_qs(const TcgArgs& a, int mode, const TgPlan& p, hipStream_t st) {
@@ -1142,7 +1154,7 @@ int dsgcn_tconv_wgrad(const float* x1, const float* s1, const float* h1, const f
   a.x1 = x1; a.x2 = x2; a.s1 = s1; a.h1 = h1; a.s2 = s2; a.h2 = h2; a.relu = relu;
   a.gz = gz; a.z = z; a.A0 = A0; a.B0 = B0; a.dwp = dwp; a.dbp = dbp; a.pstride = pstride;
   a.n = n; a.Ci = Ci; a.Co = Co; a.T = T; a.To = To; a.st = stride; a.V = V; a.splits = p.splits; a.units = p.units; a.cpl = p.cpl;
-  a.ccM = p.ccM; a.ccN = p.ccN;
+  a.ccM = p.ccM; a.ccN = p.ccN; a.narrow = g_tw_narrow;
   const dim3 grid((unsigned)(p.splits * p.ccM * p.ccN)), blk(TW_NT);
   static bool raised = false;
   if (!raised) {
@@ -1172,6 +1184,7 @@ int dsgcn_tcw_phases(long long* out) {
 }
 int dsgcn_tconv_tuning(int key, int value) {
   if (key == 0) { g_tg_quad = value; return 0; }
+  if (key == 1) { g_tw_narrow = value; return 0; }
   return DSGCN_EINVAL;
 }
 #endif

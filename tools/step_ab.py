@@ -2,7 +2,7 @@
 (comma-joined key=value pairs of dsgcn_pwconv_tuning; '' = defaults) gets a fresh model + TrainEngine (two hipGraphs) and is
 timed over `steps` replays, the variants interleaved `rounds` times so that clock / box drift shows up as spread.
     python tools/step_ab.py '' 15=0 14=1 py:WSPLIT_BATCH=0 [--steps 20] [--rounds 2] [--kind ds|ctrgcn|stgcn|...]
-(py:NAME=V sets the module-level switch NAME of ds-gcn_amd/kernels.py for that variant)"""
+(py:NAME=V sets the module-level switch NAME of ds-gcn_amd/kernels.py for that variant; tc:K=V a knob of dsgcn_tconv_tuning)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -28,16 +28,22 @@ lab = native.lab_lib()
 native._lib = lab                                   # the package now launches through the lab build (same kernels + knobs)
 DEFAULTS = {14: 2, 15: 3, 16: 256, 17: 128}
 PY_DEFAULTS = {}
+TC_DEFAULTS = {0: 1, 1: 1}
+TC_SET = {}
 
 
 def set_keys(variant):
     keys = dict(DEFAULTS)
+    TC_SET.clear(); TC_SET.update(TC_DEFAULTS)
     from dsgcn_amd import kernels
     for name, val in PY_DEFAULTS.items():
         setattr(kernels, name, val)
     if variant:
         for kv in variant.split(','):
             k, v = kv.split('=')
+            if k.startswith('tc:'):                     # a knob of the 9-tap family (dsgcn_tconv_tuning), e.g. tc:1=0
+                TC_SET[int(k[3:])] = int(v)
+                continue
             if k.startswith('py:'):                     # a module-level switch of ds-gcn_amd/kernels.py, e.g. py:WSPLIT_BATCH=0
                 name = k[3:]
                 PY_DEFAULTS.setdefault(name, getattr(kernels, name))
@@ -45,6 +51,8 @@ def set_keys(variant):
                 setattr(kernels, name, type(old)(int(v)) if isinstance(old, (bool, int)) else v)
                 continue
             keys[int(k)] = int(v)
+    for k, v in TC_SET.items():
+        assert lab.dsgcn_tconv_tuning(k, v) == 0, (k, v)
     keys.setdefault(100, 1)
     for k, v in keys.items():
         if k == 100:                                    # 100 = fuse_out backward: 16-byte form on / off
